@@ -1,0 +1,163 @@
+"""bench.py -- point clouds / s, forward + backward (+ Adam step), B=32 N=1024 per GPU.
+
+Workload (BASELINE.json configs[1]): the IST-Net point encoder ``PointNet2MSG`` with the camera
+radii of model/ist_net.py:16 -- 4 MSG set-abstraction levels + 4 feature-propagation levels
+ -- train-mode BatchNorm, loss = mean(out^2), on a synthetic "shell"
+cloud batch (seeded).  One step = zero_grad + forward + backward (+ RCCL grad all-reduce when
+N > 1) + fused Adam step.  Inputs are resident in HBM before the timed region.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+CAM_RADII = [[0.01, 0.02], [0.02, 0.04], [0.04, 0.08], [0.08, 0.16]]  # ist_net.py:16
+BATCH, NPOINTS = 32, 1024
+
+
+def shell_cloud(b, n, seed, device="cpu"):
+    """Unit-normal directions x 0.1 m + N(0, 0.002) noise, centred."""
+    g = torch.Generator().manual_seed(seed)
+    d = torch.randn(b, n, 3, generator=g)
+    pts = d / d.norm(dim=2, keepdim=True) * 0.1 + torch.randn(b, n, 3, generator=g) * 0.002
+    pts = pts - pts.mean(dim=1, keepdim=True)
+    return pts.contiguous().to(device)
+
+
+def make_model(device, seed=0):
+    from istnet_amd.modules import PointNet2MSG
+    torch.manual_seed(seed)
+    return PointNet2MSG([list(r) for r in CAM_RADII]).to(device).train()
+
+
+def make_step(model, pts, opt, world, grad_sync=None):
+    def step():
+        opt.zero_grad(set_to_none=True)
+        out = model(pts)
+        loss = out.square().mean()
+        loss.backward()
+        if world > 1:
+            grad_sync()
+        opt.step()
+        return loss
+    return step
+
+
+def cpu_baseline(budget_s=25.0):
+    """The same step on the host cores with the CPU oracle ops (kind 'port'): bounded sample."""
+    from istnet_amd.pointnet2 import pointnet2_utils
+    from oracle import pn2_oracle
+    saved = pointnet2_utils._ext
+    threads = torch.get_num_threads()
+    try:
+        pointnet2_utils._ext = pn2_oracle
+        model = make_model("cpu")
+        pts = shell_cloud(BATCH, NPOINTS, seed=0)
+        opt = torch.optim.Adam(model.parameters(), lr=1e-4)
+        step = make_step(model, pts, opt, 1)
+        step()  # warm-up
+        t0 = time.perf_counter()
+        n = 0
+        while n < 2 or (time.perf_counter() - t0 < budget_s and n < 10):
+            step()
+            n += 1
+        dt = (time.perf_counter() - t0) / n
+    finally:
+        pointnet2_utils._ext = saved
+    return {"value": BATCH / dt, "unit": "clouds/s", "cores": threads, "kind": "port",
+            "sample": f"{n} steps of the same B={BATCH} N={NPOINTS} encoder fwd+bwd+Adam step "
+                      f"(torch CPU dense layers + oracle/pn2_oracle.c index ops, OpenMP), 1 warm-up",
+            "ms_per_step": dt * 1e3}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if args.gpus == 1 and world == 1:
+            pass
+        else:
+            raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    import torch.distributed as dist
+    grad_sync = None
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=dev)  # RCCL over xGMI
+
+    model = make_model(dev, seed=0)  # identical weights on every rank (same seed)
+    pts = shell_cloud(BATCH, NPOINTS, seed=rank, device=dev)
+    opt = torch.optim.Adam(model.parameters(), lr=1e-4, fused=True)
+    if world > 1:
+        from istnet_amd.parallel import GradAllReducer
+        grad_sync = GradAllReducer(model, world).sync
+    step = make_step(model, pts, opt, world, grad_sync)
+
+    for _ in range(args.warmup):
+        step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    result = None
+    if rank == 0:
+        ms = elapsed / args.steps * 1e3
+        result = {
+            "metric": "point-clouds/sec fwd+bwd, B=32 N=1024",
+            "value": BATCH * world * args.steps / elapsed,
+            "unit": "clouds/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "PointNet2MSG encoder (4 SA-MSG + 4 FP, cam radii) fwd+bwd+Adam, "
+                                   "train-mode BN, shell clouds",
+                       "batch_per_gpu": BATCH, "npoints": NPOINTS, "global_batch": BATCH * world,
+                       "parallelism": f"dp{world}"},
+        }
+        if world == 1 and not args.no_roofline:
+            from istnet_amd import roofline
+            result["roofline"] = roofline.measure(model, pts, dev)
+        if world == 1 and not args.no_cpu_baseline:
+            result["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,85 @@
+/*
+ * istnet_pn2.h -- C ABI of libistnet_pn2.so, the MI355X (gfx950) replacement for
+ * the nine launch wrappers behind the reference's pybind module `pointnet2._ext`
+ * (reference: model/pointnet2/_ext_src/src/bindings.cpp:11-24).
+ *
+ * Conventions (all entry points):
+ *   - plain device pointers + sizes; no torch types; the library owns no memory
+ *     and keeps no state; re-entrant; every launch is asynchronous on `stream`
+ *     (a hipStream_t passed as void*, NULL = the default stream), matching the
+ *     reference's "launch on the caller's current stream, no sync"
+ *     (e.g. ball_query_gpu.cu:54).
+ *   - tensors are contiguous; floats are IEEE f32; indices are int32
+ *     (reference include/utils.h:15-30).
+ *   - return value: 0 on success, otherwise a hipError_t (launch failure) or
+ *     ISTNET_PN2_EINVAL for an invalid argument.  Never exits the process
+ *     (the reference fprintf+exit(-1)s, cuda_utils.h:35-44).
+ *   - OUTPUT OWNERSHIP: unlike the reference host code, which allocates outputs
+ *     with torch::zeros, every kernel here writes EVERY element of its output,
+ *     so the caller may pass uninitialised memory.  The only exception is
+ *     `temp` of furthest_point_sampling, which is pure scratch (never read
+ *     before written) and may be NULL.
+ *   - arithmetic that decides an index (squared distances) is IEEE f32 in the
+ *     reference's source order without FMA contraction; see DESIGN.md.
+ */
+#ifndef ISTNET_PN2_H_
+#define ISTNET_PN2_H_
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ISTNET_PN2_ABI_VERSION 1
+#define ISTNET_PN2_API __attribute__((visibility("default")))
+#define ISTNET_PN2_EINVAL 100001
+
+/* ABI version of the loaded library (== ISTNET_PN2_ABI_VERSION). */
+ISTNET_PN2_API int istnet_pn2_abi_version(void);
+/* Name of the code object's target, "gfx950". */
+ISTNET_PN2_API const char *istnet_pn2_target(void);
+
+/* replaces furthest_point_sampling_kernel_wrapper (sampling.cpp:16-18, sampling_gpu.cu:180-234)
+ * dataset (b,n,3) f32 -> idxs (b,m) i32, idxs[:,0] = 0.  temp (b,n) f32 scratch or NULL.
+ * Tie-break identical to the reference block tree with block = opt_n_threads(n). */
+ISTNET_PN2_API int istnet_pn2_furthest_point_sampling(int b, int n, int m, const float *dataset,
+                                       float *temp, int *idxs, void *stream);
+
+/* replaces gather_points_kernel_wrapper (sampling.cpp:9-11): points (b,c,n), idx (b,npoints) -> out (b,c,npoints) */
+ISTNET_PN2_API int istnet_pn2_gather_points(int b, int c, int n, int npoints, const float *points,
+                             const int *idx, float *out, void *stream);
+
+/* replaces gather_points_grad_kernel_wrapper (sampling.cpp:12-14): grad_out (b,c,npoints) -> grad_points (b,c,n)
+ * (fully written: zero where no index lands). */
+ISTNET_PN2_API int istnet_pn2_gather_points_grad(int b, int c, int n, int npoints, const float *grad_out,
+                                  const int *idx, float *grad_points, void *stream);
+
+/* replaces query_ball_point_kernel_wrapper (ball_query.cpp:9-11): new_xyz (b,m,3), xyz (b,n,3) -> idx (b,m,nsample) */
+ISTNET_PN2_API int istnet_pn2_query_ball_point(int b, int n, int m, float radius, int nsample,
+                                const float *new_xyz, const float *xyz, int *idx, void *stream);
+
+/* replaces group_points_kernel_wrapper (group_points.cpp:9-11): points (b,c,n), idx (b,npoints,nsample) -> out (b,c,npoints,nsample) */
+ISTNET_PN2_API int istnet_pn2_group_points(int b, int c, int n, int npoints, int nsample, const float *points,
+                            const int *idx, float *out, void *stream);
+
+/* replaces group_points_grad_kernel_wrapper (group_points.cpp:13-15): grad_out (b,c,npoints,nsample) -> grad_points (b,c,n) */
+ISTNET_PN2_API int istnet_pn2_group_points_grad(int b, int c, int n, int npoints, int nsample,
+                                 const float *grad_out, const int *idx, float *grad_points,
+                                 void *stream);
+
+/* replaces three_nn_kernel_wrapper (interpolate.cpp:9-10): unknown (b,n,3), known (b,m,3) -> dist2 (b,n,3) f32, idx (b,n,3) i32 */
+ISTNET_PN2_API int istnet_pn2_three_nn(int b, int n, int m, const float *unknown, const float *known,
+                        float *dist2, int *idx, void *stream);
+
+/* replaces three_interpolate_kernel_wrapper (interpolate.cpp:11-13): points (b,c,m), idx/weight (b,n,3) -> out (b,c,n) */
+ISTNET_PN2_API int istnet_pn2_three_interpolate(int b, int c, int m, int n, const float *points, const int *idx,
+                                 const float *weight, float *out, void *stream);
+
+/* replaces three_interpolate_grad_kernel_wrapper (interpolate.cpp:14-17): grad_out (b,c,n) -> grad_points (b,c,m) */
+ISTNET_PN2_API int istnet_pn2_three_interpolate_grad(int b, int c, int n, int m, const float *grad_out,
+                                      const int *idx, const float *weight, float *grad_points,
+                                      void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ISTNET_PN2_H_ */

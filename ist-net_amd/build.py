@@ -1,0 +1,49 @@
+"""Builds libistnet_pn2.so (the C-ABI library declared in include/istnet_pn2.h) with hipcc for gfx950.
+
+In-tree build: the .so lands in ist-net_amd/lib/ so it travels with the source snapshot.
+``-ffp-contract=off`` is part of the numerical contract of the index ops.
+"""
+import os
+import shutil
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB_DIR = os.path.join(HERE, "lib")
+LIB_PATH = os.path.join(LIB_DIR, "libistnet_pn2.so")
+ARCH = "gfx950"
+
+
+def sources():
+    return sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hip"))
+
+
+def hipcc():
+    exe = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(exe):
+        raise RuntimeError("hipcc not found; libistnet_pn2.so cannot be built")
+    return exe
+
+
+def needs_build():
+    if not os.path.exists(LIB_PATH):
+        return True
+    newest = max(os.path.getmtime(p) for p in sources() + [
+        os.path.join(HERE, "..", "include", f) for f in os.listdir(os.path.join(HERE, "..", "include"))])
+    return os.path.getmtime(LIB_PATH) < newest
+
+
+def build(force=False, verbose=False):
+    if not force and not needs_build():
+        return LIB_PATH
+    os.makedirs(LIB_DIR, exist_ok=True)
+    cmd = [hipcc(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
+           "-fvisibility=hidden", "-Wall", "-Wno-unused-function", "-o", LIB_PATH] + sources()
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return LIB_PATH
+
+
+if __name__ == "__main__":
+    print(build(force=True, verbose=True))

@@ -1,0 +1,598 @@
+// pn2_index_ops.hip -- hand-written gfx950 (CDNA4, wave64) kernels for the nine
+// PointNet++ index / gather ops behind the reference's `pointnet2._ext`
+// (reference: model/pointnet2/_ext_src/src/{sampling,ball_query,group_points,interpolate}_gpu.cu).
+//
+// Design (MI355X-first, not a translation of the reference launch shapes):
+//   * the reference launches grid = B (one block per cloud, <=512 threads, long
+//     serial loops).  Here every op is decomposed so a launch has >>256
+//     workgroups (point tiles x channel chunks x clouds), except FPS which is
+//     inherently sequential per cloud and is built for minimum per-round latency:
+//     one wave per cloud (n <= 1024) keeps xyz + running min-distances in VGPRs,
+//     does the arg-max with DPP cross-lane ops, and never touches a barrier.
+//   * ball_query: one wave per centroid, xyz staged SoA in LDS, 64 points tested
+//     per step, __ballot + mbcnt prefix count emits the first `nsample` hits in
+//     index order (bit-identical to the serial scan) with early exit.
+//   * three_nn: thread per unknown point, known set broadcast from LDS.
+//   * group / interpolate: output-coalesced (float4 where possible), indices
+//     loaded once per thread and reused across a channel chunk.
+//   * group_grad / interpolate_grad / gather_grad: scatter-add into an LDS
+//     accumulator per (cloud, channel) row, written back once -- no global
+//     atomics, no pre-zeroed output needed.
+//
+// Arithmetic convention for index-deciding distances: IEEE f32, source order of
+// the reference expression, NO FMA contraction (file-wide pragma below + the
+// -ffp-contract=off build flag), shared with oracle/pn2_oracle.c.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/istnet_pn2.h"
+
+#pragma clang fp contract(off)
+
+namespace {
+
+constexpr int kWave = 64;
+
+__device__ __forceinline__ int lane_id() { return threadIdx.x & (kWave - 1); }
+
+// d2 in the reference's source order ((dx*dx + dy*dy) + dz*dz), un-contracted.
+__device__ __forceinline__ float sqdist(float ax, float ay, float az, float bx, float by, float bz) {
+  const float dx = ax - bx, dy = ay - by, dz = az - bz;
+  return (dx * dx + dy * dy) + dz * dz;
+}
+
+// ---- wave64 DPP reductions (result uniform, taken from lane 63) -------------
+template <int CTRL, int ROW_MASK = 0xf>
+__device__ __forceinline__ unsigned dpp_mov(unsigned identity, unsigned v) {
+  return (unsigned)__builtin_amdgcn_update_dpp((int)identity, (int)v, CTRL, ROW_MASK, 0xf, false);
+}
+__device__ __forceinline__ unsigned wave_max_u32(unsigned v) {
+  v = max(v, dpp_mov<0x111>(0u, v));        // row_shr:1
+  v = max(v, dpp_mov<0x112>(0u, v));        // row_shr:2
+  v = max(v, dpp_mov<0x114>(0u, v));        // row_shr:4
+  v = max(v, dpp_mov<0x118>(0u, v));        // row_shr:8  -> lane 15 of each row = row max
+  v = max(v, dpp_mov<0x142, 0xa>(0u, v));   // row_bcast:15 into rows 1,3
+  v = max(v, dpp_mov<0x143, 0xc>(0u, v));   // row_bcast:31 into rows 2,3
+  return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+}
+__device__ __forceinline__ unsigned wave_min_u32(unsigned v) {
+  v = min(v, dpp_mov<0x111>(0xffffffffu, v));
+  v = min(v, dpp_mov<0x112>(0xffffffffu, v));
+  v = min(v, dpp_mov<0x114>(0xffffffffu, v));
+  v = min(v, dpp_mov<0x118>(0xffffffffu, v));
+  v = min(v, dpp_mov<0x142, 0xa>(0xffffffffu, v));
+  v = min(v, dpp_mov<0x143, 0xc>(0xffffffffu, v));
+  return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+}
+
+// ============================================================================
+// Furthest point sampling
+// ============================================================================
+// Tie order of the reference (sampling_gpu.cu:64-70,113-173): each of
+// bs = opt_n_threads(n) threads keeps the LOWEST k of its maximum (strict '>'),
+// and the shared-memory tree keeps the lower slot on ties, level offsets
+// bs/2 ... 1.  The last level compares slot bit 0, the one before bit 1, ... so
+// among equal distances the winner is the point with the smallest
+//     tiekey(k) = bitrev_{log2 bs}(k mod bs) * nper + (k / bs),  nper = ceil(n / bs).
+// We hand point slots to lanes in tiekey order (slot i of thread t <-> tiekey
+// i*THREADS + t), so a strict '>' scan per lane plus a (value max, tiekey min)
+// cross-lane reduction reproduces the reference winner exactly.
+__device__ __forceinline__ int tiekey_to_k(unsigned tk, int bs_log2, int nper) {
+  const unsigned slot_rev = tk / (unsigned)nper;
+  const unsigned row = tk - slot_rev * (unsigned)nper;
+  const unsigned slot = bs_log2 ? (__brev(slot_rev) >> (32 - bs_log2)) : 0u;
+  return (int)(slot + (row << bs_log2));
+}
+
+template <int NW, int PPT>
+__global__ __launch_bounds__(NW * 64) void fps_regs_kernel(int n, int m, int bs_log2, int nper,
+                                                           const float* __restrict__ dataset_all,
+                                                           int* __restrict__ idxs_all) {
+  constexpr int THREADS = NW * 64;
+  extern __shared__ __attribute__((aligned(16))) float fps_lds[];  // xyz AoS copy [3n] (+ exchange)
+  const int cloud = blockIdx.x;
+  const float* dataset = dataset_all + (size_t)cloud * n * 3;
+  int* idxs = idxs_all + (size_t)cloud * m;
+  const int tid = threadIdx.x;
+
+  for (int e = tid; e < 3 * n; e += THREADS) fps_lds[e] = dataset[e];
+  unsigned* xchg = reinterpret_cast<unsigned*>(fps_lds + 3 * n);  // [2][NW][2]
+  __syncthreads();
+
+  float px[PPT], py[PPT], pz[PPT], tmp[PPT];
+#pragma unroll
+  for (int i = 0; i < PPT; ++i) {
+    const unsigned tk = (unsigned)(i * THREADS + tid);
+    const int k = tiekey_to_k(tk, bs_log2, nper);
+    const bool valid = tk < ((unsigned)nper << bs_log2) && k < n;
+    px[i] = valid ? fps_lds[3 * k + 0] : 0.f;
+    py[i] = valid ? fps_lds[3 * k + 1] : 0.f;
+    pz[i] = valid ? fps_lds[3 * k + 2] : 0.f;
+    tmp[i] = valid ? 1e10f : -1.0f;  // invalid slot: min(d,-1) = -1 never beats best = -1
+  }
+
+  int old = 0;
+  if (tid == 0) idxs[0] = 0;
+  for (int j = 1; j < m; ++j) {
+    const float x1 = fps_lds[3 * old + 0];
+    const float y1 = fps_lds[3 * old + 1];
+    const float z1 = fps_lds[3 * old + 2];
+    float best = -1.0f;
+    int besti = 0;
+#pragma unroll
+    for (int i = 0; i < PPT; ++i) {
+      const float d = sqdist(px[i], py[i], pz[i], x1, y1, z1);
+      const float d2 = fminf(d, tmp[i]);
+      tmp[i] = d2;
+      const bool gt = d2 > best;
+      besti = gt ? i : besti;
+      best = gt ? d2 : best;
+    }
+    // value key: 0 for "no valid slot", otherwise float bits + 1 (d2 >= +0 => monotone)
+    const unsigned vkey = best < 0.0f ? 0u : (__float_as_uint(best) + 1u);
+    unsigned vmax = wave_max_u32(vkey);
+    const unsigned tk = (vkey == vmax) ? (unsigned)(besti * THREADS + tid) : 0xffffffffu;
+    unsigned tkmin = wave_min_u32(tk);
+    if (NW > 1) {
+      unsigned* slot = xchg + (j & 1) * (NW * 2);
+      if (lane_id() == 0) {
+        slot[(tid >> 6) * 2 + 0] = vmax;
+        slot[(tid >> 6) * 2 + 1] = tkmin;
+      }
+      __syncthreads();
+      unsigned bv = 0u, bt = 0xffffffffu;
+#pragma unroll
+      for (int w = 0; w < NW; ++w) {
+        const unsigned v = slot[w * 2 + 0], t = slot[w * 2 + 1];
+        const bool better = (v > bv) || (v == bv && t < bt);
+        bv = better ? v : bv;
+        bt = better ? t : bt;
+      }
+      tkmin = bt;
+    }
+    old = tiekey_to_k(tkmin, bs_log2, nper);
+    if (tid == 0) idxs[j] = old;
+  }
+}
+
+// Generic fallback for very large clouds (n > 4096): running distances live in
+// `temp` (global), xyz read from global/L2.  Same winner rule.
+__global__ __launch_bounds__(1024) void fps_generic_kernel(int n, int m, int bs_log2, int nper,
+                                                           const float* __restrict__ dataset_all,
+                                                           float* __restrict__ temp_all,
+                                                           int* __restrict__ idxs_all) {
+  constexpr int THREADS = 1024, NW = 16;
+  __shared__ unsigned xchg[2][NW][2];
+  const int cloud = blockIdx.x;
+  const float* dataset = dataset_all + (size_t)cloud * n * 3;
+  float* temp = temp_all + (size_t)cloud * n;
+  int* idxs = idxs_all + (size_t)cloud * m;
+  const int tid = threadIdx.x;
+  const unsigned ntk = (unsigned)nper << bs_log2;  // number of tiekeys incl. holes
+  for (int k = tid; k < n; k += THREADS) temp[k] = 1e10f;
+  int old = 0;
+  if (tid == 0) idxs[0] = 0;
+  __syncthreads();
+  for (int j = 1; j < m; ++j) {
+    const float x1 = dataset[3 * old + 0], y1 = dataset[3 * old + 1], z1 = dataset[3 * old + 2];
+    float best = -1.0f;
+    unsigned besttk = 0;
+    for (unsigned tk = tid; tk < ntk; tk += THREADS) {  // ascending tiekey per thread
+      const int k = tiekey_to_k(tk, bs_log2, nper);
+      if (k < n) {
+        const float d = sqdist(dataset[3 * k + 0], dataset[3 * k + 1], dataset[3 * k + 2], x1, y1, z1);
+        const float d2 = fminf(d, temp[k]);
+        temp[k] = d2;
+        if (d2 > best) { best = d2; besttk = tk; }
+      }
+    }
+    const unsigned vkey = best < 0.0f ? 0u : (__float_as_uint(best) + 1u);
+    const unsigned vmax = wave_max_u32(vkey);
+    const unsigned tkmin = wave_min_u32((vkey == vmax) ? besttk : 0xffffffffu);
+    if (lane_id() == 0) { xchg[j & 1][tid >> 6][0] = vmax; xchg[j & 1][tid >> 6][1] = tkmin; }
+    __syncthreads();
+    unsigned bv = 0u, bt = 0xffffffffu;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) {
+      const unsigned v = xchg[j & 1][w][0], t = xchg[j & 1][w][1];
+      const bool better = (v > bv) || (v == bv && t < bt);
+      bv = better ? v : bv;
+      bt = better ? t : bt;
+    }
+    old = tiekey_to_k(bt, bs_log2, nper);
+    if (tid == 0) idxs[j] = old;
+  }
+}
+
+// ============================================================================
+// gather_points (+grad)   (sampling_gpu.cu:13-52)
+// ============================================================================
+__global__ void gather_points_kernel(int c, int n, int m, const float* __restrict__ points,
+                                     const int* __restrict__ idx, float* __restrict__ out) {
+  const int b = blockIdx.z, l = blockIdx.y;
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= m) return;
+  const int a = idx[(size_t)b * m + j];
+  out[((size_t)b * c + l) * m + j] = points[((size_t)b * c + l) * n + a];
+}
+
+// ============================================================================
+// ball query   (ball_query_gpu.cu:14-49)
+// ============================================================================
+constexpr int kBqWaves = 4;            // waves per workgroup
+constexpr int kBqCentroidsPerWave = 4;  // centroids handled sequentially by one wave
+
+template <bool LDS_XYZ>
+__global__ __launch_bounds__(kBqWaves * 64) void ball_query_kernel(
+    int n, int m, float radius2, int nsample, const float* __restrict__ new_xyz_all,
+    const float* __restrict__ xyz_all, int* __restrict__ idx_all) {
+  extern __shared__ __attribute__((aligned(16))) float bq_lds[];  // SoA: x[n] y[n] z[n]
+  const int cloud = blockIdx.y;
+  const float* xyz = xyz_all + (size_t)cloud * n * 3;
+  const float* new_xyz = new_xyz_all + (size_t)cloud * m * 3;
+  int* idx = idx_all + (size_t)cloud * m * nsample;
+  const int lane = lane_id(), wave = threadIdx.x >> 6;
+
+  if (LDS_XYZ) {
+    for (int e = threadIdx.x; e < 3 * n; e += kBqWaves * 64) {
+      const int k = e / 3, comp = e - 3 * k;
+      bq_lds[comp * n + k] = xyz[e];
+    }
+    __syncthreads();
+  }
+  const int j0 = (blockIdx.x * kBqWaves + wave) * kBqCentroidsPerWave;
+  for (int jj = 0; jj < kBqCentroidsPerWave; ++jj) {
+    const int j = j0 + jj;
+    if (j >= m) break;  // wave-uniform
+    const float cx = new_xyz[3 * j + 0], cy = new_xyz[3 * j + 1], cz = new_xyz[3 * j + 2];
+    int* row = idx + (size_t)j * nsample;
+    int cnt = 0, first = 0;
+    for (int base = 0; base < n && cnt < nsample; base += 64) {
+      const int k = base + lane;
+      bool hit = false;
+      if (k < n) {
+        float x, y, z;
+        if (LDS_XYZ) { x = bq_lds[k]; y = bq_lds[n + k]; z = bq_lds[2 * n + k]; }
+        else { x = xyz[3 * k + 0]; y = xyz[3 * k + 1]; z = xyz[3 * k + 2]; }
+        hit = sqdist(cx, cy, cz, x, y, z) < radius2;
+      }
+      const unsigned long long mask = __ballot(hit);
+      if (mask) {
+        if (cnt == 0) first = base + __ffsll((long long)mask) - 1;
+        const int before = __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32),
+                                                     __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+        const int pos = cnt + before;
+        if (hit && pos < nsample) row[pos] = k;
+        cnt += __popcll(mask);
+      }
+    }
+    cnt = cnt < nsample ? cnt : nsample;
+    for (int pos = cnt + lane; pos < nsample; pos += 64) row[pos] = first;  // pad / zeros
+  }
+}
+
+// ============================================================================
+// group_points   (group_points_gpu.cu:13-33)
+// ============================================================================
+constexpr int kGroupChunk = 8;  // channels per thread (index reuse)
+
+__global__ __launch_bounds__(256) void group_points_vec4_kernel(int c, int n, int P4,
+                                                                const float* __restrict__ points,
+                                                                const int* __restrict__ idx,
+                                                                float* __restrict__ out) {
+  const int b = blockIdx.z;
+  const int p4 = blockIdx.x * 256 + threadIdx.x;
+  if (p4 >= P4) return;
+  const int4 ii = reinterpret_cast<const int4*>(idx + (size_t)b * P4 * 4)[p4];
+  const int c0 = blockIdx.y * kGroupChunk;
+  const int c1 = min(c0 + kGroupChunk, c);
+  for (int l = c0; l < c1; ++l) {
+    const float* row = points + ((size_t)b * c + l) * n;
+    float4 v;
+    v.x = row[ii.x]; v.y = row[ii.y]; v.z = row[ii.z]; v.w = row[ii.w];
+    reinterpret_cast<float4*>(out + ((size_t)b * c + l) * P4 * 4)[p4] = v;
+  }
+}
+__global__ __launch_bounds__(256) void group_points_scalar_kernel(int c, int n, int P,
+                                                                  const float* __restrict__ points,
+                                                                  const int* __restrict__ idx,
+                                                                  float* __restrict__ out) {
+  const int b = blockIdx.z;
+  const int p = blockIdx.x * 256 + threadIdx.x;
+  if (p >= P) return;
+  const int ii = idx[(size_t)b * P + p];
+  const int c0 = blockIdx.y * kGroupChunk;
+  const int c1 = min(c0 + kGroupChunk, c);
+  for (int l = c0; l < c1; ++l)
+    out[((size_t)b * c + l) * P + p] = points[((size_t)b * c + l) * n + ii];
+}
+
+// ============================================================================
+// scatter-add family: rows of `dst_len` accumulated in LDS, one (cloud, channel)
+// row per loop step, written back once.  Used by group_points_grad
+// (group_points_gpu.cu:48-69), three_interpolate_grad (interpolate_gpu.cu:121-148)
+// and gather_points_grad (sampling_gpu.cu:39-52).
+// ============================================================================
+constexpr int kScatterThreads = 256;
+
+// mode 0: src (rows, P) , idx (P)          : dst[idx[p]] += src[p]
+// mode 1: src (rows, n) , idx/w (n,3)      : dst[idx[j,t]] += src[j] * w[j,t]
+template <int MODE>
+__global__ __launch_bounds__(kScatterThreads) void scatter_add_rows_kernel(
+    int c, int dst_len, int src_len, const float* __restrict__ src_all,
+    const int* __restrict__ idx_all, const float* __restrict__ w_all, float* __restrict__ dst_all) {
+  extern __shared__ __attribute__((aligned(16))) float acc[];  // [dst_len]
+  const int b = blockIdx.y, l = blockIdx.x;
+  const float* src = src_all + ((size_t)b * c + l) * src_len;
+  float* dst = dst_all + ((size_t)b * c + l) * dst_len;
+  const int idx_per = MODE == 0 ? 1 : 3;
+  const int* idx = idx_all + (size_t)b * src_len * idx_per;
+  const float* w = MODE == 0 ? nullptr : w_all + (size_t)b * src_len * 3;
+  for (int i = threadIdx.x; i < dst_len; i += kScatterThreads) acc[i] = 0.f;
+  __syncthreads();
+  if (MODE == 0) {
+    for (int p = threadIdx.x; p < src_len; p += kScatterThreads) atomicAdd(&acc[idx[p]], src[p]);
+  } else {
+    for (int j = threadIdx.x; j < src_len; j += kScatterThreads) {
+      const float g = src[j];
+      atomicAdd(&acc[idx[3 * j + 0]], g * w[3 * j + 0]);
+      atomicAdd(&acc[idx[3 * j + 1]], g * w[3 * j + 1]);
+      atomicAdd(&acc[idx[3 * j + 2]], g * w[3 * j + 2]);
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < dst_len; i += kScatterThreads) dst[i] = acc[i];
+}
+
+// Fallback when a destination row does not fit in LDS: zero + global atomics.
+__global__ void fill_zero_kernel(size_t count, float* __restrict__ p) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < count) p[i] = 0.f;
+}
+template <int MODE>
+__global__ __launch_bounds__(256) void scatter_add_global_kernel(
+    int c, int dst_len, int src_len, const float* __restrict__ src_all,
+    const int* __restrict__ idx_all, const float* __restrict__ w_all, float* __restrict__ dst_all) {
+  const int b = blockIdx.z, l = blockIdx.y;
+  const int p = blockIdx.x * 256 + threadIdx.x;
+  if (p >= src_len) return;
+  const float g = src_all[((size_t)b * c + l) * src_len + p];
+  float* dst = dst_all + ((size_t)b * c + l) * dst_len;
+  if (MODE == 0) {
+    atomicAdd(&dst[idx_all[(size_t)b * src_len + p]], g);
+  } else {
+    const int* idx = idx_all + ((size_t)b * src_len + p) * 3;
+    const float* w = w_all + ((size_t)b * src_len + p) * 3;
+    atomicAdd(&dst[idx[0]], g * w[0]);
+    atomicAdd(&dst[idx[1]], g * w[1]);
+    atomicAdd(&dst[idx[2]], g * w[2]);
+  }
+}
+
+// ============================================================================
+// three_nn   (interpolate_gpu.cu:14-64)
+// ============================================================================
+constexpr int kNnTile = 2048;  // known points staged per LDS tile (24 KB)
+
+__global__ __launch_bounds__(256) void three_nn_kernel(int n, int m,
+                                                       const float* __restrict__ unknown_all,
+                                                       const float* __restrict__ known_all,
+                                                       float* __restrict__ dist2_all,
+                                                       int* __restrict__ idx_all) {
+  __shared__ __attribute__((aligned(16))) float kn[kNnTile * 3];
+  const int cloud = blockIdx.y;
+  const float* unknown = unknown_all + (size_t)cloud * n * 3;
+  const float* known = known_all + (size_t)cloud * m * 3;
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  const bool active = j < n;
+  float ux = 0.f, uy = 0.f, uz = 0.f;
+  if (active) { ux = unknown[3 * j + 0]; uy = unknown[3 * j + 1]; uz = unknown[3 * j + 2]; }
+  // The reference keeps doubles initialised to 1e40 and stores them back as f32
+  // (=> +inf when unfilled); f32 +inf gives the same comparisons and result.
+  float best1 = __builtin_inff(), best2 = __builtin_inff(), best3 = __builtin_inff();
+  int besti1 = 0, besti2 = 0, besti3 = 0;
+  for (int base = 0; base < m; base += kNnTile) {
+    const int cntk = min(kNnTile, m - base);
+    __syncthreads();
+    for (int e = threadIdx.x; e < 3 * cntk; e += 256) kn[e] = known[(size_t)3 * base + e];
+    __syncthreads();
+    if (active) {
+      for (int kk = 0; kk < cntk; ++kk) {
+        const float d = sqdist(ux, uy, uz, kn[3 * kk + 0], kn[3 * kk + 1], kn[3 * kk + 2]);
+        const int k = base + kk;
+        if (d < best1) {
+          best3 = best2; besti3 = besti2;
+          best2 = best1; besti2 = besti1;
+          best1 = d; besti1 = k;
+        } else if (d < best2) {
+          best3 = best2; besti3 = besti2;
+          best2 = d; besti2 = k;
+        } else if (d < best3) {
+          best3 = d; besti3 = k;
+        }
+      }
+    }
+  }
+  if (active) {
+    float* d2 = dist2_all + ((size_t)cloud * n + j) * 3;
+    int* ix = idx_all + ((size_t)cloud * n + j) * 3;
+    d2[0] = best1; d2[1] = best2; d2[2] = best3;
+    ix[0] = besti1; ix[1] = besti2; ix[2] = besti3;
+  }
+}
+
+// ============================================================================
+// three_interpolate   (interpolate_gpu.cu:77-106)
+// ============================================================================
+constexpr int kInterpChunk = 8;
+
+__global__ __launch_bounds__(256) void three_interpolate_kernel(int c, int m, int n,
+                                                                const float* __restrict__ points,
+                                                                const int* __restrict__ idx,
+                                                                const float* __restrict__ weight,
+                                                                float* __restrict__ out) {
+  const int b = blockIdx.z;
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= n) return;
+  const int* ix = idx + ((size_t)b * n + j) * 3;
+  const float* w = weight + ((size_t)b * n + j) * 3;
+  const int i1 = ix[0], i2 = ix[1], i3 = ix[2];
+  const float w1 = w[0], w2 = w[1], w3 = w[2];
+  const int c0 = blockIdx.y * kInterpChunk;
+  const int c1 = min(c0 + kInterpChunk, c);
+  for (int l = c0; l < c1; ++l) {
+    const float* row = points + ((size_t)b * c + l) * m;
+    out[((size_t)b * c + l) * n + j] = (row[i1] * w1 + row[i2] * w2) + row[i3] * w3;
+  }
+}
+
+inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
+inline int ilog2_floor(int v) { int r = 0; while ((1 << (r + 1)) <= v) ++r; return r; }
+inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+constexpr int kMaxLdsRowBytes = 64 * 1024;
+
+template <int MODE>
+int launch_scatter_add(int b, int c, int dst_len, int src_len, const float* src, const int* idx,
+                       const float* w, float* dst, hipStream_t st) {
+  if ((size_t)dst_len * 4 <= (size_t)kMaxLdsRowBytes) {
+    hipLaunchKernelGGL(scatter_add_rows_kernel<MODE>, dim3(c, b), dim3(kScatterThreads),
+                       (size_t)dst_len * 4, st, c, dst_len, src_len, src, idx, w, dst);
+  } else {
+    const size_t count = (size_t)b * c * dst_len;
+    hipLaunchKernelGGL(fill_zero_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, st,
+                       count, dst);
+    hipLaunchKernelGGL(scatter_add_global_kernel<MODE>, dim3(ceil_div(src_len, 256), c, b),
+                       dim3(256), 0, st, c, dst_len, src_len, src, idx, w, dst);
+  }
+  return (int)hipGetLastError();
+}
+
+template <int NW>
+int launch_fps_regs(int b, int n, int m, int bs_log2, int nper, const float* dataset, int* idxs,
+                    hipStream_t st) {
+  const int ppt = ceil_div(nper << bs_log2, NW * 64);  // tiekey slots per thread (holes included)
+  const size_t lds = (size_t)3 * n * 4 + (NW > 1 ? 2 * NW * 2 * 4 : 0);
+#define ISTNET_FPS_CASE(P)                                                                      \
+  hipLaunchKernelGGL((fps_regs_kernel<NW, P>), dim3(b), dim3(NW * 64), lds, st, n, m, bs_log2,  \
+                     nper, dataset, idxs)
+  if (ppt <= 1) ISTNET_FPS_CASE(1);
+  else if (ppt <= 2) ISTNET_FPS_CASE(2);
+  else if (ppt <= 4) ISTNET_FPS_CASE(4);
+  else if (ppt <= 8) ISTNET_FPS_CASE(8);
+  else ISTNET_FPS_CASE(16);
+#undef ISTNET_FPS_CASE
+  return (int)hipGetLastError();
+}
+
+}  // namespace
+
+extern "C" {
+
+int istnet_pn2_abi_version(void) { return ISTNET_PN2_ABI_VERSION; }
+const char* istnet_pn2_target(void) { return "gfx950"; }
+
+int istnet_pn2_furthest_point_sampling(int b, int n, int m, const float* dataset, float* temp,
+                                       int* idxs, void* stream) {
+  if (b < 0 || n <= 0 || m < 0) return ISTNET_PN2_EINVAL;
+  if (b == 0 || m == 0) return 0;
+  // reference block size: opt_n_threads(n) = clamp(2^floor(log2 n), 1, 512)  (cuda_utils.h:18-22)
+  int bs_log2 = ilog2_floor(n);
+  if (bs_log2 > 9) bs_log2 = 9;
+  const int nper = ceil_div(n, 1 << bs_log2);
+  const int slots = nper << bs_log2;
+  hipStream_t st = as_stream(stream);
+  if (slots <= 64 * 16) return launch_fps_regs<1>(b, n, m, bs_log2, nper, dataset, idxs, st);
+  if (slots <= 256 * 16) return launch_fps_regs<4>(b, n, m, bs_log2, nper, dataset, idxs, st);
+  if (temp == nullptr) return ISTNET_PN2_EINVAL;  // large clouds need the scratch buffer
+  hipLaunchKernelGGL(fps_generic_kernel, dim3(b), dim3(1024), 0, st, n, m, bs_log2, nper, dataset,
+                     temp, idxs);
+  return (int)hipGetLastError();
+}
+
+int istnet_pn2_gather_points(int b, int c, int n, int npoints, const float* points, const int* idx,
+                             float* out, void* stream) {
+  if (b < 0 || c < 0 || n <= 0 || npoints < 0) return ISTNET_PN2_EINVAL;
+  if (b == 0 || c == 0 || npoints == 0) return 0;
+  hipLaunchKernelGGL(gather_points_kernel, dim3(ceil_div(npoints, 256), c, b), dim3(256), 0,
+                     as_stream(stream), c, n, npoints, points, idx, out);
+  return (int)hipGetLastError();
+}
+
+int istnet_pn2_gather_points_grad(int b, int c, int n, int npoints, const float* grad_out,
+                                  const int* idx, float* grad_points, void* stream) {
+  if (b < 0 || c < 0 || n <= 0 || npoints < 0) return ISTNET_PN2_EINVAL;
+  if (b == 0 || c == 0) return 0;
+  return launch_scatter_add<0>(b, c, n, npoints, grad_out, idx, nullptr, grad_points,
+                               as_stream(stream));
+}
+
+int istnet_pn2_query_ball_point(int b, int n, int m, float radius, int nsample,
+                                const float* new_xyz, const float* xyz, int* idx, void* stream) {
+  if (b < 0 || n <= 0 || m < 0 || nsample < 0) return ISTNET_PN2_EINVAL;
+  if (b == 0 || m == 0 || nsample == 0) return 0;
+  const float radius2 = radius * radius;  // ball_query_gpu.cu:27, f32 product
+  const dim3 grid(ceil_div(m, kBqWaves * kBqCentroidsPerWave), b);
+  const size_t lds = (size_t)3 * n * 4;
+  if (lds <= 64 * 1024) {
+    hipLaunchKernelGGL(ball_query_kernel<true>, grid, dim3(kBqWaves * 64), lds, as_stream(stream),
+                       n, m, radius2, nsample, new_xyz, xyz, idx);
+  } else {
+    hipLaunchKernelGGL(ball_query_kernel<false>, grid, dim3(kBqWaves * 64), 0, as_stream(stream),
+                       n, m, radius2, nsample, new_xyz, xyz, idx);
+  }
+  return (int)hipGetLastError();
+}
+
+int istnet_pn2_group_points(int b, int c, int n, int npoints, int nsample, const float* points,
+                            const int* idx, float* out, void* stream) {
+  if (b < 0 || c < 0 || n <= 0 || npoints < 0 || nsample < 0) return ISTNET_PN2_EINVAL;
+  const long long P = (long long)npoints * nsample;
+  if (b == 0 || c == 0 || P == 0) return 0;
+  if (P % 4 == 0) {
+    const int P4 = (int)(P / 4);
+    hipLaunchKernelGGL(group_points_vec4_kernel, dim3(ceil_div(P4, 256), ceil_div(c, kGroupChunk), b),
+                       dim3(256), 0, as_stream(stream), c, n, P4, points, idx, out);
+  } else {
+    hipLaunchKernelGGL(group_points_scalar_kernel,
+                       dim3(ceil_div((int)P, 256), ceil_div(c, kGroupChunk), b), dim3(256), 0,
+                       as_stream(stream), c, n, (int)P, points, idx, out);
+  }
+  return (int)hipGetLastError();
+}
+
+int istnet_pn2_group_points_grad(int b, int c, int n, int npoints, int nsample,
+                                 const float* grad_out, const int* idx, float* grad_points,
+                                 void* stream) {
+  if (b < 0 || c < 0 || n <= 0 || npoints < 0 || nsample < 0) return ISTNET_PN2_EINVAL;
+  if (b == 0 || c == 0) return 0;
+  return launch_scatter_add<0>(b, c, n, npoints * nsample, grad_out, idx, nullptr, grad_points,
+                               as_stream(stream));
+}
+
+int istnet_pn2_three_nn(int b, int n, int m, const float* unknown, const float* known, float* dist2,
+                        int* idx, void* stream) {
+  if (b < 0 || n < 0 || m < 0) return ISTNET_PN2_EINVAL;
+  if (b == 0 || n == 0) return 0;
+  hipLaunchKernelGGL(three_nn_kernel, dim3(ceil_div(n, 256), b), dim3(256), 0, as_stream(stream), n,
+                     m, unknown, known, dist2, idx);
+  return (int)hipGetLastError();
+}
+
+int istnet_pn2_three_interpolate(int b, int c, int m, int n, const float* points, const int* idx,
+                                 const float* weight, float* out, void* stream) {
+  if (b < 0 || c < 0 || m <= 0 || n < 0) return ISTNET_PN2_EINVAL;
+  if (b == 0 || c == 0 || n == 0) return 0;
+  hipLaunchKernelGGL(three_interpolate_kernel, dim3(ceil_div(n, 256), ceil_div(c, kInterpChunk), b),
+                     dim3(256), 0, as_stream(stream), c, m, n, points, idx, weight, out);
+  return (int)hipGetLastError();
+}
+
+int istnet_pn2_three_interpolate_grad(int b, int c, int n, int m, const float* grad_out,
+                                      const int* idx, const float* weight, float* grad_points,
+                                      void* stream) {
+  if (b < 0 || c < 0 || m <= 0 || n < 0) return ISTNET_PN2_EINVAL;
+  if (b == 0 || c == 0) return 0;
+  return launch_scatter_add<1>(b, c, m, n, grad_out, idx, weight, grad_points, as_stream(stream));
+}
+
+}  // extern "C"

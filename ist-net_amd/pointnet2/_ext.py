@@ -1,0 +1,178 @@
+"""Drop-in for the reference's pybind module ``pointnet2._ext``.
+
+Same nine free functions, argument order and error behaviour as
+model/pointnet2/_ext_src/src/bindings.cpp:11-24 and the four host files
+(ball_query.cpp, group_points.cpp, interpolate.cpp, sampling.cpp); the work runs in the
+hand-written gfx950 kernels of ``csrc/pn2_index_ops.hip`` through the C ABI of
+``include/istnet_pn2.h``.  Outputs are allocated here with ``torch.empty`` (the kernels write
+every element; the reference allocates with ``torch::zeros``), launches go to the caller's
+current stream on the tensors' device, nothing synchronises.
+
+CPU tensors raise ``RuntimeError("CPU not supported")`` exactly like the reference
+(e.g. ball_query.cpp:32-34); there is no fallback of any kind.
+"""
+import torch
+
+from .. import _native
+
+
+def _req(cond, msg):
+    if not cond:
+        raise RuntimeError(msg)
+
+
+def _contig(t, name):
+    _req(t.is_contiguous(), f"{name} must be a contiguous tensor")      # utils.h:15-18
+
+
+def _is_float(t, name):
+    _req(t.dtype == torch.float32, f"{name} must be a float tensor")    # utils.h:26-30
+
+
+def _is_int(t, name):
+    _req(t.dtype == torch.int32, f"{name} must be an int tensor")       # utils.h:20-24
+
+
+def _device_of(lead, lead_name, *others):
+    """Reference rule: if the leading tensor is CUDA the others must be too; CPU is unsupported."""
+    if not lead.is_cuda:
+        raise RuntimeError("CPU not supported")
+    for t, name in others:
+        _req(t.is_cuda, f"{name} must be a CUDA tensor")                # utils.h:10-13
+        _req(t.device == lead.device, f"{name} must be on the same device as {lead_name}")
+    return lead.device
+
+
+def _stream(device):
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+def _ptr(t):
+    return t.data_ptr()
+
+
+def gather_points(points, idx):
+    """(B,C,N) f32, (B,npoint) i32 -> (B,C,npoint).  sampling.cpp:20-43"""
+    _contig(points, "points"); _contig(idx, "idx"); _is_float(points, "points"); _is_int(idx, "idx")
+    dev = _device_of(points, "points", (idx, "idx"))
+    b, c, n = points.shape
+    m = idx.shape[1]
+    out = torch.empty((b, c, m), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        _native.check(_native.lib().istnet_pn2_gather_points(
+            b, c, n, m, _ptr(points), _ptr(idx), _ptr(out), _stream(dev)), "gather_points")
+    return out
+
+
+def gather_points_grad(grad_out, idx, n):
+    """(B,C,npoint) f32, (B,npoint) i32, n -> (B,C,n).  sampling.cpp:45-68"""
+    _contig(grad_out, "grad_out"); _contig(idx, "idx"); _is_float(grad_out, "grad_out"); _is_int(idx, "idx")
+    dev = _device_of(grad_out, "grad_out", (idx, "idx"))
+    b, c, m = grad_out.shape
+    out = torch.empty((b, c, int(n)), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        _native.check(_native.lib().istnet_pn2_gather_points_grad(
+            b, c, int(n), m, _ptr(grad_out), _ptr(idx), _ptr(out), _stream(dev)), "gather_points_grad")
+    return out
+
+
+def furthest_point_sampling(points, nsamples):
+    """(B,N,3) f32 -> (B,nsamples) i32, first index 0.  sampling.cpp:70-91"""
+    _contig(points, "points"); _is_float(points, "points")
+    dev = _device_of(points, "points")
+    b, n = points.shape[0], points.shape[1]
+    nsamples = int(nsamples)
+    out = torch.empty((b, nsamples), dtype=torch.int32, device=dev)
+    # scratch is only needed by the large-cloud kernel (n > 4096); see include/istnet_pn2.h
+    tmp = torch.empty((b, n), dtype=torch.float32, device=dev) if n > 4096 else None
+    with torch.cuda.device(dev):
+        _native.check(_native.lib().istnet_pn2_furthest_point_sampling(
+            b, n, nsamples, _ptr(points), _ptr(tmp) if tmp is not None else None, _ptr(out),
+            _stream(dev)), "furthest_point_sampling")
+    return out
+
+
+def three_nn(unknowns, knows):
+    """(B,n,3), (B,m,3) f32 -> [dist2 (B,n,3) f32, idx (B,n,3) i32].  interpolate.cpp:19-45"""
+    _contig(unknowns, "unknowns"); _contig(knows, "knows")
+    _is_float(unknowns, "unknowns"); _is_float(knows, "knows")
+    dev = _device_of(unknowns, "unknowns", (knows, "knows"))
+    b, n = unknowns.shape[0], unknowns.shape[1]
+    m = knows.shape[1]
+    idx = torch.empty((b, n, 3), dtype=torch.int32, device=dev)
+    dist2 = torch.empty((b, n, 3), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        _native.check(_native.lib().istnet_pn2_three_nn(
+            b, n, m, _ptr(unknowns), _ptr(knows), _ptr(dist2), _ptr(idx), _stream(dev)), "three_nn")
+    return [dist2, idx]
+
+
+def three_interpolate(points, idx, weight):
+    """(B,C,m) f32, (B,n,3) i32, (B,n,3) f32 -> (B,C,n).  interpolate.cpp:47-74"""
+    _contig(points, "points"); _contig(idx, "idx"); _contig(weight, "weight")
+    _is_float(points, "points"); _is_int(idx, "idx"); _is_float(weight, "weight")
+    dev = _device_of(points, "points", (idx, "idx"), (weight, "weight"))
+    b, c, m = points.shape
+    n = idx.shape[1]
+    out = torch.empty((b, c, n), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        _native.check(_native.lib().istnet_pn2_three_interpolate(
+            b, c, m, n, _ptr(points), _ptr(idx), _ptr(weight), _ptr(out), _stream(dev)),
+            "three_interpolate")
+    return out
+
+
+def three_interpolate_grad(grad_out, idx, weight, m):
+    """(B,C,n) f32, (B,n,3) i32, (B,n,3) f32, m -> (B,C,m).  interpolate.cpp:75-104"""
+    _contig(grad_out, "grad_out"); _contig(idx, "idx"); _contig(weight, "weight")
+    _is_float(grad_out, "grad_out"); _is_int(idx, "idx"); _is_float(weight, "weight")
+    dev = _device_of(grad_out, "grad_out", (idx, "idx"), (weight, "weight"))
+    b, c, n = grad_out.shape
+    out = torch.empty((b, c, int(m)), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        _native.check(_native.lib().istnet_pn2_three_interpolate_grad(
+            b, c, n, int(m), _ptr(grad_out), _ptr(idx), _ptr(weight), _ptr(out), _stream(dev)),
+            "three_interpolate_grad")
+    return out
+
+
+def ball_query(new_xyz, xyz, radius, nsample):
+    """(B,npoint,3), (B,N,3) f32, radius, nsample -> (B,npoint,nsample) i32.  ball_query.cpp:13-37"""
+    _contig(new_xyz, "new_xyz"); _contig(xyz, "xyz"); _is_float(new_xyz, "new_xyz"); _is_float(xyz, "xyz")
+    dev = _device_of(new_xyz, "new_xyz", (xyz, "xyz"))
+    b, m = new_xyz.shape[0], new_xyz.shape[1]
+    n = xyz.shape[1]
+    nsample = int(nsample)
+    idx = torch.empty((b, m, nsample), dtype=torch.int32, device=dev)
+    with torch.cuda.device(dev):
+        _native.check(_native.lib().istnet_pn2_query_ball_point(
+            b, n, m, float(radius), nsample, _ptr(new_xyz), _ptr(xyz), _ptr(idx), _stream(dev)),
+            "ball_query")
+    return idx
+
+
+def group_points(points, idx):
+    """(B,C,N) f32, (B,npoint,nsample) i32 -> (B,C,npoint,nsample).  group_points.cpp:17-40"""
+    _contig(points, "points"); _contig(idx, "idx"); _is_float(points, "points"); _is_int(idx, "idx")
+    dev = _device_of(points, "points", (idx, "idx"))
+    b, c, n = points.shape
+    npoints, nsample = idx.shape[1], idx.shape[2]
+    out = torch.empty((b, c, npoints, nsample), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        _native.check(_native.lib().istnet_pn2_group_points(
+            b, c, n, npoints, nsample, _ptr(points), _ptr(idx), _ptr(out), _stream(dev)),
+            "group_points")
+    return out
+
+
+def group_points_grad(grad_out, idx, n):
+    """(B,C,npoint,nsample) f32, (B,npoint,nsample) i32, n -> (B,C,n).  group_points.cpp:42-65"""
+    _contig(grad_out, "grad_out"); _contig(idx, "idx"); _is_float(grad_out, "grad_out"); _is_int(idx, "idx")
+    dev = _device_of(grad_out, "grad_out", (idx, "idx"))
+    b, c, npoints, nsample = grad_out.shape
+    out = torch.empty((b, c, int(n)), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        _native.check(_native.lib().istnet_pn2_group_points_grad(
+            b, c, int(n), npoints, nsample, _ptr(grad_out), _ptr(idx), _ptr(out), _stream(dev)),
+            "group_points_grad")
+    return out

@@ -1,0 +1,96 @@
+"""PointNet++ set-abstraction (SA) and feature-propagation (FP) modules.
+
+Mirror of model/pointnet2/pointnet2_modules.py with the same class names, constructor
+arguments, tensor layouts and child-module names (``groupers``, ``mlps``, ``mlp``), so reference
+checkpoints load and reference call sites work unchanged.
+
+SA  [ref :29-73]:  FPS -> gather centroids -> per scale [ball query + group -> SharedMLP ->
+                   max over nsample] -> concat scales.
+FP  [ref :164-209]: three_nn -> inverse-distance weights -> three_interpolate -> concat skip
+                   -> SharedMLP.
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import pointnet2_utils, pytorch_utils
+
+
+class _PointnetSAModuleBase(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.npoint = None
+        self.groupers = None
+        self.mlps = None
+
+    def _sample_centroids(self, xyz):
+        """(B,N,3) -> (B,npoint,3) by furthest point sampling, or None for GroupAll.  [ref :49-58]"""
+        if self.npoint is None:
+            return None
+        picked = pointnet2_utils.furthest_point_sample(xyz, self.npoint)
+        channels_first = xyz.transpose(1, 2).contiguous()
+        return pointnet2_utils.gather_operation(channels_first, picked).transpose(1, 2).contiguous()
+
+    def forward(self, xyz, features=None):
+        """xyz (B,N,3), features (B,C,N) or None -> new_xyz (B,npoint,3), (B, sum(mlp[-1]), npoint)."""
+        new_xyz = self._sample_centroids(xyz)
+        pooled = []
+        for grouper, mlp in zip(self.groupers, self.mlps):
+            grouped = grouper(xyz, new_xyz, features)                 # (B, C_in, npoint, nsample)
+            act = mlp(grouped)                                         # (B, C_out, npoint, nsample)
+            act = F.max_pool2d(act, kernel_size=[1, act.size(3)])      # (B, C_out, npoint, 1)
+            pooled.append(act.squeeze(-1))
+        return new_xyz, torch.cat(pooled, dim=1)
+
+
+class PointnetSAModuleMSG(_PointnetSAModuleBase):
+    """Multi-scale-grouping SA layer.  [ref :76-114]
+
+    ``mlps[i][0]`` is the feature width WITHOUT xyz; 3 is added in place when ``use_xyz``
+    (the reference mutates the caller's list the same way, :110-111).
+    """
+
+    def __init__(self, npoint, radii, nsamples, mlps, bn=True, use_xyz=True):
+        super().__init__()
+        if not (len(radii) == len(nsamples) == len(mlps)):
+            raise AssertionError("radii, nsamples and mlps must have one entry per scale")
+        self.npoint = npoint
+        self.groupers = nn.ModuleList()
+        self.mlps = nn.ModuleList()
+        for radius, nsample, spec in zip(radii, nsamples, mlps):
+            self.groupers.append(
+                pointnet2_utils.QueryAndGroup(radius, nsample, use_xyz=use_xyz)
+                if npoint is not None else pointnet2_utils.GroupAll(use_xyz))
+            if use_xyz:
+                spec[0] += 3
+            self.mlps.append(pytorch_utils.SharedMLP(spec, bn=bn))
+
+
+class PointnetSAModule(PointnetSAModuleMSG):
+    """Single-scale SA layer.  [ref :117-145]"""
+
+    def __init__(self, mlp, npoint=None, radius=None, nsample=None, bn=True, use_xyz=True):
+        super().__init__(npoint=npoint, radii=[radius], nsamples=[nsample], mlps=[mlp], bn=bn,
+                         use_xyz=use_xyz)
+
+
+class PointnetFPModule(nn.Module):
+    """Feature propagation from a coarse set (known) to a dense one (unknown).  [ref :148-209]"""
+
+    def __init__(self, mlp, bn=True):
+        super().__init__()
+        self.mlp = pytorch_utils.SharedMLP(mlp, bn=bn)
+
+    def forward(self, unknown, known, unknow_feats, known_feats):
+        """unknown (B,n,3), known (B,m,3), unknow_feats (B,C1,n) or None, known_feats (B,C2,m)
+        -> (B, mlp[-1], n)."""
+        if known is None:
+            interpolated = known_feats.expand(*known_feats.size()[0:2], unknown.size(1))
+        else:
+            dist, idx = pointnet2_utils.three_nn(unknown, known)
+            inv = 1.0 / (dist + 1e-8)
+            weight = inv / torch.sum(inv, dim=2, keepdim=True)
+            interpolated = pointnet2_utils.three_interpolate(known_feats, idx.detach(), weight.detach())
+
+        stacked = interpolated if unknow_feats is None else torch.cat([interpolated, unknow_feats], dim=1)
+        return self.mlp(stacked.unsqueeze(-1)).squeeze(-1)

@@ -1,0 +1,42 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # Build the checker (oracle) and, when hipcc is available, the product library.
+    from oracle import pn2_oracle
+    pn2_oracle.build()
+    import istnet_amd  # noqa: F401
+    from istnet_amd import build as hip_build
+    if hip_build.needs_build():
+        hip_build.build()
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    from oracle import pn2_oracle
+    return pn2_oracle
+
+
+@pytest.fixture(scope="session")
+def ext():
+    """The product's drop-in for pointnet2._ext (HIP, GPU only)."""
+    from istnet_amd.pointnet2 import _ext
+    return _ext
+
+
+@pytest.fixture()
+def cpu_ops(monkeypatch, oracle):
+    """Route the operator wrappers to the CPU oracle so host logic can run without a GPU.
+
+    Test-only: the product never does this (its _ext raises "CPU not supported")."""
+    from istnet_amd.pointnet2 import pointnet2_utils
+    monkeypatch.setattr(pointnet2_utils, "_ext", oracle)
+    return pointnet2_utils

@@ -1,0 +1,187 @@
+"""GPU parity: every C-ABI op (through the pointnet2._ext drop-in) against the CPU oracle.
+
+Index outputs must be bit-exact; float outputs of pure gathers are bit-exact, of
+scatter-adds within 1e-4 (fp32 summation order differs, as it does in the reference's atomics).
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+
+
+def _cloud(b, n, seed, kind="cube", scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    if kind == "cube":
+        return torch.rand(b, n, 3, generator=g) * scale
+    if kind == "shell":
+        d = torch.randn(b, n, 3, generator=g)
+        d = d / d.norm(dim=2, keepdim=True)
+        return (d * 0.1 + torch.randn(b, n, 3, generator=g) * 0.002).contiguous()
+    if kind == "dup":  # many duplicate points -> FPS ties
+        base = torch.rand(b, max(n // 8, 1), 3, generator=g)
+        sel = torch.randint(0, base.shape[1], (b, n), generator=g)
+        return torch.gather(base, 1, sel.unsqueeze(-1).expand(b, n, 3)).contiguous()
+    if kind == "grid":  # lattice -> exact distance ties
+        pts = torch.randint(0, 4, (b, n, 3), generator=g).float() * 0.25
+        return pts.contiguous()
+    raise ValueError(kind)
+
+
+@pytest.mark.parametrize("b,n,m,kind", [
+    (4, 1024, 512, "cube"), (2, 512, 256, "shell"), (2, 256, 128, "cube"), (2, 128, 64, "cube"),
+    (3, 1024, 512, "dup"), (2, 1024, 300, "grid"), (2, 1000, 333, "cube"), (2, 700, 100, "dup"),
+    (1, 100, 50, "grid"), (2, 65, 64, "cube"), (2, 64, 64, "grid"), (1, 3, 3, "cube"), (1, 1, 1, "cube"),
+    (2, 2048, 512, "cube"), (1, 4096, 256, "dup"), (1, 3000, 200, "grid"), (1, 5000, 64, "cube"),
+    (1, 1024, 1, "cube"), (1, 37, 80, "cube"),
+])
+def test_fps_bit_exact(ext, oracle, b, n, m, kind):
+    xyz = _cloud(b, n, seed=n * 7 + m, kind=kind)
+    want = oracle.furthest_point_sampling(xyz, m)
+    got = ext.furthest_point_sampling(xyz.to(DEV), m).cpu()
+    assert got.dtype == torch.int32 and got.shape == (b, m)
+    assert torch.equal(got, want)
+    assert (got[:, 0] == 0).all()
+
+
+@pytest.mark.parametrize("b,n,m,radius,nsample,kind", [
+    (4, 1024, 512, 0.2, 32, "cube"),      # BASELINE config 1
+    (4, 1024, 512, 0.1, 16, "cube"), (2, 512, 256, 0.02, 16, "shell"), (2, 512, 256, 0.04, 32, "shell"),
+    (2, 128, 64, 0.16, 32, "shell"), (2, 1024, 512, 0.25, 32, "grid"), (2, 1000, 77, 0.3, 5, "cube"),
+    (1, 64, 64, 10.0, 100, "cube"), (1, 10, 3, 0.5, 4, "cube"), (2, 300, 300, 1e-6, 8, "cube"),
+    (1, 6000, 64, 0.05, 64, "cube"), (1, 2048, 700, 0.08, 33, "cube"),
+])
+def test_ball_query_bit_exact(ext, oracle, b, n, m, radius, nsample, kind):
+    xyz = _cloud(b, n, seed=n + m, kind=kind)
+    fps = oracle.furthest_point_sampling(xyz, m).long()
+    new_xyz = torch.gather(xyz, 1, fps.unsqueeze(-1).expand(b, m, 3)).contiguous()
+    if kind == "grid":  # off-lattice centroids too, so that some balls are empty
+        new_xyz[:, ::3] += 5.0
+    want = oracle.ball_query(new_xyz, xyz, radius, nsample)
+    got = ext.ball_query(new_xyz.to(DEV), xyz.to(DEV), radius, nsample).cpu()
+    assert got.dtype == torch.int32
+    assert torch.equal(got, want)
+
+
+def test_ball_query_edges(ext, oracle):
+    # no neighbour -> zeros; exactly one hit -> row of that index; d2 == r2 excluded
+    xyz = torch.tensor([[[0., 0, 0], [1, 0, 0], [0, 2, 0], [0, 0, 3]]])
+    new_xyz = torch.tensor([[[10., 10, 10], [1, 0, 0], [0, 0, 0.5]]])
+    for r, ns in [(0.5, 4), (1.0, 3), (2.0, 2), (100.0, 6)]:
+        want = oracle.ball_query(new_xyz, xyz, r, ns)
+        got = ext.ball_query(new_xyz.to(DEV), xyz.to(DEV), r, ns).cpu()
+        assert torch.equal(got, want), (r, ns)
+    got = ext.ball_query(new_xyz.to(DEV), xyz.to(DEV), 0.5, 4).cpu()
+    assert got[0, 0].tolist() == [0, 0, 0, 0]
+    assert got[0, 1].tolist() == [1, 1, 1, 1]
+    # point at exactly d2 == r2 is excluded (strict <): centroid (1,0,0), point (0,0,0), r = 1
+    got = ext.ball_query(new_xyz.to(DEV), xyz.to(DEV), 1.0, 3).cpu()
+    assert got[0, 1].tolist() == [1, 1, 1]
+
+
+@pytest.mark.parametrize("b,n,m,kind", [
+    (2, 128, 64, "cube"), (2, 256, 128, "shell"), (2, 512, 256, "cube"), (4, 1024, 512, "shell"),
+    (2, 1024, 512, "grid"), (2, 333, 77, "dup"), (1, 50, 2, "cube"), (1, 50, 1, "cube"),
+    (1, 10, 3, "grid"), (1, 300, 5000, "cube"),
+])
+def test_three_nn_bit_exact(ext, oracle, b, n, m, kind):
+    unknown = _cloud(b, n, seed=3 * n + m, kind=kind)
+    known = _cloud(b, m, seed=5 * n + m + 1, kind=kind)
+    d_want, i_want = oracle.three_nn(unknown, known)
+    d_got, i_got = ext.three_nn(unknown.to(DEV), known.to(DEV))
+    assert torch.equal(i_got.cpu(), i_want)
+    assert torch.equal(d_got.cpu(), d_want)  # same f32 arithmetic, inf where m < 3
+
+
+@pytest.mark.parametrize("b,c,n,m", [(2, 3, 1024, 512), (2, 64, 512, 256), (1, 7, 100, 33), (1, 1, 5, 9)])
+def test_gather_points_and_grad(ext, oracle, b, c, n, m):
+    g = torch.Generator().manual_seed(c * n)
+    pts = torch.randn(b, c, n, generator=g)
+    idx = torch.randint(0, n, (b, m), generator=g, dtype=torch.int32)
+    assert torch.equal(ext.gather_points(pts.to(DEV), idx.to(DEV)).cpu(), oracle.gather_points(pts, idx))
+    go = torch.randn(b, c, m, generator=g)
+    want = oracle.gather_points_grad(go, idx, n)
+    got = ext.gather_points_grad(go.to(DEV), idx.to(DEV), n).cpu()
+    torch.testing.assert_close(got, want, rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("b,c,n,npoint,nsample", [
+    (4, 3, 1024, 512, 32), (2, 64, 512, 256, 16), (2, 128, 256, 128, 32), (2, 256, 128, 64, 32),
+    (1, 5, 77, 13, 7), (1, 1, 4, 1, 1), (1, 9, 20000, 16, 8),
+])
+def test_group_points_and_grad(ext, oracle, b, c, n, npoint, nsample):
+    g = torch.Generator().manual_seed(c + n + npoint)
+    pts = torch.randn(b, c, n, generator=g)
+    idx = torch.randint(0, n, (b, npoint, nsample), generator=g, dtype=torch.int32)
+    # repeated indices (padded balls) accumulate in the gradient
+    idx[:, :, nsample // 2:] = idx[:, :, :1]
+    want = oracle.group_points(pts, idx)
+    got = ext.group_points(pts.to(DEV), idx.to(DEV)).cpu()
+    assert torch.equal(got, want)
+    go = torch.randn(b, c, npoint, nsample, generator=g)
+    gwant = oracle.group_points_grad(go, idx, n)
+    ggot = ext.group_points_grad(go.to(DEV), idx.to(DEV), n).cpu()
+    torch.testing.assert_close(ggot, gwant, rtol=1e-4, atol=1e-4)
+    # equals a dense scatter-add in float64
+    ref = torch.zeros(b, c, n, dtype=torch.float64)
+    ref.scatter_add_(2, idx.long().reshape(b, 1, -1).expand(b, c, -1), go.double().reshape(b, c, -1))
+    torch.testing.assert_close(ggot.double(), ref, rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("b,c,m,n", [(2, 512, 64, 128), (2, 256, 256, 512), (2, 256, 512, 1024), (1, 3, 4, 2),
+                                     (1, 10, 20000, 50)])
+def test_three_interpolate_and_grad(ext, oracle, b, c, m, n):
+    g = torch.Generator().manual_seed(c + m + n)
+    feats = torch.randn(b, c, m, generator=g)
+    idx = torch.randint(0, m, (b, n, 3), generator=g, dtype=torch.int32)
+    w = torch.rand(b, n, 3, generator=g)
+    w = w / w.sum(dim=2, keepdim=True)
+    want = oracle.three_interpolate(feats, idx, w)
+    got = ext.three_interpolate(feats.to(DEV), idx.to(DEV), w.to(DEV)).cpu()
+    assert torch.equal(got, want)  # same un-contracted f32 expression
+    go = torch.randn(b, c, n, generator=g)
+    gwant = oracle.three_interpolate_grad(go, idx, w, m)
+    ggot = ext.three_interpolate_grad(go.to(DEV), idx.to(DEV), w.to(DEV), m).cpu()
+    torch.testing.assert_close(ggot, gwant, rtol=1e-4, atol=1e-4)
+
+
+def test_three_interpolate_reference_fixture(ext):
+    """The one known answer the reference holds: pointnet2_test.py:25-30."""
+    feats = torch.randn(1, 2, 4, generator=torch.Generator().manual_seed(1))
+    idx = torch.tensor([[[0, 1, 2], [1, 2, 3]]], dtype=torch.int32)
+    w = torch.tensor([[[1., 1, 1], [2, 2, 2]]])
+    got = ext.three_interpolate(feats.to(DEV), idx.to(DEV), w.to(DEV)).cpu()
+    want = torch.stack([feats[..., 0] + feats[..., 1] + feats[..., 2],
+                        2 * (feats[..., 1] + feats[..., 2] + feats[..., 3])], dim=-1)
+    torch.testing.assert_close(got, want, rtol=1e-6, atol=1e-6)
+
+
+def test_cpu_tensors_rejected(ext):
+    x = torch.rand(1, 8, 3)
+    with pytest.raises(RuntimeError, match="CPU not supported"):
+        ext.ball_query(x, x, 0.1, 4)
+    with pytest.raises(RuntimeError, match="CPU not supported"):
+        ext.furthest_point_sampling(x, 4)
+
+
+def test_argument_checks(ext):
+    x = torch.rand(1, 8, 3, device=DEV)
+    with pytest.raises(RuntimeError, match="contiguous"):
+        ext.furthest_point_sampling(x.transpose(1, 2), 4)
+    with pytest.raises(RuntimeError, match="float tensor"):
+        ext.furthest_point_sampling(x.double(), 4)
+    with pytest.raises(RuntimeError, match="int tensor"):
+        ext.gather_points(x.transpose(1, 2).contiguous(), torch.zeros(1, 4, dtype=torch.int64, device=DEV))
+    with pytest.raises(RuntimeError, match="CUDA tensor"):
+        ext.ball_query(x, x.cpu(), 0.1, 4)
+
+
+def test_runs_on_current_stream(ext, oracle):
+    xyz = _cloud(2, 256, seed=9)
+    s = torch.cuda.Stream(device=DEV)
+    with torch.cuda.stream(s):
+        got = ext.furthest_point_sampling(xyz.to(DEV), 64)
+    s.synchronize()
+    assert torch.equal(got.cpu(), oracle.furthest_point_sampling(xyz, 64))
