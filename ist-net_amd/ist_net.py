@@ -1,0 +1,195 @@
+"""IST head and pose heads of IST-Net (point branch).
+
+Mirror of model/ist_net.py: ``FeatureDeformer`` / ``ImplicitTransformation`` (:114-183),
+``WorldSpaceEnhancer`` (:185-200), ``LightEstimator`` (:202-264), ``HeavyEstimator`` (:267-332)
+and the point-branch wiring of ``IST_Net.forward`` (:22-76).  Sub-module names and
+``nn.Sequential`` indices equal the reference's, so its state dicts load unchanged
+(e.g. ``implicit_transform.feature_refine.deform_mlp2.4.weight``).  Device-agnostic: the reference's
+``.cuda()`` literal at :38 becomes ``device=pts.device``.
+
+The RGB branch (ResNet-18 + PSPNet, model/modules.py:10-81) is outside the hot path
+(SURVEY.md 8f); ``IST_Net`` takes any module that maps rgb (B,3,H,W) -> (B,128,H,W), or
+pre-computed per-point RGB features through ``inputs['rgb_local']``.
+"""
+import torch
+import torch.nn as nn
+
+from .modules import PointNet2MSG
+from .rotation_utils import Ortho6d2Mat
+
+CAM_RADII = [[0.01, 0.02], [0.02, 0.04], [0.04, 0.08], [0.08, 0.16]]      # ist_net.py:16
+WORLD_RADII = [[0.05, 0.10], [0.10, 0.20], [0.20, 0.30], [0.30, 0.40]]    # ist_net.py:189
+
+
+def _pointwise(widths, final_relu=True):
+    """Conv1d(k=1) -> ReLU chain over (B, C, N); indices 0,2,4.. are the convs."""
+    layers = []
+    for i in range(len(widths) - 1):
+        layers.append(nn.Conv1d(widths[i], widths[i + 1], 1))
+        if final_relu or i < len(widths) - 2:
+            layers.append(nn.ReLU())
+    return nn.Sequential(*layers)
+
+
+def _fc_head(out_dim):
+    return nn.Sequential(nn.Linear(512, 512), nn.ReLU(), nn.Linear(512, 256), nn.ReLU(),
+                         nn.Linear(256, out_dim))
+
+
+def _with_global_mean(feat):
+    """(B,C,N) -> (B,2C,N): append the per-cloud mean feature to every point (:174-175,:256-257)."""
+    return torch.cat([feat, feat.mean(dim=2, keepdim=True).expand_as(feat)], dim=1)
+
+
+class FeatureDeformer(nn.Module):
+    """Camera-space features -> world-space features + per-class NOCS coordinates.  [ref :123-183]"""
+
+    def __init__(self, nclass=6):
+        super().__init__()
+        self.nclass = nclass
+        self.pts_mlp1 = _pointwise([3, 32, 64])
+        self.deform_mlp1 = _pointwise([64 + 256, 384, 256])
+        self.deform_mlp2 = _pointwise([512, 384, 256, 128])
+        self.pred_nocs = _pointwise([128, 256, 128, nclass * 3], final_relu=False)
+
+    def forward(self, pts, rgb_local, pts_local, index):
+        npoint = pts_local.size(2)
+        geo = self.pts_mlp1(pts.transpose(1, 2))
+        feat = self.deform_mlp1(torch.cat([geo, pts_local, rgb_local], dim=1))
+        pts_local_w = self.deform_mlp2(_with_global_mean(feat))
+        nocs = self.pred_nocs(pts_local_w).view(-1, 3, npoint).contiguous()   # (B*nclass, 3, N)
+        pts_w = torch.index_select(nocs, 0, index).permute(0, 2, 1).contiguous()
+        return pts_local_w, pts_w
+
+
+class ImplicitTransformation(nn.Module):
+    def __init__(self, nclass=6):
+        super().__init__()
+        self.nclass = nclass
+        self.feature_refine = FeatureDeformer(nclass)
+
+    def forward(self, rgb_local, pts_local, pts, center, index):
+        pts_local_w, pts_w = self.feature_refine(pts, rgb_local, pts_local, index)
+        return pts_w, pts_local_w
+
+
+class _PoseHeads(nn.Module):
+    """Shared tail of both estimators: pooled 512-d feature -> R (via 6-D), t, s."""
+
+    def _make_heads(self):
+        self.rotation_estimator = _fc_head(6)
+        self.translation_estimator = _fc_head(3)
+        self.size_estimator = _fc_head(3)
+
+    def _pose(self, pooled):
+        r6 = self.rotation_estimator(pooled)
+        r = Ortho6d2Mat(r6[:, :3].contiguous(), r6[:, 3:].contiguous()).view(-1, 3, 3)
+        return r, self.translation_estimator(pooled), self.size_estimator(pooled)
+
+
+class LightEstimator(_PoseHeads):
+    """Camera-space auxiliary pose head.  [ref :202-264]"""
+
+    def __init__(self):
+        super().__init__()
+        self.pts_mlp = _pointwise([3, 32, 64])
+        self.pose_mlp1 = _pointwise([128 + 64 + 128, 256, 256])
+        self.pose_mlp2 = nn.Sequential(*_pointwise([512, 512, 512]), nn.AdaptiveAvgPool1d(1))
+        self._make_heads()
+
+    def forward(self, pts, rgb_local, pts_local):
+        geo = self.pts_mlp(pts.transpose(1, 2))
+        feat = self.pose_mlp1(torch.cat([rgb_local, geo, pts_local], dim=1))
+        return self._pose(self.pose_mlp2(_with_global_mean(feat)).squeeze(2))
+
+
+class HeavyEstimator(_PoseHeads):
+    """Main pose head over camera- and world-space cues.  [ref :267-332]"""
+
+    def __init__(self):
+        super().__init__()
+        self.pts_mlp1 = _pointwise([3, 32, 64])
+        self.pts_mlp2 = _pointwise([3, 32, 64])
+        self.pose_mlp1 = _pointwise([64 + 64 + 384, 256, 256])
+        self.pose_mlp2 = nn.Sequential(*_pointwise([512, 512, 512]), nn.AdaptiveAvgPool1d(1))
+        self._make_heads()
+
+    def forward(self, pts, pts_w, rgb_local, pts_local, pts_w_local):
+        geo = self.pts_mlp1(pts.transpose(1, 2))
+        geo_w = self.pts_mlp2(pts_w.transpose(1, 2))
+        feat = self.pose_mlp1(torch.cat([rgb_local, geo, pts_local, geo_w, pts_w_local], dim=1))
+        return self._pose(self.pose_mlp2(_with_global_mean(feat)).squeeze(2))
+
+
+class WorldSpaceEnhancer(nn.Module):
+    """Training-only branch on ground-truth NOCS points.  [ref :185-200]"""
+
+    def __init__(self, freeze=False):
+        super().__init__()
+        self.freeze = freeze
+        self.extractor = PointNet2MSG(radii_list=[list(r) for r in WORLD_RADII])
+        if not freeze:
+            self.pose_estimator = HeavyEstimator()
+
+    def forward(self, pts, pts_w_gt, rgb_local, pts_local):
+        pts_w_local_gt = self.extractor(pts_w_gt)
+        if self.freeze:
+            return None, None, None, pts_w_local_gt
+        r, t, s = self.pose_estimator(pts, pts_w_gt, rgb_local.detach(), pts_local.detach(), pts_w_local_gt)
+        return r, t, s, pts_w_local_gt
+
+
+class IST_Net(nn.Module):
+    """IST-Net wiring.  [ref :10-76]  ``rgb_extractor`` maps (B,3,H,W) -> (B,128,H,W)."""
+
+    def __init__(self, nclass=6, freeze_world_enhancer=False, rgb_extractor=None):
+        super().__init__()
+        self.nclass = nclass
+        self.freeze_world_enhancer = freeze_world_enhancer
+        if rgb_extractor is not None:
+            self.rgb_cam_extractor = rgb_extractor
+        self.pts_cam_extractor = PointNet2MSG(radii_list=[list(r) for r in CAM_RADII])
+        self.implicit_transform = ImplicitTransformation(nclass)
+        self.main_estimator = HeavyEstimator()
+        self.cam_enhancer = LightEstimator()
+        self.world_enhancer = WorldSpaceEnhancer(freeze=freeze_world_enhancer)
+
+    def _rgb_local(self, inputs, b):
+        if "rgb_local" in inputs:
+            return inputs["rgb_local"]
+        feat = self.rgb_cam_extractor(inputs["rgb"])
+        d = feat.size(1)
+        choose = inputs["choose"].unsqueeze(1).repeat(1, d, 1)
+        return torch.gather(feat.view(b, d, -1), 2, choose).contiguous()   # :41-45
+
+    def forward(self, inputs):
+        end_points = {}
+        pts = inputs["pts"]
+        cls = inputs["category_label"].reshape(-1)
+        c = torch.mean(pts, 1, keepdim=True)
+        pts = pts - c
+        b = pts.size(0)
+        index = cls + torch.arange(b, dtype=torch.long, device=pts.device) * self.nclass
+        rgb_local = self._rgb_local(inputs, b)
+
+        pts_local = self.pts_cam_extractor(pts)
+        if self.training:
+            r_cam, t_cam, s_cam = self.cam_enhancer(pts, rgb_local, pts_local)
+        pts_w, pts_w_local = self.implicit_transform(rgb_local, pts_local, pts, c, index)
+        r, t, s = self.main_estimator(pts, pts_w, rgb_local, pts_local, pts_w_local)
+        end_points["pred_qo"] = pts_w
+        end_points["pred_rotation"] = r
+        end_points["pred_translation"] = t + c.squeeze(1)
+        end_points["pred_size"] = s
+        if self.training:
+            r_w, t_w, s_w, pts_w_local_gt = self.world_enhancer(pts, inputs["qo"], rgb_local, pts_local)
+            end_points["pts_w_local"] = pts_w_local
+            end_points["pts_w_local_gt"] = pts_w_local_gt
+            end_points["pred_rotation_aux_cam"] = r_cam
+            end_points["pred_translation_aux_cam"] = t_cam + c.squeeze(1)
+            end_points["pred_size_aux_cam"] = s_cam
+            if not self.freeze_world_enhancer:
+                end_points["pred_rotation_aux_world"] = r_w
+                end_points["pred_translation_aux_world"] = t_w + c.squeeze(1)
+                end_points["pred_size_aux_world"] = s_w
+        return end_points

@@ -1,0 +1,126 @@
+"""Host logic (operator wrappers, SA / FP / encoder / heads wiring, state-dict keys) on CPU:
+our modules driven over the CPU oracle must reproduce the golden vectors that the REFERENCE
+Python produced (tests/golden/make_golden.py)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+CAM = [[0.01, 0.02], [0.02, 0.04], [0.04, 0.08], [0.08, 0.16]]
+
+
+def _checksum(sd):
+    sd = {k: v for k, v in sd.items() if "running_" not in k and "num_batches" not in k}
+    return np.array([[float(v.double().sum()), float(v.double().abs().sum())] for v in sd.values()])
+
+
+def test_query_and_group_config1(cpu_ops):
+    z = np.load(os.path.join(GOLD, "config1_sa_grouping.npz"))
+    xyz, new_xyz = torch.from_numpy(z["xyz"]), torch.from_numpy(z["new_xyz"])
+    fps = cpu_ops.furthest_point_sample(xyz, 512)
+    assert np.array_equal(fps.numpy(), z["fps_idx"].astype(np.int32))
+    got_new = cpu_ops.gather_operation(xyz.transpose(1, 2).contiguous(), fps).transpose(1, 2).contiguous()
+    assert torch.equal(got_new, new_xyz)
+    grouped = cpu_ops.QueryAndGroup(0.2, 32)(xyz, new_xyz, None)
+    assert grouped.shape == (4, 3, 512, 32)
+    assert np.array_equal(grouped.numpy()[:, :, ::16], z["grouped_xyz"])
+    assert abs(float(grouped.double().abs().sum()) - float(z["grouped_abs_sum"])) < 1e-6
+
+
+def test_sa_fp_layer_matches_reference(cpu_ops):
+    from istnet_amd.pointnet2.pointnet2_modules import PointnetFPModule, PointnetSAModuleMSG
+    z = np.load(os.path.join(GOLD, "sa_fp_layer.npz"))
+    torch.manual_seed(20)
+    sa = PointnetSAModuleMSG(npoint=64, radii=[0.15, 0.3], nsamples=[8, 16], mlps=[[16, 16, 32], [16, 16, 32]])
+    fp = PointnetFPModule(mlp=[64 + 16, 32, 32])
+    np.testing.assert_allclose(_checksum({**sa.state_dict(), **fp.state_dict()}), z["state_checksum"], rtol=0, atol=0)
+    xyz = torch.from_numpy(z["xyz"])
+    feat = torch.from_numpy(z["feat"]).requires_grad_(True)
+    new_xyz, new_feat = sa(xyz, feat)
+    out = fp(xyz, new_xyz, feat, new_feat)
+    out.square().mean().backward()
+    assert np.array_equal(new_xyz.detach().numpy(), z["new_xyz"])
+    np.testing.assert_allclose(new_feat.detach().numpy(), z["sa_out"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(out.detach().numpy(), z["fp_out"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(feat.grad.numpy(), z["grad_feat"], rtol=1e-4, atol=1e-7)
+    for name, p in list(sa.named_parameters()) + list(fp.named_parameters()):
+        np.testing.assert_allclose(p.grad.numpy(), z["gradp_" + name], rtol=1e-4, atol=1e-7, err_msg=name)
+
+
+def test_encoder_matches_reference(cpu_ops):
+    from istnet_amd.modules import PointNet2MSG
+    z = np.load(os.path.join(GOLD, "encoder_b2.npz"))
+    torch.manual_seed(0)
+    enc = PointNet2MSG([list(r) for r in CAM])
+    sd = {k: v for k, v in enc.state_dict().items() if "running" not in k and "num_batches" not in k}
+    np.testing.assert_allclose(_checksum(sd), z["state_checksum"], rtol=0, atol=0)
+    assert len(enc.state_dict()) == 192 and sum(p.numel() for p in enc.parameters()) == 1307808
+    pts = torch.from_numpy(z["pts"])
+    enc.train()
+    out = enc(pts)
+    assert out.shape == (2, 128, 1024)
+    np.testing.assert_allclose(out.detach().numpy()[:, :, ::8], z["out_train"], rtol=1e-4, atol=1e-5)
+    out.square().mean().backward()
+    norms = np.array([float(p.grad.double().norm()) for _, p in enc.named_parameters()])
+    np.testing.assert_allclose(norms, z["grad_norms"], rtol=1e-3, atol=1e-9)
+    g = dict(enc.named_parameters())
+    np.testing.assert_allclose(g["SA_modules.0.mlps.0.layer0.conv.weight"].grad.numpy(), z["grad_first_conv"],
+                               rtol=1e-3, atol=1e-8)
+    sdn = enc.state_dict()
+    np.testing.assert_allclose(sdn["SA_modules.3.mlps.1.layer2.normlayer.bn.running_var"].numpy(),
+                               z["running_var_sa3"], rtol=1e-5, atol=1e-8)
+    enc.eval()
+    with torch.no_grad():
+        out_eval = enc(pts)
+    np.testing.assert_allclose(out_eval.numpy()[:, :, ::8], z["out_eval"], rtol=1e-4, atol=1e-5)
+
+
+def test_heads_match_reference():
+    from istnet_amd import ist_net, rotation_utils
+    z = np.load(os.path.join(GOLD, "ist_heads_b2.npz"))
+    t = lambda k: torch.from_numpy(z[k])
+    index = t("cls").long() + torch.arange(2) * 6
+    cases = {"deformer": (ist_net.FeatureDeformer, (t("pts"), t("rgb_local"), t("pts_local"), index)),
+             "light": (ist_net.LightEstimator, (t("pts"), t("rgb_local"), t("pts_local"))),
+             "heavy": (ist_net.HeavyEstimator, (t("pts"), t("pts_w"), t("rgb_local"), t("pts_local"), t("pts_w_local")))}
+    for name, (ctor, args) in cases.items():
+        torch.manual_seed(40)
+        m = ctor()
+        np.testing.assert_allclose(_checksum(m.state_dict()), z[f"{name}_state_checksum"], rtol=0, atol=0)
+        for i, o in enumerate(m(*args)):
+            want = z[f"{name}_out{i}"]
+            got = o.detach().numpy() if o.numel() < 4096 else o.detach().numpy().reshape(o.shape[0], -1)[:, ::16]
+            np.testing.assert_allclose(got, want, rtol=1e-4, atol=1e-5, err_msg=f"{name}[{i}]")
+    rot = rotation_utils.Ortho6d2Mat(t("x6"), t("y6"))
+    np.testing.assert_allclose(rot.numpy(), z["rot"], rtol=1e-5, atol=1e-6)
+    eye = torch.matmul(rot.transpose(1, 2), rot)
+    torch.testing.assert_close(eye, torch.eye(3).expand(5, 3, 3), rtol=1e-5, atol=1e-5)
+
+
+def test_istnet_point_branch_matches_reference(cpu_ops):
+    from istnet_amd.ist_net import IST_Net
+    z = np.load(os.path.join(GOLD, "istnet_point_branch_b2.npz"))
+    torch.manual_seed(5)
+    net = IST_Net()
+    np.testing.assert_allclose(_checksum(net.state_dict()), z["state_checksum"], rtol=0, atol=0)
+    b, n = 2, 1024
+    rgb_feat = torch.from_numpy(z["rgb_feat"])
+    choose = torch.from_numpy(z["choose"].astype(np.int64))
+    inputs = {"rgb": rgb_feat, "pts": torch.from_numpy(z["pts"]), "choose": choose,
+              "category_label": torch.from_numpy(z["cls"]).reshape(b, 1), "qo": torch.from_numpy(z["qo"])}
+    net.rgb_cam_extractor = torch.nn.Identity()
+    net.train()
+    ep = net(inputs)
+    sub = lambda v: v.detach().numpy() if v.numel() <= 8192 else v.detach().numpy().reshape(b, -1)[:, ::64]
+    keys = [k[len("train_"):] for k in z.files if k.startswith("train_")]
+    assert set(keys) == set(ep.keys())
+    for k in keys:
+        np.testing.assert_allclose(sub(ep[k]), z["train_" + k], rtol=1e-3, atol=1e-5, err_msg=k)
+    net.eval()
+    with torch.no_grad():
+        ev = net(inputs)
+    assert set(ev.keys()) == {"pred_qo", "pred_rotation", "pred_translation", "pred_size"}
+    for k in ev:
+        np.testing.assert_allclose(sub(ev[k]), z["eval_" + k], rtol=1e-4, atol=1e-5, err_msg=k)

@@ -1,0 +1,197 @@
+"""GPU parity against the golden vectors produced by the reference Python (tests/golden), plus
+size-independent properties at the BASELINE.json full size (B=32, N=1024).
+
+Bar: index tensors bit-exact; features / poses within 1e-4 (fp32), as north_star states."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+CAM = [[0.01, 0.02], [0.02, 0.04], [0.04, 0.08], [0.08, 0.16]]
+TOL = dict(rtol=1e-4, atol=1e-4)
+
+
+def test_config1_single_sa_layer():
+    """BASELINE config 1: ball_query r=0.2 nsample=32 on B=4 N=1024."""
+    from istnet_amd.pointnet2 import pointnet2_utils as pu
+    z = np.load(os.path.join(GOLD, "config1_sa_grouping.npz"))
+    xyz = torch.from_numpy(z["xyz"]).to(DEV)
+    fps = pu.furthest_point_sample(xyz, 512)
+    assert np.array_equal(fps.cpu().numpy(), z["fps_idx"].astype(np.int32))
+    new_xyz = pu.gather_operation(xyz.transpose(1, 2).contiguous(), fps).transpose(1, 2).contiguous()
+    assert np.array_equal(new_xyz.cpu().numpy(), z["new_xyz"])
+    idx = pu.ball_query(0.2, 32, xyz, new_xyz)
+    assert np.array_equal(idx.cpu().numpy(), z["ball_idx"].astype(np.int32))
+    grouped = pu.QueryAndGroup(0.2, 32)(xyz, new_xyz, None)
+    assert np.array_equal(grouped.cpu().numpy()[:, :, ::16], z["grouped_xyz"])
+
+
+def test_sa_fp_layer():
+    from istnet_amd.pointnet2.pointnet2_modules import PointnetFPModule, PointnetSAModuleMSG
+    z = np.load(os.path.join(GOLD, "sa_fp_layer.npz"))
+    torch.manual_seed(20)
+    sa = PointnetSAModuleMSG(npoint=64, radii=[0.15, 0.3], nsamples=[8, 16], mlps=[[16, 16, 32], [16, 16, 32]]).to(DEV)
+    fp = PointnetFPModule(mlp=[64 + 16, 32, 32]).to(DEV)
+    xyz = torch.from_numpy(z["xyz"]).to(DEV)
+    feat = torch.from_numpy(z["feat"]).to(DEV).requires_grad_(True)
+    new_xyz, new_feat = sa(xyz, feat)
+    out = fp(xyz, new_xyz, feat, new_feat)
+    out.square().mean().backward()
+    assert np.array_equal(new_xyz.detach().cpu().numpy(), z["new_xyz"])
+    np.testing.assert_allclose(new_feat.detach().cpu().numpy(), z["sa_out"], **TOL)
+    np.testing.assert_allclose(out.detach().cpu().numpy(), z["fp_out"], **TOL)
+    np.testing.assert_allclose(feat.grad.cpu().numpy(), z["grad_feat"], **TOL)
+    for name, p in list(sa.named_parameters()) + list(fp.named_parameters()):
+        np.testing.assert_allclose(p.grad.cpu().numpy(), z["gradp_" + name], rtol=1e-3, atol=1e-4, err_msg=name)
+
+
+def test_encoder_b2(monkeypatch):
+    from istnet_amd.modules import PointNet2MSG
+    from istnet_amd.pointnet2 import _ext
+    z = np.load(os.path.join(GOLD, "encoder_b2.npz"))
+    captured, counters = {}, {}
+
+    def tap(name):
+        orig = getattr(_ext, name)
+
+        def fn(*a, **k):
+            res = orig(*a, **k)
+            i = counters.get(name, 0)
+            counters[name] = i + 1
+            captured[f"{name}_{i}"] = res
+            return res
+        monkeypatch.setattr(_ext, name, fn)
+    for n in ("furthest_point_sampling", "ball_query", "three_nn"):
+        tap(n)
+    torch.manual_seed(0)
+    enc = PointNet2MSG([list(r) for r in CAM]).to(DEV).train()
+    pts = torch.from_numpy(z["pts"]).to(DEV)
+    out = enc(pts)
+    for i in range(4):
+        assert np.array_equal(captured[f"furthest_point_sampling_{i}"].cpu().numpy(),
+                              z[f"furthest_point_sampling_{i}"].astype(np.int32)), i
+        d2, idx = captured[f"three_nn_{i}"]
+        assert np.array_equal(idx.cpu().numpy(), z[f"three_nn_idx_{i}"].astype(np.int32)), i
+        assert np.array_equal(d2.cpu().numpy(), z[f"three_nn_dist2_{i}"]), i
+    for i in range(8):
+        assert np.array_equal(captured[f"ball_query_{i}"].cpu().numpy(), z[f"ball_query_{i}"].astype(np.int32)), i
+    np.testing.assert_allclose(out.detach().cpu().numpy()[:, :, ::8], z["out_train"], **TOL)
+    out.square().mean().backward()
+    norms = np.array([float(p.grad.double().norm()) for _, p in enc.named_parameters()])
+    np.testing.assert_allclose(norms, z["grad_norms"], rtol=2e-3, atol=1e-7)
+    g = dict(enc.named_parameters())
+    np.testing.assert_allclose(g["SA_modules.0.mlps.0.layer0.conv.weight"].grad.cpu().numpy(), z["grad_first_conv"],
+                               rtol=2e-3, atol=1e-6)
+    np.testing.assert_allclose(g["FP_modules.0.mlp.layer1.conv.weight"].grad.cpu().numpy(), z["grad_last_fp_conv"],
+                               rtol=2e-3, atol=1e-6)
+    sd = enc.state_dict()
+    np.testing.assert_allclose(sd["SA_modules.3.mlps.1.layer2.normlayer.bn.running_mean"].cpu().numpy(),
+                               z["running_mean_sa3"], rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(sd["SA_modules.3.mlps.1.layer2.normlayer.bn.running_var"].cpu().numpy(),
+                               z["running_var_sa3"], rtol=1e-4, atol=1e-7)
+    enc.eval()
+    with torch.no_grad():
+        out_eval = enc(pts)
+    np.testing.assert_allclose(out_eval.cpu().numpy()[:, :, ::8], z["out_eval"], **TOL)
+
+
+def test_istnet_point_branch_poses():
+    """Predicted R / t / s and NOCS coordinates within 1e-4 of the reference composition."""
+    from istnet_amd.ist_net import IST_Net
+    z = np.load(os.path.join(GOLD, "istnet_point_branch_b2.npz"))
+    torch.manual_seed(5)
+    net = IST_Net()
+    net.rgb_cam_extractor = torch.nn.Identity()
+    net = net.to(DEV)
+    b = 2
+    inputs = {"rgb": torch.from_numpy(z["rgb_feat"]).to(DEV), "pts": torch.from_numpy(z["pts"]).to(DEV),
+              "choose": torch.from_numpy(z["choose"].astype(np.int64)).to(DEV),
+              "category_label": torch.from_numpy(z["cls"]).reshape(b, 1).to(DEV), "qo": torch.from_numpy(z["qo"]).to(DEV)}
+    sub = lambda v: v.detach().cpu().numpy() if v.numel() <= 8192 else v.detach().cpu().numpy().reshape(b, -1)[:, ::64]
+    net.train()
+    ep = net(inputs)
+    for k in [k[len("train_"):] for k in z.files if k.startswith("train_")]:
+        np.testing.assert_allclose(sub(ep[k]), z["train_" + k], rtol=1e-3, atol=1e-4, err_msg=k)
+    net.eval()
+    with torch.no_grad():
+        ev = net(inputs)
+    for k in ("pred_rotation", "pred_translation", "pred_size", "pred_qo"):
+        np.testing.assert_allclose(sub(ev[k]), z["eval_" + k], **TOL, err_msg=k)
+
+
+# ---------------------------------------------------------------------------------------------
+# full-size (B=32, N=1024) size-independent properties
+# ---------------------------------------------------------------------------------------------
+def _shell(b, n, seed):
+    g = torch.Generator().manual_seed(seed)
+    d = torch.randn(b, n, 3, generator=g)
+    pts = d / d.norm(dim=2, keepdim=True) * 0.1 + torch.randn(b, n, 3, generator=g) * 0.002
+    return (pts - pts.mean(dim=1, keepdim=True)).contiguous()
+
+
+def test_full_size_index_properties(ext):
+    b, n, m = 32, 1024, 512
+    xyz = _shell(b, n, 0).to(DEV)
+    fps = ext.furthest_point_sampling(xyz, m)
+    assert (fps[:, 0] == 0).all() and int(fps.min()) >= 0 and int(fps.max()) < n
+    assert all(len(set(row.tolist())) == m for row in fps.cpu())            # no repeats
+    new_xyz = torch.gather(xyz, 1, fps.long().unsqueeze(-1).expand(b, m, 3)).contiguous()
+    for r, ns in ((0.01, 16), (0.02, 32)):
+        idx = ext.ball_query(new_xyz, xyz, r, ns).long()
+        assert int(idx.min()) >= 0 and int(idx.max()) < n
+        nb = torch.gather(xyz.unsqueeze(1).expand(b, m, n, 3), 2, idx.unsqueeze(-1).expand(b, m, ns, 3))
+        d2 = ((nb - new_xyz.unsqueeze(2)) ** 2).sum(-1)
+        assert bool((d2 < r * r * (1 + 1e-5)).all())                        # every slot inside the ball
+        assert bool((idx[:, :, 0] <= idx.min(dim=2).values).all())          # first hit is the lowest index
+        srt = idx.clone()
+        # hits are strictly ascending until padding starts, padding repeats the first hit
+        inc = idx[:, :, 1:] > idx[:, :, :-1]
+        pad = idx[:, :, 1:] == idx[:, :, :1]
+        assert bool((inc | pad).all())
+    d2, idx3 = ext.three_nn(xyz, new_xyz)
+    assert bool((d2[:, :, 0] <= d2[:, :, 1]).all() and (d2[:, :, 1] <= d2[:, :, 2]).all())
+    # a centroid is its own nearest neighbour at distance 0
+    self_d = torch.gather(d2[:, :, 0], 1, fps.long())
+    assert float(self_d.max()) == 0.0
+
+
+def test_full_size_group_and_interpolate_adjoint(ext):
+    """<group(x), y> == <x, group_grad(y)> and the same for three_interpolate (linearity/adjoint)."""
+    b, c, n, m, ns = 32, 64, 512, 256, 32
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(b, c, n, generator=g).to(DEV)
+    idx = torch.randint(0, n, (b, m, ns), generator=g, dtype=torch.int32).to(DEV)
+    y = torch.randn(b, c, m, ns, generator=g).to(DEV)
+    lhs = (ext.group_points(x, idx).double() * y.double()).sum()
+    rhs = (x.double() * ext.group_points_grad(y, idx, n).double()).sum()
+    assert abs(float(lhs - rhs)) <= 1e-6 * max(1.0, abs(float(lhs))) + 1e-2
+    idx3 = torch.randint(0, m, (b, n, 3), generator=g, dtype=torch.int32).to(DEV)
+    w = torch.rand(b, n, 3, generator=g).to(DEV)
+    f = torch.randn(b, c, m, generator=g).to(DEV)
+    yo = torch.randn(b, c, n, generator=g).to(DEV)
+    lhs = (ext.three_interpolate(f, idx3, w).double() * yo.double()).sum()
+    rhs = (f.double() * ext.three_interpolate_grad(yo, idx3, w, m).double()).sum()
+    assert abs(float(lhs - rhs)) <= 1e-6 * max(1.0, abs(float(lhs))) + 1e-2
+
+
+def test_full_size_encoder_matches_cpu_oracle_composition(oracle):
+    """B=32 N=1024 encoder forward on the GPU vs the same modules over the CPU oracle."""
+    from istnet_amd.modules import PointNet2MSG
+    from istnet_amd.pointnet2 import pointnet2_utils
+    torch.manual_seed(0)
+    enc = PointNet2MSG([list(r) for r in CAM]).train()
+    pts = _shell(32, 1024, 0)
+    enc_gpu = PointNet2MSG([list(r) for r in CAM]).to(DEV).train()
+    enc_gpu.load_state_dict(enc.state_dict())
+    out_gpu = enc_gpu(pts.to(DEV)).detach().cpu()
+    saved = pointnet2_utils._ext
+    try:
+        pointnet2_utils._ext = oracle
+        out_cpu = enc(pts).detach()
+    finally:
+        pointnet2_utils._ext = saved
+    torch.testing.assert_close(out_gpu, out_cpu, **TOL)

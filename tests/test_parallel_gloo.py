@@ -1,0 +1,66 @@
+"""World-size-2 data-parallel path on CPU (gloo): the gradient exchange used by bench.py --gpus N."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _make(seed=0):
+    from istnet_amd.pointnet2.pointnet2_modules import PointnetFPModule, PointnetSAModuleMSG
+    torch.manual_seed(seed)
+    sa = PointnetSAModuleMSG(npoint=32, radii=[0.2, 0.4], nsamples=[8, 16], mlps=[[4, 8, 16], [4, 8, 16]])
+    fp = PointnetFPModule(mlp=[32 + 4, 16])
+    return torch.nn.ModuleList([sa, fp])
+
+
+def _local_grads(model, rank):
+    g = torch.Generator().manual_seed(100 + rank)
+    xyz = torch.rand(2, 128, 3, generator=g)
+    feat = torch.randn(2, 4, 128, generator=g)
+    model.zero_grad()
+    nx, nf = model[0](xyz, feat)
+    model[1](xyz, nx, feat, nf).square().mean().backward()
+    return [p.grad.clone() for p in model.parameters()]
+
+
+def _worker(rank, world, port, bucket_bytes, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.set_num_threads(1)
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import istnet_amd  # noqa: F401
+    from istnet_amd.parallel import GradAllReducer, broadcast_parameters
+    from istnet_amd.pointnet2 import pointnet2_utils
+    from oracle import pn2_oracle
+    pointnet2_utils._ext = pn2_oracle     # CPU test harness only
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    model = _make(seed=rank)              # deliberately different init per rank ...
+    broadcast_parameters(model, src=0)    # ... made identical by the broadcast
+    ref = _make(seed=0)
+    same = all(torch.equal(a, b) for a, b in zip(model.state_dict().values(), ref.state_dict().values()))
+    _local_grads(model, rank)
+    GradAllReducer(model, world, bucket_bytes=bucket_bytes).sync()
+    want = [sum(gs) / world for gs in zip(*[_local_grads(_make(0), r) for r in range(world)])]
+    ok = all(torch.allclose(p.grad, w, rtol=1e-5, atol=1e-7) for p, w in zip(model.parameters(), want))
+    out[rank] = bool(same and ok)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("bucket_bytes", [64 << 20, 2048])
+def test_grad_allreduce_world2(bucket_bytes):
+    world = 2
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker, args=(world, _free_port(), bucket_bytes, out), nprocs=world, join=True)
+    assert dict(out) == {0: True, 1: True}
