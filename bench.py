@@ -150,7 +150,7 @@ def main():
         }
         if world == 1 and not args.no_roofline:
             from istnet_amd import roofline
-            result["roofline"] = roofline.measure(model, pts, dev)
+            result["roofline"] = roofline.measure(step)
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline()
         print(json.dumps(result), flush=True)

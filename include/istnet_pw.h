@@ -1,0 +1,80 @@
+/*
+ * istnet_pw.h -- C ABI of the fused per-point MLP ("SharedMLP") kernels in libistnet_pn2.so.
+ *
+ * These entry points have NO counterpart in the reference's native extension: there the dense
+ * stack Conv2d(1x1, bias=False) -> BatchNorm2d -> ReLU (model/pointnet2/pytorch_utils.py:25-50,
+ * 80-134) and the max over nsample (pointnet2_modules.py:65-68) run as separate cuDNN / ATen
+ * kernels.  Here one layer is one fp32-MFMA GEMM over the raw (pre-BN) activations; see
+ * csrc/pw_mlp.hip and DESIGN.md section 5.
+ *
+ * Conventions: as istnet_pn2.h (device pointers, int status, async on `stream`, stateless).
+ * Layout: activations (B, C, P) f32 with P (= npoint * nsample) contiguous and P % 4 == 0;
+ * conv weight w (Cout, Cin) row-major, wt = its transpose (Cin, Cout).
+ * BN constant blocks:  bn   = [4][C]: scale = gamma*invstd, shift = beta - mean*scale, mean, invstd
+ *                      bwdc = [3][C]: dY = bwdc[0]*g + bwdc[1] + bwdc[2]*y,  g = dA * [y*scale+shift > 0]
+ * Gradient w.r.t. the layer output is given either dense (d_dense (B,C,P)) or, after the fused
+ * max-pool, pooled (d_pooled (B,C,P/nsample) + arg (B,C,P/nsample) u8, nsample % 4 == 0).
+ */
+#ifndef ISTNET_PW_H_
+#define ISTNET_PW_H_
+
+#include "istnet_pn2.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* tile configuration the forward / dgrad launch picks for M output rows: M_T * 1000 + N_T (for reporting) */
+ISTNET_PN2_API int istnet_pw_tile_cfg(int b, int m, int p);
+ISTNET_PN2_API int istnet_pw_wgrad_tile_cfg(int cin, int cout);
+
+/* number of per-channel partial-statistics slots istnet_pw_forward writes for this shape */
+ISTNET_PN2_API int istnet_pw_stat_tiles(int b, int cout, int p);
+
+/* y[b][co][p] = sum_ci wt[ci][co] * act(x[b][ci][p]); act = relu(v*in_scale[ci]+in_shift[ci]) or identity
+ * when in_scale == NULL.  If part_sum != NULL: part_sum/part_sq [cout][tiles] receive per-tile sum(y), sum(y*y). */
+ISTNET_PN2_API int istnet_pw_forward(int b, int cin, int cout, int p, const float *x, const float *wt,
+                                     const float *in_scale, const float *in_shift, float *y,
+                                     float *part_sum, float *part_sq, void *stream);
+
+/* partials -> bn[4][c]; updates running_mean / running_var (unbiased) with `momentum` unless NULL */
+ISTNET_PN2_API int istnet_bn_finalize_fwd(int c, int nt, double count, const float *part_sum,
+                                          const float *part_sq, const float *gamma, const float *beta,
+                                          float eps, float momentum, float *running_mean,
+                                          float *running_var, float *bn, void *stream);
+
+/* out[b][c][g] = max_s relu(y[b][c][g][s]*scale+shift), arg = index of the first maximum (s > 1);
+ * s == 1: out = relu(y*scale+shift), arg unused (may be NULL) */
+ISTNET_PN2_API int istnet_bn_relu_pool(int b, int c, int g, int s, const float *y, const float *bn,
+                                       float *out, unsigned char *arg, void *stream);
+
+/* backward statistics: partial sums of g and g*y per channel -> [c][tiles] */
+ISTNET_PN2_API int istnet_pw_bwd_stat_tiles(int b, int p);
+ISTNET_PN2_API int istnet_pw_bwd_stats(int b, int c, int p, int nsample, const float *y,
+                                       const float *d_dense, const float *d_pooled,
+                                       const unsigned char *arg, const float *bn, float *part_g,
+                                       float *part_gy, void *stream);
+/* partials -> dgamma, dbeta, bwdc[3][c]; training = 0 treats BN as a fixed affine map (eval mode) */
+ISTNET_PN2_API int istnet_bn_finalize_bwd(int c, int nt, double count, int training, const float *part_g,
+                                          const float *part_gy, const float *gamma, const float *bn,
+                                          float *dgamma, float *dbeta, float *bwdc, void *stream);
+
+/* dx[b][m][p] = sum_co w[co][ci_off+m] * dY[b][co][p], m < m_rows  (w is (cout, cin_total)) */
+ISTNET_PN2_API int istnet_pw_dgrad(int b, int cin_total, int ci_off, int m_rows, int cout, int p,
+                                   int nsample, const float *w, const float *y, const float *d_dense,
+                                   const float *d_pooled, const unsigned char *arg, const float *bn,
+                                   const float *bwdc, float *dx, void *stream);
+
+/* dw[co][ci] = sum_{b,p} dY[b][co][p] * act(x[b][ci][p]); dw_part is workspace of
+ * istnet_pw_wgrad_splits(...) * cout * cin floats (split-K partials, reduced in a fixed order) */
+ISTNET_PN2_API int istnet_pw_wgrad_splits(int b, int cin, int cout, int p);
+ISTNET_PN2_API int istnet_pw_wgrad(int b, int cin, int cout, int p, int nsample, const float *x,
+                                   const float *in_scale, const float *in_shift, const float *y,
+                                   const float *d_dense, const float *d_pooled, const unsigned char *arg,
+                                   const float *bn, const float *bwdc, float *dw_part, float *dw,
+                                   void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ISTNET_PW_H_ */

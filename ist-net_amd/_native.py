@@ -8,10 +8,12 @@ import re
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libistnet_pn2.so")
-HEADER_PATH = os.path.join(_HERE, "..", "include", "istnet_pn2.h")
+INCLUDE_DIR = os.path.join(_HERE, "..", "include")
+HEADER_PATH = os.path.join(INCLUDE_DIR, "istnet_pn2.h")
+HEADER_PATHS = [HEADER_PATH, os.path.join(INCLUDE_DIR, "istnet_pw.h")]
 ABI_VERSION = 1
 
-_i, _f, _p = ctypes.c_int, ctypes.c_float, ctypes.c_void_p
+_i, _f, _p, _d = ctypes.c_int, ctypes.c_float, ctypes.c_void_p, ctypes.c_double
 # name -> argtypes (restype is always int); mirrors include/istnet_pn2.h
 SIGNATURES = {
     "istnet_pn2_furthest_point_sampling": [_i, _i, _i, _p, _p, _p, _p],
@@ -23,16 +25,31 @@ SIGNATURES = {
     "istnet_pn2_three_nn": [_i, _i, _i, _p, _p, _p, _p, _p],
     "istnet_pn2_three_interpolate": [_i, _i, _i, _i, _p, _p, _p, _p, _p],
     "istnet_pn2_three_interpolate_grad": [_i, _i, _i, _i, _p, _p, _p, _p, _p],
+    # include/istnet_pw.h
+    "istnet_pw_tile_cfg": [_i, _i, _i],
+    "istnet_pw_wgrad_tile_cfg": [_i, _i],
+    "istnet_pw_stat_tiles": [_i, _i, _i],
+    "istnet_pw_forward": [_i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p],
+    "istnet_bn_finalize_fwd": [_i, _i, _d, _p, _p, _p, _p, _f, _f, _p, _p, _p, _p],
+    "istnet_bn_relu_pool": [_i, _i, _i, _i, _p, _p, _p, _p, _p],
+    "istnet_pw_bwd_stat_tiles": [_i, _i],
+    "istnet_pw_bwd_stats": [_i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p],
+    "istnet_bn_finalize_bwd": [_i, _i, _d, _i, _p, _p, _p, _p, _p, _p, _p, _p],
+    "istnet_pw_dgrad": [_i, _i, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p],
+    "istnet_pw_wgrad_splits": [_i, _i, _i, _i],
+    "istnet_pw_wgrad": [_i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p],
 }
 
 _lib = None
 
 
 def declared_symbols():
-    """Every function name declared in include/istnet_pn2.h."""
-    with open(HEADER_PATH) as fh:
-        text = fh.read()
-    return sorted(set(re.findall(r"\b(istnet_pn2_[a-z0-9_]+)\s*\(", text)))
+    """Every function name declared in include/*.h."""
+    names = set()
+    for path in HEADER_PATHS:
+        with open(path) as fh:
+            names.update(re.findall(r"ISTNET_PN2_API\s+[a-z ]+\*?\s*\*?(istnet_[a-z0-9_]+)\s*\(", fh.read()))
+    return sorted(names)
 
 
 def lib():
@@ -59,3 +76,22 @@ def lib():
 def check(status, what):
     if status != 0:
         raise RuntimeError(f"{what} failed with status {status} (hipError_t / ISTNET_PN2_EINVAL=100001)")
+
+
+# ---- optional per-launch timing (bench.py roofline leg) --------------------------------------
+# When TIMING is a list, call sites bracket their kernel launches with HIP events recorded on the
+# stream the kernel is launched on (torch's current stream) and append
+# (kernel_name, flops, algorithmic_bytes, start_event, end_event).
+TIMING = None
+
+
+def timed(name, flops, nbytes, launch):
+    if TIMING is None:
+        return launch()
+    import torch
+    start, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    start.record()
+    status = launch()
+    end.record()
+    TIMING.append((name, flops, nbytes, start, end))
+    return status

@@ -78,7 +78,10 @@ __device__ __forceinline__ unsigned wave_min_u32(unsigned v) {
 // i*THREADS + t), so a strict '>' scan per lane plus a (value max, tiekey min)
 // cross-lane reduction reproduces the reference winner exactly.
 __device__ __forceinline__ int tiekey_to_k(unsigned tk, int bs_log2, int nper) {
-  const unsigned slot_rev = tk / (unsigned)nper;
+  // nper is a power of two for every n <= 512 and for the usual 1024/2048/4096 clouds: shift, not divide
+  unsigned slot_rev;
+  if ((nper & (nper - 1)) == 0) slot_rev = tk >> (31 - __clz(nper));
+  else slot_rev = tk / (unsigned)nper;
   const unsigned row = tk - slot_rev * (unsigned)nper;
   const unsigned slot = bs_log2 ? (__brev(slot_rev) >> (32 - bs_log2)) : 0u;
   return (int)(slot + (row << bs_log2));
@@ -308,40 +311,85 @@ __global__ __launch_bounds__(256) void group_points_scalar_kernel(int c, int n, 
 }
 
 // ============================================================================
-// scatter-add family: rows of `dst_len` accumulated in LDS, one (cloud, channel)
-// row per loop step, written back once.  Used by group_points_grad
-// (group_points_gpu.cu:48-69), three_interpolate_grad (interpolate_gpu.cu:121-148)
-// and gather_points_grad (sampling_gpu.cu:39-52).
+// scatter-add family (group_points_grad, group_points_gpu.cu:48-69; three_interpolate_grad,
+// interpolate_gpu.cu:121-148; gather_points_grad, sampling_gpu.cu:39-52).
+// A workgroup owns CH channel rows of one cloud, accumulates them in LDS and writes them back
+// once: no global atomics, no pre-zeroed output.  Padded ball-query slots repeat the first hit,
+// so a group row is mostly runs of one index: each thread walks one group and flushes a run
+// with a single LDS atomic instead of nsample conflicting ones.
 // ============================================================================
 constexpr int kScatterThreads = 256;
+constexpr int kGroupGradCH = 4;
+constexpr int kInterpGradCH = 8;
 
-// mode 0: src (rows, P) , idx (P)          : dst[idx[p]] += src[p]
-// mode 1: src (rows, n) , idx/w (n,3)      : dst[idx[j,t]] += src[j] * w[j,t]
-template <int MODE>
-__global__ __launch_bounds__(kScatterThreads) void scatter_add_rows_kernel(
-    int c, int dst_len, int src_len, const float* __restrict__ src_all,
-    const int* __restrict__ idx_all, const float* __restrict__ w_all, float* __restrict__ dst_all) {
-  extern __shared__ __attribute__((aligned(16))) float acc[];  // [dst_len]
-  const int b = blockIdx.y, l = blockIdx.x;
-  const float* src = src_all + ((size_t)b * c + l) * src_len;
-  float* dst = dst_all + ((size_t)b * c + l) * dst_len;
-  const int idx_per = MODE == 0 ? 1 : 3;
-  const int* idx = idx_all + (size_t)b * src_len * idx_per;
-  const float* w = MODE == 0 ? nullptr : w_all + (size_t)b * src_len * 3;
-  for (int i = threadIdx.x; i < dst_len; i += kScatterThreads) acc[i] = 0.f;
+template <bool VEC4>
+__global__ __launch_bounds__(kScatterThreads) void group_grad_kernel(
+    int c, int n, int npoints, int nsample, const float* __restrict__ grad_out,
+    const int* __restrict__ idx_all, float* __restrict__ grad_points) {
+  extern __shared__ __attribute__((aligned(16))) float acc[];  // [CH][n]
+  const int b = blockIdx.y, c0 = blockIdx.x * kGroupGradCH;
+  const int nch = min(kGroupGradCH, c - c0);
+  for (int i = threadIdx.x; i < nch * n; i += kScatterThreads) acc[i] = 0.f;
   __syncthreads();
-  if (MODE == 0) {
-    for (int p = threadIdx.x; p < src_len; p += kScatterThreads) atomicAdd(&acc[idx[p]], src[p]);
-  } else {
-    for (int j = threadIdx.x; j < src_len; j += kScatterThreads) {
-      const float g = src[j];
-      atomicAdd(&acc[idx[3 * j + 0]], g * w[3 * j + 0]);
-      atomicAdd(&acc[idx[3 * j + 1]], g * w[3 * j + 1]);
-      atomicAdd(&acc[idx[3 * j + 2]], g * w[3 * j + 2]);
+  for (int j = threadIdx.x; j < npoints; j += kScatterThreads) {
+    const int* row = idx_all + ((size_t)b * npoints + j) * nsample;
+    for (int ch = 0; ch < nch; ++ch) {
+      const float* g = grad_out + (((size_t)b * c + c0 + ch) * npoints + j) * nsample;
+      float* a = acc + ch * n;
+      int cur = row[0];
+      float run = 0.f;
+      if (VEC4) {
+        for (int k = 0; k < nsample; k += 4) {
+          const int4 ii = *reinterpret_cast<const int4*>(row + k);
+          const float4 v = *reinterpret_cast<const float4*>(g + k);
+          if (ii.x != cur) { atomicAdd(&a[cur], run); cur = ii.x; run = 0.f; }
+          run += v.x;
+          if (ii.y != cur) { atomicAdd(&a[cur], run); cur = ii.y; run = 0.f; }
+          run += v.y;
+          if (ii.z != cur) { atomicAdd(&a[cur], run); cur = ii.z; run = 0.f; }
+          run += v.z;
+          if (ii.w != cur) { atomicAdd(&a[cur], run); cur = ii.w; run = 0.f; }
+          run += v.w;
+        }
+      } else {
+        for (int k = 0; k < nsample; ++k) {
+          const int ii = row[k];
+          if (ii != cur) { atomicAdd(&a[cur], run); cur = ii; run = 0.f; }
+          run += g[k];
+        }
+      }
+      atomicAdd(&a[cur], run);
     }
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < dst_len; i += kScatterThreads) dst[i] = acc[i];
+  for (int i = threadIdx.x; i < nch * n; i += kScatterThreads)
+    grad_points[((size_t)b * c + c0) * n + i] = acc[i];
+}
+
+__global__ __launch_bounds__(kScatterThreads) void interp_grad_kernel(
+    int c, int m, int n, const float* __restrict__ grad_out, const int* __restrict__ idx_all,
+    const float* __restrict__ w_all, float* __restrict__ grad_points) {
+  extern __shared__ __attribute__((aligned(16))) float acc[];  // [CH][m]
+  const int b = blockIdx.y, c0 = blockIdx.x * kInterpGradCH;
+  const int nch = min(kInterpGradCH, c - c0);
+  for (int i = threadIdx.x; i < nch * m; i += kScatterThreads) acc[i] = 0.f;
+  __syncthreads();
+  for (int j = threadIdx.x; j < n; j += kScatterThreads) {
+    const int* ix = idx_all + ((size_t)b * n + j) * 3;
+    const float* w = w_all + ((size_t)b * n + j) * 3;
+    const int i1 = ix[0], i2 = ix[1], i3 = ix[2];
+    const float w1 = w[0], w2 = w[1], w3 = w[2];
+    for (int ch = 0; ch < nch; ++ch) {
+      const float g = grad_out[((size_t)b * c + c0 + ch) * n + j];
+      float* a = acc + ch * m;
+      atomicAdd(&a[i1], g * w1);
+      atomicAdd(&a[i2], g * w2);
+      atomicAdd(&a[i3], g * w3);
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < nch * m; i += kScatterThreads)
+    grad_points[((size_t)b * c + c0) * m + i] = acc[i];
 }
 
 // Fallback when a destination row does not fit in LDS: zero + global atomics.
@@ -452,18 +500,37 @@ inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 constexpr int kMaxLdsRowBytes = 64 * 1024;
 
 template <int MODE>
-int launch_scatter_add(int b, int c, int dst_len, int src_len, const float* src, const int* idx,
-                       const float* w, float* dst, hipStream_t st) {
-  if ((size_t)dst_len * 4 <= (size_t)kMaxLdsRowBytes) {
-    hipLaunchKernelGGL(scatter_add_rows_kernel<MODE>, dim3(c, b), dim3(kScatterThreads),
-                       (size_t)dst_len * 4, st, c, dst_len, src_len, src, idx, w, dst);
-  } else {
-    const size_t count = (size_t)b * c * dst_len;
-    hipLaunchKernelGGL(fill_zero_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, st,
-                       count, dst);
-    hipLaunchKernelGGL(scatter_add_global_kernel<MODE>, dim3(ceil_div(src_len, 256), c, b),
-                       dim3(256), 0, st, c, dst_len, src_len, src, idx, w, dst);
-  }
+int launch_scatter_fallback(int b, int c, int dst_len, int src_len, const float* src, const int* idx,
+                            const float* w, float* dst, hipStream_t st) {
+  const size_t count = (size_t)b * c * dst_len;
+  hipLaunchKernelGGL(fill_zero_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, st, count, dst);
+  hipLaunchKernelGGL(scatter_add_global_kernel<MODE>, dim3(ceil_div(src_len, 256), c, b), dim3(256), 0,
+                     st, c, dst_len, src_len, src, idx, w, dst);
+  return (int)hipGetLastError();
+}
+
+int launch_group_grad(int b, int c, int n, int npoints, int nsample, const float* grad_out,
+                      const int* idx, float* grad_points, hipStream_t st) {
+  const size_t lds = (size_t)kGroupGradCH * n * 4;
+  if (lds > (size_t)kMaxLdsRowBytes)
+    return launch_scatter_fallback<0>(b, c, n, npoints * nsample, grad_out, idx, nullptr, grad_points, st);
+  const dim3 grid(ceil_div(c, kGroupGradCH), b);
+  if (nsample % 4 == 0)
+    hipLaunchKernelGGL(group_grad_kernel<true>, grid, dim3(kScatterThreads), lds, st, c, n, npoints, nsample,
+                       grad_out, idx, grad_points);
+  else
+    hipLaunchKernelGGL(group_grad_kernel<false>, grid, dim3(kScatterThreads), lds, st, c, n, npoints,
+                       nsample, grad_out, idx, grad_points);
+  return (int)hipGetLastError();
+}
+
+int launch_interp_grad(int b, int c, int n, int m, const float* grad_out, const int* idx, const float* w,
+                       float* grad_points, hipStream_t st) {
+  const size_t lds = (size_t)kInterpGradCH * m * 4;
+  if (lds > (size_t)kMaxLdsRowBytes)
+    return launch_scatter_fallback<1>(b, c, m, n, grad_out, idx, w, grad_points, st);
+  hipLaunchKernelGGL(interp_grad_kernel, dim3(ceil_div(c, kInterpGradCH), b), dim3(kScatterThreads), lds, st,
+                     c, m, n, grad_out, idx, w, grad_points);
   return (int)hipGetLastError();
 }
 
@@ -522,8 +589,7 @@ int istnet_pn2_gather_points_grad(int b, int c, int n, int npoints, const float*
                                   const int* idx, float* grad_points, void* stream) {
   if (b < 0 || c < 0 || n <= 0 || npoints < 0) return ISTNET_PN2_EINVAL;
   if (b == 0 || c == 0) return 0;
-  return launch_scatter_add<0>(b, c, n, npoints, grad_out, idx, nullptr, grad_points,
-                               as_stream(stream));
+  return launch_group_grad(b, c, n, npoints, 1, grad_out, idx, grad_points, as_stream(stream));
 }
 
 int istnet_pn2_query_ball_point(int b, int n, int m, float radius, int nsample,
@@ -565,8 +631,8 @@ int istnet_pn2_group_points_grad(int b, int c, int n, int npoints, int nsample,
                                  void* stream) {
   if (b < 0 || c < 0 || n <= 0 || npoints < 0 || nsample < 0) return ISTNET_PN2_EINVAL;
   if (b == 0 || c == 0) return 0;
-  return launch_scatter_add<0>(b, c, n, npoints * nsample, grad_out, idx, nullptr, grad_points,
-                               as_stream(stream));
+  if (npoints == 0 || nsample == 0) return launch_group_grad(b, c, n, 0, 1, grad_out, idx, grad_points, as_stream(stream));
+  return launch_group_grad(b, c, n, npoints, nsample, grad_out, idx, grad_points, as_stream(stream));
 }
 
 int istnet_pn2_three_nn(int b, int n, int m, const float* unknown, const float* known, float* dist2,
@@ -592,7 +658,7 @@ int istnet_pn2_three_interpolate_grad(int b, int c, int n, int m, const float* g
                                       void* stream) {
   if (b < 0 || c < 0 || m <= 0 || n < 0) return ISTNET_PN2_EINVAL;
   if (b == 0 || c == 0) return 0;
-  return launch_scatter_add<1>(b, c, m, n, grad_out, idx, weight, grad_points, as_stream(stream));
+  return launch_interp_grad(b, c, n, m, grad_out, idx, weight, grad_points, as_stream(stream));
 }
 
 }  // extern "C"

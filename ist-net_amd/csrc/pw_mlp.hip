@@ -1,0 +1,819 @@
+// pw_mlp.hip -- fused per-point MLP ("SharedMLP") kernels for gfx950, fp32 MFMA.
+//
+// A SharedMLP layer of the reference (model/pointnet2/pytorch_utils.py:25-50,80-134) is
+//     Conv2d 1x1 (no bias) -> BatchNorm2d -> ReLU          over (B, C, npoint, nsample)
+// executed there as >=6 full passes over the activation per layer (cuDNN conv, BN statistics,
+// BN apply, ReLU, plus layout transposes) and a separate max_pool2d.  Here a layer is ONE GEMM
+// kernel on the raw (pre-BN) activations, with the previous layer's BN+ReLU applied while the
+// operand is staged into LDS and this layer's BN statistics reduced in the epilogue:
+//
+//   forward   Y_l[b] = W_l . act(Y_{l-1}[b])            act(v) = relu(v*scale + shift)
+//   backward  dY_l formed on the fly from (dA_l | pooled grad, Y_l, BN constants), then
+//             dA_{l-1}[b] = W_l^T . dY_l[b]   (dgrad)   and   dW_l = sum_b dY_l[b] . act(Y_{l-1}[b])^T (wgrad)
+//
+// Every activation is written once and read once per direction; normalised / ReLU'd copies and
+// the dense gradient of the max-pool never exist in memory.
+//
+// GEMM core: v_mfma_f32_32x32x2_f32 (exact f32, 157 TF peak -- the only way to keep the 1e-4 fp32
+// parity bar; there is no TF32 on gfx950).  Layout is the reference's (B, C, P) with P contiguous,
+// so the point dimension is the MFMA N dimension: B fragments (lane -> 32 consecutive points of one
+// channel) and D stores are 128-byte coalesced runs, A fragments are the weights.  Both LDS tiles
+// are k-major ([k][m], [k][n]) so every fragment read is a conflict-free ds_read_b32.
+// 256 threads = 4 waves per workgroup, LDS double-buffered, global loads for chunk t+1 in flight
+// during the MFMAs of chunk t (register staging, one barrier per chunk).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/istnet_pw.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int kThreads = 256;
+constexpr int kKT = 16;    // K chunk of the fwd / dgrad GEMMs (channels)
+constexpr int kKTW = 32;   // K chunk of the wgrad GEMM (points)
+
+__device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
+__device__ __forceinline__ int wave_id() { return threadIdx.x >> 6; }
+
+// sum over the 32 lanes of each half-wave; valid in lane 31 (lower half) and lane 63 (upper half)
+template <int CTRL, int ROW_MASK = 0xf>
+__device__ __forceinline__ float dpp_f(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xf, false));
+}
+__device__ __forceinline__ float half_wave_sum(float v) {
+  v += dpp_f<0x111>(v);         // row_shr:1
+  v += dpp_f<0x112>(v);         // row_shr:2
+  v += dpp_f<0x114>(v);         // row_shr:4
+  v += dpp_f<0x118>(v);         // row_shr:8
+  v += dpp_f<0x142, 0xa>(v);    // row_bcast:15 -> lanes 31 / 63 hold the 32-lane sums
+  return v;
+}
+__device__ __forceinline__ float wave_sum(float v) {
+  v = half_wave_sum(v);
+  v += dpp_f<0x143, 0xc>(v);    // row_bcast:31 -> lane 63 holds the wave sum
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+
+// MFMA C/D layout of v_mfma_f32_32x32x2_f32: reg r of lane l holds row (r&3)+8*(r>>2)+4*(l>>5), col l&31.
+__device__ __forceinline__ int mfma_row(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
+
+template <int M_T, int N_T, int WM, int WN>
+struct Tile {
+  static constexpr int TM = M_T / (32 * WM);
+  static constexpr int TN = N_T / (32 * WN);
+  static_assert(WM * WN == 4 && TM >= 1 && TN >= 1, "4 waves per workgroup");
+};
+
+// One K chunk of MFMAs from k-major LDS tiles.  a_lds: [KT][LDA], b_lds: [KT][LDB].
+template <int KT, int TM, int TN, int LDA, int LDB>
+__device__ __forceinline__ void mma_chunk(const float* a_lds, const float* b_lds, int a_col0, int b_col0,
+                                          f32x16 (&acc)[TM][TN]) {
+  const int lane = lane_id();
+  const int kh = lane >> 5, c = lane & 31;
+#pragma unroll
+  for (int kk = 0; kk < KT / 2; ++kk) {
+    float a[TM], b[TN];
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm) a[tm] = a_lds[(2 * kk + kh) * LDA + a_col0 + tm * 32 + c];
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) b[tn] = b_lds[(2 * kk + kh) * LDB + b_col0 + tn * 32 + c];
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+      for (int tn = 0; tn < TN; ++tn)
+        acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tm], b[tn], acc[tm][tn], 0, 0, 0);
+  }
+}
+
+// ============================================================================================
+// forward:  y[b][co][p] = sum_ci wt[ci][co] * act(x[b][ci][p]),  optional BN-statistics partials
+// ============================================================================================
+template <int M_T, int N_T, int WM, int WN>
+__global__ __launch_bounds__(kThreads) void pw_fwd_kernel(
+    int cin, int cout, int P, int tiles_per_cloud, const float* __restrict__ x,
+    const float* __restrict__ wt, const float* __restrict__ in_scale, const float* __restrict__ in_shift,
+    float* __restrict__ y, float* __restrict__ part_sum, float* __restrict__ part_sq, int nt_total) {
+  using T = Tile<M_T, N_T, WM, WN>;
+  constexpr int TM = T::TM, TN = T::TN;
+  constexpr int NA = kKT * M_T / kThreads;        // scalar weight loads per thread per chunk
+  constexpr int NB = kKT * N_T / 4 / kThreads;    // float4 activation loads per thread per chunk
+  static_assert(NA >= 1 && NB >= 1, "tile too small for 256 threads");
+  __shared__ __attribute__((aligned(16))) float As[2][kKT][M_T];
+  __shared__ __attribute__((aligned(16))) float Bs[2][kKT][N_T];
+
+  const int tid = threadIdx.x;
+  const int b = blockIdx.x / tiles_per_cloud;
+  const int p0 = (blockIdx.x - b * tiles_per_cloud) * N_T;
+  const int m0 = blockIdx.y * M_T;
+  const float* xb = x + (size_t)b * cin * P;
+  const bool has_bn = in_scale != nullptr;
+
+  float areg[NA];
+  float4 breg[NB];
+  auto load_chunk = [&](int k0) {
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+      const int e = tid + kThreads * i;
+      const int k = k0 + e / M_T, m = m0 + e % M_T;
+      areg[i] = (k < cin && m < cout) ? wt[(size_t)k * cout + m] : 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+      const int e = tid + kThreads * i;
+      const int k = k0 + e / (N_T / 4), p = p0 + (e % (N_T / 4)) * 4;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (k < cin && p < P) {
+        v = *reinterpret_cast<const float4*>(xb + (size_t)k * P + p);
+        if (has_bn) {
+          const float s = in_scale[k], h = in_shift[k];
+          v.x = fmaxf(v.x * s + h, 0.f); v.y = fmaxf(v.y * s + h, 0.f);
+          v.z = fmaxf(v.z * s + h, 0.f); v.w = fmaxf(v.w * s + h, 0.f);
+        }
+      }
+      breg[i] = v;
+    }
+  };
+  auto store_chunk = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+      const int e = tid + kThreads * i;
+      As[buf][e / M_T][e % M_T] = areg[i];
+    }
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+      const int e = tid + kThreads * i;
+      *reinterpret_cast<float4*>(&Bs[buf][e / (N_T / 4)][(e % (N_T / 4)) * 4]) = breg[i];
+    }
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[tm][tn][r] = 0.f;
+
+  const int w = wave_id();
+  const int a_col0 = (w / WN) * TM * 32, b_col0 = (w % WN) * TN * 32;
+  const int nchunks = (cin + kKT - 1) / kKT;
+  load_chunk(0);
+  store_chunk(0);
+  __syncthreads();
+  for (int t = 0; t < nchunks; ++t) {
+    const int buf = t & 1;
+    if (t + 1 < nchunks) load_chunk((t + 1) * kKT);
+    mma_chunk<kKT, TM, TN, M_T, N_T>(&As[buf][0][0], &Bs[buf][0][0], a_col0, b_col0, acc);
+    if (t + 1 < nchunks) store_chunk(buf ^ 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue: store raw y, reduce per-channel sum / sum of squares of this tile ------------
+  const int lane = lane_id();
+  float* yb = y + (size_t)b * cout * P;
+  float* red = &As[0][0][0];  // reuse LDS: [WN][M_T][2]
+#pragma unroll
+  for (int tm = 0; tm < TM; ++tm) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row_l = a_col0 + tm * 32 + mfma_row(r, lane);
+      const int row = m0 + row_l;
+      float s = 0.f, q = 0.f;
+#pragma unroll
+      for (int tn = 0; tn < TN; ++tn) {
+        const int col = p0 + b_col0 + tn * 32 + (lane & 31);
+        const float v = acc[tm][tn][r];
+        if (row < cout && col < P) {
+          yb[(size_t)row * P + col] = v;
+          s += v;
+          q += v * v;
+        }
+      }
+      if (part_sum != nullptr) {
+        s = half_wave_sum(s);
+        q = half_wave_sum(q);
+        if ((lane & 31) == 31) {
+          red[((w % WN) * M_T + row_l) * 2 + 0] = s;
+          red[((w % WN) * M_T + row_l) * 2 + 1] = q;
+        }
+      }
+    }
+  }
+  if (part_sum != nullptr) {
+    __syncthreads();
+    for (int rl = tid; rl < M_T; rl += kThreads) {
+      const int row = m0 + rl;
+      if (row < cout) {
+        float s = 0.f, q = 0.f;
+#pragma unroll
+        for (int wn = 0; wn < WN; ++wn) { s += red[(wn * M_T + rl) * 2 + 0]; q += red[(wn * M_T + rl) * 2 + 1]; }
+        part_sum[(size_t)row * nt_total + blockIdx.x] = s;
+        part_sq[(size_t)row * nt_total + blockIdx.x] = q;
+      }
+    }
+  }
+}
+
+// ============================================================================================
+// BN finalize (forward): partials -> mean / invstd / scale / shift, running statistics update
+// ============================================================================================
+// out: bn[0]=scale, bn[1]=shift, bn[2]=mean, bn[3]=invstd   (each [C])
+__global__ __launch_bounds__(64) void bn_finalize_fwd_kernel(
+    int C, int nt, double count, const float* __restrict__ part_sum, const float* __restrict__ part_sq,
+    const float* __restrict__ gamma, const float* __restrict__ beta, float eps, float momentum,
+    float* __restrict__ running_mean, float* __restrict__ running_var, float* __restrict__ bn) {
+  const int c = blockIdx.x;
+  double s = 0.0, q = 0.0;
+  for (int i = threadIdx.x; i < nt; i += 64) {
+    s += (double)part_sum[(size_t)c * nt + i];
+    q += (double)part_sq[(size_t)c * nt + i];
+  }
+  for (int off = 32; off >= 1; off >>= 1) {
+    s += __shfl_xor(s, off);
+    q += __shfl_xor(q, off);
+  }
+  if (threadIdx.x == 0) {
+    const double mean = s / count;
+    double var = q / count - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const float istd = (float)(1.0 / sqrt(var + (double)eps));
+    const float sc = gamma[c] * istd;
+    bn[0 * C + c] = sc;
+    bn[1 * C + c] = beta[c] - (float)mean * sc;
+    bn[2 * C + c] = (float)mean;
+    bn[3 * C + c] = istd;
+    if (running_mean != nullptr) {
+      const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
+      running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
+      running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
+    }
+  }
+}
+
+// ============================================================================================
+// BN + ReLU + max over nsample  (forward tail of an SA scale), nsample == 1 -> plain BN+ReLU
+// ============================================================================================
+// y (B*C, G, S) raw, out (B*C, G), arg (B*C, G) uint8 index of the first maximum
+template <int S4>  // S = 4*S4 samples per group, one thread per group
+__global__ __launch_bounds__(256) void bn_relu_pool_kernel(int C, int G, const float* __restrict__ y,
+                                                           const float* __restrict__ scale,
+                                                           const float* __restrict__ shift,
+                                                           float* __restrict__ out,
+                                                           uint8_t* __restrict__ arg) {
+  const int bc = blockIdx.y;
+  const int g = blockIdx.x * 256 + threadIdx.x;
+  if (g >= G) return;
+  const float s = scale[bc % C], h = shift[bc % C];
+  const float4* src = reinterpret_cast<const float4*>(y + ((size_t)bc * G + g) * (S4 * 4));
+  float best = -1.f;  // relu output is >= 0, so the first element always replaces this
+  int besti = 0;
+#pragma unroll
+  for (int i = 0; i < S4; ++i) {
+    const float4 v = src[i];
+    const float a0 = fmaxf(v.x * s + h, 0.f), a1 = fmaxf(v.y * s + h, 0.f);
+    const float a2 = fmaxf(v.z * s + h, 0.f), a3 = fmaxf(v.w * s + h, 0.f);
+    if (a0 > best) { best = a0; besti = 4 * i + 0; }
+    if (a1 > best) { best = a1; besti = 4 * i + 1; }
+    if (a2 > best) { best = a2; besti = 4 * i + 2; }
+    if (a3 > best) { best = a3; besti = 4 * i + 3; }
+  }
+  out[(size_t)bc * G + g] = best;
+  arg[(size_t)bc * G + g] = (uint8_t)besti;
+}
+__global__ __launch_bounds__(256) void bn_relu_apply_kernel(int C, int P4, const float* __restrict__ y,
+                                                            const float* __restrict__ scale,
+                                                            const float* __restrict__ shift,
+                                                            float* __restrict__ out) {
+  const int bc = blockIdx.y;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= P4) return;
+  const float s = scale[bc % C], h = shift[bc % C];
+  float4 v = reinterpret_cast<const float4*>(y + (size_t)bc * P4 * 4)[i];
+  v.x = fmaxf(v.x * s + h, 0.f); v.y = fmaxf(v.y * s + h, 0.f);
+  v.z = fmaxf(v.z * s + h, 0.f); v.w = fmaxf(v.w * s + h, 0.f);
+  reinterpret_cast<float4*>(out + (size_t)bc * P4 * 4)[i] = v;
+}
+
+// ============================================================================================
+// backward helpers: gradient w.r.t. the BN output,  g = dA * [relu active]
+//   dense : dA (B, C, P)
+//   pooled: dO (B, C, G) + arg (B, C, G): dA[p] = dO[p / S] if p % S == arg[p / S] else 0
+// ============================================================================================
+struct GradSrc {
+  const float* dense;    // (B*C, P) or null
+  const float* pooled;   // (B*C, G) or null
+  const uint8_t* arg;    // (B*C, G)
+  int S;                 // nsample (pooled mode)
+};
+__device__ __forceinline__ float4 load_grad4(const GradSrc& gs, size_t row, int P, int p) {
+  if (gs.dense != nullptr) return *reinterpret_cast<const float4*>(gs.dense + row * (size_t)P + p);
+  // pooled: the 4 consecutive points p..p+3 lie in one group when S % 4 == 0
+  const int G = P / gs.S;
+  const int g = p / gs.S, k = p - g * gs.S;
+  const float d = gs.pooled[row * (size_t)G + g];
+  const int a = gs.arg[row * (size_t)G + g];
+  return make_float4(a == k ? d : 0.f, a == k + 1 ? d : 0.f, a == k + 2 ? d : 0.f, a == k + 3 ? d : 0.f);
+}
+
+// per-channel partial sums of g and g * y  (-> dbeta, dgamma after finalize)
+// grid: (chunks_per_row, C, B); partials [C][B*chunks]
+constexpr int kStatChunk = 4096;
+__global__ __launch_bounds__(256) void pw_bwd_stats_kernel(int C, int P, GradSrc gs,
+                                                           const float* __restrict__ y,
+                                                           const float* __restrict__ scale,
+                                                           const float* __restrict__ shift,
+                                                           float* __restrict__ part_g,
+                                                           float* __restrict__ part_gy, int nt_total) {
+  const int c = blockIdx.y, b = blockIdx.z;
+  const size_t row = (size_t)b * C + c;
+  const float s = scale[c], h = shift[c];
+  const int pbeg = blockIdx.x * kStatChunk;
+  const int pend = min(pbeg + kStatChunk, P);
+  float sg = 0.f, sgy = 0.f;
+  for (int p = pbeg + threadIdx.x * 4; p < pend; p += 256 * 4) {
+    const float4 v = *reinterpret_cast<const float4*>(y + row * (size_t)P + p);
+    const float4 d = load_grad4(gs, row, P, p);
+    const float g0 = (v.x * s + h > 0.f) ? d.x : 0.f, g1 = (v.y * s + h > 0.f) ? d.y : 0.f;
+    const float g2 = (v.z * s + h > 0.f) ? d.z : 0.f, g3 = (v.w * s + h > 0.f) ? d.w : 0.f;
+    sg += (g0 + g1) + (g2 + g3);
+    sgy += (g0 * v.x + g1 * v.y) + (g2 * v.z + g3 * v.w);
+  }
+  __shared__ float red[4][2];
+  sg = wave_sum(sg);
+  sgy = wave_sum(sgy);
+  if (lane_id() == 0) { red[wave_id()][0] = sg; red[wave_id()][1] = sgy; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const int t = b * gridDim.x + blockIdx.x;
+    part_g[(size_t)c * nt_total + t] = (red[0][0] + red[1][0]) + (red[2][0] + red[3][0]);
+    part_gy[(size_t)c * nt_total + t] = (red[0][1] + red[1][1]) + (red[2][1] + red[3][1]);
+  }
+}
+
+// finalize: dbeta = sum g, dgamma = sum g*yhat; constants for dY = ca*g + cb + cc*y
+// bn: [4][C] from the forward (scale, shift, mean, invstd); bwdc: [3][C] = ca, cb, cc
+__global__ __launch_bounds__(64) void bn_finalize_bwd_kernel(int C, int nt, double count, int training,
+                                                             const float* __restrict__ part_g,
+                                                             const float* __restrict__ part_gy,
+                                                             const float* __restrict__ gamma,
+                                                             const float* __restrict__ bn,
+                                                             float* __restrict__ dgamma,
+                                                             float* __restrict__ dbeta,
+                                                             float* __restrict__ bwdc) {
+  const int c = blockIdx.x;
+  double sg = 0.0, sgy = 0.0;
+  for (int i = threadIdx.x; i < nt; i += 64) {
+    sg += (double)part_g[(size_t)c * nt + i];
+    sgy += (double)part_gy[(size_t)c * nt + i];
+  }
+  for (int off = 32; off >= 1; off >>= 1) {
+    sg += __shfl_xor(sg, off);
+    sgy += __shfl_xor(sgy, off);
+  }
+  if (threadIdx.x == 0) {
+    const double mean = bn[2 * C + c], istd = bn[3 * C + c];
+    const double dg = (sgy - mean * sg) * istd;  // sum g * (y - mean) * istd
+    dgamma[c] = (float)dg;
+    dbeta[c] = (float)sg;
+    const double gsc = (double)gamma[c] * istd;
+    if (training) {
+      const double c1 = sg / count, c2 = dg / count;
+      bwdc[0 * C + c] = (float)gsc;
+      bwdc[1 * C + c] = (float)(-gsc * c1 + gsc * mean * istd * c2);
+      bwdc[2 * C + c] = (float)(-gsc * istd * c2);
+    } else {  // eval-mode BN is a fixed affine map
+      bwdc[0 * C + c] = (float)gsc;
+      bwdc[1 * C + c] = 0.f;
+      bwdc[2 * C + c] = 0.f;
+    }
+  }
+}
+
+// dY for 4 consecutive points of channel k
+__device__ __forceinline__ float4 make_dy4(const GradSrc& gs, const float* __restrict__ y, size_t row, int P,
+                                           int p, float s, float h, float ca, float cb, float cc) {
+  const float4 v = *reinterpret_cast<const float4*>(y + row * (size_t)P + p);
+  const float4 d = load_grad4(gs, row, P, p);
+  float4 o;
+  o.x = ca * ((v.x * s + h > 0.f) ? d.x : 0.f) + cb + cc * v.x;
+  o.y = ca * ((v.y * s + h > 0.f) ? d.y : 0.f) + cb + cc * v.y;
+  o.z = ca * ((v.z * s + h > 0.f) ? d.z : 0.f) + cb + cc * v.z;
+  o.w = ca * ((v.w * s + h > 0.f) ? d.w : 0.f) + cb + cc * v.w;
+  return o;
+}
+
+// ============================================================================================
+// dgrad:  dx[b][m][p] = sum_co w[co][ci_off + m] * dY[b][co][p]
+// ============================================================================================
+template <int M_T, int N_T, int WM, int WN>
+__global__ __launch_bounds__(kThreads) void pw_dgrad_kernel(
+    int cin_total, int ci_off, int m_rows, int cout, int P, int tiles_per_cloud,
+    const float* __restrict__ w, const float* __restrict__ y, GradSrc gs, const float* __restrict__ bn,
+    const float* __restrict__ bwdc, float* __restrict__ dx) {
+  using T = Tile<M_T, N_T, WM, WN>;
+  constexpr int TM = T::TM, TN = T::TN;
+  constexpr int NA = kKT * M_T / kThreads;
+  constexpr int NB = kKT * N_T / 4 / kThreads;
+  __shared__ __attribute__((aligned(16))) float As[2][kKT][M_T];
+  __shared__ __attribute__((aligned(16))) float Bs[2][kKT][N_T];
+
+  const int tid = threadIdx.x;
+  const int b = blockIdx.x / tiles_per_cloud;
+  const int p0 = (blockIdx.x - b * tiles_per_cloud) * N_T;
+  const int m0 = blockIdx.y * M_T;
+  const float* scale = bn;
+  const float* shift = bn + cout;
+  const float* ca = bwdc;
+  const float* cb = bwdc + cout;
+  const float* cc = bwdc + 2 * cout;
+
+  float areg[NA];
+  float4 breg[NB];
+  auto load_chunk = [&](int k0) {
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+      const int e = tid + kThreads * i;
+      const int k = k0 + e / M_T, m = m0 + e % M_T;
+      areg[i] = (k < cout && m < m_rows) ? w[(size_t)k * cin_total + ci_off + m] : 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+      const int e = tid + kThreads * i;
+      const int k = k0 + e / (N_T / 4), p = p0 + (e % (N_T / 4)) * 4;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (k < cout && p < P)
+        v = make_dy4(gs, y, (size_t)b * cout + k, P, p, scale[k], shift[k], ca[k], cb[k], cc[k]);
+      breg[i] = v;
+    }
+  };
+  auto store_chunk = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+      const int e = tid + kThreads * i;
+      As[buf][e / M_T][e % M_T] = areg[i];
+    }
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+      const int e = tid + kThreads * i;
+      *reinterpret_cast<float4*>(&Bs[buf][e / (N_T / 4)][(e % (N_T / 4)) * 4]) = breg[i];
+    }
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[tm][tn][r] = 0.f;
+
+  const int wv = wave_id();
+  const int a_col0 = (wv / WN) * TM * 32, b_col0 = (wv % WN) * TN * 32;
+  const int nchunks = (cout + kKT - 1) / kKT;
+  load_chunk(0);
+  store_chunk(0);
+  __syncthreads();
+  for (int t = 0; t < nchunks; ++t) {
+    const int buf = t & 1;
+    if (t + 1 < nchunks) load_chunk((t + 1) * kKT);
+    mma_chunk<kKT, TM, TN, M_T, N_T>(&As[buf][0][0], &Bs[buf][0][0], a_col0, b_col0, acc);
+    if (t + 1 < nchunks) store_chunk(buf ^ 1);
+    __syncthreads();
+  }
+  const int lane = lane_id();
+  float* dxb = dx + (size_t)b * m_rows * P;
+#pragma unroll
+  for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = m0 + a_col0 + tm * 32 + mfma_row(r, lane);
+#pragma unroll
+      for (int tn = 0; tn < TN; ++tn) {
+        const int col = p0 + b_col0 + tn * 32 + (lane & 31);
+        if (row < m_rows && col < P) dxb[(size_t)row * P + col] = acc[tm][tn][r];
+      }
+    }
+}
+
+// ============================================================================================
+// wgrad:  dWpart[split][co][ci] = sum_{p in split} dY[b][co][p] * act(x[b][ci][p])
+// ============================================================================================
+// grid: (splits_per_cloud * B, ceil(cout / M_T), ceil(cin / N_T)); K = points of one split
+template <int M_T, int N_T, int WM, int WN>
+__global__ __launch_bounds__(kThreads) void pw_wgrad_kernel(
+    int cin, int cout, int P, int splits_per_cloud, int split_len, const float* __restrict__ x,
+    const float* __restrict__ in_scale, const float* __restrict__ in_shift, const float* __restrict__ y,
+    GradSrc gs, const float* __restrict__ bn, const float* __restrict__ bwdc, float* __restrict__ dw_part) {
+  using T = Tile<M_T, N_T, WM, WN>;
+  constexpr int TM = T::TM, TN = T::TN;
+  constexpr int LDA = M_T + 1, LDB = N_T + 1;  // odd leading dims: transposed scalar writes spread over banks
+  constexpr int NA = M_T * kKTW / 4 / kThreads;  // float4 (along p) per thread per chunk
+  constexpr int NB = N_T * kKTW / 4 / kThreads;
+  static_assert(NA >= 1 && NB >= 1, "tile too small");
+  __shared__ float As[2][kKTW][LDA];
+  __shared__ float Bs[2][kKTW][LDB];
+
+  const int tid = threadIdx.x;
+  const int b = blockIdx.x / splits_per_cloud;
+  const int sp = blockIdx.x - b * splits_per_cloud;
+  const int pbeg = sp * split_len;
+  const int pend = min(pbeg + split_len, P);
+  const int m0 = blockIdx.y * M_T, n0 = blockIdx.z * N_T;
+  const float* scale = bn;
+  const float* shift = bn + cout;
+  const float* ca = bwdc;
+  const float* cb = bwdc + cout;
+  const float* cc = bwdc + 2 * cout;
+  const bool has_bn = in_scale != nullptr;
+
+  float4 areg[NA], breg[NB];
+  auto load_chunk = [&](int pk) {
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+      const int e = tid + kThreads * i;
+      const int m = m0 + e / (kKTW / 4), p = pk + (e % (kKTW / 4)) * 4;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (m < cout && p < pend)
+        v = make_dy4(gs, y, (size_t)b * cout + m, P, p, scale[m], shift[m], ca[m], cb[m], cc[m]);
+      areg[i] = v;
+    }
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+      const int e = tid + kThreads * i;
+      const int n = n0 + e / (kKTW / 4), p = pk + (e % (kKTW / 4)) * 4;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (n < cin && p < pend) {
+        v = *reinterpret_cast<const float4*>(x + ((size_t)b * cin + n) * P + p);
+        if (has_bn) {
+          const float s = in_scale[n], h = in_shift[n];
+          v.x = fmaxf(v.x * s + h, 0.f); v.y = fmaxf(v.y * s + h, 0.f);
+          v.z = fmaxf(v.z * s + h, 0.f); v.w = fmaxf(v.w * s + h, 0.f);
+        }
+      }
+      breg[i] = v;
+    }
+  };
+  auto store_chunk = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+      const int e = tid + kThreads * i;
+      const int m = e / (kKTW / 4), k = (e % (kKTW / 4)) * 4;
+      As[buf][k + 0][m] = areg[i].x; As[buf][k + 1][m] = areg[i].y;
+      As[buf][k + 2][m] = areg[i].z; As[buf][k + 3][m] = areg[i].w;
+    }
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+      const int e = tid + kThreads * i;
+      const int n = e / (kKTW / 4), k = (e % (kKTW / 4)) * 4;
+      Bs[buf][k + 0][n] = breg[i].x; Bs[buf][k + 1][n] = breg[i].y;
+      Bs[buf][k + 2][n] = breg[i].z; Bs[buf][k + 3][n] = breg[i].w;
+    }
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[tm][tn][r] = 0.f;
+
+  const int wv = wave_id();
+  const int a_col0 = (wv / WN) * TM * 32, b_col0 = (wv % WN) * TN * 32;
+  const int nchunks = (pend - pbeg + kKTW - 1) / kKTW;
+  if (nchunks > 0) {
+    load_chunk(pbeg);
+    store_chunk(0);
+  }
+  __syncthreads();
+  for (int t = 0; t < nchunks; ++t) {
+    const int buf = t & 1;
+    if (t + 1 < nchunks) load_chunk(pbeg + (t + 1) * kKTW);
+    mma_chunk<kKTW, TM, TN, LDA, LDB>(&As[buf][0][0], &Bs[buf][0][0], a_col0, b_col0, acc);
+    if (t + 1 < nchunks) store_chunk(buf ^ 1);
+    __syncthreads();
+  }
+  const int lane = lane_id();
+  float* out = dw_part + (size_t)blockIdx.x * cout * cin;
+#pragma unroll
+  for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = m0 + a_col0 + tm * 32 + mfma_row(r, lane);
+#pragma unroll
+      for (int tn = 0; tn < TN; ++tn) {
+        const int col = n0 + b_col0 + tn * 32 + (lane & 31);
+        if (row < cout && col < cin) out[(size_t)row * cin + col] = acc[tm][tn][r];
+      }
+    }
+}
+
+// dw[i] = sum_s dw_part[s][i]: 16 elements x 16 split groups per workgroup, fixed reduction order
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(int count, int splits, const float* __restrict__ part,
+                                                           float* __restrict__ dw) {
+  __shared__ float red[16][17];
+  const int el = threadIdx.x & 15, sg = threadIdx.x >> 4;
+  const int i = blockIdx.x * 16 + el;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  if (i < count) {
+    int k = sg;
+    for (; k + 48 < splits; k += 64) {
+      s0 += part[(size_t)k * count + i];
+      s1 += part[(size_t)(k + 16) * count + i];
+      s2 += part[(size_t)(k + 32) * count + i];
+      s3 += part[(size_t)(k + 48) * count + i];
+    }
+    for (; k < splits; k += 16) s0 += part[(size_t)k * count + i];
+  }
+  red[sg][el] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (threadIdx.x < 16 && i < count) {
+    float s = 0.f;
+#pragma unroll
+    for (int g = 0; g < 16; ++g) s += red[g][el];
+    dw[i] = s;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
+inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+
+// tile selection shared by the forward launch and istnet_pw_stat_tiles()
+enum TileCfg { kCfg128x128, kCfg64x128, kCfg64x64, kCfg32x256 };
+inline TileCfg pick_cfg(int b, int m, int P) {
+  if (m <= 32) return kCfg32x256;
+  const long long n128 = (long long)b * ceil_div(P, 128);
+  if (m > 64 && n128 * ceil_div(m, 128) >= 256) return kCfg128x128;
+  if (n128 * ceil_div(m, 64) >= 256) return kCfg64x128;
+  return kCfg64x64;
+}
+inline int cfg_nt(TileCfg c) { return c == kCfg32x256 ? 256 : (c == kCfg64x64 ? 64 : 128); }
+inline int cfg_mt(TileCfg c) { return c == kCfg128x128 ? 128 : (c == kCfg32x256 ? 32 : 64); }
+
+inline int wgrad_mt(int cout) { return cout >= 128 ? 128 : 64; }
+inline int wgrad_nt(int cin) { return cin >= 96 ? 128 : 64; }
+inline int wgrad_split_len(int b, int cin, int cout, int P) {
+  // aim for ~1024 workgroups in total, split length a multiple of the K chunk
+  const long long tiles = (long long)ceil_div(cout, wgrad_mt(cout)) * ceil_div(cin, wgrad_nt(cin));
+  long long want = (1024 + tiles * b - 1) / (tiles * b);  // splits per cloud
+  if (want < 1) want = 1;
+  int len = ceil_div(P, (int)want);
+  len = ceil_div(len, kKTW) * kKTW;
+  if (len < 4 * kKTW) len = 4 * kKTW;
+  return len;
+}
+
+}  // namespace
+
+extern "C" {
+
+int istnet_pw_tile_cfg(int b, int m, int p) {
+  const TileCfg c = pick_cfg(b, m, p);
+  return cfg_mt(c) * 1000 + cfg_nt(c);  // e.g. 128128, 64128, 64064, 32256
+}
+
+int istnet_pw_wgrad_tile_cfg(int cin, int cout) { return wgrad_mt(cout) * 1000 + wgrad_nt(cin); }
+
+int istnet_pw_stat_tiles(int b, int cout, int p) {
+  return b * ceil_div(p, cfg_nt(pick_cfg(b, cout, p)));
+}
+
+int istnet_pw_forward(int b, int cin, int cout, int p, const float* x, const float* wt,
+                      const float* in_scale, const float* in_shift, float* y, float* part_sum,
+                      float* part_sq, void* stream) {
+  if (b <= 0 || cin <= 0 || cout <= 0 || p <= 0 || (p & 3)) return ISTNET_PN2_EINVAL;
+  const TileCfg cfg = pick_cfg(b, cout, p);
+  const int tpc = ceil_div(p, cfg_nt(cfg));
+  const dim3 grid(tpc * b, ceil_div(cout, cfg_mt(cfg)));
+  const int nt = tpc * b;
+#define ISTNET_FWD(MT, NT, WM, WN)                                                                        \
+  hipLaunchKernelGGL((pw_fwd_kernel<MT, NT, WM, WN>), grid, dim3(kThreads), 0, as_stream(stream), cin,    \
+                     cout, p, tpc, x, wt, in_scale, in_shift, y, part_sum, part_sq, nt)
+  switch (cfg) {
+    case kCfg128x128: ISTNET_FWD(128, 128, 2, 2); break;
+    case kCfg64x128: ISTNET_FWD(64, 128, 2, 2); break;
+    case kCfg64x64: ISTNET_FWD(64, 64, 2, 2); break;
+    case kCfg32x256: ISTNET_FWD(32, 256, 1, 4); break;
+  }
+#undef ISTNET_FWD
+  return (int)hipGetLastError();
+}
+
+int istnet_bn_finalize_fwd(int c, int nt, double count, const float* part_sum, const float* part_sq,
+                           const float* gamma, const float* beta, float eps, float momentum,
+                           float* running_mean, float* running_var, float* bn, void* stream) {
+  if (c <= 0 || nt <= 0) return ISTNET_PN2_EINVAL;
+  hipLaunchKernelGGL(bn_finalize_fwd_kernel, dim3(c), dim3(64), 0, as_stream(stream), c, nt, count,
+                     part_sum, part_sq, gamma, beta, eps, momentum, running_mean, running_var, bn);
+  return (int)hipGetLastError();
+}
+
+int istnet_bn_relu_pool(int b, int c, int g, int s, const float* y, const float* bn, float* out,
+                        unsigned char* arg, void* stream) {
+  if (b <= 0 || c <= 0 || g <= 0 || s <= 0) return ISTNET_PN2_EINVAL;
+  const float* scale = bn;
+  const float* shift = bn + c;
+  if (s == 1) {
+    const long long P = g;
+    if (P & 3) return ISTNET_PN2_EINVAL;
+    hipLaunchKernelGGL(bn_relu_apply_kernel, dim3(ceil_div((int)(P / 4), 256), b * c), dim3(256), 0,
+                       as_stream(stream), c, (int)(P / 4), y, scale, shift, out);
+    return (int)hipGetLastError();
+  }
+  const dim3 grid(ceil_div(g, 256), b * c);
+#define ISTNET_POOL(S4)                                                                                  \
+  hipLaunchKernelGGL((bn_relu_pool_kernel<S4>), grid, dim3(256), 0, as_stream(stream), c, g, y, scale,  \
+                     shift, out, arg)
+  switch (s) {
+    case 4: ISTNET_POOL(1); break;
+    case 8: ISTNET_POOL(2); break;
+    case 16: ISTNET_POOL(4); break;
+    case 32: ISTNET_POOL(8); break;
+    case 64: ISTNET_POOL(16); break;
+    default: return ISTNET_PN2_EINVAL;
+  }
+#undef ISTNET_POOL
+  return (int)hipGetLastError();
+}
+
+int istnet_pw_bwd_stat_tiles(int b, int p) { return b * ceil_div(p, kStatChunk); }
+
+int istnet_pw_bwd_stats(int b, int c, int p, int nsample, const float* y, const float* d_dense,
+                        const float* d_pooled, const unsigned char* arg, const float* bn, float* part_g,
+                        float* part_gy, void* stream) {
+  if (b <= 0 || c <= 0 || p <= 0 || (p & 3)) return ISTNET_PN2_EINVAL;
+  if (d_dense == nullptr && (d_pooled == nullptr || arg == nullptr || nsample <= 0 || (nsample & 3)))
+    return ISTNET_PN2_EINVAL;
+  GradSrc gs{d_dense, d_pooled, arg, nsample};
+  const int chunks = ceil_div(p, kStatChunk);
+  hipLaunchKernelGGL(pw_bwd_stats_kernel, dim3(chunks, c, b), dim3(256), 0, as_stream(stream), c, p, gs, y,
+                     bn, bn + c, part_g, part_gy, chunks * b);
+  return (int)hipGetLastError();
+}
+
+int istnet_bn_finalize_bwd(int c, int nt, double count, int training, const float* part_g,
+                           const float* part_gy, const float* gamma, const float* bn, float* dgamma,
+                           float* dbeta, float* bwdc, void* stream) {
+  if (c <= 0 || nt <= 0) return ISTNET_PN2_EINVAL;
+  hipLaunchKernelGGL(bn_finalize_bwd_kernel, dim3(c), dim3(64), 0, as_stream(stream), c, nt, count,
+                     training, part_g, part_gy, gamma, bn, dgamma, dbeta, bwdc);
+  return (int)hipGetLastError();
+}
+
+int istnet_pw_dgrad(int b, int cin_total, int ci_off, int m_rows, int cout, int p, int nsample,
+                    const float* w, const float* y, const float* d_dense, const float* d_pooled,
+                    const unsigned char* arg, const float* bn, const float* bwdc, float* dx, void* stream) {
+  if (b <= 0 || m_rows <= 0 || cout <= 0 || p <= 0 || (p & 3)) return ISTNET_PN2_EINVAL;
+  if (d_dense == nullptr && (d_pooled == nullptr || arg == nullptr || nsample <= 0 || (nsample & 3)))
+    return ISTNET_PN2_EINVAL;
+  GradSrc gs{d_dense, d_pooled, arg, nsample};
+  const TileCfg cfg = pick_cfg(b, m_rows, p);
+  const int tpc = ceil_div(p, cfg_nt(cfg));
+  const dim3 grid(tpc * b, ceil_div(m_rows, cfg_mt(cfg)));
+#define ISTNET_DGRAD(MT, NT, WM, WN)                                                                       \
+  hipLaunchKernelGGL((pw_dgrad_kernel<MT, NT, WM, WN>), grid, dim3(kThreads), 0, as_stream(stream),       \
+                     cin_total, ci_off, m_rows, cout, p, tpc, w, y, gs, bn, bwdc, dx)
+  switch (cfg) {
+    case kCfg128x128: ISTNET_DGRAD(128, 128, 2, 2); break;
+    case kCfg64x128: ISTNET_DGRAD(64, 128, 2, 2); break;
+    case kCfg64x64: ISTNET_DGRAD(64, 64, 2, 2); break;
+    case kCfg32x256: ISTNET_DGRAD(32, 256, 1, 4); break;
+  }
+#undef ISTNET_DGRAD
+  return (int)hipGetLastError();
+}
+
+int istnet_pw_wgrad_splits(int b, int cin, int cout, int p) {
+  return b * ceil_div(p, wgrad_split_len(b, cin, cout, p));
+}
+
+int istnet_pw_wgrad(int b, int cin, int cout, int p, int nsample, const float* x, const float* in_scale,
+                    const float* in_shift, const float* y, const float* d_dense, const float* d_pooled,
+                    const unsigned char* arg, const float* bn, const float* bwdc, float* dw_part, float* dw,
+                    void* stream) {
+  if (b <= 0 || cin <= 0 || cout <= 0 || p <= 0 || (p & 3)) return ISTNET_PN2_EINVAL;
+  if (d_dense == nullptr && (d_pooled == nullptr || arg == nullptr || nsample <= 0 || (nsample & 3)))
+    return ISTNET_PN2_EINVAL;
+  GradSrc gs{d_dense, d_pooled, arg, nsample};
+  const int len = wgrad_split_len(b, cin, cout, p);
+  const int spc = ceil_div(p, len);
+  const int mt = wgrad_mt(cout), nt = wgrad_nt(cin);
+  const dim3 grid(spc * b, ceil_div(cout, mt), ceil_div(cin, nt));
+#define ISTNET_WGRAD(MT, NT)                                                                                \
+  hipLaunchKernelGGL((pw_wgrad_kernel<MT, NT, 2, 2>), grid, dim3(kThreads), 0, as_stream(stream), cin, cout, \
+                     p, spc, len, x, in_scale, in_shift, y, gs, bn, bwdc, dw_part)
+  if (mt == 128 && nt == 128) ISTNET_WGRAD(128, 128);
+  else if (mt == 128) ISTNET_WGRAD(128, 64);
+  else if (nt == 128) ISTNET_WGRAD(64, 128);
+  else ISTNET_WGRAD(64, 64);
+#undef ISTNET_WGRAD
+  const int count = cout * cin;
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(ceil_div(count, 16)), dim3(256), 0, as_stream(stream), count,
+                     spc * b, dw_part, dw);
+  return (int)hipGetLastError();
+}
+
+}  // extern "C"

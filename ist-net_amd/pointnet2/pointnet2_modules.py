@@ -11,9 +11,9 @@ FP  [ref :164-209]: three_nn -> inverse-distance weights -> three_interpolate ->
 """
 import torch
 import torch.nn as nn
-import torch.nn.functional as F
 
 from . import pointnet2_utils, pytorch_utils
+from .fused_mlp import shared_mlp_maxpool
 
 
 class _PointnetSAModuleBase(nn.Module):
@@ -37,9 +37,8 @@ class _PointnetSAModuleBase(nn.Module):
         pooled = []
         for grouper, mlp in zip(self.groupers, self.mlps):
             grouped = grouper(xyz, new_xyz, features)                 # (B, C_in, npoint, nsample)
-            act = mlp(grouped)                                         # (B, C_out, npoint, nsample)
-            act = F.max_pool2d(act, kernel_size=[1, act.size(3)])      # (B, C_out, npoint, 1)
-            pooled.append(act.squeeze(-1))
+            # SharedMLP -> max over nsample -> squeeze [ref :65-69]; one fused MFMA node on the GPU
+            pooled.append(shared_mlp_maxpool(mlp, grouped))            # (B, C_out, npoint)
         return new_xyz, torch.cat(pooled, dim=1)
 
 
@@ -93,4 +92,4 @@ class PointnetFPModule(nn.Module):
             interpolated = pointnet2_utils.three_interpolate(known_feats, idx.detach(), weight.detach())
 
         stacked = interpolated if unknow_feats is None else torch.cat([interpolated, unknow_feats], dim=1)
-        return self.mlp(stacked.unsqueeze(-1)).squeeze(-1)
+        return shared_mlp_maxpool(self.mlp, stacked.unsqueeze(-1))   # mlp(...).squeeze(-1)  [ref :205-209]

@@ -10,7 +10,7 @@ import torch
 def test_library_exports_every_declared_symbol():
     from istnet_amd import _native
     names = _native.declared_symbols()
-    assert len(names) == 11 and "istnet_pn2_query_ball_point" in names
+    assert len(names) >= 23 and "istnet_pn2_query_ball_point" in names and "istnet_pw_forward" in names
     lib = ctypes.CDLL(_native.LIB_PATH)
     for name in names:
         assert hasattr(lib, name), f"{name} declared in istnet_pn2.h but not exported"
@@ -18,15 +18,16 @@ def test_library_exports_every_declared_symbol():
 
 def test_binding_table_matches_header():
     from istnet_amd import _native
-    text = open(_native.HEADER_PATH).read()
-    decls = dict(re.findall(r"ISTNET_PN2_API\s+int\s+(istnet_pn2_\w+)\s*\(([^;]*?)\)\s*;", text, flags=re.S))
+    text = "".join(open(h).read() for h in _native.HEADER_PATHS)
+    decls = dict(re.findall(r"ISTNET_PN2_API\s+int\s+(istnet_\w+)\s*\(([^;]*?)\)\s*;", text, flags=re.S))
     decls.pop("istnet_pn2_abi_version")
     assert set(decls) == set(_native.SIGNATURES)
     for name, args in decls.items():
         kinds = []
         for a in args.split(","):
             a = a.strip()
-            kinds.append(ctypes.c_void_p if "*" in a else ctypes.c_float if a.startswith("float") else ctypes.c_int)
+            kinds.append(ctypes.c_void_p if "*" in a else ctypes.c_float if a.startswith("float")
+                         else ctypes.c_double if a.startswith("double") else ctypes.c_int)
         assert kinds == _native.SIGNATURES[name], name
 
 

@@ -22,5 +22,18 @@ def main():
         print(f"{total / tot * 100:6.2f} {cnt:7d} {total / 1e3:11.1f} {avg / 1e3:9.2f} {mn / 1e3:9.2f} {mx / 1e3:9.2f}  {name[:140]}")
 
 
-if __name__ == "__main__":
+def by_grid(path, pattern, steps):
+    db = sqlite3.connect(path)
+    rows = list(db.execute(
+        "select name, grid_x, grid_y, grid_z, count(*), avg(end-start), sum(end-start) from kernels "
+        "where name like ? group by name, grid_x, grid_y, grid_z order by 7 desc", (f"%{pattern}%",)))
+    print(f"# per-shape breakdown of kernels matching '{pattern}' (grid in threads)")
+    for name, gx, gy, gz, cnt, avg, total in rows:
+        short = name.split("(")[0][-60:]
+        print(f"{total / 1e3 / steps:9.1f} us/step  calls/step {cnt / steps:5.1f}  avg {avg / 1e3:8.2f} us  grid ({gx},{gy},{gz})  {short}")
+
+
+if __name__ == "__main__" and len(sys.argv) > 3:
+    by_grid(sys.argv[1], sys.argv[3], int(sys.argv[2]))
+elif __name__ == "__main__":
     main()
