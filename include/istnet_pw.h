@@ -65,14 +65,16 @@ ISTNET_PN2_API int istnet_pw_dgrad(int b, int cin_total, int ci_off, int m_rows,
                                    const float *d_pooled, const unsigned char *arg, const float *bn,
                                    const float *bwdc, float *dx, void *stream);
 
-/* dw[co][ci] = sum_{b,p} dY[b][co][p] * act(x[b][ci][p]); dw_part is workspace of
- * istnet_pw_wgrad_splits(...) * cout * cin floats (split-K partials, reduced in a fixed order) */
+/* split-K weight gradient: dw_part[split][co][ci] = sum_{p in split} dY[b][co][p] * act(x[b][ci][p]) with
+ * istnet_pw_wgrad_splits(...) splits; istnet_pw_wgrad_reduce sums the partials in a fixed order:
+ * dw[i] = sum_s dw_part[s][i], count = cout*cin */
 ISTNET_PN2_API int istnet_pw_wgrad_splits(int b, int cin, int cout, int p);
 ISTNET_PN2_API int istnet_pw_wgrad(int b, int cin, int cout, int p, int nsample, const float *x,
                                    const float *in_scale, const float *in_shift, const float *y,
                                    const float *d_dense, const float *d_pooled, const unsigned char *arg,
-                                   const float *bn, const float *bwdc, float *dw_part, float *dw,
-                                   void *stream);
+                                   const float *bn, const float *bwdc, float *dw_part, void *stream);
+ISTNET_PN2_API int istnet_pw_wgrad_reduce(int count, int splits, const float *dw_part, float *dw,
+                                          void *stream);
 
 #ifdef __cplusplus
 }

@@ -37,7 +37,8 @@ SIGNATURES = {
     "istnet_bn_finalize_bwd": [_i, _i, _d, _i, _p, _p, _p, _p, _p, _p, _p, _p],
     "istnet_pw_dgrad": [_i, _i, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p],
     "istnet_pw_wgrad_splits": [_i, _i, _i, _i],
-    "istnet_pw_wgrad": [_i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p],
+    "istnet_pw_wgrad": [_i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p],
+    "istnet_pw_wgrad_reduce": [_i, _i, _p, _p, _p],
 }
 
 _lib = None

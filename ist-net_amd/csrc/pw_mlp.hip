@@ -792,7 +792,7 @@ int istnet_pw_wgrad_splits(int b, int cin, int cout, int p) {
 
 int istnet_pw_wgrad(int b, int cin, int cout, int p, int nsample, const float* x, const float* in_scale,
                     const float* in_shift, const float* y, const float* d_dense, const float* d_pooled,
-                    const unsigned char* arg, const float* bn, const float* bwdc, float* dw_part, float* dw,
+                    const unsigned char* arg, const float* bn, const float* bwdc, float* dw_part,
                     void* stream) {
   if (b <= 0 || cin <= 0 || cout <= 0 || p <= 0 || (p & 3)) return ISTNET_PN2_EINVAL;
   if (d_dense == nullptr && (d_pooled == nullptr || arg == nullptr || nsample <= 0 || (nsample & 3)))
@@ -810,9 +810,13 @@ int istnet_pw_wgrad(int b, int cin, int cout, int p, int nsample, const float* x
   else if (nt == 128) ISTNET_WGRAD(64, 128);
   else ISTNET_WGRAD(64, 64);
 #undef ISTNET_WGRAD
-  const int count = cout * cin;
+  return (int)hipGetLastError();
+}
+
+int istnet_pw_wgrad_reduce(int count, int splits, const float* dw_part, float* dw, void* stream) {
+  if (count <= 0 || splits <= 0) return ISTNET_PN2_EINVAL;
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(ceil_div(count, 16)), dim3(256), 0, as_stream(stream), count,
-                     spc * b, dw_part, dw);
+                     splits, dw_part, dw);
   return (int)hipGetLastError();
 }
 

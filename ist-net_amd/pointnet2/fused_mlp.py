@@ -169,7 +169,9 @@ class FusedSharedMLPFunction(Function):
                         4.0 * (b * p * (cin + cout) + grad_elems),
                         lambda: lib.istnet_pw_wgrad(b, cin, cout, p, ns_arg, src.data_ptr(), sc, sh, y.data_ptr(),
                                                     dd, dp, da, bn.data_ptr(), bwdc.data_ptr(), ws.data_ptr(),
-                                                    dw.data_ptr(), st)), "pw_wgrad")
+                                                    st)), "pw_wgrad")
+                    _native.check(lib.istnet_pw_wgrad_reduce(cout * cin, splits, ws.data_ptr(), dw.data_ptr(), st),
+                                  "pw_wgrad_reduce")
                     grads[3 * li] = dw.view_as(w)
                 grads[3 * li + 1] = dgamma
                 grads[3 * li + 2] = dbeta
