@@ -55,6 +55,43 @@ def make_step(model, pts, opt, world, grad_sync=None):
     return step
 
 
+def make_graphed_step(model, pts, opt, world, grad_sync=None):
+    """Capture forward+backward(+Adam when single-GPU) of the step in one HIP graph and return a
+    function that replays it.  Every kernel of the step (the C-ABI launches included) goes to the
+    capture stream, so a replay does exactly the work of the eager step with one host call.  With
+    N > 1 the gradient all-reduce and the optimizer run eagerly after the replay."""
+    def fwd_bwd():
+        out = model(pts)
+        loss = out.square().mean()
+        loss.backward()
+        return loss
+
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):                      # warm-up off the default stream (allocator, autograd)
+        for _ in range(3):
+            opt.zero_grad(set_to_none=True)
+            fwd_bwd()
+            if world > 1:
+                grad_sync()
+            opt.step()
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    opt.zero_grad(set_to_none=True)
+    with torch.cuda.graph(graph):
+        fwd_bwd()
+        if world == 1:
+            opt.step()
+
+    def step():
+        graph.replay()
+        if world > 1:
+            grad_sync()
+            opt.step()
+    return step
+
+
 def cpu_baseline(budget_s=25.0):
     """The same step on the host cores with the CPU oracle ops (kind 'port'): bounded sample."""
     from istnet_amd.pointnet2 import pointnet2_utils
@@ -89,6 +126,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--eager", action="store_true", help="do not capture the step in a HIP graph")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -110,11 +148,19 @@ def main():
 
     model = make_model(dev, seed=0)  # identical weights on every rank (same seed)
     pts = shell_cloud(BATCH, NPOINTS, seed=rank, device=dev)
-    opt = torch.optim.Adam(model.parameters(), lr=1e-4, fused=True)
+    opt = torch.optim.Adam(model.parameters(), lr=1e-4, fused=True, capturable=True)
     if world > 1:
         from istnet_amd.parallel import GradAllReducer
         grad_sync = GradAllReducer(model, world).sync
-    step = make_step(model, pts, opt, world, grad_sync)
+    eager_step = make_step(model, pts, opt, world, grad_sync)
+    step, mode = eager_step, "eager"
+    if not args.eager:
+        try:
+            step, mode = make_graphed_step(model, pts, opt, world, grad_sync), "hipgraph"
+        except Exception as exc:  # capture unsupported in this configuration: run the same step eagerly
+            print(f"[bench] HIP graph capture failed ({type(exc).__name__}: {exc}); running eagerly", file=sys.stderr)
+            torch.cuda.synchronize()
+            step, mode = eager_step, "eager"
 
     for _ in range(args.warmup):
         step()
@@ -146,11 +192,11 @@ def main():
             "config": {"workload": "PointNet2MSG encoder (4 SA-MSG + 4 FP, cam radii) fwd+bwd+Adam, "
                                    "train-mode BN, shell clouds",
                        "batch_per_gpu": BATCH, "npoints": NPOINTS, "global_batch": BATCH * world,
-                       "parallelism": f"dp{world}"},
+                       "parallelism": f"dp{world}", "launch": mode},
         }
         if world == 1 and not args.no_roofline:
             from istnet_amd import roofline
-            result["roofline"] = roofline.measure(step)
+            result["roofline"] = roofline.measure(eager_step)
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline()
         print(json.dumps(result), flush=True)

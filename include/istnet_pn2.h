@@ -35,6 +35,9 @@ extern "C" {
 
 /* ABI version of the loaded library (== ISTNET_PN2_ABI_VERSION). */
 ISTNET_PN2_API int istnet_pn2_abi_version(void);
+/* Tuning knobs (process-wide, for benchmarking only): key 0 = minimum FPS slot count that uses the
+ * 4-wave kernel (default 1025). */
+ISTNET_PN2_API int istnet_pn2_set_tuning(int key, int value);
 /* Name of the code object's target, "gfx950". */
 ISTNET_PN2_API const char *istnet_pn2_target(void);
 
@@ -78,6 +81,19 @@ ISTNET_PN2_API int istnet_pn2_three_interpolate(int b, int c, int m, int n, cons
 ISTNET_PN2_API int istnet_pn2_three_interpolate_grad(int b, int c, int n, int m, const float *grad_out,
                                       const int *idx, const float *weight, float *grad_points,
                                       void *stream);
+
+/* Deterministic, atomic-free form of three_interpolate_grad (no reference counterpart; the reference uses
+ * three fp32 atomicAdds per element, interpolate_gpu.cu:144-146).
+ * istnet_pn2_interp_csr_build: per cloud, groups the 3n taps e = 3*j + t by the known point idx[e] they read:
+ *   offsets (b, m+1) i32, entries (b, 3n) i32 sorted ascending inside each group.  Needs 3m+257 ints of LDS;
+ *   returns ISTNET_PN2_EINVAL when m is too large (use istnet_pn2_three_interpolate_grad then).
+ * istnet_pn2_three_interpolate_grad_csr: grad_points[b][c][i] = sum_{e in group i} grad_out[b][c][e/3] * weight[b][e]
+ *   in ascending e, i.e. the summation order of the serial loop. */
+ISTNET_PN2_API int istnet_pn2_interp_csr_build(int b, int n, int m, const int *idx, int *offsets, int *entries,
+                                               void *stream);
+ISTNET_PN2_API int istnet_pn2_three_interpolate_grad_csr(int b, int c, int n, int m, const float *grad_out,
+                                                         const float *weight, const int *offsets,
+                                                         const int *entries, float *grad_points, void *stream);
 
 #ifdef __cplusplus
 }

@@ -9,7 +9,7 @@
  *
  * Conventions: as istnet_pn2.h (device pointers, int status, async on `stream`, stateless).
  * Layout: activations (B, C, P) f32 with P (= npoint * nsample) contiguous and P % 4 == 0;
- * conv weight w (Cout, Cin) row-major, wt = its transpose (Cin, Cout).
+ * conv weight w (Cout, Cin) row-major (the Conv2d weight viewed 2-D).
  * BN constant blocks:  bn   = [4][C]: scale = gamma*invstd, shift = beta - mean*scale, mean, invstd
  *                      bwdc = [3][C]: dY = bwdc[0]*g + bwdc[1] + bwdc[2]*y,  g = dA * [y*scale+shift > 0]
  * Gradient w.r.t. the layer output is given either dense (d_dense (B,C,P)) or, after the fused
@@ -31,11 +31,20 @@ ISTNET_PN2_API int istnet_pw_wgrad_tile_cfg(int cin, int cout);
 /* number of per-channel partial-statistics slots istnet_pw_forward writes for this shape */
 ISTNET_PN2_API int istnet_pw_stat_tiles(int b, int cout, int p);
 
-/* y[b][co][p] = sum_ci wt[ci][co] * act(x[b][ci][p]); act = relu(v*in_scale[ci]+in_shift[ci]) or identity
+/* y[b][co][p] = sum_ci w[co][ci] * act(x[b][ci][p]); act = relu(v*in_scale[ci]+in_shift[ci]) or identity
  * when in_scale == NULL.  If part_sum != NULL: part_sum/part_sq [cout][tiles] receive per-tile sum(y), sum(y*y). */
-ISTNET_PN2_API int istnet_pw_forward(int b, int cin, int cout, int p, const float *x, const float *wt,
+ISTNET_PN2_API int istnet_pw_forward(int b, int cin, int cout, int p, const float *x, const float *w,
                                      const float *in_scale, const float *in_shift, float *y,
                                      float *part_sum, float *part_sq, void *stream);
+
+/* Same GEMM with the layer-0 input of a set-abstraction scale gathered on the fly (the grouped tensor of
+ * QueryAndGroup, pointnet2_utils.py:348-358, is never materialised): input channel k < 3 is
+ * xyz[b][idx[b][p]][k] - new_xyz[b][p / nsample][k], channel k >= 3 is feat[b][k-3][idx[b][p]];
+ * cin = 3 + cfeat, p = npoint * nsample, nsample % 4 == 0, feat may be NULL when cfeat == 0. */
+ISTNET_PN2_API int istnet_pw_forward_gather(int b, int n, int npoint, int nsample, int cfeat, int cout,
+                                            const float *xyz, const float *new_xyz, const float *feat,
+                                            const int *idx, const float *w, float *y, float *part_sum,
+                                            float *part_sq, void *stream);
 
 /* partials -> bn[4][c]; updates running_mean / running_var (unbiased) with `momentum` unless NULL */
 ISTNET_PN2_API int istnet_bn_finalize_fwd(int c, int nt, double count, const float *part_sum,
@@ -59,11 +68,26 @@ ISTNET_PN2_API int istnet_bn_finalize_bwd(int c, int nt, double count, int train
                                           const float *part_gy, const float *gamma, const float *bn,
                                           float *dgamma, float *dbeta, float *bwdc, void *stream);
 
-/* dx[b][m][p] = sum_co w[co][ci_off+m] * dY[b][co][p], m < m_rows  (w is (cout, cin_total)) */
+/* dx[b][m][p] = sum_co w[co][ci_off+m] * dY[b][co][p], m < m_rows  (w is (cout, cin_total)).
+ * Optional fused statistics for the layer that PRODUCED this layer's input (dx is its dA): with
+ * part_g != NULL the epilogue also writes per-tile sums of g and g*y_in (g = dx * [y_in*scale+shift > 0],
+ * y_in (b, m_rows, p) raw activation, bn_in its bn block) into part_g / part_gy [m_rows][tiles],
+ * tiles = istnet_pw_dgrad_stat_tiles(b, m_rows, p) -- a drop-in for istnet_pw_bwd_stats on that layer. */
+ISTNET_PN2_API int istnet_pw_dgrad_stat_tiles(int b, int m_rows, int p);
 ISTNET_PN2_API int istnet_pw_dgrad(int b, int cin_total, int ci_off, int m_rows, int cout, int p,
                                    int nsample, const float *w, const float *y, const float *d_dense,
                                    const float *d_pooled, const unsigned char *arg, const float *bn,
-                                   const float *bwdc, float *dx, void *stream);
+                                   const float *bwdc, float *dx, const float *y_in, const float *bn_in,
+                                   float *part_g, float *part_gy, void *stream);
+
+/* out[b][co][i] = sum_{p : idx[b][p] == i} dY[b][co][p], i < n  (the group_points_grad scatter applied to the
+ * layer's dY instead of to the layer-0 input gradient; the scatter commutes with the channel mixing, so the
+ * feature gradient of a set-abstraction scale is  W0[:, 3:]^T . out[b]  -- a GEMM over n instead of p columns).
+ * idx (b, p) i32 with values in [0, n); needs n <= 4096. */
+ISTNET_PN2_API int istnet_pw_scatter_dy(int b, int cout, int n, int p, int nsample, const float *y,
+                                        const float *d_dense, const float *d_pooled, const unsigned char *arg,
+                                        const float *bn, const float *bwdc, const int *idx, float *out,
+                                        void *stream);
 
 /* split-K weight gradient: dw_part[split][co][ci] = sum_{p in split} dY[b][co][p] * act(x[b][ci][p]) with
  * istnet_pw_wgrad_splits(...) splits; istnet_pw_wgrad_reduce sums the partials in a fixed order:
@@ -73,6 +97,14 @@ ISTNET_PN2_API int istnet_pw_wgrad(int b, int cin, int cout, int p, int nsample,
                                    const float *in_scale, const float *in_shift, const float *y,
                                    const float *d_dense, const float *d_pooled, const unsigned char *arg,
                                    const float *bn, const float *bwdc, float *dw_part, void *stream);
+/* wgrad with the gathered layer-0 input (see istnet_pw_forward_gather); grad_nsample = nsample of the pooled
+ * gradient source (0 when d_dense is given) */
+ISTNET_PN2_API int istnet_pw_wgrad_gather(int b, int n, int npoint, int nsample, int cfeat, int cout,
+                                          int grad_nsample, const float *xyz, const float *new_xyz,
+                                          const float *feat, const int *idx, const float *y,
+                                          const float *d_dense, const float *d_pooled,
+                                          const unsigned char *arg, const float *bn, const float *bwdc,
+                                          float *dw_part, void *stream);
 ISTNET_PN2_API int istnet_pw_wgrad_reduce(int count, int splits, const float *dw_part, float *dw,
                                           void *stream);
 

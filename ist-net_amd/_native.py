@@ -16,6 +16,7 @@ ABI_VERSION = 1
 _i, _f, _p, _d = ctypes.c_int, ctypes.c_float, ctypes.c_void_p, ctypes.c_double
 # name -> argtypes (restype is always int); mirrors include/istnet_pn2.h
 SIGNATURES = {
+    "istnet_pn2_set_tuning": [_i, _i],
     "istnet_pn2_furthest_point_sampling": [_i, _i, _i, _p, _p, _p, _p],
     "istnet_pn2_gather_points": [_i, _i, _i, _i, _p, _p, _p, _p],
     "istnet_pn2_gather_points_grad": [_i, _i, _i, _i, _p, _p, _p, _p],
@@ -25,17 +26,23 @@ SIGNATURES = {
     "istnet_pn2_three_nn": [_i, _i, _i, _p, _p, _p, _p, _p],
     "istnet_pn2_three_interpolate": [_i, _i, _i, _i, _p, _p, _p, _p, _p],
     "istnet_pn2_three_interpolate_grad": [_i, _i, _i, _i, _p, _p, _p, _p, _p],
+    "istnet_pn2_interp_csr_build": [_i, _i, _i, _p, _p, _p, _p],
+    "istnet_pn2_three_interpolate_grad_csr": [_i, _i, _i, _i, _p, _p, _p, _p, _p, _p],
     # include/istnet_pw.h
     "istnet_pw_tile_cfg": [_i, _i, _i],
     "istnet_pw_wgrad_tile_cfg": [_i, _i],
     "istnet_pw_stat_tiles": [_i, _i, _i],
     "istnet_pw_forward": [_i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p],
+    "istnet_pw_forward_gather": [_i, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p],
+    "istnet_pw_wgrad_gather": [_i, _i, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p],
     "istnet_bn_finalize_fwd": [_i, _i, _d, _p, _p, _p, _p, _f, _f, _p, _p, _p, _p],
     "istnet_bn_relu_pool": [_i, _i, _i, _i, _p, _p, _p, _p, _p],
     "istnet_pw_bwd_stat_tiles": [_i, _i],
     "istnet_pw_bwd_stats": [_i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p],
     "istnet_bn_finalize_bwd": [_i, _i, _d, _i, _p, _p, _p, _p, _p, _p, _p, _p],
-    "istnet_pw_dgrad": [_i, _i, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p],
+    "istnet_pw_dgrad_stat_tiles": [_i, _i, _i],
+    "istnet_pw_dgrad": [_i, _i, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p],
+    "istnet_pw_scatter_dy": [_i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p],
     "istnet_pw_wgrad_splits": [_i, _i, _i, _i],
     "istnet_pw_wgrad": [_i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p],
     "istnet_pw_wgrad_reduce": [_i, _i, _p, _p, _p],

@@ -322,48 +322,133 @@ constexpr int kScatterThreads = 256;
 constexpr int kGroupGradCH = 4;
 constexpr int kInterpGradCH = 8;
 
-template <bool VEC4>
+// group_points_grad: lanes walk consecutive grouped slots p (coalesced), runs of equal indices inside a
+// 16-lane DPP row are summed with a segmented scan (row_shr 1,2,4,8) and only the last lane of a run
+// issues the LDS atomic.
+template <int CTRL>
+__device__ __forceinline__ int dpp_row_i(int identity, int v) {
+  return __builtin_amdgcn_update_dpp(identity, v, CTRL, 0xf, 0xf, false);
+}
+template <int CTRL>
+__device__ __forceinline__ float dpp_row_f(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
+}
 __global__ __launch_bounds__(kScatterThreads) void group_grad_kernel(
-    int c, int n, int npoints, int nsample, const float* __restrict__ grad_out,
-    const int* __restrict__ idx_all, float* __restrict__ grad_points) {
+    int c, int n, int P, const float* __restrict__ grad_out, const int* __restrict__ idx_all,
+    float* __restrict__ grad_points) {
   extern __shared__ __attribute__((aligned(16))) float acc[];  // [CH][n]
   const int b = blockIdx.y, c0 = blockIdx.x * kGroupGradCH;
   const int nch = min(kGroupGradCH, c - c0);
   for (int i = threadIdx.x; i < nch * n; i += kScatterThreads) acc[i] = 0.f;
   __syncthreads();
-  for (int j = threadIdx.x; j < npoints; j += kScatterThreads) {
-    const int* row = idx_all + ((size_t)b * npoints + j) * nsample;
+  const int* idx = idx_all + (size_t)b * P;
+  const int Pr = (P + kScatterThreads - 1) / kScatterThreads * kScatterThreads;  // whole waves stay converged
+  for (int p = threadIdx.x; p < Pr; p += kScatterThreads) {
+    const bool valid = p < P;
+    const int ii = valid ? idx[p] : -1;
+    // head of a run: first lane of the 16-lane row or index differs from the previous lane
+    const int prev = dpp_row_i<0x111>(-2, ii);
+    const int head0 = (prev != ii) ? 1 : 0;
+    const int nxt = dpp_row_i<0x101>(-3, ii);      // row_shl:1 -> index of the next lane (or -3 at the row end)
+    const bool tail = nxt != ii;
     for (int ch = 0; ch < nch; ++ch) {
-      const float* g = grad_out + (((size_t)b * c + c0 + ch) * npoints + j) * nsample;
-      float* a = acc + ch * n;
-      int cur = row[0];
-      float run = 0.f;
-      if (VEC4) {
-        for (int k = 0; k < nsample; k += 4) {
-          const int4 ii = *reinterpret_cast<const int4*>(row + k);
-          const float4 v = *reinterpret_cast<const float4*>(g + k);
-          if (ii.x != cur) { atomicAdd(&a[cur], run); cur = ii.x; run = 0.f; }
-          run += v.x;
-          if (ii.y != cur) { atomicAdd(&a[cur], run); cur = ii.y; run = 0.f; }
-          run += v.y;
-          if (ii.z != cur) { atomicAdd(&a[cur], run); cur = ii.z; run = 0.f; }
-          run += v.z;
-          if (ii.w != cur) { atomicAdd(&a[cur], run); cur = ii.w; run = 0.f; }
-          run += v.w;
-        }
-      } else {
-        for (int k = 0; k < nsample; ++k) {
-          const int ii = row[k];
-          if (ii != cur) { atomicAdd(&a[cur], run); cur = ii; run = 0.f; }
-          run += g[k];
-        }
-      }
-      atomicAdd(&a[cur], run);
+      float v = valid ? grad_out[((size_t)b * c + c0 + ch) * P + p] : 0.f;
+      int f = head0;
+      float pv; int pf;
+      pv = dpp_row_f<0x111>(v); pf = dpp_row_i<0x111>(1, f); v = f ? v : v + pv; f |= pf;
+      pv = dpp_row_f<0x112>(v); pf = dpp_row_i<0x112>(1, f); v = f ? v : v + pv; f |= pf;
+      pv = dpp_row_f<0x114>(v); pf = dpp_row_i<0x114>(1, f); v = f ? v : v + pv; f |= pf;
+      pv = dpp_row_f<0x118>(v); pf = dpp_row_i<0x118>(1, f); v = f ? v : v + pv; f |= pf;
+      if (valid && tail) atomicAdd(&acc[ch * n + ii], v);
     }
   }
   __syncthreads();
   for (int i = threadIdx.x; i < nch * n; i += kScatterThreads)
     grad_points[((size_t)b * c + c0) * n + i] = acc[i];
+}
+
+// ---- three_interpolate_grad without atomics: per-cloud inverse lists (CSR) of the 3n taps, then a gather.
+// build: offsets off[b][m+1], entries ent[b][3n] = tap number e = 3*j + t, grouped by known point and
+// sorted ascending inside each group (=> the summation order of the serial reference loop).
+__global__ __launch_bounds__(256) void interp_csr_build_kernel(int n, int m, const int* __restrict__ idx_all,
+                                                               int* __restrict__ off_all,
+                                                               int* __restrict__ ent_all) {
+  extern __shared__ __attribute__((aligned(16))) int lds_i[];  // cnt[m] | cur[m] | off[m+1] | part[256]
+  int* cnt = lds_i;
+  int* cur = lds_i + m;
+  int* off = lds_i + 2 * m;
+  int* part = lds_i + 3 * m + 1;
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const int* idx = idx_all + (size_t)b * n * 3;
+  int* ent = ent_all + (size_t)b * n * 3;
+  const int E = 3 * n;
+  for (int i = tid; i < m; i += 256) cnt[i] = 0;
+  __syncthreads();
+  for (int e = tid; e < E; e += 256) atomicAdd(&cnt[idx[e]], 1);
+  __syncthreads();
+  // exclusive scan of cnt -> off: each thread owns a contiguous slice
+  const int per = (m + 255) / 256;
+  const int lo = min(tid * per, m), hi = min(lo + per, m);
+  int s = 0;
+  for (int i = lo; i < hi; ++i) s += cnt[i];
+  part[tid] = s;
+  __syncthreads();
+  if (tid == 0) {
+    int run = 0;
+    for (int t = 0; t < 256; ++t) { const int v = part[t]; part[t] = run; run += v; }
+    off[m] = run;
+  }
+  __syncthreads();
+  int run = part[tid];
+  for (int i = lo; i < hi; ++i) { off[i] = run; cur[i] = run; run += cnt[i]; }
+  __syncthreads();
+  for (int e = tid; e < E; e += 256) {
+    const int slot = atomicAdd(&cur[idx[e]], 1);
+    ent[slot] = e;
+  }
+  __syncthreads();  // ent was written with global stores by this workgroup: make them visible to it
+  __threadfence_block();
+  for (int i = tid; i < m; i += 256) {  // sort each (short) list ascending
+    const int a = off[i], z = off[i + 1];
+    for (int u = a + 1; u < z; ++u) {
+      const int key = ent[u];
+      int v = u - 1;
+      while (v >= a && ent[v] > key) { ent[v + 1] = ent[v]; --v; }
+      ent[v + 1] = key;
+    }
+  }
+  for (int i = tid; i <= m; i += 256) off_all[(size_t)b * (m + 1) + i] = off[i];
+}
+
+constexpr int kInterpCsrCH = 8;
+__global__ __launch_bounds__(256) void interp_grad_csr_kernel(int c, int n, int m,
+                                                              const float* __restrict__ grad_out,
+                                                              const float* __restrict__ w_all,
+                                                              const int* __restrict__ off_all,
+                                                              const int* __restrict__ ent_all,
+                                                              float* __restrict__ grad_points) {
+  const int b = blockIdx.z, c0 = blockIdx.y * kInterpCsrCH;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= m) return;
+  const int* off = off_all + (size_t)b * (m + 1);
+  const int* ent = ent_all + (size_t)b * n * 3;
+  const float* w = w_all + (size_t)b * n * 3;
+  const int a = off[i], z = off[i + 1];
+  const int nch = min(kInterpCsrCH, c - c0);
+  float sum[kInterpCsrCH];
+#pragma unroll
+  for (int ch = 0; ch < kInterpCsrCH; ++ch) sum[ch] = 0.f;
+  for (int u = a; u < z; ++u) {
+    const int e = ent[u];
+    const int j = e / 3;
+    const float we = w[e];
+#pragma unroll
+    for (int ch = 0; ch < kInterpCsrCH; ++ch)
+      if (ch < nch) sum[ch] += grad_out[((size_t)b * c + c0 + ch) * n + j] * we;
+  }
+#pragma unroll
+  for (int ch = 0; ch < kInterpCsrCH; ++ch)
+    if (ch < nch) grad_points[((size_t)b * c + c0 + ch) * m + i] = sum[ch];
 }
 
 __global__ __launch_bounds__(kScatterThreads) void interp_grad_kernel(
@@ -374,12 +459,13 @@ __global__ __launch_bounds__(kScatterThreads) void interp_grad_kernel(
   const int nch = min(kInterpGradCH, c - c0);
   for (int i = threadIdx.x; i < nch * m; i += kScatterThreads) acc[i] = 0.f;
   __syncthreads();
-  for (int j = threadIdx.x; j < n; j += kScatterThreads) {
+  for (int wi = threadIdx.x; wi < nch * n; wi += kScatterThreads) {  // one (channel, point) per thread
+    const int ch = wi / n, j = wi - ch * n;
     const int* ix = idx_all + ((size_t)b * n + j) * 3;
     const float* w = w_all + ((size_t)b * n + j) * 3;
     const int i1 = ix[0], i2 = ix[1], i3 = ix[2];
     const float w1 = w[0], w2 = w[1], w3 = w[2];
-    for (int ch = 0; ch < nch; ++ch) {
+    {
       const float g = grad_out[((size_t)b * c + c0 + ch) * n + j];
       float* a = acc + ch * m;
       atomicAdd(&a[i1], g * w1);
@@ -494,6 +580,7 @@ __global__ __launch_bounds__(256) void three_interpolate_kernel(int c, int m, in
   }
 }
 
+int g_fps_multiwave_min = 1025;  // tuning knob (istnet_pn2_set_tuning); measured: 1 wave wins up to 1024 points
 inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 inline int ilog2_floor(int v) { int r = 0; while ((1 << (r + 1)) <= v) ++r; return r; }
 inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
@@ -514,13 +601,8 @@ int launch_group_grad(int b, int c, int n, int npoints, int nsample, const float
   const size_t lds = (size_t)kGroupGradCH * n * 4;
   if (lds > (size_t)kMaxLdsRowBytes)
     return launch_scatter_fallback<0>(b, c, n, npoints * nsample, grad_out, idx, nullptr, grad_points, st);
-  const dim3 grid(ceil_div(c, kGroupGradCH), b);
-  if (nsample % 4 == 0)
-    hipLaunchKernelGGL(group_grad_kernel<true>, grid, dim3(kScatterThreads), lds, st, c, n, npoints, nsample,
-                       grad_out, idx, grad_points);
-  else
-    hipLaunchKernelGGL(group_grad_kernel<false>, grid, dim3(kScatterThreads), lds, st, c, n, npoints,
-                       nsample, grad_out, idx, grad_points);
+  hipLaunchKernelGGL(group_grad_kernel, dim3(ceil_div(c, kGroupGradCH), b), dim3(kScatterThreads), lds, st, c,
+                     n, npoints * nsample, grad_out, idx, grad_points);
   return (int)hipGetLastError();
 }
 
@@ -556,6 +638,10 @@ int launch_fps_regs(int b, int n, int m, int bs_log2, int nper, const float* dat
 extern "C" {
 
 int istnet_pn2_abi_version(void) { return ISTNET_PN2_ABI_VERSION; }
+int istnet_pn2_set_tuning(int key, int value) {
+  if (key == 0) { g_fps_multiwave_min = value; return 0; }
+  return ISTNET_PN2_EINVAL;
+}
 const char* istnet_pn2_target(void) { return "gfx950"; }
 
 int istnet_pn2_furthest_point_sampling(int b, int n, int m, const float* dataset, float* temp,
@@ -568,7 +654,9 @@ int istnet_pn2_furthest_point_sampling(int b, int n, int m, const float* dataset
   const int nper = ceil_div(n, 1 << bs_log2);
   const int slots = nper << bs_log2;
   hipStream_t st = as_stream(stream);
-  if (slots <= 64 * 16) return launch_fps_regs<1>(b, n, m, bs_log2, nper, dataset, idxs, st);
+  // one wave per cloud is barrier-free and measured faster than four waves (LDS exchange + barrier per
+  // round) for every n <= 1024 (profiles/r01_index_microbench.txt)
+  if (slots < g_fps_multiwave_min) return launch_fps_regs<1>(b, n, m, bs_log2, nper, dataset, idxs, st);
   if (slots <= 256 * 16) return launch_fps_regs<4>(b, n, m, bs_log2, nper, dataset, idxs, st);
   if (temp == nullptr) return ISTNET_PN2_EINVAL;  // large clouds need the scratch buffer
   hipLaunchKernelGGL(fps_generic_kernel, dim3(b), dim3(1024), 0, st, n, m, bs_log2, nper, dataset,
@@ -650,6 +738,26 @@ int istnet_pn2_three_interpolate(int b, int c, int m, int n, const float* points
   if (b == 0 || c == 0 || n == 0) return 0;
   hipLaunchKernelGGL(three_interpolate_kernel, dim3(ceil_div(n, 256), ceil_div(c, kInterpChunk), b),
                      dim3(256), 0, as_stream(stream), c, m, n, points, idx, weight, out);
+  return (int)hipGetLastError();
+}
+
+int istnet_pn2_interp_csr_build(int b, int n, int m, const int* idx, int* offsets, int* entries, void* stream) {
+  if (b < 0 || n < 0 || m <= 0) return ISTNET_PN2_EINVAL;
+  if (b == 0) return 0;
+  const size_t lds = ((size_t)3 * m + 1 + 256) * 4;
+  if (lds > (size_t)kMaxLdsRowBytes) return ISTNET_PN2_EINVAL;  // caller falls back to the atomic kernel
+  hipLaunchKernelGGL(interp_csr_build_kernel, dim3(b), dim3(256), lds, as_stream(stream), n, m, idx, offsets,
+                     entries);
+  return (int)hipGetLastError();
+}
+
+int istnet_pn2_three_interpolate_grad_csr(int b, int c, int n, int m, const float* grad_out,
+                                          const float* weight, const int* offsets, const int* entries,
+                                          float* grad_points, void* stream) {
+  if (b < 0 || c < 0 || m <= 0 || n < 0) return ISTNET_PN2_EINVAL;
+  if (b == 0 || c == 0) return 0;
+  hipLaunchKernelGGL(interp_grad_csr_kernel, dim3(ceil_div(m, 256), ceil_div(c, kInterpCsrCH), b), dim3(256), 0,
+                     as_stream(stream), c, n, m, grad_out, weight, offsets, entries, grad_points);
   return (int)hipGetLastError();
 }
 

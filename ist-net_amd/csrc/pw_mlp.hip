@@ -31,7 +31,7 @@ namespace {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int kThreads = 256;
-constexpr int kKT = 16;    // K chunk of the fwd / dgrad GEMMs (channels)
+constexpr int kKT = 16;    // K chunk of the fwd / dgrad GEMMs (channels); 32 measured no better
 constexpr int kKTW = 32;   // K chunk of the wgrad GEMM (points)
 
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
@@ -59,6 +59,32 @@ __device__ __forceinline__ float wave_sum(float v) {
 // MFMA C/D layout of v_mfma_f32_32x32x2_f32: reg r of lane l holds row (r&3)+8*(r>>2)+4*(l>>5), col l&31.
 __device__ __forceinline__ int mfma_row(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
 
+// Layer-0 input of a set-abstraction scale, gathered on the fly instead of materialising the grouped
+// tensor (reference QueryAndGroup.forward, pointnet2_utils.py:348-358): channel k < 3 is
+// xyz[idx[p]][k] - new_xyz[p / S][k], channel k >= 3 is feat[k - 3][idx[p]].
+struct GatherSrc {
+  const float* xyz;      // (B, n, 3)
+  const float* new_xyz;  // (B, P / S, 3)
+  const float* feat;     // (B, cfeat, n) or null
+  const int* idx;        // (B, P) int32
+  int n, S, cfeat;
+};
+__device__ __forceinline__ int4 gather_idx4(const GatherSrc& gs, int b, int P, int p) {
+  return *reinterpret_cast<const int4*>(gs.idx + (size_t)b * P + p);
+}
+__device__ __forceinline__ float4 gather4(const GatherSrc& gs, int b, int k, int P, int p, int4 ii) {
+  float4 v;
+  if (k < 3) {
+    const float* xb = gs.xyz + (size_t)b * gs.n * 3 + k;
+    const float c = gs.new_xyz[((size_t)b * (P / gs.S) + p / gs.S) * 3 + k];
+    v.x = xb[ii.x * 3] - c; v.y = xb[ii.y * 3] - c; v.z = xb[ii.z * 3] - c; v.w = xb[ii.w * 3] - c;
+  } else {
+    const float* row = gs.feat + ((size_t)b * gs.cfeat + (k - 3)) * gs.n;
+    v.x = row[ii.x]; v.y = row[ii.y]; v.z = row[ii.z]; v.w = row[ii.w];
+  }
+  return v;
+}
+
 template <int M_T, int N_T, int WM, int WN>
 struct Tile {
   static constexpr int TM = M_T / (32 * WM);
@@ -67,84 +93,118 @@ struct Tile {
 };
 
 // One K chunk of MFMAs from k-major LDS tiles.  a_lds: [KT][LDA], b_lds: [KT][LDB].
+// Fragments of k-step kk+1 are read while the MFMAs of k-step kk execute (register double buffer).
 template <int KT, int TM, int TN, int LDA, int LDB>
 __device__ __forceinline__ void mma_chunk(const float* a_lds, const float* b_lds, int a_col0, int b_col0,
                                           f32x16 (&acc)[TM][TN]) {
   const int lane = lane_id();
-  const int kh = lane >> 5, c = lane & 31;
+  const float* ap = a_lds + (lane >> 5) * LDA + a_col0 + (lane & 31);
+  const float* bp = b_lds + (lane >> 5) * LDB + b_col0 + (lane & 31);
+  float a[2][TM], b[2][TN];
+#pragma unroll
+  for (int tm = 0; tm < TM; ++tm) a[0][tm] = ap[tm * 32];
+#pragma unroll
+  for (int tn = 0; tn < TN; ++tn) b[0][tn] = bp[tn * 32];
 #pragma unroll
   for (int kk = 0; kk < KT / 2; ++kk) {
-    float a[TM], b[TN];
+    const int cur = kk & 1, nxt = cur ^ 1;
+    if (kk + 1 < KT / 2) {
 #pragma unroll
-    for (int tm = 0; tm < TM; ++tm) a[tm] = a_lds[(2 * kk + kh) * LDA + a_col0 + tm * 32 + c];
+      for (int tm = 0; tm < TM; ++tm) a[nxt][tm] = ap[(2 * kk + 2) * LDA + tm * 32];
 #pragma unroll
-    for (int tn = 0; tn < TN; ++tn) b[tn] = b_lds[(2 * kk + kh) * LDB + b_col0 + tn * 32 + c];
+      for (int tn = 0; tn < TN; ++tn) b[nxt][tn] = bp[(2 * kk + 2) * LDB + tn * 32];
+    }
+    __builtin_amdgcn_sched_barrier(0);  // keep the next step's ds_reads ahead of this step's MFMAs
 #pragma unroll
     for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
       for (int tn = 0; tn < TN; ++tn)
-        acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tm], b[tn], acc[tm][tn], 0, 0, 0);
+        acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][tm], b[cur][tn], acc[tm][tn], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
   }
 }
+
+// relu(v * s + h) on 4 lanes
+__device__ __forceinline__ float4 bn_relu4(float4 v, float s, float h) {
+  v.x = fmaxf(v.x * s + h, 0.f); v.y = fmaxf(v.y * s + h, 0.f);
+  v.z = fmaxf(v.z * s + h, 0.f); v.w = fmaxf(v.w * s + h, 0.f);
+  return v;
+}
+__device__ __forceinline__ float4 zero4() { return make_float4(0.f, 0.f, 0.f, 0.f); }
 
 // ============================================================================================
 // forward:  y[b][co][p] = sum_ci wt[ci][co] * act(x[b][ci][p]),  optional BN-statistics partials
 // ============================================================================================
-template <int M_T, int N_T, int WM, int WN>
+template <int M_T, int N_T, int WM, int WN, bool GATHER>
 __global__ __launch_bounds__(kThreads) void pw_fwd_kernel(
-    int cin, int cout, int P, int tiles_per_cloud, const float* __restrict__ x,
-    const float* __restrict__ wt, const float* __restrict__ in_scale, const float* __restrict__ in_shift,
+    int cin, int cout, int P, int tiles_per_cloud, const float* __restrict__ x, GatherSrc gsrc,
+    const float* __restrict__ w, const float* __restrict__ in_scale, const float* __restrict__ in_shift,
     float* __restrict__ y, float* __restrict__ part_sum, float* __restrict__ part_sq, int nt_total) {
   using T = Tile<M_T, N_T, WM, WN>;
   constexpr int TM = T::TM, TN = T::TN;
   constexpr int NA = kKT * M_T / kThreads;        // scalar weight loads per thread per chunk
   constexpr int NB = kKT * N_T / 4 / kThreads;    // float4 activation loads per thread per chunk
+  constexpr int LDA = M_T + 1;                    // w is (cout, cin): lanes walk k, odd stride spreads the banks
   static_assert(NA >= 1 && NB >= 1, "tile too small for 256 threads");
-  __shared__ __attribute__((aligned(16))) float As[2][kKT][M_T];
+  __shared__ __attribute__((aligned(16))) float As[2][kKT][LDA];
   __shared__ __attribute__((aligned(16))) float Bs[2][kKT][N_T];
 
   const int tid = threadIdx.x;
   const int b = blockIdx.x / tiles_per_cloud;
   const int p0 = (blockIdx.x - b * tiles_per_cloud) * N_T;
   const int m0 = blockIdx.y * M_T;
-  const float* xb = x + (size_t)b * cin * P;
+  const float* xb = GATHER ? nullptr : x + (size_t)b * cin * P;
   const bool has_bn = in_scale != nullptr;
 
+  // Staging is split in two so the global loads of chunk t+1 stay in flight during the MFMAs of
+  // chunk t: load_chunk only issues loads (clamped addresses, no branches, no use of the data),
+  // store_chunk applies zero-fill / BN+ReLU and writes LDS.
   float areg[NA];
-  float4 breg[NB];
+  float4 braw[NB];
+  float bsc[NB], bsh[NB];
+  int4 gidx[NB];
+  if (GATHER) {
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {  // neighbour indices depend on the point only: load once per tile
+      const int e = tid + kThreads * i;
+      const int p = min(p0 + (e % (N_T / 4)) * 4, P - 4);
+      gidx[i] = gather_idx4(gsrc, b, P, p);
+    }
+  }
   auto load_chunk = [&](int k0) {
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
       const int e = tid + kThreads * i;
-      const int k = k0 + e / M_T, m = m0 + e % M_T;
-      areg[i] = (k < cin && m < cout) ? wt[(size_t)k * cout + m] : 0.f;
+      const int k = min(k0 + e % kKT, cin - 1), m = min(m0 + e / kKT, cout - 1);
+      areg[i] = w[(size_t)m * cin + k];
     }
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
       const int e = tid + kThreads * i;
-      const int k = k0 + e / (N_T / 4), p = p0 + (e % (N_T / 4)) * 4;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (k < cin && p < P) {
-        v = *reinterpret_cast<const float4*>(xb + (size_t)k * P + p);
-        if (has_bn) {
-          const float s = in_scale[k], h = in_shift[k];
-          v.x = fmaxf(v.x * s + h, 0.f); v.y = fmaxf(v.y * s + h, 0.f);
-          v.z = fmaxf(v.z * s + h, 0.f); v.w = fmaxf(v.w * s + h, 0.f);
-        }
+      const int k = min(k0 + e / (N_T / 4), cin - 1), p = min(p0 + (e % (N_T / 4)) * 4, P - 4);
+      if (GATHER) {
+        braw[i] = gather4(gsrc, b, k, P, p, gidx[i]);
+      } else {
+        braw[i] = *reinterpret_cast<const float4*>(xb + (size_t)k * P + p);
+        if (has_bn) { bsc[i] = in_scale[k]; bsh[i] = in_shift[k]; }
       }
-      breg[i] = v;
     }
   };
-  auto store_chunk = [&](int buf) {
+  auto store_chunk = [&](int buf, int k0) {
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
       const int e = tid + kThreads * i;
-      As[buf][e / M_T][e % M_T] = areg[i];
+      const bool ok = (k0 + e % kKT < cin) && (m0 + e / kKT < cout);
+      As[buf][e % kKT][e / kKT] = ok ? areg[i] : 0.f;
     }
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
       const int e = tid + kThreads * i;
-      *reinterpret_cast<float4*>(&Bs[buf][e / (N_T / 4)][(e % (N_T / 4)) * 4]) = breg[i];
+      const bool ok = (k0 + e / (N_T / 4) < cin) && (p0 + (e % (N_T / 4)) * 4 < P);
+      float4 v = braw[i];
+      if (!GATHER && has_bn) v = bn_relu4(v, bsc[i], bsh[i]);
+      if (!ok) v = zero4();
+      *reinterpret_cast<float4*>(&Bs[buf][e / (N_T / 4)][(e % (N_T / 4)) * 4]) = v;
     }
   };
 
@@ -156,17 +216,17 @@ __global__ __launch_bounds__(kThreads) void pw_fwd_kernel(
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[tm][tn][r] = 0.f;
 
-  const int w = wave_id();
-  const int a_col0 = (w / WN) * TM * 32, b_col0 = (w % WN) * TN * 32;
+  const int wv = wave_id();
+  const int a_col0 = (wv / WN) * TM * 32, b_col0 = (wv % WN) * TN * 32;
   const int nchunks = (cin + kKT - 1) / kKT;
   load_chunk(0);
-  store_chunk(0);
+  store_chunk(0, 0);
   __syncthreads();
   for (int t = 0; t < nchunks; ++t) {
     const int buf = t & 1;
     if (t + 1 < nchunks) load_chunk((t + 1) * kKT);
-    mma_chunk<kKT, TM, TN, M_T, N_T>(&As[buf][0][0], &Bs[buf][0][0], a_col0, b_col0, acc);
-    if (t + 1 < nchunks) store_chunk(buf ^ 1);
+    mma_chunk<kKT, TM, TN, LDA, N_T>(&As[buf][0][0], &Bs[buf][0][0], a_col0, b_col0, acc);
+    if (t + 1 < nchunks) store_chunk(buf ^ 1, (t + 1) * kKT);
     __syncthreads();
   }
 
@@ -174,6 +234,7 @@ __global__ __launch_bounds__(kThreads) void pw_fwd_kernel(
   const int lane = lane_id();
   float* yb = y + (size_t)b * cout * P;
   float* red = &As[0][0][0];  // reuse LDS: [WN][M_T][2]
+  const bool full_tile = (m0 + M_T <= cout) && (p0 + N_T <= P);  // workgroup-uniform
 #pragma unroll
   for (int tm = 0; tm < TM; ++tm) {
 #pragma unroll
@@ -181,22 +242,32 @@ __global__ __launch_bounds__(kThreads) void pw_fwd_kernel(
       const int row_l = a_col0 + tm * 32 + mfma_row(r, lane);
       const int row = m0 + row_l;
       float s = 0.f, q = 0.f;
+      if (full_tile) {
 #pragma unroll
-      for (int tn = 0; tn < TN; ++tn) {
-        const int col = p0 + b_col0 + tn * 32 + (lane & 31);
-        const float v = acc[tm][tn][r];
-        if (row < cout && col < P) {
-          yb[(size_t)row * P + col] = v;
+        for (int tn = 0; tn < TN; ++tn) {
+          const float v = acc[tm][tn][r];
+          yb[(size_t)row * P + p0 + b_col0 + tn * 32 + (lane & 31)] = v;
           s += v;
           q += v * v;
+        }
+      } else {
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn) {
+          const int col = p0 + b_col0 + tn * 32 + (lane & 31);
+          const float v = acc[tm][tn][r];
+          if (row < cout && col < P) {
+            yb[(size_t)row * P + col] = v;
+            s += v;
+            q += v * v;
+          }
         }
       }
       if (part_sum != nullptr) {
         s = half_wave_sum(s);
         q = half_wave_sum(q);
         if ((lane & 31) == 31) {
-          red[((w % WN) * M_T + row_l) * 2 + 0] = s;
-          red[((w % WN) * M_T + row_l) * 2 + 1] = q;
+          red[((wv % WN) * M_T + row_l) * 2 + 0] = s;
+          red[((wv % WN) * M_T + row_l) * 2 + 1] = q;
         }
       }
     }
@@ -391,17 +462,107 @@ __global__ __launch_bounds__(64) void bn_finalize_bwd_kernel(int C, int nt, doub
   }
 }
 
-// dY for 4 consecutive points of channel k
-__device__ __forceinline__ float4 make_dy4(const GradSrc& gs, const float* __restrict__ y, size_t row, int P,
-                                           int p, float s, float h, float ca, float cb, float cc) {
-  const float4 v = *reinterpret_cast<const float4*>(y + row * (size_t)P + p);
-  const float4 d = load_grad4(gs, row, P, p);
+// dY for 4 consecutive points of one channel, split into a pure load (issued early, nothing consumed)
+// and the arithmetic (run after the MFMAs of the previous chunk).
+struct DyRaw {
+  float4 y, d;            // raw activation; dense gradient, or pooled gradient in d.x
+  int a;                  // arg-max slot (pooled mode)
+  float s, h, ca, cb, cc;  // BN scale/shift of this layer and the dY constants
+};
+__device__ __forceinline__ void load_dy_raw(DyRaw& r, const GradSrc& gs, const float* __restrict__ y,
+                                            size_t row, int P, int p, int ch, const float* __restrict__ bn,
+                                            const float* __restrict__ bwdc, int C) {
+  r.y = *reinterpret_cast<const float4*>(y + row * (size_t)P + p);
+  if (gs.dense != nullptr) {
+    r.d = *reinterpret_cast<const float4*>(gs.dense + row * (size_t)P + p);
+    r.a = 0;
+  } else {
+    const int G = P / gs.S, g = p / gs.S;
+    r.d = make_float4(gs.pooled[row * (size_t)G + g], 0.f, 0.f, 0.f);
+    r.a = gs.arg[row * (size_t)G + g];
+  }
+  r.s = bn[ch]; r.h = bn[C + ch];
+  r.ca = bwdc[ch]; r.cb = bwdc[C + ch]; r.cc = bwdc[2 * C + ch];
+}
+__device__ __forceinline__ float4 finish_dy(const DyRaw& r, const GradSrc& gs, int p) {
+  float4 d = r.d;
+  if (gs.dense == nullptr) {
+    const int k = p % gs.S;
+    const float v = r.d.x;
+    d = make_float4(r.a == k ? v : 0.f, r.a == k + 1 ? v : 0.f, r.a == k + 2 ? v : 0.f, r.a == k + 3 ? v : 0.f);
+  }
   float4 o;
-  o.x = ca * ((v.x * s + h > 0.f) ? d.x : 0.f) + cb + cc * v.x;
-  o.y = ca * ((v.y * s + h > 0.f) ? d.y : 0.f) + cb + cc * v.y;
-  o.z = ca * ((v.z * s + h > 0.f) ? d.z : 0.f) + cb + cc * v.z;
-  o.w = ca * ((v.w * s + h > 0.f) ? d.w : 0.f) + cb + cc * v.w;
+  o.x = r.ca * ((r.y.x * r.s + r.h > 0.f) ? d.x : 0.f) + r.cb + r.cc * r.y.x;
+  o.y = r.ca * ((r.y.y * r.s + r.h > 0.f) ? d.y : 0.f) + r.cb + r.cc * r.y.y;
+  o.z = r.ca * ((r.y.z * r.s + r.h > 0.f) ? d.z : 0.f) + r.cb + r.cc * r.y.z;
+  o.w = r.ca * ((r.y.w * r.s + r.h > 0.f) ? d.w : 0.f) + r.cb + r.cc * r.y.w;
   return o;
+}
+
+// ============================================================================================
+// Layer-0 feature gradient of a set-abstraction scale without the big dgrad GEMM.  The scatter-add of
+// group_points_grad is linear and acts on the point index only, so it commutes with the channel mixing:
+//     dfeat[b] = scatter(W0f^T . dY0[b]) = W0f^T . scatter(dY0[b])
+// This kernel forms G[b][co][i] = sum_{p: idx[b][p] == i} dY0[b][co][p]  (Cout0 x n per cloud) directly from
+// (y0, gradient source, BN constants); the remaining (C x Cout0).(Cout0 x n) product is a small GEMM.
+// Runs of equal indices inside a 16-lane DPP row are pre-summed (padded ball slots repeat the first hit)
+// and only the last lane of a run issues the LDS atomic.
+// ============================================================================================
+constexpr int kScatterCH = 4;
+template <int CTRL>
+__device__ __forceinline__ int dpp_row_i(int identity, int v) {
+  return __builtin_amdgcn_update_dpp(identity, v, CTRL, 0xf, 0xf, false);
+}
+template <int CTRL>
+__device__ __forceinline__ float dpp_row_f(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
+}
+__global__ __launch_bounds__(256) void pw_scatter_dy_kernel(int cout, int n, int P, const float* __restrict__ y,
+                                                            GradSrc gs, const float* __restrict__ bn,
+                                                            const float* __restrict__ bwdc,
+                                                            const int* __restrict__ idx_all,
+                                                            float* __restrict__ out) {
+  extern __shared__ __attribute__((aligned(16))) float acc[];  // [CH][n]
+  const int b = blockIdx.y, c0 = blockIdx.x * kScatterCH;
+  const int nch = min(kScatterCH, cout - c0);
+  for (int i = threadIdx.x; i < nch * n; i += 256) acc[i] = 0.f;
+  __syncthreads();
+  const int* idx = idx_all + (size_t)b * P;
+  const int Pr = (P + 255) / 256 * 256;  // whole waves stay converged for the DPP scan
+  const int G = gs.dense == nullptr ? P / gs.S : 0;
+  for (int p = threadIdx.x; p < Pr; p += 256) {
+    const bool valid = p < P;
+    const int pc = valid ? p : P - 1;
+    const int ii = valid ? idx[p] : -1;
+    const int prev = dpp_row_i<0x111>(-2, ii);   // row_shr:1
+    const int head0 = (prev != ii) ? 1 : 0;
+    const int nxt = dpp_row_i<0x101>(-3, ii);    // row_shl:1
+    const bool tail = nxt != ii;
+    for (int ch = 0; ch < nch; ++ch) {
+      const int co = c0 + ch;
+      const size_t row = (size_t)b * cout + co;
+      const float yv = y[row * (size_t)P + pc];
+      float d;
+      if (gs.dense != nullptr) {
+        d = gs.dense[row * (size_t)P + pc];
+      } else {
+        const int g = pc / gs.S;
+        d = (gs.arg[row * (size_t)G + g] == pc - g * gs.S) ? gs.pooled[row * (size_t)G + g] : 0.f;
+      }
+      const float act = yv * bn[co] + bn[cout + co];
+      float v = bwdc[co] * (act > 0.f ? d : 0.f) + bwdc[cout + co] + bwdc[2 * cout + co] * yv;
+      if (!valid) v = 0.f;
+      int f = head0;
+      float pv; int pf;
+      pv = dpp_row_f<0x111>(v); pf = dpp_row_i<0x111>(1, f); v = f ? v : v + pv; f |= pf;
+      pv = dpp_row_f<0x112>(v); pf = dpp_row_i<0x112>(1, f); v = f ? v : v + pv; f |= pf;
+      pv = dpp_row_f<0x114>(v); pf = dpp_row_i<0x114>(1, f); v = f ? v : v + pv; f |= pf;
+      pv = dpp_row_f<0x118>(v); pf = dpp_row_i<0x118>(1, f); v = f ? v : v + pv; f |= pf;
+      if (valid && tail) atomicAdd(&acc[ch * n + ii], v);
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < nch * n; i += 256) out[((size_t)b * cout + c0) * n + i] = acc[i];
 }
 
 // ============================================================================================
@@ -411,7 +572,8 @@ template <int M_T, int N_T, int WM, int WN>
 __global__ __launch_bounds__(kThreads) void pw_dgrad_kernel(
     int cin_total, int ci_off, int m_rows, int cout, int P, int tiles_per_cloud,
     const float* __restrict__ w, const float* __restrict__ y, GradSrc gs, const float* __restrict__ bn,
-    const float* __restrict__ bwdc, float* __restrict__ dx) {
+    const float* __restrict__ bwdc, float* __restrict__ dx, const float* __restrict__ y_in,
+    const float* __restrict__ bn_in, float* __restrict__ part_g, float* __restrict__ part_gy, int nt_total) {
   using T = Tile<M_T, N_T, WM, WN>;
   constexpr int TM = T::TM, TN = T::TN;
   constexpr int NA = kKT * M_T / kThreads;
@@ -423,41 +585,37 @@ __global__ __launch_bounds__(kThreads) void pw_dgrad_kernel(
   const int b = blockIdx.x / tiles_per_cloud;
   const int p0 = (blockIdx.x - b * tiles_per_cloud) * N_T;
   const int m0 = blockIdx.y * M_T;
-  const float* scale = bn;
-  const float* shift = bn + cout;
-  const float* ca = bwdc;
-  const float* cb = bwdc + cout;
-  const float* cc = bwdc + 2 * cout;
-
   float areg[NA];
-  float4 breg[NB];
+  DyRaw braw[NB];
   auto load_chunk = [&](int k0) {
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
       const int e = tid + kThreads * i;
-      const int k = k0 + e / M_T, m = m0 + e % M_T;
-      areg[i] = (k < cout && m < m_rows) ? w[(size_t)k * cin_total + ci_off + m] : 0.f;
+      const int k = min(k0 + e / M_T, cout - 1), m = min(m0 + e % M_T, m_rows - 1);
+      areg[i] = w[(size_t)k * cin_total + ci_off + m];
     }
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
       const int e = tid + kThreads * i;
-      const int k = k0 + e / (N_T / 4), p = p0 + (e % (N_T / 4)) * 4;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (k < cout && p < P)
-        v = make_dy4(gs, y, (size_t)b * cout + k, P, p, scale[k], shift[k], ca[k], cb[k], cc[k]);
-      breg[i] = v;
+      const int k = min(k0 + e / (N_T / 4), cout - 1), p = min(p0 + (e % (N_T / 4)) * 4, P - 4);
+      load_dy_raw(braw[i], gs, y, (size_t)b * cout + k, P, p, k, bn, bwdc, cout);
     }
   };
-  auto store_chunk = [&](int buf) {
+  auto store_chunk = [&](int buf, int k0) {
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
       const int e = tid + kThreads * i;
-      As[buf][e / M_T][e % M_T] = areg[i];
+      const bool ok = (k0 + e / M_T < cout) && (m0 + e % M_T < m_rows);
+      As[buf][e / M_T][e % M_T] = ok ? areg[i] : 0.f;
     }
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
       const int e = tid + kThreads * i;
-      *reinterpret_cast<float4*>(&Bs[buf][e / (N_T / 4)][(e % (N_T / 4)) * 4]) = breg[i];
+      const int p = p0 + (e % (N_T / 4)) * 4;
+      const bool ok = (k0 + e / (N_T / 4) < cout) && (p < P);
+      float4 v = finish_dy(braw[i], gs, min(p, P - 4));
+      if (!ok) v = zero4();
+      *reinterpret_cast<float4*>(&Bs[buf][e / (N_T / 4)][(e % (N_T / 4)) * 4]) = v;
     }
   };
 
@@ -473,37 +631,77 @@ __global__ __launch_bounds__(kThreads) void pw_dgrad_kernel(
   const int a_col0 = (wv / WN) * TM * 32, b_col0 = (wv % WN) * TN * 32;
   const int nchunks = (cout + kKT - 1) / kKT;
   load_chunk(0);
-  store_chunk(0);
+  store_chunk(0, 0);
   __syncthreads();
   for (int t = 0; t < nchunks; ++t) {
     const int buf = t & 1;
     if (t + 1 < nchunks) load_chunk((t + 1) * kKT);
     mma_chunk<kKT, TM, TN, M_T, N_T>(&As[buf][0][0], &Bs[buf][0][0], a_col0, b_col0, acc);
-    if (t + 1 < nchunks) store_chunk(buf ^ 1);
+    if (t + 1 < nchunks) store_chunk(buf ^ 1, (t + 1) * kKT);
     __syncthreads();
   }
+  // ---- epilogue: store dA of the producing layer; optionally reduce that layer's BN-backward statistics
+  // (sum g, sum g*y with g = dA * [relu active]) so it needs no separate pass over (dA, y) ----------------
   const int lane = lane_id();
   float* dxb = dx + (size_t)b * m_rows * P;
+  const bool full_tile = (m0 + M_T <= m_rows) && (p0 + N_T <= P);  // workgroup-uniform
+  const bool stats = part_g != nullptr;
+  const float* yin_b = stats ? y_in + (size_t)b * m_rows * P : nullptr;
+  float* red = &As[0][0][0];  // reuse LDS: [WN][M_T][2]
 #pragma unroll
   for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const int row = m0 + a_col0 + tm * 32 + mfma_row(r, lane);
+      const int row_l = a_col0 + tm * 32 + mfma_row(r, lane);
+      const int row = m0 + row_l;
+      float sg = 0.f, sgy = 0.f;
+      float sc = 0.f, sh = 0.f;
+      if (stats) { const int rc = min(row, m_rows - 1); sc = bn_in[rc]; sh = bn_in[m_rows + rc]; }
 #pragma unroll
       for (int tn = 0; tn < TN; ++tn) {
         const int col = p0 + b_col0 + tn * 32 + (lane & 31);
-        if (row < m_rows && col < P) dxb[(size_t)row * P + col] = acc[tm][tn][r];
+        const float v = acc[tm][tn][r];
+        if (full_tile || (row < m_rows && col < P)) {
+          dxb[(size_t)row * P + col] = v;
+          if (stats) {
+            const float yv = yin_b[(size_t)row * P + col];
+            const float gq = (yv * sc + sh > 0.f) ? v : 0.f;
+            sg += gq;
+            sgy += gq * yv;
+          }
+        }
+      }
+      if (stats) {
+        sg = half_wave_sum(sg);
+        sgy = half_wave_sum(sgy);
+        if ((lane & 31) == 31) {
+          red[((wv % WN) * M_T + row_l) * 2 + 0] = sg;
+          red[((wv % WN) * M_T + row_l) * 2 + 1] = sgy;
+        }
       }
     }
+  if (stats) {
+    __syncthreads();
+    for (int rl = tid; rl < M_T; rl += kThreads) {
+      const int row = m0 + rl;
+      if (row < m_rows) {
+        float a = 0.f, c = 0.f;
+#pragma unroll
+        for (int wn = 0; wn < WN; ++wn) { a += red[(wn * M_T + rl) * 2 + 0]; c += red[(wn * M_T + rl) * 2 + 1]; }
+        part_g[(size_t)row * nt_total + blockIdx.x] = a;
+        part_gy[(size_t)row * nt_total + blockIdx.x] = c;
+      }
+    }
+  }
 }
 
 // ============================================================================================
 // wgrad:  dWpart[split][co][ci] = sum_{p in split} dY[b][co][p] * act(x[b][ci][p])
 // ============================================================================================
 // grid: (splits_per_cloud * B, ceil(cout / M_T), ceil(cin / N_T)); K = points of one split
-template <int M_T, int N_T, int WM, int WN>
+template <int M_T, int N_T, int WM, int WN, bool GATHER>
 __global__ __launch_bounds__(kThreads) void pw_wgrad_kernel(
-    int cin, int cout, int P, int splits_per_cloud, int split_len, const float* __restrict__ x,
+    int cin, int cout, int P, int splits_per_cloud, int split_len, const float* __restrict__ x, GatherSrc gsrc,
     const float* __restrict__ in_scale, const float* __restrict__ in_shift, const float* __restrict__ y,
     GradSrc gs, const float* __restrict__ bn, const float* __restrict__ bwdc, float* __restrict__ dw_part) {
   using T = Tile<M_T, N_T, WM, WN>;
@@ -521,54 +719,60 @@ __global__ __launch_bounds__(kThreads) void pw_wgrad_kernel(
   const int pbeg = sp * split_len;
   const int pend = min(pbeg + split_len, P);
   const int m0 = blockIdx.y * M_T, n0 = blockIdx.z * N_T;
-  const float* scale = bn;
-  const float* shift = bn + cout;
-  const float* ca = bwdc;
-  const float* cb = bwdc + cout;
-  const float* cc = bwdc + 2 * cout;
   const bool has_bn = in_scale != nullptr;
 
-  float4 areg[NA], breg[NB];
+  DyRaw araw[NA];
+  float4 braw[NB];
+  float bsc[NB], bsh[NB];
+  int4 gidx[NB];  // GATHER: neighbour indices, loaded one chunk ahead of their use
+  auto load_gidx = [&](int pk) {
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+      const int e = tid + kThreads * i;
+      const int p = max(min(pk + (e % (kKTW / 4)) * 4, pend - 4), 0);
+      gidx[i] = gather_idx4(gsrc, b, P, p);
+    }
+  };
   auto load_chunk = [&](int pk) {
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
       const int e = tid + kThreads * i;
-      const int m = m0 + e / (kKTW / 4), p = pk + (e % (kKTW / 4)) * 4;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (m < cout && p < pend)
-        v = make_dy4(gs, y, (size_t)b * cout + m, P, p, scale[m], shift[m], ca[m], cb[m], cc[m]);
-      areg[i] = v;
+      const int m = min(m0 + e / (kKTW / 4), cout - 1), p = max(min(pk + (e % (kKTW / 4)) * 4, pend - 4), 0);
+      load_dy_raw(araw[i], gs, y, (size_t)b * cout + m, P, p, m, bn, bwdc, cout);
     }
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
       const int e = tid + kThreads * i;
-      const int n = n0 + e / (kKTW / 4), p = pk + (e % (kKTW / 4)) * 4;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (n < cin && p < pend) {
-        v = *reinterpret_cast<const float4*>(x + ((size_t)b * cin + n) * P + p);
-        if (has_bn) {
-          const float s = in_scale[n], h = in_shift[n];
-          v.x = fmaxf(v.x * s + h, 0.f); v.y = fmaxf(v.y * s + h, 0.f);
-          v.z = fmaxf(v.z * s + h, 0.f); v.w = fmaxf(v.w * s + h, 0.f);
-        }
+      const int n = min(n0 + e / (kKTW / 4), cin - 1), p = max(min(pk + (e % (kKTW / 4)) * 4, pend - 4), 0);
+      if (GATHER) {
+        braw[i] = gather4(gsrc, b, n, P, p, gidx[i]);
+      } else {
+        braw[i] = *reinterpret_cast<const float4*>(x + ((size_t)b * cin + n) * P + p);
+        if (has_bn) { bsc[i] = in_scale[n]; bsh[i] = in_shift[n]; }
       }
-      breg[i] = v;
     }
+    if (GATHER) load_gidx(pk + kKTW);
   };
-  auto store_chunk = [&](int buf) {
+  auto store_chunk = [&](int buf, int pk) {
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
       const int e = tid + kThreads * i;
       const int m = e / (kKTW / 4), k = (e % (kKTW / 4)) * 4;
-      As[buf][k + 0][m] = areg[i].x; As[buf][k + 1][m] = areg[i].y;
-      As[buf][k + 2][m] = areg[i].z; As[buf][k + 3][m] = areg[i].w;
+      const int p = pk + k;
+      const bool ok = (m0 + m < cout) && (p < pend);
+      float4 v = finish_dy(araw[i], gs, max(min(p, pend - 4), 0));
+      if (!ok) v = zero4();
+      As[buf][k + 0][m] = v.x; As[buf][k + 1][m] = v.y; As[buf][k + 2][m] = v.z; As[buf][k + 3][m] = v.w;
     }
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
       const int e = tid + kThreads * i;
       const int n = e / (kKTW / 4), k = (e % (kKTW / 4)) * 4;
-      Bs[buf][k + 0][n] = breg[i].x; Bs[buf][k + 1][n] = breg[i].y;
-      Bs[buf][k + 2][n] = breg[i].z; Bs[buf][k + 3][n] = breg[i].w;
+      const bool ok = (n0 + n < cin) && (pk + k < pend);
+      float4 v = braw[i];
+      if (!GATHER && has_bn) v = bn_relu4(v, bsc[i], bsh[i]);
+      if (!ok) v = zero4();
+      Bs[buf][k + 0][n] = v.x; Bs[buf][k + 1][n] = v.y; Bs[buf][k + 2][n] = v.z; Bs[buf][k + 3][n] = v.w;
     }
   };
 
@@ -584,15 +788,16 @@ __global__ __launch_bounds__(kThreads) void pw_wgrad_kernel(
   const int a_col0 = (wv / WN) * TM * 32, b_col0 = (wv % WN) * TN * 32;
   const int nchunks = (pend - pbeg + kKTW - 1) / kKTW;
   if (nchunks > 0) {
+    if (GATHER) load_gidx(pbeg);
     load_chunk(pbeg);
-    store_chunk(0);
+    store_chunk(0, pbeg);
   }
   __syncthreads();
   for (int t = 0; t < nchunks; ++t) {
     const int buf = t & 1;
     if (t + 1 < nchunks) load_chunk(pbeg + (t + 1) * kKTW);
     mma_chunk<kKTW, TM, TN, LDA, LDB>(&As[buf][0][0], &Bs[buf][0][0], a_col0, b_col0, acc);
-    if (t + 1 < nchunks) store_chunk(buf ^ 1);
+    if (t + 1 < nchunks) store_chunk(buf ^ 1, pbeg + (t + 1) * kKTW);
     __syncthreads();
   }
   const int lane = lane_id();
@@ -646,8 +851,8 @@ enum TileCfg { kCfg128x128, kCfg64x128, kCfg64x64, kCfg32x256 };
 inline TileCfg pick_cfg(int b, int m, int P) {
   if (m <= 32) return kCfg32x256;
   const long long n128 = (long long)b * ceil_div(P, 128);
-  if (m > 64 && n128 * ceil_div(m, 128) >= 256) return kCfg128x128;
-  if (n128 * ceil_div(m, 64) >= 256) return kCfg64x128;
+  if (m > 64 && n128 * ceil_div(m, 128) >= 512) return kCfg128x128;
+  if (n128 * ceil_div(m, 64) >= 512) return kCfg64x128;
   return kCfg64x64;
 }
 inline int cfg_nt(TileCfg c) { return c == kCfg32x256 ? 256 : (c == kCfg64x64 ? 64 : 128); }
@@ -681,17 +886,23 @@ int istnet_pw_stat_tiles(int b, int cout, int p) {
   return b * ceil_div(p, cfg_nt(pick_cfg(b, cout, p)));
 }
 
-int istnet_pw_forward(int b, int cin, int cout, int p, const float* x, const float* wt,
-                      const float* in_scale, const float* in_shift, float* y, float* part_sum,
-                      float* part_sq, void* stream) {
+static int launch_pw_forward(bool gather, int b, int cin, int cout, int p, const float* x, const GatherSrc& g,
+                             const float* w, const float* in_scale, const float* in_shift, float* y,
+                             float* part_sum, float* part_sq, void* stream) {
   if (b <= 0 || cin <= 0 || cout <= 0 || p <= 0 || (p & 3)) return ISTNET_PN2_EINVAL;
   const TileCfg cfg = pick_cfg(b, cout, p);
   const int tpc = ceil_div(p, cfg_nt(cfg));
   const dim3 grid(tpc * b, ceil_div(cout, cfg_mt(cfg)));
   const int nt = tpc * b;
-#define ISTNET_FWD(MT, NT, WM, WN)                                                                        \
-  hipLaunchKernelGGL((pw_fwd_kernel<MT, NT, WM, WN>), grid, dim3(kThreads), 0, as_stream(stream), cin,    \
-                     cout, p, tpc, x, wt, in_scale, in_shift, y, part_sum, part_sq, nt)
+#define ISTNET_FWD(MT, NT, WM, WN)                                                                          \
+  do {                                                                                                      \
+    if (gather)                                                                                             \
+      hipLaunchKernelGGL((pw_fwd_kernel<MT, NT, WM, WN, true>), grid, dim3(kThreads), 0, as_stream(stream), \
+                         cin, cout, p, tpc, x, g, w, in_scale, in_shift, y, part_sum, part_sq, nt);        \
+    else                                                                                                    \
+      hipLaunchKernelGGL((pw_fwd_kernel<MT, NT, WM, WN, false>), grid, dim3(kThreads), 0, as_stream(stream), \
+                         cin, cout, p, tpc, x, g, w, in_scale, in_shift, y, part_sum, part_sq, nt);        \
+  } while (0)
   switch (cfg) {
     case kCfg128x128: ISTNET_FWD(128, 128, 2, 2); break;
     case kCfg64x128: ISTNET_FWD(64, 128, 2, 2); break;
@@ -700,6 +911,22 @@ int istnet_pw_forward(int b, int cin, int cout, int p, const float* x, const flo
   }
 #undef ISTNET_FWD
   return (int)hipGetLastError();
+}
+
+int istnet_pw_forward(int b, int cin, int cout, int p, const float* x, const float* w,
+                      const float* in_scale, const float* in_shift, float* y, float* part_sum,
+                      float* part_sq, void* stream) {
+  return launch_pw_forward(false, b, cin, cout, p, x, GatherSrc{}, w, in_scale, in_shift, y, part_sum, part_sq,
+                           stream);
+}
+
+int istnet_pw_forward_gather(int b, int n, int npoint, int nsample, int cfeat, int cout, const float* xyz,
+                             const float* new_xyz, const float* feat, const int* idx, const float* w,
+                             float* y, float* part_sum, float* part_sq, void* stream) {
+  if (n <= 0 || npoint <= 0 || nsample <= 0 || (nsample & 3) || cfeat < 0) return ISTNET_PN2_EINVAL;
+  const GatherSrc g{xyz, new_xyz, feat, idx, n, nsample, cfeat};
+  return launch_pw_forward(true, b, 3 + cfeat, cout, npoint * nsample, nullptr, g, w, nullptr, nullptr, y,
+                           part_sum, part_sq, stream);
 }
 
 int istnet_bn_finalize_fwd(int c, int nt, double count, const float* part_sum, const float* part_sq,
@@ -765,8 +992,10 @@ int istnet_bn_finalize_bwd(int c, int nt, double count, int training, const floa
 
 int istnet_pw_dgrad(int b, int cin_total, int ci_off, int m_rows, int cout, int p, int nsample,
                     const float* w, const float* y, const float* d_dense, const float* d_pooled,
-                    const unsigned char* arg, const float* bn, const float* bwdc, float* dx, void* stream) {
+                    const unsigned char* arg, const float* bn, const float* bwdc, float* dx, const float* y_in,
+                    const float* bn_in, float* part_g, float* part_gy, void* stream) {
   if (b <= 0 || m_rows <= 0 || cout <= 0 || p <= 0 || (p & 3)) return ISTNET_PN2_EINVAL;
+  if (part_g != nullptr && (y_in == nullptr || bn_in == nullptr || part_gy == nullptr)) return ISTNET_PN2_EINVAL;
   if (d_dense == nullptr && (d_pooled == nullptr || arg == nullptr || nsample <= 0 || (nsample & 3)))
     return ISTNET_PN2_EINVAL;
   GradSrc gs{d_dense, d_pooled, arg, nsample};
@@ -775,7 +1004,8 @@ int istnet_pw_dgrad(int b, int cin_total, int ci_off, int m_rows, int cout, int 
   const dim3 grid(tpc * b, ceil_div(m_rows, cfg_mt(cfg)));
 #define ISTNET_DGRAD(MT, NT, WM, WN)                                                                       \
   hipLaunchKernelGGL((pw_dgrad_kernel<MT, NT, WM, WN>), grid, dim3(kThreads), 0, as_stream(stream),       \
-                     cin_total, ci_off, m_rows, cout, p, tpc, w, y, gs, bn, bwdc, dx)
+                     cin_total, ci_off, m_rows, cout, p, tpc, w, y, gs, bn, bwdc, dx, y_in, bn_in, part_g, part_gy, \
+                     tpc * b)
   switch (cfg) {
     case kCfg128x128: ISTNET_DGRAD(128, 128, 2, 2); break;
     case kCfg64x128: ISTNET_DGRAD(64, 128, 2, 2); break;
@@ -786,14 +1016,31 @@ int istnet_pw_dgrad(int b, int cin_total, int ci_off, int m_rows, int cout, int 
   return (int)hipGetLastError();
 }
 
+int istnet_pw_scatter_dy(int b, int cout, int n, int p, int nsample, const float* y, const float* d_dense,
+                         const float* d_pooled, const unsigned char* arg, const float* bn, const float* bwdc,
+                         const int* idx, float* out, void* stream) {
+  if (b <= 0 || cout <= 0 || n <= 0 || p <= 0) return ISTNET_PN2_EINVAL;
+  if (d_dense == nullptr && (d_pooled == nullptr || arg == nullptr || nsample <= 0)) return ISTNET_PN2_EINVAL;
+  const size_t lds = (size_t)kScatterCH * n * 4;
+  if (lds > 64 * 1024) return ISTNET_PN2_EINVAL;
+  GradSrc gs{d_dense, d_pooled, arg, nsample};
+  hipLaunchKernelGGL(pw_scatter_dy_kernel, dim3(ceil_div(cout, kScatterCH), b), dim3(256), lds,
+                     as_stream(stream), cout, n, p, y, gs, bn, bwdc, idx, out);
+  return (int)hipGetLastError();
+}
+
+int istnet_pw_dgrad_stat_tiles(int b, int m_rows, int p) {
+  return b * ceil_div(p, cfg_nt(pick_cfg(b, m_rows, p)));
+}
+
 int istnet_pw_wgrad_splits(int b, int cin, int cout, int p) {
   return b * ceil_div(p, wgrad_split_len(b, cin, cout, p));
 }
 
-int istnet_pw_wgrad(int b, int cin, int cout, int p, int nsample, const float* x, const float* in_scale,
-                    const float* in_shift, const float* y, const float* d_dense, const float* d_pooled,
-                    const unsigned char* arg, const float* bn, const float* bwdc, float* dw_part,
-                    void* stream) {
+static int launch_pw_wgrad(bool gather, int b, int cin, int cout, int p, int nsample, const float* x,
+                           const GatherSrc& g, const float* in_scale, const float* in_shift, const float* y,
+                           const float* d_dense, const float* d_pooled, const unsigned char* arg, const float* bn,
+                           const float* bwdc, float* dw_part, void* stream) {
   if (b <= 0 || cin <= 0 || cout <= 0 || p <= 0 || (p & 3)) return ISTNET_PN2_EINVAL;
   if (d_dense == nullptr && (d_pooled == nullptr || arg == nullptr || nsample <= 0 || (nsample & 3)))
     return ISTNET_PN2_EINVAL;
@@ -802,15 +1049,40 @@ int istnet_pw_wgrad(int b, int cin, int cout, int p, int nsample, const float* x
   const int spc = ceil_div(p, len);
   const int mt = wgrad_mt(cout), nt = wgrad_nt(cin);
   const dim3 grid(spc * b, ceil_div(cout, mt), ceil_div(cin, nt));
-#define ISTNET_WGRAD(MT, NT)                                                                                \
-  hipLaunchKernelGGL((pw_wgrad_kernel<MT, NT, 2, 2>), grid, dim3(kThreads), 0, as_stream(stream), cin, cout, \
-                     p, spc, len, x, in_scale, in_shift, y, gs, bn, bwdc, dw_part)
+#define ISTNET_WGRAD(MT, NT)                                                                                  \
+  do {                                                                                                        \
+    if (gather)                                                                                               \
+      hipLaunchKernelGGL((pw_wgrad_kernel<MT, NT, 2, 2, true>), grid, dim3(kThreads), 0, as_stream(stream),   \
+                         cin, cout, p, spc, len, x, g, in_scale, in_shift, y, gs, bn, bwdc, dw_part);         \
+    else                                                                                                      \
+      hipLaunchKernelGGL((pw_wgrad_kernel<MT, NT, 2, 2, false>), grid, dim3(kThreads), 0, as_stream(stream),  \
+                         cin, cout, p, spc, len, x, g, in_scale, in_shift, y, gs, bn, bwdc, dw_part);         \
+  } while (0)
   if (mt == 128 && nt == 128) ISTNET_WGRAD(128, 128);
   else if (mt == 128) ISTNET_WGRAD(128, 64);
   else if (nt == 128) ISTNET_WGRAD(64, 128);
   else ISTNET_WGRAD(64, 64);
 #undef ISTNET_WGRAD
   return (int)hipGetLastError();
+}
+
+int istnet_pw_wgrad(int b, int cin, int cout, int p, int nsample, const float* x, const float* in_scale,
+                    const float* in_shift, const float* y, const float* d_dense, const float* d_pooled,
+                    const unsigned char* arg, const float* bn, const float* bwdc, float* dw_part,
+                    void* stream) {
+  return launch_pw_wgrad(false, b, cin, cout, p, nsample, x, GatherSrc{}, in_scale, in_shift, y, d_dense,
+                         d_pooled, arg, bn, bwdc, dw_part, stream);
+}
+
+int istnet_pw_wgrad_gather(int b, int n, int npoint, int nsample, int cfeat, int cout, int grad_nsample,
+                           const float* xyz, const float* new_xyz, const float* feat, const int* idx,
+                           const float* y, const float* d_dense, const float* d_pooled,
+                           const unsigned char* arg, const float* bn, const float* bwdc, float* dw_part,
+                           void* stream) {
+  if (n <= 0 || npoint <= 0 || nsample <= 0 || (nsample & 3) || cfeat < 0) return ISTNET_PN2_EINVAL;
+  const GatherSrc g{xyz, new_xyz, feat, idx, n, nsample, cfeat};
+  return launch_pw_wgrad(true, b, 3 + cfeat, cout, npoint * nsample, grad_nsample, nullptr, g, nullptr, nullptr, y,
+                         d_dense, d_pooled, arg, bn, bwdc, dw_part, stream);
 }
 
 int istnet_pw_wgrad_reduce(int count, int splits, const float* dw_part, float* dw, void* stream) {

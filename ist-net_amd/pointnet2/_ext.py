@@ -128,11 +128,23 @@ def three_interpolate_grad(grad_out, idx, weight, m):
     _is_float(grad_out, "grad_out"); _is_int(idx, "idx"); _is_float(weight, "weight")
     dev = _device_of(grad_out, "grad_out", (idx, "idx"), (weight, "weight"))
     b, c, n = grad_out.shape
-    out = torch.empty((b, c, int(m)), dtype=torch.float32, device=dev)
+    m = int(m)
+    out = torch.empty((b, c, m), dtype=torch.float32, device=dev)
+    lib = _native.lib()
     with torch.cuda.device(dev):
-        _native.check(_native.lib().istnet_pn2_three_interpolate_grad(
-            b, c, n, int(m), _ptr(grad_out), _ptr(idx), _ptr(weight), _ptr(out), _stream(dev)),
-            "three_interpolate_grad")
+        if 3 * m + 257 <= 16384:
+            # deterministic gather over per-cloud inverse lists (built once per call, reused by all channels)
+            offsets = torch.empty((b, m + 1), dtype=torch.int32, device=dev)
+            entries = torch.empty((b, 3 * n), dtype=torch.int32, device=dev)
+            _native.check(lib.istnet_pn2_interp_csr_build(b, n, m, _ptr(idx), _ptr(offsets), _ptr(entries),
+                                                          _stream(dev)), "interp_csr_build")
+            _native.check(lib.istnet_pn2_three_interpolate_grad_csr(
+                b, c, n, m, _ptr(grad_out), _ptr(weight), _ptr(offsets), _ptr(entries), _ptr(out), _stream(dev)),
+                "three_interpolate_grad_csr")
+        else:
+            _native.check(lib.istnet_pn2_three_interpolate_grad(
+                b, c, n, m, _ptr(grad_out), _ptr(idx), _ptr(weight), _ptr(out), _stream(dev)),
+                "three_interpolate_grad")
     return out
 
 

@@ -33,15 +33,33 @@ else:
         return torch.empty(shape, dtype=dtype, device=device)
 
 
-def _kname(base, cfg):
+def _kname(base, cfg, gather=None):
     """Kernel symbol as rocprofv3 prints it, e.g. pw_dgrad_kernel<128, 128, 2, 2>."""
     mt, nt = cfg // 1000, cfg % 1000
     wm, wn = (1, 4) if mt == 32 else (2, 2)
-    return f"{base}<{mt}, {nt}, {wm}, {wn}>"
+    tail = "" if gather is None else (", true" if gather else ", false")
+    return f"{base}<{mt}, {nt}, {wm}, {wn}{tail}>"
 
 
 def _st(dev):
     return torch.cuda.current_stream(dev).cuda_stream
+
+
+# Weight gradients are off the critical path of backward (nothing consumes dW before the optimizer), so
+# the wgrad GEMM + split-K reduce of every layer CAN run on a second HIP stream, concurrently with the
+# dgrad chain on the caller's stream (the caller's stream waits for them before backward returns).
+# Measured on MI355X (B=32 encoder, eager and HIP-graph replay): 6.30 ms/step with the side stream vs
+# 6.11 ms without -- both GEMM families are HBM/L2 heavy and only evict each other -- so it is off by
+# default and kept as an opt-in experiment (ISTNET_WGRAD_SIDE_STREAM=1).
+_SIDE_STREAMS = {}
+USE_SIDE_STREAM = os.environ.get("ISTNET_WGRAD_SIDE_STREAM") == "1"
+
+
+def _side_stream(dev):
+    key = dev.index if dev.index is not None else torch.cuda.current_device()
+    if key not in _SIDE_STREAMS:
+        _SIDE_STREAMS[key] = torch.cuda.Stream(device=dev)
+    return _SIDE_STREAMS[key]
 
 
 def _p(t):
@@ -59,6 +77,177 @@ class _Layer:
         self.eps = bn.eps
 
 
+class _Gather:
+    """Layer-0 input of a set-abstraction scale described by its sources instead of a grouped tensor."""
+    __slots__ = ("xyz", "new_xyz", "feat", "idx", "n", "npoint", "nsample", "cfeat")
+
+    def __init__(self, xyz, new_xyz, feat, idx):
+        self.xyz, self.new_xyz, self.feat, self.idx = xyz, new_xyz, feat, idx
+        self.n = xyz.shape[1]
+        self.npoint, self.nsample = idx.shape[1], idx.shape[2]
+        self.cfeat = 0 if feat is None else feat.shape[1]
+
+
+def _forward_stack(lib, dev, st, b, c0, g, s, x, gather, training, layers, params):
+    """Runs all layers + the BN/ReLU/max tail.  Returns (out, arg, ys, bns)."""
+    p = g * s
+    ys, bns = [], []
+    cur, cur_c, in_bn = x, c0, None
+    for li, lay in enumerate(layers):
+        w, gamma, beta = params[3 * li], params[3 * li + 1], params[3 * li + 2]
+        cout = w.shape[0]
+        w2 = w.reshape(cout, cur_c)
+        y = _empty((b, cout, p), torch.float32, dev)
+        bn = _empty((4, cout), torch.float32, dev)
+        if training:
+            nt = lib.istnet_pw_stat_tiles(b, cout, p)
+            part = _empty((2, cout, nt), torch.float32, dev)
+            ps, pq = part[0].data_ptr(), part[1].data_ptr()
+        else:
+            nt, ps, pq = 0, None, None
+        kname = _kname("pw_fwd_kernel", lib.istnet_pw_tile_cfg(b, cout, p), gather is not None and li == 0)
+        flops, nbytes = 2.0 * b * p * cur_c * cout, 4.0 * b * p * (cur_c + cout)
+        if li == 0 and gather is not None:
+            ga = gather
+            _native.check(_native.timed(kname, flops, 4.0 * b * p * (1 + cout), lambda: lib.istnet_pw_forward_gather(
+                b, ga.n, ga.npoint, ga.nsample, ga.cfeat, cout, ga.xyz.data_ptr(), ga.new_xyz.data_ptr(),
+                _p(ga.feat), ga.idx.data_ptr(), w2.data_ptr(), y.data_ptr(), ps, pq, st)), "pw_forward_gather")
+        else:
+            sc, sh = (_p(in_bn[0]), _p(in_bn[1])) if in_bn is not None else (None, None)
+            cin_l, src = cur_c, cur
+            _native.check(_native.timed(kname, flops, nbytes, lambda: lib.istnet_pw_forward(
+                b, cin_l, cout, p, src.data_ptr(), w2.data_ptr(), sc, sh, y.data_ptr(), ps, pq, st)), "pw_forward")
+        if training:
+            _native.check(lib.istnet_bn_finalize_fwd(
+                cout, nt, float(b * p), ps, pq, gamma.data_ptr(), beta.data_ptr(), float(lay.eps),
+                float(lay.momentum), _p(lay.running_mean), _p(lay.running_var), bn.data_ptr(), st),
+                "bn_finalize_fwd")
+        else:
+            istd = torch.rsqrt(lay.running_var + lay.eps)
+            bn[0] = gamma * istd
+            bn[1] = beta - lay.running_mean * bn[0]
+            bn[2] = lay.running_mean
+            bn[3] = istd
+        ys.append(y)
+        bns.append(bn)
+        cur, cur_c, in_bn = y, cout, bn
+    out = _empty((b, cur_c, g), torch.float32, dev)
+    arg = _empty((b, cur_c, g), torch.uint8, dev) if s > 1 else None
+    _native.check(lib.istnet_bn_relu_pool(b, cur_c, g, s, cur.data_ptr(), in_bn.data_ptr(), out.data_ptr(),
+                                          _p(arg), st), "bn_relu_pool")
+    return out, arg, ys, bns
+
+
+def _backward_stack(lib, dev, st, b, c0, g, s, x, gather, training, ys, bns, params, arg, dout, need_w, need_x):
+    """Returns (grads for [w, gamma, beta] * L, gradient w.r.t. the layer-0 input or None).
+
+    With `gather`, the layer-0 input gradient is produced for the feature channels only
+    (rows 3..3+cfeat of the grouped tensor), shape (B, cfeat, P)."""
+    p = g * s
+    n = len(ys)
+    grads = [None] * (3 * n)
+    pooled = s > 1
+    d_dense, d_pooled, d_arg = (None, dout, arg) if pooled else (dout, None, None)
+    dx, scattered = None, False
+    ntb = lib.istnet_pw_bwd_stat_tiles(b, p)
+    fused_part, fused_nt = None, 0   # statistics of layer li already reduced by the dgrad of layer li+1
+    main = torch.cuda.current_stream(dev)
+    side = _side_stream(dev) if (USE_SIDE_STREAM and _native.TIMING is None) else None
+    keep = []                        # tensors the side stream reads: kept alive until the final join
+    for li in range(n - 1, -1, -1):
+        w, gamma = params[3 * li], params[3 * li + 1]
+        cout = w.shape[0]
+        cin = c0 if li == 0 else params[3 * (li - 1)].shape[0]
+        w2 = w.reshape(cout, cin)
+        y, bn = ys[li], bns[li]
+        ns_arg = s if pooled and li == n - 1 else 0
+        dd, dp, da = _p(d_dense), _p(d_pooled), _p(d_arg)
+        grad_elems = b * cout * (p if dd is not None else p // s)
+        if fused_part is not None:
+            part, nt_l = fused_part, fused_nt
+        else:
+            part, nt_l = _empty((2, cout, ntb), torch.float32, dev), ntb
+            _native.check(lib.istnet_pw_bwd_stats(b, cout, p, ns_arg, y.data_ptr(), dd, dp, da, bn.data_ptr(),
+                                                  part[0].data_ptr(), part[1].data_ptr(), st), "pw_bwd_stats")
+        fused_part = None
+        dgamma = _empty(cout, torch.float32, dev)
+        dbeta = _empty(cout, torch.float32, dev)
+        bwdc = _empty((3, cout), torch.float32, dev)
+        _native.check(lib.istnet_bn_finalize_bwd(
+            cout, nt_l, float(b * p), 1 if training else 0, part[0].data_ptr(), part[1].data_ptr(),
+            gamma.data_ptr(), bn.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), bwdc.data_ptr(), st),
+            "bn_finalize_bwd")
+        grads[3 * li + 1] = dgamma
+        grads[3 * li + 2] = dbeta
+        use_gather = li == 0 and gather is not None
+        if need_w[li]:
+            wst = st
+            if side is not None:
+                ready = torch.cuda.Event()
+                ready.record(main)
+                side.wait_event(ready)
+                wst = side.cuda_stream
+                keep += [y, d_dense, d_pooled, d_arg, bn, bwdc]
+            splits = lib.istnet_pw_wgrad_splits(b, cin, cout, p)
+            ws = _empty((splits, cout, cin), torch.float32, dev)
+            dw = _empty((cout, cin), torch.float32, dev)
+            kname = _kname("pw_wgrad_kernel", lib.istnet_pw_wgrad_tile_cfg(cin, cout), use_gather)
+            flops = 2.0 * b * p * cin * cout
+            if use_gather:
+                ga = gather
+                _native.check(_native.timed(
+                    kname, flops, 4.0 * (b * p * (1 + cout) + grad_elems), lambda: lib.istnet_pw_wgrad_gather(
+                        b, ga.n, ga.npoint, ga.nsample, ga.cfeat, cout, ns_arg, ga.xyz.data_ptr(),
+                        ga.new_xyz.data_ptr(), _p(ga.feat), ga.idx.data_ptr(), y.data_ptr(), dd, dp, da,
+                        bn.data_ptr(), bwdc.data_ptr(), ws.data_ptr(), wst)), "pw_wgrad_gather")
+            else:
+                src = x if li == 0 else ys[li - 1]
+                in_bn = None if li == 0 else bns[li - 1]
+                sc, sh = (_p(in_bn[0]), _p(in_bn[1])) if in_bn is not None else (None, None)
+                _native.check(_native.timed(
+                    kname, flops, 4.0 * (b * p * (cin + cout) + grad_elems), lambda: lib.istnet_pw_wgrad(
+                        b, cin, cout, p, ns_arg, src.data_ptr(), sc, sh, y.data_ptr(), dd, dp, da,
+                        bn.data_ptr(), bwdc.data_ptr(), ws.data_ptr(), wst)), "pw_wgrad")
+            _native.check(lib.istnet_pw_wgrad_reduce(cout * cin, splits, ws.data_ptr(), dw.data_ptr(), wst),
+                          "pw_wgrad_reduce")
+            keep += [ws, dw]
+            grads[3 * li] = dw.view_as(w)
+        if use_gather and need_x and gather.n <= 4096:
+            # feature gradient of the scale: scatter dY0 over the ball indices (Cout0 x n per cloud), then
+            # the small product W0[:, 3:]^T . G  (see pw_scatter_dy_kernel) -- no (B, C, P) tensor, no big dgrad
+            ga = gather
+            gmat = _empty((b, cout, ga.n), torch.float32, dev)
+            _native.check(lib.istnet_pw_scatter_dy(b, cout, ga.n, p, ns_arg, y.data_ptr(), dd, dp, da,
+                                                   bn.data_ptr(), bwdc.data_ptr(), ga.idx.data_ptr(),
+                                                   gmat.data_ptr(), st), "pw_scatter_dy")
+            dx = torch.matmul(w2[:, 3:].t(), gmat)          # (C, Cout0) @ (B, Cout0, n) -> (B, C, n)
+            scattered = True
+        elif li > 0 or need_x:
+            ci_off, rows = (3, gather.cfeat) if use_gather else (0, cin)
+            dprev = _empty((b, rows, p), torch.float32, dev)
+            if li > 0:   # dprev is dA of layer li-1: reduce its BN-backward statistics in the epilogue
+                fused_nt = lib.istnet_pw_dgrad_stat_tiles(b, rows, p)
+                fused_part = _empty((2, rows, fused_nt), torch.float32, dev)
+                y_in, bn_in = ys[li - 1].data_ptr(), bns[li - 1].data_ptr()
+                pg, pgy = fused_part[0].data_ptr(), fused_part[1].data_ptr()
+            else:
+                y_in = bn_in = pg = pgy = None
+            _native.check(_native.timed(
+                _kname("pw_dgrad_kernel", lib.istnet_pw_tile_cfg(b, rows, p)), 2.0 * b * p * rows * cout,
+                4.0 * (b * p * (rows + cout + (rows if li > 0 else 0)) + grad_elems), lambda: lib.istnet_pw_dgrad(
+                    b, cin, ci_off, rows, cout, p, ns_arg, w2.data_ptr(), y.data_ptr(), dd, dp, da,
+                    bn.data_ptr(), bwdc.data_ptr(), dprev.data_ptr(), y_in, bn_in, pg, pgy, st)), "pw_dgrad")
+            d_dense, d_pooled, d_arg = dprev, None, None
+            if li == 0:
+                dx = dprev
+    if side is not None and keep:
+        done = torch.cuda.Event()
+        done.record(side)
+        main.wait_event(done)
+    del keep
+    return grads, dx, scattered
+
+
 class FusedSharedMLPFunction(Function):
     """x (B, C0, G, S) -> (B, C_L, G): conv1x1/BN/ReLU stack followed by a max over S."""
 
@@ -67,55 +256,12 @@ class FusedSharedMLPFunction(Function):
         lib = _native.lib()
         dev = x.device
         b, c0, g, s = x.shape
-        p = g * s
-        st = _st(dev)
-        n_layers = len(layers)
         x = x.contiguous()
-        ys, bns, wts = [], [], []
-        cur, cur_c, in_bn = x, c0, None
         with torch.cuda.device(dev):
-            for li, lay in enumerate(layers):
-                w, gamma, beta = params[3 * li], params[3 * li + 1], params[3 * li + 2]
-                cout = w.shape[0]
-                w2 = w.reshape(cout, cur_c)
-                wt = w2.t().contiguous()
-                y = _empty((b, cout, p), torch.float32, dev)
-                bn = _empty((4, cout), torch.float32, dev)
-                if training:
-                    nt = lib.istnet_pw_stat_tiles(b, cout, p)
-                    part = _empty((2, cout, nt), torch.float32, dev)
-                    ps, pq = part[0].data_ptr(), part[1].data_ptr()
-                else:
-                    nt, ps, pq = 0, None, None
-                sc, sh = (_p(in_bn[0]), _p(in_bn[1])) if in_bn is not None else (None, None)
-                cin_l, src = cur_c, cur
-                _native.check(_native.timed(
-                    _kname("pw_fwd_kernel", lib.istnet_pw_tile_cfg(b, cout, p)), 2.0 * b * p * cin_l * cout,
-                    4.0 * b * p * (cin_l + cout),
-                    lambda: lib.istnet_pw_forward(b, cin_l, cout, p, src.data_ptr(), wt.data_ptr(), sc, sh,
-                                                  y.data_ptr(), ps, pq, st)), "pw_forward")
-                if training:
-                    _native.check(lib.istnet_bn_finalize_fwd(
-                        cout, nt, float(b * p), ps, pq, gamma.data_ptr(), beta.data_ptr(), float(lay.eps),
-                        float(lay.momentum), _p(lay.running_mean), _p(lay.running_var), bn.data_ptr(), st),
-                        "bn_finalize_fwd")
-                else:
-                    istd = torch.rsqrt(lay.running_var + lay.eps)
-                    bn[0] = gamma * istd
-                    bn[1] = beta - lay.running_mean * bn[0]
-                    bn[2] = lay.running_mean
-                    bn[3] = istd
-                ys.append(y)
-                bns.append(bn)
-                wts.append(w2)
-                cur, cur_c, in_bn = y, cout, bn
-            out = _empty((b, cur_c, g), torch.float32, dev)
-            arg = _empty((b, cur_c, g), torch.uint8, dev) if s > 1 else None
-            _native.check(lib.istnet_bn_relu_pool(b, cur_c, g, s, cur.data_ptr(), in_bn.data_ptr(),
-                                                  out.data_ptr(), _p(arg), st), "bn_relu_pool")
+            out, arg, ys, bns = _forward_stack(lib, dev, _st(dev), b, c0, g, s, x, None, training, layers, params)
         ctx.training = training
         ctx.shape = (b, c0, g, s)
-        ctx.n_layers = n_layers
+        ctx.n_layers = len(layers)
         ctx.save_for_backward(x, arg if arg is not None else torch.empty(0, device=dev), *ys, *bns, *params)
         return out
 
@@ -123,72 +269,64 @@ class FusedSharedMLPFunction(Function):
     def backward(ctx, dout):
         lib = _native.lib()
         b, c0, g, s = ctx.shape
-        p = g * s
         n = ctx.n_layers
         saved = ctx.saved_tensors
         x, arg = saved[0], saved[1]
         ys, bns, params = saved[2:2 + n], saved[2 + n:2 + 2 * n], saved[2 + 2 * n:]
         dev = x.device
-        st = _st(dev)
-        dout = dout.contiguous()
-        grads = [None] * (3 * n)
-        pooled = s > 1
-        d_dense, d_pooled, d_arg = (None, dout, arg) if pooled else (dout, None, None)
-        dx = None
+        need_w = [ctx.needs_input_grad[3 + 3 * li] for li in range(n)]
         with torch.cuda.device(dev):
-            ntb = lib.istnet_pw_bwd_stat_tiles(b, p)
-            for li in range(n - 1, -1, -1):
-                w, gamma = params[3 * li], params[3 * li + 1]
-                cout = w.shape[0]
-                cin = c0 if li == 0 else params[3 * (li - 1)].shape[0]
-                w2 = w.reshape(cout, cin)
-                y, bn = ys[li], bns[li]
-                part = _empty((2, cout, ntb), torch.float32, dev)
-                _native.check(lib.istnet_pw_bwd_stats(
-                    b, cout, p, s if pooled and li == n - 1 else 0, y.data_ptr(), _p(d_dense), _p(d_pooled),
-                    _p(d_arg), bn.data_ptr(), part[0].data_ptr(), part[1].data_ptr(), st), "pw_bwd_stats")
-                dgamma = _empty(cout, torch.float32, dev)
-                dbeta = _empty(cout, torch.float32, dev)
-                bwdc = _empty((3, cout), torch.float32, dev)
-                _native.check(lib.istnet_bn_finalize_bwd(
-                    cout, ntb, float(b * p), 1 if ctx.training else 0, part[0].data_ptr(), part[1].data_ptr(),
-                    gamma.data_ptr(), bn.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), bwdc.data_ptr(), st),
-                    "bn_finalize_bwd")
-                src = x if li == 0 else ys[li - 1]
-                in_bn = None if li == 0 else bns[li - 1]
-                ns_arg = s if pooled and li == n - 1 else 0
-                if ctx.needs_input_grad[3 + 3 * li]:
-                    splits = lib.istnet_pw_wgrad_splits(b, cin, cout, p)
-                    ws = _empty((splits, cout, cin), torch.float32, dev)
-                    dw = _empty((cout, cin), torch.float32, dev)
-                    sc, sh = (_p(in_bn[0]), _p(in_bn[1])) if in_bn is not None else (None, None)
-                    dd, dp, da = _p(d_dense), _p(d_pooled), _p(d_arg)
-                    grad_elems = b * cout * (p if dd is not None else p // s)
-                    _native.check(_native.timed(
-                        _kname("pw_wgrad_kernel", lib.istnet_pw_wgrad_tile_cfg(cin, cout)), 2.0 * b * p * cin * cout,
-                        4.0 * (b * p * (cin + cout) + grad_elems),
-                        lambda: lib.istnet_pw_wgrad(b, cin, cout, p, ns_arg, src.data_ptr(), sc, sh, y.data_ptr(),
-                                                    dd, dp, da, bn.data_ptr(), bwdc.data_ptr(), ws.data_ptr(),
-                                                    st)), "pw_wgrad")
-                    _native.check(lib.istnet_pw_wgrad_reduce(cout * cin, splits, ws.data_ptr(), dw.data_ptr(), st),
-                                  "pw_wgrad_reduce")
-                    grads[3 * li] = dw.view_as(w)
-                grads[3 * li + 1] = dgamma
-                grads[3 * li + 2] = dbeta
-                if li > 0 or ctx.needs_input_grad[0]:
-                    dprev = _empty((b, cin, p), torch.float32, dev)
-                    dd, dp, da = _p(d_dense), _p(d_pooled), _p(d_arg)
-                    grad_elems = b * cout * (p if dd is not None else p // s)
-                    _native.check(_native.timed(
-                        _kname("pw_dgrad_kernel", lib.istnet_pw_tile_cfg(b, cin, p)), 2.0 * b * p * cin * cout,
-                        4.0 * (b * p * (cin + cout) + grad_elems),
-                        lambda: lib.istnet_pw_dgrad(b, cin, 0, cin, cout, p, ns_arg, w2.data_ptr(), y.data_ptr(),
-                                                    dd, dp, da, bn.data_ptr(), bwdc.data_ptr(), dprev.data_ptr(),
-                                                    st)), "pw_dgrad")
-                    d_dense, d_pooled, d_arg = dprev, None, None
-                    if li == 0:
-                        dx = dprev.view(b, c0, g, s)
-        return (dx, None, None, *grads)
+            grads, dx, _ = _backward_stack(lib, dev, _st(dev), b, c0, g, s, x, None, ctx.training, ys, bns, params,
+                                           arg, dout.contiguous(), need_w, ctx.needs_input_grad[0])
+        return (dx.view(b, c0, g, s) if dx is not None else None, None, None, *grads)
+
+
+class FusedSAScaleFunction(Function):
+    """One scale of a set-abstraction level without the grouped tensor:
+    (xyz (B,n,3), new_xyz (B,npoint,3), features (B,C,n) | None, idx (B,npoint,nsample) i32) -> (B, C_L, npoint).
+
+    Equals ``max_pool(mlp(QueryAndGroup-output))`` (pointnet2_modules.py:61-69, pointnet2_utils.py:348-358):
+    the gather, the centroid subtraction and the concat happen in the layer-0 operand loaders; the
+    feature gradient is the dgrad of the feature rows followed by the group scatter-add."""
+
+    @staticmethod
+    def forward(ctx, features, xyz, new_xyz, idx, training, layers, *params):
+        lib = _native.lib()
+        dev = xyz.device
+        ga = _Gather(xyz.contiguous(), new_xyz.contiguous(), None if features is None else features.contiguous(),
+                     idx.contiguous())
+        b, g, s = xyz.shape[0], ga.npoint, ga.nsample
+        c0 = 3 + ga.cfeat
+        with torch.cuda.device(dev):
+            out, arg, ys, bns = _forward_stack(lib, dev, _st(dev), b, c0, g, s, None, ga, training, layers, params)
+        ctx.training = training
+        ctx.shape = (b, c0, g, s)
+        ctx.n_layers = len(layers)
+        ctx.has_feat = features is not None
+        feat_saved = ga.feat if ga.feat is not None else torch.empty(0, device=dev)
+        ctx.save_for_backward(feat_saved, ga.xyz, ga.new_xyz, ga.idx, arg, *ys, *bns, *params)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        from . import _ext
+        lib = _native.lib()
+        b, c0, g, s = ctx.shape
+        n = ctx.n_layers
+        saved = ctx.saved_tensors
+        feat, xyz, new_xyz, idx, arg = saved[:5]
+        ys, bns, params = saved[5:5 + n], saved[5 + n:5 + 2 * n], saved[5 + 2 * n:]
+        dev = xyz.device
+        ga = _Gather(xyz, new_xyz, feat if ctx.has_feat else None, idx)
+        need_w = [ctx.needs_input_grad[6 + 3 * li] for li in range(n)]
+        need_x = ctx.has_feat and ctx.needs_input_grad[0]
+        with torch.cuda.device(dev):
+            grads, dxf, scattered = _backward_stack(lib, dev, _st(dev), b, c0, g, s, None, ga, ctx.training, ys,
+                                                    bns, params, arg, dout.contiguous(), need_w, need_x)
+            dfeat = None
+            if need_x:
+                dfeat = dxf if scattered else _ext.group_points_grad(dxf.view(b, ga.cfeat, g, s), idx, ga.n)
+        return (dfeat, None, None, None, None, None, *grads)
 
 
 def _fusable(mlp, x):
@@ -223,14 +361,43 @@ def shared_mlp_maxpool(mlp, x):
     if not _fusable(mlp, x):
         act = mlp(x)
         return torch.nn.functional.max_pool2d(act, kernel_size=[1, act.size(3)]).squeeze(-1)
+    layers, params = _layer_args(mlp)
+    training = mlp.training
+    out = FusedSharedMLPFunction.apply(x, training, layers, *params)
+    if training:
+        torch._foreach_add_([unit.normlayer.bn.num_batches_tracked for unit in mlp], 1)
+    return out
+
+
+def _layer_args(mlp):
     layers, params = [], []
     for unit in mlp:
         bn = unit.normlayer.bn
         layers.append(_Layer(bn))
         params += [unit.conv.weight, bn.weight, bn.bias]
-    training = mlp.training
-    out = FusedSharedMLPFunction.apply(x, training, layers, *params)
-    if training:
-        for unit in mlp:
-            unit.normlayer.bn.num_batches_tracked += 1
+    return layers, params
+
+
+def sa_scale(grouper, mlp, xyz, new_xyz, features):
+    """One MSG scale of a set-abstraction level: ``max_pool(mlp(grouper(xyz, new_xyz, features)))``.
+
+    On CUDA, for a plain QueryAndGroup (use_xyz, no normalisation / resampling / extra returns) and a
+    fusable SharedMLP, the grouped tensor is never built; otherwise the reference composition runs."""
+    from . import pointnet2_utils
+    plain = (isinstance(grouper, pointnet2_utils.QueryAndGroup) and grouper.use_xyz
+             and not (grouper.normalize_xyz or grouper.sample_uniformly or grouper.ret_grouped_xyz
+                      or grouper.ret_unique_cnt))
+    ok = (plain and xyz.is_cuda and xyz.dtype == torch.float32 and not xyz.requires_grad
+          and not new_xyz.requires_grad and grouper.nsample in (4, 8, 16, 32, 64)
+          and (features is None or (features.is_cuda and features.dtype == torch.float32)))
+    if ok:
+        probe = torch.empty((1, 1, 1, grouper.nsample), device=xyz.device)  # shape/dtype probe only
+        ok = _fusable(mlp, probe)
+    if not ok:
+        return shared_mlp_maxpool(mlp, grouper(xyz, new_xyz, features))
+    idx = pointnet2_utils.ball_query(grouper.radius, grouper.nsample, xyz, new_xyz)
+    layers, params = _layer_args(mlp)
+    out = FusedSAScaleFunction.apply(features, xyz, new_xyz, idx, mlp.training, layers, *params)
+    if mlp.training:
+        torch._foreach_add_([unit.normlayer.bn.num_batches_tracked for unit in mlp], 1)
     return out

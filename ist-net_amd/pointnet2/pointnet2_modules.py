@@ -13,7 +13,7 @@ import torch
 import torch.nn as nn
 
 from . import pointnet2_utils, pytorch_utils
-from .fused_mlp import shared_mlp_maxpool
+from .fused_mlp import sa_scale, shared_mlp_maxpool
 
 
 class _PointnetSAModuleBase(nn.Module):
@@ -36,9 +36,9 @@ class _PointnetSAModuleBase(nn.Module):
         new_xyz = self._sample_centroids(xyz)
         pooled = []
         for grouper, mlp in zip(self.groupers, self.mlps):
-            grouped = grouper(xyz, new_xyz, features)                 # (B, C_in, npoint, nsample)
-            # SharedMLP -> max over nsample -> squeeze [ref :65-69]; one fused MFMA node on the GPU
-            pooled.append(shared_mlp_maxpool(mlp, grouped))            # (B, C_out, npoint)
+            # grouper -> SharedMLP -> max over nsample -> squeeze [ref :61-69]: one fused node on the GPU
+            # (ball query kernel + MFMA stack whose layer-0 loader gathers the neighbourhoods)
+            pooled.append(sa_scale(grouper, mlp, xyz, new_xyz, features))   # (B, C_out, npoint)
         return new_xyz, torch.cat(pooled, dim=1)
 
 

@@ -131,3 +131,43 @@ def test_fused_vs_float64(spec, b, g, s):
         err = float((gf[n] - g64[n]).norm() / (g64[n].norm() + 1e-30))
         assert err < 3e-3, (n, err)                       # robust to an isolated arg-max flip
         assert float((gf[n] - g64[n]).abs().median() / g64[n].abs().max()) < 2e-5, n
+
+
+@pytest.mark.parametrize("b,n,npoint,radius,nsample,cfeat,spec", [
+    (4, 512, 128, 0.25, 16, 0, [0, 16, 32]), (4, 512, 128, 0.3, 32, 64, [64, 32, 64]),
+    (2, 256, 64, 0.2, 8, 5, [5, 24, 40]), (32, 128, 64, 0.5, 32, 256, [256, 128, 128, 256]),
+])
+def test_sa_scale_gather_fusion_matches_grouped_path(b, n, npoint, radius, nsample, cfeat, spec):
+    """The gather-in-loader SA scale equals the materialised QueryAndGroup -> SharedMLP -> max path."""
+    from istnet_amd.pointnet2 import pointnet2_utils as pu
+    from istnet_amd.pointnet2.fused_mlp import sa_scale, shared_mlp_maxpool
+    from istnet_amd.pointnet2.pytorch_utils import SharedMLP
+    g = torch.Generator().manual_seed(5)
+    xyz = torch.rand(b, n, 3, generator=g).to(DEV)
+    feat0 = torch.randn(b, cfeat, n, generator=g).to(DEV) if cfeat else None
+    fps = pu.furthest_point_sample(xyz, npoint)
+    new_xyz = pu.gather_operation(xyz.transpose(1, 2).contiguous(), fps).transpose(1, 2).contiguous()
+    grouper = pu.QueryAndGroup(radius, nsample)
+    torch.manual_seed(3)
+    dims = list(spec)
+    dims[0] += 3
+    mlp_a = SharedMLP(list(dims), bn=True).to(DEV).train()
+    mlp_b = SharedMLP(list(dims), bn=True).to(DEV).train()
+    mlp_b.load_state_dict(mlp_a.state_dict())
+    wgt = torch.randn(b, dims[-1], npoint, generator=g).to(DEV)
+
+    def run(fused, mlp):
+        f = feat0.clone().requires_grad_(True) if feat0 is not None else None
+        out = sa_scale(grouper, mlp, xyz, new_xyz, f) if fused else shared_mlp_maxpool(mlp, grouper(xyz, new_xyz, f))
+        (out * wgt).sum().backward()
+        return out.detach(), (f.grad if f is not None else None), {k: p.grad for k, p in mlp.named_parameters()}
+
+    out_f, df_f, g_f = run(True, mlp_a)
+    out_t, df_t, g_t = run(False, mlp_b)
+    torch.testing.assert_close(out_f, out_t, rtol=1e-5, atol=1e-5)
+    if df_t is not None:
+        torch.testing.assert_close(df_f, df_t, rtol=1e-4, atol=1e-4 * float(df_t.abs().max()))
+    for k in g_t:
+        assert float((g_f[k] - g_t[k]).norm() / (g_t[k].norm() + 1e-30)) < 1e-4, k
+    for (ka, va), (kb, vb) in zip(mlp_a.state_dict().items(), mlp_b.state_dict().items()):
+        torch.testing.assert_close(va.float(), vb.float(), rtol=1e-5, atol=1e-6)
