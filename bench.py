@@ -196,7 +196,8 @@ def main():
         }
         if world == 1 and not args.no_roofline:
             from istnet_amd import roofline
-            result["roofline"] = roofline.measure(eager_step)
+            result["roofline"] = roofline.measure(
+                eager_step, traffic_file=os.path.join(ROOT, "profiles", "r01_pmc_traffic.json"))
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline()
         print(json.dumps(result), flush=True)

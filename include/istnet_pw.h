@@ -89,7 +89,7 @@ ISTNET_PN2_API int istnet_pw_scatter_dy(int b, int cout, int n, int p, int nsamp
                                         const float *bn, const float *bwdc, const int *idx, float *out,
                                         void *stream);
 
-/* split-K weight gradient: dw_part[split][co][ci] = sum_{p in split} dY[b][co][p] * act(x[b][ci][p]) with
+/* split-K weight gradient (requires p % 32 == 0): dw_part[split][co][ci] = sum_{p in split} dY[b][co][p] * act(x[b][ci][p]) with
  * istnet_pw_wgrad_splits(...) splits; istnet_pw_wgrad_reduce sums the partials in a fixed order:
  * dw[i] = sum_s dw_part[s][i], count = cout*cin */
 ISTNET_PN2_API int istnet_pw_wgrad_splits(int b, int cin, int cout, int p);

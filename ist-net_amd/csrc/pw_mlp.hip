@@ -696,12 +696,14 @@ __global__ __launch_bounds__(kThreads) void pw_dgrad_kernel(
 }
 
 // ============================================================================================
-// wgrad:  dWpart[split][co][ci] = sum_{p in split} dY[b][co][p] * act(x[b][ci][p])
+// wgrad:  dWpart[split][co][ci] = sum_{q in split} dY[q][co] * act(x[q][ci]),  q = b*P + p flattened
 // ============================================================================================
-// grid: (splits_per_cloud * B, ceil(cout / M_T), ceil(cin / N_T)); K = points of one split
+// grid: (splits, ceil(cout / M_T), ceil(cin / N_T)); K = the points of one split.  A split is a range of
+// the flattened (cloud, point) index, so few-point layers (FP levels) are not forced to one split per
+// cloud; a 32-point K chunk never straddles two clouds because P % 32 == 0 is required by the launcher.
 template <int M_T, int N_T, int WM, int WN, bool GATHER>
 __global__ __launch_bounds__(kThreads) void pw_wgrad_kernel(
-    int cin, int cout, int P, int splits_per_cloud, int split_len, const float* __restrict__ x, GatherSrc gsrc,
+    int cin, int cout, int P, long long total, int split_len, const float* __restrict__ x, GatherSrc gsrc,
     const float* __restrict__ in_scale, const float* __restrict__ in_shift, const float* __restrict__ y,
     GradSrc gs, const float* __restrict__ bn, const float* __restrict__ bwdc, float* __restrict__ dw_part) {
   using T = Tile<M_T, N_T, WM, WN>;
@@ -714,10 +716,8 @@ __global__ __launch_bounds__(kThreads) void pw_wgrad_kernel(
   __shared__ float Bs[2][kKTW][LDB];
 
   const int tid = threadIdx.x;
-  const int b = blockIdx.x / splits_per_cloud;
-  const int sp = blockIdx.x - b * splits_per_cloud;
-  const int pbeg = sp * split_len;
-  const int pend = min(pbeg + split_len, P);
+  const long long qbeg = (long long)blockIdx.x * split_len;
+  const long long qend = min(qbeg + (long long)split_len, total);
   const int m0 = blockIdx.y * M_T, n0 = blockIdx.z * N_T;
   const bool has_bn = in_scale != nullptr;
 
@@ -725,25 +725,31 @@ __global__ __launch_bounds__(kThreads) void pw_wgrad_kernel(
   float4 braw[NB];
   float bsc[NB], bsh[NB];
   int4 gidx[NB];  // GATHER: neighbour indices, loaded one chunk ahead of their use
-  auto load_gidx = [&](int pk) {
+  // chunk start qk (multiple of 32, inside one cloud) -> cloud b and in-cloud point of this thread's float4
+  auto load_gidx = [&](long long qk) {
+    const long long qc = min(qk, total - kKTW);
+    const int b = (int)(qc / P);
+    const int pk = (int)(qc - (long long)b * P);
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
       const int e = tid + kThreads * i;
-      const int p = max(min(pk + (e % (kKTW / 4)) * 4, pend - 4), 0);
-      gidx[i] = gather_idx4(gsrc, b, P, p);
+      gidx[i] = gather_idx4(gsrc, b, P, pk + (e % (kKTW / 4)) * 4);
     }
   };
-  auto load_chunk = [&](int pk) {
+  auto load_chunk = [&](long long qk) {
+    const long long qc = min(qk, total - kKTW);
+    const int b = (int)(qc / P);
+    const int pk = (int)(qc - (long long)b * P);
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
       const int e = tid + kThreads * i;
-      const int m = min(m0 + e / (kKTW / 4), cout - 1), p = max(min(pk + (e % (kKTW / 4)) * 4, pend - 4), 0);
+      const int m = min(m0 + e / (kKTW / 4), cout - 1), p = pk + (e % (kKTW / 4)) * 4;
       load_dy_raw(araw[i], gs, y, (size_t)b * cout + m, P, p, m, bn, bwdc, cout);
     }
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
       const int e = tid + kThreads * i;
-      const int n = min(n0 + e / (kKTW / 4), cin - 1), p = max(min(pk + (e % (kKTW / 4)) * 4, pend - 4), 0);
+      const int n = min(n0 + e / (kKTW / 4), cin - 1), p = pk + (e % (kKTW / 4)) * 4;
       if (GATHER) {
         braw[i] = gather4(gsrc, b, n, P, p, gidx[i]);
       } else {
@@ -751,16 +757,16 @@ __global__ __launch_bounds__(kThreads) void pw_wgrad_kernel(
         if (has_bn) { bsc[i] = in_scale[n]; bsh[i] = in_shift[n]; }
       }
     }
-    if (GATHER) load_gidx(pk + kKTW);
+    if (GATHER) load_gidx(qk + kKTW);
   };
-  auto store_chunk = [&](int buf, int pk) {
+  auto store_chunk = [&](int buf, long long qk) {
+    const int pk = (int)(min(qk, total - kKTW) % P);
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
       const int e = tid + kThreads * i;
       const int m = e / (kKTW / 4), k = (e % (kKTW / 4)) * 4;
-      const int p = pk + k;
-      const bool ok = (m0 + m < cout) && (p < pend);
-      float4 v = finish_dy(araw[i], gs, max(min(p, pend - 4), 0));
+      const bool ok = (m0 + m < cout) && (qk + k < qend);
+      float4 v = finish_dy(araw[i], gs, pk + k);
       if (!ok) v = zero4();
       As[buf][k + 0][m] = v.x; As[buf][k + 1][m] = v.y; As[buf][k + 2][m] = v.z; As[buf][k + 3][m] = v.w;
     }
@@ -768,7 +774,7 @@ __global__ __launch_bounds__(kThreads) void pw_wgrad_kernel(
     for (int i = 0; i < NB; ++i) {
       const int e = tid + kThreads * i;
       const int n = e / (kKTW / 4), k = (e % (kKTW / 4)) * 4;
-      const bool ok = (n0 + n < cin) && (pk + k < pend);
+      const bool ok = (n0 + n < cin) && (qk + k < qend);
       float4 v = braw[i];
       if (!GATHER && has_bn) v = bn_relu4(v, bsc[i], bsh[i]);
       if (!ok) v = zero4();
@@ -786,18 +792,18 @@ __global__ __launch_bounds__(kThreads) void pw_wgrad_kernel(
 
   const int wv = wave_id();
   const int a_col0 = (wv / WN) * TM * 32, b_col0 = (wv % WN) * TN * 32;
-  const int nchunks = (pend - pbeg + kKTW - 1) / kKTW;
+  const int nchunks = (int)((qend - qbeg + kKTW - 1) / kKTW);
   if (nchunks > 0) {
-    if (GATHER) load_gidx(pbeg);
-    load_chunk(pbeg);
-    store_chunk(0, pbeg);
+    if (GATHER) load_gidx(qbeg);
+    load_chunk(qbeg);
+    store_chunk(0, qbeg);
   }
   __syncthreads();
   for (int t = 0; t < nchunks; ++t) {
     const int buf = t & 1;
-    if (t + 1 < nchunks) load_chunk(pbeg + (t + 1) * kKTW);
+    if (t + 1 < nchunks) load_chunk(qbeg + (long long)(t + 1) * kKTW);
     mma_chunk<kKTW, TM, TN, LDA, LDB>(&As[buf][0][0], &Bs[buf][0][0], a_col0, b_col0, acc);
-    if (t + 1 < nchunks) store_chunk(buf ^ 1, pbeg + (t + 1) * kKTW);
+    if (t + 1 < nchunks) store_chunk(buf ^ 1, qbeg + (long long)(t + 1) * kKTW);
     __syncthreads();
   }
   const int lane = lane_id();
@@ -861,14 +867,23 @@ inline int cfg_mt(TileCfg c) { return c == kCfg128x128 ? 128 : (c == kCfg32x256 
 inline int wgrad_mt(int cout) { return cout >= 128 ? 128 : 64; }
 inline int wgrad_nt(int cin) { return cin >= 96 ? 128 : 64; }
 inline int wgrad_split_len(int b, int cin, int cout, int P) {
-  // aim for ~1024 workgroups in total, split length a multiple of the K chunk
+  // Split-K partials cost cout*cin*4 bytes per split (written here, read back by the reduce): aim for ~1024
+  // workgroups when the output is small, ~512 / ~256 when it is large (PMC: at 1024 the partials of a
+  // 128x256 layer were as much HBM traffic as its activations).
   const long long tiles = (long long)ceil_div(cout, wgrad_mt(cout)) * ceil_div(cin, wgrad_nt(cin));
-  long long want = (1024 + tiles * b - 1) / (tiles * b);  // splits per cloud
+  const long long out_elems = (long long)cout * cin;
+  const long long target = out_elems >= 256 * 256 ? 256 : (out_elems >= 128 * 128 ? 512 : 1024);
+  long long want = (target + tiles - 1) / tiles;  // splits over the flattened (cloud, point) range
   if (want < 1) want = 1;
-  int len = ceil_div(P, (int)want);
-  len = ceil_div(len, kKTW) * kKTW;
+  const long long total = (long long)b * P;
+  long long len = (total + want - 1) / want;
+  len = (len + kKTW - 1) / kKTW * kKTW;
   if (len < 4 * kKTW) len = 4 * kKTW;
-  return len;
+  return (int)len;
+}
+inline int wgrad_splits(int b, int cin, int cout, int P) {
+  const long long total = (long long)b * P;
+  return (int)((total + wgrad_split_len(b, cin, cout, P) - 1) / wgrad_split_len(b, cin, cout, P));
 }
 
 }  // namespace
@@ -1033,30 +1048,28 @@ int istnet_pw_dgrad_stat_tiles(int b, int m_rows, int p) {
   return b * ceil_div(p, cfg_nt(pick_cfg(b, m_rows, p)));
 }
 
-int istnet_pw_wgrad_splits(int b, int cin, int cout, int p) {
-  return b * ceil_div(p, wgrad_split_len(b, cin, cout, p));
-}
+int istnet_pw_wgrad_splits(int b, int cin, int cout, int p) { return wgrad_splits(b, cin, cout, p); }
 
 static int launch_pw_wgrad(bool gather, int b, int cin, int cout, int p, int nsample, const float* x,
                            const GatherSrc& g, const float* in_scale, const float* in_shift, const float* y,
                            const float* d_dense, const float* d_pooled, const unsigned char* arg, const float* bn,
                            const float* bwdc, float* dw_part, void* stream) {
-  if (b <= 0 || cin <= 0 || cout <= 0 || p <= 0 || (p & 3)) return ISTNET_PN2_EINVAL;
+  if (b <= 0 || cin <= 0 || cout <= 0 || p <= 0 || (p % kKTW)) return ISTNET_PN2_EINVAL;
   if (d_dense == nullptr && (d_pooled == nullptr || arg == nullptr || nsample <= 0 || (nsample & 3)))
     return ISTNET_PN2_EINVAL;
   GradSrc gs{d_dense, d_pooled, arg, nsample};
   const int len = wgrad_split_len(b, cin, cout, p);
-  const int spc = ceil_div(p, len);
+  const long long total = (long long)b * p;
   const int mt = wgrad_mt(cout), nt = wgrad_nt(cin);
-  const dim3 grid(spc * b, ceil_div(cout, mt), ceil_div(cin, nt));
+  const dim3 grid(wgrad_splits(b, cin, cout, p), ceil_div(cout, mt), ceil_div(cin, nt));
 #define ISTNET_WGRAD(MT, NT)                                                                                  \
   do {                                                                                                        \
     if (gather)                                                                                               \
       hipLaunchKernelGGL((pw_wgrad_kernel<MT, NT, 2, 2, true>), grid, dim3(kThreads), 0, as_stream(stream),   \
-                         cin, cout, p, spc, len, x, g, in_scale, in_shift, y, gs, bn, bwdc, dw_part);         \
+                         cin, cout, p, total, len, x, g, in_scale, in_shift, y, gs, bn, bwdc, dw_part);       \
     else                                                                                                      \
       hipLaunchKernelGGL((pw_wgrad_kernel<MT, NT, 2, 2, false>), grid, dim3(kThreads), 0, as_stream(stream),  \
-                         cin, cout, p, spc, len, x, g, in_scale, in_shift, y, gs, bn, bwdc, dw_part);         \
+                         cin, cout, p, total, len, x, g, in_scale, in_shift, y, gs, bn, bwdc, dw_part);       \
   } while (0)
   if (mt == 128 && nt == 128) ISTNET_WGRAD(128, 128);
   else if (mt == 128) ISTNET_WGRAD(128, 64);

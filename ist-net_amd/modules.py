@@ -5,9 +5,27 @@
 per-point features (B, 128, N).  Child names (``SA_modules``, ``FP_modules``) and layer widths are
 the reference's so its state dicts load unchanged.
 """
+import os
+
+import torch
 import torch.nn as nn
 
+from .pointnet2 import pointnet2_utils
 from .pointnet2.pointnet2_modules import PointnetFPModule, PointnetSAModuleMSG
+
+# Geometry pre-pass: FPS, centroid gather, ball queries and three_nn of ALL levels depend on xyz only.
+# They are tiny-grid, latency-bound kernels (FPS is 956 dependent rounds per cloud), so they are issued
+# on a second HIP stream at the start of the forward and overlap the MFMA stacks of the earlier levels;
+# the main stream waits on one event per level.
+USE_GEOMETRY_STREAM = os.environ.get("ISTNET_NO_GEOMETRY_STREAM") is None
+_GEOMETRY_STREAMS = {}
+
+
+def _geometry_stream(dev):
+    key = dev.index if dev.index is not None else torch.cuda.current_device()
+    if key not in _GEOMETRY_STREAMS:
+        _GEOMETRY_STREAMS[key] = torch.cuda.Stream(device=dev)
+    return _GEOMETRY_STREAMS[key]
 
 # (npoint, per-scale output width) of the four SA levels  [ref :249-297]
 _SA_LEVELS = ((512, (16, 16, 32)), (256, (32, 32, 64)), (128, (64, 64, 128)), (64, (128, 128, 256)))
@@ -40,15 +58,60 @@ class PointNet2MSG(nn.Module):
         features = pc[..., 3:].transpose(1, 2).contiguous() if pc.size(-1) > 3 else None
         return xyz, features
 
+    def _geometry_prepass(self, xyz):
+        """Everything that depends on coordinates only, on the geometry stream.
+        Returns (per-level (new_xyz, [ball idx], event), per-FP-level (idx, weight, event))."""
+        dev = xyz.device
+        main, side = torch.cuda.current_stream(dev), _geometry_stream(dev)
+        side.wait_stream(main)            # xyz is produced on main; also orders reuse of last step's buffers
+        sa_geo, fp_geo = [], [None] * len(self.FP_modules)
+        with torch.cuda.stream(side), torch.no_grad():
+            cur, levels = xyz, [xyz]
+            for sa in self.SA_modules:
+                new_xyz = sa._sample_centroids(cur)
+                idx = [pointnet2_utils.ball_query(g.radius, g.nsample, cur, new_xyz) for g in sa.groupers]
+                ev = torch.cuda.Event()
+                ev.record(side)
+                sa_geo.append((new_xyz, idx, ev))
+                levels.append(new_xyz)
+                cur = new_xyz
+            for lvl in range(len(self.FP_modules) - 1, -1, -1):
+                idx, weight = PointnetFPModule.interpolation_weights(levels[lvl], levels[lvl + 1])
+                ev = torch.cuda.Event()
+                ev.record(side)
+                fp_geo[lvl] = (idx, weight, ev)
+        return sa_geo, fp_geo
+
+    def _can_prepass(self, xyz):
+        if not (USE_GEOMETRY_STREAM and xyz.is_cuda and not xyz.requires_grad):
+            return False
+        return all(isinstance(sa, PointnetSAModuleMSG) and sa.npoint is not None
+                   and all(type(g) is pointnet2_utils.QueryAndGroup and not g.sample_uniformly for g in sa.groupers)
+                   for sa in self.SA_modules)
+
     def forward(self, pointcloud):
         """(B, N, 3[+C]) -> (B, 128, N)."""
         xyz, features = self._break_up_pc(pointcloud)
+        sa_geo = fp_geo = None
+        if self._can_prepass(xyz):
+            sa_geo, fp_geo = self._geometry_prepass(xyz)
+            main = torch.cuda.current_stream(xyz.device)
         l_xyz, l_features = [xyz], [features]
-        for sa in self.SA_modules:
-            nxt_xyz, nxt_feat = sa(l_xyz[-1], l_features[-1])
+        for i, sa in enumerate(self.SA_modules):
+            if sa_geo is None:
+                nxt_xyz, nxt_feat = sa(l_xyz[-1], l_features[-1])
+            else:
+                new_xyz, idx, ev = sa_geo[i]
+                main.wait_event(ev)
+                nxt_xyz, nxt_feat = sa(l_xyz[-1], l_features[-1], geometry=(new_xyz, idx))
             l_xyz.append(nxt_xyz)
             l_features.append(nxt_feat)
         for lvl in range(len(self.FP_modules) - 1, -1, -1):  # coarse -> fine  [ref :322-325]
+            interp = None
+            if fp_geo is not None:
+                idx, weight, ev = fp_geo[lvl]
+                main.wait_event(ev)
+                interp = (idx, weight)
             l_features[lvl] = self.FP_modules[lvl](l_xyz[lvl], l_xyz[lvl + 1], l_features[lvl],
-                                                   l_features[lvl + 1])
+                                                   l_features[lvl + 1], interp=interp)
         return l_features[0]

@@ -333,9 +333,12 @@ def _fusable(mlp, x):
     """True when `mlp` is a plain [conv1x1(no bias) -> BatchNorm2d -> ReLU] x k stack on a CUDA f32 tensor."""
     if not (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4):
         return False
-    s = x.shape[3]
-    if (x.shape[2] * s) % 4 != 0 or (s > 1 and s not in (4, 8, 16, 32, 64)):
-        return False
+    return _fusable_shape(mlp, x.shape[2], x.shape[3])
+
+
+def _fusable_shape(mlp, g, s):
+    if (g * s) % 32 != 0 or (s > 1 and s not in (4, 8, 16, 32, 64)):
+        return False   # the wgrad kernel walks 32-point K chunks that must not straddle clouds
     for unit in mlp:
         names = [n for n, _ in unit.named_children()]
         if names != ["conv", "normlayer", "activation"]:
@@ -378,11 +381,12 @@ def _layer_args(mlp):
     return layers, params
 
 
-def sa_scale(grouper, mlp, xyz, new_xyz, features):
+def sa_scale(grouper, mlp, xyz, new_xyz, features, idx=None):
     """One MSG scale of a set-abstraction level: ``max_pool(mlp(grouper(xyz, new_xyz, features)))``.
 
     On CUDA, for a plain QueryAndGroup (use_xyz, no normalisation / resampling / extra returns) and a
-    fusable SharedMLP, the grouped tensor is never built; otherwise the reference composition runs."""
+    fusable SharedMLP, the grouped tensor is never built; otherwise the reference composition runs.
+    ``idx`` optionally supplies the ball-query result computed ahead of time (geometry pre-pass)."""
     from . import pointnet2_utils
     plain = (isinstance(grouper, pointnet2_utils.QueryAndGroup) and grouper.use_xyz
              and not (grouper.normalize_xyz or grouper.sample_uniformly or grouper.ret_grouped_xyz
@@ -391,11 +395,11 @@ def sa_scale(grouper, mlp, xyz, new_xyz, features):
           and not new_xyz.requires_grad and grouper.nsample in (4, 8, 16, 32, 64)
           and (features is None or (features.is_cuda and features.dtype == torch.float32)))
     if ok:
-        probe = torch.empty((1, 1, 1, grouper.nsample), device=xyz.device)  # shape/dtype probe only
-        ok = _fusable(mlp, probe)
+        ok = _fusable_shape(mlp, new_xyz.shape[1], grouper.nsample)
     if not ok:
         return shared_mlp_maxpool(mlp, grouper(xyz, new_xyz, features))
-    idx = pointnet2_utils.ball_query(grouper.radius, grouper.nsample, xyz, new_xyz)
+    if idx is None:
+        idx = pointnet2_utils.ball_query(grouper.radius, grouper.nsample, xyz, new_xyz)
     layers, params = _layer_args(mlp)
     out = FusedSAScaleFunction.apply(features, xyz, new_xyz, idx, mlp.training, layers, *params)
     if mlp.training:

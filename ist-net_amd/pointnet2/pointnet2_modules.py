@@ -31,14 +31,20 @@ class _PointnetSAModuleBase(nn.Module):
         channels_first = xyz.transpose(1, 2).contiguous()
         return pointnet2_utils.gather_operation(channels_first, picked).transpose(1, 2).contiguous()
 
-    def forward(self, xyz, features=None):
-        """xyz (B,N,3), features (B,C,N) or None -> new_xyz (B,npoint,3), (B, sum(mlp[-1]), npoint)."""
-        new_xyz = self._sample_centroids(xyz)
+    def forward(self, xyz, features=None, geometry=None):
+        """xyz (B,N,3), features (B,C,N) or None -> new_xyz (B,npoint,3), (B, sum(mlp[-1]), npoint).
+
+        ``geometry`` = (new_xyz, [ball-query idx per scale]) lets a caller that already ran the
+        sampling / neighbour search (PointNet2MSG's geometry pre-pass) skip it here."""
+        if geometry is None:
+            new_xyz, ball_idx = self._sample_centroids(xyz), [None] * len(self.groupers)
+        else:
+            new_xyz, ball_idx = geometry
         pooled = []
-        for grouper, mlp in zip(self.groupers, self.mlps):
+        for (grouper, mlp), idx in zip(zip(self.groupers, self.mlps), ball_idx):
             # grouper -> SharedMLP -> max over nsample -> squeeze [ref :61-69]: one fused node on the GPU
             # (ball query kernel + MFMA stack whose layer-0 loader gathers the neighbourhoods)
-            pooled.append(sa_scale(grouper, mlp, xyz, new_xyz, features))   # (B, C_out, npoint)
+            pooled.append(sa_scale(grouper, mlp, xyz, new_xyz, features, idx))   # (B, C_out, npoint)
         return new_xyz, torch.cat(pooled, dim=1)
 
 
@@ -80,15 +86,20 @@ class PointnetFPModule(nn.Module):
         super().__init__()
         self.mlp = pytorch_utils.SharedMLP(mlp, bn=bn)
 
-    def forward(self, unknown, known, unknow_feats, known_feats):
+    @staticmethod
+    def interpolation_weights(unknown, known):
+        """three_nn + inverse-distance weights (idx (B,n,3) i32, weight (B,n,3)).  [ref :185-188]"""
+        dist, idx = pointnet2_utils.three_nn(unknown, known)
+        inv = 1.0 / (dist + 1e-8)
+        return idx, inv / torch.sum(inv, dim=2, keepdim=True)
+
+    def forward(self, unknown, known, unknow_feats, known_feats, interp=None):
         """unknown (B,n,3), known (B,m,3), unknow_feats (B,C1,n) or None, known_feats (B,C2,m)
-        -> (B, mlp[-1], n)."""
+        -> (B, mlp[-1], n).  ``interp`` = precomputed (idx, weight) of interpolation_weights()."""
         if known is None:
             interpolated = known_feats.expand(*known_feats.size()[0:2], unknown.size(1))
         else:
-            dist, idx = pointnet2_utils.three_nn(unknown, known)
-            inv = 1.0 / (dist + 1e-8)
-            weight = inv / torch.sum(inv, dim=2, keepdim=True)
+            idx, weight = interp if interp is not None else self.interpolation_weights(unknown, known)
             interpolated = pointnet2_utils.three_interpolate(known_feats, idx.detach(), weight.detach())
 
         stacked = interpolated if unknow_feats is None else torch.cat([interpolated, unknow_feats], dim=1)

@@ -17,7 +17,19 @@ PEAK_MFMA_F32_TFLOPS = 157.3
 PEAK_HBM_GBS = 8000.0
 
 
-def measure(step, steps=5, traffic=None):
+def pmc_traffic(kernel_name, path):
+    """HBM bytes per launch of `kernel_name` from a committed rocprofv3 PMC summary (tools/pmc_traffic.sh);
+    None when the file or the kernel is missing.  PMC counters cannot be read from inside the process."""
+    import json
+    import os
+    if not os.path.exists(path):
+        return None, None
+    data = json.load(open(path))
+    rec = data.get("kernels", {}).get(kernel_name)
+    return (rec["hbm_bytes_per_launch"], os.path.basename(path)) if rec else (None, None)
+
+
+def measure(step, steps=5, traffic_file=None):
     """`step` runs one full training step.  Returns the `roofline` object of the bench JSON line."""
     step()
     torch.cuda.synchronize()
@@ -42,9 +54,11 @@ def measure(step, steps=5, traffic=None):
     name, (ms, flops, nbytes, launches) = max(per_kernel.items(), key=lambda kv: kv[1][0])
     achieved = flops / (ms * 1e-3) / 1e12
     total_ms = sum(v[0] for v in per_kernel.values())
+    traffic, traffic_src = pmc_traffic(name, traffic_file) if traffic_file else (None, None)
     return {
         "bound": "mfma", "kernel": name, "achieved": achieved, "peak": PEAK_MFMA_F32_TFLOPS,
         "unit": "TFLOP/s", "frac": achieved / PEAK_MFMA_F32_TFLOPS, "traffic": traffic,
+        "traffic_source": traffic_src,
         "launches_per_step": launches / steps, "avg_launch_us": ms * 1e3 / launches,
         "flop_per_launch_avg": flops / launches, "algorithmic_bytes_per_launch_avg": nbytes / launches,
         "algorithmic_gbs": nbytes / (ms * 1e-3) / 1e9,
