@@ -465,13 +465,11 @@ __global__ __launch_bounds__(64) void bn_finalize_bwd_kernel(int C, int nt, doub
 // dY for 4 consecutive points of one channel, split into a pure load (issued early, nothing consumed)
 // and the arithmetic (run after the MFMAs of the previous chunk).
 struct DyRaw {
-  float4 y, d;            // raw activation; dense gradient, or pooled gradient in d.x
-  int a;                  // arg-max slot (pooled mode)
-  float s, h, ca, cb, cc;  // BN scale/shift of this layer and the dY constants
+  float4 y, d;   // raw activation; dense gradient, or pooled gradient in d.x
+  int a;         // arg-max slot (pooled mode)
 };
 __device__ __forceinline__ void load_dy_raw(DyRaw& r, const GradSrc& gs, const float* __restrict__ y,
-                                            size_t row, int P, int p, int ch, const float* __restrict__ bn,
-                                            const float* __restrict__ bwdc, int C) {
+                                            size_t row, int P, int p) {
   r.y = *reinterpret_cast<const float4*>(y + row * (size_t)P + p);
   if (gs.dense != nullptr) {
     r.d = *reinterpret_cast<const float4*>(gs.dense + row * (size_t)P + p);
@@ -481,10 +479,14 @@ __device__ __forceinline__ void load_dy_raw(DyRaw& r, const GradSrc& gs, const f
     r.d = make_float4(gs.pooled[row * (size_t)G + g], 0.f, 0.f, 0.f);
     r.a = gs.arg[row * (size_t)G + g];
   }
-  r.s = bn[ch]; r.h = bn[C + ch];
-  r.ca = bwdc[ch]; r.cb = bwdc[C + ch]; r.cc = bwdc[2 * C + ch];
 }
-__device__ __forceinline__ float4 finish_dy(const DyRaw& r, const GradSrc& gs, int p) {
+// ch is clamped by the caller; the five per-channel constants are tiny and cache-resident, so they are
+// read here (after the MFMAs) rather than carried in registers across the chunk.
+__device__ __forceinline__ float4 finish_dy(const DyRaw& r, const GradSrc& gs, int p, int ch,
+                                            const float* __restrict__ bn, const float* __restrict__ bwdc,
+                                            int C) {
+  const float rs = bn[ch], rh = bn[C + ch];
+  const float rca = bwdc[ch], rcb = bwdc[C + ch], rcc = bwdc[2 * C + ch];
   float4 d = r.d;
   if (gs.dense == nullptr) {
     const int k = p % gs.S;
@@ -492,10 +494,10 @@ __device__ __forceinline__ float4 finish_dy(const DyRaw& r, const GradSrc& gs, i
     d = make_float4(r.a == k ? v : 0.f, r.a == k + 1 ? v : 0.f, r.a == k + 2 ? v : 0.f, r.a == k + 3 ? v : 0.f);
   }
   float4 o;
-  o.x = r.ca * ((r.y.x * r.s + r.h > 0.f) ? d.x : 0.f) + r.cb + r.cc * r.y.x;
-  o.y = r.ca * ((r.y.y * r.s + r.h > 0.f) ? d.y : 0.f) + r.cb + r.cc * r.y.y;
-  o.z = r.ca * ((r.y.z * r.s + r.h > 0.f) ? d.z : 0.f) + r.cb + r.cc * r.y.z;
-  o.w = r.ca * ((r.y.w * r.s + r.h > 0.f) ? d.w : 0.f) + r.cb + r.cc * r.y.w;
+  o.x = rca * ((r.y.x * rs + rh > 0.f) ? d.x : 0.f) + rcb + rcc * r.y.x;
+  o.y = rca * ((r.y.y * rs + rh > 0.f) ? d.y : 0.f) + rcb + rcc * r.y.y;
+  o.z = rca * ((r.y.z * rs + rh > 0.f) ? d.z : 0.f) + rcb + rcc * r.y.z;
+  o.w = rca * ((r.y.w * rs + rh > 0.f) ? d.w : 0.f) + rcb + rcc * r.y.w;
   return o;
 }
 
@@ -598,7 +600,7 @@ __global__ __launch_bounds__(kThreads) void pw_dgrad_kernel(
     for (int i = 0; i < NB; ++i) {
       const int e = tid + kThreads * i;
       const int k = min(k0 + e / (N_T / 4), cout - 1), p = min(p0 + (e % (N_T / 4)) * 4, P - 4);
-      load_dy_raw(braw[i], gs, y, (size_t)b * cout + k, P, p, k, bn, bwdc, cout);
+      load_dy_raw(braw[i], gs, y, (size_t)b * cout + k, P, p);
     }
   };
   auto store_chunk = [&](int buf, int k0) {
@@ -613,7 +615,7 @@ __global__ __launch_bounds__(kThreads) void pw_dgrad_kernel(
       const int e = tid + kThreads * i;
       const int p = p0 + (e % (N_T / 4)) * 4;
       const bool ok = (k0 + e / (N_T / 4) < cout) && (p < P);
-      float4 v = finish_dy(braw[i], gs, min(p, P - 4));
+      float4 v = finish_dy(braw[i], gs, min(p, P - 4), min(k0 + e / (N_T / 4), cout - 1), bn, bwdc, cout);
       if (!ok) v = zero4();
       *reinterpret_cast<float4*>(&Bs[buf][e / (N_T / 4)][(e % (N_T / 4)) * 4]) = v;
     }
@@ -744,7 +746,7 @@ __global__ __launch_bounds__(kThreads) void pw_wgrad_kernel(
     for (int i = 0; i < NA; ++i) {
       const int e = tid + kThreads * i;
       const int m = min(m0 + e / (kKTW / 4), cout - 1), p = pk + (e % (kKTW / 4)) * 4;
-      load_dy_raw(araw[i], gs, y, (size_t)b * cout + m, P, p, m, bn, bwdc, cout);
+      load_dy_raw(araw[i], gs, y, (size_t)b * cout + m, P, p);
     }
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
@@ -766,7 +768,7 @@ __global__ __launch_bounds__(kThreads) void pw_wgrad_kernel(
       const int e = tid + kThreads * i;
       const int m = e / (kKTW / 4), k = (e % (kKTW / 4)) * 4;
       const bool ok = (m0 + m < cout) && (qk + k < qend);
-      float4 v = finish_dy(araw[i], gs, pk + k);
+      float4 v = finish_dy(araw[i], gs, pk + k, min(m0 + m, cout - 1), bn, bwdc, cout);
       if (!ok) v = zero4();
       As[buf][k + 0][m] = v.x; As[buf][k + 1][m] = v.y; As[buf][k + 2][m] = v.z; As[buf][k + 3][m] = v.w;
     }
@@ -868,11 +870,11 @@ inline int wgrad_mt(int cout) { return cout >= 128 ? 128 : 64; }
 inline int wgrad_nt(int cin) { return cin >= 96 ? 128 : 64; }
 inline int wgrad_split_len(int b, int cin, int cout, int P) {
   // Split-K partials cost cout*cin*4 bytes per split (written here, read back by the reduce): aim for ~1024
-  // workgroups when the output is small, ~512 / ~256 when it is large (PMC: at 1024 the partials of a
-  // 128x256 layer were as much HBM traffic as its activations).
+  // workgroups when the output is small, ~768 when it is large (PMC: at 1024 the partials of a 128x256
+  // layer were as much HBM traffic as its activations; at 256-512 the launch no longer fills the chip).
   const long long tiles = (long long)ceil_div(cout, wgrad_mt(cout)) * ceil_div(cin, wgrad_nt(cin));
   const long long out_elems = (long long)cout * cin;
-  const long long target = out_elems >= 256 * 256 ? 256 : (out_elems >= 128 * 128 ? 512 : 1024);
+  const long long target = out_elems >= 128 * 128 ? 768 : 1024;  // measured: fewer workgroups lose more than the partials cost
   long long want = (target + tiles - 1) / tiles;  // splits over the flattened (cloud, point) range
   if (want < 1) want = 1;
   const long long total = (long long)b * P;
