@@ -57,6 +57,10 @@ ISTNET_PN2_API int istnet_bn_finalize_fwd(int c, int nt, double count, const flo
 ISTNET_PN2_API int istnet_bn_relu_pool(int b, int c, int g, int s, const float *y, const float *bn,
                                        float *out, unsigned char *arg, void *stream);
 
+/* out = y * bn[0] + bn[1] (per channel), followed by ReLU when relu != 0 -- final layer of a bias stack */
+ISTNET_PN2_API int istnet_affine_apply(int b, int c, int p, int relu, const float *y, const float *bn,
+                                       float *out, void *stream);
+
 /* backward statistics: partial sums of g and g*y per channel -> [c][tiles] */
 ISTNET_PN2_API int istnet_pw_bwd_stat_tiles(int b, int p);
 ISTNET_PN2_API int istnet_pw_bwd_stats(int b, int c, int p, int nsample, const float *y,

@@ -367,6 +367,20 @@ __global__ __launch_bounds__(256) void bn_relu_apply_kernel(int C, int P4, const
   reinterpret_cast<float4*>(out + (size_t)bc * P4 * 4)[i] = v;
 }
 
+__global__ __launch_bounds__(256) void affine_apply_kernel(int C, int P4, int relu, const float* __restrict__ y,
+                                                           const float* __restrict__ scale,
+                                                           const float* __restrict__ shift,
+                                                           float* __restrict__ out) {
+  const int bc = blockIdx.y;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= P4) return;
+  const float s = scale[bc % C], h = shift[bc % C];
+  float4 v = reinterpret_cast<const float4*>(y + (size_t)bc * P4 * 4)[i];
+  v.x = v.x * s + h; v.y = v.y * s + h; v.z = v.z * s + h; v.w = v.w * s + h;
+  if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+  reinterpret_cast<float4*>(out + (size_t)bc * P4 * 4)[i] = v;
+}
+
 // ============================================================================================
 // backward helpers: gradient w.r.t. the BN output,  g = dA * [relu active]
 //   dense : dA (B, C, P)
@@ -980,6 +994,13 @@ int istnet_bn_relu_pool(int b, int c, int g, int s, const float* y, const float*
     default: return ISTNET_PN2_EINVAL;
   }
 #undef ISTNET_POOL
+  return (int)hipGetLastError();
+}
+
+int istnet_affine_apply(int b, int c, int p, int relu, const float* y, const float* bn, float* out, void* stream) {
+  if (b <= 0 || c <= 0 || p <= 0 || (p & 3)) return ISTNET_PN2_EINVAL;
+  hipLaunchKernelGGL(affine_apply_kernel, dim3(ceil_div(p / 4, 256), b * c), dim3(256), 0, as_stream(stream), c,
+                     p / 4, relu, y, bn, bn + c, out);
   return (int)hipGetLastError();
 }
 

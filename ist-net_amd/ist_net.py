@@ -15,6 +15,7 @@ import torch
 import torch.nn as nn
 
 from .modules import PointNet2MSG
+from .pointnet2.fused_mlp import pointwise_conv_stack as _run
 from .rotation_utils import Ortho6d2Mat
 
 CAM_RADII = [[0.01, 0.02], [0.02, 0.04], [0.04, 0.08], [0.08, 0.16]]      # ist_net.py:16
@@ -41,6 +42,11 @@ def _with_global_mean(feat):
     return torch.cat([feat, feat.mean(dim=2, keepdim=True).expand_as(feat)], dim=1)
 
 
+def _pooled(seq, x):
+    """``seq`` = [conv, relu, conv, relu, AdaptiveAvgPool1d(1)] (pose_mlp2): fused convs, then the mean over N."""
+    return _run(seq[:-1], x).mean(dim=2)
+
+
 class FeatureDeformer(nn.Module):
     """Camera-space features -> world-space features + per-class NOCS coordinates.  [ref :123-183]"""
 
@@ -54,10 +60,10 @@ class FeatureDeformer(nn.Module):
 
     def forward(self, pts, rgb_local, pts_local, index):
         npoint = pts_local.size(2)
-        geo = self.pts_mlp1(pts.transpose(1, 2))
-        feat = self.deform_mlp1(torch.cat([geo, pts_local, rgb_local], dim=1))
-        pts_local_w = self.deform_mlp2(_with_global_mean(feat))
-        nocs = self.pred_nocs(pts_local_w).view(-1, 3, npoint).contiguous()   # (B*nclass, 3, N)
+        geo = _run(self.pts_mlp1, pts.transpose(1, 2))
+        feat = _run(self.deform_mlp1, torch.cat([geo, pts_local, rgb_local], dim=1))
+        pts_local_w = _run(self.deform_mlp2, _with_global_mean(feat))
+        nocs = _run(self.pred_nocs, pts_local_w).view(-1, 3, npoint).contiguous()   # (B*nclass, 3, N)
         pts_w = torch.index_select(nocs, 0, index).permute(0, 2, 1).contiguous()
         return pts_local_w, pts_w
 
@@ -98,9 +104,9 @@ class LightEstimator(_PoseHeads):
         self._make_heads()
 
     def forward(self, pts, rgb_local, pts_local):
-        geo = self.pts_mlp(pts.transpose(1, 2))
-        feat = self.pose_mlp1(torch.cat([rgb_local, geo, pts_local], dim=1))
-        return self._pose(self.pose_mlp2(_with_global_mean(feat)).squeeze(2))
+        geo = _run(self.pts_mlp, pts.transpose(1, 2))
+        feat = _run(self.pose_mlp1, torch.cat([rgb_local, geo, pts_local], dim=1))
+        return self._pose(_pooled(self.pose_mlp2, _with_global_mean(feat)))
 
 
 class HeavyEstimator(_PoseHeads):
@@ -115,10 +121,10 @@ class HeavyEstimator(_PoseHeads):
         self._make_heads()
 
     def forward(self, pts, pts_w, rgb_local, pts_local, pts_w_local):
-        geo = self.pts_mlp1(pts.transpose(1, 2))
-        geo_w = self.pts_mlp2(pts_w.transpose(1, 2))
-        feat = self.pose_mlp1(torch.cat([rgb_local, geo, pts_local, geo_w, pts_w_local], dim=1))
-        return self._pose(self.pose_mlp2(_with_global_mean(feat)).squeeze(2))
+        geo = _run(self.pts_mlp1, pts.transpose(1, 2))
+        geo_w = _run(self.pts_mlp2, pts_w.transpose(1, 2))
+        feat = _run(self.pose_mlp1, torch.cat([rgb_local, geo, pts_local, geo_w, pts_w_local], dim=1))
+        return self._pose(_pooled(self.pose_mlp2, _with_global_mean(feat)))
 
 
 class WorldSpaceEnhancer(nn.Module):

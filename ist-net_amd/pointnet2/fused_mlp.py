@@ -68,13 +68,16 @@ def _p(t):
 
 class _Layer:
     """Per-layer constants handed to the autograd function (not differentiable)."""
-    __slots__ = ("running_mean", "running_var", "momentum", "eps")
+    __slots__ = ("running_mean", "running_var", "momentum", "eps", "bias_only", "relu")
 
-    def __init__(self, bn):
-        self.running_mean = bn.running_mean
-        self.running_var = bn.running_var
-        self.momentum = bn.momentum
-        self.eps = bn.eps
+    def __init__(self, bn=None, relu=True):
+        self.bias_only = bn is None      # conv + bias (+ ReLU) instead of conv + BatchNorm + ReLU
+        self.relu = relu                 # False only for the last layer of a bias stack
+        if bn is not None:
+            self.running_mean = bn.running_mean
+            self.running_var = bn.running_var
+            self.momentum = bn.momentum
+            self.eps = bn.eps
 
 
 class _Gather:
@@ -99,7 +102,9 @@ def _forward_stack(lib, dev, st, b, c0, g, s, x, gather, training, layers, param
         w2 = w.reshape(cout, cur_c)
         y = _empty((b, cout, p), torch.float32, dev)
         bn = _empty((4, cout), torch.float32, dev)
-        if training:
+        if lay.bias_only:
+            gamma = None                      # params[3*li+1] is a ones vector, beta is the conv bias
+        if training and not lay.bias_only:
             nt = lib.istnet_pw_stat_tiles(b, cout, p)
             part = _empty((2, cout, nt), torch.float32, dev)
             ps, pq = part[0].data_ptr(), part[1].data_ptr()
@@ -117,7 +122,12 @@ def _forward_stack(lib, dev, st, b, c0, g, s, x, gather, training, layers, param
             cin_l, src = cur_c, cur
             _native.check(_native.timed(kname, flops, nbytes, lambda: lib.istnet_pw_forward(
                 b, cin_l, cout, p, src.data_ptr(), w2.data_ptr(), sc, sh, y.data_ptr(), ps, pq, st)), "pw_forward")
-        if training:
+        if lay.bias_only:                    # y + bias: scale 1, shift bias, mean 0, invstd 1
+            bn[0].fill_(1.0)
+            bn[1] = beta
+            bn[2].zero_()
+            bn[3].fill_(1.0)
+        elif training:
             _native.check(lib.istnet_bn_finalize_fwd(
                 cout, nt, float(b * p), ps, pq, gamma.data_ptr(), beta.data_ptr(), float(lay.eps),
                 float(lay.momentum), _p(lay.running_mean), _p(lay.running_var), bn.data_ptr(), st),
@@ -133,8 +143,17 @@ def _forward_stack(lib, dev, st, b, c0, g, s, x, gather, training, layers, param
         cur, cur_c, in_bn = y, cout, bn
     out = _empty((b, cur_c, g), torch.float32, dev)
     arg = _empty((b, cur_c, g), torch.uint8, dev) if s > 1 else None
-    _native.check(lib.istnet_bn_relu_pool(b, cur_c, g, s, cur.data_ptr(), in_bn.data_ptr(), out.data_ptr(),
-                                          _p(arg), st), "bn_relu_pool")
+    if s == 1 and not layers[-1].relu:
+        _native.check(lib.istnet_affine_apply(b, cur_c, g, 0, cur.data_ptr(), in_bn.data_ptr(), out.data_ptr(), st),
+                      "affine_apply")
+        # backward of a ReLU-free last layer: gradient mask "always active" (scale 0, shift 1)
+        mask = torch.zeros_like(in_bn)
+        mask[1].fill_(1.0)
+        mask[3].fill_(1.0)
+        bns[-1] = mask
+    else:
+        _native.check(lib.istnet_bn_relu_pool(b, cur_c, g, s, cur.data_ptr(), in_bn.data_ptr(), out.data_ptr(),
+                                              _p(arg), st), "bn_relu_pool")
     return out, arg, ys, bns
 
 
@@ -174,7 +193,7 @@ def _backward_stack(lib, dev, st, b, c0, g, s, x, gather, training, ys, bns, par
         dbeta = _empty(cout, torch.float32, dev)
         bwdc = _empty((3, cout), torch.float32, dev)
         _native.check(lib.istnet_bn_finalize_bwd(
-            cout, nt_l, float(b * p), 1 if training else 0, part[0].data_ptr(), part[1].data_ptr(),
+            cout, nt_l, float(b * p), 1 if training else 0, part[0].data_ptr(), part[1].data_ptr(),  # training=False for bias stacks
             gamma.data_ptr(), bn.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), bwdc.data_ptr(), st),
             "bn_finalize_bwd")
         grads[3 * li + 1] = dgamma
@@ -327,6 +346,79 @@ class FusedSAScaleFunction(Function):
             if need_x:
                 dfeat = dxf if scattered else _ext.group_points_grad(dxf.view(b, ga.cfeat, g, s), idx, ga.n)
         return (dfeat, None, None, None, None, None, *grads)
+
+
+class FusedBiasMLPFunction(Function):
+    """x (B, C0, N) -> (B, C_L, N): stack of Conv1d(k=1) + bias (+ ReLU) layers -- the per-point MLPs of the
+    IST head and the pose heads (reference model/ist_net.py:130-160, 206-248, 271-316).
+
+    Same kernels as the BatchNorm stack with constant "BN" blocks (scale 1, shift = bias): each layer is
+    one MFMA GEMM whose operand loader applies the previous layer's bias + ReLU; backward uses
+    dY = g, dbias = sum g.  ``relu_last`` tells whether the last conv is followed by a ReLU."""
+
+    @staticmethod
+    def forward(ctx, x, relu_last, *params):          # params = [w0, b0, w1, b1, ...]
+        lib = _native.lib()
+        dev = x.device
+        b, c0, npts = x.shape
+        x = x.contiguous()
+        n = len(params) // 2
+        layers = [_Layer(None, relu=(relu_last or li < n - 1)) for li in range(n)]
+        ones = [torch.ones(params[2 * li].shape[0], dtype=torch.float32, device=dev) for li in range(n)]
+        flat = []
+        for li in range(n):
+            flat += [params[2 * li], ones[li], params[2 * li + 1]]
+        with torch.cuda.device(dev):
+            out, _, ys, bns = _forward_stack(lib, dev, _st(dev), b, c0, npts, 1, x, None, False, layers, flat)
+        ctx.shape = (b, c0, npts)
+        ctx.n_layers = n
+        ctx.save_for_backward(x, *ys, *bns, *flat)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        lib = _native.lib()
+        b, c0, npts = ctx.shape
+        n = ctx.n_layers
+        saved = ctx.saved_tensors
+        x = saved[0]
+        ys, bns, flat = saved[1:1 + n], saved[1 + n:1 + 2 * n], saved[1 + 2 * n:]
+        dev = x.device
+        need_w = [ctx.needs_input_grad[2 + 2 * li] for li in range(n)]
+        with torch.cuda.device(dev):
+            grads, dx, _ = _backward_stack(lib, dev, _st(dev), b, c0, npts, 1, x, None, False, ys, bns, flat,
+                                           None, dout.contiguous(), need_w, ctx.needs_input_grad[0])
+        out = []
+        for li in range(n):
+            dw = grads[3 * li]
+            out += [dw.view_as(flat[3 * li]) if dw is not None else None, grads[3 * li + 2]]   # dW, dbias
+        return (dx, None, *out)
+
+
+def pointwise_conv_stack(seq, x):
+    """Run an ``nn.Sequential`` of [Conv1d(k=1) (+ ReLU)]* on x (B, C, N).
+
+    CUDA f32 inputs with N % 32 == 0 take the fused MFMA path; anything else runs ``seq(x)``."""
+    mods = list(seq)
+    convs, relu_after = [], []
+    i = 0
+    ok = x.is_cuda and x.dtype == torch.float32 and x.dim() == 3 and x.shape[2] % 32 == 0
+    while ok and i < len(mods):
+        m = mods[i]
+        if not (isinstance(m, torch.nn.Conv1d) and m.kernel_size == (1,) and m.stride == (1,)
+                and m.padding == (0,) and m.groups == 1 and m.bias is not None):
+            ok = False
+            break
+        has_relu = i + 1 < len(mods) and isinstance(mods[i + 1], torch.nn.ReLU)
+        convs.append(m)
+        relu_after.append(has_relu)
+        i += 2 if has_relu else 1
+    if not ok or not convs or not all(relu_after[:-1]):
+        return seq(x)
+    params = []
+    for m in convs:
+        params += [m.weight, m.bias]
+    return FusedBiasMLPFunction.apply(x, relu_after[-1], *params)
 
 
 def _fusable(mlp, x):

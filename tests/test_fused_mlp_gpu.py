@@ -171,3 +171,39 @@ def test_sa_scale_gather_fusion_matches_grouped_path(b, n, npoint, radius, nsamp
         assert float((g_f[k] - g_t[k]).norm() / (g_t[k].norm() + 1e-30)) < 1e-4, k
     for (ka, va), (kb, vb) in zip(mlp_a.state_dict().items(), mlp_b.state_dict().items()):
         torch.testing.assert_close(va.float(), vb.float(), rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("widths,final_relu,b,n", [
+    ([3, 32, 64], True, 4, 1024), ([320, 384, 256], True, 4, 512), ([512, 384, 256, 128], True, 2, 1024),
+    ([128, 256, 128, 18], False, 4, 1024), ([512, 512, 512], True, 32, 1024), ([7, 5], False, 2, 96),
+])
+def test_bias_stack_matches_torch(widths, final_relu, b, n):
+    """Conv1d(k=1)+bias(+ReLU) stacks of the IST / pose heads (ist_net.py:130-160,206-248,271-316)."""
+    import copy
+    from istnet_amd.ist_net import _pointwise
+    from istnet_amd.pointnet2.fused_mlp import pointwise_conv_stack
+    torch.manual_seed(4)
+    seq_a = _pointwise(list(widths), final_relu=final_relu).to(DEV)
+    seq_b = copy.deepcopy(seq_a)
+    x0 = torch.randn(b, n, widths[0], generator=torch.Generator().manual_seed(8)).to(DEV).transpose(1, 2)  # non-contiguous
+    wgt = torch.randn(b, widths[-1], n, generator=torch.Generator().manual_seed(9)).to(DEV)
+
+    def run(seq, fused):
+        x = x0.clone().requires_grad_(True)
+        if fused:
+            out = pointwise_conv_stack(seq, x)
+        else:                                   # float64 evaluation of the same stack = ground truth
+            x = x0.double().clone().requires_grad_(True)
+            out = seq.double()(x)
+        (out * wgt.to(out.dtype)).sum().backward()
+        return out.detach().double(), x.grad.double(), {k: p.grad.double() for k, p in seq.named_parameters()}
+
+    of, dxf, gf = run(seq_a, True)
+    ot, dxt, gt = run(seq_b, False)
+    assert float((of - ot).abs().max() / ot.abs().max()) < 2e-5
+    # a unit whose pre-activation is within fp32 round-off of zero may switch its ReLU (expected count << 1 per
+    # case; torch's own f32 convolution flips far more, its algorithms carry ~1e-4 relative noise)
+    assert float((dxf - dxt).abs().median() / dxt.abs().max()) < 1e-5
+    assert float((dxf - dxt).norm() / dxt.norm()) < 1e-3
+    for k in gt:
+        assert float((gf[k] - gt[k]).norm() / (gt[k].norm() + 1e-30)) < 1e-4, k
