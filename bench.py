@@ -127,6 +127,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--eager", action="store_true", help="do not capture the step in a HIP graph")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for dry runs)")
+    ap.add_argument("--same-device", action="store_true",
+                    help="dry run of the N>1 control flow on a 1-GPU box: every rank uses cuda:0 (gloo only)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -137,6 +140,8 @@ def main():
             pass
         else:
             raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    if args.same_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
@@ -144,7 +149,10 @@ def main():
     grad_sync = None
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)  # RCCL over xGMI
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)  # RCCL over xGMI
+        else:
+            dist.init_process_group(args.backend)
 
     model = make_model(dev, seed=0)  # identical weights on every rank (same seed)
     pts = shell_cloud(BATCH, NPOINTS, seed=rank, device=dev)

@@ -664,6 +664,41 @@ __global__ __launch_bounds__(kThreads) void pw_dgrad_kernel(
   const bool stats = part_g != nullptr;
   const float* yin_b = stats ? y_in + (size_t)b * m_rows * P : nullptr;
   float* red = &As[0][0][0];  // reuse LDS: [WN][M_T][2]
+  if (full_tile && stats) {
+    // common case: issue every y_in load of a 16-row slab before consuming any (one latency, not 16*TN)
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm) {
+      float yv[16][TN];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = m0 + a_col0 + tm * 32 + mfma_row(r, lane);
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn)
+          yv[r][tn] = yin_b[(size_t)row * P + p0 + b_col0 + tn * 32 + (lane & 31)];
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row_l = a_col0 + tm * 32 + mfma_row(r, lane);
+        const int row = m0 + row_l;
+        const float sc = bn_in[row], sh = bn_in[m_rows + row];
+        float sg = 0.f, sgy = 0.f;
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn) {
+          const float v = acc[tm][tn][r];
+          dxb[(size_t)row * P + p0 + b_col0 + tn * 32 + (lane & 31)] = v;
+          const float gq = (yv[r][tn] * sc + sh > 0.f) ? v : 0.f;
+          sg += gq;
+          sgy += gq * yv[r][tn];
+        }
+        sg = half_wave_sum(sg);
+        sgy = half_wave_sum(sgy);
+        if ((lane & 31) == 31) {
+          red[((wv % WN) * M_T + row_l) * 2 + 0] = sg;
+          red[((wv % WN) * M_T + row_l) * 2 + 1] = sgy;
+        }
+      }
+    }
+  } else {
 #pragma unroll
   for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
@@ -696,6 +731,7 @@ __global__ __launch_bounds__(kThreads) void pw_dgrad_kernel(
         }
       }
     }
+  }
   if (stats) {
     __syncthreads();
     for (int rl = tid; rl < M_T; rl += kThreads) {
