@@ -111,6 +111,9 @@ ISTNET_PN2_API int istnet_pw_wgrad_gather(int b, int n, int npoint, int nsample,
                                           float *dw_part, void *stream);
 ISTNET_PN2_API int istnet_pw_wgrad_reduce(int count, int splits, const float *dw_part, float *dw,
                                           void *stream);
+/* the same reduction for n <= 8 layers in ONE launch (host arrays of length n) */
+ISTNET_PN2_API int istnet_pw_wgrad_reduce_multi(int n, const int *counts, const int *splits,
+                                                const float *const *parts, float *const *dws, void *stream);
 
 #ifdef __cplusplus
 }

@@ -47,6 +47,7 @@ SIGNATURES = {
     "istnet_pw_wgrad_splits": [_i, _i, _i, _i],
     "istnet_pw_wgrad": [_i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p],
     "istnet_pw_wgrad_reduce": [_i, _i, _p, _p, _p],
+    "istnet_pw_wgrad_reduce_multi": [_i, _p, _p, _p, _p, _p],
 }
 
 _lib = None
@@ -104,3 +105,16 @@ def timed(name, flops, nbytes, launch):
     end.record()
     TIMING.append((name, flops, nbytes, start, end))
     return status
+
+
+def reduce_multi(items, stream):
+    """items: list of (count, splits, part_ptr, dw_ptr); one launch per <= 8 layers."""
+    handle = lib()
+    for i in range(0, len(items), 8):
+        chunk = items[i:i + 8]
+        n = len(chunk)
+        counts = (ctypes.c_int * n)(*[c[0] for c in chunk])
+        splits = (ctypes.c_int * n)(*[c[1] for c in chunk])
+        parts = (ctypes.c_void_p * n)(*[c[2] for c in chunk])
+        dws = (ctypes.c_void_p * n)(*[c[3] for c in chunk])
+        check(handle.istnet_pw_wgrad_reduce_multi(n, counts, splits, parts, dws, stream), "pw_wgrad_reduce_multi")

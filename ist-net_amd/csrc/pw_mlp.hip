@@ -900,6 +900,45 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(int count, int splits
   }
 }
 
+// Same reduction for up to 8 layers in one launch (descriptors by value): one launch per SharedMLP instead of
+// one per layer -- the reduce is pure launch latency (~9 us for ~1 us of work).
+struct ReduceBatch {
+  const float* part[8];
+  float* dw[8];
+  int count[8];
+  int splits[8];
+  int block_begin[9];  // prefix sum of ceil(count / 16)
+  int n;
+};
+__global__ __launch_bounds__(256) void wgrad_reduce_multi_kernel(ReduceBatch rb) {
+  __shared__ float red[16][17];
+  int l = 0;
+  while (l + 1 < rb.n && (int)blockIdx.x >= rb.block_begin[l + 1]) ++l;
+  const int count = rb.count[l], splits = rb.splits[l];
+  const float* __restrict__ part = rb.part[l];
+  const int el = threadIdx.x & 15, sg = threadIdx.x >> 4;
+  const int i = ((int)blockIdx.x - rb.block_begin[l]) * 16 + el;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  if (i < count) {
+    int k = sg;
+    for (; k + 48 < splits; k += 64) {
+      s0 += part[(size_t)k * count + i];
+      s1 += part[(size_t)(k + 16) * count + i];
+      s2 += part[(size_t)(k + 32) * count + i];
+      s3 += part[(size_t)(k + 48) * count + i];
+    }
+    for (; k < splits; k += 16) s0 += part[(size_t)k * count + i];
+  }
+  red[sg][el] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (threadIdx.x < 16 && i < count) {
+    float s = 0.f;
+#pragma unroll
+    for (int g = 0; g < 16; ++g) s += red[g][el];
+    rb.dw[l][i] = s;
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
@@ -1155,6 +1194,24 @@ int istnet_pw_wgrad_gather(int b, int n, int npoint, int nsample, int cfeat, int
   const GatherSrc g{xyz, new_xyz, feat, idx, n, nsample, cfeat};
   return launch_pw_wgrad(true, b, 3 + cfeat, cout, npoint * nsample, grad_nsample, nullptr, g, nullptr, nullptr, y,
                          d_dense, d_pooled, arg, bn, bwdc, dw_part, stream);
+}
+
+int istnet_pw_wgrad_reduce_multi(int n, const int* counts, const int* splits, const float* const* parts,
+                                 float* const* dws, void* stream) {
+  if (n <= 0 || n > 8) return ISTNET_PN2_EINVAL;
+  ReduceBatch rb;
+  rb.n = n;
+  rb.block_begin[0] = 0;
+  for (int l = 0; l < n; ++l) {
+    if (counts[l] <= 0 || splits[l] <= 0) return ISTNET_PN2_EINVAL;
+    rb.part[l] = parts[l];
+    rb.dw[l] = dws[l];
+    rb.count[l] = counts[l];
+    rb.splits[l] = splits[l];
+    rb.block_begin[l + 1] = rb.block_begin[l] + ceil_div(counts[l], 16);
+  }
+  hipLaunchKernelGGL(wgrad_reduce_multi_kernel, dim3(rb.block_begin[n]), dim3(256), 0, as_stream(stream), rb);
+  return (int)hipGetLastError();
 }
 
 int istnet_pw_wgrad_reduce(int count, int splits, const float* dw_part, float* dw, void* stream) {

@@ -173,6 +173,7 @@ def _backward_stack(lib, dev, st, b, c0, g, s, x, gather, training, ys, bns, par
     main = torch.cuda.current_stream(dev)
     side = _side_stream(dev) if (USE_SIDE_STREAM and _native.TIMING is None) else None
     keep = []                        # tensors the side stream reads: kept alive until the final join
+    pending = []                     # split-K partials of all layers, reduced by ONE launch at the end
     for li in range(n - 1, -1, -1):
         w, gamma = params[3 * li], params[3 * li + 1]
         cout = w.shape[0]
@@ -227,8 +228,11 @@ def _backward_stack(lib, dev, st, b, c0, g, s, x, gather, training, ys, bns, par
                     kname, flops, 4.0 * (b * p * (cin + cout) + grad_elems), lambda: lib.istnet_pw_wgrad(
                         b, cin, cout, p, ns_arg, src.data_ptr(), sc, sh, y.data_ptr(), dd, dp, da,
                         bn.data_ptr(), bwdc.data_ptr(), ws.data_ptr(), wst)), "pw_wgrad")
-            _native.check(lib.istnet_pw_wgrad_reduce(cout * cin, splits, ws.data_ptr(), dw.data_ptr(), wst),
-                          "pw_wgrad_reduce")
+            if side is not None:
+                _native.check(lib.istnet_pw_wgrad_reduce(cout * cin, splits, ws.data_ptr(), dw.data_ptr(), wst),
+                              "pw_wgrad_reduce")
+            else:
+                pending.append((cout * cin, splits, ws.data_ptr(), dw.data_ptr()))   # reduced in one launch below
             keep += [ws, dw]
             grads[3 * li] = dw.view_as(w)
         if use_gather and need_x and gather.n <= 4096:
@@ -259,6 +263,8 @@ def _backward_stack(lib, dev, st, b, c0, g, s, x, gather, training, ys, bns, par
             d_dense, d_pooled, d_arg = dprev, None, None
             if li == 0:
                 dx = dprev
+    if pending:
+        _native.reduce_multi(pending, st)
     if side is not None and keep:
         done = torch.cuda.Event()
         done.record(side)
