@@ -199,3 +199,33 @@ def test_full_size_encoder_matches_cpu_oracle_composition(oracle):
     finally:
         pointnet2_utils._ext = saved
     torch.testing.assert_close(out_gpu, out_cpu, **TOL)
+
+
+def test_inference_config5_n2048_matches_cpu_oracle_composition(oracle):
+    """BASELINE config 5 shape (eval mode, N=2048; B reduced so the CPU side stays fast): the IST-Net point
+    branch on the GPU vs the same modules over the CPU oracle; poses within 1e-4."""
+    from istnet_amd.ist_net import IST_Net
+    from istnet_amd.pointnet2 import pointnet2_utils
+    b, n = 4, 2048
+    torch.manual_seed(11)
+    net = IST_Net().eval()
+    g = torch.Generator().manual_seed(12)
+    pts = _shell(b, n, 13) + torch.tensor([0.0, 0.0, 0.8])
+    inputs = {"pts": pts, "rgb_local": torch.randn(b, 128, n, generator=g),
+              "category_label": torch.randint(0, 6, (b, 1), generator=g)}
+    net_gpu = IST_Net().to(DEV).eval()
+    net_gpu.load_state_dict(net.state_dict())
+    with torch.no_grad():
+        out_gpu = net_gpu({k: v.to(DEV) for k, v in inputs.items()})
+        saved = pointnet2_utils._ext
+        try:
+            pointnet2_utils._ext = oracle
+            out_cpu = net(inputs)
+        finally:
+            pointnet2_utils._ext = saved
+    for k in ("pred_rotation", "pred_translation", "pred_size", "pred_qo"):
+        torch.testing.assert_close(out_gpu[k].cpu(), out_cpu[k], **TOL)
+    # rotations are proper
+    r = out_gpu["pred_rotation"]
+    torch.testing.assert_close(torch.matmul(r.transpose(1, 2), r), torch.eye(3, device=DEV).expand(b, 3, 3),
+                               rtol=1e-4, atol=1e-4)
