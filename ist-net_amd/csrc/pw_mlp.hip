@@ -873,6 +873,95 @@ __global__ __launch_bounds__(kThreads) void pw_wgrad_kernel(
     }
 }
 
+// ============================================================================================
+// wgrad for small layers (cout <= 32 and cin <= 32: SA1, the 32->32 layers of SA2).  The generic kernel
+// would pad the 16x16 .. 32x32 output to a 64x64 tile (16x wasted MFMA, 4x redundant loads).  Here the
+// output is ONE 32x32 MFMA tile and the four waves of a workgroup split K instead of the tile: each wave
+// walks its own 32-point chunks through wave-private LDS (no workgroup barrier in the loop), and the four
+// accumulators are summed through LDS at the end.
+// ============================================================================================
+template <bool GATHER>
+__global__ __launch_bounds__(kThreads) void pw_wgrad_small_kernel(
+    int cin, int cout, int P, long long total, int split_len, const float* __restrict__ x, GatherSrc gsrc,
+    const float* __restrict__ in_scale, const float* __restrict__ in_shift, const float* __restrict__ y,
+    GradSrc gs, const float* __restrict__ bn, const float* __restrict__ bwdc, float* __restrict__ dw_part) {
+  constexpr int LD = 33;
+  __shared__ float lds[4][2][kKTW][LD];  // [wave][A|B][k = point][row = channel]
+  const int lane = lane_id(), wv = wave_id();
+  const long long qbeg = (long long)blockIdx.x * split_len;
+  const long long qend = min(qbeg + (long long)split_len, total);
+  const bool has_bn = in_scale != nullptr;
+  float* As = &lds[wv][0][0][0];
+  float* Bs = &lds[wv][1][0][0];
+
+  // a wave's 32x32 tile of 4-point groups: 32 rows x 8 float4 = 256 items, 4 per lane
+  DyRaw araw[4];
+  float4 braw[4];
+  float bsc[4], bsh[4];
+  auto load_chunk = [&](long long qk) {
+    const long long qc = min(qk, total - kKTW);
+    const int b = (int)(qc / P);
+    const int pk = (int)(qc - (long long)b * P);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int e = lane + 64 * i;
+      const int row = e >> 3, p = pk + (e & 7) * 4;
+      load_dy_raw(araw[i], gs, y, (size_t)b * cout + min(row, cout - 1), P, p);
+      const int n = min(row, cin - 1);
+      if (GATHER) {
+        braw[i] = gather4(gsrc, b, n, P, p, gather_idx4(gsrc, b, P, p));
+      } else {
+        braw[i] = *reinterpret_cast<const float4*>(x + ((size_t)b * cin + n) * P + p);
+        if (has_bn) { bsc[i] = in_scale[n]; bsh[i] = in_shift[n]; }
+      }
+    }
+  };
+  auto store_chunk = [&](long long qk) {
+    const int pk = (int)(min(qk, total - kKTW) % P);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int e = lane + 64 * i;
+      const int row = e >> 3, k = (e & 7) * 4;
+      const bool okq = qk + k < qend;
+      float4 v = finish_dy(araw[i], gs, pk + k, min(row, cout - 1), bn, bwdc, cout);
+      if (!(okq && row < cout)) v = zero4();
+      As[(k + 0) * LD + row] = v.x; As[(k + 1) * LD + row] = v.y;
+      As[(k + 2) * LD + row] = v.z; As[(k + 3) * LD + row] = v.w;
+      float4 u = braw[i];
+      if (!GATHER && has_bn) u = bn_relu4(u, bsc[i], bsh[i]);
+      if (!(okq && row < cin)) u = zero4();
+      Bs[(k + 0) * LD + row] = u.x; Bs[(k + 1) * LD + row] = u.y;
+      Bs[(k + 2) * LD + row] = u.z; Bs[(k + 3) * LD + row] = u.w;
+    }
+  };
+
+  f32x16 acc[1][1];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[0][0][r] = 0.f;
+  // chunk c of this split belongs to wave (c & 3)
+  const int nchunks = (int)((qend - qbeg + kKTW - 1) / kKTW);
+  int t = wv;
+  if (t < nchunks) load_chunk(qbeg + (long long)t * kKTW);
+  for (; t < nchunks; t += 4) {
+    store_chunk(qbeg + (long long)t * kKTW);                       // wave-private LDS: no workgroup barrier
+    if (t + 4 < nchunks) load_chunk(qbeg + (long long)(t + 4) * kKTW);  // in flight during the MFMAs
+    __builtin_amdgcn_s_waitcnt(0xc07f);                             // lgkmcnt(0): this wave's ds_writes landed
+    mma_chunk<kKTW, 1, 1, LD, LD>(As, Bs, 0, 0, acc);
+  }
+  // cross-wave sum through LDS (reuse: [4][32*32] floats fit in the staging area)
+  __syncthreads();
+  float* red = &lds[0][0][0][0];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) red[wv * 1024 + mfma_row(r, lane) * 32 + (lane & 31)] = acc[0][0][r];
+  __syncthreads();
+  float* out = dw_part + (size_t)blockIdx.x * cout * cin;
+  for (int i = threadIdx.x; i < 1024; i += kThreads) {
+    const int row = i >> 5, col = i & 31;
+    if (row < cout && col < cin)
+      out[(size_t)row * cin + col] = (red[i] + red[1024 + i]) + (red[2048 + i] + red[3072 + i]);
+  }
+}
+
 // dw[i] = sum_s dw_part[s][i]: 16 elements x 16 split groups per workgroup, fixed reduction order
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(int count, int splits, const float* __restrict__ part,
                                                            float* __restrict__ dw) {
@@ -955,13 +1044,15 @@ inline TileCfg pick_cfg(int b, int m, int P) {
 inline int cfg_nt(TileCfg c) { return c == kCfg32x256 ? 256 : (c == kCfg64x64 ? 64 : 128); }
 inline int cfg_mt(TileCfg c) { return c == kCfg128x128 ? 128 : (c == kCfg32x256 ? 32 : 64); }
 
+inline bool wgrad_small(int cin, int cout) { return cin <= 32 && cout <= 32; }
 inline int wgrad_mt(int cout) { return cout >= 128 ? 128 : 64; }
 inline int wgrad_nt(int cin) { return cin >= 96 ? 128 : 64; }
 inline int wgrad_split_len(int b, int cin, int cout, int P) {
   // Split-K partials cost cout*cin*4 bytes per split (written here, read back by the reduce): aim for ~1024
   // workgroups when the output is small, ~768 when it is large (PMC: at 1024 the partials of a 128x256
   // layer were as much HBM traffic as its activations; at 256-512 the launch no longer fills the chip).
-  const long long tiles = (long long)ceil_div(cout, wgrad_mt(cout)) * ceil_div(cin, wgrad_nt(cin));
+  const long long tiles = wgrad_small(cin, cout)
+                              ? 1 : (long long)ceil_div(cout, wgrad_mt(cout)) * ceil_div(cin, wgrad_nt(cin));
   const long long out_elems = (long long)cout * cin;
   const long long target = out_elems >= 128 * 128 ? 768 : 1024;  // measured: fewer workgroups lose more than the partials cost
   long long want = (target + tiles - 1) / tiles;  // splits over the flattened (cloud, point) range
@@ -986,7 +1077,9 @@ int istnet_pw_tile_cfg(int b, int m, int p) {
   return cfg_mt(c) * 1000 + cfg_nt(c);  // e.g. 128128, 64128, 64064, 32256
 }
 
-int istnet_pw_wgrad_tile_cfg(int cin, int cout) { return wgrad_mt(cout) * 1000 + wgrad_nt(cin); }
+int istnet_pw_wgrad_tile_cfg(int cin, int cout) {
+  return wgrad_small(cin, cout) ? 32032 : wgrad_mt(cout) * 1000 + wgrad_nt(cin);
+}
 
 int istnet_pw_stat_tiles(int b, int cout, int p) {
   return b * ceil_div(p, cfg_nt(pick_cfg(b, cout, p)));
@@ -1158,6 +1251,16 @@ static int launch_pw_wgrad(bool gather, int b, int cin, int cout, int p, int nsa
   GradSrc gs{d_dense, d_pooled, arg, nsample};
   const int len = wgrad_split_len(b, cin, cout, p);
   const long long total = (long long)b * p;
+  if (wgrad_small(cin, cout)) {
+    const dim3 sgrid(wgrad_splits(b, cin, cout, p));
+    if (gather)
+      hipLaunchKernelGGL(pw_wgrad_small_kernel<true>, sgrid, dim3(kThreads), 0, as_stream(stream), cin, cout, p,
+                         total, len, x, g, in_scale, in_shift, y, gs, bn, bwdc, dw_part);
+    else
+      hipLaunchKernelGGL(pw_wgrad_small_kernel<false>, sgrid, dim3(kThreads), 0, as_stream(stream), cin, cout, p,
+                         total, len, x, g, in_scale, in_shift, y, gs, bn, bwdc, dw_part);
+    return (int)hipGetLastError();
+  }
   const int mt = wgrad_mt(cout), nt = wgrad_nt(cin);
   const dim3 grid(wgrad_splits(b, cin, cout, p), ceil_div(cout, mt), ceil_div(cin, nt));
 #define ISTNET_WGRAD(MT, NT)                                                                                  \

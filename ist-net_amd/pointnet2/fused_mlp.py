@@ -36,6 +36,8 @@ else:
 def _kname(base, cfg, gather=None):
     """Kernel symbol as rocprofv3 prints it, e.g. pw_dgrad_kernel<128, 128, 2, 2>."""
     mt, nt = cfg // 1000, cfg % 1000
+    if base == "pw_wgrad_kernel" and mt == 32:
+        return "pw_wgrad_small_kernel<%s>" % ("true" if gather else "false")
     wm, wn = (1, 4) if mt == 32 else (2, 2)
     tail = "" if gather is None else (", true" if gather else ", false")
     return f"{base}<{mt}, {nt}, {wm}, {wn}{tail}>"
