@@ -14,6 +14,8 @@
  *                      bwdc = [3][C]: dY = bwdc[0]*g + bwdc[1] + bwdc[2]*y,  g = dA * [y*scale+shift > 0]
  * Gradient w.r.t. the layer output is given either dense (d_dense (B,C,P)) or, after the fused
  * max-pool, pooled (d_pooled (B,C,P/nsample) + arg (B,C,P/nsample) u8, nsample % 4 == 0).
+ * pooled_bstride = elements between consecutive clouds of d_pooled (0 = C*P/nsample): a channel slice of the
+ * concatenated MSG output gradient (B, Ctot, npoint) is consumed in place, d_pooled pointing at its first row.
  */
 #ifndef ISTNET_PW_H_
 #define ISTNET_PW_H_
@@ -52,10 +54,12 @@ ISTNET_PN2_API int istnet_bn_finalize_fwd(int c, int nt, double count, const flo
                                           float eps, float momentum, float *running_mean,
                                           float *running_var, float *bn, void *stream);
 
-/* out[b][c][g] = max_s relu(y[b][c][g][s]*scale+shift), arg = index of the first maximum (s > 1);
+/* out[b][c][g] = max_s relu(y[b][c][g][s]*scale+shift), arg = index of the first maximum (s > 1); cloud b of
+ * `out` starts at out + b*out_bstride (0 = c*g), so a scale writes straight into its channel slice of the
+ * concatenated MSG output;
  * s == 1: out = relu(y*scale+shift), arg unused (may be NULL) */
 ISTNET_PN2_API int istnet_bn_relu_pool(int b, int c, int g, int s, const float *y, const float *bn,
-                                       float *out, unsigned char *arg, void *stream);
+                                       float *out, long long out_bstride, unsigned char *arg, void *stream);
 
 /* out = y * bn[0] + bn[1] (per channel), followed by ReLU when relu != 0 -- final layer of a bias stack */
 ISTNET_PN2_API int istnet_affine_apply(int b, int c, int p, int relu, const float *y, const float *bn,
@@ -64,7 +68,7 @@ ISTNET_PN2_API int istnet_affine_apply(int b, int c, int p, int relu, const floa
 /* backward statistics: partial sums of g and g*y per channel -> [c][tiles] */
 ISTNET_PN2_API int istnet_pw_bwd_stat_tiles(int b, int p);
 ISTNET_PN2_API int istnet_pw_bwd_stats(int b, int c, int p, int nsample, const float *y,
-                                       const float *d_dense, const float *d_pooled,
+                                       const float *d_dense, const float *d_pooled, long long pooled_bstride,
                                        const unsigned char *arg, const float *bn, float *part_g,
                                        float *part_gy, void *stream);
 /* partials -> dgamma, dbeta, bwdc[3][c]; training = 0 treats BN as a fixed affine map (eval mode) */
@@ -80,18 +84,19 @@ ISTNET_PN2_API int istnet_bn_finalize_bwd(int c, int nt, double count, int train
 ISTNET_PN2_API int istnet_pw_dgrad_stat_tiles(int b, int m_rows, int p);
 ISTNET_PN2_API int istnet_pw_dgrad(int b, int cin_total, int ci_off, int m_rows, int cout, int p,
                                    int nsample, const float *w, const float *y, const float *d_dense,
-                                   const float *d_pooled, const unsigned char *arg, const float *bn,
-                                   const float *bwdc, float *dx, const float *y_in, const float *bn_in,
-                                   float *part_g, float *part_gy, void *stream);
+                                   const float *d_pooled, long long pooled_bstride, const unsigned char *arg,
+                                   const float *bn, const float *bwdc, float *dx, const float *y_in,
+                                   const float *bn_in, float *part_g, float *part_gy, void *stream);
 
 /* out[b][co][i] = sum_{p : idx[b][p] == i} dY[b][co][p], i < n  (the group_points_grad scatter applied to the
  * layer's dY instead of to the layer-0 input gradient; the scatter commutes with the channel mixing, so the
  * feature gradient of a set-abstraction scale is  W0[:, 3:]^T . out[b]  -- a GEMM over n instead of p columns).
- * idx (b, p) i32 with values in [0, n); needs n <= 4096. */
+ * idx (b, p) i32 with values in [0, n); needs n <= 4096.  Cloud b of `out` starts at out + b*out_bstride
+ * (0 = cout*n). */
 ISTNET_PN2_API int istnet_pw_scatter_dy(int b, int cout, int n, int p, int nsample, const float *y,
-                                        const float *d_dense, const float *d_pooled, const unsigned char *arg,
-                                        const float *bn, const float *bwdc, const int *idx, float *out,
-                                        void *stream);
+                                        const float *d_dense, const float *d_pooled, long long pooled_bstride,
+                                        const unsigned char *arg, const float *bn, const float *bwdc,
+                                        const int *idx, float *out, long long out_bstride, void *stream);
 
 /* split-K weight gradient (requires p % 32 == 0): dw_part[split][co][ci] = sum_{p in split} dY[b][co][p] * act(x[b][ci][p]) with
  * istnet_pw_wgrad_splits(...) splits; istnet_pw_wgrad_reduce sums the partials in a fixed order:
@@ -99,14 +104,15 @@ ISTNET_PN2_API int istnet_pw_scatter_dy(int b, int cout, int n, int p, int nsamp
 ISTNET_PN2_API int istnet_pw_wgrad_splits(int b, int cin, int cout, int p);
 ISTNET_PN2_API int istnet_pw_wgrad(int b, int cin, int cout, int p, int nsample, const float *x,
                                    const float *in_scale, const float *in_shift, const float *y,
-                                   const float *d_dense, const float *d_pooled, const unsigned char *arg,
-                                   const float *bn, const float *bwdc, float *dw_part, void *stream);
+                                   const float *d_dense, const float *d_pooled, long long pooled_bstride,
+                                   const unsigned char *arg, const float *bn, const float *bwdc, float *dw_part,
+                                   void *stream);
 /* wgrad with the gathered layer-0 input (see istnet_pw_forward_gather); grad_nsample = nsample of the pooled
  * gradient source (0 when d_dense is given) */
 ISTNET_PN2_API int istnet_pw_wgrad_gather(int b, int n, int npoint, int nsample, int cfeat, int cout,
                                           int grad_nsample, const float *xyz, const float *new_xyz,
                                           const float *feat, const int *idx, const float *y,
-                                          const float *d_dense, const float *d_pooled,
+                                          const float *d_dense, const float *d_pooled, long long pooled_bstride,
                                           const unsigned char *arg, const float *bn, const float *bwdc,
                                           float *dw_part, void *stream);
 ISTNET_PN2_API int istnet_pw_wgrad_reduce(int count, int splits, const float *dw_part, float *dw,

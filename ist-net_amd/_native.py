@@ -13,7 +13,7 @@ HEADER_PATH = os.path.join(INCLUDE_DIR, "istnet_pn2.h")
 HEADER_PATHS = [HEADER_PATH, os.path.join(INCLUDE_DIR, "istnet_pw.h")]
 ABI_VERSION = 1
 
-_i, _f, _p, _d = ctypes.c_int, ctypes.c_float, ctypes.c_void_p, ctypes.c_double
+_i, _f, _p, _d, _l = ctypes.c_int, ctypes.c_float, ctypes.c_void_p, ctypes.c_double, ctypes.c_longlong
 # name -> argtypes (restype is always int); mirrors include/istnet_pn2.h
 SIGNATURES = {
     "istnet_pn2_set_tuning": [_i, _i],
@@ -34,18 +34,18 @@ SIGNATURES = {
     "istnet_pw_stat_tiles": [_i, _i, _i],
     "istnet_pw_forward": [_i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p],
     "istnet_pw_forward_gather": [_i, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p],
-    "istnet_pw_wgrad_gather": [_i, _i, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p],
+    "istnet_pw_wgrad_gather": [_i, _i, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _l, _p, _p, _p, _p, _p],
     "istnet_bn_finalize_fwd": [_i, _i, _d, _p, _p, _p, _p, _f, _f, _p, _p, _p, _p],
-    "istnet_bn_relu_pool": [_i, _i, _i, _i, _p, _p, _p, _p, _p],
+    "istnet_bn_relu_pool": [_i, _i, _i, _i, _p, _p, _p, _l, _p, _p],
     "istnet_affine_apply": [_i, _i, _i, _i, _p, _p, _p, _p],
     "istnet_pw_bwd_stat_tiles": [_i, _i],
-    "istnet_pw_bwd_stats": [_i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p],
+    "istnet_pw_bwd_stats": [_i, _i, _i, _i, _p, _p, _p, _l, _p, _p, _p, _p, _p],
     "istnet_bn_finalize_bwd": [_i, _i, _d, _i, _p, _p, _p, _p, _p, _p, _p, _p],
     "istnet_pw_dgrad_stat_tiles": [_i, _i, _i],
-    "istnet_pw_dgrad": [_i, _i, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p],
-    "istnet_pw_scatter_dy": [_i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p],
+    "istnet_pw_dgrad": [_i, _i, _i, _i, _i, _i, _i, _p, _p, _p, _p, _l, _p, _p, _p, _p, _p, _p, _p, _p, _p],
+    "istnet_pw_scatter_dy": [_i, _i, _i, _i, _i, _p, _p, _p, _l, _p, _p, _p, _p, _p, _l, _p],
     "istnet_pw_wgrad_splits": [_i, _i, _i, _i],
-    "istnet_pw_wgrad": [_i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p],
+    "istnet_pw_wgrad": [_i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _l, _p, _p, _p, _p, _p],
     "istnet_pw_wgrad_reduce": [_i, _i, _p, _p, _p],
     "istnet_pw_wgrad_reduce_multi": [_i, _p, _p, _p, _p, _p],
 }

@@ -331,7 +331,7 @@ template <int S4>  // S = 4*S4 samples per group, one thread per group
 __global__ __launch_bounds__(256) void bn_relu_pool_kernel(int C, int G, const float* __restrict__ y,
                                                            const float* __restrict__ scale,
                                                            const float* __restrict__ shift,
-                                                           float* __restrict__ out,
+                                                           float* __restrict__ out, long long out_bstride,
                                                            uint8_t* __restrict__ arg) {
   const int bc = blockIdx.y;
   const int g = blockIdx.x * 256 + threadIdx.x;
@@ -350,7 +350,7 @@ __global__ __launch_bounds__(256) void bn_relu_pool_kernel(int C, int G, const f
     if (a2 > best) { best = a2; besti = 4 * i + 2; }
     if (a3 > best) { best = a3; besti = 4 * i + 3; }
   }
-  out[(size_t)bc * G + g] = best;
+  out[(size_t)(bc / C) * out_bstride + (size_t)(bc % C) * G + g] = best;
   arg[(size_t)bc * G + g] = (uint8_t)besti;
 }
 __global__ __launch_bounds__(256) void bn_relu_apply_kernel(int C, int P4, const float* __restrict__ y,
@@ -388,16 +388,23 @@ __global__ __launch_bounds__(256) void affine_apply_kernel(int C, int P4, int re
 // ============================================================================================
 struct GradSrc {
   const float* dense;    // (B*C, P) or null
-  const float* pooled;   // (B*C, G) or null
+  const float* pooled;   // (B, C, G) or null; cloud b starts at pooled + b * pooled_bstride (a channel slice of a
+                         // wider (B, Ctot, G) tensor is addressed without a copy)
   const uint8_t* arg;    // (B*C, G)
   int S;                 // nsample (pooled mode)
+  long long pooled_bstride;  // elements between clouds of `pooled`; C*G when it is a plain (B, C, G) tensor
+  int C;                 // channels of this layer (row = b*C + c)
 };
+__device__ __forceinline__ float pooled_at(const GradSrc& gs, size_t row, int G, int g) {
+  const size_t b = row / (size_t)gs.C, c = row - b * (size_t)gs.C;
+  return gs.pooled[b * (size_t)gs.pooled_bstride + c * (size_t)G + g];
+}
 __device__ __forceinline__ float4 load_grad4(const GradSrc& gs, size_t row, int P, int p) {
   if (gs.dense != nullptr) return *reinterpret_cast<const float4*>(gs.dense + row * (size_t)P + p);
   // pooled: the 4 consecutive points p..p+3 lie in one group when S % 4 == 0
   const int G = P / gs.S;
   const int g = p / gs.S, k = p - g * gs.S;
-  const float d = gs.pooled[row * (size_t)G + g];
+  const float d = pooled_at(gs, row, G, g);
   const int a = gs.arg[row * (size_t)G + g];
   return make_float4(a == k ? d : 0.f, a == k + 1 ? d : 0.f, a == k + 2 ? d : 0.f, a == k + 3 ? d : 0.f);
 }
@@ -490,7 +497,7 @@ __device__ __forceinline__ void load_dy_raw(DyRaw& r, const GradSrc& gs, const f
     r.a = 0;
   } else {
     const int G = P / gs.S, g = p / gs.S;
-    r.d = make_float4(gs.pooled[row * (size_t)G + g], 0.f, 0.f, 0.f);
+    r.d = make_float4(pooled_at(gs, row, G, g), 0.f, 0.f, 0.f);
     r.a = gs.arg[row * (size_t)G + g];
   }
 }
@@ -537,7 +544,7 @@ __global__ __launch_bounds__(256) void pw_scatter_dy_kernel(int cout, int n, int
                                                             GradSrc gs, const float* __restrict__ bn,
                                                             const float* __restrict__ bwdc,
                                                             const int* __restrict__ idx_all,
-                                                            float* __restrict__ out) {
+                                                            float* __restrict__ out, long long out_bstride) {
   extern __shared__ __attribute__((aligned(16))) float acc[];  // [CH][n]
   const int b = blockIdx.y, c0 = blockIdx.x * kScatterCH;
   const int nch = min(kScatterCH, cout - c0);
@@ -563,7 +570,7 @@ __global__ __launch_bounds__(256) void pw_scatter_dy_kernel(int cout, int n, int
         d = gs.dense[row * (size_t)P + pc];
       } else {
         const int g = pc / gs.S;
-        d = (gs.arg[row * (size_t)G + g] == pc - g * gs.S) ? gs.pooled[row * (size_t)G + g] : 0.f;
+        d = (gs.arg[row * (size_t)G + g] == pc - g * gs.S) ? pooled_at(gs, row, G, g) : 0.f;
       }
       const float act = yv * bn[co] + bn[cout + co];
       float v = bwdc[co] * (act > 0.f ? d : 0.f) + bwdc[cout + co] + bwdc[2 * cout + co] * yv;
@@ -578,7 +585,7 @@ __global__ __launch_bounds__(256) void pw_scatter_dy_kernel(int cout, int n, int
     }
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < nch * n; i += 256) out[((size_t)b * cout + c0) * n + i] = acc[i];
+  for (int i = threadIdx.x; i < nch * n; i += 256) out[(size_t)b * out_bstride + (size_t)c0 * n + i] = acc[i];
 }
 
 // ============================================================================================
@@ -1138,13 +1145,14 @@ int istnet_bn_finalize_fwd(int c, int nt, double count, const float* part_sum, c
 }
 
 int istnet_bn_relu_pool(int b, int c, int g, int s, const float* y, const float* bn, float* out,
-                        unsigned char* arg, void* stream) {
+                        long long out_bstride, unsigned char* arg, void* stream) {
+  if (out_bstride <= 0) out_bstride = (long long)c * g;
   if (b <= 0 || c <= 0 || g <= 0 || s <= 0) return ISTNET_PN2_EINVAL;
   const float* scale = bn;
   const float* shift = bn + c;
   if (s == 1) {
     const long long P = g;
-    if (P & 3) return ISTNET_PN2_EINVAL;
+    if ((P & 3) || out_bstride != (long long)c * g) return ISTNET_PN2_EINVAL;
     hipLaunchKernelGGL(bn_relu_apply_kernel, dim3(ceil_div((int)(P / 4), 256), b * c), dim3(256), 0,
                        as_stream(stream), c, (int)(P / 4), y, scale, shift, out);
     return (int)hipGetLastError();
@@ -1152,7 +1160,7 @@ int istnet_bn_relu_pool(int b, int c, int g, int s, const float* y, const float*
   const dim3 grid(ceil_div(g, 256), b * c);
 #define ISTNET_POOL(S4)                                                                                  \
   hipLaunchKernelGGL((bn_relu_pool_kernel<S4>), grid, dim3(256), 0, as_stream(stream), c, g, y, scale,  \
-                     shift, out, arg)
+                     shift, out, out_bstride, arg)
   switch (s) {
     case 4: ISTNET_POOL(1); break;
     case 8: ISTNET_POOL(2); break;
@@ -1175,12 +1183,13 @@ int istnet_affine_apply(int b, int c, int p, int relu, const float* y, const flo
 int istnet_pw_bwd_stat_tiles(int b, int p) { return b * ceil_div(p, kStatChunk); }
 
 int istnet_pw_bwd_stats(int b, int c, int p, int nsample, const float* y, const float* d_dense,
-                        const float* d_pooled, const unsigned char* arg, const float* bn, float* part_g,
-                        float* part_gy, void* stream) {
+                        const float* d_pooled, long long pooled_bstride, const unsigned char* arg,
+                        const float* bn, float* part_g, float* part_gy, void* stream) {
+  const int GS_C = c;
   if (b <= 0 || c <= 0 || p <= 0 || (p & 3)) return ISTNET_PN2_EINVAL;
   if (d_dense == nullptr && (d_pooled == nullptr || arg == nullptr || nsample <= 0 || (nsample & 3)))
     return ISTNET_PN2_EINVAL;
-  GradSrc gs{d_dense, d_pooled, arg, nsample};
+  GradSrc gs{d_dense, d_pooled, arg, nsample, pooled_bstride > 0 ? pooled_bstride : (long long)GS_C * (nsample > 0 ? p / nsample : 0), GS_C};
   const int chunks = ceil_div(p, kStatChunk);
   hipLaunchKernelGGL(pw_bwd_stats_kernel, dim3(chunks, c, b), dim3(256), 0, as_stream(stream), c, p, gs, y,
                      bn, bn + c, part_g, part_gy, chunks * b);
@@ -1198,13 +1207,15 @@ int istnet_bn_finalize_bwd(int c, int nt, double count, int training, const floa
 
 int istnet_pw_dgrad(int b, int cin_total, int ci_off, int m_rows, int cout, int p, int nsample,
                     const float* w, const float* y, const float* d_dense, const float* d_pooled,
-                    const unsigned char* arg, const float* bn, const float* bwdc, float* dx, const float* y_in,
-                    const float* bn_in, float* part_g, float* part_gy, void* stream) {
+                    long long pooled_bstride, const unsigned char* arg, const float* bn, const float* bwdc,
+                    float* dx, const float* y_in, const float* bn_in, float* part_g, float* part_gy,
+                    void* stream) {
+  const int GS_C = cout;
   if (b <= 0 || m_rows <= 0 || cout <= 0 || p <= 0 || (p & 3)) return ISTNET_PN2_EINVAL;
   if (part_g != nullptr && (y_in == nullptr || bn_in == nullptr || part_gy == nullptr)) return ISTNET_PN2_EINVAL;
   if (d_dense == nullptr && (d_pooled == nullptr || arg == nullptr || nsample <= 0 || (nsample & 3)))
     return ISTNET_PN2_EINVAL;
-  GradSrc gs{d_dense, d_pooled, arg, nsample};
+  GradSrc gs{d_dense, d_pooled, arg, nsample, pooled_bstride > 0 ? pooled_bstride : (long long)GS_C * (nsample > 0 ? p / nsample : 0), GS_C};
   const TileCfg cfg = pick_cfg(b, m_rows, p);
   const int tpc = ceil_div(p, cfg_nt(cfg));
   const dim3 grid(tpc * b, ceil_div(m_rows, cfg_mt(cfg)));
@@ -1223,15 +1234,18 @@ int istnet_pw_dgrad(int b, int cin_total, int ci_off, int m_rows, int cout, int 
 }
 
 int istnet_pw_scatter_dy(int b, int cout, int n, int p, int nsample, const float* y, const float* d_dense,
-                         const float* d_pooled, const unsigned char* arg, const float* bn, const float* bwdc,
-                         const int* idx, float* out, void* stream) {
+                         const float* d_pooled, long long pooled_bstride, const unsigned char* arg,
+                         const float* bn, const float* bwdc, const int* idx, float* out, long long out_bstride,
+                         void* stream) {
+  const int GS_C = cout;
   if (b <= 0 || cout <= 0 || n <= 0 || p <= 0) return ISTNET_PN2_EINVAL;
   if (d_dense == nullptr && (d_pooled == nullptr || arg == nullptr || nsample <= 0)) return ISTNET_PN2_EINVAL;
   const size_t lds = (size_t)kScatterCH * n * 4;
   if (lds > 64 * 1024) return ISTNET_PN2_EINVAL;
-  GradSrc gs{d_dense, d_pooled, arg, nsample};
+  GradSrc gs{d_dense, d_pooled, arg, nsample, pooled_bstride > 0 ? pooled_bstride : (long long)GS_C * (nsample > 0 ? p / nsample : 0), GS_C};
   hipLaunchKernelGGL(pw_scatter_dy_kernel, dim3(ceil_div(cout, kScatterCH), b), dim3(256), lds,
-                     as_stream(stream), cout, n, p, y, gs, bn, bwdc, idx, out);
+                     as_stream(stream), cout, n, p, y, gs, bn, bwdc, idx, out,
+                     out_bstride > 0 ? out_bstride : (long long)cout * n);
   return (int)hipGetLastError();
 }
 
@@ -1243,12 +1257,14 @@ int istnet_pw_wgrad_splits(int b, int cin, int cout, int p) { return wgrad_split
 
 static int launch_pw_wgrad(bool gather, int b, int cin, int cout, int p, int nsample, const float* x,
                            const GatherSrc& g, const float* in_scale, const float* in_shift, const float* y,
-                           const float* d_dense, const float* d_pooled, const unsigned char* arg, const float* bn,
-                           const float* bwdc, float* dw_part, void* stream) {
+                           const float* d_dense, const float* d_pooled, long long pooled_bstride,
+                           const unsigned char* arg, const float* bn, const float* bwdc, float* dw_part,
+                           void* stream) {
+  const int GS_C = cout;
   if (b <= 0 || cin <= 0 || cout <= 0 || p <= 0 || (p % kKTW)) return ISTNET_PN2_EINVAL;
   if (d_dense == nullptr && (d_pooled == nullptr || arg == nullptr || nsample <= 0 || (nsample & 3)))
     return ISTNET_PN2_EINVAL;
-  GradSrc gs{d_dense, d_pooled, arg, nsample};
+  GradSrc gs{d_dense, d_pooled, arg, nsample, pooled_bstride > 0 ? pooled_bstride : (long long)GS_C * (nsample > 0 ? p / nsample : 0), GS_C};
   const int len = wgrad_split_len(b, cin, cout, p);
   const long long total = (long long)b * p;
   if (wgrad_small(cin, cout)) {
@@ -1282,21 +1298,21 @@ static int launch_pw_wgrad(bool gather, int b, int cin, int cout, int p, int nsa
 
 int istnet_pw_wgrad(int b, int cin, int cout, int p, int nsample, const float* x, const float* in_scale,
                     const float* in_shift, const float* y, const float* d_dense, const float* d_pooled,
-                    const unsigned char* arg, const float* bn, const float* bwdc, float* dw_part,
-                    void* stream) {
+                    long long pooled_bstride, const unsigned char* arg, const float* bn, const float* bwdc,
+                    float* dw_part, void* stream) {
   return launch_pw_wgrad(false, b, cin, cout, p, nsample, x, GatherSrc{}, in_scale, in_shift, y, d_dense,
-                         d_pooled, arg, bn, bwdc, dw_part, stream);
+                         d_pooled, pooled_bstride, arg, bn, bwdc, dw_part, stream);
 }
 
 int istnet_pw_wgrad_gather(int b, int n, int npoint, int nsample, int cfeat, int cout, int grad_nsample,
                            const float* xyz, const float* new_xyz, const float* feat, const int* idx,
                            const float* y, const float* d_dense, const float* d_pooled,
-                           const unsigned char* arg, const float* bn, const float* bwdc, float* dw_part,
-                           void* stream) {
+                           long long pooled_bstride, const unsigned char* arg, const float* bn,
+                           const float* bwdc, float* dw_part, void* stream) {
   if (n <= 0 || npoint <= 0 || nsample <= 0 || (nsample & 3) || cfeat < 0) return ISTNET_PN2_EINVAL;
   const GatherSrc g{xyz, new_xyz, feat, idx, n, nsample, cfeat};
   return launch_pw_wgrad(true, b, 3 + cfeat, cout, npoint * nsample, grad_nsample, nullptr, g, nullptr, nullptr, y,
-                         d_dense, d_pooled, arg, bn, bwdc, dw_part, stream);
+                         d_dense, d_pooled, pooled_bstride, arg, bn, bwdc, dw_part, stream);
 }
 
 int istnet_pw_wgrad_reduce_multi(int n, const int* counts, const int* splits, const float* const* parts,

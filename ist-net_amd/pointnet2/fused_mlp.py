@@ -93,8 +93,11 @@ class _Gather:
         self.cfeat = 0 if feat is None else feat.shape[1]
 
 
-def _forward_stack(lib, dev, st, b, c0, g, s, x, gather, training, layers, params):
-    """Runs all layers + the BN/ReLU/max tail.  Returns (out, arg, ys, bns)."""
+def _forward_stack(lib, dev, st, b, c0, g, s, x, gather, training, layers, params, out_spec=None):
+    """Runs all layers + the BN/ReLU/max tail.  Returns (out, arg, ys, bns).
+
+    ``out_spec`` = (tensor (B, Ctot, G), channel offset): write the pooled result into that channel slice
+    (the MSG concat happens in place) instead of a fresh tensor."""
     p = g * s
     ys, bns = [], []
     cur, cur_c, in_bn = x, c0, None
@@ -143,7 +146,12 @@ def _forward_stack(lib, dev, st, b, c0, g, s, x, gather, training, layers, param
         ys.append(y)
         bns.append(bn)
         cur, cur_c, in_bn = y, cout, bn
-    out = _empty((b, cur_c, g), torch.float32, dev)
+    if out_spec is None:
+        out = _empty((b, cur_c, g), torch.float32, dev)
+        out_ptr, out_bstride = out.data_ptr(), 0
+    else:
+        out, coff = out_spec
+        out_ptr, out_bstride = out.data_ptr() + coff * g * 4, out.shape[1] * g
     arg = _empty((b, cur_c, g), torch.uint8, dev) if s > 1 else None
     if s == 1 and not layers[-1].relu:
         _native.check(lib.istnet_affine_apply(b, cur_c, g, 0, cur.data_ptr(), in_bn.data_ptr(), out.data_ptr(), st),
@@ -154,16 +162,20 @@ def _forward_stack(lib, dev, st, b, c0, g, s, x, gather, training, layers, param
         mask[3].fill_(1.0)
         bns[-1] = mask
     else:
-        _native.check(lib.istnet_bn_relu_pool(b, cur_c, g, s, cur.data_ptr(), in_bn.data_ptr(), out.data_ptr(),
-                                              _p(arg), st), "bn_relu_pool")
+        _native.check(lib.istnet_bn_relu_pool(b, cur_c, g, s, cur.data_ptr(), in_bn.data_ptr(), out_ptr,
+                                              out_bstride, _p(arg), st), "bn_relu_pool")
     return out, arg, ys, bns
 
 
-def _backward_stack(lib, dev, st, b, c0, g, s, x, gather, training, ys, bns, params, arg, dout, need_w, need_x):
+def _backward_stack(lib, dev, st, b, c0, g, s, x, gather, training, ys, bns, params, arg, dout, need_w, need_x,
+                    pooled_bstride=0, scatter_out=None):
     """Returns (grads for [w, gamma, beta] * L, gradient w.r.t. the layer-0 input or None).
 
     With `gather`, the layer-0 input gradient is produced for the feature channels only
-    (rows 3..3+cfeat of the grouped tensor), shape (B, cfeat, P)."""
+    (rows 3..3+cfeat of the grouped tensor), shape (B, cfeat, P).
+    ``pooled_bstride``: `dout` is a channel slice (view) of a wider (B, Ctot, G) gradient, consumed in place.
+    ``scatter_out`` = (tensor (B, Rtot, n), row offset): the scattered dY0 of the scale goes into those rows and
+    the caller finishes the feature gradient for all scales with one GEMM."""
     p = g * s
     n = len(ys)
     grads = [None] * (3 * n)
@@ -184,12 +196,13 @@ def _backward_stack(lib, dev, st, b, c0, g, s, x, gather, training, ys, bns, par
         y, bn = ys[li], bns[li]
         ns_arg = s if pooled and li == n - 1 else 0
         dd, dp, da = _p(d_dense), _p(d_pooled), _p(d_arg)
+        pbs = pooled_bstride if (pooled and li == n - 1) else 0
         grad_elems = b * cout * (p if dd is not None else p // s)
         if fused_part is not None:
             part, nt_l = fused_part, fused_nt
         else:
             part, nt_l = _empty((2, cout, ntb), torch.float32, dev), ntb
-            _native.check(lib.istnet_pw_bwd_stats(b, cout, p, ns_arg, y.data_ptr(), dd, dp, da, bn.data_ptr(),
+            _native.check(lib.istnet_pw_bwd_stats(b, cout, p, ns_arg, y.data_ptr(), dd, dp, pbs, da, bn.data_ptr(),
                                                   part[0].data_ptr(), part[1].data_ptr(), st), "pw_bwd_stats")
         fused_part = None
         dgamma = _empty(cout, torch.float32, dev)
@@ -220,7 +233,7 @@ def _backward_stack(lib, dev, st, b, c0, g, s, x, gather, training, ys, bns, par
                 _native.check(_native.timed(
                     kname, flops, 4.0 * (b * p * (1 + cout) + grad_elems), lambda: lib.istnet_pw_wgrad_gather(
                         b, ga.n, ga.npoint, ga.nsample, ga.cfeat, cout, ns_arg, ga.xyz.data_ptr(),
-                        ga.new_xyz.data_ptr(), _p(ga.feat), ga.idx.data_ptr(), y.data_ptr(), dd, dp, da,
+                        ga.new_xyz.data_ptr(), _p(ga.feat), ga.idx.data_ptr(), y.data_ptr(), dd, dp, pbs, da,
                         bn.data_ptr(), bwdc.data_ptr(), ws.data_ptr(), wst)), "pw_wgrad_gather")
             else:
                 src = x if li == 0 else ys[li - 1]
@@ -228,7 +241,7 @@ def _backward_stack(lib, dev, st, b, c0, g, s, x, gather, training, ys, bns, par
                 sc, sh = (_p(in_bn[0]), _p(in_bn[1])) if in_bn is not None else (None, None)
                 _native.check(_native.timed(
                     kname, flops, 4.0 * (b * p * (cin + cout) + grad_elems), lambda: lib.istnet_pw_wgrad(
-                        b, cin, cout, p, ns_arg, src.data_ptr(), sc, sh, y.data_ptr(), dd, dp, da,
+                        b, cin, cout, p, ns_arg, src.data_ptr(), sc, sh, y.data_ptr(), dd, dp, pbs, da,
                         bn.data_ptr(), bwdc.data_ptr(), ws.data_ptr(), wst)), "pw_wgrad")
             if side is not None:
                 _native.check(lib.istnet_pw_wgrad_reduce(cout * cin, splits, ws.data_ptr(), dw.data_ptr(), wst),
@@ -241,11 +254,17 @@ def _backward_stack(lib, dev, st, b, c0, g, s, x, gather, training, ys, bns, par
             # feature gradient of the scale: scatter dY0 over the ball indices (Cout0 x n per cloud), then
             # the small product W0[:, 3:]^T . G  (see pw_scatter_dy_kernel) -- no (B, C, P) tensor, no big dgrad
             ga = gather
-            gmat = _empty((b, cout, ga.n), torch.float32, dev)
-            _native.check(lib.istnet_pw_scatter_dy(b, cout, ga.n, p, ns_arg, y.data_ptr(), dd, dp, da,
-                                                   bn.data_ptr(), bwdc.data_ptr(), ga.idx.data_ptr(),
-                                                   gmat.data_ptr(), st), "pw_scatter_dy")
-            dx = torch.matmul(w2[:, 3:].t(), gmat)          # (C, Cout0) @ (B, Cout0, n) -> (B, C, n)
+            if scatter_out is None:
+                gmat = _empty((b, cout, ga.n), torch.float32, dev)
+                gptr, gbs = gmat.data_ptr(), 0
+            else:
+                gbuf, goff = scatter_out
+                gptr, gbs = gbuf.data_ptr() + goff * ga.n * 4, gbuf.shape[1] * ga.n
+            _native.check(lib.istnet_pw_scatter_dy(b, cout, ga.n, p, ns_arg, y.data_ptr(), dd, dp, pbs, da,
+                                                   bn.data_ptr(), bwdc.data_ptr(), ga.idx.data_ptr(), gptr, gbs, st),
+                          "pw_scatter_dy")
+            if scatter_out is None:
+                dx = torch.matmul(w2[:, 3:].t(), gmat)      # (C, Cout0) @ (B, Cout0, n) -> (B, C, n)
             scattered = True
         elif li > 0 or need_x:
             ci_off, rows = (3, gather.cfeat) if use_gather else (0, cin)
@@ -260,7 +279,7 @@ def _backward_stack(lib, dev, st, b, c0, g, s, x, gather, training, ys, bns, par
             _native.check(_native.timed(
                 _kname("pw_dgrad_kernel", lib.istnet_pw_tile_cfg(b, rows, p)), 2.0 * b * p * rows * cout,
                 4.0 * (b * p * (rows + cout + (rows if li > 0 else 0)) + grad_elems), lambda: lib.istnet_pw_dgrad(
-                    b, cin, ci_off, rows, cout, p, ns_arg, w2.data_ptr(), y.data_ptr(), dd, dp, da,
+                    b, cin, ci_off, rows, cout, p, ns_arg, w2.data_ptr(), y.data_ptr(), dd, dp, pbs, da,
                     bn.data_ptr(), bwdc.data_ptr(), dprev.data_ptr(), y_in, bn_in, pg, pgy, st)), "pw_dgrad")
             d_dense, d_pooled, d_arg = dprev, None, None
             if li == 0:
@@ -354,6 +373,108 @@ class FusedSAScaleFunction(Function):
             if need_x:
                 dfeat = dxf if scattered else _ext.group_points_grad(dxf.view(b, ga.cfeat, g, s), idx, ga.n)
         return (dfeat, None, None, None, None, None, *grads)
+
+
+class FusedSALevelFunction(Function):
+    """All MSG scales of one set-abstraction level in one autograd node:
+    (features (B,C,n) | None, xyz, new_xyz, [idx per scale]) -> (B, sum C_L, npoint).
+
+    Each scale's tail writes its channel slice of the concatenated output directly (no torch.cat); backward
+    reads its slice of the incoming gradient in place (no slice copies), scatters dY0 of every scale into one
+    (B, sum Cout0, n) buffer and finishes the feature gradient with ONE MFMA GEMM over the concatenated
+    layer-0 feature weights -- reference pointnet2_modules.py:60-73 without the glue kernels."""
+
+    @staticmethod
+    def forward(ctx, features, xyz, new_xyz, training, scales, *tensors):
+        # scales: list of per-scale `layers`; tensors = [idx_0..idx_{S-1}, params of scale 0, params of scale 1, ...]
+        lib = _native.lib()
+        dev = xyz.device
+        nsc = len(scales)
+        idxs = [t.contiguous() for t in tensors[:nsc]]
+        xyz, new_xyz = xyz.contiguous(), new_xyz.contiguous()
+        feat = None if features is None else features.contiguous()
+        b, g = xyz.shape[0], new_xyz.shape[1]
+        pos, plist = nsc, []
+        for layers in scales:
+            plist.append(tensors[pos:pos + 3 * len(layers)])
+            pos += 3 * len(layers)
+        ctot = sum(pl[-3].shape[0] for pl in plist)
+        out = _empty((b, ctot, g), torch.float32, dev)
+        saved, meta, coff = [], [], 0
+        with torch.cuda.device(dev):
+            for layers, params, idx in zip(scales, plist, idxs):
+                ga = _Gather(xyz, new_xyz, feat, idx)
+                _, arg, ys, bns = _forward_stack(lib, dev, _st(dev), b, 3 + ga.cfeat, g, ga.nsample, None, ga, training,
+                                                 layers, params, out_spec=(out, coff))
+                meta.append((len(layers), ga.nsample, coff, params[-3].shape[0]))
+                coff += params[-3].shape[0]
+                saved += [arg, *ys, *bns]
+        ctx.training, ctx.meta, ctx.has_feat = training, meta, feat is not None
+        ctx.dims = (b, g, ctot)
+        ctx.save_for_backward(feat if feat is not None else torch.empty(0, device=dev), xyz, new_xyz, *idxs, *saved,
+                              *tensors[nsc:])
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        from . import _ext
+        lib = _native.lib()
+        b, g, ctot = ctx.dims
+        meta = ctx.meta
+        nsc = len(meta)
+        sv = ctx.saved_tensors
+        feat, xyz, new_xyz = sv[0], sv[1], sv[2]
+        idxs = sv[3:3 + nsc]
+        dev = xyz.device
+        dout = dout.contiguous()
+        pos = 3 + nsc
+        per_scale = []
+        for (nl, s, coff, clast) in meta:
+            arg = sv[pos]
+            ys, bns = sv[pos + 1:pos + 1 + nl], sv[pos + 1 + nl:pos + 1 + 2 * nl]
+            pos += 1 + 2 * nl
+            per_scale.append((arg, ys, bns))
+        params_all, ppos = sv[pos:], 0
+        cfeat = feat.shape[1] if ctx.has_feat else 0
+        n_src = xyz.shape[1]
+        need_x = ctx.has_feat and ctx.needs_input_grad[0]
+        use_level_gemm = need_x and n_src <= 4096 and n_src % 4 == 0
+        cout0_tot = sum(params_all[sum(3 * m[0] for m in meta[:i])].shape[0] for i in range(nsc))
+        gbuf = _empty((b, cout0_tot, n_src), torch.float32, dev) if use_level_gemm else None
+        grads_all, dfeat, goff, w0f = [], None, 0, []
+        base = 5 + nsc   # index of the first parameter among forward()'s arguments
+        with torch.cuda.device(dev):
+            st = _st(dev)
+            for (nl, s, coff, clast), (arg, ys, bns), idx in zip(meta, per_scale, idxs):
+                params = params_all[ppos:ppos + 3 * nl]
+                need_w = [ctx.needs_input_grad[base + ppos + 3 * li] for li in range(nl)]
+                ppos += 3 * nl
+                ga = _Gather(xyz, new_xyz, feat if ctx.has_feat else None, idx)
+                cout0 = params[0].shape[0]
+                grads, dxf, scattered = _backward_stack(
+                    lib, dev, st, b, 3 + cfeat, g, s, None, ga, ctx.training, ys, bns, params, arg,
+                    dout[:, coff:coff + clast], need_w, need_x, pooled_bstride=ctot * g,
+                    scatter_out=(gbuf, goff) if use_level_gemm else None)
+                grads_all += grads
+                if use_level_gemm:
+                    w0f.append(params[0].reshape(cout0, 3 + cfeat))
+                    goff += cout0
+                elif need_x:
+                    part = dxf if scattered else _ext.group_points_grad(dxf.view(b, cfeat, g, s), idx, n_src)
+                    dfeat = part if dfeat is None else dfeat + part
+            if use_level_gemm:
+                # dfeat[b] = [W0f_0^T | W0f_1^T ...] . [G_0; G_1; ...]: the dgrad kernel with identity "BN" constants
+                wcat = torch.cat(w0f, dim=0) if nsc > 1 else w0f[0]           # (sum Cout0, 3 + C)
+                ident = torch.zeros((4, cout0_tot), dtype=torch.float32, device=dev)
+                ident[1].fill_(1.0)                                           # scale 0, shift 1: mask always on
+                bwdc = torch.zeros((3, cout0_tot), dtype=torch.float32, device=dev)
+                bwdc[0].fill_(1.0)                                            # dY = g
+                dfeat = _empty((b, cfeat, n_src), torch.float32, dev)
+                _native.check(lib.istnet_pw_dgrad(
+                    b, 3 + cfeat, 3, cfeat, cout0_tot, n_src, 0, wcat.data_ptr(), gbuf.data_ptr(), gbuf.data_ptr(),
+                    None, 0, None, ident.data_ptr(), bwdc.data_ptr(), dfeat.data_ptr(), None, None, None, None, st),
+                    "pw_dgrad(level)")
+        return (dfeat, None, None, None, None, *([None] * nsc), *grads_all)
 
 
 class FusedBiasMLPFunction(Function):
@@ -504,4 +625,37 @@ def sa_scale(grouper, mlp, xyz, new_xyz, features, idx=None):
     out = FusedSAScaleFunction.apply(features, xyz, new_xyz, idx, mlp.training, layers, *params)
     if mlp.training:
         torch._foreach_add_([unit.normlayer.bn.num_batches_tracked for unit in mlp], 1)
+    return out
+
+
+def sa_level(groupers, mlps, xyz, new_xyz, features, ball_idx=None):
+    """All scales of a set-abstraction level: ``cat([max_pool(mlp_i(grouper_i(...))) for i], dim=1)``.
+
+    One fused autograd node when every scale qualifies for the gather-fused path (see ``sa_scale``); otherwise the
+    scales run one by one and are concatenated with torch.cat as in the reference."""
+    from . import pointnet2_utils
+    ball_idx = ball_idx if ball_idx is not None else [None] * len(groupers)
+
+    def plain(gr):
+        return (type(gr) is pointnet2_utils.QueryAndGroup and gr.use_xyz and gr.nsample in (4, 8, 16, 32, 64)
+                and not (gr.normalize_xyz or gr.sample_uniformly or gr.ret_grouped_xyz or gr.ret_unique_cnt))
+    ok = (xyz.is_cuda and xyz.dtype == torch.float32 and not xyz.requires_grad and new_xyz is not None
+          and not new_xyz.requires_grad
+          and (features is None or (features.is_cuda and features.dtype == torch.float32))
+          and all(plain(gr) for gr in groupers)
+          and all(_fusable_shape(mlp, new_xyz.shape[1], gr.nsample) for gr, mlp in zip(groupers, mlps)))
+    if not ok:
+        return torch.cat([sa_scale(gr, mlp, xyz, new_xyz, features, idx)
+                          for gr, mlp, idx in zip(groupers, mlps, ball_idx)], dim=1)
+    idxs = [idx if idx is not None else pointnet2_utils.ball_query(gr.radius, gr.nsample, xyz, new_xyz)
+            for gr, idx in zip(groupers, ball_idx)]
+    scales, params = [], []
+    for mlp in mlps:
+        layers, p = _layer_args(mlp)
+        scales.append(layers)
+        params += p
+    training = mlps[0].training
+    out = FusedSALevelFunction.apply(features, xyz, new_xyz, training, scales, *idxs, *params)
+    if training:
+        torch._foreach_add_([unit.normlayer.bn.num_batches_tracked for mlp in mlps for unit in mlp], 1)
     return out

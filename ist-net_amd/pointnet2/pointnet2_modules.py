@@ -13,7 +13,7 @@ import torch
 import torch.nn as nn
 
 from . import pointnet2_utils, pytorch_utils
-from .fused_mlp import sa_scale, shared_mlp_maxpool
+from .fused_mlp import sa_level, shared_mlp_maxpool
 
 
 class _PointnetSAModuleBase(nn.Module):
@@ -40,12 +40,13 @@ class _PointnetSAModuleBase(nn.Module):
             new_xyz, ball_idx = self._sample_centroids(xyz), [None] * len(self.groupers)
         else:
             new_xyz, ball_idx = geometry
-        pooled = []
-        for (grouper, mlp), idx in zip(zip(self.groupers, self.mlps), ball_idx):
-            # grouper -> SharedMLP -> max over nsample -> squeeze [ref :61-69]: one fused node on the GPU
-            # (ball query kernel + MFMA stack whose layer-0 loader gathers the neighbourhoods)
-            pooled.append(sa_scale(grouper, mlp, xyz, new_xyz, features, idx))   # (B, C_out, npoint)
-        return new_xyz, torch.cat(pooled, dim=1)
+        # per scale: grouper -> SharedMLP -> max over nsample -> squeeze, then concat [ref :60-73]; on the GPU the
+        # whole level is one fused node (ball-query kernels + gather-fused MFMA stacks writing the concat in place)
+        if new_xyz is None:      # GroupAll variant: literal composition
+            pooled = [shared_mlp_maxpool(mlp, grouper(xyz, new_xyz, features))
+                      for grouper, mlp in zip(self.groupers, self.mlps)]
+            return new_xyz, torch.cat(pooled, dim=1)
+        return new_xyz, sa_level(list(self.groupers), list(self.mlps), xyz, new_xyz, features, ball_idx)
 
 
 class PointnetSAModuleMSG(_PointnetSAModuleBase):

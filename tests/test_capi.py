@@ -27,7 +27,8 @@ def test_binding_table_matches_header():
         for a in args.split(","):
             a = a.strip()
             kinds.append(ctypes.c_void_p if "*" in a else ctypes.c_float if a.startswith("float")
-                         else ctypes.c_double if a.startswith("double") else ctypes.c_int)
+                         else ctypes.c_double if a.startswith("double")
+                         else ctypes.c_longlong if a.startswith("long long") else ctypes.c_int)
         assert kinds == _native.SIGNATURES[name], name
 
 

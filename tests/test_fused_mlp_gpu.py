@@ -207,3 +207,44 @@ def test_bias_stack_matches_torch(widths, final_relu, b, n):
     assert float((dxf - dxt).norm() / dxt.norm()) < 1e-3
     for k in gt:
         assert float((gf[k] - gt[k]).norm() / (gt[k].norm() + 1e-30)) < 1e-4, k
+
+
+def test_sa_level_fused_node_matches_reference_composition():
+    """Whole MSG level (two scales, in-place concat, strided pooled gradient, single feature-gradient GEMM)
+    against QueryAndGroup -> SharedMLP -> max_pool2d -> cat with torch ops."""
+    from istnet_amd.pointnet2 import pointnet2_utils as pu
+    from istnet_amd.pointnet2.fused_mlp import sa_level
+    from istnet_amd.pointnet2.pytorch_utils import SharedMLP
+    b, n, npoint, c = 4, 256, 64, 48
+    g = torch.Generator().manual_seed(21)
+    xyz = torch.rand(b, n, 3, generator=g).to(DEV)
+    feat0 = torch.randn(b, c, n, generator=g).to(DEV)
+    fps = pu.furthest_point_sample(xyz, npoint)
+    new_xyz = pu.gather_operation(xyz.transpose(1, 2).contiguous(), fps).transpose(1, 2).contiguous()
+    groupers = [pu.QueryAndGroup(0.2, 16), pu.QueryAndGroup(0.35, 32)]
+    torch.manual_seed(22)
+    mlps_a = [SharedMLP([c + 3, 32, 64], bn=True).to(DEV).train(), SharedMLP([c + 3, 48, 40, 96], bn=True).to(DEV).train()]
+    mlps_b = [SharedMLP([c + 3, 32, 64], bn=True).to(DEV).train(), SharedMLP([c + 3, 48, 40, 96], bn=True).to(DEV).train()]
+    for a, bb in zip(mlps_a, mlps_b):
+        bb.load_state_dict(a.state_dict())
+    wgt = torch.randn(b, 64 + 96, npoint, generator=g).to(DEV)
+
+    def run(fused, mlps):
+        f = feat0.clone().requires_grad_(True)
+        if fused:
+            out = sa_level(groupers, mlps, xyz, new_xyz, f)
+        else:
+            outs = []
+            for gr, mlp in zip(groupers, mlps):
+                act = mlp(gr(xyz, new_xyz, f))
+                outs.append(F.max_pool2d(act, kernel_size=[1, act.size(3)]).squeeze(-1))
+            out = torch.cat(outs, dim=1)
+        (out * wgt).sum().backward()
+        return out.detach(), f.grad, [p.grad for m in mlps for p in m.parameters()]
+
+    of, dff, gf = run(True, mlps_a)
+    ot, dft, gt = run(False, mlps_b)
+    torch.testing.assert_close(of, ot, rtol=1e-5, atol=1e-5)
+    assert float((dff - dft).norm() / dft.norm()) < 1e-4
+    for a, bb in zip(gf, gt):
+        assert float((a - bb).norm() / (bb.norm() + 1e-30)) < 1e-4
