@@ -42,6 +42,46 @@ def make_model(device, seed=0):
     return PointNet2MSG([list(r) for r in CAM_RADII]).to(device).train()
 
 
+def make_istnet(device, seed=0):
+    """Full IST-Net (BASELINE configs[2] / [3]): RGB branch on MIOpen + point branch on the HIP kernels."""
+    from istnet_amd.ist_net import IST_Net
+    from istnet_amd.rgb_branch import ModifiedResnet
+    torch.manual_seed(seed)
+    return IST_Net(rgb_extractor=ModifiedResnet()).to(device).train()
+
+
+def istnet_batch(b, n, seed, device, hw=192):
+    """Synthetic RGB-D batch of SURVEY.md 8(d) config 3."""
+    g = torch.Generator().manual_seed(1000 + seed)
+    pts = shell_cloud(b, n, seed) + torch.tensor([0.0, 0.0, 0.8])
+    rot = torch.linalg.qr(torch.randn(b, 3, 3, generator=g))[0]
+    batch = {"rgb": torch.randn(b, 3, hw, hw, generator=g), "pts": pts,
+             "choose": torch.randint(0, hw * hw, (b, n), generator=g),
+             "category_label": torch.randint(0, 6, (b, 1), generator=g),
+             "qo": torch.rand(b, n, 3, generator=g) - 0.5,
+             "rotation_label": rot, "translation_label": pts.mean(dim=1),
+             "size_label": torch.rand(b, 3, generator=g) * 0.25 + 0.05}
+    return {k: v.to(device) for k, v in batch.items()}
+
+
+def make_istnet_step(model, batch, opt, world, grad_sync=None):
+    from istnet_amd.losses import SupervisedLoss
+    crit = SupervisedLoss(1.0, 10.0)
+    labels = {k: batch[k] for k in ("rotation_label", "translation_label", "size_label", "qo")}
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        ep = model(batch)
+        ep.update(labels)
+        loss = crit(ep)
+        loss.backward()
+        if world > 1:
+            grad_sync()
+        opt.step()
+        return loss
+    return step
+
+
 def make_step(model, pts, opt, world, grad_sync=None):
     def step():
         opt.zero_grad(set_to_none=True)
@@ -127,6 +167,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--eager", action="store_true", help="do not capture the step in a HIP graph")
+    ap.add_argument("--workload", default="encoder", choices=["encoder", "istnet"],
+                    help="encoder = BASELINE configs[1] (the headline metric); istnet = full model, configs[2]/[3]")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for dry runs)")
     ap.add_argument("--same-device", action="store_true",
                     help="dry run of the N>1 control flow on a 1-GPU box: every rank uses cuda:0 (gloo only)")
@@ -154,13 +196,25 @@ def main():
         else:
             dist.init_process_group(args.backend)
 
-    model = make_model(dev, seed=0)  # identical weights on every rank (same seed)
-    pts = shell_cloud(BATCH, NPOINTS, seed=rank, device=dev)
-    opt = torch.optim.Adam(model.parameters(), lr=1e-4, fused=True, capturable=True)
-    if world > 1:
-        from istnet_amd.parallel import GradAllReducer
-        grad_sync = GradAllReducer(model, world).sync
-    eager_step = make_step(model, pts, opt, world, grad_sync)
+    if args.workload == "istnet":
+        model = make_istnet(dev, seed=0)
+        batch = istnet_batch(BATCH, NPOINTS, seed=rank, device=dev)
+        opt = torch.optim.Adam(model.parameters(), lr=1e-4, fused=True, capturable=True)
+        if world > 1:
+            from istnet_amd.parallel import GradAllReducer
+            grad_sync = GradAllReducer(model, world).sync
+        eager_step = make_istnet_step(model, batch, opt, world, grad_sync)
+        args.eager = True          # dropout + MIOpen find-mode: keep the full model eager
+        args.no_cpu_baseline = True
+        pts = None
+    else:
+        model = make_model(dev, seed=0)  # identical weights on every rank (same seed)
+        pts = shell_cloud(BATCH, NPOINTS, seed=rank, device=dev)
+        opt = torch.optim.Adam(model.parameters(), lr=1e-4, fused=True, capturable=True)
+        if world > 1:
+            from istnet_amd.parallel import GradAllReducer
+            grad_sync = GradAllReducer(model, world).sync
+        eager_step = make_step(model, pts, opt, world, grad_sync)
     step, mode = eager_step, "eager"
     if not args.eager:
         try:
@@ -197,8 +251,10 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "PointNet2MSG encoder (4 SA-MSG + 4 FP, cam radii) fwd+bwd+Adam, "
-                                   "train-mode BN, shell clouds",
+            "config": {"workload": ("PointNet2MSG encoder (4 SA-MSG + 4 FP, cam radii) fwd+bwd+Adam, "
+                                    "train-mode BN, shell clouds") if args.workload == "encoder" else
+                                   ("IST-Net full model (ResNet-18/PSP RGB branch on MIOpen + point branch, "
+                                    "cam + world encoders, IST head, 3 pose heads) fwd+bwd+Adam, SupervisedLoss"),
                        "batch_per_gpu": BATCH, "npoints": NPOINTS, "global_batch": BATCH * world,
                        "parallelism": f"dp{world}", "launch": mode},
         }

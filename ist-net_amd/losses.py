@@ -1,0 +1,39 @@
+"""Training losses of IST-Net (plain torch; tiny elementwise work, not part of the kernel path).
+
+Mirror of model/losses.py:3-49 and the `SupervisedLoss` of model/ist_net.py:78-111:
+loss = PoseDis(main) + PoseDis(cam aux) [+ PoseDis(world aux)] + gamma1 * SmoothL1Dis(qo) + gamma2 * MSE(features).
+"""
+import torch
+import torch.nn as nn
+
+
+def SmoothL1Dis(p1, p2, threshold=0.1):
+    """p1, p2 (B,N,3): smooth-L1 per coordinate, summed over xyz, mean over points and batch."""
+    diff = torch.abs(p1 - p2)
+    dis = torch.where(diff > threshold, diff - threshold / 2.0, diff.pow(2) / (2.0 * threshold))
+    return torch.mean(torch.sum(dis, dim=2 if p1.dim() == 3 else 1))
+
+
+def PoseDis(r1, t1, s1, r2, t2, s2):
+    """Mean column norm of R1-R2 (dim=1 as in the reference) + mean L2 of t and s differences."""
+    return (torch.mean(torch.norm(r1 - r2, dim=1)) + torch.mean(torch.norm(t1 - t2, dim=1))
+            + torch.mean(torch.norm(s1 - s2, dim=1)))
+
+
+class SupervisedLoss(nn.Module):
+    def __init__(self, gamma1=1.0, gamma2=10.0, freeze_world_enhancer=False):
+        super().__init__()
+        self.gamma1, self.gamma2, self.freeze_world_enhancer = gamma1, gamma2, freeze_world_enhancer
+
+    def forward(self, end_points):
+        ep = end_points
+        labels = (ep["rotation_label"], ep["translation_label"], ep["size_label"])
+        loss = PoseDis(ep["pred_rotation"], ep["pred_translation"], ep["pred_size"], *labels)
+        loss = loss + PoseDis(ep["pred_rotation_aux_cam"], ep["pred_translation_aux_cam"], ep["pred_size_aux_cam"],
+                              *labels)
+        loss = loss + self.gamma1 * SmoothL1Dis(ep["pred_qo"], ep["qo"])
+        loss = loss + self.gamma2 * nn.functional.mse_loss(ep["pts_w_local"], ep["pts_w_local_gt"])
+        if not self.freeze_world_enhancer:
+            loss = loss + PoseDis(ep["pred_rotation_aux_world"], ep["pred_translation_aux_world"],
+                                  ep["pred_size_aux_world"], *labels)
+        return loss

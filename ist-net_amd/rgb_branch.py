@@ -1,0 +1,152 @@
+"""RGB branch of IST-Net: ResNet-18 trunk (output stride 8) + pyramid pooling + 3 x (2x upsample, 3x3 conv).
+
+SURVEY.md 8(f) rank 1 -- outside the point-cloud hot path: dense 2-D convolutions that stay on
+PyTorch-ROCm / MIOpen.  This file only restates the module tree of the reference
+(model/modules.py:10-81,225-241 and model/resnet.py:31-60,109-214) with identical child names, so
+that a reference checkpoint (`rgb_cam_extractor.model.feats.layer1.0.conv1.weight`, ...) loads
+unchanged and the full IST-Net (`ist_net.IST_Net(rgb_extractor=ModifiedResnet())`) can be trained
+and benchmarked end to end.  rgb (B,3,H,W) -> (B,128,H,W).
+
+Reference quirks kept on purpose: the `dilation` arguments of layer3 / layer4 are ignored
+(resnet.py:153-180 only dilates once the *output_stride* is reached, and that is 32), so both run at
+stride 1, dilation 1 on the stride-8 map; `avgpool` / `fc` exist (state-dict keys) but are unused;
+the pyramid priors are upsampled with align_corners=False, the decoder with align_corners=True.
+No weights are downloaded (the reference fetches resnet18-5c106cde.pth, resnet.py:205-214).
+"""
+import math
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+
+def _conv3x3(cin, cout, stride=1, dilation=1):
+    return nn.Conv2d(cin, cout, kernel_size=3, stride=stride, padding=dilation, dilation=dilation, bias=False)
+
+
+class BasicBlock(nn.Module):
+    expansion = 1
+
+    def __init__(self, inplanes, planes, stride=1, downsample=None, dilation=1):
+        super().__init__()
+        self.conv1 = _conv3x3(inplanes, planes, stride=stride, dilation=dilation)
+        self.bn1 = nn.BatchNorm2d(planes)
+        self.relu = nn.ReLU(inplace=True)
+        self.conv2 = _conv3x3(planes, planes, dilation=dilation)
+        self.bn2 = nn.BatchNorm2d(planes)
+        self.downsample = downsample
+        self.stride = stride
+
+    def forward(self, x):
+        out = self.relu(self.bn1(self.conv1(x)))
+        out = self.bn2(self.conv2(out))
+        out = out + (x if self.downsample is None else self.downsample(x))
+        return self.relu(out)
+
+
+class ResNet(nn.Module):
+    """Trunk returning (layer4 output, layer3 output), both at 1/8 resolution.  [ref resnet.py:109-202]"""
+
+    def __init__(self, layers=(2, 2, 2, 2), num_classes=1000, output_stride=32):
+        super().__init__()
+        self._inplanes, self._stride, self._dilation, self._output_stride = 64, 4, 1, output_stride
+        self.conv1 = nn.Conv2d(3, 64, kernel_size=7, stride=2, padding=3, bias=False)
+        self.bn1 = nn.BatchNorm2d(64)
+        self.relu = nn.ReLU(inplace=True)
+        self.maxpool = nn.MaxPool2d(kernel_size=3, stride=2, padding=1)
+        self.layer1 = self._stage(64, layers[0])
+        self.layer2 = self._stage(128, layers[1], stride=2)
+        self.layer3 = self._stage(256, layers[2])   # reference passes dilation=2: ignored there
+        self.layer4 = self._stage(512, layers[3])   # reference passes dilation=4: ignored there
+        self.avgpool = nn.AvgPool2d(7)
+        self.fc = nn.Linear(512, num_classes)
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d):
+                fan = m.kernel_size[0] * m.kernel_size[1] * m.out_channels
+                m.weight.data.normal_(0, math.sqrt(2.0 / fan))
+            elif isinstance(m, nn.BatchNorm2d):
+                m.weight.data.fill_(1)
+                m.bias.data.zero_()
+
+    def _stage(self, planes, blocks, stride=1):
+        downsample = None
+        if stride != 1 or self._inplanes != planes:
+            if self._stride == self._output_stride:   # never true with output_stride 32
+                self._dilation *= stride
+                stride = 1
+            else:
+                self._stride *= stride
+            downsample = nn.Sequential(nn.Conv2d(self._inplanes, planes, kernel_size=1, stride=stride, bias=False),
+                                       nn.BatchNorm2d(planes))
+        seq = [BasicBlock(self._inplanes, planes, stride, downsample, dilation=self._dilation)]
+        self._inplanes = planes
+        seq += [BasicBlock(planes, planes, dilation=self._dilation) for _ in range(1, blocks)]
+        return nn.Sequential(*seq)
+
+    def forward(self, x):
+        x = self.maxpool(self.relu(self.bn1(self.conv1(x))))
+        x = self.layer2(self.layer1(x))
+        x3 = self.layer3(x)
+        return self.layer4(x3), x3
+
+
+class PSPModule(nn.Module):
+    """Pyramid pooling at bin sizes (1,2,3,6) + 1x1 bottleneck.  [ref modules.py:10-34]"""
+
+    def __init__(self, features, out_features=1024, sizes=(1, 2, 3, 6)):
+        super().__init__()
+        self.stages = nn.ModuleList([
+            nn.Sequential(nn.AdaptiveAvgPool2d(output_size=(size, size)),
+                          nn.Conv2d(features, features, kernel_size=1, bias=False)) for size in sizes])
+        self.bottleneck = nn.Conv2d(features * (len(sizes) + 1), out_features, kernel_size=1)
+        self.relu = nn.ReLU()
+
+    def forward(self, feats):
+        h, w = feats.size(2), feats.size(3)
+        priors = [F.interpolate(stage(feats), size=(h, w), mode="bilinear", align_corners=False)
+                  for stage in self.stages] + [feats]
+        return self.relu(self.bottleneck(torch.cat(priors, 1)))
+
+
+class PSPUpsample(nn.Module):
+    def __init__(self, in_channels, out_channels):
+        super().__init__()
+        self.conv = nn.Sequential(nn.Upsample(scale_factor=2, mode="bilinear", align_corners=True),
+                                  nn.Conv2d(in_channels, out_channels, 3, padding=1),
+                                  nn.BatchNorm2d(out_channels), nn.PReLU())
+
+    def forward(self, x):
+        return self.conv(x)
+
+
+class Modified_PSPNet(nn.Module):
+    """[ref modules.py:51-81]"""
+
+    def __init__(self, sizes=(1, 2, 3, 6), psp_size=512):
+        super().__init__()
+        self.feats = ResNet((2, 2, 2, 2))
+        self.psp = PSPModule(psp_size, 1024, sizes)
+        self.drop_1 = nn.Dropout2d(p=0.3)
+        self.up_1 = PSPUpsample(1024, 256)
+        self.up_2 = PSPUpsample(256, 64)
+        self.up_3 = PSPUpsample(64, 64)
+        self.drop_2 = nn.Dropout2d(p=0.15)
+        self.final = nn.Sequential(nn.Conv2d(64, 128, kernel_size=1), nn.BatchNorm2d(128), nn.PReLU())
+
+    def forward(self, x):
+        f, _ = self.feats(x)
+        p = self.drop_1(self.psp(f))
+        p = self.drop_2(self.up_1(p))
+        p = self.drop_2(self.up_2(p))
+        return self.final(self.up_3(p))
+
+
+class ModifiedResnet(nn.Module):
+    """`rgb_cam_extractor` of IST-Net.  [ref modules.py:232-241]"""
+
+    def __init__(self):
+        super().__init__()
+        self.model = Modified_PSPNet(sizes=(1, 2, 3, 6), psp_size=512)
+
+    def forward(self, x):
+        return self.model(x)

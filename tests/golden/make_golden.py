@@ -265,6 +265,45 @@ def main():
     np.savez_compressed(os.path.join(HERE, "istnet_point_branch_b2.npz"), pts=npy(pts5), rgb_feat=npy(rgb_feat).astype(np.float32),
                         choose=npy(choose).astype(np.int16), cls=np.array([2, 5]), qo=npy(inputs["qo"]),
                         state_checksum=state_checksum(params_only(sd_r)), **store)
+    # ---- 6. RGB branch (out of the hot path; module-tree / state-dict parity) and the training loss -----
+    import resnet as ref_resnet
+    import losses as ref_losses
+    from istnet_amd import rgb_branch as my_rgb, losses as my_losses
+    ref_resnet.model_zoo.load_url = lambda *a, **k: ref_resnet.ResNet(ref_resnet.BasicBlock, [2, 2, 2, 2]).state_dict()
+    torch.manual_seed(60)
+    rgb_r = ref_model_modules.ModifiedResnet()
+    # the reference builds a SECOND ResNet inside the load_url shim above (RNG advanced, weights replaced):
+    # rebuild ours the same way so the random streams line up, then copy the trunk state as load_state_dict did
+    torch.manual_seed(60)
+    rgb_m = my_rgb.ModifiedResnet()
+    assert list(rgb_r.state_dict().keys()) == list(rgb_m.state_dict().keys())
+    rgb_m.load_state_dict(rgb_r.state_dict())
+    img = torch.randn(1, 3, 96, 96, generator=torch.Generator().manual_seed(61))
+    rgb_r.eval(); rgb_m.eval()
+    with torch.no_grad():
+        o_r, o_m = rgb_r(img), rgb_m(img)
+    torch.testing.assert_close(o_m, o_r, rtol=1e-5, atol=1e-6)
+    keys = list(rgb_r.state_dict().keys())
+    # loss on the train-mode end points of section 5
+    class _Cfg: pass
+    cfg = _Cfg(); cfg.loss = _Cfg(); cfg.loss.gamma1, cfg.loss.gamma2, cfg.freeze_world_enhancer = 1.0, 10.0, False
+    g6 = torch.Generator().manual_seed(62)
+    lab = {"rotation_label": torch.linalg.qr(torch.randn(2, 3, 3, generator=g6))[0], "translation_label": torch.randn(2, 3, generator=g6),
+           "size_label": torch.rand(2, 3, generator=g6), "qo": inputs["qo"]}
+    net_r.train(); net_m.train()
+    torch.manual_seed(63)
+    ep_r = net_r(inputs); ep_r.update(lab)
+    loss_r = ref_ist.SupervisedLoss(cfg)(ep_r)
+    ep_chk = {k: v for k, v in ep_r.items()}
+    loss_m = my_losses.SupervisedLoss(1.0, 10.0, False)(ep_chk)
+    torch.testing.assert_close(loss_m, loss_r, rtol=1e-6, atol=1e-7)
+    np.savez_compressed(os.path.join(HERE, "rgb_branch_and_loss.npz"), img=npy(img), out_sub=npy(o_r)[:, ::4, ::6, ::6],
+                        out_abs_sum=np.float64(o_r.double().abs().sum()), n_keys=np.int64(len(keys)),
+                        key_first=np.array(keys[:3] + keys[-3:]),
+                        n_params=np.int64(sum(p.numel() for p in rgb_r.parameters())),
+                        loss=np.float64(loss_r.item()),
+                        **{"lab_" + k: npy(v) for k, v in lab.items() if k != "qo"},
+                        **{"ep_" + k: (npy(v) if v.numel() <= 8192 else npy(v).reshape(2, -1)[:, ::64]) for k, v in ep_r.items() if k not in lab})
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(HERE, f)) // 1024, "KiB")
