@@ -257,3 +257,21 @@ def test_full_istnet_with_rgb_branch_trains_one_step():
     # avgpool/fc of the trunk are unused by design (reference keeps them for the checkpoint layout)
     assert [k for k in missing if ".fc." not in k] == []
     assert len(net.state_dict()) > 400
+
+
+def test_benchmark_path_runs_only_native_kernels_for_the_dense_stack():
+    """On the GPU the encoder must not fall back to torch Conv2d / BatchNorm2d / max_pool2d: the dense stack
+    runs in the MFMA kernels of libistnet_pn2.so (module forwards are bypassed), and the library is loaded."""
+    from istnet_amd import _native
+    from istnet_amd.modules import PointNet2MSG
+    torch.manual_seed(0)
+    enc = PointNet2MSG([list(r) for r in CAM]).to(DEV).train()
+    fired = []
+    for name, m in enc.named_modules():
+        if isinstance(m, (torch.nn.Conv2d, torch.nn.BatchNorm2d, torch.nn.ReLU)):
+            m.register_forward_hook(lambda mod, i, o, name=name: fired.append(name))
+    out = enc(_shell(4, 1024, 1).to(DEV))
+    out.square().mean().backward()
+    assert fired == [], f"torch fallback used for {fired[:4]}"
+    assert _native._lib is not None and os.path.exists(_native.LIB_PATH)
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in enc.parameters())
