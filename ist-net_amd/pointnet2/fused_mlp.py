@@ -47,6 +47,23 @@ def _st(dev):
     return torch.cuda.current_stream(dev).cuda_stream
 
 
+_CONSTS = {}
+
+
+def _ident_consts(dev, c):
+    """Cached constant blocks for a pass-through layer: bn = (scale 0, shift 1, mean 0, invstd 1) makes the ReLU
+    mask always active, bwdc = (1, 0, 0) makes dY = g."""
+    key = (dev.index, c)
+    if key not in _CONSTS:
+        bn = torch.zeros((4, c), dtype=torch.float32, device=dev)
+        bn[1].fill_(1.0)
+        bn[3].fill_(1.0)
+        bwdc = torch.zeros((3, c), dtype=torch.float32, device=dev)
+        bwdc[0].fill_(1.0)
+        _CONSTS[key] = (bn, bwdc)
+    return _CONSTS[key]
+
+
 # Weight gradients are off the critical path of backward (nothing consumes dW before the optimizer), so
 # the wgrad GEMM + split-K reduce of every layer CAN run on a second HIP stream, concurrently with the
 # dgrad chain on the caller's stream (the caller's stream waits for them before backward returns).
@@ -157,10 +174,7 @@ def _forward_stack(lib, dev, st, b, c0, g, s, x, gather, training, layers, param
         _native.check(lib.istnet_affine_apply(b, cur_c, g, 0, cur.data_ptr(), in_bn.data_ptr(), out.data_ptr(), st),
                       "affine_apply")
         # backward of a ReLU-free last layer: gradient mask "always active" (scale 0, shift 1)
-        mask = torch.zeros_like(in_bn)
-        mask[1].fill_(1.0)
-        mask[3].fill_(1.0)
-        bns[-1] = mask
+        bns[-1] = _ident_consts(dev, cur_c)[0]
     else:
         _native.check(lib.istnet_bn_relu_pool(b, cur_c, g, s, cur.data_ptr(), in_bn.data_ptr(), out_ptr,
                                               out_bstride, _p(arg), st), "bn_relu_pool")
@@ -465,10 +479,7 @@ class FusedSALevelFunction(Function):
             if use_level_gemm:
                 # dfeat[b] = [W0f_0^T | W0f_1^T ...] . [G_0; G_1; ...]: the dgrad kernel with identity "BN" constants
                 wcat = torch.cat(w0f, dim=0) if nsc > 1 else w0f[0]           # (sum Cout0, 3 + C)
-                ident = torch.zeros((4, cout0_tot), dtype=torch.float32, device=dev)
-                ident[1].fill_(1.0)                                           # scale 0, shift 1: mask always on
-                bwdc = torch.zeros((3, cout0_tot), dtype=torch.float32, device=dev)
-                bwdc[0].fill_(1.0)                                            # dY = g
+                ident, bwdc = _ident_consts(dev, cout0_tot)                   # mask always on, dY = g
                 dfeat = _empty((b, cfeat, n_src), torch.float32, dev)
                 _native.check(lib.istnet_pw_dgrad(
                     b, 3 + cfeat, 3, cfeat, cout0_tot, n_src, 0, wcat.data_ptr(), gbuf.data_ptr(), gbuf.data_ptr(),
