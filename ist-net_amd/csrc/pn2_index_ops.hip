@@ -438,13 +438,27 @@ __global__ __launch_bounds__(256) void interp_grad_csr_kernel(int c, int n, int 
   float sum[kInterpCsrCH];
 #pragma unroll
   for (int ch = 0; ch < kInterpCsrCH; ++ch) sum[ch] = 0.f;
-  for (int u = a; u < z; ++u) {
-    const int e = ent[u];
-    const int j = e / 3;
-    const float we = w[e];
+  // four taps per step: the dependent chain entry -> (weight, gradient) is two HBM/L2 round trips, so issue the
+  // loads of four taps together (summation order stays ascending)
+  for (int u = a; u < z; u += 4) {
+    int e[4];
+    float we[4];
 #pragma unroll
-    for (int ch = 0; ch < kInterpCsrCH; ++ch)
-      if (ch < nch) sum[ch] += grad_out[((size_t)b * c + c0 + ch) * n + j] * we;
+    for (int q = 0; q < 4; ++q) e[q] = ent[min(u + q, z - 1)];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) we[q] = (u + q < z) ? w[e[q]] : 0.f;
+    float gq[4][kInterpCsrCH];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int j = e[q] / 3;
+#pragma unroll
+      for (int ch = 0; ch < kInterpCsrCH; ++ch)
+        gq[q][ch] = grad_out[((size_t)b * c + c0 + min(ch, nch - 1)) * n + j];
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int ch = 0; ch < kInterpCsrCH; ++ch) sum[ch] += gq[q][ch] * we[q];
   }
 #pragma unroll
   for (int ch = 0; ch < kInterpCsrCH; ++ch)
