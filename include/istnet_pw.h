@@ -42,11 +42,14 @@ ISTNET_PN2_API int istnet_pw_forward(int b, int cin, int cout, int p, const floa
 /* Same GEMM with the layer-0 input of a set-abstraction scale gathered on the fly (the grouped tensor of
  * QueryAndGroup, pointnet2_utils.py:348-358, is never materialised): input channel k < 3 is
  * xyz[b][idx[b][p]][k] - new_xyz[b][p / nsample][k], channel k >= 3 is feat[b][k-3][idx[b][p]];
- * cin = 3 + cfeat, p = npoint * nsample, nsample % 4 == 0, feat may be NULL when cfeat == 0. */
+ * cin = 3 + cfeat, p = npoint * nsample, nsample % 4 == 0, feat may be NULL when cfeat == 0.
+ * feat_t (optional, may be NULL): point-major copy of feat, (b, n, cfeat).  When given and cfeat % 16 == 0 a
+ * neighbour's channels are gathered as contiguous float4 runs (the K loop then runs features first, xyz last --
+ * the sum is the same up to fp32 association). */
 ISTNET_PN2_API int istnet_pw_forward_gather(int b, int n, int npoint, int nsample, int cfeat, int cout,
                                             const float *xyz, const float *new_xyz, const float *feat,
-                                            const int *idx, const float *w, float *y, float *part_sum,
-                                            float *part_sq, void *stream);
+                                            const float *feat_t, const int *idx, const float *w, float *y,
+                                            float *part_sum, float *part_sq, void *stream);
 
 /* partials -> bn[4][c]; updates running_mean / running_var (unbiased) with `momentum` unless NULL */
 ISTNET_PN2_API int istnet_bn_finalize_fwd(int c, int nt, double count, const float *part_sum,
@@ -111,7 +114,7 @@ ISTNET_PN2_API int istnet_pw_wgrad(int b, int cin, int cout, int p, int nsample,
  * gradient source (0 when d_dense is given) */
 ISTNET_PN2_API int istnet_pw_wgrad_gather(int b, int n, int npoint, int nsample, int cfeat, int cout,
                                           int grad_nsample, const float *xyz, const float *new_xyz,
-                                          const float *feat, const int *idx, const float *y,
+                                          const float *feat, const float *feat_t, const int *idx, const float *y,
                                           const float *d_dense, const float *d_pooled, long long pooled_bstride,
                                           const unsigned char *arg, const float *bn, const float *bwdc,
                                           float *dw_part, void *stream);

@@ -68,7 +68,14 @@ struct GatherSrc {
   const float* feat;     // (B, cfeat, n) or null
   const int* idx;        // (B, P) int32
   int n, S, cfeat;
+  const float* featT;    // (B, n, cfeat) point-major copy of feat, or null.  With it (GATHER == 2) a neighbour's
+                         // channels are one contiguous run: float4 gathers instead of one scattered load per
+                         // channel.  The GEMM then walks K in the order [features..., x, y, z].
 };
+// point-major gather of 4 consecutive channels c..c+3 of neighbour `src` (cfeat % 4 == 0)
+__device__ __forceinline__ float4 gather_featT4(const GatherSrc& gs, int b, int src, int c) {
+  return *reinterpret_cast<const float4*>(gs.featT + ((size_t)b * gs.n + src) * gs.cfeat + c);
+}
 __device__ __forceinline__ int4 gather_idx4(const GatherSrc& gs, int b, int P, int p) {
   return *reinterpret_cast<const int4*>(gs.idx + (size_t)b * P + p);
 }
@@ -135,7 +142,7 @@ __device__ __forceinline__ float4 zero4() { return make_float4(0.f, 0.f, 0.f, 0.
 // ============================================================================================
 // forward:  y[b][co][p] = sum_ci wt[ci][co] * act(x[b][ci][p]),  optional BN-statistics partials
 // ============================================================================================
-template <int M_T, int N_T, int WM, int WN, bool GATHER>
+template <int M_T, int N_T, int WM, int WN, int GATHER>  // 0: x is a tensor, 1: channel-major gather, 2: point-major gather
 __global__ __launch_bounds__(kThreads) void pw_fwd_kernel(
     int cin, int cout, int P, int tiles_per_cloud, const float* __restrict__ x, GatherSrc gsrc,
     const float* __restrict__ w, const float* __restrict__ in_scale, const float* __restrict__ in_shift,
@@ -155,6 +162,7 @@ __global__ __launch_bounds__(kThreads) void pw_fwd_kernel(
   const int m0 = blockIdx.y * M_T;
   const float* xb = GATHER ? nullptr : x + (size_t)b * cin * P;
   const bool has_bn = in_scale != nullptr;
+  const int cfeat = gsrc.cfeat;  // GATHER == 2: K order is [cfeat feature channels (multiple of 16), x, y, z]
 
   // Staging is split in two so the global loads of chunk t+1 stay in flight during the MFMAs of
   // chunk t: load_chunk only issues loads (clamped addresses, no branches, no use of the data),
@@ -163,7 +171,8 @@ __global__ __launch_bounds__(kThreads) void pw_fwd_kernel(
   float4 braw[NB];
   float bsc[NB], bsh[NB];
   int4 gidx[NB];
-  if (GATHER) {
+  int pidx[NB];
+  if (GATHER == 1) {
 #pragma unroll
     for (int i = 0; i < NB; ++i) {  // neighbour indices depend on the point only: load once per tile
       const int e = tid + kThreads * i;
@@ -171,40 +180,65 @@ __global__ __launch_bounds__(kThreads) void pw_fwd_kernel(
       gidx[i] = gather_idx4(gsrc, b, P, p);
     }
   }
+  if (GATHER == 2) {
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {  // item = (point e / 4, channel quad e % 4)
+      const int e = tid + kThreads * i;
+      pidx[i] = gsrc.idx[(size_t)b * P + min(p0 + e / 4, P - 1)];
+    }
+  }
   auto load_chunk = [&](int k0) {
+    const bool feat_chunk = GATHER == 2 && k0 < cfeat;
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
       const int e = tid + kThreads * i;
-      const int k = min(k0 + e % kKT, cin - 1), m = min(m0 + e / kKT, cout - 1);
+      int k = k0 + e % kKT;
+      if (GATHER == 2) k = feat_chunk ? k + 3 : k - cfeat;   // position in K -> column of w
+      k = min(k, cin - 1);
+      const int m = min(m0 + e / kKT, cout - 1);
       areg[i] = w[(size_t)m * cin + k];
     }
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
       const int e = tid + kThreads * i;
-      const int k = min(k0 + e / (N_T / 4), cin - 1), p = min(p0 + (e % (N_T / 4)) * 4, P - 4);
-      if (GATHER) {
-        braw[i] = gather4(gsrc, b, k, P, p, gidx[i]);
+      if (feat_chunk) {
+        braw[i] = gather_featT4(gsrc, b, pidx[i], k0 + (e % 4) * 4);
+      } else if (GATHER) {
+        const int row = e / (N_T / 4);
+        const int p = min(p0 + (e % (N_T / 4)) * 4, P - 4);
+        const int k = GATHER == 2 ? min(row, 2) : min(k0 + row, cin - 1);
+        braw[i] = gather4(gsrc, b, k, P, p, GATHER == 2 ? gather_idx4(gsrc, b, P, p) : gidx[i]);
       } else {
+        const int k = min(k0 + e / (N_T / 4), cin - 1), p = min(p0 + (e % (N_T / 4)) * 4, P - 4);
         braw[i] = *reinterpret_cast<const float4*>(xb + (size_t)k * P + p);
         if (has_bn) { bsc[i] = in_scale[k]; bsh[i] = in_shift[k]; }
       }
     }
   };
   auto store_chunk = [&](int buf, int k0) {
+    const bool feat_chunk = GATHER == 2 && k0 < cfeat;
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
       const int e = tid + kThreads * i;
-      const bool ok = (k0 + e % kKT < cin) && (m0 + e / kKT < cout);
-      As[buf][e % kKT][e / kKT] = ok ? areg[i] : 0.f;
+      const int kk = k0 + e % kKT;
+      const bool kok = GATHER == 2 ? (feat_chunk || kk - cfeat < 3) : (kk < cin);
+      As[buf][e % kKT][e / kKT] = (kok && m0 + e / kKT < cout) ? areg[i] : 0.f;
     }
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
       const int e = tid + kThreads * i;
-      const bool ok = (k0 + e / (N_T / 4) < cin) && (p0 + (e % (N_T / 4)) * 4 < P);
       float4 v = braw[i];
-      if (!GATHER && has_bn) v = bn_relu4(v, bsc[i], bsh[i]);
-      if (!ok) v = zero4();
-      *reinterpret_cast<float4*>(&Bs[buf][e / (N_T / 4)][(e % (N_T / 4)) * 4]) = v;
+      if (feat_chunk) {                         // (point, 4 channels) -> k-major tile: four scalar writes
+        const int pl = e / 4, q = (e % 4) * 4;
+        if (p0 + pl >= P) v = zero4();
+        Bs[buf][q + 0][pl] = v.x; Bs[buf][q + 1][pl] = v.y; Bs[buf][q + 2][pl] = v.z; Bs[buf][q + 3][pl] = v.w;
+      } else {
+        const int row = e / (N_T / 4);
+        const bool kok = GATHER == 2 ? row < 3 : (k0 + row < cin);
+        if (!GATHER && has_bn) v = bn_relu4(v, bsc[i], bsh[i]);
+        if (!(kok && p0 + (e % (N_T / 4)) * 4 < P)) v = zero4();
+        *reinterpret_cast<float4*>(&Bs[buf][row][(e % (N_T / 4)) * 4]) = v;
+      }
     }
   };
 
@@ -781,19 +815,20 @@ __global__ __launch_bounds__(kThreads) void pw_dgrad_kernel(
 // grid: (splits, ceil(cout / M_T), ceil(cin / N_T)); K = the points of one split.  A split is a range of
 // the flattened (cloud, point) index, so few-point layers (FP levels) are not forced to one split per
 // cloud; a 32-point K chunk never straddles two clouds because P % 32 == 0 is required by the launcher.
-template <int M_T, int N_T, int WM, int WN, bool GATHER>
+template <int M_T, int N_T, int WM, int WN, int GATHER>  // 0 tensor input, 1 channel-major gather, 2 point-major gather
 __global__ __launch_bounds__(kThreads) void pw_wgrad_kernel(
     int cin, int cout, int P, long long total, int split_len, const float* __restrict__ x, GatherSrc gsrc,
     const float* __restrict__ in_scale, const float* __restrict__ in_shift, const float* __restrict__ y,
     GradSrc gs, const float* __restrict__ bn, const float* __restrict__ bwdc, float* __restrict__ dw_part) {
   using T = Tile<M_T, N_T, WM, WN>;
   constexpr int TM = T::TM, TN = T::TN;
-  constexpr int LDA = M_T + 1, LDB = N_T + 1;  // odd leading dims: transposed scalar writes spread over banks
+  constexpr int LDA = M_T + 1;                          // odd leading dim: transposed scalar writes spread over banks
+  constexpr int LDB = GATHER == 2 ? N_T + 4 : N_T + 1;  // point-major gather writes whole float4 rows (16-B aligned)
   constexpr int NA = M_T * kKTW / 4 / kThreads;  // float4 (along p) per thread per chunk
   constexpr int NB = N_T * kKTW / 4 / kThreads;
   static_assert(NA >= 1 && NB >= 1, "tile too small");
   __shared__ float As[2][kKTW][LDA];
-  __shared__ float Bs[2][kKTW][LDB];
+  __shared__ __attribute__((aligned(16))) float Bs[2][kKTW][LDB];
 
   const int tid = threadIdx.x;
   const long long qbeg = (long long)blockIdx.x * split_len;
@@ -805,6 +840,8 @@ __global__ __launch_bounds__(kThreads) void pw_wgrad_kernel(
   float4 braw[NB];
   float bsc[NB], bsh[NB];
   int4 gidx[NB];  // GATHER: neighbour indices, loaded one chunk ahead of their use
+  int sidx[NB];   // GATHER == 2: item = (point e / (N_T/4), channel quad e % (N_T/4)), one index per item
+  const int cfeat = gsrc.cfeat;
   // chunk start qk (multiple of 32, inside one cloud) -> cloud b and in-cloud point of this thread's float4
   auto load_gidx = [&](long long qk) {
     const long long qc = min(qk, total - kKTW);
@@ -813,7 +850,8 @@ __global__ __launch_bounds__(kThreads) void pw_wgrad_kernel(
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
       const int e = tid + kThreads * i;
-      gidx[i] = gather_idx4(gsrc, b, P, pk + (e % (kKTW / 4)) * 4);
+      if (GATHER == 2) sidx[i] = gsrc.idx[(size_t)b * P + pk + e / (N_T / 4)];
+      else gidx[i] = gather_idx4(gsrc, b, P, pk + (e % (kKTW / 4)) * 4);
     }
   };
   auto load_chunk = [&](long long qk) {
@@ -830,7 +868,20 @@ __global__ __launch_bounds__(kThreads) void pw_wgrad_kernel(
     for (int i = 0; i < NB; ++i) {
       const int e = tid + kThreads * i;
       const int n = min(n0 + e / (kKTW / 4), cin - 1), p = pk + (e % (kKTW / 4)) * 4;
-      if (GATHER) {
+      if (GATHER == 2) {
+        // columns in K order [features..., x, y, z]: a float4 of 4 consecutive feature channels of one neighbour,
+        // or the (x, y, z, 0) offset to the centroid
+        const int c = n0 + (e % (N_T / 4)) * 4, pp = pk + e / (N_T / 4);
+        if (c < cfeat) {
+          braw[i] = gather_featT4(gsrc, b, sidx[i], c);
+        } else if (c == cfeat) {
+          const float* xs = gsrc.xyz + ((size_t)b * gsrc.n + sidx[i]) * 3;
+          const float* xc = gsrc.new_xyz + ((size_t)b * (P / gsrc.S) + pp / gsrc.S) * 3;
+          braw[i] = make_float4(xs[0] - xc[0], xs[1] - xc[1], xs[2] - xc[2], 0.f);
+        } else {
+          braw[i] = zero4();
+        }
+      } else if (GATHER) {
         braw[i] = gather4(gsrc, b, n, P, p, gidx[i]);
       } else {
         braw[i] = *reinterpret_cast<const float4*>(x + ((size_t)b * cin + n) * P + p);
@@ -853,9 +904,15 @@ __global__ __launch_bounds__(kThreads) void pw_wgrad_kernel(
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
       const int e = tid + kThreads * i;
+      float4 v = braw[i];
+      if (GATHER == 2) {
+        const int pl = e / (N_T / 4), c4 = (e % (N_T / 4)) * 4;
+        if (qk + pl >= qend) v = zero4();
+        *reinterpret_cast<float4*>(&Bs[buf][pl][c4]) = v;
+        continue;
+      }
       const int n = e / (kKTW / 4), k = (e % (kKTW / 4)) * 4;
       const bool ok = (n0 + n < cin) && (qk + k < qend);
-      float4 v = braw[i];
       if (!GATHER && has_bn) v = bn_relu4(v, bsc[i], bsh[i]);
       if (!ok) v = zero4();
       Bs[buf][k + 0][n] = v.x; Bs[buf][k + 1][n] = v.y; Bs[buf][k + 2][n] = v.z; Bs[buf][k + 3][n] = v.w;
@@ -895,7 +952,8 @@ __global__ __launch_bounds__(kThreads) void pw_wgrad_kernel(
       const int row = m0 + a_col0 + tm * 32 + mfma_row(r, lane);
 #pragma unroll
       for (int tn = 0; tn < TN; ++tn) {
-        const int col = n0 + b_col0 + tn * 32 + (lane & 31);
+        int col = n0 + b_col0 + tn * 32 + (lane & 31);
+        if (GATHER == 2) col = col < cfeat ? col + 3 : col - cfeat + (col < cfeat + 3 ? 0 : cin);  // K order -> column of w
         if (row < cout && col < cin) out[(size_t)row * cin + col] = acc[tm][tn][r];
       }
     }
@@ -1121,13 +1179,17 @@ static int launch_pw_forward(bool gather, int b, int cin, int cout, int p, const
   const int tpc = ceil_div(p, cfg_nt(cfg));
   const dim3 grid(tpc * b, ceil_div(cout, cfg_mt(cfg)));
   const int nt = tpc * b;
+  const int mode = !gather ? 0 : ((g.featT != nullptr && g.cfeat > 0 && g.cfeat % kKT == 0) ? 2 : 1);
 #define ISTNET_FWD(MT, NT, WM, WN)                                                                          \
   do {                                                                                                      \
-    if (gather)                                                                                             \
-      hipLaunchKernelGGL((pw_fwd_kernel<MT, NT, WM, WN, true>), grid, dim3(kThreads), 0, as_stream(stream), \
+    if (mode == 2)                                                                                          \
+      hipLaunchKernelGGL((pw_fwd_kernel<MT, NT, WM, WN, 2>), grid, dim3(kThreads), 0, as_stream(stream),    \
+                         cin, cout, p, tpc, x, g, w, in_scale, in_shift, y, part_sum, part_sq, nt);        \
+    else if (mode == 1)                                                                                     \
+      hipLaunchKernelGGL((pw_fwd_kernel<MT, NT, WM, WN, 1>), grid, dim3(kThreads), 0, as_stream(stream),    \
                          cin, cout, p, tpc, x, g, w, in_scale, in_shift, y, part_sum, part_sq, nt);        \
     else                                                                                                    \
-      hipLaunchKernelGGL((pw_fwd_kernel<MT, NT, WM, WN, false>), grid, dim3(kThreads), 0, as_stream(stream), \
+      hipLaunchKernelGGL((pw_fwd_kernel<MT, NT, WM, WN, 0>), grid, dim3(kThreads), 0, as_stream(stream),    \
                          cin, cout, p, tpc, x, g, w, in_scale, in_shift, y, part_sum, part_sq, nt);        \
   } while (0)
   switch (cfg) {
@@ -1148,10 +1210,10 @@ int istnet_pw_forward(int b, int cin, int cout, int p, const float* x, const flo
 }
 
 int istnet_pw_forward_gather(int b, int n, int npoint, int nsample, int cfeat, int cout, const float* xyz,
-                             const float* new_xyz, const float* feat, const int* idx, const float* w,
-                             float* y, float* part_sum, float* part_sq, void* stream) {
+                             const float* new_xyz, const float* feat, const float* feat_t, const int* idx,
+                             const float* w, float* y, float* part_sum, float* part_sq, void* stream) {
   if (n <= 0 || npoint <= 0 || nsample <= 0 || (nsample & 3) || cfeat < 0) return ISTNET_PN2_EINVAL;
-  const GatherSrc g{xyz, new_xyz, feat, idx, n, nsample, cfeat};
+  const GatherSrc g{xyz, new_xyz, feat, idx, n, nsample, cfeat, feat_t};
   return launch_pw_forward(true, b, 3 + cfeat, cout, npoint * nsample, nullptr, g, w, nullptr, nullptr, y,
                            part_sum, part_sq, stream);
 }
@@ -1300,13 +1362,17 @@ static int launch_pw_wgrad(bool gather, int b, int cin, int cout, int p, int nsa
   }
   const int mt = wgrad_mt(cout), nt = wgrad_nt(cin);
   const dim3 grid(wgrad_splits(b, cin, cout, p), ceil_div(cout, mt), ceil_div(cin, nt));
+  const int mode = !gather ? 0 : ((g.featT != nullptr && g.cfeat > 0 && g.cfeat % 4 == 0) ? 2 : 1);
 #define ISTNET_WGRAD(MT, NT)                                                                                  \
   do {                                                                                                        \
-    if (gather)                                                                                               \
-      hipLaunchKernelGGL((pw_wgrad_kernel<MT, NT, 2, 2, true>), grid, dim3(kThreads), 0, as_stream(stream),   \
+    if (mode == 2)                                                                                            \
+      hipLaunchKernelGGL((pw_wgrad_kernel<MT, NT, 2, 2, 2>), grid, dim3(kThreads), 0, as_stream(stream),      \
+                         cin, cout, p, total, len, x, g, in_scale, in_shift, y, gs, bn, bwdc, dw_part);       \
+    else if (mode == 1)                                                                                       \
+      hipLaunchKernelGGL((pw_wgrad_kernel<MT, NT, 2, 2, 1>), grid, dim3(kThreads), 0, as_stream(stream),      \
                          cin, cout, p, total, len, x, g, in_scale, in_shift, y, gs, bn, bwdc, dw_part);       \
     else                                                                                                      \
-      hipLaunchKernelGGL((pw_wgrad_kernel<MT, NT, 2, 2, false>), grid, dim3(kThreads), 0, as_stream(stream),  \
+      hipLaunchKernelGGL((pw_wgrad_kernel<MT, NT, 2, 2, 0>), grid, dim3(kThreads), 0, as_stream(stream),      \
                          cin, cout, p, total, len, x, g, in_scale, in_shift, y, gs, bn, bwdc, dw_part);       \
   } while (0)
   if (mt == 128 && nt == 128) ISTNET_WGRAD(128, 128);
@@ -1326,12 +1392,12 @@ int istnet_pw_wgrad(int b, int cin, int cout, int p, int nsample, const float* x
 }
 
 int istnet_pw_wgrad_gather(int b, int n, int npoint, int nsample, int cfeat, int cout, int grad_nsample,
-                           const float* xyz, const float* new_xyz, const float* feat, const int* idx,
-                           const float* y, const float* d_dense, const float* d_pooled,
+                           const float* xyz, const float* new_xyz, const float* feat, const float* feat_t,
+                           const int* idx, const float* y, const float* d_dense, const float* d_pooled,
                            long long pooled_bstride, const unsigned char* arg, const float* bn,
                            const float* bwdc, float* dw_part, void* stream) {
   if (n <= 0 || npoint <= 0 || nsample <= 0 || (nsample & 3) || cfeat < 0) return ISTNET_PN2_EINVAL;
-  const GatherSrc g{xyz, new_xyz, feat, idx, n, nsample, cfeat};
+  const GatherSrc g{xyz, new_xyz, feat, idx, n, nsample, cfeat, feat_t};
   return launch_pw_wgrad(true, b, 3 + cfeat, cout, npoint * nsample, grad_nsample, nullptr, g, nullptr, nullptr, y,
                          d_dense, d_pooled, pooled_bstride, arg, bn, bwdc, dw_part, stream);
 }

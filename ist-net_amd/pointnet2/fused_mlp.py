@@ -101,10 +101,11 @@ class _Layer:
 
 class _Gather:
     """Layer-0 input of a set-abstraction scale described by its sources instead of a grouped tensor."""
-    __slots__ = ("xyz", "new_xyz", "feat", "idx", "n", "npoint", "nsample", "cfeat")
+    __slots__ = ("xyz", "new_xyz", "feat", "idx", "n", "npoint", "nsample", "cfeat", "feat_t")
 
-    def __init__(self, xyz, new_xyz, feat, idx):
+    def __init__(self, xyz, new_xyz, feat, idx, feat_t=None):
         self.xyz, self.new_xyz, self.feat, self.idx = xyz, new_xyz, feat, idx
+        self.feat_t = feat_t     # (B, n, C) point-major copy: contiguous float4 gathers in the layer-0 loaders
         self.n = xyz.shape[1]
         self.npoint, self.nsample = idx.shape[1], idx.shape[2]
         self.cfeat = 0 if feat is None else feat.shape[1]
@@ -138,7 +139,8 @@ def _forward_stack(lib, dev, st, b, c0, g, s, x, gather, training, layers, param
             ga = gather
             _native.check(_native.timed(kname, flops, 4.0 * b * p * (1 + cout), lambda: lib.istnet_pw_forward_gather(
                 b, ga.n, ga.npoint, ga.nsample, ga.cfeat, cout, ga.xyz.data_ptr(), ga.new_xyz.data_ptr(),
-                _p(ga.feat), ga.idx.data_ptr(), w2.data_ptr(), y.data_ptr(), ps, pq, st)), "pw_forward_gather")
+                _p(ga.feat), _p(ga.feat_t), ga.idx.data_ptr(), w2.data_ptr(), y.data_ptr(), ps, pq, st)),
+                "pw_forward_gather")
         else:
             sc, sh = (_p(in_bn[0]), _p(in_bn[1])) if in_bn is not None else (None, None)
             cin_l, src = cur_c, cur
@@ -247,7 +249,7 @@ def _backward_stack(lib, dev, st, b, c0, g, s, x, gather, training, ys, bns, par
                 _native.check(_native.timed(
                     kname, flops, 4.0 * (b * p * (1 + cout) + grad_elems), lambda: lib.istnet_pw_wgrad_gather(
                         b, ga.n, ga.npoint, ga.nsample, ga.cfeat, cout, ns_arg, ga.xyz.data_ptr(),
-                        ga.new_xyz.data_ptr(), _p(ga.feat), ga.idx.data_ptr(), y.data_ptr(), dd, dp, pbs, da,
+                        ga.new_xyz.data_ptr(), _p(ga.feat), _p(ga.feat_t), ga.idx.data_ptr(), y.data_ptr(), dd, dp, pbs, da,
                         bn.data_ptr(), bwdc.data_ptr(), ws.data_ptr(), wst)), "pw_wgrad_gather")
             else:
                 src = x if li == 0 else ys[li - 1]
@@ -415,9 +417,11 @@ class FusedSALevelFunction(Function):
         ctot = sum(pl[-3].shape[0] for pl in plist)
         out = _empty((b, ctot, g), torch.float32, dev)
         saved, meta, coff = [], [], 0
+        # point-major copy of the features (one small transpose per level) for contiguous neighbour gathers
+        feat_t = feat.transpose(1, 2).contiguous() if (feat is not None and feat.shape[1] % 16 == 0) else None
         with torch.cuda.device(dev):
             for layers, params, idx in zip(scales, plist, idxs):
-                ga = _Gather(xyz, new_xyz, feat, idx)
+                ga = _Gather(xyz, new_xyz, feat, idx, feat_t)
                 _, arg, ys, bns = _forward_stack(lib, dev, _st(dev), b, 3 + ga.cfeat, g, ga.nsample, None, ga, training,
                                                  layers, params, out_spec=(out, coff))
                 meta.append((len(layers), ga.nsample, coff, params[-3].shape[0]))
@@ -425,7 +429,9 @@ class FusedSALevelFunction(Function):
                 saved += [arg, *ys, *bns]
         ctx.training, ctx.meta, ctx.has_feat = training, meta, feat is not None
         ctx.dims = (b, g, ctot)
-        ctx.save_for_backward(feat if feat is not None else torch.empty(0, device=dev), xyz, new_xyz, *idxs, *saved,
+        ctx.has_feat_t = feat_t is not None
+        ctx.save_for_backward(feat if feat is not None else torch.empty(0, device=dev), xyz, new_xyz,
+                              feat_t if feat_t is not None else torch.empty(0, device=dev), *idxs, *saved,
                               *tensors[nsc:])
         return out
 
@@ -438,10 +444,11 @@ class FusedSALevelFunction(Function):
         nsc = len(meta)
         sv = ctx.saved_tensors
         feat, xyz, new_xyz = sv[0], sv[1], sv[2]
-        idxs = sv[3:3 + nsc]
+        feat_t = sv[3] if ctx.has_feat_t else None
+        idxs = sv[4:4 + nsc]
         dev = xyz.device
         dout = dout.contiguous()
-        pos = 3 + nsc
+        pos = 4 + nsc
         per_scale = []
         for (nl, s, coff, clast) in meta:
             arg = sv[pos]
@@ -463,7 +470,7 @@ class FusedSALevelFunction(Function):
                 params = params_all[ppos:ppos + 3 * nl]
                 need_w = [ctx.needs_input_grad[base + ppos + 3 * li] for li in range(nl)]
                 ppos += 3 * nl
-                ga = _Gather(xyz, new_xyz, feat if ctx.has_feat else None, idx)
+                ga = _Gather(xyz, new_xyz, feat if ctx.has_feat else None, idx, feat_t)
                 cout0 = params[0].shape[0]
                 grads, dxf, scattered = _backward_stack(
                     lib, dev, st, b, 3 + cfeat, g, s, None, ga, ctx.training, ys, bns, params, arg,
