@@ -41,6 +41,14 @@ __device__ __forceinline__ float sqdist(float ax, float ay, float az, float bx, 
   return (dx * dx + dy * dy) + dz * dz;
 }
 
+// Two points per instruction: v_pk_add_f32 / v_pk_mul_f32 round each half exactly like the scalar ops
+// (IEEE RN, no fusion), so the packed distance is bit-identical to sqdist() and halves the VALU work.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 sqdist2(f32x2 ax, f32x2 ay, f32x2 az, float bx, float by, float bz) {
+  const f32x2 dx = ax - bx, dy = ay - by, dz = az - bz;
+  return (dx * dx + dy * dy) + dz * dz;
+}
+
 // ---- wave64 DPP reductions (result uniform, taken from lane 63) -------------
 template <int CTRL, int ROW_MASK = 0xf>
 __device__ __forceinline__ unsigned dpp_mov(unsigned identity, unsigned v) {
@@ -102,15 +110,17 @@ __global__ __launch_bounds__(NW * 64) void fps_regs_kernel(int n, int m, int bs_
   unsigned* xchg = reinterpret_cast<unsigned*>(fps_lds + 3 * n);  // [2][NW][2]
   __syncthreads();
 
-  float px[PPT], py[PPT], pz[PPT], tmp[PPT];
+  constexpr int PP = (PPT + 1) / 2;  // point slots are held in pairs (packed f32 math)
+  f32x2 px[PP], py[PP], pz[PP];
+  float tmp[2 * PP];
 #pragma unroll
-  for (int i = 0; i < PPT; ++i) {
+  for (int i = 0; i < 2 * PP; ++i) {
     const unsigned tk = (unsigned)(i * THREADS + tid);
     const int k = tiekey_to_k(tk, bs_log2, nper);
-    const bool valid = tk < ((unsigned)nper << bs_log2) && k < n;
-    px[i] = valid ? fps_lds[3 * k + 0] : 0.f;
-    py[i] = valid ? fps_lds[3 * k + 1] : 0.f;
-    pz[i] = valid ? fps_lds[3 * k + 2] : 0.f;
+    const bool valid = i < PPT && tk < ((unsigned)nper << bs_log2) && k < n;
+    px[i / 2][i % 2] = valid ? fps_lds[3 * k + 0] : 0.f;
+    py[i / 2][i % 2] = valid ? fps_lds[3 * k + 1] : 0.f;
+    pz[i / 2][i % 2] = valid ? fps_lds[3 * k + 2] : 0.f;
     tmp[i] = valid ? 1e10f : -1.0f;  // invalid slot: min(d,-1) = -1 never beats best = -1
   }
 
@@ -123,13 +133,18 @@ __global__ __launch_bounds__(NW * 64) void fps_regs_kernel(int n, int m, int bs_
     float best = -1.0f;
     int besti = 0;
 #pragma unroll
-    for (int i = 0; i < PPT; ++i) {
-      const float d = sqdist(px[i], py[i], pz[i], x1, y1, z1);
-      const float d2 = fminf(d, tmp[i]);
-      tmp[i] = d2;
-      const bool gt = d2 > best;
-      besti = gt ? i : besti;
-      best = gt ? d2 : best;
+    for (int i = 0; i < PP; ++i) {
+      const f32x2 d = sqdist2(px[i], py[i], pz[i], x1, y1, z1);
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        if (2 * i + h < PPT) {
+          const float d2 = fminf(d[h], tmp[2 * i + h]);
+          tmp[2 * i + h] = d2;
+          const bool gt = d2 > best;
+          besti = gt ? 2 * i + h : besti;
+          best = gt ? d2 : best;
+        }
+      }
     }
     // value key: 0 for "no valid slot", otherwise float bits + 1 (d2 >= +0 => monotone)
     const unsigned vkey = best < 0.0f ? 0u : (__float_as_uint(best) + 1u);

@@ -92,6 +92,20 @@ __device__ __forceinline__ float4 gather4(const GatherSrc& gs, int b, int k, int
   return v;
 }
 
+#ifdef ISTNET_TRACE
+// Debug build only (tools/trace_fwd.py): per-workgroup timestamps (100 MHz wall clock) of the forward GEMM phases.
+__device__ unsigned long long g_trace[8][8192];  // [0..3] wall clock (100 MHz), [4..7] shader clock
+#define ISTNET_TRACE_MARK(i)                                                                             \
+  do {                                                                                                   \
+    if (threadIdx.x == 0) {                                                                              \
+      const unsigned wg = blockIdx.x + gridDim.x * blockIdx.y;                                           \
+      if (wg < 8192) { g_trace[i][wg] = wall_clock64(); g_trace[4 + i][wg] = clock64(); }                \
+    }                                                                                                    \
+  } while (0)
+#else
+#define ISTNET_TRACE_MARK(i)
+#endif
+
 template <int M_T, int N_T, int WM, int WN>
 struct Tile {
   static constexpr int TM = M_T / (32 * WM);
@@ -253,9 +267,11 @@ __global__ __launch_bounds__(kThreads) void pw_fwd_kernel(
   const int wv = wave_id();
   const int a_col0 = (wv / WN) * TM * 32, b_col0 = (wv % WN) * TN * 32;
   const int nchunks = (cin + kKT - 1) / kKT;
+  ISTNET_TRACE_MARK(0);
   load_chunk(0);
   store_chunk(0, 0);
   __syncthreads();
+  ISTNET_TRACE_MARK(1);
   for (int t = 0; t < nchunks; ++t) {
     const int buf = t & 1;
     if (t + 1 < nchunks) load_chunk((t + 1) * kKT);
@@ -263,6 +279,7 @@ __global__ __launch_bounds__(kThreads) void pw_fwd_kernel(
     if (t + 1 < nchunks) store_chunk(buf ^ 1, (t + 1) * kKT);
     __syncthreads();
   }
+  ISTNET_TRACE_MARK(2);
 
   // ---- epilogue: store raw y, reduce per-channel sum / sum of squares of this tile ------------
   const int lane = lane_id();
@@ -319,26 +336,46 @@ __global__ __launch_bounds__(kThreads) void pw_fwd_kernel(
       }
     }
   }
+  ISTNET_TRACE_MARK(3);
 }
 
 // ============================================================================================
 // BN finalize (forward): partials -> mean / invstd / scale / shift, running statistics update
 // ============================================================================================
+// Sum two rows of nt float partials in f64 with 256 threads (fixed order: thread t takes i = t, t+256, ...;
+// four independent chains keep several loads in flight), result valid on thread 0.
+constexpr int kFinThreads = 256;
+__device__ __forceinline__ void reduce_partials2(const float* __restrict__ pa, const float* __restrict__ pb, int nt,
+                                                 double& ra, double& rb) {
+  double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0, b0 = 0.0, b1 = 0.0, b2 = 0.0, b3 = 0.0;
+  int i = threadIdx.x;
+  for (; i + 3 * kFinThreads < nt; i += 4 * kFinThreads) {
+    const float x0 = pa[i], x1 = pa[i + kFinThreads], x2 = pa[i + 2 * kFinThreads], x3 = pa[i + 3 * kFinThreads];
+    const float y0 = pb[i], y1 = pb[i + kFinThreads], y2 = pb[i + 2 * kFinThreads], y3 = pb[i + 3 * kFinThreads];
+    a0 += (double)x0; a1 += (double)x1; a2 += (double)x2; a3 += (double)x3;
+    b0 += (double)y0; b1 += (double)y1; b2 += (double)y2; b3 += (double)y3;
+  }
+  for (; i < nt; i += kFinThreads) { a0 += (double)pa[i]; b0 += (double)pb[i]; }
+  double a = (a0 + a1) + (a2 + a3), b = (b0 + b1) + (b2 + b3);
+  for (int off = 32; off >= 1; off >>= 1) {
+    a += __shfl_xor(a, off);
+    b += __shfl_xor(b, off);
+  }
+  __shared__ double sh[2][kFinThreads / 64];
+  if ((threadIdx.x & 63) == 0) { sh[0][threadIdx.x >> 6] = a; sh[1][threadIdx.x >> 6] = b; }
+  __syncthreads();
+  ra = (sh[0][0] + sh[0][1]) + (sh[0][2] + sh[0][3]);
+  rb = (sh[1][0] + sh[1][1]) + (sh[1][2] + sh[1][3]);
+}
+
 // out: bn[0]=scale, bn[1]=shift, bn[2]=mean, bn[3]=invstd   (each [C])
-__global__ __launch_bounds__(64) void bn_finalize_fwd_kernel(
+__global__ __launch_bounds__(kFinThreads) void bn_finalize_fwd_kernel(
     int C, int nt, double count, const float* __restrict__ part_sum, const float* __restrict__ part_sq,
     const float* __restrict__ gamma, const float* __restrict__ beta, float eps, float momentum,
     float* __restrict__ running_mean, float* __restrict__ running_var, float* __restrict__ bn) {
   const int c = blockIdx.x;
-  double s = 0.0, q = 0.0;
-  for (int i = threadIdx.x; i < nt; i += 64) {
-    s += (double)part_sum[(size_t)c * nt + i];
-    q += (double)part_sq[(size_t)c * nt + i];
-  }
-  for (int off = 32; off >= 1; off >>= 1) {
-    s += __shfl_xor(s, off);
-    q += __shfl_xor(q, off);
-  }
+  double s, q;
+  reduce_partials2(part_sum + (size_t)c * nt, part_sq + (size_t)c * nt, nt, s, q);
   if (threadIdx.x == 0) {
     const double mean = s / count;
     double var = q / count - mean * mean;
@@ -480,7 +517,7 @@ __global__ __launch_bounds__(256) void pw_bwd_stats_kernel(int C, int P, GradSrc
 
 // finalize: dbeta = sum g, dgamma = sum g*yhat; constants for dY = ca*g + cb + cc*y
 // bn: [4][C] from the forward (scale, shift, mean, invstd); bwdc: [3][C] = ca, cb, cc
-__global__ __launch_bounds__(64) void bn_finalize_bwd_kernel(int C, int nt, double count, int training,
+__global__ __launch_bounds__(kFinThreads) void bn_finalize_bwd_kernel(int C, int nt, double count, int training,
                                                              const float* __restrict__ part_g,
                                                              const float* __restrict__ part_gy,
                                                              const float* __restrict__ gamma,
@@ -489,15 +526,8 @@ __global__ __launch_bounds__(64) void bn_finalize_bwd_kernel(int C, int nt, doub
                                                              float* __restrict__ dbeta,
                                                              float* __restrict__ bwdc) {
   const int c = blockIdx.x;
-  double sg = 0.0, sgy = 0.0;
-  for (int i = threadIdx.x; i < nt; i += 64) {
-    sg += (double)part_g[(size_t)c * nt + i];
-    sgy += (double)part_gy[(size_t)c * nt + i];
-  }
-  for (int off = 32; off >= 1; off >>= 1) {
-    sg += __shfl_xor(sg, off);
-    sgy += __shfl_xor(sgy, off);
-  }
+  double sg, sgy;
+  reduce_partials2(part_g + (size_t)c * nt, part_gy + (size_t)c * nt, nt, sg, sgy);
   if (threadIdx.x == 0) {
     const double mean = bn[2 * C + c], istd = bn[3 * C + c];
     const double dg = (sgy - mean * sg) * istd;  // sum g * (y - mean) * istd
@@ -1158,6 +1188,12 @@ inline int wgrad_splits(int b, int cin, int cout, int P) {
 
 extern "C" {
 
+#ifdef ISTNET_TRACE
+ISTNET_PN2_API int istnet_pw_trace_read(unsigned long long* dst) {
+  return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_trace), sizeof(unsigned long long) * 8 * 8192);
+}
+#endif
+
 int istnet_pw_tile_cfg(int b, int m, int p) {
   const TileCfg c = pick_cfg(b, m, p);
   return cfg_mt(c) * 1000 + cfg_nt(c);  // e.g. 128128, 64128, 64064, 32256
@@ -1222,7 +1258,7 @@ int istnet_bn_finalize_fwd(int c, int nt, double count, const float* part_sum, c
                            const float* gamma, const float* beta, float eps, float momentum,
                            float* running_mean, float* running_var, float* bn, void* stream) {
   if (c <= 0 || nt <= 0) return ISTNET_PN2_EINVAL;
-  hipLaunchKernelGGL(bn_finalize_fwd_kernel, dim3(c), dim3(64), 0, as_stream(stream), c, nt, count,
+  hipLaunchKernelGGL(bn_finalize_fwd_kernel, dim3(c), dim3(kFinThreads), 0, as_stream(stream), c, nt, count,
                      part_sum, part_sq, gamma, beta, eps, momentum, running_mean, running_var, bn);
   return (int)hipGetLastError();
 }
@@ -1283,7 +1319,7 @@ int istnet_bn_finalize_bwd(int c, int nt, double count, int training, const floa
                            const float* part_gy, const float* gamma, const float* bn, float* dgamma,
                            float* dbeta, float* bwdc, void* stream) {
   if (c <= 0 || nt <= 0) return ISTNET_PN2_EINVAL;
-  hipLaunchKernelGGL(bn_finalize_bwd_kernel, dim3(c), dim3(64), 0, as_stream(stream), c, nt, count,
+  hipLaunchKernelGGL(bn_finalize_bwd_kernel, dim3(c), dim3(kFinThreads), 0, as_stream(stream), c, nt, count,
                      training, part_g, part_gy, gamma, bn, dgamma, dbeta, bwdc);
   return (int)hipGetLastError();
 }

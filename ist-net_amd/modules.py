@@ -76,10 +76,10 @@ class PointNet2MSG(nn.Module):
                 levels.append(new_xyz)
                 cur = new_xyz
             for lvl in range(len(self.FP_modules) - 1, -1, -1):
-                idx, weight = PointnetFPModule.interpolation_weights(levels[lvl], levels[lvl + 1])
+                idx, weight, csr = PointnetFPModule.interpolation_weights(levels[lvl], levels[lvl + 1], with_csr=True)
                 ev = torch.cuda.Event()
                 ev.record(side)
-                fp_geo[lvl] = (idx, weight, ev)
+                fp_geo[lvl] = (idx, weight, csr, ev)
         return sa_geo, fp_geo
 
     def _can_prepass(self, xyz):
@@ -109,9 +109,9 @@ class PointNet2MSG(nn.Module):
         for lvl in range(len(self.FP_modules) - 1, -1, -1):  # coarse -> fine  [ref :322-325]
             interp = None
             if fp_geo is not None:
-                idx, weight, ev = fp_geo[lvl]
+                idx, weight, csr, ev = fp_geo[lvl]
                 main.wait_event(ev)
-                interp = (idx, weight)
+                interp = (idx, weight, csr)
             l_features[lvl] = self.FP_modules[lvl](l_xyz[lvl], l_xyz[lvl + 1], l_features[lvl],
                                                    l_features[lvl + 1], interp=interp)
         return l_features[0]

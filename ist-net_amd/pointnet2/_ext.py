@@ -122,8 +122,28 @@ def three_interpolate(points, idx, weight):
     return out
 
 
-def three_interpolate_grad(grad_out, idx, weight, m):
-    """(B,C,n) f32, (B,n,3) i32, (B,n,3) f32, m -> (B,C,m).  interpolate.cpp:75-104"""
+def interp_csr(idx, m):
+    """Per-cloud inverse lists of a three_nn index tensor (B,n,3) over m sources: (offsets (B,m+1), entries (B,3n))
+    int32, or None when m is too large for the LDS histogram of the build kernel.  Depends on idx only, so
+    a caller that knows idx early (the encoder's geometry pre-pass) can build it off the critical path and
+    hand it to three_interpolate_grad."""
+    _contig(idx, "idx"); _is_int(idx, "idx")
+    m = int(m)
+    if 3 * m + 257 > 16384:
+        return None
+    dev = _device_of(idx, "idx")
+    b, n = idx.shape[0], idx.shape[1]
+    offsets = torch.empty((b, m + 1), dtype=torch.int32, device=dev)
+    entries = torch.empty((b, 3 * n), dtype=torch.int32, device=dev)
+    with torch.cuda.device(dev):
+        _native.check(_native.lib().istnet_pn2_interp_csr_build(b, n, m, _ptr(idx), _ptr(offsets), _ptr(entries),
+                                                                _stream(dev)), "interp_csr_build")
+    return offsets, entries
+
+
+def three_interpolate_grad(grad_out, idx, weight, m, csr=None):
+    """(B,C,n) f32, (B,n,3) i32, (B,n,3) f32, m -> (B,C,m).  interpolate.cpp:75-104
+    ``csr``: optional result of interp_csr(idx, m) (extension of the reference signature)."""
     _contig(grad_out, "grad_out"); _contig(idx, "idx"); _contig(weight, "weight")
     _is_float(grad_out, "grad_out"); _is_int(idx, "idx"); _is_float(weight, "weight")
     dev = _device_of(grad_out, "grad_out", (idx, "idx"), (weight, "weight"))
@@ -131,13 +151,11 @@ def three_interpolate_grad(grad_out, idx, weight, m):
     m = int(m)
     out = torch.empty((b, c, m), dtype=torch.float32, device=dev)
     lib = _native.lib()
+    if csr is None:
+        csr = interp_csr(idx, m)   # deterministic gather over per-cloud inverse lists, reused by all channels
     with torch.cuda.device(dev):
-        if 3 * m + 257 <= 16384:
-            # deterministic gather over per-cloud inverse lists (built once per call, reused by all channels)
-            offsets = torch.empty((b, m + 1), dtype=torch.int32, device=dev)
-            entries = torch.empty((b, 3 * n), dtype=torch.int32, device=dev)
-            _native.check(lib.istnet_pn2_interp_csr_build(b, n, m, _ptr(idx), _ptr(offsets), _ptr(entries),
-                                                          _stream(dev)), "interp_csr_build")
+        if csr is not None:
+            offsets, entries = csr
             _native.check(lib.istnet_pn2_three_interpolate_grad_csr(
                 b, c, n, m, _ptr(grad_out), _ptr(weight), _ptr(offsets), _ptr(entries), _ptr(out), _stream(dev)),
                 "three_interpolate_grad_csr")

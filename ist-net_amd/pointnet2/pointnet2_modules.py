@@ -88,11 +88,16 @@ class PointnetFPModule(nn.Module):
         self.mlp = pytorch_utils.SharedMLP(mlp, bn=bn)
 
     @staticmethod
-    def interpolation_weights(unknown, known):
-        """three_nn + inverse-distance weights (idx (B,n,3) i32, weight (B,n,3)).  [ref :185-188]"""
+    def interpolation_weights(unknown, known, with_csr=False):
+        """three_nn + inverse-distance weights (idx (B,n,3) i32, weight (B,n,3)).  [ref :185-188]
+        with_csr: also return the inverse lists of idx used by the backward of three_interpolate."""
         dist, idx = pointnet2_utils.three_nn(unknown, known)
         inv = 1.0 / (dist + 1e-8)
-        return idx, inv / torch.sum(inv, dim=2, keepdim=True)
+        weight = inv / torch.sum(inv, dim=2, keepdim=True)
+        if with_csr:
+            interp_csr = getattr(pointnet2_utils._ext, "interp_csr", None)   # absent from a plain reference _ext
+            return idx, weight, (interp_csr(idx, known.size(1)) if interp_csr is not None and idx.is_cuda else None)
+        return idx, weight
 
     def forward(self, unknown, known, unknow_feats, known_feats, interp=None):
         """unknown (B,n,3), known (B,m,3), unknow_feats (B,C1,n) or None, known_feats (B,C2,m)
@@ -100,8 +105,11 @@ class PointnetFPModule(nn.Module):
         if known is None:
             interpolated = known_feats.expand(*known_feats.size()[0:2], unknown.size(1))
         else:
-            idx, weight = interp if interp is not None else self.interpolation_weights(unknown, known)
-            interpolated = pointnet2_utils.three_interpolate(known_feats, idx.detach(), weight.detach())
+            idx, weight, *csr = interp if interp is not None else self.interpolation_weights(unknown, known)
+            if csr and csr[0] is not None:
+                interpolated = pointnet2_utils.three_interpolate(known_feats, idx.detach(), weight.detach(), csr[0])
+            else:
+                interpolated = pointnet2_utils.three_interpolate(known_feats, idx.detach(), weight.detach())
 
         stacked = interpolated if unknow_feats is None else torch.cat([interpolated, unknow_feats], dim=1)
         return shared_mlp_maxpool(self.mlp, stacked.unsqueeze(-1))   # mlp(...).squeeze(-1)  [ref :205-209]

@@ -75,16 +75,21 @@ class ThreeInterpolate(Function):
     """features (B,c,m), idx (B,n,3) i32, weight (B,n,3) -> (B,c,n).  [ref :152-206]"""
 
     @staticmethod
-    def forward(ctx, features, idx, weight):
+    def forward(ctx, features, idx, weight, csr=None):
+        # csr (optional, not in the reference): inverse lists of idx from _ext.interp_csr, built ahead of time
         ctx.m_src = features.size(2)
+        ctx.csr = csr
         ctx.save_for_backward(idx, weight)
         return _ext.three_interpolate(features, idx, weight)
 
     @staticmethod
     def backward(ctx, grad_out):
         idx, weight = ctx.saved_tensors
-        grad_features = _ext.three_interpolate_grad(grad_out.contiguous(), idx, weight, ctx.m_src)
-        return grad_features, None, None
+        if ctx.csr is not None:
+            grad_features = _ext.three_interpolate_grad(grad_out.contiguous(), idx, weight, ctx.m_src, ctx.csr)
+        else:
+            grad_features = _ext.three_interpolate_grad(grad_out.contiguous(), idx, weight, ctx.m_src)
+        return grad_features, None, None, None
 
 
 three_interpolate = ThreeInterpolate.apply

@@ -45,12 +45,12 @@ for name, P, s, spec in LAYERS:
         bwdc = torch.stack([torch.ones(cout, device=dev), torch.zeros(cout, device=dev) + 0.01, torch.zeros(cout, device=dev) - 0.01]).contiguous()
         dA = torch.randn(B, cout, P, device=dev)
         dx = torch.empty(B, cin, P, device=dev)
-        d = lambda: lib.istnet_pw_dgrad(B, cin, 0, cin, cout, P, 0, w.data_ptr(), y.data_ptr(), dA.data_ptr(), None, None, bn.data_ptr(), bwdc.data_ptr(), dx.data_ptr(), None, None, None, None, st)
+        d = lambda: lib.istnet_pw_dgrad(B, cin, 0, cin, cout, P, 0, w.data_ptr(), y.data_ptr(), dA.data_ptr(), None, 0, None, bn.data_ptr(), bwdc.data_ptr(), dx.data_ptr(), None, None, None, None, st)
         t_d = timeit(d)
         splits = lib.istnet_pw_wgrad_splits(B, cin, cout, P)
         ws = torch.empty(splits, cout, cin, device=dev); dw = torch.empty(cout, cin, device=dev)
         g = lambda: lib.istnet_pw_wgrad(B, cin, cout, P, 0, x.data_ptr(), insc.data_ptr() if has_bn else None, insh.data_ptr() if has_bn else None,
-                                        y.data_ptr(), dA.data_ptr(), None, None, bn.data_ptr(), bwdc.data_ptr(), ws.data_ptr(), st)
+                                        y.data_ptr(), dA.data_ptr(), None, 0, None, bn.data_ptr(), bwdc.data_ptr(), ws.data_ptr(), st)
         t_w = timeit(g)
         r = lambda: lib.istnet_pw_wgrad_reduce(cout * cin, splits, ws.data_ptr(), dw.data_ptr(), st)
         t_r = timeit(r)
