@@ -60,9 +60,11 @@ ISTNET_PN2_API int istnet_bn_finalize_fwd(int c, int nt, double count, const flo
 /* out[b][c][g] = max_s relu(y[b][c][g][s]*scale+shift), arg = index of the first maximum (s > 1); cloud b of
  * `out` starts at out + b*out_bstride (0 = c*g), so a scale writes straight into its channel slice of the
  * concatenated MSG output;
- * s == 1: out = relu(y*scale+shift), arg unused (may be NULL) */
+ * s == 1: out = relu(y*scale+shift), arg unused (may be NULL);
+ * ymax (optional, (b, c, g)): raw y at the arg-max, consumed by istnet_pw_bwd_stats_pooled */
 ISTNET_PN2_API int istnet_bn_relu_pool(int b, int c, int g, int s, const float *y, const float *bn,
-                                       float *out, long long out_bstride, unsigned char *arg, void *stream);
+                                       float *out, long long out_bstride, unsigned char *arg, float *ymax,
+                                       void *stream);
 
 /* out = y * bn[0] + bn[1] (per channel), followed by ReLU when relu != 0 -- final layer of a bias stack */
 ISTNET_PN2_API int istnet_affine_apply(int b, int c, int p, int relu, const float *y, const float *bn,
@@ -74,6 +76,11 @@ ISTNET_PN2_API int istnet_pw_bwd_stats(int b, int c, int p, int nsample, const f
                                        const float *d_dense, const float *d_pooled, long long pooled_bstride,
                                        const unsigned char *arg, const float *bn, float *part_g,
                                        float *part_gy, void *stream);
+/* the same partial sums for a max-pooled gradient source, from the (b, c, g) tensors only: d_pooled (cloud
+ * stride pooled_bstride, 0 = c*g) and the raw maxima `ymax` of istnet_bn_relu_pool; partials [c][b] (nt = b) */
+ISTNET_PN2_API int istnet_pw_bwd_stats_pooled(int b, int c, int g, const float *d_pooled,
+                                              long long pooled_bstride, const float *ymax, const float *bn,
+                                              float *part_g, float *part_gy, void *stream);
 /* partials -> dgamma, dbeta, bwdc[3][c]; training = 0 treats BN as a fixed affine map (eval mode) */
 ISTNET_PN2_API int istnet_bn_finalize_bwd(int c, int nt, double count, int training, const float *part_g,
                                           const float *part_gy, const float *gamma, const float *bn,

@@ -403,26 +403,28 @@ __global__ __launch_bounds__(256) void bn_relu_pool_kernel(int C, int G, const f
                                                            const float* __restrict__ scale,
                                                            const float* __restrict__ shift,
                                                            float* __restrict__ out, long long out_bstride,
-                                                           uint8_t* __restrict__ arg) {
+                                                           uint8_t* __restrict__ arg, float* __restrict__ ymax) {
   const int bc = blockIdx.y;
   const int g = blockIdx.x * 256 + threadIdx.x;
   if (g >= G) return;
   const float s = scale[bc % C], h = shift[bc % C];
   const float4* src = reinterpret_cast<const float4*>(y + ((size_t)bc * G + g) * (S4 * 4));
   float best = -1.f;  // relu output is >= 0, so the first element always replaces this
+  float raw = 0.f;    // raw y at the arg-max: lets the backward statistics skip the full activation tensor
   int besti = 0;
 #pragma unroll
   for (int i = 0; i < S4; ++i) {
     const float4 v = src[i];
     const float a0 = fmaxf(v.x * s + h, 0.f), a1 = fmaxf(v.y * s + h, 0.f);
     const float a2 = fmaxf(v.z * s + h, 0.f), a3 = fmaxf(v.w * s + h, 0.f);
-    if (a0 > best) { best = a0; besti = 4 * i + 0; }
-    if (a1 > best) { best = a1; besti = 4 * i + 1; }
-    if (a2 > best) { best = a2; besti = 4 * i + 2; }
-    if (a3 > best) { best = a3; besti = 4 * i + 3; }
+    if (a0 > best) { best = a0; besti = 4 * i + 0; raw = v.x; }
+    if (a1 > best) { best = a1; besti = 4 * i + 1; raw = v.y; }
+    if (a2 > best) { best = a2; besti = 4 * i + 2; raw = v.z; }
+    if (a3 > best) { best = a3; besti = 4 * i + 3; raw = v.w; }
   }
   out[(size_t)(bc / C) * out_bstride + (size_t)(bc % C) * G + g] = best;
   arg[(size_t)bc * G + g] = (uint8_t)besti;
+  if (ymax != nullptr) ymax[(size_t)bc * G + g] = raw;
 }
 __global__ __launch_bounds__(256) void bn_relu_apply_kernel(int C, int P4, const float* __restrict__ y,
                                                             const float* __restrict__ scale,
@@ -512,6 +514,35 @@ __global__ __launch_bounds__(256) void pw_bwd_stats_kernel(int C, int P, GradSrc
     const int t = b * gridDim.x + blockIdx.x;
     part_g[(size_t)c * nt_total + t] = (red[0][0] + red[1][0]) + (red[2][0] + red[3][0]);
     part_gy[(size_t)c * nt_total + t] = (red[0][1] + red[1][1]) + (red[2][1] + red[3][1]);
+  }
+}
+
+// Same sums when the gradient arrives through the max-pool: g is non-zero only at the arg-max of each
+// group, where y is the raw maximum `ymax` saved by bn_relu_pool -- (B, C, G) reads instead of (B, C, G*S).
+// grid: (C, B), one wave per row; partials [C][B]
+__global__ __launch_bounds__(64) void pw_bwd_stats_pooled_kernel(int C, int G, const float* __restrict__ pooled,
+                                                                 long long pooled_bstride,
+                                                                 const float* __restrict__ ymax,
+                                                                 const float* __restrict__ scale,
+                                                                 const float* __restrict__ shift,
+                                                                 float* __restrict__ part_g,
+                                                                 float* __restrict__ part_gy) {
+  const int c = blockIdx.x, b = blockIdx.y, B = gridDim.y;
+  const float s = scale[c], h = shift[c];
+  const float* d = pooled + (size_t)b * pooled_bstride + (size_t)c * G;
+  const float* v = ymax + ((size_t)b * C + c) * G;
+  float sg = 0.f, sgy = 0.f;
+  for (int g = threadIdx.x; g < G; g += 64) {
+    const float y = v[g];
+    const float gr = (y * s + h > 0.f) ? d[g] : 0.f;
+    sg += gr;
+    sgy += gr * y;
+  }
+  sg = wave_sum(sg);
+  sgy = wave_sum(sgy);
+  if (threadIdx.x == 0) {
+    part_g[(size_t)c * B + b] = sg;
+    part_gy[(size_t)c * B + b] = sgy;
   }
 }
 
@@ -1264,7 +1295,7 @@ int istnet_bn_finalize_fwd(int c, int nt, double count, const float* part_sum, c
 }
 
 int istnet_bn_relu_pool(int b, int c, int g, int s, const float* y, const float* bn, float* out,
-                        long long out_bstride, unsigned char* arg, void* stream) {
+                        long long out_bstride, unsigned char* arg, float* ymax, void* stream) {
   if (out_bstride <= 0) out_bstride = (long long)c * g;
   if (b <= 0 || c <= 0 || g <= 0 || s <= 0) return ISTNET_PN2_EINVAL;
   const float* scale = bn;
@@ -1279,7 +1310,7 @@ int istnet_bn_relu_pool(int b, int c, int g, int s, const float* y, const float*
   const dim3 grid(ceil_div(g, 256), b * c);
 #define ISTNET_POOL(S4)                                                                                  \
   hipLaunchKernelGGL((bn_relu_pool_kernel<S4>), grid, dim3(256), 0, as_stream(stream), c, g, y, scale,  \
-                     shift, out, out_bstride, arg)
+                     shift, out, out_bstride, arg, ymax)
   switch (s) {
     case 4: ISTNET_POOL(1); break;
     case 8: ISTNET_POOL(2); break;
@@ -1300,6 +1331,14 @@ int istnet_affine_apply(int b, int c, int p, int relu, const float* y, const flo
 }
 
 int istnet_pw_bwd_stat_tiles(int b, int p) { return b * ceil_div(p, kStatChunk); }
+
+int istnet_pw_bwd_stats_pooled(int b, int c, int g, const float* d_pooled, long long pooled_bstride,
+                               const float* ymax, const float* bn, float* part_g, float* part_gy, void* stream) {
+  if (b <= 0 || c <= 0 || g <= 0 || d_pooled == nullptr || ymax == nullptr) return ISTNET_PN2_EINVAL;
+  hipLaunchKernelGGL(pw_bwd_stats_pooled_kernel, dim3(c, b), dim3(64), 0, as_stream(stream), c, g, d_pooled,
+                     pooled_bstride > 0 ? pooled_bstride : (long long)c * g, ymax, bn, bn + c, part_g, part_gy);
+  return (int)hipGetLastError();
+}
 
 int istnet_pw_bwd_stats(int b, int c, int p, int nsample, const float* y, const float* d_dense,
                         const float* d_pooled, long long pooled_bstride, const unsigned char* arg,

@@ -171,7 +171,8 @@ def _forward_stack(lib, dev, st, b, c0, g, s, x, gather, training, layers, param
     else:
         out, coff = out_spec
         out_ptr, out_bstride = out.data_ptr() + coff * g * 4, out.shape[1] * g
-    arg = _empty((b, cur_c, g), torch.uint8, dev) if s > 1 else None
+    # arg-max slots (uint8) followed by the raw maxima (f32) in one buffer: see _ymax_ptr
+    arg = _empty((_arg_bytes(b * cur_c * g) + 4 * b * cur_c * g,), torch.uint8, dev) if s > 1 else None
     if s == 1 and not layers[-1].relu:
         _native.check(lib.istnet_affine_apply(b, cur_c, g, 0, cur.data_ptr(), in_bn.data_ptr(), out.data_ptr(), st),
                       "affine_apply")
@@ -179,8 +180,20 @@ def _forward_stack(lib, dev, st, b, c0, g, s, x, gather, training, layers, param
         bns[-1] = _ident_consts(dev, cur_c)[0]
     else:
         _native.check(lib.istnet_bn_relu_pool(b, cur_c, g, s, cur.data_ptr(), in_bn.data_ptr(), out_ptr,
-                                              out_bstride, _p(arg), st), "bn_relu_pool")
+                                              out_bstride, _p(arg), _ymax_ptr(arg, b * cur_c * g), st), "bn_relu_pool")
     return out, arg, ys, bns
+
+
+_AB_OLD = os.environ.get("ISTNET_AB_OLD") is not None   # debug: previous code path of the change under test
+
+
+def _arg_bytes(n):
+    return (n + 15) // 16 * 16
+
+
+def _ymax_ptr(arg, n):
+    """Device address of the f32 raw maxima stored behind the n uint8 arg-max slots of `arg` (or None)."""
+    return None if arg is None else arg.data_ptr() + _arg_bytes(n)
 
 
 def _backward_stack(lib, dev, st, b, c0, g, s, x, gather, training, ys, bns, params, arg, dout, need_w, need_x,
@@ -216,6 +229,11 @@ def _backward_stack(lib, dev, st, b, c0, g, s, x, gather, training, ys, bns, par
         grad_elems = b * cout * (p if dd is not None else p // s)
         if fused_part is not None:
             part, nt_l = fused_part, fused_nt
+        elif ns_arg and not _AB_OLD:   # gradient through the max-pool: statistics from the (B, C, G) tensors only
+            part, nt_l = _empty((2, cout, b), torch.float32, dev), b
+            _native.check(lib.istnet_pw_bwd_stats_pooled(b, cout, g, dp, pbs, _ymax_ptr(d_arg, b * cout * g),
+                                                         bn.data_ptr(), part[0].data_ptr(), part[1].data_ptr(), st),
+                          "pw_bwd_stats_pooled")
         else:
             part, nt_l = _empty((2, cout, ntb), torch.float32, dev), ntb
             _native.check(lib.istnet_pw_bwd_stats(b, cout, p, ns_arg, y.data_ptr(), dd, dp, pbs, da, bn.data_ptr(),
