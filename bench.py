@@ -174,6 +174,11 @@ def main():
                     help="dry run of the N>1 control flow on a 1-GPU box: every rank uses cuda:0 (gloo only)")
     args = ap.parse_args()
 
+    if os.environ.get("ISTNET_PW_TUNE"):   # experiments: "key:value,..." for istnet_pw_set_tuning
+        from istnet_amd import _native
+        for kv in os.environ["ISTNET_PW_TUNE"].split(","):
+            k, v = kv.split(":")
+            assert _native.lib().istnet_pw_set_tuning(int(k), int(v)) == 0
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))

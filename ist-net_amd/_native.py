@@ -30,7 +30,8 @@ SIGNATURES = {
     "istnet_pn2_three_interpolate_grad_csr": [_i, _i, _i, _i, _p, _p, _p, _p, _p, _p],
     # include/istnet_pw.h
     "istnet_pw_tile_cfg": [_i, _i, _i],
-    "istnet_pw_wgrad_tile_cfg": [_i, _i],
+    "istnet_pw_wgrad_tile_cfg": [_i, _i, _i, _i],
+    "istnet_pw_set_tuning": [_i, _i],
     "istnet_pw_stat_tiles": [_i, _i, _i],
     "istnet_pw_forward": [_i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p],
     "istnet_pw_forward_gather": [_i, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p],

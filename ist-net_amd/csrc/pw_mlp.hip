@@ -1192,16 +1192,20 @@ inline int cfg_nt(TileCfg c) { return c == kCfg32x256 ? 256 : (c == kCfg64x64 ? 
 inline int cfg_mt(TileCfg c) { return c == kCfg128x128 ? 128 : (c == kCfg32x256 ? 32 : 64); }
 
 inline bool wgrad_small(int cin, int cout) { return cin <= 32 && cout <= 32; }
-inline int wgrad_mt(int cout) { return cout >= 128 ? 128 : 64; }
-inline int wgrad_nt(int cin) { return cin >= 96 ? 128 : 64; }
+// tuning knobs (istnet_pw_set_tuning): experiments only, defaults are the measured best
+int g_wg_small_pts = 0x7fffffff;  // layers with b*P <= this use 64x64 wgrad tiles: measured best for every encoder layer (smaller split-K partials)
+int g_wg_target_big = 768;   // target workgroup count, outputs >= 128x128
+int g_wg_target_small = 1024;
+inline int wgrad_mt(int cout, long long pts) { return (cout >= 128 && pts > g_wg_small_pts) ? 128 : 64; }
+inline int wgrad_nt(int cin, long long pts) { return (cin >= 96 && pts > g_wg_small_pts) ? 128 : 64; }
 inline int wgrad_split_len(int b, int cin, int cout, int P) {
   // Split-K partials cost cout*cin*4 bytes per split (written here, read back by the reduce): aim for ~1024
   // workgroups when the output is small, ~768 when it is large (PMC: at 1024 the partials of a 128x256
   // layer were as much HBM traffic as its activations; at 256-512 the launch no longer fills the chip).
   const long long tiles = wgrad_small(cin, cout)
-                              ? 1 : (long long)ceil_div(cout, wgrad_mt(cout)) * ceil_div(cin, wgrad_nt(cin));
+                              ? 1 : (long long)ceil_div(cout, wgrad_mt(cout, (long long)b * P)) * ceil_div(cin, wgrad_nt(cin, (long long)b * P));
   const long long out_elems = (long long)cout * cin;
-  const long long target = out_elems >= 128 * 128 ? 768 : 1024;  // measured: fewer workgroups lose more than the partials cost
+  const long long target = out_elems >= 128 * 128 ? g_wg_target_big : g_wg_target_small;  // measured: fewer workgroups lose more than the partials cost
   long long want = (target + tiles - 1) / tiles;  // splits over the flattened (cloud, point) range
   if (want < 1) want = 1;
   const long long total = (long long)b * P;
@@ -1230,8 +1234,18 @@ int istnet_pw_tile_cfg(int b, int m, int p) {
   return cfg_mt(c) * 1000 + cfg_nt(c);  // e.g. 128128, 64128, 64064, 32256
 }
 
-int istnet_pw_wgrad_tile_cfg(int cin, int cout) {
-  return wgrad_small(cin, cout) ? 32032 : wgrad_mt(cout) * 1000 + wgrad_nt(cin);
+int istnet_pw_wgrad_tile_cfg(int b, int cin, int cout, int p) {
+  const long long pts = (long long)b * p;
+  return wgrad_small(cin, cout) ? 32032 : wgrad_mt(cout, pts) * 1000 + wgrad_nt(cin, pts);
+}
+
+int istnet_pw_set_tuning(int key, int value) {
+  switch (key) {
+    case 0: g_wg_small_pts = value; return 0;
+    case 1: g_wg_target_big = value; return 0;
+    case 2: g_wg_target_small = value; return 0;
+    default: return ISTNET_PN2_EINVAL;
+  }
 }
 
 int istnet_pw_stat_tiles(int b, int cout, int p) {
@@ -1435,7 +1449,7 @@ static int launch_pw_wgrad(bool gather, int b, int cin, int cout, int p, int nsa
                          total, len, x, g, in_scale, in_shift, y, gs, bn, bwdc, dw_part);
     return (int)hipGetLastError();
   }
-  const int mt = wgrad_mt(cout), nt = wgrad_nt(cin);
+  const int mt = wgrad_mt(cout, total), nt = wgrad_nt(cin, total);
   const dim3 grid(wgrad_splits(b, cin, cout, p), ceil_div(cout, mt), ceil_div(cin, nt));
   const int mode = !gather ? 0 : ((g.featT != nullptr && g.cfeat > 0 && g.cfeat % 4 == 0) ? 2 : 1);
 #define ISTNET_WGRAD(MT, NT)                                                                                  \

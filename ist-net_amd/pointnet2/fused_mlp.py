@@ -229,7 +229,7 @@ def _backward_stack(lib, dev, st, b, c0, g, s, x, gather, training, ys, bns, par
         grad_elems = b * cout * (p if dd is not None else p // s)
         if fused_part is not None:
             part, nt_l = fused_part, fused_nt
-        elif ns_arg and not _AB_OLD:   # gradient through the max-pool: statistics from the (B, C, G) tensors only
+        elif ns_arg:   # gradient through the max-pool: statistics from the (B, C, G) tensors only
             part, nt_l = _empty((2, cout, b), torch.float32, dev), b
             _native.check(lib.istnet_pw_bwd_stats_pooled(b, cout, g, dp, pbs, _ymax_ptr(d_arg, b * cout * g),
                                                          bn.data_ptr(), part[0].data_ptr(), part[1].data_ptr(), st),
@@ -260,7 +260,7 @@ def _backward_stack(lib, dev, st, b, c0, g, s, x, gather, training, ys, bns, par
             splits = lib.istnet_pw_wgrad_splits(b, cin, cout, p)
             ws = _empty((splits, cout, cin), torch.float32, dev)
             dw = _empty((cout, cin), torch.float32, dev)
-            kname = _kname("pw_wgrad_kernel", lib.istnet_pw_wgrad_tile_cfg(cin, cout), use_gather)
+            kname = _kname("pw_wgrad_kernel", lib.istnet_pw_wgrad_tile_cfg(b, cin, cout, p), use_gather)
             flops = 2.0 * b * p * cin * cout
             if use_gather:
                 ga = gather

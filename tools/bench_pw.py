@@ -15,6 +15,9 @@ for lvl, (npoint, spec) in enumerate([(512, [3, 16, 16, 32]), (256, [67, 32, 32,
 for name, n, spec in [("FP3", 128, [768, 512, 512]), ("FP2", 256, [640, 256, 256]), ("FP1", 512, [320, 256, 256]), ("FP0", 1024, [256, 128, 128])]:
     LAYERS.append((name, n, 1, spec))
 st = torch.cuda.current_stream().cuda_stream
+for kv in os.environ.get("PW_TUNE", "").split(","):   # e.g. PW_TUNE=0:16384,1:512
+    if kv:
+        k, v = kv.split(":"); assert lib.istnet_pw_set_tuning(int(k), int(v)) == 0
 
 def timeit(fn, reps=20):
     for _ in range(3): fn()
