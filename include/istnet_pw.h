@@ -28,6 +28,7 @@ extern "C" {
 
 /* tile configuration the forward / dgrad launch picks for M output rows: M_T * 1000 + N_T (for reporting) */
 ISTNET_PN2_API int istnet_pw_tile_cfg(int b, int m, int p);
+ISTNET_PN2_API int istnet_pw_dgrad_tile_cfg(int b, int m, int p);
 ISTNET_PN2_API int istnet_pw_wgrad_tile_cfg(int b, int cin, int cout, int p);
 /* launch heuristics (experiments): key 0 = point count up to which wgrad uses 64x64 tiles, 1 / 2 = split-K
  * workgroup targets for large / small outputs.  Returns ISTNET_PN2_EINVAL for an unknown key. */

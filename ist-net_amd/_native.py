@@ -31,6 +31,7 @@ SIGNATURES = {
     # include/istnet_pw.h
     "istnet_pw_tile_cfg": [_i, _i, _i],
     "istnet_pw_wgrad_tile_cfg": [_i, _i, _i, _i],
+    "istnet_pw_dgrad_tile_cfg": [_i, _i, _i],
     "istnet_pw_set_tuning": [_i, _i],
     "istnet_pw_stat_tiles": [_i, _i, _i],
     "istnet_pw_forward": [_i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p],

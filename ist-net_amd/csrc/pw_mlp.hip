@@ -1181,12 +1181,21 @@ inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 
 // tile selection shared by the forward launch and istnet_pw_stat_tiles()
 enum TileCfg { kCfg128x128, kCfg64x128, kCfg64x64, kCfg32x256 };
-inline TileCfg pick_cfg(int b, int m, int P) {
+int g_force_fwd_cfg = -1, g_force_dgrad_cfg = -1;  // experiments (istnet_pw_set_tuning keys 3, 4): TileCfg or -1
+inline TileCfg pick_cfg(int b, int m, int P, int force = -1) {
+  if (force >= 0) return (TileCfg)force;
   if (m <= 32) return kCfg32x256;
   const long long n128 = (long long)b * ceil_div(P, 128);
   if (m > 64 && n128 * ceil_div(m, 128) >= 512) return kCfg128x128;
   if (n128 * ceil_div(m, 64) >= 512) return kCfg64x128;
   return kCfg64x64;
+}
+// dgrad: the dY loader dominates and 64x64 tiles measured fastest for every layer with more than 32 input
+// channels (profiles/r01_tile_sweep.txt); -2 = the forward rule (experiments)
+inline TileCfg pick_dgrad_cfg(int b, int m, int P, int force) {
+  if (force >= 0) return (TileCfg)force;
+  if (force == -2) return pick_cfg(b, m, P);
+  return m <= 32 ? kCfg32x256 : kCfg64x64;
 }
 inline int cfg_nt(TileCfg c) { return c == kCfg32x256 ? 256 : (c == kCfg64x64 ? 64 : 128); }
 inline int cfg_mt(TileCfg c) { return c == kCfg128x128 ? 128 : (c == kCfg32x256 ? 32 : 64); }
@@ -1234,6 +1243,11 @@ int istnet_pw_tile_cfg(int b, int m, int p) {
   return cfg_mt(c) * 1000 + cfg_nt(c);  // e.g. 128128, 64128, 64064, 32256
 }
 
+int istnet_pw_dgrad_tile_cfg(int b, int m, int p) {
+  const TileCfg c = pick_dgrad_cfg(b, m, p, g_force_dgrad_cfg);
+  return cfg_mt(c) * 1000 + cfg_nt(c);
+}
+
 int istnet_pw_wgrad_tile_cfg(int b, int cin, int cout, int p) {
   const long long pts = (long long)b * p;
   return wgrad_small(cin, cout) ? 32032 : wgrad_mt(cout, pts) * 1000 + wgrad_nt(cin, pts);
@@ -1244,19 +1258,21 @@ int istnet_pw_set_tuning(int key, int value) {
     case 0: g_wg_small_pts = value; return 0;
     case 1: g_wg_target_big = value; return 0;
     case 2: g_wg_target_small = value; return 0;
+    case 3: g_force_fwd_cfg = value; return 0;
+    case 4: g_force_dgrad_cfg = value; return 0;
     default: return ISTNET_PN2_EINVAL;
   }
 }
 
 int istnet_pw_stat_tiles(int b, int cout, int p) {
-  return b * ceil_div(p, cfg_nt(pick_cfg(b, cout, p)));
+  return b * ceil_div(p, cfg_nt(pick_cfg(b, cout, p, g_force_fwd_cfg)));
 }
 
 static int launch_pw_forward(bool gather, int b, int cin, int cout, int p, const float* x, const GatherSrc& g,
                              const float* w, const float* in_scale, const float* in_shift, float* y,
                              float* part_sum, float* part_sq, void* stream) {
   if (b <= 0 || cin <= 0 || cout <= 0 || p <= 0 || (p & 3)) return ISTNET_PN2_EINVAL;
-  const TileCfg cfg = pick_cfg(b, cout, p);
+  const TileCfg cfg = pick_cfg(b, cout, p, g_force_fwd_cfg);
   const int tpc = ceil_div(p, cfg_nt(cfg));
   const dim3 grid(tpc * b, ceil_div(cout, cfg_mt(cfg)));
   const int nt = tpc * b;
@@ -1388,7 +1404,7 @@ int istnet_pw_dgrad(int b, int cin_total, int ci_off, int m_rows, int cout, int 
   if (d_dense == nullptr && (d_pooled == nullptr || arg == nullptr || nsample <= 0 || (nsample & 3)))
     return ISTNET_PN2_EINVAL;
   GradSrc gs{d_dense, d_pooled, arg, nsample, pooled_bstride > 0 ? pooled_bstride : (long long)GS_C * (nsample > 0 ? p / nsample : 0), GS_C};
-  const TileCfg cfg = pick_cfg(b, m_rows, p);
+  const TileCfg cfg = pick_dgrad_cfg(b, m_rows, p, g_force_dgrad_cfg);
   const int tpc = ceil_div(p, cfg_nt(cfg));
   const dim3 grid(tpc * b, ceil_div(m_rows, cfg_mt(cfg)));
 #define ISTNET_DGRAD(MT, NT, WM, WN)                                                                       \
@@ -1422,7 +1438,7 @@ int istnet_pw_scatter_dy(int b, int cout, int n, int p, int nsample, const float
 }
 
 int istnet_pw_dgrad_stat_tiles(int b, int m_rows, int p) {
-  return b * ceil_div(p, cfg_nt(pick_cfg(b, m_rows, p)));
+  return b * ceil_div(p, cfg_nt(pick_dgrad_cfg(b, m_rows, p, g_force_dgrad_cfg)));
 }
 
 int istnet_pw_wgrad_splits(int b, int cin, int cout, int p) { return wgrad_splits(b, cin, cout, p); }

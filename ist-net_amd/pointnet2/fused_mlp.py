@@ -311,7 +311,7 @@ def _backward_stack(lib, dev, st, b, c0, g, s, x, gather, training, ys, bns, par
             else:
                 y_in = bn_in = pg = pgy = None
             _native.check(_native.timed(
-                _kname("pw_dgrad_kernel", lib.istnet_pw_tile_cfg(b, rows, p)), 2.0 * b * p * rows * cout,
+                _kname("pw_dgrad_kernel", lib.istnet_pw_dgrad_tile_cfg(b, rows, p)), 2.0 * b * p * rows * cout,
                 4.0 * (b * p * (rows + cout + (rows if li > 0 else 0)) + grad_elems), lambda: lib.istnet_pw_dgrad(
                     b, cin, ci_off, rows, cout, p, ns_arg, w2.data_ptr(), y.data_ptr(), dd, dp, pbs, da,
                     bn.data_ptr(), bwdc.data_ptr(), dprev.data_ptr(), y_in, bn_in, pg, pgy, st)), "pw_dgrad")
