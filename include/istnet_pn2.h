@@ -46,6 +46,10 @@ ISTNET_PN2_API const char *istnet_pn2_target(void);
  * Tie-break identical to the reference block tree with block = opt_n_threads(n). */
 ISTNET_PN2_API int istnet_pn2_furthest_point_sampling(int b, int n, int m, const float *dataset,
                                        float *temp, int *idxs, void *stream);
+/* the same sampling, additionally writing the coordinates of the picks, picked (b,m,3) -- what the reference
+ * composes as gather_operation(xyz^T, idxs)^T right after sampling (pointnet2_modules.py:49-58).  n <= 4096. */
+ISTNET_PN2_API int istnet_pn2_fps_gather(int b, int n, int m, const float *dataset, int *idxs,
+                                         float *picked, void *stream);
 
 /* replaces gather_points_kernel_wrapper (sampling.cpp:9-11): points (b,c,n), idx (b,npoints) -> out (b,c,npoints) */
 ISTNET_PN2_API int istnet_pn2_gather_points(int b, int c, int n, int npoints, const float *points,

@@ -18,6 +18,7 @@ _i, _f, _p, _d, _l = ctypes.c_int, ctypes.c_float, ctypes.c_void_p, ctypes.c_dou
 SIGNATURES = {
     "istnet_pn2_set_tuning": [_i, _i],
     "istnet_pn2_furthest_point_sampling": [_i, _i, _i, _p, _p, _p, _p],
+    "istnet_pn2_fps_gather": [_i, _i, _i, _p, _p, _p, _p],
     "istnet_pn2_gather_points": [_i, _i, _i, _i, _p, _p, _p, _p],
     "istnet_pn2_gather_points_grad": [_i, _i, _i, _i, _p, _p, _p, _p],
     "istnet_pn2_query_ball_point": [_i, _i, _i, _f, _i, _p, _p, _p, _p],

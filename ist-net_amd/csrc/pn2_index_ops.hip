@@ -98,12 +98,14 @@ __device__ __forceinline__ int tiekey_to_k(unsigned tk, int bs_log2, int nper) {
 template <int NW, int PPT>
 __global__ __launch_bounds__(NW * 64) void fps_regs_kernel(int n, int m, int bs_log2, int nper,
                                                            const float* __restrict__ dataset_all,
-                                                           int* __restrict__ idxs_all) {
+                                                           int* __restrict__ idxs_all,
+                                                           float* __restrict__ picked_all) {
   constexpr int THREADS = NW * 64;
   extern __shared__ __attribute__((aligned(16))) float fps_lds[];  // xyz AoS copy [3n] (+ exchange)
   const int cloud = blockIdx.x;
   const float* dataset = dataset_all + (size_t)cloud * n * 3;
   int* idxs = idxs_all + (size_t)cloud * m;
+  float* picked = picked_all ? picked_all + (size_t)cloud * m * 3 : nullptr;  // optional: coordinates of the picks
   const int tid = threadIdx.x;
 
   for (int e = tid; e < 3 * n; e += THREADS) fps_lds[e] = dataset[e];
@@ -126,6 +128,7 @@ __global__ __launch_bounds__(NW * 64) void fps_regs_kernel(int n, int m, int bs_
 
   int old = 0;
   if (tid == 0) idxs[0] = 0;
+  if (picked != nullptr && tid < 3) picked[tid] = fps_lds[tid];
   for (int j = 1; j < m; ++j) {
     const float x1 = fps_lds[3 * old + 0];
     const float y1 = fps_lds[3 * old + 1];
@@ -170,6 +173,7 @@ __global__ __launch_bounds__(NW * 64) void fps_regs_kernel(int n, int m, int bs_
     }
     old = tiekey_to_k(tkmin, bs_log2, nper);
     if (tid == 0) idxs[j] = old;
+    if (picked != nullptr && tid < 3) picked[3 * j + tid] = fps_lds[3 * old + tid];
   }
 }
 
@@ -647,12 +651,12 @@ int launch_interp_grad(int b, int c, int n, int m, const float* grad_out, const 
 
 template <int NW>
 int launch_fps_regs(int b, int n, int m, int bs_log2, int nper, const float* dataset, int* idxs,
-                    hipStream_t st) {
+                    float* picked, hipStream_t st) {
   const int ppt = ceil_div(nper << bs_log2, NW * 64);  // tiekey slots per thread (holes included)
   const size_t lds = (size_t)3 * n * 4 + (NW > 1 ? 2 * NW * 2 * 4 : 0);
 #define ISTNET_FPS_CASE(P)                                                                      \
   hipLaunchKernelGGL((fps_regs_kernel<NW, P>), dim3(b), dim3(NW * 64), lds, st, n, m, bs_log2,  \
-                     nper, dataset, idxs)
+                     nper, dataset, idxs, picked)
   if (ppt <= 1) ISTNET_FPS_CASE(1);
   else if (ppt <= 2) ISTNET_FPS_CASE(2);
   else if (ppt <= 4) ISTNET_FPS_CASE(4);
@@ -673,8 +677,8 @@ int istnet_pn2_set_tuning(int key, int value) {
 }
 const char* istnet_pn2_target(void) { return "gfx950"; }
 
-int istnet_pn2_furthest_point_sampling(int b, int n, int m, const float* dataset, float* temp,
-                                       int* idxs, void* stream) {
+static int fps_impl(int b, int n, int m, const float* dataset, float* temp, int* idxs, float* picked,
+                    void* stream) {
   if (b < 0 || n <= 0 || m < 0) return ISTNET_PN2_EINVAL;
   if (b == 0 || m == 0) return 0;
   // reference block size: opt_n_threads(n) = clamp(2^floor(log2 n), 1, 512)  (cuda_utils.h:18-22)
@@ -685,12 +689,22 @@ int istnet_pn2_furthest_point_sampling(int b, int n, int m, const float* dataset
   hipStream_t st = as_stream(stream);
   // one wave per cloud is barrier-free and measured faster than four waves (LDS exchange + barrier per
   // round) for every n <= 1024 (profiles/r01_index_microbench.txt)
-  if (slots < g_fps_multiwave_min) return launch_fps_regs<1>(b, n, m, bs_log2, nper, dataset, idxs, st);
-  if (slots <= 256 * 16) return launch_fps_regs<4>(b, n, m, bs_log2, nper, dataset, idxs, st);
-  if (temp == nullptr) return ISTNET_PN2_EINVAL;  // large clouds need the scratch buffer
+  if (slots < g_fps_multiwave_min) return launch_fps_regs<1>(b, n, m, bs_log2, nper, dataset, idxs, picked, st);
+  if (slots <= 256 * 16) return launch_fps_regs<4>(b, n, m, bs_log2, nper, dataset, idxs, picked, st);
+  if (temp == nullptr || picked != nullptr) return ISTNET_PN2_EINVAL;  // large clouds: scratch buffer, no fused gather
   hipLaunchKernelGGL(fps_generic_kernel, dim3(b), dim3(1024), 0, st, n, m, bs_log2, nper, dataset,
                      temp, idxs);
   return (int)hipGetLastError();
+}
+
+int istnet_pn2_furthest_point_sampling(int b, int n, int m, const float* dataset, float* temp,
+                                       int* idxs, void* stream) {
+  return fps_impl(b, n, m, dataset, temp, idxs, nullptr, stream);
+}
+
+int istnet_pn2_fps_gather(int b, int n, int m, const float* dataset, int* idxs, float* picked, void* stream) {
+  if (picked == nullptr || n > 4096) return ISTNET_PN2_EINVAL;
+  return fps_impl(b, n, m, dataset, nullptr, idxs, picked, stream);
 }
 
 int istnet_pn2_gather_points(int b, int c, int n, int npoints, const float* points, const int* idx,

@@ -31,7 +31,7 @@ namespace {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int kThreads = 256;
-constexpr int kKT = 16;    // K chunk of the fwd / dgrad GEMMs (channels); 32 measured no better
+constexpr int kKT = 16;    // K chunk of the fwd / dgrad GEMMs (channels); 32 measured slower (profiles/r01_tile_sweep.txt era, re-checked with 64x64 tiles)
 constexpr int kKTW = 32;   // K chunk of the wgrad GEMM (points)
 
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }

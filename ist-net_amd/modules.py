@@ -11,6 +11,7 @@ import torch
 import torch.nn as nn
 
 from .pointnet2 import pointnet2_utils
+from .pointnet2.fused_mlp import defer_bn_counters
 from .pointnet2.pointnet2_modules import PointnetFPModule, PointnetSAModuleMSG
 
 # Geometry pre-pass: FPS, centroid gather, ball queries and three_nn of ALL levels depend on xyz only.
@@ -91,6 +92,10 @@ class PointNet2MSG(nn.Module):
 
     def forward(self, pointcloud):
         """(B, N, 3[+C]) -> (B, 128, N)."""
+        with defer_bn_counters():
+            return self._forward(pointcloud)
+
+    def _forward(self, pointcloud):
         xyz, features = self._break_up_pc(pointcloud)
         sa_geo = fp_geo = None
         if self._can_prepass(xyz):

@@ -92,6 +92,21 @@ def furthest_point_sampling(points, nsamples):
     return out
 
 
+def furthest_point_sampling_gather(points, nsamples):
+    """(B,N,3) f32 -> idx (B,nsamples) i32 and the picked coordinates (B,nsamples,3) in one launch
+    (extension: the reference gathers them with gather_points on the transposed cloud).  N <= 4096."""
+    _contig(points, "points"); _is_float(points, "points")
+    dev = _device_of(points, "points")
+    b, n = points.shape[0], points.shape[1]
+    nsamples = int(nsamples)
+    out = torch.empty((b, nsamples), dtype=torch.int32, device=dev)
+    picked = torch.empty((b, nsamples, 3), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        _native.check(_native.lib().istnet_pn2_fps_gather(b, n, nsamples, _ptr(points), _ptr(out), _ptr(picked),
+                                                          _stream(dev)), "fps_gather")
+    return out, picked
+
+
 def three_nn(unknowns, knows):
     """(B,n,3), (B,m,3) f32 -> [dist2 (B,n,3) f32, idx (B,n,3) i32].  interpolate.cpp:19-45"""
     _contig(unknowns, "unknowns"); _contig(knows, "knows")

@@ -612,6 +612,33 @@ def _fusable_shape(mlp, g, s):
     return len(mlp) > 0
 
 
+class defer_bn_counters:
+    """Context manager: the ``num_batches_tracked += 1`` of every fused stack run inside it is issued as ONE
+    ``_foreach_add_`` at exit instead of one small launch per stack (PointNet2MSG.forward uses it)."""
+    _pending = None
+
+    def __enter__(self):
+        self._outer = defer_bn_counters._pending
+        if self._outer is None:
+            defer_bn_counters._pending = []
+        return self
+
+    def __exit__(self, *exc):
+        if self._outer is None:
+            pending, defer_bn_counters._pending = defer_bn_counters._pending, None
+            if pending and exc[0] is None:
+                torch._foreach_add_(pending, 1)
+        return False
+
+
+def _bump_counters(units):
+    counters = [unit.normlayer.bn.num_batches_tracked for unit in units]
+    if defer_bn_counters._pending is not None:
+        defer_bn_counters._pending += counters
+    else:
+        torch._foreach_add_(counters, 1)
+
+
 def shared_mlp_maxpool(mlp, x):
     """``max_pool2d(mlp(x), [1, nsample]).squeeze(-1)`` for x (B, C, npoint, nsample) -> (B, C', npoint).
 
@@ -625,7 +652,7 @@ def shared_mlp_maxpool(mlp, x):
     training = mlp.training
     out = FusedSharedMLPFunction.apply(x, training, layers, *params)
     if training:
-        torch._foreach_add_([unit.normlayer.bn.num_batches_tracked for unit in mlp], 1)
+        _bump_counters(list(mlp))
     return out
 
 
@@ -660,7 +687,7 @@ def sa_scale(grouper, mlp, xyz, new_xyz, features, idx=None):
     layers, params = _layer_args(mlp)
     out = FusedSAScaleFunction.apply(features, xyz, new_xyz, idx, mlp.training, layers, *params)
     if mlp.training:
-        torch._foreach_add_([unit.normlayer.bn.num_batches_tracked for unit in mlp], 1)
+        _bump_counters(list(mlp))
     return out
 
 
@@ -693,5 +720,5 @@ def sa_level(groupers, mlps, xyz, new_xyz, features, ball_idx=None):
     training = mlps[0].training
     out = FusedSALevelFunction.apply(features, xyz, new_xyz, training, scales, *idxs, *params)
     if training:
-        torch._foreach_add_([unit.normlayer.bn.num_batches_tracked for mlp in mlps for unit in mlp], 1)
+        _bump_counters([unit for mlp in mlps for unit in mlp])
     return out

@@ -27,6 +27,9 @@ class _PointnetSAModuleBase(nn.Module):
         """(B,N,3) -> (B,npoint,3) by furthest point sampling, or None for GroupAll.  [ref :49-58]"""
         if self.npoint is None:
             return None
+        fused = getattr(pointnet2_utils._ext, "furthest_point_sampling_gather", None)
+        if fused is not None and xyz.is_cuda and not xyz.requires_grad and xyz.shape[1] <= 4096:
+            return fused(xyz.contiguous(), self.npoint)[1]   # sampling + coordinate gather in one kernel
         picked = pointnet2_utils.furthest_point_sample(xyz, self.npoint)
         channels_first = xyz.transpose(1, 2).contiguous()
         return pointnet2_utils.gather_operation(channels_first, picked).transpose(1, 2).contiguous()

@@ -65,14 +65,14 @@ def test_encoder_b2(monkeypatch):
             captured[f"{name}_{i}"] = res
             return res
         monkeypatch.setattr(_ext, name, fn)
-    for n in ("furthest_point_sampling", "ball_query", "three_nn"):
+    for n in ("furthest_point_sampling_gather", "ball_query", "three_nn"):   # the encoder samples + gathers in one op
         tap(n)
     torch.manual_seed(0)
     enc = PointNet2MSG([list(r) for r in CAM]).to(DEV).train()
     pts = torch.from_numpy(z["pts"]).to(DEV)
     out = enc(pts)
     for i in range(4):
-        assert np.array_equal(captured[f"furthest_point_sampling_{i}"].cpu().numpy(),
+        assert np.array_equal(captured[f"furthest_point_sampling_gather_{i}"][0].cpu().numpy(),
                               z[f"furthest_point_sampling_{i}"].astype(np.int32)), i
         d2, idx = captured[f"three_nn_{i}"]
         assert np.array_equal(idx.cpu().numpy(), z[f"three_nn_idx_{i}"].astype(np.int32)), i

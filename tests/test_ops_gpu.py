@@ -185,3 +185,14 @@ def test_runs_on_current_stream(ext, oracle):
         got = ext.furthest_point_sampling(xyz.to(DEV), 64)
     s.synchronize()
     assert torch.equal(got.cpu(), oracle.furthest_point_sampling(xyz, 64))
+
+
+@pytest.mark.parametrize("n,m,kind", [(1024, 512, "shell"), (300, 77, "dup"), (4096, 64, "cube"), (1000, 333, "grid")])
+def test_fps_gather_matches_fps_plus_gather(ext, oracle, n, m, kind):
+    """istnet_pn2_fps_gather = furthest_point_sampling + gather of the picked coordinates, bit-exact."""
+    xyz = _cloud(3, n, seed=n + m, kind=kind)
+    idx_ref = oracle.furthest_point_sampling(xyz, m)
+    idx, picked = ext.furthest_point_sampling_gather(xyz.to(DEV), m)
+    assert torch.equal(idx.cpu(), idx_ref)
+    expect = torch.gather(xyz, 1, idx_ref.long().unsqueeze(-1).expand(-1, -1, 3))
+    assert torch.equal(picked.cpu(), expect)
