@@ -187,6 +187,34 @@ def _forward_stack(lib, dev, st, b, c0, g, s, x, gather, training, layers, param
 _AB_OLD = os.environ.get("ISTNET_AB_OLD") is not None   # debug: previous code path of the change under test
 
 
+# The scales of an MSG level are independent chains of ~10 dependent launches each (GEMM, finalize, ...).
+# Run scale i >= 1 on its own stream: one chain's launch gaps and tiny kernels are filled by the other's GEMMs.
+# Fork/join discipline: the side stream waits on the main stream before it starts and the main stream joins it
+# before the level's result is used, so tensors may cross (allocated in one stream's pool, read by the other).
+USE_SCALE_STREAMS = os.environ.get("ISTNET_NO_SCALE_STREAMS") is None
+_SCALE_STREAMS = {}
+
+
+def _scale_streams(dev, n):
+    """[current stream, side stream 1, ...] for the n scales of a level (side streams only if enabled)."""
+    main = torch.cuda.current_stream(dev)
+    if not USE_SCALE_STREAMS or _native.TIMING is not None or n < 2:
+        return [main] * n
+    key = dev.index if dev.index is not None else torch.cuda.current_device()
+    pool = _SCALE_STREAMS.setdefault(key, [])
+    while len(pool) < n - 1:
+        pool.append(torch.cuda.Stream(device=dev))
+    for side in pool[:n - 1]:
+        side.wait_stream(main)      # fork before anything of this level is enqueued on the main stream
+    return [main] + pool[:n - 1]
+
+
+def _join_streams(streams):
+    for side in streams[1:]:
+        if side is not streams[0]:
+            streams[0].wait_stream(side)
+
+
 def _arg_bytes(n):
     return (n + 15) // 16 * 16
 
@@ -438,13 +466,16 @@ class FusedSALevelFunction(Function):
         # point-major copy of the features (one small transpose per level) for contiguous neighbour gathers
         feat_t = feat.transpose(1, 2).contiguous() if (feat is not None and feat.shape[1] % 16 == 0) else None
         with torch.cuda.device(dev):
-            for layers, params, idx in zip(scales, plist, idxs):
+            streams = _scale_streams(dev, len(scales))
+            for layers, params, idx, stream in zip(scales, plist, idxs, streams):
                 ga = _Gather(xyz, new_xyz, feat, idx, feat_t)
-                _, arg, ys, bns = _forward_stack(lib, dev, _st(dev), b, 3 + ga.cfeat, g, ga.nsample, None, ga, training,
-                                                 layers, params, out_spec=(out, coff))
+                with torch.cuda.stream(stream):
+                    _, arg, ys, bns = _forward_stack(lib, dev, _st(dev), b, 3 + ga.cfeat, g, ga.nsample, None, ga,
+                                                     training, layers, params, out_spec=(out, coff))
                 meta.append((len(layers), ga.nsample, coff, params[-3].shape[0]))
                 coff += params[-3].shape[0]
                 saved += [arg, *ys, *bns]
+            _join_streams(streams)
         ctx.training, ctx.meta, ctx.has_feat = training, meta, feat is not None
         ctx.dims = (b, g, ctot)
         ctx.has_feat_t = feat_t is not None
@@ -484,16 +515,18 @@ class FusedSALevelFunction(Function):
         base = 5 + nsc   # index of the first parameter among forward()'s arguments
         with torch.cuda.device(dev):
             st = _st(dev)
-            for (nl, s, coff, clast), (arg, ys, bns), idx in zip(meta, per_scale, idxs):
+            streams = _scale_streams(dev, nsc) if (use_level_gemm or not need_x) else [torch.cuda.current_stream(dev)] * nsc
+            for (nl, s, coff, clast), (arg, ys, bns), idx, stream in zip(meta, per_scale, idxs, streams):
                 params = params_all[ppos:ppos + 3 * nl]
                 need_w = [ctx.needs_input_grad[base + ppos + 3 * li] for li in range(nl)]
                 ppos += 3 * nl
                 ga = _Gather(xyz, new_xyz, feat if ctx.has_feat else None, idx, feat_t)
                 cout0 = params[0].shape[0]
-                grads, dxf, scattered = _backward_stack(
-                    lib, dev, st, b, 3 + cfeat, g, s, None, ga, ctx.training, ys, bns, params, arg,
-                    dout[:, coff:coff + clast], need_w, need_x, pooled_bstride=ctot * g,
-                    scatter_out=(gbuf, goff) if use_level_gemm else None)
+                with torch.cuda.stream(stream):
+                    grads, dxf, scattered = _backward_stack(
+                        lib, dev, _st(dev), b, 3 + cfeat, g, s, None, ga, ctx.training, ys, bns, params, arg,
+                        dout[:, coff:coff + clast], need_w, need_x, pooled_bstride=ctot * g,
+                        scatter_out=(gbuf, goff) if use_level_gemm else None)
                 grads_all += grads
                 if use_level_gemm:
                     w0f.append(params[0].reshape(cout0, 3 + cfeat))
@@ -501,6 +534,7 @@ class FusedSALevelFunction(Function):
                 elif need_x:
                     part = dxf if scattered else _ext.group_points_grad(dxf.view(b, cfeat, g, s), idx, n_src)
                     dfeat = part if dfeat is None else dfeat + part
+            _join_streams(streams)
             if use_level_gemm:
                 # dfeat[b] = [W0f_0^T | W0f_1^T ...] . [G_0; G_1; ...]: the dgrad kernel with identity "BN" constants
                 wcat = torch.cat(w0f, dim=0) if nsc > 1 else w0f[0]           # (sum Cout0, 3 + C)
