@@ -64,21 +64,50 @@ def _ident_consts(dev, c):
     return _CONSTS[key]
 
 
-# Weight gradients are off the critical path of backward (nothing consumes dW before the optimizer), so
-# the wgrad GEMM + split-K reduce of every layer CAN run on a second HIP stream, concurrently with the
-# dgrad chain on the caller's stream (the caller's stream waits for them before backward returns).
-# Measured on MI355X (B=32 encoder, eager and HIP-graph replay): 6.30 ms/step with the side stream vs
-# 6.11 ms without -- both GEMM families are HBM/L2 heavy and only evict each other -- so it is off by
-# default and kept as an opt-in experiment (ISTNET_WGRAD_SIDE_STREAM=1).
-_SIDE_STREAMS = {}
-USE_SIDE_STREAM = os.environ.get("ISTNET_WGRAD_SIDE_STREAM") == "1"
+# Weight gradients are off the critical path of backward (nothing downstream reads them before the optimizer),
+# while the dgrad chain is a sequence of dependent launches.  When the engine allows it, the wgrad GEMMs of a
+# stack are issued AFTER its dgrad chain on a dedicated stream (one cross-stream edge per stack) and joined once,
+# by an autograd-engine callback at the end of the backward pass: they overlap the dgrad chains of the following
+# levels.  Conditions: every parameter's .grad is None (AccumulateGrad then only stores the tensor; an existing
+# .grad would be read on the main stream before the join), no kernel timing in progress.  Everything the
+# deferred launches read is kept alive until the join.  (A per-layer fork onto a side stream was measured
+# slower: 32 extra cross-stream edges per step.)
+USE_DEFERRED_WGRAD = os.environ.get("ISTNET_NO_DEFER_WGRAD") is None
 
 
-def _side_stream(dev):
+class _Deferred:
+    streams = {}     # device index -> wgrad stream
+    mains = {}       # device index -> stream to join into (the stream the backward nodes run on)
+    keep = []        # tensors / closures referenced by launches in flight
+    armed = False
+
+    @classmethod
+    def stream(cls, dev):
+        key = dev.index if dev.index is not None else torch.cuda.current_device()
+        if key not in cls.streams:
+            cls.streams[key] = torch.cuda.Stream(device=dev)
+        return key, cls.streams[key]
+
+    @classmethod
+    def flush(cls):
+        for key, main in cls.mains.items():
+            main.wait_stream(cls.streams[key])
+        cls.mains.clear()
+        cls.keep.clear()
+        cls.armed = False
+
+
+def _enter_backward(dev):
+    """Called at the top of every fused node's backward (on the node's own stream): remembers the stream the
+    deferred weight gradients are joined into."""
     key = dev.index if dev.index is not None else torch.cuda.current_device()
-    if key not in _SIDE_STREAMS:
-        _SIDE_STREAMS[key] = torch.cuda.Stream(device=dev)
-    return _SIDE_STREAMS[key]
+    if key not in _Deferred.mains:
+        _Deferred.mains[key] = torch.cuda.current_stream(dev)
+
+
+def _can_defer(params):
+    return (USE_DEFERRED_WGRAD and _native.TIMING is None and torch.is_grad_enabled() is False
+            and all(getattr(p, "grad", None) is None for p in params))
 
 
 def _p(t):
@@ -224,6 +253,33 @@ def _ymax_ptr(arg, n):
     return None if arg is None else arg.data_ptr() + _arg_bytes(n)
 
 
+def _wgrad_job(lib, dev, b, cin, cout, p, ns_arg, use_gather, ga, src, in_bn, y, d_dense, d_pooled, pbs, d_arg, bn,
+               bwdc, grad_elems):
+    """Closure launching the split-K wgrad GEMM of one layer on a given stream; returns (elements, splits,
+    partials, dw) for the batched reduce.  It owns references to every tensor the launch reads."""
+    def launch(wst):
+        splits = lib.istnet_pw_wgrad_splits(b, cin, cout, p)
+        ws = _empty((splits, cout, cin), torch.float32, dev)
+        dw = _empty((cout, cin), torch.float32, dev)
+        kname = _kname("pw_wgrad_kernel", lib.istnet_pw_wgrad_tile_cfg(b, cin, cout, p), use_gather)
+        flops = 2.0 * b * p * cin * cout
+        dd, dp, da = _p(d_dense), _p(d_pooled), _p(d_arg)
+        if use_gather:
+            _native.check(_native.timed(
+                kname, flops, 4.0 * (b * p * (1 + cout) + grad_elems), lambda: lib.istnet_pw_wgrad_gather(
+                    b, ga.n, ga.npoint, ga.nsample, ga.cfeat, cout, ns_arg, ga.xyz.data_ptr(),
+                    ga.new_xyz.data_ptr(), _p(ga.feat), _p(ga.feat_t), ga.idx.data_ptr(), y.data_ptr(), dd, dp, pbs, da,
+                    bn.data_ptr(), bwdc.data_ptr(), ws.data_ptr(), wst)), "pw_wgrad_gather")
+        else:
+            sc, sh = (_p(in_bn[0]), _p(in_bn[1])) if in_bn is not None else (None, None)
+            _native.check(_native.timed(
+                kname, flops, 4.0 * (b * p * (cin + cout) + grad_elems), lambda: lib.istnet_pw_wgrad(
+                    b, cin, cout, p, ns_arg, src.data_ptr(), sc, sh, y.data_ptr(), dd, dp, pbs, da,
+                    bn.data_ptr(), bwdc.data_ptr(), ws.data_ptr(), wst)), "pw_wgrad")
+        return cout * cin, splits, ws, dw
+    return launch
+
+
 def _backward_stack(lib, dev, st, b, c0, g, s, x, gather, training, ys, bns, params, arg, dout, need_w, need_x,
                     pooled_bstride=0, scatter_out=None):
     """Returns (grads for [w, gamma, beta] * L, gradient w.r.t. the layer-0 input or None).
@@ -241,10 +297,7 @@ def _backward_stack(lib, dev, st, b, c0, g, s, x, gather, training, ys, bns, par
     dx, scattered = None, False
     ntb = lib.istnet_pw_bwd_stat_tiles(b, p)
     fused_part, fused_nt = None, 0   # statistics of layer li already reduced by the dgrad of layer li+1
-    main = torch.cuda.current_stream(dev)
-    side = _side_stream(dev) if (USE_SIDE_STREAM and _native.TIMING is None) else None
-    keep = []                        # tensors the side stream reads: kept alive until the final join
-    pending = []                     # split-K partials of all layers, reduced by ONE launch at the end
+    wjobs = []                       # weight-gradient launches of the stack: (launch(stream) -> (n, splits, ws, dw))
     for li in range(n - 1, -1, -1):
         w, gamma = params[3 * li], params[3 * li + 1]
         cout = w.shape[0]
@@ -278,40 +331,9 @@ def _backward_stack(lib, dev, st, b, c0, g, s, x, gather, training, ys, bns, par
         grads[3 * li + 2] = dbeta
         use_gather = li == 0 and gather is not None
         if need_w[li]:
-            wst = st
-            if side is not None:
-                ready = torch.cuda.Event()
-                ready.record(main)
-                side.wait_event(ready)
-                wst = side.cuda_stream
-                keep += [y, d_dense, d_pooled, d_arg, bn, bwdc]
-            splits = lib.istnet_pw_wgrad_splits(b, cin, cout, p)
-            ws = _empty((splits, cout, cin), torch.float32, dev)
-            dw = _empty((cout, cin), torch.float32, dev)
-            kname = _kname("pw_wgrad_kernel", lib.istnet_pw_wgrad_tile_cfg(b, cin, cout, p), use_gather)
-            flops = 2.0 * b * p * cin * cout
-            if use_gather:
-                ga = gather
-                _native.check(_native.timed(
-                    kname, flops, 4.0 * (b * p * (1 + cout) + grad_elems), lambda: lib.istnet_pw_wgrad_gather(
-                        b, ga.n, ga.npoint, ga.nsample, ga.cfeat, cout, ns_arg, ga.xyz.data_ptr(),
-                        ga.new_xyz.data_ptr(), _p(ga.feat), _p(ga.feat_t), ga.idx.data_ptr(), y.data_ptr(), dd, dp, pbs, da,
-                        bn.data_ptr(), bwdc.data_ptr(), ws.data_ptr(), wst)), "pw_wgrad_gather")
-            else:
-                src = x if li == 0 else ys[li - 1]
-                in_bn = None if li == 0 else bns[li - 1]
-                sc, sh = (_p(in_bn[0]), _p(in_bn[1])) if in_bn is not None else (None, None)
-                _native.check(_native.timed(
-                    kname, flops, 4.0 * (b * p * (cin + cout) + grad_elems), lambda: lib.istnet_pw_wgrad(
-                        b, cin, cout, p, ns_arg, src.data_ptr(), sc, sh, y.data_ptr(), dd, dp, pbs, da,
-                        bn.data_ptr(), bwdc.data_ptr(), ws.data_ptr(), wst)), "pw_wgrad")
-            if side is not None:
-                _native.check(lib.istnet_pw_wgrad_reduce(cout * cin, splits, ws.data_ptr(), dw.data_ptr(), wst),
-                              "pw_wgrad_reduce")
-            else:
-                pending.append((cout * cin, splits, ws.data_ptr(), dw.data_ptr()))   # reduced in one launch below
-            keep += [ws, dw]
-            grads[3 * li] = dw.view_as(w)
+            wjobs.append(_wgrad_job(lib, dev, b, cin, cout, p, ns_arg, use_gather, gather,
+                                    x if li == 0 else ys[li - 1], None if li == 0 else bns[li - 1], y,
+                                    d_dense, d_pooled, pbs, d_arg, bn, bwdc, grad_elems))
         if use_gather and need_x and gather.n <= 4096:
             # feature gradient of the scale: scatter dY0 over the ball indices (Cout0 x n per cloud), then
             # the small product W0[:, 3:]^T . G  (see pw_scatter_dy_kernel) -- no (B, C, P) tensor, no big dgrad
@@ -346,13 +368,28 @@ def _backward_stack(lib, dev, st, b, c0, g, s, x, gather, training, ys, bns, par
             d_dense, d_pooled, d_arg = dprev, None, None
             if li == 0:
                 dx = dprev
-    if pending:
-        _native.reduce_multi(pending, st)
-    if side is not None and keep:
-        done = torch.cuda.Event()
-        done.record(side)
-        main.wait_event(done)
-    del keep
+    if wjobs:
+        wparams = [params[3 * li] for li in range(n) if need_w[li]]
+        if _can_defer(wparams):
+            # after the chain, on the wgrad stream; joined by the end-of-backward callback
+            cur = torch.cuda.current_stream(dev)
+            key, wstream = _Deferred.stream(dev)
+            _Deferred.mains.setdefault(key, cur)
+            wstream.wait_stream(cur)
+            with torch.cuda.stream(wstream):
+                done = [job(wstream.cuda_stream) for job in wjobs]
+                _native.reduce_multi([(cnt, splits, ws.data_ptr(), dw.data_ptr()) for cnt, splits, ws, dw in done],
+                                     wstream.cuda_stream)
+            _Deferred.keep += [wjobs, done]
+            if not _Deferred.armed:
+                torch.autograd.Variable._execution_engine.queue_callback(_Deferred.flush)
+                _Deferred.armed = True
+        else:
+            done = [job(st) for job in wjobs]
+            _native.reduce_multi([(cnt, splits, ws.data_ptr(), dw.data_ptr()) for cnt, splits, ws, dw in done], st)
+        order = [li for li in range(n - 1, -1, -1) if need_w[li]]   # jobs were queued from the last layer down
+        for li, (_, _, _, dw) in zip(order, done):
+            grads[3 * li] = dw.view_as(params[3 * li])
     return grads, dx, scattered
 
 
@@ -382,6 +419,7 @@ class FusedSharedMLPFunction(Function):
         x, arg = saved[0], saved[1]
         ys, bns, params = saved[2:2 + n], saved[2 + n:2 + 2 * n], saved[2 + 2 * n:]
         dev = x.device
+        _enter_backward(dev)
         need_w = [ctx.needs_input_grad[3 + 3 * li] for li in range(n)]
         with torch.cuda.device(dev):
             grads, dx, _ = _backward_stack(lib, dev, _st(dev), b, c0, g, s, x, None, ctx.training, ys, bns, params,
@@ -425,6 +463,7 @@ class FusedSAScaleFunction(Function):
         feat, xyz, new_xyz, idx, arg = saved[:5]
         ys, bns, params = saved[5:5 + n], saved[5 + n:5 + 2 * n], saved[5 + 2 * n:]
         dev = xyz.device
+        _enter_backward(dev)
         ga = _Gather(xyz, new_xyz, feat if ctx.has_feat else None, idx)
         need_w = [ctx.needs_input_grad[6 + 3 * li] for li in range(n)]
         need_x = ctx.has_feat and ctx.needs_input_grad[0]
@@ -496,6 +535,7 @@ class FusedSALevelFunction(Function):
         feat_t = sv[3] if ctx.has_feat_t else None
         idxs = sv[4:4 + nsc]
         dev = xyz.device
+        _enter_backward(dev)
         dout = dout.contiguous()
         pos = 4 + nsc
         per_scale = []
@@ -583,6 +623,7 @@ class FusedBiasMLPFunction(Function):
         x = saved[0]
         ys, bns, flat = saved[1:1 + n], saved[1 + n:1 + 2 * n], saved[1 + 2 * n:]
         dev = x.device
+        _enter_backward(dev)
         need_w = [ctx.needs_input_grad[2 + 2 * li] for li in range(n)]
         with torch.cuda.device(dev):
             grads, dx, _ = _backward_stack(lib, dev, _st(dev), b, c0, npts, 1, x, None, False, ys, bns, flat,
