@@ -3,8 +3,8 @@
 Workload (BASELINE.json configs[1]): the IST-Net point encoder ``PointNet2MSG`` with the camera
 radii of model/ist_net.py:16 -- 4 MSG set-abstraction levels + 4 feature-propagation levels
  -- train-mode BatchNorm, loss = mean(out^2), on a synthetic "shell"
-cloud batch (seeded).  One step = zero_grad + forward + backward (+ RCCL grad all-reduce when
-N > 1) + fused Adam step.  Inputs are resident in HBM before the timed region.
+cloud batch (seeded).  One step = zero_grad + forward + backward (+ one RCCL all-reduce of the packed
+gradients when N > 1) + fused Adam step over the flat parameter buffer (istnet_amd.optim.FlatAdam).  Inputs are resident in HBM before the timed region.
 
     python bench.py [--gpus N] [--steps K] [--warmup W]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
@@ -64,7 +64,7 @@ def istnet_batch(b, n, seed, device, hw=192):
     return {k: v.to(device) for k, v in batch.items()}
 
 
-def make_istnet_step(model, batch, opt, world, grad_sync=None):
+def make_istnet_step(model, batch, opt, world, reducer=None):
     from istnet_amd.losses import SupervisedLoss
     crit = SupervisedLoss(1.0, 10.0)
     labels = {k: batch[k] for k in ("rotation_label", "translation_label", "size_label", "qo")}
@@ -75,27 +75,31 @@ def make_istnet_step(model, batch, opt, world, grad_sync=None):
         ep.update(labels)
         loss = crit(ep)
         loss.backward()
-        if world > 1:
-            grad_sync()
-        opt.step()
+        optimizer_step(opt, world, reducer)
         return loss
     return step
 
 
-def make_step(model, pts, opt, world, grad_sync=None):
+def optimizer_step(opt, world, reducer):
+    """FlatAdam: pack the gradients once, average the flat buffer over ranks (one RCCL all-reduce), update."""
+    if world > 1:
+        opt.step(reducer.average_(opt.pack_grads()))
+    else:
+        opt.step()
+
+
+def make_step(model, pts, opt, world, reducer=None):
     def step():
         opt.zero_grad(set_to_none=True)
         out = model(pts)
         loss = out.square().mean()
         loss.backward()
-        if world > 1:
-            grad_sync()
-        opt.step()
+        optimizer_step(opt, world, reducer)
         return loss
     return step
 
 
-def make_graphed_step(model, pts, opt, world, grad_sync=None):
+def make_graphed_step(model, pts, opt, world, reducer=None):
     """Capture forward+backward(+Adam when single-GPU) of the step in one HIP graph and return a
     function that replays it.  Every kernel of the step (the C-ABI launches included) goes to the
     capture stream, so a replay does exactly the work of the eager step with one host call.  With
@@ -112,23 +116,23 @@ def make_graphed_step(model, pts, opt, world, grad_sync=None):
         for _ in range(3):
             opt.zero_grad(set_to_none=True)
             fwd_bwd()
-            if world > 1:
-                grad_sync()
-            opt.step()
+            optimizer_step(opt, world, reducer)
     torch.cuda.current_stream().wait_stream(side)
     torch.cuda.synchronize()
     graph = torch.cuda.CUDAGraph()
     opt.zero_grad(set_to_none=True)
+    packed = None
     with torch.cuda.graph(graph):
         fwd_bwd()
         if world == 1:
             opt.step()
+        else:
+            packed = opt.pack_grads()      # static buffer of the graph: the all-reduce and Adam read it eagerly
 
     def step():
         graph.replay()
         if world > 1:
-            grad_sync()
-            opt.step()
+            opt.step(reducer.average_(packed))
     return step
 
 
@@ -193,6 +197,7 @@ def main():
     dev = torch.device("cuda", local_rank)
 
     import torch.distributed as dist
+    from istnet_amd.optim import FlatAdam
     grad_sync = None
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -204,10 +209,10 @@ def main():
     if args.workload == "istnet":
         model = make_istnet(dev, seed=0)
         batch = istnet_batch(BATCH, NPOINTS, seed=rank, device=dev)
-        opt = torch.optim.Adam(model.parameters(), lr=1e-4, fused=True, capturable=True)
+        opt = FlatAdam(model.parameters(), lr=1e-4)
         if world > 1:
             from istnet_amd.parallel import GradAllReducer
-            grad_sync = GradAllReducer(model, world).sync
+            grad_sync = GradAllReducer(model, world)
         eager_step = make_istnet_step(model, batch, opt, world, grad_sync)
         args.eager = True          # dropout + MIOpen find-mode: keep the full model eager
         args.no_cpu_baseline = True
@@ -215,10 +220,10 @@ def main():
     else:
         model = make_model(dev, seed=0)  # identical weights on every rank (same seed)
         pts = shell_cloud(BATCH, NPOINTS, seed=rank, device=dev)
-        opt = torch.optim.Adam(model.parameters(), lr=1e-4, fused=True, capturable=True)
+        opt = FlatAdam(model.parameters(), lr=1e-4)
         if world > 1:
             from istnet_amd.parallel import GradAllReducer
-            grad_sync = GradAllReducer(model, world).sync
+            grad_sync = GradAllReducer(model, world)
         eager_step = make_step(model, pts, opt, world, grad_sync)
     step, mode = eager_step, "eager"
     if not args.eager:

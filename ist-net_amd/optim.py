@@ -1,0 +1,78 @@
+"""Adam over one flat parameter buffer.
+
+The reference trains with ``torch.optim.Adam(model.parameters(), lr)`` (train.py:101-107 through
+solver.py).  The encoder has 96 small parameter tensors (the full model 400+): a multi-tensor optimizer
+spends its time walking tensor lists, and the data-parallel exchange has to pack and unpack them.  Here all
+parameters are re-pointed into ONE contiguous fp32 buffer at construction, the gradients are packed by one
+``torch.cat`` (or arrive already packed and averaged from ``parallel.GradAllReducer``), and the update is one
+launch of PyTorch's own fused Adam kernel on that single tensor -- element for element the arithmetic of
+``torch.optim.Adam(fused=True)`` (same kernel, same hyper-parameters), just without the tensor-list walk.
+State lives on the device, so a step can be captured in a HIP graph.
+"""
+import torch
+
+
+class FlatAdam:
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
+        self.params = [p for p in params if p.requires_grad]
+        if not self.params:
+            raise ValueError("FlatAdam: no trainable parameters")
+        dev, dt = self.params[0].device, self.params[0].dtype
+        if any(p.device != dev or p.dtype != dt for p in self.params):
+            raise ValueError("FlatAdam: all parameters must share one device and dtype")
+        self.flat = torch.cat([p.detach().reshape(-1) for p in self.params])
+        self.offsets, off = [], 0
+        for p in self.params:                       # parameters become views of the flat buffer
+            n = p.numel()
+            p.data = self.flat[off:off + n].view_as(p)
+            self.offsets.append(off)
+            off += n
+        self.exp_avg = torch.zeros_like(self.flat)
+        self.exp_avg_sq = torch.zeros_like(self.flat)
+        self.step_count = torch.zeros((), dtype=torch.float32, device=dev)
+        self.lr, self.betas, self.eps, self.weight_decay = float(lr), tuple(betas), float(eps), float(weight_decay)
+
+    def zero_grad(self, set_to_none=True):
+        for p in self.params:
+            if set_to_none:
+                p.grad = None
+            elif p.grad is not None:
+                p.grad.zero_()
+
+    def pack_grads(self):
+        """One flat gradient tensor in parameter order (a parameter without gradient contributes zeros)."""
+        return torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in self.params])
+
+    def grad_views(self, flat_grad):
+        return [flat_grad[o:o + p.numel()].view_as(p) for o, p in zip(self.offsets, self.params)]
+
+    @torch.no_grad()
+    def step(self, flat_grad=None):
+        """``flat_grad``: gradients already packed in parameter order (e.g. by the all-reduce); default: pack
+        the parameters' ``.grad``."""
+        g = self.pack_grads() if flat_grad is None else flat_grad
+        self.step_count += 1
+        if self.flat.is_cuda:
+            torch._fused_adam_([self.flat], [g], [self.exp_avg], [self.exp_avg_sq], [], [self.step_count],
+                               amsgrad=False, lr=self.lr, beta1=self.betas[0], beta2=self.betas[1],
+                               weight_decay=self.weight_decay, eps=self.eps, maximize=False,
+                               grad_scale=None, found_inf=None)
+            return
+        # CPU (host-logic tests): the same update with plain ops
+        b1, b2 = self.betas
+        if self.weight_decay:
+            g = g + self.weight_decay * self.flat
+        self.exp_avg.mul_(b1).add_(g, alpha=1 - b1)
+        self.exp_avg_sq.mul_(b2).addcmul_(g, g, value=1 - b2)
+        t = float(self.step_count)
+        denom = (self.exp_avg_sq.sqrt() / (1 - b2 ** t) ** 0.5).add_(self.eps)
+        self.flat.addcdiv_(self.exp_avg, denom, value=-self.lr / (1 - b1 ** t))
+
+    def state_dict(self):
+        return {"flat": self.flat, "exp_avg": self.exp_avg, "exp_avg_sq": self.exp_avg_sq, "step": self.step_count,
+                "lr": self.lr, "betas": self.betas, "eps": self.eps, "weight_decay": self.weight_decay}
+
+    def load_state_dict(self, sd):
+        self.flat.copy_(sd["flat"]); self.exp_avg.copy_(sd["exp_avg"]); self.exp_avg_sq.copy_(sd["exp_avg_sq"])
+        self.step_count.copy_(sd["step"])
+        self.lr, self.betas, self.eps, self.weight_decay = sd["lr"], tuple(sd["betas"]), sd["eps"], sd["weight_decay"]

@@ -60,6 +60,15 @@ class GradAllReducer:
             torch._foreach_copy_(grads, views)
 
 
+    def average_(self, flat):
+        """In-place average across ranks of gradients that are already packed in ONE flat tensor
+        (``optim.FlatAdam.pack_grads``): a single large all-reduce, no pack / unpack here."""
+        if self.world == 1:
+            return flat
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
+        return flat.mul_(1.0 / self.world)
+
+
 def broadcast_parameters(model, src=0, group=None):
     """Make every replica start from rank ``src``'s parameters and buffers."""
     for t in list(model.parameters()) + list(model.buffers()):

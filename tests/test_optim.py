@@ -1,0 +1,55 @@
+"""FlatAdam against torch.optim.Adam on the same parameters and gradients (CPU; the GPU path is the same fused
+kernel torch.optim.Adam(fused=True) launches, checked in test_optim_gpu)."""
+import pytest
+import torch
+
+import istnet_amd  # noqa: F401
+from istnet_amd.optim import FlatAdam
+
+
+def _models():
+    torch.manual_seed(0)
+    a = torch.nn.Sequential(torch.nn.Linear(5, 7), torch.nn.ReLU(), torch.nn.Linear(7, 3))
+    b = torch.nn.Sequential(torch.nn.Linear(5, 7), torch.nn.ReLU(), torch.nn.Linear(7, 3))
+    b.load_state_dict(a.state_dict())
+    return a, b
+
+
+def _run(dev, steps=5, wd=0.0):
+    a, b = _models()
+    a, b = a.to(dev), b.to(dev)
+    ref = torch.optim.Adam(a.parameters(), lr=1e-2, weight_decay=wd)
+    opt = FlatAdam(b.parameters(), lr=1e-2, weight_decay=wd)
+    g = torch.Generator().manual_seed(1)
+    for _ in range(steps):
+        x = torch.randn(4, 5, generator=g).to(dev)
+        for m, o in ((a, ref), (b, opt)):
+            o.zero_grad(set_to_none=True)
+            m(x).square().mean().backward()
+            o.step()
+    for p, q in zip(a.parameters(), b.parameters()):
+        torch.testing.assert_close(q, p, rtol=1e-5, atol=1e-7)
+
+
+def test_flat_adam_matches_torch_adam_cpu():
+    _run("cpu")
+    _run("cpu", wd=0.01)
+
+
+def test_flat_adam_parameters_are_views_and_packed_grads():
+    _, b = _models()
+    opt = FlatAdam(b.parameters(), lr=1e-2)
+    assert all(p.data_ptr() == opt.flat.data_ptr() + 4 * o for p, o in zip(opt.params, opt.offsets))
+    b(torch.ones(2, 5)).sum().backward()
+    flat = opt.pack_grads()
+    for v, p in zip(opt.grad_views(flat), opt.params):
+        assert torch.equal(v, p.grad)
+    before = opt.flat.clone()
+    opt.step(flat)                      # pre-packed gradients
+    assert not torch.equal(before, opt.flat)
+
+
+@pytest.mark.gpu
+def test_flat_adam_matches_torch_adam_gpu():
+    _run("cuda:0")
+    _run("cuda:0", wd=0.01)
