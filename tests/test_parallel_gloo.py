@@ -64,3 +64,61 @@ def test_grad_allreduce_world2(bucket_bytes):
     out = mgr.dict()
     mp.spawn(_worker, args=(world, _free_port(), bucket_bytes, out), nprocs=world, join=True)
     assert dict(out) == {0: True, 1: True}
+
+
+def _flat_worker(rank, world, port, out):
+    """bench.py's N>1 optimizer path: FlatAdam.pack_grads -> GradAllReducer.average_ -> FlatAdam.step(flat)."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.set_num_threads(1)
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import istnet_amd  # noqa: F401
+    from istnet_amd.optim import FlatAdam
+    from istnet_amd.parallel import GradAllReducer
+    from istnet_amd.pointnet2 import pointnet2_utils
+    from oracle import pn2_oracle
+    pointnet2_utils._ext = pn2_oracle     # CPU test harness only
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    model = _make(seed=0)
+    opt = FlatAdam(model.parameters(), lr=1e-2)
+    reducer = GradAllReducer(model, world)
+    for _ in range(2):
+        opt.zero_grad(set_to_none=True)
+        _local_grads_keep(model, rank)
+        opt.step(reducer.average_(opt.pack_grads()))
+    # single-process replay with the averaged gradients of both ranks
+    ref = _make(seed=0)
+    ropt = torch.optim.Adam(ref.parameters(), lr=1e-2)
+    for _ in range(2):
+        per_rank = []
+        for r in range(world):
+            ref.zero_grad(set_to_none=True)
+            _local_grads_keep(ref, r)
+            per_rank.append([p.grad.clone() for p in ref.parameters()])
+        for p, gs in zip(ref.parameters(), zip(*per_rank)):
+            p.grad = sum(gs) / world
+        ropt.step()
+    ok = all(torch.allclose(p, q, rtol=1e-4, atol=1e-6) for p, q in zip(model.parameters(), ref.parameters()))
+    flat = torch.cat([p.detach().reshape(-1) for p in model.parameters()])
+    gathered = [torch.empty_like(flat) for _ in range(world)]
+    dist.all_gather(gathered, flat)
+    out[rank] = bool(ok and torch.equal(gathered[0], gathered[1]))   # replicas stay bit-identical
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _local_grads_keep(model, rank):
+    g = torch.Generator().manual_seed(100 + rank)
+    xyz = torch.rand(2, 128, 3, generator=g)
+    feat = torch.randn(2, 4, 128, generator=g)
+    nx, nf = model[0](xyz, feat)
+    model[1](xyz, nx, feat, nf).square().mean().backward()
+
+
+def test_flat_adam_allreduce_world2():
+    world = 2
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_flat_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    assert dict(out) == {0: True, 1: True}
