@@ -38,6 +38,10 @@ ISTNET_PN2_API int istnet_pn2_abi_version(void);
 /* Tuning knobs (process-wide, for benchmarking only): key 0 = minimum FPS slot count that uses the
  * 4-wave kernel (default 1025). */
 ISTNET_PN2_API int istnet_pn2_set_tuning(int key, int value);
+/* Debug aid: enqueue a one-thread kernel that stores the GPU's 100 MHz wall clock into *slot (device memory)
+ * when `stream` reaches this point -- used to draw the timeline of a captured step (tools/step_timeline.py). */
+ISTNET_PN2_API int istnet_debug_marker(unsigned long long *slot, void *stream);
+
 /* Name of the code object's target, "gfx950". */
 ISTNET_PN2_API const char *istnet_pn2_target(void);
 

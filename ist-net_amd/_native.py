@@ -18,6 +18,7 @@ _i, _f, _p, _d, _l = ctypes.c_int, ctypes.c_float, ctypes.c_void_p, ctypes.c_dou
 SIGNATURES = {
     "istnet_pn2_set_tuning": [_i, _i],
     "istnet_pn2_furthest_point_sampling": [_i, _i, _i, _p, _p, _p, _p],
+    "istnet_debug_marker": [_p, _p],
     "istnet_pn2_fps_gather": [_i, _i, _i, _p, _p, _p, _p],
     "istnet_pn2_gather_points": [_i, _i, _i, _i, _p, _p, _p, _p],
     "istnet_pn2_gather_points_grad": [_i, _i, _i, _i, _p, _p, _p, _p],
@@ -109,6 +110,22 @@ def timed(name, flops, nbytes, launch):
     end.record()
     TIMING.append((name, flops, nbytes, start, end))
     return status
+
+
+MARKERS = None   # debug: {"buf": int64 cuda tensor, "names": [...]} set by tools/step_timeline.py
+
+
+def mark(name):
+    """Debug: record when the CURRENT stream reaches this point (no-op unless MARKERS is set)."""
+    if MARKERS is None:
+        return
+    import torch
+    i = len(MARKERS["names"])
+    if i >= MARKERS["buf"].numel():
+        return
+    MARKERS["names"].append(name)
+    check(lib().istnet_debug_marker(MARKERS["buf"].data_ptr() + 8 * i, torch.cuda.current_stream().cuda_stream),
+          "debug_marker")
 
 
 def reduce_multi(items, stream):

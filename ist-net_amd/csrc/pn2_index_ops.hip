@@ -671,6 +671,14 @@ int launch_fps_regs(int b, int n, int m, int bs_log2, int nper, const float* dat
 extern "C" {
 
 int istnet_pn2_abi_version(void) { return ISTNET_PN2_ABI_VERSION; }
+
+// Debug aid (tools/step_timeline.py): one thread stores the 100 MHz wall clock when the stream reaches this point.
+__global__ void debug_marker_kernel(unsigned long long* slot) { *slot = wall_clock64(); }
+int istnet_debug_marker(unsigned long long* slot, void* stream) {
+  if (slot == nullptr) return ISTNET_PN2_EINVAL;
+  hipLaunchKernelGGL(debug_marker_kernel, dim3(1), dim3(1), 0, as_stream(stream), slot);
+  return (int)hipGetLastError();
+}
 int istnet_pn2_set_tuning(int key, int value) {
   if (key == 0) { g_fps_multiwave_min = value; return 0; }
   return ISTNET_PN2_EINVAL;

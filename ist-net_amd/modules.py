@@ -10,6 +10,7 @@ import os
 import torch
 import torch.nn as nn
 
+from . import _native
 from .pointnet2 import pointnet2_utils
 from .pointnet2.fused_mlp import defer_bn_counters
 from .pointnet2.pointnet2_modules import PointnetFPModule, PointnetSAModuleMSG
@@ -102,6 +103,7 @@ class PointNet2MSG(nn.Module):
             sa_geo, fp_geo = self._geometry_prepass(xyz)
             main = torch.cuda.current_stream(xyz.device)
         l_xyz, l_features = [xyz], [features]
+        _native.mark("fwd start")
         for i, sa in enumerate(self.SA_modules):
             if sa_geo is None:
                 nxt_xyz, nxt_feat = sa(l_xyz[-1], l_features[-1])
@@ -111,6 +113,7 @@ class PointNet2MSG(nn.Module):
                 nxt_xyz, nxt_feat = sa(l_xyz[-1], l_features[-1], geometry=(new_xyz, idx))
             l_xyz.append(nxt_xyz)
             l_features.append(nxt_feat)
+            _native.mark(f"fwd SA{i + 1} done")
         for lvl in range(len(self.FP_modules) - 1, -1, -1):  # coarse -> fine  [ref :322-325]
             interp = None
             if fp_geo is not None:
@@ -119,4 +122,5 @@ class PointNet2MSG(nn.Module):
                 interp = (idx, weight, csr)
             l_features[lvl] = self.FP_modules[lvl](l_xyz[lvl], l_xyz[lvl + 1], l_features[lvl],
                                                    l_features[lvl + 1], interp=interp)
+            _native.mark(f"fwd FP{lvl + 1} done")
         return l_features[0]

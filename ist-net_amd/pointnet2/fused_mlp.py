@@ -98,6 +98,8 @@ class _Deferred:
     def flush(cls):
         for (key, _), wstream in cls.streams.items():
             if key in cls.mains:
+                with torch.cuda.stream(wstream):
+                    _native.mark("wgrad stream drained")
                 cls.mains[key].wait_stream(wstream)
         cls.mains.clear()
         cls.keep.clear()
@@ -427,10 +429,12 @@ class FusedSharedMLPFunction(Function):
         ys, bns, params = saved[2:2 + n], saved[2 + n:2 + 2 * n], saved[2 + 2 * n:]
         dev = x.device
         _enter_backward(dev)
+        _native.mark(f"bwd MLP(g={g},s={s}) start")
         need_w = [ctx.needs_input_grad[3 + 3 * li] for li in range(n)]
         with torch.cuda.device(dev):
             grads, dx, _ = _backward_stack(lib, dev, _st(dev), b, c0, g, s, x, None, ctx.training, ys, bns, params,
                                            arg, dout.contiguous(), need_w, ctx.needs_input_grad[0])
+        _native.mark(f"bwd MLP(g={g},s={s}) chain done")
         return (dx.view(b, c0, g, s) if dx is not None else None, None, None, *grads)
 
 
@@ -543,6 +547,7 @@ class FusedSALevelFunction(Function):
         idxs = sv[4:4 + nsc]
         dev = xyz.device
         _enter_backward(dev)
+        _native.mark(f"bwd SA(g={g}) start")
         dout = dout.contiguous()
         pos = 4 + nsc
         per_scale = []
@@ -591,6 +596,7 @@ class FusedSALevelFunction(Function):
                     b, 3 + cfeat, 3, cfeat, cout0_tot, n_src, 0, wcat.data_ptr(), gbuf.data_ptr(), gbuf.data_ptr(),
                     None, 0, None, ident.data_ptr(), bwdc.data_ptr(), dfeat.data_ptr(), None, None, None, None, st),
                     "pw_dgrad(level)")
+            _native.mark(f"bwd SA(g={g}) chains done")
         return (dfeat, None, None, None, None, *([None] * nsc), *grads_all)
 
 
