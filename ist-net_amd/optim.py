@@ -27,6 +27,12 @@ class FlatAdam:
             p.data = self.flat[off:off + n].view_as(p)
             self.offsets.append(off)
             off += n
+        # Gradients are produced in place: the fused backward kernels write dW / dgamma / dbeta of a parameter
+        # straight into its slot of this buffer (fused_mlp._grad_dest), so step() and the data-parallel
+        # all-reduce use it as is -- no pack.  Parameters whose gradient arrives some other way are packed.
+        self.flat_grad = torch.zeros_like(self.flat)
+        for p, o in zip(self.params, self.offsets):
+            p._istnet_grad_slot = self.flat_grad[o:o + p.numel()]
         self.exp_avg = torch.zeros_like(self.flat)
         self.exp_avg_sq = torch.zeros_like(self.flat)
         self.step_count = torch.zeros((), dtype=torch.float32, device=dev)
@@ -39,8 +45,16 @@ class FlatAdam:
             elif p.grad is not None:
                 p.grad.zero_()
 
+    def grads_in_place(self):
+        """True when every parameter's .grad is its slot of ``flat_grad`` (written there by the backward kernels)."""
+        return all(p.grad is not None and p.grad.data_ptr() == p._istnet_grad_slot.data_ptr()
+                   and p.grad.is_contiguous() for p in self.params)
+
     def pack_grads(self):
-        """One flat gradient tensor in parameter order (a parameter without gradient contributes zeros)."""
+        """One flat gradient tensor in parameter order (a parameter without gradient contributes zeros):
+        ``flat_grad`` itself when the gradients were produced in place, else one ``torch.cat``."""
+        if self.grads_in_place():
+            return self.flat_grad
         return torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in self.params])
 
     def grad_views(self, flat_grad):

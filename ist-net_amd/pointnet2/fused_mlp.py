@@ -262,14 +262,27 @@ def _ymax_ptr(arg, n):
     return None if arg is None else arg.data_ptr() + _arg_bytes(n)
 
 
+def _grad_dest(param, shape, dev):
+    """Where the gradient of `param` is written: its slot of an optimizer's flat gradient buffer when one is
+    attached (optim.FlatAdam) and no gradient is accumulated yet, else a fresh tensor."""
+    slot = getattr(param, "_istnet_grad_slot", None)
+    if slot is not None and param.grad is None and slot.device == dev:
+        n = 1
+        for d in shape:
+            n *= d
+        if slot.numel() == n:
+            return slot.view(shape)
+    return _empty(shape, torch.float32, dev)
+
+
 def _wgrad_job(lib, dev, b, cin, cout, p, ns_arg, use_gather, ga, src, in_bn, y, d_dense, d_pooled, pbs, d_arg, bn,
-               bwdc, grad_elems):
+               bwdc, grad_elems, wparam):
     """Closure launching the split-K wgrad GEMM of one layer on a given stream; returns (elements, splits,
     partials, dw) for the batched reduce.  It owns references to every tensor the launch reads."""
     def launch(wst):
         splits = lib.istnet_pw_wgrad_splits(b, cin, cout, p)
         ws = _empty((splits, cout, cin), torch.float32, dev)
-        dw = _empty((cout, cin), torch.float32, dev)
+        dw = _grad_dest(wparam, (cout, cin), dev)
         kname = _kname("pw_wgrad_kernel", lib.istnet_pw_wgrad_tile_cfg(b, cin, cout, p), use_gather)
         flops = 2.0 * b * p * cin * cout
         dd, dp, da = _p(d_dense), _p(d_pooled), _p(d_arg)
@@ -329,8 +342,8 @@ def _backward_stack(lib, dev, st, b, c0, g, s, x, gather, training, ys, bns, par
             _native.check(lib.istnet_pw_bwd_stats(b, cout, p, ns_arg, y.data_ptr(), dd, dp, pbs, da, bn.data_ptr(),
                                                   part[0].data_ptr(), part[1].data_ptr(), st), "pw_bwd_stats")
         fused_part = None
-        dgamma = _empty(cout, torch.float32, dev)
-        dbeta = _empty(cout, torch.float32, dev)
+        dgamma = _grad_dest(gamma, (cout,), dev)
+        dbeta = _grad_dest(params[3 * li + 2], (cout,), dev)
         bwdc = _empty((3, cout), torch.float32, dev)
         _native.check(lib.istnet_bn_finalize_bwd(
             cout, nt_l, float(b * p), 1 if training else 0, part[0].data_ptr(), part[1].data_ptr(),  # training=False for bias stacks
@@ -342,7 +355,7 @@ def _backward_stack(lib, dev, st, b, c0, g, s, x, gather, training, ys, bns, par
         if need_w[li]:
             wjobs.append(_wgrad_job(lib, dev, b, cin, cout, p, ns_arg, use_gather, gather,
                                     x if li == 0 else ys[li - 1], None if li == 0 else bns[li - 1], y,
-                                    d_dense, d_pooled, pbs, d_arg, bn, bwdc, grad_elems))
+                                    d_dense, d_pooled, pbs, d_arg, bn, bwdc, grad_elems, w))
         if use_gather and need_x and gather.n <= 4096:
             # feature gradient of the scale: scatter dY0 over the ball indices (Cout0 x n per cloud), then
             # the small product W0[:, 3:]^T . G  (see pw_scatter_dy_kernel) -- no (B, C, P) tensor, no big dgrad

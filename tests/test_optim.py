@@ -53,3 +53,39 @@ def test_flat_adam_parameters_are_views_and_packed_grads():
 def test_flat_adam_matches_torch_adam_gpu():
     _run("cuda:0")
     _run("cuda:0", wd=0.01)
+
+
+@pytest.mark.gpu
+def test_fused_backward_writes_gradients_in_place():
+    """With FlatAdam attached, the fused SA / FP backward kernels write every dW, dgamma, dbeta straight into the
+    optimizer's flat gradient buffer (no pack), and the result equals the unattached run."""
+    from istnet_amd.pointnet2.pointnet2_modules import PointnetFPModule, PointnetSAModuleMSG
+
+    def make():
+        torch.manual_seed(0)
+        sa = PointnetSAModuleMSG(npoint=64, radii=[0.2, 0.4], nsamples=[16, 32], mlps=[[16, 32, 32], [16, 32, 64]])
+        fp = PointnetFPModule(mlp=[96 + 16, 64, 32])
+        return torch.nn.ModuleList([sa, fp]).cuda().train()
+
+    g = torch.Generator().manual_seed(3)
+    xyz = torch.rand(2, 256, 3, generator=g).cuda()
+    feat = torch.randn(2, 16, 256, generator=g).cuda()
+
+    def run(model):
+        nx, nf = model[0](xyz, feat)
+        model[1](xyz, nx, feat, nf).square().mean().backward()
+
+    ref = make()
+    run(ref)
+    model = make()
+    opt = FlatAdam(model.parameters(), lr=1e-3)
+    run(model)
+    torch.cuda.synchronize()
+    assert opt.grads_in_place()
+    assert opt.pack_grads().data_ptr() == opt.flat_grad.data_ptr()
+    for p, q in zip(model.parameters(), ref.parameters()):
+        torch.testing.assert_close(p.grad, q.grad, rtol=1e-5, atol=1e-7)
+    run(model)                          # second backward without zero_grad: accumulates, still the same storage
+    torch.cuda.synchronize()
+    for p, q in zip(model.parameters(), ref.parameters()):
+        torch.testing.assert_close(p.grad, 2 * q.grad, rtol=1e-4, atol=1e-6)
