@@ -70,6 +70,12 @@ ISTNET_PN2_API int istnet_bn_relu_pool(int b, int c, int g, int s, const float *
                                        float *out, long long out_bstride, unsigned char *arg, float *ymax,
                                        void *stream);
 
+/* bn[4][c] = scale, shift, mean, invstd of a FIXED affine normalisation: eval-mode BatchNorm
+ * (scale = gamma / sqrt(var + eps), shift = beta - mean * scale) or, with gamma = mean = var = NULL, a plain conv
+ * bias (scale 1, shift beta).  The forward / backward kernels then treat the layer like any other. */
+ISTNET_PN2_API int istnet_affine_consts(int c, const float *gamma, const float *beta, const float *mean,
+                                        const float *var, float eps, float *bn, void *stream);
+
 /* out = y * bn[0] + bn[1] (per channel), followed by ReLU when relu != 0 -- final layer of a bias stack */
 ISTNET_PN2_API int istnet_affine_apply(int b, int c, int p, int relu, const float *y, const float *bn,
                                        float *out, void *stream);

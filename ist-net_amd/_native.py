@@ -42,6 +42,7 @@ SIGNATURES = {
     "istnet_bn_finalize_fwd": [_i, _i, _d, _p, _p, _p, _p, _f, _f, _p, _p, _p, _p],
     "istnet_bn_relu_pool": [_i, _i, _i, _i, _p, _p, _p, _l, _p, _p, _p],
     "istnet_pw_bwd_stats_pooled": [_i, _i, _i, _p, _l, _p, _p, _p, _p, _p],
+    "istnet_affine_consts": [_i, _p, _p, _p, _p, _f, _p, _p],
     "istnet_affine_apply": [_i, _i, _i, _i, _p, _p, _p, _p],
     "istnet_pw_bwd_stat_tiles": [_i, _i],
     "istnet_pw_bwd_stats": [_i, _i, _i, _i, _p, _p, _p, _l, _p, _p, _p, _p, _p],

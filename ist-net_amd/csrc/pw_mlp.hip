@@ -440,6 +440,24 @@ __global__ __launch_bounds__(256) void bn_relu_apply_kernel(int C, int P4, const
   reinterpret_cast<float4*>(out + (size_t)bc * P4 * 4)[i] = v;
 }
 
+// bn[4][C] of a layer whose normalisation is a fixed affine map: eval-mode BatchNorm (running statistics) or a
+// plain conv bias (gamma / mean / var absent).  One launch instead of the 4-9 tiny tensor ops it replaces.
+__global__ __launch_bounds__(256) void affine_consts_kernel(int C, const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta,
+                                                            const float* __restrict__ mean,
+                                                            const float* __restrict__ var, float eps,
+                                                            float* __restrict__ bn) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  const float istd = var != nullptr ? (float)(1.0 / sqrt((double)var[c] + (double)eps)) : 1.f;
+  const float m = mean != nullptr ? mean[c] : 0.f;
+  const float sc = (gamma != nullptr ? gamma[c] : 1.f) * istd;
+  bn[0 * C + c] = sc;
+  bn[1 * C + c] = beta[c] - m * sc;
+  bn[2 * C + c] = m;
+  bn[3 * C + c] = istd;
+}
+
 __global__ __launch_bounds__(256) void affine_apply_kernel(int C, int P4, int relu, const float* __restrict__ y,
                                                            const float* __restrict__ scale,
                                                            const float* __restrict__ shift,
@@ -1350,6 +1368,14 @@ int istnet_bn_relu_pool(int b, int c, int g, int s, const float* y, const float*
     default: return ISTNET_PN2_EINVAL;
   }
 #undef ISTNET_POOL
+  return (int)hipGetLastError();
+}
+
+int istnet_affine_consts(int c, const float* gamma, const float* beta, const float* mean, const float* var,
+                         float eps, float* bn, void* stream) {
+  if (c <= 0 || beta == nullptr || bn == nullptr) return ISTNET_PN2_EINVAL;
+  hipLaunchKernelGGL(affine_consts_kernel, dim3(ceil_div(c, 256)), dim3(256), 0, as_stream(stream), c, gamma, beta,
+                     mean, var, eps, bn);
   return (int)hipGetLastError();
 }
 

@@ -185,21 +185,17 @@ def _forward_stack(lib, dev, st, b, c0, g, s, x, gather, training, layers, param
             _native.check(_native.timed(kname, flops, nbytes, lambda: lib.istnet_pw_forward(
                 b, cin_l, cout, p, src.data_ptr(), w2.data_ptr(), sc, sh, y.data_ptr(), ps, pq, st)), "pw_forward")
         if lay.bias_only:                    # y + bias: scale 1, shift bias, mean 0, invstd 1
-            bn[0].fill_(1.0)
-            bn[1] = beta
-            bn[2].zero_()
-            bn[3].fill_(1.0)
+            _native.check(lib.istnet_affine_consts(cout, None, beta.data_ptr(), None, None, 0.0, bn.data_ptr(), st),
+                          "affine_consts")
         elif training:
             _native.check(lib.istnet_bn_finalize_fwd(
                 cout, nt, float(b * p), ps, pq, gamma.data_ptr(), beta.data_ptr(), float(lay.eps),
                 float(lay.momentum), _p(lay.running_mean), _p(lay.running_var), bn.data_ptr(), st),
                 "bn_finalize_fwd")
-        else:
-            istd = torch.rsqrt(lay.running_var + lay.eps)
-            bn[0] = gamma * istd
-            bn[1] = beta - lay.running_mean * bn[0]
-            bn[2] = lay.running_mean
-            bn[3] = istd
+        else:                                # eval-mode BatchNorm: fixed affine map from the running statistics
+            _native.check(lib.istnet_affine_consts(cout, gamma.data_ptr(), beta.data_ptr(),
+                                                   lay.running_mean.data_ptr(), lay.running_var.data_ptr(),
+                                                   float(lay.eps), bn.data_ptr(), st), "affine_consts")
         ys.append(y)
         bns.append(bn)
         cur, cur_c, in_bn = y, cout, bn
@@ -613,6 +609,16 @@ class FusedSALevelFunction(Function):
         return (dfeat, None, None, None, None, *([None] * nsc), *grads_all)
 
 
+_ONES = {}
+
+
+def _ones(dev, c):
+    key = (dev.index, c)
+    if key not in _ONES:
+        _ONES[key] = torch.ones(c, dtype=torch.float32, device=dev)
+    return _ONES[key]
+
+
 class FusedBiasMLPFunction(Function):
     """x (B, C0, N) -> (B, C_L, N): stack of Conv1d(k=1) + bias (+ ReLU) layers -- the per-point MLPs of the
     IST head and the pose heads (reference model/ist_net.py:130-160, 206-248, 271-316).
@@ -629,7 +635,7 @@ class FusedBiasMLPFunction(Function):
         x = x.contiguous()
         n = len(params) // 2
         layers = [_Layer(None, relu=(relu_last or li < n - 1)) for li in range(n)]
-        ones = [torch.ones(params[2 * li].shape[0], dtype=torch.float32, device=dev) for li in range(n)]
+        ones = [_ones(dev, params[2 * li].shape[0]) for li in range(n)]   # stand-in "gamma" of a bias layer
         flat = []
         for li in range(n):
             flat += [params[2 * li], ones[li], params[2 * li + 1]]
