@@ -165,8 +165,13 @@ class IST_Net(nn.Module):
             return inputs["rgb_local"]
         feat = self.rgb_cam_extractor(inputs["rgb"])
         d = feat.size(1)
+        if not feat.is_contiguous() and feat.is_contiguous(memory_format=torch.channels_last):
+            # channels-last extractor (MIOpen's faster layout): pick whole d-vectors of the chosen pixels
+            rows = feat.permute(0, 2, 3, 1).reshape(b, -1, d)                       # view (B, H*W, d)
+            picked = torch.gather(rows, 1, inputs["choose"].unsqueeze(-1).expand(-1, -1, d))
+            return picked.transpose(1, 2).contiguous()
         choose = inputs["choose"].unsqueeze(1).repeat(1, d, 1)
-        return torch.gather(feat.view(b, d, -1), 2, choose).contiguous()   # :41-45
+        return torch.gather(feat.reshape(b, d, -1), 2, choose).contiguous()   # :41-45
 
     def forward(self, inputs):
         end_points = {}

@@ -153,3 +153,24 @@ def test_rgb_branch_and_loss_match_reference():
     torch.testing.assert_close(got, want)
     p1 = torch.tensor([[[0.0, 0.05, 0.3]]]); p2 = torch.zeros(1, 1, 3)
     torch.testing.assert_close(losses.SmoothL1Dis(p1, p2), torch.tensor(0.05 ** 2 / 0.2 + (0.3 - 0.05)))
+
+
+def test_rgb_local_gather_is_layout_agnostic():
+    """IST_Net._rgb_local picks the same per-point RGB features from an NCHW and a channels-last extractor."""
+    import torch
+    from istnet_amd.ist_net import IST_Net
+
+    class Ext(torch.nn.Module):
+        def __init__(self, cl):
+            super().__init__()
+            self.cl = cl
+
+        def forward(self, rgb):
+            f = torch.arange(2 * 128 * 6 * 5, dtype=torch.float32).reshape(2, 128, 6, 5)
+            return f.contiguous(memory_format=torch.channels_last) if self.cl else f
+
+    choose = torch.tensor([[0, 7, 29, 3], [29, 1, 1, 15]])
+    a = IST_Net(rgb_extractor=Ext(False))._rgb_local({"rgb": None, "choose": choose}, 2)
+    b = IST_Net(rgb_extractor=Ext(True))._rgb_local({"rgb": None, "choose": choose}, 2)
+    assert a.shape == (2, 128, 4) and torch.equal(a, b)
+    assert torch.equal(a[1, :, 3], torch.arange(2 * 128 * 30, dtype=torch.float32).reshape(2, 128, 30)[1, :, 15])
