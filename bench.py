@@ -67,17 +67,33 @@ def istnet_batch(b, n, seed, device, hw=192):
     return {k: v.to(device) for k, v in batch.items()}
 
 
-def make_istnet_step(model, batch, opt, world, reducer=None):
+def make_istnet_fwd_bwd(model, batch):
     from istnet_amd.losses import SupervisedLoss
     crit = SupervisedLoss(1.0, 10.0)
     labels = {k: batch[k] for k in ("rotation_label", "translation_label", "size_label", "qo")}
 
-    def step():
-        opt.zero_grad(set_to_none=True)
+    def fwd_bwd():
         ep = model(batch)
         ep.update(labels)
         loss = crit(ep)
         loss.backward()
+        return loss
+    return fwd_bwd
+
+
+def make_encoder_fwd_bwd(model, pts):
+    def fwd_bwd():
+        out = model(pts)
+        loss = out.square().mean()
+        loss.backward()
+        return loss
+    return fwd_bwd
+
+
+def make_eager_step(fwd_bwd, opt, world, reducer=None):
+    def step():
+        opt.zero_grad(set_to_none=True)
+        loss = fwd_bwd()
         optimizer_step(opt, world, reducer)
         return loss
     return step
@@ -92,26 +108,14 @@ def optimizer_step(opt, world, reducer):
 
 
 def make_step(model, pts, opt, world, reducer=None):
-    def step():
-        opt.zero_grad(set_to_none=True)
-        out = model(pts)
-        loss = out.square().mean()
-        loss.backward()
-        optimizer_step(opt, world, reducer)
-        return loss
-    return step
+    return make_eager_step(make_encoder_fwd_bwd(model, pts), opt, world, reducer)
 
 
-def make_graphed_step(model, pts, opt, world, reducer=None):
+def make_graphed_step(fwd_bwd, opt, world, reducer=None):
     """Capture forward+backward(+Adam when single-GPU) of the step in one HIP graph and return a
     function that replays it.  Every kernel of the step (the C-ABI launches included) goes to the
-    capture stream, so a replay does exactly the work of the eager step with one host call.  With
-    N > 1 the gradient all-reduce and the optimizer run eagerly after the replay."""
-    def fwd_bwd():
-        out = model(pts)
-        loss = out.square().mean()
-        loss.backward()
-        return loss
+    capture stream or a stream forked from it, so a replay does exactly the work of the eager step with one
+    host call.  With N > 1 the gradient all-reduce and the optimizer run eagerly after the replay."""
 
     side = torch.cuda.Stream()
     side.wait_stream(torch.cuda.current_stream())
@@ -216,10 +220,8 @@ def main():
         if world > 1:
             from istnet_amd.parallel import GradAllReducer
             grad_sync = GradAllReducer(model, world)
-        eager_step = make_istnet_step(model, batch, opt, world, grad_sync)
-        args.eager = True          # dropout + MIOpen find-mode: keep the full model eager
+        fwd_bwd = make_istnet_fwd_bwd(model, batch)
         args.no_cpu_baseline = True
-        pts = None
     else:
         model = make_model(dev, seed=0)  # identical weights on every rank (same seed)
         pts = shell_cloud(BATCH, NPOINTS, seed=rank, device=dev)
@@ -227,11 +229,12 @@ def main():
         if world > 1:
             from istnet_amd.parallel import GradAllReducer
             grad_sync = GradAllReducer(model, world)
-        eager_step = make_step(model, pts, opt, world, grad_sync)
+        fwd_bwd = make_encoder_fwd_bwd(model, pts)
+    eager_step = make_eager_step(fwd_bwd, opt, world, grad_sync)
     step, mode = eager_step, "eager"
     if not args.eager:
         try:
-            step, mode = make_graphed_step(model, pts, opt, world, grad_sync), "hipgraph"
+            step, mode = make_graphed_step(fwd_bwd, opt, world, grad_sync), "hipgraph"
         except Exception as exc:  # capture unsupported in this configuration: run the same step eagerly
             print(f"[bench] HIP graph capture failed ({type(exc).__name__}: {exc}); running eagerly", file=sys.stderr)
             torch.cuda.synchronize()

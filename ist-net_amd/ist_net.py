@@ -11,6 +11,8 @@ The RGB branch (ResNet-18 + PSPNet, model/modules.py:10-81) is outside the hot p
 (SURVEY.md 8f); ``IST_Net`` takes any module that maps rgb (B,3,H,W) -> (B,128,H,W), or
 pre-computed per-point RGB features through ``inputs['rgb_local']``.
 """
+import os
+
 import torch
 import torch.nn as nn
 
@@ -145,6 +147,17 @@ class WorldSpaceEnhancer(nn.Module):
         return r, t, s, pts_w_local_gt
 
 
+USE_RGB_STREAM = os.environ.get("ISTNET_NO_RGB_STREAM") is None
+_RGB_STREAMS = {}
+
+
+def _rgb_stream(dev):
+    key = dev.index if dev.index is not None else torch.cuda.current_device()
+    if key not in _RGB_STREAMS:
+        _RGB_STREAMS[key] = torch.cuda.Stream(device=dev)
+    return _RGB_STREAMS[key]
+
+
 class IST_Net(nn.Module):
     """IST-Net wiring.  [ref :10-76]  ``rgb_extractor`` maps (B,3,H,W) -> (B,128,H,W)."""
 
@@ -181,9 +194,23 @@ class IST_Net(nn.Module):
         pts = pts - c
         b = pts.size(0)
         index = cls + torch.arange(b, dtype=torch.long, device=pts.device) * self.nclass
-        rgb_local = self._rgb_local(inputs, b)
+        # The RGB branch (dense 2-D convolutions) and the point encoder are independent until the heads: run the
+        # RGB branch on its own stream so the encoder's many short kernels fill in around the convolutions
+        # (autograd replays each op's backward on the stream its forward ran on, so backward overlaps too).
+        side = None
+        if "rgb_local" not in inputs and pts.is_cuda and USE_RGB_STREAM:
+            main = torch.cuda.current_stream(pts.device)
+            side = _rgb_stream(pts.device)
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                rgb_local = self._rgb_local(inputs, b)
+        else:
+            rgb_local = self._rgb_local(inputs, b)
 
         pts_local = self.pts_cam_extractor(pts)
+        if side is not None:
+            main.wait_stream(side)
+            rgb_local.record_stream(main)
         if self.training:
             r_cam, t_cam, s_cam = self.cam_enhancer(pts, rgb_local, pts_local)
         pts_w, pts_w_local = self.implicit_transform(rgb_local, pts_local, pts, c, index)

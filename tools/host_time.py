@@ -5,7 +5,7 @@ import bench
 dev = torch.device("cuda:0")
 model = bench.make_model(dev); pts = bench.shell_cloud(32, 1024, 0, dev)
 opt = torch.optim.Adam(model.parameters(), lr=1e-4, fused=True)
-step = bench.make_step(model, pts, opt, 1)
+step = bench.make_step(model, pts, opt, 1)  # eager encoder step
 for _ in range(5): step()
 torch.cuda.synchronize()
 t0 = time.perf_counter()
