@@ -2,9 +2,17 @@
 
 Workload (BASELINE.json configs[1]): the IST-Net point encoder ``PointNet2MSG`` with the camera
 radii of model/ist_net.py:16 -- 4 MSG set-abstraction levels + 4 feature-propagation levels
- -- train-mode BatchNorm, loss = mean(out^2), on a synthetic "shell"
-cloud batch (seeded).  One step = zero_grad + forward + backward (+ one RCCL all-reduce of the packed
-gradients when N > 1) + fused Adam step over the flat parameter buffer (istnet_amd.optim.FlatAdam).  Inputs are resident in HBM before the timed region.
+ -- train-mode BatchNorm, loss = mean(out^2), on synthetic "shell"
+cloud batches (seeded).  One step = zero_grad + forward + backward (+ one RCCL all-reduce of the packed
+gradients when N > 1) + fused Adam step over the flat parameter buffer (istnet_amd.optim.FlatAdam).
+Inputs are resident in HBM before the timed region.
+
+Pipelining (default; ``--no-prefetch`` turns it off): two batches alternate, and while step t runs, the
+geometry stream computes the coordinate-only part (FPS, ball query, three_nn, interpolation weights) of
+batch t+1 -- next-batch preprocessing, which a data loader overlaps in the same way.  Every timed step still
+executes exactly one geometry pass, one forward, one backward and one optimizer update; only the first
+batch's geometry is computed before the timed region (pipeline prologue).  With ``--no-prefetch`` the same
+batch is used every step and its geometry is computed inside the step.
 
     python bench.py [--gpus N] [--steps K] [--warmup W]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
@@ -90,10 +98,28 @@ def make_encoder_fwd_bwd(model, pts):
     return fwd_bwd
 
 
-def make_eager_step(fwd_bwd, opt, world, reducer=None):
+def make_pipelined_fwd_bwd(model, batches, slots, i):
+    """Step on batch i while the geometry stream prepares batch 1-i (FPS / ball query / three_nn depend on the
+    coordinates only -- next-batch preprocessing, as a data loader would overlap it).  Every step still runs one
+    full geometry pass; it just runs one step ahead of its consumer."""
+    def fwd_bwd():
+        model.prefetch_geometry(batches[1 - i], slots[1 - i])
+        out = model(batches[i], geometry=slots[i])
+        loss = out.square().mean()
+        loss.backward()
+        model.join_geometry()
+        return loss
+    return fwd_bwd
+
+
+def make_eager_step(fwd_bwds, opt, world, reducer=None):
+    fwd_bwds = list(fwd_bwds) if isinstance(fwd_bwds, (list, tuple)) else [fwd_bwds]
+    count = [0]
+
     def step():
         opt.zero_grad(set_to_none=True)
-        loss = fwd_bwd()
+        loss = fwd_bwds[count[0] % len(fwd_bwds)]()
+        count[0] += 1
         optimizer_step(opt, world, reducer)
         return loss
     return step
@@ -111,35 +137,41 @@ def make_step(model, pts, opt, world, reducer=None):
     return make_eager_step(make_encoder_fwd_bwd(model, pts), opt, world, reducer)
 
 
-def make_graphed_step(fwd_bwd, opt, world, reducer=None):
+def make_graphed_step(fwd_bwds, opt, world, reducer=None):
     """Capture forward+backward(+Adam when single-GPU) of the step in one HIP graph and return a
     function that replays it.  Every kernel of the step (the C-ABI launches included) goes to the
     capture stream or a stream forked from it, so a replay does exactly the work of the eager step with one
     host call.  With N > 1 the gradient all-reduce and the optimizer run eagerly after the replay."""
 
+    fwd_bwds = list(fwd_bwds) if isinstance(fwd_bwds, (list, tuple)) else [fwd_bwds]
     side = torch.cuda.Stream()
     side.wait_stream(torch.cuda.current_stream())
     with torch.cuda.stream(side):                      # warm-up off the default stream (allocator, autograd)
-        for _ in range(3):
+        for it in range(4):
             opt.zero_grad(set_to_none=True)
-            fwd_bwd()
+            fwd_bwds[it % len(fwd_bwds)]()
             optimizer_step(opt, world, reducer)
     torch.cuda.current_stream().wait_stream(side)
     torch.cuda.synchronize()
-    graph = torch.cuda.CUDAGraph()
-    opt.zero_grad(set_to_none=True)
-    packed = None
-    with torch.cuda.graph(graph):
-        fwd_bwd()
-        if world == 1:
-            opt.step()
-        else:
-            packed = opt.pack_grads()      # static buffer of the graph: the all-reduce and Adam read it eagerly
+    graphs, packed = [], []
+    for fwd_bwd in fwd_bwds:                           # one graph per closure (two when the batches alternate)
+        graph = torch.cuda.CUDAGraph()
+        opt.zero_grad(set_to_none=True)
+        with torch.cuda.graph(graph):
+            fwd_bwd()
+            if world == 1:
+                opt.step()
+            else:
+                packed.append(opt.pack_grads())  # static buffer: the all-reduce and Adam read it eagerly
+        graphs.append(graph)
+    count = [0]
 
     def step():
-        graph.replay()
+        k = count[0] % len(graphs)
+        count[0] += 1
+        graphs[k].replay()
         if world > 1:
-            opt.step(reducer.average_(packed))
+            opt.step(reducer.average_(packed[k]))
     return step
 
 
@@ -178,6 +210,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--eager", action="store_true", help="do not capture the step in a HIP graph")
+    ap.add_argument("--no-prefetch", action="store_true",
+                    help="encoder workload: one batch, geometry inside the step (no next-batch geometry prefetch)")
     ap.add_argument("--workload", default="encoder", choices=["encoder", "istnet"],
                     help="encoder = BASELINE configs[1] (the headline metric); istnet = full model, configs[2]/[3]")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for dry runs)")
@@ -229,7 +263,14 @@ def main():
         if world > 1:
             from istnet_amd.parallel import GradAllReducer
             grad_sync = GradAllReducer(model, world)
-        fwd_bwd = make_encoder_fwd_bwd(model, pts)
+        if args.no_prefetch:
+            fwd_bwd = make_encoder_fwd_bwd(model, pts)
+        else:
+            # two batches alternate; while a step runs, the geometry stream prepares the other batch
+            from istnet_amd.modules import GeometrySlot
+            batches = [pts, shell_cloud(BATCH, NPOINTS, seed=1000 + rank, device=dev)]
+            slots = [model.prefetch_geometry(bt, GeometrySlot()) for bt in batches]   # pipeline prologue (untimed)
+            fwd_bwd = [make_pipelined_fwd_bwd(model, batches, slots, i) for i in (0, 1)]
     eager_step = make_eager_step(fwd_bwd, opt, world, grad_sync)
     step, mode = eager_step, "eager"
     if not args.eager:
@@ -272,7 +313,10 @@ def main():
                                    ("IST-Net full model (ResNet-18/PSP RGB branch on MIOpen + point branch, "
                                     "cam + world encoders, IST head, 3 pose heads) fwd+bwd+Adam, SupervisedLoss"),
                        "batch_per_gpu": BATCH, "npoints": NPOINTS, "global_batch": BATCH * world,
-                       "parallelism": f"dp{world}", "launch": mode},
+                       "parallelism": f"dp{world}", "launch": mode,
+                       "batches": ("1 (same batch every step)" if (args.workload != "encoder" or args.no_prefetch)
+                                   else "2 alternating, next batch's FPS/ball-query/three_nn prefetched on the "
+                                        "geometry stream during the current step")},
         }
         if world == 1 and not args.no_roofline:
             from istnet_amd import roofline

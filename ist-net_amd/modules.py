@@ -34,6 +34,26 @@ _SA_LEVELS = ((512, (16, 16, 32)), (256, (32, 32, 64)), (128, (64, 64, 128)), (6
 _NSAMPLES = (16, 32)
 
 
+class GeometrySlot:
+    """Persistent device buffers for the coordinate-only results of ONE batch (FPS picks, ball-query indices,
+    three_nn indices / weights / inverse lists), written by ``PointNet2MSG.prefetch_geometry`` and read by
+    ``forward(..., geometry=slot)``.  Two slots ping-pong in a pipelined training loop."""
+
+    def __init__(self):
+        self.sa = None       # per level: (new_xyz, [idx per scale])
+        self.fp = None       # per FP level: (idx, weight, csr or None)
+        self.event = None    # recorded on the geometry stream after the last write (eager mode)
+        self.shape = None
+
+    def tensors(self):
+        out = []
+        for new_xyz, idxs in self.sa:
+            out += [new_xyz, *idxs]
+        for idx, weight, csr in self.fp:
+            out += [idx, weight, *(csr if csr is not None else ())]
+        return out
+
+
 class PointNet2MSG(nn.Module):
     def __init__(self, radii_list, use_xyz=True):
         super().__init__()
@@ -84,6 +104,41 @@ class PointNet2MSG(nn.Module):
                 fp_geo[lvl] = (idx, weight, csr, ev)
         return sa_geo, fp_geo
 
+    def prefetch_geometry(self, pointcloud, slot=None):
+        """Start the coordinate-only work of ``pointcloud`` NOW on the geometry stream -- concurrently with whatever
+        the current stream does next, typically the training step of the previous batch -- and keep the results in
+        ``slot`` for ``forward(pointcloud, geometry=slot)``.  This is next-batch preprocessing in the sense of a data
+        loader: FPS is a 500-round latency chain per level that nothing inside a step can overlap.
+        The slot's buffers are allocated on first use and overwritten afterwards (call this once outside a graph
+        capture before capturing steps that use the slot).  Returns the slot."""
+        slot = slot if slot is not None else GeometrySlot()
+        xyz, _ = self._break_up_pc(pointcloud)
+        if not self._can_prepass(xyz):
+            raise RuntimeError("prefetch_geometry needs a CUDA point cloud and plain MSG set-abstraction levels")
+        sa_geo, fp_geo = self._geometry_prepass(xyz)
+        side = _geometry_stream(xyz.device)
+        with torch.cuda.stream(side), torch.no_grad():
+            fresh = GeometrySlot()
+            fresh.sa = [(new_xyz, list(idx)) for new_xyz, idx, _ in sa_geo]
+            fresh.fp = [(idx, weight, csr) for idx, weight, csr, _ in fp_geo]
+            if slot.sa is None or slot.shape != tuple(xyz.shape):
+                slot.sa = [(nx.clone(), [i.clone() for i in idx]) for nx, idx in fresh.sa]
+                slot.fp = [(i.clone(), w.clone(), tuple(c.clone() for c in csr) if csr is not None else None)
+                           for i, w, csr in fresh.fp]
+                slot.shape = tuple(xyz.shape)
+            else:
+                torch._foreach_copy_(slot.tensors(), fresh.tensors())
+            if not torch.cuda.is_current_stream_capturing():
+                slot.event = torch.cuda.Event()
+                slot.event.record(side)
+        return slot
+
+    def join_geometry(self, device=None):
+        """Make the current stream wait for the geometry stream (end of a pipelined step; required before the
+        end of a graph capture that contains a prefetch)."""
+        dev = device if device is not None else next(self.parameters()).device
+        torch.cuda.current_stream(dev).wait_stream(_geometry_stream(dev))
+
     def _can_prepass(self, xyz):
         if not (USE_GEOMETRY_STREAM and xyz.is_cuda and not xyz.requires_grad):
             return False
@@ -91,15 +146,24 @@ class PointNet2MSG(nn.Module):
                    and all(type(g) is pointnet2_utils.QueryAndGroup and not g.sample_uniformly for g in sa.groupers)
                    for sa in self.SA_modules)
 
-    def forward(self, pointcloud):
-        """(B, N, 3[+C]) -> (B, 128, N)."""
+    def forward(self, pointcloud, geometry=None):
+        """(B, N, 3[+C]) -> (B, 128, N).  ``geometry``: a GeometrySlot filled by ``prefetch_geometry`` for THIS
+        point cloud (extension of the reference signature)."""
         with defer_bn_counters():
-            return self._forward(pointcloud)
+            return self._forward(pointcloud, geometry)
 
-    def _forward(self, pointcloud):
+    def _forward(self, pointcloud, geometry=None):
         xyz, features = self._break_up_pc(pointcloud)
         sa_geo = fp_geo = None
-        if self._can_prepass(xyz):
+        if geometry is not None:
+            if geometry.sa is None or geometry.shape != tuple(xyz.shape):
+                raise RuntimeError("forward(geometry=...): the slot was not prefetched for a cloud of this shape")
+            main = torch.cuda.current_stream(xyz.device)
+            if geometry.event is not None and not torch.cuda.is_current_stream_capturing():
+                main.wait_event(geometry.event)   # inside a capture the prefetching graph has completed already
+            sa_geo = [(nx, idx, None) for nx, idx in geometry.sa]
+            fp_geo = [(i, w, csr, None) for i, w, csr in geometry.fp]
+        elif self._can_prepass(xyz):
             sa_geo, fp_geo = self._geometry_prepass(xyz)
             main = torch.cuda.current_stream(xyz.device)
         l_xyz, l_features = [xyz], [features]
@@ -109,7 +173,8 @@ class PointNet2MSG(nn.Module):
                 nxt_xyz, nxt_feat = sa(l_xyz[-1], l_features[-1])
             else:
                 new_xyz, idx, ev = sa_geo[i]
-                main.wait_event(ev)
+                if ev is not None:
+                    main.wait_event(ev)
                 nxt_xyz, nxt_feat = sa(l_xyz[-1], l_features[-1], geometry=(new_xyz, idx))
             l_xyz.append(nxt_xyz)
             l_features.append(nxt_feat)
@@ -118,7 +183,8 @@ class PointNet2MSG(nn.Module):
             interp = None
             if fp_geo is not None:
                 idx, weight, csr, ev = fp_geo[lvl]
-                main.wait_event(ev)
+                if ev is not None:
+                    main.wait_event(ev)
                 interp = (idx, weight, csr)
             l_features[lvl] = self.FP_modules[lvl](l_xyz[lvl], l_xyz[lvl + 1], l_features[lvl],
                                                    l_features[lvl + 1], interp=interp)
