@@ -127,6 +127,19 @@ ISTNET_PN2_API int istnet_pw_wgrad(int b, int cin, int cout, int p, int nsample,
                                    const float *d_dense, const float *d_pooled, long long pooled_bstride,
                                    const unsigned char *arg, const float *bn, const float *bwdc, float *dw_part,
                                    void *stream);
+/* Fused backward of a small layer (cin <= 32, cout <= 32, input = raw output x of the previous layer with its
+ * BN block bn_in): one pass writes dx (b, cin, p) = W^T . dY, the statistics partials part_g / part_gy
+ * [cin][splits] of g = dx * [relu(bn_in(x)) > 0] (for istnet_bn_finalize_bwd of the previous layer,
+ * nt = splits = istnet_pw_bwd_small_splits(b, p)) and the split-K partials dw_part [splits][cout][cin] of dW --
+ * i.e. istnet_pw_dgrad + istnet_pw_wgrad in one read of (y, gradient source, x). */
+ISTNET_PN2_API int istnet_pw_bwd_small_ok(int cin, int cout, int p);
+ISTNET_PN2_API int istnet_pw_bwd_small_splits(int b, int p);
+ISTNET_PN2_API int istnet_pw_bwd_small(int b, int cin, int cout, int p, int nsample, const float *w, const float *x,
+                                       const float *bn_in, const float *y, const float *d_dense,
+                                       const float *d_pooled, long long pooled_bstride, const unsigned char *arg,
+                                       const float *bn, const float *bwdc, float *dx, float *part_g,
+                                       float *part_gy, float *dw_part, void *stream);
+
 /* wgrad with the gathered layer-0 input (see istnet_pw_forward_gather); grad_nsample = nsample of the pooled
  * gradient source (0 when d_dense is given) */
 ISTNET_PN2_API int istnet_pw_wgrad_gather(int b, int n, int npoint, int nsample, int cfeat, int cout,

@@ -1127,6 +1127,157 @@ __global__ __launch_bounds__(kThreads) void pw_wgrad_small_kernel(
   }
 }
 
+// ============================================================================================
+// Fused backward of a small layer (cin <= 32, cout <= 32, not the first of its stack): ONE pass over
+// (y_l, gradient source, y_{l-1}) produces
+//     dA_{l-1} = W^T . dY_l                      (what pw_dgrad_kernel would write),
+//     partials of sum g, sum g*y_{l-1}           (its fused BN-backward statistics, g = dA * [relu active]),
+//     a split-K partial of dW = dY_l . act(y_{l-1})^T   (what pw_wgrad_small_kernel would write).
+// These layers (SA1, SA2 layer 1) are HBM-bound: dgrad and wgrad each read y_l and the gradient source, so one
+// pass saves ~45 % of the bytes.  Same structure as pw_wgrad_small_kernel: the four waves of a workgroup walk
+// their own 32-point chunks through wave-private LDS.  Per chunk and wave: dY [pt][co] and RAW y_{l-1} [pt][ci]
+// tiles (odd stride, so both the k-major and the transposed fragment reads are conflict-free), 16 MFMAs for dW
+// (K = points) and 16 for dA (K = cout, A operand = W held in registers).
+// ============================================================================================
+__global__ __launch_bounds__(kThreads) void pw_bwd_small_kernel(
+    int cin, int cout, int P, long long total, int split_len, const float* __restrict__ w,
+    const float* __restrict__ x, const float* __restrict__ in_scale, const float* __restrict__ in_shift,
+    const float* __restrict__ y, GradSrc gs, const float* __restrict__ bn, const float* __restrict__ bwdc,
+    float* __restrict__ dx, float* __restrict__ part_g, float* __restrict__ part_gy, int nt_total,
+    float* __restrict__ dw_part) {
+  constexpr int LD = 33;
+  __shared__ float lds[4][2][kKTW][LD];  // [wave][dY | raw x][k = point][row = channel]
+  __shared__ float s_in[2][32];          // BN constants of the input layer
+  const int lane = lane_id(), wv = wave_id();
+  const long long qbeg = (long long)blockIdx.x * split_len;
+  const long long qend = min(qbeg + (long long)split_len, total);
+  float* As = &lds[wv][0][0][0];
+  float* Bs = &lds[wv][1][0][0];
+  if (threadIdx.x < 32) {
+    const int c = min((int)threadIdx.x, cin - 1);
+    s_in[0][threadIdx.x] = in_scale[c];
+    s_in[1][threadIdx.x] = in_shift[c];
+  }
+  // A operand of the dgrad MFMAs: A[i = ci][k = co] = w[co][ci], co = 2*kk + (lane >> 5), ci = lane & 31
+  float wfrag[16];
+#pragma unroll
+  for (int kk = 0; kk < 16; ++kk) {
+    const int co = 2 * kk + (lane >> 5), ci = lane & 31;
+    wfrag[kk] = (co < cout && ci < cin) ? w[(size_t)co * cin + ci] : 0.f;
+  }
+  __syncthreads();
+  const float bsc = s_in[0][lane & 31], bsh = s_in[1][lane & 31];  // activation of the wgrad B fragments
+
+  DyRaw araw[4];
+  float4 braw[4];
+  auto load_chunk = [&](long long qk) {
+    const long long qc = min(qk, total - kKTW);
+    const int b = (int)(qc / P);
+    const int pk = (int)(qc - (long long)b * P);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int e = lane + 64 * i;
+      const int row = e >> 3, p = pk + (e & 7) * 4;
+      load_dy_raw(araw[i], gs, y, (size_t)b * cout + min(row, cout - 1), P, p);
+      braw[i] = *reinterpret_cast<const float4*>(x + ((size_t)b * cin + min(row, cin - 1)) * P + p);
+    }
+  };
+  auto store_chunk = [&](long long qk) {
+    const int pk = (int)(min(qk, total - kKTW) % P);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int e = lane + 64 * i;
+      const int row = e >> 3, k = (e & 7) * 4;
+      const bool okq = qk + k < qend;
+      float4 v = finish_dy(araw[i], gs, pk + k, min(row, cout - 1), bn, bwdc, cout);
+      if (!(okq && row < cout)) v = zero4();
+      As[(k + 0) * LD + row] = v.x; As[(k + 1) * LD + row] = v.y;
+      As[(k + 2) * LD + row] = v.z; As[(k + 3) * LD + row] = v.w;
+      const float4 u = braw[i];   // raw: the statistics need y_{l-1} itself, the activation is applied on read
+      Bs[(k + 0) * LD + row] = u.x; Bs[(k + 1) * LD + row] = u.y;
+      Bs[(k + 2) * LD + row] = u.z; Bs[(k + 3) * LD + row] = u.w;
+    }
+  };
+
+  f32x16 accw;
+  float sg[16], sgy[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { accw[r] = 0.f; sg[r] = 0.f; sgy[r] = 0.f; }
+  const int nchunks = (int)((qend - qbeg + kKTW - 1) / kKTW);
+  int t = wv;
+  if (t < nchunks) load_chunk(qbeg + (long long)t * kKTW);
+  for (; t < nchunks; t += 4) {
+    const long long qk = qbeg + (long long)t * kKTW;
+    store_chunk(qk);                                                // wave-private LDS: no workgroup barrier
+    if (t + 4 < nchunks) load_chunk(qbeg + (long long)(t + 4) * kKTW);  // in flight during the MFMAs
+    __builtin_amdgcn_s_waitcnt(0xc07f);                             // lgkmcnt(0): this wave's ds_writes landed
+    f32x16 accd;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) accd[r] = 0.f;
+    const float* ap = As + (lane >> 5) * LD + (lane & 31);   // dY[pt = 2kk + half][co = lane & 31]
+    const float* bp = Bs + (lane >> 5) * LD + (lane & 31);   // x [pt = 2kk + half][ci = lane & 31]
+    const float* tp = As + (lane & 31) * LD + (lane >> 5);   // dY[pt = lane & 31][co = 2kk + half]
+#pragma unroll
+    for (int kk = 0; kk < 16; ++kk) {
+      const float a = ap[2 * kk * LD];
+      const float bx = fmaxf(bp[2 * kk * LD] * bsc + bsh, 0.f);
+      const float bt = tp[2 * kk];
+      accw = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bx, accw, 0, 0, 0);            // dW[co][ci] += dY . act(x)^T
+      accd = __builtin_amdgcn_mfma_f32_32x32x2f32(wfrag[kk], bt, accd, 0, 0, 0);    // dA[ci][pt]  = W^T . dY
+    }
+    // dA of this chunk: register r of a lane is (ci = mfma_row(r, lane), pt = lane & 31)
+    const long long qc = min(qk, total - kKTW);
+    const int b = (int)(qc / P);
+    const int pk = (int)(qc - (long long)b * P);
+    const int pt = lane & 31;
+    const bool okp = qk + pt < qend;
+    float* dxb = dx + (size_t)b * cin * P + pk + pt;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int ci = mfma_row(r, lane);
+      if (okp && ci < cin) {
+        const float v = accd[r];
+        dxb[(size_t)ci * P] = v;
+        const float yin = Bs[pt * LD + ci];
+        const float gq = (yin * s_in[0][ci] + s_in[1][ci] > 0.f) ? v : 0.f;
+        sg[r] += gq;
+        sgy[r] += gq * yin;
+      }
+    }
+  }
+  // ---- per-workgroup results: dW partial (sum of the four waves) and the statistics partials ----
+  __syncthreads();
+  float* red = &lds[0][0][0][0];   // [4][32*32] floats fit in the staging area
+#pragma unroll
+  for (int r = 0; r < 16; ++r) red[wv * 1024 + mfma_row(r, lane) * 32 + (lane & 31)] = accw[r];
+  __syncthreads();
+  float* out = dw_part + (size_t)blockIdx.x * cout * cin;
+  for (int i = threadIdx.x; i < 1024; i += kThreads) {
+    const int row = i >> 5, col = i & 31;
+    if (row < cout && col < cin)
+      out[(size_t)row * cin + col] = (red[i] + red[1024 + i]) + (red[2048 + i] + red[3072 + i]);
+  }
+  __syncthreads();
+  float* sred = red;               // [4 waves][32 rows][2]
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const float a = half_wave_sum(sg[r]), c = half_wave_sum(sgy[r]);
+    if ((lane & 31) == 31) {
+      sred[(wv * 32 + mfma_row(r, lane)) * 2 + 0] = a;
+      sred[(wv * 32 + mfma_row(r, lane)) * 2 + 1] = c;
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < cin) {
+    const int ci = threadIdx.x;
+    float a = 0.f, c = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { a += sred[(k * 32 + ci) * 2 + 0]; c += sred[(k * 32 + ci) * 2 + 1]; }
+    part_g[(size_t)ci * nt_total + blockIdx.x] = a;
+    part_gy[(size_t)ci * nt_total + blockIdx.x] = c;
+  }
+}
+
 // dw[i] = sum_s dw_part[s][i]: 16 elements x 16 split groups per workgroup, fixed reduction order
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(int count, int splits, const float* __restrict__ part,
                                                            float* __restrict__ dw) {
@@ -1223,6 +1374,7 @@ inline bool wgrad_small(int cin, int cout) { return cin <= 32 && cout <= 32; }
 int g_wg_small_pts = 0x7fffffff;  // layers with b*P <= this use 64x64 wgrad tiles: measured best for every encoder layer (smaller split-K partials)
 int g_wg_target_big = 768;   // target workgroup count, outputs >= 128x128
 int g_wg_target_small = 1024;
+int g_bwd_small_target = 256; // workgroups of the fused small-layer backward (key 5)
 inline int wgrad_mt(int cout, long long pts) { return (cout >= 128 && pts > g_wg_small_pts) ? 128 : 64; }
 inline int wgrad_nt(int cin, long long pts) { return (cin >= 96 && pts > g_wg_small_pts) ? 128 : 64; }
 inline int wgrad_split_len(int b, int cin, int cout, int P) {
@@ -1278,6 +1430,7 @@ int istnet_pw_set_tuning(int key, int value) {
     case 2: g_wg_target_small = value; return 0;
     case 3: g_force_fwd_cfg = value; return 0;
     case 4: g_force_dgrad_cfg = value; return 0;
+    case 5: g_bwd_small_target = value > 0 ? value : 256; return 0;
     default: return ISTNET_PN2_EINVAL;
   }
 }
@@ -1511,6 +1664,43 @@ static int launch_pw_wgrad(bool gather, int b, int cin, int cout, int p, int nsa
   else if (nt == 128) ISTNET_WGRAD(64, 128);
   else ISTNET_WGRAD(64, 64);
 #undef ISTNET_WGRAD
+  return (int)hipGetLastError();
+}
+
+int istnet_pw_bwd_small_ok(int cin, int cout, int p) {
+  return cin > 0 && cout > 0 && cin <= 32 && cout <= 32 && p % kKTW == 0;
+}
+
+// the fused kernel has more per-workgroup set-up (weight fragments, two cross-wave reductions) than the plain
+// wgrad: ~256 workgroups (16+ chunks per wave) measured 15-25 % faster than 1024 (tools/bench_bwd_small.py)
+static int bwd_small_len(int b, int p) {
+  const long long total = (long long)b * p;
+  long long len = (total + g_bwd_small_target - 1) / g_bwd_small_target;
+  len = (len + 4 * kKTW - 1) / (4 * kKTW) * (4 * kKTW);   // whole rounds of the four waves
+  return (int)len;
+}
+int istnet_pw_bwd_small_splits(int b, int p) {
+  const long long total = (long long)b * p;
+  return (int)((total + bwd_small_len(b, p) - 1) / bwd_small_len(b, p));
+}
+
+int istnet_pw_bwd_small(int b, int cin, int cout, int p, int nsample, const float* w, const float* x,
+                        const float* bn_in, const float* y, const float* d_dense, const float* d_pooled,
+                        long long pooled_bstride, const unsigned char* arg, const float* bn, const float* bwdc,
+                        float* dx, float* part_g, float* part_gy, float* dw_part, void* stream) {
+  const int GS_C = cout;
+  if (b <= 0 || !istnet_pw_bwd_small_ok(cin, cout, p)) return ISTNET_PN2_EINVAL;
+  if (w == nullptr || x == nullptr || bn_in == nullptr || dx == nullptr || part_g == nullptr || part_gy == nullptr ||
+      dw_part == nullptr)
+    return ISTNET_PN2_EINVAL;
+  if (d_dense == nullptr && (d_pooled == nullptr || arg == nullptr || nsample <= 0 || (nsample & 3)))
+    return ISTNET_PN2_EINVAL;
+  GradSrc gs{d_dense, d_pooled, arg, nsample, pooled_bstride > 0 ? pooled_bstride : (long long)GS_C * (nsample > 0 ? p / nsample : 0), GS_C};
+  const int len = bwd_small_len(b, p);
+  const int splits = istnet_pw_bwd_small_splits(b, p);   // also the number of statistics partials per channel
+  hipLaunchKernelGGL(pw_bwd_small_kernel, dim3(splits), dim3(kThreads), 0, as_stream(stream), cin, cout, p,
+                     (long long)b * p, len, w, x, bn_in, bn_in + cin, y, gs, bn, bwdc, dx, part_g, part_gy, splits,
+                     dw_part);
   return (int)hipGetLastError();
 }
 

@@ -298,6 +298,16 @@ def _wgrad_job(lib, dev, b, cin, cout, p, ns_arg, use_gather, ga, src, in_bn, y,
     return launch
 
 
+USE_FUSED_SMALL_BWD = os.environ.get("ISTNET_NO_FUSED_SMALL_BWD") is None
+
+
+def _reduce_only_job(dev, wparam, cout, cin, splits, ws):
+    """wgrad job whose partials already exist (written by the fused backward kernel): only the reduce is left."""
+    def launch(wst):
+        return cout * cin, splits, ws, _grad_dest(wparam, (cout, cin), dev)
+    return launch
+
+
 def _backward_stack(lib, dev, st, b, c0, g, s, x, gather, training, ys, bns, params, arg, dout, need_w, need_x,
                     pooled_bstride=0, scatter_out=None):
     """Returns (grads for [w, gamma, beta] * L, gradient w.r.t. the layer-0 input or None).
@@ -348,6 +358,20 @@ def _backward_stack(lib, dev, st, b, c0, g, s, x, gather, training, ys, bns, par
         grads[3 * li + 1] = dgamma
         grads[3 * li + 2] = dbeta
         use_gather = li == 0 and gather is not None
+        if (li > 0 and need_w[li] and USE_FUSED_SMALL_BWD and _native.TIMING is None
+                and lib.istnet_pw_bwd_small_ok(cin, cout, p)):
+            # small layer: dA_{l-1}, its statistics partials and the dW partials from ONE pass over (y, g, y_{l-1})
+            splits = lib.istnet_pw_bwd_small_splits(b, p)
+            ws = _empty((splits, cout, cin), torch.float32, dev)
+            dprev = _empty((b, cin, p), torch.float32, dev)
+            fused_part, fused_nt = _empty((2, cin, splits), torch.float32, dev), splits
+            _native.check(lib.istnet_pw_bwd_small(
+                b, cin, cout, p, ns_arg, w2.data_ptr(), ys[li - 1].data_ptr(), bns[li - 1].data_ptr(), y.data_ptr(),
+                dd, dp, pbs, da, bn.data_ptr(), bwdc.data_ptr(), dprev.data_ptr(), fused_part[0].data_ptr(),
+                fused_part[1].data_ptr(), ws.data_ptr(), st), "pw_bwd_small")
+            wjobs.append(_reduce_only_job(dev, w, cout, cin, splits, ws))
+            d_dense, d_pooled, d_arg = dprev, None, None
+            continue
         if need_w[li]:
             wjobs.append(_wgrad_job(lib, dev, b, cin, cout, p, ns_arg, use_gather, gather,
                                     x if li == 0 else ys[li - 1], None if li == 0 else bns[li - 1], y,

@@ -9,7 +9,10 @@ from istnet_amd.optim import FlatAdam
 
 dev = torch.device("cuda:0")
 model = bench.make_model(dev)
-pts = bench.shell_cloud(32, 1024, 0, dev)
+from istnet_amd.modules import GeometrySlot
+batches = [bench.shell_cloud(32, 1024, 0, dev), bench.shell_cloud(32, 1024, 1000, dev)]
+slots = [model.prefetch_geometry(bt, GeometrySlot()) for bt in batches]
+pts = batches[0]
 opt = FlatAdam(model.parameters(), lr=1e-4)
 buf = torch.zeros(256, dtype=torch.int64, device=dev)
 
@@ -17,11 +20,15 @@ buf = torch.zeros(256, dtype=torch.int64, device=dev)
 def step():
     _native.mark("step start")
     opt.zero_grad(set_to_none=True)
-    out = model(pts)
+    model.prefetch_geometry(batches[1], slots[1])
+    with torch.cuda.stream(__import__("istnet_amd").modules._geometry_stream(dev)):
+        _native.mark("geometry of the next batch done (geometry stream)")
+    out = model(pts, geometry=slots[0])
     loss = out.square().mean()
     _native.mark("loss fwd done")
     loss.backward()
     _native.mark("backward joined")
+    model.join_geometry()
     opt.step()
     _native.mark("optimizer done")
 
