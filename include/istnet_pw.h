@@ -43,6 +43,20 @@ ISTNET_PN2_API int istnet_pw_forward(int b, int cin, int cout, int p, const floa
                                      const float *in_scale, const float *in_shift, float *y,
                                      float *part_sum, float *part_sq, void *stream);
 
+/* istnet_pw_forward with w a column slice of a wider row-major matrix: row stride ldw >= cin */
+ISTNET_PN2_API int istnet_pw_forward_ld(int b, int cin, int cout, int p, const float *x, const float *w, int ldw,
+                                        const float *in_scale, const float *in_shift, float *y,
+                                        float *part_sum, float *part_sq, void *stream);
+
+/* Layer 0 of a set-abstraction scale split by linearity: with z = W0[:, 3:] . feat (b, cout, n) computed over the
+ * n SOURCE points (istnet_pw_forward_ld), y[b][co][p] = z[b][co][idx[p]] + W0[co][0:3] . (xyz[idx[p]] - new_xyz[p / nsample]),
+ * plus the per-channel partials of sum(y), sum(y*y) ([cout][istnet_pw_gather_add_tiles(b, p)], may be NULL).
+ * w0 is (cout, ldw) row-major, its first three columns are the xyz weights. */
+ISTNET_PN2_API int istnet_pw_gather_add_tiles(int b, int p);
+ISTNET_PN2_API int istnet_pw_gather_add(int b, int n, int npoint, int nsample, int cout, const float *xyz,
+                                        const float *new_xyz, const int *idx, const float *z, const float *w0,
+                                        int ldw, float *y, float *part_sum, float *part_sq, void *stream);
+
 /* Same GEMM with the layer-0 input of a set-abstraction scale gathered on the fly (the grouped tensor of
  * QueryAndGroup, pointnet2_utils.py:348-358, is never materialised): input channel k < 3 is
  * xyz[b][idx[b][p]][k] - new_xyz[b][p / nsample][k], channel k >= 3 is feat[b][k-3][idx[b][p]];

@@ -37,6 +37,9 @@ SIGNATURES = {
     "istnet_pw_set_tuning": [_i, _i],
     "istnet_pw_stat_tiles": [_i, _i, _i],
     "istnet_pw_forward": [_i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p],
+    "istnet_pw_forward_ld": [_i, _i, _i, _i, _p, _p, _i, _p, _p, _p, _p, _p, _p],
+    "istnet_pw_gather_add_tiles": [_i, _i],
+    "istnet_pw_gather_add": [_i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _i, _p, _p, _p, _p],
     "istnet_pw_forward_gather": [_i, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p],
     "istnet_pw_wgrad_gather": [_i, _i, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _l, _p, _p, _p, _p, _p],
     "istnet_bn_finalize_fwd": [_i, _i, _d, _p, _p, _p, _p, _f, _f, _p, _p, _p, _p],

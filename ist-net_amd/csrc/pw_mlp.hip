@@ -160,7 +160,7 @@ template <int M_T, int N_T, int WM, int WN, int GATHER>  // 0: x is a tensor, 1:
 __global__ __launch_bounds__(kThreads) void pw_fwd_kernel(
     int cin, int cout, int P, int tiles_per_cloud, const float* __restrict__ x, GatherSrc gsrc,
     const float* __restrict__ w, const float* __restrict__ in_scale, const float* __restrict__ in_shift,
-    float* __restrict__ y, float* __restrict__ part_sum, float* __restrict__ part_sq, int nt_total) {
+    float* __restrict__ y, float* __restrict__ part_sum, float* __restrict__ part_sq, int nt_total, int ldw) {
   using T = Tile<M_T, N_T, WM, WN>;
   constexpr int TM = T::TM, TN = T::TN;
   constexpr int NA = kKT * M_T / kThreads;        // scalar weight loads per thread per chunk
@@ -210,7 +210,7 @@ __global__ __launch_bounds__(kThreads) void pw_fwd_kernel(
       if (GATHER == 2) k = feat_chunk ? k + 3 : k - cfeat;   // position in K -> column of w
       k = min(k, cin - 1);
       const int m = min(m0 + e / kKT, cout - 1);
-      areg[i] = w[(size_t)m * cin + k];
+      areg[i] = w[(size_t)m * ldw + k];   // ldw > cin: w is a column slice of a wider matrix
     }
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
@@ -337,6 +337,60 @@ __global__ __launch_bounds__(kThreads) void pw_fwd_kernel(
     }
   }
   ISTNET_TRACE_MARK(3);
+}
+
+// ============================================================================================
+// Layer 0 of a set-abstraction scale, split by linearity.  The grouped input of point p is
+// [xyz[idx[p]] - centre(p) ; feat[:, idx[p]]], so
+//     y0[:, p] = W0x . (xyz[idx[p]] - centre(p)) + (W0f . feat)[:, idx[p]].
+// Z = W0f . feat is a GEMM over the n source points of the cloud -- nsample * npoint / n (16..32) times fewer
+// MACs than the same product over the P grouped points -- and this kernel gathers it: one thread per grouped
+// point, loop over the output channels, per-channel sum / sum-of-squares partials for the BatchNorm.
+// grid (ceil(P / 256), B); partials [cout][B * tiles].
+// ============================================================================================
+__global__ __launch_bounds__(256) void pw_gather_add_kernel(int n, int P, int S, int cout, int ldw,
+                                                            const float* __restrict__ xyz,
+                                                            const float* __restrict__ new_xyz,
+                                                            const int* __restrict__ idx,
+                                                            const float* __restrict__ z,
+                                                            const float* __restrict__ w0,
+                                                            float* __restrict__ y, float* __restrict__ part_sum,
+                                                            float* __restrict__ part_sq, int nt_total) {
+  extern __shared__ float ga_lds[];          // [cout][3] xyz weights, then [4 waves][cout][2] statistics
+  float* wx = ga_lds;
+  float* red = ga_lds + 3 * cout;
+  const int b = blockIdx.y, tid = threadIdx.x;
+  for (int i = tid; i < 3 * cout; i += 256) wx[i] = w0[(size_t)(i / 3) * ldw + (i % 3)];
+  const int p = blockIdx.x * 256 + tid;
+  const bool valid = p < P;
+  const int pc = valid ? p : P - 1;
+  const int src = idx[(size_t)b * P + pc];
+  const float* xs = xyz + ((size_t)b * n + src) * 3;
+  const float* xc = new_xyz + ((size_t)b * (P / S) + pc / S) * 3;
+  const float dx = xs[0] - xc[0], dy = xs[1] - xc[1], dz = xs[2] - xc[2];
+  const float* zb = z + (size_t)b * cout * n + src;
+  float* yb = y + (size_t)b * cout * P + pc;
+  __syncthreads();
+  const int wv = tid >> 6;
+  for (int co = 0; co < cout; ++co) {
+    float v = zb[(size_t)co * n] + ((wx[3 * co] * dx + wx[3 * co + 1] * dy) + wx[3 * co + 2] * dz);
+    if (valid) yb[(size_t)co * P] = v; else v = 0.f;
+    if (part_sum != nullptr) {
+      const float s = wave_sum(v), q = wave_sum(v * v);
+      if ((tid & 63) == 0) { red[(wv * cout + co) * 2] = s; red[(wv * cout + co) * 2 + 1] = q; }
+    }
+  }
+  if (part_sum != nullptr) {
+    __syncthreads();
+    const int tile = b * gridDim.x + blockIdx.x;
+    for (int co = tid; co < cout; co += 256) {
+      float s = 0.f, q = 0.f;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { s += red[(k * cout + co) * 2]; q += red[(k * cout + co) * 2 + 1]; }
+      part_sum[(size_t)co * nt_total + tile] = s;
+      part_sq[(size_t)co * nt_total + tile] = q;
+    }
+  }
 }
 
 // ============================================================================================
@@ -1440,7 +1494,7 @@ int istnet_pw_stat_tiles(int b, int cout, int p) {
 }
 
 static int launch_pw_forward(bool gather, int b, int cin, int cout, int p, const float* x, const GatherSrc& g,
-                             const float* w, const float* in_scale, const float* in_shift, float* y,
+                             const float* w, int ldw, const float* in_scale, const float* in_shift, float* y,
                              float* part_sum, float* part_sq, void* stream) {
   if (b <= 0 || cin <= 0 || cout <= 0 || p <= 0 || (p & 3)) return ISTNET_PN2_EINVAL;
   const TileCfg cfg = pick_cfg(b, cout, p, g_force_fwd_cfg);
@@ -1452,13 +1506,13 @@ static int launch_pw_forward(bool gather, int b, int cin, int cout, int p, const
   do {                                                                                                      \
     if (mode == 2)                                                                                          \
       hipLaunchKernelGGL((pw_fwd_kernel<MT, NT, WM, WN, 2>), grid, dim3(kThreads), 0, as_stream(stream),    \
-                         cin, cout, p, tpc, x, g, w, in_scale, in_shift, y, part_sum, part_sq, nt);        \
+                         cin, cout, p, tpc, x, g, w, in_scale, in_shift, y, part_sum, part_sq, nt, ldw);   \
     else if (mode == 1)                                                                                     \
       hipLaunchKernelGGL((pw_fwd_kernel<MT, NT, WM, WN, 1>), grid, dim3(kThreads), 0, as_stream(stream),    \
-                         cin, cout, p, tpc, x, g, w, in_scale, in_shift, y, part_sum, part_sq, nt);        \
+                         cin, cout, p, tpc, x, g, w, in_scale, in_shift, y, part_sum, part_sq, nt, ldw);   \
     else                                                                                                    \
       hipLaunchKernelGGL((pw_fwd_kernel<MT, NT, WM, WN, 0>), grid, dim3(kThreads), 0, as_stream(stream),    \
-                         cin, cout, p, tpc, x, g, w, in_scale, in_shift, y, part_sum, part_sq, nt);        \
+                         cin, cout, p, tpc, x, g, w, in_scale, in_shift, y, part_sum, part_sq, nt, ldw);   \
   } while (0)
   switch (cfg) {
     case kCfg128x128: ISTNET_FWD(128, 128, 2, 2); break;
@@ -1473,8 +1527,31 @@ static int launch_pw_forward(bool gather, int b, int cin, int cout, int p, const
 int istnet_pw_forward(int b, int cin, int cout, int p, const float* x, const float* w,
                       const float* in_scale, const float* in_shift, float* y, float* part_sum,
                       float* part_sq, void* stream) {
-  return launch_pw_forward(false, b, cin, cout, p, x, GatherSrc{}, w, in_scale, in_shift, y, part_sum, part_sq,
+  return launch_pw_forward(false, b, cin, cout, p, x, GatherSrc{}, w, cin, in_scale, in_shift, y, part_sum, part_sq,
                            stream);
+}
+
+int istnet_pw_forward_ld(int b, int cin, int cout, int p, const float* x, const float* w, int ldw,
+                         const float* in_scale, const float* in_shift, float* y, float* part_sum,
+                         float* part_sq, void* stream) {
+  if (ldw < cin) return ISTNET_PN2_EINVAL;
+  return launch_pw_forward(false, b, cin, cout, p, x, GatherSrc{}, w, ldw, in_scale, in_shift, y, part_sum, part_sq,
+                           stream);
+}
+
+int istnet_pw_gather_add_tiles(int b, int p) { return b * ceil_div(p, 256); }
+
+int istnet_pw_gather_add(int b, int n, int npoint, int nsample, int cout, const float* xyz, const float* new_xyz,
+                         const int* idx, const float* z, const float* w0, int ldw, float* y, float* part_sum,
+                         float* part_sq, void* stream) {
+  if (b <= 0 || n <= 0 || npoint <= 0 || nsample <= 0 || cout <= 0 || ldw < 3) return ISTNET_PN2_EINVAL;
+  const int p = npoint * nsample;
+  const size_t lds = (size_t)(3 * cout + 4 * cout * 2) * sizeof(float);
+  if (lds > 64 * 1024) return ISTNET_PN2_EINVAL;
+  const dim3 grid(ceil_div(p, 256), b);
+  hipLaunchKernelGGL(pw_gather_add_kernel, grid, dim3(256), lds, as_stream(stream), n, p, nsample, cout, ldw, xyz,
+                     new_xyz, idx, z, w0, y, part_sum, part_sq, (int)(grid.x * b));
+  return (int)hipGetLastError();
 }
 
 int istnet_pw_forward_gather(int b, int n, int npoint, int nsample, int cfeat, int cout, const float* xyz,
@@ -1482,7 +1559,7 @@ int istnet_pw_forward_gather(int b, int n, int npoint, int nsample, int cfeat, i
                              const float* w, float* y, float* part_sum, float* part_sq, void* stream) {
   if (n <= 0 || npoint <= 0 || nsample <= 0 || (nsample & 3) || cfeat < 0) return ISTNET_PN2_EINVAL;
   const GatherSrc g{xyz, new_xyz, feat, idx, n, nsample, cfeat, feat_t};
-  return launch_pw_forward(true, b, 3 + cfeat, cout, npoint * nsample, nullptr, g, w, nullptr, nullptr, y,
+  return launch_pw_forward(true, b, 3 + cfeat, cout, npoint * nsample, nullptr, g, w, 3 + cfeat, nullptr, nullptr, y,
                            part_sum, part_sq, stream);
 }
 

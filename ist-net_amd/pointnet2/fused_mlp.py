@@ -173,7 +173,21 @@ def _forward_stack(lib, dev, st, b, c0, g, s, x, gather, training, layers, param
             nt, ps, pq = 0, None, None
         kname = _kname("pw_fwd_kernel", lib.istnet_pw_tile_cfg(b, cout, p), gather is not None and li == 0)
         flops, nbytes = 2.0 * b * p * cur_c * cout, 4.0 * b * p * (cur_c + cout)
-        if li == 0 and gather is not None:
+        if li == 0 and gather is not None and gather.cfeat > 0 and USE_SPLIT_LAYER0 and _native.TIMING is None:
+            # layer 0 by linearity: Z = W0[:, 3:] . feat over the n source points (nsample*npoint/n times fewer MACs
+            # than over the grouped points), then y0 = Z[:, idx] + W0[:, :3] . (xyz[idx] - centre)
+            ga = gather
+            z = _empty((b, cout, ga.n), torch.float32, dev)
+            _native.check(lib.istnet_pw_forward_ld(b, ga.cfeat, cout, ga.n, ga.feat.data_ptr(), w2.data_ptr() + 12,
+                                                   cur_c, None, None, z.data_ptr(), None, None, st), "pw_forward_ld")
+            if ps is not None:
+                nt = lib.istnet_pw_gather_add_tiles(b, p)
+                part = _empty((2, cout, nt), torch.float32, dev)
+                ps, pq = part[0].data_ptr(), part[1].data_ptr()
+            _native.check(lib.istnet_pw_gather_add(b, ga.n, ga.npoint, ga.nsample, cout, ga.xyz.data_ptr(),
+                                                   ga.new_xyz.data_ptr(), ga.idx.data_ptr(), z.data_ptr(),
+                                                   w2.data_ptr(), cur_c, y.data_ptr(), ps, pq, st), "pw_gather_add")
+        elif li == 0 and gather is not None:
             ga = gather
             _native.check(_native.timed(kname, flops, 4.0 * b * p * (1 + cout), lambda: lib.istnet_pw_forward_gather(
                 b, ga.n, ga.npoint, ga.nsample, ga.cfeat, cout, ga.xyz.data_ptr(), ga.new_xyz.data_ptr(),
@@ -299,6 +313,7 @@ def _wgrad_job(lib, dev, b, cin, cout, p, ns_arg, use_gather, ga, src, in_bn, y,
 
 
 USE_FUSED_SMALL_BWD = os.environ.get("ISTNET_NO_FUSED_SMALL_BWD") is None
+USE_SPLIT_LAYER0 = os.environ.get("ISTNET_NO_SPLIT_LAYER0") is None
 
 
 def _reduce_only_job(dev, wparam, cout, cin, splits, ws):
