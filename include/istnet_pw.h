@@ -126,11 +126,16 @@ ISTNET_PN2_API int istnet_pw_dgrad(int b, int cin_total, int ci_off, int m_rows,
  * layer's dY instead of to the layer-0 input gradient; the scatter commutes with the channel mixing, so the
  * feature gradient of a set-abstraction scale is  W0[:, 3:]^T . out[b]  -- a GEMM over n instead of p columns).
  * idx (b, p) i32 with values in [0, n); needs n <= 4096.  Cloud b of `out` starts at out + b*out_bstride
- * (0 = cout*n). */
+ * (0 = cout*n).
+ * The same `out` also gives the layer-0 weight gradient without a pass over the grouped points:
+ *   dW0[:, 3:] = sum_b out[b] . feat[b]^T  (a wgrad over the n source points), and, when dwx != NULL, this call
+ *   also writes dwx[b][co][k] = sum_p dY[b][co][p] * (xyz[b][idx[p]][k] - new_xyz[b][p / group_nsample][k]),
+ *   whose sum over b is dW0[:, 0:3]. */
 ISTNET_PN2_API int istnet_pw_scatter_dy(int b, int cout, int n, int p, int nsample, const float *y,
                                         const float *d_dense, const float *d_pooled, long long pooled_bstride,
                                         const unsigned char *arg, const float *bn, const float *bwdc,
-                                        const int *idx, float *out, long long out_bstride, void *stream);
+                                        const int *idx, float *out, long long out_bstride, const float *xyz,
+                                        const float *new_xyz, int group_nsample, float *dwx, void *stream);
 
 /* split-K weight gradient (requires p % 32 == 0): dw_part[split][co][ci] = sum_{p in split} dY[b][co][p] * act(x[b][ci][p]) with
  * istnet_pw_wgrad_splits(...) splits; istnet_pw_wgrad_reduce sums the partials in a fixed order:

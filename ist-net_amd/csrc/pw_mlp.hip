@@ -711,7 +711,10 @@ __global__ __launch_bounds__(256) void pw_scatter_dy_kernel(int cout, int n, int
                                                             GradSrc gs, const float* __restrict__ bn,
                                                             const float* __restrict__ bwdc,
                                                             const int* __restrict__ idx_all,
-                                                            float* __restrict__ out, long long out_bstride) {
+                                                            float* __restrict__ out, long long out_bstride,
+                                                            const float* __restrict__ xyz,
+                                                            const float* __restrict__ new_xyz, int group_s,
+                                                            float* __restrict__ dwx) {
   extern __shared__ __attribute__((aligned(16))) float acc[];  // [CH][n]
   const int b = blockIdx.y, c0 = blockIdx.x * kScatterCH;
   const int nch = min(kScatterCH, cout - c0);
@@ -725,10 +728,19 @@ __global__ __launch_bounds__(256) void pw_scatter_dy_kernel(int cout, int n, int
   // 32 dependent steps x ~2 us at P = 8192).
   int ii_n = -1;
   float yv_n[kScatterCH], d_n[kScatterCH];
+  float xr_n[3] = {0.f, 0.f, 0.f};   // dwx != nullptr: offset of the neighbour to its centroid (layer-0 xyz input)
+  float wxa[kScatterCH][3];          // per-thread partial of dW0[:, 0:3] = sum_p dY0[:, p] * xrel[p]
+#pragma unroll
+  for (int ch = 0; ch < kScatterCH; ++ch) wxa[ch][0] = wxa[ch][1] = wxa[ch][2] = 0.f;
   auto prefetch = [&](int p) {
     const bool valid = p < P;
     const int pc = valid ? p : P - 1;
     ii_n = valid ? idx[p] : -1;
+    if (dwx != nullptr) {
+      const float* xs = xyz + ((size_t)b * n + idx[pc]) * 3;
+      const float* xc = new_xyz + ((size_t)b * (P / group_s) + pc / group_s) * 3;
+      xr_n[0] = xs[0] - xc[0]; xr_n[1] = xs[1] - xc[1]; xr_n[2] = xs[2] - xc[2];
+    }
 #pragma unroll
     for (int ch = 0; ch < kScatterCH; ++ch) {
       const int co = min(c0 + ch, cout - 1);
@@ -749,6 +761,7 @@ __global__ __launch_bounds__(256) void pw_scatter_dy_kernel(int cout, int n, int
     float yv_c[kScatterCH], d_c[kScatterCH];
 #pragma unroll
     for (int ch = 0; ch < kScatterCH; ++ch) { yv_c[ch] = yv_n[ch]; d_c[ch] = d_n[ch]; }
+    const float xr0 = xr_n[0], xr1 = xr_n[1], xr2 = xr_n[2];
     if (p + 256 < Pr) prefetch(p + 256);
     const int prev = dpp_row_i<0x111>(-2, ii);   // row_shr:1
     const int head0 = (prev != ii) ? 1 : 0;
@@ -762,6 +775,7 @@ __global__ __launch_bounds__(256) void pw_scatter_dy_kernel(int cout, int n, int
         const float act = yv * bn[co] + bn[cout + co];
         float v = bwdc[co] * (act > 0.f ? d_c[ch] : 0.f) + bwdc[cout + co] + bwdc[2 * cout + co] * yv;
         if (!valid) v = 0.f;
+        if (dwx != nullptr) { wxa[ch][0] += v * xr0; wxa[ch][1] += v * xr1; wxa[ch][2] += v * xr2; }
         int f = head0;
         float pv; int pf;
         pv = dpp_row_f<0x111>(v); pf = dpp_row_i<0x111>(1, f); v = f ? v : v + pv; f |= pf;
@@ -774,6 +788,20 @@ __global__ __launch_bounds__(256) void pw_scatter_dy_kernel(int cout, int n, int
   }
   __syncthreads();
   for (int i = threadIdx.x; i < nch * n; i += 256) out[(size_t)b * out_bstride + (size_t)c0 * n + i] = acc[i];
+  if (dwx != nullptr) {   // workgroup sum of the xyz-weight partials -> dwx[b][co][0:3]
+    __shared__ float wred[4][kScatterCH * 3];
+#pragma unroll
+    for (int ch = 0; ch < kScatterCH; ++ch)
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        const float t = wave_sum(wxa[ch][k]);
+        if (lane_id() == 0) wred[wave_id()][ch * 3 + k] = t;
+      }
+    __syncthreads();
+    if (threadIdx.x < nch * 3)
+      dwx[((size_t)b * cout + c0) * 3 + threadIdx.x] = (wred[0][threadIdx.x] + wred[1][threadIdx.x]) +
+                                                        (wred[2][threadIdx.x] + wred[3][threadIdx.x]);
+  }
 }
 
 // ============================================================================================
@@ -1680,16 +1708,19 @@ int istnet_pw_dgrad(int b, int cin_total, int ci_off, int m_rows, int cout, int 
 int istnet_pw_scatter_dy(int b, int cout, int n, int p, int nsample, const float* y, const float* d_dense,
                          const float* d_pooled, long long pooled_bstride, const unsigned char* arg,
                          const float* bn, const float* bwdc, const int* idx, float* out, long long out_bstride,
-                         void* stream) {
+                         const float* xyz, const float* new_xyz, int group_nsample, float* dwx, void* stream) {
   const int GS_C = cout;
   if (b <= 0 || cout <= 0 || n <= 0 || p <= 0) return ISTNET_PN2_EINVAL;
   if (d_dense == nullptr && (d_pooled == nullptr || arg == nullptr || nsample <= 0)) return ISTNET_PN2_EINVAL;
+  if (dwx != nullptr && (xyz == nullptr || new_xyz == nullptr || group_nsample <= 0 || p % group_nsample))
+    return ISTNET_PN2_EINVAL;
   const size_t lds = (size_t)kScatterCH * n * 4;
   if (lds > 64 * 1024) return ISTNET_PN2_EINVAL;
   GradSrc gs{d_dense, d_pooled, arg, nsample, pooled_bstride > 0 ? pooled_bstride : (long long)GS_C * (nsample > 0 ? p / nsample : 0), GS_C};
   hipLaunchKernelGGL(pw_scatter_dy_kernel, dim3(ceil_div(cout, kScatterCH), b), dim3(256), lds,
                      as_stream(stream), cout, n, p, y, gs, bn, bwdc, idx, out,
-                     out_bstride > 0 ? out_bstride : (long long)cout * n);
+                     out_bstride > 0 ? out_bstride : (long long)cout * n, xyz, new_xyz,
+                     group_nsample > 0 ? group_nsample : 1, dwx);
   return (int)hipGetLastError();
 }
 

@@ -341,6 +341,7 @@ def _backward_stack(lib, dev, st, b, c0, g, s, x, gather, training, ys, bns, par
     ntb = lib.istnet_pw_bwd_stat_tiles(b, p)
     fused_part, fused_nt = None, 0   # statistics of layer li already reduced by the dgrad of layer li+1
     wjobs = []                       # weight-gradient launches of the stack: (launch(stream) -> (n, splits, ws, dw))
+    wlayers = []                     # layer index of each job
     for li in range(n - 1, -1, -1):
         w, gamma = params[3 * li], params[3 * li + 1]
         cout = w.shape[0]
@@ -373,6 +374,9 @@ def _backward_stack(lib, dev, st, b, c0, g, s, x, gather, training, ys, bns, par
         grads[3 * li + 1] = dgamma
         grads[3 * li + 2] = dbeta
         use_gather = li == 0 and gather is not None
+        # layer 0 of a scale inside a fused level: dW0 comes from the scattered dY0 (see FusedSALevelFunction)
+        split_w0 = (use_gather and need_w[0] and need_x and scatter_out is not None and gather.n <= 4096
+                    and gather.cfeat > 0 and USE_SPLIT_LAYER0 and _native.TIMING is None)
         if (li > 0 and need_w[li] and USE_FUSED_SMALL_BWD and _native.TIMING is None
                 and lib.istnet_pw_bwd_small_ok(cin, cout, p)):
             # small layer: dA_{l-1}, its statistics partials and the dW partials from ONE pass over (y, g, y_{l-1})
@@ -385,12 +389,14 @@ def _backward_stack(lib, dev, st, b, c0, g, s, x, gather, training, ys, bns, par
                 dd, dp, pbs, da, bn.data_ptr(), bwdc.data_ptr(), dprev.data_ptr(), fused_part[0].data_ptr(),
                 fused_part[1].data_ptr(), ws.data_ptr(), st), "pw_bwd_small")
             wjobs.append(_reduce_only_job(dev, w, cout, cin, splits, ws))
+            wlayers.append(li)
             d_dense, d_pooled, d_arg = dprev, None, None
             continue
-        if need_w[li]:
+        if need_w[li] and not split_w0:
             wjobs.append(_wgrad_job(lib, dev, b, cin, cout, p, ns_arg, use_gather, gather,
                                     x if li == 0 else ys[li - 1], None if li == 0 else bns[li - 1], y,
                                     d_dense, d_pooled, pbs, d_arg, bn, bwdc, grad_elems, w))
+            wlayers.append(li)
         if use_gather and need_x and gather.n <= 4096:
             # feature gradient of the scale: scatter dY0 over the ball indices (Cout0 x n per cloud), then
             # the small product W0[:, 3:]^T . G  (see pw_scatter_dy_kernel) -- no (B, C, P) tensor, no big dgrad
@@ -401,9 +407,13 @@ def _backward_stack(lib, dev, st, b, c0, g, s, x, gather, training, ys, bns, par
             else:
                 gbuf, goff = scatter_out
                 gptr, gbs = gbuf.data_ptr() + goff * ga.n * 4, gbuf.shape[1] * ga.n
+            dwx = _empty((b, cout, 3), torch.float32, dev) if split_w0 else None
             _native.check(lib.istnet_pw_scatter_dy(b, cout, ga.n, p, ns_arg, y.data_ptr(), dd, dp, pbs, da,
-                                                   bn.data_ptr(), bwdc.data_ptr(), ga.idx.data_ptr(), gptr, gbs, st),
+                                                   bn.data_ptr(), bwdc.data_ptr(), ga.idx.data_ptr(), gptr, gbs,
+                                                   ga.xyz.data_ptr(), ga.new_xyz.data_ptr(), ga.nsample, _p(dwx), st),
                           "pw_scatter_dy")
+            if split_w0:
+                grads[0] = dwx          # placeholder: the level node turns it into dW0 (see _finish_layer0_grads)
             if scatter_out is None:
                 dx = torch.matmul(w2[:, 3:].t(), gmat)      # (C, Cout0) @ (B, Cout0, n) -> (B, C, n)
             scattered = True
@@ -426,7 +436,7 @@ def _backward_stack(lib, dev, st, b, c0, g, s, x, gather, training, ys, bns, par
             if li == 0:
                 dx = dprev
     if wjobs:
-        wparams = [params[3 * li] for li in range(n) if need_w[li]]
+        wparams = [params[3 * li] for li in wlayers]
         if _can_defer(wparams):
             # after the chain, on the wgrad stream; joined by the end-of-backward callback
             cur = torch.cuda.current_stream(dev)
@@ -444,8 +454,7 @@ def _backward_stack(lib, dev, st, b, c0, g, s, x, gather, training, ys, bns, par
         else:
             done = [job(st) for job in wjobs]
             _native.reduce_multi([(cnt, splits, ws.data_ptr(), dw.data_ptr()) for cnt, splits, ws, dw in done], st)
-        order = [li for li in range(n - 1, -1, -1) if need_w[li]]   # jobs were queued from the last layer down
-        for li, (_, _, _, dw) in zip(order, done):
+        for li, (_, _, _, dw) in zip(wlayers, done):
             grads[3 * li] = dw.view_as(params[3 * li])
     return grads, dx, scattered
 
@@ -562,7 +571,8 @@ class FusedSALevelFunction(Function):
         out = _empty((b, ctot, g), torch.float32, dev)
         saved, meta, coff = [], [], 0
         # point-major copy of the features (one small transpose per level) for contiguous neighbour gathers
-        feat_t = feat.transpose(1, 2).contiguous() if (feat is not None and feat.shape[1] % 16 == 0) else None
+        feat_t = (feat.transpose(1, 2).contiguous()
+                  if (feat is not None and feat.shape[1] % 16 == 0 and not USE_SPLIT_LAYER0) else None)
         with torch.cuda.device(dev):
             streams = _scale_streams(dev, len(scales))
             for layers, params, idx, stream in zip(scales, plist, idxs, streams):
@@ -644,8 +654,56 @@ class FusedSALevelFunction(Function):
                     b, 3 + cfeat, 3, cfeat, cout0_tot, n_src, 0, wcat.data_ptr(), gbuf.data_ptr(), gbuf.data_ptr(),
                     None, 0, None, ident.data_ptr(), bwdc.data_ptr(), dfeat.data_ptr(), None, None, None, None, st),
                     "pw_dgrad(level)")
+                # layer-0 weight gradients of the scales that left a dwx placeholder: dW0[:, 3:] = sum_b G[b].feat[b]^T
+                # -- ONE wgrad over the n source points for all scales (gbuf holds every scale's G) -- and
+                # dW0[:, :3] = sum_b dwx[b]; off the critical path like the other weight gradients
+                w0_slots, pos_g = [], 0
+                for i, (nl, _, _, _) in enumerate(meta):
+                    gi = sum(3 * m[0] for m in meta[:i])
+                    if grads_all[gi] is not None and grads_all[gi].dim() == 3 and grads_all[gi].shape[-1] == 3:
+                        w0_slots.append((gi, pos_g, params_all[gi]))
+                    pos_g += params_all[gi].shape[0]
+                if w0_slots:
+                    _finish_layer0_grads(lib, dev, b, cfeat, cout0_tot, n_src, feat, gbuf, ident, bwdc, w0_slots,
+                                         grads_all)
             _native.mark(f"bwd SA(g={g}) chains done")
         return (dfeat, None, None, None, None, *([None] * nsc), *grads_all)
+
+
+def _finish_layer0_grads(lib, dev, b, cfeat, cout0_tot, n_src, feat, gbuf, ident, bwdc, w0_slots, grads_all):
+    """dW0 of every scale of a level from the scattered dY0 (gbuf, (B, sum Cout0, n)) and the per-cloud xyz partials
+    left in grads_all as placeholders.  Runs on the deferred-wgrad stream when the engine allows it."""
+    params = [p for _, _, p in w0_slots]
+    placeholders = [grads_all[gi] for gi, _, _ in w0_slots]
+    dests = [_grad_dest(p, (p.shape[0], 3 + cfeat), dev) for p in params]
+    for (gi, _, p), d in zip(w0_slots, dests):
+        grads_all[gi] = d.view_as(p)
+
+    def work(wst):
+        splits = lib.istnet_pw_wgrad_splits(b, cfeat, cout0_tot, n_src)
+        ws = _empty((splits, cout0_tot, cfeat), torch.float32, dev)
+        dwf = _empty((cout0_tot, cfeat), torch.float32, dev)
+        _native.check(lib.istnet_pw_wgrad(b, cfeat, cout0_tot, n_src, 0, feat.data_ptr(), None, None, gbuf.data_ptr(),
+                                          gbuf.data_ptr(), None, 0, None, ident.data_ptr(), bwdc.data_ptr(),
+                                          ws.data_ptr(), wst), "pw_wgrad(level G)")
+        _native.reduce_multi([(cout0_tot * cfeat, splits, ws.data_ptr(), dwf.data_ptr())], wst)
+        for (gi, row0, p), dwx, dest in zip(w0_slots, placeholders, dests):
+            torch.cat([dwx.sum(dim=0), dwf[row0:row0 + p.shape[0]]], dim=1, out=dest)
+        return ws, dwf
+
+    if _can_defer(params):
+        cur = torch.cuda.current_stream(dev)
+        key, wstream = _Deferred.stream(dev, cur)
+        _Deferred.mains.setdefault(key, cur)
+        wstream.wait_stream(cur)
+        with torch.cuda.stream(wstream):
+            kept = work(wstream.cuda_stream)
+        _Deferred.keep += [kept, placeholders, gbuf, feat, dests]
+        if not _Deferred.armed:
+            torch.autograd.Variable._execution_engine.queue_callback(_Deferred.flush)
+            _Deferred.armed = True
+    else:
+        work(torch.cuda.current_stream(dev).cuda_stream)
 
 
 _ONES = {}
