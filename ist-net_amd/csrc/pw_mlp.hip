@@ -348,6 +348,8 @@ __global__ __launch_bounds__(kThreads) void pw_fwd_kernel(
 // point, loop over the output channels, per-channel sum / sum-of-squares partials for the BatchNorm.
 // grid (ceil(P / 256), B); partials [cout][B * tiles].
 // ============================================================================================
+constexpr int kGatherAddCO = 32;   // output channels per workgroup (grid.z): keeps enough waves in flight for the
+                                   // deep levels, where a cloud has only a few 256-point tiles
 __global__ __launch_bounds__(256) void pw_gather_add_kernel(int n, int P, int S, int cout, int ldw,
                                                             const float* __restrict__ xyz,
                                                             const float* __restrict__ new_xyz,
@@ -356,11 +358,12 @@ __global__ __launch_bounds__(256) void pw_gather_add_kernel(int n, int P, int S,
                                                             const float* __restrict__ w0,
                                                             float* __restrict__ y, float* __restrict__ part_sum,
                                                             float* __restrict__ part_sq, int nt_total) {
-  extern __shared__ float ga_lds[];          // [cout][3] xyz weights, then [4 waves][cout][2] statistics
-  float* wx = ga_lds;
-  float* red = ga_lds + 3 * cout;
+  __shared__ float wx[kGatherAddCO * 3];          // xyz weights of this channel chunk
+  __shared__ float red[4][kGatherAddCO][2];       // per-wave statistics
   const int b = blockIdx.y, tid = threadIdx.x;
-  for (int i = tid; i < 3 * cout; i += 256) wx[i] = w0[(size_t)(i / 3) * ldw + (i % 3)];
+  const int c0 = blockIdx.z * kGatherAddCO;
+  const int nco = min(kGatherAddCO, cout - c0);
+  if (tid < nco * 3) wx[tid] = w0[(size_t)(c0 + tid / 3) * ldw + (tid % 3)];
   const int p = blockIdx.x * 256 + tid;
   const bool valid = p < P;
   const int pc = valid ? p : P - 1;
@@ -368,27 +371,36 @@ __global__ __launch_bounds__(256) void pw_gather_add_kernel(int n, int P, int S,
   const float* xs = xyz + ((size_t)b * n + src) * 3;
   const float* xc = new_xyz + ((size_t)b * (P / S) + pc / S) * 3;
   const float dx = xs[0] - xc[0], dy = xs[1] - xc[1], dz = xs[2] - xc[2];
-  const float* zb = z + (size_t)b * cout * n + src;
-  float* yb = y + (size_t)b * cout * P + pc;
+  const float* zb = z + ((size_t)b * cout + c0) * n + src;
+  float* yb = y + ((size_t)b * cout + c0) * P + pc;
   __syncthreads();
   const int wv = tid >> 6;
-  for (int co = 0; co < cout; ++co) {
-    float v = zb[(size_t)co * n] + ((wx[3 * co] * dx + wx[3 * co + 1] * dy) + wx[3 * co + 2] * dz);
-    if (valid) yb[(size_t)co * P] = v; else v = 0.f;
-    if (part_sum != nullptr) {
-      const float s = wave_sum(v), q = wave_sum(v * v);
-      if ((tid & 63) == 0) { red[(wv * cout + co) * 2] = s; red[(wv * cout + co) * 2 + 1] = q; }
+  const bool stats = part_sum != nullptr;
+  for (int co = 0; co < nco; co += 4) {
+    float zv[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) zv[j] = zb[(size_t)min(co + j, nco - 1) * n];   // four gathers in flight
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      if (co + j < nco) {
+        const int c = co + j;
+        float v = zv[j] + ((wx[3 * c] * dx + wx[3 * c + 1] * dy) + wx[3 * c + 2] * dz);
+        if (valid) yb[(size_t)c * P] = v; else v = 0.f;
+        if (stats) {
+          const float s = wave_sum(v), q = wave_sum(v * v);
+          if ((tid & 63) == 0) { red[wv][c][0] = s; red[wv][c][1] = q; }
+        }
+      }
     }
   }
-  if (part_sum != nullptr) {
+  if (stats) {
     __syncthreads();
     const int tile = b * gridDim.x + blockIdx.x;
-    for (int co = tid; co < cout; co += 256) {
-      float s = 0.f, q = 0.f;
-#pragma unroll
-      for (int k = 0; k < 4; ++k) { s += red[(k * cout + co) * 2]; q += red[(k * cout + co) * 2 + 1]; }
-      part_sum[(size_t)co * nt_total + tile] = s;
-      part_sq[(size_t)co * nt_total + tile] = q;
+    if (tid < nco) {
+      const float s = (red[0][tid][0] + red[1][tid][0]) + (red[2][tid][0] + red[3][tid][0]);
+      const float q = (red[0][tid][1] + red[1][tid][1]) + (red[2][tid][1] + red[3][tid][1]);
+      part_sum[(size_t)(c0 + tid) * nt_total + tile] = s;
+      part_sq[(size_t)(c0 + tid) * nt_total + tile] = q;
     }
   }
 }
@@ -1574,10 +1586,8 @@ int istnet_pw_gather_add(int b, int n, int npoint, int nsample, int cout, const 
                          float* part_sq, void* stream) {
   if (b <= 0 || n <= 0 || npoint <= 0 || nsample <= 0 || cout <= 0 || ldw < 3) return ISTNET_PN2_EINVAL;
   const int p = npoint * nsample;
-  const size_t lds = (size_t)(3 * cout + 4 * cout * 2) * sizeof(float);
-  if (lds > 64 * 1024) return ISTNET_PN2_EINVAL;
-  const dim3 grid(ceil_div(p, 256), b);
-  hipLaunchKernelGGL(pw_gather_add_kernel, grid, dim3(256), lds, as_stream(stream), n, p, nsample, cout, ldw, xyz,
+  const dim3 grid(ceil_div(p, 256), b, ceil_div(cout, kGatherAddCO));
+  hipLaunchKernelGGL(pw_gather_add_kernel, grid, dim3(256), 0, as_stream(stream), n, p, nsample, cout, ldw, xyz,
                      new_xyz, idx, z, w0, y, part_sum, part_sq, (int)(grid.x * b));
   return (int)hipGetLastError();
 }
