@@ -44,6 +44,7 @@ class GeometrySlot:
         self.fp = None       # per FP level: (idx, weight, csr or None)
         self.event = None    # recorded on the geometry stream after the last write (eager mode)
         self.shape = None
+        self.flat = None     # dtype -> flat storage the tensors above are views of
 
     def tensors(self):
         out = []
@@ -121,13 +122,24 @@ class PointNet2MSG(nn.Module):
             fresh = GeometrySlot()
             fresh.sa = [(new_xyz, list(idx)) for new_xyz, idx, _ in sa_geo]
             fresh.fp = [(idx, weight, csr) for idx, weight, csr, _ in fp_geo]
+            src = fresh.tensors()
             if slot.sa is None or slot.shape != tuple(xyz.shape):
-                slot.sa = [(nx.clone(), [i.clone() for i in idx]) for nx, idx in fresh.sa]
-                slot.fp = [(i.clone(), w.clone(), tuple(c.clone() for c in csr) if csr is not None else None)
-                           for i, w, csr in fresh.fp]
+                # persistent storage: one flat buffer per dtype, the slot's tensors are views into them, so a refill
+                # is two pack kernels instead of one copy per tensor
+                slot.flat = {dt: torch.empty(sum(t.numel() for t in src if t.dtype == dt), dtype=dt, device=xyz.device)
+                             for dt in {t.dtype for t in src}}
+                off = {dt: 0 for dt in slot.flat}
+                views = []
+                for t in src:
+                    views.append(slot.flat[t.dtype][off[t.dtype]:off[t.dtype] + t.numel()].view(t.shape))
+                    off[t.dtype] += t.numel()
+                it = iter(views)
+                slot.sa = [(next(it), [next(it) for _ in idxs]) for _, idxs in fresh.sa]
+                slot.fp = [(next(it), next(it), (next(it), next(it)) if csr is not None else None)
+                           for _, _, csr in fresh.fp]
                 slot.shape = tuple(xyz.shape)
-            else:
-                torch._foreach_copy_(slot.tensors(), fresh.tensors())
+            for dt, flat in slot.flat.items():
+                torch.cat([t.reshape(-1) for t in src if t.dtype == dt], out=flat)
             if not torch.cuda.is_current_stream_capturing():
                 slot.event = torch.cuda.Event()
                 slot.event.record(side)
