@@ -51,7 +51,7 @@ ISTNET_PN2_API int istnet_pw_forward_ld(int b, int cin, int cout, int p, const f
 /* Layer 0 of a set-abstraction scale split by linearity: with z = W0[:, 3:] . feat (b, cout, n) computed over the
  * n SOURCE points (istnet_pw_forward_ld), y[b][co][p] = z[b][co][idx[p]] + W0[co][0:3] . (xyz[idx[p]] - new_xyz[p / nsample]),
  * plus the per-channel partials of sum(y), sum(y*y) ([cout][istnet_pw_gather_add_tiles(b, p)], may be NULL).
- * w0 is (cout, ldw) row-major, its first three columns are the xyz weights. */
+ * w0 is (cout, ldw) row-major, its first three columns are the xyz weights.  z == NULL: xyz-only layer (no features). */
 ISTNET_PN2_API int istnet_pw_gather_add_tiles(int b, int p);
 ISTNET_PN2_API int istnet_pw_gather_add(int b, int n, int npoint, int nsample, int cout, const float *xyz,
                                         const float *new_xyz, const int *idx, const float *z, const float *w0,
@@ -130,7 +130,10 @@ ISTNET_PN2_API int istnet_pw_dgrad(int b, int cin_total, int ci_off, int m_rows,
  * The same `out` also gives the layer-0 weight gradient without a pass over the grouped points:
  *   dW0[:, 3:] = sum_b out[b] . feat[b]^T  (a wgrad over the n source points), and, when dwx != NULL, this call
  *   also writes dwx[b][co][k] = sum_p dY[b][co][p] * (xyz[b][idx[p]][k] - new_xyz[b][p / group_nsample][k]),
- *   whose sum over b is dW0[:, 0:3]. */
+ *   whose sum over b is dW0[:, 0:3].
+ * out == NULL (xyz-only layer 0, no feature gradient wanted): only dwx is produced, no scatter; the points of a
+ * cloud are then split over istnet_pw_dwx_chunks(b, cout, p) workgroups and dwx is (b * chunks, cout, 3). */
+ISTNET_PN2_API int istnet_pw_dwx_chunks(int b, int cout, int p);
 ISTNET_PN2_API int istnet_pw_scatter_dy(int b, int cout, int n, int p, int nsample, const float *y,
                                         const float *d_dense, const float *d_pooled, long long pooled_bstride,
                                         const unsigned char *arg, const float *bn, const float *bwdc,

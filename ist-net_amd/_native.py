@@ -52,6 +52,7 @@ SIGNATURES = {
     "istnet_bn_finalize_bwd": [_i, _i, _d, _i, _p, _p, _p, _p, _p, _p, _p, _p],
     "istnet_pw_dgrad_stat_tiles": [_i, _i, _i],
     "istnet_pw_dgrad": [_i, _i, _i, _i, _i, _i, _i, _p, _p, _p, _p, _l, _p, _p, _p, _p, _p, _p, _p, _p, _p],
+    "istnet_pw_dwx_chunks": [_i, _i, _i],
     "istnet_pw_scatter_dy": [_i, _i, _i, _i, _i, _p, _p, _p, _l, _p, _p, _p, _p, _p, _l, _p, _p, _i, _p, _p],
     "istnet_pw_bwd_small_ok": [_i, _i, _i],
     "istnet_pw_bwd_small_splits": [_i, _i],

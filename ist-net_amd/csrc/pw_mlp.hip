@@ -379,7 +379,7 @@ __global__ __launch_bounds__(256) void pw_gather_add_kernel(int n, int P, int S,
   for (int co = 0; co < nco; co += 4) {
     float zv[4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) zv[j] = zb[(size_t)min(co + j, nco - 1) * n];   // four gathers in flight
+    for (int j = 0; j < 4; ++j) zv[j] = z != nullptr ? zb[(size_t)min(co + j, nco - 1) * n] : 0.f;   // four gathers in flight
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       if (co + j < nco) {
@@ -730,10 +730,16 @@ __global__ __launch_bounds__(256) void pw_scatter_dy_kernel(int cout, int n, int
   extern __shared__ __attribute__((aligned(16))) float acc[];  // [CH][n]
   const int b = blockIdx.y, c0 = blockIdx.x * kScatterCH;
   const int nch = min(kScatterCH, cout - c0);
-  for (int i = threadIdx.x; i < nch * n; i += 256) acc[i] = 0.f;
-  __syncthreads();
+  const bool scatter = out != nullptr;   // false: only the xyz-weight partials are wanted (no LDS image, no atomics)
+  if (scatter) {
+    for (int i = threadIdx.x; i < nch * n; i += 256) acc[i] = 0.f;
+    __syncthreads();
+  }
   const int* idx = idx_all + (size_t)b * P;
-  const int Pr = (P + 255) / 256 * 256;  // whole waves stay converged for the DPP scan
+  // gridDim.z > 1 (dwx-only mode) splits the points of a cloud over workgroups
+  const int pchunk = ((P + (int)gridDim.z - 1) / (int)gridDim.z + 255) / 256 * 256;
+  const int pbeg = blockIdx.z * pchunk;
+  const int Pr = min(pbeg + pchunk, (P + 255) / 256 * 256);  // whole waves stay converged for the DPP scan
   const int G = gs.dense == nullptr ? P / gs.S : 0;
   // One 256-slot step per iteration; the loads of step t+1 (index + y + gradient of every channel) are issued
   // before step t is reduced, otherwise each step pays a full HBM round trip (the kernel was latency-bound:
@@ -766,8 +772,8 @@ __global__ __launch_bounds__(256) void pw_scatter_dy_kernel(int cout, int n, int
       }
     }
   };
-  prefetch(threadIdx.x);
-  for (int p = threadIdx.x; p < Pr; p += 256) {
+  prefetch(pbeg + threadIdx.x);
+  for (int p = pbeg + threadIdx.x; p < Pr; p += 256) {
     const bool valid = p < P;
     const int ii = ii_n;
     float yv_c[kScatterCH], d_c[kScatterCH];
@@ -794,12 +800,13 @@ __global__ __launch_bounds__(256) void pw_scatter_dy_kernel(int cout, int n, int
         pv = dpp_row_f<0x112>(v); pf = dpp_row_i<0x112>(1, f); v = f ? v : v + pv; f |= pf;
         pv = dpp_row_f<0x114>(v); pf = dpp_row_i<0x114>(1, f); v = f ? v : v + pv; f |= pf;
         pv = dpp_row_f<0x118>(v); pf = dpp_row_i<0x118>(1, f); v = f ? v : v + pv; f |= pf;
-        if (valid && tail) atomicAdd(&acc[ch * n + ii], v);
+        if (scatter && valid && tail) atomicAdd(&acc[ch * n + ii], v);
       }
     }
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < nch * n; i += 256) out[(size_t)b * out_bstride + (size_t)c0 * n + i] = acc[i];
+  if (scatter)
+    for (int i = threadIdx.x; i < nch * n; i += 256) out[(size_t)b * out_bstride + (size_t)c0 * n + i] = acc[i];
   if (dwx != nullptr) {   // workgroup sum of the xyz-weight partials -> dwx[b][co][0:3]
     __shared__ float wred[4][kScatterCH * 3];
 #pragma unroll
@@ -811,7 +818,7 @@ __global__ __launch_bounds__(256) void pw_scatter_dy_kernel(int cout, int n, int
       }
     __syncthreads();
     if (threadIdx.x < nch * 3)
-      dwx[((size_t)b * cout + c0) * 3 + threadIdx.x] = (wred[0][threadIdx.x] + wred[1][threadIdx.x]) +
+      dwx[(((size_t)b * gridDim.z + blockIdx.z) * cout + c0) * 3 + threadIdx.x] = (wred[0][threadIdx.x] + wred[1][threadIdx.x]) +
                                                         (wred[2][threadIdx.x] + wred[3][threadIdx.x]);
   }
 }
@@ -1715,6 +1722,15 @@ int istnet_pw_dgrad(int b, int cin_total, int ci_off, int m_rows, int cout, int 
   return (int)hipGetLastError();
 }
 
+// dwx-only mode of istnet_pw_scatter_dy (out == NULL): point chunks per cloud so that ~1024 workgroups run
+int istnet_pw_dwx_chunks(int b, int cout, int p) {
+  const int wgs = b * ceil_div(cout, kScatterCH);
+  int chunks = ceil_div(1024, wgs > 0 ? wgs : 1);
+  const int maxc = ceil_div(p, 1024);   // at least four 256-point steps per workgroup
+  if (chunks > maxc) chunks = maxc;
+  return chunks < 1 ? 1 : chunks;
+}
+
 int istnet_pw_scatter_dy(int b, int cout, int n, int p, int nsample, const float* y, const float* d_dense,
                          const float* d_pooled, long long pooled_bstride, const unsigned char* arg,
                          const float* bn, const float* bwdc, const int* idx, float* out, long long out_bstride,
@@ -1724,10 +1740,12 @@ int istnet_pw_scatter_dy(int b, int cout, int n, int p, int nsample, const float
   if (d_dense == nullptr && (d_pooled == nullptr || arg == nullptr || nsample <= 0)) return ISTNET_PN2_EINVAL;
   if (dwx != nullptr && (xyz == nullptr || new_xyz == nullptr || group_nsample <= 0 || p % group_nsample))
     return ISTNET_PN2_EINVAL;
-  const size_t lds = (size_t)kScatterCH * n * 4;
+  if (out == nullptr && dwx == nullptr) return ISTNET_PN2_EINVAL;
+  const size_t lds = out != nullptr ? (size_t)kScatterCH * n * 4 : 0;
   if (lds > 64 * 1024) return ISTNET_PN2_EINVAL;
+  const int chunks = out != nullptr ? 1 : istnet_pw_dwx_chunks(b, cout, p);
   GradSrc gs{d_dense, d_pooled, arg, nsample, pooled_bstride > 0 ? pooled_bstride : (long long)GS_C * (nsample > 0 ? p / nsample : 0), GS_C};
-  hipLaunchKernelGGL(pw_scatter_dy_kernel, dim3(ceil_div(cout, kScatterCH), b), dim3(256), lds,
+  hipLaunchKernelGGL(pw_scatter_dy_kernel, dim3(ceil_div(cout, kScatterCH), b, chunks), dim3(256), lds,
                      as_stream(stream), cout, n, p, y, gs, bn, bwdc, idx, out,
                      out_bstride > 0 ? out_bstride : (long long)cout * n, xyz, new_xyz,
                      group_nsample > 0 ? group_nsample : 1, dwx);

@@ -173,19 +173,22 @@ def _forward_stack(lib, dev, st, b, c0, g, s, x, gather, training, layers, param
             nt, ps, pq = 0, None, None
         kname = _kname("pw_fwd_kernel", lib.istnet_pw_tile_cfg(b, cout, p), gather is not None and li == 0)
         flops, nbytes = 2.0 * b * p * cur_c * cout, 4.0 * b * p * (cur_c + cout)
-        if li == 0 and gather is not None and gather.cfeat > 0 and USE_SPLIT_LAYER0 and _native.TIMING is None:
+        if li == 0 and gather is not None and USE_SPLIT_LAYER0 and _native.TIMING is None:
             # layer 0 by linearity: Z = W0[:, 3:] . feat over the n source points (nsample*npoint/n times fewer MACs
-            # than over the grouped points), then y0 = Z[:, idx] + W0[:, :3] . (xyz[idx] - centre)
+            # than over the grouped points), then y0 = Z[:, idx] + W0[:, :3] . (xyz[idx] - centre); an xyz-only
+            # layer (level 1) is just the second term
             ga = gather
-            z = _empty((b, cout, ga.n), torch.float32, dev)
-            _native.check(lib.istnet_pw_forward_ld(b, ga.cfeat, cout, ga.n, ga.feat.data_ptr(), w2.data_ptr() + 12,
-                                                   cur_c, None, None, z.data_ptr(), None, None, st), "pw_forward_ld")
+            z = None
+            if ga.cfeat > 0:
+                z = _empty((b, cout, ga.n), torch.float32, dev)
+                _native.check(lib.istnet_pw_forward_ld(b, ga.cfeat, cout, ga.n, ga.feat.data_ptr(), w2.data_ptr() + 12,
+                                                       cur_c, None, None, z.data_ptr(), None, None, st), "pw_forward_ld")
             if ps is not None:
                 nt = lib.istnet_pw_gather_add_tiles(b, p)
                 part = _empty((2, cout, nt), torch.float32, dev)
                 ps, pq = part[0].data_ptr(), part[1].data_ptr()
             _native.check(lib.istnet_pw_gather_add(b, ga.n, ga.npoint, ga.nsample, cout, ga.xyz.data_ptr(),
-                                                   ga.new_xyz.data_ptr(), ga.idx.data_ptr(), z.data_ptr(),
+                                                   ga.new_xyz.data_ptr(), ga.idx.data_ptr(), _p(z),
                                                    w2.data_ptr(), cur_c, y.data_ptr(), ps, pq, st), "pw_gather_add")
         elif li == 0 and gather is not None:
             ga = gather
@@ -316,6 +319,21 @@ USE_FUSED_SMALL_BWD = os.environ.get("ISTNET_NO_FUSED_SMALL_BWD") is None
 USE_SPLIT_LAYER0 = os.environ.get("ISTNET_NO_SPLIT_LAYER0") is None
 
 
+def _dwx_only_job(lib, dev, b, cout, p, ns_arg, ga, y, d_dense, d_pooled, pbs, d_arg, bn, bwdc, wparam):
+    """Weight gradient of an xyz-only layer 0: per-(cloud, point chunk) partials of sum_p dY0 * xrel from the
+    scatter kernel in its dwx-only mode; the batched reduce sums them into dW0 (cout, 3)."""
+    def launch(wst):
+        chunks = lib.istnet_pw_dwx_chunks(b, cout, p)
+        ws = _empty((b * chunks, cout, 3), torch.float32, dev)
+        dw = _grad_dest(wparam, (cout, 3), dev)
+        _native.check(lib.istnet_pw_scatter_dy(b, cout, ga.n, p, ns_arg, y.data_ptr(), _p(d_dense), _p(d_pooled), pbs,
+                                               _p(d_arg), bn.data_ptr(), bwdc.data_ptr(), ga.idx.data_ptr(), None, 0,
+                                               ga.xyz.data_ptr(), ga.new_xyz.data_ptr(), ga.nsample, ws.data_ptr(),
+                                               wst), "pw_scatter_dy(dwx)")
+        return cout * 3, b * chunks, ws, dw
+    return launch
+
+
 def _reduce_only_job(dev, wparam, cout, cin, splits, ws):
     """wgrad job whose partials already exist (written by the fused backward kernel): only the reduce is left."""
     def launch(wst):
@@ -392,7 +410,12 @@ def _backward_stack(lib, dev, st, b, c0, g, s, x, gather, training, ys, bns, par
             wlayers.append(li)
             d_dense, d_pooled, d_arg = dprev, None, None
             continue
-        if need_w[li] and not split_w0:
+        if (use_gather and need_w[0] and gather.cfeat == 0 and USE_SPLIT_LAYER0 and _native.TIMING is None):
+            # xyz-only layer 0 (level 1): dW0 = sum_p dY0[:, p] * xrel[p], a reduction over (y0, dA0) -- no GEMM
+            wjobs.append(_dwx_only_job(lib, dev, b, cout, p, ns_arg, gather, y, d_dense, d_pooled, pbs, d_arg, bn,
+                                       bwdc, w))
+            wlayers.append(li)
+        elif need_w[li] and not split_w0:
             wjobs.append(_wgrad_job(lib, dev, b, cin, cout, p, ns_arg, use_gather, gather,
                                     x if li == 0 else ys[li - 1], None if li == 0 else bns[li - 1], y,
                                     d_dense, d_pooled, pbs, d_arg, bn, bwdc, grad_elems, w))
