@@ -48,6 +48,20 @@ ISTNET_PN2_API int istnet_pw_forward_ld(int b, int cin, int cout, int p, const f
                                         const float *in_scale, const float *in_shift, float *y,
                                         float *part_sum, float *part_sq, void *stream);
 
+/* y = c_init + w . x (no input activation): the accumulators start from the (b, cout, p) tensor c_init.  Used by the
+ * feature-propagation layer 0, y0 = interpolate(Wa . known) + Wb . skip. */
+ISTNET_PN2_API int istnet_pw_forward_acc(int b, int cin, int cout, int p, const float *x, const float *w, int ldw,
+                                         const float *c_init, float *y, float *part_sum, float *part_sq,
+                                         void *stream);
+
+/* BatchNorm statistics partials of an arbitrary (b, c, p) tensor: part_sum / part_sq [c][istnet_pw_bwd_stat_tiles(b, p)] */
+ISTNET_PN2_API int istnet_pw_channel_stats(int b, int c, int p, const float *y, float *part_sum, float *part_sq,
+                                           void *stream);
+
+/* out = dY = bwdc[0]*(d_dense*[relu(bn(y)) > 0]) + bwdc[1] + bwdc[2]*y, materialised (b, c, p) */
+ISTNET_PN2_API int istnet_pw_dy(int b, int c, int p, const float *y, const float *d_dense, const float *bn,
+                                const float *bwdc, float *out, void *stream);
+
 /* Layer 0 of a set-abstraction scale split by linearity: with z = W0[:, 3:] . feat (b, cout, n) computed over the
  * n SOURCE points (istnet_pw_forward_ld), y[b][co][p] = z[b][co][idx[p]] + W0[co][0:3] . (xyz[idx[p]] - new_xyz[p / nsample]),
  * plus the per-channel partials of sum(y), sum(y*y) ([cout][istnet_pw_gather_add_tiles(b, p)], may be NULL).

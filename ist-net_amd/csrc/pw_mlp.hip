@@ -160,7 +160,8 @@ template <int M_T, int N_T, int WM, int WN, int GATHER>  // 0: x is a tensor, 1:
 __global__ __launch_bounds__(kThreads) void pw_fwd_kernel(
     int cin, int cout, int P, int tiles_per_cloud, const float* __restrict__ x, GatherSrc gsrc,
     const float* __restrict__ w, const float* __restrict__ in_scale, const float* __restrict__ in_shift,
-    float* __restrict__ y, float* __restrict__ part_sum, float* __restrict__ part_sq, int nt_total, int ldw) {
+    float* __restrict__ y, float* __restrict__ part_sum, float* __restrict__ part_sq, int nt_total, int ldw,
+    const float* __restrict__ c_init) {
   using T = Tile<M_T, N_T, WM, WN>;
   constexpr int TM = T::TM, TN = T::TN;
   constexpr int NA = kKT * M_T / kThreads;        // scalar weight loads per thread per chunk
@@ -266,6 +267,21 @@ __global__ __launch_bounds__(kThreads) void pw_fwd_kernel(
 
   const int wv = wave_id();
   const int a_col0 = (wv / WN) * TM * 32, b_col0 = (wv % WN) * TN * 32;
+  if (c_init != nullptr) {   // y = c_init + w . act(x): the accumulators start from a (b, cout, P) tensor
+    const float* cb = c_init + (size_t)b * cout * P;
+    const int ln = lane_id();
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = m0 + a_col0 + tm * 32 + mfma_row(r, ln);
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn) {
+          const int col = p0 + b_col0 + tn * 32 + (ln & 31);
+          if (row < cout && col < P) acc[tm][tn][r] = cb[(size_t)row * P + col];
+        }
+      }
+  }
   const int nchunks = (cin + kKT - 1) / kKT;
   ISTNET_TRACE_MARK(0);
   load_chunk(0);
@@ -564,6 +580,51 @@ __device__ __forceinline__ float4 load_grad4(const GradSrc& gs, size_t row, int 
   const float d = pooled_at(gs, row, G, g);
   const int a = gs.arg[row * (size_t)G + g];
   return make_float4(a == k ? d : 0.f, a == k + 1 ? d : 0.f, a == k + 2 ? d : 0.f, a == k + 3 ? d : 0.f);
+}
+
+// per-channel partial sums of y and y*y of a (B, C, P) tensor (BatchNorm statistics of a tensor that was not
+// produced by one of the GEMM kernels).  grid: (chunks_per_row, C, B); partials [C][B*chunks]
+__global__ __launch_bounds__(256) void pw_channel_stats_kernel(int C, int P, const float* __restrict__ y,
+                                                               float* __restrict__ part_sum,
+                                                               float* __restrict__ part_sq, int nt_total) {
+  const int c = blockIdx.y, b = blockIdx.z;
+  const float* row = y + ((size_t)b * C + c) * P;
+  const int pbeg = blockIdx.x * 4096, pend = min(pbeg + 4096, P);
+  float s = 0.f, q = 0.f;
+  for (int p = pbeg + threadIdx.x * 4; p < pend; p += 256 * 4) {
+    const float4 v = *reinterpret_cast<const float4*>(row + p);
+    s += (v.x + v.y) + (v.z + v.w);
+    q += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+  }
+  __shared__ float red[4][2];
+  s = wave_sum(s);
+  q = wave_sum(q);
+  if (lane_id() == 0) { red[wave_id()][0] = s; red[wave_id()][1] = q; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const int t = b * gridDim.x + blockIdx.x;
+    part_sum[(size_t)c * nt_total + t] = (red[0][0] + red[1][0]) + (red[2][0] + red[3][0]);
+    part_sq[(size_t)c * nt_total + t] = (red[0][1] + red[1][1]) + (red[2][1] + red[3][1]);
+  }
+}
+
+// dY = ca * (dA * [relu(bn(y)) > 0]) + cb + cc * y, written out (dense gradient source).  Used where the same dY
+// feeds several small products (feature-propagation layer 0).  grid (ceil(P/4 / 256), B*C)
+__global__ __launch_bounds__(256) void pw_dy_kernel(int C, int P4, const float* __restrict__ y,
+                                                    const float* __restrict__ d, const float* __restrict__ bn,
+                                                    const float* __restrict__ bwdc, float* __restrict__ out) {
+  const int bc = blockIdx.y, c = bc % C;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= P4) return;
+  const float rs = bn[c], rh = bn[C + c], ca = bwdc[c], cb = bwdc[C + c], cc = bwdc[2 * C + c];
+  const float4 v = reinterpret_cast<const float4*>(y + (size_t)bc * P4 * 4)[i];
+  const float4 g = reinterpret_cast<const float4*>(d + (size_t)bc * P4 * 4)[i];
+  float4 o;
+  o.x = ca * ((v.x * rs + rh > 0.f) ? g.x : 0.f) + cb + cc * v.x;
+  o.y = ca * ((v.y * rs + rh > 0.f) ? g.y : 0.f) + cb + cc * v.y;
+  o.z = ca * ((v.z * rs + rh > 0.f) ? g.z : 0.f) + cb + cc * v.z;
+  o.w = ca * ((v.w * rs + rh > 0.f) ? g.w : 0.f) + cb + cc * v.w;
+  reinterpret_cast<float4*>(out + (size_t)bc * P4 * 4)[i] = o;
 }
 
 // per-channel partial sums of g and g * y  (-> dbeta, dgamma after finalize)
@@ -1542,7 +1603,7 @@ int istnet_pw_stat_tiles(int b, int cout, int p) {
 
 static int launch_pw_forward(bool gather, int b, int cin, int cout, int p, const float* x, const GatherSrc& g,
                              const float* w, int ldw, const float* in_scale, const float* in_shift, float* y,
-                             float* part_sum, float* part_sq, void* stream) {
+                             float* part_sum, float* part_sq, void* stream, const float* c_init = nullptr) {
   if (b <= 0 || cin <= 0 || cout <= 0 || p <= 0 || (p & 3)) return ISTNET_PN2_EINVAL;
   const TileCfg cfg = pick_cfg(b, cout, p, g_force_fwd_cfg);
   const int tpc = ceil_div(p, cfg_nt(cfg));
@@ -1553,13 +1614,13 @@ static int launch_pw_forward(bool gather, int b, int cin, int cout, int p, const
   do {                                                                                                      \
     if (mode == 2)                                                                                          \
       hipLaunchKernelGGL((pw_fwd_kernel<MT, NT, WM, WN, 2>), grid, dim3(kThreads), 0, as_stream(stream),    \
-                         cin, cout, p, tpc, x, g, w, in_scale, in_shift, y, part_sum, part_sq, nt, ldw);   \
+                         cin, cout, p, tpc, x, g, w, in_scale, in_shift, y, part_sum, part_sq, nt, ldw, c_init); \
     else if (mode == 1)                                                                                     \
       hipLaunchKernelGGL((pw_fwd_kernel<MT, NT, WM, WN, 1>), grid, dim3(kThreads), 0, as_stream(stream),    \
-                         cin, cout, p, tpc, x, g, w, in_scale, in_shift, y, part_sum, part_sq, nt, ldw);   \
+                         cin, cout, p, tpc, x, g, w, in_scale, in_shift, y, part_sum, part_sq, nt, ldw, c_init); \
     else                                                                                                    \
       hipLaunchKernelGGL((pw_fwd_kernel<MT, NT, WM, WN, 0>), grid, dim3(kThreads), 0, as_stream(stream),    \
-                         cin, cout, p, tpc, x, g, w, in_scale, in_shift, y, part_sum, part_sq, nt, ldw);   \
+                         cin, cout, p, tpc, x, g, w, in_scale, in_shift, y, part_sum, part_sq, nt, ldw, c_init); \
   } while (0)
   switch (cfg) {
     case kCfg128x128: ISTNET_FWD(128, 128, 2, 2); break;
@@ -1584,6 +1645,13 @@ int istnet_pw_forward_ld(int b, int cin, int cout, int p, const float* x, const 
   if (ldw < cin) return ISTNET_PN2_EINVAL;
   return launch_pw_forward(false, b, cin, cout, p, x, GatherSrc{}, w, ldw, in_scale, in_shift, y, part_sum, part_sq,
                            stream);
+}
+
+int istnet_pw_forward_acc(int b, int cin, int cout, int p, const float* x, const float* w, int ldw,
+                          const float* c_init, float* y, float* part_sum, float* part_sq, void* stream) {
+  if (ldw < cin || c_init == nullptr) return ISTNET_PN2_EINVAL;
+  return launch_pw_forward(false, b, cin, cout, p, x, GatherSrc{}, w, ldw, nullptr, nullptr, y, part_sum, part_sq,
+                           stream, c_init);
 }
 
 int istnet_pw_gather_add_tiles(int b, int p) { return b * ceil_div(p, 256); }
@@ -1662,6 +1730,22 @@ int istnet_affine_apply(int b, int c, int p, int relu, const float* y, const flo
 }
 
 int istnet_pw_bwd_stat_tiles(int b, int p) { return b * ceil_div(p, kStatChunk); }
+
+int istnet_pw_channel_stats(int b, int c, int p, const float* y, float* part_sum, float* part_sq, void* stream) {
+  if (b <= 0 || c <= 0 || p <= 0 || (p & 3)) return ISTNET_PN2_EINVAL;
+  const dim3 grid(ceil_div(p, 4096), c, b);   // partials [c][istnet_pw_bwd_stat_tiles(b, p)]
+  hipLaunchKernelGGL(pw_channel_stats_kernel, grid, dim3(256), 0, as_stream(stream), c, p, y, part_sum, part_sq,
+                     (int)(grid.x * b));
+  return (int)hipGetLastError();
+}
+
+int istnet_pw_dy(int b, int c, int p, const float* y, const float* d_dense, const float* bn, const float* bwdc,
+                 float* out, void* stream) {
+  if (b <= 0 || c <= 0 || p <= 0 || (p & 3)) return ISTNET_PN2_EINVAL;
+  hipLaunchKernelGGL(pw_dy_kernel, dim3(ceil_div(p / 4, 256), b * c), dim3(256), 0, as_stream(stream), c, p / 4, y,
+                     d_dense, bn, bwdc, out);
+  return (int)hipGetLastError();
+}
 
 int istnet_pw_bwd_stats_pooled(int b, int c, int g, const float* d_pooled, long long pooled_bstride,
                                const float* ymax, const float* bn, float* part_g, float* part_gy, void* stream) {

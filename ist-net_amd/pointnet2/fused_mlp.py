@@ -149,7 +149,7 @@ class _Gather:
         self.cfeat = 0 if feat is None else feat.shape[1]
 
 
-def _forward_stack(lib, dev, st, b, c0, g, s, x, gather, training, layers, params, out_spec=None):
+def _forward_stack(lib, dev, st, b, c0, g, s, x, gather, training, layers, params, out_spec=None, start=None):
     """Runs all layers + the BN/ReLU/max tail.  Returns (out, arg, ys, bns).
 
     ``out_spec`` = (tensor (B, Ctot, G), channel offset): write the pooled result into that channel slice
@@ -160,6 +160,11 @@ def _forward_stack(lib, dev, st, b, c0, g, s, x, gather, training, layers, param
     for li, lay in enumerate(layers):
         w, gamma, beta = params[3 * li], params[3 * li + 1], params[3 * li + 2]
         cout = w.shape[0]
+        if li == 0 and start is not None:    # layer 0 (raw output + BN block) was produced by the caller
+            ys.append(start[0])
+            bns.append(start[1])
+            cur, cur_c, in_bn = start[0], cout, start[1]
+            continue
         w2 = w.reshape(cout, cur_c)
         y = _empty((b, cout, p), torch.float32, dev)
         bn = _empty((4, cout), torch.float32, dev)
@@ -342,7 +347,7 @@ def _reduce_only_job(dev, wparam, cout, cin, splits, ws):
 
 
 def _backward_stack(lib, dev, st, b, c0, g, s, x, gather, training, ys, bns, params, arg, dout, need_w, need_x,
-                    pooled_bstride=0, scatter_out=None):
+                    pooled_bstride=0, scatter_out=None, layer0_hook=None):
     """Returns (grads for [w, gamma, beta] * L, gradient w.r.t. the layer-0 input or None).
 
     With `gather`, the layer-0 input gradient is produced for the feature channels only
@@ -360,6 +365,7 @@ def _backward_stack(lib, dev, st, b, c0, g, s, x, gather, training, ys, bns, par
     fused_part, fused_nt = None, 0   # statistics of layer li already reduced by the dgrad of layer li+1
     wjobs = []                       # weight-gradient launches of the stack: (launch(stream) -> (n, splits, ws, dw))
     wlayers = []                     # layer index of each job
+    wextra = []                      # further closures for the wgrad stream (layer0_hook)
     for li in range(n - 1, -1, -1):
         w, gamma = params[3 * li], params[3 * li + 1]
         cout = w.shape[0]
@@ -391,6 +397,10 @@ def _backward_stack(lib, dev, st, b, c0, g, s, x, gather, training, ys, bns, par
             "bn_finalize_bwd")
         grads[3 * li + 1] = dgamma
         grads[3 * li + 2] = dbeta
+        if li == 0 and layer0_hook is not None:
+            # the caller finishes layer 0 itself (feature propagation: interpolated + skip input)
+            dx = layer0_hook(y, d_dense, bn, bwdc, grads, wextra)
+            break
         use_gather = li == 0 and gather is not None
         # layer 0 of a scale inside a fused level: dW0 comes from the scattered dY0 (see FusedSALevelFunction)
         split_w0 = (use_gather and need_w[0] and need_x and scatter_out is not None and gather.n <= 4096
@@ -458,8 +468,8 @@ def _backward_stack(lib, dev, st, b, c0, g, s, x, gather, training, ys, bns, par
             d_dense, d_pooled, d_arg = dprev, None, None
             if li == 0:
                 dx = dprev
-    if wjobs:
-        wparams = [params[3 * li] for li in wlayers]
+    if wjobs or wextra:
+        wparams = [params[3 * li] for li in wlayers] + ([params[0]] if wextra else [])
         if _can_defer(wparams):
             # after the chain, on the wgrad stream; joined by the end-of-backward callback
             cur = torch.cuda.current_stream(dev)
@@ -468,15 +478,20 @@ def _backward_stack(lib, dev, st, b, c0, g, s, x, gather, training, ys, bns, par
             wstream.wait_stream(cur)
             with torch.cuda.stream(wstream):
                 done = [job(wstream.cuda_stream) for job in wjobs]
-                _native.reduce_multi([(cnt, splits, ws.data_ptr(), dw.data_ptr()) for cnt, splits, ws, dw in done],
-                                     wstream.cuda_stream)
-            _Deferred.keep += [wjobs, done]
+                if done:
+                    _native.reduce_multi([(cnt, splits, ws.data_ptr(), dw.data_ptr()) for cnt, splits, ws, dw in done],
+                                         wstream.cuda_stream)
+                extra_keep = [fn(wstream.cuda_stream) for fn in wextra]
+            _Deferred.keep += [wjobs, done, wextra, extra_keep]
             if not _Deferred.armed:
                 torch.autograd.Variable._execution_engine.queue_callback(_Deferred.flush)
                 _Deferred.armed = True
         else:
             done = [job(st) for job in wjobs]
-            _native.reduce_multi([(cnt, splits, ws.data_ptr(), dw.data_ptr()) for cnt, splits, ws, dw in done], st)
+            if done:
+                _native.reduce_multi([(cnt, splits, ws.data_ptr(), dw.data_ptr()) for cnt, splits, ws, dw in done], st)
+            for fn in wextra:
+                fn(st)
         for li, (_, _, _, dw) in zip(wlayers, done):
             grads[3 * li] = dw.view_as(params[3 * li])
     return grads, dx, scattered
@@ -729,6 +744,171 @@ def _finish_layer0_grads(lib, dev, b, cfeat, cout0_tot, n_src, feat, gbuf, ident
         work(torch.cuda.current_stream(dev).cuda_stream)
 
 
+class FusedFPFunction(Function):
+    """Feature propagation: ``mlp(cat([three_interpolate(known_feats, idx, weight), skip]))`` as one node
+    (reference pointnet2_modules.py:185-209), with layer 0 split by linearity.  With W0 = [Wa | Wb]:
+
+        y0 = Wa . interp(K) + Wb . S = interp(Wa . K) + Wb . S
+
+    so the product with the interpolated part runs over the m KNOWN points (m = n/2 in the encoder) and the
+    interpolation acts on the layer's output width; the concatenated input never exists.  Backward, with
+    G' = interp_grad(dY0):  dK = Wa^T . G',  dWa = G' . K^T (both over m points),  dS = Wb^T . dY0,
+    dWb = dY0 . S^T (over n points, skip columns only).
+
+    known_feats (B, C2, m), skip (B, C1, n) or None, idx / weight (B, n, 3), csr = _ext.interp_csr(idx, m) or None."""
+
+    @staticmethod
+    def forward(ctx, known_feats, skip, idx, weight, csr, training, layers, *params):
+        from . import _ext
+        lib = _native.lib()
+        dev = known_feats.device
+        known = known_feats.contiguous()
+        skip_c = skip.contiguous() if skip is not None else None
+        b, c2, m = known.shape
+        n = idx.shape[1]
+        c1 = skip_c.shape[1] if skip_c is not None else 0
+        w0, gamma0, beta0 = params[0], params[1], params[2]
+        cout0, cin = w0.shape[0], c2 + c1
+        w2 = w0.reshape(cout0, cin)
+        lay0 = layers[0]
+        with torch.cuda.device(dev):
+            st = _st(dev)
+            zk = _empty((b, cout0, m), torch.float32, dev)
+            _native.check(lib.istnet_pw_forward_ld(b, c2, cout0, m, known.data_ptr(), w2.data_ptr(), cin, None, None,
+                                                   zk.data_ptr(), None, None, st), "pw_forward_ld(fp)")
+            t = _ext.three_interpolate(zk, idx, weight)               # (B, cout0, n)
+            bn0 = _empty((4, cout0), torch.float32, dev)
+            part = None
+            if skip_c is not None:
+                y0 = _empty((b, cout0, n), torch.float32, dev)
+                if training:
+                    nt = lib.istnet_pw_stat_tiles(b, cout0, n)
+                    part = _empty((2, cout0, nt), torch.float32, dev)
+                _native.check(lib.istnet_pw_forward_acc(b, c1, cout0, n, skip_c.data_ptr(), w2.data_ptr() + 4 * c2, cin,
+                                                        t.data_ptr(), y0.data_ptr(), _p(part[0]) if training else None,
+                                                        _p(part[1]) if training else None, st), "pw_forward_acc")
+            else:
+                y0 = t
+                if training:
+                    nt = lib.istnet_pw_bwd_stat_tiles(b, n)
+                    part = _empty((2, cout0, nt), torch.float32, dev)
+                    _native.check(lib.istnet_pw_channel_stats(b, cout0, n, y0.data_ptr(), part[0].data_ptr(),
+                                                              part[1].data_ptr(), st), "pw_channel_stats")
+            if training:
+                _native.check(lib.istnet_bn_finalize_fwd(
+                    cout0, nt, float(b * n), part[0].data_ptr(), part[1].data_ptr(), gamma0.data_ptr(), beta0.data_ptr(),
+                    float(lay0.eps), float(lay0.momentum), _p(lay0.running_mean), _p(lay0.running_var),
+                    bn0.data_ptr(), st), "bn_finalize_fwd")
+            else:
+                _native.check(lib.istnet_affine_consts(cout0, gamma0.data_ptr(), beta0.data_ptr(),
+                                                       lay0.running_mean.data_ptr(), lay0.running_var.data_ptr(),
+                                                       float(lay0.eps), bn0.data_ptr(), st), "affine_consts")
+            out, _, ys, bns = _forward_stack(lib, dev, st, b, cin, n, 1, None, None, training, layers, params,
+                                             start=(y0, bn0))
+        ctx.training, ctx.dims, ctx.n_layers, ctx.has_skip, ctx.csr = training, (b, c2, c1, m, n), len(layers), \
+            skip_c is not None, csr
+        ctx.save_for_backward(known, skip_c if skip_c is not None else torch.empty(0, device=dev), idx, weight,
+                              *ys, *bns, *params)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        from . import _ext
+        lib = _native.lib()
+        b, c2, c1, m, n = ctx.dims
+        nl = ctx.n_layers
+        sv = ctx.saved_tensors
+        known, skip, idx, weight = sv[0], (sv[1] if ctx.has_skip else None), sv[2], sv[3]
+        ys, bns, params = sv[4:4 + nl], sv[4 + nl:4 + 2 * nl], sv[4 + 2 * nl:]
+        dev = known.device
+        _enter_backward(dev)
+        cin = c2 + c1
+        w0 = params[0]
+        cout0 = w0.shape[0]
+        w2 = w0.reshape(cout0, cin)
+        need_known, need_skip = ctx.needs_input_grad[0], ctx.has_skip and ctx.needs_input_grad[1]
+        need_w = [ctx.needs_input_grad[7 + 3 * li] for li in range(nl)]
+        result = {}
+
+        def layer0(y0, d_a0, bn0, bwdc0, grads, wextra):
+            st = _st(dev)
+            ident, ibw = _ident_consts(dev, cout0)          # mask always on, dY = g: products of a given dY
+            dy0 = _empty((b, cout0, n), torch.float32, dev)
+            _native.check(lib.istnet_pw_dy(b, cout0, n, y0.data_ptr(), d_a0.data_ptr(), bn0.data_ptr(),
+                                           bwdc0.data_ptr(), dy0.data_ptr(), st), "pw_dy")
+            if need_skip:
+                ds = _empty((b, c1, n), torch.float32, dev)
+                _native.check(lib.istnet_pw_dgrad(b, cin, c2, c1, cout0, n, 0, w2.data_ptr(), dy0.data_ptr(),
+                                                  dy0.data_ptr(), None, 0, None, ident.data_ptr(), ibw.data_ptr(),
+                                                  ds.data_ptr(), None, None, None, None, st), "pw_dgrad(fp skip)")
+                result["dskip"] = ds
+            gk = None
+            if need_known or need_w[0]:
+                gk = (_ext.three_interpolate_grad(dy0, idx, weight, m, ctx.csr) if ctx.csr is not None
+                      else _ext.three_interpolate_grad(dy0, idx, weight, m))                       # (B, cout0, m)
+            if need_known:
+                dk = _empty((b, c2, m), torch.float32, dev)
+                _native.check(lib.istnet_pw_dgrad(b, cin, 0, c2, cout0, m, 0, w2.data_ptr(), gk.data_ptr(),
+                                                  gk.data_ptr(), None, 0, None, ident.data_ptr(), ibw.data_ptr(),
+                                                  dk.data_ptr(), None, None, None, None, st), "pw_dgrad(fp known)")
+                result["dknown"] = dk
+            if need_w[0]:
+                dest = _grad_dest(w0, (cout0, cin), dev)
+                grads[0] = dest.view_as(w0)
+
+                def wjob(wst):
+                    sp_a = lib.istnet_pw_wgrad_splits(b, c2, cout0, m)
+                    ws_a = _empty((sp_a, cout0, c2), torch.float32, dev)
+                    dwa = _empty((cout0, c2), torch.float32, dev)
+                    _native.check(lib.istnet_pw_wgrad(b, c2, cout0, m, 0, known.data_ptr(), None, None, gk.data_ptr(),
+                                                      gk.data_ptr(), None, 0, None, ident.data_ptr(), ibw.data_ptr(),
+                                                      ws_a.data_ptr(), wst), "pw_wgrad(fp known)")
+                    red = [(cout0 * c2, sp_a, ws_a.data_ptr(), dwa.data_ptr())]
+                    keep = [ws_a, dwa]
+                    if skip is not None:
+                        sp_b = lib.istnet_pw_wgrad_splits(b, c1, cout0, n)
+                        ws_b = _empty((sp_b, cout0, c1), torch.float32, dev)
+                        dwb = _empty((cout0, c1), torch.float32, dev)
+                        _native.check(lib.istnet_pw_wgrad(b, c1, cout0, n, 0, skip.data_ptr(), None, None,
+                                                          dy0.data_ptr(), dy0.data_ptr(), None, 0, None,
+                                                          ident.data_ptr(), ibw.data_ptr(), ws_b.data_ptr(), wst),
+                                      "pw_wgrad(fp skip)")
+                        red.append((cout0 * c1, sp_b, ws_b.data_ptr(), dwb.data_ptr()))
+                        keep += [ws_b, dwb]
+                    _native.reduce_multi(red, wst)
+                    if skip is not None:
+                        torch.cat([dwa, dwb], dim=1, out=dest)
+                    else:
+                        dest.copy_(dwa)
+                    return keep, dy0, gk
+                wextra.append(wjob)
+            return None
+
+        with torch.cuda.device(dev):
+            grads, _, _ = _backward_stack(lib, dev, _st(dev), b, cin, n, 1, None, None, ctx.training, ys, bns, params,
+                                          None, dout.contiguous(), need_w, True, layer0_hook=layer0)
+        return (result.get("dknown"), result.get("dskip"), None, None, None, None, None, *grads)
+
+
+def fp_level(mlp, known_feats, skip, idx, weight, csr=None):
+    """``mlp(cat([three_interpolate(known_feats, idx, weight), skip], 1).unsqueeze(-1)).squeeze(-1)`` through the
+    fused node when shapes allow; None otherwise (the caller then runs the reference composition)."""
+    if not (USE_FUSED_FP and known_feats.is_cuda and known_feats.dtype == torch.float32 and _native.TIMING is None):
+        return None
+    n, m = idx.shape[1], known_feats.shape[2]
+    if skip is not None and not (skip.is_cuda and skip.dtype == torch.float32 and skip.shape[2] == n):
+        return None
+    c1 = skip.shape[1] if skip is not None else 0
+    if m % 32 or n % 32 or known_feats.shape[1] % 4 or c1 % 4 or not _fusable_shape(mlp, n, 1):
+        return None
+    layers, params = _layer_args(mlp)
+    out = FusedFPFunction.apply(known_feats, skip, idx, weight, csr, mlp.training, layers, *params)
+    if mlp.training:
+        _bump_counters(list(mlp))
+    return out
+
+
+USE_FUSED_FP = os.environ.get("ISTNET_NO_FUSED_FP") is None
 _ONES = {}
 
 

@@ -13,7 +13,7 @@ import torch
 import torch.nn as nn
 
 from . import pointnet2_utils, pytorch_utils
-from .fused_mlp import sa_level, shared_mlp_maxpool
+from .fused_mlp import fp_level, sa_level, shared_mlp_maxpool
 
 
 class _PointnetSAModuleBase(nn.Module):
@@ -109,6 +109,10 @@ class PointnetFPModule(nn.Module):
             interpolated = known_feats.expand(*known_feats.size()[0:2], unknown.size(1))
         else:
             idx, weight, *csr = interp if interp is not None else self.interpolation_weights(unknown, known)
+            fused = fp_level(self.mlp, known_feats, unknow_feats, idx.detach(), weight.detach(),
+                             csr[0] if csr else None)
+            if fused is not None:        # interpolation + concat + SharedMLP as one node (layer 0 split by linearity)
+                return fused
             if csr and csr[0] is not None:
                 interpolated = pointnet2_utils.three_interpolate(known_feats, idx.detach(), weight.detach(), csr[0])
             else:

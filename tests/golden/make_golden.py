@@ -53,6 +53,42 @@ def npy(t):
     return t.detach().cpu().numpy()
 
 
+class F64Ops:
+    """``pointnet2._ext`` stand-in for a float64 run of the reference encoder: index decisions come from the fp32
+    oracle (so they are the ones every fp32 implementation takes), every feature-valued op is torch float64.
+    Forward only.  Gives the arithmetic 'truth' the fp32 outputs are within rounding of."""
+
+    def __init__(self, ops):
+        self.ops = ops
+
+    def furthest_point_sampling(self, xyz, m):
+        return self.ops.furthest_point_sampling(xyz.float().contiguous(), m)
+
+    def ball_query(self, new_xyz, xyz, radius, nsample):
+        return self.ops.ball_query(new_xyz.float().contiguous(), xyz.float().contiguous(), radius, nsample)
+
+    def three_nn(self, unknown, known):
+        d2, idx = self.ops.three_nn(unknown.float().contiguous(), known.float().contiguous())
+        return d2.double(), idx
+
+    @staticmethod
+    def gather_points(points, idx):
+        return torch.gather(points, 2, idx.long().unsqueeze(1).expand(-1, points.size(1), -1))
+
+    @staticmethod
+    def group_points(points, idx):
+        b, c, n = points.shape
+        flat = idx.long().reshape(b, 1, -1).expand(-1, c, -1)
+        return torch.gather(points, 2, flat).reshape(b, c, idx.size(1), idx.size(2))
+
+    @staticmethod
+    def three_interpolate(points, idx, weight):
+        b, c, m = points.shape
+        n = idx.size(1)
+        taps = torch.gather(points, 2, idx.long().reshape(b, 1, -1).expand(-1, c, -1)).reshape(b, c, n, 3)
+        return (taps * weight.unsqueeze(1)).sum(dim=3)
+
+
 def state_checksum(sd):
     """Order-sensitive fingerprint of a state dict: per-tensor (sum, abs-sum) in float64."""
     return np.array([[float(v.double().sum()), float(v.double().abs().sum())] for v in sd.values()])
@@ -153,6 +189,17 @@ def main():
             return res
         return fn
 
+    # float64 evaluation of the reference encoder (same initial weights, same index decisions)
+    import copy
+    enc64 = copy.deepcopy(enc_ref).double().train()
+    saved_ext = ref_utils._ext
+    ref_utils._ext = F64Ops(pn2_oracle)
+    try:
+        with torch.no_grad():
+            out_train_f64 = enc64(pts.double())
+    finally:
+        ref_utils._ext = saved_ext
+
     enc_ref.train()
     for n in orig:
         setattr(pn2_oracle, n, tap(n))
@@ -168,6 +215,8 @@ def main():
     out_my = enc_my(pts)
     out_my.square().mean().backward()
     torch.testing.assert_close(out_my, out_train, rtol=1e-5, atol=1e-6)
+    print("encoder_b2: max |reference fp32 - reference fp64| =",
+          float((out_train.double() - out_train_f64).abs().max()))
     for n, p in enc_my.named_parameters():
         torch.testing.assert_close(p.grad, grads[n], rtol=1e-4, atol=1e-7)
     enc_ref.eval()
@@ -175,7 +224,8 @@ def main():
         out_eval = enc_ref(pts)
     np.savez_compressed(
         os.path.join(HERE, "encoder_b2.npz"), pts=npy(pts),
-        out_train=npy(out_train)[:, :, ::8], out_train_sum=np.float64(out_train.double().sum()),
+        out_train=npy(out_train)[:, :, ::8], out_train_f64=npy(out_train_f64)[:, :, ::8],
+        out_train_sum=np.float64(out_train.double().sum()),
         out_train_abs_sum=np.float64(out_train.double().abs().sum()),
         out_eval=npy(out_eval)[:, :, ::8], out_eval_abs_sum=np.float64(out_eval.double().abs().sum()),
         grad_norms=np.array([float(grads[n].double().norm()) for n, _ in enc_ref.named_parameters()]),
