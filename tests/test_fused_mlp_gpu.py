@@ -253,3 +253,50 @@ def test_sa_level_fused_node_matches_reference_composition():
     assert float((dff - dft).norm() / dft.norm()) < 1e-4
     for a, bb in zip(gf, gt):
         assert float((a - bb).norm() / (bb.norm() + 1e-30)) < 1e-4
+
+
+@pytest.mark.parametrize("c2,c1,m,n,widths", [(64, 32, 64, 128, [48, 40]), (128, 0, 128, 256, [64, 64]),
+                                              (256, 64, 32, 64, [96])])
+def test_fp_fused_node_matches_reference_composition(c2, c1, m, n, widths):
+    """FusedFPFunction (layer 0 as interp(Wa.K) + Wb.S, interpolation gradient taken on dY0) against
+    three_interpolate -> cat -> SharedMLP with torch ops: output and every gradient."""
+    from istnet_amd.pointnet2 import pointnet2_utils as pu
+    from istnet_amd.pointnet2.fused_mlp import fp_level
+    from istnet_amd.pointnet2.pointnet2_modules import PointnetFPModule
+    from istnet_amd.pointnet2.pytorch_utils import SharedMLP
+    b = 4
+    g = torch.Generator().manual_seed(31)
+    unknown = torch.rand(b, n, 3, generator=g).to(DEV)
+    known = unknown[:, :m].contiguous()
+    k0 = torch.randn(b, c2, m, generator=g).to(DEV)
+    s0 = torch.randn(b, c1, n, generator=g).to(DEV) if c1 else None
+    idx, weight = PointnetFPModule.interpolation_weights(unknown, known)
+    torch.manual_seed(32)
+    mlp_a = SharedMLP([c2 + c1, *widths], bn=True).to(DEV).train()
+    mlp_b = SharedMLP([c2 + c1, *widths], bn=True).to(DEV).train()
+    mlp_b.load_state_dict(mlp_a.state_dict())
+    wgt = torch.randn(b, widths[-1], n, generator=g).to(DEV)
+
+    def run(fused, mlp):
+        k = k0.clone().requires_grad_(True)
+        s = s0.clone().requires_grad_(True) if s0 is not None else None
+        if fused:
+            out = fp_level(mlp, k, s, idx, weight)
+            assert out is not None
+        else:
+            interp = pu.three_interpolate(k, idx, weight)
+            x = interp if s is None else torch.cat([interp, s], dim=1)
+            out = mlp(x.unsqueeze(-1)).squeeze(-1)
+        (out * wgt).sum().backward()
+        return out.detach(), k.grad, (s.grad if s is not None else None), [p.grad for p in mlp.parameters()]
+
+    of, dkf, dsf, gf = run(True, mlp_a)
+    ot, dkt, dst, gt = run(False, mlp_b)
+    torch.testing.assert_close(of, ot, rtol=1e-4, atol=1e-4)
+    assert float((dkf - dkt).norm() / dkt.norm()) < 1e-4
+    if dst is not None:
+        assert float((dsf - dst).norm() / dst.norm()) < 1e-4
+    for a, bb in zip(gf, gt):
+        assert float((a - bb).norm() / (bb.norm() + 1e-30)) < 1e-4
+    for (ka, va), (kb, vb) in zip(mlp_a.state_dict().items(), mlp_b.state_dict().items()):
+        torch.testing.assert_close(va.float(), vb.float(), rtol=1e-5, atol=1e-6)
