@@ -34,13 +34,22 @@ else:
 
 
 def _kname(base, cfg, gather=None):
-    """Kernel symbol as rocprofv3 prints it, e.g. pw_dgrad_kernel<128, 128, 2, 2>."""
+    """Kernel symbol as rocprofv3 prints it, e.g. pw_dgrad_kernel<64, 64, 2, 2> or pw_fwd_kernel<128, 128, 2, 2, 0>.
+    ``gather``: None for kernels without the template parameter, else the operand-loader mode (0 tensor input,
+    1 channel-major gather, 2 point-major gather; a bool counts as 0 / 1)."""
     mt, nt = cfg // 1000, cfg % 1000
     if base == "pw_wgrad_kernel" and mt == 32:
         return "pw_wgrad_small_kernel<%s>" % ("true" if gather else "false")
     wm, wn = (1, 4) if mt == 32 else (2, 2)
-    tail = "" if gather is None else (", true" if gather else ", false")
+    tail = "" if gather is None else f", {int(gather)}"
     return f"{base}<{mt}, {nt}, {wm}, {wn}{tail}>"
+
+
+def _gather_mode(ga, multiple):
+    """Loader mode the C launcher picks for a gathered layer 0 (see launch_pw_forward / launch_pw_wgrad)."""
+    if ga is None:
+        return 0
+    return 2 if (ga.feat_t is not None and ga.cfeat > 0 and ga.cfeat % multiple == 0) else 1
 
 
 def _st(dev):
@@ -176,9 +185,9 @@ def _forward_stack(lib, dev, st, b, c0, g, s, x, gather, training, layers, param
             ps, pq = part[0].data_ptr(), part[1].data_ptr()
         else:
             nt, ps, pq = 0, None, None
-        kname = _kname("pw_fwd_kernel", lib.istnet_pw_tile_cfg(b, cout, p), gather is not None and li == 0)
+        kname = _kname("pw_fwd_kernel", lib.istnet_pw_tile_cfg(b, cout, p), _gather_mode(gather if li == 0 else None, 16))
         flops, nbytes = 2.0 * b * p * cur_c * cout, 4.0 * b * p * (cur_c + cout)
-        if li == 0 and gather is not None and USE_SPLIT_LAYER0 and _native.TIMING is None:
+        if li == 0 and gather is not None and USE_SPLIT_LAYER0:
             # layer 0 by linearity: Z = W0[:, 3:] . feat over the n source points (nsample*npoint/n times fewer MACs
             # than over the grouped points), then y0 = Z[:, idx] + W0[:, :3] . (xyz[idx] - centre); an xyz-only
             # layer (level 1) is just the second term
@@ -186,8 +195,11 @@ def _forward_stack(lib, dev, st, b, c0, g, s, x, gather, training, layers, param
             z = None
             if ga.cfeat > 0:
                 z = _empty((b, cout, ga.n), torch.float32, dev)
-                _native.check(lib.istnet_pw_forward_ld(b, ga.cfeat, cout, ga.n, ga.feat.data_ptr(), w2.data_ptr() + 12,
-                                                       cur_c, None, None, z.data_ptr(), None, None, st), "pw_forward_ld")
+                _native.check(_native.timed(
+                    _kname("pw_fwd_kernel", lib.istnet_pw_tile_cfg(b, cout, ga.n), 0), 2.0 * b * ga.n * ga.cfeat * cout,
+                    4.0 * b * ga.n * (ga.cfeat + cout), lambda: lib.istnet_pw_forward_ld(
+                        b, ga.cfeat, cout, ga.n, ga.feat.data_ptr(), w2.data_ptr() + 12, cur_c, None, None,
+                        z.data_ptr(), None, None, st)), "pw_forward_ld")
             if ps is not None:
                 nt = lib.istnet_pw_gather_add_tiles(b, p)
                 part = _empty((2, cout, nt), torch.float32, dev)
@@ -301,7 +313,9 @@ def _wgrad_job(lib, dev, b, cin, cout, p, ns_arg, use_gather, ga, src, in_bn, y,
         splits = lib.istnet_pw_wgrad_splits(b, cin, cout, p)
         ws = _empty((splits, cout, cin), torch.float32, dev)
         dw = _grad_dest(wparam, (cout, cin), dev)
-        kname = _kname("pw_wgrad_kernel", lib.istnet_pw_wgrad_tile_cfg(b, cin, cout, p), use_gather)
+        kname = _kname("pw_wgrad_kernel", lib.istnet_pw_wgrad_tile_cfg(b, cin, cout, p),
+                       (_gather_mode(ga, 4) if lib.istnet_pw_wgrad_tile_cfg(b, cin, cout, p) // 1000 != 32 else use_gather)
+                       if use_gather else 0)
         flops = 2.0 * b * p * cin * cout
         dd, dp, da = _p(d_dense), _p(d_pooled), _p(d_arg)
         if use_gather:
@@ -404,8 +418,8 @@ def _backward_stack(lib, dev, st, b, c0, g, s, x, gather, training, ys, bns, par
         use_gather = li == 0 and gather is not None
         # layer 0 of a scale inside a fused level: dW0 comes from the scattered dY0 (see FusedSALevelFunction)
         split_w0 = (use_gather and need_w[0] and need_x and scatter_out is not None and gather.n <= 4096
-                    and gather.cfeat > 0 and USE_SPLIT_LAYER0 and _native.TIMING is None)
-        if (li > 0 and need_w[li] and USE_FUSED_SMALL_BWD and _native.TIMING is None
+                    and gather.cfeat > 0 and USE_SPLIT_LAYER0)
+        if (li > 0 and need_w[li] and USE_FUSED_SMALL_BWD
                 and lib.istnet_pw_bwd_small_ok(cin, cout, p)):
             # small layer: dA_{l-1}, its statistics partials and the dW partials from ONE pass over (y, g, y_{l-1})
             splits = lib.istnet_pw_bwd_small_splits(b, p)
@@ -420,7 +434,7 @@ def _backward_stack(lib, dev, st, b, c0, g, s, x, gather, training, ys, bns, par
             wlayers.append(li)
             d_dense, d_pooled, d_arg = dprev, None, None
             continue
-        if (use_gather and need_w[0] and gather.cfeat == 0 and USE_SPLIT_LAYER0 and _native.TIMING is None):
+        if (use_gather and need_w[0] and gather.cfeat == 0 and USE_SPLIT_LAYER0):
             # xyz-only layer 0 (level 1): dW0 = sum_p dY0[:, p] * xrel[p], a reduction over (y0, dA0) -- no GEMM
             wjobs.append(_dwx_only_job(lib, dev, b, cout, p, ns_arg, gather, y, d_dense, d_pooled, pbs, d_arg, bn,
                                        bwdc, w))
@@ -893,7 +907,7 @@ class FusedFPFunction(Function):
 def fp_level(mlp, known_feats, skip, idx, weight, csr=None):
     """``mlp(cat([three_interpolate(known_feats, idx, weight), skip], 1).unsqueeze(-1)).squeeze(-1)`` through the
     fused node when shapes allow; None otherwise (the caller then runs the reference composition)."""
-    if not (USE_FUSED_FP and known_feats.is_cuda and known_feats.dtype == torch.float32 and _native.TIMING is None):
+    if not (USE_FUSED_FP and known_feats.is_cuda and known_feats.dtype == torch.float32):
         return None
     n, m = idx.shape[1], known_feats.shape[2]
     if skip is not None and not (skip.is_cuda and skip.dtype == torch.float32 and skip.shape[2] == n):
