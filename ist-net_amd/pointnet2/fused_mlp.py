@@ -84,6 +84,8 @@ def _ident_consts(dev, c):
 USE_DEFERRED_WGRAD = os.environ.get("ISTNET_NO_DEFER_WGRAD") is None
 
 
+# Stream priorities were tried too (capture stream and scale streams at priority -1, the wgrad stream at 0): the step
+# went from 3.47 to 5.4 ms, so every stream stays at the default priority.
 # one wgrad stream for all chains: a stream per concurrent dgrad chain measured 0.2 ms/step SLOWER (the extra
 # GEMMs contend with the dependent chains they were meant to stay out of the way of)
 _W_PER_CHAIN = os.environ.get("ISTNET_WGRAD_STREAM_PER_CHAIN") is not None
@@ -840,6 +842,7 @@ class FusedFPFunction(Function):
         w0 = params[0]
         cout0 = w0.shape[0]
         w2 = w0.reshape(cout0, cin)
+        _native.mark(f"bwd FP(n={n}) start")
         need_known, need_skip = ctx.needs_input_grad[0], ctx.has_skip and ctx.needs_input_grad[1]
         need_w = [ctx.needs_input_grad[7 + 3 * li] for li in range(nl)]
         result = {}
@@ -901,6 +904,7 @@ class FusedFPFunction(Function):
         with torch.cuda.device(dev):
             grads, _, _ = _backward_stack(lib, dev, _st(dev), b, cin, n, 1, None, None, ctx.training, ys, bns, params,
                                           None, dout.contiguous(), need_w, True, layer0_hook=layer0)
+            _native.mark(f"bwd FP(n={n}) chain done")
         return (result.get("dknown"), result.get("dskip"), None, None, None, None, None, *grads)
 
 
