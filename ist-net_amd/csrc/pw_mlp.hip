@@ -56,6 +56,15 @@ __device__ __forceinline__ float wave_sum(float v) {
   return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 
+// (cloud, in-cloud point) of a flattened point index q = b*P + p.  The launchers reject b*P >= 2^31, so this is a
+// 32-bit division; the 64-bit one it replaces cost ~100 scalar instructions per K chunk.
+__device__ __forceinline__ void split_point(long long q, int P, int& b, int& p) {
+  const unsigned uq = (unsigned)q, up = (unsigned)P;
+  const unsigned ub = uq / up;
+  b = (int)ub;
+  p = (int)(uq - ub * up);
+}
+
 // MFMA C/D layout of v_mfma_f32_32x32x2_f32: reg r of lane l holds row (r&3)+8*(r>>2)+4*(l>>5), col l&31.
 __device__ __forceinline__ int mfma_row(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
 
@@ -1086,8 +1095,8 @@ __global__ __launch_bounds__(kThreads) void pw_wgrad_kernel(
   // chunk start qk (multiple of 32, inside one cloud) -> cloud b and in-cloud point of this thread's float4
   auto load_gidx = [&](long long qk) {
     const long long qc = min(qk, total - kKTW);
-    const int b = (int)(qc / P);
-    const int pk = (int)(qc - (long long)b * P);
+    int b, pk;
+    split_point(qc, P, b, pk);
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
       const int e = tid + kThreads * i;
@@ -1097,8 +1106,8 @@ __global__ __launch_bounds__(kThreads) void pw_wgrad_kernel(
   };
   auto load_chunk = [&](long long qk) {
     const long long qc = min(qk, total - kKTW);
-    const int b = (int)(qc / P);
-    const int pk = (int)(qc - (long long)b * P);
+    int b, pk;
+    split_point(qc, P, b, pk);
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
       const int e = tid + kThreads * i;
@@ -1132,7 +1141,8 @@ __global__ __launch_bounds__(kThreads) void pw_wgrad_kernel(
     if (GATHER) load_gidx(qk + kKTW);
   };
   auto store_chunk = [&](int buf, long long qk) {
-    const int pk = (int)(min(qk, total - kKTW) % P);
+    int b_unused, pk;
+    split_point(min(qk, total - kKTW), P, b_unused, pk);
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
       const int e = tid + kThreads * i;
@@ -1227,8 +1237,8 @@ __global__ __launch_bounds__(kThreads) void pw_wgrad_small_kernel(
   float bsc[4], bsh[4];
   auto load_chunk = [&](long long qk) {
     const long long qc = min(qk, total - kKTW);
-    const int b = (int)(qc / P);
-    const int pk = (int)(qc - (long long)b * P);
+    int b, pk;
+    split_point(qc, P, b, pk);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int e = lane + 64 * i;
@@ -1244,7 +1254,8 @@ __global__ __launch_bounds__(kThreads) void pw_wgrad_small_kernel(
     }
   };
   auto store_chunk = [&](long long qk) {
-    const int pk = (int)(min(qk, total - kKTW) % P);
+    int b_unused, pk;
+    split_point(min(qk, total - kKTW), P, b_unused, pk);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int e = lane + 64 * i;
@@ -1334,8 +1345,8 @@ __global__ __launch_bounds__(kThreads) void pw_bwd_small_kernel(
   float4 braw[4];
   auto load_chunk = [&](long long qk) {
     const long long qc = min(qk, total - kKTW);
-    const int b = (int)(qc / P);
-    const int pk = (int)(qc - (long long)b * P);
+    int b, pk;
+    split_point(qc, P, b, pk);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int e = lane + 64 * i;
@@ -1345,7 +1356,8 @@ __global__ __launch_bounds__(kThreads) void pw_bwd_small_kernel(
     }
   };
   auto store_chunk = [&](long long qk) {
-    const int pk = (int)(min(qk, total - kKTW) % P);
+    int b_unused, pk;
+    split_point(min(qk, total - kKTW), P, b_unused, pk);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int e = lane + 64 * i;
@@ -1389,8 +1401,8 @@ __global__ __launch_bounds__(kThreads) void pw_bwd_small_kernel(
     }
     // dA of this chunk: register r of a lane is (ci = mfma_row(r, lane), pt = lane & 31)
     const long long qc = min(qk, total - kKTW);
-    const int b = (int)(qc / P);
-    const int pk = (int)(qc - (long long)b * P);
+    int b, pk;
+    split_point(qc, P, b, pk);
     const int pt = lane & 31;
     const bool okp = qk + pt < qend;
     float* dxb = dx + (size_t)b * cin * P + pk + pt;
@@ -1849,6 +1861,7 @@ static int launch_pw_wgrad(bool gather, int b, int cin, int cout, int p, int nsa
                            void* stream) {
   const int GS_C = cout;
   if (b <= 0 || cin <= 0 || cout <= 0 || p <= 0 || (p % kKTW)) return ISTNET_PN2_EINVAL;
+  if ((long long)b * p >= (1LL << 31)) return ISTNET_PN2_EINVAL;   // 32-bit point indexing in the kernels
   if (d_dense == nullptr && (d_pooled == nullptr || arg == nullptr || nsample <= 0 || (nsample & 3)))
     return ISTNET_PN2_EINVAL;
   GradSrc gs{d_dense, d_pooled, arg, nsample, pooled_bstride > 0 ? pooled_bstride : (long long)GS_C * (nsample > 0 ? p / nsample : 0), GS_C};
@@ -1909,7 +1922,7 @@ int istnet_pw_bwd_small(int b, int cin, int cout, int p, int nsample, const floa
                         long long pooled_bstride, const unsigned char* arg, const float* bn, const float* bwdc,
                         float* dx, float* part_g, float* part_gy, float* dw_part, void* stream) {
   const int GS_C = cout;
-  if (b <= 0 || !istnet_pw_bwd_small_ok(cin, cout, p)) return ISTNET_PN2_EINVAL;
+  if (b <= 0 || !istnet_pw_bwd_small_ok(cin, cout, p) || (long long)b * p >= (1LL << 31)) return ISTNET_PN2_EINVAL;
   if (w == nullptr || x == nullptr || bn_in == nullptr || dx == nullptr || part_g == nullptr || part_gy == nullptr ||
       dw_part == nullptr)
     return ISTNET_PN2_EINVAL;

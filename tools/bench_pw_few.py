@@ -4,7 +4,7 @@ import torch, istnet_amd
 from istnet_amd import _native
 lib = _native.lib(); dev = torch.device("cuda:0"); st = torch.cuda.current_stream().cuda_stream
 B = 32
-for (cin, cout, P) in [(128, 128, 2048), (128, 256, 2048), (64, 128, 4096), (768, 512, 128), (256, 128, 1024)]:
+for (cin, cout, P) in [(128, 128, 2048), (128, 256, 2048), (64, 128, 4096), (512, 512, 128), (256, 256, 512)]:
     x = torch.randn(B, cin, P, device=dev); w = torch.randn(cout, cin, device=dev) * 0.1; wt = w.t().contiguous()
     y = torch.empty(B, cout, P, device=dev); nt = lib.istnet_pw_stat_tiles(B, cout, P); part = torch.empty(2, cout, nt, device=dev)
     bn = torch.stack([torch.rand(cout, device=dev) + 0.5, torch.randn(cout, device=dev) * 0.1, torch.zeros(cout, device=dev), torch.ones(cout, device=dev)]).contiguous()
