@@ -96,6 +96,18 @@ class _Deferred:
     mains = {}       # device index -> stream to join into (the stream the backward nodes run on)
     keep = []        # tensors / closures referenced by launches in flight
     armed = False
+    task = -1        # autograd graph-task id the pending work belongs to
+
+    @classmethod
+    def arm(cls):
+        """Register the end-of-backward join once per backward pass.  If a previous pass died before its callback
+        ran (an exception in some backward node), its leftovers are joined and dropped first."""
+        task = torch._C._current_graph_task_id()
+        if cls.armed and task != cls.task:
+            cls.flush()
+        if not cls.armed:
+            torch.autograd.Variable._execution_engine.queue_callback(cls.flush)
+            cls.armed, cls.task = True, task
 
     @classmethod
     def stream(cls, dev, chain):
@@ -499,9 +511,7 @@ def _backward_stack(lib, dev, st, b, c0, g, s, x, gather, training, ys, bns, par
                                          wstream.cuda_stream)
                 extra_keep = [fn(wstream.cuda_stream) for fn in wextra]
             _Deferred.keep += [wjobs, done, wextra, extra_keep]
-            if not _Deferred.armed:
-                torch.autograd.Variable._execution_engine.queue_callback(_Deferred.flush)
-                _Deferred.armed = True
+            _Deferred.arm()
         else:
             done = [job(st) for job in wjobs]
             if done:
@@ -753,9 +763,7 @@ def _finish_layer0_grads(lib, dev, b, cfeat, cout0_tot, n_src, feat, gbuf, ident
         with torch.cuda.stream(wstream):
             kept = work(wstream.cuda_stream)
         _Deferred.keep += [kept, placeholders, gbuf, feat, dests]
-        if not _Deferred.armed:
-            torch.autograd.Variable._execution_engine.queue_callback(_Deferred.flush)
-            _Deferred.armed = True
+        _Deferred.arm()
     else:
         work(torch.cuda.current_stream(dev).cuda_stream)
 

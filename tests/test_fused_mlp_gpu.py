@@ -300,3 +300,34 @@ def test_fp_fused_node_matches_reference_composition(c2, c1, m, n, widths):
         assert float((a - bb).norm() / (bb.norm() + 1e-30)) < 1e-4
     for (ka, va), (kb, vb) in zip(mlp_a.state_dict().items(), mlp_b.state_dict().items()):
         torch.testing.assert_close(va.float(), vb.float(), rtol=1e-5, atol=1e-6)
+
+
+def test_deferred_wgrad_survives_a_failed_backward():
+    """Weight gradients are deferred to a side stream and joined by an end-of-backward callback.  If a backward pass
+    dies after a fused node has deferred work (the callback never runs), the next pass must still be correct."""
+    from istnet_amd.pointnet2.fused_mlp import shared_mlp_maxpool
+    from istnet_amd.pointnet2.pytorch_utils import SharedMLP
+
+    class Boom(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, x):
+            return x.clone()
+
+        @staticmethod
+        def backward(ctx, g):
+            raise RuntimeError("boom")
+
+    torch.manual_seed(41)
+    mlp = SharedMLP([64, 64, 128], bn=True).to(DEV).train()
+    ref = SharedMLP([64, 64, 128], bn=True).to(DEV).train()
+    ref.load_state_dict(mlp.state_dict())
+    x = torch.randn(4, 64, 128, 16, device=DEV)
+    with pytest.raises(RuntimeError, match="boom"):
+        shared_mlp_maxpool(mlp, Boom.apply(x.clone().requires_grad_(True))).sum().backward()
+    mlp.zero_grad(set_to_none=True)
+    shared_mlp_maxpool(mlp, x).square().sum().backward()
+    act = ref(x)
+    F.max_pool2d(act, kernel_size=[1, act.size(3)]).squeeze(-1).square().sum().backward()
+    torch.cuda.synchronize()
+    for p, q in zip(mlp.parameters(), ref.parameters()):
+        assert float((p.grad - q.grad).norm() / (q.grad.norm() + 1e-30)) < 1e-3
