@@ -266,9 +266,6 @@ def _forward_stack(lib, dev, st, b, c0, g, s, x, gather, training, layers, param
     return out, arg, ys, bns
 
 
-_AB_OLD = os.environ.get("ISTNET_AB_OLD") is not None   # debug: previous code path of the change under test
-
-
 # The scales of an MSG level are independent chains of ~10 dependent launches each (GEMM, finalize, ...).
 # Run scale i >= 1 on its own stream: one chain's launch gaps and tiny kernels are filled by the other's GEMMs.
 # Fork/join discipline: the side stream waits on the main stream before it starts and the main stream joins it
