@@ -1546,8 +1546,8 @@ inline int cfg_mt(TileCfg c) { return c == kCfg128x128 ? 128 : (c == kCfg32x256 
 inline bool wgrad_small(int cin, int cout) { return cin <= 32 && cout <= 32; }
 // tuning knobs (istnet_pw_set_tuning): experiments only, defaults are the measured best
 int g_wg_small_pts = 0x7fffffff;  // layers with b*P <= this use 64x64 wgrad tiles: measured best for every encoder layer (smaller split-K partials)
-int g_wg_target_big = 768;   // target workgroup count, outputs >= 128x128
-int g_wg_target_small = 1024;
+int g_wg_target_big = 512;   // target workgroup count, outputs >= 128x128 (re-tuned end to end once the wgrads ran beside the dgrad chain: 768/1024 -> 512/512 is 1.5 % faster)
+int g_wg_target_small = 512;
 int g_bwd_small_target = 256; // workgroups of the fused small-layer backward (key 5)
 inline int wgrad_mt(int cout, long long pts) { return (cout >= 128 && pts > g_wg_small_pts) ? 128 : 64; }
 inline int wgrad_nt(int cin, long long pts) { return (cin >= 96 && pts > g_wg_small_pts) ? 128 : 64; }
