@@ -279,6 +279,12 @@ def main():
         except Exception as exc:  # capture unsupported in this configuration: run the same step eagerly
             print(f"[bench] HIP graph capture failed ({type(exc).__name__}: {exc}); running eagerly", file=sys.stderr)
             torch.cuda.synchronize()
+            # eager launches are host-bound (~13 us each): the extra streams only add host work there, so the
+            # fallback runs the single-stream, unpipelined step (measured 5.7 vs 7.2 ms/step)
+            from istnet_amd.pointnet2 import fused_mlp
+            fused_mlp.USE_SCALE_STREAMS = fused_mlp.USE_DEFERRED_WGRAD = False
+            if args.workload == "encoder":
+                eager_step = make_eager_step(make_encoder_fwd_bwd(model, pts), opt, world, grad_sync)
             step, mode = eager_step, "eager"
 
     for _ in range(args.warmup):
