@@ -285,6 +285,7 @@ def main():
             fused_mlp.USE_SCALE_STREAMS = fused_mlp.USE_DEFERRED_WGRAD = False
             if args.workload == "encoder":
                 eager_step = make_eager_step(make_encoder_fwd_bwd(model, pts), opt, world, grad_sync)
+                args.no_prefetch = True
             step, mode = eager_step, "eager"
 
     for _ in range(args.warmup):
