@@ -210,6 +210,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--eager", action="store_true", help="do not capture the step in a HIP graph")
+    ap.add_argument("--no-unpipelined", action="store_true", help="skip the extra unpipelined measurement")
     ap.add_argument("--no-prefetch", action="store_true",
                     help="encoder workload: one batch, geometry inside the step (no next-batch geometry prefetch)")
     ap.add_argument("--workload", default="encoder", choices=["encoder", "istnet"],
@@ -325,6 +326,21 @@ def main():
                                    else "2 alternating, next batch's FPS/ball-query/three_nn prefetched on the "
                                         "geometry stream during the current step")},
         }
+        if world == 1 and args.workload == "encoder" and not args.no_prefetch and mode == "hipgraph" \
+                and not args.no_unpipelined:
+            # the same step WITHOUT the next-batch geometry prefetch (one batch, geometry inside the step), for
+            # reference: what the pipelining is worth, and the number to compare with an unpipelined loop
+            plain = make_graphed_step(make_encoder_fwd_bwd(model, pts), opt, world, grad_sync)
+            for _ in range(min(args.warmup, 5)):
+                plain()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(args.steps):
+                plain()
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t1) / args.steps
+            result["unpipelined"] = {"value": BATCH / dt, "unit": "clouds/s", "ms_per_step": dt * 1e3,
+                                     "note": "one batch, FPS / ball query / three_nn inside the step (--no-prefetch)"}
         if world == 1 and not args.no_roofline:
             from istnet_amd import roofline
             result["roofline"] = roofline.measure(
