@@ -577,16 +577,17 @@ struct GradSrc {
   long long pooled_bstride;  // elements between clouds of `pooled`; C*G when it is a plain (B, C, G) tensor
   int C;                 // channels of this layer (row = b*C + c)
 };
-__device__ __forceinline__ float pooled_at(const GradSrc& gs, size_t row, int G, int g) {
-  const size_t b = row / (size_t)gs.C, c = row - b * (size_t)gs.C;
-  return gs.pooled[b * (size_t)gs.pooled_bstride + c * (size_t)G + g];
+// (b, c) are passed separately: deriving them from row = b*C + c cost a 64-bit division per loaded element
+__device__ __forceinline__ float pooled_at(const GradSrc& gs, int b, int c, int G, int g) {
+  return gs.pooled[(size_t)b * (size_t)gs.pooled_bstride + (size_t)c * (size_t)G + g];
 }
-__device__ __forceinline__ float4 load_grad4(const GradSrc& gs, size_t row, int P, int p) {
+__device__ __forceinline__ float4 load_grad4(const GradSrc& gs, int b, int c, int P, int p) {
+  const size_t row = (size_t)b * gs.C + c;
   if (gs.dense != nullptr) return *reinterpret_cast<const float4*>(gs.dense + row * (size_t)P + p);
   // pooled: the 4 consecutive points p..p+3 lie in one group when S % 4 == 0
   const int G = P / gs.S;
   const int g = p / gs.S, k = p - g * gs.S;
-  const float d = pooled_at(gs, row, G, g);
+  const float d = pooled_at(gs, b, c, G, g);
   const int a = gs.arg[row * (size_t)G + g];
   return make_float4(a == k ? d : 0.f, a == k + 1 ? d : 0.f, a == k + 2 ? d : 0.f, a == k + 3 ? d : 0.f);
 }
@@ -653,7 +654,7 @@ __global__ __launch_bounds__(256) void pw_bwd_stats_kernel(int C, int P, GradSrc
   float sg = 0.f, sgy = 0.f;
   for (int p = pbeg + threadIdx.x * 4; p < pend; p += 256 * 4) {
     const float4 v = *reinterpret_cast<const float4*>(y + row * (size_t)P + p);
-    const float4 d = load_grad4(gs, row, P, p);
+    const float4 d = load_grad4(gs, b, c, P, p);
     const float g0 = (v.x * s + h > 0.f) ? d.x : 0.f, g1 = (v.y * s + h > 0.f) ? d.y : 0.f;
     const float g2 = (v.z * s + h > 0.f) ? d.z : 0.f, g3 = (v.w * s + h > 0.f) ? d.w : 0.f;
     sg += (g0 + g1) + (g2 + g3);
@@ -739,14 +740,15 @@ struct DyRaw {
   int a;         // arg-max slot (pooled mode)
 };
 __device__ __forceinline__ void load_dy_raw(DyRaw& r, const GradSrc& gs, const float* __restrict__ y,
-                                            size_t row, int P, int p) {
+                                            int b, int ch, int P, int p) {
+  const size_t row = (size_t)b * gs.C + ch;
   r.y = *reinterpret_cast<const float4*>(y + row * (size_t)P + p);
   if (gs.dense != nullptr) {
     r.d = *reinterpret_cast<const float4*>(gs.dense + row * (size_t)P + p);
     r.a = 0;
   } else {
     const int G = P / gs.S, g = p / gs.S;
-    r.d = make_float4(pooled_at(gs, row, G, g), 0.f, 0.f, 0.f);
+    r.d = make_float4(pooled_at(gs, b, ch, G, g), 0.f, 0.f, 0.f);
     r.a = gs.arg[row * (size_t)G + g];
   }
 }
@@ -838,7 +840,7 @@ __global__ __launch_bounds__(256) void pw_scatter_dy_kernel(int cout, int n, int
         d_n[ch] = gs.dense[row * (size_t)P + pc];
       } else {
         const int g = pc / gs.S;
-        d_n[ch] = (gs.arg[row * (size_t)G + g] == pc - g * gs.S) ? pooled_at(gs, row, G, g) : 0.f;
+        d_n[ch] = (gs.arg[row * (size_t)G + g] == pc - g * gs.S) ? pooled_at(gs, b, co, G, g) : 0.f;
       }
     }
   };
@@ -926,7 +928,7 @@ __global__ __launch_bounds__(kThreads) void pw_dgrad_kernel(
     for (int i = 0; i < NB; ++i) {
       const int e = tid + kThreads * i;
       const int k = min(k0 + e / (N_T / 4), cout - 1), p = min(p0 + (e % (N_T / 4)) * 4, P - 4);
-      load_dy_raw(braw[i], gs, y, (size_t)b * cout + k, P, p);
+      load_dy_raw(braw[i], gs, y, b, k, P, p);
     }
   };
   auto store_chunk = [&](int buf, int k0) {
@@ -1112,7 +1114,7 @@ __global__ __launch_bounds__(kThreads) void pw_wgrad_kernel(
     for (int i = 0; i < NA; ++i) {
       const int e = tid + kThreads * i;
       const int m = min(m0 + e / (kKTW / 4), cout - 1), p = pk + (e % (kKTW / 4)) * 4;
-      load_dy_raw(araw[i], gs, y, (size_t)b * cout + m, P, p);
+      load_dy_raw(araw[i], gs, y, b, m, P, p);
     }
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
@@ -1243,7 +1245,7 @@ __global__ __launch_bounds__(kThreads) void pw_wgrad_small_kernel(
     for (int i = 0; i < 4; ++i) {
       const int e = lane + 64 * i;
       const int row = e >> 3, p = pk + (e & 7) * 4;
-      load_dy_raw(araw[i], gs, y, (size_t)b * cout + min(row, cout - 1), P, p);
+      load_dy_raw(araw[i], gs, y, b, min(row, cout - 1), P, p);
       const int n = min(row, cin - 1);
       if (GATHER) {
         braw[i] = gather4(gsrc, b, n, P, p, gather_idx4(gsrc, b, P, p));
@@ -1351,7 +1353,7 @@ __global__ __launch_bounds__(kThreads) void pw_bwd_small_kernel(
     for (int i = 0; i < 4; ++i) {
       const int e = lane + 64 * i;
       const int row = e >> 3, p = pk + (e & 7) * 4;
-      load_dy_raw(araw[i], gs, y, (size_t)b * cout + min(row, cout - 1), P, p);
+      load_dy_raw(araw[i], gs, y, b, min(row, cout - 1), P, p);
       braw[i] = *reinterpret_cast<const float4*>(x + ((size_t)b * cin + min(row, cin - 1)) * P + p);
     }
   };
