@@ -898,7 +898,7 @@ __global__ __launch_bounds__(256) void pw_scatter_dy_kernel(int cout, int n, int
 // ============================================================================================
 // dgrad:  dx[b][m][p] = sum_co w[co][ci_off + m] * dY[b][co][p]
 // ============================================================================================
-template <int M_T, int N_T, int WM, int WN>
+template <int M_T, int N_T, int WM, int WN, bool FAST>   // FAST: every tile interior, cout % kKT == 0 (host-checked)
 __global__ __launch_bounds__(kThreads) void pw_dgrad_kernel(
     int cin_total, int ci_off, int m_rows, int cout, int P, int tiles_per_cloud,
     const float* __restrict__ w, const float* __restrict__ y, GradSrc gs, const float* __restrict__ bn,
@@ -917,7 +917,56 @@ __global__ __launch_bounds__(kThreads) void pw_dgrad_kernel(
   const int m0 = blockIdx.y * M_T;
   float areg[NA];
   DyRaw braw[NB];
+  // ---- staging -------------------------------------------------------------------------------------------
+  // These kernels are VALU-issue-bound (PMC: ~12 VALU instructions per MFMA), and most of them were index
+  // arithmetic: clamps, 64-bit address products, zero-fill selects.  An interior tile (whole M / N tile inside the
+  // tensor, cout a multiple of the K chunk -- every tile of the encoder's layers) therefore takes a FAST path: every
+  // address is  uniform base (scalar registers, advanced once per chunk) + a per-thread offset computed ONCE
+  // before the loop, and nothing is clamped or masked.  Edge tiles keep the general code.
+  constexpr bool fast = FAST;
+  // per-thread invariant offsets (FAST)
+  int aoff[NA], boff[NB], coff[NB], goff[NB], kslot[NB];
+#pragma unroll
+  for (int i = 0; i < NA; ++i) {
+    const int e = tid + kThreads * i;
+    aoff[i] = (e / M_T) * cin_total + (e % M_T);
+  }
+  const int G = gs.dense == nullptr ? P / gs.S : 0;
+#pragma unroll
+  for (int i = 0; i < NB; ++i) {
+    const int e = tid + kThreads * i;
+    const int kl = e / (N_T / 4), pl = (e % (N_T / 4)) * 4;
+    boff[i] = kl * P + pl;           // into y / dense, relative to (row k0, point p0)
+    coff[i] = kl;                    // into the per-channel constant tables, relative to k0
+    goff[i] = gs.dense == nullptr ? kl * G + (p0 + pl) / gs.S : 0;   // into pooled / arg, relative to row k0
+    kslot[i] = gs.dense == nullptr ? (p0 + pl) % gs.S : 0;           // slot of the first of the 4 points in its group
+  }
+  // uniform bases (FAST), advanced by one chunk per iteration
+  const float* wk = w + ci_off + m0;
+  const float* yk = y + ((size_t)b * cout) * P + p0;
+  const float* dk = gs.dense != nullptr ? gs.dense + ((size_t)b * cout) * P + p0 : nullptr;
+  const float* pk_ = gs.dense == nullptr ? gs.pooled + (size_t)b * gs.pooled_bstride : nullptr;
+  const uint8_t* ak = gs.dense == nullptr ? gs.arg + ((size_t)b * cout) * G : nullptr;
+
   auto load_chunk = [&](int k0) {
+    if (fast) {
+      const float* wc = wk + (size_t)k0 * cin_total;
+      const float* yc = yk + (size_t)k0 * P;
+#pragma unroll
+      for (int i = 0; i < NA; ++i) areg[i] = wc[aoff[i]];
+#pragma unroll
+      for (int i = 0; i < NB; ++i) {
+        braw[i].y = *reinterpret_cast<const float4*>(yc + boff[i]);
+        if (gs.dense != nullptr) {
+          braw[i].d = *reinterpret_cast<const float4*>(dk + (size_t)k0 * P + boff[i]);
+          braw[i].a = 0;
+        } else {
+          braw[i].d = make_float4((pk_ + (size_t)k0 * G)[goff[i]], 0.f, 0.f, 0.f);
+          braw[i].a = (ak + (size_t)k0 * G)[goff[i]];
+        }
+      }
+      return;
+    }
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
       const int e = tid + kThreads * i;
@@ -932,6 +981,35 @@ __global__ __launch_bounds__(kThreads) void pw_dgrad_kernel(
     }
   };
   auto store_chunk = [&](int buf, int k0) {
+    if (fast) {
+      const float* bnk = bn + k0;
+      const float* bwk = bwdc + k0;
+#pragma unroll
+      for (int i = 0; i < NA; ++i) {
+        const int e = tid + kThreads * i;
+        As[buf][e / M_T][e % M_T] = areg[i];
+      }
+#pragma unroll
+      for (int i = 0; i < NB; ++i) {
+        const int e = tid + kThreads * i;
+        const float rs = bnk[coff[i]], rh = bnk[cout + coff[i]];
+        const float rca = bwk[coff[i]], rcb = bwk[cout + coff[i]], rcc = bwk[2 * cout + coff[i]];
+        const float4 yv = braw[i].y;
+        float4 d = braw[i].d;
+        if (gs.dense == nullptr) {
+          const int k = kslot[i], a = braw[i].a;
+          const float v = d.x;
+          d = make_float4(a == k ? v : 0.f, a == k + 1 ? v : 0.f, a == k + 2 ? v : 0.f, a == k + 3 ? v : 0.f);
+        }
+        float4 o;
+        o.x = rca * ((yv.x * rs + rh > 0.f) ? d.x : 0.f) + rcb + rcc * yv.x;
+        o.y = rca * ((yv.y * rs + rh > 0.f) ? d.y : 0.f) + rcb + rcc * yv.y;
+        o.z = rca * ((yv.z * rs + rh > 0.f) ? d.z : 0.f) + rcb + rcc * yv.z;
+        o.w = rca * ((yv.w * rs + rh > 0.f) ? d.w : 0.f) + rcb + rcc * yv.w;
+        *reinterpret_cast<float4*>(&Bs[buf][e / (N_T / 4)][(e % (N_T / 4)) * 4]) = o;
+      }
+      return;
+    }
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
       const int e = tid + kThreads * i;
@@ -1551,6 +1629,7 @@ int g_wg_small_pts = 0x7fffffff;  // layers with b*P <= this use 64x64 wgrad til
 int g_wg_target_big = 512;   // target workgroup count, outputs >= 128x128 (re-tuned end to end once the wgrads ran beside the dgrad chain: 768/1024 -> 512/512 is 1.5 % faster)
 int g_wg_target_small = 512;
 int g_bwd_small_target = 256; // workgroups of the fused small-layer backward (key 5)
+int g_exp_no_fast = 0;        // experiment (key 6): 1 = never take the interior-tile fast kernels
 inline int wgrad_mt(int cout, long long pts) { return (cout >= 128 && pts > g_wg_small_pts) ? 128 : 64; }
 inline int wgrad_nt(int cin, long long pts) { return (cin >= 96 && pts > g_wg_small_pts) ? 128 : 64; }
 inline int wgrad_split_len(int b, int cin, int cout, int P) {
@@ -1607,6 +1686,7 @@ int istnet_pw_set_tuning(int key, int value) {
     case 3: g_force_fwd_cfg = value; return 0;
     case 4: g_force_dgrad_cfg = value; return 0;
     case 5: g_bwd_small_target = value > 0 ? value : 256; return 0;
+    case 6: g_exp_no_fast = value; return 0;
     default: return ISTNET_PN2_EINVAL;
   }
 }
@@ -1806,10 +1886,19 @@ int istnet_pw_dgrad(int b, int cin_total, int ci_off, int m_rows, int cout, int 
   const TileCfg cfg = pick_dgrad_cfg(b, m_rows, p, g_force_dgrad_cfg);
   const int tpc = ceil_div(p, cfg_nt(cfg));
   const dim3 grid(tpc * b, ceil_div(m_rows, cfg_mt(cfg)));
+  const bool interior = (m_rows % cfg_mt(cfg) == 0) && (p % cfg_nt(cfg) == 0) && (cout % kKT == 0) &&
+                        (g_exp_no_fast == 0);
 #define ISTNET_DGRAD(MT, NT, WM, WN)                                                                       \
-  hipLaunchKernelGGL((pw_dgrad_kernel<MT, NT, WM, WN>), grid, dim3(kThreads), 0, as_stream(stream),       \
-                     cin_total, ci_off, m_rows, cout, p, tpc, w, y, gs, bn, bwdc, dx, y_in, bn_in, part_g, part_gy, \
-                     tpc * b)
+  do {                                                                                                     \
+    if (interior)                                                                                          \
+      hipLaunchKernelGGL((pw_dgrad_kernel<MT, NT, WM, WN, true>), grid, dim3(kThreads), 0, as_stream(stream), \
+                         cin_total, ci_off, m_rows, cout, p, tpc, w, y, gs, bn, bwdc, dx, y_in, bn_in, part_g,  \
+                         part_gy, tpc * b);                                                                 \
+    else                                                                                                   \
+      hipLaunchKernelGGL((pw_dgrad_kernel<MT, NT, WM, WN, false>), grid, dim3(kThreads), 0, as_stream(stream), \
+                         cin_total, ci_off, m_rows, cout, p, tpc, w, y, gs, bn, bwdc, dx, y_in, bn_in, part_g,  \
+                         part_gy, tpc * b);                                                                 \
+  } while (0)
   switch (cfg) {
     case kCfg128x128: ISTNET_DGRAD(128, 128, 2, 2); break;
     case kCfg64x128: ISTNET_DGRAD(64, 128, 2, 2); break;
