@@ -1,0 +1,155 @@
+"""Direct checks of the newer C-ABI entry points of include/istnet_pw.h against plain torch expressions
+(the module-level tests cover them only through the fused autograd nodes)."""
+import pytest
+import torch
+
+import istnet_amd  # noqa: F401
+from istnet_amd import _native
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _st():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _bn_block(c, g):
+    return torch.stack([torch.rand(c, generator=g) + 0.5, torch.randn(c, generator=g) * 0.1, torch.zeros(c),
+                        torch.ones(c)]).contiguous().to(DEV)
+
+
+@pytest.mark.parametrize("b,n,npoint,s,cfeat,cout", [(2, 128, 32, 16, 16, 48), (3, 256, 64, 32, 0, 16), (2, 512, 128, 8, 64, 32)])
+def test_gather_add_equals_grouped_product(b, n, npoint, s, cfeat, cout):
+    lib = _native.lib()
+    g = torch.Generator().manual_seed(b + n)
+    xyz = torch.rand(b, n, 3, generator=g).to(DEV)
+    new_xyz = xyz[:, :npoint].contiguous()
+    idx = torch.randint(0, n, (b, npoint, s), generator=g, dtype=torch.int32).to(DEV)
+    w0 = (torch.randn(cout, 3 + cfeat, generator=g) * 0.3).to(DEV)
+    feat = torch.randn(b, cfeat, n, generator=g).to(DEV) if cfeat else None
+    p = npoint * s
+    z = None
+    if cfeat:
+        z = torch.empty(b, cout, n, device=DEV)
+        assert lib.istnet_pw_forward_ld(b, cfeat, cout, n, feat.data_ptr(), w0.data_ptr() + 12, 3 + cfeat, None, None,
+                                        z.data_ptr(), None, None, _st()) == 0
+        torch.testing.assert_close(z, torch.matmul(w0[:, 3:], feat), rtol=1e-4, atol=1e-4)
+    y = torch.empty(b, cout, p, device=DEV)
+    nt = lib.istnet_pw_gather_add_tiles(b, p)
+    part = torch.empty(2, cout, nt, device=DEV)
+    assert lib.istnet_pw_gather_add(b, n, npoint, s, cout, xyz.data_ptr(), new_xyz.data_ptr(), idx.data_ptr(),
+                                    z.data_ptr() if z is not None else None, w0.data_ptr(), 3 + cfeat, y.data_ptr(),
+                                    part[0].data_ptr(), part[1].data_ptr(), _st()) == 0
+    flat = idx.long().reshape(b, p)
+    xrel = torch.gather(xyz, 1, flat.unsqueeze(-1).expand(-1, -1, 3)) - new_xyz.repeat_interleave(s, dim=1)
+    grouped = xrel.transpose(1, 2)
+    if cfeat:
+        grouped = torch.cat([grouped, torch.gather(feat, 2, flat.unsqueeze(1).expand(-1, cfeat, -1))], dim=1)
+    want = torch.matmul(w0, grouped)
+    torch.testing.assert_close(y, want, rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(part[0].sum(-1), want.sum(dim=(0, 2)), rtol=1e-4, atol=1e-3)
+    torch.testing.assert_close(part[1].sum(-1), want.square().sum(dim=(0, 2)), rtol=1e-4, atol=1e-3)
+
+
+@pytest.mark.parametrize("cin,cout,p,pooled", [(16, 32, 512, False), (32, 32, 256, True), (16, 16, 1024, True)])
+def test_bwd_small_equals_dgrad_plus_wgrad(cin, cout, p, pooled):
+    lib = _native.lib()
+    b, s = 3, 16
+    g = torch.Generator().manual_seed(cin + cout + p)
+    x = torch.randn(b, cin, p, generator=g).to(DEV)
+    y = torch.randn(b, cout, p, generator=g).to(DEV)
+    w = (torch.randn(cout, cin, generator=g) * 0.2).to(DEV)
+    bn, bn_in = _bn_block(cout, g), _bn_block(cin, g)
+    bwdc = torch.stack([torch.rand(cout, generator=g) + 0.5, torch.randn(cout, generator=g) * 0.01,
+                        torch.randn(cout, generator=g) * 0.01]).contiguous().to(DEV)
+    if pooled:
+        gr = p // s
+        dpool = torch.randn(b, cout, gr, generator=g).to(DEV)
+        arg = torch.randint(0, s, (b, cout, gr), generator=g, dtype=torch.uint8).to(DEV)
+        src = (None, dpool.data_ptr(), arg.data_ptr(), s)
+        gdense = torch.zeros(b, cout, gr, s, device=DEV).scatter_(3, arg.long().unsqueeze(-1), dpool.unsqueeze(-1)).reshape(b, cout, p)
+    else:
+        gdense = torch.randn(b, cout, p, generator=g).to(DEV)
+        src = (gdense.data_ptr(), None, None, 0)
+    dx = torch.empty(b, cin, p, device=DEV)
+    splits = lib.istnet_pw_bwd_small_splits(b, p)
+    part = torch.empty(2, cin, splits, device=DEV)
+    ws = torch.empty(splits, cout, cin, device=DEV)
+    assert lib.istnet_pw_bwd_small(b, cin, cout, p, src[3], w.data_ptr(), x.data_ptr(), bn_in.data_ptr(), y.data_ptr(),
+                                   src[0], src[1], 0, src[2], bn.data_ptr(), bwdc.data_ptr(), dx.data_ptr(),
+                                   part[0].data_ptr(), part[1].data_ptr(), ws.data_ptr(), _st()) == 0
+    mask = (y * bn[0].view(1, -1, 1) + bn[1].view(1, -1, 1)) > 0
+    dy = bwdc[0].view(1, -1, 1) * (gdense * mask) + bwdc[1].view(1, -1, 1) + bwdc[2].view(1, -1, 1) * y
+    want_dx = torch.matmul(w.t(), dy)
+    act = torch.relu(x * bn_in[0].view(1, -1, 1) + bn_in[1].view(1, -1, 1))
+    want_dw = torch.einsum("bop,bip->oi", dy, act)
+    gq = want_dx * (act > 0)
+    torch.testing.assert_close(dx, want_dx, rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(ws.sum(0), want_dw, rtol=1e-4, atol=1e-3)
+    torch.testing.assert_close(part[0].sum(-1), gq.sum(dim=(0, 2)), rtol=1e-3, atol=1e-2)
+    torch.testing.assert_close(part[1].sum(-1), (gq * x).sum(dim=(0, 2)), rtol=1e-3, atol=1e-2)
+
+
+def test_forward_acc_channel_stats_and_dy():
+    lib = _native.lib()
+    b, cin, cout, p = 2, 24, 40, 256
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(b, cin, p, generator=g).to(DEV)
+    w = (torch.randn(cout, cin + 8, generator=g) * 0.2).to(DEV)          # the layer uses columns 8.. of a wider matrix
+    t = torch.randn(b, cout, p, generator=g).to(DEV)
+    y = torch.empty(b, cout, p, device=DEV)
+    nt = lib.istnet_pw_stat_tiles(b, cout, p)
+    part = torch.empty(2, cout, nt, device=DEV)
+    assert lib.istnet_pw_forward_acc(b, cin, cout, p, x.data_ptr(), w.data_ptr() + 32, cin + 8, t.data_ptr(), y.data_ptr(),
+                                     part[0].data_ptr(), part[1].data_ptr(), _st()) == 0
+    want = t + torch.matmul(w[:, 8:], x)
+    torch.testing.assert_close(y, want, rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(part[0].sum(-1), want.sum(dim=(0, 2)), rtol=1e-4, atol=1e-3)
+    nt2 = lib.istnet_pw_bwd_stat_tiles(b, p)
+    part2 = torch.empty(2, cout, nt2, device=DEV)
+    assert lib.istnet_pw_channel_stats(b, cout, p, y.data_ptr(), part2[0].data_ptr(), part2[1].data_ptr(), _st()) == 0
+    torch.testing.assert_close(part2[1].sum(-1), want.square().sum(dim=(0, 2)), rtol=1e-4, atol=1e-3)
+    bn = _bn_block(cout, g)
+    bwdc = torch.stack([torch.rand(cout, generator=g), torch.randn(cout, generator=g), torch.randn(cout, generator=g)]).contiguous().to(DEV)
+    d = torch.randn(b, cout, p, generator=g).to(DEV)
+    out = torch.empty_like(y)
+    assert lib.istnet_pw_dy(b, cout, p, y.data_ptr(), d.data_ptr(), bn.data_ptr(), bwdc.data_ptr(), out.data_ptr(), _st()) == 0
+    mask = (y * bn[0].view(1, -1, 1) + bn[1].view(1, -1, 1)) > 0
+    torch.testing.assert_close(out, bwdc[0].view(1, -1, 1) * (d * mask) + bwdc[1].view(1, -1, 1) + bwdc[2].view(1, -1, 1) * y,
+                               rtol=1e-5, atol=1e-5)
+
+
+def test_scatter_dwx_partials():
+    """istnet_pw_scatter_dy: the scattered dY0 and, in both modes, the xyz-weight partials."""
+    lib = _native.lib()
+    b, n, npoint, s, cout = 2, 128, 32, 16, 12
+    g = torch.Generator().manual_seed(5)
+    xyz = torch.rand(b, n, 3, generator=g).to(DEV)
+    new_xyz = xyz[:, :npoint].contiguous()
+    idx = torch.randint(0, n, (b, npoint, s), generator=g, dtype=torch.int32).to(DEV)
+    p = npoint * s
+    y = torch.randn(b, cout, p, generator=g).to(DEV)
+    d = torch.randn(b, cout, p, generator=g).to(DEV)
+    bn = _bn_block(cout, g)
+    bwdc = torch.stack([torch.rand(cout, generator=g) + 0.5, torch.randn(cout, generator=g) * 0.1,
+                        torch.randn(cout, generator=g) * 0.1]).contiguous().to(DEV)
+    mask = (y * bn[0].view(1, -1, 1) + bn[1].view(1, -1, 1)) > 0
+    dy = bwdc[0].view(1, -1, 1) * (d * mask) + bwdc[1].view(1, -1, 1) + bwdc[2].view(1, -1, 1) * y
+    flat = idx.long().reshape(b, p)
+    xrel = torch.gather(xyz, 1, flat.unsqueeze(-1).expand(-1, -1, 3)) - new_xyz.repeat_interleave(s, dim=1)
+    want_g = torch.zeros(b, cout, n, device=DEV).scatter_add_(2, flat.unsqueeze(1).expand(-1, cout, -1), dy)
+    want_dwx = torch.einsum("bcp,bpk->ck", dy, xrel)
+    out = torch.empty(b, cout, n, device=DEV)
+    dwx = torch.empty(b, cout, 3, device=DEV)
+    assert lib.istnet_pw_scatter_dy(b, cout, n, p, 0, y.data_ptr(), d.data_ptr(), None, 0, None, bn.data_ptr(),
+                                    bwdc.data_ptr(), idx.data_ptr(), out.data_ptr(), 0, xyz.data_ptr(),
+                                    new_xyz.data_ptr(), s, dwx.data_ptr(), _st()) == 0
+    torch.testing.assert_close(out, want_g, rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(dwx.sum(0), want_dwx, rtol=1e-4, atol=1e-4)
+    chunks = lib.istnet_pw_dwx_chunks(b, cout, p)
+    dwx2 = torch.empty(b * chunks, cout, 3, device=DEV)
+    assert lib.istnet_pw_scatter_dy(b, cout, n, p, 0, y.data_ptr(), d.data_ptr(), None, 0, None, bn.data_ptr(),
+                                    bwdc.data_ptr(), idx.data_ptr(), None, 0, xyz.data_ptr(), new_xyz.data_ptr(), s,
+                                    dwx2.data_ptr(), _st()) == 0
+    torch.testing.assert_close(dwx2.sum(0), want_dwx, rtol=1e-4, atol=1e-4)
