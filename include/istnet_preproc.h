@@ -1,0 +1,44 @@
+/*
+ * istnet_preproc.h -- C ABI (same library, libistnet_pn2.so, and same conventions as istnet_pn2.h) of the
+ * per-instance input preparation that the reference does in numpy inside its Dataset classes
+ * (SURVEY.md 8f rank 2): depth back-projection at the sampled pixels and the remap of the `choose`
+ * indices from crop coordinates to the resized img_size x img_size crop.
+ */
+#ifndef ISTNET_PREPROC_H_
+#define ISTNET_PREPROC_H_
+
+#include "istnet_pn2.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* replaces provider/dataset.py:203-210 + :226-231 (TrainingDataset.__getitem__) and :348-355 + :392,401-405
+ * (TestDataset.__getitem__), which build the full (h,w,3) float64 point map per image on the host and then
+ * keep n of its pixels.  Here only the n sampled pixels of each instance are back-projected.
+ *
+ *   depth        (h,w) image per instance, device memory; depth_kind 0 = uint16 millimetres (load_depth,
+ *                utils/data_utils.py:6-22), 1 = float32 (the output of fill_missing, data_utils.py:516-540).
+ *                Instance i reads depth + i*depth_stride ELEMENTS (0 = all instances share one image, as the
+ *                instances of one test image do).
+ *   bbox         (count,4) int32: rmin, rmax, cmin, cmax of get_bbox (crop = [rmin:rmax, cmin:cmax]).
+ *   choose       (count,n) int32: flat row-major indices into the crop (width cmax-cmin), dataset.py:191-199.
+ *   fx,fy,cx,cy  camera intrinsics; norm_scale = 1000.0; img_size = side of the resized crop (192).
+ *   pts          (count,n,3) f32 out: ((x-cx)*z/fx, (y-cy)*z/fy, z), z = depth/norm_scale, evaluated in
+ *                float64 in numpy's promotion order and rounded to f32 once (bit-exact with the host code;
+ *                for depth_kind 1, z itself is the f32 quotient, as numpy keeps float32/python-float in f32).
+ *   choose_out   (count,n) int64 out: floor(row*ratio)*img_size + floor(col*ratio), row = choose / crop_w,
+ *                col = choose % crop_w, crop_w = rmax-rmin, ratio = img_size/crop_w in float64 (the reference
+ *                uses the crop HEIGHT for both, get_bbox crops are square).
+ * Returns ISTNET_PN2_EINVAL for negative sizes, depth_kind outside {0,1} or img_size < 1.  A `choose` index
+ * outside its crop or a crop outside the image is the caller's error (the reference raises IndexError); the kernel
+ * clamps the pixel coordinate into the image instead of reading out of bounds. */
+ISTNET_PN2_API int istnet_backproject_choose(int count, int n, int h, int w, const void *depth, int depth_kind,
+                                             long long depth_stride, const int *bbox, const int *choose,
+                                             double fx, double fy, double cx, double cy, double norm_scale,
+                                             int img_size, float *pts, long long *choose_out, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -148,6 +148,7 @@ class WorldSpaceEnhancer(nn.Module):
 
 
 USE_RGB_STREAM = os.environ.get("ISTNET_NO_RGB_STREAM") is None
+USE_GATHER_FIRST = os.environ.get("ISTNET_NO_GATHER_FIRST") is None
 _RGB_STREAMS = {}
 
 
@@ -176,6 +177,8 @@ class IST_Net(nn.Module):
     def _rgb_local(self, inputs, b):
         if "rgb_local" in inputs:
             return inputs["rgb_local"]
+        if not self.training and USE_GATHER_FIRST and getattr(self.rgb_cam_extractor, "gathers_choose", False):
+            return self.rgb_cam_extractor(inputs["rgb"], inputs["choose"])   # eval: last layer on the chosen pixels only
         feat = self.rgb_cam_extractor(inputs["rgb"])
         d = feat.size(1)
         if not feat.is_contiguous() and feat.is_contiguous(memory_format=torch.channels_last):

@@ -1,0 +1,46 @@
+"""Per-instance input preparation on the GPU.
+
+``backproject_choose`` replaces the numpy block of the reference's Dataset classes that turns a depth image, an
+instance crop and the sampled pixel list into the network inputs ``pts`` and ``choose``
+(provider/dataset.py:203-210,226-231 for training, :348-355,392,401-405 for testing).  The host code there builds
+the whole (480,640,3) float64 point map for every image; the kernel (csrc/preproc.hip through
+include/istnet_preproc.h) back-projects only the sampled pixels, bit-exactly.  Mask logic, random sampling
+(`np.random.choice`), image decoding and the RGB resize stay with the caller.
+"""
+import torch
+
+from . import _native
+
+REAL_INTRINSICS = (591.0125, 590.16775, 322.525, 244.11084)     # fx, fy, cx, cy   [ref dataset.py:305]
+CAMERA_INTRINSICS = (577.5, 577.5, 319.5, 239.5)
+
+
+def backproject_choose(depth, bboxes, choose, intrinsics=REAL_INTRINSICS, norm_scale=1000.0, img_size=192):
+    """depth: (h,w) shared by all instances or (count,h,w), uint16 (raw millimetres; int16 storage accepted) or
+    float32 (after fill_missing); bboxes (count,4) rmin,rmax,cmin,cmax; choose (count,n) flat crop indices.
+    Returns pts (count,n,3) float32 and choose_out (count,n) int64.  CUDA tensors only (no CPU path)."""
+    if not depth.is_cuda:
+        raise RuntimeError("backproject_choose: CPU not supported")
+    if depth.dtype not in (torch.uint16, torch.int16, torch.float32):
+        raise TypeError(f"backproject_choose: depth must be uint16 or float32, got {depth.dtype}")
+    if depth.dim() not in (2, 3) or choose.dim() != 2 or bboxes.shape != (choose.size(0), 4):
+        raise ValueError("backproject_choose: expected depth (h,w) or (count,h,w), bboxes (count,4), choose (count,n)")
+    count, n = choose.shape
+    if depth.dim() == 3 and depth.size(0) != count:
+        raise ValueError("backproject_choose: one depth image per instance, or one shared image")
+    depth = depth.contiguous()
+    h, w = depth.shape[-2:]
+    bboxes = bboxes.to(device=depth.device, dtype=torch.int32).contiguous()
+    choose = choose.to(device=depth.device, dtype=torch.int32).contiguous()
+    pts = torch.empty(count, n, 3, dtype=torch.float32, device=depth.device)
+    out = torch.empty(count, n, dtype=torch.int64, device=depth.device)
+    fx, fy, cx, cy = (float(v) for v in intrinsics)
+    with torch.cuda.device(depth.device):
+        rc = _native.lib().istnet_backproject_choose(
+            count, n, h, w, depth.data_ptr(), 1 if depth.dtype == torch.float32 else 0,
+            h * w if depth.dim() == 3 else 0, bboxes.data_ptr(), choose.data_ptr(), fx, fy, cx, cy,
+            float(norm_scale), int(img_size), pts.data_ptr(), out.data_ptr(),
+            torch.cuda.current_stream(depth.device).cuda_stream)
+    if rc != 0:
+        raise RuntimeError(f"istnet_backproject_choose failed with code {rc}")
+    return pts, out

@@ -133,20 +133,43 @@ class Modified_PSPNet(nn.Module):
         self.drop_2 = nn.Dropout2d(p=0.15)
         self.final = nn.Sequential(nn.Conv2d(64, 128, kernel_size=1), nn.BatchNorm2d(128), nn.PReLU())
 
-    def forward(self, x):
+    def forward(self, x, choose=None):
+        """rgb (B,3,H,W) -> (B,128,H,W); with ``choose`` (B,N) flat pixel indices in eval mode -> (B,128,N), the
+        features of the chosen pixels only (see ``_final_at``)."""
         f, _ = self.feats(x)
         p = self.drop_1(self.psp(f))
         p = self.drop_2(self.up_1(p))
         p = self.drop_2(self.up_2(p))
-        return self.final(self.up_3(p))
+        p = self.up_3(p)
+        if choose is not None and not self.training:
+            return self._final_at(p, choose)
+        return self.final(p)
+
+    def _final_at(self, p, choose):
+        """`final` (1x1 conv + BatchNorm + PReLU, all per-pixel in eval mode) on the chosen pixels only: IST-Net reads
+        N of the H*W output pixels (ist_net.py:41-45), so gathering the 64-channel decoder output first skips
+        (H*W - N)/H*W of the last layer's work and never materialises the (B,128,H,W) map (1.2 GB at B=64).  Same
+        arithmetic per pixel as the dense path; not valid in training mode, where BatchNorm takes batch statistics
+        over all pixels."""
+        b, c = p.size(0), p.size(1)
+        if not p.is_contiguous() and p.is_contiguous(memory_format=torch.channels_last):
+            rows = p.permute(0, 2, 3, 1).reshape(b, -1, c)
+            picked = torch.gather(rows, 1, choose.unsqueeze(-1).expand(-1, -1, c)).transpose(1, 2)
+        else:
+            picked = torch.gather(p.reshape(b, c, -1), 2, choose.unsqueeze(1).expand(-1, c, -1))
+        conv, bn, act = self.final[0], self.final[1], self.final[2]
+        y = F.conv1d(picked, conv.weight.view(conv.out_channels, c, 1), conv.bias)
+        y = F.batch_norm(y, bn.running_mean, bn.running_var, bn.weight, bn.bias, False, 0.0, bn.eps)
+        return F.prelu(y, act.weight).contiguous()
 
 
 class ModifiedResnet(nn.Module):
     """`rgb_cam_extractor` of IST-Net.  [ref modules.py:232-241]"""
+    gathers_choose = True     # forward(x, choose) returns the chosen pixels' features in eval mode
 
     def __init__(self):
         super().__init__()
         self.model = Modified_PSPNet(sizes=(1, 2, 3, 6), psp_size=512)
 
-    def forward(self, x):
-        return self.model(x)
+    def forward(self, x, choose=None):
+        return self.model(x, choose)

@@ -174,3 +174,30 @@ def test_rgb_local_gather_is_layout_agnostic():
     b = IST_Net(rgb_extractor=Ext(True))._rgb_local({"rgb": None, "choose": choose}, 2)
     assert a.shape == (2, 128, 4) and torch.equal(a, b)
     assert torch.equal(a[1, :, 3], torch.arange(2 * 128 * 30, dtype=torch.float32).reshape(2, 128, 30)[1, :, 15])
+
+
+def test_rgb_gather_first_equals_dense_tail_in_eval():
+    """Eval mode: `final` applied to the chosen pixels only == the dense (B,128,H,W) map gathered afterwards
+    (reference order, ist_net.py:41-45), for NCHW and channels-last; training mode keeps the dense path."""
+    import torch
+    from istnet_amd import rgb_branch
+    from istnet_amd.ist_net import IST_Net
+    torch.manual_seed(3)
+    ext = rgb_branch.ModifiedResnet()
+    bn = ext.model.final[1]
+    bn.running_mean.normal_(0, 0.3); bn.running_var.uniform_(0.5, 2.0); bn.weight.data.normal_(1, 0.2); bn.bias.data.normal_(0, 0.2)
+    ext.eval()
+    net = IST_Net(rgb_extractor=ext).eval()
+    rgb = torch.randn(2, 3, 48, 48)
+    choose = torch.randint(0, 48 * 48, (2, 37))
+    with torch.no_grad():
+        dense = ext(rgb)
+        want = torch.gather(dense.reshape(2, 128, -1), 2, choose.unsqueeze(1).expand(-1, 128, -1))
+        got = net._rgb_local({"rgb": rgb, "choose": choose}, 2)
+        ext_cl = ext.to(memory_format=torch.channels_last)
+        got_cl = net._rgb_local({"rgb": rgb.contiguous(memory_format=torch.channels_last), "choose": choose}, 2)
+    assert got.shape == (2, 128, 37) and got.is_contiguous()
+    torch.testing.assert_close(got, want, rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(got_cl, want, rtol=1e-5, atol=1e-5)
+    net.train()
+    assert ext_cl(rgb, choose).shape == (2, 128, 48, 48)       # training mode ignores `choose`
