@@ -45,6 +45,15 @@ def _kname(base, cfg, gather=None):
     return f"{base}<{mt}, {nt}, {wm}, {wn}{tail}>"
 
 
+def _dgrad_kname(lib, b, rows, cout, p):
+    """pw_dgrad_kernel<M_T, N_T, WM, WN, FAST> as launch_pw_dgrad picks it: FAST = every tile interior and the
+    reduction length a multiple of the k-tile (kKT = 16)."""
+    cfg = lib.istnet_pw_dgrad_tile_cfg(b, rows, p)
+    mt, nt = cfg // 1000, cfg % 1000
+    fast = rows % mt == 0 and p % nt == 0 and cout % 16 == 0
+    return _kname("pw_dgrad_kernel", cfg)[:-1] + (", true>" if fast else ", false>")
+
+
 def _gather_mode(ga, multiple):
     """Loader mode the C launcher picks for a gathered layer 0 (see launch_pw_forward / launch_pw_wgrad)."""
     if ga is None:
@@ -437,10 +446,12 @@ def _backward_stack(lib, dev, st, b, c0, g, s, x, gather, training, ys, bns, par
             ws = _empty((splits, cout, cin), torch.float32, dev)
             dprev = _empty((b, cin, p), torch.float32, dev)
             fused_part, fused_nt = _empty((2, cin, splits), torch.float32, dev), splits
-            _native.check(lib.istnet_pw_bwd_small(
-                b, cin, cout, p, ns_arg, w2.data_ptr(), ys[li - 1].data_ptr(), bns[li - 1].data_ptr(), y.data_ptr(),
-                dd, dp, pbs, da, bn.data_ptr(), bwdc.data_ptr(), dprev.data_ptr(), fused_part[0].data_ptr(),
-                fused_part[1].data_ptr(), ws.data_ptr(), st), "pw_bwd_small")
+            _native.check(_native.timed(
+                "pw_bwd_small_kernel", 4.0 * b * p * cin * cout, 4.0 * (b * p * (2 * cin + cout) + grad_elems),
+                lambda: lib.istnet_pw_bwd_small(
+                    b, cin, cout, p, ns_arg, w2.data_ptr(), ys[li - 1].data_ptr(), bns[li - 1].data_ptr(),
+                    y.data_ptr(), dd, dp, pbs, da, bn.data_ptr(), bwdc.data_ptr(), dprev.data_ptr(),
+                    fused_part[0].data_ptr(), fused_part[1].data_ptr(), ws.data_ptr(), st)), "pw_bwd_small")
             wjobs.append(_reduce_only_job(dev, w, cout, cin, splits, ws))
             wlayers.append(li)
             d_dense, d_pooled, d_arg = dprev, None, None
@@ -486,7 +497,7 @@ def _backward_stack(lib, dev, st, b, c0, g, s, x, gather, training, ys, bns, par
             else:
                 y_in = bn_in = pg = pgy = None
             _native.check(_native.timed(
-                _kname("pw_dgrad_kernel", lib.istnet_pw_dgrad_tile_cfg(b, rows, p)), 2.0 * b * p * rows * cout,
+                _dgrad_kname(lib, b, rows, cout, p), 2.0 * b * p * rows * cout,
                 4.0 * (b * p * (rows + cout + (rows if li > 0 else 0)) + grad_elems), lambda: lib.istnet_pw_dgrad(
                     b, cin, ci_off, rows, cout, p, ns_arg, w2.data_ptr(), y.data_ptr(), dd, dp, pbs, da,
                     bn.data_ptr(), bwdc.data_ptr(), dprev.data_ptr(), y_in, bn_in, pg, pgy, st)), "pw_dgrad")
@@ -711,10 +722,12 @@ class FusedSALevelFunction(Function):
                 wcat = torch.cat(w0f, dim=0) if nsc > 1 else w0f[0]           # (sum Cout0, 3 + C)
                 ident, bwdc = _ident_consts(dev, cout0_tot)                   # mask always on, dY = g
                 dfeat = _empty((b, cfeat, n_src), torch.float32, dev)
-                _native.check(lib.istnet_pw_dgrad(
-                    b, 3 + cfeat, 3, cfeat, cout0_tot, n_src, 0, wcat.data_ptr(), gbuf.data_ptr(), gbuf.data_ptr(),
-                    None, 0, None, ident.data_ptr(), bwdc.data_ptr(), dfeat.data_ptr(), None, None, None, None, st),
-                    "pw_dgrad(level)")
+                _native.check(_native.timed(
+                    _dgrad_kname(lib, b, cfeat, cout0_tot, n_src),
+                    2.0 * b * n_src * cfeat * cout0_tot, 4.0 * b * n_src * (cfeat + cout0_tot), lambda: lib.istnet_pw_dgrad(
+                        b, 3 + cfeat, 3, cfeat, cout0_tot, n_src, 0, wcat.data_ptr(), gbuf.data_ptr(), gbuf.data_ptr(),
+                        None, 0, None, ident.data_ptr(), bwdc.data_ptr(), dfeat.data_ptr(), None, None, None, None,
+                        st)), "pw_dgrad(level)")
                 # layer-0 weight gradients of the scales that left a dwx placeholder: dW0[:, 3:] = sum_b G[b].feat[b]^T
                 # -- ONE wgrad over the n source points for all scales (gbuf holds every scale's G) -- and
                 # dW0[:, :3] = sum_b dwx[b]; off the critical path like the other weight gradients
@@ -744,9 +757,11 @@ def _finish_layer0_grads(lib, dev, b, cfeat, cout0_tot, n_src, feat, gbuf, ident
         splits = lib.istnet_pw_wgrad_splits(b, cfeat, cout0_tot, n_src)
         ws = _empty((splits, cout0_tot, cfeat), torch.float32, dev)
         dwf = _empty((cout0_tot, cfeat), torch.float32, dev)
-        _native.check(lib.istnet_pw_wgrad(b, cfeat, cout0_tot, n_src, 0, feat.data_ptr(), None, None, gbuf.data_ptr(),
-                                          gbuf.data_ptr(), None, 0, None, ident.data_ptr(), bwdc.data_ptr(),
-                                          ws.data_ptr(), wst), "pw_wgrad(level G)")
+        _native.check(_native.timed(
+            _kname("pw_wgrad_kernel", lib.istnet_pw_wgrad_tile_cfg(b, cfeat, cout0_tot, n_src), 0),
+            2.0 * b * n_src * cfeat * cout0_tot, 4.0 * b * n_src * (cfeat + cout0_tot), lambda: lib.istnet_pw_wgrad(
+                b, cfeat, cout0_tot, n_src, 0, feat.data_ptr(), None, None, gbuf.data_ptr(), gbuf.data_ptr(), None, 0,
+                None, ident.data_ptr(), bwdc.data_ptr(), ws.data_ptr(), wst)), "pw_wgrad(level G)")
         _native.reduce_multi([(cout0_tot * cfeat, splits, ws.data_ptr(), dwf.data_ptr())], wst)
         for (gi, row0, p), dwx, dest in zip(w0_slots, placeholders, dests):
             torch.cat([dwx.sum(dim=0), dwf[row0:row0 + p.shape[0]]], dim=1, out=dest)
@@ -795,8 +810,11 @@ class FusedFPFunction(Function):
         with torch.cuda.device(dev):
             st = _st(dev)
             zk = _empty((b, cout0, m), torch.float32, dev)
-            _native.check(lib.istnet_pw_forward_ld(b, c2, cout0, m, known.data_ptr(), w2.data_ptr(), cin, None, None,
-                                                   zk.data_ptr(), None, None, st), "pw_forward_ld(fp)")
+            _native.check(_native.timed(
+                _kname("pw_fwd_kernel", lib.istnet_pw_tile_cfg(b, cout0, m), 0), 2.0 * b * m * c2 * cout0,
+                4.0 * b * m * (c2 + cout0), lambda: lib.istnet_pw_forward_ld(
+                    b, c2, cout0, m, known.data_ptr(), w2.data_ptr(), cin, None, None, zk.data_ptr(), None, None,
+                    st)), "pw_forward_ld(fp)")
             t = _ext.three_interpolate(zk, idx, weight)               # (B, cout0, n)
             bn0 = _empty((4, cout0), torch.float32, dev)
             part = None
@@ -805,9 +823,11 @@ class FusedFPFunction(Function):
                 if training:
                     nt = lib.istnet_pw_stat_tiles(b, cout0, n)
                     part = _empty((2, cout0, nt), torch.float32, dev)
-                _native.check(lib.istnet_pw_forward_acc(b, c1, cout0, n, skip_c.data_ptr(), w2.data_ptr() + 4 * c2, cin,
-                                                        t.data_ptr(), y0.data_ptr(), _p(part[0]) if training else None,
-                                                        _p(part[1]) if training else None, st), "pw_forward_acc")
+                _native.check(_native.timed(
+                    _kname("pw_fwd_kernel", lib.istnet_pw_tile_cfg(b, cout0, n), 0), 2.0 * b * n * c1 * cout0,
+                    4.0 * b * n * (c1 + 2 * cout0), lambda: lib.istnet_pw_forward_acc(
+                        b, c1, cout0, n, skip_c.data_ptr(), w2.data_ptr() + 4 * c2, cin, t.data_ptr(), y0.data_ptr(),
+                        _p(part[0]) if training else None, _p(part[1]) if training else None, st)), "pw_forward_acc")
             else:
                 y0 = t
                 if training:
@@ -860,9 +880,12 @@ class FusedFPFunction(Function):
                                            bwdc0.data_ptr(), dy0.data_ptr(), st), "pw_dy")
             if need_skip:
                 ds = _empty((b, c1, n), torch.float32, dev)
-                _native.check(lib.istnet_pw_dgrad(b, cin, c2, c1, cout0, n, 0, w2.data_ptr(), dy0.data_ptr(),
-                                                  dy0.data_ptr(), None, 0, None, ident.data_ptr(), ibw.data_ptr(),
-                                                  ds.data_ptr(), None, None, None, None, st), "pw_dgrad(fp skip)")
+                _native.check(_native.timed(
+                    _dgrad_kname(lib, b, c1, cout0, n), 2.0 * b * n * c1 * cout0,
+                    4.0 * b * n * (c1 + cout0), lambda: lib.istnet_pw_dgrad(
+                        b, cin, c2, c1, cout0, n, 0, w2.data_ptr(), dy0.data_ptr(), dy0.data_ptr(), None, 0, None,
+                        ident.data_ptr(), ibw.data_ptr(), ds.data_ptr(), None, None, None, None, st)),
+                    "pw_dgrad(fp skip)")
                 result["dskip"] = ds
             gk = None
             if need_known or need_w[0]:
@@ -870,9 +893,12 @@ class FusedFPFunction(Function):
                       else _ext.three_interpolate_grad(dy0, idx, weight, m))                       # (B, cout0, m)
             if need_known:
                 dk = _empty((b, c2, m), torch.float32, dev)
-                _native.check(lib.istnet_pw_dgrad(b, cin, 0, c2, cout0, m, 0, w2.data_ptr(), gk.data_ptr(),
-                                                  gk.data_ptr(), None, 0, None, ident.data_ptr(), ibw.data_ptr(),
-                                                  dk.data_ptr(), None, None, None, None, st), "pw_dgrad(fp known)")
+                _native.check(_native.timed(
+                    _dgrad_kname(lib, b, c2, cout0, m), 2.0 * b * m * c2 * cout0,
+                    4.0 * b * m * (c2 + cout0), lambda: lib.istnet_pw_dgrad(
+                        b, cin, 0, c2, cout0, m, 0, w2.data_ptr(), gk.data_ptr(), gk.data_ptr(), None, 0, None,
+                        ident.data_ptr(), ibw.data_ptr(), dk.data_ptr(), None, None, None, None, st)),
+                    "pw_dgrad(fp known)")
                 result["dknown"] = dk
             if need_w[0]:
                 dest = _grad_dest(w0, (cout0, cin), dev)
@@ -882,19 +908,22 @@ class FusedFPFunction(Function):
                     sp_a = lib.istnet_pw_wgrad_splits(b, c2, cout0, m)
                     ws_a = _empty((sp_a, cout0, c2), torch.float32, dev)
                     dwa = _empty((cout0, c2), torch.float32, dev)
-                    _native.check(lib.istnet_pw_wgrad(b, c2, cout0, m, 0, known.data_ptr(), None, None, gk.data_ptr(),
-                                                      gk.data_ptr(), None, 0, None, ident.data_ptr(), ibw.data_ptr(),
-                                                      ws_a.data_ptr(), wst), "pw_wgrad(fp known)")
+                    _native.check(_native.timed(
+                        _kname("pw_wgrad_kernel", lib.istnet_pw_wgrad_tile_cfg(b, c2, cout0, m), 0),
+                        2.0 * b * m * c2 * cout0, 4.0 * b * m * (c2 + cout0), lambda: lib.istnet_pw_wgrad(
+                            b, c2, cout0, m, 0, known.data_ptr(), None, None, gk.data_ptr(), gk.data_ptr(), None, 0,
+                            None, ident.data_ptr(), ibw.data_ptr(), ws_a.data_ptr(), wst)), "pw_wgrad(fp known)")
                     red = [(cout0 * c2, sp_a, ws_a.data_ptr(), dwa.data_ptr())]
                     keep = [ws_a, dwa]
                     if skip is not None:
                         sp_b = lib.istnet_pw_wgrad_splits(b, c1, cout0, n)
                         ws_b = _empty((sp_b, cout0, c1), torch.float32, dev)
                         dwb = _empty((cout0, c1), torch.float32, dev)
-                        _native.check(lib.istnet_pw_wgrad(b, c1, cout0, n, 0, skip.data_ptr(), None, None,
-                                                          dy0.data_ptr(), dy0.data_ptr(), None, 0, None,
-                                                          ident.data_ptr(), ibw.data_ptr(), ws_b.data_ptr(), wst),
-                                      "pw_wgrad(fp skip)")
+                        _native.check(_native.timed(
+                            _kname("pw_wgrad_kernel", lib.istnet_pw_wgrad_tile_cfg(b, c1, cout0, n), 0),
+                            2.0 * b * n * c1 * cout0, 4.0 * b * n * (c1 + cout0), lambda: lib.istnet_pw_wgrad(
+                                b, c1, cout0, n, 0, skip.data_ptr(), None, None, dy0.data_ptr(), dy0.data_ptr(), None,
+                                0, None, ident.data_ptr(), ibw.data_ptr(), ws_b.data_ptr(), wst)), "pw_wgrad(fp skip)")
                         red.append((cout0 * c1, sp_b, ws_b.data_ptr(), dwb.data_ptr()))
                         keep += [ws_b, dwb]
                     _native.reduce_multi(red, wst)
