@@ -126,9 +126,9 @@ def make_eager_step(fwd_bwds, opt, world, reducer=None):
 
 
 def optimizer_step(opt, world, reducer):
-    """FlatAdam: pack the gradients once, average the flat buffer over ranks (one RCCL all-reduce), update."""
+    """FlatAdam: pack the gradients once, sum the flat buffer over ranks (one RCCL all-reduce), update with 1/world."""
     if world > 1:
-        opt.step(reducer.average_(opt.pack_grads()))
+        opt.step(reducer.sum_(opt.pack_grads()), grad_scale=1.0 / world)
     else:
         opt.step()
 
@@ -171,7 +171,7 @@ def make_graphed_step(fwd_bwds, opt, world, reducer=None):
         count[0] += 1
         graphs[k].replay()
         if world > 1:
-            opt.step(reducer.average_(packed[k]))
+            opt.step(reducer.sum_(packed[k]), grad_scale=1.0 / world)   # one RCCL all-reduce + one Adam launch
     return step
 
 

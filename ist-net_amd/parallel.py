@@ -68,6 +68,13 @@ class GradAllReducer:
         dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
         return flat.mul_(1.0 / self.world)
 
+    def sum_(self, flat):
+        """In-place SUM across ranks of an already packed gradient tensor; the caller folds 1/world into the
+        optimizer (``FlatAdam.step(flat, grad_scale=1/world)``), saving the scaling pass over the buffer."""
+        if self.world > 1:
+            dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
+        return flat
+
 
 def broadcast_parameters(model, src=0, group=None):
     """Make every replica start from rank ``src``'s parameters and buffers."""

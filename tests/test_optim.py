@@ -89,3 +89,25 @@ def test_fused_backward_writes_gradients_in_place():
     torch.cuda.synchronize()
     for p, q in zip(model.parameters(), ref.parameters()):
         torch.testing.assert_close(p.grad, 2 * q.grad, rtol=1e-4, atol=1e-6)
+
+
+@pytest.mark.gpu
+def test_flat_adam_kernel_odd_sizes_and_grad_scale():
+    """istnet_adam_step on lengths that are not multiples of 4 / 1024, with weight decay and a folded 1/world scale,
+    against the plain-ops update in float64."""
+    dev = torch.device("cuda:0")
+    for n in (1, 3, 1021, 4096, 70001):
+        g = torch.Generator().manual_seed(n)
+        p0 = torch.randn(n, generator=g)
+        model = [torch.nn.Parameter(p0.clone().to(dev))]
+        opt = FlatAdam(model, lr=3e-3, betas=(0.8, 0.95), eps=1e-6, weight_decay=0.02)
+        p, m, v = p0.double(), torch.zeros(n, dtype=torch.float64), torch.zeros(n, dtype=torch.float64)
+        for t in range(1, 4):
+            grad = torch.randn(n, generator=g)
+            opt.step(grad.to(dev), grad_scale=0.5)
+            gg = grad.double() * 0.5 + 0.02 * p
+            m = 0.8 * m + 0.2 * gg
+            v = 0.95 * v + 0.05 * gg * gg
+            p = p - 3e-3 / (1 - 0.8 ** t) * m / (v.sqrt() / (1 - 0.95 ** t) ** 0.5 + 1e-6)
+        torch.testing.assert_close(opt.flat.cpu().double(), p, rtol=2e-5, atol=1e-7)
+        assert model[0].data_ptr() == opt.flat.data_ptr()

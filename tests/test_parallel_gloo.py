@@ -67,7 +67,8 @@ def test_grad_allreduce_world2(bucket_bytes):
 
 
 def _flat_worker(rank, world, port, out):
-    """bench.py's N>1 optimizer path: FlatAdam.pack_grads -> GradAllReducer.average_ -> FlatAdam.step(flat)."""
+    """bench.py's N>1 optimizer path: FlatAdam.pack_grads -> GradAllReducer.sum_ -> FlatAdam.step(flat, 1/world)
+    (first step), and the average_ spelling of the same exchange (second step)."""
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     torch.set_num_threads(1)
@@ -83,10 +84,13 @@ def _flat_worker(rank, world, port, out):
     model = _make(seed=0)
     opt = FlatAdam(model.parameters(), lr=1e-2)
     reducer = GradAllReducer(model, world)
-    for _ in range(2):
+    for it in range(2):
         opt.zero_grad(set_to_none=True)
         _local_grads_keep(model, rank)
-        opt.step(reducer.average_(opt.pack_grads()))
+        if it == 0:
+            opt.step(reducer.sum_(opt.pack_grads()), grad_scale=1.0 / world)
+        else:
+            opt.step(reducer.average_(opt.pack_grads()))
     # single-process replay with the averaged gradients of both ranks
     ref = _make(seed=0)
     ropt = torch.optim.Adam(ref.parameters(), lr=1e-2)
