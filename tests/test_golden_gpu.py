@@ -285,6 +285,14 @@ def test_inference_config5_n2048_matches_cpu_oracle_composition(oracle):
     r = out_gpu["pred_rotation"]
     torch.testing.assert_close(torch.matmul(r.transpose(1, 2), r), torch.eye(3, device=DEV).expand(b, 3, 3),
                                rtol=1e-4, atol=1e-4)
+    # the same deltas in the evaluation's own units (degrees / cm, evaluation_utils.py:632-660) after the
+    # post-processing of test_func (solver.py:231-241); class ids without symmetry so the full rotation counts
+    from istnet_amd import postprocess
+    rts_gpu, scales_gpu = postprocess.assemble_pred_RTs(*(out_gpu[k].cpu() for k in ("pred_rotation", "pred_translation", "pred_size")))
+    rts_cpu, scales_cpu = postprocess.assemble_pred_RTs(*(out_cpu[k] for k in ("pred_rotation", "pred_translation", "pred_size")))
+    err = postprocess.pose_errors(rts_gpu, rts_cpu, [3] * b, [1] * b).diagonal(dim1=0, dim2=1)
+    assert float(err[0].max()) < 0.05 and float(err[1].max()) < 0.01, err      # degrees, centimetres
+    torch.testing.assert_close(scales_gpu, scales_cpu, **TOL)
 
 
 def test_full_istnet_with_rgb_branch_trains_one_step():
