@@ -12,6 +12,9 @@ CSRC = os.path.join(HERE, "csrc")
 LIB_DIR = os.path.join(HERE, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libistnet_pn2.so")
 ARCH = "gfx950"
+# -ffp-contract per source.  "off" for the index ops is part of their numerical contract (the
+# squared distances that decide an index are IEEE f32 in the reference's source order, no FMA contraction).
+FP_CONTRACT = {"pn2_index_ops.hip": "off", "preproc.hip": "off"}
 
 
 def sources():
@@ -37,11 +40,27 @@ def build(force=False, verbose=False):
     if not force and not needs_build():
         return LIB_PATH
     os.makedirs(LIB_DIR, exist_ok=True)
-    cmd = [hipcc(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
-           "-fvisibility=hidden", "-Wall", "-Wno-unused-function", "-o", LIB_PATH] + sources()
+    common = [hipcc(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-Wall",
+              "-Wno-unused-function"]
+    obj_dir = os.path.join(LIB_DIR, "obj")
+    os.makedirs(obj_dir, exist_ok=True)
+    objs, procs = [], []
+    for src in sources():       # one translation unit per file, compiled in parallel, each with its own FP contract
+        obj = os.path.join(obj_dir, os.path.basename(src)[:-4] + ".o")
+        contract = os.environ.get("ISTNET_FP_CONTRACT_" + os.path.basename(src)[:-4].upper(),
+                                  FP_CONTRACT.get(os.path.basename(src), "off"))
+        cmd = common + [f"-ffp-contract={contract}", "-c", src, "-o", obj]
+        if verbose:
+            print(" ".join(cmd))
+        procs.append((cmd, subprocess.Popen(cmd)))
+        objs.append(obj)
+    for cmd, proc in procs:
+        if proc.wait() != 0:
+            raise subprocess.CalledProcessError(proc.returncode, cmd)
+    link = common + ["-shared", "-o", LIB_PATH] + objs
     if verbose:
-        print(" ".join(cmd))
-    subprocess.check_call(cmd)
+        print(" ".join(link))
+    subprocess.check_call(link)
     return LIB_PATH
 
 
