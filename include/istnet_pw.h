@@ -104,6 +104,13 @@ ISTNET_PN2_API int istnet_bn_relu_pool(int b, int c, int g, int s, const float *
 ISTNET_PN2_API int istnet_affine_consts(int c, const float *gamma, const float *beta, const float *mean,
                                         const float *var, float eps, float *bn, void *stream);
 
+/* the same for n <= 8 layers in ONE launch (host arrays of length n; gamma[l] / mean[l] / var[l] may be NULL as
+ * above): the constants depend on parameters only, so a stack computes all of them before its first GEMM */
+ISTNET_PN2_API int istnet_affine_consts_multi(int n, const int *c, const float *const *gamma,
+                                              const float *const *beta, const float *const *mean,
+                                              const float *const *var, const float *eps, float *const *bn,
+                                              void *stream);
+
 /* out = y * bn[0] + bn[1] (per channel), followed by ReLU when relu != 0 -- final layer of a bias stack */
 ISTNET_PN2_API int istnet_affine_apply(int b, int c, int p, int relu, const float *y, const float *bn,
                                        float *out, void *stream);

@@ -52,6 +52,7 @@ SIGNATURES = {
     "istnet_bn_relu_pool": [_i, _i, _i, _i, _p, _p, _p, _l, _p, _p, _p],
     "istnet_pw_bwd_stats_pooled": [_i, _i, _i, _p, _l, _p, _p, _p, _p, _p],
     "istnet_affine_consts": [_i, _p, _p, _p, _p, _f, _p, _p],
+    "istnet_affine_consts_multi": [_i, _p, _p, _p, _p, _p, _p, _p, _p],
     "istnet_affine_apply": [_i, _i, _i, _i, _p, _p, _p, _p],
     "istnet_pw_bwd_stat_tiles": [_i, _i],
     "istnet_pw_bwd_stats": [_i, _i, _i, _i, _p, _p, _p, _l, _p, _p, _p, _p, _p],
@@ -140,6 +141,18 @@ def mark(name):
     MARKERS["names"].append(name)
     check(lib().istnet_debug_marker(MARKERS["buf"].data_ptr() + 8 * i, torch.cuda.current_stream().cuda_stream),
           "debug_marker")
+
+
+def affine_consts_multi(items, stream):
+    """items: list of (c, gamma_ptr|None, beta_ptr, mean_ptr|None, var_ptr|None, eps, bn_ptr); one launch per <= 8."""
+    handle = lib()
+    for i in range(0, len(items), 8):
+        chunk = items[i:i + 8]
+        n = len(chunk)
+        arr = lambda k: (ctypes.c_void_p * n)(*[it[k] for it in chunk])
+        check(handle.istnet_affine_consts_multi(
+            n, (ctypes.c_int * n)(*[it[0] for it in chunk]), arr(1), arr(2), arr(3), arr(4),
+            (ctypes.c_float * n)(*[it[5] for it in chunk]), arr(6), stream), "affine_consts_multi")
 
 
 def reduce_multi(items, stream):

@@ -549,6 +549,38 @@ __global__ __launch_bounds__(256) void affine_consts_kernel(int C, const float* 
   bn[3 * C + c] = istd;
 }
 
+// the same for up to 8 layers in ONE launch: the constants depend on parameters only, so a stack computes all of
+// them before its first GEMM instead of one tiny launch per layer inside the dependent chain
+struct AffineBatch {
+  const float* gamma[8];
+  const float* beta[8];
+  const float* mean[8];
+  const float* var[8];
+  float* bn[8];
+  int c[8];
+  float eps[8];
+  int block_begin[9];  // prefix sum of ceil(c / 256)
+  int n;
+};
+__global__ __launch_bounds__(256) void affine_consts_multi_kernel(AffineBatch ab) {
+  int l = 0;
+  while (l + 1 < ab.n && (int)blockIdx.x >= ab.block_begin[l + 1]) ++l;
+  const int C = ab.c[l];
+  const int c = ((int)blockIdx.x - ab.block_begin[l]) * 256 + threadIdx.x;
+  if (c >= C) return;
+  const float* gamma = ab.gamma[l];
+  const float* mean = ab.mean[l];
+  const float* var = ab.var[l];
+  float* bn = ab.bn[l];
+  const float istd = var != nullptr ? (float)(1.0 / sqrt((double)var[c] + (double)ab.eps[l])) : 1.f;
+  const float m = mean != nullptr ? mean[c] : 0.f;
+  const float sc = (gamma != nullptr ? gamma[c] : 1.f) * istd;
+  bn[0 * C + c] = sc;
+  bn[1 * C + c] = ab.beta[l][c] - m * sc;
+  bn[2 * C + c] = m;
+  bn[3 * C + c] = istd;
+}
+
 __global__ __launch_bounds__(256) void affine_apply_kernel(int C, int P4, int relu, const float* __restrict__ y,
                                                            const float* __restrict__ scale,
                                                            const float* __restrict__ shift,
@@ -1813,6 +1845,25 @@ int istnet_affine_consts(int c, const float* gamma, const float* beta, const flo
   if (c <= 0 || beta == nullptr || bn == nullptr) return ISTNET_PN2_EINVAL;
   hipLaunchKernelGGL(affine_consts_kernel, dim3(ceil_div(c, 256)), dim3(256), 0, as_stream(stream), c, gamma, beta,
                      mean, var, eps, bn);
+  return (int)hipGetLastError();
+}
+
+int istnet_affine_consts_multi(int n, const int* c, const float* const* gamma, const float* const* beta,
+                               const float* const* mean, const float* const* var, const float* eps,
+                               float* const* bn, void* stream) {
+  if (n <= 0 || n > 8 || c == nullptr || gamma == nullptr || beta == nullptr || mean == nullptr || var == nullptr ||
+      eps == nullptr || bn == nullptr)
+    return ISTNET_PN2_EINVAL;
+  AffineBatch ab;
+  ab.n = n;
+  ab.block_begin[0] = 0;
+  for (int l = 0; l < n; ++l) {
+    if (c[l] <= 0 || beta[l] == nullptr || bn[l] == nullptr) return ISTNET_PN2_EINVAL;
+    ab.gamma[l] = gamma[l]; ab.beta[l] = beta[l]; ab.mean[l] = mean[l]; ab.var[l] = var[l]; ab.bn[l] = bn[l];
+    ab.c[l] = c[l]; ab.eps[l] = eps[l];
+    ab.block_begin[l + 1] = ab.block_begin[l] + ceil_div(c[l], 256);
+  }
+  hipLaunchKernelGGL(affine_consts_multi_kernel, dim3(ab.block_begin[n]), dim3(256), 0, as_stream(stream), ab);
   return (int)hipGetLastError();
 }
 

@@ -189,6 +189,22 @@ def _forward_stack(lib, dev, st, b, c0, g, s, x, gather, training, layers, param
     p = g * s
     ys, bns = [], []
     cur, cur_c, in_bn = x, c0, None
+    # layers whose normalisation is a fixed affine map (conv bias; eval-mode BatchNorm): their constant blocks depend
+    # on parameters only -- ONE launch for the whole stack, before its first GEMM, instead of one per layer in the chain
+    fixed, fixed_items = {}, []
+    for li, lay in enumerate(layers):
+        if (li == 0 and start is not None) or not (lay.bias_only or not training):
+            continue
+        cout = params[3 * li].shape[0]
+        fixed[li] = _empty((4, cout), torch.float32, dev)
+        if lay.bias_only:                    # y + bias: scale 1, shift bias, mean 0, invstd 1
+            fixed_items.append((cout, None, params[3 * li + 2].data_ptr(), None, None, 0.0, fixed[li].data_ptr()))
+        else:                                # eval-mode BatchNorm: fixed affine map from the running statistics
+            fixed_items.append((cout, params[3 * li + 1].data_ptr(), params[3 * li + 2].data_ptr(),
+                                lay.running_mean.data_ptr(), lay.running_var.data_ptr(), float(lay.eps),
+                                fixed[li].data_ptr()))
+    if fixed_items:
+        _native.affine_consts_multi(fixed_items, st)
     for li, lay in enumerate(layers):
         w, gamma, beta = params[3 * li], params[3 * li + 1], params[3 * li + 2]
         cout = w.shape[0]
@@ -199,7 +215,7 @@ def _forward_stack(lib, dev, st, b, c0, g, s, x, gather, training, layers, param
             continue
         w2 = w.reshape(cout, cur_c)
         y = _empty((b, cout, p), torch.float32, dev)
-        bn = _empty((4, cout), torch.float32, dev)
+        bn = fixed[li] if li in fixed else _empty((4, cout), torch.float32, dev)
         if lay.bias_only:
             gamma = None                      # params[3*li+1] is a ones vector, beta is the conv bias
         if training and not lay.bias_only:
@@ -241,18 +257,11 @@ def _forward_stack(lib, dev, st, b, c0, g, s, x, gather, training, layers, param
             cin_l, src = cur_c, cur
             _native.check(_native.timed(kname, flops, nbytes, lambda: lib.istnet_pw_forward(
                 b, cin_l, cout, p, src.data_ptr(), w2.data_ptr(), sc, sh, y.data_ptr(), ps, pq, st)), "pw_forward")
-        if lay.bias_only:                    # y + bias: scale 1, shift bias, mean 0, invstd 1
-            _native.check(lib.istnet_affine_consts(cout, None, beta.data_ptr(), None, None, 0.0, bn.data_ptr(), st),
-                          "affine_consts")
-        elif training:
+        if li not in fixed:                  # training-mode BatchNorm: batch statistics of this layer's output
             _native.check(lib.istnet_bn_finalize_fwd(
                 cout, nt, float(b * p), ps, pq, gamma.data_ptr(), beta.data_ptr(), float(lay.eps),
                 float(lay.momentum), _p(lay.running_mean), _p(lay.running_var), bn.data_ptr(), st),
                 "bn_finalize_fwd")
-        else:                                # eval-mode BatchNorm: fixed affine map from the running statistics
-            _native.check(lib.istnet_affine_consts(cout, gamma.data_ptr(), beta.data_ptr(),
-                                                   lay.running_mean.data_ptr(), lay.running_var.data_ptr(),
-                                                   float(lay.eps), bn.data_ptr(), st), "affine_consts")
         ys.append(y)
         bns.append(bn)
         cur, cur_c, in_bn = y, cout, bn
