@@ -196,3 +196,30 @@ def test_fps_gather_matches_fps_plus_gather(ext, oracle, n, m, kind):
     assert torch.equal(idx.cpu(), idx_ref)
     expect = torch.gather(xyz, 1, idx_ref.long().unsqueeze(-1).expand(-1, -1, 3))
     assert torch.equal(picked.cpu(), expect)
+
+
+def test_index_ops_random_shapes_bit_exact(ext, oracle):
+    """Seeded fuzz over small random shapes / distributions: FPS, ball query and three_nn stay bit-exact with the
+    oracle for sizes that are not multiples of any tile, m > n, heavy ties and empty balls."""
+    rng = np.random.default_rng(2024)
+    kinds = ["cube", "shell", "dup", "grid"]
+    for trial in range(40):
+        b = int(rng.integers(1, 4))
+        n = int(rng.integers(1, 700))
+        m = int(rng.integers(1, 2 * n + 2)) if trial % 5 == 0 else int(rng.integers(1, n + 1))
+        kind = kinds[trial % 4]
+        xyz = _cloud(b, n, seed=1000 + trial, kind=kind)
+        tag = f"trial {trial}: b={b} n={n} m={m} {kind}"
+        want = oracle.furthest_point_sampling(xyz, m)
+        got = ext.furthest_point_sampling(xyz.to(DEV), m).cpu()
+        assert torch.equal(got, want), tag
+        centers = torch.gather(xyz, 1, want.long().clamp_(0, n - 1).unsqueeze(-1).expand(b, m, 3)).contiguous()
+        centers = centers + (torch.rand(b, m, 3, generator=torch.Generator().manual_seed(trial)) - 0.5) * (0.1 if trial % 3 == 0 else 0.0)
+        radius = float(rng.choice([0.01, 0.05, 0.2, 0.5, 2.0]))
+        nsample = int(rng.integers(1, 70))
+        assert torch.equal(ext.ball_query(centers.to(DEV), xyz.to(DEV), radius, nsample).cpu(),
+                           oracle.ball_query(centers, xyz, radius, nsample)), tag + f" r={radius} ns={nsample}"
+        d_got, i_got = ext.three_nn(centers.to(DEV), xyz.to(DEV))
+        d_want, i_want = oracle.three_nn(centers, xyz)
+        assert torch.equal(i_got.cpu(), i_want), tag
+        assert torch.equal(d_got.cpu().view(torch.int32), d_want.view(torch.int32)), tag
