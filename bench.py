@@ -127,7 +127,7 @@ def make_eager_step(fwd_bwds, opt, world, reducer=None):
 
 def optimizer_step(opt, world, reducer):
     """FlatAdam: pack the gradients once, sum the flat buffer over ranks (one RCCL all-reduce), update with 1/world."""
-    if world > 1:
+    if reducer is not None:          # data parallel (or its one-rank dry run): all-reduce, then the update
         opt.step(reducer.sum_(opt.pack_grads()), grad_scale=1.0 / world)
     else:
         opt.step()
@@ -154,12 +154,17 @@ def make_graphed_step(fwd_bwds, opt, world, reducer=None):
     torch.cuda.current_stream().wait_stream(side)
     torch.cuda.synchronize()
     graphs, packed = [], []
+    # With a process group alive, ProcessGroupNCCL's watchdog thread polls its events (hipEventQuery) at any time;
+    # under the default "global" capture mode that call is illegal while ANOTHER thread captures and the watchdog
+    # aborts the process (measured on this stack: tools/exp/rccl_capture_modes.py).  "thread_local" restricts the
+    # check to the capturing thread.
+    capture_mode = "global" if reducer is None else "thread_local"
     for fwd_bwd in fwd_bwds:                           # one graph per closure (two when the batches alternate)
         graph = torch.cuda.CUDAGraph()
         opt.zero_grad(set_to_none=True)
-        with torch.cuda.graph(graph):
+        with torch.cuda.graph(graph, capture_error_mode=capture_mode):
             fwd_bwd()
-            if world == 1:
+            if reducer is None:
                 opt.step()
             else:
                 packed.append(opt.pack_grads())  # static buffer: the all-reduce and Adam read it eagerly
@@ -170,7 +175,7 @@ def make_graphed_step(fwd_bwds, opt, world, reducer=None):
         k = count[0] % len(graphs)
         count[0] += 1
         graphs[k].replay()
-        if world > 1:
+        if reducer is not None:
             opt.step(reducer.sum_(packed[k]), grad_scale=1.0 / world)   # one RCCL all-reduce + one Adam launch
     return step
 
@@ -216,6 +221,9 @@ def main():
     ap.add_argument("--workload", default="encoder", choices=["encoder", "istnet"],
                     help="encoder = BASELINE configs[1] (the headline metric); istnet = full model, configs[2]/[3]")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for dry runs)")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="dry run of the N>1 code path (process group, all-reduce, eager Adam after the replay) with "
+                         "one rank: exercises RCCL + HIP-graph capture on a 1-GPU box")
     ap.add_argument("--same-device", action="store_true",
                     help="dry run of the N>1 control flow on a 1-GPU box: every rank uses cuda:0 (gloo only)")
     args = ap.parse_args()
@@ -241,29 +249,52 @@ def main():
     import torch.distributed as dist
     from istnet_amd.optim import FlatAdam
     grad_sync = None
-    if world > 1:
+    dist_on = world > 1 or args.force_dist
+    if dist_on:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        if args.backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)  # RCCL over xGMI
-        else:
-            dist.init_process_group(args.backend)
+        if world == 1:      # --force-dist without a launcher
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29531")
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
+        # RCCL prints a version banner to the C-level stdout when its first communicator comes up; the driver reads
+        # ONE JSON line from rank 0's stdout, so fd 1 points at stderr until the communicator exists
+        import ctypes
+        libc = ctypes.CDLL(None)
+        sys.stdout.flush()
+        saved_fd = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            if args.backend == "nccl":
+                dist.init_process_group("nccl", device_id=dev)  # RCCL over xGMI
+            else:
+                dist.init_process_group(args.backend)
+            warm = torch.ones(1, device=dev)
+            dist.all_reduce(warm)            # forces communicator creation
+            torch.cuda.synchronize()
+            libc.fflush(None)
+        finally:
+            os.dup2(saved_fd, 1)
+            os.close(saved_fd)
 
     if args.workload == "istnet":
         model = make_istnet(dev, seed=0)
         batch = istnet_batch(BATCH, NPOINTS, seed=rank, device=dev)
         opt = FlatAdam(model.parameters(), lr=1e-4)
-        if world > 1:
+        if dist_on:
             from istnet_amd.parallel import GradAllReducer
             grad_sync = GradAllReducer(model, world)
+            grad_sync.always = args.force_dist
         fwd_bwd = make_istnet_fwd_bwd(model, batch)
         args.no_cpu_baseline = True
     else:
         model = make_model(dev, seed=0)  # identical weights on every rank (same seed)
         pts = shell_cloud(BATCH, NPOINTS, seed=rank, device=dev)
         opt = FlatAdam(model.parameters(), lr=1e-4)
-        if world > 1:
+        if dist_on:
             from istnet_amd.parallel import GradAllReducer
             grad_sync = GradAllReducer(model, world)
+            grad_sync.always = args.force_dist
         if args.no_prefetch:
             fwd_bwd = make_encoder_fwd_bwd(model, pts)
         else:
@@ -291,17 +322,17 @@ def main():
 
     for _ in range(args.warmup):
         step()
-    if world > 1:
+    if dist_on:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     torch.cuda.synchronize()
-    if world > 1:
+    if dist_on:
         dist.barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if dist_on:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -321,12 +352,13 @@ def main():
                                    ("IST-Net full model (ResNet-18/PSP RGB branch on MIOpen + point branch, "
                                     "cam + world encoders, IST head, 3 pose heads) fwd+bwd+Adam, SupervisedLoss"),
                        "batch_per_gpu": BATCH, "npoints": NPOINTS, "global_batch": BATCH * world,
-                       "parallelism": f"dp{world}", "launch": mode,
+                       "parallelism": f"dp{world}" + (" (one-rank dry run of the RCCL path)" if args.force_dist and world == 1 else ""),
+                       "launch": mode,
                        "batches": ("1 (same batch every step)" if (args.workload != "encoder" or args.no_prefetch)
                                    else "2 alternating, next batch's FPS/ball-query/three_nn prefetched on the "
                                         "geometry stream during the current step")},
         }
-        if world == 1 and args.workload == "encoder" and not args.no_prefetch and mode == "hipgraph" \
+        if not dist_on and args.workload == "encoder" and not args.no_prefetch and mode == "hipgraph" \
                 and not args.no_unpipelined:
             # the same step WITHOUT the next-batch geometry prefetch (one batch, geometry inside the step), for
             # reference: what the pipelining is worth, and the number to compare with an unpipelined loop
@@ -341,16 +373,19 @@ def main():
             dt = (time.perf_counter() - t1) / args.steps
             result["unpipelined"] = {"value": BATCH / dt, "unit": "clouds/s", "ms_per_step": dt * 1e3,
                                      "note": "one batch, FPS / ball query / three_nn inside the step (--no-prefetch)"}
-        if world == 1 and not args.no_roofline:
+        if not dist_on and not args.no_roofline:
             from istnet_amd import roofline
             result["roofline"] = roofline.measure(
                 eager_step, traffic_file=os.path.join(ROOT, "profiles", "r01_pmc_traffic.json"))
-        if world == 1 and not args.no_cpu_baseline:
+        if not dist_on and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline()
-        print(json.dumps(result), flush=True)
-    if world > 1:
+    if dist_on:
         dist.barrier()
         dist.destroy_process_group()
+    if rank == 0:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)       # anything native code left in the C stdout buffer goes out first
+        print(json.dumps(result), flush=True)
 
 
 if __name__ == "__main__":

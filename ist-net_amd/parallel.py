@@ -18,6 +18,7 @@ class GradAllReducer:
     def __init__(self, model, world_size=None, bucket_bytes=64 << 20, group=None):
         self.group = group
         self.world = world_size if world_size is not None else dist.get_world_size(group)
+        self.always = False    # True: issue the collectives even with one rank (single-GPU dry run of the RCCL path)
         params = [p for p in model.parameters() if p.requires_grad]
         params.reverse()  # backward finishes the last layers first
         self.buckets, cur, cur_bytes = [], [], 0
@@ -63,7 +64,7 @@ class GradAllReducer:
     def average_(self, flat):
         """In-place average across ranks of gradients that are already packed in ONE flat tensor
         (``optim.FlatAdam.pack_grads``): a single large all-reduce, no pack / unpack here."""
-        if self.world == 1:
+        if self.world == 1 and not self.always:
             return flat
         dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
         return flat.mul_(1.0 / self.world)
@@ -71,7 +72,7 @@ class GradAllReducer:
     def sum_(self, flat):
         """In-place SUM across ranks of an already packed gradient tensor; the caller folds 1/world into the
         optimizer (``FlatAdam.step(flat, grad_scale=1/world)``), saving the scaling pass over the buffer."""
-        if self.world > 1:
+        if self.world > 1 or self.always:
             dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
         return flat
 
