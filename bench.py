@@ -15,6 +15,8 @@ batch's geometry is computed before the timed region (pipeline prologue).  With 
 batch is used every step and its geometry is computed inside the step.
 
     python bench.py [--gpus N] [--steps K] [--warmup W]
+    python bench.py --workload istnet      # full IST-Net training step (configs[2]/[3]): RGB branch + point branch
+    python bench.py --workload infer       # eval-mode full model + post-processing, B=64 N=2048 (config 5)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 Prints ONE JSON line on rank 0.
@@ -180,6 +182,53 @@ def make_graphed_step(fwd_bwds, opt, world, reducer=None):
     return step
 
 
+def run_inference(args, dev, world, rank, dist):
+    """``--workload infer`` (BASELINE configs[4] / SURVEY 8d config 5): eval-mode IST-Net, B=64 instances of
+    N=2048 points + 192x192 crops per step; one step = the forward pass, the post-processing of test_func
+    (solver.py:231-241) and the device->host copy of the result.  Replicas only: no collective in the step."""
+    from istnet_amd import postprocess
+    b, n = 64, 2048
+    net = make_istnet(dev, seed=0)
+    g = torch.Generator().manual_seed(5)
+    for m in net.modules():          # non-trivial running statistics, as after training
+        if isinstance(m, torch.nn.modules.batchnorm._BatchNorm):
+            m.running_mean.copy_(torch.randn(m.num_features, generator=g) * 0.1)
+            m.running_var.copy_(torch.rand(m.num_features, generator=g) + 0.5)
+    net.eval()
+    batch = istnet_batch(b, n, seed=rank, device=dev)
+
+    def step():
+        with torch.no_grad():
+            ep = net(batch)
+            rts, scales = postprocess.assemble_pred_RTs(ep["pred_rotation"], ep["pred_translation"], ep["pred_size"])
+            return rts.cpu(), scales.cpu()
+
+    for _ in range(args.warmup):
+        step()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    return {"metric": "instances/sec inference, B=64 N=2048", "value": b * world * args.steps / elapsed,
+            "unit": "instances/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "IST-Net inference (eval mode; RGB branch on MIOpen with the last layer on the chosen "
+                                   "pixels only, point branch on the HIP kernels, pose post-processing, result copied "
+                                   "to the host)", "batch_per_gpu": b, "npoints": n, "global_batch": b * world,
+                       "parallelism": f"replicas x{world}", "launch": "eager"}}
+
+
 def cpu_baseline(budget_s=25.0):
     """The same step on the host cores with the CPU oracle ops (kind 'port'): bounded sample."""
     from istnet_amd.pointnet2 import pointnet2_utils
@@ -218,8 +267,9 @@ def main():
     ap.add_argument("--no-unpipelined", action="store_true", help="skip the extra unpipelined measurement")
     ap.add_argument("--no-prefetch", action="store_true",
                     help="encoder workload: one batch, geometry inside the step (no next-batch geometry prefetch)")
-    ap.add_argument("--workload", default="encoder", choices=["encoder", "istnet"],
-                    help="encoder = BASELINE configs[1] (the headline metric); istnet = full model, configs[2]/[3]")
+    ap.add_argument("--workload", default="encoder", choices=["encoder", "istnet", "infer"],
+                    help="encoder = BASELINE configs[1] (the headline metric); istnet = full model, configs[2]/[3]; "
+                         "infer = eval-mode full model + post-processing, B=64 N=2048 (config 5)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for dry runs)")
     ap.add_argument("--force-dist", action="store_true",
                     help="dry run of the N>1 code path (process group, all-reduce, eager Adam after the replay) with "
@@ -277,6 +327,14 @@ def main():
             os.dup2(saved_fd, 1)
             os.close(saved_fd)
 
+    if args.workload == "infer":
+        result = run_inference(args, dev, world, rank, dist if dist_on else None)
+        if dist_on:
+            dist.barrier()
+            dist.destroy_process_group()
+        if rank == 0:
+            print(json.dumps(result), flush=True)
+        return
     if args.workload == "istnet":
         model = make_istnet(dev, seed=0)
         batch = istnet_batch(BATCH, NPOINTS, seed=rank, device=dev)
