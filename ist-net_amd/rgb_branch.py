@@ -135,30 +135,44 @@ class Modified_PSPNet(nn.Module):
 
     def forward(self, x, choose=None):
         """rgb (B,3,H,W) -> (B,128,H,W); with ``choose`` (B,N) flat pixel indices in eval mode -> (B,128,N), the
-        features of the chosen pixels only (see ``_final_at``)."""
+        features of the chosen pixels only (see ``_tail_at``)."""
         f, _ = self.feats(x)
         p = self.drop_1(self.psp(f))
         p = self.drop_2(self.up_1(p))
         p = self.drop_2(self.up_2(p))
-        p = self.up_3(p)
         if choose is not None and not self.training:
-            return self._final_at(p, choose)
-        return self.final(p)
+            return self._tail_at(p, choose)
+        return self.final(self.up_3(p))
 
-    def _final_at(self, p, choose):
-        """`final` (1x1 conv + BatchNorm + PReLU, all per-pixel in eval mode) on the chosen pixels only: IST-Net reads
-        N of the H*W output pixels (ist_net.py:41-45), so gathering the 64-channel decoder output first skips
-        (H*W - N)/H*W of the last layer's work and never materialises the (B,128,H,W) map (1.2 GB at B=64).  Same
-        arithmetic per pixel as the dense path; not valid in training mode, where BatchNorm takes batch statistics
-        over all pixels."""
-        b, c = p.size(0), p.size(1)
-        if not p.is_contiguous() and p.is_contiguous(memory_format=torch.channels_last):
-            rows = p.permute(0, 2, 3, 1).reshape(b, -1, c)
-            picked = torch.gather(rows, 1, choose.unsqueeze(-1).expand(-1, -1, c)).transpose(1, 2)
+    def _tail_at(self, p, choose):
+        """Eval mode: the last decoder stage (`up_3`: 2x bilinear upsample, 3x3 conv, BatchNorm, PReLU) and `final`
+        (1x1 conv, BatchNorm, PReLU) evaluated at the chosen pixels only.  IST-Net reads N of the H*W output pixels
+        (ist_net.py:41-45) and every op after the upsample is local to a 3x3 window of it, so the 3x3 conv becomes a
+        (B*N, 9*64) x (9*64, 64) product over gathered windows instead of a convolution over the full 192x192 map, and
+        the (B,64,H,W) conv output and the (B,128,H,W) feature map (1.2 GB at B=64) are never materialised.  Same
+        arithmetic per pixel as the dense path up to summation order; not valid in training mode, where BatchNorm
+        takes batch statistics over all pixels."""
+        upsample, conv, bn, act = self.up_3.conv[0], self.up_3.conv[1], self.up_3.conv[2], self.up_3.conv[3]
+        up = upsample(p)                                             # (B, C, H, W)
+        b, c, h, w = up.shape
+        if not up.is_contiguous() and up.is_contiguous(memory_format=torch.channels_last):
+            rows = up.permute(0, 2, 3, 1).reshape(b, h * w, c)       # view
         else:
-            picked = torch.gather(p.reshape(b, c, -1), 2, choose.unsqueeze(1).expand(-1, c, -1))
+            rows = up.reshape(b, c, h * w).transpose(1, 2)           # strided view; gather handles it
+        r, q = choose // w, choose % w                               # (B, N)
+        d = torch.tensor([-1, 0, 1], device=choose.device)
+        rr = (r.unsqueeze(-1) + d.repeat_interleave(3)).clamp_(0, h - 1)     # (B, N, 9): window rows, kernel-row major
+        qq = (q.unsqueeze(-1) + d.repeat(3)).clamp_(0, w - 1)
+        inside = ((r.unsqueeze(-1) + d.repeat_interleave(3) == rr) & (q.unsqueeze(-1) + d.repeat(3) == qq))
+        flat = (rr * w + qq).reshape(b, -1)                          # (B, N*9)
+        win = torch.gather(rows, 1, flat.unsqueeze(-1).expand(-1, -1, c))    # (B, N*9, C)
+        win = (win * inside.reshape(b, -1, 1)).reshape(b, choose.size(1), 9 * c)   # zero padding of the conv
+        w2 = conv.weight.permute(0, 2, 3, 1).reshape(conv.out_channels, 9 * c)      # (Cout, kr, kc, Cin)
+        y = torch.matmul(win, w2.t()) + conv.bias                    # (B, N, Cout)
+        y = F.batch_norm(y.transpose(1, 2), bn.running_mean, bn.running_var, bn.weight, bn.bias, False, 0.0, bn.eps)
+        y = F.prelu(y, act.weight)                                   # (B, Cout, N)
         conv, bn, act = self.final[0], self.final[1], self.final[2]
-        y = F.conv1d(picked, conv.weight.view(conv.out_channels, c, 1), conv.bias)
+        y = F.conv1d(y, conv.weight.view(conv.out_channels, -1, 1), conv.bias)
         y = F.batch_norm(y, bn.running_mean, bn.running_var, bn.weight, bn.bias, False, 0.0, bn.eps)
         return F.prelu(y, act.weight).contiguous()
 

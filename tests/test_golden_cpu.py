@@ -184,12 +184,13 @@ def test_rgb_gather_first_equals_dense_tail_in_eval():
     from istnet_amd.ist_net import IST_Net
     torch.manual_seed(3)
     ext = rgb_branch.ModifiedResnet()
-    bn = ext.model.final[1]
-    bn.running_mean.normal_(0, 0.3); bn.running_var.uniform_(0.5, 2.0); bn.weight.data.normal_(1, 0.2); bn.bias.data.normal_(0, 0.2)
+    for bn in (ext.model.final[1], ext.model.up_3.conv[2]):
+        bn.running_mean.normal_(0, 0.3); bn.running_var.uniform_(0.5, 2.0); bn.weight.data.normal_(1, 0.2); bn.bias.data.normal_(0, 0.2)
     ext.eval()
     net = IST_Net(rgb_extractor=ext).eval()
     rgb = torch.randn(2, 3, 48, 48)
     choose = torch.randint(0, 48 * 48, (2, 37))
+    choose[0, :6] = torch.tensor([0, 47, 47 * 48, 48 * 48 - 1, 5, 48 * 20])    # corners and edges: the conv's zero padding
     with torch.no_grad():
         dense = ext(rgb)
         want = torch.gather(dense.reshape(2, 128, -1), 2, choose.unsqueeze(1).expand(-1, 128, -1))
