@@ -375,3 +375,35 @@ def test_encoder_odd_shapes_match_cpu_oracle_composition(oracle, b, n, extra):
     gn = torch.stack([p.grad.norm() for p in enc_gpu.parameters()]).cpu()
     cn = torch.stack([q.grad.norm() for q in enc.parameters()])
     assert float(((gn - cn).abs() / (cn + 1e-12)).median()) < 2e-2
+
+
+def test_eval_rgb_tail_on_chosen_pixels_matches_dense_order():
+    """Eval mode on the GPU (channels-last extractor, as bench.py builds it): IST-Net poses with the RGB decoder tail
+    evaluated at the chosen pixels only == the reference order (dense feature map, then the `choose` gather)."""
+    from istnet_amd import ist_net, rgb_branch
+    torch.manual_seed(21)
+    ext = rgb_branch.ModifiedResnet()
+    g = torch.Generator().manual_seed(22)
+    for m in ext.modules():
+        if isinstance(m, torch.nn.modules.batchnorm._BatchNorm):
+            m.running_mean.copy_(torch.randn(m.num_features, generator=g) * 0.1)
+            m.running_var.copy_(torch.rand(m.num_features, generator=g) + 0.5)
+    net = ist_net.IST_Net(rgb_extractor=ext).to(DEV).eval()
+    net.rgb_cam_extractor.to(memory_format=torch.channels_last)
+    b, n, hw = 2, 256, 96
+    inputs = {"rgb": torch.randn(b, 3, hw, hw, generator=g).to(DEV).contiguous(memory_format=torch.channels_last),
+              "pts": (_shell(b, n, 23) + torch.tensor([0.0, 0.0, 0.8])).to(DEV),
+              "choose": torch.randint(0, hw * hw, (b, n), generator=g).to(DEV),
+              "category_label": torch.randint(0, 6, (b, 1), generator=g).to(DEV)}
+    inputs["choose"][0, :4] = torch.tensor([0, hw - 1, hw * (hw - 1), hw * hw - 1], device=DEV)   # image corners
+    saved = ist_net.USE_GATHER_FIRST
+    try:
+        with torch.no_grad():
+            ist_net.USE_GATHER_FIRST = True
+            fast = net(inputs)
+            ist_net.USE_GATHER_FIRST = False
+            dense = net(inputs)
+    finally:
+        ist_net.USE_GATHER_FIRST = saved
+    for k in ("pred_rotation", "pred_translation", "pred_size", "pred_qo"):
+        torch.testing.assert_close(fast[k], dense[k], rtol=1e-4, atol=1e-5)
