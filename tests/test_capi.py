@@ -77,3 +77,20 @@ def test_product_does_not_import_oracle():
         for f in files:
             if f.endswith((".py", ".hip", ".h", ".cpp")):
                 assert not bad.search(open(os.path.join(dp, f)).read()), f
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    """No HIP library -> RuntimeError naming the file from the one loader every product entry point goes through
+    (istnet_amd._native.lib); there is no torch or CPU fallback to land on."""
+    from istnet_amd import _native
+    monkeypatch.setattr(_native, "_lib", None)
+    monkeypatch.setattr(_native, "LIB_PATH", str(tmp_path / "libistnet_pn2.so"))
+    with pytest.raises(RuntimeError, match="libistnet_pn2.so is missing"):
+        _native.lib()
+    # every module of the product that launches kernels does so through that loader
+    import os
+    import istnet_amd
+    root = os.path.dirname(istnet_amd.__file__)
+    for rel in ("pointnet2/_ext.py", "pointnet2/fused_mlp.py", "optim.py", "preprocess.py"):
+        text = open(os.path.join(root, rel)).read()
+        assert "_native.lib()" in text and "ctypes.CDLL" not in text, rel
