@@ -202,3 +202,36 @@ def test_rgb_gather_first_equals_dense_tail_in_eval():
     torch.testing.assert_close(got_cl, want, rtol=1e-5, atol=1e-5)
     net.train()
     assert ext_cl(rgb, choose).shape == (2, 128, 48, 48)       # training mode ignores `choose`
+
+
+def _freeze_case():
+    from istnet_amd.ist_net import IST_Net
+    z = np.load(os.path.join(GOLD, "istnet_freeze_b2.npz"))
+    torch.manual_seed(7)
+    net = IST_Net(freeze_world_enhancer=True)
+    net.rgb_cam_extractor = torch.nn.Identity()
+    b = 2
+    inputs = {"rgb": torch.from_numpy(z["rgb_feat"]), "pts": torch.from_numpy(z["pts"]),
+              "choose": torch.from_numpy(z["choose"].astype(np.int64)),
+              "category_label": torch.from_numpy(z["cls"]).reshape(b, 1), "qo": torch.from_numpy(z["qo"])}
+    labels = {k[4:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("lab_")}
+    return z, net, inputs, labels
+
+
+def test_istnet_frozen_world_enhancer_matches_reference(cpu_ops):
+    """IST_Net(freeze_world_enhancer=True) -- the second training stage of train.py:102-118: same state-dict keys
+    (no world pose head), same train-mode end points (no *_aux_world), same SupervisedLoss value as the reference."""
+    from istnet_amd import losses
+    z, net, inputs, labels = _freeze_case()
+    assert list(net.state_dict().keys()) == [str(k) for k in z["state_keys"]]
+    assert not any(k.startswith("world_enhancer.pose_estimator") for k in net.state_dict())
+    np.testing.assert_allclose(_checksum(net.state_dict()), z["state_checksum"], rtol=0, atol=0)
+    net.train()
+    ep = net(inputs)
+    keys = [k[len("train_"):] for k in z.files if k.startswith("train_")]
+    assert set(keys) == set(ep.keys()) and not any("aux_world" in k for k in ep)
+    sub = lambda v: v.detach().numpy() if v.numel() <= 8192 else v.detach().numpy().reshape(2, -1)[:, ::64]
+    for k in keys:
+        np.testing.assert_allclose(sub(ep[k]), z["train_" + k], rtol=1e-3, atol=1e-5, err_msg=k)
+    loss = losses.SupervisedLoss(1.0, 10.0, freeze_world_enhancer=True)({**ep, **labels, "qo": inputs["qo"]})
+    np.testing.assert_allclose(float(loss.detach()), float(z["loss"]), rtol=1e-5)
