@@ -52,12 +52,16 @@ def make_model(device, seed=0):
     return PointNet2MSG([list(r) for r in CAM_RADII]).to(device).train()
 
 
-def make_istnet(device, seed=0):
-    """Full IST-Net (BASELINE configs[2] / [3]): RGB branch on MIOpen + point branch on the HIP kernels."""
+def make_istnet(device, seed=0, freeze_world_enhancer=False):
+    """Full IST-Net (BASELINE configs[2] / [3]): RGB branch on MIOpen + point branch on the HIP kernels.
+    freeze_world_enhancer: the second training stage (train.py:102-118) -- world encoder frozen, no world pose head."""
     from istnet_amd.ist_net import IST_Net
     from istnet_amd.rgb_branch import ModifiedResnet
     torch.manual_seed(seed)
-    net = IST_Net(rgb_extractor=ModifiedResnet()).to(device).train()
+    net = IST_Net(rgb_extractor=ModifiedResnet(), freeze_world_enhancer=freeze_world_enhancer).to(device).train()
+    if freeze_world_enhancer:
+        for p in net.world_enhancer.parameters():
+            p.requires_grad_(False)
     # MIOpen runs the 2-D convolutions 1.5x faster in NHWC (fp32 either way; tools/bench_rgb.py: 83.9 -> 56.2 ms)
     net.rgb_cam_extractor.to(memory_format=torch.channels_last)
     return net
@@ -79,7 +83,7 @@ def istnet_batch(b, n, seed, device, hw=192):
 
 def make_istnet_fwd_bwd(model, batch):
     from istnet_amd.losses import SupervisedLoss
-    crit = SupervisedLoss(1.0, 10.0)
+    crit = SupervisedLoss(1.0, 10.0, freeze_world_enhancer=model.freeze_world_enhancer)
     labels = {k: batch[k] for k in ("rotation_label", "translation_label", "size_label", "qo")}
 
     def fwd_bwd():
@@ -271,6 +275,8 @@ def main():
                     help="encoder = BASELINE configs[1] (the headline metric); istnet = full model, configs[2]/[3]; "
                          "infer = eval-mode full model + post-processing, B=64 N=2048 (config 5)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for dry runs)")
+    ap.add_argument("--freeze-world-enhancer", action="store_true",
+                    help="istnet workload: second training stage (world encoder frozen, 23.6 M of 26.8 M parameters trained)")
     ap.add_argument("--force-dist", action="store_true",
                     help="dry run of the N>1 code path (process group, all-reduce, eager Adam after the replay) with "
                          "one rank: exercises RCCL + HIP-graph capture on a 1-GPU box")
@@ -336,7 +342,7 @@ def main():
             print(json.dumps(result), flush=True)
         return
     if args.workload == "istnet":
-        model = make_istnet(dev, seed=0)
+        model = make_istnet(dev, seed=0, freeze_world_enhancer=args.freeze_world_enhancer)
         batch = istnet_batch(BATCH, NPOINTS, seed=rank, device=dev)
         opt = FlatAdam(model.parameters(), lr=1e-4)
         if dist_on:
@@ -408,7 +414,8 @@ def main():
             "config": {"workload": ("PointNet2MSG encoder (4 SA-MSG + 4 FP, cam radii) fwd+bwd+Adam, "
                                     "train-mode BN, shell clouds") if args.workload == "encoder" else
                                    ("IST-Net full model (ResNet-18/PSP RGB branch on MIOpen + point branch, "
-                                    "cam + world encoders, IST head, 3 pose heads) fwd+bwd+Adam, SupervisedLoss"),
+                                    "cam + world encoders, IST head, 3 pose heads) fwd+bwd+Adam, SupervisedLoss"
+                                    + (", world enhancer frozen" if args.freeze_world_enhancer else "")),
                        "batch_per_gpu": BATCH, "npoints": NPOINTS, "global_batch": BATCH * world,
                        "parallelism": f"dp{world}" + (" (one-rank dry run of the RCCL path)" if args.force_dist and world == 1 else ""),
                        "launch": mode,
