@@ -18,6 +18,24 @@ from torch.autograd import Function
 from . import _ext
 
 
+class RandomDropout(nn.Module):
+    """Feature dropout with a per-call rate drawn from U(0, p) and NO rescaling of the kept values.  [ref :40-48]
+    (The reference's forward calls ``pt_utils.feature_dropout_no_scaling``, which its pytorch_utils.py does not
+    define -- the class is dead code there; this is the behaviour of the PointNet++ code it was taken from.)"""
+
+    def __init__(self, p=0.5, inplace=False):
+        super().__init__()
+        self.p = p
+        self.inplace = inplace
+
+    def forward(self, X):
+        if not self.training:
+            return X
+        theta = float(torch.empty(1).uniform_(0, self.p))
+        keep = (torch.rand_like(X) >= theta).to(X.dtype)
+        return X.mul_(keep) if self.inplace else X * keep
+
+
 class FurthestPointSampling(Function):
     """xyz (B,N,3) f32, npoint -> (B,npoint) i32 indices (first is 0).  [ref :51-80]"""
 

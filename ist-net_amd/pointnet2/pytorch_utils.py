@@ -116,6 +116,15 @@ class SharedMLP(nn.Sequential):
                        activation=None if plain_head else activation, preact=preact))
 
 
+def group_model_params(model, **kwargs):
+    """Two optimizer parameter groups: weights (with ``kwargs``) and normalisation / bias terms (weight decay 0).
+    [ref :282-299; unused by the reference's own solver, kept for callers that build their optimizer with it]"""
+    decayed, plain = [], []
+    for name, param in model.named_parameters():
+        (plain if ("normlayer" in name or "bias" in name) else decayed).append(param)
+    return [dict(params=decayed, **kwargs), dict(params=plain, **{**kwargs, "weight_decay": 0.0})]
+
+
 def set_bn_momentum_default(bn_momentum):
     def fn(m):
         if isinstance(m, (nn.BatchNorm1d, nn.BatchNorm2d, nn.BatchNorm3d)):

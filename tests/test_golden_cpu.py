@@ -235,3 +235,19 @@ def test_istnet_frozen_world_enhancer_matches_reference(cpu_ops):
         np.testing.assert_allclose(sub(ep[k]), z["train_" + k], rtol=1e-3, atol=1e-5, err_msg=k)
     loss = losses.SupervisedLoss(1.0, 10.0, freeze_world_enhancer=True)({**ep, **labels, "qo": inputs["qo"]})
     np.testing.assert_allclose(float(loss.detach()), float(z["loss"]), rtol=1e-5)
+
+
+def test_small_host_helpers():
+    """group_model_params / RandomDropout of the reference's utility modules."""
+    from istnet_amd.pointnet2 import pointnet2_utils, pytorch_utils
+    mlp = pytorch_utils.SharedMLP([3, 8, 8], bn=True)
+    groups = pytorch_utils.group_model_params(mlp, lr=0.1, weight_decay=0.01)
+    assert [len(g["params"]) for g in groups] == [2, 4] and groups[0]["weight_decay"] == 0.01
+    assert groups[1]["weight_decay"] == 0.0 and groups[1]["lr"] == 0.1
+    torch.optim.SGD(groups)          # accepted as is
+    drop = pointnet2_utils.RandomDropout(p=0.9)
+    x = torch.ones(4, 16, 32)
+    torch.manual_seed(0)
+    y = drop(x)
+    assert set(y.unique().tolist()) <= {0.0, 1.0} and 0 < float(y.mean()) <= 1.0     # kept values are not rescaled
+    assert torch.equal(drop.eval()(x), x)
