@@ -14,6 +14,13 @@ def SmoothL1Dis(p1, p2, threshold=0.1):
     return torch.mean(torch.sum(dis, dim=2 if p1.dim() == 3 else 1))
 
 
+def ChamferDis(p1, p2):
+    """Symmetric Chamfer distance of (B,n1,3) and (B,n2,3): mean nearest-neighbour L2 both ways, halved, batch mean.
+    [ref losses.py:25-34; imported but not used by the reference's IST-Net loss]"""
+    pair = torch.cdist(p1, p2)                       # (B, n1, n2)
+    return (0.5 * pair.min(dim=2).values.mean(dim=1) + 0.5 * pair.min(dim=1).values.mean(dim=1)).mean()
+
+
 def PoseDis(r1, t1, s1, r2, t2, s2):
     """Mean column norm of R1-R2 (dim=1 as in the reference) + mean L2 of t and s differences."""
     return (torch.mean(torch.norm(r1 - r2, dim=1)) + torch.mean(torch.norm(t1 - t2, dim=1))

@@ -238,7 +238,13 @@ def test_istnet_frozen_world_enhancer_matches_reference(cpu_ops):
 
 
 def test_small_host_helpers():
-    """group_model_params / RandomDropout of the reference's utility modules."""
+    """group_model_params / RandomDropout / ChamferDis of the reference's utility modules."""
+    from istnet_amd import losses
+    g = torch.Generator().manual_seed(3)
+    a, b = torch.randn(2, 7, 3, generator=g), torch.randn(2, 5, 3, generator=g)
+    d = (a.unsqueeze(2) - b.unsqueeze(1)).norm(dim=3)
+    want = (0.5 * d.min(2)[0].mean(1) + 0.5 * d.min(1)[0].mean(1)).mean()
+    torch.testing.assert_close(losses.ChamferDis(a, b), want, rtol=1e-5, atol=1e-6)
     from istnet_amd.pointnet2 import pointnet2_utils, pytorch_utils
     mlp = pytorch_utils.SharedMLP([3, 8, 8], bn=True)
     groups = pytorch_utils.group_model_params(mlp, lr=0.1, weight_decay=0.01)
