@@ -24,10 +24,12 @@ __device__ __forceinline__ void adam_one(float& p, float g, float& m, float& v, 
 
 __global__ void adam_step_kernel(long long n, float* __restrict__ param, const float* __restrict__ grad,
                                  float* __restrict__ exp_avg, float* __restrict__ exp_avg_sq,
-                                 const float* __restrict__ step, AdamConsts c) {
+                                 const float* __restrict__ step, const float* __restrict__ lr_dev,
+                                 AdamConsts c) {
   // bias corrections in double, once per thread (the step count is the same for every element)
   const double t = (double)*step;
-  const float step_size = (float)(c.lr / (1.0 - pow(c.beta1, t)));
+  const double lr = lr_dev != nullptr ? (double)*lr_dev : c.lr;
+  const float step_size = (float)(lr / (1.0 - pow(c.beta1, t)));
   const float inv_bc2_sqrt = (float)(1.0 / sqrt(1.0 - pow(c.beta2, t)));
   const long long i = ((long long)blockIdx.x * kThreads + threadIdx.x) * 4;
   if (i + 3 < n) {
@@ -56,8 +58,8 @@ __global__ void adam_step_kernel(long long n, float* __restrict__ param, const f
 }  // namespace
 
 extern "C" int istnet_adam_step(long long n, float* param, const float* grad, float* exp_avg, float* exp_avg_sq,
-                                const float* step, double lr, double beta1, double beta2, double eps,
-                                double weight_decay, double grad_scale, void* stream) {
+                                const float* step, const float* lr_dev, double lr, double beta1, double beta2,
+                                double eps, double weight_decay, double grad_scale, void* stream) {
   if (n < 0 || (n > 0 && (!param || !grad || !exp_avg || !exp_avg_sq || !step))) return ISTNET_PN2_EINVAL;
   // float4 path needs 16-byte aligned bases; torch allocations are, sub-views at odd offsets are not
   if (((uintptr_t)param | (uintptr_t)grad | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq) & 15) return ISTNET_PN2_EINVAL;
@@ -66,6 +68,6 @@ extern "C" int istnet_adam_step(long long n, float* param, const float* grad, fl
                (float)weight_decay, (float)grad_scale, lr, beta1, beta2};
   const long long quads = (n + 3) / 4;
   const unsigned blocks = (unsigned)((quads + kThreads - 1) / kThreads);
-  adam_step_kernel<<<blocks, kThreads, 0, (hipStream_t)stream>>>(n, param, grad, exp_avg, exp_avg_sq, step, c);
+  adam_step_kernel<<<blocks, kThreads, 0, (hipStream_t)stream>>>(n, param, grad, exp_avg, exp_avg_sq, step, lr_dev, c);
   return (int)hipGetLastError();
 }

@@ -37,7 +37,20 @@ class FlatAdam:
         self.exp_avg = torch.zeros_like(self.flat)
         self.exp_avg_sq = torch.zeros_like(self.flat)
         self.step_count = torch.zeros((), dtype=torch.float32, device=dev)
-        self.lr, self.betas, self.eps, self.weight_decay = float(lr), tuple(betas), float(eps), float(weight_decay)
+        # the learning rate lives on the device: a per-iteration schedule writes this scalar (``opt.lr = value``) and
+        # a step captured in a HIP graph picks the new value up without re-capture
+        self._lr_dev = torch.full((), float(lr), dtype=torch.float32, device=dev)
+        self._lr = float(lr)
+        self.betas, self.eps, self.weight_decay = tuple(betas), float(eps), float(weight_decay)
+
+    @property
+    def lr(self):
+        return self._lr
+
+    @lr.setter
+    def lr(self, value):
+        self._lr = float(value)
+        self._lr_dev.fill_(self._lr)
 
     def zero_grad(self, set_to_none=True):
         for p in self.params:
@@ -75,7 +88,8 @@ class FlatAdam:
             with torch.cuda.device(self.flat.device):
                 _native.check(_native.lib().istnet_adam_step(
                     self.flat.numel(), self.flat.data_ptr(), g.data_ptr(), self.exp_avg.data_ptr(),
-                    self.exp_avg_sq.data_ptr(), self.step_count.data_ptr(), self.lr, self.betas[0], self.betas[1],
+                    self.exp_avg_sq.data_ptr(), self.step_count.data_ptr(), self._lr_dev.data_ptr(), self._lr,
+                    self.betas[0], self.betas[1],
                     self.eps, self.weight_decay, float(grad_scale),
                     torch.cuda.current_stream(self.flat.device).cuda_stream), "adam_step")
             return
@@ -98,4 +112,5 @@ class FlatAdam:
     def load_state_dict(self, sd):
         self.flat.copy_(sd["flat"]); self.exp_avg.copy_(sd["exp_avg"]); self.exp_avg_sq.copy_(sd["exp_avg_sq"])
         self.step_count.copy_(sd["step"])
-        self.lr, self.betas, self.eps, self.weight_decay = sd["lr"], tuple(sd["betas"]), sd["eps"], sd["weight_decay"]
+        self.lr = sd["lr"]
+        self.betas, self.eps, self.weight_decay = tuple(sd["betas"]), sd["eps"], sd["weight_decay"]

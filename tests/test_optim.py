@@ -111,3 +111,38 @@ def test_flat_adam_kernel_odd_sizes_and_grad_scale():
             p = p - 3e-3 / (1 - 0.8 ** t) * m / (v.sqrt() / (1 - 0.95 ** t) ** 0.5 + 1e-6)
         torch.testing.assert_close(opt.flat.cpu().double(), p, rtol=2e-5, atol=1e-7)
         assert model[0].data_ptr() == opt.flat.data_ptr()
+
+
+@pytest.mark.gpu
+def test_lr_schedule_reaches_a_captured_step_without_recapture():
+    """FlatAdam keeps the learning rate on the device: ``opt.lr = v`` between replays of ONE captured step changes
+    the update exactly as it does for torch.optim.Adam with a per-iteration schedule (solver.py:88-89)."""
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    ref_p = torch.nn.Parameter(torch.randn(1000, device=dev))
+    my_p = torch.nn.Parameter(ref_p.detach().clone())
+    ref = torch.optim.Adam([ref_p], lr=1e-2)
+    opt = FlatAdam([my_p], lr=1e-2)
+    grad = torch.randn(1000, device=dev)
+    static_grad = torch.zeros_like(grad)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        opt.step(static_grad)                      # warm-up launch outside the capture (a zero-gradient step)
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    ref_p.grad = torch.zeros_like(grad)
+    ref.step()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        opt.step(static_grad)
+    for it, lr in enumerate([1e-2, 3e-3, 5e-2, 1e-4]):
+        g = grad * (it + 1)
+        static_grad.copy_(g)
+        opt.lr = lr
+        graph.replay()
+        ref.param_groups[0]["lr"] = lr
+        ref_p.grad = g.clone()
+        ref.step()
+    torch.testing.assert_close(opt.flat, ref_p.detach(), rtol=1e-5, atol=1e-7)
+    assert opt.lr == 1e-4 and int(opt.step_count) == 5     # warm-up + four replays (the capture pass does not execute)
