@@ -13,8 +13,15 @@ State lives on the device, so a step can be captured in a HIP graph.
 import torch
 
 
-class FlatAdam:
+class FlatAdam(torch.optim.Optimizer):
+    """A ``torch.optim.Optimizer`` (so ``torch.optim.lr_scheduler`` classes accept it -- the reference drives Adam
+    with ``CyclicLR``, utils/solver.py:41-47) with ONE parameter group: ``param_groups[0]['lr']`` is what schedulers
+    write and what ``step()`` reads."""
+
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
+        params = list(params)
+        if params and isinstance(params[0], dict):
+            raise ValueError("FlatAdam: one parameter group only (pass the parameters, not a list of groups)")
         self.params = [p for p in params if p.requires_grad]
         if not self.params:
             raise ValueError("FlatAdam: no trainable parameters")
@@ -42,6 +49,8 @@ class FlatAdam:
         self._lr_dev = torch.full((), float(lr), dtype=torch.float32, device=dev)
         self._lr = float(lr)
         self.betas, self.eps, self.weight_decay = tuple(betas), float(eps), float(weight_decay)
+        super().__init__(self.params, dict(lr=float(lr), betas=tuple(betas), eps=float(eps),
+                                           weight_decay=float(weight_decay)))
 
     @property
     def lr(self):
@@ -50,7 +59,14 @@ class FlatAdam:
     @lr.setter
     def lr(self, value):
         self._lr = float(value)
+        self.param_groups[0]["lr"] = self._lr
         self._lr_dev.fill_(self._lr)
+
+    def sync_lr(self):
+        """Copy ``param_groups[0]['lr']`` (what an lr scheduler just wrote) to the device scalar the update kernel
+        reads.  ``step()`` does this itself; call it before replaying a HIP graph that captured ``step()``."""
+        if float(self.param_groups[0]["lr"]) != self._lr:
+            self.lr = float(self.param_groups[0]["lr"])
 
     def zero_grad(self, set_to_none=True):
         for p in self.params:
@@ -80,6 +96,8 @@ class FlatAdam:
         the parameters' ``.grad``.  ``grad_scale`` multiplies the gradient inside the update (1/world_size after a
         sum all-reduce).  On the GPU the update is ONE launch of istnet_adam_step (include/istnet_optim.h)."""
         g = self.pack_grads() if flat_grad is None else flat_grad
+        if not (self.flat.is_cuda and torch.cuda.is_current_stream_capturing()):
+            self.sync_lr()          # (inside a capture the fill would be recorded and replayed: sync before capturing)
         self.step_count += 1
         if self.flat.is_cuda:
             from . import _native

@@ -146,3 +146,25 @@ def test_lr_schedule_reaches_a_captured_step_without_recapture():
         ref.step()
     torch.testing.assert_close(opt.flat, ref_p.detach(), rtol=1e-5, atol=1e-7)
     assert opt.lr == 1e-4 and int(opt.step_count) == 5     # warm-up + four replays (the capture pass does not execute)
+
+
+def test_flat_adam_works_with_torch_lr_schedulers():
+    """FlatAdam is a torch.optim.Optimizer: CyclicLR (what utils/solver.py:46-47 builds) drives it like torch's Adam."""
+    a, b = _models()
+    ref = torch.optim.Adam(a.parameters(), lr=1e-3)
+    opt = FlatAdam(b.parameters(), lr=1e-3)
+    scheds = [torch.optim.lr_scheduler.CyclicLR(o, base_lr=1e-5, max_lr=1e-2, step_size_up=3, mode="triangular",
+                                                cycle_momentum=False) for o in (ref, opt)]
+    g = torch.Generator().manual_seed(2)
+    for _ in range(8):
+        x = torch.randn(4, 5, generator=g)
+        for m, o, sch in ((a, ref, scheds[0]), (b, opt, scheds[1])):
+            o.zero_grad(set_to_none=True)
+            m(x).square().mean().backward()
+            o.step()
+            sch.step()
+    assert abs(opt.param_groups[0]["lr"] - ref.param_groups[0]["lr"]) < 1e-12
+    for p, q in zip(a.parameters(), b.parameters()):
+        torch.testing.assert_close(q, p, rtol=1e-5, atol=1e-7)
+    with pytest.raises(ValueError):
+        FlatAdam([{"params": list(b.parameters())}])
