@@ -1,0 +1,86 @@
+"""The reference's training loop (train.py + utils/solver.py:84-100) on this package, with synthetic batches.
+
+Same objects as the reference builds -- IST_Net with the ResNet-18/PSP RGB branch, SupervisedLoss, Adam driven by a
+per-iteration CyclicLR, the BatchNorm-momentum schedule -- with the three substitutions INTEGRATION.md describes:
+``FlatAdam`` for ``torch.optim.Adam``, one process per GPU + ``GradAllReducer`` for ``nn.DataParallel``, and synthetic
+data for the NOCS loaders (no dataset in this repository).
+
+    python examples/train_synthetic.py --iters 20
+    python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 examples/train_synthetic.py --iters 20
+"""
+import argparse
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402  (synthetic batch generator of SURVEY.md 8d config 3)
+import istnet_amd  # noqa: E402,F401
+from istnet_amd.ist_net import IST_Net  # noqa: E402
+from istnet_amd.losses import SupervisedLoss  # noqa: E402
+from istnet_amd.optim import FlatAdam  # noqa: E402
+from istnet_amd.parallel import GradAllReducer, broadcast_parameters  # noqa: E402
+from istnet_amd.pointnet2.pytorch_utils import BNMomentumScheduler  # noqa: E402
+from istnet_amd.rgb_branch import ModifiedResnet  # noqa: E402
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--iters", type=int, default=20)
+    ap.add_argument("--batch", type=int, default=8)
+    ap.add_argument("--npoints", type=int, default=1024)
+    ap.add_argument("--img", type=int, default=192)
+    ap.add_argument("--freeze-world-enhancer", action="store_true")
+    args = ap.parse_args(argv)
+    world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=dev)
+
+    torch.manual_seed(0)
+    model = IST_Net(rgb_extractor=ModifiedResnet(), freeze_world_enhancer=args.freeze_world_enhancer).to(dev).train()
+    model.rgb_cam_extractor.to(memory_format=torch.channels_last)
+    if args.freeze_world_enhancer:                      # train.py:116-118
+        for p in model.world_enhancer.parameters():
+            p.requires_grad_(False)
+    if world > 1:
+        broadcast_parameters(model, src=0)
+    # solver.py:40-49 -- Adam (betas of config/ist_net_default.yaml), CyclicLR every iteration, BN momentum decay
+    opt = FlatAdam(model.parameters(), lr=1e-5, betas=(0.5, 0.999))
+    sched = torch.optim.lr_scheduler.CyclicLR(opt, base_lr=1e-5, max_lr=1e-3, step_size_up=max(args.iters // 6, 1),
+                                              mode="triangular", cycle_momentum=False)
+    bnm = BNMomentumScheduler(model, bn_lambda=lambda it: max(0.5 * 0.5 ** int(it / 200000), 0.01), last_epoch=0)
+    reducer = GradAllReducer(model, world) if world > 1 else None
+    criterion = SupervisedLoss(1.0, 10.0, freeze_world_enhancer=args.freeze_world_enhancer)
+
+    history = []
+    for it in range(args.iters):
+        batch = bench.istnet_batch(args.batch, args.npoints, seed=1000 * rank + it, device=dev, hw=args.img)
+        bnm.step(it)
+        opt.zero_grad(set_to_none=True)
+        end_points = model(batch)
+        end_points.update({k: batch[k] for k in ("rotation_label", "translation_label", "size_label", "qo")})
+        loss = criterion(end_points)
+        loss.backward()
+        if reducer is not None:
+            opt.step(reducer.sum_(opt.pack_grads()), grad_scale=1.0 / world)
+        else:
+            opt.step()
+        sched.step()
+        history.append(float(loss.detach()))
+        if rank == 0 and (it % 5 == 0 or it == args.iters - 1):
+            print(f"iter {it:4d}  lr {opt.param_groups[0]['lr']:.2e}  loss {history[-1]:.4f}", flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    return history
+
+
+if __name__ == "__main__":
+    main()

@@ -65,3 +65,17 @@ def test_pipelined_training_steps_match_plain_steps_under_graph_capture():
         a, b = run(False, steps), run(True, steps)
         rel = ((a - b).norm() / a.norm()).item()
         assert rel < 1e-4, (steps, rel)
+
+
+def test_reference_style_training_loop_example():
+    """examples/train_synthetic.py -- the reference's solver loop (Adam + CyclicLR + BN momentum schedule +
+    SupervisedLoss) on this package: runs, the loss is finite and goes down on repeated small batches."""
+    import importlib.util
+    import os
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples", "train_synthetic.py")
+    spec = importlib.util.spec_from_file_location("train_synthetic", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    hist = mod.main(["--iters", "12", "--batch", "4", "--npoints", "256", "--img", "64"])
+    assert len(hist) == 12 and all(h == h and h < 1e4 for h in hist)
+    assert min(hist[6:]) < hist[0]
