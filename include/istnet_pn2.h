@@ -99,6 +99,11 @@ ISTNET_PN2_API int istnet_pn2_three_interpolate_grad(int b, int c, int n, int m,
  *   in ascending e, i.e. the summation order of the serial loop. */
 ISTNET_PN2_API int istnet_pn2_interp_csr_build(int b, int n, int m, const int *idx, int *offsets, int *entries,
                                                void *stream);
+/* the same inverse lists for any index tensor: idx (b, e) with values in [0, m) -> offsets (b, m+1), entries (b, e)
+ * (entries of a list in ascending slot order).  Used with the ball-query indices (e = npoint*nsample, m = n) by the
+ * atomic-free layer-0 gradient scatter, istnet_pw_scatter_dy_csr. */
+ISTNET_PN2_API int istnet_pn2_csr_build(int b, int e, int m, const int *idx, int *offsets, int *entries,
+                                        void *stream);
 ISTNET_PN2_API int istnet_pn2_three_interpolate_grad_csr(int b, int c, int n, int m, const float *grad_out,
                                                          const float *weight, const int *offsets,
                                                          const int *entries, float *grad_points, void *stream);

@@ -160,6 +160,16 @@ ISTNET_PN2_API int istnet_pw_scatter_dy(int b, int cout, int n, int p, int nsamp
                                         const unsigned char *arg, const float *bn, const float *bwdc,
                                         const int *idx, float *out, long long out_bstride, const float *xyz,
                                         const float *new_xyz, int group_nsample, float *dwx, void *stream);
+/* The same scatter, atomic-free and deterministic, over inverse lists (offsets (b,n+1), entries (b,p)) of the
+ * ball-query indices built by istnet_pn2_csr_build: source point i sums dY0 over the slots that picked it in
+ * ascending slot order.  Dense gradient source only.  dwx (b*chunks, cout, 3) with chunks =
+ * istnet_pw_scatter_csr_chunks(n) receives the per-workgroup partials of dW0[:, 0:3] (NULL to skip). */
+ISTNET_PN2_API int istnet_pw_scatter_csr_chunks(int n);
+ISTNET_PN2_API int istnet_pw_scatter_dy_csr(int b, int cout, int n, int p, const float *y, const float *d_dense,
+                                            const float *bn, const float *bwdc, const int *offsets,
+                                            const int *entries, float *out, long long out_bstride,
+                                            const float *xyz, const float *new_xyz, int group_nsample,
+                                            float *dwx, void *stream);
 
 /* split-K weight gradient (requires p % 32 == 0): dw_part[split][co][ci] = sum_{p in split} dY[b][co][p] * act(x[b][ci][p]) with
  * istnet_pw_wgrad_splits(...) splits; istnet_pw_wgrad_reduce sums the partials in a fixed order:

@@ -17,6 +17,9 @@ ABI_VERSION = 1
 _i, _f, _p, _d, _l = ctypes.c_int, ctypes.c_float, ctypes.c_void_p, ctypes.c_double, ctypes.c_longlong
 # name -> argtypes (restype is always int); mirrors include/istnet_pn2.h
 SIGNATURES = {
+    "istnet_pn2_csr_build": [_i, _i, _i, _p, _p, _p, _p],
+    "istnet_pw_scatter_csr_chunks": [_i],
+    "istnet_pw_scatter_dy_csr": [_i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _l, _p, _p, _i, _p, _p],
     "istnet_adam_step": [_l, _p, _p, _p, _p, _p, _p, _d, _d, _d, _d, _d, _d, _p],
     "istnet_backproject_choose": [_i, _i, _i, _i, _p, _i, _l, _p, _p, _d, _d, _d, _d, _d, _i, _p, _p, _p],
     "istnet_pn2_set_tuning": [_i, _i],

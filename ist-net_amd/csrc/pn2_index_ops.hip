@@ -389,7 +389,7 @@ __global__ __launch_bounds__(kScatterThreads) void group_grad_kernel(
 // ---- three_interpolate_grad without atomics: per-cloud inverse lists (CSR) of the 3n taps, then a gather.
 // build: offsets off[b][m+1], entries ent[b][3n] = tap number e = 3*j + t, grouped by known point and
 // sorted ascending inside each group (=> the summation order of the serial reference loop).
-__global__ __launch_bounds__(256) void interp_csr_build_kernel(int n, int m, const int* __restrict__ idx_all,
+__global__ __launch_bounds__(256) void interp_csr_build_kernel(int E, int m, const int* __restrict__ idx_all,
                                                                int* __restrict__ off_all,
                                                                int* __restrict__ ent_all) {
   extern __shared__ __attribute__((aligned(16))) int lds_i[];  // cnt[m] | cur[m] | off[m+1] | part[256]
@@ -398,9 +398,8 @@ __global__ __launch_bounds__(256) void interp_csr_build_kernel(int n, int m, con
   int* off = lds_i + 2 * m;
   int* part = lds_i + 3 * m + 1;
   const int b = blockIdx.x, tid = threadIdx.x;
-  const int* idx = idx_all + (size_t)b * n * 3;
-  int* ent = ent_all + (size_t)b * n * 3;
-  const int E = 3 * n;
+  const int* idx = idx_all + (size_t)b * E;   // E index slots per cloud (3n taps of three_nn, or npoint*nsample ball slots)
+  int* ent = ent_all + (size_t)b * E;
   for (int i = tid; i < m; i += 256) cnt[i] = 0;
   __syncthreads();
   for (int e = tid; e < E; e += 256) atomicAdd(&cnt[idx[e]], 1);
@@ -436,6 +435,58 @@ __global__ __launch_bounds__(256) void interp_csr_build_kernel(int n, int m, con
       ent[v + 1] = key;
     }
   }
+  for (int i = tid; i <= m; i += 256) off_all[(size_t)b * (m + 1) + i] = off[i];
+}
+
+// The same build with the entry array resident in LDS (E + 3m + 257 ints must fit): long lists -- a ball-query
+// source point that pads many groups is referenced by hundreds of slots -- make the per-list insertion sort O(L^2)
+// dependent accesses, which costs milliseconds against global memory and microseconds against LDS.
+__global__ __launch_bounds__(256) void csr_build_lds_kernel(int E, int m, const int* __restrict__ idx_all,
+                                                            int* __restrict__ off_all, int* __restrict__ ent_all) {
+  extern __shared__ __attribute__((aligned(16))) int lds_i[];  // cnt[m] | cur[m] | off[m+1] | part[256] | ent[E]
+  int* cnt = lds_i;
+  int* cur = lds_i + m;
+  int* off = lds_i + 2 * m;
+  int* part = lds_i + 3 * m + 1;
+  int* ent = lds_i + 3 * m + 1 + 256;
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const int* idx = idx_all + (size_t)b * E;
+  for (int i = tid; i < m; i += 256) cnt[i] = 0;
+  __syncthreads();
+  for (int e = tid; e < E; e += 256) atomicAdd(&cnt[idx[e]], 1);
+  __syncthreads();
+  const int per = (m + 255) / 256;
+  const int lo = min(tid * per, m), hi = min(lo + per, m);
+  int s = 0;
+  for (int i = lo; i < hi; ++i) s += cnt[i];
+  part[tid] = s;
+  __syncthreads();
+  if (tid == 0) {
+    int run = 0;
+    for (int t = 0; t < 256; ++t) { const int v = part[t]; part[t] = run; run += v; }
+    off[m] = run;
+  }
+  __syncthreads();
+  int run = part[tid];
+  for (int i = lo; i < hi; ++i) { off[i] = run; cur[i] = run; run += cnt[i]; }
+  __syncthreads();
+  // ascending rounds of 256 slots keep every list nearly sorted (only the order inside a round is arbitrary)
+  for (int e0 = 0; e0 < E; e0 += 256) {
+    const int e = e0 + tid;
+    if (e < E) ent[atomicAdd(&cur[idx[e]], 1)] = e;
+    __syncthreads();
+  }
+  for (int i = tid; i < m; i += 256) {  // canonical order: ascending slot
+    const int a = off[i], z = off[i + 1];
+    for (int u = a + 1; u < z; ++u) {
+      const int key = ent[u];
+      int v = u - 1;
+      while (v >= a && ent[v] > key) { ent[v + 1] = ent[v]; --v; }
+      ent[v + 1] = key;
+    }
+  }
+  __syncthreads();
+  for (int e = tid; e < E; e += 256) ent_all[(size_t)b * E + e] = ent[e];
   for (int i = tid; i <= m; i += 256) off_all[(size_t)b * (m + 1) + i] = off[i];
 }
 
@@ -797,8 +848,21 @@ int istnet_pn2_interp_csr_build(int b, int n, int m, const int* idx, int* offset
   if (b == 0) return 0;
   const size_t lds = ((size_t)3 * m + 1 + 256) * 4;
   if (lds > (size_t)kMaxLdsRowBytes) return ISTNET_PN2_EINVAL;  // caller falls back to the atomic kernel
-  hipLaunchKernelGGL(interp_csr_build_kernel, dim3(b), dim3(256), lds, as_stream(stream), n, m, idx, offsets,
+  hipLaunchKernelGGL(interp_csr_build_kernel, dim3(b), dim3(256), lds, as_stream(stream), 3 * n, m, idx, offsets,
                      entries);
+  return (int)hipGetLastError();
+}
+
+int istnet_pn2_csr_build(int b, int e, int m, const int* idx, int* offsets, int* entries, void* stream) {
+  if (b < 0 || e < 0 || m <= 0) return ISTNET_PN2_EINVAL;
+  if (b == 0) return 0;
+  const size_t lds = ((size_t)3 * m + 1 + 256) * 4;
+  if (lds > (size_t)kMaxLdsRowBytes) return ISTNET_PN2_EINVAL;
+  if (lds + (size_t)e * 4 <= (size_t)kMaxLdsRowBytes)
+    hipLaunchKernelGGL(csr_build_lds_kernel, dim3(b), dim3(256), lds + (size_t)e * 4, as_stream(stream), e, m, idx,
+                       offsets, entries);
+  else
+    hipLaunchKernelGGL(interp_csr_build_kernel, dim3(b), dim3(256), lds, as_stream(stream), e, m, idx, offsets, entries);
   return (int)hipGetLastError();
 }
 

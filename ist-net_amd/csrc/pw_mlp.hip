@@ -927,6 +927,107 @@ __global__ __launch_bounds__(256) void pw_scatter_dy_kernel(int cout, int n, int
   }
 }
 
+// The same scatter without atomics, over inverse lists of the ball-query indices (built from coordinates only,
+// istnet_pn2_csr_build): source point i sums dY0 over the slots that picked it, in ascending slot order, so the
+// result is deterministic, and the LDS atomic unit that bounds pw_scatter_dy_kernel (one ds_add_f32
+// wave-instruction per channel per 256 slots) is out of the picture.  A workgroup owns CH channels of one cloud:
+// phase 1 streams (y0, dA0) coalesced, forms dY0 and keeps it in LDS point-major ([slot][CH]); phase 2 walks the
+// lists, one source point per thread at a time, reading dY0 from LDS (a gather straight from global memory moves a
+// cache line per 4 useful bytes and measured 3x slower than the atomics).
+// dwx[b][co][0:3] = sum_i xyz[i] * G[co][i] - sum_slots dY0[co][e] * centre[e / S].
+template <int CH>
+__global__ __launch_bounds__(256) void pw_scatter_csr_kernel(int cout, int n, int P, const float* __restrict__ y,
+                                                             const float* __restrict__ d,
+                                                             const float* __restrict__ bn,
+                                                             const float* __restrict__ bwdc,
+                                                             const int* __restrict__ off_all,
+                                                             const int* __restrict__ ent_all,
+                                                             float* __restrict__ out, long long out_bstride,
+                                                             const float* __restrict__ xyz,
+                                                             const float* __restrict__ new_xyz, int group_s,
+                                                             float* __restrict__ dwx) {
+  extern __shared__ __attribute__((aligned(16))) float dy[];   // [P][CH]
+  const int b = blockIdx.y, c0 = blockIdx.x * CH;
+  const int nch = min(CH, cout - c0);
+  float rs[CH], rh[CH], ca[CH], cb[CH], cc[CH];
+#pragma unroll
+  for (int ch = 0; ch < CH; ++ch) {
+    const int co = min(c0 + ch, cout - 1);
+    rs[ch] = bn[co]; rh[ch] = bn[cout + co];
+    ca[ch] = bwdc[co]; cb[ch] = bwdc[cout + co]; cc[ch] = bwdc[2 * cout + co];
+  }
+  // ---- phase 1: dY0 of CH channel rows -> LDS (P % 4 == 0) ----
+  for (int p = threadIdx.x * 4; p < P; p += 1024) {
+    float4 v[CH];
+#pragma unroll
+    for (int ch = 0; ch < CH; ++ch) {
+      const size_t row = ((size_t)b * cout + min(c0 + ch, cout - 1)) * P + p;
+      const float4 yv = *reinterpret_cast<const float4*>(y + row);
+      const float4 dv = *reinterpret_cast<const float4*>(d + row);
+      v[ch].x = ca[ch] * ((yv.x * rs[ch] + rh[ch] > 0.f) ? dv.x : 0.f) + cb[ch] + cc[ch] * yv.x;
+      v[ch].y = ca[ch] * ((yv.y * rs[ch] + rh[ch] > 0.f) ? dv.y : 0.f) + cb[ch] + cc[ch] * yv.y;
+      v[ch].z = ca[ch] * ((yv.z * rs[ch] + rh[ch] > 0.f) ? dv.z : 0.f) + cb[ch] + cc[ch] * yv.z;
+      v[ch].w = ca[ch] * ((yv.w * rs[ch] + rh[ch] > 0.f) ? dv.w : 0.f) + cb[ch] + cc[ch] * yv.w;
+    }
+#pragma unroll
+    for (int ch = 0; ch < CH; ++ch) {
+      dy[(size_t)(p + 0) * CH + ch] = v[ch].x; dy[(size_t)(p + 1) * CH + ch] = v[ch].y;
+      dy[(size_t)(p + 2) * CH + ch] = v[ch].z; dy[(size_t)(p + 3) * CH + ch] = v[ch].w;
+    }
+  }
+  __syncthreads();
+  // ---- phase 2: each source point sums its list in ascending slot order ----
+  const int* off = off_all + (size_t)b * (n + 1);
+  const int* ent = ent_all + (size_t)b * P;
+  const float* ctr = new_xyz + (size_t)b * (P / group_s) * 3;
+  float wx[CH][3];
+#pragma unroll
+  for (int ch = 0; ch < CH; ++ch) wx[ch][0] = wx[ch][1] = wx[ch][2] = 0.f;
+  for (int i = threadIdx.x; i < n; i += 256) {
+    const int a = off[i], z = off[i + 1];
+    float sum[CH], wc[CH][3];
+#pragma unroll
+    for (int ch = 0; ch < CH; ++ch) { sum[ch] = 0.f; wc[ch][0] = wc[ch][1] = wc[ch][2] = 0.f; }
+    for (int u = a; u < z; ++u) {
+      const int e = ent[u];
+      float c3[3] = {0.f, 0.f, 0.f};
+      if (dwx != nullptr) { const float* cp = ctr + (size_t)(e / group_s) * 3; c3[0] = cp[0]; c3[1] = cp[1]; c3[2] = cp[2]; }
+#pragma unroll
+      for (int ch = 0; ch < CH; ++ch) {
+        const float v = dy[(size_t)e * CH + ch];
+        sum[ch] += v;
+        wc[ch][0] += v * c3[0]; wc[ch][1] += v * c3[1]; wc[ch][2] += v * c3[2];
+      }
+    }
+#pragma unroll
+    for (int ch = 0; ch < CH; ++ch)
+      if (ch < nch) out[(size_t)b * out_bstride + (size_t)(c0 + ch) * n + i] = sum[ch];
+    if (dwx != nullptr) {
+      const float* xs = xyz + ((size_t)b * n + i) * 3;
+      const float px = xs[0], py = xs[1], pz = xs[2];
+#pragma unroll
+      for (int ch = 0; ch < CH; ++ch) {
+        wx[ch][0] += px * sum[ch] - wc[ch][0]; wx[ch][1] += py * sum[ch] - wc[ch][1]; wx[ch][2] += pz * sum[ch] - wc[ch][2];
+      }
+    }
+  }
+  if (dwx != nullptr) {   // fixed-order workgroup sum -> dwx[b][co][0:3]
+    __syncthreads();
+    float* wred = dy;     // [4 waves][CH*3]
+#pragma unroll
+    for (int ch = 0; ch < CH; ++ch)
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        const float t = wave_sum(wx[ch][k]);
+        if (lane_id() == 0) wred[wave_id() * CH * 3 + ch * 3 + k] = t;
+      }
+    __syncthreads();
+    if (threadIdx.x < nch * 3)
+      dwx[((size_t)b * cout + c0) * 3 + threadIdx.x] = (wred[threadIdx.x] + wred[CH * 3 + threadIdx.x]) +
+                                                       (wred[2 * CH * 3 + threadIdx.x] + wred[3 * CH * 3 + threadIdx.x]);
+  }
+}
+
 // ============================================================================================
 // dgrad:  dx[b][m][p] = sum_co w[co][ci_off + m] * dY[b][co][p]
 // ============================================================================================
@@ -1987,6 +2088,43 @@ int istnet_pw_scatter_dy(int b, int cout, int n, int p, int nsample, const float
                      as_stream(stream), cout, n, p, y, gs, bn, bwdc, idx, out,
                      out_bstride > 0 ? out_bstride : (long long)cout * n, xyz, new_xyz,
                      group_nsample > 0 ? group_nsample : 1, dwx);
+  return (int)hipGetLastError();
+}
+
+int istnet_pw_scatter_csr_chunks(int n) { (void)n; return 1; }
+
+// channels per workgroup of the list scatter: the dY0 rows must fit 64 KB of LDS, and the grid should fill the chip
+static int scatter_csr_ch(int b, int cout, int p) {
+  int ch = 16;
+  while (ch > 1 && ((size_t)ch * p * 4 > 64 * 1024 || (long long)b * ceil_div(cout, ch) < 512)) ch >>= 1;
+  return ch;
+}
+
+int istnet_pw_scatter_dy_csr(int b, int cout, int n, int p, const float* y, const float* d_dense, const float* bn,
+                             const float* bwdc, const int* offsets, const int* entries, float* out,
+                             long long out_bstride, const float* xyz, const float* new_xyz, int group_nsample,
+                             float* dwx, void* stream) {
+  if (b <= 0 || cout <= 0 || n <= 0 || p <= 0 || (p & 3) || !y || !d_dense || !bn || !bwdc || !offsets || !entries || !out)
+    return ISTNET_PN2_EINVAL;
+  if (dwx != nullptr && (xyz == nullptr || new_xyz == nullptr || group_nsample <= 0 || p % group_nsample))
+    return ISTNET_PN2_EINVAL;
+  const int ch = scatter_csr_ch(b, cout, p);
+  if ((size_t)ch * p * 4 > 64 * 1024) return ISTNET_PN2_EINVAL;    // a single row does not fit: caller uses the atomic kernel
+  const size_t lds = (size_t)ch * p * 4 < 4 * 16 * 3 * 4 ? 4 * 16 * 3 * 4 : (size_t)ch * p * 4;
+  const dim3 grid(ceil_div(cout, ch), b);
+  const long long obs = out_bstride > 0 ? out_bstride : (long long)cout * n;
+  const int gsz = group_nsample > 0 ? group_nsample : 1;
+#define ISTNET_SCSR(CH)                                                                                            \
+  hipLaunchKernelGGL(pw_scatter_csr_kernel<CH>, grid, dim3(256), lds, as_stream(stream), cout, n, p, y, d_dense, bn, \
+                     bwdc, offsets, entries, out, obs, xyz, new_xyz, gsz, dwx)
+  switch (ch) {
+    case 16: ISTNET_SCSR(16); break;
+    case 8: ISTNET_SCSR(8); break;
+    case 4: ISTNET_SCSR(4); break;
+    case 2: ISTNET_SCSR(2); break;
+    default: ISTNET_SCSR(1); break;
+  }
+#undef ISTNET_SCSR
   return (int)hipGetLastError();
 }
 

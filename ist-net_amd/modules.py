@@ -11,7 +11,7 @@ import torch
 import torch.nn as nn
 
 from . import _native
-from .pointnet2 import pointnet2_utils
+from .pointnet2 import fused_mlp, pointnet2_utils
 from .pointnet2.fused_mlp import defer_bn_counters
 from .pointnet2.pointnet2_modules import PointnetFPModule, PointnetSAModuleMSG
 
@@ -40,7 +40,7 @@ class GeometrySlot:
     ``forward(..., geometry=slot)``.  Two slots ping-pong in a pipelined training loop."""
 
     def __init__(self):
-        self.sa = None       # per level: (new_xyz, [idx per scale])
+        self.sa = None       # per level: (new_xyz, [idx per scale], [inverse lists of idx per scale] or None)
         self.fp = None       # per FP level: (idx, weight, csr or None)
         self.event = None    # recorded on the geometry stream after the last write (eager mode)
         self.shape = None
@@ -48,8 +48,10 @@ class GeometrySlot:
 
     def tensors(self):
         out = []
-        for new_xyz, idxs in self.sa:
+        for new_xyz, idxs, csrs in self.sa:
             out += [new_xyz, *idxs]
+            for csr in (csrs or ()):
+                out += list(csr)
         for idx, weight, csr in self.fp:
             out += [idx, weight, *(csr if csr is not None else ())]
         return out
@@ -81,9 +83,11 @@ class PointNet2MSG(nn.Module):
         features = pc[..., 3:].transpose(1, 2).contiguous() if pc.size(-1) > 3 else None
         return xyz, features
 
-    def _geometry_prepass(self, xyz):
+    def _geometry_prepass(self, xyz, with_ball_csr=False):
         """Everything that depends on coordinates only, on the geometry stream.
-        Returns (per-level (new_xyz, [ball idx], event), per-FP-level (idx, weight, event))."""
+        Returns (per-level [new_xyz, [ball idx], event, inverse lists or None], per-FP-level (idx, weight, csr, event),
+        event after the inverse lists).  The inverse lists of the ball indices (``with_ball_csr``) are only read by the
+        backward pass, so they are built last and the forward never waits for them."""
         dev = xyz.device
         main, side = torch.cuda.current_stream(dev), _geometry_stream(dev)
         side.wait_stream(main)            # xyz is produced on main; also orders reuse of last step's buffers
@@ -95,7 +99,7 @@ class PointNet2MSG(nn.Module):
                 idx = [pointnet2_utils.ball_query(g.radius, g.nsample, cur, new_xyz) for g in sa.groupers]
                 ev = torch.cuda.Event()
                 ev.record(side)
-                sa_geo.append((new_xyz, idx, ev))
+                sa_geo.append([new_xyz, idx, ev, None])
                 levels.append(new_xyz)
                 cur = new_xyz
             for lvl in range(len(self.FP_modules) - 1, -1, -1):
@@ -103,7 +107,15 @@ class PointNet2MSG(nn.Module):
                 ev = torch.cuda.Event()
                 ev.record(side)
                 fp_geo[lvl] = (idx, weight, csr, ev)
-        return sa_geo, fp_geo
+            csr_ev = None
+            ball_csr = getattr(pointnet2_utils._ext, "ball_csr", None)     # absent from a plain reference _ext
+            if with_ball_csr and ball_csr is not None and fused_mlp.USE_CSR_SCATTER:
+                for lvl in range(1, len(sa_geo)):       # level 0 has no input features, hence no scatter
+                    lists = [ball_csr(i, levels[lvl].shape[1]) for i in sa_geo[lvl][1]]
+                    sa_geo[lvl][3] = lists if all(c is not None for c in lists) else None
+                csr_ev = torch.cuda.Event()
+                csr_ev.record(side)
+        return sa_geo, fp_geo, csr_ev
 
     def prefetch_geometry(self, pointcloud, slot=None):
         """Start the coordinate-only work of ``pointcloud`` NOW on the geometry stream -- concurrently with whatever
@@ -116,14 +128,14 @@ class PointNet2MSG(nn.Module):
         xyz, _ = self._break_up_pc(pointcloud)
         if not self._can_prepass(xyz):
             raise RuntimeError("prefetch_geometry needs a CUDA point cloud and plain MSG set-abstraction levels")
-        sa_geo, fp_geo = self._geometry_prepass(xyz)
+        sa_geo, fp_geo, _ = self._geometry_prepass(xyz, with_ball_csr=torch.is_grad_enabled())
         side = _geometry_stream(xyz.device)
         with torch.cuda.stream(side), torch.no_grad():
             fresh = GeometrySlot()
-            fresh.sa = [(new_xyz, list(idx)) for new_xyz, idx, _ in sa_geo]
+            fresh.sa = [(new_xyz, list(idx), csrs) for new_xyz, idx, _, csrs in sa_geo]
             fresh.fp = [(idx, weight, csr) for idx, weight, csr, _ in fp_geo]
             src = fresh.tensors()
-            if slot.sa is None or slot.shape != tuple(xyz.shape):
+            if slot.sa is None or slot.shape != tuple(xyz.shape) or len(src) != len(slot.tensors()):
                 # persistent storage: one flat buffer per dtype, the slot's tensors are views into them, so a refill
                 # is two pack kernels instead of one copy per tensor
                 slot.flat = {dt: torch.empty(sum(t.numel() for t in src if t.dtype == dt), dtype=dt, device=xyz.device)
@@ -134,7 +146,9 @@ class PointNet2MSG(nn.Module):
                     views.append(slot.flat[t.dtype][off[t.dtype]:off[t.dtype] + t.numel()].view(t.shape))
                     off[t.dtype] += t.numel()
                 it = iter(views)
-                slot.sa = [(next(it), [next(it) for _ in idxs]) for _, idxs in fresh.sa]
+                slot.sa = [(next(it), [next(it) for _ in idxs],
+                            [(next(it), next(it)) for _ in csrs] if csrs is not None else None)
+                           for _, idxs, csrs in fresh.sa]
                 slot.fp = [(next(it), next(it), (next(it), next(it)) if csr is not None else None)
                            for _, _, csr in fresh.fp]
                 slot.shape = tuple(xyz.shape)
@@ -166,17 +180,17 @@ class PointNet2MSG(nn.Module):
 
     def _forward(self, pointcloud, geometry=None):
         xyz, features = self._break_up_pc(pointcloud)
-        sa_geo = fp_geo = None
+        sa_geo = fp_geo = csr_ev = None
         if geometry is not None:
             if geometry.sa is None or geometry.shape != tuple(xyz.shape):
                 raise RuntimeError("forward(geometry=...): the slot was not prefetched for a cloud of this shape")
             main = torch.cuda.current_stream(xyz.device)
             if geometry.event is not None and not torch.cuda.is_current_stream_capturing():
                 main.wait_event(geometry.event)   # inside a capture the prefetching graph has completed already
-            sa_geo = [(nx, idx, None) for nx, idx in geometry.sa]
+            sa_geo = [(nx, idx, None, csrs) for nx, idx, csrs in geometry.sa]
             fp_geo = [(i, w, csr, None) for i, w, csr in geometry.fp]
         elif self._can_prepass(xyz):
-            sa_geo, fp_geo = self._geometry_prepass(xyz)
+            sa_geo, fp_geo, csr_ev = self._geometry_prepass(xyz, with_ball_csr=torch.is_grad_enabled())
             main = torch.cuda.current_stream(xyz.device)
         l_xyz, l_features = [xyz], [features]
         _native.mark("fwd start")
@@ -184,10 +198,10 @@ class PointNet2MSG(nn.Module):
             if sa_geo is None:
                 nxt_xyz, nxt_feat = sa(l_xyz[-1], l_features[-1])
             else:
-                new_xyz, idx, ev = sa_geo[i]
+                new_xyz, idx, ev, csrs = sa_geo[i]
                 if ev is not None:
                     main.wait_event(ev)
-                nxt_xyz, nxt_feat = sa(l_xyz[-1], l_features[-1], geometry=(new_xyz, idx))
+                nxt_xyz, nxt_feat = sa(l_xyz[-1], l_features[-1], geometry=(new_xyz, idx, csrs))
             l_xyz.append(nxt_xyz)
             l_features.append(nxt_feat)
             _native.mark(f"fwd SA{i + 1} done")
@@ -201,4 +215,6 @@ class PointNet2MSG(nn.Module):
             l_features[lvl] = self.FP_modules[lvl](l_xyz[lvl], l_xyz[lvl + 1], l_features[lvl],
                                                    l_features[lvl + 1], interp=interp)
             _native.mark(f"fwd FP{lvl + 1} done")
+        if csr_ev is not None:
+            main.wait_event(csr_ev)       # the backward pass reads the inverse lists built at the end of the pre-pass
         return l_features[0]

@@ -156,6 +156,25 @@ def interp_csr(idx, m):
     return offsets, entries
 
 
+def ball_csr(idx, n):
+    """Per-cloud inverse lists of a ball-query index tensor (B,npoint,nsample) over the n source points:
+    (offsets (B,n+1), entries (B,npoint*nsample)) int32, entries of a list in ascending slot order; None when n is too
+    large for the LDS histogram of the build kernel.  Depends on coordinates only (build it in the geometry pre-pass);
+    consumed by the atomic-free layer-0 gradient scatter of the fused set-abstraction backward."""
+    _contig(idx, "idx"); _is_int(idx, "idx")
+    n = int(n)
+    if 3 * n + 257 > 16384:
+        return None
+    dev = _device_of(idx, "idx")
+    b, e = idx.shape[0], idx.shape[1] * idx.shape[2]
+    offsets = torch.empty((b, n + 1), dtype=torch.int32, device=dev)
+    entries = torch.empty((b, e), dtype=torch.int32, device=dev)
+    with torch.cuda.device(dev):
+        _native.check(_native.lib().istnet_pn2_csr_build(b, e, n, _ptr(idx), _ptr(offsets), _ptr(entries),
+                                                         _stream(dev)), "csr_build")
+    return offsets, entries
+
+
 def three_interpolate_grad(grad_out, idx, weight, m, csr=None):
     """(B,C,n) f32, (B,n,3) i32, (B,n,3) f32, m -> (B,C,m).  interpolate.cpp:75-104
     ``csr``: optional result of interp_csr(idx, m) (extension of the reference signature)."""

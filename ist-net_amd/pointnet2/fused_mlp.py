@@ -171,10 +171,11 @@ class _Layer:
 
 class _Gather:
     """Layer-0 input of a set-abstraction scale described by its sources instead of a grouped tensor."""
-    __slots__ = ("xyz", "new_xyz", "feat", "idx", "n", "npoint", "nsample", "cfeat", "feat_t")
+    __slots__ = ("xyz", "new_xyz", "feat", "idx", "n", "npoint", "nsample", "cfeat", "feat_t", "csr")
 
-    def __init__(self, xyz, new_xyz, feat, idx, feat_t=None):
+    def __init__(self, xyz, new_xyz, feat, idx, feat_t=None, csr=None):
         self.xyz, self.new_xyz, self.feat, self.idx = xyz, new_xyz, feat, idx
+        self.csr = csr           # (offsets, entries): inverse lists of idx over the n source points, or None
         self.feat_t = feat_t     # (B, n, C) point-major copy: contiguous float4 gathers in the layer-0 loaders
         self.n = xyz.shape[1]
         self.npoint, self.nsample = idx.shape[1], idx.shape[2]
@@ -365,6 +366,7 @@ def _wgrad_job(lib, dev, b, cin, cout, p, ns_arg, use_gather, ga, src, in_bn, y,
 
 USE_FUSED_SMALL_BWD = os.environ.get("ISTNET_NO_FUSED_SMALL_BWD") is None
 USE_SPLIT_LAYER0 = os.environ.get("ISTNET_NO_SPLIT_LAYER0") is None
+USE_CSR_SCATTER = os.environ.get("ISTNET_NO_CSR_SCATTER") is None
 
 
 def _dwx_only_job(lib, dev, b, cout, p, ns_arg, ga, y, d_dense, d_pooled, pbs, d_arg, bn, bwdc, wparam):
@@ -486,10 +488,17 @@ def _backward_stack(lib, dev, st, b, c0, g, s, x, gather, training, ys, bns, par
                 gbuf, goff = scatter_out
                 gptr, gbs = gbuf.data_ptr() + goff * ga.n * 4, gbuf.shape[1] * ga.n
             dwx = _empty((b, cout, 3), torch.float32, dev) if split_w0 else None
-            _native.check(lib.istnet_pw_scatter_dy(b, cout, ga.n, p, ns_arg, y.data_ptr(), dd, dp, pbs, da,
-                                                   bn.data_ptr(), bwdc.data_ptr(), ga.idx.data_ptr(), gptr, gbs,
-                                                   ga.xyz.data_ptr(), ga.new_xyz.data_ptr(), ga.nsample, _p(dwx), st),
-                          "pw_scatter_dy")
+            if USE_CSR_SCATTER and ga.csr is not None and d_dense is not None and p % 4 == 0 and 4 * p <= 65536:
+                # atomic-free and deterministic: every source point sums its inverse list from an LDS-staged dY0 row
+                _native.check(lib.istnet_pw_scatter_dy_csr(
+                    b, cout, ga.n, p, y.data_ptr(), dd, bn.data_ptr(), bwdc.data_ptr(), ga.csr[0].data_ptr(),
+                    ga.csr[1].data_ptr(), gptr, gbs, ga.xyz.data_ptr(), ga.new_xyz.data_ptr(), ga.nsample, _p(dwx),
+                    st), "pw_scatter_dy_csr")
+            else:
+                _native.check(lib.istnet_pw_scatter_dy(b, cout, ga.n, p, ns_arg, y.data_ptr(), dd, dp, pbs, da,
+                                                       bn.data_ptr(), bwdc.data_ptr(), ga.idx.data_ptr(), gptr, gbs,
+                                                       ga.xyz.data_ptr(), ga.new_xyz.data_ptr(), ga.nsample, _p(dwx),
+                                                       st), "pw_scatter_dy")
             if split_w0:
                 grads[0] = dwx          # placeholder: the level node turns it into dW0 (see _finish_layer0_grads)
             if scatter_out is None:
@@ -635,8 +644,9 @@ class FusedSALevelFunction(Function):
     layer-0 feature weights -- reference pointnet2_modules.py:60-73 without the glue kernels."""
 
     @staticmethod
-    def forward(ctx, features, xyz, new_xyz, training, scales, *tensors):
-        # scales: list of per-scale `layers`; tensors = [idx_0..idx_{S-1}, params of scale 0, params of scale 1, ...]
+    def forward(ctx, features, xyz, new_xyz, training, scales, csrs, *tensors):
+        # scales: list of per-scale `layers`; csrs: per scale (offsets, entries) inverse lists of idx or None;
+        # tensors = [idx_0..idx_{S-1}, params of scale 0, params of scale 1, ...]
         lib = _native.lib()
         dev = xyz.device
         nsc = len(scales)
@@ -666,6 +676,14 @@ class FusedSALevelFunction(Function):
                 saved += [arg, *ys, *bns]
             _join_streams(streams)
         ctx.training, ctx.meta, ctx.has_feat = training, meta, feat is not None
+        # the feature gradient scatters dY0 over the ball indices: with inverse lists that is atomic-free and
+        # deterministic.  Lists not supplied by the caller (PointNet2MSG's geometry pre-pass builds them off the
+        # critical path) are built here.
+        csrs = list(csrs) if csrs is not None else [None] * nsc
+        if USE_CSR_SCATTER and feat is not None and features.requires_grad and xyz.shape[1] <= 4096:
+            from . import _ext
+            csrs = [c if c is not None else _ext.ball_csr(idx, xyz.shape[1]) for c, idx in zip(csrs, idxs)]
+        ctx.csrs = csrs
         ctx.dims = (b, g, ctot)
         ctx.has_feat_t = feat_t is not None
         ctx.save_for_backward(feat if feat is not None else torch.empty(0, device=dev), xyz, new_xyz,
@@ -703,15 +721,15 @@ class FusedSALevelFunction(Function):
         cout0_tot = sum(params_all[sum(3 * m[0] for m in meta[:i])].shape[0] for i in range(nsc))
         gbuf = _empty((b, cout0_tot, n_src), torch.float32, dev) if use_level_gemm else None
         grads_all, dfeat, goff, w0f = [], None, 0, []
-        base = 5 + nsc   # index of the first parameter among forward()'s arguments
+        base = 6 + nsc   # index of the first parameter among forward()'s arguments
         with torch.cuda.device(dev):
             st = _st(dev)
             streams = _scale_streams(dev, nsc) if (use_level_gemm or not need_x) else [torch.cuda.current_stream(dev)] * nsc
-            for (nl, s, coff, clast), (arg, ys, bns), idx, stream in zip(meta, per_scale, idxs, streams):
+            for (nl, s, coff, clast), (arg, ys, bns), idx, csr, stream in zip(meta, per_scale, idxs, ctx.csrs, streams):
                 params = params_all[ppos:ppos + 3 * nl]
                 need_w = [ctx.needs_input_grad[base + ppos + 3 * li] for li in range(nl)]
                 ppos += 3 * nl
-                ga = _Gather(xyz, new_xyz, feat if ctx.has_feat else None, idx, feat_t)
+                ga = _Gather(xyz, new_xyz, feat if ctx.has_feat else None, idx, feat_t, csr=csr)
                 cout0 = params[0].shape[0]
                 with torch.cuda.stream(stream):
                     grads, dxf, scattered = _backward_stack(
@@ -750,7 +768,7 @@ class FusedSALevelFunction(Function):
                     _finish_layer0_grads(lib, dev, b, cfeat, cout0_tot, n_src, feat, gbuf, ident, bwdc, w0_slots,
                                          grads_all)
             _native.mark(f"bwd SA(g={g}) chains done")
-        return (dfeat, None, None, None, None, *([None] * nsc), *grads_all)
+        return (dfeat, None, None, None, None, None, *([None] * nsc), *grads_all)
 
 
 def _finish_layer0_grads(lib, dev, b, cfeat, cout0_tot, n_src, feat, gbuf, ident, bwdc, w0_slots, grads_all):
@@ -1159,7 +1177,7 @@ def sa_scale(grouper, mlp, xyz, new_xyz, features, idx=None):
     return out
 
 
-def sa_level(groupers, mlps, xyz, new_xyz, features, ball_idx=None):
+def sa_level(groupers, mlps, xyz, new_xyz, features, ball_idx=None, ball_csr=None):
     """All scales of a set-abstraction level: ``cat([max_pool(mlp_i(grouper_i(...))) for i], dim=1)``.
 
     One fused autograd node when every scale qualifies for the gather-fused path (see ``sa_scale``); otherwise the
@@ -1186,7 +1204,7 @@ def sa_level(groupers, mlps, xyz, new_xyz, features, ball_idx=None):
         scales.append(layers)
         params += p
     training = mlps[0].training
-    out = FusedSALevelFunction.apply(features, xyz, new_xyz, training, scales, *idxs, *params)
+    out = FusedSALevelFunction.apply(features, xyz, new_xyz, training, scales, ball_csr, *idxs, *params)
     if training:
         _bump_counters([unit for mlp in mlps for unit in mlp])
     return out

@@ -37,10 +37,13 @@ class _PointnetSAModuleBase(nn.Module):
     def forward(self, xyz, features=None, geometry=None):
         """xyz (B,N,3), features (B,C,N) or None -> new_xyz (B,npoint,3), (B, sum(mlp[-1]), npoint).
 
-        ``geometry`` = (new_xyz, [ball-query idx per scale]) lets a caller that already ran the
-        sampling / neighbour search (PointNet2MSG's geometry pre-pass) skip it here."""
+        ``geometry`` = (new_xyz, [ball-query idx per scale][, [inverse lists of idx per scale]]) lets a caller that
+        already ran the sampling / neighbour search (PointNet2MSG's geometry pre-pass) skip it here."""
+        ball_csr = None
         if geometry is None:
             new_xyz, ball_idx = self._sample_centroids(xyz), [None] * len(self.groupers)
+        elif len(geometry) == 3:     # + inverse lists of the ball indices (fused_mlp: atomic-free gradient scatter)
+            new_xyz, ball_idx, ball_csr = geometry
         else:
             new_xyz, ball_idx = geometry
         # per scale: grouper -> SharedMLP -> max over nsample -> squeeze, then concat [ref :60-73]; on the GPU the
@@ -49,7 +52,7 @@ class _PointnetSAModuleBase(nn.Module):
             pooled = [shared_mlp_maxpool(mlp, grouper(xyz, new_xyz, features))
                       for grouper, mlp in zip(self.groupers, self.mlps)]
             return new_xyz, torch.cat(pooled, dim=1)
-        return new_xyz, sa_level(list(self.groupers), list(self.mlps), xyz, new_xyz, features, ball_idx)
+        return new_xyz, sa_level(list(self.groupers), list(self.mlps), xyz, new_xyz, features, ball_idx, ball_csr)
 
 
 class PointnetSAModuleMSG(_PointnetSAModuleBase):

@@ -118,3 +118,27 @@ def test_training_trajectory_matches_torch_composition(monkeypatch):
     rel = (fused - composed).abs() / composed.abs()
     assert float(rel[0]) < 1e-5                                        # same loss before the first update
     assert float(rel.max()) < 2.5e-2 and float(rel.mean()) < 1e-2, (fused, composed)
+
+
+def test_training_steps_are_bit_reproducible():
+    """Two runs of the same 6 encoder training steps (eager, then again) end in bit-identical parameters: no kernel
+    of the step depends on atomic ordering (the ball-index gradient scatter and the interpolation gradient walk
+    inverse lists, split-K and statistics partials are reduced in a fixed order)."""
+    import torch
+    import bench
+    from istnet_amd.optim import FlatAdam
+    dev = torch.device("cuda:0")
+
+    def run():
+        model = bench.make_model(dev, seed=11)
+        opt = FlatAdam(model.parameters(), lr=1e-3)
+        pts = [bench.shell_cloud(8, 1024, seed=40 + k, device=dev) for k in range(2)]
+        for it in range(6):
+            opt.zero_grad(set_to_none=True)
+            model(pts[it % 2]).square().mean().backward()
+            opt.step()
+        torch.cuda.synchronize()
+        return opt.flat.clone()
+
+    a, b = run(), run()
+    assert torch.equal(a, b), float((a - b).abs().max())

@@ -153,3 +153,47 @@ def test_scatter_dwx_partials():
                                     bwdc.data_ptr(), idx.data_ptr(), None, 0, xyz.data_ptr(), new_xyz.data_ptr(), s,
                                     dwx2.data_ptr(), _st()) == 0
     torch.testing.assert_close(dwx2.sum(0), want_dwx, rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("n,npoint,s,cout", [(128, 32, 16, 12), (512, 256, 32, 32), (300, 64, 8, 5), (1024, 512, 16, 64)])
+def test_scatter_csr_matches_dense_scatter_and_is_deterministic(n, npoint, s, cout):
+    """istnet_pw_scatter_dy_csr (inverse lists, no atomics) == scatter_add of the dense dY0, same dwx, and two runs
+    are bit-identical."""
+    from istnet_amd.pointnet2 import _ext
+    lib = _native.lib()
+    b = 3
+    g = torch.Generator().manual_seed(n + s)
+    xyz = torch.rand(b, n, 3, generator=g).to(DEV)
+    new_xyz = xyz[:, :npoint].contiguous()
+    idx = torch.sort(torch.randint(0, n, (b, npoint, s), generator=g), dim=2).values.int()
+    idx[:, :, s // 2:] = idx[:, :, s // 2 - 1:s // 2]          # padded rows: the tail repeats one index
+    idx = idx.to(DEV).contiguous()
+    p = npoint * s
+    y = torch.randn(b, cout, p, generator=g).to(DEV)
+    d = torch.randn(b, cout, p, generator=g).to(DEV)
+    bn = _bn_block(cout, g)
+    bwdc = torch.stack([torch.rand(cout, generator=g) + 0.5, torch.randn(cout, generator=g) * 0.1,
+                        torch.randn(cout, generator=g) * 0.1]).contiguous().to(DEV)
+    off, ent = _ext.ball_csr(idx, n)
+    flat = idx.long().reshape(b, p)
+    # lists: ascending slots, covering every slot once, consistent with idx
+    assert int(off[:, -1].min()) == p and torch.equal(torch.sort(ent, dim=1).values, torch.arange(p, device=DEV).expand(b, p).int())
+    assert torch.equal(torch.gather(flat, 1, ent.long()), torch.repeat_interleave(torch.arange(n, device=DEV), 1).expand(b, n)
+                       .repeat_interleave(1, dim=1).gather(1, torch.searchsorted(off[:, 1:].contiguous().long(), torch.arange(p, device=DEV).expand(b, p).contiguous(), right=True)))
+    mask = (y * bn[0].view(1, -1, 1) + bn[1].view(1, -1, 1)) > 0
+    dy = bwdc[0].view(1, -1, 1) * (d * mask) + bwdc[1].view(1, -1, 1) + bwdc[2].view(1, -1, 1) * y
+    xrel = torch.gather(xyz, 1, flat.unsqueeze(-1).expand(-1, -1, 3)) - new_xyz.repeat_interleave(s, dim=1)
+    want_g = torch.zeros(b, cout, n, device=DEV).scatter_add_(2, flat.unsqueeze(1).expand(-1, cout, -1), dy)
+    want_dwx = torch.einsum("bcp,bpk->ck", dy, xrel)
+    chunks = lib.istnet_pw_scatter_csr_chunks(n)
+    outs = []
+    for _ in range(2):
+        out = torch.empty(b, cout, n, device=DEV)
+        dwx = torch.empty(b * chunks, cout, 3, device=DEV)
+        assert lib.istnet_pw_scatter_dy_csr(b, cout, n, p, y.data_ptr(), d.data_ptr(), bn.data_ptr(), bwdc.data_ptr(),
+                                            off.data_ptr(), ent.data_ptr(), out.data_ptr(), 0, xyz.data_ptr(),
+                                            new_xyz.data_ptr(), s, dwx.data_ptr(), _st()) == 0
+        outs.append((out, dwx))
+    torch.testing.assert_close(outs[0][0], want_g, rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(outs[0][1].sum(0), want_dwx, rtol=1e-4, atol=2e-4)
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
