@@ -976,15 +976,21 @@ __global__ __launch_bounds__(256) void pw_scatter_csr_kernel(int cout, int n, in
     }
   }
   __syncthreads();
-  // ---- phase 2: each source point sums its list in ascending slot order ----
+  // ---- phase 2: each source point sums its list; four lanes split a list into contiguous quarters (padded ball
+  // rows make a few lists hundreds of slots long) and combine as (q0 + q1) + (q2 + q3): a fixed order ----
   const int* off = off_all + (size_t)b * (n + 1);
   const int* ent = ent_all + (size_t)b * P;
   const float* ctr = new_xyz + (size_t)b * (P / group_s) * 3;
   float wx[CH][3];
 #pragma unroll
   for (int ch = 0; ch < CH; ++ch) wx[ch][0] = wx[ch][1] = wx[ch][2] = 0.f;
-  for (int i = threadIdx.x; i < n; i += 256) {
-    const int a = off[i], z = off[i + 1];
+  const int part = threadIdx.x & 3;
+  const int n_round = (n + 63) / 64 * 64;            // whole quads stay converged for the DPP combine
+  for (int i = threadIdx.x >> 2; i < n_round; i += 64) {
+    const bool valid = i < n;
+    const int a0 = valid ? off[i] : 0, z0 = valid ? off[i + 1] : 0;
+    const int len = z0 - a0, q = (len + 3) >> 2;
+    const int a = min(a0 + part * q, z0), z = min(a + q, z0);
     float sum[CH], wc[CH][3];
 #pragma unroll
     for (int ch = 0; ch < CH; ++ch) { sum[ch] = 0.f; wc[ch][0] = wc[ch][1] = wc[ch][2] = 0.f; }
@@ -999,15 +1005,28 @@ __global__ __launch_bounds__(256) void pw_scatter_csr_kernel(int cout, int n, in
         wc[ch][0] += v * c3[0]; wc[ch][1] += v * c3[1]; wc[ch][2] += v * c3[2];
       }
     }
+    // quad combine: lane ^ 1, then lane ^ 2 (quad_perm DPP); every lane of the quad ends with the same total
 #pragma unroll
-    for (int ch = 0; ch < CH; ++ch)
-      if (ch < nch) out[(size_t)b * out_bstride + (size_t)(c0 + ch) * n + i] = sum[ch];
-    if (dwx != nullptr) {
-      const float* xs = xyz + ((size_t)b * n + i) * 3;
-      const float px = xs[0], py = xs[1], pz = xs[2];
+    for (int ch = 0; ch < CH; ++ch) {
+      sum[ch] += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(sum[ch]), 0xB1, 0xf, 0xf, false));   // [1,0,3,2]
+      sum[ch] += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(sum[ch]), 0x4E, 0xf, 0xf, false));   // [2,3,0,1]
 #pragma unroll
-      for (int ch = 0; ch < CH; ++ch) {
-        wx[ch][0] += px * sum[ch] - wc[ch][0]; wx[ch][1] += py * sum[ch] - wc[ch][1]; wx[ch][2] += pz * sum[ch] - wc[ch][2];
+      for (int k = 0; k < 3; ++k) {
+        wc[ch][k] += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(wc[ch][k]), 0xB1, 0xf, 0xf, false));
+        wc[ch][k] += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(wc[ch][k]), 0x4E, 0xf, 0xf, false));
+      }
+    }
+    if (valid && part == 0) {
+#pragma unroll
+      for (int ch = 0; ch < CH; ++ch)
+        if (ch < nch) out[(size_t)b * out_bstride + (size_t)(c0 + ch) * n + i] = sum[ch];
+      if (dwx != nullptr) {
+        const float* xs = xyz + ((size_t)b * n + i) * 3;
+        const float px = xs[0], py = xs[1], pz = xs[2];
+#pragma unroll
+        for (int ch = 0; ch < CH; ++ch) {
+          wx[ch][0] += px * sum[ch] - wc[ch][0]; wx[ch][1] += py * sum[ch] - wc[ch][1]; wx[ch][2] += pz * sum[ch] - wc[ch][2];
+        }
       }
     }
   }
