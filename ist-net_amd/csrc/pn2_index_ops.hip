@@ -438,17 +438,18 @@ __global__ __launch_bounds__(256) void interp_csr_build_kernel(int E, int m, con
   for (int i = tid; i <= m; i += 256) off_all[(size_t)b * (m + 1) + i] = off[i];
 }
 
-// The same build with the entry array resident in LDS (E + 3m + 257 ints must fit): long lists -- a ball-query
-// source point that pads many groups is referenced by hundreds of slots -- make the per-list insertion sort O(L^2)
-// dependent accesses, which costs milliseconds against global memory and microseconds against LDS.
+// The same lists with the entry array resident in LDS (E + 3m + 257 ints must fit) and a stable placement instead
+// of fill-then-sort: a ball-query source point that pads many groups is referenced by hundreds of slots, and the
+// per-list insertion sort of the kernel above is O(L^2) dependent accesses (milliseconds against global memory).
 __global__ __launch_bounds__(256) void csr_build_lds_kernel(int E, int m, const int* __restrict__ idx_all,
                                                             int* __restrict__ off_all, int* __restrict__ ent_all) {
-  extern __shared__ __attribute__((aligned(16))) int lds_i[];  // cnt[m] | cur[m] | off[m+1] | part[256] | ent[E]
-  int* cnt = lds_i;
-  int* cur = lds_i + m;
-  int* off = lds_i + 2 * m;
-  int* part = lds_i + 3 * m + 1;
-  int* ent = lds_i + 3 * m + 1 + 256;
+  extern __shared__ __attribute__((aligned(16))) int lds_i[];  // keys[256] | cnt[m] | cur[m] | off[m+1] | part[256] | ent[E]
+  int* keys = lds_i;                                            // 16-byte aligned: read as int4
+  int* cnt = lds_i + 256;
+  int* cur = cnt + m;
+  int* off = cnt + 2 * m;
+  int* part = cnt + 3 * m + 1;
+  int* ent = cnt + 3 * m + 1 + 256;
   const int b = blockIdx.x, tid = threadIdx.x;
   const int* idx = idx_all + (size_t)b * E;
   for (int i = tid; i < m; i += 256) cnt[i] = 0;
@@ -470,22 +471,24 @@ __global__ __launch_bounds__(256) void csr_build_lds_kernel(int E, int m, const 
   int run = part[tid];
   for (int i = lo; i < hi; ++i) { off[i] = run; cur[i] = run; run += cnt[i]; }
   __syncthreads();
-  // ascending rounds of 256 slots keep every list nearly sorted (only the order inside a round is arbitrary)
+  // Stable placement, no sort: slots are taken in ascending rounds of 256; a slot's position in its list is the
+  // list's fill level before the round plus the number of lower threads of the round with the same key (counted
+  // against an LDS copy of the round's keys; every thread reads the same address at a time -> broadcast reads).
   for (int e0 = 0; e0 < E; e0 += 256) {
     const int e = e0 + tid;
-    if (e < E) ent[atomicAdd(&cur[idx[e]], 1)] = e;
+    const int key = e < E ? idx[e] : -1;
+    keys[tid] = key;
+    __syncthreads();
+    int rank = 0;
+    for (int j = 0; j < tid; ++j) rank += (keys[j] == key) ? 1 : 0;   // (an int4-per-read variant measured slower)
+    const int base = key >= 0 ? cur[key] : 0;
+    __syncthreads();                                   // everyone has read the fill levels of this round
+    if (key >= 0) {
+      ent[base + rank] = e;
+      atomicAdd(&cur[key], 1);
+    }
     __syncthreads();
   }
-  for (int i = tid; i < m; i += 256) {  // canonical order: ascending slot
-    const int a = off[i], z = off[i + 1];
-    for (int u = a + 1; u < z; ++u) {
-      const int key = ent[u];
-      int v = u - 1;
-      while (v >= a && ent[v] > key) { ent[v + 1] = ent[v]; --v; }
-      ent[v + 1] = key;
-    }
-  }
-  __syncthreads();
   for (int e = tid; e < E; e += 256) ent_all[(size_t)b * E + e] = ent[e];
   for (int i = tid; i <= m; i += 256) off_all[(size_t)b * (m + 1) + i] = off[i];
 }
@@ -858,9 +861,9 @@ int istnet_pn2_csr_build(int b, int e, int m, const int* idx, int* offsets, int*
   if (b == 0) return 0;
   const size_t lds = ((size_t)3 * m + 1 + 256) * 4;
   if (lds > (size_t)kMaxLdsRowBytes) return ISTNET_PN2_EINVAL;
-  if (lds + (size_t)e * 4 <= (size_t)kMaxLdsRowBytes)
-    hipLaunchKernelGGL(csr_build_lds_kernel, dim3(b), dim3(256), lds + (size_t)e * 4, as_stream(stream), e, m, idx,
-                       offsets, entries);
+  if (lds + ((size_t)e + 256) * 4 <= (size_t)kMaxLdsRowBytes)
+    hipLaunchKernelGGL(csr_build_lds_kernel, dim3(b), dim3(256), lds + ((size_t)e + 256) * 4, as_stream(stream), e, m,
+                       idx, offsets, entries);
   else
     hipLaunchKernelGGL(interp_csr_build_kernel, dim3(b), dim3(256), lds, as_stream(stream), e, m, idx, offsets, entries);
   return (int)hipGetLastError();
