@@ -846,14 +846,14 @@ int istnet_pn2_three_interpolate(int b, int c, int m, int n, const float* points
   return (int)hipGetLastError();
 }
 
+int istnet_pn2_csr_build(int b, int e, int m, const int* idx, int* offsets, int* entries, void* stream);
+
 int istnet_pn2_interp_csr_build(int b, int n, int m, const int* idx, int* offsets, int* entries, void* stream) {
   if (b < 0 || n < 0 || m <= 0) return ISTNET_PN2_EINVAL;
   if (b == 0) return 0;
   const size_t lds = ((size_t)3 * m + 1 + 256) * 4;
   if (lds > (size_t)kMaxLdsRowBytes) return ISTNET_PN2_EINVAL;  // caller falls back to the atomic kernel
-  hipLaunchKernelGGL(interp_csr_build_kernel, dim3(b), dim3(256), lds, as_stream(stream), 3 * n, m, idx, offsets,
-                     entries);
-  return (int)hipGetLastError();
+  return istnet_pn2_csr_build(b, 3 * n, m, idx, offsets, entries, stream);   // same lists: e = 3n taps per cloud
 }
 
 int istnet_pn2_csr_build(int b, int e, int m, const int* idx, int* offsets, int* entries, void* stream) {
