@@ -197,3 +197,19 @@ def test_scatter_csr_matches_dense_scatter_and_is_deterministic(n, npoint, s, co
     torch.testing.assert_close(outs[0][0], want_g, rtol=1e-4, atol=1e-4)
     torch.testing.assert_close(outs[0][1].sum(0), want_dwx, rtol=1e-4, atol=2e-4)
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+
+
+def test_inverse_lists_on_degenerate_indices():
+    """Every slot pointing at the same source point (one list of length E), and a permutation (all lists length 1):
+    the stable build returns ascending entries in bounded time."""
+    from istnet_amd.pointnet2 import _ext
+    b, npoint, s, n = 2, 256, 32, 512
+    same = torch.full((b, npoint, s), 7, dtype=torch.int32, device=DEV)
+    off, ent = _ext.ball_csr(same, n)
+    e = npoint * s
+    assert torch.equal(ent, torch.arange(e, device=DEV, dtype=torch.int32).expand(b, e))
+    assert int(off[0, 7]) == 0 and int(off[0, 8]) == e and int(off[0, -1]) == e
+    perm = torch.stack([torch.randperm(n, generator=torch.Generator().manual_seed(k)) for k in range(b)]).int().to(DEV)
+    off, ent = _ext.ball_csr(perm.view(b, n // 16, 16).contiguous(), n)
+    assert torch.equal(off, torch.arange(n + 1, device=DEV, dtype=torch.int32).expand(b, n + 1))
+    assert torch.equal(torch.gather(perm.long(), 1, ent.long()), torch.arange(n, device=DEV).expand(b, n))
