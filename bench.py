@@ -260,6 +260,25 @@ def cpu_baseline(budget_s=25.0):
             "ms_per_step": dt * 1e3}
 
 
+def self_launch(n):
+    """``python bench.py --gpus N`` without a launcher: re-run this command as N ranks (one process per GPU) under
+    ``torch.distributed.run`` on 127.0.0.1 with a free port; rank 0 of the children prints the one JSON line, which
+    passes through this process's stdout.  Returns the launcher's exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "8")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    rc = subprocess.call(cmd, env=env)
+    if rc != 0:
+        raise SystemExit(rc)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -282,25 +301,42 @@ def main():
                          "one rank: exercises RCCL + HIP-graph capture on a 1-GPU box")
     ap.add_argument("--same-device", action="store_true",
                     help="dry run of the N>1 control flow on a 1-GPU box: every rank uses cuda:0 (gloo only)")
+    ap.add_argument("--cpu-dry-run", action="store_true",
+                    help="NOT a measurement: run the launch / rendezvous / barrier / all-reduce / rank-0-JSON control "
+                         "flow of --gpus N on host cores (gloo, B=2, the cpu_baseline port over the oracle ops) so the "
+                         "driver's command form can be tested on a box without GPUs")
     args = ap.parse_args()
+    if args.cpu_dry_run:
+        args.backend, args.eager, args.no_prefetch = "gloo", True, True
+        args.no_roofline = args.no_cpu_baseline = args.no_unpipelined = True
 
     if os.environ.get("ISTNET_PW_TUNE"):   # experiments: "key:value,..." for istnet_pw_set_tuning
         from istnet_amd import _native
         for kv in os.environ["ISTNET_PW_TUNE"].split(","):
             k, v = kv.split(":")
             assert _native.lib().istnet_pw_set_tuning(int(k), int(v)) == 0
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return self_launch(args.gpus)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if args.gpus == 1 and world == 1:
-            pass
-        else:
-            raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: the launcher's --nproc-per-node must equal --gpus")
     if args.same_device:
         local_rank = 0
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    batch_size = BATCH
+    if args.cpu_dry_run:
+        from istnet_amd.pointnet2 import pointnet2_utils
+        from oracle import pn2_oracle
+        pointnet2_utils._ext = pn2_oracle      # checker ops stand in for the HIP library in the dry run only
+        torch.set_num_threads(max(1, min(4, (os.cpu_count() or 2) // max(args.gpus, 1))))
+        dev, batch_size = torch.device("cpu"), 2
+        if args.workload != "encoder":
+            raise SystemExit("--cpu-dry-run covers the encoder workload only")
+    else:
+        torch.cuda.set_device(local_rank)
+        dev = torch.device("cuda", local_rank)
+    sync = (lambda: None) if args.cpu_dry_run else torch.cuda.synchronize
 
     import torch.distributed as dist
     from istnet_amd.optim import FlatAdam
@@ -327,7 +363,7 @@ def main():
                 dist.init_process_group(args.backend)
             warm = torch.ones(1, device=dev)
             dist.all_reduce(warm)            # forces communicator creation
-            torch.cuda.synchronize()
+            sync()
             libc.fflush(None)
         finally:
             os.dup2(saved_fd, 1)
@@ -353,7 +389,7 @@ def main():
         args.no_cpu_baseline = True
     else:
         model = make_model(dev, seed=0)  # identical weights on every rank (same seed)
-        pts = shell_cloud(BATCH, NPOINTS, seed=rank, device=dev)
+        pts = shell_cloud(batch_size, NPOINTS, seed=rank, device=dev)
         opt = FlatAdam(model.parameters(), lr=1e-4)
         if dist_on:
             from istnet_amd.parallel import GradAllReducer
@@ -388,11 +424,11 @@ def main():
         step()
     if dist_on:
         dist.barrier()
-    torch.cuda.synchronize()
+    sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
-    torch.cuda.synchronize()
+    sync()
     if dist_on:
         dist.barrier()
     elapsed = time.perf_counter() - t0
@@ -406,17 +442,18 @@ def main():
         ms = elapsed / args.steps * 1e3
         result = {
             "metric": "point-clouds/sec fwd+bwd, B=32 N=1024",
-            "value": BATCH * world * args.steps / elapsed,
+            "value": batch_size * world * args.steps / elapsed,
             "unit": "clouds/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic" if not args.cpu_dry_run else "synthetic (CPU dry run of the launch path: NOT a measurement)",
             "config": {"workload": ("PointNet2MSG encoder (4 SA-MSG + 4 FP, cam radii) fwd+bwd+Adam, "
                                     "train-mode BN, shell clouds") if args.workload == "encoder" else
                                    ("IST-Net full model (ResNet-18/PSP RGB branch on MIOpen + point branch, "
                                     "cam + world encoders, IST head, 3 pose heads) fwd+bwd+Adam, SupervisedLoss"
                                     + (", world enhancer frozen" if args.freeze_world_enhancer else "")),
-                       "batch_per_gpu": BATCH, "npoints": NPOINTS, "global_batch": BATCH * world,
+                       "batch_per_gpu": batch_size, "npoints": NPOINTS, "global_batch": batch_size * world,
                        "parallelism": f"dp{world}" + (" (one-rank dry run of the RCCL path)" if args.force_dist and world == 1 else ""),
                        "launch": mode,
                        "batches": ("1 (same batch every step)" if (args.workload != "encoder" or args.no_prefetch)

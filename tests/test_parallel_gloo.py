@@ -126,3 +126,37 @@ def test_flat_adam_allreduce_world2():
     out = mgr.dict()
     mp.spawn(_flat_worker, args=(world, _free_port(), out), nprocs=world, join=True)
     assert dict(out) == {0: True, 1: True}
+
+
+def _run_bench(cmd):
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    env.pop("WORLD_SIZE", None); env.pop("RANK", None); env.pop("LOCAL_RANK", None)
+    proc = subprocess.run([sys.executable] + cmd, cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert proc.returncode == 0, proc.stderr[-2000:]
+    lines = [ln for ln in proc.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, f"stdout must carry exactly one JSON line, got {lines!r}"
+    return json.loads(lines[0])
+
+
+def test_bench_self_launches_n_ranks():
+    """``python bench.py --gpus 2 ...`` (the driver's N=1 command form with N=2, no launcher, WORLD_SIZE unset)
+    spawns its own two ranks and rank 0 prints the one JSON line.  --cpu-dry-run keeps the control flow of the GPU
+    run (rendezvous, flat-gradient all-reduce, barriers, max-over-ranks timing) on host cores."""
+    res = _run_bench(["bench.py", "--gpus", "2", "--steps", "2", "--warmup", "1", "--cpu-dry-run"])
+    assert res["n_gpus"] == 2 and res["steps"] == 2 and res["warmup"] == 1
+    assert res["config"]["parallelism"] == "dp2" and res["scaling"] == "weak"
+    assert res["config"]["global_batch"] == 2 * res["config"]["batch_per_gpu"]
+    assert res["value"] > 0 and "NOT a measurement" in res["data"]
+
+
+def test_bench_under_torch_distributed_run():
+    """The driver's N>1 command form: ``python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr
+    127.0.0.1 --master-port P bench.py --gpus N --steps K --warmup W``."""
+    res = _run_bench(["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                      "127.0.0.1", "--master-port", str(_free_port()), "bench.py", "--gpus", "2", "--steps", "1",
+                      "--warmup", "1", "--cpu-dry-run"])
+    assert res["n_gpus"] == 2 and res["config"]["parallelism"] == "dp2"
