@@ -35,8 +35,11 @@ extern "C" {
 
 /* ABI version of the loaded library (== ISTNET_PN2_ABI_VERSION). */
 ISTNET_PN2_API int istnet_pn2_abi_version(void);
-/* Tuning knobs (process-wide, for benchmarking only): key 0 = minimum FPS slot count that uses the
- * 4-wave kernel (default 1025). */
+/* Process-wide knobs.  key 0 = minimum FPS slot count that uses the 4-wave kernel (1..1025, default 1025;
+ * benchmarking only).  key 1 = convention of the index-deciding squared distances of FPS / ball query /
+ * three_nn: 0 (default) un-contracted ((dx*dx + dy*dy) + dz*dz); 1 fma(dz,dz,fma(dx,dx,dy*dy)); 2
+ * fma(dz,dz,fma(dy,dy,dx*dx)) -- the forms a reference build with nvcc's default -fmad=true may use
+ * (profiles/r02_fma_convention_flips.txt).  Out-of-range values: ISTNET_PN2_EINVAL. */
 ISTNET_PN2_API int istnet_pn2_set_tuning(int key, int value);
 /* Debug aid: enqueue a one-thread kernel that stores the GPU's 100 MHz wall clock into *slot (device memory)
  * when `stream` reaches this point -- used to draw the timeline of a captured step (tools/step_timeline.py). */

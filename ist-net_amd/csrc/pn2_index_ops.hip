@@ -19,9 +19,12 @@
 //     accumulator per (cloud, channel) row, written back once -- no global
 //     atomics, no pre-zeroed output needed.
 //
-// Arithmetic convention for index-deciding distances: IEEE f32, source order of
-// the reference expression, NO FMA contraction (file-wide pragma below + the
-// -ffp-contract=off build flag), shared with oracle/pn2_oracle.c.
+// Arithmetic convention for index-deciding distances (shared with oracle/pn2_oracle.c):
+// IEEE f32 in the source order of the reference expression.  Convention 0 (default): NO FMA contraction
+// (file-wide pragma below + the -ffp-contract=off build flag).  Conventions 1 and 2 are the two ways a compiler
+// with contraction on (nvcc's default -fmad=true) can fuse  dx*dx + dy*dy + dz*dz :
+//     1:  fma(dz, dz, fma(dx, dx, dy*dy))        2:  fma(dz, dz, fma(dy, dy, dx*dx))
+// selected at run time with istnet_pn2_set_tuning(1, c) -- explicit fmaf calls, so the build flags stay as they are.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -35,17 +38,31 @@ constexpr int kWave = 64;
 
 __device__ __forceinline__ int lane_id() { return threadIdx.x & (kWave - 1); }
 
-// d2 in the reference's source order ((dx*dx + dy*dy) + dz*dz), un-contracted.
-__device__ __forceinline__ float sqdist(float ax, float ay, float az, float bx, float by, float bz) {
-  const float dx = ax - bx, dy = ay - by, dz = az - bz;
+// d2 in the reference's source order ((dx*dx + dy*dy) + dz*dz): un-contracted (CONV 0) or with the products
+// fused the way a contracting compiler would (CONV 1 / 2, see the header).
+template <int CONV>
+__device__ __forceinline__ float sqdist_d(float dx, float dy, float dz) {
+  if (CONV == 1) return __builtin_fmaf(dz, dz, __builtin_fmaf(dx, dx, dy * dy));
+  if (CONV == 2) return __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
   return (dx * dx + dy * dy) + dz * dz;
+}
+template <int CONV>
+__device__ __forceinline__ float sqdist(float ax, float ay, float az, float bx, float by, float bz) {
+  return sqdist_d<CONV>(ax - bx, ay - by, az - bz);
 }
 
 // Two points per instruction: v_pk_add_f32 / v_pk_mul_f32 round each half exactly like the scalar ops
 // (IEEE RN, no fusion), so the packed distance is bit-identical to sqdist() and halves the VALU work.
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+template <int CONV>
 __device__ __forceinline__ f32x2 sqdist2(f32x2 ax, f32x2 ay, f32x2 az, float bx, float by, float bz) {
   const f32x2 dx = ax - bx, dy = ay - by, dz = az - bz;
+  if (CONV != 0) {
+    f32x2 r;
+    r[0] = sqdist_d<CONV>(dx[0], dy[0], dz[0]);
+    r[1] = sqdist_d<CONV>(dx[1], dy[1], dz[1]);
+    return r;
+  }
   return (dx * dx + dy * dy) + dz * dz;
 }
 
@@ -95,7 +112,7 @@ __device__ __forceinline__ int tiekey_to_k(unsigned tk, int bs_log2, int nper) {
   return (int)(slot + (row << bs_log2));
 }
 
-template <int NW, int PPT>
+template <int NW, int PPT, int CONV>
 __global__ __launch_bounds__(NW * 64) void fps_regs_kernel(int n, int m, int bs_log2, int nper,
                                                            const float* __restrict__ dataset_all,
                                                            int* __restrict__ idxs_all,
@@ -137,7 +154,7 @@ __global__ __launch_bounds__(NW * 64) void fps_regs_kernel(int n, int m, int bs_
     int besti = 0;
 #pragma unroll
     for (int i = 0; i < PP; ++i) {
-      const f32x2 d = sqdist2(px[i], py[i], pz[i], x1, y1, z1);
+      const f32x2 d = sqdist2<CONV>(px[i], py[i], pz[i], x1, y1, z1);
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
         if (2 * i + h < PPT) {
@@ -179,6 +196,7 @@ __global__ __launch_bounds__(NW * 64) void fps_regs_kernel(int n, int m, int bs_
 
 // Generic fallback for very large clouds (n > 4096): running distances live in
 // `temp` (global), xyz read from global/L2.  Same winner rule.
+template <int CONV>
 __global__ __launch_bounds__(1024) void fps_generic_kernel(int n, int m, int bs_log2, int nper,
                                                            const float* __restrict__ dataset_all,
                                                            float* __restrict__ temp_all,
@@ -202,7 +220,7 @@ __global__ __launch_bounds__(1024) void fps_generic_kernel(int n, int m, int bs_
     for (unsigned tk = tid; tk < ntk; tk += THREADS) {  // ascending tiekey per thread
       const int k = tiekey_to_k(tk, bs_log2, nper);
       if (k < n) {
-        const float d = sqdist(dataset[3 * k + 0], dataset[3 * k + 1], dataset[3 * k + 2], x1, y1, z1);
+        const float d = sqdist<CONV>(dataset[3 * k + 0], dataset[3 * k + 1], dataset[3 * k + 2], x1, y1, z1);
         const float d2 = fminf(d, temp[k]);
         temp[k] = d2;
         if (d2 > best) { best = d2; besttk = tk; }
@@ -244,7 +262,7 @@ __global__ void gather_points_kernel(int c, int n, int m, const float* __restric
 constexpr int kBqWaves = 4;            // waves per workgroup
 constexpr int kBqCentroidsPerWave = 4;  // centroids handled sequentially by one wave
 
-template <bool LDS_XYZ>
+template <bool LDS_XYZ, int CONV>
 __global__ __launch_bounds__(kBqWaves * 64) void ball_query_kernel(
     int n, int m, float radius2, int nsample, const float* __restrict__ new_xyz_all,
     const float* __restrict__ xyz_all, int* __restrict__ idx_all) {
@@ -276,7 +294,7 @@ __global__ __launch_bounds__(kBqWaves * 64) void ball_query_kernel(
         float x, y, z;
         if (LDS_XYZ) { x = bq_lds[k]; y = bq_lds[n + k]; z = bq_lds[2 * n + k]; }
         else { x = xyz[3 * k + 0]; y = xyz[3 * k + 1]; z = xyz[3 * k + 2]; }
-        hit = sqdist(cx, cy, cz, x, y, z) < radius2;
+        hit = sqdist<CONV>(cx, cy, cz, x, y, z) < radius2;
       }
       const unsigned long long mask = __ballot(hit);
       if (mask) {
@@ -595,6 +613,7 @@ __global__ __launch_bounds__(256) void scatter_add_global_kernel(
 // ============================================================================
 constexpr int kNnTile = 2048;  // known points staged per LDS tile (24 KB)
 
+template <int CONV>
 __global__ __launch_bounds__(256) void three_nn_kernel(int n, int m,
                                                        const float* __restrict__ unknown_all,
                                                        const float* __restrict__ known_all,
@@ -619,7 +638,7 @@ __global__ __launch_bounds__(256) void three_nn_kernel(int n, int m,
     __syncthreads();
     if (active) {
       for (int kk = 0; kk < cntk; ++kk) {
-        const float d = sqdist(ux, uy, uz, kn[3 * kk + 0], kn[3 * kk + 1], kn[3 * kk + 2]);
+        const float d = sqdist<CONV>(ux, uy, uz, kn[3 * kk + 0], kn[3 * kk + 1], kn[3 * kk + 2]);
         const int k = base + kk;
         if (d < best1) {
           best3 = best2; besti3 = besti2;
@@ -667,6 +686,14 @@ __global__ __launch_bounds__(256) void three_interpolate_kernel(int c, int m, in
   }
 }
 
+int g_dist_conv = 0;  // distance convention (file header); istnet_pn2_set_tuning key 1
+// expands LAUNCH three times with CONV_ = 0, 1, 2 and runs the one g_dist_conv selects
+#define ISTNET_CONV_DISPATCH(LAUNCH)                                           \
+  do {                                                                         \
+    if (g_dist_conv == 1) { constexpr int CONV_ = 1; LAUNCH; }                 \
+    else if (g_dist_conv == 2) { constexpr int CONV_ = 2; LAUNCH; }            \
+    else { constexpr int CONV_ = 0; LAUNCH; }                                  \
+  } while (0)
 int g_fps_multiwave_min = 1025;  // tuning knob (istnet_pn2_set_tuning); measured: 1 wave wins up to 1024 points
 inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 inline int ilog2_floor(int v) { int r = 0; while ((1 << (r + 1)) <= v) ++r; return r; }
@@ -708,9 +735,9 @@ int launch_fps_regs(int b, int n, int m, int bs_log2, int nper, const float* dat
                     float* picked, hipStream_t st) {
   const int ppt = ceil_div(nper << bs_log2, NW * 64);  // tiekey slots per thread (holes included)
   const size_t lds = (size_t)3 * n * 4 + (NW > 1 ? 2 * NW * 2 * 4 : 0);
-#define ISTNET_FPS_CASE(P)                                                                      \
-  hipLaunchKernelGGL((fps_regs_kernel<NW, P>), dim3(b), dim3(NW * 64), lds, st, n, m, bs_log2,  \
-                     nper, dataset, idxs, picked)
+#define ISTNET_FPS_CASE(P)                                                                          \
+  ISTNET_CONV_DISPATCH(hipLaunchKernelGGL((fps_regs_kernel<NW, P, CONV_>), dim3(b), dim3(NW * 64), lds, st, n, m, \
+                                          bs_log2, nper, dataset, idxs, picked))
   if (ppt <= 1) ISTNET_FPS_CASE(1);
   else if (ppt <= 2) ISTNET_FPS_CASE(2);
   else if (ppt <= 4) ISTNET_FPS_CASE(4);
@@ -734,7 +761,10 @@ int istnet_debug_marker(unsigned long long* slot, void* stream) {
   return (int)hipGetLastError();
 }
 int istnet_pn2_set_tuning(int key, int value) {
-  if (key == 0) { g_fps_multiwave_min = value; return 0; }
+  // key 0: tiekey-slot count from which FPS uses four waves per cloud; one wave holds at most 16 slots per lane
+  if (key == 0) { if (value < 1 || value > 1025) return ISTNET_PN2_EINVAL; g_fps_multiwave_min = value; return 0; }
+  // key 1: distance convention of FPS / ball query / three_nn (0 un-contracted, 1 / 2 FMA-contracted; file header)
+  if (key == 1) { if (value < 0 || value > 2) return ISTNET_PN2_EINVAL; g_dist_conv = value; return 0; }
   return ISTNET_PN2_EINVAL;
 }
 const char* istnet_pn2_target(void) { return "gfx950"; }
@@ -754,8 +784,8 @@ static int fps_impl(int b, int n, int m, const float* dataset, float* temp, int*
   if (slots < g_fps_multiwave_min) return launch_fps_regs<1>(b, n, m, bs_log2, nper, dataset, idxs, picked, st);
   if (slots <= 256 * 16) return launch_fps_regs<4>(b, n, m, bs_log2, nper, dataset, idxs, picked, st);
   if (temp == nullptr || picked != nullptr) return ISTNET_PN2_EINVAL;  // large clouds: scratch buffer, no fused gather
-  hipLaunchKernelGGL(fps_generic_kernel, dim3(b), dim3(1024), 0, st, n, m, bs_log2, nper, dataset,
-                     temp, idxs);
+  ISTNET_CONV_DISPATCH(hipLaunchKernelGGL(fps_generic_kernel<CONV_>, dim3(b), dim3(1024), 0, st, n, m, bs_log2, nper,
+                                          dataset, temp, idxs));
   return (int)hipGetLastError();
 }
 
@@ -793,11 +823,11 @@ int istnet_pn2_query_ball_point(int b, int n, int m, float radius, int nsample,
   const dim3 grid(ceil_div(m, kBqWaves * kBqCentroidsPerWave), b);
   const size_t lds = (size_t)3 * n * 4;
   if (lds <= 64 * 1024) {
-    hipLaunchKernelGGL(ball_query_kernel<true>, grid, dim3(kBqWaves * 64), lds, as_stream(stream),
-                       n, m, radius2, nsample, new_xyz, xyz, idx);
+    ISTNET_CONV_DISPATCH(hipLaunchKernelGGL((ball_query_kernel<true, CONV_>), grid, dim3(kBqWaves * 64), lds,
+                                            as_stream(stream), n, m, radius2, nsample, new_xyz, xyz, idx));
   } else {
-    hipLaunchKernelGGL(ball_query_kernel<false>, grid, dim3(kBqWaves * 64), 0, as_stream(stream),
-                       n, m, radius2, nsample, new_xyz, xyz, idx);
+    ISTNET_CONV_DISPATCH(hipLaunchKernelGGL((ball_query_kernel<false, CONV_>), grid, dim3(kBqWaves * 64), 0,
+                                            as_stream(stream), n, m, radius2, nsample, new_xyz, xyz, idx));
   }
   return (int)hipGetLastError();
 }
@@ -832,8 +862,8 @@ int istnet_pn2_three_nn(int b, int n, int m, const float* unknown, const float* 
                         int* idx, void* stream) {
   if (b < 0 || n < 0 || m < 0) return ISTNET_PN2_EINVAL;
   if (b == 0 || n == 0) return 0;
-  hipLaunchKernelGGL(three_nn_kernel, dim3(ceil_div(n, 256), b), dim3(256), 0, as_stream(stream), n,
-                     m, unknown, known, dist2, idx);
+  ISTNET_CONV_DISPATCH(hipLaunchKernelGGL(three_nn_kernel<CONV_>, dim3(ceil_div(n, 256), b), dim3(256), 0,
+                                          as_stream(stream), n, m, unknown, known, dist2, idx));
   return (int)hipGetLastError();
 }
 

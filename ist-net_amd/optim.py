@@ -124,11 +124,49 @@ class FlatAdam(torch.optim.Optimizer):
         self.flat.addcdiv_(self.exp_avg, denom, value=-self.lr / (1 - b1 ** t))
 
     def state_dict(self):
-        return {"flat": self.flat, "exp_avg": self.exp_avg, "exp_avg_sq": self.exp_avg_sq, "step": self.step_count,
-                "lr": self.lr, "betas": self.betas, "eps": self.eps, "weight_decay": self.weight_decay}
+        """The layout of ``torch.optim.Adam.state_dict()`` (what the reference's checkpoints hold, utils/solver.py
+        save_checkpoint): per-parameter ``step`` / ``exp_avg`` / ``exp_avg_sq`` -- copies of this parameter's slice of the
+        flat moment buffers (a snapshot: torch's ``load_state_dict`` keeps the tensors it is given when dtype and device
+        already match) -- plus ``param_groups``.  Weights are NOT part of an optimizer state."""
+        state = {}
+        for i, (p, o) in enumerate(zip(self.params, self.offsets)):
+            n = p.numel()
+            state[i] = {"step": self.step_count.detach().clone(),
+                        "exp_avg": self.exp_avg[o:o + n].view_as(p).clone(),
+                        "exp_avg_sq": self.exp_avg_sq[o:o + n].view_as(p).clone()}
+        group = {"lr": self.lr, "betas": self.betas, "eps": self.eps, "weight_decay": self.weight_decay,
+                 "amsgrad": False, "maximize": False, "foreach": None, "capturable": False, "differentiable": False,
+                 "fused": None, "decoupled_weight_decay": False, "params": list(range(len(self.params)))}
+        return {"state": state, "param_groups": [group]}
 
     def load_state_dict(self, sd):
-        self.flat.copy_(sd["flat"]); self.exp_avg.copy_(sd["exp_avg"]); self.exp_avg_sq.copy_(sd["exp_avg_sq"])
-        self.step_count.copy_(sd["step"])
-        self.lr = sd["lr"]
-        self.betas, self.eps, self.weight_decay = tuple(sd["betas"]), sd["eps"], sd["weight_decay"]
+        """Accepts ``torch.optim.Adam.state_dict()`` of an optimizer over the same parameters in the same order (and
+        this class's own).  Moments are copied into the flat buffers; the model's weights are left alone."""
+        groups = sd["param_groups"]
+        if len(groups) != 1:
+            raise ValueError("FlatAdam.load_state_dict: exactly one parameter group expected")
+        g = groups[0]
+        if len(g["params"]) != len(self.params):
+            raise ValueError(f"FlatAdam.load_state_dict: {len(g['params'])} parameters in the state, "
+                             f"{len(self.params)} in the optimizer")
+        if g.get("amsgrad", False) or g.get("maximize", False):
+            raise ValueError("FlatAdam.load_state_dict: amsgrad / maximize states are not supported")
+        steps = set()
+        for key, p, o in zip(g["params"], self.params, self.offsets):
+            st = sd["state"].get(key)
+            n = p.numel()
+            if st is None:                       # parameter never stepped: zero moments
+                self.exp_avg[o:o + n].zero_(); self.exp_avg_sq[o:o + n].zero_()
+                continue
+            if tuple(st["exp_avg"].shape) != tuple(p.shape):
+                raise ValueError(f"FlatAdam.load_state_dict: shape mismatch for parameter {key}: "
+                                 f"{tuple(st['exp_avg'].shape)} vs {tuple(p.shape)}")
+            self.exp_avg[o:o + n].copy_(st["exp_avg"].reshape(-1))
+            self.exp_avg_sq[o:o + n].copy_(st["exp_avg_sq"].reshape(-1))
+            steps.add(float(st["step"]))
+        if len(steps) > 1:
+            raise ValueError("FlatAdam.load_state_dict: parameters with different step counts cannot share one flat step")
+        self.step_count.fill_(steps.pop() if steps else 0.0)
+        self.lr = float(g["lr"])
+        self.betas, self.eps, self.weight_decay = tuple(g["betas"]), float(g["eps"]), float(g["weight_decay"])
+        self.param_groups[0].update(lr=self.lr, betas=self.betas, eps=self.eps, weight_decay=self.weight_decay)

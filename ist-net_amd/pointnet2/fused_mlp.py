@@ -147,8 +147,19 @@ def _enter_backward(dev):
 
 
 def _can_defer(params):
-    return (USE_DEFERRED_WGRAD and _native.TIMING is None and torch.is_grad_enabled() is False
-            and all(getattr(p, "grad", None) is None for p in params))
+    """Deferral is legal only while AccumulateGrad will just STORE the produced tensors.  A parameter with an
+    existing .grad, or one that another node of this pass already produced a gradient for (shared module: the
+    engine adds the two tensors on the main stream), forces the launches onto the current stream -- after the
+    current stream has waited for whatever the wgrad stream still holds of the earlier producer."""
+    if not (USE_DEFERRED_WGRAD and _native.TIMING is None and torch.is_grad_enabled() is False
+            and all(getattr(p, "grad", None) is None for p in params)):
+        return False
+    if any(_Claims.taken_by_other_node(p) for p in params):
+        for (key, _), wstream in _Deferred.streams.items():
+            if key in _Deferred.mains:
+                torch.cuda.current_stream().wait_stream(wstream)
+        return False
+    return True
 
 
 def _p(t):
@@ -322,15 +333,44 @@ def _ymax_ptr(arg, n):
     return None if arg is None else arg.data_ptr() + _arg_bytes(n)
 
 
+class _Claims:
+    """Parameters whose flat-gradient slot has been handed out during the current backward pass (autograd graph
+    task), and the autograd node that took it.  A slot may be written by ONE producer node per pass: when a module
+    runs twice in one graph (weight sharing, siamese use, loss = f(m(a)) + f(m(b))), ``param.grad`` is still None at
+    the second producer -- AccumulateGrad runs after all uses -- and the engine then sums the producers' outputs,
+    which must be distinct tensors."""
+    task = -2
+    owner = {}     # id(param) -> id of the backward node that produces its gradient in this pass
+
+    @classmethod
+    def _sync(cls):
+        task = torch._C._current_graph_task_id()
+        if task != cls.task:
+            cls.task, cls.owner = task, {}
+        return id(torch._C._current_autograd_node())
+
+    @classmethod
+    def taken_by_other_node(cls, param):
+        node = cls._sync()
+        return cls.owner.get(id(param), node) != node
+
+    @classmethod
+    def claim(cls, param):
+        """True when the calling node is (or becomes) the producer of this parameter's gradient in the current pass."""
+        node = cls._sync()
+        return cls.owner.setdefault(id(param), node) == node
+
+
 def _grad_dest(param, shape, dev):
     """Where the gradient of `param` is written: its slot of an optimizer's flat gradient buffer when one is
-    attached (optim.FlatAdam) and no gradient is accumulated yet, else a fresh tensor."""
+    attached (optim.FlatAdam), no gradient is accumulated yet and no other node of this backward pass took the
+    slot already; else a fresh tensor (which autograd then adds to the first producer's)."""
     slot = getattr(param, "_istnet_grad_slot", None)
     if slot is not None and param.grad is None and slot.device == dev:
         n = 1
         for d in shape:
             n *= d
-        if slot.numel() == n:
+        if slot.numel() == n and _Claims.claim(param):
             return slot.view(shape)
     return _empty(shape, torch.float32, dev)
 

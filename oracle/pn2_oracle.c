@@ -16,7 +16,9 @@
  *
  * Arithmetic convention (shared with the HIP kernels): IEEE-754 binary32,
  * round-to-nearest-even, operations in SOURCE ORDER, NO fused multiply-add
- * contraction.  Build with -ffp-contract=off (see oracle/Makefile).
+ * contraction by default.  Build with -ffp-contract=off (see oracle/Makefile); the
+ * two FMA-contracted variants a CUDA build may use instead are explicit fmaf calls
+ * selected with oracle_set_convention() (see g_conv below).
  *
  * All functions are batch-parallel with OpenMP when built with -fopenmp; the
  * per-cloud arithmetic is unchanged by that.
@@ -26,7 +28,40 @@
 #include <stdlib.h>
 #include <string.h>
 
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
 #define ORACLE_API __attribute__((visibility("default")))
+
+/* Distance convention of the index-deciding squared distances (FPS, ball query, three_nn).
+ *   0 (default)  ((dx*dx + dy*dy) + dz*dz), every operation rounded: the convention the product and the
+ *                golden vectors use.
+ *   1            fmaf(dz, dz, fmaf(dx, dx, dy*dy))   } the two ways a contracting compiler (nvcc's default
+ *   2            fmaf(dz, dz, fmaf(dy, dy, dx*dx))   } -fmad=true) can fuse the reference expression
+ * 1 and 2 exist to MEASURE how many index decisions depend on the choice (tools/fma_flip_table.py,
+ * profiles/r02_fma_convention_flips.txt) and to keep the HIP kernels checked under each of them. */
+static int g_conv = 0;
+ORACLE_API int oracle_set_convention(int c) {
+  if (c < 0 || c > 2) return -1;
+  g_conv = c;
+  return 0;
+}
+ORACLE_API int oracle_get_convention(void) { return g_conv; }
+static inline float sqdist_d(float dx, float dy, float dz) {
+  if (g_conv == 1) return fmaf(dz, dz, fmaf(dx, dx, dy * dy));
+  if (g_conv == 2) return fmaf(dz, dz, fmaf(dy, dy, dx * dx));
+  return (dx * dx + dy * dy) + dz * dz;
+}
+
+/* OpenMP team size of the batch-parallel loops (cpu_baseline thread sweep); 0 = runtime default */
+ORACLE_API void oracle_set_threads(int n) {
+#ifdef _OPENMP
+  if (n > 0) omp_set_num_threads(n);
+#else
+  (void)n;
+#endif
+}
 
 /* include/cuda_utils.h:18-22  opt_n_threads: clamp(2^floor(log2 w), 1, 512) */
 ORACLE_API int oracle_opt_n_threads(int work_size) {
@@ -98,9 +133,9 @@ ORACLE_API void oracle_furthest_point_sampling(int b, int n, int m,
           const float x2 = dataset[k * 3 + 0];
           const float y2 = dataset[k * 3 + 1];
           const float z2 = dataset[k * 3 + 2];
-          /* :108-109, source order, no contraction */
+          /* :108-109, source order; contraction per g_conv (default none) */
           const float dx = x2 - x1, dy = y2 - y1, dz = z2 - z1;
-          const float d = (dx * dx + dy * dy) + dz * dz;
+          const float d = sqdist_d(dx, dy, dz);
           const float d2 = d < temp[k] ? d : temp[k]; /* min(d, temp[k]) :111 */
           temp[k] = d2;
           besti = d2 > best ? k : besti;
@@ -146,7 +181,7 @@ ORACLE_API void oracle_query_ball_point(int b, int n, int m, float radius,
         const float y = xyz[k * 3 + 1];
         const float z = xyz[k * 3 + 2];
         const float dx = new_x - x, dy = new_y - y, dz = new_z - z;
-        const float d2 = (dx * dx + dy * dy) + dz * dz; /* :36-37 */
+        const float d2 = sqdist_d(dx, dy, dz);          /* :36-37 */
         if (d2 < radius2) {                             /* :38 strict */
           if (cnt == 0)
             for (int l = 0; l < nsample; ++l) idx[j * nsample + l] = k;
@@ -215,7 +250,7 @@ ORACLE_API void oracle_three_nn(int b, int n, int m, const float *unknown_all,
         const float y = known[k * 3 + 1];
         const float z = known[k * 3 + 2];
         const float dx = ux - x, dy = uy - y, dz = uz - z;
-        const float d = (dx * dx + dy * dy) + dz * dz; /* :38 */
+        const float d = sqdist_d(dx, dy, dz); /* :38 */
         if (d < best1) {
           best3 = best2; besti3 = besti2;
           best2 = best1; besti2 = besti1;

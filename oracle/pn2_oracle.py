@@ -62,6 +62,20 @@ def _chk_i(t, name):
     _check(t.device.type == "cpu", f"oracle: {name} must be a CPU tensor")
 
 
+def set_convention(c):
+    """Distance convention of FPS / ball query / three_nn: 0 un-contracted (default; what the product and the golden
+    vectors use), 1 / 2 the FMA-contracted forms (see pn2_oracle.c).  Returns the previous value."""
+    prev = lib().oracle_get_convention()
+    if lib().oracle_set_convention(int(c)) != 0:
+        raise ValueError(f"oracle: unknown distance convention {c}")
+    return prev
+
+
+def set_threads(n):
+    """OpenMP team size of the oracle's batch-parallel loops (cpu_baseline thread sweep)."""
+    lib().oracle_set_threads(int(n))
+
+
 def opt_n_threads(work_size):
     return lib().oracle_opt_n_threads(int(work_size))
 

@@ -223,3 +223,43 @@ def test_index_ops_random_shapes_bit_exact(ext, oracle):
         d_want, i_want = oracle.three_nn(centers, xyz)
         assert torch.equal(i_got.cpu(), i_want), tag
         assert torch.equal(d_got.cpu().view(torch.int32), d_want.view(torch.int32)), tag
+
+
+@pytest.mark.parametrize("conv", [1, 2])
+def test_index_ops_bit_exact_under_fma_conventions(ext, oracle, conv):
+    """The index-deciding distances are un-contracted by default; a reference build with nvcc's
+    default -fmad=true may fuse them.  Under each of the two contracted forms (oracle.set_convention /
+    istnet_pn2_set_tuning(1, c)) the HIP kernels stay bit-exact against the oracle -- including dist2 of three_nn,
+    18 % of whose values change in the last bit -- on the clouds where tools/fma_flip_table.py finds flips
+    (config-2 cube) and on tie-heavy inputs."""
+    from istnet_amd import _native
+    lib = _native.lib()
+    assert lib.istnet_pn2_set_tuning(1, 3) != 0 and lib.istnet_pn2_set_tuning(0, 2000) != 0   # validated knobs
+    g = torch.Generator().manual_seed(0)
+    cube = torch.rand(32, 1024, 3, generator=g) * 0.2 - 0.1
+    cases = [(cube - cube.mean(1, keepdim=True)).contiguous(), _cloud(4, 1024, 3, "shell"), _cloud(2, 1024, 5, "dup"),
+             _cloud(2, 1000, 6, "grid"), _cloud(1, 2048, 7, "cube", 0.3), _cloud(1, 5000, 8, "cube")]
+    base = {}
+    for ci, xyz in enumerate(cases):
+        base[ci] = oracle.furthest_point_sampling(xyz, min(512, xyz.shape[1] // 2))
+    prev = oracle.set_convention(conv)
+    assert lib.istnet_pn2_set_tuning(1, conv) == 0
+    try:
+        changed = 0
+        for ci, xyz in enumerate(cases):
+            b, n, _ = xyz.shape
+            m = min(512, n // 2)
+            fps = oracle.furthest_point_sampling(xyz, m)
+            changed += int((fps != base[ci]).sum())
+            assert torch.equal(ext.furthest_point_sampling(xyz.to(DEV), m).cpu(), fps)
+            new_xyz = torch.gather(xyz, 1, fps.long().unsqueeze(-1).expand(b, m, 3)).contiguous()
+            for radius, ns in ((0.02, 16), (0.04, 32), (0.25, 8)):
+                want = oracle.ball_query(new_xyz, xyz, radius, ns)
+                assert torch.equal(ext.ball_query(new_xyz.to(DEV), xyz.to(DEV), radius, ns).cpu(), want)
+            d_want, i_want = oracle.three_nn(xyz, new_xyz)
+            d_got, i_got = ext.three_nn(xyz.to(DEV), new_xyz.to(DEV))
+            assert torch.equal(i_got.cpu(), i_want) and torch.equal(d_got.cpu(), d_want)
+        assert changed > 0    # the convention is really in effect: the cube cloud has FPS picks that depend on it
+    finally:
+        oracle.set_convention(prev)
+        assert lib.istnet_pn2_set_tuning(1, 0) == 0

@@ -168,3 +168,108 @@ def test_flat_adam_works_with_torch_lr_schedulers():
         torch.testing.assert_close(q, p, rtol=1e-5, atol=1e-7)
     with pytest.raises(ValueError):
         FlatAdam([{"params": list(b.parameters())}])
+
+
+def test_flat_adam_state_dict_round_trips_with_torch_adam():
+    """FlatAdam.state_dict() has torch.optim.Adam's layout (the reference checkpoints hold optimizer.state_dict() of
+    torch Adam, utils/solver.py): a torch Adam loads ours, ours loads torch's, training continues identically, and
+    loading an optimizer state never touches the weights."""
+    a, b = _models()
+    ref = torch.optim.Adam(a.parameters(), lr=1e-2, weight_decay=0.01)
+    opt = FlatAdam(b.parameters(), lr=1e-2, weight_decay=0.01)
+    g = torch.Generator().manual_seed(7)
+
+    def steps(pairs, n):
+        for _ in range(n):
+            x = torch.randn(4, 5, generator=g)
+            for m, o in pairs:
+                o.zero_grad(set_to_none=True)
+                m(x).square().mean().backward()
+                o.step()
+
+    steps(((a, ref), (b, opt)), 3)
+    sd_ref, sd_opt = ref.state_dict(), opt.state_dict()
+    assert set(sd_opt) == {"state", "param_groups"} and set(sd_opt["state"]) == set(sd_ref["state"])
+    for k in sd_ref["state"]:
+        assert set(sd_opt["state"][k]) == set(sd_ref["state"][k])
+        for name in ("exp_avg", "exp_avg_sq"):
+            torch.testing.assert_close(sd_opt["state"][k][name], sd_ref["state"][k][name], rtol=1e-5, atol=1e-9)
+        assert float(sd_opt["state"][k]["step"]) == float(sd_ref["state"][k]["step"]) == 3.0
+    assert sd_opt["param_groups"][0]["params"] == sd_ref["param_groups"][0]["params"]
+    # cross-load: fresh optimizers of each kind resume from the other kind's state
+    a2, b2 = _models()
+    a2.load_state_dict(a.state_dict()); b2.load_state_dict(b.state_dict())
+    ref2 = torch.optim.Adam(a2.parameters(), lr=5e-1)
+    opt2 = FlatAdam(b2.parameters(), lr=5e-1)
+    weights_before = opt2.flat.clone()
+    ref2.load_state_dict(sd_opt)
+    opt2.load_state_dict(sd_ref)
+    assert torch.equal(opt2.flat, weights_before)                     # an optimizer state carries no weights
+    assert opt2.lr == 1e-2 and opt2.weight_decay == 0.01 and int(opt2.step_count) == 3
+    steps(((a, ref), (b, opt), (a2, ref2), (b2, opt2)), 2)
+    for p, q, r, s in zip(a.parameters(), b.parameters(), a2.parameters(), b2.parameters()):
+        torch.testing.assert_close(q, p, rtol=1e-5, atol=1e-7)
+        torch.testing.assert_close(r, p, rtol=1e-5, atol=1e-7)
+        torch.testing.assert_close(s, p, rtol=1e-5, atol=1e-7)
+    with pytest.raises(ValueError):
+        FlatAdam(list(b.parameters())[:2], lr=1e-2).load_state_dict(sd_ref)
+
+
+@pytest.mark.gpu
+def test_shared_module_used_twice_in_one_graph_under_flat_adam():
+    """A fused module applied twice in ONE autograd graph (siamese use): both backward nodes see ``param.grad is
+    None``; only the first may take the parameter's slot of the flat gradient buffer, the engine adds the second
+    producer's tensor.  Three optimizer steps against torch.optim.Adam on an identical copy."""
+    from istnet_amd.modules import PointNet2MSG
+    from istnet_amd.pointnet2.pointnet2_modules import PointnetFPModule, PointnetSAModuleMSG
+
+    def make():
+        torch.manual_seed(0)
+        sa = PointnetSAModuleMSG(npoint=64, radii=[0.2, 0.4], nsamples=[16, 32], mlps=[[16, 32, 32], [16, 32, 64]])
+        fp = PointnetFPModule(mlp=[96 + 16, 64, 32])
+        return torch.nn.ModuleList([sa, fp]).cuda().train()
+
+    g = torch.Generator().manual_seed(3)
+    clouds = [(torch.rand(2, 256, 3, generator=g).cuda(), torch.randn(2, 16, 256, generator=g).cuda()) for _ in range(2)]
+
+    def loss_of(model):
+        total = 0.0
+        for xyz, feat in clouds:                       # the same modules twice in one graph
+            nx, nf = model[0](xyz, feat)
+            total = total + model[1](xyz, nx, feat, nf).square().mean()
+        return total
+
+    ref, model = make(), make()
+    ref_opt = torch.optim.Adam(ref.parameters(), lr=1e-3)
+    opt = FlatAdam(model.parameters(), lr=1e-3)
+    for it in range(3):
+        for m, o in ((ref, ref_opt), (model, opt)):
+            o.zero_grad(set_to_none=True)
+            loss_of(m).backward()
+        torch.cuda.synchronize()
+        if it == 0:
+            for (name, p), q in zip(model.named_parameters(), ref.parameters()):
+                torch.testing.assert_close(p.grad, q.grad, rtol=2e-4, atol=1e-6, msg=lambda s: f"{name}: {s}")
+        ref_opt.step(); opt.step()
+    for p, q in zip(model.parameters(), ref.parameters()):
+        torch.testing.assert_close(p, q, rtol=1e-4, atol=2e-6)
+
+    # the whole encoder, siamese, against two separate single-use backward passes summed
+    torch.manual_seed(1)
+    enc = PointNet2MSG([[0.05, 0.1], [0.1, 0.2], [0.2, 0.4], [0.4, 0.8]]).cuda().train()
+    pts = [torch.rand(2, 1024, 3, generator=g).cuda() - 0.5 for _ in range(2)]
+    state = {k: v.clone() for k, v in enc.state_dict().items()}
+    want = None
+    for x in pts:
+        enc.load_state_dict(state)
+        enc.zero_grad(set_to_none=True)
+        enc(x).square().mean().backward()
+        grads = [p.grad.clone() for p in enc.parameters()]
+        want = grads if want is None else [a + b for a, b in zip(want, grads)]
+    enc.load_state_dict(state)
+    enc_opt = FlatAdam(enc.parameters(), lr=1e-3)
+    enc_opt.zero_grad(set_to_none=True)
+    (enc(pts[0]).square().mean() + enc(pts[1]).square().mean()).backward()
+    torch.cuda.synchronize()
+    for (name, p), w in zip(enc.named_parameters(), want):
+        torch.testing.assert_close(p.grad, w, rtol=2e-4, atol=1e-6, msg=lambda s: f"{name}: {s}")
