@@ -243,16 +243,20 @@ def test_shared_module_used_twice_in_one_graph_under_flat_adam():
     ref_opt = torch.optim.Adam(ref.parameters(), lr=1e-3)
     opt = FlatAdam(model.parameters(), lr=1e-3)
     for it in range(3):
+        ref.load_state_dict(model.state_dict())        # same weights and BN buffers going into the step
         for m, o in ((ref, ref_opt), (model, opt)):
             o.zero_grad(set_to_none=True)
             loss_of(m).backward()
         torch.cuda.synchronize()
-        if it == 0:
-            for (name, p), q in zip(model.named_parameters(), ref.parameters()):
-                torch.testing.assert_close(p.grad, q.grad, rtol=2e-4, atol=1e-6, msg=lambda s: f"{name}: {s}")
+        for (name, p), q in zip(model.named_parameters(), ref.parameters()):
+            torch.testing.assert_close(p.grad, q.grad, rtol=2e-4, atol=1e-6, msg=lambda s: f"step {it} {name}: {s}")
+        # Adam divides by sqrt(v): parameters whose gradient is rounding noise (a conv weight's scale under train-mode
+        # BN) would amplify 1e-7 differences to lr-sized ones, so the update itself is checked on IDENTICAL gradients
+        for p, q in zip(model.parameters(), ref.parameters()):
+            q.grad = p.grad.detach().clone()
         ref_opt.step(); opt.step()
-    for p, q in zip(model.parameters(), ref.parameters()):
-        torch.testing.assert_close(p, q, rtol=1e-4, atol=2e-6)
+        for (name, p), q in zip(model.named_parameters(), ref.parameters()):
+            torch.testing.assert_close(p, q, rtol=1e-5, atol=1e-7, msg=lambda s: f"step {it} {name}: {s}")
 
     # the whole encoder, siamese, against two separate single-use backward passes summed
     torch.manual_seed(1)
