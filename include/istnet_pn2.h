@@ -39,7 +39,8 @@ ISTNET_PN2_API int istnet_pn2_abi_version(void);
  * benchmarking only).  key 1 = convention of the index-deciding squared distances of FPS / ball query /
  * three_nn: 0 (default) un-contracted ((dx*dx + dy*dy) + dz*dz); 1 fma(dz,dz,fma(dx,dx,dy*dy)); 2
  * fma(dz,dz,fma(dy,dy,dx*dx)) -- the forms a reference build with nvcc's default -fmad=true may use
- * (profiles/r02_fma_convention_flips.txt).  Out-of-range values: ISTNET_PN2_EINVAL. */
+ * (profiles/r02_fma_convention_flips.txt).  key 2 = 1: inverse lists by the one-workgroup-per-cloud
+ * kernels (A/B and tests).  Out-of-range values: ISTNET_PN2_EINVAL. */
 ISTNET_PN2_API int istnet_pn2_set_tuning(int key, int value);
 /* Debug aid: enqueue a one-thread kernel that stores the GPU's 100 MHz wall clock into *slot (device memory)
  * when `stream` reaches this point -- used to draw the timeline of a captured step (tools/step_timeline.py). */
@@ -107,6 +108,13 @@ ISTNET_PN2_API int istnet_pn2_interp_csr_build(int b, int n, int m, const int *i
  * atomic-free layer-0 gradient scatter, istnet_pw_scatter_dy_csr. */
 ISTNET_PN2_API int istnet_pn2_csr_build(int b, int e, int m, const int *idx, int *offsets, int *entries,
                                         void *stream);
+/* nprob (<= 12) independent list builds over the same batch size in ONE launch (e.g. the ball-query and three_nn
+ * index tensors of every level of an encoder pass): problem l has e[l] slots per cloud with keys in [0, m[l]).
+ * A workgroup owns 64 consecutive keys of one cloud (grid = b * sum ceil(m[l] / 64)); no atomics; the lists are
+ * identical to istnet_pn2_csr_build's.  ISTNET_PN2_EINVAL when a problem's slots do not fit the LDS queue
+ * (e[l] > ~15000): build that one with istnet_pn2_csr_build. */
+ISTNET_PN2_API int istnet_pn2_csr_build_multi(int nprob, int b, const int *e, const int *m, const int *const *idx,
+                                              int *const *offsets, int *const *entries, void *stream);
 ISTNET_PN2_API int istnet_pn2_three_interpolate_grad_csr(int b, int c, int n, int m, const float *grad_out,
                                                          const float *weight, const int *offsets,
                                                          const int *entries, float *grad_points, void *stream);

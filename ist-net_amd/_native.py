@@ -18,6 +18,7 @@ _i, _f, _p, _d, _l = ctypes.c_int, ctypes.c_float, ctypes.c_void_p, ctypes.c_dou
 # name -> argtypes (restype is always int); mirrors include/istnet_pn2.h
 SIGNATURES = {
     "istnet_pn2_csr_build": [_i, _i, _i, _p, _p, _p, _p],
+    "istnet_pn2_csr_build_multi": [_i, _i, _p, _p, _p, _p, _p, _p],
     "istnet_pw_scatter_csr_chunks": [_i],
     "istnet_pw_scatter_dy_csr": [_i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _l, _p, _p, _i, _p, _p],
     "istnet_adam_step": [_l, _p, _p, _p, _p, _p, _p, _d, _d, _d, _d, _d, _d, _p],

@@ -511,6 +511,158 @@ __global__ __launch_bounds__(256) void csr_build_lds_kernel(int E, int m, const 
   for (int i = tid; i <= m; i += 256) off_all[(size_t)b * (m + 1) + i] = off[i];
 }
 
+// ---- inverse lists, key-range decomposition: the default build ------------------------------------------------
+// csr_build_lds_kernel above runs ONE workgroup per cloud with a 256-iteration rank loop per thread per round
+// (grid = B = 32 on a 256-CU chip: 8 % of all kernel time of a training step in round 1).  Here a workgroup owns a
+// RANGE of 16..64 keys (source points) of one cloud, so a launch has B * ceil(m / range) workgroups and needs no atomics,
+// no sort and no communication between workgroups:
+//   phase 1  every workgroup scans all E slots of its cloud (L2-resident, coalesced); each of its four waves takes a
+//            contiguous quarter of the slots and appends the ones whose key is in the range to a wave-private LDS
+//            queue with __ballot / mbcnt ordered compaction -- the queue is in ascending slot order -- and counts the
+//            slots with a smaller key (their total is where the range's first list starts);
+//   phase 2  each wave counts the keys of its own queue (lane k holds key k's counter), the four waves' counts are
+//            exchanged through LDS (one barrier), a 64-lane scan turns the list lengths into offsets, and a second
+//            pass over the queue writes the entries.  Lists come out in ascending slot order by construction: the
+//            summation order of the serial reference loops, bit-identical to the kernels above.
+// Several independent problems (the ball-query and three_nn index tensors of all levels of an encoder pass) share one
+// launch through a descriptor table.
+constexpr int kCsrKeys = 64;
+constexpr int kCsrMaxProblems = 12;
+struct CsrProblem {
+  const int* idx;   // (B, E) keys in [0, m)
+  int* off;         // (B, m + 1)
+  int* ent;         // (B, E)
+  int E, m, ranges, block_begin, qcap, kr;   // kr = keys per workgroup (16 / 32 / 64)
+};
+struct CsrBatch {
+  CsrProblem p[kCsrMaxProblems];
+  int n;
+};
+__global__ __launch_bounds__(256) void csr_range_kernel(CsrBatch cb) {
+  extern __shared__ __attribute__((aligned(16))) int csr_lds[];   // queue[4][qcap] | cnt[4][64] | less[4]
+  int l = 0;
+  while (l + 1 < cb.n && (int)blockIdx.x >= cb.p[l + 1].block_begin) ++l;
+  const CsrProblem& P = cb.p[l];
+  const int local = (int)blockIdx.x - P.block_begin;
+  const int b = local / P.ranges, r = local - b * P.ranges;
+  const int KR = P.kr;
+  const int k0 = r * KR, E = P.E, m = P.m, qcap = P.qcap;
+  const int* idx = P.idx + (size_t)b * E;
+  const int lane = lane_id(), wave = threadIdx.x >> 6;
+  int* q = csr_lds + wave * qcap;
+  int* cnts = csr_lds + 4 * qcap;
+  int* lessw = cnts + 4 * kCsrKeys;
+  // ---- phase 1: ordered compaction of this wave's quarter of the slots ----
+  const int per = ((E + 3) / 4 + 63) / 64 * 64;
+  const int beg = min(wave * per, E), end = min(beg + per, E);
+  int qlen = 0, nless = 0;
+  for (int e0 = beg; e0 < end; e0 += 4 * 64) {
+    int key[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {                       // four loads in flight
+      const int e = e0 + u * 64 + lane;
+      key[u] = e < end ? idx[e] : 0x7fffffff;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int e = e0 + u * 64 + lane;
+      const bool in = (unsigned)(key[u] - k0) < (unsigned)KR;
+      const unsigned long long bi = __ballot(in);
+      nless += __popcll(__ballot(key[u] < k0));
+      if (in) {
+        const int pos = qlen + __builtin_amdgcn_mbcnt_hi((unsigned)(bi >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bi, 0u));
+        q[pos] = (e << 7) | (key[u] - k0);
+      }
+      qlen += __popcll(bi);
+    }
+  }
+  // ---- phase 2: lane = key holds that key's counters.  Two ways to consume the (ordered) queue, same result:
+  //   match   blocks of 64 items (lane = item), one iteration per DISTINCT key of a block: all items with the leader's
+  //           key are handled at once (ballot) and leave as consecutive stores.  Cost ~ distinct keys: right for the
+  //           queues dominated by runs of one key -- padded ball rows repeat their first hit up to nsample times,
+  //           and the small indices that are "first hit" of most balls concentrate in the first key ranges;
+  //   walk    every lane reads every item (LDS broadcast) and keeps what carries its key.  Cost ~ items: right for
+  //           queues of mostly distinct keys, where a match iteration is a serial chain (ballot -> readlane -> compare).
+  // A wave picks by the number of distinct keys in its first block.
+  if (lane < 4) q[qlen + lane] = 127;          // pad to a multiple of 4 with a key no lane owns (walk reads int4)
+  const int qlen4 = (qlen + 3) & ~3;
+  bool use_match = false;
+  {
+    const int item = lane < qlen ? q[lane] : -1;
+    const int kl = item < 0 ? 127 : (item & 127);
+    unsigned long long todo = __ballot(item >= 0);
+    int distinct = 0;
+    while (todo && distinct <= 16) {
+      const int k = __builtin_amdgcn_readlane(kl, __ffsll((long long)todo) - 1);
+      todo &= ~__ballot(kl == k);
+      ++distinct;
+    }
+    use_match = distinct <= 16 && qlen > 64;
+  }
+  int cnt = 0;
+  if (use_match) {
+    for (int i = 0; i < qlen; i += 64) {
+      const int item = i + lane < qlen ? q[i + lane] : -1;
+      const int kl = item < 0 ? 127 : (item & 127);
+      unsigned long long todo = __ballot(item >= 0);
+      while (todo) {
+        const int k = __builtin_amdgcn_readlane(kl, __ffsll((long long)todo) - 1);
+        const unsigned long long mask = __ballot(kl == k);
+        cnt += lane == k ? __popcll(mask) : 0;
+        todo &= ~mask;
+      }
+    }
+  } else {
+    for (int i = 0; i < qlen4; i += 4) {
+      const int4 it = *reinterpret_cast<const int4*>(q + i);   // same address in every lane: LDS broadcast
+      cnt += ((it.x & 127) == lane) + ((it.y & 127) == lane) + ((it.z & 127) == lane) + ((it.w & 127) == lane);
+    }
+  }
+  cnts[wave * kCsrKeys + lane] = cnt;
+  if (lane == 0) lessw[wave] = nless;
+  __syncthreads();
+  const int c0 = cnts[lane], c1 = cnts[kCsrKeys + lane], c2 = cnts[2 * kCsrKeys + lane], c3 = cnts[3 * kCsrKeys + lane];
+  const int total = (c0 + c1) + (c2 + c3);
+  int incl = total;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const int up = __shfl_up(incl, d);
+    if (lane >= d) incl += up;
+  }
+  const int start = (lessw[0] + lessw[1]) + (lessw[2] + lessw[3]) + (incl - total);   // off[k0 + lane]
+  int* off = P.off + (size_t)b * (m + 1);
+  if (wave == 0) {
+    if (lane < KR && k0 + lane < m) off[k0 + lane] = start;
+    if (r == P.ranges - 1 && lane == 0) off[m] = E;
+  }
+  int pos = start + (wave > 0 ? c0 : 0) + (wave > 1 ? c1 : 0) + (wave > 2 ? c2 : 0);   // next free entry of key `lane`
+  int* ent = P.ent + (size_t)b * E;
+  if (use_match) {
+    for (int i = 0; i < qlen; i += 64) {
+      const int item = i + lane < qlen ? q[i + lane] : -1;
+      const int kl = item < 0 ? 127 : (item & 127);
+      unsigned long long todo = __ballot(item >= 0);
+      while (todo) {
+        const int k = __builtin_amdgcn_readlane(kl, __ffsll((long long)todo) - 1);
+        const unsigned long long mask = __ballot(kl == k);
+        const int base = __builtin_amdgcn_readlane(pos, k);
+        if (kl == k)
+          ent[base + __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u))] = item >> 7;
+        pos += lane == k ? __popcll(mask) : 0;
+        todo &= ~mask;
+      }
+    }
+  } else {
+    for (int i = 0; i < qlen4; i += 4) {
+      const int4 it = *reinterpret_cast<const int4*>(q + i);
+      if ((it.x & 127) == lane) ent[pos++] = it.x >> 7;
+      if ((it.y & 127) == lane) ent[pos++] = it.y >> 7;
+      if ((it.z & 127) == lane) ent[pos++] = it.z >> 7;
+      if ((it.w & 127) == lane) ent[pos++] = it.w >> 7;
+    }
+  }
+}
+
 constexpr int kInterpCsrCH = 8;
 __global__ __launch_bounds__(256) void interp_grad_csr_kernel(int c, int n, int m,
                                                               const float* __restrict__ grad_out,
@@ -686,6 +838,7 @@ __global__ __launch_bounds__(256) void three_interpolate_kernel(int c, int m, in
   }
 }
 
+int g_csr_legacy = 0;  // istnet_pn2_set_tuning key 2: 1 = one-workgroup-per-cloud list builds (A/B, tests)
 int g_dist_conv = 0;  // distance convention (file header); istnet_pn2_set_tuning key 1
 // expands LAUNCH three times with CONV_ = 0, 1, 2 and runs the one g_dist_conv selects
 #define ISTNET_CONV_DISPATCH(LAUNCH)                                           \
@@ -765,6 +918,8 @@ int istnet_pn2_set_tuning(int key, int value) {
   if (key == 0) { if (value < 1 || value > 1025) return ISTNET_PN2_EINVAL; g_fps_multiwave_min = value; return 0; }
   // key 1: distance convention of FPS / ball query / three_nn (0 un-contracted, 1 / 2 FMA-contracted; file header)
   if (key == 1) { if (value < 0 || value > 2) return ISTNET_PN2_EINVAL; g_dist_conv = value; return 0; }
+  // key 2: 1 = build inverse lists with the one-workgroup-per-cloud kernels (the fallback for very large slot counts)
+  if (key == 2) { g_csr_legacy = value ? 1 : 0; return 0; }
   return ISTNET_PN2_EINVAL;
 }
 const char* istnet_pn2_target(void) { return "gfx950"; }
@@ -876,21 +1031,51 @@ int istnet_pn2_three_interpolate(int b, int c, int m, int n, const float* points
   return (int)hipGetLastError();
 }
 
+// queue capacity per wave of csr_range_kernel (ints): its quarter of the slots, rounded to whole 64-slot steps, + pad
+static int csr_qcap(int e) { return ((e + 3) / 4 + 63) / 64 * 64 + 8; }
+static size_t csr_range_lds(int e) { return ((size_t)4 * csr_qcap(e) + 4 * kCsrKeys + 4) * 4; }
+
+int istnet_pn2_csr_build_multi(int nprob, int b, const int* e, const int* m, const int* const* idx,
+                               int* const* offsets, int* const* entries, void* stream) {
+  if (nprob <= 0 || nprob > kCsrMaxProblems || b < 0 || !e || !m || !idx || !offsets || !entries) return ISTNET_PN2_EINVAL;
+  if (b == 0) return 0;
+  CsrBatch cb;
+  cb.n = nprob;
+  int blocks = 0;
+  size_t lds = 0;
+  for (int l = 0; l < nprob; ++l) {
+    if (e[l] < 0 || m[l] <= 0 || e[l] >= (1 << 24) || !idx[l] || !offsets[l] || !entries[l]) return ISTNET_PN2_EINVAL;
+    const size_t need = csr_range_lds(e[l]);
+    if (need > (size_t)kMaxLdsRowBytes) return ISTNET_PN2_EINVAL;     // caller builds this one with istnet_pn2_csr_build
+    lds = need > lds ? need : lds;
+    CsrProblem& P = cb.p[l];
+    P.idx = idx[l]; P.off = offsets[l]; P.ent = entries[l];
+    // keys per workgroup: 64 when that already gives >= 512 workgroups, else fewer keys -> more, shorter workgroups
+    int kr = kCsrKeys;
+    while (kr > 16 && (long long)b * ceil_div(m[l], kr) < 512) kr >>= 1;
+    P.E = e[l]; P.m = m[l]; P.kr = kr; P.ranges = ceil_div(m[l], kr); P.block_begin = blocks; P.qcap = csr_qcap(e[l]);
+    blocks += b * P.ranges;
+  }
+  hipLaunchKernelGGL(csr_range_kernel, dim3(blocks), dim3(256), lds, as_stream(stream), cb);
+  return (int)hipGetLastError();
+}
+
 int istnet_pn2_csr_build(int b, int e, int m, const int* idx, int* offsets, int* entries, void* stream);
 
 int istnet_pn2_interp_csr_build(int b, int n, int m, const int* idx, int* offsets, int* entries, void* stream) {
   if (b < 0 || n < 0 || m <= 0) return ISTNET_PN2_EINVAL;
   if (b == 0) return 0;
-  const size_t lds = ((size_t)3 * m + 1 + 256) * 4;
-  if (lds > (size_t)kMaxLdsRowBytes) return ISTNET_PN2_EINVAL;  // caller falls back to the atomic kernel
   return istnet_pn2_csr_build(b, 3 * n, m, idx, offsets, entries, stream);   // same lists: e = 3n taps per cloud
 }
 
 int istnet_pn2_csr_build(int b, int e, int m, const int* idx, int* offsets, int* entries, void* stream) {
   if (b < 0 || e < 0 || m <= 0) return ISTNET_PN2_EINVAL;
   if (b == 0) return 0;
+  if (csr_range_lds(e) <= (size_t)kMaxLdsRowBytes && e < (1 << 24) && g_csr_legacy == 0)
+    return istnet_pn2_csr_build_multi(1, b, &e, &m, &idx, &offsets, &entries, stream);
+  // slot counts beyond the LDS queue of the range kernel: one workgroup per cloud
   const size_t lds = ((size_t)3 * m + 1 + 256) * 4;
-  if (lds > (size_t)kMaxLdsRowBytes) return ISTNET_PN2_EINVAL;
+  if (lds > (size_t)kMaxLdsRowBytes) return ISTNET_PN2_EINVAL;  // caller falls back to the atomic kernels
   if (lds + ((size_t)e + 256) * 4 <= (size_t)kMaxLdsRowBytes)
     hipLaunchKernelGGL(csr_build_lds_kernel, dim3(b), dim3(256), lds + ((size_t)e + 256) * 4, as_stream(stream), e, m,
                        idx, offsets, entries);

@@ -103,18 +103,39 @@ class PointNet2MSG(nn.Module):
                 levels.append(new_xyz)
                 cur = new_xyz
             for lvl in range(len(self.FP_modules) - 1, -1, -1):
-                idx, weight, csr = PointnetFPModule.interpolation_weights(levels[lvl], levels[lvl + 1], with_csr=True)
+                idx, weight = PointnetFPModule.interpolation_weights(levels[lvl], levels[lvl + 1])
                 ev = torch.cuda.Event()
                 ev.record(side)
-                fp_geo[lvl] = (idx, weight, csr, ev)
+                fp_geo[lvl] = [idx, weight, None, ev]
             csr_ev = None
-            ball_csr = getattr(pointnet2_utils._ext, "ball_csr", None)     # absent from a plain reference _ext
-            if with_ball_csr and ball_csr is not None and fused_mlp.USE_CSR_SCATTER:
-                for lvl in range(1, len(sa_geo)):       # level 0 has no input features, hence no scatter
-                    lists = [ball_csr(i, levels[lvl].shape[1]) for i in sa_geo[lvl][1]]
-                    sa_geo[lvl][3] = lists if all(c is not None for c in lists) else None
+            csr_multi = getattr(pointnet2_utils._ext, "csr_multi", None)     # absent from a plain reference _ext
+            if with_ball_csr and csr_multi is not None:
+                # inverse lists of every index tensor the backward pass scatters through -- ball queries of the levels
+                # that have input features, three_nn taps of every FP level -- in ONE launch, at the end of the
+                # pre-pass: only the backward pass reads them
+                problems, where = [], []
+                if fused_mlp.USE_CSR_SCATTER:
+                    for lvl in range(1, len(sa_geo)):       # level 0 has no input features, hence no scatter
+                        for si, i in enumerate(sa_geo[lvl][1]):
+                            problems.append((i, levels[lvl].shape[1]))
+                            where.append(("sa", lvl, si))
+                for lvl in range(len(self.FP_modules)):
+                    problems.append((fp_geo[lvl][0], levels[lvl + 1].shape[1]))
+                    where.append(("fp", lvl, 0))
+                lists = csr_multi(problems)
+                for (kind, lvl, si), res in zip(where, lists):
+                    if kind == "fp":
+                        fp_geo[lvl][2] = res
+                    else:
+                        if sa_geo[lvl][3] is None:
+                            sa_geo[lvl][3] = [None] * len(sa_geo[lvl][1])
+                        sa_geo[lvl][3][si] = res
+                for lvl in range(1, len(sa_geo)):
+                    if sa_geo[lvl][3] is not None and any(c is None for c in sa_geo[lvl][3]):
+                        sa_geo[lvl][3] = None
                 csr_ev = torch.cuda.Event()
                 csr_ev.record(side)
+            fp_geo = [tuple(g) for g in fp_geo]
         return sa_geo, fp_geo, csr_ev
 
     def prefetch_geometry(self, pointcloud, slot=None):

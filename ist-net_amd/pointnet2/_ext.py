@@ -137,42 +137,67 @@ def three_interpolate(points, idx, weight):
     return out
 
 
+def _csr_fits(e, m):
+    """(range kernel ok, legacy kernel ok) for e slots per cloud with keys in [0, m): mirrors the launchers' LDS rules
+    (csr_range_lds / the one-workgroup-per-cloud histogram) in csrc/pn2_index_ops.hip."""
+    qcap = ((e + 3) // 4 + 63) // 64 * 64 + 8
+    return (4 * qcap + 4 * 64 + 4) * 4 <= 65536 and e < (1 << 24), 3 * m + 257 <= 16384
+
+
+def csr_multi(problems):
+    """Inverse lists of several index tensors over the same batch in ONE launch (istnet_pn2_csr_build_multi).
+
+    problems: list of (idx, m) with idx an int32 CUDA tensor (B, ...) of keys in [0, m); every trailing dim is
+    flattened into the slot index e.  Returns a list of (offsets (B, m+1), entries (B, E)) int32 -- entries of a list in
+    ascending slot order -- or None for a problem too large for either build kernel."""
+    import ctypes
+    out, batch = [None] * len(problems), []
+    lib = _native.lib()
+    dev = None
+    for i, (idx, m) in enumerate(problems):
+        _contig(idx, "idx"); _is_int(idx, "idx")
+        dev = _device_of(idx, "idx")
+        b, m = idx.shape[0], int(m)
+        e = idx.numel() // max(b, 1)
+        fits_range, fits_legacy = _csr_fits(e, m)
+        if not (fits_range or fits_legacy):
+            continue
+        offsets = torch.empty((b, m + 1), dtype=torch.int32, device=dev)
+        entries = torch.empty((b, e), dtype=torch.int32, device=dev)
+        out[i] = (offsets, entries)
+        if fits_range:
+            batch.append((b, e, m, idx, offsets, entries))
+        else:
+            with torch.cuda.device(dev):
+                _native.check(lib.istnet_pn2_csr_build(b, e, m, _ptr(idx), _ptr(offsets), _ptr(entries), _stream(dev)),
+                              "csr_build")
+    for b in sorted({t[0] for t in batch}):
+        group = [t for t in batch if t[0] == b]
+        for i in range(0, len(group), 12):
+            chunk = group[i:i + 12]
+            n = len(chunk)
+            arr = lambda k: (ctypes.c_void_p * n)(*[_ptr(t[k]) for t in chunk])
+            with torch.cuda.device(dev):
+                _native.check(lib.istnet_pn2_csr_build_multi(
+                    n, b, (ctypes.c_int * n)(*[t[1] for t in chunk]), (ctypes.c_int * n)(*[t[2] for t in chunk]),
+                    arr(3), arr(4), arr(5), _stream(dev)), "csr_build_multi")
+    return out
+
+
 def interp_csr(idx, m):
     """Per-cloud inverse lists of a three_nn index tensor (B,n,3) over m sources: (offsets (B,m+1), entries (B,3n))
-    int32, or None when m is too large for the LDS histogram of the build kernel.  Depends on idx only, so
-    a caller that knows idx early (the encoder's geometry pre-pass) can build it off the critical path and
-    hand it to three_interpolate_grad."""
-    _contig(idx, "idx"); _is_int(idx, "idx")
-    m = int(m)
-    if 3 * m + 257 > 16384:
-        return None
-    dev = _device_of(idx, "idx")
-    b, n = idx.shape[0], idx.shape[1]
-    offsets = torch.empty((b, m + 1), dtype=torch.int32, device=dev)
-    entries = torch.empty((b, 3 * n), dtype=torch.int32, device=dev)
-    with torch.cuda.device(dev):
-        _native.check(_native.lib().istnet_pn2_interp_csr_build(b, n, m, _ptr(idx), _ptr(offsets), _ptr(entries),
-                                                                _stream(dev)), "interp_csr_build")
-    return offsets, entries
+    int32 -- tap e = 3*j + t, ascending inside each list -- or None when the tensor is too large for the build kernels.
+    Depends on idx only, so a caller that knows idx early (the encoder's geometry pre-pass) can build it off the
+    critical path and hand it to three_interpolate_grad."""
+    return csr_multi([(idx, m)])[0]
 
 
 def ball_csr(idx, n):
     """Per-cloud inverse lists of a ball-query index tensor (B,npoint,nsample) over the n source points:
-    (offsets (B,n+1), entries (B,npoint*nsample)) int32, entries of a list in ascending slot order; None when n is too
-    large for the LDS histogram of the build kernel.  Depends on coordinates only (build it in the geometry pre-pass);
+    (offsets (B,n+1), entries (B,npoint*nsample)) int32, entries of a list in ascending slot order; None when the
+    tensor is too large for the build kernels.  Depends on coordinates only (build it in the geometry pre-pass);
     consumed by the atomic-free layer-0 gradient scatter of the fused set-abstraction backward."""
-    _contig(idx, "idx"); _is_int(idx, "idx")
-    n = int(n)
-    if 3 * n + 257 > 16384:
-        return None
-    dev = _device_of(idx, "idx")
-    b, e = idx.shape[0], idx.shape[1] * idx.shape[2]
-    offsets = torch.empty((b, n + 1), dtype=torch.int32, device=dev)
-    entries = torch.empty((b, e), dtype=torch.int32, device=dev)
-    with torch.cuda.device(dev):
-        _native.check(_native.lib().istnet_pn2_csr_build(b, e, n, _ptr(idx), _ptr(offsets), _ptr(entries),
-                                                         _stream(dev)), "csr_build")
-    return offsets, entries
+    return csr_multi([(idx, n)])[0]
 
 
 def three_interpolate_grad(grad_out, idx, weight, m, csr=None):

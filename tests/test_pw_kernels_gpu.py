@@ -213,3 +213,60 @@ def test_inverse_lists_on_degenerate_indices():
     off, ent = _ext.ball_csr(perm.view(b, n // 16, 16).contiguous(), n)
     assert torch.equal(off, torch.arange(n + 1, device=DEV, dtype=torch.int32).expand(b, n + 1))
     assert torch.equal(torch.gather(perm.long(), 1, ent.long()), torch.arange(n, device=DEV).expand(b, n))
+
+
+def _lists_reference(idx2d, m):
+    """Inverse lists by a stable sort on the host: offsets (B, m+1), entries (B, E) ascending inside each list."""
+    b, e = idx2d.shape
+    keys = idx2d.long().cpu()
+    ent = torch.argsort(keys, dim=1, stable=True).int()
+    off = torch.zeros(b, m + 1, dtype=torch.int32)
+    for bi in range(b):
+        off[bi, 1:] = torch.cumsum(torch.bincount(keys[bi], minlength=m), 0).int()
+    return off, ent
+
+
+@pytest.mark.parametrize("b,shapes", [
+    (3, [((256, 16), 512), ((256, 32), 512), ((128, 16), 256), ((64, 32), 128), ((1024, 3), 512), ((128, 3), 64)]),
+    (32, [((256, 32), 512), ((512, 3), 256)]),
+    (2, [((5, 3), 1), ((1, 1), 70), ((300, 7), 130), ((3000, 5), 4000)]),
+])
+def test_inverse_lists_key_range_kernel_vs_stable_sort(b, shapes):
+    """istnet_pn2_csr_build_multi (a workgroup per 64 source points, several index tensors per launch) against a stable
+    argsort on the host and against the one-workgroup-per-cloud kernels: identical offsets and entries, on ball-query-like
+    rows (ascending with a padded tail), on three_nn-like taps, on a key count that is not a multiple of 64, on more
+    keys than slots, and on slot counts that are not multiples of 256."""
+    from istnet_amd.pointnet2 import _ext
+    lib = _native.lib()
+    g = torch.Generator().manual_seed(b)
+    problems = []
+    for (rows, s), m in shapes:
+        idx = torch.sort(torch.randint(0, m, (b, rows, s), generator=g), dim=2).values
+        if s >= 8:
+            idx[:, ::3, s // 2:] = idx[:, ::3, :1]          # padded rows repeat the first hit
+            idx[:, :, -1] = idx[:, :1, 0]                    # one source point referenced by every row (a long list)
+        problems.append((idx.int().to(DEV).contiguous(), m))
+    got = _ext.csr_multi(problems)
+    torch.cuda.synchronize()
+    assert lib.istnet_pn2_set_tuning(2, 1) == 0
+    try:
+        legacy = [_ext.csr_multi([p])[0] for p in problems]
+        torch.cuda.synchronize()
+    finally:
+        assert lib.istnet_pn2_set_tuning(2, 0) == 0
+    for (idx, m), (off, ent), old in zip(problems, got, legacy):
+        want_off, want_ent = _lists_reference(idx.reshape(b, -1), m)
+        assert torch.equal(off.cpu(), want_off) and torch.equal(ent.cpu(), want_ent)
+        if old is not None:
+            assert torch.equal(old[0], off) and torch.equal(old[1], ent)
+
+
+def test_inverse_lists_large_slot_count_takes_the_per_cloud_kernel():
+    """More slots than the range kernel's LDS queue holds (N=2048 level 1: 1024 x 32 slots): the per-cloud kernels
+    build the same lists."""
+    from istnet_amd.pointnet2 import _ext
+    g = torch.Generator().manual_seed(9)
+    idx = torch.randint(0, 2048, (2, 1024, 32), generator=g).int().to(DEV)
+    off, ent = _ext.ball_csr(idx, 2048)
+    want_off, want_ent = _lists_reference(idx.reshape(2, -1), 2048)
+    assert torch.equal(off.cpu(), want_off) and torch.equal(ent.cpu(), want_ent)
