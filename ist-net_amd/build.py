@@ -49,7 +49,8 @@ def build(force=False, verbose=False):
         obj = os.path.join(obj_dir, os.path.basename(src)[:-4] + ".o")
         contract = os.environ.get("ISTNET_FP_CONTRACT_" + os.path.basename(src)[:-4].upper(),
                                   FP_CONTRACT.get(os.path.basename(src), "off"))
-        cmd = common + [f"-ffp-contract={contract}", "-c", src, "-o", obj]
+        extra = os.environ.get("ISTNET_HIPCC_FLAGS", "").split()      # experiments (e.g. -DISTNET_BWD_SMALL_WAVES=3)
+        cmd = common + extra + [f"-ffp-contract={contract}", "-c", src, "-o", obj]
         if verbose:
             print(" ".join(cmd))
         procs.append((cmd, subprocess.Popen(cmd)))

@@ -1544,7 +1544,11 @@ __global__ __launch_bounds__(kThreads) void pw_wgrad_small_kernel(
 // tiles (odd stride, so both the k-major and the transposed fragment reads are conflict-free), 16 MFMAs for dW
 // (K = points) and 16 for dA (K = cout, A operand = W held in registers).
 // ============================================================================================
-__global__ __launch_bounds__(kThreads) void pw_bwd_small_kernel(
+template <bool POOLED>   // gradient source: dense dA (B, C, P), or the max-pool's (dO, arg) pair (the last layer of a scale)
+#ifndef ISTNET_BWD_SMALL_WAVES
+#define ISTNET_BWD_SMALL_WAVES 2   // waves per SIMD the register allocation targets (A/B: 3 spills 26 registers)
+#endif
+__global__ __launch_bounds__(kThreads, ISTNET_BWD_SMALL_WAVES) void pw_bwd_small_kernel(
     int cin, int cout, int P, long long total, int split_len, const float* __restrict__ w,
     const float* __restrict__ x, const float* __restrict__ in_scale, const float* __restrict__ in_shift,
     const float* __restrict__ y, GradSrc gs, const float* __restrict__ bn, const float* __restrict__ bwdc,
@@ -1563,7 +1567,7 @@ __global__ __launch_bounds__(kThreads) void pw_bwd_small_kernel(
     s_in[0][threadIdx.x] = in_scale[c];
     s_in[1][threadIdx.x] = in_shift[c];
   }
-  // A operand of the dgrad MFMAs: A[i = ci][k = co] = w[co][ci], co = 2*kk + (lane >> 5), ci = lane & 31
+  // B operand of the dgrad MFMAs: B[k = co][j = ci] = w[co][ci], co = 2*kk + (lane >> 5), ci = lane & 31
   float wfrag[16];
 #pragma unroll
   for (int kk = 0; kk < 16; ++kk) {
@@ -1571,10 +1575,17 @@ __global__ __launch_bounds__(kThreads) void pw_bwd_small_kernel(
     wfrag[kk] = (co < cout && ci < cin) ? w[(size_t)co * cin + ci] : 0.f;
   }
   __syncthreads();
-  const float bsc = s_in[0][lane & 31], bsh = s_in[1][lane & 31];  // activation of the wgrad B fragments
+  const float bsc = s_in[0][lane & 31], bsh = s_in[1][lane & 31];  // BN constants of input channel ci = lane & 31
 
-  DyRaw araw[4];
-  float4 braw[4];
+  // Register budget: the kernel is HBM-bound and lives on waves in flight, so everything that is carried across a
+  // chunk is kept small -- the loads of the next chunk hold only the fields their gradient mode uses (dense: y + dA;
+  // pooled: y + one pooled value + its arg-max slot), and dA^T is what the dgrad MFMAs produce (rows = points,
+  // column = input channel of the lane): its BN-backward statistics are then two scalars per lane instead of two
+  // per accumulator register, and dA leaves as four 16-byte stores per lane (4 consecutive points of one channel).
+  float4 ay[4], bx4[4];
+  float4 ad[POOLED ? 1 : 4];
+  float apv[POOLED ? 4 : 1];
+  int aarg[POOLED ? 4 : 1];
   auto load_chunk = [&](long long qk) {
     const long long qc = min(qk, total - kKTW);
     int b, pk;
@@ -1583,8 +1594,17 @@ __global__ __launch_bounds__(kThreads) void pw_bwd_small_kernel(
     for (int i = 0; i < 4; ++i) {
       const int e = lane + 64 * i;
       const int row = e >> 3, p = pk + (e & 7) * 4;
-      load_dy_raw(araw[i], gs, y, b, min(row, cout - 1), P, p);
-      braw[i] = *reinterpret_cast<const float4*>(x + ((size_t)b * cin + min(row, cin - 1)) * P + p);
+      const int ch = min(row, cout - 1);
+      const size_t rowo = (size_t)b * cout + ch;
+      ay[i] = *reinterpret_cast<const float4*>(y + rowo * (size_t)P + p);
+      if (POOLED) {
+        const int G = P / gs.S, g = p / gs.S;
+        apv[i] = pooled_at(gs, b, ch, G, g);
+        aarg[i] = gs.arg[rowo * (size_t)G + g];
+      } else {
+        ad[i] = *reinterpret_cast<const float4*>(gs.dense + rowo * (size_t)P + p);
+      }
+      bx4[i] = *reinterpret_cast<const float4*>(x + ((size_t)b * cin + min(row, cin - 1)) * P + p);
     }
   };
   auto store_chunk = [&](long long qk) {
@@ -1595,26 +1615,43 @@ __global__ __launch_bounds__(kThreads) void pw_bwd_small_kernel(
       const int e = lane + 64 * i;
       const int row = e >> 3, k = (e & 7) * 4;
       const bool okq = qk + k < qend;
-      float4 v = finish_dy(araw[i], gs, pk + k, min(row, cout - 1), bn, bwdc, cout);
+      const int ch = min(row, cout - 1);
+      const float rs = bn[ch], rh = bn[cout + ch];
+      const float rca = bwdc[ch], rcb = bwdc[cout + ch], rcc = bwdc[2 * cout + ch];
+      float4 d;
+      if (POOLED) {
+        const int ks = (pk + k) % gs.S, a = aarg[i];
+        const float pv = apv[i];
+        d = make_float4(a == ks ? pv : 0.f, a == ks + 1 ? pv : 0.f, a == ks + 2 ? pv : 0.f, a == ks + 3 ? pv : 0.f);
+      } else {
+        d = ad[i];
+      }
+      const float4 yv = ay[i];
+      float4 v;
+      v.x = rca * ((yv.x * rs + rh > 0.f) ? d.x : 0.f) + rcb + rcc * yv.x;
+      v.y = rca * ((yv.y * rs + rh > 0.f) ? d.y : 0.f) + rcb + rcc * yv.y;
+      v.z = rca * ((yv.z * rs + rh > 0.f) ? d.z : 0.f) + rcb + rcc * yv.z;
+      v.w = rca * ((yv.w * rs + rh > 0.f) ? d.w : 0.f) + rcb + rcc * yv.w;
       if (!(okq && row < cout)) v = zero4();
       As[(k + 0) * LD + row] = v.x; As[(k + 1) * LD + row] = v.y;
       As[(k + 2) * LD + row] = v.z; As[(k + 3) * LD + row] = v.w;
-      const float4 u = braw[i];   // raw: the statistics need y_{l-1} itself, the activation is applied on read
+      const float4 u = bx4[i];   // raw: the statistics need y_{l-1} itself, the activation is applied on read
       Bs[(k + 0) * LD + row] = u.x; Bs[(k + 1) * LD + row] = u.y;
       Bs[(k + 2) * LD + row] = u.z; Bs[(k + 3) * LD + row] = u.w;
     }
   };
 
   f32x16 accw;
-  float sg[16], sgy[16];
 #pragma unroll
-  for (int r = 0; r < 16; ++r) { accw[r] = 0.f; sg[r] = 0.f; sgy[r] = 0.f; }
+  for (int r = 0; r < 16; ++r) accw[r] = 0.f;
+  float sg = 0.f, sgy = 0.f;   // statistics of input channel ci = lane & 31 over the point rows this lane holds
   const int nchunks = (int)((qend - qbeg + kKTW - 1) / kKTW);
   int t = wv;
   if (t < nchunks) load_chunk(qbeg + (long long)t * kKTW);
   for (; t < nchunks; t += 4) {
     const long long qk = qbeg + (long long)t * kKTW;
     store_chunk(qk);                                                // wave-private LDS: no workgroup barrier
+    __builtin_amdgcn_sched_barrier(0);                              // the next loads reuse the registers just consumed
     if (t + 4 < nchunks) load_chunk(qbeg + (long long)(t + 4) * kKTW);  // in flight during the MFMAs
     __builtin_amdgcn_s_waitcnt(0xc07f);                             // lgkmcnt(0): this wave's ds_writes landed
     f32x16 accd;
@@ -1623,31 +1660,41 @@ __global__ __launch_bounds__(kThreads) void pw_bwd_small_kernel(
     const float* ap = As + (lane >> 5) * LD + (lane & 31);   // dY[pt = 2kk + half][co = lane & 31]
     const float* bp = Bs + (lane >> 5) * LD + (lane & 31);   // x [pt = 2kk + half][ci = lane & 31]
     const float* tp = As + (lane & 31) * LD + (lane >> 5);   // dY[pt = lane & 31][co = 2kk + half]
+    // fragments of step kk+1 are read while the MFMAs of step kk run; the scheduling barriers keep the compiler from
+    // hoisting all 48 LDS reads of the unrolled loop (registers)
+    float fa[2], fb[2], ft[2];
+    fa[0] = ap[0]; fb[0] = bp[0]; ft[0] = tp[0];
 #pragma unroll
     for (int kk = 0; kk < 16; ++kk) {
-      const float a = ap[2 * kk * LD];
-      const float bx = fmaxf(bp[2 * kk * LD] * bsc + bsh, 0.f);
-      const float bt = tp[2 * kk];
-      accw = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bx, accw, 0, 0, 0);            // dW[co][ci] += dY . act(x)^T
-      accd = __builtin_amdgcn_mfma_f32_32x32x2f32(wfrag[kk], bt, accd, 0, 0, 0);    // dA[ci][pt]  = W^T . dY
+      const int cur = kk & 1, nxt = cur ^ 1;
+      if (kk + 1 < 16) { fa[nxt] = ap[2 * (kk + 1) * LD]; fb[nxt] = bp[2 * (kk + 1) * LD]; ft[nxt] = tp[2 * (kk + 1)]; }
+      __builtin_amdgcn_sched_barrier(0);
+      const float bx = fmaxf(fb[cur] * bsc + bsh, 0.f);
+      accw = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur], bx, accw, 0, 0, 0);         // dW[co][ci] += dY . act(x)^T
+      accd = __builtin_amdgcn_mfma_f32_32x32x2f32(ft[cur], wfrag[kk], accd, 0, 0, 0);  // dA^T[pt][ci] = dY^T . W
+      __builtin_amdgcn_sched_barrier(0);
     }
-    // dA of this chunk: register r of a lane is (ci = mfma_row(r, lane), pt = lane & 31)
+    // dA^T of this chunk: register r of a lane is (pt = mfma_row(r, lane), ci = lane & 31); registers 4j .. 4j+3 are
+    // four consecutive points
     const long long qc = min(qk, total - kKTW);
     int b, pk;
     split_point(qc, P, b, pk);
-    const int pt = lane & 31;
-    const bool okp = qk + pt < qend;
-    float* dxb = dx + (size_t)b * cin * P + pk + pt;
+    const int ci = lane & 31;
+    float* dxb = dx + ((size_t)b * cin + ci) * P + pk + 4 * (lane >> 5);
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int ci = mfma_row(r, lane);
-      if (okp && ci < cin) {
-        const float v = accd[r];
-        dxb[(size_t)ci * P] = v;
-        const float yin = Bs[pt * LD + ci];
-        const float gq = (yin * s_in[0][ci] + s_in[1][ci] > 0.f) ? v : 0.f;
-        sg[r] += gq;
-        sgy[r] += gq * yin;
+    for (int j = 0; j < 4; ++j) {
+      const int pt0 = 8 * j + 4 * (lane >> 5);
+      if (ci < cin && qk + pt0 < qend) {            // splits end on multiples of 4 points (P % 32 == 0)
+        float4 o;
+        o.x = accd[4 * j + 0]; o.y = accd[4 * j + 1]; o.z = accd[4 * j + 2]; o.w = accd[4 * j + 3];
+        *reinterpret_cast<float4*>(dxb + 8 * j) = o;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const float yin = Bs[(pt0 + u) * LD + ci];
+          const float gq = (yin * bsc + bsh > 0.f) ? accd[4 * j + u] : 0.f;
+          sg += gq;
+          sgy += gq * yin;
+        }
       }
     }
   }
@@ -1664,21 +1711,15 @@ __global__ __launch_bounds__(kThreads) void pw_bwd_small_kernel(
       out[(size_t)row * cin + col] = (red[i] + red[1024 + i]) + (red[2048 + i] + red[3072 + i]);
   }
   __syncthreads();
-  float* sred = red;               // [4 waves][32 rows][2]
-#pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const float a = half_wave_sum(sg[r]), c = half_wave_sum(sgy[r]);
-    if ((lane & 31) == 31) {
-      sred[(wv * 32 + mfma_row(r, lane)) * 2 + 0] = a;
-      sred[(wv * 32 + mfma_row(r, lane)) * 2 + 1] = c;
-    }
-  }
+  float* sred = red;               // [4 waves][2 halves][32 channels][2]
+  sred[((wv * 2 + (lane >> 5)) * 32 + (lane & 31)) * 2 + 0] = sg;
+  sred[((wv * 2 + (lane >> 5)) * 32 + (lane & 31)) * 2 + 1] = sgy;
   __syncthreads();
   if (threadIdx.x < cin) {
     const int ci = threadIdx.x;
     float a = 0.f, c = 0.f;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) { a += sred[(k * 32 + ci) * 2 + 0]; c += sred[(k * 32 + ci) * 2 + 1]; }
+    for (int k = 0; k < 8; ++k) { a += sred[(k * 32 + ci) * 2 + 0]; c += sred[(k * 32 + ci) * 2 + 1]; }
     part_g[(size_t)ci * nt_total + blockIdx.x] = a;
     part_gy[(size_t)ci * nt_total + blockIdx.x] = c;
   }
@@ -1755,7 +1796,7 @@ inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s);
 inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 
 // tile selection shared by the forward launch and istnet_pw_stat_tiles()
-enum TileCfg { kCfg128x128, kCfg64x128, kCfg64x64, kCfg32x256 };
+enum TileCfg { kCfg128x128, kCfg64x128, kCfg64x64, kCfg32x256, kCfg128x64, kCfg256x64 };   // 128x64 / 256x64: dgrad only
 int g_force_fwd_cfg = -1, g_force_dgrad_cfg = -1;  // experiments (istnet_pw_set_tuning keys 3, 4): TileCfg or -1
 inline TileCfg pick_cfg(int b, int m, int P, int force = -1) {
   if (force >= 0) return (TileCfg)force;
@@ -1765,15 +1806,25 @@ inline TileCfg pick_cfg(int b, int m, int P, int force = -1) {
   if (n128 * ceil_div(m, 64) >= 512) return kCfg64x128;
   return kCfg64x64;
 }
-// dgrad: the dY loader dominates and 64x64 tiles measured fastest for every layer with more than 32 input
-// channels (profiles/r01_tile_sweep.txt); -2 = the forward rule (experiments)
+// dgrad: the B operand is dY, formed from (y, gradient source, 5 per-channel constants) by the loader -- the expensive
+// operand.  Every row tile of a point tile re-reads and re-forms the same dY, so the tile is made as TALL as the
+// launch allows (the whole output height when that still gives enough workgroups): 64-point tiles, 64 / 128 / 256
+// rows.  -2 = the forward rule, 0..5 = a fixed TileCfg (experiments).
+int g_dgrad_min_wgs = 384;   // istnet_pw_set_tuning key 7
 inline TileCfg pick_dgrad_cfg(int b, int m, int P, int force) {
   if (force >= 0) return (TileCfg)force;
   if (force == -2) return pick_cfg(b, m, P);
-  return m <= 32 ? kCfg32x256 : kCfg64x64;
+  if (m <= 32) return kCfg32x256;
+  if (m <= 64) return kCfg64x64;
+  const long long n64 = (long long)b * ceil_div(P, 64);
+  if (m > 128 && n64 * ceil_div(m, 256) >= g_dgrad_min_wgs) return kCfg256x64;
+  if (n64 * ceil_div(m, 128) >= g_dgrad_min_wgs) return kCfg128x64;
+  return kCfg64x64;
 }
-inline int cfg_nt(TileCfg c) { return c == kCfg32x256 ? 256 : (c == kCfg64x64 ? 64 : 128); }
-inline int cfg_mt(TileCfg c) { return c == kCfg128x128 ? 128 : (c == kCfg32x256 ? 32 : 64); }
+inline int cfg_nt(TileCfg c) { return c == kCfg32x256 ? 256 : ((c == kCfg64x64 || c == kCfg128x64 || c == kCfg256x64) ? 64 : 128); }
+inline int cfg_mt(TileCfg c) {
+  return c == kCfg256x64 ? 256 : ((c == kCfg128x128 || c == kCfg128x64) ? 128 : (c == kCfg32x256 ? 32 : 64));
+}
 
 inline bool wgrad_small(int cin, int cout) { return cin <= 32 && cout <= 32; }
 // tuning knobs (istnet_pw_set_tuning): experiments only, defaults are the measured best
@@ -1839,6 +1890,7 @@ int istnet_pw_set_tuning(int key, int value) {
     case 4: g_force_dgrad_cfg = value; return 0;
     case 5: g_bwd_small_target = value > 0 ? value : 256; return 0;
     case 6: g_exp_no_fast = value; return 0;
+    case 7: g_dgrad_min_wgs = value > 0 ? value : 384; return 0;
     default: return ISTNET_PN2_EINVAL;
   }
 }
@@ -1873,6 +1925,7 @@ static int launch_pw_forward(bool gather, int b, int cin, int cout, int p, const
     case kCfg64x128: ISTNET_FWD(64, 128, 2, 2); break;
     case kCfg64x64: ISTNET_FWD(64, 64, 2, 2); break;
     case kCfg32x256: ISTNET_FWD(32, 256, 1, 4); break;
+    default: return ISTNET_PN2_EINVAL;     // the tall 64-point tiles exist for dgrad only
   }
 #undef ISTNET_FWD
   return (int)hipGetLastError();
@@ -2075,6 +2128,8 @@ int istnet_pw_dgrad(int b, int cin_total, int ci_off, int m_rows, int cout, int 
     case kCfg64x128: ISTNET_DGRAD(64, 128, 2, 2); break;
     case kCfg64x64: ISTNET_DGRAD(64, 64, 2, 2); break;
     case kCfg32x256: ISTNET_DGRAD(32, 256, 1, 4); break;
+    case kCfg128x64: ISTNET_DGRAD(128, 64, 2, 2); break;
+    case kCfg256x64: ISTNET_DGRAD(256, 64, 4, 1); break;
   }
 #undef ISTNET_DGRAD
   return (int)hipGetLastError();
@@ -2230,9 +2285,14 @@ int istnet_pw_bwd_small(int b, int cin, int cout, int p, int nsample, const floa
   GradSrc gs{d_dense, d_pooled, arg, nsample, pooled_bstride > 0 ? pooled_bstride : (long long)GS_C * (nsample > 0 ? p / nsample : 0), GS_C};
   const int len = bwd_small_len(b, p);
   const int splits = istnet_pw_bwd_small_splits(b, p);   // also the number of statistics partials per channel
-  hipLaunchKernelGGL(pw_bwd_small_kernel, dim3(splits), dim3(kThreads), 0, as_stream(stream), cin, cout, p,
-                     (long long)b * p, len, w, x, bn_in, bn_in + cin, y, gs, bn, bwdc, dx, part_g, part_gy, splits,
-                     dw_part);
+  if (d_dense != nullptr)
+    hipLaunchKernelGGL(pw_bwd_small_kernel<false>, dim3(splits), dim3(kThreads), 0, as_stream(stream), cin, cout, p,
+                       (long long)b * p, len, w, x, bn_in, bn_in + cin, y, gs, bn, bwdc, dx, part_g, part_gy, splits,
+                       dw_part);
+  else
+    hipLaunchKernelGGL(pw_bwd_small_kernel<true>, dim3(splits), dim3(kThreads), 0, as_stream(stream), cin, cout, p,
+                       (long long)b * p, len, w, x, bn_in, bn_in + cin, y, gs, bn, bwdc, dx, part_g, part_gy, splits,
+                       dw_part);
   return (int)hipGetLastError();
 }
 

@@ -40,7 +40,7 @@ def _kname(base, cfg, gather=None):
     mt, nt = cfg // 1000, cfg % 1000
     if base == "pw_wgrad_kernel" and mt == 32:
         return "pw_wgrad_small_kernel<%s>" % ("true" if gather else "false")
-    wm, wn = (1, 4) if mt == 32 else (2, 2)
+    wm, wn = (1, 4) if mt == 32 else ((4, 1) if mt == 256 else (2, 2))
     tail = "" if gather is None else f", {int(gather)}"
     return f"{base}<{mt}, {nt}, {wm}, {wn}{tail}>"
 
