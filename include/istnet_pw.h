@@ -207,6 +207,54 @@ ISTNET_PN2_API int istnet_pw_wgrad_reduce(int count, int splits, const float *dw
 ISTNET_PN2_API int istnet_pw_wgrad_reduce_multi(int n, const int *counts, const int *splits,
                                                 const float *const *parts, float *const *dws, void *stream);
 
+/* ---- compact-column form of a set-abstraction scale (csrc/sa_compact.hip) ------------------------------------------
+ * The reference pads every ball-query row to nsample slots by repeating its first hit (ball_query_gpu.cu:38-45) and
+ * pushes the repeats through SharedMLP + max_pool2d like any other slot (pointnet2_modules.py:61-68).  A repeat has the
+ * activations of slot 0 of its group; what it adds is its MULTIPLICITY in every sum over points (BatchNorm statistics
+ * forward and backward, weight gradients, gradient scatter).  These entry points evaluate a scale on compact columns:
+ * per group its distinct neighbours, then one representative of the repeats carrying their number as a column weight.
+ * All groups of all clouds share one point axis of static capacity cap = b*g*s (a multiple of 256); the number of valid
+ * columns lives in device memory (gstart[b*g]), so grids are static and workgroups past it return at once.
+ *
+ * istnet_sa_compact: idx (b, g, s) ball-query indices over n source points per cloud ->
+ *   glen (b*g) columns per group, gstart (b*g + 1) their exclusive scan (gstart[b*g] = T, the valid column count),
+ *   cidx (cap) global source point b*n + i of a column, meta (cap) = group * 64 + position in the group,
+ *   colw (cap) multiplicity (1, or nsample - cnt for the representative; 0 on the null columns T .. roundup(T, 256)). */
+ISTNET_PN2_API int istnet_sa_compact(int b, int g, int s, int n, const int *idx, int *glen, int *gstart, int *cidx,
+                                     int *meta, float *colw, void *stream);
+/* layer 0 on compact columns: y (cout, cap) = z[cloud][:, point] + W0[:, 0:3] . (xyz[source] - new_xyz[group]), weighted
+ * partials [cout][cap / 256]; z (b, cout, n) or NULL (xyz-only level) */
+ISTNET_PN2_API int istnet_pw_gather_add_cols(int b, int n, int g, long long cap, int cout, const float *xyz,
+                                             const float *new_xyz, const int *cidx, const int *meta, const float *colw,
+                                             const int *ncols, const float *z, const float *w0, int ldw, float *y,
+                                             float *part_sum, float *part_sq, void *stream);
+/* istnet_pw_forward on compact columns: x (cin, cap) -> y (cout, cap), weighted partials [cout][istnet_pw_stat_tiles(1, cout, cap)] */
+ISTNET_PN2_API int istnet_pw_forward_cols(int cin, int cout, long long cap, const float *x, const float *w,
+                                          const float *in_scale, const float *in_shift, float *y, float *part_sum,
+                                          float *part_sq, const int *ncols, const float *colw, void *stream);
+/* istnet_bn_relu_pool over the ragged groups: out (b, c, g) slice, arg = position of the first maximum inside the group */
+ISTNET_PN2_API int istnet_bn_relu_pool_cols(int b, int c, int g, long long cap, const float *y, const float *bn,
+                                            const int *gstart, float *out, long long out_bstride, unsigned char *arg,
+                                            float *ymax, void *stream);
+/* gradient through the max-pool as a dense compact tensor (c, cap): d_pooled at each group's arg-max column, else 0 */
+ISTNET_PN2_API int istnet_pw_pooled_grad_cols(int b, int c, int g, long long cap, const float *d_pooled,
+                                              long long pooled_bstride, const unsigned char *arg, const int *meta,
+                                              const int *ncols, float *out, void *stream);
+/* istnet_pw_bwd_small on compact columns (dense gradient source); partials: [cin][splits], dw_part [splits][cout][cin],
+ * splits = istnet_pw_bwd_small_cols_splits() */
+ISTNET_PN2_API int istnet_pw_bwd_small_cols_splits(void);
+ISTNET_PN2_API int istnet_pw_bwd_small_cols(int cin, int cout, long long cap, const float *w, const float *x,
+                                            const float *bn_in, const float *y, const float *d_dense, const float *bn,
+                                            const float *bwdc, float *dx, float *part_g, float *part_gy,
+                                            float *dw_part, const int *ncols, const float *colw, void *stream);
+/* xyz weight gradient of layer 0 on compact columns: dwx (chunks, cout, 3) partials, chunks = istnet_pw_dwx_cols_chunks(cout) */
+ISTNET_PN2_API int istnet_pw_dwx_cols_chunks(int cout);
+ISTNET_PN2_API int istnet_pw_dwx_cols(int cout, long long cap, const float *y, const float *d_dense, const float *bn,
+                                      const float *bwdc, const int *cidx, const int *meta, const float *colw,
+                                      const int *ncols, const float *xyz, const float *new_xyz, float *dwx,
+                                      void *stream);
+
+
 #ifdef __cplusplus
 }
 #endif

@@ -72,6 +72,16 @@ SIGNATURES = {
     "istnet_pw_wgrad": [_i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _l, _p, _p, _p, _p, _p],
     "istnet_pw_wgrad_reduce": [_i, _i, _p, _p, _p],
     "istnet_pw_wgrad_reduce_multi": [_i, _p, _p, _p, _p, _p],
+    # compact-column form of a set-abstraction scale (csrc/sa_compact.hip)
+    "istnet_sa_compact": [_i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p],
+    "istnet_pw_gather_add_cols": [_i, _i, _i, _l, _i, _p, _p, _p, _p, _p, _p, _p, _p, _i, _p, _p, _p, _p],
+    "istnet_pw_forward_cols": [_i, _i, _l, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p],
+    "istnet_bn_relu_pool_cols": [_i, _i, _i, _l, _p, _p, _p, _p, _l, _p, _p, _p],
+    "istnet_pw_pooled_grad_cols": [_i, _i, _i, _l, _p, _l, _p, _p, _p, _p, _p],
+    "istnet_pw_bwd_small_cols_splits": [],
+    "istnet_pw_bwd_small_cols": [_i, _i, _l, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p],
+    "istnet_pw_dwx_cols_chunks": [_i],
+    "istnet_pw_dwx_cols": [_i, _l, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p],
 }
 
 _lib = None

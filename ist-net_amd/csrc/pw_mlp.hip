@@ -170,9 +170,22 @@ __global__ __launch_bounds__(kThreads) void pw_fwd_kernel(
     int cin, int cout, int P, int tiles_per_cloud, const float* __restrict__ x, GatherSrc gsrc,
     const float* __restrict__ w, const float* __restrict__ in_scale, const float* __restrict__ in_shift,
     float* __restrict__ y, float* __restrict__ part_sum, float* __restrict__ part_sq, int nt_total, int ldw,
-    const float* __restrict__ c_init) {
+    const float* __restrict__ c_init, const int* __restrict__ ncols, const float* __restrict__ colw) {
   using T = Tile<M_T, N_T, WM, WN>;
   constexpr int TM = T::TM, TN = T::TN;
+  // compact-column mode (csrc/sa_compact.hip): ONE point axis of static capacity P whose first *ncols columns are
+  // valid, colw = per-column multiplicity in the statistics.  A tile past the valid columns only zeroes its partials.
+  if (ncols != nullptr && (int)((blockIdx.x % tiles_per_cloud) * N_T) >= *ncols) {
+    if (part_sum != nullptr)
+      for (int rl = threadIdx.x; rl < M_T; rl += kThreads) {
+        const int row = blockIdx.y * M_T + rl;
+        if (row < cout) {
+          part_sum[(size_t)row * nt_total + blockIdx.x] = 0.f;
+          part_sq[(size_t)row * nt_total + blockIdx.x] = 0.f;
+        }
+      }
+    return;
+  }
   constexpr int NA = kKT * M_T / kThreads;        // scalar weight loads per thread per chunk
   constexpr int NB = kKT * N_T / 4 / kThreads;    // float4 activation loads per thread per chunk
   constexpr int LDA = M_T + 1;                    // w is (cout, cin): lanes walk k, odd stride spreads the banks
@@ -311,6 +324,10 @@ __global__ __launch_bounds__(kThreads) void pw_fwd_kernel(
   float* yb = y + (size_t)b * cout * P;
   float* red = &As[0][0][0];  // reuse LDS: [WN][M_T][2]
   const bool full_tile = (m0 + M_T <= cout) && (p0 + N_T <= P);  // workgroup-uniform
+  float wcol[TN];                                                  // column multiplicities (compact-column mode)
+#pragma unroll
+  for (int tn = 0; tn < TN; ++tn)
+    wcol[tn] = colw != nullptr ? colw[min(p0 + b_col0 + tn * 32 + (lane & 31), P - 1)] : 1.f;
 #pragma unroll
   for (int tm = 0; tm < TM; ++tm) {
 #pragma unroll
@@ -323,8 +340,8 @@ __global__ __launch_bounds__(kThreads) void pw_fwd_kernel(
         for (int tn = 0; tn < TN; ++tn) {
           const float v = acc[tm][tn][r];
           yb[(size_t)row * P + p0 + b_col0 + tn * 32 + (lane & 31)] = v;
-          s += v;
-          q += v * v;
+          s += wcol[tn] * v;
+          q += wcol[tn] * v * v;
         }
       } else {
 #pragma unroll
@@ -333,8 +350,8 @@ __global__ __launch_bounds__(kThreads) void pw_fwd_kernel(
           const float v = acc[tm][tn][r];
           if (row < cout && col < P) {
             yb[(size_t)row * P + col] = v;
-            s += v;
-            q += v * v;
+            s += wcol[tn] * v;
+            q += wcol[tn] * v * v;
           }
         }
       }
@@ -1553,13 +1570,20 @@ __global__ __launch_bounds__(kThreads, ISTNET_BWD_SMALL_WAVES) void pw_bwd_small
     const float* __restrict__ x, const float* __restrict__ in_scale, const float* __restrict__ in_shift,
     const float* __restrict__ y, GradSrc gs, const float* __restrict__ bn, const float* __restrict__ bwdc,
     float* __restrict__ dx, float* __restrict__ part_g, float* __restrict__ part_gy, int nt_total,
-    float* __restrict__ dw_part) {
+    float* __restrict__ dw_part, const int* __restrict__ ncols, const float* __restrict__ colw) {
   constexpr int LD = 33;
   __shared__ float lds[4][2][kKTW][LD];  // [wave][dY | raw x][k = point][row = channel]
   __shared__ float s_in[2][32];          // BN constants of the input layer
+  __shared__ float s_w[4][kKTW];         // column multiplicities of a wave's chunk (compact-column mode)
   const int lane = lane_id(), wv = wave_id();
+  if (ncols != nullptr) {                // compact columns: the valid range and an even split of it come from the device
+    total = ((long long)*ncols + kKTW - 1) / kKTW * kKTW;
+    const long long per = (total + gridDim.x - 1) / gridDim.x;
+    split_len = (int)((per + 4 * kKTW - 1) / (4 * kKTW) * (4 * kKTW));
+  }
+  const bool weighted = colw != nullptr;
   const long long qbeg = (long long)blockIdx.x * split_len;
-  const long long qend = min(qbeg + (long long)split_len, total);
+  const long long qend = max(qbeg, min(qbeg + (long long)split_len, total));
   float* As = &lds[wv][0][0][0];
   float* Bs = &lds[wv][1][0][0];
   if (threadIdx.x < 32) {
@@ -1651,6 +1675,7 @@ __global__ __launch_bounds__(kThreads, ISTNET_BWD_SMALL_WAVES) void pw_bwd_small
   for (; t < nchunks; t += 4) {
     const long long qk = qbeg + (long long)t * kKTW;
     store_chunk(qk);                                                // wave-private LDS: no workgroup barrier
+    if (weighted && lane < kKTW) s_w[wv][lane] = colw[min(qk, total - kKTW) + lane];
     __builtin_amdgcn_sched_barrier(0);                              // the next loads reuse the registers just consumed
     if (t + 4 < nchunks) load_chunk(qbeg + (long long)(t + 4) * kKTW);  // in flight during the MFMAs
     __builtin_amdgcn_s_waitcnt(0xc07f);                             // lgkmcnt(0): this wave's ds_writes landed
@@ -1669,7 +1694,8 @@ __global__ __launch_bounds__(kThreads, ISTNET_BWD_SMALL_WAVES) void pw_bwd_small
       const int cur = kk & 1, nxt = cur ^ 1;
       if (kk + 1 < 16) { fa[nxt] = ap[2 * (kk + 1) * LD]; fb[nxt] = bp[2 * (kk + 1) * LD]; ft[nxt] = tp[2 * (kk + 1)]; }
       __builtin_amdgcn_sched_barrier(0);
-      const float bx = fmaxf(fb[cur] * bsc + bsh, 0.f);
+      float bx = fmaxf(fb[cur] * bsc + bsh, 0.f);
+      if (weighted) bx *= s_w[wv][2 * kk + (lane >> 5)];                                // multiplicity of point 2kk + half
       accw = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur], bx, accw, 0, 0, 0);         // dW[co][ci] += dY . act(x)^T
       accd = __builtin_amdgcn_mfma_f32_32x32x2f32(ft[cur], wfrag[kk], accd, 0, 0, 0);  // dA^T[pt][ci] = dY^T . W
       __builtin_amdgcn_sched_barrier(0);
@@ -1691,7 +1717,8 @@ __global__ __launch_bounds__(kThreads, ISTNET_BWD_SMALL_WAVES) void pw_bwd_small
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
           const float yin = Bs[(pt0 + u) * LD + ci];
-          const float gq = (yin * bsc + bsh > 0.f) ? accd[4 * j + u] : 0.f;
+          float gq = (yin * bsc + bsh > 0.f) ? accd[4 * j + u] : 0.f;
+          if (weighted) gq *= s_w[wv][pt0 + u];
           sg += gq;
           sgy += gq * yin;
         }
@@ -1901,7 +1928,8 @@ int istnet_pw_stat_tiles(int b, int cout, int p) {
 
 static int launch_pw_forward(bool gather, int b, int cin, int cout, int p, const float* x, const GatherSrc& g,
                              const float* w, int ldw, const float* in_scale, const float* in_shift, float* y,
-                             float* part_sum, float* part_sq, void* stream, const float* c_init = nullptr) {
+                             float* part_sum, float* part_sq, void* stream, const float* c_init = nullptr,
+                             const int* ncols = nullptr, const float* colw = nullptr) {
   if (b <= 0 || cin <= 0 || cout <= 0 || p <= 0 || (p & 3)) return ISTNET_PN2_EINVAL;
   const TileCfg cfg = pick_cfg(b, cout, p, g_force_fwd_cfg);
   const int tpc = ceil_div(p, cfg_nt(cfg));
@@ -1912,13 +1940,13 @@ static int launch_pw_forward(bool gather, int b, int cin, int cout, int p, const
   do {                                                                                                      \
     if (mode == 2)                                                                                          \
       hipLaunchKernelGGL((pw_fwd_kernel<MT, NT, WM, WN, 2>), grid, dim3(kThreads), 0, as_stream(stream),    \
-                         cin, cout, p, tpc, x, g, w, in_scale, in_shift, y, part_sum, part_sq, nt, ldw, c_init); \
+                         cin, cout, p, tpc, x, g, w, in_scale, in_shift, y, part_sum, part_sq, nt, ldw, c_init, ncols, colw); \
     else if (mode == 1)                                                                                     \
       hipLaunchKernelGGL((pw_fwd_kernel<MT, NT, WM, WN, 1>), grid, dim3(kThreads), 0, as_stream(stream),    \
-                         cin, cout, p, tpc, x, g, w, in_scale, in_shift, y, part_sum, part_sq, nt, ldw, c_init); \
+                         cin, cout, p, tpc, x, g, w, in_scale, in_shift, y, part_sum, part_sq, nt, ldw, c_init, ncols, colw); \
     else                                                                                                    \
       hipLaunchKernelGGL((pw_fwd_kernel<MT, NT, WM, WN, 0>), grid, dim3(kThreads), 0, as_stream(stream),    \
-                         cin, cout, p, tpc, x, g, w, in_scale, in_shift, y, part_sum, part_sq, nt, ldw, c_init); \
+                         cin, cout, p, tpc, x, g, w, in_scale, in_shift, y, part_sum, part_sq, nt, ldw, c_init, ncols, colw); \
   } while (0)
   switch (cfg) {
     case kCfg128x128: ISTNET_FWD(128, 128, 2, 2); break;
@@ -1951,6 +1979,14 @@ int istnet_pw_forward_acc(int b, int cin, int cout, int p, const float* x, const
   if (ldw < cin || c_init == nullptr) return ISTNET_PN2_EINVAL;
   return launch_pw_forward(false, b, cin, cout, p, x, GatherSrc{}, w, ldw, nullptr, nullptr, y, part_sum, part_sq,
                            stream, c_init);
+}
+
+int istnet_pw_forward_cols(int cin, int cout, long long cap, const float* x, const float* w, const float* in_scale,
+                           const float* in_shift, float* y, float* part_sum, float* part_sq, const int* ncols,
+                           const float* colw, void* stream) {
+  if (cap <= 0 || (cap & 255) || cap >= (1LL << 31) || ncols == nullptr || colw == nullptr) return ISTNET_PN2_EINVAL;
+  return launch_pw_forward(false, 1, cin, cout, (int)cap, x, GatherSrc{}, w, cin, in_scale, in_shift, y, part_sum,
+                           part_sq, stream, nullptr, ncols, colw);
 }
 
 int istnet_pw_gather_add_tiles(int b, int p) { return b * ceil_div(p, 256); }
@@ -2288,11 +2324,30 @@ int istnet_pw_bwd_small(int b, int cin, int cout, int p, int nsample, const floa
   if (d_dense != nullptr)
     hipLaunchKernelGGL(pw_bwd_small_kernel<false>, dim3(splits), dim3(kThreads), 0, as_stream(stream), cin, cout, p,
                        (long long)b * p, len, w, x, bn_in, bn_in + cin, y, gs, bn, bwdc, dx, part_g, part_gy, splits,
-                       dw_part);
+                       dw_part, nullptr, nullptr);
   else
     hipLaunchKernelGGL(pw_bwd_small_kernel<true>, dim3(splits), dim3(kThreads), 0, as_stream(stream), cin, cout, p,
                        (long long)b * p, len, w, x, bn_in, bn_in + cin, y, gs, bn, bwdc, dx, part_g, part_gy, splits,
-                       dw_part);
+                       dw_part, nullptr, nullptr);
+  return (int)hipGetLastError();
+}
+
+// compact-column form (csrc/sa_compact.hip): one point axis of capacity `cap`, *ncols valid columns, column
+// multiplicities colw in the weight gradient and the statistics; dense gradient source only
+int istnet_pw_bwd_small_cols_splits(void) { return g_bwd_small_target; }
+
+int istnet_pw_bwd_small_cols(int cin, int cout, long long cap, const float* w, const float* x, const float* bn_in,
+                             const float* y, const float* d_dense, const float* bn, const float* bwdc, float* dx,
+                             float* part_g, float* part_gy, float* dw_part, const int* ncols, const float* colw,
+                             void* stream) {
+  if (cap <= 0 || (cap & 255) || cap >= (1LL << 31) || !istnet_pw_bwd_small_ok(cin, cout, (int)cap)) return ISTNET_PN2_EINVAL;
+  if (!w || !x || !bn_in || !y || !d_dense || !bn || !bwdc || !dx || !part_g || !part_gy || !dw_part || !ncols || !colw)
+    return ISTNET_PN2_EINVAL;
+  GradSrc gs{d_dense, nullptr, nullptr, 0, 0, cout};
+  const int splits = g_bwd_small_target;
+  hipLaunchKernelGGL(pw_bwd_small_kernel<false>, dim3(splits), dim3(kThreads), 0, as_stream(stream), cin, cout,
+                     (int)cap, cap, 0, w, x, bn_in, bn_in + cin, y, gs, bn, bwdc, dx, part_g, part_gy, splits, dw_part,
+                     ncols, colw);
   return (int)hipGetLastError();
 }
 

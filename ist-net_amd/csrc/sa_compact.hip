@@ -1,0 +1,344 @@
+// sa_compact.hip -- compact-column form of a set-abstraction scale (gfx950).
+//
+// The reference pads every ball-query row to nsample slots by repeating the row's first hit
+// (ball_query_gpu.cu:38-45), and QueryAndGroup / SharedMLP / max_pool2d then process the padded slots like any
+// other (pointnet2_utils.py:348-358, pointnet2_modules.py:61-68).  With the radii of IST-Net (model/ist_net.py:16)
+// most slots of the fine levels are such repeats: 83 % / 67 % of level 1 and 68 % / 36 % of level 2 on the benchmark
+// clouds (tools/ball_padding_stats.py).  A repeated slot carries the same input as slot 0 of its group, hence the
+// same activations in every layer of the per-point MLP; its only footprint is its MULTIPLICITY in the sums taken
+// over points -- BatchNorm statistics forward and backward, weight gradients, the layer-0 gradient scatter.
+//
+// So a scale can be evaluated on COMPACT columns: per group its `cnt` distinct neighbours followed, when the row is
+// padded, by ONE representative of the nsample - cnt repeats, which carries that multiplicity as a column weight
+// (the representative keeps its own column because its gradient differs from slot 0's: the max-pool routes to the
+// first maximum, never to a repeat).  Columns of all groups of all clouds are concatenated on one point axis
+// of static capacity B * npoint * nsample; the number of valid columns T lives in device memory, so launches keep
+// static grids (HIP-graph capturable) and workgroups past T leave at once.  Results equal the padded evaluation up
+// to fp32 summation order.
+//
+// This file: the compaction (column tables from the ball-query indices) and the kernels of a scale that are not
+// GEMMs (layer-0 gather-add, BN + ReLU + max over ragged groups, pooled gradient -> compact dense gradient, xyz
+// weight gradient).  The GEMM kernels of csrc/pw_mlp.hip take the same (T, column weight) pair.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/istnet_pw.h"
+
+namespace {
+
+__device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
+template <int CTRL, int ROW_MASK = 0xf>
+__device__ __forceinline__ float dpp_f(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xf, false));
+}
+__device__ __forceinline__ float wave_sum(float v) {
+  v += dpp_f<0x111>(v);
+  v += dpp_f<0x112>(v);
+  v += dpp_f<0x114>(v);
+  v += dpp_f<0x118>(v);
+  v += dpp_f<0x142, 0xa>(v);
+  v += dpp_f<0x143, 0xc>(v);
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
+inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+
+// ---- compaction ------------------------------------------------------------------------------------------------
+// glen[g] = columns of group g = cnt + (cnt < S), cnt = distinct leading entries of the row (a valid entry never
+// equals the row's first hit again: valid entries ascend strictly, ball_query_gpu.cu:33-47).
+__global__ __launch_bounds__(256) void compact_count_kernel(int NG, int S, const int* __restrict__ idx,
+                                                            int* __restrict__ glen) {
+  const int g = blockIdx.x * 256 + threadIdx.x;
+  if (g >= NG) return;
+  const int* row = idx + (size_t)g * S;
+  const int first = row[0];
+  int cnt = 1;
+  for (int s = 1; s < S; ++s) cnt += row[s] != first ? 1 : 0;
+  glen[g] = cnt + (cnt < S ? 1 : 0);
+}
+// gstart = exclusive scan of glen over all NG groups (one workgroup; NG <= 1024 * 64), gstart[NG] = T
+__global__ __launch_bounds__(1024) void compact_scan_kernel(int NG, const int* __restrict__ glen,
+                                                            int* __restrict__ gstart) {
+  __shared__ int part[1024];
+  const int tid = threadIdx.x;
+  const int per = (NG + 1023) / 1024;
+  const int lo = min(tid * per, NG), hi = min(lo + per, NG);
+  int s = 0;
+  for (int i = lo; i < hi; ++i) s += glen[i];
+  part[tid] = s;
+  __syncthreads();
+  for (int d = 1; d < 1024; d <<= 1) {          // Hillis-Steele inclusive scan
+    const int v = tid >= d ? part[tid - d] : 0;
+    __syncthreads();
+    part[tid] += v;
+    __syncthreads();
+  }
+  int run = part[tid] - s;
+  for (int i = lo; i < hi; ++i) { gstart[i] = run; run += glen[i]; }
+  if (tid == 1023) gstart[NG] = part[1023];
+}
+// column tables: cidx[p] = global source point (cloud * n + point), meta[p] = group * 64 + position in the group,
+// colw[p] = multiplicity; columns T .. roundup(T, 256) - 1 are null columns (weight 0, a valid address) so that tiles
+// straddling T compute finite values
+__global__ __launch_bounds__(256) void compact_fill_kernel(int NG, int G, int S, int n, const int* __restrict__ idx,
+                                                           const int* __restrict__ gstart, int* __restrict__ cidx,
+                                                           int* __restrict__ meta, float* __restrict__ colw) {
+  const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+  const long long total = (long long)NG * S;
+  if (e < 256) {                                  // tail (also covers T == 0)
+    const int T = gstart[NG];
+    const long long p = T + e;
+    if (p < ((long long)T + 255) / 256 * 256 && p < total) { cidx[p] = 0; meta[p] = 0; colw[p] = 0.f; }
+  }
+  if (e >= total) return;
+  const int g = (int)(e / S), s = (int)(e - (long long)g * S);
+  const int* row = idx + (size_t)g * S;
+  const int first = row[0], len = gstart[g + 1] - gstart[g];
+  const int cnt = len < S ? len - 1 : (row[S - 1] != first || S == 1 ? S : S - 1);
+  // cnt: len == cnt + 1 when padded; len == S means either cnt == S, or cnt == S - 1 with one repeat
+  const int b = g / G;
+  const int base = gstart[g];
+  if (s < cnt) {
+    cidx[base + s] = b * n + row[s];
+    meta[base + s] = g * 64 + s;
+    colw[base + s] = 1.f;
+  } else if (s == cnt) {                          // the representative of the S - cnt repeats of slot 0
+    cidx[base + s] = b * n + first;
+    meta[base + s] = g * 64 + s;
+    colw[base + s] = (float)(S - cnt);
+  }
+}
+
+// ---- layer 0: y0[c][p] = z[cloud][c][point] + W0x[c] . (xyz[source] - centre[group]), weighted statistics ------------
+constexpr int kGatherAddCO = 32;
+__global__ __launch_bounds__(256) void gather_add_cols_kernel(int n, int G, long long cap, int cout, int ldw,
+                                                              const float* __restrict__ xyz,
+                                                              const float* __restrict__ new_xyz,
+                                                              const int* __restrict__ cidx,
+                                                              const int* __restrict__ meta,
+                                                              const float* __restrict__ colw,
+                                                              const int* __restrict__ ncols,
+                                                              const float* __restrict__ z,
+                                                              const float* __restrict__ w0, float* __restrict__ y,
+                                                              float* __restrict__ part_sum,
+                                                              float* __restrict__ part_sq, int nt_total) {
+  __shared__ float wx[kGatherAddCO * 3];
+  __shared__ float red[4][kGatherAddCO][2];
+  const int tid = threadIdx.x;
+  const int c0 = blockIdx.y * kGatherAddCO;
+  const int nco = min(kGatherAddCO, cout - c0);
+  const bool stats = part_sum != nullptr;
+  const long long p = (long long)blockIdx.x * 256 + tid;
+  if ((long long)blockIdx.x * 256 >= *ncols) {      // tile past the valid columns
+    if (stats && tid < nco) {
+      part_sum[(size_t)(c0 + tid) * nt_total + blockIdx.x] = 0.f;
+      part_sq[(size_t)(c0 + tid) * nt_total + blockIdx.x] = 0.f;
+    }
+    return;
+  }
+  if (tid < nco * 3) wx[tid] = w0[(size_t)(c0 + tid / 3) * ldw + (tid % 3)];
+  const int src = cidx[p], g = meta[p] >> 6;
+  const float wcol = colw[p];
+  const float* xs = xyz + (size_t)src * 3;
+  const float* xc = new_xyz + (size_t)g * 3;
+  const float dx = xs[0] - xc[0], dy = xs[1] - xc[1], dz = xs[2] - xc[2];
+  const int cloud = g / G;
+  const float* zb = z != nullptr ? z + ((size_t)cloud * cout + c0) * n + (src - cloud * n) : nullptr;
+  float* yb = y + (size_t)c0 * cap + p;
+  __syncthreads();
+  const int wv = tid >> 6;
+  for (int co = 0; co < nco; co += 4) {
+    float zv[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) zv[j] = zb != nullptr ? zb[(size_t)min(co + j, nco - 1) * n] : 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      if (co + j < nco) {
+        const int c = co + j;
+        const float v = zv[j] + ((wx[3 * c] * dx + wx[3 * c + 1] * dy) + wx[3 * c + 2] * dz);
+        yb[(size_t)c * cap] = v;
+        if (stats) {
+          const float s = wave_sum(wcol * v), q = wave_sum(wcol * v * v);
+          if ((tid & 63) == 0) { red[wv][c][0] = s; red[wv][c][1] = q; }
+        }
+      }
+    }
+  }
+  if (stats) {
+    __syncthreads();
+    if (tid < nco) {
+      part_sum[(size_t)(c0 + tid) * nt_total + blockIdx.x] = (red[0][tid][0] + red[1][tid][0]) + (red[2][tid][0] + red[3][tid][0]);
+      part_sq[(size_t)(c0 + tid) * nt_total + blockIdx.x] = (red[0][tid][1] + red[1][tid][1]) + (red[2][tid][1] + red[3][tid][1]);
+    }
+  }
+}
+
+// ---- tail: out[cloud][c][group] = max over the group's columns of relu(bn(y)); arg = position of the first maximum --
+__global__ __launch_bounds__(256) void bn_relu_pool_cols_kernel(int C, int G, int NG, long long cap,
+                                                                const float* __restrict__ y,
+                                                                const float* __restrict__ scale,
+                                                                const float* __restrict__ shift,
+                                                                const int* __restrict__ gstart,
+                                                                float* __restrict__ out, long long out_bstride,
+                                                                uint8_t* __restrict__ arg, float* __restrict__ ymax) {
+  const int c = blockIdx.y;
+  const int g = blockIdx.x * 256 + threadIdx.x;
+  if (g >= NG) return;
+  const float s = scale[c], h = shift[c];
+  const int a = gstart[g], z = gstart[g + 1];
+  const float* row = y + (size_t)c * cap;
+  float best = -1.f, raw = 0.f;
+  int besti = 0;
+  for (int p = a; p < z; ++p) {
+    const float v = row[p];
+    const float act = fmaxf(v * s + h, 0.f);
+    if (act > best) { best = act; besti = p - a; raw = v; }
+  }
+  const int cloud = g / G, j = g - cloud * G;
+  out[(size_t)cloud * out_bstride + (size_t)c * G + j] = best;
+  arg[((size_t)cloud * C + c) * G + j] = (uint8_t)besti;
+  if (ymax != nullptr) ymax[((size_t)cloud * C + c) * G + j] = raw;
+}
+
+// ---- gradient through the max-pool as a dense compact tensor: dA[c][p] = dO[cloud][c][group] at the arg-max column ----
+__global__ __launch_bounds__(256) void pooled_grad_cols_kernel(int C, int G, long long cap,
+                                                               const float* __restrict__ pooled,
+                                                               long long pooled_bstride,
+                                                               const uint8_t* __restrict__ arg,
+                                                               const int* __restrict__ meta,
+                                                               const int* __restrict__ ncols,
+                                                               float* __restrict__ out) {
+  const long long p = (long long)blockIdx.x * 256 + threadIdx.x;
+  if ((long long)blockIdx.x * 256 >= *ncols) return;
+  const int m = meta[p], g = m >> 6, k = m & 63;
+  const int cloud = g / G, j = g - cloud * G;
+  const int c0 = blockIdx.y * 8;
+#pragma unroll
+  for (int u = 0; u < 8; ++u) {
+    const int c = c0 + u;
+    if (c < C) {
+      const int a = arg[((size_t)cloud * C + c) * G + j];
+      out[(size_t)c * cap + p] = a == k ? pooled[(size_t)cloud * pooled_bstride + (size_t)c * G + j] : 0.f;
+    }
+  }
+}
+
+// ---- xyz weight gradient of layer 0: dwx[chunk][c][k] = sum_p w_p dY0[c][p] (xyz[source_p] - centre_p)[k] ----------
+constexpr int kDwxCH = 4;
+__global__ __launch_bounds__(256) void dwx_cols_kernel(int cout, long long cap, const float* __restrict__ y,
+                                                       const float* __restrict__ d, const float* __restrict__ bn,
+                                                       const float* __restrict__ bwdc,
+                                                       const int* __restrict__ cidx, const int* __restrict__ meta,
+                                                       const float* __restrict__ colw,
+                                                       const int* __restrict__ ncols, const float* __restrict__ xyz,
+                                                       const float* __restrict__ new_xyz, float* __restrict__ dwx) {
+  const int c0 = blockIdx.x * kDwxCH;
+  const int nch = min(kDwxCH, cout - c0);
+  const int T = *ncols;
+  const int chunks = gridDim.y;
+  const long long per = (((long long)T + chunks - 1) / chunks + 255) / 256 * 256;
+  const long long beg = (long long)blockIdx.y * per, end = min(beg + per, (long long)T);
+  float acc[kDwxCH][3];
+#pragma unroll
+  for (int ch = 0; ch < kDwxCH; ++ch) acc[ch][0] = acc[ch][1] = acc[ch][2] = 0.f;
+  float rs[kDwxCH], rh[kDwxCH], ca[kDwxCH], cb[kDwxCH], cc[kDwxCH];
+#pragma unroll
+  for (int ch = 0; ch < kDwxCH; ++ch) {
+    const int co = min(c0 + ch, cout - 1);
+    rs[ch] = bn[co]; rh[ch] = bn[cout + co];
+    ca[ch] = bwdc[co]; cb[ch] = bwdc[cout + co]; cc[ch] = bwdc[2 * cout + co];
+  }
+  for (long long p = beg + threadIdx.x; p < end; p += 256) {
+    const int src = cidx[p], g = meta[p] >> 6;
+    const float wcol = colw[p];
+    const float* xs = xyz + (size_t)src * 3;
+    const float* xc = new_xyz + (size_t)g * 3;
+    const float x0 = (xs[0] - xc[0]) * wcol, x1 = (xs[1] - xc[1]) * wcol, x2 = (xs[2] - xc[2]) * wcol;
+#pragma unroll
+    for (int ch = 0; ch < kDwxCH; ++ch) {
+      const size_t o = (size_t)min(c0 + ch, cout - 1) * cap + p;
+      const float yv = y[o];
+      const float v = ca[ch] * ((yv * rs[ch] + rh[ch] > 0.f) ? d[o] : 0.f) + cb[ch] + cc[ch] * yv;
+      acc[ch][0] += v * x0; acc[ch][1] += v * x1; acc[ch][2] += v * x2;
+    }
+  }
+  __shared__ float wred[4][kDwxCH * 3];
+#pragma unroll
+  for (int ch = 0; ch < kDwxCH; ++ch)
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const float t = wave_sum(acc[ch][k]);
+      if (lane_id() == 0) wred[threadIdx.x >> 6][ch * 3 + k] = t;
+    }
+  __syncthreads();
+  if (threadIdx.x < nch * 3)
+    dwx[((size_t)blockIdx.y * cout + c0) * 3 + threadIdx.x] =
+        (wred[0][threadIdx.x] + wred[1][threadIdx.x]) + (wred[2][threadIdx.x] + wred[3][threadIdx.x]);
+}
+
+}  // namespace
+
+extern "C" {
+
+int istnet_sa_compact(int b, int g, int s, int n, const int* idx, int* glen, int* gstart, int* cidx, int* meta,
+                      float* colw, void* stream) {
+  if (b <= 0 || g <= 0 || s <= 0 || s > 64 || n <= 0 || !idx || !glen || !gstart || !cidx || !meta || !colw)
+    return ISTNET_PN2_EINVAL;
+  const long long ng = (long long)b * g;
+  if (ng > 1024 * 64 || ng * s >= (1LL << 31) || ng >= (1 << 25)) return ISTNET_PN2_EINVAL;
+  hipLaunchKernelGGL(compact_count_kernel, dim3(ceil_div((int)ng, 256)), dim3(256), 0, as_stream(stream), (int)ng, s,
+                     idx, glen);
+  hipLaunchKernelGGL(compact_scan_kernel, dim3(1), dim3(1024), 0, as_stream(stream), (int)ng, glen, gstart);
+  hipLaunchKernelGGL(compact_fill_kernel, dim3((unsigned)((ng * s + 255) / 256)), dim3(256), 0, as_stream(stream),
+                     (int)ng, g, s, n, idx, gstart, cidx, meta, colw);
+  return (int)hipGetLastError();
+}
+
+int istnet_pw_gather_add_cols(int b, int n, int g, long long cap, int cout, const float* xyz, const float* new_xyz,
+                              const int* cidx, const int* meta, const float* colw, const int* ncols, const float* z,
+                              const float* w0, int ldw, float* y, float* part_sum, float* part_sq, void* stream) {
+  if (b <= 0 || n <= 0 || g <= 0 || cap <= 0 || (cap & 255) || cout <= 0 || ldw < 3 || !cidx || !meta || !colw || !ncols)
+    return ISTNET_PN2_EINVAL;
+  const dim3 grid((unsigned)(cap / 256), ceil_div(cout, kGatherAddCO));
+  hipLaunchKernelGGL(gather_add_cols_kernel, grid, dim3(256), 0, as_stream(stream), n, g, cap, cout, ldw, xyz, new_xyz,
+                     cidx, meta, colw, ncols, z, w0, y, part_sum, part_sq, (int)(cap / 256));
+  return (int)hipGetLastError();
+}
+
+int istnet_bn_relu_pool_cols(int b, int c, int g, long long cap, const float* y, const float* bn, const int* gstart,
+                             float* out, long long out_bstride, unsigned char* arg, float* ymax, void* stream) {
+  if (b <= 0 || c <= 0 || g <= 0 || cap <= 0 || !y || !bn || !gstart || !out || !arg) return ISTNET_PN2_EINVAL;
+  if (out_bstride <= 0) out_bstride = (long long)c * g;
+  const int ng = b * g;
+  hipLaunchKernelGGL(bn_relu_pool_cols_kernel, dim3(ceil_div(ng, 256), c), dim3(256), 0, as_stream(stream), c, g, ng,
+                     cap, y, bn, bn + c, gstart, out, out_bstride, arg, ymax);
+  return (int)hipGetLastError();
+}
+
+int istnet_pw_pooled_grad_cols(int b, int c, int g, long long cap, const float* d_pooled, long long pooled_bstride,
+                               const unsigned char* arg, const int* meta, const int* ncols, float* out, void* stream) {
+  if (b <= 0 || c <= 0 || g <= 0 || cap <= 0 || (cap & 255) || !d_pooled || !arg || !meta || !ncols || !out)
+    return ISTNET_PN2_EINVAL;
+  if (pooled_bstride <= 0) pooled_bstride = (long long)c * g;
+  hipLaunchKernelGGL(pooled_grad_cols_kernel, dim3((unsigned)(cap / 256), ceil_div(c, 8)), dim3(256), 0,
+                     as_stream(stream), c, g, cap, d_pooled, pooled_bstride, arg, meta, ncols, out);
+  return (int)hipGetLastError();
+}
+
+int istnet_pw_dwx_cols_chunks(int cout) {
+  const int wgs = ceil_div(cout, kDwxCH);
+  return ceil_div(1024, wgs > 0 ? wgs : 1);
+}
+
+int istnet_pw_dwx_cols(int cout, long long cap, const float* y, const float* d_dense, const float* bn,
+                       const float* bwdc, const int* cidx, const int* meta, const float* colw, const int* ncols,
+                       const float* xyz, const float* new_xyz, float* dwx, void* stream) {
+  if (cout <= 0 || cap <= 0 || !y || !d_dense || !bn || !bwdc || !cidx || !meta || !colw || !ncols || !xyz ||
+      !new_xyz || !dwx)
+    return ISTNET_PN2_EINVAL;
+  hipLaunchKernelGGL(dwx_cols_kernel, dim3(ceil_div(cout, kDwxCH), istnet_pw_dwx_cols_chunks(cout)), dim3(256), 0,
+                     as_stream(stream), cout, cap, y, d_dense, bn, bwdc, cidx, meta, colw, ncols, xyz, new_xyz, dwx);
+  return (int)hipGetLastError();
+}
+
+}  // extern "C"

@@ -40,7 +40,8 @@ class GeometrySlot:
     ``forward(..., geometry=slot)``.  Two slots ping-pong in a pipelined training loop."""
 
     def __init__(self):
-        self.sa = None       # per level: (new_xyz, [idx per scale], [inverse lists of idx per scale] or None)
+        self.sa = None       # per level: (new_xyz, [idx per scale], [inverse lists per scale] or None,
+                             #             [compact-column tables per scale] or None)
         self.fp = None       # per FP level: (idx, weight, csr or None)
         self.event = None    # recorded on the geometry stream after the last write (eager mode)
         self.shape = None
@@ -48,10 +49,12 @@ class GeometrySlot:
 
     def tensors(self):
         out = []
-        for new_xyz, idxs, csrs in self.sa:
+        for new_xyz, idxs, csrs, comps in self.sa:
             out += [new_xyz, *idxs]
             for csr in (csrs or ()):
                 out += list(csr)
+            for comp in (comps or ()):
+                out += comp.tensors()
         for idx, weight, csr in self.fp:
             out += [idx, weight, *(csr if csr is not None else ())]
         return out
@@ -97,9 +100,14 @@ class PointNet2MSG(nn.Module):
             for sa in self.SA_modules:
                 new_xyz = sa._sample_centroids(cur)
                 idx = [pointnet2_utils.ball_query(g.radius, g.nsample, cur, new_xyz) for g in sa.groupers]
+                comps = None
+                ball_compact = getattr(pointnet2_utils._ext, "ball_compact", None)   # absent from a plain reference _ext
+                if ball_compact is not None and len(sa_geo) in fused_mlp.COMPACT_LEVELS:
+                    comps = [ball_compact(i, cur.shape[1]) for i in idx]
+                    comps = comps if all(c is not None for c in comps) else None
                 ev = torch.cuda.Event()
                 ev.record(side)
-                sa_geo.append([new_xyz, idx, ev, None])
+                sa_geo.append([new_xyz, idx, ev, None, comps])
                 levels.append(new_xyz)
                 cur = new_xyz
             for lvl in range(len(self.FP_modules) - 1, -1, -1):
@@ -153,7 +161,7 @@ class PointNet2MSG(nn.Module):
         side = _geometry_stream(xyz.device)
         with torch.cuda.stream(side), torch.no_grad():
             fresh = GeometrySlot()
-            fresh.sa = [(new_xyz, list(idx), csrs) for new_xyz, idx, _, csrs in sa_geo]
+            fresh.sa = [(new_xyz, list(idx), csrs, comps) for new_xyz, idx, _, csrs, comps in sa_geo]
             fresh.fp = [(idx, weight, csr) for idx, weight, csr, _ in fp_geo]
             src = fresh.tensors()
             if slot.sa is None or slot.shape != tuple(xyz.shape) or len(src) != len(slot.tensors()):
@@ -168,8 +176,9 @@ class PointNet2MSG(nn.Module):
                     off[t.dtype] += t.numel()
                 it = iter(views)
                 slot.sa = [(next(it), [next(it) for _ in idxs],
-                            [(next(it), next(it)) for _ in csrs] if csrs is not None else None)
-                           for _, idxs, csrs in fresh.sa]
+                            [(next(it), next(it)) for _ in csrs] if csrs is not None else None,
+                            [c.with_tensors([next(it) for _ in c.tensors()]) for c in comps] if comps is not None else None)
+                           for _, idxs, csrs, comps in fresh.sa]
                 slot.fp = [(next(it), next(it), (next(it), next(it)) if csr is not None else None)
                            for _, _, csr in fresh.fp]
                 slot.shape = tuple(xyz.shape)
@@ -208,7 +217,7 @@ class PointNet2MSG(nn.Module):
             main = torch.cuda.current_stream(xyz.device)
             if geometry.event is not None and not torch.cuda.is_current_stream_capturing():
                 main.wait_event(geometry.event)   # inside a capture the prefetching graph has completed already
-            sa_geo = [(nx, idx, None, csrs) for nx, idx, csrs in geometry.sa]
+            sa_geo = [(nx, idx, None, csrs, comps) for nx, idx, csrs, comps in geometry.sa]
             fp_geo = [(i, w, csr, None) for i, w, csr in geometry.fp]
         elif self._can_prepass(xyz):
             sa_geo, fp_geo, csr_ev = self._geometry_prepass(xyz, with_ball_csr=torch.is_grad_enabled())
@@ -219,10 +228,10 @@ class PointNet2MSG(nn.Module):
             if sa_geo is None:
                 nxt_xyz, nxt_feat = sa(l_xyz[-1], l_features[-1])
             else:
-                new_xyz, idx, ev, csrs = sa_geo[i]
+                new_xyz, idx, ev, csrs, comps = sa_geo[i]
                 if ev is not None:
                     main.wait_event(ev)
-                nxt_xyz, nxt_feat = sa(l_xyz[-1], l_features[-1], geometry=(new_xyz, idx, csrs))
+                nxt_xyz, nxt_feat = sa(l_xyz[-1], l_features[-1], geometry=(new_xyz, idx, csrs, comps))
             l_xyz.append(nxt_xyz)
             l_features.append(nxt_feat)
             _native.mark(f"fwd SA{i + 1} done")

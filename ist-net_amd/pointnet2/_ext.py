@@ -200,6 +200,48 @@ def ball_csr(idx, n):
     return csr_multi([(idx, n)])[0]
 
 
+class BallCompact:
+    """Compact-column tables of one ball-query index tensor (csrc/sa_compact.hip): per group its distinct neighbours
+    plus one weighted representative of the padded repeats, all groups of all clouds on one point axis of static
+    capacity ``cap`` = B * npoint * nsample; the valid column count is ``gstart[-1]`` on the device."""
+    __slots__ = ("glen", "gstart", "cidx", "meta", "colw", "b", "g", "s", "n", "cap")
+
+    def __init__(self, glen, gstart, cidx, meta, colw, b, g, s, n):
+        self.glen, self.gstart, self.cidx, self.meta, self.colw = glen, gstart, cidx, meta, colw
+        self.b, self.g, self.s, self.n, self.cap = b, g, s, n, b * g * s
+
+    @property
+    def ncols_ptr(self):
+        return self.gstart.data_ptr() + 4 * self.b * self.g
+
+    def tensors(self):
+        return [self.glen, self.gstart, self.cidx, self.meta, self.colw]
+
+    def with_tensors(self, tensors):
+        return BallCompact(*tensors, self.b, self.g, self.s, self.n)
+
+
+def ball_compact(idx, n):
+    """Column tables for the compact evaluation of a set-abstraction scale from its ball-query indices
+    (B, npoint, nsample) over n source points per cloud; None when the shape is outside what the kernels take
+    (capacity must be a multiple of 256, nsample <= 64).  Depends on coordinates only."""
+    _contig(idx, "idx"); _is_int(idx, "idx")
+    dev = _device_of(idx, "idx")
+    b, g, s = idx.shape
+    cap = b * g * s
+    if cap % 256 or s > 64 or b * g > 1024 * 64 or cap >= 2 ** 31:
+        return None
+    glen = torch.empty(b * g, dtype=torch.int32, device=dev)
+    gstart = torch.empty(b * g + 1, dtype=torch.int32, device=dev)
+    cidx = torch.empty(cap, dtype=torch.int32, device=dev)
+    meta = torch.empty(cap, dtype=torch.int32, device=dev)
+    colw = torch.empty(cap, dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        _native.check(_native.lib().istnet_sa_compact(b, g, s, int(n), _ptr(idx), _ptr(glen), _ptr(gstart), _ptr(cidx),
+                                                      _ptr(meta), _ptr(colw), _stream(dev)), "sa_compact")
+    return BallCompact(glen, gstart, cidx, meta, colw, b, g, s, int(n))
+
+
 def three_interpolate_grad(grad_out, idx, weight, m, csr=None):
     """(B,C,n) f32, (B,n,3) i32, (B,n,3) f32, m -> (B,C,m).  interpolate.cpp:75-104
     ``csr``: optional result of interp_csr(idx, m) (extension of the reference signature)."""

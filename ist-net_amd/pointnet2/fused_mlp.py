@@ -182,11 +182,12 @@ class _Layer:
 
 class _Gather:
     """Layer-0 input of a set-abstraction scale described by its sources instead of a grouped tensor."""
-    __slots__ = ("xyz", "new_xyz", "feat", "idx", "n", "npoint", "nsample", "cfeat", "feat_t", "csr")
+    __slots__ = ("xyz", "new_xyz", "feat", "idx", "n", "npoint", "nsample", "cfeat", "feat_t", "csr", "compact")
 
-    def __init__(self, xyz, new_xyz, feat, idx, feat_t=None, csr=None):
+    def __init__(self, xyz, new_xyz, feat, idx, feat_t=None, csr=None, compact=None):
         self.xyz, self.new_xyz, self.feat, self.idx = xyz, new_xyz, feat, idx
         self.csr = csr           # (offsets, entries): inverse lists of idx over the n source points, or None
+        self.compact = compact   # _ext.BallCompact: evaluate the scale on compact columns (padded repeats once), or None
         self.feat_t = feat_t     # (B, n, C) point-major copy: contiguous float4 gathers in the layer-0 loaders
         self.n = xyz.shape[1]
         self.npoint, self.nsample = idx.shape[1], idx.shape[2]
@@ -199,6 +200,8 @@ def _forward_stack(lib, dev, st, b, c0, g, s, x, gather, training, layers, param
     ``out_spec`` = (tensor (B, Ctot, G), channel offset): write the pooled result into that channel slice
     (the MSG concat happens in place) instead of a fresh tensor."""
     p = g * s
+    if gather is not None and gather.compact is not None:
+        return _forward_stack_compact(lib, dev, st, b, g, s, gather, training, layers, params, out_spec)
     ys, bns = [], []
     cur, cur_c, in_bn = x, c0, None
     # layers whose normalisation is a fixed affine map (conv bias; eval-mode BatchNorm): their constant blocks depend
@@ -293,6 +296,58 @@ def _forward_stack(lib, dev, st, b, c0, g, s, x, gather, training, layers, param
     else:
         _native.check(lib.istnet_bn_relu_pool(b, cur_c, g, s, cur.data_ptr(), in_bn.data_ptr(), out_ptr,
                                               out_bstride, _p(arg), _ymax_ptr(arg, b * cur_c * g), st), "bn_relu_pool")
+    return out, arg, ys, bns
+
+
+def _forward_stack_compact(lib, dev, st, b, g, s, ga, training, layers, params, out_spec):
+    """_forward_stack on compact columns (xyz-only layer 0): activations are (1, C, cap) with the first T columns
+    valid, T on the device.  Statistics are weighted by the column multiplicities, so BatchNorm sees exactly the sums of
+    the padded evaluation (count = b * g * s)."""
+    cm = ga.compact
+    cap, ncols = cm.cap, cm.ncols_ptr
+    ys, bns = [], []
+    cur, cur_c, in_bn = None, 3, None
+    for li, lay in enumerate(layers):
+        w, gamma, beta = params[3 * li], params[3 * li + 1], params[3 * li + 2]
+        cout = w.shape[0]
+        w2 = w.reshape(cout, cur_c)
+        y = _empty((1, cout, cap), torch.float32, dev)
+        bn = _empty((4, cout), torch.float32, dev)
+        if training:
+            nt = cap // 256 if li == 0 else lib.istnet_pw_stat_tiles(1, cout, cap)
+            part = _empty((2, cout, nt), torch.float32, dev)
+            ps, pq = part[0].data_ptr(), part[1].data_ptr()
+        else:
+            nt, ps, pq = 0, None, None
+        if li == 0:
+            _native.check(lib.istnet_pw_gather_add_cols(
+                b, ga.n, g, cap, cout, ga.xyz.data_ptr(), ga.new_xyz.data_ptr(), cm.cidx.data_ptr(), cm.meta.data_ptr(),
+                cm.colw.data_ptr(), ncols, None, w2.data_ptr(), cur_c, y.data_ptr(), ps, pq, st), "pw_gather_add_cols")
+        else:
+            _native.check(lib.istnet_pw_forward_cols(
+                cur_c, cout, cap, cur.data_ptr(), w2.data_ptr(), in_bn[0].data_ptr(), in_bn[1].data_ptr(), y.data_ptr(),
+                ps, pq, ncols, cm.colw.data_ptr(), st), "pw_forward_cols")
+        if training:
+            _native.check(lib.istnet_bn_finalize_fwd(
+                cout, nt, float(b * g * s), ps, pq, gamma.data_ptr(), beta.data_ptr(), float(lay.eps),
+                float(lay.momentum), _p(lay.running_mean), _p(lay.running_var), bn.data_ptr(), st), "bn_finalize_fwd")
+        else:
+            _native.check(lib.istnet_affine_consts(cout, gamma.data_ptr(), beta.data_ptr(), lay.running_mean.data_ptr(),
+                                                   lay.running_var.data_ptr(), float(lay.eps), bn.data_ptr(), st),
+                          "affine_consts")
+        ys.append(y)
+        bns.append(bn)
+        cur, cur_c, in_bn = y, cout, bn
+    if out_spec is None:
+        out = _empty((b, cur_c, g), torch.float32, dev)
+        out_ptr, out_bstride = out.data_ptr(), 0
+    else:
+        out, coff = out_spec
+        out_ptr, out_bstride = out.data_ptr() + coff * g * 4, out.shape[1] * g
+    arg = _empty((_arg_bytes(b * cur_c * g) + 4 * b * cur_c * g,), torch.uint8, dev)
+    _native.check(lib.istnet_bn_relu_pool_cols(b, cur_c, g, cap, cur.data_ptr(), in_bn.data_ptr(), cm.gstart.data_ptr(),
+                                               out_ptr, out_bstride, arg.data_ptr(), _ymax_ptr(arg, b * cur_c * g), st),
+                  "bn_relu_pool_cols")
     return out, arg, ys, bns
 
 
@@ -404,6 +459,21 @@ def _wgrad_job(lib, dev, b, cin, cout, p, ns_arg, use_gather, ga, src, in_bn, y,
     return launch
 
 
+# Set-abstraction levels (0-based) whose scales are evaluated on compact columns (csrc/sa_compact.hip): the repeats that
+# pad a ball-query row are computed once and enter every sum over points with their multiplicity.  Level 0 (xyz only,
+# 16/16/32 channels) is where the padding is heaviest -- 83 % / 67 % of the slots on the benchmark clouds.
+COMPACT_LEVELS = frozenset() if os.environ.get("ISTNET_NO_COMPACT") is not None else frozenset({0})
+
+
+def _compact_ok(lib, ga, layers, params):
+    """The compact-column kernels cover: xyz-only layer 0 (no feature scatter), every later layer within the fused
+    small-layer backward (cin, cout <= 32)."""
+    if ga.compact is None or ga.cfeat != 0 or not USE_SPLIT_LAYER0 or not USE_FUSED_SMALL_BWD:
+        return False
+    widths = [params[3 * li].shape[0] for li in range(len(layers))]
+    return len(widths) >= 2 and all(lib.istnet_pw_bwd_small_ok(widths[li - 1], widths[li], 256) for li in range(1, len(widths)))
+
+
 USE_FUSED_SMALL_BWD = os.environ.get("ISTNET_NO_FUSED_SMALL_BWD") is None
 USE_SPLIT_LAYER0 = os.environ.get("ISTNET_NO_SPLIT_LAYER0") is None
 USE_CSR_SCATTER = os.environ.get("ISTNET_NO_CSR_SCATTER") is None
@@ -441,6 +511,9 @@ def _backward_stack(lib, dev, st, b, c0, g, s, x, gather, training, ys, bns, par
     ``scatter_out`` = (tensor (B, Rtot, n), row offset): the scattered dY0 of the scale goes into those rows and
     the caller finishes the feature gradient for all scales with one GEMM."""
     p = g * s
+    if gather is not None and gather.compact is not None:
+        return _backward_stack_compact(lib, dev, st, b, g, s, gather, training, ys, bns, params, arg, dout, need_w,
+                                       pooled_bstride)
     n = len(ys)
     grads = [None] * (3 * n)
     pooled = s > 1
@@ -589,6 +662,88 @@ def _backward_stack(lib, dev, st, b, c0, g, s, x, gather, training, ys, bns, par
     return grads, dx, scattered
 
 
+def _backward_stack_compact(lib, dev, st, b, g, s, ga, training, ys, bns, params, arg, dout, need_w, pooled_bstride):
+    """_backward_stack on compact columns (xyz-only scale: no input gradient).  The gradient through the max-pool becomes
+    a dense compact tensor once; every layer above layer 0 runs the fused small-layer backward with column weights;
+    layer 0's weight gradient is the weighted xyz reduction."""
+    cm = ga.compact
+    cap, ncols, colw = cm.cap, cm.ncols_ptr, cm.colw.data_ptr()
+    n = len(ys)
+    grads = [None] * (3 * n)
+    count = float(b * g * s)
+    wjobs, wlayers = [], []
+    d_dense, fused_part, fused_nt = None, None, 0
+    for li in range(n - 1, -1, -1):
+        w, gamma = params[3 * li], params[3 * li + 1]
+        cout = w.shape[0]
+        cin = 3 if li == 0 else params[3 * (li - 1)].shape[0]
+        y, bn = ys[li], bns[li]
+        if li == n - 1:      # through the max-pool: statistics from the (B, C, G) tensors, then the dense compact gradient
+            part, nt_l = _empty((2, cout, b), torch.float32, dev), b
+            _native.check(lib.istnet_pw_bwd_stats_pooled(b, cout, g, dout.data_ptr(), pooled_bstride,
+                                                         _ymax_ptr(arg, b * cout * g), bn.data_ptr(),
+                                                         part[0].data_ptr(), part[1].data_ptr(), st), "pw_bwd_stats_pooled")
+            d_dense = _empty((1, cout, cap), torch.float32, dev)
+            _native.check(lib.istnet_pw_pooled_grad_cols(b, cout, g, cap, dout.data_ptr(), pooled_bstride, arg.data_ptr(),
+                                                         cm.meta.data_ptr(), ncols, d_dense.data_ptr(), st),
+                          "pw_pooled_grad_cols")
+        else:
+            part, nt_l = fused_part, fused_nt
+        dgamma = _grad_dest(gamma, (cout,), dev)
+        dbeta = _grad_dest(params[3 * li + 2], (cout,), dev)
+        bwdc = _empty((3, cout), torch.float32, dev)
+        _native.check(lib.istnet_bn_finalize_bwd(
+            cout, nt_l, count, 1 if training else 0, part[0].data_ptr(), part[1].data_ptr(), gamma.data_ptr(),
+            bn.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), bwdc.data_ptr(), st), "bn_finalize_bwd")
+        grads[3 * li + 1], grads[3 * li + 2] = dgamma, dbeta
+        if li > 0:
+            splits = lib.istnet_pw_bwd_small_cols_splits()
+            ws = _empty((splits, cout, cin), torch.float32, dev)
+            dprev = _empty((1, cin, cap), torch.float32, dev)
+            fused_part, fused_nt = _empty((2, cin, splits), torch.float32, dev), splits
+            _native.check(lib.istnet_pw_bwd_small_cols(
+                cin, cout, cap, w.reshape(cout, cin).data_ptr(), ys[li - 1].data_ptr(), bns[li - 1].data_ptr(),
+                y.data_ptr(), d_dense.data_ptr(), bn.data_ptr(), bwdc.data_ptr(), dprev.data_ptr(),
+                fused_part[0].data_ptr(), fused_part[1].data_ptr(), ws.data_ptr(), ncols, colw, st), "pw_bwd_small_cols")
+            if need_w[li]:
+                wjobs.append(_reduce_only_job(dev, w, cout, cin, splits, ws))
+                wlayers.append(li)
+            d_dense = dprev
+        elif need_w[0]:
+            chunks = lib.istnet_pw_dwx_cols_chunks(cout)
+            y0, d0, bn0 = y, d_dense, bn
+
+            def dwx_job(wst, cout=cout, chunks=chunks, y0=y0, d0=d0, bn0=bn0, bwdc=bwdc, w=w):
+                ws0 = _empty((chunks, cout, 3), torch.float32, dev)
+                dw = _grad_dest(w, (cout, 3), dev)
+                _native.check(lib.istnet_pw_dwx_cols(cout, cap, y0.data_ptr(), d0.data_ptr(), bn0.data_ptr(),
+                                                     bwdc.data_ptr(), cm.cidx.data_ptr(), cm.meta.data_ptr(), colw, ncols,
+                                                     ga.xyz.data_ptr(), ga.new_xyz.data_ptr(), ws0.data_ptr(), wst),
+                              "pw_dwx_cols")
+                return cout * 3, chunks, ws0, dw
+            wjobs.append(dwx_job)
+            wlayers.append(0)
+    if wjobs:
+        wparams = [params[3 * li] for li in wlayers]
+        if _can_defer(wparams):
+            cur = torch.cuda.current_stream(dev)
+            key, wstream = _Deferred.stream(dev, cur)
+            _Deferred.mains.setdefault(key, cur)
+            wstream.wait_stream(cur)
+            with torch.cuda.stream(wstream):
+                done = [job(wstream.cuda_stream) for job in wjobs]
+                _native.reduce_multi([(cnt, splits, ws.data_ptr(), dw.data_ptr()) for cnt, splits, ws, dw in done],
+                                     wstream.cuda_stream)
+            _Deferred.keep += [wjobs, done, ys, bns, cm.tensors()]
+            _Deferred.arm()
+        else:
+            done = [job(st) for job in wjobs]
+            _native.reduce_multi([(cnt, splits, ws.data_ptr(), dw.data_ptr()) for cnt, splits, ws, dw in done], st)
+        for li, (_, _, _, dw) in zip(wlayers, done):
+            grads[3 * li] = dw.view_as(params[3 * li])
+    return grads, None, False
+
+
 class FusedSharedMLPFunction(Function):
     """x (B, C0, G, S) -> (B, C_L, G): conv1x1/BN/ReLU stack followed by a max over S."""
 
@@ -684,8 +839,9 @@ class FusedSALevelFunction(Function):
     layer-0 feature weights -- reference pointnet2_modules.py:60-73 without the glue kernels."""
 
     @staticmethod
-    def forward(ctx, features, xyz, new_xyz, training, scales, csrs, *tensors):
+    def forward(ctx, features, xyz, new_xyz, training, scales, csrs, compacts, *tensors):
         # scales: list of per-scale `layers`; csrs: per scale (offsets, entries) inverse lists of idx or None;
+        # compacts: per scale _ext.BallCompact (compact-column tables of idx) or None;
         # tensors = [idx_0..idx_{S-1}, params of scale 0, params of scale 1, ...]
         lib = _native.lib()
         dev = xyz.device
@@ -706,8 +862,13 @@ class FusedSALevelFunction(Function):
                   if (feat is not None and feat.shape[1] % 16 == 0 and not USE_SPLIT_LAYER0) else None)
         with torch.cuda.device(dev):
             streams = _scale_streams(dev, len(scales))
-            for layers, params, idx, stream in zip(scales, plist, idxs, streams):
-                ga = _Gather(xyz, new_xyz, feat, idx, feat_t)
+            compacts = list(compacts) if compacts is not None else [None] * nsc
+            used = []
+            for layers, params, idx, stream, cm in zip(scales, plist, idxs, streams, compacts):
+                ga = _Gather(xyz, new_xyz, feat, idx, feat_t, compact=cm)
+                if not _compact_ok(lib, ga, layers, params):
+                    ga.compact = None
+                used.append(ga.compact)
                 with torch.cuda.stream(stream):
                     _, arg, ys, bns = _forward_stack(lib, dev, _st(dev), b, 3 + ga.cfeat, g, ga.nsample, None, ga,
                                                      training, layers, params, out_spec=(out, coff))
@@ -724,6 +885,7 @@ class FusedSALevelFunction(Function):
             from . import _ext
             csrs = [c if c is not None else _ext.ball_csr(idx, xyz.shape[1]) for c, idx in zip(csrs, idxs)]
         ctx.csrs = csrs
+        ctx.compacts = used
         ctx.dims = (b, g, ctot)
         ctx.has_feat_t = feat_t is not None
         ctx.save_for_backward(feat if feat is not None else torch.empty(0, device=dev), xyz, new_xyz,
@@ -761,15 +923,16 @@ class FusedSALevelFunction(Function):
         cout0_tot = sum(params_all[sum(3 * m[0] for m in meta[:i])].shape[0] for i in range(nsc))
         gbuf = _empty((b, cout0_tot, n_src), torch.float32, dev) if use_level_gemm else None
         grads_all, dfeat, goff, w0f = [], None, 0, []
-        base = 6 + nsc   # index of the first parameter among forward()'s arguments
+        base = 7 + nsc   # index of the first parameter among forward()'s arguments
         with torch.cuda.device(dev):
             st = _st(dev)
             streams = _scale_streams(dev, nsc) if (use_level_gemm or not need_x) else [torch.cuda.current_stream(dev)] * nsc
-            for (nl, s, coff, clast), (arg, ys, bns), idx, csr, stream in zip(meta, per_scale, idxs, ctx.csrs, streams):
+            for (nl, s, coff, clast), (arg, ys, bns), idx, csr, stream, cm in zip(meta, per_scale, idxs, ctx.csrs, streams,
+                                                                                      ctx.compacts):
                 params = params_all[ppos:ppos + 3 * nl]
                 need_w = [ctx.needs_input_grad[base + ppos + 3 * li] for li in range(nl)]
                 ppos += 3 * nl
-                ga = _Gather(xyz, new_xyz, feat if ctx.has_feat else None, idx, feat_t, csr=csr)
+                ga = _Gather(xyz, new_xyz, feat if ctx.has_feat else None, idx, feat_t, csr=csr, compact=cm)
                 cout0 = params[0].shape[0]
                 with torch.cuda.stream(stream):
                     grads, dxf, scattered = _backward_stack(
@@ -808,7 +971,7 @@ class FusedSALevelFunction(Function):
                     _finish_layer0_grads(lib, dev, b, cfeat, cout0_tot, n_src, feat, gbuf, ident, bwdc, w0_slots,
                                          grads_all)
             _native.mark(f"bwd SA(g={g}) chains done")
-        return (dfeat, None, None, None, None, None, *([None] * nsc), *grads_all)
+        return (dfeat, None, None, None, None, None, None, *([None] * nsc), *grads_all)
 
 
 def _finish_layer0_grads(lib, dev, b, cfeat, cout0_tot, n_src, feat, gbuf, ident, bwdc, w0_slots, grads_all):
@@ -1217,7 +1380,7 @@ def sa_scale(grouper, mlp, xyz, new_xyz, features, idx=None):
     return out
 
 
-def sa_level(groupers, mlps, xyz, new_xyz, features, ball_idx=None, ball_csr=None):
+def sa_level(groupers, mlps, xyz, new_xyz, features, ball_idx=None, ball_csr=None, ball_compact=None):
     """All scales of a set-abstraction level: ``cat([max_pool(mlp_i(grouper_i(...))) for i], dim=1)``.
 
     One fused autograd node when every scale qualifies for the gather-fused path (see ``sa_scale``); otherwise the
@@ -1244,7 +1407,7 @@ def sa_level(groupers, mlps, xyz, new_xyz, features, ball_idx=None, ball_csr=Non
         scales.append(layers)
         params += p
     training = mlps[0].training
-    out = FusedSALevelFunction.apply(features, xyz, new_xyz, training, scales, ball_csr, *idxs, *params)
+    out = FusedSALevelFunction.apply(features, xyz, new_xyz, training, scales, ball_csr, ball_compact, *idxs, *params)
     if training:
         _bump_counters([unit for mlp in mlps for unit in mlp])
     return out

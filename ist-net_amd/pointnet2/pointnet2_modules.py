@@ -39,9 +39,11 @@ class _PointnetSAModuleBase(nn.Module):
 
         ``geometry`` = (new_xyz, [ball-query idx per scale][, [inverse lists of idx per scale]]) lets a caller that
         already ran the sampling / neighbour search (PointNet2MSG's geometry pre-pass) skip it here."""
-        ball_csr = None
+        ball_csr = ball_compact = None
         if geometry is None:
             new_xyz, ball_idx = self._sample_centroids(xyz), [None] * len(self.groupers)
+        elif len(geometry) == 4:     # + compact-column tables of the ball indices (padded repeats evaluated once)
+            new_xyz, ball_idx, ball_csr, ball_compact = geometry
         elif len(geometry) == 3:     # + inverse lists of the ball indices (fused_mlp: atomic-free gradient scatter)
             new_xyz, ball_idx, ball_csr = geometry
         else:
@@ -52,7 +54,8 @@ class _PointnetSAModuleBase(nn.Module):
             pooled = [shared_mlp_maxpool(mlp, grouper(xyz, new_xyz, features))
                       for grouper, mlp in zip(self.groupers, self.mlps)]
             return new_xyz, torch.cat(pooled, dim=1)
-        return new_xyz, sa_level(list(self.groupers), list(self.mlps), xyz, new_xyz, features, ball_idx, ball_csr)
+        return new_xyz, sa_level(list(self.groupers), list(self.mlps), xyz, new_xyz, features, ball_idx, ball_csr,
+                                 ball_compact)
 
 
 class PointnetSAModuleMSG(_PointnetSAModuleBase):

@@ -331,3 +331,80 @@ def test_deferred_wgrad_survives_a_failed_backward():
     torch.cuda.synchronize()
     for p, q in zip(mlp.parameters(), ref.parameters()):
         assert float((p.grad - q.grad).norm() / (q.grad.norm() + 1e-30)) < 1e-3
+
+
+def _shell(b, n, seed):
+    g = torch.Generator().manual_seed(seed)
+    d = torch.randn(b, n, 3, generator=g)
+    return (d / d.norm(dim=2, keepdim=True) * 0.1 + torch.randn(b, n, 3, generator=g) * 0.002).contiguous()
+
+
+def test_compact_column_tables_match_host_construction():
+    """istnet_sa_compact: per group the distinct leading neighbours, then one representative of the padded repeats with
+    their number as weight; exclusive scan of the group lengths; null columns up to the next multiple of 256."""
+    from istnet_amd.pointnet2 import _ext
+    xyz = _shell(4, 1024, 3).to(DEV)
+    _, new_xyz = _ext.furthest_point_sampling_gather(xyz, 256)
+    for radius, s in ((0.01, 16), (0.02, 32), (0.3, 16), (1e-6, 8)):
+        idx = _ext.ball_query(new_xyz, xyz, radius, s)
+        cm = _ext.ball_compact(idx, 1024)
+        torch.cuda.synchronize()
+        rows = idx.cpu().reshape(-1, s)
+        cnt = 1 + (rows[:, 1:] != rows[:, :1]).sum(1)
+        glen = cnt + (cnt < s).int()
+        gstart = torch.cat([torch.zeros(1, dtype=torch.long), torch.cumsum(glen.long(), 0)])
+        assert torch.equal(cm.glen.cpu().long(), glen.long()) and torch.equal(cm.gstart.cpu().long(), gstart)
+        t = int(gstart[-1])
+        cidx, meta, colw = cm.cidx.cpu()[:t], cm.meta.cpu()[:t], cm.colw.cpu()[:t]
+        gid = torch.repeat_interleave(torch.arange(rows.shape[0]), glen.long())
+        pos = torch.arange(t) - gstart[gid]
+        assert torch.equal(meta.long(), gid * 64 + pos)
+        is_rep = pos == cnt[gid]
+        src = torch.where(is_rep, rows[gid, 0], rows[gid, torch.clamp(pos, max=s - 1)]) + (gid // 256) * 1024
+        assert torch.equal(cidx.long(), src.long())
+        assert torch.equal(colw, torch.where(is_rep, (s - cnt[gid]).float(), torch.ones(t)))
+        assert float(colw.sum()) == rows.numel()                          # multiplicities add up to the padded slot count
+        tail = (t + 255) // 256 * 256
+        assert float(cm.colw.cpu()[t:tail].abs().sum()) == 0.0
+
+
+@pytest.mark.parametrize("training", [True, False])
+def test_compact_columns_equal_padded_evaluation(training):
+    """A level-1-like MSG set-abstraction level (xyz only, heavy padding) evaluated on compact columns vs the padded
+    evaluation of the same module: pooled features, every parameter gradient, running statistics -- fp32 round-off
+    apart (the sums are the same, taken in a different order)."""
+    from istnet_amd.pointnet2 import _ext, fused_mlp
+    from istnet_amd.pointnet2.pointnet2_modules import PointnetSAModuleMSG
+
+    def make():
+        torch.manual_seed(11)
+        m = PointnetSAModuleMSG(npoint=256, radii=[0.01, 0.025], nsamples=[16, 32], mlps=[[0, 16, 16, 32], [0, 16, 32, 32]])
+        return m.to(DEV).train(training)
+
+    xyz = _shell(4, 1024, 5).to(DEV)
+    _, new_xyz = _ext.furthest_point_sampling_gather(xyz, 256)
+    idx = [_ext.ball_query(new_xyz, xyz, r, s) for r, s in ((0.01, 16), (0.025, 32))]
+    comps = [_ext.ball_compact(i, 1024) for i in idx]
+    assert all(c is not None for c in comps)
+    frac = [float(c.gstart[-1]) / c.cap for c in comps]
+    assert max(frac) < 0.8                                   # the input really is padded
+    g = torch.Generator().manual_seed(2)
+    wgt = torch.randn(4, 64, 256, generator=g).to(DEV)
+    res = []
+    for use in (True, False):
+        m = make()
+        if not training:
+            gen = torch.Generator().manual_seed(4)
+            for bn in [mod for mod in m.modules() if isinstance(mod, torch.nn.BatchNorm2d)]:
+                bn.running_mean.copy_(torch.rand(bn.num_features, generator=gen) * 0.4 - 0.2)
+                bn.running_var.copy_(torch.rand(bn.num_features, generator=gen) + 0.5)
+        _, out = m(xyz, None, geometry=(new_xyz, idx, None, comps if use else None))
+        (out * wgt).sum().backward()
+        torch.cuda.synchronize()
+        res.append((out.detach(), {k: p.grad.clone() for k, p in m.named_parameters()},
+                    {k: v.clone() for k, v in m.state_dict().items() if "running" in k}))
+    torch.testing.assert_close(res[0][0], res[1][0], rtol=1e-5, atol=2e-5)
+    for k in res[0][1]:
+        torch.testing.assert_close(res[0][1][k], res[1][1][k], rtol=2e-4, atol=2e-5, msg=lambda s, k=k: f"{k}: {s}")
+    for k in res[0][2]:
+        torch.testing.assert_close(res[0][2][k], res[1][2][k], rtol=1e-5, atol=1e-6, msg=lambda s, k=k: f"{k}: {s}")

@@ -439,3 +439,36 @@ def test_istnet_frozen_world_enhancer_on_gpu():
     missing = [n for n, p in net.named_parameters() if p.requires_grad and p.grad is None]
     assert not missing, missing
     assert all(bool(torch.isfinite(p.grad).all()) for p in net.parameters() if p.grad is not None)
+
+
+def test_rgb_branch_matches_reference_golden_on_gpu():
+    """the RGB branch (ResNet-18 trunk + PSP decoder on MIOpen) against the feature map the
+    reference's own modules produced (tests/golden/rgb_branch_and_loss.npz), in both memory layouts the product uses:
+    NCHW and channels-last (the bench's layout), and through the eval-mode tail that evaluates the decoder's last stage
+    on the chosen pixels only.  Features within 1e-4."""
+    from istnet_amd import rgb_branch
+    from istnet_amd.ist_net import IST_Net
+    z = np.load(os.path.join(GOLD, "rgb_branch_and_loss.npz"))
+    torch.manual_seed(60)
+    rgb_branch.ResNet()                      # the reference consumed one trunk's worth of the random stream first
+    net = rgb_branch.ModifiedResnet().eval().to(DEV)
+    img = torch.from_numpy(z["img"]).to(DEV)
+    with torch.no_grad():
+        out = net(img)
+        net_cl = net.to(memory_format=torch.channels_last)
+        out_cl = net_cl(img.contiguous(memory_format=torch.channels_last))
+    assert out.shape == (1, 128, 96, 96)
+    np.testing.assert_allclose(out.cpu().numpy()[:, ::4, ::6, ::6], z["out_sub"], **TOL)
+    np.testing.assert_allclose(out_cl.cpu().numpy()[:, ::4, ::6, ::6], z["out_sub"], **TOL)
+    # the per-point gather of IST_Net (dense order in train mode, tail-at-chosen-pixels in eval mode) picks these values
+    g = torch.Generator().manual_seed(1)
+    choose = torch.randint(0, 96 * 96, (1, 512), generator=g).to(DEV)
+    model = IST_Net(rgb_extractor=net_cl).to(DEV).eval()
+    with torch.no_grad():
+        local = model._rgb_local({"rgb": img.contiguous(memory_format=torch.channels_last), "choose": choose}, 1)
+    want = out.reshape(1, 128, -1).gather(2, choose.unsqueeze(1).expand(-1, 128, -1))
+    torch.testing.assert_close(local, want, **TOL)
+    sub_rows = (torch.arange(0, 96, 6).view(-1, 1) * 96 + torch.arange(0, 96, 6).view(1, -1)).reshape(1, -1).to(DEV)
+    with torch.no_grad():
+        local_sub = model._rgb_local({"rgb": img.contiguous(memory_format=torch.channels_last), "choose": sub_rows}, 1)
+    np.testing.assert_allclose(local_sub.cpu().numpy()[:, ::4].reshape(1, 32, 16, 16), z["out_sub"], **TOL)
