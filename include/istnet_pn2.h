@@ -115,6 +115,13 @@ ISTNET_PN2_API int istnet_pn2_csr_build(int b, int e, int m, const int *idx, int
  * (e[l] > ~15000): build that one with istnet_pn2_csr_build. */
 ISTNET_PN2_API int istnet_pn2_csr_build_multi(int nprob, int b, const int *e, const int *m, const int *const *idx,
                                               int *const *offsets, int *const *entries, void *stream);
+/* the same over SEGMENTED slot arrays (compact columns, csrc/sa_compact.hip): problem l keeps the slots of all clouds
+ * on one axis, cloud c owning idx[l][seg[l][c] .. seg[l][c+1]) (seg on the device, at most e[l] slots per cloud); its
+ * keys are idx - c * key_sub[l]; entries are slot numbers relative to seg[l][c], written to entries[l] + seg[l][c];
+ * offsets stay (b, m[l] + 1) per cloud. */
+ISTNET_PN2_API int istnet_pn2_csr_build_segmented(int nprob, int b, const int *e, const int *m, const int *const *idx,
+                                                  int *const *offsets, int *const *entries, const int *const *seg,
+                                                  const int *key_sub, void *stream);
 ISTNET_PN2_API int istnet_pn2_three_interpolate_grad_csr(int b, int c, int n, int m, const float *grad_out,
                                                          const float *weight, const int *offsets,
                                                          const int *entries, float *grad_points, void *stream);

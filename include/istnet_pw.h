@@ -255,6 +255,27 @@ ISTNET_PN2_API int istnet_pw_dwx_cols(int cout, long long cap, const float *y, c
                                       void *stream);
 
 
+/* dense-gradient dgrad / wgrad on compact columns (layers too wide for the fused small-layer backward): same
+ * arithmetic as istnet_pw_dgrad / istnet_pw_wgrad with b = 1, p = cap; statistics partials [m_rows][istnet_pw_dgrad_stat_tiles(1, m_rows, cap)]
+ * and weight-gradient partials [istnet_pw_wgrad_cols_splits(cin, cout)][cout][cin] carry the column multiplicities */
+ISTNET_PN2_API int istnet_pw_dgrad_cols(int cin_total, int ci_off, int m_rows, int cout, long long cap, const float *w,
+                                        const float *y, const float *d_dense, const float *bn, const float *bwdc,
+                                        float *dx, const float *y_in, const float *bn_in, float *part_g,
+                                        float *part_gy, const int *ncols, const float *colw, void *stream);
+ISTNET_PN2_API int istnet_pw_wgrad_cols_splits(int cin, int cout);
+ISTNET_PN2_API int istnet_pw_wgrad_cols(int cin, int cout, long long cap, const float *x, const float *in_scale,
+                                        const float *in_shift, const float *y, const float *d_dense, const float *bn,
+                                        const float *bwdc, float *dw_part, const int *ncols, const float *colw,
+                                        void *stream);
+/* istnet_pw_scatter_dy_csr on compact columns: inverse lists from istnet_pn2_csr_build_segmented over cidx (seg = gstart
+ * taken every g groups, key_sub = n); out (b, rows, n) / dwx (b, cout, 3) as in the padded form */
+ISTNET_PN2_API int istnet_pw_scatter_dy_csr_cols(int b, int cout, int n, int g, long long cap, const float *y,
+                                                 const float *d_dense, const float *bn, const float *bwdc,
+                                                 const int *gstart, const int *offsets, const int *entries,
+                                                 const int *meta, const float *colw, float *out,
+                                                 long long out_bstride, const float *xyz, const float *new_xyz,
+                                                 float *dwx, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -19,6 +19,7 @@ _i, _f, _p, _d, _l = ctypes.c_int, ctypes.c_float, ctypes.c_void_p, ctypes.c_dou
 SIGNATURES = {
     "istnet_pn2_csr_build": [_i, _i, _i, _p, _p, _p, _p],
     "istnet_pn2_csr_build_multi": [_i, _i, _p, _p, _p, _p, _p, _p],
+    "istnet_pn2_csr_build_segmented": [_i, _i, _p, _p, _p, _p, _p, _p, _p, _p],
     "istnet_pw_scatter_csr_chunks": [_i],
     "istnet_pw_scatter_dy_csr": [_i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _l, _p, _p, _i, _p, _p],
     "istnet_adam_step": [_l, _p, _p, _p, _p, _p, _p, _d, _d, _d, _d, _d, _d, _p],
@@ -81,6 +82,10 @@ SIGNATURES = {
     "istnet_pw_bwd_small_cols_splits": [],
     "istnet_pw_bwd_small_cols": [_i, _i, _l, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p],
     "istnet_pw_dwx_cols_chunks": [_i],
+    "istnet_pw_dgrad_cols": [_i, _i, _i, _i, _l, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p],
+    "istnet_pw_wgrad_cols_splits": [_i, _i],
+    "istnet_pw_wgrad_cols": [_i, _i, _l, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p],
+    "istnet_pw_scatter_dy_csr_cols": [_i, _i, _i, _i, _l, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _l, _p, _p, _p, _p],
     "istnet_pw_dwx_cols": [_i, _l, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p],
 }
 

@@ -533,6 +533,9 @@ struct CsrProblem {
   int* off;         // (B, m + 1)
   int* ent;         // (B, E)
   int E, m, ranges, block_begin, qcap, kr;   // kr = keys per workgroup (16 / 32 / 64)
+  const int* seg;   // optional (B + 1) device offsets: cloud b owns slots idx[seg[b] .. seg[b+1]) (at most E of them) and
+                    // writes its entries (slot numbers relative to seg[b]) to ent + seg[b]; NULL = the (B, E) layout
+  int key_sub;      // seg != NULL: keys are idx[..] - b * key_sub (global -> per-cloud point numbers)
 };
 struct CsrBatch {
   CsrProblem p[kCsrMaxProblems];
@@ -546,8 +549,10 @@ __global__ __launch_bounds__(256) void csr_range_kernel(CsrBatch cb) {
   const int local = (int)blockIdx.x - P.block_begin;
   const int b = local / P.ranges, r = local - b * P.ranges;
   const int KR = P.kr;
-  const int k0 = r * KR, E = P.E, m = P.m, qcap = P.qcap;
-  const int* idx = P.idx + (size_t)b * E;
+  const int k0 = r * KR, m = P.m, qcap = P.qcap;
+  const int E = P.seg != nullptr ? P.seg[b + 1] - P.seg[b] : P.E;
+  const int* idx = P.seg != nullptr ? P.idx + P.seg[b] : P.idx + (size_t)b * P.E;
+  const int ksub = P.seg != nullptr ? b * P.key_sub : 0;
   const int lane = lane_id(), wave = threadIdx.x >> 6;
   int* q = csr_lds + wave * qcap;
   int* cnts = csr_lds + 4 * qcap;
@@ -561,7 +566,7 @@ __global__ __launch_bounds__(256) void csr_range_kernel(CsrBatch cb) {
 #pragma unroll
     for (int u = 0; u < 4; ++u) {                       // four loads in flight
       const int e = e0 + u * 64 + lane;
-      key[u] = e < end ? idx[e] : 0x7fffffff;
+      key[u] = e < end ? idx[e] - ksub : 0x7fffffff;
     }
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
@@ -636,7 +641,7 @@ __global__ __launch_bounds__(256) void csr_range_kernel(CsrBatch cb) {
     if (r == P.ranges - 1 && lane == 0) off[m] = E;
   }
   int pos = start + (wave > 0 ? c0 : 0) + (wave > 1 ? c1 : 0) + (wave > 2 ? c2 : 0);   // next free entry of key `lane`
-  int* ent = P.ent + (size_t)b * E;
+  int* ent = P.seg != nullptr ? P.ent + P.seg[b] : P.ent + (size_t)b * E;
   if (use_match) {
     for (int i = 0; i < qlen; i += 64) {
       const int item = i + lane < qlen ? q[i + lane] : -1;
@@ -1035,8 +1040,25 @@ int istnet_pn2_three_interpolate(int b, int c, int m, int n, const float* points
 static int csr_qcap(int e) { return ((e + 3) / 4 + 63) / 64 * 64 + 8; }
 static size_t csr_range_lds(int e) { return ((size_t)4 * csr_qcap(e) + 4 * kCsrKeys + 4) * 4; }
 
+static int csr_build_multi_impl(int nprob, int b, const int* e, const int* m, const int* const* idx,
+                                int* const* offsets, int* const* entries, const int* const* seg, const int* key_sub,
+                                void* stream);
+
 int istnet_pn2_csr_build_multi(int nprob, int b, const int* e, const int* m, const int* const* idx,
                                int* const* offsets, int* const* entries, void* stream) {
+  return csr_build_multi_impl(nprob, b, e, m, idx, offsets, entries, nullptr, nullptr, stream);
+}
+
+int istnet_pn2_csr_build_segmented(int nprob, int b, const int* e, const int* m, const int* const* idx,
+                                   int* const* offsets, int* const* entries, const int* const* seg,
+                                   const int* key_sub, void* stream) {
+  if (!seg || !key_sub) return ISTNET_PN2_EINVAL;
+  return csr_build_multi_impl(nprob, b, e, m, idx, offsets, entries, seg, key_sub, stream);
+}
+
+static int csr_build_multi_impl(int nprob, int b, const int* e, const int* m, const int* const* idx,
+                                int* const* offsets, int* const* entries, const int* const* seg, const int* key_sub,
+                                void* stream) {
   if (nprob <= 0 || nprob > kCsrMaxProblems || b < 0 || !e || !m || !idx || !offsets || !entries) return ISTNET_PN2_EINVAL;
   if (b == 0) return 0;
   CsrBatch cb;
@@ -1050,6 +1072,9 @@ int istnet_pn2_csr_build_multi(int nprob, int b, const int* e, const int* m, con
     lds = need > lds ? need : lds;
     CsrProblem& P = cb.p[l];
     P.idx = idx[l]; P.off = offsets[l]; P.ent = entries[l];
+    P.seg = seg != nullptr ? seg[l] : nullptr;
+    P.key_sub = (seg != nullptr && key_sub != nullptr) ? key_sub[l] : 0;
+    if (seg != nullptr && seg[l] == nullptr) return ISTNET_PN2_EINVAL;
     // keys per workgroup: 64 when that already gives >= 512 workgroups, else fewer keys -> more, shorter workgroups
     int kr = kCsrKeys;
     while (kr > 16 && (long long)b * ceil_div(m[l], kr) < 512) kr >>= 1;

@@ -1072,11 +1072,24 @@ __global__ __launch_bounds__(kThreads) void pw_dgrad_kernel(
     int cin_total, int ci_off, int m_rows, int cout, int P, int tiles_per_cloud,
     const float* __restrict__ w, const float* __restrict__ y, GradSrc gs, const float* __restrict__ bn,
     const float* __restrict__ bwdc, float* __restrict__ dx, const float* __restrict__ y_in,
-    const float* __restrict__ bn_in, float* __restrict__ part_g, float* __restrict__ part_gy, int nt_total) {
+    const float* __restrict__ bn_in, float* __restrict__ part_g, float* __restrict__ part_gy, int nt_total,
+    const int* __restrict__ ncols, const float* __restrict__ colw) {
   using T = Tile<M_T, N_T, WM, WN>;
   constexpr int TM = T::TM, TN = T::TN;
   constexpr int NA = kKT * M_T / kThreads;
   constexpr int NB = kKT * N_T / 4 / kThreads;
+  // compact-column mode (csrc/sa_compact.hip): a tile past the valid columns only zeroes its statistics partials
+  if (ncols != nullptr && (int)((blockIdx.x % tiles_per_cloud) * N_T) >= *ncols) {
+    if (part_g != nullptr)
+      for (int rl = threadIdx.x; rl < M_T; rl += kThreads) {
+        const int row = blockIdx.y * M_T + rl;
+        if (row < m_rows) {
+          part_g[(size_t)row * nt_total + blockIdx.x] = 0.f;
+          part_gy[(size_t)row * nt_total + blockIdx.x] = 0.f;
+        }
+      }
+    return;
+  }
   __shared__ __attribute__((aligned(16))) float As[2][kKT][M_T];
   __shared__ __attribute__((aligned(16))) float Bs[2][kKT][N_T];
 
@@ -1225,6 +1238,10 @@ __global__ __launch_bounds__(kThreads) void pw_dgrad_kernel(
   const bool stats = part_g != nullptr;
   const float* yin_b = stats ? y_in + (size_t)b * m_rows * P : nullptr;
   float* red = &As[0][0][0];  // reuse LDS: [WN][M_T][2]
+  float wcol[TN];             // column multiplicities in the statistics (compact-column mode)
+#pragma unroll
+  for (int tn = 0; tn < TN; ++tn)
+    wcol[tn] = colw != nullptr ? colw[min(p0 + b_col0 + tn * 32 + (lane & 31), P - 1)] : 1.f;
   if (full_tile && stats) {
     // common case: issue every y_in load of a 16-row slab before consuming any (one latency, not 16*TN)
 #pragma unroll
@@ -1247,7 +1264,7 @@ __global__ __launch_bounds__(kThreads) void pw_dgrad_kernel(
         for (int tn = 0; tn < TN; ++tn) {
           const float v = acc[tm][tn][r];
           dxb[(size_t)row * P + p0 + b_col0 + tn * 32 + (lane & 31)] = v;
-          const float gq = (yv[r][tn] * sc + sh > 0.f) ? v : 0.f;
+          const float gq = (yv[r][tn] * sc + sh > 0.f) ? v * wcol[tn] : 0.f;
           sg += gq;
           sgy += gq * yv[r][tn];
         }
@@ -1277,7 +1294,7 @@ __global__ __launch_bounds__(kThreads) void pw_dgrad_kernel(
           dxb[(size_t)row * P + col] = v;
           if (stats) {
             const float yv = yin_b[(size_t)row * P + col];
-            const float gq = (yv * sc + sh > 0.f) ? v : 0.f;
+            const float gq = (yv * sc + sh > 0.f) ? v * wcol[tn] : 0.f;
             sg += gq;
             sgy += gq * yv;
           }
@@ -1318,9 +1335,15 @@ template <int M_T, int N_T, int WM, int WN, int GATHER>  // 0 tensor input, 1 ch
 __global__ __launch_bounds__(kThreads) void pw_wgrad_kernel(
     int cin, int cout, int P, long long total, int split_len, const float* __restrict__ x, GatherSrc gsrc,
     const float* __restrict__ in_scale, const float* __restrict__ in_shift, const float* __restrict__ y,
-    GradSrc gs, const float* __restrict__ bn, const float* __restrict__ bwdc, float* __restrict__ dw_part) {
+    GradSrc gs, const float* __restrict__ bn, const float* __restrict__ bwdc, float* __restrict__ dw_part,
+    const int* __restrict__ ncols, const float* __restrict__ colw) {
   using T = Tile<M_T, N_T, WM, WN>;
   constexpr int TM = T::TM, TN = T::TN;
+  if (ncols != nullptr) {   // compact columns (csrc/sa_compact.hip): valid range and an even split of it from the device
+    total = ((long long)*ncols + kKTW - 1) / kKTW * kKTW;
+    const long long per = (total + gridDim.x - 1) / gridDim.x;
+    split_len = (int)((per + kKTW - 1) / kKTW * kKTW);
+  }
   constexpr int LDA = M_T + 1;                          // odd leading dim: transposed scalar writes spread over banks
   constexpr int LDB = GATHER == 2 ? N_T + 4 : N_T + 1;  // point-major gather writes whole float4 rows (16-B aligned)
   constexpr int NA = M_T * kKTW / 4 / kThreads;  // float4 (along p) per thread per chunk
@@ -1331,7 +1354,7 @@ __global__ __launch_bounds__(kThreads) void pw_wgrad_kernel(
 
   const int tid = threadIdx.x;
   const long long qbeg = (long long)blockIdx.x * split_len;
-  const long long qend = min(qbeg + (long long)split_len, total);
+  const long long qend = max(qbeg, min(qbeg + (long long)split_len, total));
   const int m0 = blockIdx.y * M_T, n0 = blockIdx.z * N_T;
   const bool has_bn = in_scale != nullptr;
 
@@ -1398,6 +1421,10 @@ __global__ __launch_bounds__(kThreads) void pw_wgrad_kernel(
       const int m = e / (kKTW / 4), k = (e % (kKTW / 4)) * 4;
       const bool ok = (m0 + m < cout) && (qk + k < qend);
       float4 v = finish_dy(araw[i], gs, pk + k, min(m0 + m, cout - 1), bn, bwdc, cout);
+      if (colw != nullptr) {      // column multiplicities of the compact evaluation
+        const float4 cw = *reinterpret_cast<const float4*>(colw + min(qk, total - kKTW) + k);
+        v.x *= cw.x; v.y *= cw.y; v.z *= cw.z; v.w *= cw.w;
+      }
       if (!ok) v = zero4();
       As[buf][k + 0][m] = v.x; As[buf][k + 1][m] = v.y; As[buf][k + 2][m] = v.z; As[buf][k + 3][m] = v.w;
     }
@@ -2132,11 +2159,11 @@ int istnet_bn_finalize_bwd(int c, int nt, double count, int training, const floa
   return (int)hipGetLastError();
 }
 
-int istnet_pw_dgrad(int b, int cin_total, int ci_off, int m_rows, int cout, int p, int nsample,
-                    const float* w, const float* y, const float* d_dense, const float* d_pooled,
-                    long long pooled_bstride, const unsigned char* arg, const float* bn, const float* bwdc,
-                    float* dx, const float* y_in, const float* bn_in, float* part_g, float* part_gy,
-                    void* stream) {
+static int launch_pw_dgrad(int b, int cin_total, int ci_off, int m_rows, int cout, int p, int nsample,
+                           const float* w, const float* y, const float* d_dense, const float* d_pooled,
+                           long long pooled_bstride, const unsigned char* arg, const float* bn, const float* bwdc,
+                           float* dx, const float* y_in, const float* bn_in, float* part_g, float* part_gy,
+                           void* stream, const int* ncols, const float* colw) {
   const int GS_C = cout;
   if (b <= 0 || m_rows <= 0 || cout <= 0 || p <= 0 || (p & 3)) return ISTNET_PN2_EINVAL;
   if (part_g != nullptr && (y_in == nullptr || bn_in == nullptr || part_gy == nullptr)) return ISTNET_PN2_EINVAL;
@@ -2153,11 +2180,11 @@ int istnet_pw_dgrad(int b, int cin_total, int ci_off, int m_rows, int cout, int 
     if (interior)                                                                                          \
       hipLaunchKernelGGL((pw_dgrad_kernel<MT, NT, WM, WN, true>), grid, dim3(kThreads), 0, as_stream(stream), \
                          cin_total, ci_off, m_rows, cout, p, tpc, w, y, gs, bn, bwdc, dx, y_in, bn_in, part_g,  \
-                         part_gy, tpc * b);                                                                 \
+                         part_gy, tpc * b, ncols, colw);                                                    \
     else                                                                                                   \
       hipLaunchKernelGGL((pw_dgrad_kernel<MT, NT, WM, WN, false>), grid, dim3(kThreads), 0, as_stream(stream), \
                          cin_total, ci_off, m_rows, cout, p, tpc, w, y, gs, bn, bwdc, dx, y_in, bn_in, part_g,  \
-                         part_gy, tpc * b);                                                                 \
+                         part_gy, tpc * b, ncols, colw);                                                    \
   } while (0)
   switch (cfg) {
     case kCfg128x128: ISTNET_DGRAD(128, 128, 2, 2); break;
@@ -2169,6 +2196,24 @@ int istnet_pw_dgrad(int b, int cin_total, int ci_off, int m_rows, int cout, int 
   }
 #undef ISTNET_DGRAD
   return (int)hipGetLastError();
+}
+
+int istnet_pw_dgrad(int b, int cin_total, int ci_off, int m_rows, int cout, int p, int nsample,
+                    const float* w, const float* y, const float* d_dense, const float* d_pooled,
+                    long long pooled_bstride, const unsigned char* arg, const float* bn, const float* bwdc,
+                    float* dx, const float* y_in, const float* bn_in, float* part_g, float* part_gy,
+                    void* stream) {
+  return launch_pw_dgrad(b, cin_total, ci_off, m_rows, cout, p, nsample, w, y, d_dense, d_pooled, pooled_bstride, arg,
+                         bn, bwdc, dx, y_in, bn_in, part_g, part_gy, stream, nullptr, nullptr);
+}
+
+int istnet_pw_dgrad_cols(int cin_total, int ci_off, int m_rows, int cout, long long cap, const float* w,
+                         const float* y, const float* d_dense, const float* bn, const float* bwdc, float* dx,
+                         const float* y_in, const float* bn_in, float* part_g, float* part_gy, const int* ncols,
+                         const float* colw, void* stream) {
+  if (cap <= 0 || (cap & 255) || cap >= (1LL << 31) || !d_dense || !ncols || !colw) return ISTNET_PN2_EINVAL;
+  return launch_pw_dgrad(1, cin_total, ci_off, m_rows, cout, (int)cap, 0, w, y, d_dense, nullptr, 0, nullptr, bn, bwdc,
+                         dx, y_in, bn_in, part_g, part_gy, stream, ncols, colw);
 }
 
 // dwx-only mode of istnet_pw_scatter_dy (out == NULL): point chunks per cloud so that ~1024 workgroups run
@@ -2248,7 +2293,7 @@ static int launch_pw_wgrad(bool gather, int b, int cin, int cout, int p, int nsa
                            const GatherSrc& g, const float* in_scale, const float* in_shift, const float* y,
                            const float* d_dense, const float* d_pooled, long long pooled_bstride,
                            const unsigned char* arg, const float* bn, const float* bwdc, float* dw_part,
-                           void* stream) {
+                           void* stream, const int* ncols = nullptr, const float* colw = nullptr, int fixed_splits = 0) {
   const int GS_C = cout;
   if (b <= 0 || cin <= 0 || cout <= 0 || p <= 0 || (p % kKTW)) return ISTNET_PN2_EINVAL;
   if ((long long)b * p >= (1LL << 31)) return ISTNET_PN2_EINVAL;   // 32-bit point indexing in the kernels
@@ -2257,6 +2302,7 @@ static int launch_pw_wgrad(bool gather, int b, int cin, int cout, int p, int nsa
   GradSrc gs{d_dense, d_pooled, arg, nsample, pooled_bstride > 0 ? pooled_bstride : (long long)GS_C * (nsample > 0 ? p / nsample : 0), GS_C};
   const int len = wgrad_split_len(b, cin, cout, p);
   const long long total = (long long)b * p;
+  if (ncols != nullptr && (wgrad_small(cin, cout) || fixed_splits <= 0)) return ISTNET_PN2_EINVAL;
   if (wgrad_small(cin, cout)) {
     const dim3 sgrid(wgrad_splits(b, cin, cout, p));
     if (gather)
@@ -2268,19 +2314,19 @@ static int launch_pw_wgrad(bool gather, int b, int cin, int cout, int p, int nsa
     return (int)hipGetLastError();
   }
   const int mt = wgrad_mt(cout, total), nt = wgrad_nt(cin, total);
-  const dim3 grid(wgrad_splits(b, cin, cout, p), ceil_div(cout, mt), ceil_div(cin, nt));
+  const dim3 grid(fixed_splits > 0 ? fixed_splits : wgrad_splits(b, cin, cout, p), ceil_div(cout, mt), ceil_div(cin, nt));
   const int mode = !gather ? 0 : ((g.featT != nullptr && g.cfeat > 0 && g.cfeat % 4 == 0) ? 2 : 1);
 #define ISTNET_WGRAD(MT, NT)                                                                                  \
   do {                                                                                                        \
     if (mode == 2)                                                                                            \
       hipLaunchKernelGGL((pw_wgrad_kernel<MT, NT, 2, 2, 2>), grid, dim3(kThreads), 0, as_stream(stream),      \
-                         cin, cout, p, total, len, x, g, in_scale, in_shift, y, gs, bn, bwdc, dw_part);       \
+                         cin, cout, p, total, len, x, g, in_scale, in_shift, y, gs, bn, bwdc, dw_part, ncols, colw); \
     else if (mode == 1)                                                                                       \
       hipLaunchKernelGGL((pw_wgrad_kernel<MT, NT, 2, 2, 1>), grid, dim3(kThreads), 0, as_stream(stream),      \
-                         cin, cout, p, total, len, x, g, in_scale, in_shift, y, gs, bn, bwdc, dw_part);       \
+                         cin, cout, p, total, len, x, g, in_scale, in_shift, y, gs, bn, bwdc, dw_part, ncols, colw); \
     else                                                                                                      \
       hipLaunchKernelGGL((pw_wgrad_kernel<MT, NT, 2, 2, 0>), grid, dim3(kThreads), 0, as_stream(stream),      \
-                         cin, cout, p, total, len, x, g, in_scale, in_shift, y, gs, bn, bwdc, dw_part);       \
+                         cin, cout, p, total, len, x, g, in_scale, in_shift, y, gs, bn, bwdc, dw_part, ncols, colw); \
   } while (0)
   if (mt == 128 && nt == 128) ISTNET_WGRAD(128, 128);
   else if (mt == 128) ISTNET_WGRAD(128, 64);
@@ -2357,6 +2403,22 @@ int istnet_pw_wgrad(int b, int cin, int cout, int p, int nsample, const float* x
                     float* dw_part, void* stream) {
   return launch_pw_wgrad(false, b, cin, cout, p, nsample, x, GatherSrc{}, in_scale, in_shift, y, d_dense,
                          d_pooled, pooled_bstride, arg, bn, bwdc, dw_part, stream);
+}
+
+// compact-column form: splits = istnet_pw_wgrad_cols_splits(cin, cout) workgroup columns share the valid range evenly
+int istnet_pw_wgrad_cols_splits(int cin, int cout) {
+  if (wgrad_small(cin, cout)) return 0;     // those layers run the fused small-layer backward
+  const long long tiles = (long long)ceil_div(cout, 64) * ceil_div(cin, 64);
+  const long long want = (g_wg_target_small + tiles - 1) / tiles;
+  return (int)(want < 1 ? 1 : want);
+}
+
+int istnet_pw_wgrad_cols(int cin, int cout, long long cap, const float* x, const float* in_scale,
+                         const float* in_shift, const float* y, const float* d_dense, const float* bn,
+                         const float* bwdc, float* dw_part, const int* ncols, const float* colw, void* stream) {
+  if (cap <= 0 || (cap & 255) || cap >= (1LL << 31) || !d_dense || !ncols || !colw) return ISTNET_PN2_EINVAL;
+  return launch_pw_wgrad(false, 1, cin, cout, (int)cap, 0, x, GatherSrc{}, in_scale, in_shift, y, d_dense, nullptr, 0,
+                         nullptr, bn, bwdc, dw_part, stream, ncols, colw, istnet_pw_wgrad_cols_splits(cin, cout));
 }
 
 int istnet_pw_wgrad_gather(int b, int n, int npoint, int nsample, int cfeat, int cout, int grad_nsample,

@@ -56,26 +56,36 @@ __global__ __launch_bounds__(256) void compact_count_kernel(int NG, int S, const
   for (int s = 1; s < S; ++s) cnt += row[s] != first ? 1 : 0;
   glen[g] = cnt + (cnt < S ? 1 : 0);
 }
-// gstart = exclusive scan of glen over all NG groups (one workgroup; NG <= 1024 * 64), gstart[NG] = T
+// gstart = exclusive scan of glen over all NG groups (one workgroup; NG <= 1024 * 64), gstart[NG] = T.
+// Each thread owns a contiguous slice; slice sums are scanned inside the wave with shuffles and across the 16 waves
+// through LDS: two barriers in all.
 __global__ __launch_bounds__(1024) void compact_scan_kernel(int NG, const int* __restrict__ glen,
                                                             int* __restrict__ gstart) {
-  __shared__ int part[1024];
-  const int tid = threadIdx.x;
-  const int per = (NG + 1023) / 1024;
+  __shared__ int wave_tot[16];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int per = ((NG + 1023) / 1024 + 3) & ~3;          // multiple of 4: int4 loads
   const int lo = min(tid * per, NG), hi = min(lo + per, NG);
   int s = 0;
-  for (int i = lo; i < hi; ++i) s += glen[i];
-  part[tid] = s;
-  __syncthreads();
-  for (int d = 1; d < 1024; d <<= 1) {          // Hillis-Steele inclusive scan
-    const int v = tid >= d ? part[tid - d] : 0;
-    __syncthreads();
-    part[tid] += v;
-    __syncthreads();
+  int i = lo;
+  for (; i + 3 < hi; i += 4) {
+    const int4 v = *reinterpret_cast<const int4*>(glen + i);
+    s += (v.x + v.y) + (v.z + v.w);
   }
-  int run = part[tid] - s;
-  for (int i = lo; i < hi; ++i) { gstart[i] = run; run += glen[i]; }
-  if (tid == 1023) gstart[NG] = part[1023];
+  for (; i < hi; ++i) s += glen[i];
+  int incl = s;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const int up = __shfl_up(incl, d);
+    if (lane >= d) incl += up;
+  }
+  if (lane == 63) wave_tot[wv] = incl;
+  __syncthreads();
+  int base = 0;
+#pragma unroll
+  for (int w = 0; w < 16; ++w) base += w < wv ? wave_tot[w] : 0;
+  int run = base + incl - s;
+  for (i = lo; i < hi; ++i) { gstart[i] = run; run += glen[i]; }
+  if (tid == 1023) gstart[NG] = base + incl;
 }
 // column tables: cidx[p] = global source point (cloud * n + point), meta[p] = group * 64 + position in the group,
 // colw[p] = multiplicity; columns T .. roundup(T, 256) - 1 are null columns (weight 0, a valid address) so that tiles
@@ -276,6 +286,117 @@ __global__ __launch_bounds__(256) void dwx_cols_kernel(int cout, long long cap, 
         (wred[0][threadIdx.x] + wred[1][threadIdx.x]) + (wred[2][threadIdx.x] + wred[3][threadIdx.x]);
 }
 
+// ---- layer-0 gradient scatter over inverse lists of the compact columns (csrc/pw_mlp.hip: pw_scatter_csr_kernel) ----
+// G[cloud][c][i] = sum over the columns p of the cloud whose source point is i of w_p dY0[c][p]; a workgroup owns CH
+// channels of one cloud, stages the weighted dY0 of the cloud's columns in LDS (coalesced), then every source point sums
+// its list (ascending columns, four lanes per list combined in a fixed order): no atomics, deterministic.
+// dwx[cloud][c][0:3] = sum_i xyz[i] G[c][i] - sum_p w_p dY0[c][p] centre(group of p).
+template <int CH>
+__global__ __launch_bounds__(256) void scatter_csr_cols_kernel(int cout, int n, int G, long long cap,
+                                                               const float* __restrict__ y,
+                                                               const float* __restrict__ d,
+                                                               const float* __restrict__ bn,
+                                                               const float* __restrict__ bwdc,
+                                                               const int* __restrict__ gstart,
+                                                               const int* __restrict__ off_all,
+                                                               const int* __restrict__ ent_all,
+                                                               const int* __restrict__ meta,
+                                                               const float* __restrict__ colw,
+                                                               float* __restrict__ out, long long out_bstride,
+                                                               const float* __restrict__ xyz,
+                                                               const float* __restrict__ new_xyz,
+                                                               float* __restrict__ dwx) {
+  extern __shared__ __attribute__((aligned(16))) float dy[];   // [columns of the cloud][CH]
+  const int b = blockIdx.y, c0 = blockIdx.x * CH;
+  const int nch = min(CH, cout - c0);
+  const int base = gstart[b * G], Pb = gstart[(b + 1) * G] - base;
+  float rs[CH], rh[CH], ca[CH], cb[CH], cc[CH];
+#pragma unroll
+  for (int ch = 0; ch < CH; ++ch) {
+    const int co = min(c0 + ch, cout - 1);
+    rs[ch] = bn[co]; rh[ch] = bn[cout + co];
+    ca[ch] = bwdc[co]; cb[ch] = bwdc[cout + co]; cc[ch] = bwdc[2 * cout + co];
+  }
+  for (int p = threadIdx.x; p < Pb; p += 256) {
+    const float wcol = colw[base + p];
+#pragma unroll
+    for (int ch = 0; ch < CH; ++ch) {
+      const size_t o = (size_t)min(c0 + ch, cout - 1) * cap + base + p;
+      const float yv = y[o];
+      dy[(size_t)p * CH + ch] = wcol * (ca[ch] * ((yv * rs[ch] + rh[ch] > 0.f) ? d[o] : 0.f) + cb[ch] + cc[ch] * yv);
+    }
+  }
+  __syncthreads();
+  const int* off = off_all + (size_t)b * (n + 1);
+  const int* ent = ent_all + base;
+  float wx[CH][3];
+#pragma unroll
+  for (int ch = 0; ch < CH; ++ch) wx[ch][0] = wx[ch][1] = wx[ch][2] = 0.f;
+  const int part = threadIdx.x & 3;
+  const int n_round = (n + 63) / 64 * 64;
+  for (int i = threadIdx.x >> 2; i < n_round; i += 64) {
+    const bool valid = i < n;
+    const int a0 = valid ? off[i] : 0, z0 = valid ? off[i + 1] : 0;
+    const int len = z0 - a0, q = (len + 3) >> 2;
+    const int a = min(a0 + part * q, z0), z = min(a + q, z0);
+    float sum[CH], wc[CH][3];
+#pragma unroll
+    for (int ch = 0; ch < CH; ++ch) { sum[ch] = 0.f; wc[ch][0] = wc[ch][1] = wc[ch][2] = 0.f; }
+    for (int u = a; u < z; ++u) {
+      const int e = ent[u];
+      float c3[3] = {0.f, 0.f, 0.f};
+      if (dwx != nullptr) {
+        const float* cp = new_xyz + (size_t)(meta[base + e] >> 6) * 3;
+        c3[0] = cp[0]; c3[1] = cp[1]; c3[2] = cp[2];
+      }
+#pragma unroll
+      for (int ch = 0; ch < CH; ++ch) {
+        const float v = dy[(size_t)e * CH + ch];
+        sum[ch] += v;
+        wc[ch][0] += v * c3[0]; wc[ch][1] += v * c3[1]; wc[ch][2] += v * c3[2];
+      }
+    }
+#pragma unroll
+    for (int ch = 0; ch < CH; ++ch) {
+      sum[ch] += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(sum[ch]), 0xB1, 0xf, 0xf, false));
+      sum[ch] += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(sum[ch]), 0x4E, 0xf, 0xf, false));
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        wc[ch][k] += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(wc[ch][k]), 0xB1, 0xf, 0xf, false));
+        wc[ch][k] += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(wc[ch][k]), 0x4E, 0xf, 0xf, false));
+      }
+    }
+    if (valid && part == 0) {
+#pragma unroll
+      for (int ch = 0; ch < CH; ++ch)
+        if (ch < nch) out[(size_t)b * out_bstride + (size_t)(c0 + ch) * n + i] = sum[ch];
+      if (dwx != nullptr) {
+        const float* xs = xyz + ((size_t)b * n + i) * 3;
+        const float px = xs[0], py = xs[1], pz = xs[2];
+#pragma unroll
+        for (int ch = 0; ch < CH; ++ch) {
+          wx[ch][0] += px * sum[ch] - wc[ch][0]; wx[ch][1] += py * sum[ch] - wc[ch][1]; wx[ch][2] += pz * sum[ch] - wc[ch][2];
+        }
+      }
+    }
+  }
+  if (dwx != nullptr) {
+    __syncthreads();
+    float* wred = dy;     // [4 waves][CH*3]
+#pragma unroll
+    for (int ch = 0; ch < CH; ++ch)
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        const float t = wave_sum(wx[ch][k]);
+        if (lane_id() == 0) wred[(threadIdx.x >> 6) * CH * 3 + ch * 3 + k] = t;
+      }
+    __syncthreads();
+    if (threadIdx.x < nch * 3)
+      dwx[((size_t)b * cout + c0) * 3 + threadIdx.x] = (wred[threadIdx.x] + wred[CH * 3 + threadIdx.x]) +
+                                                       (wred[2 * CH * 3 + threadIdx.x] + wred[3 * CH * 3 + threadIdx.x]);
+  }
+}
+
 }  // namespace
 
 extern "C" {
@@ -338,6 +459,36 @@ int istnet_pw_dwx_cols(int cout, long long cap, const float* y, const float* d_d
     return ISTNET_PN2_EINVAL;
   hipLaunchKernelGGL(dwx_cols_kernel, dim3(ceil_div(cout, kDwxCH), istnet_pw_dwx_cols_chunks(cout)), dim3(256), 0,
                      as_stream(stream), cout, cap, y, d_dense, bn, bwdc, cidx, meta, colw, ncols, xyz, new_xyz, dwx);
+  return (int)hipGetLastError();
+}
+
+int istnet_pw_scatter_dy_csr_cols(int b, int cout, int n, int g, long long cap, const float* y, const float* d_dense,
+                                  const float* bn, const float* bwdc, const int* gstart, const int* offsets,
+                                  const int* entries, const int* meta, const float* colw, float* out,
+                                  long long out_bstride, const float* xyz, const float* new_xyz, float* dwx,
+                                  void* stream) {
+  if (b <= 0 || cout <= 0 || n <= 0 || g <= 0 || cap <= 0 || (cap % b) || !y || !d_dense || !bn || !bwdc || !gstart ||
+      !offsets || !entries || !meta || !colw || !out)
+    return ISTNET_PN2_EINVAL;
+  if (dwx != nullptr && (xyz == nullptr || new_xyz == nullptr)) return ISTNET_PN2_EINVAL;
+  const long long pc = cap / b;                         // most columns one cloud can hold
+  int ch = 16;
+  while (ch > 1 && ((size_t)ch * pc * 4 > 64 * 1024 || (long long)b * ceil_div(cout, ch) < 512)) ch >>= 1;
+  if ((size_t)ch * pc * 4 > 64 * 1024) return ISTNET_PN2_EINVAL;
+  const size_t lds = (size_t)ch * pc * 4 < 4 * 16 * 3 * 4 ? 4 * 16 * 3 * 4 : (size_t)ch * pc * 4;
+  const dim3 grid(ceil_div(cout, ch), b);
+  const long long obs = out_bstride > 0 ? out_bstride : (long long)cout * n;
+#define ISTNET_SCSRC(CH)                                                                                          \
+  hipLaunchKernelGGL(scatter_csr_cols_kernel<CH>, grid, dim3(256), lds, as_stream(stream), cout, n, g, cap, y,     \
+                     d_dense, bn, bwdc, gstart, offsets, entries, meta, colw, out, obs, xyz, new_xyz, dwx)
+  switch (ch) {
+    case 16: ISTNET_SCSRC(16); break;
+    case 8: ISTNET_SCSRC(8); break;
+    case 4: ISTNET_SCSRC(4); break;
+    case 2: ISTNET_SCSRC(2); break;
+    default: ISTNET_SCSRC(1); break;
+  }
+#undef ISTNET_SCSRC
   return (int)hipGetLastError();
 }
 

@@ -124,6 +124,8 @@ class PointNet2MSG(nn.Module):
                 problems, where = [], []
                 if fused_mlp.USE_CSR_SCATTER:
                     for lvl in range(1, len(sa_geo)):       # level 0 has no input features, hence no scatter
+                        if sa_geo[lvl][4] is not None:      # compact-column level: lists of its columns instead (below)
+                            continue
                         for si, i in enumerate(sa_geo[lvl][1]):
                             problems.append((i, levels[lvl].shape[1]))
                             where.append(("sa", lvl, si))
@@ -141,6 +143,12 @@ class PointNet2MSG(nn.Module):
                 for lvl in range(1, len(sa_geo)):
                     if sa_geo[lvl][3] is not None and any(c is None for c in sa_geo[lvl][3]):
                         sa_geo[lvl][3] = None
+                # inverse lists of the compact columns of the levels that have input features (their backward scatters
+                # the layer-0 gradient through them)
+                lists_of = getattr(pointnet2_utils._ext, "ball_compact_lists", None)
+                todo = [c for lvl in range(1, len(sa_geo)) for c in (sa_geo[lvl][4] or ())]
+                if todo and lists_of is not None and fused_mlp.USE_CSR_SCATTER:
+                    lists_of(todo)
                 csr_ev = torch.cuda.Event()
                 csr_ev.record(side)
             fp_geo = [tuple(g) for g in fp_geo]

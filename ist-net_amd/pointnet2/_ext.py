@@ -203,11 +203,14 @@ def ball_csr(idx, n):
 class BallCompact:
     """Compact-column tables of one ball-query index tensor (csrc/sa_compact.hip): per group its distinct neighbours
     plus one weighted representative of the padded repeats, all groups of all clouds on one point axis of static
-    capacity ``cap`` = B * npoint * nsample; the valid column count is ``gstart[-1]`` on the device."""
-    __slots__ = ("glen", "gstart", "cidx", "meta", "colw", "b", "g", "s", "n", "cap")
+    capacity ``cap`` = B * npoint * nsample; the valid column count is ``gstart[-1]`` on the device.
+    ``cstart`` (B + 1) = first column of every cloud; ``csr`` = (offsets (B, n + 1), entries (cap)) inverse lists of the
+    columns over the source points (``ball_compact_lists``), needed by the backward of a scale that has input features."""
+    __slots__ = ("glen", "gstart", "cidx", "meta", "colw", "cstart", "csr", "b", "g", "s", "n", "cap")
 
-    def __init__(self, glen, gstart, cidx, meta, colw, b, g, s, n):
+    def __init__(self, glen, gstart, cidx, meta, colw, b, g, s, n, cstart=None, csr=None):
         self.glen, self.gstart, self.cidx, self.meta, self.colw = glen, gstart, cidx, meta, colw
+        self.cstart, self.csr = cstart, csr
         self.b, self.g, self.s, self.n, self.cap = b, g, s, n, b * g * s
 
     @property
@@ -215,10 +218,51 @@ class BallCompact:
         return self.gstart.data_ptr() + 4 * self.b * self.g
 
     def tensors(self):
-        return [self.glen, self.gstart, self.cidx, self.meta, self.colw]
+        out = [self.glen, self.gstart, self.cidx, self.meta, self.colw]
+        if self.csr is not None:
+            out += [self.cstart, *self.csr]
+        return out
 
     def with_tensors(self, tensors):
-        return BallCompact(*tensors, self.b, self.g, self.s, self.n)
+        tensors = list(tensors)
+        cm = BallCompact(*tensors[:5], self.b, self.g, self.s, self.n)
+        if self.csr is not None:
+            cm.cstart, cm.csr = tensors[5], (tensors[6], tensors[7])
+        return cm
+
+
+def ball_compact_lists(compacts):
+    """Inverse lists (source point -> its compact columns, ascending) for several BallCompact tables in one launch
+    (istnet_pn2_csr_build_segmented); sets ``cstart`` / ``csr`` on each and returns True, or False when a table is too
+    large for the build kernel (nothing is set then)."""
+    import ctypes
+    compacts = [c for c in compacts if c is not None]
+    if not compacts:
+        return False
+    lib = _native.lib()
+    b = compacts[0].b
+    if any(c.b != b for c in compacts) or len(compacts) > 12:
+        return False
+    if not all(_csr_fits(c.g * c.s, c.n)[0] for c in compacts):
+        return False
+    dev = compacts[0].gstart.device
+    work = []
+    for c in compacts:
+        cstart = c.gstart[::c.g].contiguous()                                    # (B + 1): first column of every cloud
+        off = torch.empty((b, c.n + 1), dtype=torch.int32, device=dev)
+        ent = torch.empty((c.cap,), dtype=torch.int32, device=dev)
+        work.append((c, cstart, off, ent))
+    n = len(work)
+    arr = lambda ts: (ctypes.c_void_p * n)(*[_ptr(t) for t in ts])
+    with torch.cuda.device(dev):
+        _native.check(lib.istnet_pn2_csr_build_segmented(
+            n, b, (ctypes.c_int * n)(*[c.g * c.s for c, _, _, _ in work]), (ctypes.c_int * n)(*[c.n for c, _, _, _ in work]),
+            arr([c.cidx for c, _, _, _ in work]), arr([w[2] for w in work]), arr([w[3] for w in work]),
+            arr([w[1] for w in work]), (ctypes.c_int * n)(*[c.n for c, _, _, _ in work]), _stream(dev)),
+            "csr_build_segmented")
+    for c, cstart, off, ent in work:
+        c.cstart, c.csr = cstart, (off, ent)
+    return True
 
 
 def ball_compact(idx, n):

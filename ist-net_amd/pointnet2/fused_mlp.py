@@ -300,13 +300,14 @@ def _forward_stack(lib, dev, st, b, c0, g, s, x, gather, training, layers, param
 
 
 def _forward_stack_compact(lib, dev, st, b, g, s, ga, training, layers, params, out_spec):
-    """_forward_stack on compact columns (xyz-only layer 0): activations are (1, C, cap) with the first T columns
-    valid, T on the device.  Statistics are weighted by the column multiplicities, so BatchNorm sees exactly the sums of
-    the padded evaluation (count = b * g * s)."""
+    """_forward_stack on compact columns: activations are (1, C, cap) with the first T columns valid, T on the device.
+    Statistics are weighted by the column multiplicities, so BatchNorm sees exactly the sums of the padded evaluation
+    (count = b * g * s).  Layer 0 is the split form: Z = W0[:, 3:] . feat over the n source points, then
+    y0 = Z[:, source] + W0[:, :3] . (xyz[source] - centre) per compact column."""
     cm = ga.compact
     cap, ncols = cm.cap, cm.ncols_ptr
     ys, bns = [], []
-    cur, cur_c, in_bn = None, 3, None
+    cur, cur_c, in_bn = None, 3 + ga.cfeat, None
     for li, lay in enumerate(layers):
         w, gamma, beta = params[3 * li], params[3 * li + 1], params[3 * li + 2]
         cout = w.shape[0]
@@ -320,9 +321,17 @@ def _forward_stack_compact(lib, dev, st, b, g, s, ga, training, layers, params, 
         else:
             nt, ps, pq = 0, None, None
         if li == 0:
+            z = None
+            if ga.cfeat > 0:
+                z = _empty((b, cout, ga.n), torch.float32, dev)
+                _native.check(_native.timed(
+                    _kname("pw_fwd_kernel", lib.istnet_pw_tile_cfg(b, cout, ga.n), 0), 2.0 * b * ga.n * ga.cfeat * cout,
+                    4.0 * b * ga.n * (ga.cfeat + cout), lambda: lib.istnet_pw_forward_ld(
+                        b, ga.cfeat, cout, ga.n, ga.feat.data_ptr(), w2.data_ptr() + 12, cur_c, None, None,
+                        z.data_ptr(), None, None, st)), "pw_forward_ld")
             _native.check(lib.istnet_pw_gather_add_cols(
                 b, ga.n, g, cap, cout, ga.xyz.data_ptr(), ga.new_xyz.data_ptr(), cm.cidx.data_ptr(), cm.meta.data_ptr(),
-                cm.colw.data_ptr(), ncols, None, w2.data_ptr(), cur_c, y.data_ptr(), ps, pq, st), "pw_gather_add_cols")
+                cm.colw.data_ptr(), ncols, _p(z), w2.data_ptr(), cur_c, y.data_ptr(), ps, pq, st), "pw_gather_add_cols")
         else:
             _native.check(lib.istnet_pw_forward_cols(
                 cur_c, cout, cap, cur.data_ptr(), w2.data_ptr(), in_bn[0].data_ptr(), in_bn[1].data_ptr(), y.data_ptr(),
@@ -461,17 +470,27 @@ def _wgrad_job(lib, dev, b, cin, cout, p, ns_arg, use_gather, ga, src, in_bn, y,
 
 # Set-abstraction levels (0-based) whose scales are evaluated on compact columns (csrc/sa_compact.hip): the repeats that
 # pad a ball-query row are computed once and enter every sum over points with their multiplicity.  Level 0 (xyz only,
-# 16/16/32 channels) is where the padding is heaviest -- 83 % / 67 % of the slots on the benchmark clouds.
-COMPACT_LEVELS = frozenset() if os.environ.get("ISTNET_NO_COMPACT") is not None else frozenset({0})
+# 16/16/32 channels) is where the padding is heaviest -- 83 % / 67 % of the slots on the benchmark clouds -- and where it
+# pays: 3.31 -> 3.22 ms/step.  Level 1 (68 % / 36 % padded; its tables, lists and weighted dgrad / wgrad / scatter are
+# implemented and tested) measured level with the padded evaluation on the same box (3.23 ms): what the fewer columns
+# save goes into the dense compact gradient of the pooled layer and the per-column list scatter; level 2 (12 % padded)
+# loses 0.25 ms.  ISTNET_COMPACT_LEVELS=0,1 selects more levels (denser padding: the cube clouds keep 10 % / 39 % at
+# level 1).
+COMPACT_LEVELS = (frozenset() if os.environ.get("ISTNET_NO_COMPACT") is not None else
+                  frozenset(int(v) for v in os.environ.get("ISTNET_COMPACT_LEVELS", "0").split(",") if v != ""))
 
 
-def _compact_ok(lib, ga, layers, params):
-    """The compact-column kernels cover: xyz-only layer 0 (no feature scatter), every later layer within the fused
-    small-layer backward (cin, cout <= 32)."""
-    if ga.compact is None or ga.cfeat != 0 or not USE_SPLIT_LAYER0 or not USE_FUSED_SMALL_BWD:
+def _compact_ok(lib, ga, layers, params, needs_backward, needs_feature_grad):
+    """Can this scale run on compact columns?  Layer 0 must be the split form (source-point GEMM + gather-add); the
+    backward of a scale with input features scatters the layer-0 gradient through the inverse lists of its columns into
+    the level-wide feature-gradient GEMM (n <= 4096, n % 4 == 0), which exists only when that gradient is wanted."""
+    if ga.compact is None or not USE_SPLIT_LAYER0 or len(layers) < 2:
         return False
-    widths = [params[3 * li].shape[0] for li in range(len(layers))]
-    return len(widths) >= 2 and all(lib.istnet_pw_bwd_small_ok(widths[li - 1], widths[li], 256) for li in range(1, len(widths)))
+    if ga.cfeat > 0 and (ga.cfeat % 4 or ga.n % 4):
+        return False
+    if ga.cfeat > 0 and needs_backward:
+        return needs_feature_grad and USE_CSR_SCATTER and ga.compact.csr is not None and ga.n <= 4096
+    return True
 
 
 USE_FUSED_SMALL_BWD = os.environ.get("ISTNET_NO_FUSED_SMALL_BWD") is None
@@ -513,7 +532,7 @@ def _backward_stack(lib, dev, st, b, c0, g, s, x, gather, training, ys, bns, par
     p = g * s
     if gather is not None and gather.compact is not None:
         return _backward_stack_compact(lib, dev, st, b, g, s, gather, training, ys, bns, params, arg, dout, need_w,
-                                       pooled_bstride)
+                                       need_x, pooled_bstride, scatter_out)
     n = len(ys)
     grads = [None] * (3 * n)
     pooled = s > 1
@@ -662,10 +681,12 @@ def _backward_stack(lib, dev, st, b, c0, g, s, x, gather, training, ys, bns, par
     return grads, dx, scattered
 
 
-def _backward_stack_compact(lib, dev, st, b, g, s, ga, training, ys, bns, params, arg, dout, need_w, pooled_bstride):
-    """_backward_stack on compact columns (xyz-only scale: no input gradient).  The gradient through the max-pool becomes
-    a dense compact tensor once; every layer above layer 0 runs the fused small-layer backward with column weights;
-    layer 0's weight gradient is the weighted xyz reduction."""
+def _backward_stack_compact(lib, dev, st, b, g, s, ga, training, ys, bns, params, arg, dout, need_w, need_x,
+                            pooled_bstride, scatter_out):
+    """_backward_stack on compact columns.  The gradient through the max-pool becomes a dense compact tensor once; the
+    layers above layer 0 run the fused small-layer backward (<= 32 channels) or the dgrad / wgrad pair, all with column
+    weights; layer 0: the weighted xyz reduction (xyz-only scale), or the weighted scatter over the inverse lists of
+    the columns into the level's G buffer (``scatter_out``) -- the level node finishes dW0 and the feature gradient."""
     cm = ga.compact
     cap, ncols, colw = cm.cap, cm.ncols_ptr, cm.colw.data_ptr()
     n = len(ys)
@@ -673,10 +694,12 @@ def _backward_stack_compact(lib, dev, st, b, g, s, ga, training, ys, bns, params
     count = float(b * g * s)
     wjobs, wlayers = [], []
     d_dense, fused_part, fused_nt = None, None, 0
+    scattered = False
     for li in range(n - 1, -1, -1):
         w, gamma = params[3 * li], params[3 * li + 1]
         cout = w.shape[0]
-        cin = 3 if li == 0 else params[3 * (li - 1)].shape[0]
+        cin = 3 + ga.cfeat if li == 0 else params[3 * (li - 1)].shape[0]
+        w2 = w.reshape(cout, cin)
         y, bn = ys[li], bns[li]
         if li == n - 1:      # through the max-pool: statistics from the (B, C, G) tensors, then the dense compact gradient
             part, nt_l = _empty((2, cout, b), torch.float32, dev), b
@@ -696,33 +719,69 @@ def _backward_stack_compact(lib, dev, st, b, g, s, ga, training, ys, bns, params
             cout, nt_l, count, 1 if training else 0, part[0].data_ptr(), part[1].data_ptr(), gamma.data_ptr(),
             bn.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), bwdc.data_ptr(), st), "bn_finalize_bwd")
         grads[3 * li + 1], grads[3 * li + 2] = dgamma, dbeta
-        if li > 0:
+        if li > 0 and USE_FUSED_SMALL_BWD and lib.istnet_pw_bwd_small_ok(cin, cout, 256):
             splits = lib.istnet_pw_bwd_small_cols_splits()
             ws = _empty((splits, cout, cin), torch.float32, dev)
             dprev = _empty((1, cin, cap), torch.float32, dev)
             fused_part, fused_nt = _empty((2, cin, splits), torch.float32, dev), splits
             _native.check(lib.istnet_pw_bwd_small_cols(
-                cin, cout, cap, w.reshape(cout, cin).data_ptr(), ys[li - 1].data_ptr(), bns[li - 1].data_ptr(),
+                cin, cout, cap, w2.data_ptr(), ys[li - 1].data_ptr(), bns[li - 1].data_ptr(),
                 y.data_ptr(), d_dense.data_ptr(), bn.data_ptr(), bwdc.data_ptr(), dprev.data_ptr(),
                 fused_part[0].data_ptr(), fused_part[1].data_ptr(), ws.data_ptr(), ncols, colw, st), "pw_bwd_small_cols")
             if need_w[li]:
                 wjobs.append(_reduce_only_job(dev, w, cout, cin, splits, ws))
                 wlayers.append(li)
             d_dense = dprev
-        elif need_w[0]:
-            chunks = lib.istnet_pw_dwx_cols_chunks(cout)
-            y0, d0, bn0 = y, d_dense, bn
+        elif li > 0:
+            if need_w[li]:
+                def wgrad_job(wst, cin=cin, cout=cout, w=w, x=ys[li - 1], bn_in=bns[li - 1], y=y, d=d_dense, bn=bn, bwdc=bwdc):
+                    splits = lib.istnet_pw_wgrad_cols_splits(cin, cout)
+                    ws = _empty((splits, cout, cin), torch.float32, dev)
+                    dw = _grad_dest(w, (cout, cin), dev)
+                    _native.check(lib.istnet_pw_wgrad_cols(cin, cout, cap, x.data_ptr(), bn_in[0].data_ptr(),
+                                                           bn_in[1].data_ptr(), y.data_ptr(), d.data_ptr(), bn.data_ptr(),
+                                                           bwdc.data_ptr(), ws.data_ptr(), ncols, colw, wst), "pw_wgrad_cols")
+                    return cout * cin, splits, ws, dw
+                wjobs.append(wgrad_job)
+                wlayers.append(li)
+            dprev = _empty((1, cin, cap), torch.float32, dev)
+            fused_nt = lib.istnet_pw_dgrad_stat_tiles(1, cin, cap)
+            fused_part = _empty((2, cin, fused_nt), torch.float32, dev)
+            _native.check(lib.istnet_pw_dgrad_cols(
+                cin, 0, cin, cout, cap, w2.data_ptr(), y.data_ptr(), d_dense.data_ptr(), bn.data_ptr(), bwdc.data_ptr(),
+                dprev.data_ptr(), ys[li - 1].data_ptr(), bns[li - 1].data_ptr(), fused_part[0].data_ptr(),
+                fused_part[1].data_ptr(), ncols, colw, st), "pw_dgrad_cols")
+            d_dense = dprev
+        elif ga.cfeat == 0:
+            if need_w[0]:
+                chunks = lib.istnet_pw_dwx_cols_chunks(cout)
 
-            def dwx_job(wst, cout=cout, chunks=chunks, y0=y0, d0=d0, bn0=bn0, bwdc=bwdc, w=w):
-                ws0 = _empty((chunks, cout, 3), torch.float32, dev)
-                dw = _grad_dest(w, (cout, 3), dev)
-                _native.check(lib.istnet_pw_dwx_cols(cout, cap, y0.data_ptr(), d0.data_ptr(), bn0.data_ptr(),
-                                                     bwdc.data_ptr(), cm.cidx.data_ptr(), cm.meta.data_ptr(), colw, ncols,
-                                                     ga.xyz.data_ptr(), ga.new_xyz.data_ptr(), ws0.data_ptr(), wst),
-                              "pw_dwx_cols")
-                return cout * 3, chunks, ws0, dw
-            wjobs.append(dwx_job)
-            wlayers.append(0)
+                def dwx_job(wst, cout=cout, chunks=chunks, y0=y, d0=d_dense, bn0=bn, bwdc=bwdc, w=w):
+                    ws0 = _empty((chunks, cout, 3), torch.float32, dev)
+                    dw = _grad_dest(w, (cout, 3), dev)
+                    _native.check(lib.istnet_pw_dwx_cols(cout, cap, y0.data_ptr(), d0.data_ptr(), bn0.data_ptr(),
+                                                         bwdc.data_ptr(), cm.cidx.data_ptr(), cm.meta.data_ptr(), colw,
+                                                         ncols, ga.xyz.data_ptr(), ga.new_xyz.data_ptr(), ws0.data_ptr(),
+                                                         wst), "pw_dwx_cols")
+                    return cout * 3, chunks, ws0, dw
+                wjobs.append(dwx_job)
+                wlayers.append(0)
+        elif need_x and scatter_out is not None:
+            # G = weighted scatter of dY0 over the inverse lists of the columns, into this scale's rows of the level's
+            # buffer; dwx = its xyz-weight partials per cloud (placeholder the level node turns into dW0)
+            gbuf, goff = scatter_out
+            dwx = _empty((b, cout, 3), torch.float32, dev) if need_w[0] else None
+            off, ent = cm.csr
+            _native.check(lib.istnet_pw_scatter_dy_csr_cols(
+                b, cout, ga.n, g, cap, y.data_ptr(), d_dense.data_ptr(), bn.data_ptr(), bwdc.data_ptr(),
+                cm.gstart.data_ptr(), off.data_ptr(), ent.data_ptr(), cm.meta.data_ptr(), colw,
+                gbuf.data_ptr() + goff * ga.n * 4, gbuf.shape[1] * ga.n, ga.xyz.data_ptr(), ga.new_xyz.data_ptr(),
+                _p(dwx), st), "pw_scatter_dy_csr_cols")
+            if need_w[0]:
+                grads[0] = dwx
+            scattered = True
+        else:
+            raise RuntimeError("compact set-abstraction scale with input features needs the level-wide feature gradient")
     if wjobs:
         wparams = [params[3 * li] for li in wlayers]
         if _can_defer(wparams):
@@ -741,7 +800,7 @@ def _backward_stack_compact(lib, dev, st, b, g, s, ga, training, ys, bns, params
             _native.reduce_multi([(cnt, splits, ws.data_ptr(), dw.data_ptr()) for cnt, splits, ws, dw in done], st)
         for li, (_, _, _, dw) in zip(wlayers, done):
             grads[3 * li] = dw.view_as(params[3 * li])
-    return grads, None, False
+    return grads, None, scattered
 
 
 class FusedSharedMLPFunction(Function):
@@ -866,7 +925,7 @@ class FusedSALevelFunction(Function):
             used = []
             for layers, params, idx, stream, cm in zip(scales, plist, idxs, streams, compacts):
                 ga = _Gather(xyz, new_xyz, feat, idx, feat_t, compact=cm)
-                if not _compact_ok(lib, ga, layers, params):
+                if not _compact_ok(lib, ga, layers, params, any(ctx.needs_input_grad), ctx.needs_input_grad[0]):
                     ga.compact = None
                 used.append(ga.compact)
                 with torch.cuda.stream(stream):
@@ -883,7 +942,8 @@ class FusedSALevelFunction(Function):
         csrs = list(csrs) if csrs is not None else [None] * nsc
         if USE_CSR_SCATTER and feat is not None and features.requires_grad and xyz.shape[1] <= 4096:
             from . import _ext
-            csrs = [c if c is not None else _ext.ball_csr(idx, xyz.shape[1]) for c, idx in zip(csrs, idxs)]
+            csrs = [c if (c is not None or cm is not None) else _ext.ball_csr(idx, xyz.shape[1])
+                    for c, idx, cm in zip(csrs, idxs, used)]     # compact scales scatter through their own lists
         ctx.csrs = csrs
         ctx.compacts = used
         ctx.dims = (b, g, ctot)

@@ -408,3 +408,60 @@ def test_compact_columns_equal_padded_evaluation(training):
         torch.testing.assert_close(res[0][1][k], res[1][1][k], rtol=2e-4, atol=2e-5, msg=lambda s, k=k: f"{k}: {s}")
     for k in res[0][2]:
         torch.testing.assert_close(res[0][2][k], res[1][2][k], rtol=1e-5, atol=1e-6, msg=lambda s, k=k: f"{k}: {s}")
+
+
+@pytest.mark.parametrize("widths", [[32, 32, 64], [64, 64, 128], [16, 32]])
+def test_compact_columns_with_input_features_equal_padded_evaluation(widths):
+    """A level-2-like MSG level (input features, padded balls) on compact columns vs the padded evaluation: output,
+    feature gradient, every parameter gradient.  [32, 32, 64] takes the fused small-layer backward for layer 1 and the
+    weighted dgrad / wgrad pair for layer 2; [64, 64, 128] the pair for both; layer 0 scatters through the inverse lists
+    of the compact columns into the level-wide feature-gradient GEMM."""
+    from istnet_amd.pointnet2 import _ext
+    from istnet_amd.pointnet2.pointnet2_modules import PointnetSAModuleMSG
+    cfeat = 32
+
+    def make():
+        torch.manual_seed(13)
+        return PointnetSAModuleMSG(npoint=128, radii=[0.02, 0.04], nsamples=[16, 32],
+                                   mlps=[[cfeat, *widths], [cfeat, *widths]]).to(DEV).train()
+
+    xyz = _shell(4, 512, 8).to(DEV)
+    g = torch.Generator().manual_seed(3)
+    feat0 = torch.randn(4, cfeat, 512, generator=g).to(DEV)
+    _, new_xyz = _ext.furthest_point_sampling_gather(xyz, 128)
+    idx = [_ext.ball_query(new_xyz, xyz, r, s) for r, s in ((0.02, 16), (0.04, 32))]
+    comps = [_ext.ball_compact(i, 512) for i in idx]
+    assert _ext.ball_compact_lists(comps) and all(c.csr is not None for c in comps)
+    assert max(float(c.gstart[-1]) / c.cap for c in comps) < 0.9
+    wgt = torch.randn(4, 2 * widths[-1], 128, generator=g).to(DEV)
+    res = []
+    for use in (True, False):
+        m = make()
+        feat = feat0.clone().requires_grad_(True)
+        _, out = m(xyz, feat, geometry=(new_xyz, idx, None, comps if use else None))
+        (out * wgt).sum().backward()
+        torch.cuda.synchronize()
+        res.append((out.detach(), feat.grad.clone(), {k: p.grad.clone() for k, p in m.named_parameters()}))
+    torch.testing.assert_close(res[0][0], res[1][0], rtol=1e-5, atol=2e-5)
+    torch.testing.assert_close(res[0][1], res[1][1], rtol=2e-4, atol=2e-5)
+    for k in res[0][2]:
+        torch.testing.assert_close(res[0][2][k], res[1][2][k], rtol=3e-4, atol=3e-5, msg=lambda s, k=k: f"{k}: {s}")
+
+
+def test_compact_column_lists_are_the_inverse_of_the_column_table():
+    from istnet_amd.pointnet2 import _ext
+    xyz = _shell(3, 512, 4).to(DEV)
+    _, new_xyz = _ext.furthest_point_sampling_gather(xyz, 128)
+    idx = _ext.ball_query(new_xyz, xyz, 0.03, 32)
+    cm = _ext.ball_compact(idx, 512)
+    assert _ext.ball_compact_lists([cm])
+    torch.cuda.synchronize()
+    off, ent = cm.csr[0].cpu().long(), cm.csr[1].cpu().long()
+    cstart = cm.cstart.cpu().long()
+    assert torch.equal(cstart, cm.gstart.cpu().long()[::128])
+    for b in range(3):
+        lo, hi = int(cstart[b]), int(cstart[b + 1])
+        local = cm.cidx.cpu().long()[lo:hi] - b * 512
+        want = torch.argsort(local, stable=True)
+        assert torch.equal(ent[lo:hi], want)
+        assert torch.equal(off[b, 1:], torch.cumsum(torch.bincount(local, minlength=512), 0))
