@@ -6,7 +6,7 @@ db = sqlite3.connect(sys.argv[1])
 per = int(sys.argv[2]) if len(sys.argv) > 2 and sys.argv[2].isdigit() else 401
 cols = [r[1] for r in db.execute("pragma table_info(kernels)")]
 qcol = "queue_id" if "queue_id" in cols else ("queue" if "queue" in cols else None)
-strm = "stream_id" if "stream_id" in cols else qcol
+strm = qcol or "stream_id"      # hardware queue: a replayed graph reports stream 0 for every kernel
 rows = list(db.execute(f"select start, end, name, {strm} from kernels order by start"))
 rows = rows[-per:]
 t0 = rows[0][0]; t1 = max(r[1] for r in rows)
