@@ -147,8 +147,8 @@ class WorldSpaceEnhancer(nn.Module):
         return r, t, s, pts_w_local_gt
 
 
-USE_RGB_STREAM = os.environ.get("ISTNET_NO_RGB_STREAM") is None
-USE_GATHER_FIRST = os.environ.get("ISTNET_NO_GATHER_FIRST") is None
+USE_RGB_STREAM = True
+USE_GATHER_FIRST = True
 _RGB_STREAMS = {}
 
 

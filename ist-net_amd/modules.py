@@ -19,7 +19,7 @@ from .pointnet2.pointnet2_modules import PointnetFPModule, PointnetSAModuleMSG
 # They are tiny-grid, latency-bound kernels (FPS is 956 dependent rounds per cloud), so they are issued
 # on a second HIP stream at the start of the forward and overlap the MFMA stacks of the earlier levels;
 # the main stream waits on one event per level.
-USE_GEOMETRY_STREAM = os.environ.get("ISTNET_NO_GEOMETRY_STREAM") is None
+USE_GEOMETRY_STREAM = True
 _GEOMETRY_STREAMS = {}
 
 

@@ -33,6 +33,19 @@ else:
         return torch.empty(shape, dtype=dtype, device=device)
 
 
+FALLBACKS = {}     # reason -> number of times a CUDA input took the torch composition instead of the fused kernels
+
+
+def _note_fallback(reason):
+    """A CUDA input that the fused kernels do not cover runs the reference composition on torch / MIOpen: different
+    kernels, speed and (within fp32 round-off) numerics.  Counted per reason; the first occurrence warns."""
+    import warnings
+    FALLBACKS[reason] = FALLBACKS.get(reason, 0) + 1
+    if FALLBACKS[reason] == 1:
+        warnings.warn(f"istnet_amd: fused MFMA path not taken ({reason}); running the torch composition instead",
+                      RuntimeWarning, stacklevel=3)
+
+
 def _kname(base, cfg, gather=None):
     """Kernel symbol as rocprofv3 prints it, e.g. pw_dgrad_kernel<64, 64, 2, 2> or pw_fwd_kernel<128, 128, 2, 2, 0>.
     ``gather``: None for kernels without the template parameter, else the operand-loader mode (0 tensor input,
@@ -90,14 +103,14 @@ def _ident_consts(dev, c):
 # .grad would be read on the main stream before the join), no kernel timing in progress.  Everything the
 # deferred launches read is kept alive until the join.  (A per-layer fork onto a side stream was measured
 # slower: 32 extra cross-stream edges per step.)
-USE_DEFERRED_WGRAD = os.environ.get("ISTNET_NO_DEFER_WGRAD") is None
+USE_DEFERRED_WGRAD = True    # module attributes, not environment switches: tests flip each fallback once
+                             # (tests/test_pipeline_gpu.py::test_fallback_paths_agree_with_default)
 
 
 # Stream priorities were tried too (capture stream and scale streams at priority -1, the wgrad stream at 0): the step
 # went from 3.47 to 5.4 ms, so every stream stays at the default priority.
 # one wgrad stream for all chains: a stream per concurrent dgrad chain measured 0.2 ms/step SLOWER (the extra
 # GEMMs contend with the dependent chains they were meant to stay out of the way of)
-_W_PER_CHAIN = os.environ.get("ISTNET_WGRAD_STREAM_PER_CHAIN") is not None
 
 
 class _Deferred:
@@ -121,7 +134,7 @@ class _Deferred:
     @classmethod
     def stream(cls, dev, chain):
         key = dev.index if dev.index is not None else torch.cuda.current_device()
-        skey = (key, chain.cuda_stream if _W_PER_CHAIN else 0)
+        skey = (key, 0)
         if skey not in cls.streams:
             cls.streams[skey] = torch.cuda.Stream(device=dev)
         return key, cls.streams[skey]
@@ -364,7 +377,7 @@ def _forward_stack_compact(lib, dev, st, b, g, s, ga, training, layers, params, 
 # Run scale i >= 1 on its own stream: one chain's launch gaps and tiny kernels are filled by the other's GEMMs.
 # Fork/join discipline: the side stream waits on the main stream before it starts and the main stream joins it
 # before the level's result is used, so tensors may cross (allocated in one stream's pool, read by the other).
-USE_SCALE_STREAMS = os.environ.get("ISTNET_NO_SCALE_STREAMS") is None
+USE_SCALE_STREAMS = True
 _SCALE_STREAMS = {}
 
 
@@ -474,10 +487,9 @@ def _wgrad_job(lib, dev, b, cin, cout, p, ns_arg, use_gather, ga, src, in_bn, y,
 # pays: 3.31 -> 3.22 ms/step.  Level 1 (68 % / 36 % padded; its tables, lists and weighted dgrad / wgrad / scatter are
 # implemented and tested) measured level with the padded evaluation on the same box (3.23 ms): what the fewer columns
 # save goes into the dense compact gradient of the pooled layer and the per-column list scatter; level 2 (12 % padded)
-# loses 0.25 ms.  ISTNET_COMPACT_LEVELS=0,1 selects more levels (denser padding: the cube clouds keep 10 % / 39 % at
-# level 1).
-COMPACT_LEVELS = (frozenset() if os.environ.get("ISTNET_NO_COMPACT") is not None else
-                  frozenset(int(v) for v in os.environ.get("ISTNET_COMPACT_LEVELS", "0").split(",") if v != ""))
+# loses 0.25 ms.  ISTNET_COMPACT_LEVELS=0,1 (or assigning this attribute) selects more levels -- denser padding: the
+# cube clouds keep 10 % / 39 % at level 1 -- and ISTNET_COMPACT_LEVELS= none.
+COMPACT_LEVELS = frozenset(int(v) for v in os.environ.get("ISTNET_COMPACT_LEVELS", "0").split(",") if v != "")
 
 
 def _compact_ok(lib, ga, layers, params, needs_backward, needs_feature_grad):
@@ -486,6 +498,9 @@ def _compact_ok(lib, ga, layers, params, needs_backward, needs_feature_grad):
     the level-wide feature-gradient GEMM (n <= 4096, n % 4 == 0), which exists only when that gradient is wanted."""
     if ga.compact is None or not USE_SPLIT_LAYER0 or len(layers) < 2:
         return False
+    widths = [params[3 * li].shape[0] for li in range(len(layers))]
+    if not USE_FUSED_SMALL_BWD and any(lib.istnet_pw_bwd_small_ok(widths[li - 1], widths[li], 256) for li in range(1, len(widths))):
+        return False       # <= 32-channel layers have no weighted dgrad / wgrad pair, only the fused kernel
     if ga.cfeat > 0 and (ga.cfeat % 4 or ga.n % 4):
         return False
     if ga.cfeat > 0 and needs_backward:
@@ -493,9 +508,9 @@ def _compact_ok(lib, ga, layers, params, needs_backward, needs_feature_grad):
     return True
 
 
-USE_FUSED_SMALL_BWD = os.environ.get("ISTNET_NO_FUSED_SMALL_BWD") is None
-USE_SPLIT_LAYER0 = os.environ.get("ISTNET_NO_SPLIT_LAYER0") is None
-USE_CSR_SCATTER = os.environ.get("ISTNET_NO_CSR_SCATTER") is None
+USE_FUSED_SMALL_BWD = True
+USE_SPLIT_LAYER0 = True
+USE_CSR_SCATTER = True     # False: LDS-atomic scatter (steps are then not bit-reproducible)
 
 
 def _dwx_only_job(lib, dev, b, cout, p, ns_arg, ga, y, d_dense, d_pooled, pbs, d_arg, bn, bwdc, wparam):
@@ -1242,6 +1257,8 @@ def fp_level(mlp, known_feats, skip, idx, weight, csr=None):
         return None
     c1 = skip.shape[1] if skip is not None else 0
     if m % 32 or n % 32 or known_feats.shape[1] % 4 or c1 % 4 or not _fusable_shape(mlp, n, 1):
+        _note_fallback(f"feature propagation with n={n}, m={m}, channels {known_feats.shape[1]}+{c1}: needs n, m % 32 == 0, "
+                       "channels % 4 == 0 and a plain conv1x1/BatchNorm/ReLU stack")
         return None
     layers, params = _layer_args(mlp)
     out = FusedFPFunction.apply(known_feats, skip, idx, weight, csr, mlp.training, layers, *params)
@@ -1250,7 +1267,7 @@ def fp_level(mlp, known_feats, skip, idx, weight, csr=None):
     return out
 
 
-USE_FUSED_FP = os.environ.get("ISTNET_NO_FUSED_FP") is None
+USE_FUSED_FP = True
 _ONES = {}
 
 
@@ -1328,6 +1345,9 @@ def pointwise_conv_stack(seq, x):
         relu_after.append(has_relu)
         i += 2 if has_relu else 1
     if not ok or not convs or not all(relu_after[:-1]):
+        if x.is_cuda:
+            _note_fallback(f"per-point conv stack on input {tuple(x.shape)} {x.dtype}: needs float32 (B, C, N) with N % 32 == 0 "
+                           "and Conv1d(k=1, bias) [+ ReLU] layers")
         return seq(x)
     params = []
     for m in convs:
@@ -1395,6 +1415,9 @@ def shared_mlp_maxpool(mlp, x):
     host-logic tests, exotic module stacks) takes the reference composition with torch ops.
     """
     if not _fusable(mlp, x):
+        if x.is_cuda:
+            _note_fallback(f"SharedMLP + max-pool on input {tuple(x.shape)} {x.dtype}: needs float32, (npoint * nsample) % 32 == 0, "
+                           "nsample in {1, 4, 8, 16, 32, 64} and a plain conv1x1/BatchNorm/ReLU stack")
         act = mlp(x)
         return torch.nn.functional.max_pool2d(act, kernel_size=[1, act.size(3)]).squeeze(-1)
     layers, params = _layer_args(mlp)
@@ -1429,6 +1452,8 @@ def sa_scale(grouper, mlp, xyz, new_xyz, features, idx=None):
           and (features is None or (features.is_cuda and features.dtype == torch.float32)))
     if ok:
         ok = _fusable_shape(mlp, new_xyz.shape[1], grouper.nsample)
+    if ok and features is not None and (xyz.shape[1] % 4 or features.shape[1] % 4):
+        ok = False          # the source-point GEMM of the split layer 0 takes n % 4 == 0 and channels % 4 == 0
     if not ok:
         return shared_mlp_maxpool(mlp, grouper(xyz, new_xyz, features))
     if idx is None:
@@ -1455,7 +1480,8 @@ def sa_level(groupers, mlps, xyz, new_xyz, features, ball_idx=None, ball_csr=Non
           and not new_xyz.requires_grad
           and (features is None or (features.is_cuda and features.dtype == torch.float32))
           and all(plain(gr) for gr in groupers)
-          and all(_fusable_shape(mlp, new_xyz.shape[1], gr.nsample) for gr, mlp in zip(groupers, mlps)))
+          and all(_fusable_shape(mlp, new_xyz.shape[1], gr.nsample) for gr, mlp in zip(groupers, mlps))
+          and (features is None or (xyz.shape[1] % 4 == 0 and features.shape[1] % 4 == 0)))
     if not ok:
         return torch.cat([sa_scale(gr, mlp, xyz, new_xyz, features, idx)
                           for gr, mlp, idx in zip(groupers, mlps, ball_idx)], dim=1)
