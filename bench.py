@@ -233,6 +233,76 @@ def run_inference(args, dev, world, rank, dist):
                        "parallelism": f"replicas x{world}", "launch": "eager"}}
 
 
+def run_sa_layer(args, dev):
+    """``--workload sa_layer`` (BASELINE configs[0]): ONE set-abstraction layer -- furthest point
+    sampling to 512 centroids, ball_query r=0.2 nsample=32, grouping, SharedMLP [3, 64, 64, 128] with train-mode
+    BatchNorm, max over the ball -- forward + backward on xyz = U[0,1)^3, B=4 N=1024 (seed 0), timed on the GPU and,
+    with the same modules over the CPU oracle ops, on the host cores; index tensors are compared bit-exact on the way."""
+    from istnet_amd.pointnet2 import pointnet2_utils
+    from istnet_amd.pointnet2.pointnet2_modules import PointnetSAModule
+    from oracle import pn2_oracle
+    b, n = 4, 1024
+    xyz = torch.rand(b, n, 3, generator=torch.Generator().manual_seed(0))
+
+    def make(device):
+        torch.manual_seed(0)
+        return PointnetSAModule(mlp=[0, 64, 64, 128], npoint=512, radius=0.2, nsample=32).to(device).train()
+
+    def make_step(model, pts):
+        def step():
+            model.zero_grad(set_to_none=True)
+            new_xyz, feat = model(pts)
+            feat.square().mean().backward()
+            return new_xyz, feat
+        return step
+
+    gpu_step = make_step(make(dev), xyz.to(dev))
+    for _ in range(args.warmup):
+        gpu_step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        new_xyz_g, feat_g = gpu_step()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / args.steps
+    # the same layer over the CPU oracle (checker + cpu_baseline leg)
+    saved = pointnet2_utils._ext
+    try:
+        pointnet2_utils._ext = pn2_oracle
+        torch.set_num_threads(min(8, os.cpu_count() or 1))
+        pn2_oracle.set_threads(min(8, os.cpu_count() or 1))
+        cpu_step = make_step(make("cpu"), xyz)
+        for _ in range(3):
+            new_xyz_c, feat_c = cpu_step()
+        times = []
+        for _ in range(10):
+            t1 = time.perf_counter()
+            cpu_step()
+            times.append(time.perf_counter() - t1)
+        idx_c = pn2_oracle.ball_query(new_xyz_c.contiguous(), xyz, 0.2, 32)
+    finally:
+        pointnet2_utils._ext = saved
+    from istnet_amd.pointnet2 import _ext
+    idx_g = _ext.ball_query(new_xyz_g.contiguous(), xyz.to(dev), 0.2, 32).cpu()
+    parity = {"centroids_bit_exact": bool(torch.equal(new_xyz_g.cpu(), new_xyz_c)),
+              "ball_query_bit_exact": bool(torch.equal(idx_g, idx_c)),
+              "features_max_abs_diff": float((feat_g.detach().cpu() - feat_c.detach()).abs().max())}
+    times.sort()
+    cpu_dt = 0.5 * (times[4] + times[5])
+    model_name, physical, logical = host_cpu()
+    return {"metric": "point-clouds/sec fwd+bwd, one SA layer, B=4 N=1024", "value": b / dt, "unit": "clouds/s",
+            "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt * 1e3, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "single set-abstraction layer: FPS 1024->512, ball_query r=0.2 nsample=32, SharedMLP "
+                                   "[3,64,64,128] train-mode BN, max-pool; fwd+bwd (BASELINE configs[0])",
+                       "batch_per_gpu": b, "npoints": n, "global_batch": b, "parallelism": "dp1", "launch": "eager"},
+            "parity": parity,
+            "cpu_baseline": {"value": b / cpu_dt, "unit": "clouds/s", "cores": min(8, os.cpu_count() or 1), "kind": "port",
+                             "cpu_model": model_name, "physical_cores": physical, "ms_per_step": cpu_dt * 1e3,
+                             "sample": "median of 10 steps after 3 warm-up steps of the same layer (torch CPU dense "
+                                       "layers + oracle/pn2_oracle.c index ops, 8 threads)"}}
+
+
 def host_cpu():
     """(model string, physical cores, logical CPUs) of the host, from /proc/cpuinfo."""
     model, cores, logical = "unknown", set(), 0
@@ -347,9 +417,10 @@ def main():
     ap.add_argument("--no-unpipelined", action="store_true", help="skip the extra unpipelined measurement")
     ap.add_argument("--no-prefetch", action="store_true",
                     help="encoder workload: one batch, geometry inside the step (no next-batch geometry prefetch)")
-    ap.add_argument("--workload", default="encoder", choices=["encoder", "istnet", "infer"],
+    ap.add_argument("--workload", default="encoder", choices=["encoder", "istnet", "infer", "sa_layer"],
                     help="encoder = BASELINE configs[1] (the headline metric); istnet = full model, configs[2]/[3]; "
-                         "infer = eval-mode full model + post-processing, B=64 N=2048 (config 5)")
+                         "infer = eval-mode full model + post-processing, B=64 N=2048 (config 5); sa_layer = configs[0]: "
+                         "one set-abstraction layer (ball_query r=0.2, nsample=32) on B=4 N=1024, GPU beside the CPU path")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for dry runs)")
     ap.add_argument("--freeze-world-enhancer", action="store_true",
                     help="istnet workload: second training stage (world encoder frozen, 23.6 M of 26.8 M parameters trained)")
@@ -426,6 +497,11 @@ def main():
             os.dup2(saved_fd, 1)
             os.close(saved_fd)
 
+    if args.workload == "sa_layer":
+        if dist_on:
+            raise SystemExit("--workload sa_layer is a single-GPU parity / timing case (BASELINE configs[0])")
+        print(json.dumps(run_sa_layer(args, dev)), flush=True)
+        return
     if args.workload == "infer":
         result = run_inference(args, dev, world, rank, dist if dist_on else None)
         if dist_on:
@@ -534,8 +610,16 @@ def main():
                                      "note": "one batch, FPS / ball query / three_nn inside the step (--no-prefetch)"}
         if not dist_on and not args.no_roofline:
             from istnet_amd import roofline
+            capture = None
+            if mode == "hipgraph":
+                n_graphs = len(fwd_bwd) if isinstance(fwd_bwd, (list, tuple)) else 1
+
+                def capture():          # the same captured step(s) with timing events around every GEMM launch
+                    timed_step = make_graphed_step(fwd_bwd, opt, world, grad_sync)
+                    return lambda: [timed_step() for _ in range(n_graphs)]
             result["roofline"] = roofline.measure(
-                eager_step, traffic_file=os.path.join(ROOT, "profiles", "r01_pmc_traffic.json"))
+                eager_step, traffic_file=os.path.join(ROOT, "profiles", "r02_pmc_traffic.json"), capture=capture,
+                steps_per_replay=(len(fwd_bwd) if isinstance(fwd_bwd, (list, tuple)) else 1))
         if not dist_on and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline()
     if dist_on:

@@ -131,13 +131,38 @@ def check(status, what):
 # When TIMING is a list, call sites bracket their kernel launches with HIP events recorded on the
 # stream the kernel is launched on (torch's current stream) and append
 # (kernel_name, flops, algorithmic_bytes, start_event, end_event).
+# TIMING_IN_GRAPH: the step is being CAPTURED for timing.  HIP refuses to read events recorded in a capturing stream
+# (hipErrorCapturedEvent, also for external event nodes on this stack), so inside a capture a launch is bracketed by two
+# one-thread marker kernels on the launch stream (istnet_debug_marker: each stores the 100 MHz wall clock when the
+# stream reaches it) writing to TIMING_BUF; after a replay the buffer holds that replay's times, taken with the
+# step's real stream concurrency (side streams and deferred weight gradients stay on: fused_mlp._scale_streams /
+# _can_defer).  A bracket includes the two launch gaps (~1.5 us each), so it never flatters the kernel.
 TIMING = None
+TIMING_IN_GRAPH = False
+TIMING_BUF = None      # int64 CUDA tensor of wall-clock slots, two per timed launch
+TIMING_ONLY = None     # in-graph timing: bracket only launches of this kernel (fewer markers = less perturbation)
 
 
 def timed(name, flops, nbytes, launch):
     if TIMING is None:
         return launch()
     import torch
+    if TIMING_IN_GRAPH:
+        i = len(TIMING)
+        if TIMING_BUF is None or 2 * i + 1 >= TIMING_BUF.numel() or (TIMING_ONLY is not None and name != TIMING_ONLY):
+            return launch()
+        st = torch.cuda.current_stream(TIMING_BUF.device).cuda_stream
+        check(lib().istnet_debug_marker(TIMING_BUF.data_ptr() + 16 * i, st), "debug_marker")
+        status = launch()
+        check(lib().istnet_debug_marker(TIMING_BUF.data_ptr() + 16 * i + 8, st), "debug_marker")
+        TIMING.append((name, flops, nbytes, i, None))
+        if i % 4 == 0 and 2 * i + 3 < TIMING_BUF.numel():
+            # calibration: an EMPTY bracket at the same place of the step measures what a bracket costs by itself
+            # (marker execution + launch gap under the step's load); roofline.measure_replayed subtracts its median
+            check(lib().istnet_debug_marker(TIMING_BUF.data_ptr() + 16 * (i + 1), st), "debug_marker")
+            check(lib().istnet_debug_marker(TIMING_BUF.data_ptr() + 16 * (i + 1) + 8, st), "debug_marker")
+            TIMING.append(("", 0.0, 0.0, i + 1, None))
+        return status
     start, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     start.record()
     status = launch()

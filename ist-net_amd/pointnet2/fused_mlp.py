@@ -164,7 +164,7 @@ def _can_defer(params):
     existing .grad, or one that another node of this pass already produced a gradient for (shared module: the
     engine adds the two tensors on the main stream), forces the launches onto the current stream -- after the
     current stream has waited for whatever the wgrad stream still holds of the earlier producer."""
-    if not (USE_DEFERRED_WGRAD and _native.TIMING is None and torch.is_grad_enabled() is False
+    if not (USE_DEFERRED_WGRAD and (_native.TIMING is None or _native.TIMING_IN_GRAPH) and torch.is_grad_enabled() is False
             and all(getattr(p, "grad", None) is None for p in params)):
         return False
     if any(_Claims.taken_by_other_node(p) for p in params):
@@ -384,7 +384,7 @@ _SCALE_STREAMS = {}
 def _scale_streams(dev, n):
     """[current stream, side stream 1, ...] for the n scales of a level (side streams only if enabled)."""
     main = torch.cuda.current_stream(dev)
-    if not USE_SCALE_STREAMS or _native.TIMING is not None or n < 2:
+    if not USE_SCALE_STREAMS or (_native.TIMING is not None and not _native.TIMING_IN_GRAPH) or n < 2:
         return [main] * n
     key = dev.index if dev.index is not None else torch.cuda.current_device()
     pool = _SCALE_STREAMS.setdefault(key, [])
