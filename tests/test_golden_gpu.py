@@ -229,6 +229,26 @@ class _F64Ext:
         taps = torch.gather(points, 2, idx.long().reshape(b, 1, -1).expand(-1, c, -1)).reshape(b, c, n, 3)
         return (taps * weight.unsqueeze(1)).sum(dim=3)
 
+    # gradients of the three differentiable ops (the autograd Functions of pointnet2_utils call them in backward)
+    @staticmethod
+    def gather_points_grad(grad_out, idx, n):
+        b, c, m = grad_out.shape
+        return torch.zeros(b, c, n, dtype=grad_out.dtype, device=grad_out.device).scatter_add_(
+            2, idx.long().unsqueeze(1).expand(-1, c, -1), grad_out)
+
+    @staticmethod
+    def group_points_grad(grad_out, idx, n):
+        b, c = grad_out.shape[:2]
+        flat = idx.long().reshape(b, 1, -1).expand(-1, c, -1)
+        return torch.zeros(b, c, n, dtype=grad_out.dtype, device=grad_out.device).scatter_add_(2, flat, grad_out.reshape(b, c, -1))
+
+    @staticmethod
+    def three_interpolate_grad(grad_out, idx, weight, m, csr=None):
+        b, c, n = grad_out.shape
+        contrib = (grad_out.unsqueeze(3) * weight.unsqueeze(1)).reshape(b, c, 3 * n)
+        return torch.zeros(b, c, m, dtype=grad_out.dtype, device=grad_out.device).scatter_add_(
+            2, idx.long().reshape(b, 1, -1).expand(-1, c, -1), contrib)
+
 
 def test_full_size_encoder_matches_cpu_oracle_composition(oracle, ext):
     """B=32 N=1024 encoder forward: the HIP path and the CPU oracle composition (both fp32) against a float64
@@ -472,3 +492,62 @@ def test_rgb_branch_matches_reference_golden_on_gpu():
     with torch.no_grad():
         local_sub = model._rgb_local({"rgb": img.contiguous(memory_format=torch.channels_last), "choose": sub_rows}, 1)
     np.testing.assert_allclose(local_sub.cpu().numpy()[:, ::4].reshape(1, 32, 16, 16), z["out_sub"], **TOL)
+
+
+def test_encoder_parameter_gradients_vs_float64_autograd(ext):
+    """Every parameter gradient of the full encoder (train-mode BN, loss = mean(out^2), the bench's shell clouds, B=8)
+    against a float64 autograd evaluation of the same model with the same index decisions (`_F64Ext`: index ops from the
+    bit-exact kernels, every feature op and the whole dense stack in float64).  Relative L2 error per tensor and over all
+    1.3 M parameters together; the torch-fp32 composition (fused path off) is measured on the same footing and is the
+    yardstick (see the comment at the assertions: 1e-4 against float64 is not attainable by any fp32 evaluation)."""
+    from istnet_amd.modules import PointNet2MSG
+    from istnet_amd.pointnet2 import fused_mlp, pointnet2_utils
+    torch.manual_seed(0)
+    base = PointNet2MSG([list(r) for r in CAM]).train()
+    state = {k: v.clone() for k, v in base.state_dict().items()}
+    pts = _shell(8, 1024, 0).to(DEV)
+
+    def grads(double=False, fused=True):
+        m = PointNet2MSG([list(r) for r in CAM]).to(DEV).train()
+        m.load_state_dict(state)
+        saved_ext, saved_fus = pointnet2_utils._ext, fused_mlp._fusable_shape
+        try:
+            if double:
+                m = m.double()
+                pointnet2_utils._ext = _F64Ext(ext)
+            if not fused:
+                fused_mlp._fusable_shape = lambda *a, **k: False
+            out = m(pts.double() if double else pts)
+            out.square().mean().backward()
+        finally:
+            pointnet2_utils._ext, fused_mlp._fusable_shape = saved_ext, saved_fus
+        torch.cuda.synchronize()
+        return {k: p.grad.double() for k, p in m.named_parameters()}
+
+    g64, ghip, gtorch = grads(double=True), grads(), grads(fused=False)
+
+    def rel(g):
+        per = {k: float((g[k] - g64[k]).norm() / g64[k].norm().clamp_min(1e-30)) for k in g64}
+        num = sum(float((g[k] - g64[k]).pow(2).sum()) for k in g64) ** 0.5
+        den = sum(float(g64[k].pow(2).sum()) for k in g64) ** 0.5
+        return per, num / den
+
+    per_hip, all_hip = rel(ghip)
+    per_torch, all_torch = rel(gtorch)
+    # Measured (profiles/r02_gradient_budget.txt): BOTH fp32 evaluations sit ~5e-3 (relative L2, all parameters) from the
+    # float64 gradient -- the torch composition, i.e. the reference's own arithmetic, 4.7e-3, the fused path 6.8e-3:
+    # a max-pool arg-max that resolves differently in fp32 and float64 re-routes a whole gradient column, so the
+    # gradient is a discontinuous function of round-off and no fp32 implementation can meet 1e-4 against float64.  The
+    # bar that CAN be held is "as close to float64 as the reference's fp32 arithmetic": aggregate error within 2x of the
+    # torch composition's, every tensor of non-negligible norm within 3x of it.  (Layer-level gradients, where no
+    # re-routing happens, are checked at ~1e-6 against float64 in test_fused_mlp_gpu.py::test_fused_vs_float64.)
+    top = max(float(v.norm()) for v in g64.values())
+    big = [k for k in g64 if float(g64[k].norm()) > 1e-6 * top]
+    worst = max(big, key=lambda k: per_hip[k] / (per_torch[k] + 1e-4))
+    msg = (f"all parameters: hip {all_hip:.2e}, torch-fp32 {all_torch:.2e}; worst tensor vs torch {worst}: hip {per_hip[worst]:.2e}, "
+           f"torch-fp32 {per_torch[worst]:.2e}; {len(big)} of {len(g64)} tensors above the norm floor")
+    print(msg)
+    assert all_hip < 2.0 * all_torch + 1e-5, msg
+    assert all_hip < 2e-2 and all_torch < 2e-2, msg
+    for k in big:
+        assert per_hip[k] < 3.0 * per_torch[k] + 1e-3, f"{k}: hip {per_hip[k]:.2e} torch {per_torch[k]:.2e} | {msg}"
