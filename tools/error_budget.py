@@ -68,8 +68,8 @@ def stats(a, ref):
     return d.max().item(), d.pow(2).mean().sqrt().item(), scale
 
 
-def main():
-    which = sys.argv[1] if len(sys.argv) > 1 else "golden"
+def compute(which="golden"):
+    """Rows (level, scale of the output, hip / torch cumulative and local max / rms error vs float64) + the input label."""
     if which == "golden":
         z = np.load(os.path.join(ROOT, "tests", "golden", "encoder_b2.npz"))
         pts = torch.from_numpy(z["pts"]).to(DEV)
@@ -120,24 +120,36 @@ def main():
         return res
 
     loc_hip, loc_torch = local(True), local(False)
+    rows = []
+    for (name, ref), (_, a), (_, b), (_, la), (_, lb) in zip(out64, out_hip, out_torch, loc_hip, loc_torch):
+        ha, hr, sc = stats(a, ref)
+        ta, tr, _ = stats(b, ref)
+        lha, lhr, _ = stats(la, ref)
+        lta, ltr, _ = stats(lb, ref)
+        rows.append({"level": name, "scale": sc, "hip_cum_max": ha, "hip_cum_rms": hr, "hip_loc_max": lha, "hip_loc_rms": lhr,
+                     "torch_cum_max": ta, "torch_cum_rms": tr, "torch_loc_max": lta, "torch_loc_rms": ltr})
+    ref = out64[-1][1]
+    final = {}
+    for tag, t in (("hip", out_hip[-1][1]), ("torch", out_torch[-1][1])):
+        d = (t.double() - ref).abs()
+        final[tag] = (d.max().item(), (d > 1e-4 + 1e-4 * ref.abs()).double().mean().item())
+    return rows, final, label
+
+
+def main():
+    rows, final, label = compute(sys.argv[1] if len(sys.argv) > 1 else "golden")
     print(f"# fp32 error budget of the encoder vs a float64 evaluation with identical index decisions")
     print(f"# input: {label}")
     print(f"# hip = fused MFMA path (product); torch = Conv2d/BatchNorm2d/ReLU/max_pool2d composition in fp32 on the same GPU")
     print(f"# cumulative: own earlier levels; local: the level alone on the float64 inputs rounded to fp32")
     print(f"{'level':<6}{'|out|max':>10} | {'hip cum max':>12}{'hip cum rms':>12}{'hip loc max':>12}{'hip loc rms':>12} | "
           f"{'torch cum max':>14}{'torch cum rms':>14}{'torch loc max':>14}{'torch loc rms':>14}")
-    for (name, ref), (_, a), (_, b), (_, la), (_, lb) in zip(out64, out_hip, out_torch, loc_hip, loc_torch):
-        ha, hr, sc = stats(a, ref)
-        ta, tr, _ = stats(b, ref)
-        lha, lhr, _ = stats(la, ref)
-        lta, ltr, _ = stats(lb, ref)
-        print(f"{name:<6}{sc:>10.3f} | {ha:>12.2e}{hr:>12.2e}{lha:>12.2e}{lhr:>12.2e} | "
-              f"{ta:>14.2e}{tr:>14.2e}{lta:>14.2e}{ltr:>14.2e}")
-    ref, a, b = out64[-1][1], out_hip[-1][1], out_torch[-1][1]
-    for tag, t in (("hip", a), ("torch", b)):
-        d = (t.double() - ref).abs()
-        viol = (d > 1e-4 + 1e-4 * ref.abs()).double().mean().item()
-        print(f"# final output, {tag}: max |err| {d.max().item():.3e}, fraction outside atol=rtol=1e-4: {viol:.2e}")
+    for r in rows:
+        print(f"{r['level']:<6}{r['scale']:>10.3f} | {r['hip_cum_max']:>12.2e}{r['hip_cum_rms']:>12.2e}{r['hip_loc_max']:>12.2e}"
+              f"{r['hip_loc_rms']:>12.2e} | {r['torch_cum_max']:>14.2e}{r['torch_cum_rms']:>14.2e}{r['torch_loc_max']:>14.2e}"
+              f"{r['torch_loc_rms']:>14.2e}")
+    for tag in ("hip", "torch"):
+        print(f"# final output, {tag}: max |err| {final[tag][0]:.3e}, fraction outside atol=rtol=1e-4: {final[tag][1]:.2e}")
 
 
 if __name__ == "__main__":
