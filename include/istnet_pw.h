@@ -207,6 +207,15 @@ ISTNET_PN2_API int istnet_pw_wgrad_reduce(int count, int splits, const float *dw
 ISTNET_PN2_API int istnet_pw_wgrad_reduce_multi(int n, const int *counts, const int *splits,
                                                 const float *const *parts, float *const *dws, void *stream);
 
+/* Layer 0 of a stack whose input is the channel concatenation of nsrc <= 6 tensors srcs[s] (b, chans[s], p), without
+ * building the concatenation (the IST / pose heads concatenate 3-5 feature tensors in front of every per-point MLP,
+ * model/ist_net.py:167-171,253,322): y (b, cout, p) = w[:, 0:sum chans] . [srcs...] (+ row_init[b][co], an optional
+ * per-cloud bias (b, cout) -- the rank-1 term W[:, C:] . mean(feat) that replaces the reference's expand + concat of
+ * the global mean feature, :174-175,256-257,324-325).  chans[s] % 16 == 0; w is (cout, ldw) row-major. */
+ISTNET_PN2_API int istnet_pw_forward_multi(int b, int nsrc, const float *const *srcs, const int *chans, int cout,
+                                           int p, const float *w, int ldw, const float *row_init, float *y,
+                                           void *stream);
+
 /* ---- compact-column form of a set-abstraction scale (csrc/sa_compact.hip) ------------------------------------------
  * The reference pads every ball-query row to nsample slots by repeating its first hit (ball_query_gpu.cu:38-45) and
  * pushes the repeats through SharedMLP + max_pool2d like any other slot (pointnet2_modules.py:61-68).  A repeat has the

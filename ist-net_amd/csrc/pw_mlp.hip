@@ -115,6 +115,17 @@ __device__ unsigned long long g_trace[8][8192];  // [0..3] wall clock (100 MHz),
 #define ISTNET_TRACE_MARK(i)
 #endif
 
+// Layer-0 input given as several tensors instead of their channel concatenation (the IST / pose heads concatenate 3-5
+// feature tensors in front of every stack, model/ist_net.py:167-171,253,322): source s holds channels
+// cbeg[s] .. cbeg[s+1]-1 of the virtual input, each (B, C_s, P).  Channel counts are multiples of the K chunk, so a chunk
+// lies in ONE source and the loader only swaps its base pointer per chunk.
+constexpr int kMaxSrc = 6;
+struct MultiSrc {
+  const float* ptr[kMaxSrc];
+  int cbeg[kMaxSrc + 1];
+  int n;          // 0: single tensor x
+};
+
 template <int M_T, int N_T, int WM, int WN>
 struct Tile {
   static constexpr int TM = M_T / (32 * WM);
@@ -170,7 +181,8 @@ __global__ __launch_bounds__(kThreads) void pw_fwd_kernel(
     int cin, int cout, int P, int tiles_per_cloud, const float* __restrict__ x, GatherSrc gsrc,
     const float* __restrict__ w, const float* __restrict__ in_scale, const float* __restrict__ in_shift,
     float* __restrict__ y, float* __restrict__ part_sum, float* __restrict__ part_sq, int nt_total, int ldw,
-    const float* __restrict__ c_init, const int* __restrict__ ncols, const float* __restrict__ colw) {
+    const float* __restrict__ c_init, const int* __restrict__ ncols, const float* __restrict__ colw, MultiSrc msrc,
+    const float* __restrict__ row_init) {
   using T = Tile<M_T, N_T, WM, WN>;
   constexpr int TM = T::TM, TN = T::TN;
   // compact-column mode (csrc/sa_compact.hip): ONE point axis of static capacity P whose first *ncols columns are
@@ -247,8 +259,16 @@ __global__ __launch_bounds__(kThreads) void pw_fwd_kernel(
         braw[i] = gather4(gsrc, b, k, P, p, GATHER == 2 ? gather_idx4(gsrc, b, P, p) : gidx[i]);
       } else {
         const int k = min(k0 + e / (N_T / 4), cin - 1), p = min(p0 + (e % (N_T / 4)) * 4, P - 4);
-        braw[i] = *reinterpret_cast<const float4*>(xb + (size_t)k * P + p);
-        if (has_bn) { bsc[i] = in_scale[k]; bsh[i] = in_shift[k]; }
+        if (msrc.n > 0) {          // the chunk's source tensor (uniform: chunks do not straddle sources)
+          int sidx = 0;
+#pragma unroll
+          for (int q = 1; q < kMaxSrc; ++q) sidx += (q < msrc.n && k0 >= msrc.cbeg[q]) ? 1 : 0;
+          const int cs = msrc.cbeg[sidx + 1] - msrc.cbeg[sidx];
+          braw[i] = *reinterpret_cast<const float4*>(msrc.ptr[sidx] + ((size_t)b * cs + (k - msrc.cbeg[sidx])) * P + p);
+        } else {
+          braw[i] = *reinterpret_cast<const float4*>(xb + (size_t)k * P + p);
+          if (has_bn) { bsc[i] = in_scale[k]; bsh[i] = in_shift[k]; }
+        }
       }
     }
   };
@@ -302,6 +322,18 @@ __global__ __launch_bounds__(kThreads) void pw_fwd_kernel(
           const int col = p0 + b_col0 + tn * 32 + (ln & 31);
           if (row < cout && col < P) acc[tm][tn][r] = cb[(size_t)row * P + col];
         }
+      }
+  }
+  if (row_init != nullptr) {   // y = row_init[b][row] + w . x: a per-cloud bias (the global-mean term of the heads)
+    const int ln = lane_id();
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = m0 + a_col0 + tm * 32 + mfma_row(r, ln);
+        const float v = row < cout ? row_init[(size_t)b * cout + row] : 0.f;
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn) acc[tm][tn][r] = v;
       }
   }
   const int nchunks = (cin + kKT - 1) / kKT;
@@ -1956,7 +1988,11 @@ int istnet_pw_stat_tiles(int b, int cout, int p) {
 static int launch_pw_forward(bool gather, int b, int cin, int cout, int p, const float* x, const GatherSrc& g,
                              const float* w, int ldw, const float* in_scale, const float* in_shift, float* y,
                              float* part_sum, float* part_sq, void* stream, const float* c_init = nullptr,
-                             const int* ncols = nullptr, const float* colw = nullptr) {
+                             const int* ncols = nullptr, const float* colw = nullptr, const MultiSrc* msrc_p = nullptr,
+                             const float* row_init = nullptr) {
+  MultiSrc msrc;
+  msrc.n = 0;
+  if (msrc_p != nullptr) msrc = *msrc_p;
   if (b <= 0 || cin <= 0 || cout <= 0 || p <= 0 || (p & 3)) return ISTNET_PN2_EINVAL;
   const TileCfg cfg = pick_cfg(b, cout, p, g_force_fwd_cfg);
   const int tpc = ceil_div(p, cfg_nt(cfg));
@@ -1967,13 +2003,13 @@ static int launch_pw_forward(bool gather, int b, int cin, int cout, int p, const
   do {                                                                                                      \
     if (mode == 2)                                                                                          \
       hipLaunchKernelGGL((pw_fwd_kernel<MT, NT, WM, WN, 2>), grid, dim3(kThreads), 0, as_stream(stream),    \
-                         cin, cout, p, tpc, x, g, w, in_scale, in_shift, y, part_sum, part_sq, nt, ldw, c_init, ncols, colw); \
+                         cin, cout, p, tpc, x, g, w, in_scale, in_shift, y, part_sum, part_sq, nt, ldw, c_init, ncols, colw, msrc, row_init); \
     else if (mode == 1)                                                                                     \
       hipLaunchKernelGGL((pw_fwd_kernel<MT, NT, WM, WN, 1>), grid, dim3(kThreads), 0, as_stream(stream),    \
-                         cin, cout, p, tpc, x, g, w, in_scale, in_shift, y, part_sum, part_sq, nt, ldw, c_init, ncols, colw); \
+                         cin, cout, p, tpc, x, g, w, in_scale, in_shift, y, part_sum, part_sq, nt, ldw, c_init, ncols, colw, msrc, row_init); \
     else                                                                                                    \
       hipLaunchKernelGGL((pw_fwd_kernel<MT, NT, WM, WN, 0>), grid, dim3(kThreads), 0, as_stream(stream),    \
-                         cin, cout, p, tpc, x, g, w, in_scale, in_shift, y, part_sum, part_sq, nt, ldw, c_init, ncols, colw); \
+                         cin, cout, p, tpc, x, g, w, in_scale, in_shift, y, part_sum, part_sq, nt, ldw, c_init, ncols, colw, msrc, row_init); \
   } while (0)
   switch (cfg) {
     case kCfg128x128: ISTNET_FWD(128, 128, 2, 2); break;
@@ -2006,6 +2042,24 @@ int istnet_pw_forward_acc(int b, int cin, int cout, int p, const float* x, const
   if (ldw < cin || c_init == nullptr) return ISTNET_PN2_EINVAL;
   return launch_pw_forward(false, b, cin, cout, p, x, GatherSrc{}, w, ldw, nullptr, nullptr, y, part_sum, part_sq,
                            stream, c_init);
+}
+
+int istnet_pw_forward_multi(int b, int nsrc, const float* const* srcs, const int* chans, int cout, int p,
+                            const float* w, int ldw, const float* row_init, float* y, void* stream) {
+  if (nsrc <= 0 || nsrc > kMaxSrc || srcs == nullptr || chans == nullptr) return ISTNET_PN2_EINVAL;
+  MultiSrc ms;
+  ms.n = nsrc;
+  ms.cbeg[0] = 0;
+  for (int s = 0; s < nsrc; ++s) {
+    if (srcs[s] == nullptr || chans[s] <= 0 || (chans[s] % kKT)) return ISTNET_PN2_EINVAL;   // chunks must not straddle sources
+    ms.ptr[s] = srcs[s];
+    ms.cbeg[s + 1] = ms.cbeg[s] + chans[s];
+  }
+  for (int s = nsrc; s < kMaxSrc; ++s) { ms.ptr[s] = nullptr; ms.cbeg[s + 1] = ms.cbeg[nsrc]; }
+  const int cin = ms.cbeg[nsrc];
+  if (ldw < cin) return ISTNET_PN2_EINVAL;
+  return launch_pw_forward(false, b, cin, cout, p, nullptr, GatherSrc{}, w, ldw, nullptr, nullptr, y, nullptr, nullptr,
+                           stream, nullptr, nullptr, nullptr, &ms, row_init);
 }
 
 int istnet_pw_forward_cols(int cin, int cout, long long cap, const float* x, const float* w, const float* in_scale,

@@ -18,6 +18,7 @@ import torch.nn as nn
 
 from .modules import PointNet2MSG
 from .pointnet2.fused_mlp import pointwise_conv_stack as _run
+from .pointnet2.fused_mlp import pointwise_conv_stack_multi as _run_multi
 from .rotation_utils import Ortho6d2Mat
 
 CAM_RADII = [[0.01, 0.02], [0.02, 0.04], [0.04, 0.08], [0.08, 0.16]]      # ist_net.py:16
@@ -39,14 +40,10 @@ def _fc_head(out_dim):
                          nn.Linear(256, out_dim))
 
 
-def _with_global_mean(feat):
-    """(B,C,N) -> (B,2C,N): append the per-cloud mean feature to every point (:174-175,:256-257)."""
-    return torch.cat([feat, feat.mean(dim=2, keepdim=True).expand_as(feat)], dim=1)
-
-
-def _pooled(seq, x):
-    """``seq`` = [conv, relu, conv, relu, AdaptiveAvgPool1d(1)] (pose_mlp2): fused convs, then the mean over N."""
-    return _run(seq[:-1], x).mean(dim=2)
+def _pooled(seq, feat):
+    """``seq`` = [conv, relu, conv, relu, AdaptiveAvgPool1d(1)] (pose_mlp2) on [feat, global mean of feat] (:256-257,
+    :324-325): fused convs with the mean as a per-cloud bias, then the mean over N."""
+    return _run_multi(seq[:-1], [feat], with_mean=True).mean(dim=2)
 
 
 class FeatureDeformer(nn.Module):
@@ -63,8 +60,8 @@ class FeatureDeformer(nn.Module):
     def forward(self, pts, rgb_local, pts_local, index):
         npoint = pts_local.size(2)
         geo = _run(self.pts_mlp1, pts.transpose(1, 2))
-        feat = _run(self.deform_mlp1, torch.cat([geo, pts_local, rgb_local], dim=1))
-        pts_local_w = _run(self.deform_mlp2, _with_global_mean(feat))
+        feat = _run_multi(self.deform_mlp1, [geo, pts_local, rgb_local])          # :167-171 without the concat
+        pts_local_w = _run_multi(self.deform_mlp2, [feat], with_mean=True)        # :174-175 without expand + concat
         nocs = _run(self.pred_nocs, pts_local_w).view(-1, 3, npoint).contiguous()   # (B*nclass, 3, N)
         pts_w = torch.index_select(nocs, 0, index).permute(0, 2, 1).contiguous()
         return pts_local_w, pts_w
@@ -107,8 +104,8 @@ class LightEstimator(_PoseHeads):
 
     def forward(self, pts, rgb_local, pts_local):
         geo = _run(self.pts_mlp, pts.transpose(1, 2))
-        feat = _run(self.pose_mlp1, torch.cat([rgb_local, geo, pts_local], dim=1))
-        return self._pose(_pooled(self.pose_mlp2, _with_global_mean(feat)))
+        feat = _run_multi(self.pose_mlp1, [rgb_local, geo, pts_local])
+        return self._pose(_pooled(self.pose_mlp2, feat))
 
 
 class HeavyEstimator(_PoseHeads):
@@ -125,8 +122,8 @@ class HeavyEstimator(_PoseHeads):
     def forward(self, pts, pts_w, rgb_local, pts_local, pts_w_local):
         geo = _run(self.pts_mlp1, pts.transpose(1, 2))
         geo_w = _run(self.pts_mlp2, pts_w.transpose(1, 2))
-        feat = _run(self.pose_mlp1, torch.cat([rgb_local, geo, pts_local, geo_w, pts_w_local], dim=1))
-        return self._pose(_pooled(self.pose_mlp2, _with_global_mean(feat)))
+        feat = _run_multi(self.pose_mlp1, [rgb_local, geo, pts_local, geo_w, pts_w_local])
+        return self._pose(_pooled(self.pose_mlp2, feat))
 
 
 class WorldSpaceEnhancer(nn.Module):

@@ -465,3 +465,43 @@ def test_compact_column_lists_are_the_inverse_of_the_column_table():
         want = torch.argsort(local, stable=True)
         assert torch.equal(ent[lo:hi], want)
         assert torch.equal(off[b, 1:], torch.cumsum(torch.bincount(local, minlength=512), 0))
+
+
+@pytest.mark.parametrize("chans,with_mean,widths", [
+    ([64, 128, 128], False, [384, 256]),          # FeatureDeformer.deform_mlp1
+    ([128, 64, 128, 64, 128], False, [256, 256]),  # HeavyEstimator.pose_mlp1
+    ([256], True, [384, 256, 128]),               # deform_mlp2 on [feat, global mean]
+    ([256], True, [512, 512]),                    # pose_mlp2 on [feat, global mean]
+])
+def test_concat_free_head_stack_equals_concatenated_input(chans, with_mean, widths):
+    """pointwise_conv_stack_multi (layer 0 walks the source tensors, the global mean enters as a per-cloud bias) vs the
+    same nn.Sequential on the built concatenation: output, the gradient of every source and of every parameter."""
+    from istnet_amd.pointnet2 import fused_mlp
+    g = torch.Generator().manual_seed(sum(chans))
+    b, n = 4, 512
+    cin = sum(chans) * (2 if with_mean else 1)
+    layers, w = [], [cin, *widths]
+    for i in range(len(w) - 1):
+        layers += [torch.nn.Conv1d(w[i], w[i + 1], 1), torch.nn.ReLU()]
+    torch.manual_seed(5)
+    seq = torch.nn.Sequential(*layers).to(DEV)
+    srcs0 = [torch.randn(b, c, n, generator=g).to(DEV) for c in chans]
+    wgt = torch.randn(b, widths[-1], n, generator=g).to(DEV)
+    res = []
+    for fused in (True, False):
+        seq.zero_grad(set_to_none=True)
+        srcs = [t.clone().requires_grad_(True) for t in srcs0]
+        saved = fused_mlp.USE_CONCAT_FREE_HEADS
+        try:
+            fused_mlp.USE_CONCAT_FREE_HEADS = fused
+            out = fused_mlp.pointwise_conv_stack_multi(seq, srcs, with_mean=with_mean)
+        finally:
+            fused_mlp.USE_CONCAT_FREE_HEADS = saved
+        (out * wgt).sum().backward()
+        torch.cuda.synchronize()
+        res.append((out.detach(), [t.grad.clone() for t in srcs], [p.grad.clone() for p in seq.parameters()]))
+    torch.testing.assert_close(res[0][0], res[1][0], rtol=1e-4, atol=1e-4)
+    for a, c in zip(res[0][1], res[1][1]):
+        torch.testing.assert_close(a, c, rtol=1e-4, atol=1e-4)
+    for a, c in zip(res[0][2], res[1][2]):
+        torch.testing.assert_close(a, c, rtol=2e-4, atol=2e-3)
