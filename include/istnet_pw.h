@@ -249,6 +249,19 @@ ISTNET_PN2_API int istnet_bn_relu_pool_cols(int b, int c, int g, long long cap, 
 ISTNET_PN2_API int istnet_pw_pooled_grad_cols(int b, int c, int g, long long cap, const float *d_pooled,
                                               long long pooled_bstride, const unsigned char *arg, const int *meta,
                                               const int *ncols, float *out, void *stream);
+/* The same contract for a mid-size layer (cout in {64, 128}, cin in {32, 64, 128} with cin <= cout, p % 128 == 0; replaces
+ * the istnet_pw_dgrad + istnet_pw_wgrad pair of such a layer -- reference: the autograd backward of one
+ * Conv2d(1x1) + BatchNorm2d + ReLU block of pt_utils.SharedMLP, /root/reference/lib/pointnet2/pytorch_utils.py:10-60):
+ * dx (b, cin, p), statistics partials [cin][splits], dw_part [splits][cout][cin], splits = istnet_pw_bwd_mid_splits(...).
+ * istnet_pw_set_tuning key 8 = target workgroup count, key 9 = 0 disables (istnet_pw_bwd_mid_ok then returns 0). */
+ISTNET_PN2_API int istnet_pw_bwd_mid_ok(int cin, int cout, int p);
+ISTNET_PN2_API int istnet_pw_bwd_mid_splits(int b, int cin, int cout, int p);
+ISTNET_PN2_API int istnet_pw_bwd_mid(int b, int cin, int cout, int p, int nsample, const float *w, const float *x,
+                                     const float *bn_in, const float *y, const float *d_dense, const float *d_pooled,
+                                     long long pooled_bstride, const unsigned char *arg, const float *bn,
+                                     const float *bwdc, float *dx, float *part_g, float *part_gy, float *dw_part,
+                                     void *stream);
+
 /* istnet_pw_bwd_small on compact columns (dense gradient source); partials: [cin][splits], dw_part [splits][cout][cin],
  * splits = istnet_pw_bwd_small_cols_splits() */
 ISTNET_PN2_API int istnet_pw_bwd_small_cols_splits(void);

@@ -80,6 +80,9 @@ SIGNATURES = {
     "istnet_pw_forward_cols": [_i, _i, _l, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p],
     "istnet_bn_relu_pool_cols": [_i, _i, _i, _l, _p, _p, _p, _p, _l, _p, _p, _p],
     "istnet_pw_pooled_grad_cols": [_i, _i, _i, _l, _p, _l, _p, _p, _p, _p, _p],
+    "istnet_pw_bwd_mid_ok": [_i, _i, _i],
+    "istnet_pw_bwd_mid_splits": [_i, _i, _i, _i],
+    "istnet_pw_bwd_mid": [_i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _l, _p, _p, _p, _p, _p, _p, _p, _p],
     "istnet_pw_bwd_small_cols_splits": [],
     "istnet_pw_bwd_small_cols": [_i, _i, _l, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p],
     "istnet_pw_dwx_cols_chunks": [_i],

@@ -1811,6 +1811,252 @@ __global__ __launch_bounds__(kThreads, ISTNET_BWD_SMALL_WAVES) void pw_bwd_small
   }
 }
 
+// ============================================================================================
+// Fused backward of a mid-size layer (cout in {64, 128}, cin in {32, 64, 128}, not the first of its stack): the
+// pw_bwd_small_kernel contract -- dA_{l-1}, its BN-backward statistics partials and a split-K partial of dW from ONE
+// pass over (y_l, gradient source, y_{l-1}) -- for the layers whose whole weight matrix still fits one workgroup.
+// The separate dgrad / wgrad pair reads y_l and the gradient source twice, y_{l-1} twice, and forms dY (relu mask,
+// three BN-backward constants) in both operand loaders; here a chunk of PT points is loaded and finished ONCE into
+// two LDS tiles kept in the tensors' own layout ([channel][point], float4 stores straight from the load registers):
+//   dgrad  dA^T[pt][ci] = sum_co dY^T[pt][co] W[co][ci]  A = dY^T: ds_read_b32 over 32 consecutive points of a row,
+//                                                        B = W fragments held in registers for the whole kernel;
+//   wgrad  dW[co][ci]  += sum_pt dY[co][pt] act(x)[ci][pt]  K = points: both operands are rows of the tiles, read as
+//          float4 along the points -- a lane's four values feed four consecutive MFMA k-steps (the k index is a dummy
+//          index, so A and B only have to agree on which point a (lane half, step) pair means: point 8j + 4*half + t).
+// Work split over the four waves: one 32x32 dA^T tile each (PT = 128 / (cin/32) points per chunk), and the dW tiles
+// as a (WGM x WGN) grid of TM x TN tiles, over point halves (WGK = 2) when the matrix has only two tiles.
+// ============================================================================================
+template <int COT, int CIT>
+struct MidCfg {
+  static constexpr int COUT = 32 * COT, CIN = 32 * CIT;
+  static constexpr int PT = 128 / CIT;                  // points per chunk: CIT * PT / 32 == 4 dA^T tiles, one per wave
+  static constexpr int LD = PT + 4;                     // 16-byte aligned rows; +4 floats: float4 reads of 8 rows cover 32 banks
+  static constexpr int F4 = PT / 4;                     // float4 per tile row
+  static constexpr int NY = COUT * F4 / kThreads;       // float4 per thread, y / gradient tile
+  static constexpr int NX = CIN * F4 / kThreads;
+  static constexpr int WGN = CIT < 2 ? CIT : 2;
+  static constexpr int WGM = COT < 4 / WGN ? COT : 4 / WGN;
+  static constexpr int WGK = 4 / (WGM * WGN);
+  static constexpr int TM = COT / WGM, TN = CIT / WGN;
+  static_assert(NY >= 1 && NX >= 1 && WGM * WGN * WGK == 4 && TM * WGM == COT && TN * WGN == CIT, "unsupported shape");
+};
+
+template <int COT, int CIT, bool POOLED>
+__global__ __launch_bounds__(kThreads, 2) void pw_bwd_mid_kernel(
+    int P, long long total, int split_len, const float* __restrict__ w, const float* __restrict__ x,
+    const float* __restrict__ in_scale, const float* __restrict__ in_shift, const float* __restrict__ y, GradSrc gs,
+    const float* __restrict__ bn, const float* __restrict__ bwdc, float* __restrict__ dx,
+    float* __restrict__ part_g, float* __restrict__ part_gy, int nt_total, float* __restrict__ dw_part) {
+  using C = MidCfg<COT, CIT>;
+  constexpr int COUT = C::COUT, CIN = C::CIN, PT = C::PT, LD = C::LD, F4 = C::F4, NY = C::NY, NX = C::NX;
+  constexpr int TM = C::TM, TN = C::TN;
+  __shared__ __attribute__((aligned(16))) float dYs[COUT * LD];
+  __shared__ __attribute__((aligned(16))) float Xs[CIN * LD];    // RAW y_{l-1}: the statistics need it, act() is applied on read
+  __shared__ float s_c[5][COUT];                                 // scale, shift of this layer's BN; the three BN-backward constants
+  const int tid = threadIdx.x, lane = lane_id(), wv = wave_id();
+  const int l31 = lane & 31, half = lane >> 5;
+  const long long qbeg = (long long)blockIdx.x * split_len;
+  const long long qend = max(qbeg, min(qbeg + (long long)split_len, total));
+  for (int c = tid; c < COUT; c += kThreads) {
+    s_c[0][c] = bn[c]; s_c[1][c] = bn[COUT + c];
+    s_c[2][c] = bwdc[c]; s_c[3][c] = bwdc[COUT + c]; s_c[4][c] = bwdc[2 * COUT + c];
+  }
+  // dgrad: wave -> (point block pb, input-channel block cb); B[k = co][j = ci] = w[co][32 cb + j]
+  const int pb = wv / CIT, cb = wv % CIT;
+  float wfrag[COUT / 2];
+#pragma unroll
+  for (int kk = 0; kk < COUT / 2; ++kk) wfrag[kk] = w[(size_t)(2 * kk + half) * CIN + 32 * cb + l31];
+  const float dsc = in_scale[32 * cb + l31], dsh = in_shift[32 * cb + l31];
+  // wgrad: wave -> (row group wm, column group wn, point half wk)
+  const int wk = wv / (C::WGM * C::WGN), wm = (wv / C::WGN) % C::WGM, wn = wv % C::WGN;
+  float wsc[TN], wsh[TN];
+#pragma unroll
+  for (int tn = 0; tn < TN; ++tn) {
+    wsc[tn] = in_scale[32 * (wn * TN + tn) + l31];
+    wsh[tn] = in_shift[32 * (wn * TN + tn) + l31];
+  }
+
+  float4 ry[NY], rx[NX];
+  float4 rd[POOLED ? 1 : NY];
+  float rpv[POOLED ? NY : 1];
+  int rarg[POOLED ? NY : 1];
+  auto load_chunk = [&](long long qk) {
+    int b, pk;
+    split_point(qk, P, b, pk);
+#pragma unroll
+    for (int i = 0; i < NY; ++i) {
+      const int e = tid + kThreads * i, row = e / F4, p = pk + (e % F4) * 4;
+      const size_t rowo = (size_t)b * COUT + row;
+      ry[i] = *reinterpret_cast<const float4*>(y + rowo * (size_t)P + p);
+      if (POOLED) {
+        const int G = P / gs.S, g = p / gs.S;
+        rpv[i] = pooled_at(gs, b, row, G, g);
+        rarg[i] = gs.arg[rowo * (size_t)G + g];
+      } else {
+        rd[i] = *reinterpret_cast<const float4*>(gs.dense + rowo * (size_t)P + p);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < NX; ++i) {
+      const int e = tid + kThreads * i, row = e / F4, p = pk + (e % F4) * 4;
+      rx[i] = *reinterpret_cast<const float4*>(x + ((size_t)b * CIN + row) * P + p);
+    }
+  };
+  auto store_chunk = [&](long long qk) {
+    int b_unused, pk;
+    split_point(qk, P, b_unused, pk);
+#pragma unroll
+    for (int i = 0; i < NY; ++i) {
+      const int e = tid + kThreads * i, row = e / F4, k = (e % F4) * 4;
+      const float rs = s_c[0][row], rh = s_c[1][row], rca = s_c[2][row], rcb = s_c[3][row], rcc = s_c[4][row];
+      float4 d;
+      if (POOLED) {
+        const int ks = (pk + k) % gs.S, a = rarg[i];
+        const float pv = rpv[i];
+        d = make_float4(a == ks ? pv : 0.f, a == ks + 1 ? pv : 0.f, a == ks + 2 ? pv : 0.f, a == ks + 3 ? pv : 0.f);
+      } else {
+        d = rd[i];
+      }
+      const float4 yv = ry[i];
+      float4 v;
+      v.x = rca * ((yv.x * rs + rh > 0.f) ? d.x : 0.f) + rcb + rcc * yv.x;
+      v.y = rca * ((yv.y * rs + rh > 0.f) ? d.y : 0.f) + rcb + rcc * yv.y;
+      v.z = rca * ((yv.z * rs + rh > 0.f) ? d.z : 0.f) + rcb + rcc * yv.z;
+      v.w = rca * ((yv.w * rs + rh > 0.f) ? d.w : 0.f) + rcb + rcc * yv.w;
+      *reinterpret_cast<float4*>(&dYs[row * LD + k]) = v;
+    }
+#pragma unroll
+    for (int i = 0; i < NX; ++i) {
+      const int e = tid + kThreads * i, row = e / F4, k = (e % F4) * 4;
+      *reinterpret_cast<float4*>(&Xs[row * LD + k]) = rx[i];
+    }
+  };
+
+  f32x16 accw[TM][TN];
+#pragma unroll
+  for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) accw[tm][tn][r] = 0.f;
+  float sg = 0.f, sgy = 0.f;   // statistics of input channel 32 cb + l31 over the point rows this lane holds
+  const int nchunks = (int)((qend - qbeg) / PT);   // P % PT == 0 (host-checked): whole chunks, each inside one cloud
+  if (nchunks > 0) load_chunk(qbeg);
+  __syncthreads();                                 // s_c
+  for (int t = 0; t < nchunks; ++t) {
+    const long long qk = qbeg + (long long)t * PT;
+    store_chunk(qk);
+    __syncthreads();
+    if (t + 1 < nchunks) load_chunk(qk + PT);      // in flight during the MFMAs
+    // ---- dgrad: dA^T tile (points 32 pb .., input channels 32 cb ..) ----
+    {
+      f32x16 accd;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) accd[r] = 0.f;
+      const float* ap = dYs + half * LD + 32 * pb + l31;   // dY[co = 2kk + half][pt = 32 pb + l31]
+      float fa[2];
+      fa[0] = ap[0];
+#pragma unroll
+      for (int kk = 0; kk < COUT / 2; ++kk) {
+        const int cur = kk & 1, nxt = cur ^ 1;
+        if (kk + 1 < COUT / 2) fa[nxt] = ap[2 * (kk + 1) * LD];
+        __builtin_amdgcn_sched_barrier(0);
+        accd = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur], wfrag[kk], accd, 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      // register r of a lane: point mfma_row(r, lane) of the block, input channel l31; 4j .. 4j+3 = 4 consecutive points
+      int b, pk;
+      split_point(qk, P, b, pk);
+      const int ci = 32 * cb + l31;
+      float* dxb = dx + ((size_t)b * CIN + ci) * P + pk + 32 * pb + 4 * half;
+      const float* xr = Xs + ci * LD + 32 * pb + 4 * half;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float4 o;
+        o.x = accd[4 * j + 0]; o.y = accd[4 * j + 1]; o.z = accd[4 * j + 2]; o.w = accd[4 * j + 3];
+        *reinterpret_cast<float4*>(dxb + 8 * j) = o;
+        const float4 yin = *reinterpret_cast<const float4*>(xr + 8 * j);
+        const float g0 = (yin.x * dsc + dsh > 0.f) ? o.x : 0.f, g1 = (yin.y * dsc + dsh > 0.f) ? o.y : 0.f;
+        const float g2 = (yin.z * dsc + dsh > 0.f) ? o.z : 0.f, g3 = (yin.w * dsc + dsh > 0.f) ? o.w : 0.f;
+        sg += g0; sgy += g0 * yin.x;
+        sg += g1; sgy += g1 * yin.y;
+        sg += g2; sgy += g2 * yin.z;
+        sg += g3; sgy += g3 * yin.w;
+      }
+    }
+    // ---- wgrad: this wave's TM x TN tiles over its share of the chunk's points ----
+    {
+      constexpr int KP = PT / C::WGK;          // points of this wave's K range
+      const float* ap = dYs + (32 * wm * TM + l31) * LD + wk * KP + 4 * half;
+      const float* bp = Xs + (32 * wn * TN + l31) * LD + wk * KP + 4 * half;
+#pragma unroll
+      for (int j = 0; j < KP / 8; ++j) {
+        float4 a4[TM], b4[TN];
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm) a4[tm] = *reinterpret_cast<const float4*>(ap + tm * 32 * LD + 8 * j);
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn) {
+          b4[tn] = bn_relu4(*reinterpret_cast<const float4*>(bp + tn * 32 * LD + 8 * j), wsc[tn], wsh[tn]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+          for (int tn = 0; tn < TN; ++tn) {
+            accw[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[tm].x, b4[tn].x, accw[tm][tn], 0, 0, 0);
+            accw[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[tm].y, b4[tn].y, accw[tm][tn], 0, 0, 0);
+            accw[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[tm].z, b4[tn].z, accw[tm][tn], 0, 0, 0);
+            accw[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[tm].w, b4[tn].w, accw[tm][tn], 0, 0, 0);
+          }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    __syncthreads();    // every wave is done with the tiles before the next chunk overwrites them
+  }
+  // ---- per-workgroup results ----
+  float* red = dYs;     // reuse: the loop ended on a barrier
+  if (C::WGK == 2) {    // two waves hold halves of the same dW tile
+    if (wk == 1) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) red[(wv & 1) * 1024 + r * 64 + lane] = accw[0][0][r];
+    }
+    __syncthreads();
+    if (wk == 0) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) accw[0][0][r] += red[(wv & 1) * 1024 + r * 64 + lane];
+    }
+    __syncthreads();
+  }
+  if (wk == 0) {
+    float* out = dw_part + (size_t)blockIdx.x * COUT * CIN;
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+      for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = 32 * (wm * TM + tm) + mfma_row(r, lane), col = 32 * (wn * TN + tn) + l31;
+          out[(size_t)row * CIN + col] = accw[tm][tn][r];
+        }
+  }
+  float* sred = red;    // [4 waves][2 halves][32][2]
+  sred[((wv * 2 + half) * 32 + l31) * 2 + 0] = sg;
+  sred[((wv * 2 + half) * 32 + l31) * 2 + 1] = sgy;
+  __syncthreads();
+  if (tid < CIN) {
+    const int cbk = tid >> 5, l = tid & 31;
+    float a = 0.f, c = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4 / CIT; ++k) {        // the waves with this channel block, in wave order; both halves
+      const int wsrc = k * CIT + cbk;
+      a += sred[((wsrc * 2 + 0) * 32 + l) * 2 + 0] + sred[((wsrc * 2 + 1) * 32 + l) * 2 + 0];
+      c += sred[((wsrc * 2 + 0) * 32 + l) * 2 + 1] + sred[((wsrc * 2 + 1) * 32 + l) * 2 + 1];
+    }
+    part_g[(size_t)tid * nt_total + blockIdx.x] = a;
+    part_gy[(size_t)tid * nt_total + blockIdx.x] = c;
+  }
+}
+
 // dw[i] = sum_s dw_part[s][i]: 16 elements x 16 split groups per workgroup, fixed reduction order
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(int count, int splits, const float* __restrict__ part,
                                                            float* __restrict__ dw) {
@@ -1918,6 +2164,8 @@ int g_wg_small_pts = 0x7fffffff;  // layers with b*P <= this use 64x64 wgrad til
 int g_wg_target_big = 512;   // target workgroup count, outputs >= 128x128 (re-tuned end to end once the wgrads ran beside the dgrad chain: 768/1024 -> 512/512 is 1.5 % faster)
 int g_wg_target_small = 512;
 int g_bwd_small_target = 256; // workgroups of the fused small-layer backward (key 5)
+int g_bwd_mid_target = 512;   // workgroups of the fused mid-size-layer backward (key 8)
+int g_bwd_mid_enable = 1;     // key 9: 0 = those layers run the dgrad / wgrad pair
 int g_exp_no_fast = 0;        // experiment (key 6): 1 = never take the interior-tile fast kernels
 inline int wgrad_mt(int cout, long long pts) { return (cout >= 128 && pts > g_wg_small_pts) ? 128 : 64; }
 inline int wgrad_nt(int cin, long long pts) { return (cin >= 96 && pts > g_wg_small_pts) ? 128 : 64; }
@@ -1977,6 +2225,8 @@ int istnet_pw_set_tuning(int key, int value) {
     case 5: g_bwd_small_target = value > 0 ? value : 256; return 0;
     case 6: g_exp_no_fast = value; return 0;
     case 7: g_dgrad_min_wgs = value > 0 ? value : 384; return 0;
+    case 8: g_bwd_mid_target = value > 0 ? value : 512; return 0;
+    case 9: g_bwd_mid_enable = value != 0; return 0;
     default: return ISTNET_PN2_EINVAL;
   }
 }
@@ -2429,6 +2679,57 @@ int istnet_pw_bwd_small(int b, int cin, int cout, int p, int nsample, const floa
     hipLaunchKernelGGL(pw_bwd_small_kernel<true>, dim3(splits), dim3(kThreads), 0, as_stream(stream), cin, cout, p,
                        (long long)b * p, len, w, x, bn_in, bn_in + cin, y, gs, bn, bwdc, dx, part_g, part_gy, splits,
                        dw_part, nullptr, nullptr);
+  return (int)hipGetLastError();
+}
+
+// ---- fused backward of a mid-size layer (pw_bwd_mid_kernel) ----
+int istnet_pw_bwd_mid_ok(int cin, int cout, int p) {
+  if (!g_bwd_mid_enable || p <= 0 || (p % 128)) return 0;
+  return (cout == 64 && (cin == 32 || cin == 64)) || (cout == 128 && (cin == 64 || cin == 128));
+}
+static int bwd_mid_pt(int cin) { return 128 / (cin / 32); }
+static int bwd_mid_len(int b, int cin, int p) {
+  const long long total = (long long)b * p;
+  const int pt = bwd_mid_pt(cin);
+  long long len = (total + g_bwd_mid_target - 1) / g_bwd_mid_target;
+  len = (len + pt - 1) / pt * pt;
+  if (len < 2 * pt) len = 2 * pt;
+  return (int)len;
+}
+int istnet_pw_bwd_mid_splits(int b, int cin, int cout, int p) {
+  if (!istnet_pw_bwd_mid_ok(cin, cout, p) || b <= 0) return 0;
+  const long long total = (long long)b * p;
+  const int len = bwd_mid_len(b, cin, p);
+  return (int)((total + len - 1) / len);
+}
+
+int istnet_pw_bwd_mid(int b, int cin, int cout, int p, int nsample, const float* w, const float* x,
+                      const float* bn_in, const float* y, const float* d_dense, const float* d_pooled,
+                      long long pooled_bstride, const unsigned char* arg, const float* bn, const float* bwdc,
+                      float* dx, float* part_g, float* part_gy, float* dw_part, void* stream) {
+  if (b <= 0 || !istnet_pw_bwd_mid_ok(cin, cout, p) || (long long)b * p >= (1LL << 31)) return ISTNET_PN2_EINVAL;
+  if (!w || !x || !bn_in || !y || !bn || !bwdc || !dx || !part_g || !part_gy || !dw_part) return ISTNET_PN2_EINVAL;
+  if (d_dense == nullptr && (d_pooled == nullptr || arg == nullptr || nsample <= 0 || (nsample & 3)))
+    return ISTNET_PN2_EINVAL;
+  GradSrc gs{d_dense, d_pooled, arg, nsample, pooled_bstride > 0 ? pooled_bstride : (long long)cout * (nsample > 0 ? p / nsample : 0), cout};
+  const int len = bwd_mid_len(b, cin, p);
+  const int splits = istnet_pw_bwd_mid_splits(b, cin, cout, p);
+#define ISTNET_BWD_MID(COT, CIT)                                                                                   \
+  do {                                                                                                             \
+    if (d_dense != nullptr)                                                                                        \
+      hipLaunchKernelGGL((pw_bwd_mid_kernel<COT, CIT, false>), dim3(splits), dim3(kThreads), 0, as_stream(stream), \
+                         p, (long long)b * p, len, w, x, bn_in, bn_in + cin, y, gs, bn, bwdc, dx, part_g, part_gy, \
+                         splits, dw_part);                                                                         \
+    else                                                                                                           \
+      hipLaunchKernelGGL((pw_bwd_mid_kernel<COT, CIT, true>), dim3(splits), dim3(kThreads), 0, as_stream(stream),  \
+                         p, (long long)b * p, len, w, x, bn_in, bn_in + cin, y, gs, bn, bwdc, dx, part_g, part_gy, \
+                         splits, dw_part);                                                                         \
+  } while (0)
+  if (cout == 64 && cin == 32) ISTNET_BWD_MID(2, 1);
+  else if (cout == 64) ISTNET_BWD_MID(2, 2);
+  else if (cin == 64) ISTNET_BWD_MID(4, 2);
+  else ISTNET_BWD_MID(4, 4);
+#undef ISTNET_BWD_MID
   return (int)hipGetLastError();
 }
 

@@ -509,6 +509,7 @@ def _compact_ok(lib, ga, layers, params, needs_backward, needs_feature_grad):
 
 
 USE_FUSED_SMALL_BWD = True
+USE_FUSED_MID_BWD = True     # 64 / 128-channel layers: dgrad + wgrad + statistics in one pass (pw_bwd_mid_kernel)
 USE_SPLIT_LAYER0 = True
 USE_CSR_SCATTER = True     # False: LDS-atomic scatter (steps are then not bit-reproducible)
 
@@ -613,6 +614,23 @@ def _backward_stack(lib, dev, st, b, c0, g, s, x, gather, training, ys, bns, par
                     b, cin, cout, p, ns_arg, w2.data_ptr(), ys[li - 1].data_ptr(), bns[li - 1].data_ptr(),
                     y.data_ptr(), dd, dp, pbs, da, bn.data_ptr(), bwdc.data_ptr(), dprev.data_ptr(),
                     fused_part[0].data_ptr(), fused_part[1].data_ptr(), ws.data_ptr(), st)), "pw_bwd_small")
+            wjobs.append(_reduce_only_job(dev, w, cout, cin, splits, ws))
+            wlayers.append(li)
+            d_dense, d_pooled, d_arg = dprev, None, None
+            continue
+        if li > 0 and need_w[li] and USE_FUSED_MID_BWD and lib.istnet_pw_bwd_mid_ok(cin, cout, p):
+            # mid-size layer (64 / 128 channels): the same one-pass contract, the whole weight matrix in one workgroup
+            splits = lib.istnet_pw_bwd_mid_splits(b, cin, cout, p)
+            ws = _empty((splits, cout, cin), torch.float32, dev)
+            dprev = _empty((b, cin, p), torch.float32, dev)
+            fused_part, fused_nt = _empty((2, cin, splits), torch.float32, dev), splits
+            _native.check(_native.timed(
+                f"pw_bwd_mid_kernel<{cout // 32},{cin // 32},{'false' if dd is not None else 'true'}>", 4.0 * b * p * cin * cout,
+                4.0 * (b * p * (2 * cin + cout) + grad_elems),
+                lambda: lib.istnet_pw_bwd_mid(
+                    b, cin, cout, p, ns_arg, w2.data_ptr(), ys[li - 1].data_ptr(), bns[li - 1].data_ptr(),
+                    y.data_ptr(), dd, dp, pbs, da, bn.data_ptr(), bwdc.data_ptr(), dprev.data_ptr(),
+                    fused_part[0].data_ptr(), fused_part[1].data_ptr(), ws.data_ptr(), st)), "pw_bwd_mid")
             wjobs.append(_reduce_only_job(dev, w, cout, cin, splits, ws))
             wlayers.append(li)
             d_dense, d_pooled, d_arg = dprev, None, None

@@ -91,6 +91,66 @@ def test_bwd_small_equals_dgrad_plus_wgrad(cin, cout, p, pooled):
     torch.testing.assert_close(part[1].sum(-1), (gq * x).sum(dim=(0, 2)), rtol=1e-3, atol=1e-2)
 
 
+@pytest.mark.parametrize("cin,cout,p,pooled", [(32, 64, 1024, True), (64, 64, 512, False), (64, 128, 2048, True),
+                                               (128, 128, 256, False), (128, 128, 1024, True), (32, 64, 384, False)])
+def test_bwd_mid_equals_dgrad_plus_wgrad(cin, cout, p, pooled):
+    """pw_bwd_mid_kernel (64 / 128-channel layers) against float64 expressions of dA, dW and the statistics sums."""
+    lib = _native.lib()
+    b, s = 3, 16
+    assert lib.istnet_pw_bwd_mid_ok(cin, cout, p)
+    assert not lib.istnet_pw_bwd_mid_ok(cin, cout, p + 32) and not lib.istnet_pw_bwd_mid_ok(96, cout, p)
+    g = torch.Generator().manual_seed(cin + cout + p)
+    x = torch.randn(b, cin, p, generator=g).to(DEV)
+    y = torch.randn(b, cout, p, generator=g).to(DEV)
+    w = (torch.randn(cout, cin, generator=g) * 0.2).to(DEV)
+    bn, bn_in = _bn_block(cout, g), _bn_block(cin, g)
+    bwdc = torch.stack([torch.rand(cout, generator=g) + 0.5, torch.randn(cout, generator=g) * 0.01,
+                        torch.randn(cout, generator=g) * 0.01]).contiguous().to(DEV)
+    if pooled:
+        gr = p // s
+        dpool = torch.randn(b, cout, gr, generator=g).to(DEV)
+        arg = torch.randint(0, s, (b, cout, gr), generator=g, dtype=torch.uint8).to(DEV)
+        src = (None, dpool.data_ptr(), arg.data_ptr(), s)
+        gdense = torch.zeros(b, cout, gr, s, device=DEV).scatter_(3, arg.long().unsqueeze(-1), dpool.unsqueeze(-1)).reshape(b, cout, p)
+    else:
+        gdense = torch.randn(b, cout, p, generator=g).to(DEV)
+        src = (gdense.data_ptr(), None, None, 0)
+    dx = torch.full((b, cin, p), float("nan"), device=DEV)
+    splits = lib.istnet_pw_bwd_mid_splits(b, cin, cout, p)
+    assert splits >= 1
+    part = torch.full((2, cin, splits), float("nan"), device=DEV)
+    ws = torch.full((splits, cout, cin), float("nan"), device=DEV)
+    assert lib.istnet_pw_bwd_mid(b, cin, cout, p, src[3], w.data_ptr(), x.data_ptr(), bn_in.data_ptr(), y.data_ptr(),
+                                 src[0], src[1], 0, src[2], bn.data_ptr(), bwdc.data_ptr(), dx.data_ptr(),
+                                 part[0].data_ptr(), part[1].data_ptr(), ws.data_ptr(), _st()) == 0
+    d = torch.float64
+    mask = (y * bn[0].view(1, -1, 1) + bn[1].view(1, -1, 1)) > 0          # fp32, as the kernel decides it
+    dy = bwdc[0].to(d).view(1, -1, 1) * (gdense.to(d) * mask) + bwdc[1].to(d).view(1, -1, 1) + bwdc[2].to(d).view(1, -1, 1) * y.to(d)
+    want_dx = torch.matmul(w.to(d).t(), dy)
+    pre = x * bn_in[0].view(1, -1, 1) + bn_in[1].view(1, -1, 1)
+    act = torch.relu(pre).to(d)
+    want_dw = torch.einsum("bop,bip->oi", dy, act)
+    gq = want_dx * (pre > 0)
+    torch.testing.assert_close(dx.to(d), want_dx, rtol=1e-5, atol=2e-5)
+    torch.testing.assert_close(ws.to(d).sum(0), want_dw, rtol=1e-5, atol=1e-3)
+    torch.testing.assert_close(part[0].to(d).sum(-1), gq.sum(dim=(0, 2)), rtol=1e-4, atol=2e-3)
+    torch.testing.assert_close(part[1].to(d).sum(-1), (gq * x.to(d)).sum(dim=(0, 2)), rtol=1e-4, atol=2e-3)
+    # the workgroup count is a tuning parameter: another split of the points gives the same sums
+    assert lib.istnet_pw_set_tuning(8, 7) == 0
+    try:
+        s2 = lib.istnet_pw_bwd_mid_splits(b, cin, cout, p)
+        assert 1 <= s2 <= 7
+        dx2, part2, ws2 = torch.empty_like(dx), torch.empty(2, cin, s2, device=DEV), torch.empty(s2, cout, cin, device=DEV)
+        assert lib.istnet_pw_bwd_mid(b, cin, cout, p, src[3], w.data_ptr(), x.data_ptr(), bn_in.data_ptr(), y.data_ptr(),
+                                     src[0], src[1], 0, src[2], bn.data_ptr(), bwdc.data_ptr(), dx2.data_ptr(),
+                                     part2[0].data_ptr(), part2[1].data_ptr(), ws2.data_ptr(), _st()) == 0
+    finally:
+        lib.istnet_pw_set_tuning(8, 0)
+    assert torch.equal(dx2, dx)
+    torch.testing.assert_close(ws2.to(d).sum(0), want_dw, rtol=1e-5, atol=1e-3)
+    torch.testing.assert_close(part2[0].to(d).sum(-1), gq.sum(dim=(0, 2)), rtol=1e-4, atol=2e-3)
+
+
 def test_forward_acc_channel_stats_and_dy():
     lib = _native.lib()
     b, cin, cout, p = 2, 24, 40, 256
