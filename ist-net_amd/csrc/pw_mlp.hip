@@ -1823,26 +1823,43 @@ __global__ __launch_bounds__(kThreads, ISTNET_BWD_SMALL_WAVES) void pw_bwd_small
 //   wgrad  dW[co][ci]  += sum_pt dY[co][pt] act(x)[ci][pt]  K = points: both operands are rows of the tiles, read as
 //          float4 along the points -- a lane's four values feed four consecutive MFMA k-steps (the k index is a dummy
 //          index, so A and B only have to agree on which point a (lane half, step) pair means: point 8j + 4*half + t).
-// Work split over the four waves: one 32x32 dA^T tile each (PT = 128 / (cin/32) points per chunk), and the dW tiles
-// as a (WGM x WGN) grid of TM x TN tiles, over point halves (WGK = 2) when the matrix has only two tiles.
+// Eight waves with two roles (one workgroup per CU, one wave of each role per SIMD): waves 4..7 are LOADERS -- global
+// loads two chunks ahead in two register sets, dY finished and both tiles written into the other half of a
+// double-buffered LDS -- and waves 0..3 only issue MFMAs (one 32x32 dA^T tile each, PT = 128 / (cin/32) points per
+// chunk; the dW tiles as a (WGM x WGN) grid of TM x TN tiles, over point halves (WGK = 2) when the matrix has only two
+// tiles) and store dA with its statistics.  One barrier per chunk.  Measured before the split (four waves doing both,
+// two workgroups per CU): MFMA phase, loads and the dY arithmetic ran back to back (24 + 10 + 10 us on the 128 -> 128
+// layer of SA4), because every workgroup of the launch is in the same phase at the same time.
 // ============================================================================================
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() is a release / acquire fence pair around s_barrier,
+// and on gfx9 the release waits for vmcnt(0): every global load in flight -- here the loaders' prefetch of the chunk
+// after next -- and every dA store of the compute waves would be drained at each chunk.
+__device__ __forceinline__ void lds_barrier() {
+  __atomic_signal_fence(__ATOMIC_SEQ_CST);
+  __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): this wave's LDS writes have landed; vmcnt / expcnt untouched
+  __builtin_amdgcn_s_barrier();
+  __atomic_signal_fence(__ATOMIC_SEQ_CST);
+}
+constexpr int kMidThreads = 512;
 template <int COT, int CIT>
 struct MidCfg {
   static constexpr int COUT = 32 * COT, CIN = 32 * CIT;
-  static constexpr int PT = 128 / CIT;                  // points per chunk: CIT * PT / 32 == 4 dA^T tiles, one per wave
+  static constexpr int PT = 128 / CIT;                  // points per chunk: CIT * PT / 32 == 4 dA^T tiles, one per compute wave
   static constexpr int LD = PT + 4;                     // 16-byte aligned rows; +4 floats: float4 reads of 8 rows cover 32 banks
   static constexpr int F4 = PT / 4;                     // float4 per tile row
-  static constexpr int NY = COUT * F4 / kThreads;       // float4 per thread, y / gradient tile
-  static constexpr int NX = CIN * F4 / kThreads;
+  static constexpr int NY = COUT * F4 / 256;            // float4 per loader thread, y / gradient tile
+  static constexpr int NX = CIN * F4 / 256;
   static constexpr int WGN = CIT < 2 ? CIT : 2;
   static constexpr int WGM = COT < 4 / WGN ? COT : 4 / WGN;
   static constexpr int WGK = 4 / (WGM * WGN);
   static constexpr int TM = COT / WGM, TN = CIT / WGN;
+  static constexpr int TILE = (COUT + CIN) * LD;        // floats of one LDS buffer: dY tile, then the raw x tile
+  static constexpr size_t LDS_BYTES = (2 * TILE + 5 * COUT) * sizeof(float);
   static_assert(NY >= 1 && NX >= 1 && WGM * WGN * WGK == 4 && TM * WGM == COT && TN * WGN == CIT, "unsupported shape");
 };
 
 template <int COT, int CIT, bool POOLED>
-__global__ __launch_bounds__(kThreads, 2) void pw_bwd_mid_kernel(
+__global__ __launch_bounds__(kMidThreads) void pw_bwd_mid_kernel(
     int P, long long total, int split_len, const float* __restrict__ w, const float* __restrict__ x,
     const float* __restrict__ in_scale, const float* __restrict__ in_shift, const float* __restrict__ y, GradSrc gs,
     const float* __restrict__ bn, const float* __restrict__ bwdc, float* __restrict__ dx,
@@ -1850,74 +1867,71 @@ __global__ __launch_bounds__(kThreads, 2) void pw_bwd_mid_kernel(
   using C = MidCfg<COT, CIT>;
   constexpr int COUT = C::COUT, CIN = C::CIN, PT = C::PT, LD = C::LD, F4 = C::F4, NY = C::NY, NX = C::NX;
   constexpr int TM = C::TM, TN = C::TN;
-  __shared__ __attribute__((aligned(16))) float dYs[COUT * LD];
-  __shared__ __attribute__((aligned(16))) float Xs[CIN * LD];    // RAW y_{l-1}: the statistics need it, act() is applied on read
-  __shared__ float s_c[5][COUT];                                 // scale, shift of this layer's BN; the three BN-backward constants
-  const int tid = threadIdx.x, lane = lane_id(), wv = wave_id();
+  extern __shared__ __attribute__((aligned(16))) float mid_lds[];
+  float* const s_c = mid_lds + 2 * C::TILE;     // [5][COUT]: scale, shift of this layer's BN; the three BN-backward constants
+  const int lane = lane_id();
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // scalar: the role branches are wave-uniform
+  const bool loader = wv >= 4;
+  const int cw = wv & 3;                        // index within the role
+  const int tid = threadIdx.x & 255;            // thread index within the role
   const int l31 = lane & 31, half = lane >> 5;
   const long long qbeg = (long long)blockIdx.x * split_len;
   const long long qend = max(qbeg, min(qbeg + (long long)split_len, total));
-  for (int c = tid; c < COUT; c += kThreads) {
-    s_c[0][c] = bn[c]; s_c[1][c] = bn[COUT + c];
-    s_c[2][c] = bwdc[c]; s_c[3][c] = bwdc[COUT + c]; s_c[4][c] = bwdc[2 * COUT + c];
-  }
-  // dgrad: wave -> (point block pb, input-channel block cb); B[k = co][j = ci] = w[co][32 cb + j]
-  const int pb = wv / CIT, cb = wv % CIT;
-  float wfrag[COUT / 2];
-#pragma unroll
-  for (int kk = 0; kk < COUT / 2; ++kk) wfrag[kk] = w[(size_t)(2 * kk + half) * CIN + 32 * cb + l31];
-  const float dsc = in_scale[32 * cb + l31], dsh = in_shift[32 * cb + l31];
-  // wgrad: wave -> (row group wm, column group wn, point half wk)
-  const int wk = wv / (C::WGM * C::WGN), wm = (wv / C::WGN) % C::WGM, wn = wv % C::WGN;
-  float wsc[TN], wsh[TN];
-#pragma unroll
-  for (int tn = 0; tn < TN; ++tn) {
-    wsc[tn] = in_scale[32 * (wn * TN + tn) + l31];
-    wsh[tn] = in_shift[32 * (wn * TN + tn) + l31];
+  const int nchunks = (int)((qend - qbeg) / PT);   // P % PT == 0 (host-checked): whole chunks, each inside one cloud
+  for (int c = threadIdx.x; c < COUT; c += kMidThreads) {
+    s_c[0 * COUT + c] = bn[c]; s_c[1 * COUT + c] = bn[COUT + c];
+    s_c[2 * COUT + c] = bwdc[c]; s_c[3 * COUT + c] = bwdc[COUT + c]; s_c[4 * COUT + c] = bwdc[2 * COUT + c];
   }
 
-  float4 ry[NY], rx[NX];
-  float4 rd[POOLED ? 1 : NY];
-  float rpv[POOLED ? NY : 1];
-  int rarg[POOLED ? NY : 1];
-  auto load_chunk = [&](long long qk) {
+  // ---------------- loader state ----------------
+  float4 ry[2][NY], rx[2][NX];
+  float4 rd[2][POOLED ? 1 : NY];
+  float rpv[2][POOLED ? NY : 1];
+  int rarg[2][POOLED ? NY : 1];
+  auto load_chunk = [&](int set, long long qk) {
     int b, pk;
     split_point(qk, P, b, pk);
 #pragma unroll
     for (int i = 0; i < NY; ++i) {
-      const int e = tid + kThreads * i, row = e / F4, p = pk + (e % F4) * 4;
+      const int e = tid + 256 * i, row = e / F4, p = pk + (e % F4) * 4;
       const size_t rowo = (size_t)b * COUT + row;
-      ry[i] = *reinterpret_cast<const float4*>(y + rowo * (size_t)P + p);
+      ry[set][i] = *reinterpret_cast<const float4*>(y + rowo * (size_t)P + p);
       if (POOLED) {
         const int G = P / gs.S, g = p / gs.S;
-        rpv[i] = pooled_at(gs, b, row, G, g);
-        rarg[i] = gs.arg[rowo * (size_t)G + g];
+        rpv[set][i] = pooled_at(gs, b, row, G, g);
+        rarg[set][i] = gs.arg[rowo * (size_t)G + g];
       } else {
-        rd[i] = *reinterpret_cast<const float4*>(gs.dense + rowo * (size_t)P + p);
+        rd[set][i] = *reinterpret_cast<const float4*>(gs.dense + rowo * (size_t)P + p);
       }
     }
 #pragma unroll
     for (int i = 0; i < NX; ++i) {
-      const int e = tid + kThreads * i, row = e / F4, p = pk + (e % F4) * 4;
-      rx[i] = *reinterpret_cast<const float4*>(x + ((size_t)b * CIN + row) * P + p);
+      const int e = tid + 256 * i, row = e / F4, p = pk + (e % F4) * 4;
+      rx[set][i] = *reinterpret_cast<const float4*>(x + ((size_t)b * CIN + row) * P + p);
     }
   };
-  auto store_chunk = [&](long long qk) {
-    int b_unused, pk;
-    split_point(qk, P, b_unused, pk);
+  auto store_chunk = [&](int set, float* buf, long long qk) {
+    float* dYs = buf;
+    float* Xs = buf + COUT * LD;
+    int pk = 0;
+    if (POOLED) {
+      int b_unused;
+      split_point(qk, P, b_unused, pk);
+    }
 #pragma unroll
     for (int i = 0; i < NY; ++i) {
-      const int e = tid + kThreads * i, row = e / F4, k = (e % F4) * 4;
-      const float rs = s_c[0][row], rh = s_c[1][row], rca = s_c[2][row], rcb = s_c[3][row], rcc = s_c[4][row];
+      const int e = tid + 256 * i, row = e / F4, k = (e % F4) * 4;
+      const float rs = s_c[row], rh = s_c[COUT + row], rca = s_c[2 * COUT + row], rcb = s_c[3 * COUT + row],
+                  rcc = s_c[4 * COUT + row];
       float4 d;
       if (POOLED) {
-        const int ks = (pk + k) % gs.S, a = rarg[i];
-        const float pv = rpv[i];
+        const int ks = (pk + k) % gs.S, a = rarg[set][i];
+        const float pv = rpv[set][i];
         d = make_float4(a == ks ? pv : 0.f, a == ks + 1 ? pv : 0.f, a == ks + 2 ? pv : 0.f, a == ks + 3 ? pv : 0.f);
       } else {
-        d = rd[i];
+        d = rd[set][i];
       }
-      const float4 yv = ry[i];
+      const float4 yv = ry[set][i];
       float4 v;
       v.x = rca * ((yv.x * rs + rh > 0.f) ? d.x : 0.f) + rcb + rcc * yv.x;
       v.y = rca * ((yv.y * rs + rh > 0.f) ? d.y : 0.f) + rcb + rcc * yv.y;
@@ -1927,41 +1941,89 @@ __global__ __launch_bounds__(kThreads, 2) void pw_bwd_mid_kernel(
     }
 #pragma unroll
     for (int i = 0; i < NX; ++i) {
-      const int e = tid + kThreads * i, row = e / F4, k = (e % F4) * 4;
-      *reinterpret_cast<float4*>(&Xs[row * LD + k]) = rx[i];
+      const int e = tid + 256 * i, row = e / F4, k = (e % F4) * 4;
+      *reinterpret_cast<float4*>(&Xs[row * LD + k]) = rx[set][i];   // RAW y_{l-1}: the statistics need it, act() is applied on read
     }
   };
 
+  // Each role runs its OWN loop (same number of barriers on both sides), so the register allocation of a role does
+  // not carry the other role's state.
+  __syncthreads();                                 // s_c
+  if (loader) {
+    // Chunk t: the loaders fill buffer t & 1 BEFORE barrier t, the compute waves read it AFTER barrier t.  A loader is
+    // at most one chunk ahead: it reaches barrier t + 1 (buffer (t + 1) & 1 written) only after the compute waves
+    // passed barrier t, i.e. finished chunk t - 1, the last reader of that buffer.
+    // The loader's VALU work shares the SIMD's issue port with the MFMA wave and loses to it (measured: the store phase
+    // takes 1.7x longer beside the MFMAs).  Where the loaders are the longer side (cin <= 64) they get priority; on
+    // the 128 -> 128 layers the MFMA wave is the critical path and priority costs 8 %.
+    if (CIT <= 2) __builtin_amdgcn_s_setprio(3);
+    if (nchunks > 0) load_chunk(0, qbeg);
+    if (nchunks > 1) load_chunk(1, qbeg + PT);
+    for (int t = 0; t < nchunks; t += 2) {
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        if (t + u < nchunks) {
+          const long long qk = qbeg + (long long)(t + u) * PT;
+          store_chunk(u, mid_lds + u * C::TILE, qk);
+          if (t + u + 2 < nchunks) load_chunk(u, qk + 2 * PT);     // two chunks ahead, into the set just consumed
+          lds_barrier();
+        }
+      }
+    }
+    __syncthreads();                               // the four barriers of the compute waves' epilogue
+    if (C::WGK == 2) { __syncthreads(); __syncthreads(); }
+    __syncthreads();
+    return;
+  }
+  // ---------------- compute waves ----------------
+  // dgrad: wave -> (point block pb, input-channel block cb); B[k = co][j = ci] = w[co][32 cb + j]
+  const int pb = cw / CIT, cb = cw % CIT;
+  // wgrad: wave -> (row group wm, column group wn, point half wk)
+  const int wk = cw / (C::WGM * C::WGN), wm = (cw / C::WGN) % C::WGM, wn = cw % C::WGN;
+  float wfrag[COUT / 2];
+  float wsc[TN], wsh[TN];
   f32x16 accw[TM][TN];
+  float sg = 0.f, sgy = 0.f;   // statistics of input channel 32 cb + l31 over the point rows this lane holds
+#pragma unroll
+  for (int kk = 0; kk < COUT / 2; ++kk) wfrag[kk] = w[(size_t)(2 * kk + half) * CIN + 32 * cb + l31];
+  const float dsc = in_scale[32 * cb + l31], dsh = in_shift[32 * cb + l31];
+#pragma unroll
+  for (int tn = 0; tn < TN; ++tn) {
+    wsc[tn] = in_scale[32 * (wn * TN + tn) + l31];
+    wsh[tn] = in_shift[32 * (wn * TN + tn) + l31];
+  }
 #pragma unroll
   for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
     for (int tn = 0; tn < TN; ++tn)
 #pragma unroll
       for (int r = 0; r < 16; ++r) accw[tm][tn][r] = 0.f;
-  float sg = 0.f, sgy = 0.f;   // statistics of input channel 32 cb + l31 over the point rows this lane holds
-  const int nchunks = (int)((qend - qbeg) / PT);   // P % PT == 0 (host-checked): whole chunks, each inside one cloud
-  if (nchunks > 0) load_chunk(qbeg);
-  __syncthreads();                                 // s_c
-  for (int t = 0; t < nchunks; ++t) {
-    const long long qk = qbeg + (long long)t * PT;
-    store_chunk(qk);
-    __syncthreads();
-    if (t + 1 < nchunks) load_chunk(qk + PT);      // in flight during the MFMAs
+
+  auto compute_chunk = [&](const float* buf, long long qk) {
+    const float* dYs = buf;
+    const float* Xs = buf + COUT * LD;
     // ---- dgrad: dA^T tile (points 32 pb .., input channels 32 cb ..) ----
     {
       f32x16 accd;
 #pragma unroll
       for (int r = 0; r < 16; ++r) accd[r] = 0.f;
       const float* ap = dYs + half * LD + 32 * pb + l31;   // dY[co = 2kk + half][pt = 32 pb + l31]
-      float fa[2];
-      fa[0] = ap[0];
+      // fragments of the NEXT group of kDG k-steps are read while the MFMAs of this group run
+      constexpr int kDG = 8;
+      float fa[2][kDG];
 #pragma unroll
-      for (int kk = 0; kk < COUT / 2; ++kk) {
-        const int cur = kk & 1, nxt = cur ^ 1;
-        if (kk + 1 < COUT / 2) fa[nxt] = ap[2 * (kk + 1) * LD];
+      for (int u = 0; u < kDG; ++u) fa[0][u] = ap[2 * u * LD];
+#pragma unroll
+      for (int gk = 0; gk < COUT / 2 / kDG; ++gk) {
+        const int cur = gk & 1, nxt = cur ^ 1;
+        if (gk + 1 < COUT / 2 / kDG) {
+#pragma unroll
+          for (int u = 0; u < kDG; ++u) fa[nxt][u] = ap[2 * ((gk + 1) * kDG + u) * LD];
+        }
         __builtin_amdgcn_sched_barrier(0);
-        accd = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur], wfrag[kk], accd, 0, 0, 0);
+#pragma unroll
+        for (int u = 0; u < kDG; ++u)
+          accd = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][u], wfrag[gk * kDG + u], accd, 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
       }
       // register r of a lane: point mfma_row(r, lane) of the block, input channel l31; 4j .. 4j+3 = 4 consecutive points
@@ -1989,41 +2051,54 @@ __global__ __launch_bounds__(kThreads, 2) void pw_bwd_mid_kernel(
       constexpr int KP = PT / C::WGK;          // points of this wave's K range
       const float* ap = dYs + (32 * wm * TM + l31) * LD + wk * KP + 4 * half;
       const float* bp = Xs + (32 * wn * TN + l31) * LD + wk * KP + 4 * half;
+      float4 a4[2][TM], b4[2][TN];
+#pragma unroll
+      for (int tm = 0; tm < TM; ++tm) a4[0][tm] = *reinterpret_cast<const float4*>(ap + tm * 32 * LD);
+#pragma unroll
+      for (int tn = 0; tn < TN; ++tn) b4[0][tn] = *reinterpret_cast<const float4*>(bp + tn * 32 * LD);
 #pragma unroll
       for (int j = 0; j < KP / 8; ++j) {
-        float4 a4[TM], b4[TN];
+        const int cur = j & 1, nxt = cur ^ 1;
+        if (j + 1 < KP / 8) {      // next group's rows in flight during this group's MFMAs
 #pragma unroll
-        for (int tm = 0; tm < TM; ++tm) a4[tm] = *reinterpret_cast<const float4*>(ap + tm * 32 * LD + 8 * j);
+          for (int tm = 0; tm < TM; ++tm) a4[nxt][tm] = *reinterpret_cast<const float4*>(ap + tm * 32 * LD + 8 * (j + 1));
 #pragma unroll
-        for (int tn = 0; tn < TN; ++tn) {
-          b4[tn] = bn_relu4(*reinterpret_cast<const float4*>(bp + tn * 32 * LD + 8 * j), wsc[tn], wsh[tn]);
+          for (int tn = 0; tn < TN; ++tn) b4[nxt][tn] = *reinterpret_cast<const float4*>(bp + tn * 32 * LD + 8 * (j + 1));
         }
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn) b4[cur][tn] = bn_relu4(b4[cur][tn], wsc[tn], wsh[tn]);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int tm = 0; tm < TM; ++tm)
+        for (int t = 0; t < 4; ++t)
 #pragma unroll
-          for (int tn = 0; tn < TN; ++tn) {
-            accw[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[tm].x, b4[tn].x, accw[tm][tn], 0, 0, 0);
-            accw[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[tm].y, b4[tn].y, accw[tm][tn], 0, 0, 0);
-            accw[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[tm].z, b4[tn].z, accw[tm][tn], 0, 0, 0);
-            accw[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[tm].w, b4[tn].w, accw[tm][tn], 0, 0, 0);
-          }
+          for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn) {
+              const float av = t == 0 ? a4[cur][tm].x : (t == 1 ? a4[cur][tm].y : (t == 2 ? a4[cur][tm].z : a4[cur][tm].w));
+              const float bv = t == 0 ? b4[cur][tn].x : (t == 1 ? b4[cur][tn].y : (t == 2 ? b4[cur][tn].z : b4[cur][tn].w));
+              accw[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, accw[tm][tn], 0, 0, 0);
+            }
         __builtin_amdgcn_sched_barrier(0);
       }
     }
-    __syncthreads();    // every wave is done with the tiles before the next chunk overwrites them
+  };
+
+  for (int t = 0; t < nchunks; ++t) {
+    lds_barrier();
+    compute_chunk(mid_lds + (t & 1) * C::TILE, qbeg + (long long)t * PT);
   }
   // ---- per-workgroup results ----
-  float* red = dYs;     // reuse: the loop ended on a barrier
+  __syncthreads();      // the compute waves are done with the tiles
+  float* red = mid_lds;
   if (C::WGK == 2) {    // two waves hold halves of the same dW tile
     if (wk == 1) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) red[(wv & 1) * 1024 + r * 64 + lane] = accw[0][0][r];
+      for (int r = 0; r < 16; ++r) red[(cw & 1) * 1024 + r * 64 + lane] = accw[0][0][r];
     }
     __syncthreads();
     if (wk == 0) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) accw[0][0][r] += red[(wv & 1) * 1024 + r * 64 + lane];
+      for (int r = 0; r < 16; ++r) accw[0][0][r] += red[(cw & 1) * 1024 + r * 64 + lane];
     }
     __syncthreads();
   }
@@ -2040,11 +2115,11 @@ __global__ __launch_bounds__(kThreads, 2) void pw_bwd_mid_kernel(
         }
   }
   float* sred = red;    // [4 waves][2 halves][32][2]
-  sred[((wv * 2 + half) * 32 + l31) * 2 + 0] = sg;
-  sred[((wv * 2 + half) * 32 + l31) * 2 + 1] = sgy;
+  sred[((cw * 2 + half) * 32 + l31) * 2 + 0] = sg;
+  sred[((cw * 2 + half) * 32 + l31) * 2 + 1] = sgy;
   __syncthreads();
-  if (tid < CIN) {
-    const int cbk = tid >> 5, l = tid & 31;
+  if (threadIdx.x < CIN) {
+    const int cbk = threadIdx.x >> 5, l = threadIdx.x & 31;
     float a = 0.f, c = 0.f;
 #pragma unroll
     for (int k = 0; k < 4 / CIT; ++k) {        // the waves with this channel block, in wave order; both halves
@@ -2052,8 +2127,8 @@ __global__ __launch_bounds__(kThreads, 2) void pw_bwd_mid_kernel(
       a += sred[((wsrc * 2 + 0) * 32 + l) * 2 + 0] + sred[((wsrc * 2 + 1) * 32 + l) * 2 + 0];
       c += sred[((wsrc * 2 + 0) * 32 + l) * 2 + 1] + sred[((wsrc * 2 + 1) * 32 + l) * 2 + 1];
     }
-    part_g[(size_t)tid * nt_total + blockIdx.x] = a;
-    part_gy[(size_t)tid * nt_total + blockIdx.x] = c;
+    part_g[(size_t)threadIdx.x * nt_total + blockIdx.x] = a;
+    part_gy[(size_t)threadIdx.x * nt_total + blockIdx.x] = c;
   }
 }
 
@@ -2164,7 +2239,7 @@ int g_wg_small_pts = 0x7fffffff;  // layers with b*P <= this use 64x64 wgrad til
 int g_wg_target_big = 512;   // target workgroup count, outputs >= 128x128 (re-tuned end to end once the wgrads ran beside the dgrad chain: 768/1024 -> 512/512 is 1.5 % faster)
 int g_wg_target_small = 512;
 int g_bwd_small_target = 256; // workgroups of the fused small-layer backward (key 5)
-int g_bwd_mid_target = 512;   // workgroups of the fused mid-size-layer backward (key 8)
+int g_bwd_mid_target = 256;   // workgroups of the fused mid-size-layer backward (key 8): one per CU
 int g_bwd_mid_enable = 1;     // key 9: 0 = those layers run the dgrad / wgrad pair
 int g_exp_no_fast = 0;        // experiment (key 6): 1 = never take the interior-tile fast kernels
 inline int wgrad_mt(int cout, long long pts) { return (cout >= 128 && pts > g_wg_small_pts) ? 128 : 64; }
@@ -2225,7 +2300,7 @@ int istnet_pw_set_tuning(int key, int value) {
     case 5: g_bwd_small_target = value > 0 ? value : 256; return 0;
     case 6: g_exp_no_fast = value; return 0;
     case 7: g_dgrad_min_wgs = value > 0 ? value : 384; return 0;
-    case 8: g_bwd_mid_target = value > 0 ? value : 512; return 0;
+    case 8: g_bwd_mid_target = value > 0 ? value : 256; return 0;
     case 9: g_bwd_mid_enable = value != 0; return 0;
     default: return ISTNET_PN2_EINVAL;
   }
@@ -2716,14 +2791,24 @@ int istnet_pw_bwd_mid(int b, int cin, int cout, int p, int nsample, const float*
   const int splits = istnet_pw_bwd_mid_splits(b, cin, cout, p);
 #define ISTNET_BWD_MID(COT, CIT)                                                                                   \
   do {                                                                                                             \
+    constexpr size_t lds = MidCfg<COT, CIT>::LDS_BYTES;                                                            \
+    static bool attr_set = false;   /* more than 64 KB of LDS per workgroup needs the opt-in, once per kernel */   \
+    if (!attr_set) {                                                                                               \
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(&pw_bwd_mid_kernel<COT, CIT, false>),                  \
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||              \
+          hipFuncSetAttribute(reinterpret_cast<const void*>(&pw_bwd_mid_kernel<COT, CIT, true>),                   \
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)                \
+        return ISTNET_PN2_EINVAL;                                                                                  \
+      attr_set = true;                                                                                             \
+    }                                                                                                              \
     if (d_dense != nullptr)                                                                                        \
-      hipLaunchKernelGGL((pw_bwd_mid_kernel<COT, CIT, false>), dim3(splits), dim3(kThreads), 0, as_stream(stream), \
-                         p, (long long)b * p, len, w, x, bn_in, bn_in + cin, y, gs, bn, bwdc, dx, part_g, part_gy, \
-                         splits, dw_part);                                                                         \
+      hipLaunchKernelGGL((pw_bwd_mid_kernel<COT, CIT, false>), dim3(splits), dim3(kMidThreads), lds,               \
+                         as_stream(stream), p, (long long)b * p, len, w, x, bn_in, bn_in + cin, y, gs, bn, bwdc,   \
+                         dx, part_g, part_gy, splits, dw_part);                                                    \
     else                                                                                                           \
-      hipLaunchKernelGGL((pw_bwd_mid_kernel<COT, CIT, true>), dim3(splits), dim3(kThreads), 0, as_stream(stream),  \
-                         p, (long long)b * p, len, w, x, bn_in, bn_in + cin, y, gs, bn, bwdc, dx, part_g, part_gy, \
-                         splits, dw_part);                                                                         \
+      hipLaunchKernelGGL((pw_bwd_mid_kernel<COT, CIT, true>), dim3(splits), dim3(kMidThreads), lds,                \
+                         as_stream(stream), p, (long long)b * p, len, w, x, bn_in, bn_in + cin, y, gs, bn, bwdc,   \
+                         dx, part_g, part_gy, splits, dw_part);                                                    \
   } while (0)
   if (cout == 64 && cin == 32) ISTNET_BWD_MID(2, 1);
   else if (cout == 64) ISTNET_BWD_MID(2, 2);
