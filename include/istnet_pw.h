@@ -31,7 +31,10 @@ ISTNET_PN2_API int istnet_pw_tile_cfg(int b, int m, int p);
 ISTNET_PN2_API int istnet_pw_dgrad_tile_cfg(int b, int m, int p);
 ISTNET_PN2_API int istnet_pw_wgrad_tile_cfg(int b, int cin, int cout, int p);
 /* launch heuristics (experiments): key 0 = point count up to which wgrad uses 64x64 tiles, 1 / 2 = split-K
- * workgroup targets for large / small outputs.  Returns ISTNET_PN2_EINVAL for an unknown key. */
+ * workgroup targets for large / small outputs, 5 = workgroups of the fused small-layer backward, 7 = minimum workgroup
+ * count for the tall dgrad tiles, 8 / 9 = workgroups / enable of the fused mid-size-layer backward, 11 / 12 = enable /
+ * workgroups of the role-split wgrad kernel (dense input, cin and cout >= 64; istnet_pw_wgrad_tile_cfg then reports
+ * 1000000 + M_T * 1000 + N_T).  Returns ISTNET_PN2_EINVAL for an unknown key. */
 ISTNET_PN2_API int istnet_pw_set_tuning(int key, int value);
 
 /* number of per-channel partial-statistics slots istnet_pw_forward writes for this shape */

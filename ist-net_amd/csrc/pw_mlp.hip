@@ -65,6 +65,18 @@ __device__ __forceinline__ void split_point(long long q, int P, int& b, int& p) 
   p = (int)(uq - ub * up);
 }
 
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() is a release / acquire fence pair around s_barrier,
+// and on gfx9 the release waits for vmcnt(0): every global load in flight -- in the role-split kernels the loaders' prefetch of
+// the chunk after next and the compute waves' stores -- would be drained at each chunk.
+__device__ __forceinline__ void lds_barrier() {
+  __atomic_signal_fence(__ATOMIC_SEQ_CST);
+  __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): this wave's LDS writes have landed; vmcnt / expcnt untouched
+  __builtin_amdgcn_s_barrier();
+  __atomic_signal_fence(__ATOMIC_SEQ_CST);
+}
+constexpr int kMidThreads = 512;   // role-split kernels: waves 0..3 issue MFMAs, waves 4..7 load
+
+
 // MFMA C/D layout of v_mfma_f32_32x32x2_f32: reg r of lane l holds row (r&3)+8*(r>>2)+4*(l>>5), col l&31.
 __device__ __forceinline__ int mfma_row(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
 
@@ -1519,6 +1531,185 @@ __global__ __launch_bounds__(kThreads) void pw_wgrad_kernel(
 }
 
 // ============================================================================================
+// wgrad, dense input, cout and cin >= 64 (the FP levels, SA4, the layers pw_bwd_mid_kernel does not take): the same
+// product as pw_wgrad_kernel with the machinery of pw_bwd_mid_kernel -- eight waves in two roles, one workgroup per
+// CU.  Waves 4..7 load (two chunks of 32 points ahead, two register sets), finish dY and write both operand tiles
+// into the other half of a double-buffered LDS IN THE TENSORS' OWN LAYOUT ([channel][point], float4 stores; the
+// k-major tiles of pw_wgrad_kernel need four scalar ds_write_b32 per float4).  Waves 0..3 own a 2 x 2 grid of
+// (M_T/2) x (N_T/2) sub-tiles and read both operands as float4 ALONG THE POINTS: K is a dummy index, so a lane's four
+// values serve four consecutive k-steps as long as A and B agree on the point a (lane half, step) pair means -- a
+// quarter of the LDS reads and no per-step address arithmetic.  Barriers order LDS only (lds_barrier).
+// grid: (splits, ceil(cout / M_T), ceil(cin / N_T)); P % 32 == 0, total = B * P, split_len % 32 == 0.
+// ============================================================================================
+template <int M_T, int N_T, bool POOLED>
+__global__ __launch_bounds__(kMidThreads) void pw_wgrad2_kernel(
+    int cin, int cout, int P, long long total, int split_len, const float* __restrict__ x,
+    const float* __restrict__ in_scale, const float* __restrict__ in_shift, const float* __restrict__ y, GradSrc gs,
+    const float* __restrict__ bn, const float* __restrict__ bwdc, float* __restrict__ dw_part) {
+  constexpr int PT = 32, LD = PT + 4, F4 = PT / 4;
+  constexpr int NA = M_T * F4 / 256, NB = N_T * F4 / 256;   // float4 per loader thread
+  constexpr int TM = M_T / 64, TN = N_T / 64;               // 32x32 MFMA tiles per compute wave (2 x 2 waves)
+  constexpr int TILE = (M_T + N_T) * LD;
+  static_assert(NA >= 1 && NB >= 1 && TM >= 1 && TN >= 1, "tile too small");
+  extern __shared__ __attribute__((aligned(16))) float wg2_lds[];
+  float* const s_c = wg2_lds + 2 * TILE;        // [5][M_T]: BN scale / shift of this layer, the three BN-backward constants
+  const int lane = lane_id();
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const bool loader = wv >= 4;
+  const int cw = wv & 3, tid = threadIdx.x & 255;
+  const int l31 = lane & 31, half = lane >> 5;
+  const int m0 = blockIdx.y * M_T, n0 = blockIdx.z * N_T;
+  const long long qbeg = (long long)blockIdx.x * split_len;
+  const long long qend = max(qbeg, min(qbeg + (long long)split_len, total));
+  const int nchunks = (int)((qend - qbeg) / PT);
+  const bool has_bn = in_scale != nullptr;
+  for (int c = threadIdx.x; c < M_T; c += kMidThreads) {
+    const int ch = min(m0 + c, cout - 1);
+    s_c[c] = bn[ch]; s_c[M_T + c] = bn[cout + ch];
+    s_c[2 * M_T + c] = bwdc[ch]; s_c[3 * M_T + c] = bwdc[cout + ch]; s_c[4 * M_T + c] = bwdc[2 * cout + ch];
+  }
+  __syncthreads();
+  if (loader) {
+    float4 ry[2][NA], rx[2][NB];
+    float4 rd[2][POOLED ? 1 : NA];
+    float rpv[2][POOLED ? NA : 1];
+    int rarg[2][POOLED ? NA : 1];
+    auto load_chunk = [&](int set, long long qk) {
+      int b, pk;
+      split_point(qk, P, b, pk);
+#pragma unroll
+      for (int i = 0; i < NA; ++i) {
+        const int e = tid + 256 * i, row = min(m0 + e / F4, cout - 1), p = pk + (e % F4) * 4;
+        const size_t rowo = (size_t)b * cout + row;
+        ry[set][i] = *reinterpret_cast<const float4*>(y + rowo * (size_t)P + p);
+        if (POOLED) {
+          const int G = P / gs.S, g = p / gs.S;
+          rpv[set][i] = pooled_at(gs, b, row, G, g);
+          rarg[set][i] = gs.arg[rowo * (size_t)G + g];
+        } else {
+          rd[set][i] = *reinterpret_cast<const float4*>(gs.dense + rowo * (size_t)P + p);
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < NB; ++i) {
+        const int e = tid + 256 * i, row = min(n0 + e / F4, cin - 1), p = pk + (e % F4) * 4;
+        rx[set][i] = *reinterpret_cast<const float4*>(x + ((size_t)b * cin + row) * P + p);
+      }
+    };
+    auto store_chunk = [&](int set, float* buf, long long qk) {
+      float* As = buf;
+      float* Bs = buf + M_T * LD;
+      int pk = 0;
+      if (POOLED) {
+        int b_unused;
+        split_point(qk, P, b_unused, pk);
+      }
+#pragma unroll
+      for (int i = 0; i < NA; ++i) {
+        const int e = tid + 256 * i, row = e / F4, k = (e % F4) * 4;
+        const float rs = s_c[row], rh = s_c[M_T + row], rca = s_c[2 * M_T + row], rcb = s_c[3 * M_T + row],
+                    rcc = s_c[4 * M_T + row];
+        float4 d;
+        if (POOLED) {
+          const int ks = (pk + k) % gs.S, a = rarg[set][i];
+          const float pv = rpv[set][i];
+          d = make_float4(a == ks ? pv : 0.f, a == ks + 1 ? pv : 0.f, a == ks + 2 ? pv : 0.f, a == ks + 3 ? pv : 0.f);
+        } else {
+          d = rd[set][i];
+        }
+        const float4 yv = ry[set][i];
+        float4 v;
+        v.x = rca * ((yv.x * rs + rh > 0.f) ? d.x : 0.f) + rcb + rcc * yv.x;
+        v.y = rca * ((yv.y * rs + rh > 0.f) ? d.y : 0.f) + rcb + rcc * yv.y;
+        v.z = rca * ((yv.z * rs + rh > 0.f) ? d.z : 0.f) + rcb + rcc * yv.z;
+        v.w = rca * ((yv.w * rs + rh > 0.f) ? d.w : 0.f) + rcb + rcc * yv.w;
+        if (m0 + row >= cout) v = zero4();
+        *reinterpret_cast<float4*>(&As[row * LD + k]) = v;
+      }
+#pragma unroll
+      for (int i = 0; i < NB; ++i) {
+        const int e = tid + 256 * i, row = e / F4, k = (e % F4) * 4;
+        float4 v = rx[set][i];
+        if (has_bn) {
+          const int ch = min(n0 + row, cin - 1);
+          v = bn_relu4(v, in_scale[ch], in_shift[ch]);
+        }
+        if (n0 + row >= cin) v = zero4();
+        *reinterpret_cast<float4*>(&Bs[row * LD + k]) = v;
+      }
+    };
+    if (nchunks > 0) load_chunk(0, qbeg);
+    if (nchunks > 1) load_chunk(1, qbeg + PT);
+    for (int t = 0; t < nchunks; t += 2) {
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        if (t + u < nchunks) {
+          const long long qk = qbeg + (long long)(t + u) * PT;
+          store_chunk(u, wg2_lds + u * TILE, qk);
+          if (t + u + 2 < nchunks) load_chunk(u, qk + 2 * PT);
+          lds_barrier();
+        }
+      }
+    }
+    return;
+  }
+  // ---------------- compute waves ----------------
+  const int wm = cw >> 1, wn = cw & 1;
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[tm][tn][r] = 0.f;
+  for (int t = 0; t < nchunks; ++t) {
+    lds_barrier();
+    const float* buf = wg2_lds + (t & 1) * TILE;
+    const float* ap = buf + (32 * wm * TM + l31) * LD + 4 * half;
+    const float* bp = buf + M_T * LD + (32 * wn * TN + l31) * LD + 4 * half;
+    float4 a4[2][TM], b4[2][TN];
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm) a4[0][tm] = *reinterpret_cast<const float4*>(ap + tm * 32 * LD);
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) b4[0][tn] = *reinterpret_cast<const float4*>(bp + tn * 32 * LD);
+#pragma unroll
+    for (int j = 0; j < PT / 8; ++j) {
+      const int cur = j & 1, nxt = cur ^ 1;
+      if (j + 1 < PT / 8) {
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm) a4[nxt][tm] = *reinterpret_cast<const float4*>(ap + tm * 32 * LD + 8 * (j + 1));
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn) b4[nxt][tn] = *reinterpret_cast<const float4*>(bp + tn * 32 * LD + 8 * (j + 1));
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+          for (int tn = 0; tn < TN; ++tn) {
+            const float av = q == 0 ? a4[cur][tm].x : (q == 1 ? a4[cur][tm].y : (q == 2 ? a4[cur][tm].z : a4[cur][tm].w));
+            const float bv = q == 0 ? b4[cur][tn].x : (q == 1 ? b4[cur][tn].y : (q == 2 ? b4[cur][tn].z : b4[cur][tn].w));
+            acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[tm][tn], 0, 0, 0);
+          }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  float* out = dw_part + (size_t)blockIdx.x * cout * cin;
+#pragma unroll
+  for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = m0 + 32 * (wm * TM + tm) + mfma_row(r, lane);
+#pragma unroll
+      for (int tn = 0; tn < TN; ++tn) {
+        const int col = n0 + 32 * (wn * TN + tn) + l31;
+        if (row < cout && col < cin) out[(size_t)row * cin + col] = acc[tm][tn][r];
+      }
+    }
+}
+
+// ============================================================================================
 // wgrad for small layers (cout <= 32 and cin <= 32: SA1, the 32->32 layers of SA2).  The generic kernel
 // would pad the 16x16 .. 32x32 output to a 64x64 tile (16x wasted MFMA, 4x redundant loads).  Here the
 // output is ONE 32x32 MFMA tile and the four waves of a workgroup split K instead of the tile: each wave
@@ -1831,16 +2022,6 @@ __global__ __launch_bounds__(kThreads, ISTNET_BWD_SMALL_WAVES) void pw_bwd_small
 // two workgroups per CU): MFMA phase, loads and the dY arithmetic ran back to back (24 + 10 + 10 us on the 128 -> 128
 // layer of SA4), because every workgroup of the launch is in the same phase at the same time.
 // ============================================================================================
-// Workgroup barrier that orders LDS traffic only.  __syncthreads() is a release / acquire fence pair around s_barrier,
-// and on gfx9 the release waits for vmcnt(0): every global load in flight -- here the loaders' prefetch of the chunk
-// after next -- and every dA store of the compute waves would be drained at each chunk.
-__device__ __forceinline__ void lds_barrier() {
-  __atomic_signal_fence(__ATOMIC_SEQ_CST);
-  __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): this wave's LDS writes have landed; vmcnt / expcnt untouched
-  __builtin_amdgcn_s_barrier();
-  __atomic_signal_fence(__ATOMIC_SEQ_CST);
-}
-constexpr int kMidThreads = 512;
 template <int COT, int CIT>
 struct MidCfg {
   static constexpr int COUT = 32 * COT, CIN = 32 * CIT;
@@ -2244,7 +2425,25 @@ int g_bwd_mid_enable = 1;     // key 9: 0 = those layers run the dgrad / wgrad p
 int g_exp_no_fast = 0;        // experiment (key 6): 1 = never take the interior-tile fast kernels
 inline int wgrad_mt(int cout, long long pts) { return (cout >= 128 && pts > g_wg_small_pts) ? 128 : 64; }
 inline int wgrad_nt(int cin, long long pts) { return (cin >= 96 && pts > g_wg_small_pts) ? 128 : 64; }
+int g_wgrad2_enable = 1;       // key 11: 0 = pw_wgrad_kernel for every dense layer
+int g_wgrad2_target = 256;     // key 12: workgroups of a pw_wgrad2_kernel launch (one per CU)
+inline bool wgrad2_ok(int cin, int cout) {
+  return g_wgrad2_enable && cin >= 64 && cout >= 64 && cin % 32 == 0 && cout % 32 == 0;
+}
+inline int wgrad2_mt(int cout) { return cout >= 128 ? 128 : 64; }
+inline int wgrad2_nt(int cin) { return cin >= 128 ? 128 : 64; }
 inline int wgrad_split_len(int b, int cin, int cout, int P) {
+  if (wgrad2_ok(cin, cout)) {
+    // one workgroup of eight waves per CU: as many splits as keep tiles * splits at or under the target
+    const long long tiles = (long long)ceil_div(cout, wgrad2_mt(cout)) * ceil_div(cin, wgrad2_nt(cin));
+    long long want = g_wgrad2_target / tiles;
+    if (want < 1) want = 1;
+    const long long total = (long long)b * P;
+    long long len = (total + want - 1) / want;
+    len = (len + kKTW - 1) / kKTW * kKTW;
+    if (len < 4 * kKTW) len = 4 * kKTW;
+    return (int)len;
+  }
   // Split-K partials cost cout*cin*4 bytes per split (written here, read back by the reduce): aim for ~1024
   // workgroups when the output is small, ~768 when it is large (PMC: at 1024 the partials of a 128x256
   // layer were as much HBM traffic as its activations; at 256-512 the launch no longer fills the chip).
@@ -2287,6 +2486,7 @@ int istnet_pw_dgrad_tile_cfg(int b, int m, int p) {
 
 int istnet_pw_wgrad_tile_cfg(int b, int cin, int cout, int p) {
   const long long pts = (long long)b * p;
+  if (wgrad2_ok(cin, cout)) return 1000000 + wgrad2_mt(cout) * 1000 + wgrad2_nt(cin);   // pw_wgrad2_kernel (dense input)
   return wgrad_small(cin, cout) ? 32032 : wgrad_mt(cout, pts) * 1000 + wgrad_nt(cin, pts);
 }
 
@@ -2302,6 +2502,8 @@ int istnet_pw_set_tuning(int key, int value) {
     case 7: g_dgrad_min_wgs = value > 0 ? value : 384; return 0;
     case 8: g_bwd_mid_target = value > 0 ? value : 256; return 0;
     case 9: g_bwd_mid_enable = value != 0; return 0;
+    case 11: g_wgrad2_enable = value != 0; return 0;
+    case 12: g_wgrad2_target = value > 0 ? value : 256; return 0;
     default: return ISTNET_PN2_EINVAL;
   }
 }
@@ -2690,6 +2892,35 @@ static int launch_pw_wgrad(bool gather, int b, int cin, int cout, int p, int nsa
     else
       hipLaunchKernelGGL(pw_wgrad_small_kernel<false>, sgrid, dim3(kThreads), 0, as_stream(stream), cin, cout, p,
                          total, len, x, g, in_scale, in_shift, y, gs, bn, bwdc, dw_part);
+    return (int)hipGetLastError();
+  }
+  if (!gather && ncols == nullptr && wgrad2_ok(cin, cout)) {
+    const int mt2 = wgrad2_mt(cout), nt2 = wgrad2_nt(cin);
+    const dim3 grid2(wgrad_splits(b, cin, cout, p), ceil_div(cout, mt2), ceil_div(cin, nt2));
+#define ISTNET_WGRAD2(MT, NT)                                                                                      \
+  do {                                                                                                             \
+    constexpr size_t lds = (2 * (MT + NT) * 36 + 5 * MT) * sizeof(float);                                          \
+    static bool attr_set = false;   /* > 64 KB of LDS per workgroup: opt in once per kernel */                     \
+    if (!attr_set) {                                                                                               \
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(&pw_wgrad2_kernel<MT, NT, false>),                     \
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||              \
+          hipFuncSetAttribute(reinterpret_cast<const void*>(&pw_wgrad2_kernel<MT, NT, true>),                      \
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)                \
+        return ISTNET_PN2_EINVAL;                                                                                  \
+      attr_set = true;                                                                                             \
+    }                                                                                                              \
+    if (d_dense != nullptr)                                                                                        \
+      hipLaunchKernelGGL((pw_wgrad2_kernel<MT, NT, false>), grid2, dim3(kMidThreads), lds, as_stream(stream), cin, \
+                         cout, p, total, len, x, in_scale, in_shift, y, gs, bn, bwdc, dw_part);                    \
+    else                                                                                                           \
+      hipLaunchKernelGGL((pw_wgrad2_kernel<MT, NT, true>), grid2, dim3(kMidThreads), lds, as_stream(stream), cin,  \
+                         cout, p, total, len, x, in_scale, in_shift, y, gs, bn, bwdc, dw_part);                    \
+  } while (0)
+    if (mt2 == 128 && nt2 == 128) ISTNET_WGRAD2(128, 128);
+    else if (mt2 == 128) ISTNET_WGRAD2(128, 64);
+    else if (nt2 == 128) ISTNET_WGRAD2(64, 128);
+    else ISTNET_WGRAD2(64, 64);
+#undef ISTNET_WGRAD2
     return (int)hipGetLastError();
   }
   const int mt = wgrad_mt(cout, total), nt = wgrad_nt(cin, total);

@@ -46,10 +46,15 @@ def _note_fallback(reason):
                       RuntimeWarning, stacklevel=3)
 
 
-def _kname(base, cfg, gather=None):
+def _kname(base, cfg, gather=None, pooled=False):
     """Kernel symbol as rocprofv3 prints it, e.g. pw_dgrad_kernel<64, 64, 2, 2> or pw_fwd_kernel<128, 128, 2, 2, 0>.
     ``gather``: None for kernels without the template parameter, else the operand-loader mode (0 tensor input,
     1 channel-major gather, 2 point-major gather; a bool counts as 0 / 1)."""
+    if cfg >= 1000000:       # istnet_pw_wgrad_tile_cfg: the role-split kernel takes dense-input layers of this shape
+        cfg -= 1000000
+        if base == "pw_wgrad_kernel" and not gather:
+            return f"pw_wgrad2_kernel<{cfg // 1000}, {cfg % 1000}, {'true' if pooled else 'false'}>"
+        cfg = 64064          # gathered input: pw_wgrad_kernel with its 64 x 64 tiles
     mt, nt = cfg // 1000, cfg % 1000
     if base == "pw_wgrad_kernel" and mt == 32:
         return "pw_wgrad_small_kernel<%s>" % ("true" if gather else "false")
@@ -462,7 +467,7 @@ def _wgrad_job(lib, dev, b, cin, cout, p, ns_arg, use_gather, ga, src, in_bn, y,
         dw = _grad_dest(wparam, (cout, cin), dev)
         kname = _kname("pw_wgrad_kernel", lib.istnet_pw_wgrad_tile_cfg(b, cin, cout, p),
                        (_gather_mode(ga, 4) if lib.istnet_pw_wgrad_tile_cfg(b, cin, cout, p) // 1000 != 32 else use_gather)
-                       if use_gather else 0)
+                       if use_gather else 0, pooled=d_dense is None)
         flops = 2.0 * b * p * cin * cout
         dd, dp, da = _p(d_dense), _p(d_pooled), _p(d_arg)
         if use_gather:

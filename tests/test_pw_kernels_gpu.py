@@ -151,6 +151,52 @@ def test_bwd_mid_equals_dgrad_plus_wgrad(cin, cout, p, pooled):
     torch.testing.assert_close(part2[0].to(d).sum(-1), gq.sum(dim=(0, 2)), rtol=1e-4, atol=2e-3)
 
 
+@pytest.mark.parametrize("cin,cout,p,pooled,has_bn", [(320, 256, 512, False, True), (128, 256, 1024, True, True),
+                                                      (64, 64, 256, False, False), (768, 512, 128, False, True),
+                                                      (96, 160, 384, True, True)])
+def test_wgrad_role_split_kernel(cin, cout, p, pooled, has_bn):
+    """pw_wgrad2_kernel (dense input, cin and cout >= 64): split-K partials against a float64 product, with partial
+    tiles, both gradient sources, with / without an input BN block; the old kernel (tuning key 11 = 0) gives the same
+    weight gradient."""
+    lib = _native.lib()
+    b, s = 3, 16
+    g = torch.Generator().manual_seed(cin + cout + p)
+    x = torch.randn(b, cin, p, generator=g).to(DEV)
+    y = torch.randn(b, cout, p, generator=g).to(DEV)
+    bn, bn_in = _bn_block(cout, g), _bn_block(cin, g)
+    bwdc = torch.stack([torch.rand(cout, generator=g) + 0.5, torch.randn(cout, generator=g) * 0.01,
+                        torch.randn(cout, generator=g) * 0.01]).contiguous().to(DEV)
+    if pooled:
+        gr = p // s
+        dpool = torch.randn(b, cout, gr, generator=g).to(DEV)
+        arg = torch.randint(0, s, (b, cout, gr), generator=g, dtype=torch.uint8).to(DEV)
+        src = (None, dpool.data_ptr(), 0, arg.data_ptr())
+        gdense = torch.zeros(b, cout, gr, s, device=DEV).scatter_(3, arg.long().unsqueeze(-1), dpool.unsqueeze(-1)).reshape(b, cout, p)
+    else:
+        gdense = torch.randn(b, cout, p, generator=g).to(DEV)
+        src = (gdense.data_ptr(), None, 0, None)
+    d = torch.float64
+    mask = (y * bn[0].view(1, -1, 1) + bn[1].view(1, -1, 1)) > 0
+    dy = bwdc[0].to(d).view(1, -1, 1) * (gdense.to(d) * mask) + bwdc[1].to(d).view(1, -1, 1) + bwdc[2].to(d).view(1, -1, 1) * y.to(d)
+    act = torch.relu(x * bn_in[0].view(1, -1, 1) + bn_in[1].view(1, -1, 1)).to(d) if has_bn else x.to(d)
+    want = torch.einsum("bop,bip->oi", dy, act)
+    sc, sh = (bn_in[0].data_ptr(), bn_in[1].data_ptr()) if has_bn else (None, None)
+    got = []
+    for enable in (1, 0):
+        assert lib.istnet_pw_set_tuning(11, enable) == 0
+        try:
+            splits = lib.istnet_pw_wgrad_splits(b, cin, cout, p)
+            ws = torch.full((splits, cout, cin), float("nan"), device=DEV)
+            assert lib.istnet_pw_wgrad(b, cin, cout, p, s if pooled else 0, x.data_ptr(), sc, sh, y.data_ptr(), *src,
+                                       bn.data_ptr(), bwdc.data_ptr(), ws.data_ptr(), _st()) == 0
+            got.append(ws.to(d).sum(0))
+        finally:
+            lib.istnet_pw_set_tuning(11, 1)
+    tol = dict(rtol=1e-5, atol=2e-5 * (b * p) ** 0.5)
+    torch.testing.assert_close(got[0], want, **tol)
+    torch.testing.assert_close(got[1], want, **tol)
+
+
 def test_forward_acc_channel_stats_and_dy():
     lib = _native.lib()
     b, cin, cout, p = 2, 24, 40, 256
