@@ -11,7 +11,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libistnet_pn2.so")
 INCLUDE_DIR = os.path.join(_HERE, "..", "include")
 HEADER_PATH = os.path.join(INCLUDE_DIR, "istnet_pn2.h")
 HEADER_PATHS = [HEADER_PATH, os.path.join(INCLUDE_DIR, "istnet_pw.h"), os.path.join(INCLUDE_DIR, "istnet_preproc.h"),
-                os.path.join(INCLUDE_DIR, "istnet_optim.h")]
+                os.path.join(INCLUDE_DIR, "istnet_optim.h"), os.path.join(INCLUDE_DIR, "istnet_rgb.h")]
 ABI_VERSION = 1
 
 _i, _f, _p, _d, _l = ctypes.c_int, ctypes.c_float, ctypes.c_void_p, ctypes.c_double, ctypes.c_longlong
@@ -23,6 +23,9 @@ SIGNATURES = {
     "istnet_pw_scatter_csr_chunks": [_i],
     "istnet_pw_scatter_dy_csr": [_i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _l, _p, _p, _i, _p, _p],
     "istnet_adam_step": [_l, _p, _p, _p, _p, _p, _p, _d, _d, _d, _d, _d, _d, _p],
+    "istnet_prelu_bwd_parts": [_l],
+    "istnet_prelu_bwd": [_l, _p, _p, _p, _p, _p, _p],
+    "istnet_upsample_bilinear_ac_bwd_nhwc": [_i, _i, _i, _i, _i, _i, _p, _p, _p],
     "istnet_backproject_choose": [_i, _i, _i, _i, _p, _i, _l, _p, _p, _d, _d, _d, _d, _d, _i, _p, _p, _p],
     "istnet_pn2_set_tuning": [_i, _i],
     "istnet_pn2_furthest_point_sampling": [_i, _i, _i, _p, _p, _p, _p],

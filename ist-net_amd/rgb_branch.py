@@ -20,6 +20,86 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 
+USE_NATIVE_DECODER_BACKWARD = True   # False: the framework's own backward of PReLU / bilinear upsample
+
+
+class _PReLUFn(torch.autograd.Function):
+    """nn.PReLU() with one slope: the framework's forward, include/istnet_rgb.h's backward (one streaming pass, partial
+    sums of the slope gradient in a fixed order).  The framework's backward kernel walks the tensor with per-element
+    stride arithmetic and ran at 0.35 TB/s on the decoder's channels-last maps -- 24 % of the branch's training step
+    (profiles/r02_rgb_branch_breakdown.txt)."""
+
+    @staticmethod
+    def forward(ctx, x, weight):
+        ctx.save_for_backward(x, weight)
+        return F.prelu(x, weight)
+
+    @staticmethod
+    def backward(ctx, dy):
+        from . import _native
+        x, weight = ctx.saved_tensors
+        fmt = torch.channels_last if (x.dim() == 4 and x.is_contiguous(memory_format=torch.channels_last)
+                                      and not x.is_contiguous()) else torch.contiguous_format
+        x = x.contiguous(memory_format=fmt)
+        dy = dy.contiguous(memory_format=fmt)
+        dx = torch.empty_like(x, memory_format=fmt)
+        lib = _native.lib()
+        n = x.numel()
+        part = torch.empty(lib.istnet_prelu_bwd_parts(n), dtype=torch.float32, device=x.device)
+        with torch.cuda.device(x.device):
+            _native.check(lib.istnet_prelu_bwd(n, x.data_ptr(), dy.data_ptr(), weight.data_ptr(), dx.data_ptr(),
+                                               part.data_ptr(), torch.cuda.current_stream(x.device).cuda_stream),
+                          "prelu_bwd")
+        return dx, part.sum().reshape(weight.shape)
+
+
+class PReLU(nn.PReLU):
+    """nn.PReLU (same parameter, same state-dict key) with the native backward on the GPU."""
+
+    def forward(self, x):
+        if (USE_NATIVE_DECODER_BACKWARD and x.is_cuda and x.dtype == torch.float32 and self.weight.numel() == 1
+                and torch.is_grad_enabled() and (x.requires_grad or self.weight.requires_grad)):
+            return _PReLUFn.apply(x, self.weight)
+        return super().forward(x)
+
+
+class _UpsampleAlignedFn(torch.autograd.Function):
+    """Bilinear upsample with align_corners=True on a channels-last map: the framework's forward, a gather-form backward
+    (every input pixel sums its weighted output pixels: no atomics, so the step stays bit-reproducible)."""
+
+    @staticmethod
+    def forward(ctx, x, size):
+        ctx.in_shape = tuple(x.shape)
+        return F.interpolate(x, size=size, mode="bilinear", align_corners=True)
+
+    @staticmethod
+    def backward(ctx, dy):
+        from . import _native
+        b, c, hin, win = ctx.in_shape
+        dy = dy.contiguous(memory_format=torch.channels_last)
+        dx = torch.empty(ctx.in_shape, dtype=dy.dtype, device=dy.device, memory_format=torch.channels_last)
+        with torch.cuda.device(dy.device):
+            _native.check(_native.lib().istnet_upsample_bilinear_ac_bwd_nhwc(
+                b, c, hin, win, dy.shape[2], dy.shape[3], dy.data_ptr(), dx.data_ptr(),
+                torch.cuda.current_stream(dy.device).cuda_stream), "upsample_bilinear_ac_bwd_nhwc")
+        return dx, None
+
+
+class Upsample2x(nn.Upsample):
+    """nn.Upsample(scale_factor=2, mode="bilinear", align_corners=True) with the native backward for channels-last
+    float32 maps on the GPU."""
+
+    def __init__(self):
+        super().__init__(scale_factor=2, mode="bilinear", align_corners=True)
+
+    def forward(self, x):
+        if (USE_NATIVE_DECODER_BACKWARD and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4
+                and x.shape[1] % 4 == 0 and x.shape[2] > 1 and x.shape[3] > 1 and torch.is_grad_enabled()
+                and x.requires_grad and x.is_contiguous(memory_format=torch.channels_last)):
+            return _UpsampleAlignedFn.apply(x, (2 * x.shape[2], 2 * x.shape[3]))
+        return super().forward(x)
+
+
 def _conv3x3(cin, cout, stride=1, dilation=1):
     return nn.Conv2d(cin, cout, kernel_size=3, stride=stride, padding=dilation, dilation=dilation, bias=False)
 
@@ -111,9 +191,8 @@ class PSPModule(nn.Module):
 class PSPUpsample(nn.Module):
     def __init__(self, in_channels, out_channels):
         super().__init__()
-        self.conv = nn.Sequential(nn.Upsample(scale_factor=2, mode="bilinear", align_corners=True),
-                                  nn.Conv2d(in_channels, out_channels, 3, padding=1),
-                                  nn.BatchNorm2d(out_channels), nn.PReLU())
+        self.conv = nn.Sequential(Upsample2x(), nn.Conv2d(in_channels, out_channels, 3, padding=1),
+                                  nn.BatchNorm2d(out_channels), PReLU())
 
     def forward(self, x):
         return self.conv(x)
@@ -131,7 +210,7 @@ class Modified_PSPNet(nn.Module):
         self.up_2 = PSPUpsample(256, 64)
         self.up_3 = PSPUpsample(64, 64)
         self.drop_2 = nn.Dropout2d(p=0.15)
-        self.final = nn.Sequential(nn.Conv2d(64, 128, kernel_size=1), nn.BatchNorm2d(128), nn.PReLU())
+        self.final = nn.Sequential(nn.Conv2d(64, 128, kernel_size=1), nn.BatchNorm2d(128), PReLU())
 
     def forward(self, x, choose=None):
         """rgb (B,3,H,W) -> (B,128,H,W); with ``choose`` (B,N) flat pixel indices in eval mode -> (B,128,N), the

@@ -1,0 +1,101 @@
+"""include/istnet_rgb.h: the native backward of the RGB decoder's PReLU and aligned bilinear upsample against the
+framework's own autograd (reference modules: model/modules.py:36-49 PSPUpsample, :64-68 final)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+import istnet_amd  # noqa: F401
+from istnet_amd import rgb_branch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+@pytest.mark.parametrize("shape,channels_last", [((2, 64, 24, 24), True), ((3, 128, 17, 9), True), ((2, 8, 5, 7), False),
+                                                 ((5, 1031), False)])
+def test_prelu_backward_matches_autograd(shape, channels_last):
+    g = torch.Generator().manual_seed(sum(shape))
+    x = torch.randn(shape, generator=g).to(DEV)
+    dy = torch.randn(shape, generator=g).to(DEV)
+    if channels_last:
+        x, dy = x.contiguous(memory_format=torch.channels_last), dy.contiguous(memory_format=torch.channels_last)
+    act = rgb_branch.PReLU().to(DEV)
+    with torch.no_grad():
+        act.weight.fill_(0.3)
+    xa = x.clone().requires_grad_(True)
+    ya = act(xa)
+    assert ya.grad_fn is not None and "PReLUFn" in type(ya.grad_fn).__name__
+    ya.backward(dy)
+    xb = x.clone().requires_grad_(True)
+    wb = act.weight.detach().clone().requires_grad_(True)
+    yb = F.prelu(xb, wb)
+    yb.backward(dy)
+    assert torch.equal(ya, yb)
+    assert torch.equal(xa.grad, xb.grad)
+    torch.testing.assert_close(act.weight.grad, wb.grad, rtol=1e-5, atol=1e-4)
+    # deterministic slope gradient
+    act.weight.grad = None
+    xc = x.clone().requires_grad_(True)
+    act(xc).backward(dy)
+    w1 = act.weight.grad.clone()
+    act.weight.grad = None
+    xd = x.clone().requires_grad_(True)
+    act(xd).backward(dy)
+    assert torch.equal(w1, act.weight.grad)
+
+
+@pytest.mark.parametrize("b,c,h,w", [(2, 64, 24, 24), (1, 8, 7, 13), (3, 256, 12, 12), (2, 4, 2, 2)])
+def test_aligned_upsample_backward_matches_autograd(b, c, h, w):
+    g = torch.Generator().manual_seed(b + c + h + w)
+    x = torch.randn(b, c, h, w, generator=g).to(DEV).contiguous(memory_format=torch.channels_last)
+    dy = torch.randn(b, c, 2 * h, 2 * w, generator=g).to(DEV).contiguous(memory_format=torch.channels_last)
+    up = rgb_branch.Upsample2x()
+    xa = x.clone(memory_format=torch.preserve_format).requires_grad_(True)
+    ya = up(xa)
+    assert "UpsampleAlignedFn" in type(ya.grad_fn).__name__
+    ya.backward(dy)
+    xb = x.clone(memory_format=torch.preserve_format).requires_grad_(True)
+    yb = F.interpolate(xb, scale_factor=2, mode="bilinear", align_corners=True)
+    yb.backward(dy)
+    assert torch.equal(ya, yb)
+    torch.testing.assert_close(xa.grad, xb.grad, rtol=1e-5, atol=1e-5)
+    # the gradient of sum(y) is the column sum of the interpolation matrix: every output pixel's weights sum to 1
+    xs = x.clone(memory_format=torch.preserve_format).requires_grad_(True)
+    up(xs).sum().backward()
+    torch.testing.assert_close(xs.grad.sum(dim=(2, 3)), torch.full((b, c), 4.0 * h * w, device=DEV), rtol=1e-5, atol=1e-3)
+
+
+def test_decoder_modules_keep_reference_state_dict_keys():
+    net = rgb_branch.ModifiedResnet()
+    keys = set(net.state_dict())
+    for k in ("model.up_1.conv.1.weight", "model.up_1.conv.3.weight", "model.up_3.conv.2.running_mean",
+              "model.final.2.weight", "model.final.0.bias"):
+        assert k in keys
+    assert not any(".conv.0." in k for k in keys)      # the upsample has no parameters or buffers
+
+
+def test_native_decoder_backward_equals_framework_backward():
+    """Whole branch, small input: same output, parameter gradients within fp32 round-off of the framework's backward."""
+    torch.manual_seed(0)
+    net = rgb_branch.ModifiedResnet().to(DEV).train().to(memory_format=torch.channels_last)
+    for m in net.modules():
+        if isinstance(m, torch.nn.Dropout2d):
+            m.p = 0.0
+    x = torch.randn(2, 3, 64, 64, device=DEV).contiguous(memory_format=torch.channels_last)
+    grads = []
+    for native in (True, False):
+        rgb_branch.USE_NATIVE_DECODER_BACKWARD = native
+        try:
+            net.zero_grad(set_to_none=True)
+            out = net(x)
+            out.square().mean().backward()
+            grads.append((out.detach().clone(), {k: p.grad.clone() for k, p in net.named_parameters() if p.grad is not None}))   # (avgpool / fc of the trunk are unused)
+        finally:
+            rgb_branch.USE_NATIVE_DECODER_BACKWARD = True
+    torch.testing.assert_close(grads[0][0], grads[1][0], rtol=1e-4, atol=1e-4)   # (MIOpen may pick another algorithm on the second pass)
+    assert len(grads[0][1]) == len(grads[1][1]) > 60
+    worst = max(((float((grads[0][1][k] - grads[1][1][k]).norm() / (grads[1][1][k].norm() + 1e-12)), k) for k in grads[0][1]))
+    # conv biases in front of a train-mode BatchNorm have a mathematically zero gradient (round-off only): not compared
+    rel = {k: float((grads[0][1][k] - grads[1][1][k]).norm() / (grads[1][1][k].norm() + 1e-12)) for k in grads[0][1]
+           if not (k.endswith(".bias") and float(grads[1][1][k].norm()) < 1e-4)}
+    assert max(rel.values()) < 2e-3, (worst, sorted(rel.items(), key=lambda kv: -kv[1])[:5])
