@@ -45,6 +45,13 @@ ISTNET_PN2_API int istnet_pw_stat_tiles(int b, int cout, int p);
 ISTNET_PN2_API int istnet_pw_forward(int b, int cin, int cout, int p, const float *x, const float *w,
                                      const float *in_scale, const float *in_shift, float *y,
                                      float *part_sum, float *part_sq, void *stream);
+/* istnet_pw_forward takes the direct-operand kernel (pw_fwd2_kernel: the activation operand goes from global memory to
+ * the MFMA without an LDS tile) when cin % 16 == 0, cin <= 1024, p % 128 == 0 and cout >= 16 (istnet_pw_set_tuning
+ * key 13 = 0 disables it).  istnet_pw_forward_tiles = number of statistics partials per channel that launch writes
+ * (istnet_pw_stat_tiles for the other forward entry points); istnet_pw_forward_cfg = 0 for pw_fwd_kernel, else
+ * TMW * 1000 + WM * 100 + WN * 10 + (K chunk == 32) of the pw_fwd2_kernel instance (for reporting). */
+ISTNET_PN2_API int istnet_pw_forward_tiles(int b, int cin, int cout, int p);
+ISTNET_PN2_API int istnet_pw_forward_cfg(int b, int cin, int cout, int p);
 
 /* istnet_pw_forward with w a column slice of a wider row-major matrix: row stride ldw >= cin */
 ISTNET_PN2_API int istnet_pw_forward_ld(int b, int cin, int cout, int p, const float *x, const float *w, int ldw,

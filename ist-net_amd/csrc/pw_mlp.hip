@@ -426,6 +426,142 @@ __global__ __launch_bounds__(kThreads) void pw_fwd_kernel(
 }
 
 // ============================================================================================
+// forward, dense input, cin % 16 == 0, P % 128 == 0 (every layer after the first of a stack): the B operand never
+// touches LDS.  In  y[co][p] = sum_ci w[co][ci] act(x[ci][p])  the points are the N index and contiguous in memory, and
+// N is only a LABEL of the MFMA's columns: a lane loads a float4 of FOUR consecutive points of row ci = 2 kk + half
+// (one global_load_dwordx4; the 32 lanes of a half cover 512 contiguous bytes of the row) and uses element q as the
+// B operand of MFMA q, whose 32 columns are then the points {4 l + q}.  So one load feeds 4 x TMW MFMAs, the accumulators
+// of q = 0..3 hold four consecutive points of an output row, and y leaves as float4 stores of 512 contiguous bytes per
+// row.  Only the weights go through LDS (k-major, shared by the four waves, double-buffered in K chunks).  Per k-step
+// and wave: 1 global load, TMW ds_read_b32, 8 VALU (BatchNorm + ReLU of the previous layer on the loaded values) and
+// 4 TMW MFMAs -- the LDS-tiled kernel above needs 2 ds_read_b32 per MFMA at its 64 x 64 tiles.
+// Wave tile: 32 TMW rows x 128 points; WM x WN waves per workgroup; grid (tiles_per_cloud * B, ceil(cout / M_WG)).
+// ============================================================================================
+template <int TMW, int WM, int WN, int KC>
+__global__ __launch_bounds__(kThreads, 2) void pw_fwd2_kernel(
+    int cin, int cout, int P, int tiles_per_cloud, const float* __restrict__ x, const float* __restrict__ w,
+    const float* __restrict__ in_scale, const float* __restrict__ in_shift, float* __restrict__ y,
+    float* __restrict__ part_sum, float* __restrict__ part_sq, int nt_total) {
+  static_assert(WM * WN == 4 && (KC == 16 || KC == 32), "4 waves; K chunk of 16 or 32 channels");
+  constexpr int M_WG = 32 * TMW * WM, N_WG = 128 * WN;
+  constexpr int LDA = M_WG + 1;                 // odd: the transposed scalar stores of a weight chunk spread over the banks
+  constexpr int NA = KC * M_WG / kThreads;      // weight elements per thread per chunk
+  constexpr int DEPTH = 8;                      // k-steps of B loads in flight per wave
+  constexpr int kMaxCin = 1024;
+  static_assert(NA >= 1 && (KC / 2) % DEPTH == 0, "chunk too small");
+  __shared__ float As[2][KC][LDA];
+  __shared__ float s_in[2][kMaxCin];            // scale / shift of the input layer's BatchNorm (host: cin <= kMaxCin)
+  const int tid = threadIdx.x, lane = lane_id(), wv = wave_id();
+  const int l31 = lane & 31, half = lane >> 5;
+  const int b = blockIdx.x / tiles_per_cloud;
+  const int p0 = (blockIdx.x - b * tiles_per_cloud) * N_WG + (wv % WN) * 128;   // this wave's 128 points
+  const int m0 = blockIdx.y * M_WG, a_col0 = (wv / WN) * 32 * TMW;
+  const bool has_bn = in_scale != nullptr;
+  const bool live = p0 < P;                     // P % 128 == 0: a wave's tile is all inside or all outside the cloud
+  const float* xb = x + (size_t)b * cin * P + (live ? p0 : 0) + 4 * l31;
+  if (has_bn)
+    for (int c = tid; c < cin; c += kThreads) { s_in[0][c] = in_scale[c]; s_in[1][c] = in_shift[c]; }
+
+  float areg[NA];
+  auto load_a = [&](int k0) {
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+      const int e = tid + kThreads * i;
+      areg[i] = w[(size_t)min(m0 + e / KC, cout - 1) * cin + k0 + e % KC];
+    }
+  };
+  auto store_a = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+      const int e = tid + kThreads * i;
+      As[buf][e % KC][e / KC] = (m0 + e / KC < cout) ? areg[i] : 0.f;
+    }
+  };
+  const int ksteps = cin / 2;
+  float4 ring[DEPTH];
+#pragma unroll
+  for (int i = 0; i < DEPTH; ++i)
+    if (i < ksteps) ring[i] = *reinterpret_cast<const float4*>(xb + (size_t)(2 * i + half) * P);
+
+  f32x16 acc[TMW][4];
+#pragma unroll
+  for (int tm = 0; tm < TMW; ++tm)
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[tm][q][r] = 0.f;
+
+  const int nchunks = cin / KC;
+  load_a(0);
+  store_a(0);
+  __syncthreads();
+  for (int t = 0; t < nchunks; ++t) {
+    const int buf = t & 1;
+    if (t + 1 < nchunks) load_a((t + 1) * KC);
+    const float* ap = &As[buf][half][a_col0 + l31];
+    float a[2][TMW];
+#pragma unroll
+    for (int tm = 0; tm < TMW; ++tm) a[0][tm] = ap[tm * 32];
+#pragma unroll
+    for (int kk = 0; kk < KC / 2; ++kk) {
+      const int g = t * (KC / 2) + kk, cur = kk & 1, nxt = cur ^ 1;
+      float4 bv = ring[kk % DEPTH];
+      if (g + DEPTH < ksteps) ring[kk % DEPTH] = *reinterpret_cast<const float4*>(xb + (size_t)(2 * (g + DEPTH) + half) * P);
+      if (has_bn) bv = bn_relu4(bv, s_in[0][2 * g + half], s_in[1][2 * g + half]);
+      if (kk + 1 < KC / 2) {
+#pragma unroll
+        for (int tm = 0; tm < TMW; ++tm) a[nxt][tm] = ap[(2 * kk + 2) * LDA + tm * 32];
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int tm = 0; tm < TMW; ++tm) {
+        acc[tm][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][tm], bv.x, acc[tm][0], 0, 0, 0);
+        acc[tm][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][tm], bv.y, acc[tm][1], 0, 0, 0);
+        acc[tm][2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][tm], bv.z, acc[tm][2], 0, 0, 0);
+        acc[tm][3] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][tm], bv.w, acc[tm][3], 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (t + 1 < nchunks) store_a(buf ^ 1);
+    lds_barrier();
+  }
+  // ---- epilogue: register r of accumulator (tm, q) is output row 32 tm + mfma_row(r, lane), point 4 l31 + q ----
+  float* red = &As[0][0][0];      // [WN][M_WG][2]; the loop ended on a barrier
+  float* yb = y + (size_t)b * cout * P + (live ? p0 : 0) + 4 * l31;
+#pragma unroll
+  for (int tm = 0; tm < TMW; ++tm)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row_l = a_col0 + 32 * tm + mfma_row(r, lane), row = m0 + row_l;
+      const float4 v = make_float4(acc[tm][0][r], acc[tm][1][r], acc[tm][2][r], acc[tm][3][r]);
+      if (live && row < cout) *reinterpret_cast<float4*>(yb + (size_t)row * P) = v;
+      if (part_sum != nullptr) {
+        float s = live ? (v.x + v.y) + (v.z + v.w) : 0.f;
+        float q = live ? (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w) : 0.f;
+        s = half_wave_sum(s);
+        q = half_wave_sum(q);
+        if (l31 == 31) {
+          red[((wv % WN) * M_WG + row_l) * 2 + 0] = s;
+          red[((wv % WN) * M_WG + row_l) * 2 + 1] = q;
+        }
+      }
+    }
+  if (part_sum != nullptr) {
+    __syncthreads();
+    for (int rl = tid; rl < M_WG; rl += kThreads) {
+      const int row = m0 + rl;
+      if (row < cout) {
+        float s = 0.f, q = 0.f;
+#pragma unroll
+        for (int wn = 0; wn < WN; ++wn) { s += red[(wn * M_WG + rl) * 2 + 0]; q += red[(wn * M_WG + rl) * 2 + 1]; }
+        part_sum[(size_t)row * nt_total + blockIdx.x] = s;
+        part_sq[(size_t)row * nt_total + blockIdx.x] = q;
+      }
+    }
+  }
+}
+
+// ============================================================================================
 // Layer 0 of a set-abstraction scale, split by linearity.  The grouped input of point p is
 // [xyz[idx[p]] - centre(p) ; feat[:, idx[p]]], so
 //     y0[:, p] = W0x . (xyz[idx[p]] - centre(p)) + (W0f . feat)[:, idx[p]].
@@ -2065,33 +2201,39 @@ __global__ __launch_bounds__(kMidThreads) void pw_bwd_mid_kernel(
   }
 
   // ---------------- loader state ----------------
-  float4 ry[2][NY], rx[2][NX];
-  float4 rd[2][POOLED ? 1 : NY];
-  float rpv[2][POOLED ? NY : 1];
-  int rarg[2][POOLED ? NY : 1];
-  auto load_chunk = [&](int set, long long qk) {
+  // two register sets of raw loads, passed to the lambdas BY NAME: as one array indexed by the set number they ended
+  // up in scratch memory, and a kernel with a scratch segment does not share the chip with kernels of other streams
+  // (measured, tools/exp/corun.py: a 128-workgroup finalize kernel took 60 us instead of 8 beside this one)
+  struct Raw {
+    float4 y[NY], x[NX];
+    float4 d[POOLED ? 1 : NY];
+    float pv[POOLED ? NY : 1];
+    int arg[POOLED ? NY : 1];
+  };
+  Raw raw0, raw1;
+  auto load_chunk = [&](Raw& rw, long long qk) {
     int b, pk;
     split_point(qk, P, b, pk);
 #pragma unroll
     for (int i = 0; i < NY; ++i) {
       const int e = tid + 256 * i, row = e / F4, p = pk + (e % F4) * 4;
       const size_t rowo = (size_t)b * COUT + row;
-      ry[set][i] = *reinterpret_cast<const float4*>(y + rowo * (size_t)P + p);
+      rw.y[i] = *reinterpret_cast<const float4*>(y + rowo * (size_t)P + p);
       if (POOLED) {
         const int G = P / gs.S, g = p / gs.S;
-        rpv[set][i] = pooled_at(gs, b, row, G, g);
-        rarg[set][i] = gs.arg[rowo * (size_t)G + g];
+        rw.pv[i] = pooled_at(gs, b, row, G, g);
+        rw.arg[i] = gs.arg[rowo * (size_t)G + g];
       } else {
-        rd[set][i] = *reinterpret_cast<const float4*>(gs.dense + rowo * (size_t)P + p);
+        rw.d[i] = *reinterpret_cast<const float4*>(gs.dense + rowo * (size_t)P + p);
       }
     }
 #pragma unroll
     for (int i = 0; i < NX; ++i) {
       const int e = tid + 256 * i, row = e / F4, p = pk + (e % F4) * 4;
-      rx[set][i] = *reinterpret_cast<const float4*>(x + ((size_t)b * CIN + row) * P + p);
+      rw.x[i] = *reinterpret_cast<const float4*>(x + ((size_t)b * CIN + row) * P + p);
     }
   };
-  auto store_chunk = [&](int set, float* buf, long long qk) {
+  auto store_chunk = [&](const Raw& rw, float* buf, long long qk) {
     float* dYs = buf;
     float* Xs = buf + COUT * LD;
     int pk = 0;
@@ -2106,13 +2248,13 @@ __global__ __launch_bounds__(kMidThreads) void pw_bwd_mid_kernel(
                   rcc = s_c[4 * COUT + row];
       float4 d;
       if (POOLED) {
-        const int ks = (pk + k) % gs.S, a = rarg[set][i];
-        const float pv = rpv[set][i];
+        const int ks = (pk + k) % gs.S, a = rw.arg[i];
+        const float pv = rw.pv[i];
         d = make_float4(a == ks ? pv : 0.f, a == ks + 1 ? pv : 0.f, a == ks + 2 ? pv : 0.f, a == ks + 3 ? pv : 0.f);
       } else {
-        d = rd[set][i];
+        d = rw.d[i];
       }
-      const float4 yv = ry[set][i];
+      const float4 yv = rw.y[i];
       float4 v;
       v.x = rca * ((yv.x * rs + rh > 0.f) ? d.x : 0.f) + rcb + rcc * yv.x;
       v.y = rca * ((yv.y * rs + rh > 0.f) ? d.y : 0.f) + rcb + rcc * yv.y;
@@ -2123,7 +2265,7 @@ __global__ __launch_bounds__(kMidThreads) void pw_bwd_mid_kernel(
 #pragma unroll
     for (int i = 0; i < NX; ++i) {
       const int e = tid + 256 * i, row = e / F4, k = (e % F4) * 4;
-      *reinterpret_cast<float4*>(&Xs[row * LD + k]) = rx[set][i];   // RAW y_{l-1}: the statistics need it, act() is applied on read
+      *reinterpret_cast<float4*>(&Xs[row * LD + k]) = rw.x[i];   // RAW y_{l-1}: the statistics need it, act() is applied on read
     }
   };
 
@@ -2138,17 +2280,17 @@ __global__ __launch_bounds__(kMidThreads) void pw_bwd_mid_kernel(
     // takes 1.7x longer beside the MFMAs).  Where the loaders are the longer side (cin <= 64) they get priority; on
     // the 128 -> 128 layers the MFMA wave is the critical path and priority costs 8 %.
     if (CIT <= 2) __builtin_amdgcn_s_setprio(3);
-    if (nchunks > 0) load_chunk(0, qbeg);
-    if (nchunks > 1) load_chunk(1, qbeg + PT);
+    if (nchunks > 0) load_chunk(raw0, qbeg);
+    if (nchunks > 1) load_chunk(raw1, qbeg + PT);
     for (int t = 0; t < nchunks; t += 2) {
-#pragma unroll
-      for (int u = 0; u < 2; ++u) {
-        if (t + u < nchunks) {
-          const long long qk = qbeg + (long long)(t + u) * PT;
-          store_chunk(u, mid_lds + u * C::TILE, qk);
-          if (t + u + 2 < nchunks) load_chunk(u, qk + 2 * PT);     // two chunks ahead, into the set just consumed
-          lds_barrier();
-        }
+      const long long qk = qbeg + (long long)t * PT;
+      store_chunk(raw0, mid_lds, qk);
+      if (t + 2 < nchunks) load_chunk(raw0, qk + 2 * PT);          // two chunks ahead, into the set just consumed
+      lds_barrier();
+      if (t + 1 < nchunks) {
+        store_chunk(raw1, mid_lds + C::TILE, qk + PT);
+        if (t + 3 < nchunks) load_chunk(raw1, qk + 3 * PT);
+        lds_barrier();
       }
     }
     __syncthreads();                               // the four barriers of the compute waves' epilogue
@@ -2425,6 +2567,8 @@ int g_bwd_mid_enable = 1;     // key 9: 0 = those layers run the dgrad / wgrad p
 int g_exp_no_fast = 0;        // experiment (key 6): 1 = never take the interior-tile fast kernels
 inline int wgrad_mt(int cout, long long pts) { return (cout >= 128 && pts > g_wg_small_pts) ? 128 : 64; }
 inline int wgrad_nt(int cin, long long pts) { return (cin >= 96 && pts > g_wg_small_pts) ? 128 : 64; }
+int g_fwd2_enable = 1;         // key 13: 0 = pw_fwd_kernel for every forward launch
+int g_fwd2_min_waves = 2048;   // key 14
 int g_wgrad2_enable = 1;       // key 11: 0 = pw_wgrad_kernel for every dense layer
 int g_wgrad2_target = 256;     // key 12: workgroups of a pw_wgrad2_kernel launch (one per CU)
 inline bool wgrad2_ok(int cin, int cout) {
@@ -2503,6 +2647,8 @@ int istnet_pw_set_tuning(int key, int value) {
     case 8: g_bwd_mid_target = value > 0 ? value : 256; return 0;
     case 9: g_bwd_mid_enable = value != 0; return 0;
     case 11: g_wgrad2_enable = value != 0; return 0;
+    case 13: g_fwd2_enable = value != 0; return 0;
+    case 14: g_fwd2_min_waves = value > 0 ? value : 2048; return 0;
     case 12: g_wgrad2_target = value > 0 ? value : 256; return 0;
     default: return ISTNET_PN2_EINVAL;
   }
@@ -2510,6 +2656,50 @@ int istnet_pw_set_tuning(int key, int value) {
 
 int istnet_pw_stat_tiles(int b, int cout, int p) {
   return b * ceil_div(p, cfg_nt(pick_cfg(b, cout, p, g_force_fwd_cfg)));
+}
+
+// ---- pw_fwd2_kernel (dense input, B operand straight from global memory) ----
+// 0: pw_fwd_kernel; else TMW * 1000 + WM * 100 + WN * 10 + (KC == 32)
+static int fwd2_cfg(int b, int cin, int cout, int p) {
+  if (!g_fwd2_enable || cin % 16 || cin > 1024 || p % 128 || cout < 16) return 0;
+  const long long wave_tiles = (long long)b * (p / 128);
+  int tmw, wm, wn;
+  if (cout <= 32) { tmw = 1; wm = 1; wn = 4; }
+  else if (cout <= 64) { tmw = 2; wm = 1; wn = 4; }
+  else if (cout <= 128) { tmw = 2; wm = 2; wn = 2; }
+  else { tmw = 2; wm = 4; wn = 1; }
+  // A wave owns 32 TMW rows x 128 points: the launch needs two waves per SIMD of the chip (2048) to hide its loads;
+  // measured at 512 - 1024 waves (SA3 / SA4 at nsample 16, the FP levels) the 64 x 64 LDS tiles are 1.5 - 3x faster.
+  if (wave_tiles * ceil_div(cout, 32 * tmw) < g_fwd2_min_waves) return 0;
+  while (wn > 1 && (wave_tiles / wn) * ceil_div(cout, 32 * tmw * wm) < 256) { wn /= 2; wm *= 2; }
+  if (p % (128 * wn)) return 0;
+  const int kc = (wm > 1 || cin % 32) ? 16 : 32;       // more than one row block of weights per workgroup: 16-channel chunks
+                                                        // (registers of the staging loads, As under 64 KB)
+  return tmw * 1000 + wm * 100 + wn * 10 + (kc == 32);
+}
+int istnet_pw_forward_cfg(int b, int cin, int cout, int p) { return fwd2_cfg(b, cin, cout, p); }
+
+static int launch_pw_fwd2(int cfg, int b, int cin, int cout, int p, const float* x, const float* w,
+                          const float* in_scale, const float* in_shift, float* y, float* part_sum, float* part_sq,
+                          void* stream) {
+  const int tmw = cfg / 1000, wm = (cfg / 100) % 10, wn = (cfg / 10) % 10, kc32 = cfg % 10;
+  const int tpc = p / (128 * wn);
+  const dim3 grid(tpc * b, ceil_div(cout, 32 * tmw * wm));
+#define ISTNET_FWD2(TMW, WM, WN, KC)                                                                               \
+  hipLaunchKernelGGL((pw_fwd2_kernel<TMW, WM, WN, KC>), grid, dim3(kThreads), 0, as_stream(stream), cin, cout, p,  \
+                     tpc, x, w, in_scale, in_shift, y, part_sum, part_sq, tpc * b)
+#define ISTNET_FWD2_K(TMW, WM, WN)                                                                                 \
+  do {                                                                                                             \
+    if (kc32) ISTNET_FWD2(TMW, WM, WN, 32); else ISTNET_FWD2(TMW, WM, WN, 16);                                     \
+  } while (0)
+  if (tmw == 1) {
+    if (wn == 4) ISTNET_FWD2_K(1, 1, 4); else if (wn == 2) ISTNET_FWD2(1, 2, 2, 16); else ISTNET_FWD2(1, 4, 1, 16);
+  } else {
+    if (wn == 4) ISTNET_FWD2_K(2, 1, 4); else if (wn == 2) ISTNET_FWD2(2, 2, 2, 16); else ISTNET_FWD2(2, 4, 1, 16);
+  }
+#undef ISTNET_FWD2_K
+#undef ISTNET_FWD2
+  return (int)hipGetLastError();
 }
 
 static int launch_pw_forward(bool gather, int b, int cin, int cout, int p, const float* x, const GatherSrc& g,
@@ -2552,8 +2742,17 @@ static int launch_pw_forward(bool gather, int b, int cin, int cout, int p, const
 int istnet_pw_forward(int b, int cin, int cout, int p, const float* x, const float* w,
                       const float* in_scale, const float* in_shift, float* y, float* part_sum,
                       float* part_sq, void* stream) {
+  if (b <= 0 || cin <= 0 || cout <= 0 || p <= 0 || (p & 3)) return ISTNET_PN2_EINVAL;
+  const int cfg2 = fwd2_cfg(b, cin, cout, p);
+  if (cfg2) return launch_pw_fwd2(cfg2, b, cin, cout, p, x, w, in_scale, in_shift, y, part_sum, part_sq, stream);
   return launch_pw_forward(false, b, cin, cout, p, x, GatherSrc{}, w, cin, in_scale, in_shift, y, part_sum, part_sq,
                            stream);
+}
+
+int istnet_pw_forward_tiles(int b, int cin, int cout, int p) {
+  const int cfg2 = fwd2_cfg(b, cin, cout, p);
+  if (cfg2) return b * (p / (128 * ((cfg2 / 10) % 10)));
+  return istnet_pw_stat_tiles(b, cout, p);
 }
 
 int istnet_pw_forward_ld(int b, int cin, int cout, int p, const float* x, const float* w, int ldw,

@@ -251,13 +251,17 @@ def _forward_stack(lib, dev, st, b, c0, g, s, x, gather, training, layers, param
         bn = fixed[li] if li in fixed else _empty((4, cout), torch.float32, dev)
         if lay.bias_only:
             gamma = None                      # params[3*li+1] is a ones vector, beta is the conv bias
+        plain = not (li == 0 and gather is not None)      # istnet_pw_forward (dense input tensor)
         if training and not lay.bias_only:
-            nt = lib.istnet_pw_stat_tiles(b, cout, p)
+            nt = lib.istnet_pw_forward_tiles(b, cur_c, cout, p) if plain else lib.istnet_pw_stat_tiles(b, cout, p)
             part = _empty((2, cout, nt), torch.float32, dev)
             ps, pq = part[0].data_ptr(), part[1].data_ptr()
         else:
             nt, ps, pq = 0, None, None
         kname = _kname("pw_fwd_kernel", lib.istnet_pw_tile_cfg(b, cout, p), _gather_mode(gather if li == 0 else None, 16))
+        cfg2 = lib.istnet_pw_forward_cfg(b, cur_c, cout, p) if plain else 0
+        if cfg2:
+            kname = f"pw_fwd2_kernel<{cfg2 // 1000}, {cfg2 // 100 % 10}, {cfg2 // 10 % 10}, {32 if cfg2 % 10 else 16}>"
         flops, nbytes = 2.0 * b * p * cur_c * cout, 4.0 * b * p * (cur_c + cout)
         if li == 0 and gather is not None and USE_SPLIT_LAYER0:
             # layer 0 by linearity: Z = W0[:, 3:] . feat over the n source points (nsample*npoint/n times fewer MACs

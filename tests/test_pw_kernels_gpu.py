@@ -197,6 +197,49 @@ def test_wgrad_role_split_kernel(cin, cout, p, pooled, has_bn):
     torch.testing.assert_close(got[1], want, **tol)
 
 
+@pytest.mark.parametrize("b,cin,cout,p,has_bn", [(3, 64, 128, 512, True), (2, 16, 16, 1024, True), (2, 32, 64, 384, False),
+                                                 (4, 768, 512, 128, True), (2, 48, 96, 256, True), (3, 128, 40, 640, True),
+                                                 (32, 256, 256, 256, True)])
+def test_forward_direct_operand_kernel(b, cin, cout, p, has_bn):
+    """pw_fwd2_kernel (activation operand from global memory straight into the MFMA) against a float64 product: output,
+    statistics partials, partial row tiles (cout = 40, 96), every workgroup shape; the LDS-tiled kernel (tuning key
+    13 = 0) agrees."""
+    lib = _native.lib()
+    assert lib.istnet_pw_set_tuning(14, 1) == 0      # (the launch-size threshold would send these small cases to pw_fwd_kernel)
+    assert lib.istnet_pw_forward_cfg(b, cin, cout, p) > 0
+    assert lib.istnet_pw_forward_cfg(b, cin + 8, cout, p) == 0 and lib.istnet_pw_forward_cfg(b, cin, cout, p + 4) == 0
+    g = torch.Generator().manual_seed(b + cin + cout + p)
+    x = torch.randn(b, cin, p, generator=g).to(DEV)
+    w = (torch.randn(cout, cin, generator=g) / cin ** 0.5).to(DEV)
+    bn_in = _bn_block(cin, g)
+    sc, sh = (bn_in[0].data_ptr(), bn_in[1].data_ptr()) if has_bn else (None, None)
+    d = torch.float64
+    act = torch.relu(x * bn_in[0].view(1, -1, 1) + bn_in[1].view(1, -1, 1)).to(d) if has_bn else x.to(d)
+    want = torch.matmul(w.to(d), act)
+    outs = []
+    for enable in (1, 0):
+        assert lib.istnet_pw_set_tuning(13, enable) == 0
+        try:
+            nt = lib.istnet_pw_forward_tiles(b, cin, cout, p)
+            y = torch.full((b, cout, p), float("nan"), device=DEV)
+            part = torch.full((2, cout, nt), float("nan"), device=DEV)
+            assert lib.istnet_pw_forward(b, cin, cout, p, x.data_ptr(), w.data_ptr(), sc, sh, y.data_ptr(),
+                                         part[0].data_ptr(), part[1].data_ptr(), _st()) == 0
+            outs.append((y, part))
+        finally:
+            lib.istnet_pw_set_tuning(13, 1)
+    for y, part in outs:
+        torch.testing.assert_close(y.to(d), want, rtol=1e-5, atol=1e-5)
+        torch.testing.assert_close(part[0].to(d).sum(-1), want.sum(dim=(0, 2)), rtol=1e-5, atol=1e-3)
+        torch.testing.assert_close(part[1].to(d).sum(-1), want.square().sum(dim=(0, 2)), rtol=1e-5, atol=1e-3)
+    # without statistics (eval mode)
+    y2 = torch.empty(b, cout, p, device=DEV)
+    assert lib.istnet_pw_forward(b, cin, cout, p, x.data_ptr(), w.data_ptr(), sc, sh, y2.data_ptr(), None, None, _st()) == 0
+    assert torch.equal(y2, outs[0][0])
+    assert lib.istnet_pw_set_tuning(14, 0) == 0
+    assert lib.istnet_pw_forward_cfg(2, 64, 64, 1024) == 0 and lib.istnet_pw_forward_cfg(32, 64, 128, 4096) > 0
+
+
 def test_forward_acc_channel_stats_and_dy():
     lib = _native.lib()
     b, cin, cout, p = 2, 24, 40, 256

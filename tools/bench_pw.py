@@ -37,7 +37,7 @@ for name, P, s, spec in LAYERS:
         w = torch.randn(cout, cin, device=dev) * 0.1
         wt = w.t().contiguous()
         y = torch.empty(B, cout, P, device=dev)
-        nt = lib.istnet_pw_stat_tiles(B, cout, P)
+        nt = max(lib.istnet_pw_stat_tiles(B, cout, P), lib.istnet_pw_forward_tiles(B, cin, cout, P))
         part = torch.empty(2, cout, nt, device=dev)
         insc = torch.rand(cin, device=dev) + 0.5; insh = torch.randn(cin, device=dev) * 0.1
         has_bn = li > 0
