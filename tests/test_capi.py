@@ -94,3 +94,39 @@ def test_missing_library_fails_loudly(monkeypatch, tmp_path):
     for rel in ("pointnet2/_ext.py", "pointnet2/fused_mlp.py", "optim.py", "preprocess.py"):
         text = open(os.path.join(root, rel)).read()
         assert "_native.lib()" in text and "ctypes.CDLL" not in text, rel
+
+
+def test_no_kernel_has_a_scratch_segment(tmp_path):
+    """A kernel with a scratch (private) segment does not share the chip with kernels of other streams (DESIGN.md 5.4:
+    a 128-workgroup finalize kernel waited 55 us for the GEMM beside it), and register spills cost bandwidth on their own:
+    every kernel of the built library must report private_segment_fixed_size 0 and no spills."""
+    import os
+    import re
+    import subprocess
+    from istnet_amd import _native
+    tools = "/opt/rocm/lib/llvm/bin"
+    objcopy, bundler, readelf = (os.path.join(tools, t) for t in ("llvm-objcopy", "clang-offload-bundler", "llvm-readelf"))
+    if not all(os.path.exists(t) for t in (objcopy, bundler, readelf)):
+        pytest.skip("LLVM binary tools of the ROCm install not found")
+    _native.lib()
+    fat = tmp_path / "fat.bin"
+    subprocess.run([objcopy, f"--dump-section=.hip_fatbin={fat}", _native.LIB_PATH, str(tmp_path / "discard.so")], check=True)
+    blob = fat.read_bytes()
+    magic = b"__CLANG_OFFLOAD_BUNDLE__"
+    starts = [m.start() for m in re.finditer(re.escape(magic), blob)]
+    assert len(starts) >= 5          # one bundle per .hip source
+    kernels = 0
+    for i, a in enumerate(starts):
+        part = tmp_path / f"bundle{i}.bin"
+        part.write_bytes(blob[a:starts[i + 1] if i + 1 < len(starts) else len(blob)])
+        co = tmp_path / f"dev{i}.co"
+        subprocess.run([bundler, "--unbundle", "--type=o", f"--input={part}", "--targets=hipv4-amdgcn-amd-amdhsa--gfx950",
+                        f"--output={co}"], check=True)
+        notes = subprocess.run([readelf, "--notes", str(co)], check=True, capture_output=True, text=True).stdout
+        names = re.findall(r"\.name:\s+(\S+)", notes)
+        scratch = [int(v) for v in re.findall(r"\.private_segment_fixed_size:\s+(\d+)", notes)]
+        spills = [int(v) for v in re.findall(r"\.vgpr_spill_count:\s+(\d+)", notes)]
+        kernels += len(scratch)
+        bad = [n for n, sc, sp in zip([n for n in names if not n.startswith(("hidden_", "by_"))], scratch, spills) if sc or sp]
+        assert not any(scratch) and not any(spills), bad
+    assert kernels > 100
