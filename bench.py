@@ -132,9 +132,10 @@ def make_eager_step(fwd_bwds, opt, world, reducer=None):
 
 
 def optimizer_step(opt, world, reducer):
-    """FlatAdam: pack the gradients once, sum the flat buffer over ranks (one RCCL all-reduce), update with 1/world."""
-    if reducer is not None:          # data parallel (or its one-rank dry run): all-reduce, then the update
-        opt.step(reducer.sum_(opt.pack_grads()), grad_scale=1.0 / world)
+    """FlatAdam: the flat gradient buffer is summed over ranks in buckets (parallel.OverlappedFlatReducer: issued from
+    autograd hooks while backward runs in an eager step, back to back after a graph replay), update with 1/world."""
+    if reducer is not None:          # data parallel (or its one-rank dry run): the buckets went out during backward
+        opt.step(reducer.finish(), grad_scale=1.0 / world)
     else:
         opt.step()
 
@@ -159,7 +160,7 @@ def make_graphed_step(fwd_bwds, opt, world, reducer=None):
             optimizer_step(opt, world, reducer)
     torch.cuda.current_stream().wait_stream(side)
     torch.cuda.synchronize()
-    graphs, packed = [], []
+    graphs = []
     # With a process group alive, ProcessGroupNCCL's watchdog thread polls its events (hipEventQuery) at any time;
     # under the default "global" capture mode that call is illegal while ANOTHER thread captures and the watchdog
     # aborts the process (measured on this stack: tools/exp/rccl_capture_modes.py).  "thread_local" restricts the
@@ -172,8 +173,7 @@ def make_graphed_step(fwd_bwds, opt, world, reducer=None):
             fwd_bwd()
             if reducer is None:
                 opt.step()
-            else:
-                packed.append(opt.pack_grads())  # static buffer: the all-reduce and Adam read it eagerly
+            # else: the gradients stay in their (static) buffers; the all-reduce and Adam follow the replay eagerly
         graphs.append(graph)
     count = [0]
 
@@ -182,7 +182,7 @@ def make_graphed_step(fwd_bwds, opt, world, reducer=None):
         count[0] += 1
         graphs[k].replay()
         if reducer is not None:
-            opt.step(reducer.sum_(packed[k]), grad_scale=1.0 / world)   # one RCCL all-reduce + one Adam launch
+            opt.step(reducer.finish(), grad_scale=1.0 / world)   # bucketed RCCL all-reduce + one Adam launch
     return step
 
 
@@ -415,6 +415,10 @@ def main():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--eager", action="store_true", help="do not capture the step in a HIP graph")
     ap.add_argument("--no-unpipelined", action="store_true", help="skip the extra unpipelined measurement")
+    ap.add_argument("--overlap-allreduce", action="store_true",
+                    help="N > 1: run the step eagerly so that each ~25 MB bucket of the flat gradient is all-reduced "
+                         "from an autograd hook while backward still runs (a replayed graph issues the buckets after "
+                         "the replay); meant for --workload istnet (107 MB of gradients)")
     ap.add_argument("--no-prefetch", action="store_true",
                     help="encoder workload: one batch, geometry inside the step (no next-batch geometry prefetch)")
     ap.add_argument("--workload", default="encoder", choices=["encoder", "istnet", "infer", "sa_layer"],
@@ -515,9 +519,8 @@ def main():
         batch = istnet_batch(BATCH, NPOINTS, seed=rank, device=dev)
         opt = FlatAdam(model.parameters(), lr=1e-4)
         if dist_on:
-            from istnet_amd.parallel import GradAllReducer
-            grad_sync = GradAllReducer(model, world)
-            grad_sync.always = args.force_dist
+            from istnet_amd.parallel import OverlappedFlatReducer
+            grad_sync = OverlappedFlatReducer(opt, world, always=args.force_dist)
         fwd_bwd = make_istnet_fwd_bwd(model, batch)
         args.no_cpu_baseline = True
     else:
@@ -525,9 +528,8 @@ def main():
         pts = shell_cloud(batch_size, NPOINTS, seed=rank, device=dev)
         opt = FlatAdam(model.parameters(), lr=1e-4)
         if dist_on:
-            from istnet_amd.parallel import GradAllReducer
-            grad_sync = GradAllReducer(model, world)
-            grad_sync.always = args.force_dist
+            from istnet_amd.parallel import OverlappedFlatReducer
+            grad_sync = OverlappedFlatReducer(opt, world, always=args.force_dist)
         if args.no_prefetch:
             fwd_bwd = make_encoder_fwd_bwd(model, pts)
         else:
@@ -538,6 +540,8 @@ def main():
             fwd_bwd = [make_pipelined_fwd_bwd(model, batches, slots, i) for i in (0, 1)]
     eager_step = make_eager_step(fwd_bwd, opt, world, grad_sync)
     step, mode = eager_step, "eager"
+    if args.overlap_allreduce and dist_on:
+        args.eager = True       # hooks issue the collectives during backward: not inside a capture
     if not args.eager:
         try:
             step, mode = make_graphed_step(fwd_bwd, opt, world, grad_sync), "hipgraph"
@@ -589,6 +593,10 @@ def main():
                        "batch_per_gpu": batch_size, "npoints": NPOINTS, "global_batch": batch_size * world,
                        "parallelism": f"dp{world}" + (" (one-rank dry run of the RCCL path)" if args.force_dist and world == 1 else ""),
                        "launch": mode,
+                       "gradient_exchange": (None if not dist_on else
+                                             f"{len(grad_sync.buckets)} bucket(s) of FlatAdam.flat_grad, sum all-reduce "
+                                             + ("from autograd hooks during backward" if mode == "eager"
+                                                else "issued back to back after the graph replay")),
                        "batches": ("1 (same batch every step)" if (args.workload != "encoder" or args.no_prefetch)
                                    else "2 alternating, next batch's FPS/ball-query/three_nn prefetched on the "
                                         "geometry stream during the current step")},

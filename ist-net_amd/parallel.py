@@ -77,6 +77,113 @@ class GradAllReducer:
         return flat
 
 
+class OverlappedFlatReducer:
+    """Sum all-reduce of ``FlatAdam.flat_grad`` in buckets, each issued AS SOON AS ITS SLICE IS FINAL, during backward.
+
+    The reference exchanges gradients inside ``nn.DataParallel``'s backward (train.py:98-99, reduce-add onto GPU 0).
+    Here the gradients of all parameters live in one flat buffer (``optim.FlatAdam.flat_grad``, written in place by the
+    backward kernels); backward produces them roughly in reverse parameter order, so the buffer is cut into contiguous
+    buckets of ~``bucket_bytes`` from its END, and a ``post_accumulate_grad`` hook per parameter counts a bucket down.
+    When the last parameter of a bucket has its gradient, a side stream waits for the producers -- the stream backward
+    runs on AND the deferred weight-gradient streams of ``fused_mlp`` (the kernels that write those slots are enqueued
+    before autograd stores ``.grad``) -- and issues ONE asynchronous all-reduce of that slice.  The full IST-Net has
+    107 MB of gradients (4 buckets of ~25 MB): the first three exchanges run under the rest of backward instead of
+    after it.  xGMI rings are per-link bound, so few large messages: the default bucket is 25 MB.
+
+        red = OverlappedFlatReducer(opt)           # once; opt = FlatAdam
+        opt.zero_grad(set_to_none=True); loss.backward()
+        opt.step(red.finish(), grad_scale=1.0 / world)
+
+    Inside a HIP-graph capture no collective is issued from the hooks (the buckets are only marked); ``finish()`` after
+    the replay then issues them back to back -- bucketed, but not overlapped with backward."""
+
+    def __init__(self, opt, world_size=None, bucket_bytes=25 << 20, group=None, always=False):
+        self.opt, self.group = opt, group
+        self.world = world_size if world_size is not None else dist.get_world_size(group)
+        self.always = always       # True: issue the collectives even with one rank (single-GPU dry run of the RCCL path)
+        esz = opt.flat_grad.element_size()
+        self.buckets = []          # [lo, hi, parameter indices], from the end of the buffer
+        cur, hi = [], opt.flat_grad.numel()
+        for i in range(len(opt.params) - 1, -1, -1):
+            cur.append(i)
+            lo = opt.offsets[i]
+            if (hi - lo) * esz >= bucket_bytes or i == 0:
+                self.buckets.append((lo, hi, cur))
+                cur, hi = [], lo
+        self.bucket_of = {}
+        for b, (_, _, idxs) in enumerate(self.buckets):
+            for i in idxs:
+                self.bucket_of[i] = b
+        self.comm = torch.cuda.Stream(device=opt.flat_grad.device) if opt.flat_grad.is_cuda else None
+        self._reset()
+        self.issued_in_backward = 0          # statistics of the last step (tests, logging)
+        for i, p in enumerate(opt.params):
+            p.register_post_accumulate_grad_hook(self._make_hook(i))
+
+    def _active(self):
+        return self.world > 1 or self.always
+
+    def _reset(self):
+        self.left = [len(idxs) for _, _, idxs in self.buckets]
+        self.seen = [False] * len(self.opt.params)
+        self.works = [None] * len(self.buckets)
+        self.launched = [False] * len(self.buckets)
+
+    def _make_hook(self, i):
+        def hook(param):
+            if self.seen[i]:
+                return
+            self.seen[i] = True
+            b = self.bucket_of[i]
+            self.left[b] -= 1
+            if self.left[b] == 0 and self._active() and not (
+                    param.is_cuda and torch.cuda.is_current_stream_capturing()):
+                self._launch(b)
+                self.issued_in_backward += 1
+        return hook
+
+    def _launch(self, b):
+        lo, hi, idxs = self.buckets[b]
+        opt = self.opt
+        for i in idxs:                     # gradients that did not arrive in place (or not at all) go into their slots
+            p, slot = opt.params[i], opt.params[i]._istnet_grad_slot
+            if p.grad is None:
+                slot.zero_()
+            elif p.grad.data_ptr() != slot.data_ptr() or not p.grad.is_contiguous():
+                slot.copy_(p.grad.reshape(-1))
+        piece = opt.flat_grad[lo:hi]
+        if self.comm is None:              # CPU tensors (gloo tests): no streams
+            self.works[b] = dist.all_reduce(piece, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        else:
+            dev = piece.device
+            self.comm.wait_stream(torch.cuda.current_stream(dev))
+            from .pointnet2 import fused_mlp
+            for wstream in fused_mlp.deferred_streams(dev):
+                self.comm.wait_stream(wstream)
+            with torch.cuda.stream(self.comm):
+                self.works[b] = dist.all_reduce(piece, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        self.launched[b] = True
+
+    def finish(self):
+        """Issue what backward did not (unused parameters, a captured step), wait for every bucket on the current
+        stream and return the summed flat gradient (``FlatAdam.step(flat, grad_scale=1/world)`` divides)."""
+        opt = self.opt
+        if self._active():
+            for b in range(len(self.buckets)):
+                if not self.launched[b]:
+                    self._launch(b)
+            for w in self.works:
+                if w is not None:
+                    w.wait()
+            if self.comm is not None:
+                torch.cuda.current_stream(opt.flat_grad.device).wait_stream(self.comm)
+            out = opt.flat_grad
+        else:
+            out = opt.pack_grads()
+        self._reset()
+        return out
+
+
 def broadcast_parameters(model, src=0, group=None):
     """Make every replica start from rank ``src``'s parameters and buffers."""
     for t in list(model.parameters()) + list(model.buffers()):

@@ -156,6 +156,13 @@ class _Deferred:
         cls.armed = False
 
 
+def deferred_streams(dev):
+    """The deferred weight-gradient streams of ``dev`` (parallel.OverlappedFlatReducer orders its collectives after
+    them: the kernels that write a parameter's gradient slot are enqueued there before autograd stores ``.grad``)."""
+    key = dev.index if dev.index is not None else torch.cuda.current_device()
+    return [s for (k, _), s in _Deferred.streams.items() if k == key]
+
+
 def _enter_backward(dev):
     """Called at the top of every fused node's backward (on the node's own stream): remembers the stream the
     deferred weight gradients are joined into."""

@@ -128,6 +128,65 @@ def test_flat_adam_allreduce_world2():
     assert dict(out) == {0: True, 1: True}
 
 
+def _overlap_worker(rank, world, port, out):
+    """parallel.OverlappedFlatReducer: buckets of FlatAdam.flat_grad all-reduced from post-accumulate-grad hooks while
+    backward runs; two steps, the second with a parameter that receives no gradient."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.set_num_threads(1)
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import istnet_amd  # noqa: F401
+    from istnet_amd.optim import FlatAdam
+    from istnet_amd.parallel import OverlappedFlatReducer
+    from istnet_amd.pointnet2 import pointnet2_utils
+    from oracle import pn2_oracle
+    pointnet2_utils._ext = pn2_oracle     # CPU test harness only
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    model = _make(seed=0)
+    extra = torch.nn.Parameter(torch.ones(7))          # a parameter no loss depends on
+    opt = FlatAdam(list(model.parameters()) + [extra], lr=1e-2)
+    red = OverlappedFlatReducer(opt, world, bucket_bytes=1024)      # several buckets
+    assert len(red.buckets) >= 3 and red.buckets[0][1] == opt.flat_grad.numel() and red.buckets[-1][0] == 0
+    assert sum(len(b[2]) for b in red.buckets) == len(opt.params)
+    issued = []
+    for it in range(2):
+        opt.zero_grad(set_to_none=True)
+        red.issued_in_backward = 0
+        _local_grads_keep(model, rank)
+        issued.append(red.issued_in_backward)
+        opt.step(red.finish(), grad_scale=1.0 / world)
+    ref = _make(seed=0)
+    ropt = torch.optim.Adam(ref.parameters(), lr=1e-2)
+    for _ in range(2):
+        per_rank = []
+        for r in range(world):
+            ref.zero_grad(set_to_none=True)
+            _local_grads_keep(ref, r)
+            per_rank.append([p.grad.clone() for p in ref.parameters()])
+        for p, gs in zip(ref.parameters(), zip(*per_rank)):
+            p.grad = sum(gs) / world
+        ropt.step()
+    ok = all(torch.allclose(p, q, rtol=1e-4, atol=1e-6) for p, q in zip(model.parameters(), ref.parameters()))
+    ok = ok and torch.equal(extra.detach(), torch.ones(7))          # zero gradient: Adam leaves it alone
+    # every bucket but the one holding the unused parameter (the last of the buffer, i.e. bucket 0) went out in backward
+    ok = ok and all(n == len(red.buckets) - 1 for n in issued)
+    flat = torch.cat([p.detach().reshape(-1) for p in model.parameters()])
+    gathered = [torch.empty_like(flat) for _ in range(world)]
+    dist.all_gather(gathered, flat)
+    out[rank] = bool(ok and torch.equal(gathered[0], gathered[1]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_overlapped_bucket_allreduce_world2():
+    world = 2
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_overlap_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    assert dict(out) == {0: True, 1: True}
+
+
 def _run_bench(cmd):
     import json
     import subprocess

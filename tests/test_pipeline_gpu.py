@@ -204,3 +204,54 @@ def test_unsupported_shapes_fall_back_with_a_warning():
     fused_mlp.FALLBACKS.clear()
     _, out2 = sa2(xyz, feat.detach())
     assert out2.shape == (2, 32, 32) and not fused_mlp.FALLBACKS
+
+
+def test_overlapped_bucket_allreduce_on_rccl_one_rank():
+    """parallel.OverlappedFlatReducer on the GPU with a one-rank RCCL group (``always=True`` issues the collectives):
+    buckets leave from autograd hooks during backward, ordered after the backward stream AND the deferred
+    weight-gradient stream.  A sum over one rank is the identity, so parameters after two steps must equal the run
+    without any exchange, bit for bit."""
+    import os
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    code = f"""
+import os, sys, torch
+sys.path.insert(0, {root!r})
+import torch.distributed as dist
+import bench
+from istnet_amd.optim import FlatAdam
+from istnet_amd.parallel import OverlappedFlatReducer
+dev = torch.device("cuda:0")
+os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="{port}")
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+pts = bench.shell_cloud(4, 1024, seed=3, device=dev)
+finals, issued = [], None
+for exchange in (True, False):
+    model = bench.make_model(dev, seed=0)
+    opt = FlatAdam(model.parameters(), lr=1e-3)
+    red = OverlappedFlatReducer(opt, 1, bucket_bytes=1 << 20, always=True) if exchange else None
+    for it in range(2):
+        opt.zero_grad(set_to_none=True)
+        model(pts).square().mean().backward()
+        if red is not None:
+            issued = (red.issued_in_backward, len(red.buckets))
+            opt.step(red.finish(), grad_scale=1.0)
+        else:
+            opt.step()
+    torch.cuda.synchronize()
+    finals.append(opt.flat.clone())
+assert issued[1] >= 4 and issued[0] >= issued[1], issued     # every bucket left during backward, in both steps
+assert torch.equal(finals[0], finals[1]), float((finals[0] - finals[1]).abs().max())
+dist.destroy_process_group()
+print("OK", issued)
+"""
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    proc = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert proc.returncode == 0 and "OK" in proc.stdout, (proc.stdout[-500:], proc.stderr[-2000:])
