@@ -52,6 +52,11 @@ ISTNET_PN2_API int istnet_pw_forward(int b, int cin, int cout, int p, const floa
  * TMW * 1000 + WM * 100 + WN * 10 + (K chunk == 32) of the pw_fwd2_kernel instance (for reporting). */
 ISTNET_PN2_API int istnet_pw_forward_tiles(int b, int cin, int cout, int p);
 ISTNET_PN2_API int istnet_pw_forward_cfg(int b, int cin, int cout, int p);
+/* Small launches (at most 1024 tiles of 32 x 128, cin % 8 == 0, cin >= 64, p % 128 == 0, cout >= 32; keys 15 / 16 of
+ * istnet_pw_set_tuning) of istnet_pw_forward, istnet_pw_forward_ld and istnet_pw_forward_acc run pw_fwd_sk_kernel (no LDS
+ * operands, K split over the four waves of a workgroup; istnet_pw_forward_cfg reports 1).  Number of statistics partials
+ * per channel of an istnet_pw_forward_ld / istnet_pw_forward_acc launch: */
+ISTNET_PN2_API int istnet_pw_forward_ld_tiles(int b, int cin, int cout, int p);
 
 /* istnet_pw_forward with w a column slice of a wider row-major matrix: row stride ldw >= cin */
 ISTNET_PN2_API int istnet_pw_forward_ld(int b, int cin, int cout, int p, const float *x, const float *w, int ldw,

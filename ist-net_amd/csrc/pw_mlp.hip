@@ -562,6 +562,124 @@ __global__ __launch_bounds__(kThreads, 2) void pw_fwd2_kernel(
 }
 
 // ============================================================================================
+// forward for SMALL launches (the feature-propagation levels: 4 096 - 32 768 points, K = 128 - 768): neither operand
+// goes through LDS and the four waves of a workgroup split K.  With few points there are only a few hundred 64 x 64
+// tiles; one tile per wave walks the whole K with one MFMA per two ds_read_b32 and a barrier every 16 channels, and the
+// launch is latency, not throughput.  Here a workgroup owns ONE 32 x 128 output tile and its four waves each take every
+// fourth group of 8 input channels:
+//   B (activations): float4 of four consecutive points of row k -- the column relabelling of pw_fwd2_kernel;
+//   A (weights):     float4 of four consecutive k of row co -- K is a dummy index too: a lane's four values serve four
+//                    k-steps as long as both operands agree that (lane half, step t) of group j means k = 8j + 4 half + t;
+// per group a wave issues 5 global loads for 16 MFMAs: no LDS traffic, no barrier, a quarter of the chain length.  The
+// four partial accumulators meet in LDS at the end and each wave finishes 8 of the 32 rows (float4 stores of 512
+// contiguous bytes, statistics partials straight from the half-wave sums).  Optional: accumulators start from a tensor
+// (c_init: the interpolated term of a feature-propagation layer 0); weights may be a column slice of a wider matrix (ldw).
+// grid: (B * P / 128, ceil(cout / 32)); cin % 8 == 0, cin <= 2048, P % 128 == 0.
+// ============================================================================================
+__global__ __launch_bounds__(kThreads, 2) void pw_fwd_sk_kernel(
+    int cin, int cout, int P, int tiles_per_cloud, const float* __restrict__ x, const float* __restrict__ w, int ldw,
+    const float* __restrict__ in_scale, const float* __restrict__ in_shift, const float* __restrict__ c_init,
+    float* __restrict__ y, float* __restrict__ part_sum, float* __restrict__ part_sq, int nt_total) {
+  __shared__ __attribute__((aligned(16))) float lds[4 * 4 * 16 * 64];   // 64 KB: BN constants during the loop, then the partials
+  float* s_sc = lds;            // [cin]
+  float* s_sh = lds + 2048;     // [cin]
+  const int tid = threadIdx.x, lane = lane_id(), wv = wave_id();
+  const int l31 = lane & 31, half = lane >> 5;
+  const int b = blockIdx.x / tiles_per_cloud;
+  const int p0 = (blockIdx.x - b * tiles_per_cloud) * 128;
+  const int m0 = blockIdx.y * 32;
+  const bool has_bn = in_scale != nullptr;
+  const bool w_vec = (ldw & 3) == 0 && ((uintptr_t)w & 15) == 0;
+  if (has_bn) {
+    for (int c = tid; c < cin; c += kThreads) { s_sc[c] = in_scale[c]; s_sh[c] = in_shift[c]; }
+    __syncthreads();
+  }
+  const float* xb = x + (size_t)b * cin * P + p0 + 4 * l31;
+  const float* wrow = w + (size_t)min(m0 + l31, cout - 1) * ldw + 4 * half;
+
+  f32x16 acc[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[q][r] = 0.f;
+
+  const int ngroups = cin / 8;
+  float4 a4[2], b4[2][4];
+  auto load_group = [&](float4& a, float4 (&bq)[4], int j) {
+    const float* wp = wrow + 8 * j;
+    a = w_vec ? *reinterpret_cast<const float4*>(wp) : make_float4(wp[0], wp[1], wp[2], wp[3]);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) bq[t] = *reinterpret_cast<const float4*>(xb + (size_t)(8 * j + 4 * half + t) * P);
+  };
+  auto mma_group = [&](const float4& a, float4 (&bq)[4], int j) {
+    if (has_bn) {
+      const float4 sc = *reinterpret_cast<const float4*>(&s_sc[8 * j + 4 * half]);
+      const float4 sh = *reinterpret_cast<const float4*>(&s_sh[8 * j + 4 * half]);
+      bq[0] = bn_relu4(bq[0], sc.x, sh.x);
+      bq[1] = bn_relu4(bq[1], sc.y, sh.y);
+      bq[2] = bn_relu4(bq[2], sc.z, sh.z);
+      bq[3] = bn_relu4(bq[3], sc.w, sh.w);
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const float av = t == 0 ? a.x : (t == 1 ? a.y : (t == 2 ? a.z : a.w));
+      acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bq[t].x, acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bq[t].y, acc[1], 0, 0, 0);
+      acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bq[t].z, acc[2], 0, 0, 0);
+      acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bq[t].w, acc[3], 0, 0, 0);
+    }
+  };
+  // this wave's groups: wv, wv + 4, ...; two register sets, the next group's loads in flight during the MFMAs
+  int j = wv;
+  if (j < ngroups) load_group(a4[0], b4[0], j);
+  for (; j < ngroups; j += 8) {
+    if (j + 4 < ngroups) load_group(a4[1], b4[1], j + 4);
+    mma_group(a4[0], b4[0], j);
+    if (j + 4 < ngroups) {
+      if (j + 8 < ngroups) load_group(a4[0], b4[0], j + 8);
+      mma_group(a4[1], b4[1], j + 4);
+    }
+  }
+  // ---- the four partial sums meet in LDS; wave w finishes registers 4w .. 4w + 3, i.e. rows 8w .. 8w + 7 ----
+  __syncthreads();              // every wave is done with the BN constants
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) lds[((wv * 4 + q) * 16 + r) * 64 + lane] = acc[q][r];
+  __syncthreads();
+  float* yb = y + (size_t)b * cout * P + p0 + 4 * l31;
+  const float* cb = c_init != nullptr ? c_init + (size_t)b * cout * P + p0 + 4 * l31 : nullptr;
+#pragma unroll
+  for (int rr = 0; rr < 4; ++rr) {
+    const int r = 4 * wv + rr;
+    const int row = m0 + mfma_row(r, lane);
+    float v[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float* pr = lds + (q * 16 + r) * 64 + lane;
+      v[q] = (pr[0] + pr[4 * 16 * 64]) + (pr[2 * 4 * 16 * 64] + pr[3 * 4 * 16 * 64]);
+    }
+    float4 o = make_float4(v[0], v[1], v[2], v[3]);
+    const bool ok = row < cout;
+    if (cb != nullptr && ok) {
+      const float4 c0 = *reinterpret_cast<const float4*>(cb + (size_t)row * P);
+      o.x += c0.x; o.y += c0.y; o.z += c0.z; o.w += c0.w;
+    }
+    if (ok) *reinterpret_cast<float4*>(yb + (size_t)row * P) = o;
+    if (part_sum != nullptr) {
+      float s1 = (o.x + o.y) + (o.z + o.w);
+      float s2 = (o.x * o.x + o.y * o.y) + (o.z * o.z + o.w * o.w);
+      s1 = half_wave_sum(s1);
+      s2 = half_wave_sum(s2);
+      if (l31 == 31 && ok) {
+        part_sum[(size_t)row * nt_total + blockIdx.x] = s1;
+        part_sq[(size_t)row * nt_total + blockIdx.x] = s2;
+      }
+    }
+  }
+}
+
+// ============================================================================================
 // Layer 0 of a set-abstraction scale, split by linearity.  The grouped input of point p is
 // [xyz[idx[p]] - centre(p) ; feat[:, idx[p]]], so
 //     y0[:, p] = W0x . (xyz[idx[p]] - centre(p)) + (W0f . feat)[:, idx[p]].
@@ -2567,6 +2685,9 @@ int g_bwd_mid_enable = 1;     // key 9: 0 = those layers run the dgrad / wgrad p
 int g_exp_no_fast = 0;        // experiment (key 6): 1 = never take the interior-tile fast kernels
 inline int wgrad_mt(int cout, long long pts) { return (cout >= 128 && pts > g_wg_small_pts) ? 128 : 64; }
 inline int wgrad_nt(int cin, long long pts) { return (cin >= 96 && pts > g_wg_small_pts) ? 128 : 64; }
+int g_fwd_sk_enable = 1;       // key 15: 0 = no pw_fwd_sk_kernel
+int g_fwd_sk_max_tiles = 1024; // key 16: launches with more 32 x 128 tiles than this keep the LDS-tiled kernel (measured:
+                               // +15-35 % at <= 1024 tiles -- the FP levels --, -8 % at 2048)
 int g_fwd2_enable = 1;         // key 13: 0 = pw_fwd_kernel for every forward launch
 int g_fwd2_min_waves = 2048;   // key 14
 int g_wgrad2_enable = 1;       // key 11: 0 = pw_wgrad_kernel for every dense layer
@@ -2648,6 +2769,8 @@ int istnet_pw_set_tuning(int key, int value) {
     case 9: g_bwd_mid_enable = value != 0; return 0;
     case 11: g_wgrad2_enable = value != 0; return 0;
     case 13: g_fwd2_enable = value != 0; return 0;
+    case 15: g_fwd_sk_enable = value != 0; return 0;
+    case 16: g_fwd_sk_max_tiles = value > 0 ? value : 1024; return 0;
     case 14: g_fwd2_min_waves = value > 0 ? value : 2048; return 0;
     case 12: g_wgrad2_target = value > 0 ? value : 256; return 0;
     default: return ISTNET_PN2_EINVAL;
@@ -2658,6 +2781,12 @@ int istnet_pw_stat_tiles(int b, int cout, int p) {
   return b * ceil_div(p, cfg_nt(pick_cfg(b, cout, p, g_force_fwd_cfg)));
 }
 
+// ---- pw_fwd_sk_kernel (small launches: no LDS operands, K split over the waves of a workgroup) ----
+static bool fwd_sk_ok(int b, int cin, int cout, int p) {
+  if (!g_fwd_sk_enable || cin % 8 || cin > 2048 || cin < 64 || p % 128 || cout < 32) return false;
+  const long long tiles = (long long)b * (p / 128) * ceil_div(cout, 32);
+  return tiles <= g_fwd_sk_max_tiles;
+}
 // ---- pw_fwd2_kernel (dense input, B operand straight from global memory) ----
 // 0: pw_fwd_kernel; else TMW * 1000 + WM * 100 + WN * 10 + (KC == 32)
 static int fwd2_cfg(int b, int cin, int cout, int p) {
@@ -2677,7 +2806,10 @@ static int fwd2_cfg(int b, int cin, int cout, int p) {
                                                         // (registers of the staging loads, As under 64 KB)
   return tmw * 1000 + wm * 100 + wn * 10 + (kc == 32);
 }
-int istnet_pw_forward_cfg(int b, int cin, int cout, int p) { return fwd2_cfg(b, cin, cout, p); }
+int istnet_pw_forward_cfg(int b, int cin, int cout, int p) {
+  const int c2 = fwd2_cfg(b, cin, cout, p);
+  return c2 ? c2 : (fwd_sk_ok(b, cin, cout, p) ? 1 : 0);      // 1: pw_fwd_sk_kernel
+}
 
 static int launch_pw_fwd2(int cfg, int b, int cin, int cout, int p, const float* x, const float* w,
                           const float* in_scale, const float* in_shift, float* y, float* part_sum, float* part_sq,
@@ -2711,6 +2843,12 @@ static int launch_pw_forward(bool gather, int b, int cin, int cout, int p, const
   msrc.n = 0;
   if (msrc_p != nullptr) msrc = *msrc_p;
   if (b <= 0 || cin <= 0 || cout <= 0 || p <= 0 || (p & 3)) return ISTNET_PN2_EINVAL;
+  if (!gather && msrc_p == nullptr && ncols == nullptr && row_init == nullptr && fwd_sk_ok(b, cin, cout, p)) {
+    const int tpc = p / 128;
+    hipLaunchKernelGGL(pw_fwd_sk_kernel, dim3(tpc * b, ceil_div(cout, 32)), dim3(kThreads), 0, as_stream(stream), cin, cout,
+                       p, tpc, x, w, ldw, in_scale, in_shift, c_init, y, part_sum, part_sq, tpc * b);
+    return (int)hipGetLastError();
+  }
   const TileCfg cfg = pick_cfg(b, cout, p, g_force_fwd_cfg);
   const int tpc = ceil_div(p, cfg_nt(cfg));
   const dim3 grid(tpc * b, ceil_div(cout, cfg_mt(cfg)));
@@ -2752,7 +2890,12 @@ int istnet_pw_forward(int b, int cin, int cout, int p, const float* x, const flo
 int istnet_pw_forward_tiles(int b, int cin, int cout, int p) {
   const int cfg2 = fwd2_cfg(b, cin, cout, p);
   if (cfg2) return b * (p / (128 * ((cfg2 / 10) % 10)));
+  if (fwd_sk_ok(b, cin, cout, p)) return b * (p / 128);
   return istnet_pw_stat_tiles(b, cout, p);
+}
+
+int istnet_pw_forward_ld_tiles(int b, int cin, int cout, int p) {
+  return fwd_sk_ok(b, cin, cout, p) ? b * (p / 128) : istnet_pw_stat_tiles(b, cout, p);
 }
 
 int istnet_pw_forward_ld(int b, int cin, int cout, int p, const float* x, const float* w, int ldw,

@@ -63,6 +63,13 @@ def _kname(base, cfg, gather=None, pooled=False):
     return f"{base}<{mt}, {nt}, {wm}, {wn}{tail}>"
 
 
+def _fwd_ld_kname(lib, b, cin, cout, p):
+    """Kernel an istnet_pw_forward_ld / istnet_pw_forward_acc launch runs: the split-K kernel for small launches."""
+    if lib.istnet_pw_forward_cfg(b, cin, cout, p) == 1:
+        return "pw_fwd_sk_kernel"
+    return _kname("pw_fwd_kernel", lib.istnet_pw_tile_cfg(b, cout, p), 0)
+
+
 def _dgrad_kname(lib, b, rows, cout, p):
     """pw_dgrad_kernel<M_T, N_T, WM, WN, FAST> as launch_pw_dgrad picks it: FAST = every tile interior and the
     reduction length a multiple of the k-tile (kKT = 16)."""
@@ -267,7 +274,9 @@ def _forward_stack(lib, dev, st, b, c0, g, s, x, gather, training, layers, param
             nt, ps, pq = 0, None, None
         kname = _kname("pw_fwd_kernel", lib.istnet_pw_tile_cfg(b, cout, p), _gather_mode(gather if li == 0 else None, 16))
         cfg2 = lib.istnet_pw_forward_cfg(b, cur_c, cout, p) if plain else 0
-        if cfg2:
+        if cfg2 == 1:
+            kname = "pw_fwd_sk_kernel"
+        elif cfg2:
             kname = f"pw_fwd2_kernel<{cfg2 // 1000}, {cfg2 // 100 % 10}, {cfg2 // 10 % 10}, {32 if cfg2 % 10 else 16}>"
         flops, nbytes = 2.0 * b * p * cur_c * cout, 4.0 * b * p * (cur_c + cout)
         if li == 0 and gather is not None and USE_SPLIT_LAYER0:
@@ -279,7 +288,7 @@ def _forward_stack(lib, dev, st, b, c0, g, s, x, gather, training, layers, param
             if ga.cfeat > 0:
                 z = _empty((b, cout, ga.n), torch.float32, dev)
                 _native.check(_native.timed(
-                    _kname("pw_fwd_kernel", lib.istnet_pw_tile_cfg(b, cout, ga.n), 0), 2.0 * b * ga.n * ga.cfeat * cout,
+                    _fwd_ld_kname(lib, b, ga.cfeat, cout, ga.n), 2.0 * b * ga.n * ga.cfeat * cout,
                     4.0 * b * ga.n * (ga.cfeat + cout), lambda: lib.istnet_pw_forward_ld(
                         b, ga.cfeat, cout, ga.n, ga.feat.data_ptr(), w2.data_ptr() + 12, cur_c, None, None,
                         z.data_ptr(), None, None, st)), "pw_forward_ld")
@@ -354,7 +363,7 @@ def _forward_stack_compact(lib, dev, st, b, g, s, ga, training, layers, params, 
             if ga.cfeat > 0:
                 z = _empty((b, cout, ga.n), torch.float32, dev)
                 _native.check(_native.timed(
-                    _kname("pw_fwd_kernel", lib.istnet_pw_tile_cfg(b, cout, ga.n), 0), 2.0 * b * ga.n * ga.cfeat * cout,
+                    _fwd_ld_kname(lib, b, ga.cfeat, cout, ga.n), 2.0 * b * ga.n * ga.cfeat * cout,
                     4.0 * b * ga.n * (ga.cfeat + cout), lambda: lib.istnet_pw_forward_ld(
                         b, ga.cfeat, cout, ga.n, ga.feat.data_ptr(), w2.data_ptr() + 12, cur_c, None, None,
                         z.data_ptr(), None, None, st)), "pw_forward_ld")
@@ -1153,7 +1162,7 @@ class FusedFPFunction(Function):
             st = _st(dev)
             zk = _empty((b, cout0, m), torch.float32, dev)
             _native.check(_native.timed(
-                _kname("pw_fwd_kernel", lib.istnet_pw_tile_cfg(b, cout0, m), 0), 2.0 * b * m * c2 * cout0,
+                _fwd_ld_kname(lib, b, c2, cout0, m), 2.0 * b * m * c2 * cout0,
                 4.0 * b * m * (c2 + cout0), lambda: lib.istnet_pw_forward_ld(
                     b, c2, cout0, m, known.data_ptr(), w2.data_ptr(), cin, None, None, zk.data_ptr(), None, None,
                     st)), "pw_forward_ld(fp)")
@@ -1163,10 +1172,10 @@ class FusedFPFunction(Function):
             if skip_c is not None:
                 y0 = _empty((b, cout0, n), torch.float32, dev)
                 if training:
-                    nt = lib.istnet_pw_stat_tiles(b, cout0, n)
+                    nt = lib.istnet_pw_forward_ld_tiles(b, c1, cout0, n)
                     part = _empty((2, cout0, nt), torch.float32, dev)
                 _native.check(_native.timed(
-                    _kname("pw_fwd_kernel", lib.istnet_pw_tile_cfg(b, cout0, n), 0), 2.0 * b * n * c1 * cout0,
+                    _fwd_ld_kname(lib, b, c1, cout0, n), 2.0 * b * n * c1 * cout0,
                     4.0 * b * n * (c1 + 2 * cout0), lambda: lib.istnet_pw_forward_acc(
                         b, c1, cout0, n, skip_c.data_ptr(), w2.data_ptr() + 4 * c2, cin, t.data_ptr(), y0.data_ptr(),
                         _p(part[0]) if training else None, _p(part[1]) if training else None, st)), "pw_forward_acc")

@@ -207,7 +207,7 @@ def test_forward_direct_operand_kernel(b, cin, cout, p, has_bn):
     lib = _native.lib()
     assert lib.istnet_pw_set_tuning(14, 1) == 0      # (the launch-size threshold would send these small cases to pw_fwd_kernel)
     assert lib.istnet_pw_forward_cfg(b, cin, cout, p) > 0
-    assert lib.istnet_pw_forward_cfg(b, cin + 8, cout, p) == 0 and lib.istnet_pw_forward_cfg(b, cin, cout, p + 4) == 0
+    assert lib.istnet_pw_forward_cfg(b, cin + 8, cout, p) in (0, 1) and lib.istnet_pw_forward_cfg(b, cin, cout, p + 4) == 0   # (1: the split-K kernel)
     g = torch.Generator().manual_seed(b + cin + cout + p)
     x = torch.randn(b, cin, p, generator=g).to(DEV)
     w = (torch.randn(cout, cin, generator=g) / cin ** 0.5).to(DEV)
@@ -237,7 +237,55 @@ def test_forward_direct_operand_kernel(b, cin, cout, p, has_bn):
     assert lib.istnet_pw_forward(b, cin, cout, p, x.data_ptr(), w.data_ptr(), sc, sh, y2.data_ptr(), None, None, _st()) == 0
     assert torch.equal(y2, outs[0][0])
     assert lib.istnet_pw_set_tuning(14, 0) == 0
-    assert lib.istnet_pw_forward_cfg(2, 64, 64, 1024) == 0 and lib.istnet_pw_forward_cfg(32, 64, 128, 4096) > 0
+    assert lib.istnet_pw_forward_cfg(2, 64, 64, 1024) in (0, 1) and lib.istnet_pw_forward_cfg(32, 64, 128, 4096) > 1
+
+
+@pytest.mark.parametrize("b,cin,cout,p,has_bn,mode", [(4, 512, 512, 128, True, "plain"), (2, 256, 96, 256, False, "plain"),
+                                                      (3, 64, 40, 384, True, "plain"), (4, 256, 512, 128, False, "acc"),
+                                                      (2, 128, 256, 256, False, "ld"), (2, 72, 64, 128, False, "ld_unaligned")])
+def test_forward_split_k_kernel_for_small_launches(b, cin, cout, p, has_bn, mode):
+    """pw_fwd_sk_kernel (no LDS operands, K split over the waves of a workgroup) through the three entry points that
+    can take it -- istnet_pw_forward, istnet_pw_forward_acc (accumulators start from a tensor), istnet_pw_forward_ld
+    (weights are a column slice of a wider matrix, aligned or not) -- against float64, and against pw_fwd_kernel."""
+    lib = _native.lib()
+    assert lib.istnet_pw_forward_cfg(b, cin, cout, p) == 1
+    g = torch.Generator().manual_seed(b + cin + cout + p)
+    x = torch.randn(b, cin, p, generator=g).to(DEV)
+    pad = {"ld": 64, "ld_unaligned": 3, "acc": 128}.get(mode, 0)
+    wfull = (torch.randn(cout, cin + pad, generator=g) / cin ** 0.5).to(DEV)
+    off = pad if mode in ("ld", "acc") else 0           # the slice starts after `pad` columns (or at 0, unaligned row stride)
+    w = wfull[:, off:off + cin]
+    bn_in = _bn_block(cin, g)
+    sc, sh = (bn_in[0].data_ptr(), bn_in[1].data_ptr()) if has_bn else (None, None)
+    cinit = torch.randn(b, cout, p, generator=g).to(DEV) if mode == "acc" else None
+    d = torch.float64
+    act = torch.relu(x * bn_in[0].view(1, -1, 1) + bn_in[1].view(1, -1, 1)).to(d) if has_bn else x.to(d)
+    want = torch.matmul(w.to(d), act) + (cinit.to(d) if cinit is not None else 0)
+    wptr, ldw = wfull.data_ptr() + 4 * off, cin + pad
+    outs = []
+    for enable in (1, 0):
+        assert lib.istnet_pw_set_tuning(15, enable) == 0
+        try:
+            nt = lib.istnet_pw_forward_tiles(b, cin, cout, p) if mode == "plain" else lib.istnet_pw_forward_ld_tiles(b, cin, cout, p)
+            y = torch.full((b, cout, p), float("nan"), device=DEV)
+            part = torch.full((2, cout, nt), float("nan"), device=DEV)
+            if mode == "plain":
+                rc = lib.istnet_pw_forward(b, cin, cout, p, x.data_ptr(), wptr, sc, sh, y.data_ptr(), part[0].data_ptr(),
+                                           part[1].data_ptr(), _st())
+            elif mode == "acc":
+                rc = lib.istnet_pw_forward_acc(b, cin, cout, p, x.data_ptr(), wptr, ldw, cinit.data_ptr(), y.data_ptr(),
+                                               part[0].data_ptr(), part[1].data_ptr(), _st())
+            else:
+                rc = lib.istnet_pw_forward_ld(b, cin, cout, p, x.data_ptr(), wptr, ldw, sc, sh, y.data_ptr(),
+                                              part[0].data_ptr(), part[1].data_ptr(), _st())
+            assert rc == 0
+            outs.append((y, part))
+        finally:
+            lib.istnet_pw_set_tuning(15, 1)
+    for y, part in outs:
+        torch.testing.assert_close(y.to(d), want, rtol=1e-5, atol=2e-5)
+        torch.testing.assert_close(part[0].to(d).sum(-1), want.sum(dim=(0, 2)), rtol=1e-5, atol=1e-3)
+        torch.testing.assert_close(part[1].to(d).sum(-1), want.square().sum(dim=(0, 2)), rtol=1e-5, atol=1e-3)
 
 
 def test_forward_acc_channel_stats_and_dy():
