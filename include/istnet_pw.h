@@ -57,6 +57,11 @@ ISTNET_PN2_API int istnet_pw_forward_cfg(int b, int cin, int cout, int p);
  * operands, K split over the four waves of a workgroup; istnet_pw_forward_cfg reports 1).  Number of statistics partials
  * per channel of an istnet_pw_forward_ld / istnet_pw_forward_acc launch: */
 ISTNET_PN2_API int istnet_pw_forward_ld_tiles(int b, int cin, int cout, int p);
+/* The same for istnet_pw_dgrad with a dense gradient source (pw_dgrad_sk_kernel; cout % 8 == 0, 256 <= cout <= 2048 (key 18),
+ * p % 128 == 0, m_rows >= 32, at most 1024 tiles; key 17 disables): istnet_pw_dgrad_sk = 1 when that kernel runs,
+ * istnet_pw_dgrad_tiles = statistics partials per input channel the launch writes (dense: 1 = dense gradient source). */
+ISTNET_PN2_API int istnet_pw_dgrad_sk(int b, int m_rows, int cout, int p);
+ISTNET_PN2_API int istnet_pw_dgrad_tiles(int b, int m_rows, int cout, int p, int dense);
 
 /* istnet_pw_forward with w a column slice of a wider row-major matrix: row stride ldw >= cin */
 ISTNET_PN2_API int istnet_pw_forward_ld(int b, int cin, int cout, int p, const float *x, const float *w, int ldw,

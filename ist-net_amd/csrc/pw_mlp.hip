@@ -1624,6 +1624,132 @@ __global__ __launch_bounds__(kThreads) void pw_dgrad_kernel(
 }
 
 // ============================================================================================
+// dgrad for SMALL launches with a dense gradient source (the feature-propagation levels, the level-wide feature
+// gradients of the set-abstraction levels): pw_fwd_sk_kernel's structure for  dA[ci][p] = sum_co w[co][ci] dY[co][p].
+// One 32 x 128 output tile per workgroup, the four waves take every fourth group of 8 output channels (K), no LDS
+// operands: dY is formed in registers from float4 loads of y and dA_l along the points (the column relabelling: MFMA q
+// owns the points {4 l + q}) with the five per-channel constants of row k read from an LDS table; the weights are rows
+// of w (a lane's input channel is contiguous in memory, so one coalesced dword per k and half).  The partial
+// accumulators meet in LDS; each wave finishes 8 rows: float4 stores of dA and, when the layer below has a BatchNorm,
+// the partial sums of g = dA [relu active] and g y_in over the tile (y_in read as float4 in the same layout).
+// grid: (B * P / 128, ceil(m_rows / 32)); cout % 8 == 0, cout <= 2048, P % 128 == 0.
+// ============================================================================================
+__global__ __launch_bounds__(kThreads, 2) void pw_dgrad_sk_kernel(
+    int cin_total, int ci_off, int m_rows, int cout, int P, int tiles_per_cloud, const float* __restrict__ w,
+    const float* __restrict__ y, const float* __restrict__ dA, const float* __restrict__ bn,
+    const float* __restrict__ bwdc, float* __restrict__ dx, const float* __restrict__ y_in,
+    const float* __restrict__ bn_in, float* __restrict__ part_g, float* __restrict__ part_gy, int nt_total) {
+  __shared__ __attribute__((aligned(16))) float lds[4 * 4 * 16 * 64];   // 64 KB: constants during the loop, then the partials
+  const int tid = threadIdx.x, lane = lane_id(), wv = wave_id();
+  const int l31 = lane & 31, half = lane >> 5;
+  const int b = blockIdx.x / tiles_per_cloud;
+  const int p0 = (blockIdx.x - b * tiles_per_cloud) * 128;
+  const int m0 = blockIdx.y * 32;
+  // [5][cout]: scale, shift of this layer's BatchNorm; ca, cb, cc of dY = ca * g + cb + cc * y
+  for (int c = tid; c < cout; c += kThreads) {
+    lds[c] = bn[c]; lds[2048 + c] = bn[cout + c];
+    lds[4096 + c] = bwdc[c]; lds[6144 + c] = bwdc[cout + c]; lds[8192 + c] = bwdc[2 * cout + c];
+  }
+  __syncthreads();
+  const float* yb = y + (size_t)b * cout * P + p0 + 4 * l31;
+  const float* gb = dA + (size_t)b * cout * P + p0 + 4 * l31;
+  const float* wcol = w + ci_off + min(m0 + l31, m_rows - 1);      // + k * cin_total: w[k][ci]
+
+  f32x16 acc[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[q][r] = 0.f;
+
+  const int ngroups = cout / 8;
+  float a4[2][4];
+  float4 y4[2][4], g4[2][4];
+  auto load_group = [&](float (&a)[4], float4 (&yq)[4], float4 (&gq)[4], int j) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int k = 8 * j + 4 * half + t;
+      a[t] = wcol[(size_t)k * cin_total];
+      yq[t] = *reinterpret_cast<const float4*>(yb + (size_t)k * P);
+      gq[t] = *reinterpret_cast<const float4*>(gb + (size_t)k * P);
+    }
+  };
+  auto mma_group = [&](const float (&a)[4], const float4 (&yq)[4], const float4 (&gq)[4], int j) {
+    const int k0 = 8 * j + 4 * half;
+    const float4 rs = *reinterpret_cast<const float4*>(&lds[k0]), rh = *reinterpret_cast<const float4*>(&lds[2048 + k0]);
+    const float4 ca = *reinterpret_cast<const float4*>(&lds[4096 + k0]), cb = *reinterpret_cast<const float4*>(&lds[6144 + k0]);
+    const float4 cc = *reinterpret_cast<const float4*>(&lds[8192 + k0]);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const float s = t == 0 ? rs.x : (t == 1 ? rs.y : (t == 2 ? rs.z : rs.w));
+      const float h = t == 0 ? rh.x : (t == 1 ? rh.y : (t == 2 ? rh.z : rh.w));
+      const float fa = t == 0 ? ca.x : (t == 1 ? ca.y : (t == 2 ? ca.z : ca.w));
+      const float fb = t == 0 ? cb.x : (t == 1 ? cb.y : (t == 2 ? cb.z : cb.w));
+      const float fc = t == 0 ? cc.x : (t == 1 ? cc.y : (t == 2 ? cc.z : cc.w));
+      const float4 yv = yq[t], gv = gq[t];
+      float4 d;
+      d.x = fa * ((yv.x * s + h > 0.f) ? gv.x : 0.f) + fb + fc * yv.x;
+      d.y = fa * ((yv.y * s + h > 0.f) ? gv.y : 0.f) + fb + fc * yv.y;
+      d.z = fa * ((yv.z * s + h > 0.f) ? gv.z : 0.f) + fb + fc * yv.z;
+      d.w = fa * ((yv.w * s + h > 0.f) ? gv.w : 0.f) + fb + fc * yv.w;
+      acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t], d.x, acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t], d.y, acc[1], 0, 0, 0);
+      acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t], d.z, acc[2], 0, 0, 0);
+      acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t], d.w, acc[3], 0, 0, 0);
+    }
+  };
+  int j = wv;
+  if (j < ngroups) load_group(a4[0], y4[0], g4[0], j);
+  for (; j < ngroups; j += 8) {
+    if (j + 4 < ngroups) load_group(a4[1], y4[1], g4[1], j + 4);
+    mma_group(a4[0], y4[0], g4[0], j);
+    if (j + 4 < ngroups) {
+      if (j + 8 < ngroups) load_group(a4[0], y4[0], g4[0], j + 8);
+      mma_group(a4[1], y4[1], g4[1], j + 4);
+    }
+  }
+  __syncthreads();              // every wave is done with the constants
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) lds[((wv * 4 + q) * 16 + r) * 64 + lane] = acc[q][r];
+  __syncthreads();
+  float* dxb = dx + (size_t)b * m_rows * P + p0 + 4 * l31;
+  const bool stats = part_g != nullptr;
+  const float* xin = stats ? y_in + (size_t)b * m_rows * P + p0 + 4 * l31 : nullptr;
+#pragma unroll
+  for (int rr = 0; rr < 4; ++rr) {
+    const int r = 4 * wv + rr;
+    const int row = m0 + mfma_row(r, lane);
+    const bool ok = row < m_rows;
+    float v[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float* pr = lds + (q * 16 + r) * 64 + lane;
+      v[q] = (pr[0] + pr[4 * 16 * 64]) + (pr[2 * 4 * 16 * 64] + pr[3 * 4 * 16 * 64]);
+    }
+    const float4 o = make_float4(v[0], v[1], v[2], v[3]);
+    if (ok) *reinterpret_cast<float4*>(dxb + (size_t)row * P) = o;
+    if (stats) {
+      float sg = 0.f, sgy = 0.f;
+      if (ok) {
+        const float4 yi = *reinterpret_cast<const float4*>(xin + (size_t)row * P);
+        const float is = bn_in[row], ih = bn_in[m_rows + row];
+        const float g0 = (yi.x * is + ih > 0.f) ? o.x : 0.f, g1 = (yi.y * is + ih > 0.f) ? o.y : 0.f;
+        const float g2 = (yi.z * is + ih > 0.f) ? o.z : 0.f, g3 = (yi.w * is + ih > 0.f) ? o.w : 0.f;
+        sg = (g0 + g1) + (g2 + g3);
+        sgy = (g0 * yi.x + g1 * yi.y) + (g2 * yi.z + g3 * yi.w);
+      }
+      sg = half_wave_sum(sg);
+      sgy = half_wave_sum(sgy);
+      if (l31 == 31 && ok) {
+        part_g[(size_t)row * nt_total + blockIdx.x] = sg;
+        part_gy[(size_t)row * nt_total + blockIdx.x] = sgy;
+      }
+    }
+  }
+}
+
+// ============================================================================================
 // wgrad:  dWpart[split][co][ci] = sum_{q in split} dY[q][co] * act(x[q][ci]),  q = b*P + p flattened
 // ============================================================================================
 // grid: (splits, ceil(cout / M_T), ceil(cin / N_T)); K = the points of one split.  A split is a range of
@@ -2686,6 +2812,8 @@ int g_exp_no_fast = 0;        // experiment (key 6): 1 = never take the interior
 inline int wgrad_mt(int cout, long long pts) { return (cout >= 128 && pts > g_wg_small_pts) ? 128 : 64; }
 inline int wgrad_nt(int cin, long long pts) { return (cin >= 96 && pts > g_wg_small_pts) ? 128 : 64; }
 int g_fwd_sk_enable = 1;       // key 15: 0 = no pw_fwd_sk_kernel
+int g_dgrad_sk_enable = 1;     // key 17: 0 = no pw_dgrad_sk_kernel
+int g_dgrad_sk_min_k = 256;    // key 18
 int g_fwd_sk_max_tiles = 1024; // key 16: launches with more 32 x 128 tiles than this keep the LDS-tiled kernel (measured:
                                // +15-35 % at <= 1024 tiles -- the FP levels --, -8 % at 2048)
 int g_fwd2_enable = 1;         // key 13: 0 = pw_fwd_kernel for every forward launch
@@ -2770,6 +2898,8 @@ int istnet_pw_set_tuning(int key, int value) {
     case 11: g_wgrad2_enable = value != 0; return 0;
     case 13: g_fwd2_enable = value != 0; return 0;
     case 15: g_fwd_sk_enable = value != 0; return 0;
+    case 17: g_dgrad_sk_enable = value != 0; return 0;
+    case 18: g_dgrad_sk_min_k = value > 0 ? value : 256; return 0;
     case 16: g_fwd_sk_max_tiles = value > 0 ? value : 1024; return 0;
     case 14: g_fwd2_min_waves = value > 0 ? value : 2048; return 0;
     case 12: g_wgrad2_target = value > 0 ? value : 256; return 0;
@@ -3082,6 +3212,20 @@ int istnet_bn_finalize_bwd(int c, int nt, double count, int training, const floa
   return (int)hipGetLastError();
 }
 
+// ---- pw_dgrad_sk_kernel (small launches, dense gradient source) ----
+static bool dgrad_sk_ok(int b, int m_rows, int cout, int p) {
+  // (measured, tools/bench_pw.py: +6-17 % at K = cout >= 256, 10-50 % SLOWER at K = 64-128 -- forming dY costs ~14 VALU
+  //  per element and short K leaves nothing to hide it behind)
+  if (!g_dgrad_sk_enable || cout % 8 || cout > 2048 || cout < g_dgrad_sk_min_k || p % 128 || m_rows < 32) return false;
+  return (long long)b * (p / 128) * ceil_div(m_rows, 32) <= g_fwd_sk_max_tiles;
+}
+/* 1 when istnet_pw_dgrad with a dense gradient source runs the split-K kernel for this shape */
+int istnet_pw_dgrad_sk(int b, int m_rows, int cout, int p) { return dgrad_sk_ok(b, m_rows, cout, p) ? 1 : 0; }
+int istnet_pw_dgrad_tiles(int b, int m_rows, int cout, int p, int dense) {
+  if (dense && dgrad_sk_ok(b, m_rows, cout, p)) return b * (p / 128);
+  return b * ceil_div(p, cfg_nt(pick_dgrad_cfg(b, m_rows, p, g_force_dgrad_cfg)));
+}
+
 static int launch_pw_dgrad(int b, int cin_total, int ci_off, int m_rows, int cout, int p, int nsample,
                            const float* w, const float* y, const float* d_dense, const float* d_pooled,
                            long long pooled_bstride, const unsigned char* arg, const float* bn, const float* bwdc,
@@ -3092,6 +3236,13 @@ static int launch_pw_dgrad(int b, int cin_total, int ci_off, int m_rows, int cou
   if (part_g != nullptr && (y_in == nullptr || bn_in == nullptr || part_gy == nullptr)) return ISTNET_PN2_EINVAL;
   if (d_dense == nullptr && (d_pooled == nullptr || arg == nullptr || nsample <= 0 || (nsample & 3)))
     return ISTNET_PN2_EINVAL;
+  if (d_dense != nullptr && ncols == nullptr && dgrad_sk_ok(b, m_rows, cout, p)) {
+    const int tpc = p / 128;
+    hipLaunchKernelGGL(pw_dgrad_sk_kernel, dim3(tpc * b, ceil_div(m_rows, 32)), dim3(kThreads), 0, as_stream(stream),
+                       cin_total, ci_off, m_rows, cout, p, tpc, w, y, d_dense, bn, bwdc, dx, y_in, bn_in, part_g, part_gy,
+                       tpc * b);
+    return (int)hipGetLastError();
+  }
   GradSrc gs{d_dense, d_pooled, arg, nsample, pooled_bstride > 0 ? pooled_bstride : (long long)GS_C * (nsample > 0 ? p / nsample : 0), GS_C};
   const TileCfg cfg = pick_dgrad_cfg(b, m_rows, p, g_force_dgrad_cfg);
   const int tpc = ceil_div(p, cfg_nt(cfg));

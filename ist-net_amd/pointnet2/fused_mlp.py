@@ -70,9 +70,11 @@ def _fwd_ld_kname(lib, b, cin, cout, p):
     return _kname("pw_fwd_kernel", lib.istnet_pw_tile_cfg(b, cout, p), 0)
 
 
-def _dgrad_kname(lib, b, rows, cout, p):
+def _dgrad_kname(lib, b, rows, cout, p, dense=False):
     """pw_dgrad_kernel<M_T, N_T, WM, WN, FAST> as launch_pw_dgrad picks it: FAST = every tile interior and the
     reduction length a multiple of the k-tile (kKT = 16)."""
+    if dense and lib.istnet_pw_dgrad_sk(b, rows, cout, p):
+        return "pw_dgrad_sk_kernel"          # small launch, dense gradient source: K split over the waves, no LDS operands
     cfg = lib.istnet_pw_dgrad_tile_cfg(b, rows, p)
     mt, nt = cfg // 1000, cfg % 1000
     fast = rows % mt == 0 and p % nt == 0 and cout % 16 == 0
@@ -701,14 +703,14 @@ def _backward_stack(lib, dev, st, b, c0, g, s, x, gather, training, ys, bns, par
             ci_off, rows = (3, gather.cfeat) if use_gather else (0, cin)
             dprev = _empty((b, rows, p), torch.float32, dev)
             if li > 0:   # dprev is dA of layer li-1: reduce its BN-backward statistics in the epilogue
-                fused_nt = lib.istnet_pw_dgrad_stat_tiles(b, rows, p)
+                fused_nt = lib.istnet_pw_dgrad_tiles(b, rows, cout, p, 1 if dd is not None else 0)
                 fused_part = _empty((2, rows, fused_nt), torch.float32, dev)
                 y_in, bn_in = ys[li - 1].data_ptr(), bns[li - 1].data_ptr()
                 pg, pgy = fused_part[0].data_ptr(), fused_part[1].data_ptr()
             else:
                 y_in = bn_in = pg = pgy = None
             _native.check(_native.timed(
-                _dgrad_kname(lib, b, rows, cout, p), 2.0 * b * p * rows * cout,
+                _dgrad_kname(lib, b, rows, cout, p, dense=dd is not None), 2.0 * b * p * rows * cout,
                 4.0 * (b * p * (rows + cout + (rows if li > 0 else 0)) + grad_elems), lambda: lib.istnet_pw_dgrad(
                     b, cin, ci_off, rows, cout, p, ns_arg, w2.data_ptr(), y.data_ptr(), dd, dp, pbs, da,
                     bn.data_ptr(), bwdc.data_ptr(), dprev.data_ptr(), y_in, bn_in, pg, pgy, st)), "pw_dgrad")
@@ -1074,7 +1076,7 @@ class FusedSALevelFunction(Function):
                 ident, bwdc = _ident_consts(dev, cout0_tot)                   # mask always on, dY = g
                 dfeat = _empty((b, cfeat, n_src), torch.float32, dev)
                 _native.check(_native.timed(
-                    _dgrad_kname(lib, b, cfeat, cout0_tot, n_src),
+                    _dgrad_kname(lib, b, cfeat, cout0_tot, n_src, dense=True),
                     2.0 * b * n_src * cfeat * cout0_tot, 4.0 * b * n_src * (cfeat + cout0_tot), lambda: lib.istnet_pw_dgrad(
                         b, 3 + cfeat, 3, cfeat, cout0_tot, n_src, 0, wcat.data_ptr(), gbuf.data_ptr(), gbuf.data_ptr(),
                         None, 0, None, ident.data_ptr(), bwdc.data_ptr(), dfeat.data_ptr(), None, None, None, None,
@@ -1232,7 +1234,7 @@ class FusedFPFunction(Function):
             if need_skip:
                 ds = _empty((b, c1, n), torch.float32, dev)
                 _native.check(_native.timed(
-                    _dgrad_kname(lib, b, c1, cout0, n), 2.0 * b * n * c1 * cout0,
+                    _dgrad_kname(lib, b, c1, cout0, n, dense=True), 2.0 * b * n * c1 * cout0,
                     4.0 * b * n * (c1 + cout0), lambda: lib.istnet_pw_dgrad(
                         b, cin, c2, c1, cout0, n, 0, w2.data_ptr(), dy0.data_ptr(), dy0.data_ptr(), None, 0, None,
                         ident.data_ptr(), ibw.data_ptr(), ds.data_ptr(), None, None, None, None, st)),
@@ -1245,7 +1247,7 @@ class FusedFPFunction(Function):
             if need_known:
                 dk = _empty((b, c2, m), torch.float32, dev)
                 _native.check(_native.timed(
-                    _dgrad_kname(lib, b, c2, cout0, m), 2.0 * b * m * c2 * cout0,
+                    _dgrad_kname(lib, b, c2, cout0, m, dense=True), 2.0 * b * m * c2 * cout0,
                     4.0 * b * m * (c2 + cout0), lambda: lib.istnet_pw_dgrad(
                         b, cin, 0, c2, cout0, m, 0, w2.data_ptr(), gk.data_ptr(), gk.data_ptr(), None, 0, None,
                         ident.data_ptr(), ibw.data_ptr(), dk.data_ptr(), None, None, None, None, st)),

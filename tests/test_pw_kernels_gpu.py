@@ -288,6 +288,52 @@ def test_forward_split_k_kernel_for_small_launches(b, cin, cout, p, has_bn, mode
         torch.testing.assert_close(part[1].to(d).sum(-1), want.square().sum(dim=(0, 2)), rtol=1e-5, atol=1e-3)
 
 
+@pytest.mark.parametrize("b,cin_total,ci_off,rows,cout,p,stats", [(4, 512, 0, 512, 512, 128, True), (2, 320, 256, 64, 256, 256, False),
+                                                                  (3, 131, 3, 128, 192, 384, False), (2, 96, 0, 40, 64, 128, True)])
+def test_dgrad_split_k_kernel_for_small_launches(b, cin_total, ci_off, rows, cout, p, stats):
+    """pw_dgrad_sk_kernel (dense gradient source, small launches) against float64: dA for a column slice of the weight
+    matrix, partial row tiles (rows = 40), the BatchNorm-backward statistics partials of the layer below; pw_dgrad_kernel
+    (tuning key 17 = 0) agrees."""
+    lib = _native.lib()
+    assert lib.istnet_pw_dgrad_sk(2, 128, 128, 1024) == 0          # short K keeps the LDS-tiled kernel by default
+    assert lib.istnet_pw_set_tuning(18, 64) == 0
+    assert lib.istnet_pw_dgrad_sk(b, rows, cout, p) == 1
+    g = torch.Generator().manual_seed(b + cin_total + cout + p)
+    w = (torch.randn(cout, cin_total, generator=g) / cout ** 0.5).to(DEV)
+    y = torch.randn(b, cout, p, generator=g).to(DEV)
+    dA = torch.randn(b, cout, p, generator=g).to(DEV)
+    bn = _bn_block(cout, g)
+    bwdc = torch.stack([torch.rand(cout, generator=g) + 0.5, torch.randn(cout, generator=g) * 0.01,
+                        torch.randn(cout, generator=g) * 0.01]).contiguous().to(DEV)
+    y_in = torch.randn(b, rows, p, generator=g).to(DEV)
+    bn_in = _bn_block(rows, g)
+    d = torch.float64
+    mask = (y * bn[0].view(1, -1, 1) + bn[1].view(1, -1, 1)) > 0
+    dy = bwdc[0].to(d).view(1, -1, 1) * (dA.to(d) * mask) + bwdc[1].to(d).view(1, -1, 1) + bwdc[2].to(d).view(1, -1, 1) * y.to(d)
+    want = torch.matmul(w[:, ci_off:ci_off + rows].to(d).t(), dy)
+    gq = want * ((y_in * bn_in[0].view(1, -1, 1) + bn_in[1].view(1, -1, 1)) > 0)
+    outs = []
+    for enable in (1, 0):
+        assert lib.istnet_pw_set_tuning(17, enable) == 0
+        try:
+            nt = lib.istnet_pw_dgrad_tiles(b, rows, cout, p, 1)
+            dx = torch.full((b, rows, p), float("nan"), device=DEV)
+            part = torch.full((2, rows, nt), float("nan"), device=DEV)
+            pg, pgy = (part[0].data_ptr(), part[1].data_ptr()) if stats else (None, None)
+            assert lib.istnet_pw_dgrad(b, cin_total, ci_off, rows, cout, p, 0, w.data_ptr(), y.data_ptr(), dA.data_ptr(), None, 0,
+                                       None, bn.data_ptr(), bwdc.data_ptr(), dx.data_ptr(), y_in.data_ptr() if stats else None,
+                                       bn_in.data_ptr() if stats else None, pg, pgy, _st()) == 0
+            outs.append((dx, part))
+        finally:
+            lib.istnet_pw_set_tuning(17, 1)
+    for dx, part in outs:
+        torch.testing.assert_close(dx.to(d), want, rtol=1e-5, atol=2e-5)
+        if stats:
+            torch.testing.assert_close(part[0].to(d).sum(-1), gq.sum(dim=(0, 2)), rtol=1e-4, atol=2e-3)
+            torch.testing.assert_close(part[1].to(d).sum(-1), (gq * y_in.to(d)).sum(dim=(0, 2)), rtol=1e-4, atol=2e-3)
+    assert lib.istnet_pw_set_tuning(18, 0) == 0
+
+
 def test_forward_acc_channel_stats_and_dy():
     lib = _native.lib()
     b, cin, cout, p = 2, 24, 40, 256
