@@ -2,7 +2,7 @@
 
 Same objects as the reference builds -- IST_Net with the ResNet-18/PSP RGB branch, SupervisedLoss, Adam driven by a
 per-iteration CyclicLR, the BatchNorm-momentum schedule -- with the three substitutions INTEGRATION.md describes:
-``FlatAdam`` for ``torch.optim.Adam``, one process per GPU + ``GradAllReducer`` for ``nn.DataParallel``, and synthetic
+``FlatAdam`` for ``torch.optim.Adam``, one process per GPU + ``OverlappedFlatReducer`` for ``nn.DataParallel``, and synthetic
 data for the NOCS loaders (no dataset in this repository).
 
     python examples/train_synthetic.py --iters 20
@@ -21,7 +21,7 @@ import istnet_amd  # noqa: E402,F401
 from istnet_amd.ist_net import IST_Net  # noqa: E402
 from istnet_amd.losses import SupervisedLoss  # noqa: E402
 from istnet_amd.optim import FlatAdam  # noqa: E402
-from istnet_amd.parallel import GradAllReducer, broadcast_parameters  # noqa: E402
+from istnet_amd.parallel import OverlappedFlatReducer, broadcast_parameters  # noqa: E402
 from istnet_amd.pointnet2.pytorch_utils import BNMomentumScheduler  # noqa: E402
 from istnet_amd.rgb_branch import ModifiedResnet  # noqa: E402
 
@@ -56,7 +56,8 @@ def main(argv=None):
     sched = torch.optim.lr_scheduler.CyclicLR(opt, base_lr=1e-5, max_lr=1e-3, step_size_up=max(args.iters // 6, 1),
                                               mode="triangular", cycle_momentum=False)
     bnm = BNMomentumScheduler(model, bn_lambda=lambda it: max(0.5 * 0.5 ** int(it / 200000), 0.01), last_epoch=0)
-    reducer = GradAllReducer(model, world) if world > 1 else None
+    # buckets of the flat gradient buffer leave from autograd hooks while backward still runs
+    reducer = OverlappedFlatReducer(opt, world) if world > 1 else None
     criterion = SupervisedLoss(1.0, 10.0, freeze_world_enhancer=args.freeze_world_enhancer)
 
     history = []
@@ -69,7 +70,7 @@ def main(argv=None):
         loss = criterion(end_points)
         loss.backward()
         if reducer is not None:
-            opt.step(reducer.sum_(opt.pack_grads()), grad_scale=1.0 / world)
+            opt.step(reducer.finish(), grad_scale=1.0 / world)
         else:
             opt.step()
         sched.step()
