@@ -1,6 +1,6 @@
 #!/bin/bash
 # A/B of the fused mid-size-layer backward inside the training step (one box)
-B="python bench.py --no-roofline --no-cpu-baseline --steps 50 --warmup 10"
+cd "$(dirname "$0")/../.." && B="python bench.py --no-roofline --no-cpu-baseline --steps 50 --warmup 10"
 ms() { tail -1 | python -c "import sys,json; print(json.loads(sys.stdin.read())['ms_per_step'])"; }
 for i in 1 2; do
   echo -n "pair : "; ISTNET_PW_TUNE=9:0 $B 2>&1 | ms
