@@ -146,6 +146,12 @@ ISTNET_PN2_API int istnet_pw_bwd_stats(int b, int c, int p, int nsample, const f
 ISTNET_PN2_API int istnet_pw_bwd_stats_pooled(int b, int c, int g, const float *d_pooled,
                                               long long pooled_bstride, const float *ymax, const float *bn,
                                               float *part_g, float *part_gy, void *stream);
+/* istnet_pw_bwd_stats_pooled followed by istnet_bn_finalize_bwd in one launch (count = b * g * nsample points per
+ * channel): dgamma, dbeta and the three BN-backward constants bwdc [3][c] of the last layer of a set-abstraction scale */
+ISTNET_PN2_API int istnet_bn_bwd_pooled_finalize(int b, int c, int g, double count, int training, const float *d_pooled,
+                                                 long long pooled_bstride, const float *ymax, const float *gamma,
+                                                 const float *bn, float *dgamma, float *dbeta, float *bwdc,
+                                                 void *stream);
 /* partials -> dgamma, dbeta, bwdc[3][c]; training = 0 treats BN as a fixed affine map (eval mode) */
 ISTNET_PN2_API int istnet_bn_finalize_bwd(int c, int nt, double count, int training, const float *part_g,
                                           const float *part_gy, const float *gamma, const float *bn,

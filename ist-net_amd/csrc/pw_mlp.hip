@@ -1080,6 +1080,56 @@ __global__ __launch_bounds__(kFinThreads) void bn_finalize_bwd_kernel(int C, int
   }
 }
 
+// pw_bwd_stats_pooled_kernel + bn_finalize_bwd_kernel in ONE launch (the last layer of a set-abstraction scale: both are
+// tiny and sit back to back on the critical chain of the backward pass).  One workgroup of 16 waves per channel; wave w
+// sums the clouds w, w + 16, ...: per cloud the same float wave sum over the G groups as the stand-alone kernel, accumulated over
+// clouds in double.
+constexpr int kPoolFinWaves = 16;
+__global__ __launch_bounds__(64 * kPoolFinWaves) void bn_bwd_pooled_finalize_kernel(
+    int C, int B, int G, double count, int training, const float* __restrict__ pooled, long long pooled_bstride,
+    const float* __restrict__ ymax, const float* __restrict__ gamma, const float* __restrict__ bn,
+    float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ bwdc) {
+  const int c = blockIdx.x, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const float s = bn[c], h = bn[C + c];
+  double ag = 0.0, agy = 0.0;
+  for (int b = wv; b < B; b += kPoolFinWaves) {
+    const float* d = pooled + (size_t)b * pooled_bstride + (size_t)c * G;
+    const float* v = ymax + ((size_t)b * C + c) * G;
+    float sg = 0.f, sgy = 0.f;
+    for (int g = lane; g < G; g += 64) {
+      const float y = v[g];
+      const float gr = (y * s + h > 0.f) ? d[g] : 0.f;
+      sg += gr;
+      sgy += gr * y;
+    }
+    ag += (double)wave_sum(sg);
+    agy += (double)wave_sum(sgy);
+  }
+  __shared__ double sh[2][kPoolFinWaves];
+  if (lane == 0) { sh[0][wv] = ag; sh[1][wv] = agy; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double sg = 0.0, sgy = 0.0;
+#pragma unroll
+    for (int k = 0; k < kPoolFinWaves; ++k) { sg += sh[0][k]; sgy += sh[1][k]; }
+    const double mean = bn[2 * C + c], istd = bn[3 * C + c];
+    const double dg = (sgy - mean * sg) * istd;
+    dgamma[c] = (float)dg;
+    dbeta[c] = (float)sg;
+    const double gsc = (double)gamma[c] * istd;
+    if (training) {
+      const double c1 = sg / count, c2 = dg / count;
+      bwdc[0 * C + c] = (float)gsc;
+      bwdc[1 * C + c] = (float)(-gsc * c1 + gsc * mean * istd * c2);
+      bwdc[2 * C + c] = (float)(-gsc * istd * c2);
+    } else {
+      bwdc[0 * C + c] = (float)gsc;
+      bwdc[1 * C + c] = 0.f;
+      bwdc[2 * C + c] = 0.f;
+    }
+  }
+}
+
 // dY for 4 consecutive points of one channel, split into a pure load (issued early, nothing consumed)
 // and the arithmetic (run after the MFMAs of the previous chunk).
 struct DyRaw {
@@ -3186,6 +3236,16 @@ int istnet_pw_bwd_stats_pooled(int b, int c, int g, const float* d_pooled, long 
   if (b <= 0 || c <= 0 || g <= 0 || d_pooled == nullptr || ymax == nullptr) return ISTNET_PN2_EINVAL;
   hipLaunchKernelGGL(pw_bwd_stats_pooled_kernel, dim3(c, b), dim3(64), 0, as_stream(stream), c, g, d_pooled,
                      pooled_bstride > 0 ? pooled_bstride : (long long)c * g, ymax, bn, bn + c, part_g, part_gy);
+  return (int)hipGetLastError();
+}
+
+int istnet_bn_bwd_pooled_finalize(int b, int c, int g, double count, int training, const float* d_pooled,
+                                  long long pooled_bstride, const float* ymax, const float* gamma, const float* bn,
+                                  float* dgamma, float* dbeta, float* bwdc, void* stream) {
+  if (b <= 0 || c <= 0 || g <= 0 || !d_pooled || !ymax || !gamma || !bn || !dgamma || !dbeta || !bwdc) return ISTNET_PN2_EINVAL;
+  hipLaunchKernelGGL(bn_bwd_pooled_finalize_kernel, dim3(c), dim3(64 * kPoolFinWaves), 0, as_stream(stream), c, b, g, count,
+                     training, d_pooled, pooled_bstride > 0 ? pooled_bstride : (long long)c * g, ymax, gamma, bn, dgamma,
+                     dbeta, bwdc);
   return (int)hipGetLastError();
 }
 

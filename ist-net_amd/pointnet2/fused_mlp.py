@@ -536,6 +536,7 @@ def _compact_ok(lib, ga, layers, params, needs_backward, needs_feature_grad):
 
 
 USE_FUSED_SMALL_BWD = True
+USE_POOLED_FINALIZE = True   # last layer of a scale: pooled statistics + BN-backward finalize in one launch
 USE_FUSED_MID_BWD = True     # 64 / 128-channel layers: dgrad + wgrad + statistics in one pass (pw_bwd_mid_kernel)
 USE_SPLIT_LAYER0 = True
 USE_CSR_SCATTER = True     # False: LDS-atomic scatter (steps are then not bit-reproducible)
@@ -596,8 +597,11 @@ def _backward_stack(lib, dev, st, b, c0, g, s, x, gather, training, ys, bns, par
         dd, dp, da = _p(d_dense), _p(d_pooled), _p(d_arg)
         pbs = pooled_bstride if (pooled and li == n - 1) else 0
         grad_elems = b * cout * (p if dd is not None else p // s)
+        part = None
         if fused_part is not None:
             part, nt_l = fused_part, fused_nt
+        elif ns_arg and USE_POOLED_FINALIZE and not (li == 0 and layer0_hook is not None):
+            pass       # statistics and finalize in one launch, below
         elif ns_arg:   # gradient through the max-pool: statistics from the (B, C, G) tensors only
             part, nt_l = _empty((2, cout, b), torch.float32, dev), b
             _native.check(lib.istnet_pw_bwd_stats_pooled(b, cout, g, dp, pbs, _ymax_ptr(d_arg, b * cout * g),
@@ -611,10 +615,15 @@ def _backward_stack(lib, dev, st, b, c0, g, s, x, gather, training, ys, bns, par
         dgamma = _grad_dest(gamma, (cout,), dev)
         dbeta = _grad_dest(params[3 * li + 2], (cout,), dev)
         bwdc = _empty((3, cout), torch.float32, dev)
-        _native.check(lib.istnet_bn_finalize_bwd(
-            cout, nt_l, float(b * p), 1 if training else 0, part[0].data_ptr(), part[1].data_ptr(),  # training=False for bias stacks
-            gamma.data_ptr(), bn.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), bwdc.data_ptr(), st),
-            "bn_finalize_bwd")
+        if part is None:
+            _native.check(lib.istnet_bn_bwd_pooled_finalize(
+                b, cout, g, float(b * p), 1 if training else 0, dp, pbs, _ymax_ptr(d_arg, b * cout * g), gamma.data_ptr(),
+                bn.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), bwdc.data_ptr(), st), "bn_bwd_pooled_finalize")
+        else:
+            _native.check(lib.istnet_bn_finalize_bwd(
+                cout, nt_l, float(b * p), 1 if training else 0, part[0].data_ptr(), part[1].data_ptr(),  # training=False for bias stacks
+                gamma.data_ptr(), bn.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), bwdc.data_ptr(), st),
+                "bn_finalize_bwd")
         grads[3 * li + 1] = dgamma
         grads[3 * li + 2] = dbeta
         if li == 0 and layer0_hook is not None:
