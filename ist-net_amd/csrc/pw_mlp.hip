@@ -809,10 +809,11 @@ __global__ __launch_bounds__(256) void bn_relu_pool_kernel(int C, int G, const f
                                                            const float* __restrict__ scale,
                                                            const float* __restrict__ shift,
                                                            float* __restrict__ out, long long out_bstride,
-                                                           uint8_t* __restrict__ arg, float* __restrict__ ymax) {
-  const int bc = blockIdx.y;
+                                                           uint8_t* __restrict__ arg, float* __restrict__ ymax,
+                                                           int rows) {
   const int g = blockIdx.x * 256 + threadIdx.x;
   if (g >= G) return;
+  for (int bc = blockIdx.y; bc < rows; bc += gridDim.y) {   // rows = B * C may exceed the 65 535 limit of grid.y
   const float s = scale[bc % C], h = shift[bc % C];
   const float4* src = reinterpret_cast<const float4*>(y + ((size_t)bc * G + g) * (S4 * 4));
   float best = -1.f;  // relu output is >= 0, so the first element always replaces this
@@ -831,19 +832,21 @@ __global__ __launch_bounds__(256) void bn_relu_pool_kernel(int C, int G, const f
   out[(size_t)(bc / C) * out_bstride + (size_t)(bc % C) * G + g] = best;
   arg[(size_t)bc * G + g] = (uint8_t)besti;
   if (ymax != nullptr) ymax[(size_t)bc * G + g] = raw;
+  }
 }
 __global__ __launch_bounds__(256) void bn_relu_apply_kernel(int C, int P4, const float* __restrict__ y,
                                                             const float* __restrict__ scale,
                                                             const float* __restrict__ shift,
-                                                            float* __restrict__ out) {
-  const int bc = blockIdx.y;
+                                                            float* __restrict__ out, int rows) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= P4) return;
-  const float s = scale[bc % C], h = shift[bc % C];
-  float4 v = reinterpret_cast<const float4*>(y + (size_t)bc * P4 * 4)[i];
-  v.x = fmaxf(v.x * s + h, 0.f); v.y = fmaxf(v.y * s + h, 0.f);
-  v.z = fmaxf(v.z * s + h, 0.f); v.w = fmaxf(v.w * s + h, 0.f);
-  reinterpret_cast<float4*>(out + (size_t)bc * P4 * 4)[i] = v;
+  for (int bc = blockIdx.y; bc < rows; bc += gridDim.y) {
+    const float s = scale[bc % C], h = shift[bc % C];
+    float4 v = reinterpret_cast<const float4*>(y + (size_t)bc * P4 * 4)[i];
+    v.x = fmaxf(v.x * s + h, 0.f); v.y = fmaxf(v.y * s + h, 0.f);
+    v.z = fmaxf(v.z * s + h, 0.f); v.w = fmaxf(v.w * s + h, 0.f);
+    reinterpret_cast<float4*>(out + (size_t)bc * P4 * 4)[i] = v;
+  }
 }
 
 // bn[4][C] of a layer whose normalisation is a fixed affine map: eval-mode BatchNorm (running statistics) or a
@@ -899,15 +902,16 @@ __global__ __launch_bounds__(256) void affine_consts_multi_kernel(AffineBatch ab
 __global__ __launch_bounds__(256) void affine_apply_kernel(int C, int P4, int relu, const float* __restrict__ y,
                                                            const float* __restrict__ scale,
                                                            const float* __restrict__ shift,
-                                                           float* __restrict__ out) {
-  const int bc = blockIdx.y;
+                                                           float* __restrict__ out, int rows) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= P4) return;
-  const float s = scale[bc % C], h = shift[bc % C];
-  float4 v = reinterpret_cast<const float4*>(y + (size_t)bc * P4 * 4)[i];
-  v.x = v.x * s + h; v.y = v.y * s + h; v.z = v.z * s + h; v.w = v.w * s + h;
-  if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-  reinterpret_cast<float4*>(out + (size_t)bc * P4 * 4)[i] = v;
+  for (int bc = blockIdx.y; bc < rows; bc += gridDim.y) {
+    const float s = scale[bc % C], h = shift[bc % C];
+    float4 v = reinterpret_cast<const float4*>(y + (size_t)bc * P4 * 4)[i];
+    v.x = v.x * s + h; v.y = v.y * s + h; v.z = v.z * s + h; v.w = v.w * s + h;
+    if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+    reinterpret_cast<float4*>(out + (size_t)bc * P4 * 4)[i] = v;
+  }
 }
 
 // ============================================================================================
@@ -969,19 +973,22 @@ __global__ __launch_bounds__(256) void pw_channel_stats_kernel(int C, int P, con
 // feeds several small products (feature-propagation layer 0).  grid (ceil(P/4 / 256), B*C)
 __global__ __launch_bounds__(256) void pw_dy_kernel(int C, int P4, const float* __restrict__ y,
                                                     const float* __restrict__ d, const float* __restrict__ bn,
-                                                    const float* __restrict__ bwdc, float* __restrict__ out) {
-  const int bc = blockIdx.y, c = bc % C;
+                                                    const float* __restrict__ bwdc, float* __restrict__ out,
+                                                    int rows) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= P4) return;
-  const float rs = bn[c], rh = bn[C + c], ca = bwdc[c], cb = bwdc[C + c], cc = bwdc[2 * C + c];
-  const float4 v = reinterpret_cast<const float4*>(y + (size_t)bc * P4 * 4)[i];
-  const float4 g = reinterpret_cast<const float4*>(d + (size_t)bc * P4 * 4)[i];
-  float4 o;
-  o.x = ca * ((v.x * rs + rh > 0.f) ? g.x : 0.f) + cb + cc * v.x;
-  o.y = ca * ((v.y * rs + rh > 0.f) ? g.y : 0.f) + cb + cc * v.y;
-  o.z = ca * ((v.z * rs + rh > 0.f) ? g.z : 0.f) + cb + cc * v.z;
-  o.w = ca * ((v.w * rs + rh > 0.f) ? g.w : 0.f) + cb + cc * v.w;
-  reinterpret_cast<float4*>(out + (size_t)bc * P4 * 4)[i] = o;
+  for (int bc = blockIdx.y; bc < rows; bc += gridDim.y) {
+    const int c = bc % C;
+    const float rs = bn[c], rh = bn[C + c], ca = bwdc[c], cb = bwdc[C + c], cc = bwdc[2 * C + c];
+    const float4 v = reinterpret_cast<const float4*>(y + (size_t)bc * P4 * 4)[i];
+    const float4 g = reinterpret_cast<const float4*>(d + (size_t)bc * P4 * 4)[i];
+    float4 o;
+    o.x = ca * ((v.x * rs + rh > 0.f) ? g.x : 0.f) + cb + cc * v.x;
+    o.y = ca * ((v.y * rs + rh > 0.f) ? g.y : 0.f) + cb + cc * v.y;
+    o.z = ca * ((v.z * rs + rh > 0.f) ? g.z : 0.f) + cb + cc * v.z;
+    o.w = ca * ((v.w * rs + rh > 0.f) ? g.w : 0.f) + cb + cc * v.w;
+    reinterpret_cast<float4*>(out + (size_t)bc * P4 * 4)[i] = o;
+  }
 }
 
 // per-channel partial sums of g and g * y  (-> dbeta, dgamma after finalize)
@@ -2818,6 +2825,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_multi_kernel(ReduceBatch rb)
 // ---------------------------------------------------------------------------------------------
 inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+inline int grid_rows(long long rows) { return (int)(rows < 65535 ? rows : 65535); }   // grid.y limit; the kernels loop over rows
 
 // tile selection shared by the forward launch and istnet_pw_stat_tiles()
 enum TileCfg { kCfg128x128, kCfg64x128, kCfg64x64, kCfg32x256, kCfg128x64, kCfg256x64 };   // 128x64 / 256x64: dgrad only
@@ -3159,14 +3167,14 @@ int istnet_bn_relu_pool(int b, int c, int g, int s, const float* y, const float*
   if (s == 1) {
     const long long P = g;
     if ((P & 3) || out_bstride != (long long)c * g) return ISTNET_PN2_EINVAL;
-    hipLaunchKernelGGL(bn_relu_apply_kernel, dim3(ceil_div((int)(P / 4), 256), b * c), dim3(256), 0,
-                       as_stream(stream), c, (int)(P / 4), y, scale, shift, out);
+    hipLaunchKernelGGL(bn_relu_apply_kernel, dim3(ceil_div((int)(P / 4), 256), grid_rows(b * c)), dim3(256), 0,
+                       as_stream(stream), c, (int)(P / 4), y, scale, shift, out, b * c);
     return (int)hipGetLastError();
   }
-  const dim3 grid(ceil_div(g, 256), b * c);
+  const dim3 grid(ceil_div(g, 256), grid_rows(b * c));
 #define ISTNET_POOL(S4)                                                                                  \
   hipLaunchKernelGGL((bn_relu_pool_kernel<S4>), grid, dim3(256), 0, as_stream(stream), c, g, y, scale,  \
-                     shift, out, out_bstride, arg, ymax)
+                     shift, out, out_bstride, arg, ymax, b * c)
   switch (s) {
     case 4: ISTNET_POOL(1); break;
     case 8: ISTNET_POOL(2); break;
@@ -3208,8 +3216,8 @@ int istnet_affine_consts_multi(int n, const int* c, const float* const* gamma, c
 
 int istnet_affine_apply(int b, int c, int p, int relu, const float* y, const float* bn, float* out, void* stream) {
   if (b <= 0 || c <= 0 || p <= 0 || (p & 3)) return ISTNET_PN2_EINVAL;
-  hipLaunchKernelGGL(affine_apply_kernel, dim3(ceil_div(p / 4, 256), b * c), dim3(256), 0, as_stream(stream), c,
-                     p / 4, relu, y, bn, bn + c, out);
+  hipLaunchKernelGGL(affine_apply_kernel, dim3(ceil_div(p / 4, 256), grid_rows(b * c)), dim3(256), 0, as_stream(stream), c,
+                     p / 4, relu, y, bn, bn + c, out, b * c);
   return (int)hipGetLastError();
 }
 
@@ -3226,8 +3234,8 @@ int istnet_pw_channel_stats(int b, int c, int p, const float* y, float* part_sum
 int istnet_pw_dy(int b, int c, int p, const float* y, const float* d_dense, const float* bn, const float* bwdc,
                  float* out, void* stream) {
   if (b <= 0 || c <= 0 || p <= 0 || (p & 3)) return ISTNET_PN2_EINVAL;
-  hipLaunchKernelGGL(pw_dy_kernel, dim3(ceil_div(p / 4, 256), b * c), dim3(256), 0, as_stream(stream), c, p / 4, y,
-                     d_dense, bn, bwdc, out);
+  hipLaunchKernelGGL(pw_dy_kernel, dim3(ceil_div(p / 4, 256), grid_rows(b * c)), dim3(256), 0, as_stream(stream), c, p / 4, y,
+                     d_dense, bn, bwdc, out, b * c);
   return (int)hipGetLastError();
 }
 

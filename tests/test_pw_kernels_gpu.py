@@ -513,3 +513,30 @@ def test_inverse_lists_large_slot_count_takes_the_per_cloud_kernel():
     off, ent = _ext.ball_csr(idx, 2048)
     want_off, want_ent = _lists_reference(idx.reshape(2, -1), 2048)
     assert torch.equal(off.cpu(), want_off) and torch.equal(ent.cpu(), want_ent)
+
+
+def test_row_kernels_beyond_the_grid_y_limit():
+    """B * C = 81 920 rows (> 65 535, the limit of grid.y): the BN + ReLU (+ max-pool) tail and the dY kernel loop over
+    rows instead of failing the launch."""
+    lib = _native.lib()
+    b, c, g, s = 160, 512, 4, 4
+    gen = torch.Generator().manual_seed(9)
+    y = torch.randn(b, c, g * s, generator=gen).to(DEV)
+    bn = _bn_block(c, gen)
+    out = torch.empty(b, c, g, device=DEV)
+    arg = torch.empty(b, c, g, dtype=torch.uint8, device=DEV)
+    ymax = torch.empty(b, c, g, device=DEV)
+    assert lib.istnet_bn_relu_pool(b, c, g, s, y.data_ptr(), bn.data_ptr(), out.data_ptr(), 0, arg.data_ptr(), ymax.data_ptr(),
+                                   _st()) == 0
+    act = torch.relu(y * bn[0].view(1, -1, 1) + bn[1].view(1, -1, 1)).view(b, c, g, s)
+    torch.testing.assert_close(out, act.amax(dim=3), rtol=0, atol=0)
+    dense = torch.empty(b, c, g * s, device=DEV)
+    assert lib.istnet_bn_relu_pool(b, c, g * s, 1, y.data_ptr(), bn.data_ptr(), dense.data_ptr(), 0, None, None, _st()) == 0
+    torch.testing.assert_close(dense, act.view(b, c, g * s), rtol=0, atol=0)
+    d = torch.randn(b, c, g * s, generator=gen).to(DEV)
+    bwdc = torch.stack([torch.rand(c, generator=gen) + 0.5, torch.randn(c, generator=gen) * 0.01,
+                        torch.randn(c, generator=gen) * 0.01]).contiguous().to(DEV)
+    dy = torch.empty_like(y)
+    assert lib.istnet_pw_dy(b, c, g * s, y.data_ptr(), d.data_ptr(), bn.data_ptr(), bwdc.data_ptr(), dy.data_ptr(), _st()) == 0
+    want = bwdc[0].view(1, -1, 1) * (d * (act.view(b, c, -1) > 0)) + bwdc[1].view(1, -1, 1) + bwdc[2].view(1, -1, 1) * y
+    torch.testing.assert_close(dy, want, rtol=1e-6, atol=1e-6)
