@@ -62,6 +62,9 @@ ISTNET_PN2_API int istnet_pw_forward_ld_tiles(int b, int cin, int cout, int p);
  * istnet_pw_dgrad_tiles = statistics partials per input channel the launch writes (dense: 1 = dense gradient source). */
 ISTNET_PN2_API int istnet_pw_dgrad_sk(int b, int m_rows, int cout, int p);
 ISTNET_PN2_API int istnet_pw_dgrad_tiles(int b, int m_rows, int cout, int p, int dense);
+/* 1 when istnet_pw_dgrad runs the loader / MFMA-wave kernel (pw_bwd_mid_kernel<8, 4, POOLED, false>: cout = 256, all 128
+ * input channels (ci_off = 0, cin_total = m_rows), p % 128 == 0, statistics requested; key 19 disables) */
+ISTNET_PN2_API int istnet_pw_dgrad_rs(int b, int m_rows, int cout, int p, int dense);
 
 /* istnet_pw_forward with w a column slice of a wider row-major matrix: row stride ldw >= cin */
 ISTNET_PN2_API int istnet_pw_forward_ld(int b, int cin, int cout, int p, const float *x, const float *w, int ldw,

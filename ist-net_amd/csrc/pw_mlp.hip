@@ -2476,7 +2476,7 @@ struct MidCfg {
   static_assert(NY >= 1 && NX >= 1 && WGM * WGN * WGK == 4 && TM * WGM == COT && TN * WGN == CIT, "unsupported shape");
 };
 
-template <int COT, int CIT, bool POOLED>
+template <int COT, int CIT, bool POOLED, bool WGRAD = true>   // WGRAD false: dA and its statistics only (cout = 256)
 __global__ __launch_bounds__(kMidThreads) void pw_bwd_mid_kernel(
     int P, long long total, int split_len, const float* __restrict__ w, const float* __restrict__ x,
     const float* __restrict__ in_scale, const float* __restrict__ in_shift, const float* __restrict__ y, GradSrc gs,
@@ -2595,7 +2595,7 @@ __global__ __launch_bounds__(kMidThreads) void pw_bwd_mid_kernel(
       }
     }
     __syncthreads();                               // the four barriers of the compute waves' epilogue
-    if (C::WGK == 2) { __syncthreads(); __syncthreads(); }
+    if (WGRAD && C::WGK == 2) { __syncthreads(); __syncthreads(); }
     __syncthreads();
     return;
   }
@@ -2671,7 +2671,7 @@ __global__ __launch_bounds__(kMidThreads) void pw_bwd_mid_kernel(
       }
     }
     // ---- wgrad: this wave's TM x TN tiles over its share of the chunk's points ----
-    {
+    if (WGRAD) {
       constexpr int KP = PT / C::WGK;          // points of this wave's K range
       const float* ap = dYs + (32 * wm * TM + l31) * LD + wk * KP + 4 * half;
       const float* bp = Xs + (32 * wn * TN + l31) * LD + wk * KP + 4 * half;
@@ -2714,7 +2714,7 @@ __global__ __launch_bounds__(kMidThreads) void pw_bwd_mid_kernel(
   // ---- per-workgroup results ----
   __syncthreads();      // the compute waves are done with the tiles
   float* red = mid_lds;
-  if (C::WGK == 2) {    // two waves hold halves of the same dW tile
+  if (WGRAD && C::WGK == 2) {    // two waves hold halves of the same dW tile
     if (wk == 1) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) red[(cw & 1) * 1024 + r * 64 + lane] = accw[0][0][r];
@@ -2726,7 +2726,7 @@ __global__ __launch_bounds__(kMidThreads) void pw_bwd_mid_kernel(
     }
     __syncthreads();
   }
-  if (wk == 0) {
+  if (WGRAD && wk == 0) {
     float* out = dw_part + (size_t)blockIdx.x * COUT * CIN;
 #pragma unroll
     for (int tm = 0; tm < TM; ++tm)
@@ -2870,6 +2870,7 @@ int g_exp_no_fast = 0;        // experiment (key 6): 1 = never take the interior
 inline int wgrad_mt(int cout, long long pts) { return (cout >= 128 && pts > g_wg_small_pts) ? 128 : 64; }
 inline int wgrad_nt(int cin, long long pts) { return (cin >= 96 && pts > g_wg_small_pts) ? 128 : 64; }
 int g_fwd_sk_enable = 1;       // key 15: 0 = no pw_fwd_sk_kernel
+int g_dgrad_rs_enable = 1;     // key 19: 0 = no role-split dgrad for cout = 256 / cin = 128
 int g_dgrad_sk_enable = 1;     // key 17: 0 = no pw_dgrad_sk_kernel
 int g_dgrad_sk_min_k = 256;    // key 18
 int g_fwd_sk_max_tiles = 1024; // key 16: launches with more 32 x 128 tiles than this keep the LDS-tiled kernel (measured:
@@ -2957,6 +2958,7 @@ int istnet_pw_set_tuning(int key, int value) {
     case 13: g_fwd2_enable = value != 0; return 0;
     case 15: g_fwd_sk_enable = value != 0; return 0;
     case 17: g_dgrad_sk_enable = value != 0; return 0;
+    case 19: g_dgrad_rs_enable = value != 0; return 0;
     case 18: g_dgrad_sk_min_k = value > 0 ? value : 256; return 0;
     case 16: g_fwd_sk_max_tiles = value > 0 ? value : 1024; return 0;
     case 14: g_fwd2_min_waves = value > 0 ? value : 2048; return 0;
@@ -3281,6 +3283,8 @@ int istnet_bn_finalize_bwd(int c, int nt, double count, int training, const floa
 }
 
 // ---- pw_dgrad_sk_kernel (small launches, dense gradient source) ----
+static bool dgrad_rs_ok(int m_rows, int cout, int p);
+static int bwd_mid_len(int b, int cin, int p);
 static bool dgrad_sk_ok(int b, int m_rows, int cout, int p) {
   // (measured, tools/bench_pw.py: +6-17 % at K = cout >= 256, 10-50 % SLOWER at K = 64-128 -- forming dY costs ~14 VALU
   //  per element and short K leaves nothing to hide it behind)
@@ -3289,9 +3293,22 @@ static bool dgrad_sk_ok(int b, int m_rows, int cout, int p) {
 }
 /* 1 when istnet_pw_dgrad with a dense gradient source runs the split-K kernel for this shape */
 int istnet_pw_dgrad_sk(int b, int m_rows, int cout, int p) { return dgrad_sk_ok(b, m_rows, cout, p) ? 1 : 0; }
+int istnet_pw_dgrad_rs(int b, int m_rows, int cout, int p, int dense) {
+  return (dgrad_rs_ok(m_rows, cout, p) && !(dense && dgrad_sk_ok(b, m_rows, cout, p))) ? 1 : 0;
+}
 int istnet_pw_dgrad_tiles(int b, int m_rows, int cout, int p, int dense) {
   if (dense && dgrad_sk_ok(b, m_rows, cout, p)) return b * (p / 128);
+  if (dgrad_rs_ok(m_rows, cout, p)) {       // (a launch with ci_off = 0, cin_total = m_rows and statistics)
+    const int len = bwd_mid_len(b, m_rows, p);
+    return (int)(((long long)b * p + len - 1) / len);
+  }
   return b * ceil_div(p, cfg_nt(pick_dgrad_cfg(b, m_rows, p, g_force_dgrad_cfg)));
+}
+
+// ---- dgrad through the loader / MFMA-wave kernel (pw_bwd_mid_kernel<8, 4, POOLED, false>): cout = 256, all 128 input
+// channels, statistics requested -- the last layer of an SA4 scale, whose weight matrix is too large for the fused form ----
+static bool dgrad_rs_ok(int m_rows, int cout, int p) {
+  return g_dgrad_rs_enable && cout == 256 && m_rows == 128 && p % 128 == 0;
 }
 
 static int launch_pw_dgrad(int b, int cin_total, int ci_off, int m_rows, int cout, int p, int nsample,
@@ -3304,6 +3321,31 @@ static int launch_pw_dgrad(int b, int cin_total, int ci_off, int m_rows, int cou
   if (part_g != nullptr && (y_in == nullptr || bn_in == nullptr || part_gy == nullptr)) return ISTNET_PN2_EINVAL;
   if (d_dense == nullptr && (d_pooled == nullptr || arg == nullptr || nsample <= 0 || (nsample & 3)))
     return ISTNET_PN2_EINVAL;
+  if (ncols == nullptr && part_g != nullptr && ci_off == 0 && cin_total == m_rows && dgrad_rs_ok(m_rows, cout, p) &&
+      !(d_dense != nullptr && dgrad_sk_ok(b, m_rows, cout, p))) {
+    GradSrc gsr{d_dense, d_pooled, arg, nsample, pooled_bstride > 0 ? pooled_bstride : (long long)GS_C * (nsample > 0 ? p / nsample : 0), GS_C};
+    const int len = bwd_mid_len(b, m_rows, p);
+    const int splits = (int)(((long long)b * p + len - 1) / len);
+    constexpr size_t lds = MidCfg<8, 4>::LDS_BYTES;
+    static bool attr_set = false;
+    if (!attr_set) {
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(&pw_bwd_mid_kernel<8, 4, false, false>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
+          hipFuncSetAttribute(reinterpret_cast<const void*>(&pw_bwd_mid_kernel<8, 4, true, false>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        return ISTNET_PN2_EINVAL;
+      attr_set = true;
+    }
+    if (d_dense != nullptr)
+      hipLaunchKernelGGL((pw_bwd_mid_kernel<8, 4, false, false>), dim3(splits), dim3(kMidThreads), lds, as_stream(stream), p,
+                         (long long)b * p, len, w, y_in, bn_in, bn_in + m_rows, y, gsr, bn, bwdc, dx, part_g, part_gy, splits,
+                         nullptr);
+    else
+      hipLaunchKernelGGL((pw_bwd_mid_kernel<8, 4, true, false>), dim3(splits), dim3(kMidThreads), lds, as_stream(stream), p,
+                         (long long)b * p, len, w, y_in, bn_in, bn_in + m_rows, y, gsr, bn, bwdc, dx, part_g, part_gy, splits,
+                         nullptr);
+    return (int)hipGetLastError();
+  }
   if (d_dense != nullptr && ncols == nullptr && dgrad_sk_ok(b, m_rows, cout, p)) {
     const int tpc = p / 128;
     hipLaunchKernelGGL(pw_dgrad_sk_kernel, dim3(tpc * b, ceil_div(m_rows, 32)), dim3(kThreads), 0, as_stream(stream),

@@ -70,11 +70,13 @@ def _fwd_ld_kname(lib, b, cin, cout, p):
     return _kname("pw_fwd_kernel", lib.istnet_pw_tile_cfg(b, cout, p), 0)
 
 
-def _dgrad_kname(lib, b, rows, cout, p, dense=False):
+def _dgrad_kname(lib, b, rows, cout, p, dense=False, stats=False):
     """pw_dgrad_kernel<M_T, N_T, WM, WN, FAST> as launch_pw_dgrad picks it: FAST = every tile interior and the
     reduction length a multiple of the k-tile (kKT = 16)."""
     if dense and lib.istnet_pw_dgrad_sk(b, rows, cout, p):
         return "pw_dgrad_sk_kernel"          # small launch, dense gradient source: K split over the waves, no LDS operands
+    if stats and lib.istnet_pw_dgrad_rs(b, rows, cout, p, 1 if dense else 0):
+        return "pw_bwd_mid_kernel<8, 4, %s, false>" % ("false" if dense else "true")   # dgrad-only mode
     cfg = lib.istnet_pw_dgrad_tile_cfg(b, rows, p)
     mt, nt = cfg // 1000, cfg % 1000
     fast = rows % mt == 0 and p % nt == 0 and cout % 16 == 0
@@ -719,7 +721,7 @@ def _backward_stack(lib, dev, st, b, c0, g, s, x, gather, training, ys, bns, par
             else:
                 y_in = bn_in = pg = pgy = None
             _native.check(_native.timed(
-                _dgrad_kname(lib, b, rows, cout, p, dense=dd is not None), 2.0 * b * p * rows * cout,
+                _dgrad_kname(lib, b, rows, cout, p, dense=dd is not None, stats=li > 0 and not use_gather), 2.0 * b * p * rows * cout,
                 4.0 * (b * p * (rows + cout + (rows if li > 0 else 0)) + grad_elems), lambda: lib.istnet_pw_dgrad(
                     b, cin, ci_off, rows, cout, p, ns_arg, w2.data_ptr(), y.data_ptr(), dd, dp, pbs, da,
                     bn.data_ptr(), bwdc.data_ptr(), dprev.data_ptr(), y_in, bn_in, pg, pgy, st)), "pw_dgrad")

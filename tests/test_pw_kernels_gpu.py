@@ -334,6 +334,57 @@ def test_dgrad_split_k_kernel_for_small_launches(b, cin_total, ci_off, rows, cou
     assert lib.istnet_pw_set_tuning(18, 0) == 0
 
 
+@pytest.mark.parametrize("b,p,pooled", [(3, 512, True), (2, 1024, False), (32, 2048, True)])
+def test_dgrad_loader_mfma_roles_for_256_output_channels(b, p, pooled):
+    """istnet_pw_dgrad at cout = 256, cin = 128 with statistics: the dgrad-only mode of pw_bwd_mid_kernel (loader / MFMA
+    wave roles) against float64 and against pw_dgrad_kernel (tuning key 19 = 0), dense and pooled gradient source."""
+    lib = _native.lib()
+    cin, cout, s = 128, 256, 16
+    assert lib.istnet_pw_set_tuning(17, 0) == 0          # (keep the small dense cases off the split-K kernel)
+    try:
+        assert lib.istnet_pw_dgrad_rs(b, cin, cout, p, 0 if pooled else 1) == 1
+        g = torch.Generator().manual_seed(b + p)
+        w = (torch.randn(cout, cin, generator=g) / cout ** 0.5).to(DEV)
+        y = torch.randn(b, cout, p, generator=g).to(DEV)
+        bn, bn_in = _bn_block(cout, g), _bn_block(cin, g)
+        bwdc = torch.stack([torch.rand(cout, generator=g) + 0.5, torch.randn(cout, generator=g) * 0.01,
+                            torch.randn(cout, generator=g) * 0.01]).contiguous().to(DEV)
+        y_in = torch.randn(b, cin, p, generator=g).to(DEV)
+        if pooled:
+            gr = p // s
+            dpool = torch.randn(b, cout, gr, generator=g).to(DEV)
+            arg = torch.randint(0, s, (b, cout, gr), generator=g, dtype=torch.uint8).to(DEV)
+            src = (None, dpool.data_ptr(), 0, arg.data_ptr())
+            gdense = torch.zeros(b, cout, gr, s, device=DEV).scatter_(3, arg.long().unsqueeze(-1), dpool.unsqueeze(-1)).reshape(b, cout, p)
+        else:
+            gdense = torch.randn(b, cout, p, generator=g).to(DEV)
+            src = (gdense.data_ptr(), None, 0, None)
+        d = torch.float64
+        mask = (y * bn[0].view(1, -1, 1) + bn[1].view(1, -1, 1)) > 0
+        dy = bwdc[0].to(d).view(1, -1, 1) * (gdense.to(d) * mask) + bwdc[1].to(d).view(1, -1, 1) + bwdc[2].to(d).view(1, -1, 1) * y.to(d)
+        want = torch.matmul(w.to(d).t(), dy)
+        gq = want * ((y_in * bn_in[0].view(1, -1, 1) + bn_in[1].view(1, -1, 1)) > 0)
+        outs = []
+        for enable in (1, 0):
+            assert lib.istnet_pw_set_tuning(19, enable) == 0
+            try:
+                nt = lib.istnet_pw_dgrad_tiles(b, cin, cout, p, 0 if pooled else 1)
+                dx = torch.full((b, cin, p), float("nan"), device=DEV)
+                part = torch.full((2, cin, nt), float("nan"), device=DEV)
+                assert lib.istnet_pw_dgrad(b, cin, 0, cin, cout, p, s if pooled else 0, w.data_ptr(), y.data_ptr(), *src,
+                                           bn.data_ptr(), bwdc.data_ptr(), dx.data_ptr(), y_in.data_ptr(), bn_in.data_ptr(),
+                                           part[0].data_ptr(), part[1].data_ptr(), _st()) == 0
+                outs.append((dx, part))
+            finally:
+                lib.istnet_pw_set_tuning(19, 1)
+        for dx, part in outs:
+            torch.testing.assert_close(dx.to(d), want, rtol=1e-5, atol=2e-5)
+            torch.testing.assert_close(part[0].to(d).sum(-1), gq.sum(dim=(0, 2)), rtol=1e-4, atol=2e-3)
+            torch.testing.assert_close(part[1].to(d).sum(-1), (gq * y_in.to(d)).sum(dim=(0, 2)), rtol=1e-4, atol=2e-3)
+    finally:
+        lib.istnet_pw_set_tuning(17, 1)
+
+
 def test_forward_acc_channel_stats_and_dy():
     lib = _native.lib()
     b, cin, cout, p = 2, 24, 40, 256
