@@ -142,5 +142,10 @@ def _roofline_object(per_kernel, steps, traffic_file, timing):
         "algorithmic_gbs": nbytes / (ms * 1e-3) / 1e9,
         "all_gemm_kernels_ms_per_step": total_ms / steps,
         "all_gemm_kernels_tflops": sum(v[1] for v in per_kernel.values()) / (total_ms * 1e-3) / 1e12,
+        # every timed launch against the two-roof model: time the roofs allow (per kernel instance: the larger of
+        # flops / MFMA peak and algorithmic bytes / HBM peak) over the time taken, eager and isolated
+        "all_gemm_kernels_roofline_model_frac": sum(
+            max(v[1] / (PEAK_MFMA_F32_TFLOPS * 1e12), v[2] / (PEAK_HBM_GBS * 1e9)) for v in per_kernel.values())
+        / (total_ms * 1e-3),
         "timing": timing,
     }
