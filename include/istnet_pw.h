@@ -151,6 +151,11 @@ ISTNET_PN2_API int istnet_pw_bwd_stats_pooled(int b, int c, int g, const float *
                                               float *part_g, float *part_gy, void *stream);
 /* istnet_pw_bwd_stats_pooled followed by istnet_bn_finalize_bwd in one launch (count = b * g * nsample points per
  * channel): dgamma, dbeta and the three BN-backward constants bwdc [3][c] of the last layer of a set-abstraction scale */
+/* istnet_pw_bwd_stats (dense gradient source) followed by istnet_bn_finalize_bwd in one launch, count = b * p: the first
+ * layer met by the backward pass of a stack without a max-pool (feature propagation) */
+ISTNET_PN2_API int istnet_bn_bwd_dense_finalize(int b, int c, int p, double count, int training, const float *y,
+                                                const float *d_dense, const float *gamma, const float *bn,
+                                                float *dgamma, float *dbeta, float *bwdc, void *stream);
 ISTNET_PN2_API int istnet_bn_bwd_pooled_finalize(int b, int c, int g, double count, int training, const float *d_pooled,
                                                  long long pooled_bstride, const float *ymax, const float *gamma,
                                                  const float *bn, float *dgamma, float *dbeta, float *bwdc,

@@ -66,6 +66,7 @@ SIGNATURES = {
     "istnet_bn_finalize_fwd": [_i, _i, _d, _p, _p, _p, _p, _f, _f, _p, _p, _p, _p],
     "istnet_bn_relu_pool": [_i, _i, _i, _i, _p, _p, _p, _l, _p, _p, _p],
     "istnet_pw_bwd_stats_pooled": [_i, _i, _i, _p, _l, _p, _p, _p, _p, _p],
+    "istnet_bn_bwd_dense_finalize": [_i, _i, _i, _d, _i, _p, _p, _p, _p, _p, _p, _p, _p],
     "istnet_bn_bwd_pooled_finalize": [_i, _i, _i, _d, _i, _p, _l, _p, _p, _p, _p, _p, _p, _p],
     "istnet_affine_consts": [_i, _p, _p, _p, _p, _f, _p, _p],
     "istnet_affine_consts_multi": [_i, _p, _p, _p, _p, _p, _p, _p, _p],

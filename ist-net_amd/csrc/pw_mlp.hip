@@ -1026,6 +1026,58 @@ __global__ __launch_bounds__(256) void pw_bwd_stats_kernel(int C, int P, GradSrc
   }
 }
 
+// pw_bwd_stats_kernel (dense gradient source) + bn_finalize_bwd_kernel in ONE launch: the first layer met by the backward
+// pass of a feature-propagation stack.  One workgroup of 16 waves per channel walks the B rows of that channel (float4
+// along the points, float partial per wave and row chunk, accumulated over the chunks in double).
+__global__ __launch_bounds__(1024) void bn_bwd_dense_finalize_kernel(
+    int C, int B, int P, double count, int training, const float* __restrict__ y, const float* __restrict__ dA,
+    const float* __restrict__ gamma, const float* __restrict__ bn, float* __restrict__ dgamma,
+    float* __restrict__ dbeta, float* __restrict__ bwdc) {
+  const int c = blockIdx.x, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const float s = bn[c], h = bn[C + c];
+  const int P4 = P >> 2;                       // float4 per row
+  const int chunks = (P4 + 63) / 64;           // 64 float4 (256 points) per wave visit
+  double ag = 0.0, agy = 0.0;
+  for (int t = wv; t < B * chunks; t += 16) {
+    const int b = t / chunks, i = (t - b * chunks) * 64 + lane;
+    float sg = 0.f, sgy = 0.f;
+    if (i < P4) {
+      const size_t off = ((size_t)b * C + c) * (size_t)P + 4 * (size_t)i;
+      const float4 v = *reinterpret_cast<const float4*>(y + off);
+      const float4 d = *reinterpret_cast<const float4*>(dA + off);
+      const float g0 = (v.x * s + h > 0.f) ? d.x : 0.f, g1 = (v.y * s + h > 0.f) ? d.y : 0.f;
+      const float g2 = (v.z * s + h > 0.f) ? d.z : 0.f, g3 = (v.w * s + h > 0.f) ? d.w : 0.f;
+      sg = (g0 + g1) + (g2 + g3);
+      sgy = (g0 * v.x + g1 * v.y) + (g2 * v.z + g3 * v.w);
+    }
+    ag += (double)wave_sum(sg);
+    agy += (double)wave_sum(sgy);
+  }
+  __shared__ double sh[2][16];
+  if (lane == 0) { sh[0][wv] = ag; sh[1][wv] = agy; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double sg = 0.0, sgy = 0.0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) { sg += sh[0][k]; sgy += sh[1][k]; }
+    const double mean = bn[2 * C + c], istd = bn[3 * C + c];
+    const double dg = (sgy - mean * sg) * istd;
+    dgamma[c] = (float)dg;
+    dbeta[c] = (float)sg;
+    const double gsc = (double)gamma[c] * istd;
+    if (training) {
+      const double c1 = sg / count, c2 = dg / count;
+      bwdc[0 * C + c] = (float)gsc;
+      bwdc[1 * C + c] = (float)(-gsc * c1 + gsc * mean * istd * c2);
+      bwdc[2 * C + c] = (float)(-gsc * istd * c2);
+    } else {
+      bwdc[0 * C + c] = (float)gsc;
+      bwdc[1 * C + c] = 0.f;
+      bwdc[2 * C + c] = 0.f;
+    }
+  }
+}
+
 // Same sums when the gradient arrives through the max-pool: g is non-zero only at the arg-max of each
 // group, where y is the raw maximum `ymax` saved by bn_relu_pool -- (B, C, G) reads instead of (B, C, G*S).
 // grid: (C, B), one wave per row; partials [C][B]
@@ -3246,6 +3298,15 @@ int istnet_pw_bwd_stats_pooled(int b, int c, int g, const float* d_pooled, long 
   if (b <= 0 || c <= 0 || g <= 0 || d_pooled == nullptr || ymax == nullptr) return ISTNET_PN2_EINVAL;
   hipLaunchKernelGGL(pw_bwd_stats_pooled_kernel, dim3(c, b), dim3(64), 0, as_stream(stream), c, g, d_pooled,
                      pooled_bstride > 0 ? pooled_bstride : (long long)c * g, ymax, bn, bn + c, part_g, part_gy);
+  return (int)hipGetLastError();
+}
+
+int istnet_bn_bwd_dense_finalize(int b, int c, int p, double count, int training, const float* y, const float* d_dense,
+                                 const float* gamma, const float* bn, float* dgamma, float* dbeta, float* bwdc,
+                                 void* stream) {
+  if (b <= 0 || c <= 0 || p <= 0 || (p & 3) || !y || !d_dense || !gamma || !bn || !dgamma || !dbeta || !bwdc) return ISTNET_PN2_EINVAL;
+  hipLaunchKernelGGL(bn_bwd_dense_finalize_kernel, dim3(c), dim3(1024), 0, as_stream(stream), c, b, p, count, training, y,
+                     d_dense, gamma, bn, dgamma, dbeta, bwdc);
   return (int)hipGetLastError();
 }
 

@@ -539,6 +539,7 @@ def _compact_ok(lib, ga, layers, params, needs_backward, needs_feature_grad):
 
 USE_FUSED_SMALL_BWD = True
 USE_POOLED_FINALIZE = True   # last layer of a scale: pooled statistics + BN-backward finalize in one launch
+USE_DENSE_FINALIZE = True    # last layer of an FP / head stack (dense gradient, <= 65 536 points): the same
 USE_FUSED_MID_BWD = True     # 64 / 128-channel layers: dgrad + wgrad + statistics in one pass (pw_bwd_mid_kernel)
 USE_SPLIT_LAYER0 = True
 USE_CSR_SCATTER = True     # False: LDS-atomic scatter (steps are then not bit-reproducible)
@@ -599,7 +600,7 @@ def _backward_stack(lib, dev, st, b, c0, g, s, x, gather, training, ys, bns, par
         dd, dp, da = _p(d_dense), _p(d_pooled), _p(d_arg)
         pbs = pooled_bstride if (pooled and li == n - 1) else 0
         grad_elems = b * cout * (p if dd is not None else p // s)
-        part = None
+        part, dense_fin = None, False
         if fused_part is not None:
             part, nt_l = fused_part, fused_nt
         elif ns_arg and USE_POOLED_FINALIZE and not (li == 0 and layer0_hook is not None):
@@ -609,6 +610,9 @@ def _backward_stack(lib, dev, st, b, c0, g, s, x, gather, training, ys, bns, par
             _native.check(lib.istnet_pw_bwd_stats_pooled(b, cout, g, dp, pbs, _ymax_ptr(d_arg, b * cout * g),
                                                          bn.data_ptr(), part[0].data_ptr(), part[1].data_ptr(), st),
                           "pw_bwd_stats_pooled")
+        elif (dd is not None and not ns_arg and USE_DENSE_FINALIZE and b * p <= 65536
+              and not (li == 0 and layer0_hook is not None)):
+            dense_fin = True       # dense statistics and finalize in one launch, below (small launches: the FP levels)
         else:
             part, nt_l = _empty((2, cout, ntb), torch.float32, dev), ntb
             _native.check(lib.istnet_pw_bwd_stats(b, cout, p, ns_arg, y.data_ptr(), dd, dp, pbs, da, bn.data_ptr(),
@@ -617,7 +621,11 @@ def _backward_stack(lib, dev, st, b, c0, g, s, x, gather, training, ys, bns, par
         dgamma = _grad_dest(gamma, (cout,), dev)
         dbeta = _grad_dest(params[3 * li + 2], (cout,), dev)
         bwdc = _empty((3, cout), torch.float32, dev)
-        if part is None:
+        if dense_fin:
+            _native.check(lib.istnet_bn_bwd_dense_finalize(
+                b, cout, p, float(b * p), 1 if training else 0, y.data_ptr(), dd, gamma.data_ptr(), bn.data_ptr(),
+                dgamma.data_ptr(), dbeta.data_ptr(), bwdc.data_ptr(), st), "bn_bwd_dense_finalize")
+        elif part is None:
             _native.check(lib.istnet_bn_bwd_pooled_finalize(
                 b, cout, g, float(b * p), 1 if training else 0, dp, pbs, _ymax_ptr(d_arg, b * cout * g), gamma.data_ptr(),
                 bn.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), bwdc.data_ptr(), st), "bn_bwd_pooled_finalize")
