@@ -57,6 +57,13 @@ ISTNET_PN2_API int istnet_pw_forward_cfg(int b, int cin, int cout, int p);
  * operands, K split over the four waves of a workgroup; istnet_pw_forward_cfg reports 1).  Number of statistics partials
  * per channel of an istnet_pw_forward_ld / istnet_pw_forward_acc launch: */
 ISTNET_PN2_API int istnet_pw_forward_ld_tiles(int b, int cin, int cout, int p);
+/* Layer 0 of a feature-propagation stack in one launch: y = three_interpolate(zk, idx, weight) + w . x, with
+ * zk (b, cout, m) the product over the known points, idx / weight (b, p, 3) as three_nn returns them (reference
+ * pointnet2_utils.py:249-273 for the interpolation).  Only for shapes the split-K kernel takes (istnet_pw_forward_cfg
+ * == 1, else ISTNET_PN2_EINVAL: interpolate first and call istnet_pw_forward_acc); partials: istnet_pw_forward_ld_tiles. */
+ISTNET_PN2_API int istnet_pw_forward_acc_interp(int b, int cin, int cout, int p, const float *x, const float *w, int ldw,
+                                                const float *zk, int m, const int *idx, const float *weight, float *y,
+                                                float *part_sum, float *part_sq, void *stream);
 /* The same for istnet_pw_dgrad with a dense gradient source (pw_dgrad_sk_kernel; cout % 8 == 0, 256 <= cout <= 2048 (key 18),
  * p % 128 == 0, m_rows >= 32, at most 1024 tiles; key 17 disables): istnet_pw_dgrad_sk = 1 when that kernel runs,
  * istnet_pw_dgrad_tiles = statistics partials per input channel the launch writes (dense: 1 = dense gradient source). */

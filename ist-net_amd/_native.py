@@ -50,6 +50,7 @@ SIGNATURES = {
     "istnet_pw_forward_tiles": [_i, _i, _i, _i],
     "istnet_pw_forward_cfg": [_i, _i, _i, _i],
     "istnet_pw_forward_ld_tiles": [_i, _i, _i, _i],
+    "istnet_pw_forward_acc_interp": [_i, _i, _i, _i, _p, _p, _i, _p, _i, _p, _p, _p, _p, _p, _p],
     "istnet_pw_dgrad_sk": [_i, _i, _i, _i],
     "istnet_pw_dgrad_tiles": [_i, _i, _i, _i, _i],
     "istnet_pw_dgrad_rs": [_i, _i, _i, _i, _i],

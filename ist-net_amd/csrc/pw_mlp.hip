@@ -579,7 +579,8 @@ __global__ __launch_bounds__(kThreads, 2) void pw_fwd2_kernel(
 __global__ __launch_bounds__(kThreads, 2) void pw_fwd_sk_kernel(
     int cin, int cout, int P, int tiles_per_cloud, const float* __restrict__ x, const float* __restrict__ w, int ldw,
     const float* __restrict__ in_scale, const float* __restrict__ in_shift, const float* __restrict__ c_init,
-    float* __restrict__ y, float* __restrict__ part_sum, float* __restrict__ part_sq, int nt_total) {
+    float* __restrict__ y, float* __restrict__ part_sum, float* __restrict__ part_sq, int nt_total,
+    const float* __restrict__ zk, int m_known, const int* __restrict__ iidx, const float* __restrict__ iw) {
   __shared__ __attribute__((aligned(16))) float lds[4 * 4 * 16 * 64];   // 64 KB: BN constants during the loop, then the partials
   float* s_sc = lds;            // [cin]
   float* s_sh = lds + 2048;     // [cin]
@@ -649,6 +650,22 @@ __global__ __launch_bounds__(kThreads, 2) void pw_fwd_sk_kernel(
   __syncthreads();
   float* yb = y + (size_t)b * cout * P + p0 + 4 * l31;
   const float* cb = c_init != nullptr ? c_init + (size_t)b * cout * P + p0 + 4 * l31 : nullptr;
+  // feature propagation, layer 0: the accumulators start from three_interpolate(zk) (reference
+  // pointnet2_utils.py:249-273), evaluated here instead of by a launch of its own: the three neighbours and weights of
+  // this lane's four points, then 3 gathers per output from the (B, cout, m) product over the known points
+  int nb[12];
+  float nw[12];
+  if (zk != nullptr) {
+    const int4* ip = reinterpret_cast<const int4*>(iidx + ((size_t)b * P + p0 + 4 * l31) * 3);
+    const float4* wp = reinterpret_cast<const float4*>(iw + ((size_t)b * P + p0 + 4 * l31) * 3);
+#pragma unroll
+    for (int u = 0; u < 3; ++u) {
+      const int4 iv = ip[u];
+      const float4 wv4 = wp[u];
+      nb[4 * u + 0] = iv.x; nb[4 * u + 1] = iv.y; nb[4 * u + 2] = iv.z; nb[4 * u + 3] = iv.w;
+      nw[4 * u + 0] = wv4.x; nw[4 * u + 1] = wv4.y; nw[4 * u + 2] = wv4.z; nw[4 * u + 3] = wv4.w;
+    }
+  }
 #pragma unroll
   for (int rr = 0; rr < 4; ++rr) {
     const int r = 4 * wv + rr;
@@ -664,6 +681,13 @@ __global__ __launch_bounds__(kThreads, 2) void pw_fwd_sk_kernel(
     if (cb != nullptr && ok) {
       const float4 c0 = *reinterpret_cast<const float4*>(cb + (size_t)row * P);
       o.x += c0.x; o.y += c0.y; o.z += c0.z; o.w += c0.w;
+    }
+    if (zk != nullptr && ok) {
+      const float* zr = zk + ((size_t)b * cout + row) * m_known;
+      o.x += (zr[nb[0]] * nw[0] + zr[nb[1]] * nw[1]) + zr[nb[2]] * nw[2];
+      o.y += (zr[nb[3]] * nw[3] + zr[nb[4]] * nw[4]) + zr[nb[5]] * nw[5];
+      o.z += (zr[nb[6]] * nw[6] + zr[nb[7]] * nw[7]) + zr[nb[8]] * nw[8];
+      o.w += (zr[nb[9]] * nw[9] + zr[nb[10]] * nw[10]) + zr[nb[11]] * nw[11];
     }
     if (ok) *reinterpret_cast<float4*>(yb + (size_t)row * P) = o;
     if (part_sum != nullptr) {
@@ -3088,7 +3112,8 @@ static int launch_pw_forward(bool gather, int b, int cin, int cout, int p, const
   if (!gather && msrc_p == nullptr && ncols == nullptr && row_init == nullptr && fwd_sk_ok(b, cin, cout, p)) {
     const int tpc = p / 128;
     hipLaunchKernelGGL(pw_fwd_sk_kernel, dim3(tpc * b, ceil_div(cout, 32)), dim3(kThreads), 0, as_stream(stream), cin, cout,
-                       p, tpc, x, w, ldw, in_scale, in_shift, c_init, y, part_sum, part_sq, tpc * b);
+                       p, tpc, x, w, ldw, in_scale, in_shift, c_init, y, part_sum, part_sq, tpc * b, nullptr, 0, nullptr,
+                       nullptr);
     return (int)hipGetLastError();
   }
   const TileCfg cfg = pick_cfg(b, cout, p, g_force_fwd_cfg);
@@ -3153,6 +3178,20 @@ int istnet_pw_forward_acc(int b, int cin, int cout, int p, const float* x, const
   if (ldw < cin || c_init == nullptr) return ISTNET_PN2_EINVAL;
   return launch_pw_forward(false, b, cin, cout, p, x, GatherSrc{}, w, ldw, nullptr, nullptr, y, part_sum, part_sq,
                            stream, c_init);
+}
+
+// y = three_interpolate(zk, idx, weight) + w . x for a launch the split-K kernel takes (istnet_pw_forward_cfg == 1):
+// istnet_pw_forward_acc without the interpolated tensor
+int istnet_pw_forward_acc_interp(int b, int cin, int cout, int p, const float* x, const float* w, int ldw, const float* zk,
+                                 int m, const int* idx, const float* weight, float* y, float* part_sum, float* part_sq,
+                                 void* stream) {
+  if (b <= 0 || cin <= 0 || cout <= 0 || p <= 0 || m <= 0 || ldw < cin || !x || !w || !zk || !idx || !weight || !y)
+    return ISTNET_PN2_EINVAL;
+  if (!fwd_sk_ok(b, cin, cout, p)) return ISTNET_PN2_EINVAL;
+  const int tpc = p / 128;
+  hipLaunchKernelGGL(pw_fwd_sk_kernel, dim3(tpc * b, ceil_div(cout, 32)), dim3(kThreads), 0, as_stream(stream), cin, cout,
+                     p, tpc, x, w, ldw, nullptr, nullptr, nullptr, y, part_sum, part_sq, tpc * b, zk, m, idx, weight);
+  return (int)hipGetLastError();
 }
 
 int istnet_pw_forward_multi(int b, int nsrc, const float* const* srcs, const int* chans, int cout, int p,

@@ -539,6 +539,7 @@ def _compact_ok(lib, ga, layers, params, needs_backward, needs_feature_grad):
 
 USE_FUSED_SMALL_BWD = True
 USE_POOLED_FINALIZE = True   # last layer of a scale: pooled statistics + BN-backward finalize in one launch
+USE_INTERP_IN_EPILOGUE = True   # FP layer 0 (small launches): three_interpolate inside the skip product's epilogue
 USE_DENSE_FINALIZE = True    # last layer of an FP / head stack (dense gradient, <= 65 536 points): the same
 USE_FUSED_MID_BWD = True     # 64 / 128-channel layers: dgrad + wgrad + statistics in one pass (pw_bwd_mid_kernel)
 USE_SPLIT_LAYER0 = True
@@ -1187,10 +1188,24 @@ class FusedFPFunction(Function):
                 4.0 * b * m * (c2 + cout0), lambda: lib.istnet_pw_forward_ld(
                     b, c2, cout0, m, known.data_ptr(), w2.data_ptr(), cin, None, None, zk.data_ptr(), None, None,
                     st)), "pw_forward_ld(fp)")
-            t = _ext.three_interpolate(zk, idx, weight)               # (B, cout0, n)
+            fuse_interp = (skip_c is not None and USE_INTERP_IN_EPILOGUE and lib.istnet_pw_forward_cfg(b, c1, cout0, n) == 1
+                           and idx.dtype == torch.int32 and idx.is_contiguous() and weight.is_contiguous())
+            t = None if fuse_interp else _ext.three_interpolate(zk, idx, weight)               # (B, cout0, n)
             bn0 = _empty((4, cout0), torch.float32, dev)
             part = None
-            if skip_c is not None:
+            if fuse_interp:
+                # small launch: the interpolation of zk is evaluated in the epilogue of the skip-connection product
+                y0 = _empty((b, cout0, n), torch.float32, dev)
+                if training:
+                    nt = lib.istnet_pw_forward_ld_tiles(b, c1, cout0, n)
+                    part = _empty((2, cout0, nt), torch.float32, dev)
+                _native.check(_native.timed(
+                    "pw_fwd_sk_kernel", 2.0 * b * n * c1 * cout0, 4.0 * b * n * (c1 + cout0),
+                    lambda: lib.istnet_pw_forward_acc_interp(
+                        b, c1, cout0, n, skip_c.data_ptr(), w2.data_ptr() + 4 * c2, cin, zk.data_ptr(), m, idx.data_ptr(),
+                        weight.data_ptr(), y0.data_ptr(), _p(part[0]) if training else None,
+                        _p(part[1]) if training else None, st)), "pw_forward_acc_interp")
+            elif skip_c is not None:
                 y0 = _empty((b, cout0, n), torch.float32, dev)
                 if training:
                     nt = lib.istnet_pw_forward_ld_tiles(b, c1, cout0, n)

@@ -385,6 +385,43 @@ def test_dgrad_loader_mfma_roles_for_256_output_channels(b, p, pooled):
         lib.istnet_pw_set_tuning(17, 1)
 
 
+@pytest.mark.parametrize("b,c1,cout,n,m", [(4, 256, 512, 128, 64), (2, 64, 72, 256, 100), (3, 128, 256, 384, 192)])
+def test_forward_acc_with_the_interpolation_in_the_epilogue(b, c1, cout, n, m):
+    """istnet_pw_forward_acc_interp: y = three_interpolate(zk, idx, weight) + w . x in one launch, against float64, with the
+    statistics partials; same result as interpolating first and calling istnet_pw_forward_acc."""
+    from istnet_amd.pointnet2 import _ext
+    lib = _native.lib()
+    assert lib.istnet_pw_forward_cfg(b, c1, cout, n) == 1
+    g = torch.Generator().manual_seed(b + c1 + cout + n)
+    x = torch.randn(b, c1, n, generator=g).to(DEV)
+    ldw = c1 + 32
+    wfull = (torch.randn(cout, ldw, generator=g) / c1 ** 0.5).to(DEV)
+    zk = torch.randn(b, cout, m, generator=g).to(DEV)
+    idx = torch.randint(0, m, (b, n, 3), generator=g, dtype=torch.int32).to(DEV)
+    wt = torch.rand(b, n, 3, generator=g)
+    wt = (wt / wt.sum(-1, keepdim=True)).to(DEV)
+    nt = lib.istnet_pw_forward_ld_tiles(b, c1, cout, n)
+    y = torch.full((b, cout, n), float("nan"), device=DEV)
+    part = torch.full((2, cout, nt), float("nan"), device=DEV)
+    assert lib.istnet_pw_forward_acc_interp(b, c1, cout, n, x.data_ptr(), wfull.data_ptr() + 4 * 32, ldw, zk.data_ptr(), m,
+                                            idx.data_ptr(), wt.data_ptr(), y.data_ptr(), part[0].data_ptr(),
+                                            part[1].data_ptr(), _st()) == 0
+    d = torch.float64
+    gathered = torch.gather(zk.to(d).unsqueeze(2).expand(-1, -1, n, -1), 3,
+                            idx.long().unsqueeze(1).expand(-1, cout, -1, -1))          # (b, cout, n, 3)
+    want = (gathered * wt.to(d).unsqueeze(1)).sum(-1) + torch.matmul(wfull[:, 32:].to(d), x.to(d))
+    torch.testing.assert_close(y.to(d), want, rtol=1e-5, atol=2e-5)
+    torch.testing.assert_close(part[0].to(d).sum(-1), want.sum(dim=(0, 2)), rtol=1e-5, atol=1e-3)
+    torch.testing.assert_close(part[1].to(d).sum(-1), want.square().sum(dim=(0, 2)), rtol=1e-5, atol=1e-3)
+    t_int = _ext.three_interpolate(zk, idx, wt)
+    y2 = torch.empty_like(y)
+    assert lib.istnet_pw_forward_acc(b, c1, cout, n, x.data_ptr(), wfull.data_ptr() + 4 * 32, ldw, t_int.data_ptr(),
+                                     y2.data_ptr(), None, None, _st()) == 0
+    torch.testing.assert_close(y, y2, rtol=1e-6, atol=2e-6)
+    assert lib.istnet_pw_forward_acc_interp(32, c1, cout, 32768, x.data_ptr(), wfull.data_ptr(), ldw, zk.data_ptr(), m,
+                                            idx.data_ptr(), wt.data_ptr(), y.data_ptr(), None, None, _st()) != 0   # too large: refused
+
+
 def test_forward_acc_channel_stats_and_dy():
     lib = _native.lib()
     b, cin, cout, p = 2, 24, 40, 256
