@@ -211,6 +211,16 @@ ISTNET_PN2_API int istnet_pw_scatter_dy_csr(int b, int cout, int n, int p, const
                                             const int *entries, float *out, long long out_bstride,
                                             const float *xyz, const float *new_xyz, int group_nsample,
                                             float *dwx, void *stream);
+/* istnet_bn_finalize_bwd of the layer folded into istnet_pw_scatter_dy_csr: every workgroup derives the BN-backward
+ * constants of its few channels from the nt statistics partials (part_g / part_gy [cout][nt]); the workgroups of cloud 0
+ * store dgamma, dbeta and bwdc [3][cout] (bwdc is an OUTPUT here). */
+ISTNET_PN2_API int istnet_pw_scatter_dy_csr_fin(int b, int cout, int n, int p, const float *y, const float *d_dense,
+                                                const float *bn, int nt, double count, int training,
+                                                const float *part_g, const float *part_gy, const float *gamma,
+                                                float *dgamma, float *dbeta, float *bwdc, const int *offsets,
+                                                const int *entries, float *out, long long out_bstride,
+                                                const float *xyz, const float *new_xyz, int group_nsample, float *dwx,
+                                                void *stream);
 
 /* split-K weight gradient (requires p % 32 == 0): dw_part[split][co][ci] = sum_{p in split} dY[b][co][p] * act(x[b][ci][p]) with
  * istnet_pw_wgrad_splits(...) splits; istnet_pw_wgrad_reduce sums the partials in a fixed order:

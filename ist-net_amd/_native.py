@@ -22,6 +22,7 @@ SIGNATURES = {
     "istnet_pn2_csr_build_segmented": [_i, _i, _p, _p, _p, _p, _p, _p, _p, _p],
     "istnet_pw_scatter_csr_chunks": [_i],
     "istnet_pw_scatter_dy_csr": [_i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _l, _p, _p, _i, _p, _p],
+    "istnet_pw_scatter_dy_csr_fin": [_i, _i, _i, _i, _p, _p, _p, _i, _d, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _l, _p, _p, _i, _p, _p],
     "istnet_adam_step": [_l, _p, _p, _p, _p, _p, _p, _d, _d, _d, _d, _d, _d, _p],
     "istnet_prelu_bwd_parts": [_l],
     "istnet_prelu_bwd": [_l, _p, _p, _p, _p, _p, _p],

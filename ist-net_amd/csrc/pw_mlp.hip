@@ -1383,6 +1383,19 @@ __global__ __launch_bounds__(256) void pw_scatter_dy_kernel(int cout, int n, int
 // lists, one source point per thread at a time, reading dY0 from LDS (a gather straight from global memory moves a
 // cache line per 4 useful bytes and measured 3x slower than the atomics).
 // dwx[b][co][0:3] = sum_i xyz[i] * G[co][i] - sum_slots dY0[co][e] * centre[e / S].
+// Optional: bn_finalize_bwd of this layer done here (the statistics partials of layer 0 come from the fused backward
+// kernel of layer 1; each workgroup needs the constants of its CH channels only): one launch less on the chain.
+struct BwdFinArgs {
+  const float* part_g;     // [cout][nt]; null: constants come from bwdc
+  const float* part_gy;
+  const float* gamma;
+  float* dgamma;
+  float* dbeta;
+  float* bwdc_out;         // [3][cout], written by the workgroups of cloud 0 (later consumers: deferred weight gradients)
+  double count;
+  int nt;
+  int training;
+};
 template <int CH>
 __global__ __launch_bounds__(256) void pw_scatter_csr_kernel(int cout, int n, int P, const float* __restrict__ y,
                                                              const float* __restrict__ d,
@@ -1393,16 +1406,56 @@ __global__ __launch_bounds__(256) void pw_scatter_csr_kernel(int cout, int n, in
                                                              float* __restrict__ out, long long out_bstride,
                                                              const float* __restrict__ xyz,
                                                              const float* __restrict__ new_xyz, int group_s,
-                                                             float* __restrict__ dwx) {
+                                                             float* __restrict__ dwx, BwdFinArgs fin) {
   extern __shared__ __attribute__((aligned(16))) float dy[];   // [P][CH]
   const int b = blockIdx.y, c0 = blockIdx.x * CH;
   const int nch = min(CH, cout - c0);
   float rs[CH], rh[CH], ca[CH], cb[CH], cc[CH];
+  if (fin.part_g != nullptr) {
+    // wave w reduces the partials of channels w, w + 4, ... of this workgroup (double, fixed order), then the constants
+    // go through LDS to every thread
+    float* cst = dy;                     // [CH][3] (dy is written after the barrier below)
+    for (int ch = wave_id(); ch < CH; ch += 4) {
+      const int co = min(c0 + ch, cout - 1);
+      const float* pg = fin.part_g + (size_t)co * fin.nt;
+      const float* pgy = fin.part_gy + (size_t)co * fin.nt;
+      double a = 0.0, c = 0.0;
+      for (int i = lane_id(); i < fin.nt; i += 64) { a += (double)pg[i]; c += (double)pgy[i]; }
+      for (int off = 32; off >= 1; off >>= 1) { a += __shfl_xor(a, off); c += __shfl_xor(c, off); }
+      if (lane_id() == 0) {
+        const double mean = bn[2 * cout + co], istd = bn[3 * cout + co];
+        const double dg = (c - mean * a) * istd;
+        const double gsc = (double)fin.gamma[co] * istd;
+        float fa, fb, fc;
+        if (fin.training) {
+          const double c1 = a / fin.count, c2 = dg / fin.count;
+          fa = (float)gsc; fb = (float)(-gsc * c1 + gsc * mean * istd * c2); fc = (float)(-gsc * istd * c2);
+        } else {
+          fa = (float)gsc; fb = 0.f; fc = 0.f;
+        }
+        cst[ch * 3 + 0] = fa; cst[ch * 3 + 1] = fb; cst[ch * 3 + 2] = fc;
+        if (b == 0 && c0 + ch < cout) {
+          fin.dgamma[co] = (float)dg;
+          fin.dbeta[co] = (float)a;
+          fin.bwdc_out[co] = fa; fin.bwdc_out[cout + co] = fb; fin.bwdc_out[2 * cout + co] = fc;
+        }
+      }
+    }
+    __syncthreads();
 #pragma unroll
-  for (int ch = 0; ch < CH; ++ch) {
-    const int co = min(c0 + ch, cout - 1);
-    rs[ch] = bn[co]; rh[ch] = bn[cout + co];
-    ca[ch] = bwdc[co]; cb[ch] = bwdc[cout + co]; cc[ch] = bwdc[2 * cout + co];
+    for (int ch = 0; ch < CH; ++ch) {
+      const int co = min(c0 + ch, cout - 1);
+      rs[ch] = bn[co]; rh[ch] = bn[cout + co];
+      ca[ch] = cst[ch * 3 + 0]; cb[ch] = cst[ch * 3 + 1]; cc[ch] = cst[ch * 3 + 2];
+    }
+    __syncthreads();
+  } else {
+#pragma unroll
+    for (int ch = 0; ch < CH; ++ch) {
+      const int co = min(c0 + ch, cout - 1);
+      rs[ch] = bn[co]; rh[ch] = bn[cout + co];
+      ca[ch] = bwdc[co]; cb[ch] = bwdc[cout + co]; cc[ch] = bwdc[2 * cout + co];
+    }
   }
   // ---- phase 1: dY0 of CH channel rows -> LDS (P % 4 == 0) ----
   for (int p = threadIdx.x * 4; p < P; p += 1024) {
@@ -3539,10 +3592,10 @@ static int scatter_csr_ch(int b, int cout, int p) {
   return ch;
 }
 
-int istnet_pw_scatter_dy_csr(int b, int cout, int n, int p, const float* y, const float* d_dense, const float* bn,
-                             const float* bwdc, const int* offsets, const int* entries, float* out,
-                             long long out_bstride, const float* xyz, const float* new_xyz, int group_nsample,
-                             float* dwx, void* stream) {
+static int scatter_dy_csr_impl(int b, int cout, int n, int p, const float* y, const float* d_dense, const float* bn,
+                               const float* bwdc, const int* offsets, const int* entries, float* out,
+                               long long out_bstride, const float* xyz, const float* new_xyz, int group_nsample,
+                               float* dwx, void* stream, const BwdFinArgs& fin) {
   if (b <= 0 || cout <= 0 || n <= 0 || p <= 0 || (p & 3) || !y || !d_dense || !bn || !bwdc || !offsets || !entries || !out)
     return ISTNET_PN2_EINVAL;
   if (dwx != nullptr && (xyz == nullptr || new_xyz == nullptr || group_nsample <= 0 || p % group_nsample))
@@ -3555,7 +3608,7 @@ int istnet_pw_scatter_dy_csr(int b, int cout, int n, int p, const float* y, cons
   const int gsz = group_nsample > 0 ? group_nsample : 1;
 #define ISTNET_SCSR(CH)                                                                                            \
   hipLaunchKernelGGL(pw_scatter_csr_kernel<CH>, grid, dim3(256), lds, as_stream(stream), cout, n, p, y, d_dense, bn, \
-                     bwdc, offsets, entries, out, obs, xyz, new_xyz, gsz, dwx)
+                     bwdc, offsets, entries, out, obs, xyz, new_xyz, gsz, dwx, fin)
   switch (ch) {
     case 16: ISTNET_SCSR(16); break;
     case 8: ISTNET_SCSR(8); break;
@@ -3565,6 +3618,26 @@ int istnet_pw_scatter_dy_csr(int b, int cout, int n, int p, const float* y, cons
   }
 #undef ISTNET_SCSR
   return (int)hipGetLastError();
+}
+
+int istnet_pw_scatter_dy_csr(int b, int cout, int n, int p, const float* y, const float* d_dense, const float* bn,
+                             const float* bwdc, const int* offsets, const int* entries, float* out,
+                             long long out_bstride, const float* xyz, const float* new_xyz, int group_nsample,
+                             float* dwx, void* stream) {
+  BwdFinArgs fin{};
+  return scatter_dy_csr_impl(b, cout, n, p, y, d_dense, bn, bwdc, offsets, entries, out, out_bstride, xyz, new_xyz,
+                             group_nsample, dwx, stream, fin);
+}
+
+int istnet_pw_scatter_dy_csr_fin(int b, int cout, int n, int p, const float* y, const float* d_dense, const float* bn,
+                                 int nt, double count, int training, const float* part_g, const float* part_gy,
+                                 const float* gamma, float* dgamma, float* dbeta, float* bwdc, const int* offsets,
+                                 const int* entries, float* out, long long out_bstride, const float* xyz,
+                                 const float* new_xyz, int group_nsample, float* dwx, void* stream) {
+  if (nt <= 0 || !part_g || !part_gy || !gamma || !dgamma || !dbeta || !bwdc) return ISTNET_PN2_EINVAL;
+  BwdFinArgs fin{part_g, part_gy, gamma, dgamma, dbeta, bwdc, count, nt, training};
+  return scatter_dy_csr_impl(b, cout, n, p, y, d_dense, bn, bwdc, offsets, entries, out, out_bstride, xyz, new_xyz,
+                             group_nsample, dwx, stream, fin);
 }
 
 int istnet_pw_dgrad_stat_tiles(int b, int m_rows, int p) {

@@ -539,6 +539,7 @@ def _compact_ok(lib, ga, layers, params, needs_backward, needs_feature_grad):
 
 USE_FUSED_SMALL_BWD = True
 USE_POOLED_FINALIZE = True   # last layer of a scale: pooled statistics + BN-backward finalize in one launch
+USE_FINALIZE_IN_SCATTER = True  # layer 0 of an SA scale: BN-backward finalize inside the inverse-list scatter kernel
 USE_INTERP_IN_EPILOGUE = True   # FP layer 0 (small launches): three_interpolate inside the skip product's epilogue
 USE_DENSE_FINALIZE = True    # last layer of an FP / head stack (dense gradient, <= 65 536 points): the same
 USE_FUSED_MID_BWD = True     # 64 / 128-channel layers: dgrad + wgrad + statistics in one pass (pw_bwd_mid_kernel)
@@ -622,7 +623,14 @@ def _backward_stack(lib, dev, st, b, c0, g, s, x, gather, training, ys, bns, par
         dgamma = _grad_dest(gamma, (cout,), dev)
         dbeta = _grad_dest(params[3 * li + 2], (cout,), dev)
         bwdc = _empty((3, cout), torch.float32, dev)
-        if dense_fin:
+        # layer 0 of a scale whose gradient leaves through the inverse-list scatter: that kernel derives the constants
+        # of its channels from the partials itself (one launch less on the chain)
+        scatter_fin = (li == 0 and part is not None and gather is not None and need_x and gather.n <= 4096
+                       and layer0_hook is None and USE_FINALIZE_IN_SCATTER and USE_CSR_SCATTER and gather.csr is not None
+                       and d_dense is not None and p % 4 == 0 and 4 * p <= 65536)
+        if scatter_fin:
+            pass
+        elif dense_fin:
             _native.check(lib.istnet_bn_bwd_dense_finalize(
                 b, cout, p, float(b * p), 1 if training else 0, y.data_ptr(), dd, gamma.data_ptr(), bn.data_ptr(),
                 dgamma.data_ptr(), dbeta.data_ptr(), bwdc.data_ptr(), st), "bn_bwd_dense_finalize")
@@ -705,10 +713,17 @@ def _backward_stack(lib, dev, st, b, c0, g, s, x, gather, training, ys, bns, par
             dwx = _empty((b, cout, 3), torch.float32, dev) if split_w0 else None
             if USE_CSR_SCATTER and ga.csr is not None and d_dense is not None and p % 4 == 0 and 4 * p <= 65536:
                 # atomic-free and deterministic: every source point sums its inverse list from an LDS-staged dY0 row
-                _native.check(lib.istnet_pw_scatter_dy_csr(
-                    b, cout, ga.n, p, y.data_ptr(), dd, bn.data_ptr(), bwdc.data_ptr(), ga.csr[0].data_ptr(),
-                    ga.csr[1].data_ptr(), gptr, gbs, ga.xyz.data_ptr(), ga.new_xyz.data_ptr(), ga.nsample, _p(dwx),
-                    st), "pw_scatter_dy_csr")
+                if scatter_fin:
+                    _native.check(lib.istnet_pw_scatter_dy_csr_fin(
+                        b, cout, ga.n, p, y.data_ptr(), dd, bn.data_ptr(), nt_l, float(b * p), 1 if training else 0,
+                        part[0].data_ptr(), part[1].data_ptr(), gamma.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(),
+                        bwdc.data_ptr(), ga.csr[0].data_ptr(), ga.csr[1].data_ptr(), gptr, gbs, ga.xyz.data_ptr(),
+                        ga.new_xyz.data_ptr(), ga.nsample, _p(dwx), st), "pw_scatter_dy_csr_fin")
+                else:
+                    _native.check(lib.istnet_pw_scatter_dy_csr(
+                        b, cout, ga.n, p, y.data_ptr(), dd, bn.data_ptr(), bwdc.data_ptr(), ga.csr[0].data_ptr(),
+                        ga.csr[1].data_ptr(), gptr, gbs, ga.xyz.data_ptr(), ga.new_xyz.data_ptr(), ga.nsample, _p(dwx),
+                        st), "pw_scatter_dy_csr")
             else:
                 _native.check(lib.istnet_pw_scatter_dy(b, cout, ga.n, p, ns_arg, y.data_ptr(), dd, dp, pbs, da,
                                                        bn.data_ptr(), bwdc.data_ptr(), ga.idx.data_ptr(), gptr, gbs,
