@@ -3005,7 +3005,7 @@ int g_dgrad_sk_min_k = 256;    // key 18
 int g_fwd_sk_max_tiles = 1024; // key 16: launches with more 32 x 128 tiles than this keep the LDS-tiled kernel (measured:
                                // +15-35 % at <= 1024 tiles -- the FP levels --, -8 % at 2048)
 int g_fwd2_enable = 1;         // key 13: 0 = pw_fwd_kernel for every forward launch
-int g_fwd2_min_waves = 2048;   // key 14
+int g_fwd2_min_waves = 1024;   // key 14 (step time at 2048 / 1024 / 768 / 512 / 256: 2.912 / 2.870 / 2.879 / 2.933 / 2.997 ms)
 int g_wgrad2_enable = 1;       // key 11: 0 = pw_wgrad_kernel for every dense layer
 int g_wgrad2_target = 256;     // key 12: workgroups of a pw_wgrad2_kernel launch (one per CU)
 inline bool wgrad2_ok(int cin, int cout) {
@@ -3090,7 +3090,7 @@ int istnet_pw_set_tuning(int key, int value) {
     case 19: g_dgrad_rs_enable = value != 0; return 0;
     case 18: g_dgrad_sk_min_k = value > 0 ? value : 256; return 0;
     case 16: g_fwd_sk_max_tiles = value > 0 ? value : 1024; return 0;
-    case 14: g_fwd2_min_waves = value > 0 ? value : 2048; return 0;
+    case 14: g_fwd2_min_waves = value > 0 ? value : 1024; return 0;
     case 12: g_wgrad2_target = value > 0 ? value : 256; return 0;
     default: return ISTNET_PN2_EINVAL;
   }
@@ -3116,8 +3116,8 @@ static int fwd2_cfg(int b, int cin, int cout, int p) {
   else if (cout <= 64) { tmw = 2; wm = 1; wn = 4; }
   else if (cout <= 128) { tmw = 2; wm = 2; wn = 2; }
   else { tmw = 2; wm = 4; wn = 1; }
-  // A wave owns 32 TMW rows x 128 points: the launch needs two waves per SIMD of the chip (2048) to hide its loads;
-  // measured at 512 - 1024 waves (SA3 / SA4 at nsample 16, the FP levels) the 64 x 64 LDS tiles are 1.5 - 3x faster.
+  // A wave owns 32 TMW rows x 128 points: the launch needs about one wave per SIMD of the chip (1024) to hide its
+  // loads; measured at 256 - 512 waves (the FP levels) the 64 x 64 LDS tiles are 1.5 - 3x faster.
   if (wave_tiles * ceil_div(cout, 32 * tmw) < g_fwd2_min_waves) return 0;
   while (wn > 1 && (wave_tiles / wn) * ceil_div(cout, 32 * tmw * wm) < 256) { wn /= 2; wm *= 2; }
   if (p % (128 * wn)) return 0;
