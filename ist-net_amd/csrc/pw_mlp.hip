@@ -2992,8 +2992,10 @@ inline bool wgrad_small(int cin, int cout) { return cin <= 32 && cout <= 32; }
 int g_wg_small_pts = 0x7fffffff;  // layers with b*P <= this use 64x64 wgrad tiles: measured best for every encoder layer (smaller split-K partials)
 int g_wg_target_big = 512;   // target workgroup count, outputs >= 128x128 (re-tuned end to end once the wgrads ran beside the dgrad chain: 768/1024 -> 512/512 is 1.5 % faster)
 int g_wg_target_small = 512;
-int g_bwd_small_target = 256; // workgroups of the fused small-layer backward (key 5)
-int g_bwd_mid_target = 256;   // workgroups of the fused mid-size-layer backward (key 8): one per CU
+int g_bwd_small_target = 512; // workgroups of the fused small-layer backward (key 5; inside the step 512 beats 256 by 0.4 %, alone 256 wins)
+int g_bwd_mid_target = 128;   // workgroups of the fused mid-size-layer backward (key 8).  Alone, one per CU (256) is 10 % faster;
+                              // inside the step 128 wins by 0.9 % (2.848 -> 2.823 ms): the other half of the chip stays open to
+                              // the other scale's chain and the weight-gradient stream
 int g_bwd_mid_enable = 1;     // key 9: 0 = those layers run the dgrad / wgrad pair
 int g_exp_no_fast = 0;        // experiment (key 6): 1 = never take the interior-tile fast kernels
 inline int wgrad_mt(int cout, long long pts) { return (cout >= 128 && pts > g_wg_small_pts) ? 128 : 64; }
@@ -3078,10 +3080,10 @@ int istnet_pw_set_tuning(int key, int value) {
     case 2: g_wg_target_small = value; return 0;
     case 3: g_force_fwd_cfg = value; return 0;
     case 4: g_force_dgrad_cfg = value; return 0;
-    case 5: g_bwd_small_target = value > 0 ? value : 256; return 0;
+    case 5: g_bwd_small_target = value > 0 ? value : 512; return 0;
     case 6: g_exp_no_fast = value; return 0;
     case 7: g_dgrad_min_wgs = value > 0 ? value : 384; return 0;
-    case 8: g_bwd_mid_target = value > 0 ? value : 256; return 0;
+    case 8: g_bwd_mid_target = value > 0 ? value : 128; return 0;
     case 9: g_bwd_mid_enable = value != 0; return 0;
     case 11: g_wgrad2_enable = value != 0; return 0;
     case 13: g_fwd2_enable = value != 0; return 0;
