@@ -126,6 +126,14 @@ ISTNET_PN2_API int istnet_pn2_three_interpolate_grad_csr(int b, int c, int n, in
                                                          const float *weight, const int *offsets,
                                                          const int *entries, float *grad_points, void *stream);
 
+/* Deterministic, atomic-free form of group_points_grad over the inverse lists of idx (istnet_pn2_csr_build with
+ * e = npoints*nsample, m = n): grad_points[b][c][i] = sum over the slots that picked point i.  The reference uses one
+ * fp32 atomicAdd per slot (group_points_gpu.cu:62-66).  Needs one gradient row (npoints*nsample floats) to fit 64 KB
+ * of LDS; ISTNET_PN2_EINVAL otherwise (use istnet_pn2_group_points_grad then). */
+ISTNET_PN2_API int istnet_pn2_group_points_grad_csr(int b, int c, int n, int npoints, int nsample,
+                                                    const float *grad_out, const int *offsets, const int *entries,
+                                                    float *grad_points, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -42,6 +42,7 @@ SIGNATURES = {
     "istnet_pn2_three_interpolate_grad": [_i, _i, _i, _i, _p, _p, _p, _p, _p],
     "istnet_pn2_interp_csr_build": [_i, _i, _i, _p, _p, _p, _p],
     "istnet_pn2_three_interpolate_grad_csr": [_i, _i, _i, _i, _p, _p, _p, _p, _p, _p],
+    "istnet_pn2_group_points_grad_csr": [_i, _i, _i, _i, _i, _p, _p, _p, _p, _p],
     # include/istnet_pw.h
     "istnet_pw_tile_cfg": [_i, _i, _i],
     "istnet_pw_wgrad_tile_cfg": [_i, _i, _i, _i],

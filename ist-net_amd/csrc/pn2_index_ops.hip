@@ -356,7 +356,13 @@ __global__ __launch_bounds__(256) void group_points_scalar_kernel(int c, int n, 
 // with a single LDS atomic instead of nsample conflicting ones.
 // ============================================================================
 constexpr int kScatterThreads = 256;
-constexpr int kGroupGradCH = 4;
+#ifndef ISTNET_GROUP_GRAD_CH
+#define ISTNET_GROUP_GRAD_CH 2
+#endif
+#ifndef ISTNET_GROUP_GRAD_UNROLL
+#define ISTNET_GROUP_GRAD_UNROLL 4
+#endif
+constexpr int kGroupGradCH = ISTNET_GROUP_GRAD_CH;
 constexpr int kInterpGradCH = 8;
 
 // group_points_grad: lanes walk consecutive grouped slots p (coalesced), runs of equal indices inside a
@@ -370,6 +376,7 @@ template <int CTRL>
 __device__ __forceinline__ float dpp_row_f(float v) {
   return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
 }
+constexpr int kGroupGradUnroll = ISTNET_GROUP_GRAD_UNROLL;   // slots per thread in flight: the loop is latency-bound (few waves per CU)
 __global__ __launch_bounds__(kScatterThreads) void group_grad_kernel(
     int c, int n, int P, const float* __restrict__ grad_out, const int* __restrict__ idx_all,
     float* __restrict__ grad_points) {
@@ -379,29 +386,104 @@ __global__ __launch_bounds__(kScatterThreads) void group_grad_kernel(
   for (int i = threadIdx.x; i < nch * n; i += kScatterThreads) acc[i] = 0.f;
   __syncthreads();
   const int* idx = idx_all + (size_t)b * P;
-  const int Pr = (P + kScatterThreads - 1) / kScatterThreads * kScatterThreads;  // whole waves stay converged
-  for (int p = threadIdx.x; p < Pr; p += kScatterThreads) {
-    const bool valid = p < P;
-    const int ii = valid ? idx[p] : -1;
-    // head of a run: first lane of the 16-lane row or index differs from the previous lane
-    const int prev = dpp_row_i<0x111>(-2, ii);
-    const int head0 = (prev != ii) ? 1 : 0;
-    const int nxt = dpp_row_i<0x101>(-3, ii);      // row_shl:1 -> index of the next lane (or -3 at the row end)
-    const bool tail = nxt != ii;
-    for (int ch = 0; ch < nch; ++ch) {
-      float v = valid ? grad_out[((size_t)b * c + c0 + ch) * P + p] : 0.f;
-      int f = head0;
-      float pv; int pf;
-      pv = dpp_row_f<0x111>(v); pf = dpp_row_i<0x111>(1, f); v = f ? v : v + pv; f |= pf;
-      pv = dpp_row_f<0x112>(v); pf = dpp_row_i<0x112>(1, f); v = f ? v : v + pv; f |= pf;
-      pv = dpp_row_f<0x114>(v); pf = dpp_row_i<0x114>(1, f); v = f ? v : v + pv; f |= pf;
-      pv = dpp_row_f<0x118>(v); pf = dpp_row_i<0x118>(1, f); v = f ? v : v + pv; f |= pf;
-      if (valid && tail) atomicAdd(&acc[ch * n + ii], v);
+  const float* g = grad_out + ((size_t)b * c + c0) * P;
+  constexpr int STEP = kScatterThreads * kGroupGradUnroll;
+  const int Pr = (P + STEP - 1) / STEP * STEP;  // whole waves stay converged
+  for (int p0 = threadIdx.x; p0 < Pr; p0 += STEP) {
+    int ii[kGroupGradUnroll];
+    float v[kGroupGradUnroll][kGroupGradCH];
+#pragma unroll
+    for (int u = 0; u < kGroupGradUnroll; ++u) {          // all loads of the step are issued before the first use
+      const int p = p0 + u * kScatterThreads;
+      ii[u] = p < P ? idx[p] : -1;
+#pragma unroll
+      for (int ch = 0; ch < kGroupGradCH; ++ch)
+        v[u][ch] = (p < P && ch < nch) ? g[(size_t)ch * P + p] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < kGroupGradUnroll; ++u) {
+      // head of a run: first lane of the 16-lane row or index differs from the previous lane
+      const int prev = dpp_row_i<0x111>(-2, ii[u]);
+      const int head0 = (prev != ii[u]) ? 1 : 0;
+      const int nxt = dpp_row_i<0x101>(-3, ii[u]);   // row_shl:1 -> index of the next lane (or -3 at the row end)
+      const bool tail = nxt != ii[u] && ii[u] >= 0;
+#pragma unroll
+      for (int ch = 0; ch < kGroupGradCH; ++ch) {
+        float x = v[u][ch];
+        int f = head0;
+        float pv; int pf;
+        pv = dpp_row_f<0x111>(x); pf = dpp_row_i<0x111>(1, f); x = f ? x : x + pv; f |= pf;
+        pv = dpp_row_f<0x112>(x); pf = dpp_row_i<0x112>(1, f); x = f ? x : x + pv; f |= pf;
+        pv = dpp_row_f<0x114>(x); pf = dpp_row_i<0x114>(1, f); x = f ? x : x + pv; f |= pf;
+        pv = dpp_row_f<0x118>(x); pf = dpp_row_i<0x118>(1, f); x = f ? x : x + pv; f |= pf;
+        if (tail && ch < nch) atomicAdd(&acc[ch * n + ii[u]], x);
+      }
     }
   }
   __syncthreads();
   for (int i = threadIdx.x; i < nch * n; i += kScatterThreads)
     grad_points[((size_t)b * c + c0) * n + i] = acc[i];
+}
+
+// group_points_grad over inverse lists (istnet_pn2_csr_build): the LDS float-atomic unit bounds the kernel above at
+// ~1 TB/s whatever the number of loads in flight (round-2 sweep of channels per workgroup x unroll: no effect), so
+// the default route stages CH gradient rows point-major in LDS ([slot][CH], coalesced float4 reads of grad_out) and
+// lets every source point sum its own list: no atomics, summation in a fixed order (four lanes take contiguous
+// quarters of a list, combined as (q0 + q1) + (q2 + q3)), each grad_out element read from HBM exactly once.
+template <int CH>
+__global__ __launch_bounds__(256) void group_grad_csr_kernel(int c, int n, int P, const float* __restrict__ grad_out,
+                                                             const int* __restrict__ off_all,
+                                                             const int* __restrict__ ent_all,
+                                                             float* __restrict__ grad_points) {
+  extern __shared__ __attribute__((aligned(16))) float gg_rows[];   // [P][CH]
+  const int b = blockIdx.y, c0 = blockIdx.x * CH;
+  const int nch = min(CH, c - c0);
+  const float* g = grad_out + ((size_t)b * c + c0) * P;
+  if ((P & 3) == 0) {
+    for (int p = threadIdx.x * 4; p < P; p += 1024) {
+      float4 v[CH];
+#pragma unroll
+      for (int ch = 0; ch < CH; ++ch) v[ch] = *reinterpret_cast<const float4*>(g + (size_t)min(ch, nch - 1) * P + p);
+#pragma unroll
+      for (int ch = 0; ch < CH; ++ch) {
+        gg_rows[(size_t)(p + 0) * CH + ch] = v[ch].x; gg_rows[(size_t)(p + 1) * CH + ch] = v[ch].y;
+        gg_rows[(size_t)(p + 2) * CH + ch] = v[ch].z; gg_rows[(size_t)(p + 3) * CH + ch] = v[ch].w;
+      }
+    }
+  } else {
+    for (int p = threadIdx.x; p < P; p += 256)
+#pragma unroll
+      for (int ch = 0; ch < CH; ++ch) gg_rows[(size_t)p * CH + ch] = g[(size_t)min(ch, nch - 1) * P + p];
+  }
+  __syncthreads();
+  const int* off = off_all + (size_t)b * (n + 1);
+  const int* ent = ent_all + (size_t)b * P;
+  const int part = threadIdx.x & 3;
+  const int n_round = (n + 63) / 64 * 64;            // whole quads stay converged for the DPP combine
+  for (int i = threadIdx.x >> 2; i < n_round; i += 64) {
+    const bool valid = i < n;
+    const int a0 = valid ? off[i] : 0, z0 = valid ? off[i + 1] : 0;
+    const int q = (z0 - a0 + 3) >> 2;
+    const int a = min(a0 + part * q, z0), z = min(a + q, z0);
+    float sum[CH];
+#pragma unroll
+    for (int ch = 0; ch < CH; ++ch) sum[ch] = 0.f;
+    for (int u = a; u < z; ++u) {
+      const int e = ent[u];
+#pragma unroll
+      for (int ch = 0; ch < CH; ++ch) sum[ch] += gg_rows[(size_t)e * CH + ch];
+    }
+#pragma unroll
+    for (int ch = 0; ch < CH; ++ch) {
+      sum[ch] += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(sum[ch]), 0xB1, 0xf, 0xf, false));   // [1,0,3,2]
+      sum[ch] += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(sum[ch]), 0x4E, 0xf, 0xf, false));   // [2,3,0,1]
+    }
+    if (valid && part == 0) {
+#pragma unroll
+      for (int ch = 0; ch < CH; ++ch)
+        if (ch < nch) grad_points[((size_t)b * c + c0 + ch) * n + i] = sum[ch];
+    }
+  }
 }
 
 // ---- three_interpolate_grad without atomics: per-cloud inverse lists (CSR) of the 3n taps, then a gather.
@@ -1016,6 +1098,36 @@ int istnet_pn2_group_points_grad(int b, int c, int n, int npoints, int nsample,
   if (b == 0 || c == 0) return 0;
   if (npoints == 0 || nsample == 0) return launch_group_grad(b, c, n, 0, 1, grad_out, idx, grad_points, as_stream(stream));
   return launch_group_grad(b, c, n, npoints, nsample, grad_out, idx, grad_points, as_stream(stream));
+}
+
+// channels per workgroup of group_grad_csr_kernel: the rows must fit 64 KB of LDS and the grid should fill the chip
+static int group_grad_csr_ch(int b, int c, long long P) {
+  int ch = 16;
+  while (ch > 1 && ((size_t)ch * P * 4 > (size_t)kMaxLdsRowBytes || (long long)b * ceil_div(c, ch) < 1024)) ch >>= 1;
+  return ch;
+}
+
+int istnet_pn2_group_points_grad_csr(int b, int c, int n, int npoints, int nsample, const float* grad_out,
+                                     const int* offsets, const int* entries, float* grad_points, void* stream) {
+  if (b < 0 || c < 0 || n <= 0 || npoints <= 0 || nsample <= 0 || !offsets || !entries) return ISTNET_PN2_EINVAL;
+  if (b == 0 || c == 0) return 0;
+  const long long P = (long long)npoints * nsample;
+  const int ch = group_grad_csr_ch(b, c, P);
+  if ((size_t)ch * P * 4 > (size_t)kMaxLdsRowBytes) return ISTNET_PN2_EINVAL;   // one row does not fit: atomic kernel
+  const dim3 grid(ceil_div(c, ch), b);
+  const size_t lds = (size_t)ch * P * 4;
+#define ISTNET_GGC(CH)                                                                                           \
+  hipLaunchKernelGGL(group_grad_csr_kernel<CH>, grid, dim3(256), lds, as_stream(stream), c, n, (int)P, grad_out, \
+                     offsets, entries, grad_points)
+  switch (ch) {
+    case 16: ISTNET_GGC(16); break;
+    case 8: ISTNET_GGC(8); break;
+    case 4: ISTNET_GGC(4); break;
+    case 2: ISTNET_GGC(2); break;
+    default: ISTNET_GGC(1); break;
+  }
+#undef ISTNET_GGC
+  return (int)hipGetLastError();
 }
 
 int istnet_pn2_three_nn(int b, int n, int m, const float* unknown, const float* known, float* dist2,

@@ -340,14 +340,27 @@ def group_points(points, idx):
     return out
 
 
-def group_points_grad(grad_out, idx, n):
-    """(B,C,npoint,nsample) f32, (B,npoint,nsample) i32, n -> (B,C,n).  group_points.cpp:42-65"""
+def group_points_grad(grad_out, idx, n, csr=None):
+    """(B,C,npoint,nsample) f32, (B,npoint,nsample) i32, n -> (B,C,n).  group_points.cpp:42-65
+    ``csr``: optional result of ball_csr(idx, n) (extension of the reference signature)."""
     _contig(grad_out, "grad_out"); _contig(idx, "idx"); _is_float(grad_out, "grad_out"); _is_int(idx, "idx")
     dev = _device_of(grad_out, "grad_out", (idx, "idx"))
     b, c, npoints, nsample = grad_out.shape
     out = torch.empty((b, c, int(n)), dtype=torch.float32, device=dev)
+    lib = _native.lib()
+    # default up to 4096 slots per cloud: deterministic gather over per-cloud inverse lists (one extra launch builds
+    # them, all channels reuse them): 2.2-2.6x faster than the LDS-atomic kernel there (list build included); at 8192
+    # slots the build (34 us) + a 2-channel-per-workgroup gather (44 us) lose to the atomics (62 us), so larger rows
+    # take the list route only when the caller hands the lists in (built once, off the critical path)
+    if csr is None and b * c > 0 and 0 < npoints * nsample <= 4096:
+        csr = ball_csr(idx, int(n))
     with torch.cuda.device(dev):
-        _native.check(_native.lib().istnet_pn2_group_points_grad(
-            b, c, int(n), npoints, nsample, _ptr(grad_out), _ptr(idx), _ptr(out), _stream(dev)),
-            "group_points_grad")
+        if csr is not None and 0 < npoints * nsample <= 16384:
+            _native.check(lib.istnet_pn2_group_points_grad_csr(
+                b, c, int(n), npoints, nsample, _ptr(grad_out), _ptr(csr[0]), _ptr(csr[1]), _ptr(out), _stream(dev)),
+                "group_points_grad_csr")
+        else:
+            _native.check(lib.istnet_pn2_group_points_grad(
+                b, c, int(n), npoints, nsample, _ptr(grad_out), _ptr(idx), _ptr(out), _stream(dev)),
+                "group_points_grad")
     return out

@@ -128,6 +128,20 @@ def test_group_points_and_grad(ext, oracle, b, c, n, npoint, nsample):
     ref = torch.zeros(b, c, n, dtype=torch.float64)
     ref.scatter_add_(2, idx.long().reshape(b, 1, -1).expand(b, c, -1), go.double().reshape(b, c, -1))
     torch.testing.assert_close(ggot.double(), ref, rtol=1e-4, atol=1e-4)
+    # the reference-shaped C entry (LDS atomics, no lists) stays a supported route: same sums
+    from istnet_amd import _native
+    god, idxd = go.to(DEV), idx.to(DEV)
+    out = torch.empty(b, c, n, device=DEV)
+    _native.check(_native.lib().istnet_pn2_group_points_grad(b, c, n, npoint, nsample, god.data_ptr(), idxd.data_ptr(),
+                                                             out.data_ptr(), torch.cuda.current_stream().cuda_stream), "gg")
+    torch.testing.assert_close(out.cpu().double(), ref, rtol=1e-4, atol=1e-4)
+    # the list route (default up to 4096 slots per cloud, on request up to 16384) is deterministic
+    if npoint * nsample <= 16384:
+        csr = ext.ball_csr(idxd, n)
+        assert csr is not None
+        a = ext.group_points_grad(god, idxd, n, csr=csr).cpu()
+        torch.testing.assert_close(a.double(), ref, rtol=1e-4, atol=1e-4)
+        assert torch.equal(ext.group_points_grad(god, idxd, n, csr=csr).cpu(), a)
 
 
 @pytest.mark.parametrize("b,c,m,n", [(2, 512, 64, 128), (2, 256, 256, 512), (2, 256, 512, 1024), (1, 3, 4, 2),
