@@ -90,6 +90,16 @@ __device__ __forceinline__ unsigned wave_min_u32(unsigned v) {
   return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
 }
 
+// Workgroup barrier that orders LDS traffic only (s_waitcnt lgkmcnt(0) + s_barrier): __syncthreads() also waits for
+// vmcnt(0), i.e. for the acknowledgement of the global stores of the previous FPS round (idxs[j], picked[j]) -- a full
+// memory round trip per round in the multi-wave kernel.
+__device__ __forceinline__ void lds_only_barrier() {
+  __atomic_signal_fence(__ATOMIC_SEQ_CST);
+  __builtin_amdgcn_s_waitcnt(0xc07f);
+  __builtin_amdgcn_s_barrier();
+  __atomic_signal_fence(__ATOMIC_SEQ_CST);
+}
+
 // ============================================================================
 // Furthest point sampling
 // ============================================================================
@@ -131,7 +141,12 @@ __global__ __launch_bounds__(NW * 64) void fps_regs_kernel(int n, int m, int bs_
 
   constexpr int PP = (PPT + 1) / 2;  // point slots are held in pairs (packed f32 math)
   f32x2 px[PP], py[PP], pz[PP];
-  float tmp[2 * PP];
+  // Running minimum distances as the BITS of the f32 value: squared distances are >= +0, and for non-negative floats
+  // the signed-integer order of the bits is the float order, so min / max are v_min_i32 / v_max3_i32 -- exact, and
+  // without the canonicalising v_max_f32 x,x the compiler must put in front of every loop-carried fminf operand.
+  // An invalid slot holds -1: min(d, -1) = -1 stays invalid and never beats best = -1.  (A NaN distance has positive
+  // bits above every finite value: min keeps the old value, as fminf and the reference's min() do.)
+  int tmp[2 * PP];
 #pragma unroll
   for (int i = 0; i < 2 * PP; ++i) {
     const unsigned tk = (unsigned)(i * THREADS + tid);
@@ -140,7 +155,7 @@ __global__ __launch_bounds__(NW * 64) void fps_regs_kernel(int n, int m, int bs_
     px[i / 2][i % 2] = valid ? fps_lds[3 * k + 0] : 0.f;
     py[i / 2][i % 2] = valid ? fps_lds[3 * k + 1] : 0.f;
     pz[i / 2][i % 2] = valid ? fps_lds[3 * k + 2] : 0.f;
-    tmp[i] = valid ? 1e10f : -1.0f;  // invalid slot: min(d,-1) = -1 never beats best = -1
+    tmp[i] = valid ? __float_as_int(1e10f) : -1;
   }
 
   int old = 0;
@@ -150,24 +165,30 @@ __global__ __launch_bounds__(NW * 64) void fps_regs_kernel(int n, int m, int bs_
     const float x1 = fps_lds[3 * old + 0];
     const float y1 = fps_lds[3 * old + 1];
     const float z1 = fps_lds[3 * old + 2];
-    float best = -1.0f;
+    // Per PAIR of slots: two integer minima, one v_max3 for the running maximum, and the index bookkeeping once per
+    // pair (which of the two is larger -- the lower slot on a tie -- and whether the pair beat the maximum strictly,
+    // so a lane keeps its LOWEST slot among equals): 7 instructions per pair besides the distances.
+    int best = -1;
     int besti = 0;
 #pragma unroll
     for (int i = 0; i < PP; ++i) {
       const f32x2 d = sqdist2<CONV>(px[i], py[i], pz[i], x1, y1, z1);
-#pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        if (2 * i + h < PPT) {
-          const float d2 = fminf(d[h], tmp[2 * i + h]);
-          tmp[2 * i + h] = d2;
-          const bool gt = d2 > best;
-          besti = gt ? 2 * i + h : besti;
-          best = gt ? d2 : best;
-        }
+      const int a = min(__float_as_int(d[0]), tmp[2 * i]);
+      tmp[2 * i] = a;
+      if (2 * i + 1 < PPT) {
+        const int c = min(__float_as_int(d[1]), tmp[2 * i + 1]);
+        tmp[2 * i + 1] = c;
+        const int code = c > a ? 2 * i + 1 : 2 * i;
+        const int nb = max(best, max(a, c));
+        besti = nb > best ? code : besti;
+        best = nb;
+      } else {
+        besti = a > best ? 2 * i : besti;
+        best = max(best, a);
       }
     }
     // value key: 0 for "no valid slot", otherwise float bits + 1 (d2 >= +0 => monotone)
-    const unsigned vkey = best < 0.0f ? 0u : (__float_as_uint(best) + 1u);
+    const unsigned vkey = (unsigned)(best + 1);
     unsigned vmax = wave_max_u32(vkey);
     const unsigned tk = (vkey == vmax) ? (unsigned)(besti * THREADS + tid) : 0xffffffffu;
     unsigned tkmin = wave_min_u32(tk);
@@ -177,7 +198,7 @@ __global__ __launch_bounds__(NW * 64) void fps_regs_kernel(int n, int m, int bs_
         slot[(tid >> 6) * 2 + 0] = vmax;
         slot[(tid >> 6) * 2 + 1] = tkmin;
       }
-      __syncthreads();
+      lds_only_barrier();
       unsigned bv = 0u, bt = 0xffffffffu;
 #pragma unroll
       for (int w = 0; w < NW; ++w) {
@@ -1021,8 +1042,9 @@ static int fps_impl(int b, int n, int m, const float* dataset, float* temp, int*
   const int nper = ceil_div(n, 1 << bs_log2);
   const int slots = nper << bs_log2;
   hipStream_t st = as_stream(stream);
-  // one wave per cloud is barrier-free and measured faster than four waves (LDS exchange + barrier per
-  // round) for every n <= 1024 (profiles/r01_index_microbench.txt)
+  // one wave per cloud is barrier-free and measured faster than 2 / 4 / 8 waves (LDS exchange + barrier per round:
+  // ~0.5 us per round whatever the points per lane, against 0.28-0.50 us for one wave) for every n <= 1024
+  // (profiles/r01_index_microbench.txt; round 2 re-measured with the LDS-only barrier: 256 vs 266 / 270 / 405 us)
   if (slots < g_fps_multiwave_min) return launch_fps_regs<1>(b, n, m, bs_log2, nper, dataset, idxs, picked, st);
   if (slots <= 256 * 16) return launch_fps_regs<4>(b, n, m, bs_log2, nper, dataset, idxs, picked, st);
   if (temp == nullptr || picked != nullptr) return ISTNET_PN2_EINVAL;  // large clouds: scratch buffer, no fused gather
