@@ -17,16 +17,35 @@ PEAK_MFMA_F32_TFLOPS = 157.3
 PEAK_HBM_GBS = 8000.0
 
 
+def kernel_source_hash():
+    """sha256 over csrc/*.hip (sorted by name): stamps a PMC summary with the kernel sources it was measured on."""
+    import hashlib
+    import os
+    csrc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
+    h = hashlib.sha256()
+    for f in sorted(os.listdir(csrc)):
+        if f.endswith(".hip"):
+            h.update(f.encode())
+            h.update(open(os.path.join(csrc, f), "rb").read())
+    return h.hexdigest()
+
+
 def pmc_traffic(kernel_name, path):
-    """HBM bytes per launch of `kernel_name` from a committed rocprofv3 PMC summary (tools/pmc_traffic.sh);
-    None when the file or the kernel is missing.  PMC counters cannot be read from inside the process."""
+    """HBM bytes per launch of `kernel_name` from a committed rocprofv3 PMC summary (tools/pmc_traffic.sh).  PMC
+    counters cannot be read from inside the process, so the summary carries the hash of the kernel sources it was
+    collected on (kernel_source_hash): a summary of other sources is STALE and reported as traffic = null with the
+    reason, never as a number.  (None, None) when the file or the kernel is missing."""
     import json
     import os
     if not os.path.exists(path):
         return None, None
     data = json.load(open(path))
     rec = data.get("kernels", {}).get(kernel_name)
-    return (rec["hbm_bytes_per_launch"], os.path.basename(path)) if rec else (None, None)
+    if not rec:
+        return None, None
+    if data.get("kernel_source_sha256") != kernel_source_hash():
+        return None, "stale: %s was collected on other kernel sources (re-run tools/pmc_traffic.sh)" % os.path.basename(path)
+    return rec["hbm_bytes_per_launch"], os.path.basename(path)
 
 
 def measure_replayed(capture, replays=5, only=None):

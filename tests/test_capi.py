@@ -130,3 +130,20 @@ def test_no_kernel_has_a_scratch_segment(tmp_path):
         bad = [n for n, sc, sp in zip([n for n in names if not n.startswith(("hidden_", "by_"))], scratch, spills) if sc or sp]
         assert not any(scratch) and not any(spills), bad
     assert kernels > 100
+
+
+def test_pmc_traffic_summary_is_tied_to_the_kernel_sources(tmp_path):
+    """bench.py reports roofline.traffic from a committed rocprofv3 PMC summary; a summary collected on other kernel
+    sources must come back as null with the reason, never as a number."""
+    import json
+    from istnet_amd import roofline
+    rec = {"kernels": {"some_kernel": {"hbm_bytes_per_launch": 123.0}}}
+    f = tmp_path / "t.json"
+    f.write_text(json.dumps(dict(rec, kernel_source_sha256=roofline.kernel_source_hash())))
+    assert roofline.pmc_traffic("some_kernel", str(f)) == (123.0, "t.json")
+    assert roofline.pmc_traffic("other_kernel", str(f)) == (None, None)
+    f.write_text(json.dumps(dict(rec, kernel_source_sha256="0" * 64)))
+    val, why = roofline.pmc_traffic("some_kernel", str(f))
+    assert val is None and why.startswith("stale")
+    f.write_text(json.dumps(rec))                      # summaries from before the stamp existed
+    assert roofline.pmc_traffic("some_kernel", str(f))[0] is None

@@ -25,7 +25,11 @@ for name, d in rows[:40]:
     # bytes per launch: FETCH_SIZE KiB x 1024 x 2 (gfx950 wide-read correction) + WRITE_SIZE KiB x 1024
     out[short] = {"fetch_kib_raw": f[0], "write_kib_raw": w[0], "launches": f[1],
                   "hbm_bytes_per_launch": f[0] * 1024 * 2 + w[0] * 1024}
-json.dump({"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) over bench.py --eager",
+import sys, os
+sys.path.insert(0, os.getcwd())
+import istnet_amd
+from istnet_amd.roofline import kernel_source_hash
+json.dump({"kernel_source_sha256": kernel_source_hash(), "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) over bench.py --eager",
            "correction": "FETCH_SIZE x2 on gfx950 for wide coalesced reads (MI355X_MICROARCH.md, HBM); WRITE_SIZE as reported",
            "kernels": out}, open("gpurun_out/pmc_${TAG}_traffic.json", "w"), indent=1)
 PY
