@@ -1280,14 +1280,21 @@ class FusedFPFunction(Function):
             dy0 = _empty((b, cout0, n), torch.float32, dev)
             _native.check(lib.istnet_pw_dy(b, cout0, n, y0.data_ptr(), d_a0.data_ptr(), bn0.data_ptr(),
                                            bwdc0.data_ptr(), dy0.data_ptr(), st), "pw_dy")
+            # The skip gradient feeds the set-abstraction backward much later; the interpolation gradient feeds the next
+            # (coarser) propagation level at once.  So the skip dgrad leaves the chain: it runs on a side stream beside
+            # the interpolation scatter and the known-feature dgrad, joined before this node returns.
+            streams = _scale_streams(dev, 2) if (USE_FP_SKIP_STREAM and need_skip and (need_known or need_w[0])) \
+                else [torch.cuda.current_stream(dev)] * 2
             if need_skip:
                 ds = _empty((b, c1, n), torch.float32, dev)
-                _native.check(_native.timed(
-                    _dgrad_kname(lib, b, c1, cout0, n, dense=True), 2.0 * b * n * c1 * cout0,
-                    4.0 * b * n * (c1 + cout0), lambda: lib.istnet_pw_dgrad(
-                        b, cin, c2, c1, cout0, n, 0, w2.data_ptr(), dy0.data_ptr(), dy0.data_ptr(), None, 0, None,
-                        ident.data_ptr(), ibw.data_ptr(), ds.data_ptr(), None, None, None, None, st)),
-                    "pw_dgrad(fp skip)")
+                with torch.cuda.stream(streams[1]):
+                    sst = _st(dev)
+                    _native.check(_native.timed(
+                        _dgrad_kname(lib, b, c1, cout0, n, dense=True), 2.0 * b * n * c1 * cout0,
+                        4.0 * b * n * (c1 + cout0), lambda: lib.istnet_pw_dgrad(
+                            b, cin, c2, c1, cout0, n, 0, w2.data_ptr(), dy0.data_ptr(), dy0.data_ptr(), None, 0, None,
+                            ident.data_ptr(), ibw.data_ptr(), ds.data_ptr(), None, None, None, None, sst)),
+                        "pw_dgrad(fp skip)")
                 result["dskip"] = ds
             gk = None
             if need_known or need_w[0]:
@@ -1335,6 +1342,7 @@ class FusedFPFunction(Function):
                         dest.copy_(dwa)
                     return keep, dy0, gk
                 wextra.append(wjob)
+            _join_streams(streams)
             return None
 
         with torch.cuda.device(dev):
@@ -1365,6 +1373,7 @@ def fp_level(mlp, known_feats, skip, idx, weight, csr=None):
 
 
 USE_FUSED_FP = True
+USE_FP_SKIP_STREAM = True     # feature-propagation backward: skip-branch dgrad on a side stream (off the chain)
 _ONES = {}
 
 
