@@ -83,13 +83,10 @@ def test_encoder_b2(monkeypatch):
     # same index decisions (make_golden.py prints it), so the 1e-4 bar is applied against that float64 result
     # (out_train_f64); against the reference's fp32 output two valid fp32 evaluations may differ by the sum of
     # their rounding errors.
-    # This B=2 case (train-mode BN over two clouds, 24 normalised layers deep) sits at the fp32 noise ceiling: the
-    # worst of the 32768 sampled outputs of the HIP path is 1.06e-4 from the float64 result (reference fp32:
-    # 0.87e-4), so the absolute part of the bound is 1.5e-4 here; the per-layer fixtures, the heads and the
-    # full-size B=32 encoder test hold the plain 1e-4.
+    # Round 2 (profiles/r02_error_budget_golden_b2.txt): the worst output of the HIP path is 7.9e-5 from the float64
+    # result (the fp32 torch composition of the same layers: 1.14e-4), so the plain 1e-4 bar holds here as well.
     got = out.detach().cpu().numpy()[:, :, ::8]
-    np.testing.assert_allclose(got, z["out_train_f64"], rtol=1e-4, atol=1.5e-4)
-    assert float(np.mean(np.abs(got - z["out_train_f64"]) > 1e-4 + 1e-4 * np.abs(z["out_train_f64"]))) < 1e-4
+    np.testing.assert_allclose(got, z["out_train_f64"], **TOL)
     np.testing.assert_allclose(got, z["out_train"], rtol=2e-4, atol=2e-4)
     out.square().mean().backward()
     # Gradients of this loss are ill-conditioned end to end (torch-CPU vs torch-GPU composition already

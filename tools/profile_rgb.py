@@ -42,5 +42,5 @@ tot = sum(e.device_time_total for e in rows)
 print(f"# RGB branch fwd+bwd, B=32 3x192x192, fp32 channels-last on MIOpen: {ms:.2f} ms/step wall; sum of kernel time {tot / 1e3:.2f} ms")
 print(f"# top-level children: {list(parts)}")
 print(f"{'pct':>6} {'calls':>6} {'total_us':>10} {'avg_us':>9}  kernel")
-for e in rows[:40]:
+for e in rows[:70]:
     print(f"{100 * e.device_time_total / tot:6.2f} {e.count:6d} {e.device_time_total:10.1f} {e.device_time_total / e.count:9.1f}  {e.key[:150]}")
