@@ -27,6 +27,24 @@ ISTNET_PN2_API int istnet_prelu_bwd(long long n, const float *x, const float *dy
 ISTNET_PN2_API int istnet_upsample_bilinear_ac_bwd_nhwc(int b, int c, int hin, int win, int hout, int wout,
                                                         const float *dy, float *dx, void *stream);
 
+/* Forward of the same op: y (b, hout, wout, c) from x (b, hin, win, c), channels-last, c % 4 == 0; the blend in the
+ * framework's order h0*(w0*a + w1*b) + h1*(w0*c + w1*d).  One thread per output pixel and channel quad; the
+ * framework's kernel writes the decoder's 192x192 map at ~0.8 TB/s, this one is bound by the store stream. */
+ISTNET_PN2_API int istnet_upsample_bilinear_ac_fwd_nhwc(int b, int c, int hin, int win, int hout, int wout,
+                                                        const float *x, float *y, void *stream);
+
+/* PSPUpsample (modules.py:36-49) = bilinear 2x upsample (align_corners) -> 3x3 convolution (padding 1) without the
+ * convolution at full size: conv3x3(U p) = sum_taps shift_tap(U (W_tap p)).  The caller forms q = p . Wr on the small
+ * map (one GEMM, (b*hin*win, cin) x (cin, 9*c), Wr[ci][(ky*3+kx)*c + co] = W[co][ci][ky][kx]: a quarter of the
+ * convolution's flops, forward and both backward products); these two kernels do what is left at full size:
+ *   fwd: y[b,oy,ox,co] = bias[co] + sum_{ky,kx} inside(oy+ky-1, ox+kx-1) * bilinear(q[b,:,:,ky*3+kx,co]; oy+ky-1, ox+kx-1)
+ *   bwd: dq = transpose of that map applied to dy (gather form, no atomics).
+ * q / dq: (b, hin, win, 9, c) f32; y / dy: (b, hout, wout, c) channels-last; c % 4 == 0; bias may be NULL. */
+ISTNET_PN2_API int istnet_upconv3_fwd_nhwc(int b, int c, int hin, int win, int hout, int wout, const float *q,
+                                           const float *bias, float *y, void *stream);
+ISTNET_PN2_API int istnet_upconv3_bwd_nhwc(int b, int c, int hin, int win, int hout, int wout, const float *dy,
+                                           float *dq, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -27,6 +27,9 @@ SIGNATURES = {
     "istnet_prelu_bwd_parts": [_l],
     "istnet_prelu_bwd": [_l, _p, _p, _p, _p, _p, _p],
     "istnet_upsample_bilinear_ac_bwd_nhwc": [_i, _i, _i, _i, _i, _i, _p, _p, _p],
+    "istnet_upsample_bilinear_ac_fwd_nhwc": [_i, _i, _i, _i, _i, _i, _p, _p, _p],
+    "istnet_upconv3_fwd_nhwc": [_i, _i, _i, _i, _i, _i, _p, _p, _p, _p],
+    "istnet_upconv3_bwd_nhwc": [_i, _i, _i, _i, _i, _i, _p, _p, _p],
     "istnet_backproject_choose": [_i, _i, _i, _i, _p, _i, _l, _p, _p, _d, _d, _d, _d, _d, _i, _p, _p, _p],
     "istnet_pn2_set_tuning": [_i, _i],
     "istnet_pn2_furthest_point_sampling": [_i, _i, _i, _p, _p, _p, _p],

@@ -85,6 +85,120 @@ __global__ __launch_bounds__(kThreads) void upsample_ac_bwd_nhwc_kernel(int c4, 
   reinterpret_cast<float4*>(dx)[t] = acc;
 }
 
+// Forward of the same upsample: one thread per (output pixel, channel quad), the four taps as float4 loads (the
+// 2x-smaller source stays in L2), the blend in the framework's order
+//   h0 * (w0 * a + w1 * b) + h1 * (w0 * c + w1 * d),   h1 = src_y - floor(src_y), src_y = oy * (hin-1)/(hout-1).
+__global__ __launch_bounds__(kThreads) void upsample_ac_fwd_nhwc_kernel(int c4, int hin, int win, int hout, int wout,
+                                                                        float rh, float rw, const float* __restrict__ x,
+                                                                        float* __restrict__ y, long long total) {
+  const long long t = (long long)blockIdx.x * kThreads + threadIdx.x;
+  if (t >= total) return;
+  const int q = (int)(t % c4);
+  long long p = t / c4;
+  const int ox = (int)(p % wout); p /= wout;
+  const int oy = (int)(p % hout);
+  const int b = (int)(p / hout);
+  const float sy = rh * (float)oy, sx = rw * (float)ox;
+  const int y0 = (int)sy, x0 = (int)sx;
+  const int y1 = min(y0 + 1, hin - 1), x1 = min(x0 + 1, win - 1);
+  const float ly = sy - (float)y0, lx = sx - (float)x0;
+  const float hy = 1.f - ly, hx = 1.f - lx;
+  const float4* base = reinterpret_cast<const float4*>(x) + (size_t)b * hin * win * c4 + q;
+  const float4 a = base[((size_t)y0 * win + x0) * c4], bb = base[((size_t)y0 * win + x1) * c4];
+  const float4 c = base[((size_t)y1 * win + x0) * c4], d = base[((size_t)y1 * win + x1) * c4];
+  float4 o;
+  o.x = hy * (hx * a.x + lx * bb.x) + ly * (hx * c.x + lx * d.x);
+  o.y = hy * (hx * a.y + lx * bb.y) + ly * (hx * c.y + lx * d.y);
+  o.z = hy * (hx * a.z + lx * bb.z) + ly * (hx * c.z + lx * d.z);
+  o.w = hy * (hx * a.w + lx * bb.w) + ly * (hx * c.w + lx * d.w);
+  reinterpret_cast<float4*>(y)[t] = o;
+}
+
+// ---- bilinear 2x upsample (align_corners) followed by a 3x3 convolution, without the convolution at full size ----
+// conv3x3(U p) = sum_taps shift_tap(U (W_tap p)): the channel mixing W_tap (Cin -> Cout per tap) is a 1x1 product
+// on the SMALL map -- one GEMM p (B h w, Cin) x Wr (Cin, 9 Cout) = q, a quarter of the convolution's flops -- and
+// what is left at full size is linear interpolation and nine shifted adds, done here:
+//   out[b, y, x, co] = bias[co] + sum_{ky, kx} [ (y+ky-1, x+kx-1) inside ] * bilinear(q[b, :, :, ky*3+kx, co]; y+ky-1, x+kx-1)
+// q: (b, hin, win, 9, c) f32, out: (b, hout, wout, c) channels-last; one thread per output pixel and channel quad;
+// the 36 taps of a thread hit the L2-resident small map.  Fixed summation order.
+__global__ __launch_bounds__(kThreads) void upconv3_fwd_kernel(int c4, int hin, int win, int hout, int wout, float rh,
+                                                               float rw, const float* __restrict__ q,
+                                                               const float* __restrict__ bias, float* __restrict__ y,
+                                                               long long total) {
+  const long long t = (long long)blockIdx.x * kThreads + threadIdx.x;
+  if (t >= total) return;
+  const int cq = (int)(t % c4);
+  long long p = t / c4;
+  const int ox = (int)(p % wout); p /= wout;
+  const int oy = (int)(p % hout);
+  const int b = (int)(p / hout);
+  // (scalar reads: a parameter that lives in a flat optimizer buffer is only 4-byte aligned)
+  float4 acc = bias != nullptr ? make_float4(bias[4 * cq], bias[4 * cq + 1], bias[4 * cq + 2], bias[4 * cq + 3])
+                               : make_float4(0.f, 0.f, 0.f, 0.f);
+  const float4* qb = reinterpret_cast<const float4*>(q) + (size_t)b * hin * win * 9 * c4 + cq;
+#pragma unroll
+  for (int ky = 0; ky < 3; ++ky) {
+    const int yy = oy + ky - 1;
+    if (yy < 0 || yy >= hout) continue;
+    const float sy = rh * (float)yy;
+    const int y0 = (int)sy, y1 = min(y0 + 1, hin - 1);
+    const float ly = sy - (float)y0, hy = 1.f - ly;
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) {
+      const int xx = ox + kx - 1;
+      if (xx < 0 || xx >= wout) continue;
+      const float sx = rw * (float)xx;
+      const int x0 = (int)sx, x1 = min(x0 + 1, win - 1);
+      const float lx = sx - (float)x0, hx = 1.f - lx;
+      const int tap = ky * 3 + kx;
+      const float4 a = qb[(((size_t)y0 * win + x0) * 9 + tap) * c4], bb = qb[(((size_t)y0 * win + x1) * 9 + tap) * c4];
+      const float4 c = qb[(((size_t)y1 * win + x0) * 9 + tap) * c4], d = qb[(((size_t)y1 * win + x1) * 9 + tap) * c4];
+      acc.x += hy * (hx * a.x + lx * bb.x) + ly * (hx * c.x + lx * d.x);
+      acc.y += hy * (hx * a.y + lx * bb.y) + ly * (hx * c.y + lx * d.y);
+      acc.z += hy * (hx * a.z + lx * bb.z) + ly * (hx * c.z + lx * d.z);
+      acc.w += hy * (hx * a.w + lx * bb.w) + ly * (hx * c.w + lx * d.w);
+    }
+  }
+  reinterpret_cast<float4*>(y)[t] = acc;
+}
+
+// gradient of the above w.r.t. q, gather form: q[b, iy, ix, tap, :] collects, over the full-size positions (yy, xx)
+// whose interpolation reads (iy, ix), weight * dy[b, yy - ky + 1, xx - kx + 1, :] when that output exists.
+__global__ __launch_bounds__(kThreads) void upconv3_bwd_kernel(int c4, int hin, int win, int hout, int wout, float rh,
+                                                               float rw, float inv_rh, float inv_rw,
+                                                               const float* __restrict__ dy, float* __restrict__ dq,
+                                                               long long total) {
+  const long long t = (long long)blockIdx.x * kThreads + threadIdx.x;
+  if (t >= total) return;
+  const int cq = (int)(t % c4);
+  long long p = t / c4;
+  const int tap = (int)(p % 9); p /= 9;
+  const int ix = (int)(p % win); p /= win;
+  const int iy = (int)(p % hin);
+  const int b = (int)(p / hin);
+  const int ky = tap / 3, kx = tap - 3 * ky;
+  // full-size rows / columns that can read input row iy / column ix: src in (i - 1, i + 1)
+  // (one extra on each side absorbs the rounding of the f32 products, as in upsample_ac_bwd_nhwc_kernel)
+  const int yy0 = max(0, (int)floorf((float)(iy - 1) * inv_rh) - 1), yy1 = min(hout - 1, (int)ceilf((float)(iy + 1) * inv_rh) + 1);
+  const int xx0 = max(0, (int)floorf((float)(ix - 1) * inv_rw) - 1), xx1 = min(wout - 1, (int)ceilf((float)(ix + 1) * inv_rw) + 1);
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  const float4* gb = reinterpret_cast<const float4*>(dy) + (size_t)b * hout * wout * c4 + cq;
+  for (int yy = yy0; yy <= yy1; ++yy) {
+    const float wy = tap_weight(yy, iy, rh, hin);
+    const int oy = yy - ky + 1;
+    if (wy == 0.f || oy < 0 || oy >= hout) continue;
+    for (int xx = xx0; xx <= xx1; ++xx) {
+      const int ox = xx - kx + 1;
+      if (ox < 0 || ox >= wout) continue;
+      const float w = wy * tap_weight(xx, ix, rw, win);
+      if (w == 0.f) continue;
+      const float4 g = gb[((size_t)oy * wout + ox) * c4];
+      acc.x += w * g.x; acc.y += w * g.y; acc.z += w * g.z; acc.w += w * g.w;
+    }
+  }
+  reinterpret_cast<float4*>(dq)[t] = acc;
+}
+
 }  // namespace
 
 extern "C" {
@@ -110,6 +224,39 @@ int istnet_upsample_bilinear_ac_bwd_nhwc(int b, int c, int hin, int win, int hou
   const long long total = (long long)b * hin * win * (c / 4);
   hipLaunchKernelGGL(upsample_ac_bwd_nhwc_kernel, dim3((unsigned)((total + kThreads - 1) / kThreads)), dim3(kThreads), 0,
                      (hipStream_t)stream, c / 4, hin, win, hout, wout, rh, rw, 1.f / rh, 1.f / rw, dy, dx, total);
+  return (int)hipGetLastError();
+}
+
+int istnet_upsample_bilinear_ac_fwd_nhwc(int b, int c, int hin, int win, int hout, int wout, const float* x, float* y,
+                                         void* stream) {
+  if (b <= 0 || c <= 0 || (c & 3) || hin < 2 || win < 2 || hout < 2 || wout < 2 || !x || !y) return ISTNET_PN2_EINVAL;
+  if (((uintptr_t)x | (uintptr_t)y) & 15) return ISTNET_PN2_EINVAL;
+  const float rh = (float)(hin - 1) / (float)(hout - 1), rw = (float)(win - 1) / (float)(wout - 1);
+  const long long total = (long long)b * hout * wout * (c / 4);
+  hipLaunchKernelGGL(upsample_ac_fwd_nhwc_kernel, dim3((unsigned)((total + kThreads - 1) / kThreads)), dim3(kThreads), 0,
+                     (hipStream_t)stream, c / 4, hin, win, hout, wout, rh, rw, x, y, total);
+  return (int)hipGetLastError();
+}
+
+int istnet_upconv3_fwd_nhwc(int b, int c, int hin, int win, int hout, int wout, const float* q, const float* bias,
+                            float* y, void* stream) {
+  if (b <= 0 || c <= 0 || (c & 3) || hin < 2 || win < 2 || hout < 2 || wout < 2 || !q || !y) return ISTNET_PN2_EINVAL;
+  if (((uintptr_t)q | (uintptr_t)y) & 15) return ISTNET_PN2_EINVAL;
+  const float rh = (float)(hin - 1) / (float)(hout - 1), rw = (float)(win - 1) / (float)(wout - 1);
+  const long long total = (long long)b * hout * wout * (c / 4);
+  hipLaunchKernelGGL(upconv3_fwd_kernel, dim3((unsigned)((total + kThreads - 1) / kThreads)), dim3(kThreads), 0,
+                     (hipStream_t)stream, c / 4, hin, win, hout, wout, rh, rw, q, bias, y, total);
+  return (int)hipGetLastError();
+}
+
+int istnet_upconv3_bwd_nhwc(int b, int c, int hin, int win, int hout, int wout, const float* dy, float* dq,
+                            void* stream) {
+  if (b <= 0 || c <= 0 || (c & 3) || hin < 2 || win < 2 || hout < 2 || wout < 2 || !dy || !dq) return ISTNET_PN2_EINVAL;
+  if (((uintptr_t)dy | (uintptr_t)dq) & 15) return ISTNET_PN2_EINVAL;
+  const float rh = (float)(hin - 1) / (float)(hout - 1), rw = (float)(win - 1) / (float)(wout - 1);
+  const long long total = (long long)b * hin * win * 9 * (c / 4);
+  hipLaunchKernelGGL(upconv3_bwd_kernel, dim3((unsigned)((total + kThreads - 1) / kThreads)), dim3(kThreads), 0,
+                     (hipStream_t)stream, c / 4, hin, win, hout, wout, rh, rw, 1.f / rh, 1.f / rw, dy, dq, total);
   return (int)hipGetLastError();
 }
 

@@ -63,6 +63,19 @@ class PReLU(nn.PReLU):
         return super().forward(x)
 
 
+def _upsample_aligned_forward(x, size):
+    """F.interpolate(x, size, mode="bilinear", align_corners=True) of a channels-last float32 CUDA map through
+    include/istnet_rgb.h's forward kernel."""
+    from . import _native
+    b, c, hin, win = x.shape
+    y = torch.empty((b, c, size[0], size[1]), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
+    with torch.cuda.device(x.device):
+        _native.check(_native.lib().istnet_upsample_bilinear_ac_fwd_nhwc(
+            b, c, hin, win, size[0], size[1], x.data_ptr(), y.data_ptr(),
+            torch.cuda.current_stream(x.device).cuda_stream), "upsample_bilinear_ac_fwd_nhwc")
+    return y
+
+
 class _UpsampleAlignedFn(torch.autograd.Function):
     """Bilinear upsample with align_corners=True on a channels-last map: the framework's forward, a gather-form backward
     (every input pixel sums its weighted output pixels: no atomics, so the step stays bit-reproducible)."""
@@ -70,7 +83,7 @@ class _UpsampleAlignedFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, size):
         ctx.in_shape = tuple(x.shape)
-        return F.interpolate(x, size=size, mode="bilinear", align_corners=True)
+        return _upsample_aligned_forward(x, size)
 
     @staticmethod
     def backward(ctx, dy):
@@ -94,9 +107,12 @@ class Upsample2x(nn.Upsample):
 
     def forward(self, x):
         if (USE_NATIVE_DECODER_BACKWARD and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4
-                and x.shape[1] % 4 == 0 and x.shape[2] > 1 and x.shape[3] > 1 and torch.is_grad_enabled()
-                and x.requires_grad and x.is_contiguous(memory_format=torch.channels_last)):
-            return _UpsampleAlignedFn.apply(x, (2 * x.shape[2], 2 * x.shape[3]))
+                and x.shape[1] % 4 == 0 and x.shape[2] > 1 and x.shape[3] > 1
+                and x.is_contiguous(memory_format=torch.channels_last)):
+            size = (2 * x.shape[2], 2 * x.shape[3])
+            if torch.is_grad_enabled() and x.requires_grad:
+                return _UpsampleAlignedFn.apply(x, size)
+            return _upsample_aligned_forward(x, size)        # inference: the same forward kernel, no autograd node
         return super().forward(x)
 
 
@@ -170,8 +186,62 @@ class ResNet(nn.Module):
         return self.layer4(x3), x3
 
 
+USE_PSP_LINEAR_FUSION = True   # False: the reference composition (pool -> conv -> upsample -> cat -> 2560-channel bottleneck)
+_PSP_MATRICES = {}
+
+
+def _psp_matrices(sizes, h, w, device):
+    """Fixed matrices of the pyramid: P (R, h*w) stacks the adaptive-average-pool operators of all bin sizes
+    (bin i covers [floor(i*h/s), ceil((i+1)*h/s)), as the framework's AdaptiveAvgPool2d), U (h*w, R) the bilinear
+    upsample operators back to (h, w) with align_corners=False (source index max(0, (o + 0.5) * s/h - 0.5), float32
+    as the framework computes it); rows[k] = row range of bin size k; R = sum s*s."""
+    key = (tuple(sizes), h, w, str(device))
+    if key in _PSP_MATRICES:
+        return _PSP_MATRICES[key]
+
+    def pool_1d(s, n):
+        m = torch.zeros(s, n, dtype=torch.float64)
+        for i in range(s):
+            a, b = (i * n) // s, -((-(i + 1) * n) // s)
+            m[i, a:b] = 1.0 / (b - a)
+        return m
+
+    def up_1d(s, n):
+        m = torch.zeros(n, s, dtype=torch.float32)
+        scale = torch.tensor(float(s), dtype=torch.float32) / torch.tensor(float(n), dtype=torch.float32)
+        for o in range(n):
+            src = scale * (o + 0.5) - 0.5
+            src = src.clamp(min=0.0)
+            i0 = int(src)
+            i1 = i0 + (1 if i0 < s - 1 else 0)
+            l1 = src - i0
+            m[o, i0] += 1.0 - l1
+            m[o, i1] += l1
+        return m
+
+    ps, us, rows, r = [], [], [], 0
+    for s_ in sizes:
+        ps.append(torch.kron(pool_1d(s_, h), pool_1d(s_, w)).float())          # (s*s, h*w)
+        us.append(torch.kron(up_1d(s_, h), up_1d(s_, w)))                      # (h*w, s*s)
+        rows.append((r, r + s_ * s_))
+        r += s_ * s_
+    out = (torch.cat(ps, 0).to(device).contiguous(), torch.cat(us, 1).to(device).contiguous(), rows)
+    _PSP_MATRICES[key] = out
+    return out
+
+
 class PSPModule(nn.Module):
-    """Pyramid pooling at bin sizes (1,2,3,6) + 1x1 bottleneck.  [ref modules.py:10-34]"""
+    """Pyramid pooling at bin sizes (1,2,3,6) + 1x1 bottleneck.  [ref modules.py:10-34]
+
+    Every operator between ``feats`` and the bottleneck's ReLU is linear, and a 1x1 convolution commutes with a spatial
+    interpolation, so on the GPU (channels-last float32) the module is evaluated as
+
+        relu( feats . Wf^T + bias  +  U . [ (P_k feats) . Ws_k^T . Wb_k^T ]_k )
+
+    with the fixed pooling / upsampling matrices P, U of _psp_matrices: the bottleneck's slices Wb_k act on the s x s
+    maps BEFORE the upsample, the 2560-channel concatenation never exists, the large product is 512 -> 1024 instead
+    of 2560 -> 1024 (forward and both backward products), and pooling / upsampling are two small matrix products
+    (deterministic: the framework's upsample backward uses atomics).  Same parameters, same state-dict keys."""
 
     def __init__(self, features, out_features=1024, sizes=(1, 2, 3, 6)):
         super().__init__()
@@ -180,22 +250,98 @@ class PSPModule(nn.Module):
                           nn.Conv2d(features, features, kernel_size=1, bias=False)) for size in sizes])
         self.bottleneck = nn.Conv2d(features * (len(sizes) + 1), out_features, kernel_size=1)
         self.relu = nn.ReLU()
+        self.sizes = tuple(sizes)
+
+    def _forward_linear(self, feats):
+        b, c, h, w = feats.shape
+        n, cout = len(self.stages), self.bottleneck.out_channels
+        x = feats.permute(0, 2, 3, 1).reshape(b, h * w, c)                 # a view of the channels-last map
+        pmat, umat, rows = _psp_matrices(self.sizes, h, w, feats.device)
+        wb = self.bottleneck.weight.view(cout, (n + 1) * c)
+        pooled = torch.matmul(pmat, x)                                     # (B, R, C): all bin sizes at once
+        small = [torch.matmul(torch.matmul(pooled[:, r0:r1], st[1].weight.view(c, c).t()), wb[:, k * c:(k + 1) * c].t())
+                 for k, (st, (r0, r1)) in enumerate(zip(self.stages, rows))]
+        t = torch.cat(small, dim=1)                                        # (B, R, Cout)
+        acc = torch.addmm(self.bottleneck.bias, x.reshape(b * h * w, c), wb[:, n * c:].t()).view(b, h * w, cout)
+        y = torch.baddbmm(acc, umat.unsqueeze(0).expand(b, -1, -1), t)
+        return torch.relu_(y).view(b, h, w, cout).permute(0, 3, 1, 2)      # (B, Cout, h, w), channels-last
 
     def forward(self, feats):
+        if (USE_PSP_LINEAR_FUSION and feats.is_cuda and feats.dtype == torch.float32 and feats.dim() == 4
+                and feats.is_contiguous(memory_format=torch.channels_last) and self.bottleneck.bias is not None):
+            return self._forward_linear(feats)
         h, w = feats.size(2), feats.size(3)
         priors = [F.interpolate(stage(feats), size=(h, w), mode="bilinear", align_corners=False)
                   for stage in self.stages] + [feats]
         return self.relu(self.bottleneck(torch.cat(priors, 1)))
 
 
+USE_UPCONV_SPLIT = True      # PSPUpsample: channel mixing on the small map + interpolate / shift / add kernel
+UPCONV_MIN_CIN = 128         # below this the 3x3 convolution at full size is cheaper than moving q (9 x Cout channels)
+
+
+class _UpConvTailFn(torch.autograd.Function):
+    """q (B, h, w, 9*Cout) -> y (B, Cout, 2h, 2w) channels-last: the full-size part of upsample -> conv3x3
+    (include/istnet_rgb.h, istnet_upconv3_*).  Linear in q; the bias gradient is the plain sum of dy."""
+
+    @staticmethod
+    def forward(ctx, q, bias, cout):
+        from . import _native
+        b, h, w, _ = q.shape
+        ctx.dims = (b, h, w, cout)
+        ctx.has_bias = bias is not None
+        y = torch.empty((b, cout, 2 * h, 2 * w), dtype=q.dtype, device=q.device, memory_format=torch.channels_last)
+        with torch.cuda.device(q.device):
+            _native.check(_native.lib().istnet_upconv3_fwd_nhwc(
+                b, cout, h, w, 2 * h, 2 * w, q.data_ptr(), bias.data_ptr() if bias is not None else None, y.data_ptr(),
+                torch.cuda.current_stream(q.device).cuda_stream), "upconv3_fwd_nhwc")
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        from . import _native
+        b, h, w, cout = ctx.dims
+        dy = dy.contiguous(memory_format=torch.channels_last)
+        dq = torch.empty((b, h, w, 9 * cout), dtype=dy.dtype, device=dy.device)
+        with torch.cuda.device(dy.device):
+            _native.check(_native.lib().istnet_upconv3_bwd_nhwc(
+                b, cout, h, w, 2 * h, 2 * w, dy.data_ptr(), dq.data_ptr(),
+                torch.cuda.current_stream(dy.device).cuda_stream), "upconv3_bwd_nhwc")
+        dbias = dy.sum(dim=(0, 2, 3)) if (ctx.has_bias and ctx.needs_input_grad[1]) else None
+        return dq, dbias, None
+
+
 class PSPUpsample(nn.Module):
+    """Upsample(2x, bilinear, align_corners) -> Conv2d(3x3, padding 1) -> BatchNorm2d -> PReLU  [ref modules.py:36-49].
+
+    On the GPU (channels-last float32, Cin >= UPCONV_MIN_CIN) the convolution is not run at full size: by linearity
+    conv3x3(U p) = sum_taps shift_tap(U (W_tap p)), so the channel mixing is ONE matrix product on the small map,
+    q = p (B h w, Cin) x Wr (Cin, 9 Cout) -- a quarter of the convolution's flops, and the same for both backward
+    products, which autograd takes from the matmul -- and an interpolate / shift / add kernel produces the full-size
+    map.  up_1 (1024 -> 256 at 48 x 48) is 348 GFLOP per pass as a convolution, 87 this way.  Same parameters and
+    state-dict keys (conv.1.weight / conv.1.bias)."""
+
     def __init__(self, in_channels, out_channels):
         super().__init__()
         self.conv = nn.Sequential(Upsample2x(), nn.Conv2d(in_channels, out_channels, 3, padding=1),
                                   nn.BatchNorm2d(out_channels), PReLU())
 
+    def _split_ok(self, x):
+        conv = self.conv[1]
+        return (USE_UPCONV_SPLIT and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4
+                and x.is_contiguous(memory_format=torch.channels_last) and x.shape[2] > 1 and x.shape[3] > 1
+                and conv.in_channels >= UPCONV_MIN_CIN and conv.out_channels % 4 == 0)
+
     def forward(self, x):
-        return self.conv(x)
+        if not self._split_ok(x):
+            return self.conv(x)
+        conv = self.conv[1]
+        b, cin, h, w = x.shape
+        cout = conv.out_channels
+        wr = conv.weight.permute(1, 2, 3, 0).reshape(cin, 9 * cout)          # Wr[ci][(ky*3+kx)*Cout + co]
+        q = torch.matmul(x.permute(0, 2, 3, 1).reshape(b * h * w, cin), wr).view(b, h, w, 9 * cout)
+        y = _UpConvTailFn.apply(q, conv.bias, cout)
+        return self.conv[3](self.conv[2](y))
 
 
 class Modified_PSPNet(nn.Module):

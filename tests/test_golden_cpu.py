@@ -257,3 +257,20 @@ def test_small_host_helpers():
     y = drop(x)
     assert set(y.unique().tolist()) <= {0.0, 1.0} and 0 < float(y.mean()) <= 1.0     # kept values are not rescaled
     assert torch.equal(drop.eval()(x), x)
+
+
+def test_pyramid_matrices_restate_adaptive_pool_and_bilinear_upsample():
+    """The fixed pooling / upsampling matrices of the GPU form of PSPModule against the framework's own operators."""
+    import torch.nn.functional as F
+    from istnet_amd import rgb_branch
+    sizes, h, w = (1, 2, 3, 6), 24, 20
+    pmat, umat, rows = rgb_branch._psp_matrices(sizes, h, w, "cpu")
+    x = torch.randn(2, 5, h, w, generator=torch.Generator().manual_seed(0))
+    xv = x.permute(0, 2, 3, 1).reshape(2, h * w, 5)
+    for s, (r0, r1) in zip(sizes, rows):
+        want = F.adaptive_avg_pool2d(x, (s, s)).permute(0, 2, 3, 1).reshape(2, s * s, 5)
+        torch.testing.assert_close(torch.matmul(pmat[r0:r1], xv), want, rtol=1e-5, atol=1e-6)
+        z = torch.randn(2, 5, s, s, generator=torch.Generator().manual_seed(s))
+        want = F.interpolate(z, size=(h, w), mode="bilinear", align_corners=False).permute(0, 2, 3, 1).reshape(2, h * w, 5)
+        torch.testing.assert_close(torch.matmul(umat[:, r0:r1], z.permute(0, 2, 3, 1).reshape(2, s * s, 5)), want,
+                                   rtol=1e-5, atol=1e-6)

@@ -57,7 +57,12 @@ def test_aligned_upsample_backward_matches_autograd(b, c, h, w):
     xb = x.clone(memory_format=torch.preserve_format).requires_grad_(True)
     yb = F.interpolate(xb, scale_factor=2, mode="bilinear", align_corners=True)
     yb.backward(dy)
-    assert torch.equal(ya, yb)
+    # forward: the native kernel blends in the framework's order; the two builds may contract products differently
+    torch.testing.assert_close(ya, yb, rtol=1e-6, atol=1e-6)
+    assert ya.is_contiguous(memory_format=torch.channels_last)
+    with torch.no_grad():                                   # inference path: same kernel, no autograd node
+        yi = up(x)
+    assert yi.grad_fn is None and torch.equal(yi, ya.detach())
     torch.testing.assert_close(xa.grad, xb.grad, rtol=1e-5, atol=1e-5)
     # the gradient of sum(y) is the column sum of the interpolation matrix: every output pixel's weights sum to 1
     xs = x.clone(memory_format=torch.preserve_format).requires_grad_(True)
@@ -101,3 +106,86 @@ def test_native_decoder_backward_equals_framework_backward():
     # wiring-level bound: MIOpen may pick other (non-deterministic) algorithms on the second pass and the B=2 train-mode
     # BatchNorms amplify round-off; the op-level tests above hold the kernels themselves to 1e-5
     assert max(rel.values()) < 2e-2, (worst, sorted(rel.items(), key=lambda kv: -kv[1])[:5])
+
+
+@pytest.mark.parametrize("b,c,cout,h", [(2, 32, 48, 24), (3, 16, 8, 12), (1, 8, 8, 7)])
+def test_pyramid_module_linear_form_matches_the_reference_composition(b, c, cout, h):
+    """PSPModule on the GPU (bottleneck slices applied before the upsample, pooling / upsampling as matrix products)
+    against pool -> conv -> upsample -> cat -> bottleneck of the reference (model/modules.py:10-34): output and every
+    gradient."""
+    torch.manual_seed(b + c + h)
+    mod = rgb_branch.PSPModule(c, cout).to(DEV)
+    x = torch.randn(b, c, h, h, device=DEV).contiguous(memory_format=torch.channels_last)
+    dy = torch.randn(b, cout, h, h, device=DEV).contiguous(memory_format=torch.channels_last)
+
+    def run(flag):
+        old = rgb_branch.USE_PSP_LINEAR_FUSION
+        rgb_branch.USE_PSP_LINEAR_FUSION = flag
+        try:
+            mod.zero_grad(set_to_none=True)
+            xi = x.clone(memory_format=torch.preserve_format).requires_grad_(True)
+            y = mod(xi)
+            y.backward(dy)
+            return y.detach(), xi.grad, [p.grad.clone() for p in mod.parameters()]
+        finally:
+            rgb_branch.USE_PSP_LINEAR_FUSION = old
+
+    y1, g1, p1 = run(True)
+    y0, g0, p0 = run(False)
+    assert y1.shape == y0.shape and y1.is_contiguous(memory_format=torch.channels_last)
+    torch.testing.assert_close(y1, y0, rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(g1, g0, rtol=1e-4, atol=1e-5)
+    for a, r in zip(p1, p0):
+        torch.testing.assert_close(a, r, rtol=1e-4, atol=1e-4 * float(r.abs().max()) + 1e-6)
+
+
+@pytest.mark.parametrize("b,cin,cout,h,w", [(2, 128, 32, 12, 12), (1, 256, 8, 5, 9), (3, 128, 64, 2, 2)])
+def test_upsample_conv_split_matches_the_full_size_convolution(b, cin, cout, h, w):
+    """PSPUpsample with the channel mixing on the small map (one GEMM + istnet_upconv3_*) against
+    upsample -> Conv2d(3x3) -> BatchNorm2d -> PReLU at full size: output, input gradient, every parameter gradient."""
+    torch.manual_seed(b + cin + h)
+    mod = rgb_branch.PSPUpsample(cin, cout).to(DEV).to(memory_format=torch.channels_last).train()
+    x = torch.randn(b, cin, h, w, device=DEV).contiguous(memory_format=torch.channels_last)
+    dy = torch.randn(b, cout, 2 * h, 2 * w, device=DEV).contiguous(memory_format=torch.channels_last)
+
+    def run(flag):
+        old = rgb_branch.USE_UPCONV_SPLIT
+        rgb_branch.USE_UPCONV_SPLIT = flag
+        try:
+            mod.zero_grad(set_to_none=True)
+            xi = x.clone(memory_format=torch.preserve_format).requires_grad_(True)
+            y = mod(xi)
+            y.backward(dy)
+            return y.detach(), xi.grad, {n: p.grad.clone() for n, p in mod.named_parameters()}
+        finally:
+            rgb_branch.USE_UPCONV_SPLIT = old
+
+    y1, g1, p1 = run(True)
+    y0, g0, p0 = run(False)
+    assert y1.is_contiguous(memory_format=torch.channels_last)
+    torch.testing.assert_close(y1, y0, rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(g1, g0, rtol=1e-3, atol=1e-4 * float(g0.abs().max()))
+    for n in p0:
+        # the convolution bias sits in front of a train-mode BatchNorm: its true gradient is 0, both values are round-off
+        atol = 2e-3 if n == "conv.1.bias" else 2e-4 * float(p0[n].abs().max()) + 1e-6
+        torch.testing.assert_close(p1[n], p0[n], rtol=1e-3, atol=atol, msg=n)
+    # the tail alone (no BatchNorm in between): against conv2d(interpolate(.)) directly, bias included
+    conv = mod.conv[1]
+    with torch.no_grad():
+        ref = F.conv2d(F.interpolate(x, scale_factor=2, mode="bilinear", align_corners=True), conv.weight, conv.bias, padding=1)
+        wr = conv.weight.permute(1, 2, 3, 0).reshape(cin, 9 * cout)
+        q = torch.matmul(x.permute(0, 2, 3, 1).reshape(b * h * w, cin), wr).view(b, h, w, 9 * cout)
+        got = rgb_branch._UpConvTailFn.apply(q, conv.bias, cout)
+    torch.testing.assert_close(got, ref, rtol=1e-4, atol=1e-4)
+    # gradients of the tail w.r.t. q and the bias against autograd through the same composition
+    wr = conv.weight.detach().permute(1, 2, 3, 0).reshape(cin, 9 * cout)
+    q = torch.matmul(x.permute(0, 2, 3, 1).reshape(b * h * w, cin), wr).view(b, h, w, 9 * cout).requires_grad_(True)
+    bias = conv.bias.detach().clone().requires_grad_(True)
+    rgb_branch._UpConvTailFn.apply(q, bias, cout).backward(dy)
+    xr = x.clone(memory_format=torch.preserve_format).requires_grad_(True)
+    br = conv.bias.detach().clone().requires_grad_(True)
+    F.conv2d(F.interpolate(xr, scale_factor=2, mode="bilinear", align_corners=True), conv.weight.detach(), br,
+             padding=1).backward(dy)
+    torch.testing.assert_close(bias.grad, br.grad, rtol=1e-4, atol=1e-3)
+    dx = torch.matmul(q.grad.view(b * h * w, 9 * cout), wr.t()).view(b, h, w, cin).permute(0, 3, 1, 2)
+    torch.testing.assert_close(dx, xr.grad, rtol=1e-3, atol=1e-4 * float(xr.grad.abs().max()))
