@@ -277,7 +277,7 @@ class PSPModule(nn.Module):
 
 
 USE_UPCONV_SPLIT = True      # PSPUpsample: channel mixing on the small map + interpolate / shift / add kernel
-UPCONV_MIN_CIN = 128         # below this the 3x3 convolution at full size is cheaper than moving q (9 x Cout channels)
+UPCONV_MIN_CIN = 64          # all three decoder stages; below this moving q (9 x Cout channels) costs more than it saves
 
 
 class _UpConvTailFn(torch.autograd.Function):
@@ -311,6 +311,34 @@ class _UpConvTailFn(torch.autograd.Function):
         return dq, dbias, None
 
 
+class _PointMixFn(torch.autograd.Function):
+    """q = x @ wr for x (points, Cin) with very many points and a small (Cin, N) weight.  Forward and the input
+    gradient are plain products (hipBLASLt runs them at 100-145 TFLOP/s); the weight gradient x^T dq reduces over the
+    points, has only Cin x N outputs, and the library gives it too few workgroups (64 / 33 TFLOP/s on the up_1 / up_2
+    shapes): it is issued as a batch of 16 / 32 products over slices of the points and summed in a fixed order
+    (132 / 113 TFLOP/s, tools/exp/gemm_lib.py)."""
+
+    @staticmethod
+    def forward(ctx, x, wr):
+        ctx.save_for_backward(x, wr)
+        return torch.matmul(x, wr)
+
+    @staticmethod
+    def backward(ctx, dq):
+        x, wr = ctx.saved_tensors
+        dq = dq.contiguous()
+        dx = torch.matmul(dq, wr.t()) if ctx.needs_input_grad[0] else None
+        dw = None
+        if ctx.needs_input_grad[1]:
+            m = x.shape[0]
+            s = 32 if m >= 200000 else 16
+            if m % s == 0 and m // s >= 256 and x.is_contiguous():
+                dw = torch.bmm(x.view(s, m // s, x.shape[1]).transpose(1, 2), dq.view(s, m // s, dq.shape[1])).sum(0)
+            else:
+                dw = torch.matmul(x.t(), dq)
+        return dx, dw
+
+
 class PSPUpsample(nn.Module):
     """Upsample(2x, bilinear, align_corners) -> Conv2d(3x3, padding 1) -> BatchNorm2d -> PReLU  [ref modules.py:36-49].
 
@@ -339,7 +367,7 @@ class PSPUpsample(nn.Module):
         b, cin, h, w = x.shape
         cout = conv.out_channels
         wr = conv.weight.permute(1, 2, 3, 0).reshape(cin, 9 * cout)          # Wr[ci][(ky*3+kx)*Cout + co]
-        q = torch.matmul(x.permute(0, 2, 3, 1).reshape(b * h * w, cin), wr).view(b, h, w, 9 * cout)
+        q = _PointMixFn.apply(x.permute(0, 2, 3, 1).reshape(b * h * w, cin), wr).view(b, h, w, 9 * cout)
         y = _UpConvTailFn.apply(q, conv.bias, cout)
         return self.conv[3](self.conv[2](y))
 

@@ -139,7 +139,7 @@ def test_pyramid_module_linear_form_matches_the_reference_composition(b, c, cout
         torch.testing.assert_close(a, r, rtol=1e-4, atol=1e-4 * float(r.abs().max()) + 1e-6)
 
 
-@pytest.mark.parametrize("b,cin,cout,h,w", [(2, 128, 32, 12, 12), (1, 256, 8, 5, 9), (3, 128, 64, 2, 2)])
+@pytest.mark.parametrize("b,cin,cout,h,w", [(2, 128, 32, 12, 12), (1, 256, 8, 5, 9), (3, 128, 64, 2, 2), (2, 64, 64, 16, 16)])
 def test_upsample_conv_split_matches_the_full_size_convolution(b, cin, cout, h, w):
     """PSPUpsample with the channel mixing on the small map (one GEMM + istnet_upconv3_*) against
     upsample -> Conv2d(3x3) -> BatchNorm2d -> PReLU at full size: output, input gradient, every parameter gradient."""
