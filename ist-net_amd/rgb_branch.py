@@ -1,11 +1,13 @@
 """RGB branch of IST-Net: ResNet-18 trunk (output stride 8) + pyramid pooling + 3 x (2x upsample, 3x3 conv).
 
-SURVEY.md 8(f) rank 1 -- outside the point-cloud hot path: dense 2-D convolutions that stay on
-PyTorch-ROCm / MIOpen.  This file only restates the module tree of the reference
+SURVEY.md 8(f) rank 1 -- outside the point-cloud hot path.  The module tree of the reference
 (model/modules.py:10-81,225-241 and model/resnet.py:31-60,109-214) with identical child names, so
 that a reference checkpoint (`rgb_cam_extractor.model.feats.layer1.0.conv1.weight`, ...) loads
 unchanged and the full IST-Net (`ist_net.IST_Net(rgb_extractor=ModifiedResnet())`) can be trained
-and benchmarked end to end.  rgb (B,3,H,W) -> (B,128,H,W).
+and benchmarked end to end.  rgb (B,3,H,W) -> (B,128,H,W).  The trunk's convolutions run on
+PyTorch-ROCm / MIOpen; on the GPU (channels-last float32) the pyramid module and the three decoder
+stages are evaluated in algebraically equivalent forms that do a quarter of the convolution work
+(PSPModule, PSPUpsample) over the kernels of include/istnet_rgb.h.
 
 Reference quirks kept on purpose: the `dilation` arguments of layer3 / layer4 are ignored
 (resnet.py:153-180 only dilates once the *output_stride* is reached, and that is 32), so both run at
