@@ -415,7 +415,7 @@ class Modified_PSPNet(nn.Module):
         else:
             rows = up.reshape(b, c, h * w).transpose(1, 2)           # strided view; gather handles it
         r, q = choose // w, choose % w                               # (B, N)
-        d = torch.tensor([-1, 0, 1], device=choose.device)
+        d = torch.arange(-1, 2, device=choose.device)               # (a kernel, not a host copy: capturable)
         rr = (r.unsqueeze(-1) + d.repeat_interleave(3)).clamp_(0, h - 1)     # (B, N, 9): window rows, kernel-row major
         qq = (q.unsqueeze(-1) + d.repeat(3)).clamp_(0, w - 1)
         inside = ((r.unsqueeze(-1) + d.repeat_interleave(3) == rr) & (q.unsqueeze(-1) + d.repeat(3) == qq))

@@ -255,3 +255,33 @@ print("OK", issued)
         env.pop(k, None)
     proc = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=600)
     assert proc.returncode == 0 and "OK" in proc.stdout, (proc.stdout[-500:], proc.stderr[-2000:])
+
+
+def test_inference_step_is_graph_capturable():
+    """Eval-mode IST-Net forward + pose assembly (BASELINE config 5 at a small size) captured into one HIP graph: no host
+    copies or synchronisations inside (the gather-first RGB tail included); replays equal the eager result."""
+    import bench
+    from istnet_amd import postprocess
+    net = bench.make_istnet(DEV, seed=0).eval()
+    batch = bench.istnet_batch(4, 256, seed=3, device=DEV, hw=64)
+
+    def fwd():
+        with torch.no_grad():
+            ep = net(batch)
+            return postprocess.assemble_pred_RTs(ep["pred_rotation"], ep["pred_translation"], ep["pred_size"])
+
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(2):
+            ref = fwd()
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        out = fwd()
+    for _ in range(2):
+        graph.replay()
+    torch.cuda.synchronize()
+    torch.testing.assert_close(out[0], ref[0], rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(out[1], ref[1], rtol=1e-5, atol=1e-6)
