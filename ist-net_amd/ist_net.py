@@ -174,8 +174,9 @@ class IST_Net(nn.Module):
     def _rgb_local(self, inputs, b):
         if "rgb_local" in inputs:
             return inputs["rgb_local"]
-        if not self.training and USE_GATHER_FIRST and getattr(self.rgb_cam_extractor, "gathers_choose", False):
-            return self.rgb_cam_extractor(inputs["rgb"], inputs["choose"])   # eval: last layer on the chosen pixels only
+        if USE_GATHER_FIRST and getattr(self.rgb_cam_extractor, "gathers_choose", False):
+            # last layer(s) on the chosen pixels only (eval: rgb_branch._tail_at; training: _FinalAtChosenFn)
+            return self.rgb_cam_extractor(inputs["rgb"], inputs["choose"])
         feat = self.rgb_cam_extractor(inputs["rgb"])
         d = feat.size(1)
         if not feat.is_contiguous() and feat.is_contiguous(memory_format=torch.channels_last):

@@ -374,6 +374,92 @@ class PSPUpsample(nn.Module):
         return self.conv[3](self.conv[2](y))
 
 
+USE_TRAIN_GATHER_FIRST = True    # training: `final` at the chosen pixels only, batch statistics from the moments of its input
+
+
+def _moments(rows):
+    """sum_p u_p (C) and sum_p u_p u_p^T (C, C) of rows (P, C): the reduction over P as a batch of slice products (the
+    library under-fills the chip on a (C, P) x (P, C) product, see _PointMixFn), summed in a fixed order."""
+    p, c = rows.shape
+    s = 32 if p >= 200000 else 16
+    if p % s == 0 and p // s >= 256:
+        v = rows.view(s, p // s, c)
+        return v.sum(1).sum(0), torch.bmm(v.transpose(1, 2), v).sum(0)
+    return rows.sum(0), torch.matmul(rows.t(), rows)
+
+
+class _FinalAtChosenFn(torch.autograd.Function):
+    """`final` = Conv2d(1x1) -> BatchNorm2d (train mode) -> PReLU of the decoder, evaluated at the chosen pixels only.
+
+    IST-Net reads N of the H*W pixels of the (B, 128, H, W) feature map (ist_net.py:41-45).  In training mode the
+    BatchNorm statistics are taken over ALL pixels, but z = W u + b is linear in the layer's input u, so they follow
+    exactly from the first and second moments of u (one pass over u, a (C, P) x (P, C) product):
+        mean_z = W mean_u + b,   var_z[c] = w_c^T Cov(u) w_c.
+    The map itself (604 MB at B = 32) and the conv / BatchNorm / PReLU passes over it, forward and backward, are never
+    run.  Backward: the loss reaches u through the chosen pixels and through the two statistics; the second path is
+    affine in u for every pixel, dL/du_p = A u_p + c0 with A = W^T diag(k) W (one dense (P, C) x (C, C) product), and
+    the parameter gradients need only the moments.  Same values as the dense composition up to summation order;
+    running statistics updated as BatchNorm2d does (momentum, unbiased variance)."""
+
+    @staticmethod
+    def forward(ctx, u, choose, weight, bias, gamma, beta, slope, running_mean, running_var, momentum, eps):
+        b, c, h, w = u.shape
+        npix = b * h * w
+        rows = u.permute(0, 2, 3, 1).reshape(npix, c)                      # view of the channels-last map
+        s1, s2 = _moments(rows)
+        w2 = weight.reshape(weight.shape[0], c)
+        wd, bd = w2.double(), bias.double()
+        m_u = s1.double() / npix
+        cov = s2.double() / npix - torch.outer(m_u, m_u)
+        mu = wd @ m_u + bd
+        var = ((wd @ cov) * wd).sum(1).clamp_(min=0.0)
+        istd = (var + eps).rsqrt()
+        n = choose.shape[1]
+        u_sel = torch.gather(rows.view(b, h * w, c), 1, choose.unsqueeze(-1).expand(-1, -1, c))     # (B, N, C)
+        z = torch.addmm(bias, u_sel.reshape(b * n, c), w2.t())                                      # (B N, Cout)
+        zhat = (z - mu.to(z.dtype)) * istd.to(z.dtype)
+        v = zhat * gamma + beta
+        y = torch.where(v > 0, v, v * slope)
+        if running_mean is not None:
+            with torch.no_grad():
+                running_mean.mul_(1.0 - momentum).add_(mu.to(running_mean.dtype), alpha=momentum)
+                running_var.mul_(1.0 - momentum).add_((var * (npix / max(npix - 1, 1))).to(running_var.dtype), alpha=momentum)
+        ctx.save_for_backward(u, choose, weight, bias, gamma, slope, u_sel, zhat, v, s1, s2, mu, istd)
+        return y.view(b, n, -1).transpose(1, 2).contiguous()                                        # (B, Cout, N)
+
+    @staticmethod
+    def backward(ctx, dy):
+        u, choose, weight, bias, gamma, slope, u_sel, zhat, v, s1, s2, mu, istd = ctx.saved_tensors
+        b, c, h, w = u.shape
+        npix, n, cout = b * h * w, choose.shape[1], weight.shape[0]
+        w2 = weight.reshape(cout, c)
+        g = dy.transpose(1, 2).reshape(b * n, cout)
+        neg = v <= 0
+        dslope = (g * v * neg).sum().reshape(slope.shape)
+        gv = torch.where(neg, g * slope, g)
+        dbeta, dgamma = gv.sum(0), (gv * zhat).sum(0)
+        gz = gv * gamma                                                    # dL/dzhat at the chosen pixels
+        istd_f = istd.to(gz.dtype)
+        # z - mu at the chosen pixels = zhat / istd; the statistics couple every pixel: dL/dz_p += a + k (z_p - mu)
+        a = (-(istd * gz.sum(0).double()) / npix)                          # dL/dmu / P                     (float64, Cout)
+        k = (-(istd ** 2) * (gz * zhat).sum(0).double() / npix)            # 2 dL/dvar / P = -istd^2 sum(gz zhat) / P
+        dz = gz * istd_f                                                   # direct path, (B N, Cout)
+        wd = w2.double()
+        off = a + k * (bias.double() - mu)                                 # constant part of the dense term
+        amat = (wd.t() * k) @ wd                                           # W^T diag(k) W  (C, C)
+        c0 = wd.t() @ off
+        rows = u.permute(0, 2, 3, 1).reshape(npix, c)
+        du = torch.addmm(c0.to(rows.dtype), rows, amat.to(rows.dtype).t())               # dense: A u_p + c0, (P, C)
+        du = du.view(b, h * w, c)
+        du.scatter_add_(1, choose.unsqueeze(-1).expand(-1, -1, c), torch.matmul(dz, w2).view(b, n, c))
+        du = du.view(b, h, w, c).permute(0, 3, 1, 2)                       # (B, C, H, W), channels-last
+        s1d, s2d = s1.double(), s2.double()
+        dw = (dz.t() @ u_sel.reshape(b * n, c)).double() + torch.outer(a, s1d) \
+            + k.unsqueeze(1) * (wd @ s2d + torch.outer(bias.double() - mu, s1d))
+        db = dz.sum(0).double() + npix * a + k * (wd @ s1d + npix * (bias.double() - mu))
+        return (du, None, dw.to(weight.dtype).view_as(weight), db.to(bias.dtype), dgamma, dbeta, dslope, None, None, None, None)
+
+
 class Modified_PSPNet(nn.Module):
     """[ref modules.py:51-81]"""
 
@@ -389,15 +475,38 @@ class Modified_PSPNet(nn.Module):
         self.final = nn.Sequential(nn.Conv2d(64, 128, kernel_size=1), nn.BatchNorm2d(128), PReLU())
 
     def forward(self, x, choose=None):
-        """rgb (B,3,H,W) -> (B,128,H,W); with ``choose`` (B,N) flat pixel indices in eval mode -> (B,128,N), the
-        features of the chosen pixels only (see ``_tail_at``)."""
+        """rgb (B,3,H,W) -> (B,128,H,W); with ``choose`` (B,N) flat pixel indices -> (B,128,N), the features of the chosen
+        pixels only: eval mode through ``_tail_at``, training mode through ``_FinalAtChosenFn`` (exact batch statistics
+        from the moments of the last stage's input)."""
         f, _ = self.feats(x)
         p = self.drop_1(self.psp(f))
         p = self.drop_2(self.up_1(p))
         p = self.drop_2(self.up_2(p))
         if choose is not None and not self.training:
             return self._tail_at(p, choose)
-        return self.final(self.up_3(p))
+        u = self.up_3(p)
+        if choose is not None and self._train_gather_ok(u):
+            conv, bn, act = self.final[0], self.final[1], self.final[2]
+            if bn.track_running_stats and bn.num_batches_tracked is not None:
+                bn.num_batches_tracked.add_(1)
+            return _FinalAtChosenFn.apply(u, choose, conv.weight, conv.bias, bn.weight, bn.bias, act.weight,
+                                          bn.running_mean if bn.track_running_stats else None,
+                                          bn.running_var if bn.track_running_stats else None,
+                                          bn.momentum, bn.eps)
+        out = self.final(u)
+        if choose is None:
+            return out
+        b, d = out.size(0), out.size(1)                                     # dense map, then the gather (reference order)
+        if not out.is_contiguous() and out.is_contiguous(memory_format=torch.channels_last):
+            rows = out.permute(0, 2, 3, 1).reshape(b, -1, d)
+            return torch.gather(rows, 1, choose.unsqueeze(-1).expand(-1, -1, d)).transpose(1, 2).contiguous()
+        return torch.gather(out.reshape(b, d, -1), 2, choose.unsqueeze(1).expand(-1, d, -1)).contiguous()
+
+    def _train_gather_ok(self, u):
+        conv, bn, act = self.final[0], self.final[1], self.final[2]
+        return (USE_TRAIN_GATHER_FIRST and self.training and u.is_cuda and u.dtype == torch.float32
+                and u.is_contiguous(memory_format=torch.channels_last) and conv.bias is not None and bn.affine
+                and bn.momentum is not None and act.weight.numel() == 1)
 
     def _tail_at(self, p, choose):
         """Eval mode: the last decoder stage (`up_3`: 2x bilinear upsample, 3x3 conv, BatchNorm, PReLU) and `final`

@@ -189,3 +189,77 @@ def test_upsample_conv_split_matches_the_full_size_convolution(b, cin, cout, h, 
     torch.testing.assert_close(bias.grad, br.grad, rtol=1e-4, atol=1e-3)
     dx = torch.matmul(q.grad.view(b * h * w, 9 * cout), wr.t()).view(b, h, w, cin).permute(0, 3, 1, 2)
     torch.testing.assert_close(dx, xr.grad, rtol=1e-3, atol=1e-4 * float(xr.grad.abs().max()))
+
+
+@pytest.mark.parametrize("b,c,cout,h,w,n", [(2, 64, 128, 48, 48, 256), (3, 16, 8, 10, 14, 40), (32, 64, 128, 32, 32, 64)])
+def test_training_mode_final_stage_at_the_chosen_pixels(b, c, cout, h, w, n):
+    """_FinalAtChosenFn (conv1x1 -> train-mode BatchNorm -> PReLU at the chosen pixels, batch statistics from the
+    moments of the input) against the dense map followed by the gather (reference order, ist_net.py:41-45): output,
+    running statistics, gradients of the input and of every parameter."""
+    torch.manual_seed(b + c + n)
+    final = torch.nn.Sequential(torch.nn.Conv2d(c, cout, 1), torch.nn.BatchNorm2d(cout), rgb_branch.PReLU()).to(DEV)
+    final = final.to(memory_format=torch.channels_last).train()
+    with torch.no_grad():
+        final[1].weight.uniform_(0.5, 1.5)
+        final[1].bias.normal_()
+    x = (torch.randn(b, c, h, w, device=DEV) * 0.7 + 0.3).contiguous(memory_format=torch.channels_last)
+    choose = torch.randint(0, h * w, (b, n), device=DEV)
+    choose[0, :3] = 5                                                       # repeated pixels accumulate
+    dy = torch.randn(b, cout, n, device=DEV)
+
+    def reset():
+        final.zero_grad(set_to_none=True)
+        final[1].running_mean.zero_(); final[1].running_var.fill_(1.0)
+
+    reset()
+    xr = x.clone(memory_format=torch.preserve_format).requires_grad_(True)
+    out = final(xr)
+    ref = torch.gather(out.permute(0, 2, 3, 1).reshape(b, h * w, cout), 1, choose.unsqueeze(-1).expand(-1, -1, cout)).transpose(1, 2)
+    ref.backward(dy)
+    want = [xr.grad.clone()] + [p.grad.clone() for p in final.parameters()]
+    rm, rv = final[1].running_mean.clone(), final[1].running_var.clone()
+    reset()
+    xa = x.clone(memory_format=torch.preserve_format).requires_grad_(True)
+    got = rgb_branch._FinalAtChosenFn.apply(xa, choose, final[0].weight, final[0].bias, final[1].weight, final[1].bias,
+                                            final[2].weight, final[1].running_mean, final[1].running_var, 0.1, 1e-5)
+    torch.testing.assert_close(got, ref, rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(final[1].running_mean, rm, rtol=1e-4, atol=1e-6)
+    torch.testing.assert_close(final[1].running_var, rv, rtol=1e-4, atol=1e-6)
+    got.backward(dy)
+    have = [xa.grad] + [p.grad for p in final.parameters()]
+    for name, a, r in zip(["input", "conv.weight", "conv.bias", "bn.weight", "bn.bias", "prelu.weight"], have, want):
+        # the convolution bias in front of a train-mode BatchNorm has a zero gradient: both values are round-off
+        atol = 1e-3 if name == "conv.bias" else 2e-4 * float(r.abs().max()) + 1e-6
+        torch.testing.assert_close(a, r, rtol=1e-3, atol=atol, msg=name)
+
+
+def test_extractor_training_forward_with_choose_equals_dense_then_gather():
+    """ModifiedResnet in training mode, channels-last: forward(x, choose) (last stage at the chosen pixels) against
+    forward(x) followed by the gather, same dropout masks (same seed), output and a spread of parameter gradients."""
+    torch.manual_seed(0)
+    net = rgb_branch.ModifiedResnet().to(DEV).to(memory_format=torch.channels_last).train()
+    x = torch.randn(2, 3, 64, 64, device=DEV).contiguous(memory_format=torch.channels_last)
+    choose = torch.randint(0, 64 * 64, (2, 200), device=DEV)
+    dy = torch.randn(2, 128, 200, device=DEV)
+
+    def run(flag):
+        old = rgb_branch.USE_TRAIN_GATHER_FIRST
+        rgb_branch.USE_TRAIN_GATHER_FIRST = flag
+        try:
+            net.zero_grad(set_to_none=True)
+            torch.manual_seed(7)                                            # the Dropout2d masks
+            y = net(x, choose)
+            y.backward(dy)
+            grads = {n: p.grad.clone() for n, p in net.named_parameters() if p.grad is not None}
+            return y.detach(), grads
+        finally:
+            rgb_branch.USE_TRAIN_GATHER_FIRST = old
+
+    y1, g1 = run(True)
+    y0, g0 = run(False)
+    torch.testing.assert_close(y1, y0, rtol=1e-3, atol=1e-4)
+    for name in ("model.final.0.weight", "model.final.1.weight", "model.final.2.weight", "model.up_3.conv.1.weight",
+                 "model.up_1.conv.1.weight", "model.psp.bottleneck.weight", "model.feats.layer4.1.conv2.weight",
+                 "model.feats.conv1.weight"):
+        err = float((g1[name] - g0[name]).norm() / (g0[name].norm() + 1e-12))
+        assert err < 2e-2, (name, err)          # MIOpen's own run-to-run differences on the trunk are of this order
