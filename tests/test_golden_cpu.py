@@ -201,7 +201,14 @@ def test_rgb_gather_first_equals_dense_tail_in_eval():
     torch.testing.assert_close(got, want, rtol=1e-5, atol=1e-5)
     torch.testing.assert_close(got_cl, want, rtol=1e-5, atol=1e-5)
     net.train()
-    assert ext_cl(rgb, choose).shape == (2, 128, 48, 48)       # training mode ignores `choose`
+    # training mode: the chosen pixels of the dense map (same dropout masks), in the reference's gather order
+    torch.manual_seed(3)
+    picked = ext_cl(rgb, choose)
+    torch.manual_seed(3)
+    dense_train = ext_cl(rgb)
+    assert picked.shape == (2, 128, 37)
+    torch.testing.assert_close(picked, torch.gather(dense_train.reshape(2, 128, -1), 2, choose.unsqueeze(1).expand(-1, 128, -1)),
+                               rtol=1e-5, atol=1e-5)
 
 
 def _freeze_case():
