@@ -126,6 +126,13 @@ ISTNET_PN2_API int istnet_pn2_three_interpolate_grad_csr(int b, int c, int n, in
                                                          const float *weight, const int *offsets,
                                                          const int *entries, float *grad_points, void *stream);
 
+/* three_nn plus the inverse-distance weights PointnetFPModule forms from it (pointnet2_modules.py:185-188 over
+ * ThreeNN's sqrt, pointnet2_utils.py:140-149) in the same launch: idx (b, n, 3) i32 as istnet_pn2_three_nn,
+ * weight (b, n, 3) = r_k / (r_0 + r_1 + r_2), r_k = 1 / (sqrt(dist2_k) + 1e-8).  Replaces five framework
+ * elementwise / reduce launches per propagation level. */
+ISTNET_PN2_API int istnet_pn2_three_nn_weights(int b, int n, int m, const float *unknown, const float *known,
+                                               int *idx, float *weight, void *stream);
+
 /* Deterministic, atomic-free form of group_points_grad over the inverse lists of idx (istnet_pn2_csr_build with
  * e = npoints*nsample, m = n): grad_points[b][c][i] = sum over the slots that picked point i.  The reference uses one
  * fp32 atomicAdd per slot (group_points_gpu.cu:62-66).  Needs one gradient row (npoints*nsample floats) to fit 64 KB

@@ -878,7 +878,8 @@ __global__ __launch_bounds__(256) void three_nn_kernel(int n, int m,
                                                        const float* __restrict__ unknown_all,
                                                        const float* __restrict__ known_all,
                                                        float* __restrict__ dist2_all,
-                                                       int* __restrict__ idx_all) {
+                                                       int* __restrict__ idx_all,
+                                                       float* __restrict__ weight_all) {
   __shared__ __attribute__((aligned(16))) float kn[kNnTile * 3];
   const int cloud = blockIdx.y;
   const float* unknown = unknown_all + (size_t)cloud * n * 3;
@@ -914,10 +915,20 @@ __global__ __launch_bounds__(256) void three_nn_kernel(int n, int m,
     }
   }
   if (active) {
-    float* d2 = dist2_all + ((size_t)cloud * n + j) * 3;
     int* ix = idx_all + ((size_t)cloud * n + j) * 3;
-    d2[0] = best1; d2[1] = best2; d2[2] = best3;
     ix[0] = besti1; ix[1] = besti2; ix[2] = besti3;
+    if (dist2_all != nullptr) {
+      float* d2 = dist2_all + ((size_t)cloud * n + j) * 3;
+      d2[0] = best1; d2[1] = best2; d2[2] = best3;
+    }
+    if (weight_all != nullptr) {
+      // inverse-distance weights of PointnetFPModule (pointnet2_modules.py:185-188 with ThreeNN's sqrt,
+      // pointnet2_utils.py:140-149): r = 1 / (sqrt(d2) + 1e-8), w = r / (r0 + r1 + r2); IEEE sqrt and division
+      const float r1 = 1.0f / (sqrtf(best1) + 1e-8f), r2 = 1.0f / (sqrtf(best2) + 1e-8f), r3 = 1.0f / (sqrtf(best3) + 1e-8f);
+      const float norm = (r1 + r2) + r3;
+      float* w = weight_all + ((size_t)cloud * n + j) * 3;
+      w[0] = r1 / norm; w[1] = r2 / norm; w[2] = r3 / norm;
+    }
   }
 }
 
@@ -1157,7 +1168,16 @@ int istnet_pn2_three_nn(int b, int n, int m, const float* unknown, const float* 
   if (b < 0 || n < 0 || m < 0) return ISTNET_PN2_EINVAL;
   if (b == 0 || n == 0) return 0;
   ISTNET_CONV_DISPATCH(hipLaunchKernelGGL(three_nn_kernel<CONV_>, dim3(ceil_div(n, 256), b), dim3(256), 0,
-                                          as_stream(stream), n, m, unknown, known, dist2, idx));
+                                          as_stream(stream), n, m, unknown, known, dist2, idx, (float*)nullptr));
+  return (int)hipGetLastError();
+}
+
+int istnet_pn2_three_nn_weights(int b, int n, int m, const float* unknown, const float* known, int* idx, float* weight,
+                                void* stream) {
+  if (b < 0 || n < 0 || m < 0 || !idx || !weight) return ISTNET_PN2_EINVAL;
+  if (b == 0 || n == 0) return 0;
+  ISTNET_CONV_DISPATCH(hipLaunchKernelGGL(three_nn_kernel<CONV_>, dim3(ceil_div(n, 256), b), dim3(256), 0,
+                                          as_stream(stream), n, m, unknown, known, (float*)nullptr, idx, weight));
   return (int)hipGetLastError();
 }
 

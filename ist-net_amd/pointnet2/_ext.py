@@ -122,6 +122,22 @@ def three_nn(unknowns, knows):
     return [dist2, idx]
 
 
+def three_nn_weights(unknowns, knows):
+    """(B,n,3), (B,m,3) f32 -> (idx (B,n,3) i32, weight (B,n,3) f32): three_nn and the inverse-distance weights of
+    PointnetFPModule (pointnet2_modules.py:185-188) in one launch (extension of the reference's nine functions)."""
+    _contig(unknowns, "unknowns"); _contig(knows, "knows")
+    _is_float(unknowns, "unknowns"); _is_float(knows, "knows")
+    dev = _device_of(unknowns, "unknowns", (knows, "knows"))
+    b, n = unknowns.shape[0], unknowns.shape[1]
+    m = knows.shape[1]
+    idx = torch.empty((b, n, 3), dtype=torch.int32, device=dev)
+    weight = torch.empty((b, n, 3), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        _native.check(_native.lib().istnet_pn2_three_nn_weights(
+            b, n, m, _ptr(unknowns), _ptr(knows), _ptr(idx), _ptr(weight), _stream(dev)), "three_nn_weights")
+    return idx, weight
+
+
 def three_interpolate(points, idx, weight):
     """(B,C,m) f32, (B,n,3) i32, (B,n,3) f32 -> (B,C,n).  interpolate.cpp:47-74"""
     _contig(points, "points"); _contig(idx, "idx"); _contig(weight, "weight")

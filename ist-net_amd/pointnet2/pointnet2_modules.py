@@ -89,6 +89,8 @@ class PointnetSAModule(PointnetSAModuleMSG):
                          use_xyz=use_xyz)
 
 
+USE_FUSED_NN_WEIGHTS = True   # three_nn + inverse-distance weights in one kernel (False: the reference's five tensor ops)
+
 class PointnetFPModule(nn.Module):
     """Feature propagation from a coarse set (known) to a dense one (unknown).  [ref :148-209]"""
 
@@ -100,9 +102,14 @@ class PointnetFPModule(nn.Module):
     def interpolation_weights(unknown, known, with_csr=False):
         """three_nn + inverse-distance weights (idx (B,n,3) i32, weight (B,n,3)).  [ref :185-188]
         with_csr: also return the inverse lists of idx used by the backward of three_interpolate."""
-        dist, idx = pointnet2_utils.three_nn(unknown, known)
-        inv = 1.0 / (dist + 1e-8)
-        weight = inv / torch.sum(inv, dim=2, keepdim=True)
+        fused = getattr(pointnet2_utils._ext, "three_nn_weights", None)     # absent from a plain reference _ext
+        if (USE_FUSED_NN_WEIGHTS and fused is not None and unknown.is_cuda and unknown.dtype == torch.float32
+                and not unknown.requires_grad and not known.requires_grad and known.size(1) >= 3):
+            idx, weight = fused(unknown.contiguous(), known.contiguous())   # one launch instead of six
+        else:
+            dist, idx = pointnet2_utils.three_nn(unknown, known)
+            inv = 1.0 / (dist + 1e-8)
+            weight = inv / torch.sum(inv, dim=2, keepdim=True)
         if with_csr:
             interp_csr = getattr(pointnet2_utils._ext, "interp_csr", None)   # absent from a plain reference _ext
             return idx, weight, (interp_csr(idx, known.size(1)) if interp_csr is not None and idx.is_cuda else None)

@@ -65,7 +65,8 @@ def test_encoder_b2(monkeypatch):
             captured[f"{name}_{i}"] = res
             return res
         monkeypatch.setattr(_ext, name, fn)
-    for n in ("furthest_point_sampling_gather", "ball_query", "three_nn"):   # the encoder samples + gathers in one op
+    # the encoder samples + gathers in one op, and takes three_nn together with the interpolation weights
+    for n in ("furthest_point_sampling_gather", "ball_query", "three_nn_weights"):
         tap(n)
     torch.manual_seed(0)
     enc = PointNet2MSG([list(r) for r in CAM]).to(DEV).train()
@@ -74,9 +75,16 @@ def test_encoder_b2(monkeypatch):
     for i in range(4):
         assert np.array_equal(captured[f"furthest_point_sampling_gather_{i}"][0].cpu().numpy(),
                               z[f"furthest_point_sampling_{i}"].astype(np.int32)), i
-        d2, idx = captured[f"three_nn_{i}"]
+        idx, wgt = captured[f"three_nn_weights_{i}"]
         assert np.array_equal(idx.cpu().numpy(), z[f"three_nn_idx_{i}"].astype(np.int32)), i
+        # the weights follow from the golden distances; the squared distances themselves bit for bit from the
+        # stand-alone op on the same level coordinates (call i of the encoder is propagation level 3 - i)
+        levels = [pts[:, :, :3].contiguous()] + [captured[f"furthest_point_sampling_gather_{k}"][1] for k in range(4)]
+        d2, idx_again = _ext.three_nn(levels[3 - i].contiguous(), levels[4 - i].contiguous())
         assert np.array_equal(d2.cpu().numpy(), z[f"three_nn_dist2_{i}"]), i
+        assert torch.equal(idx_again, idx)
+        inv = 1.0 / (np.sqrt(z[f"three_nn_dist2_{i}"].astype(np.float32)) + np.float32(1e-8))
+        np.testing.assert_allclose(wgt.cpu().numpy(), inv / inv.sum(axis=2, keepdims=True), rtol=3e-6, atol=1e-7)
     for i in range(8):
         assert np.array_equal(captured[f"ball_query_{i}"].cpu().numpy(), z[f"ball_query_{i}"].astype(np.int32)), i
     # The reference's own fp32 output is up to 8.7e-5 away from a float64 evaluation of the same model with the

@@ -277,3 +277,21 @@ def test_index_ops_bit_exact_under_fma_conventions(ext, oracle, conv):
     finally:
         oracle.set_convention(prev)
         assert lib.istnet_pn2_set_tuning(1, 0) == 0
+
+
+@pytest.mark.parametrize("b,n,m", [(4, 1024, 512), (2, 128, 64), (1, 77, 5), (1, 10, 3), (2, 33, 2)])
+def test_three_nn_with_weights_in_one_launch(ext, b, n, m):
+    """istnet_pn2_three_nn_weights: the indices of three_nn bit for bit, and the inverse-distance weights of
+    PointnetFPModule (reference pointnet2_modules.py:185-188) as the five tensor ops compute them."""
+    g = torch.Generator().manual_seed(n + m)
+    unk = torch.rand(b, n, 3, generator=g).to(DEV)
+    kn = torch.rand(b, m, 3, generator=g).to(DEV)
+    kn[:, 0] = unk[:, 0]                                   # a zero distance: weight 1e8 / (1e8 + ...) after the epsilon
+    d2, idx = ext.three_nn(unk, kn)
+    idx2, w = ext.three_nn_weights(unk, kn)
+    assert torch.equal(idx2, idx)
+    inv = 1.0 / (torch.sqrt(d2) + 1e-8)
+    want = inv / inv.sum(dim=2, keepdim=True)
+    torch.testing.assert_close(w, want, rtol=2e-6, atol=1e-7, equal_nan=True)
+    if m >= 3:
+        torch.testing.assert_close(w.sum(dim=2), torch.ones(b, n, device=DEV), rtol=1e-6, atol=1e-6)
