@@ -213,9 +213,12 @@ def test_training_mode_final_stage_at_the_chosen_pixels(b, c, cout, h, w, n):
 
     reset()
     xr = x.clone(memory_format=torch.preserve_format).requires_grad_(True)
-    out = final(xr)
-    ref = torch.gather(out.permute(0, 2, 3, 1).reshape(b, h * w, cout), 1, choose.unsqueeze(-1).expand(-1, -1, cout)).transpose(1, 2)
-    ref.backward(dy)
+    # the dense reference on the framework's native kernels: MIOpen's solver search aborts the process on some of these
+    # toy shapes (16 -> 8 channels on a 10 x 14 map) depending on what it has searched before in the same process
+    with torch.backends.cudnn.flags(enabled=False):
+        out = final(xr)
+        ref = torch.gather(out.permute(0, 2, 3, 1).reshape(b, h * w, cout), 1, choose.unsqueeze(-1).expand(-1, -1, cout)).transpose(1, 2)
+        ref.backward(dy)
     want = [xr.grad.clone()] + [p.grad.clone() for p in final.parameters()]
     rm, rv = final[1].running_mean.clone(), final[1].running_var.clone()
     reset()
