@@ -259,6 +259,7 @@ class PSPModule(nn.Module):
         n, cout = len(self.stages), self.bottleneck.out_channels
         x = feats.permute(0, 2, 3, 1).reshape(b, h * w, c)                 # a view of the channels-last map
         pmat, umat, rows = _psp_matrices(self.sizes, h, w, feats.device)
+        pmat, umat = pmat.to(x.dtype), umat.to(x.dtype)                   # no-ops for float32
         wb = self.bottleneck.weight.view(cout, (n + 1) * c)
         pooled = torch.matmul(pmat, x)                                     # (B, R, C): all bin sizes at once
         small = [torch.matmul(torch.matmul(pooled[:, r0:r1], st[1].weight.view(c, c).t()), wb[:, k * c:(k + 1) * c].t())

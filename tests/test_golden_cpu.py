@@ -281,3 +281,58 @@ def test_pyramid_matrices_restate_adaptive_pool_and_bilinear_upsample():
         want = F.interpolate(z, size=(h, w), mode="bilinear", align_corners=False).permute(0, 2, 3, 1).reshape(2, h * w, 5)
         torch.testing.assert_close(torch.matmul(umat[:, r0:r1], z.permute(0, 2, 3, 1).reshape(2, s * s, 5)), want,
                                    rtol=1e-5, atol=1e-6)
+
+
+def test_final_stage_at_chosen_pixels_is_exact_in_float64():
+    """rgb_branch._FinalAtChosenFn (training-mode `final` at the chosen pixels, BatchNorm batch statistics from the input
+    moments, affine backward through the statistics) against the dense composition + gather, in float64 on the host:
+    equal to round-off, running statistics included."""
+    from istnet_amd import rgb_branch
+    torch.manual_seed(0)
+    b, c, h, w, n, co = 2, 8, 12, 10, 30, 16
+    final = torch.nn.Sequential(torch.nn.Conv2d(c, co, 1), torch.nn.BatchNorm2d(co), torch.nn.PReLU()).double()
+    final[1].weight.data.uniform_(0.5, 1.5)
+    final[1].bias.data.normal_()
+    u = torch.randn(b, c, h, w, dtype=torch.float64).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    choose = torch.randint(0, h * w, (b, n))
+    choose[0, :3] = 5
+    out = final(u)
+    ref = torch.gather(out.reshape(b, co, -1), 2, choose.unsqueeze(1).expand(-1, co, -1))
+    dy = torch.randn_like(ref)
+    ref.backward(dy)
+    want = [u.grad.clone()] + [p.grad.clone() for p in final.parameters()]
+    rm, rv = final[1].running_mean.clone(), final[1].running_var.clone()
+    u.grad = None
+    for p in final.parameters():
+        p.grad = None
+    final[1].running_mean.zero_()
+    final[1].running_var.fill_(1)
+    y = rgb_branch._FinalAtChosenFn.apply(u, choose, final[0].weight, final[0].bias, final[1].weight, final[1].bias,
+                                          final[2].weight, final[1].running_mean, final[1].running_var, 0.1, 1e-5)
+    torch.testing.assert_close(y, ref, rtol=1e-12, atol=1e-12)
+    y.backward(dy)
+    for a, r in zip([u.grad] + [p.grad for p in final.parameters()], want):
+        torch.testing.assert_close(a, r, rtol=1e-10, atol=1e-12)
+    torch.testing.assert_close(final[1].running_mean, rm, rtol=1e-12, atol=1e-14)
+    torch.testing.assert_close(final[1].running_var, rv, rtol=1e-12, atol=1e-14)
+
+
+def test_pyramid_module_linear_form_is_exact_in_float64():
+    """rgb_branch.PSPModule._forward_linear (bottleneck slices before the upsample, pooling / upsampling as matrix
+    products) against the reference composition (modules.py:10-34) in float64 on the host: output and gradients."""
+    from istnet_amd import rgb_branch
+    torch.manual_seed(1)
+    mod = rgb_branch.PSPModule(12, 20).double()
+    x = torch.randn(2, 12, 24, 18, dtype=torch.float64).contiguous(memory_format=torch.channels_last)
+    dy = torch.randn(2, 20, 24, 18, dtype=torch.float64)
+    xr = x.clone(memory_format=torch.preserve_format).requires_grad_(True)
+    ref = mod(xr)                                                           # CPU: the reference composition
+    ref.backward(dy)
+    want = [xr.grad.clone()] + [p.grad.clone() for p in mod.parameters()]
+    mod.zero_grad(set_to_none=True)
+    xa = x.clone(memory_format=torch.preserve_format).requires_grad_(True)
+    got = mod._forward_linear(xa)
+    torch.testing.assert_close(got, ref, rtol=1e-6, atol=1e-6)             # the fixed matrices are float32
+    got.backward(dy)
+    for a, r in zip([xa.grad] + [p.grad for p in mod.parameters()], want):
+        torch.testing.assert_close(a, r, rtol=1e-5, atol=1e-5 * float(r.abs().max()))
