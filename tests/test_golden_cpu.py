@@ -336,3 +336,25 @@ def test_pyramid_module_linear_form_is_exact_in_float64():
     got.backward(dy)
     for a, r in zip([xa.grad] + [p.grad for p in mod.parameters()], want):
         torch.testing.assert_close(a, r, rtol=1e-5, atol=1e-5 * float(r.abs().max()))
+
+
+def test_upsample_then_conv3x3_equals_small_map_mixing_plus_shifted_interpolation():
+    """The identity behind rgb_branch.PSPUpsample's GPU form, in float64 on the host:
+    conv3x3(U p) = sum_taps shift_tap(U (W_tap p)) with zero padding at the full-size border (what
+    istnet_upconv3_fwd_nhwc evaluates from q = p . Wr)."""
+    import torch.nn.functional as F
+    torch.manual_seed(2)
+    b, cin, cout, h, w = 2, 5, 4, 6, 7
+    p = torch.randn(b, cin, h, w, dtype=torch.float64)
+    weight = torch.randn(cout, cin, 3, 3, dtype=torch.float64)
+    bias = torch.randn(cout, dtype=torch.float64)
+    ref = F.conv2d(F.interpolate(p, scale_factor=2, mode="bilinear", align_corners=True), weight, bias, padding=1)
+    wr = weight.permute(1, 2, 3, 0).reshape(cin, 9 * cout)                       # Wr[ci][(ky*3+kx)*Cout + co]
+    q = torch.matmul(p.permute(0, 2, 3, 1).reshape(b * h * w, cin), wr).view(b, h, w, 9, cout)
+    out = bias.view(1, cout, 1, 1).expand(b, cout, 2 * h, 2 * w).clone()
+    for ky in range(3):
+        for kx in range(3):
+            up = F.interpolate(q[:, :, :, ky * 3 + kx].permute(0, 3, 1, 2), scale_factor=2, mode="bilinear", align_corners=True)
+            up = F.pad(up, (1, 1, 1, 1))                                         # zeros outside the full-size map
+            out += up[:, :, ky:ky + 2 * h, kx:kx + 2 * w]                        # position (y + ky - 1, x + kx - 1)
+    torch.testing.assert_close(out, ref, rtol=1e-12, atol=1e-12)
