@@ -1587,6 +1587,17 @@ def pointwise_conv_stack_multi(seq, sources, with_mean=False):
     csum = sum(t.shape[1] for t in sources) * (2 if with_mean else 1)
     if not ok or len(convs) < 2 or not all(relu_after[:-1]) or convs[0].in_channels != csum:
         return pointwise_conv_stack(seq, build())
+    if with_mean:
+        # the mean term's backward reads the per-cloud sums of dY0 out of the statistics partials of the layer-1 dgrad,
+        # which are laid out [cloud][tile] only on the plain / split-K dgrad paths; the fused small / mid-size backward
+        # and the role-split dgrad cut the flattened (cloud, point) axis into chunks that straddle clouds
+        lib = _native.lib()
+        b, npts = sources[0].shape[0], sources[0].shape[2]
+        c0, c1 = convs[0].out_channels, convs[1].out_channels
+        if ((USE_FUSED_SMALL_BWD and lib.istnet_pw_bwd_small_ok(c0, c1, npts))
+                or (USE_FUSED_MID_BWD and lib.istnet_pw_bwd_mid_ok(c0, c1, npts))
+                or lib.istnet_pw_dgrad_rs(b, c0, c1, npts, 1)):
+            return pointwise_conv_stack(seq, build())
     params = []
     for m in convs:
         params += [m.weight, m.bias]

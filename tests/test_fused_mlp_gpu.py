@@ -472,6 +472,9 @@ def test_compact_column_lists_are_the_inverse_of_the_column_table():
     ([128, 64, 128, 64, 128], False, [256, 256]),  # HeavyEstimator.pose_mlp1
     ([256], True, [384, 256, 128]),               # deform_mlp2 on [feat, global mean]
     ([256], True, [512, 512]),                    # pose_mlp2 on [feat, global mean]
+    ([32], True, [64, 64, 32]),                   # layer 1 is a fused mid-size / small layer: partials straddle clouds
+    ([64], True, [128, 256]),                     # layer 1 = 128 -> 256: the role-split dgrad shape
+    ([16], True, [32, 32]),                       # layer 1 <= 32 channels: the fused small-layer backward
 ])
 def test_concat_free_head_stack_equals_concatenated_input(chans, with_mean, widths):
     """pointwise_conv_stack_multi (layer 0 walks the source tensors, the global mean enters as a per-cloud bias) vs the
