@@ -169,20 +169,23 @@ def make_graphed_step(fwd_bwds, opt, world, reducer=None):
     for fwd_bwd in fwd_bwds:                           # one graph per closure (two when the batches alternate)
         graph = torch.cuda.CUDAGraph()
         opt.zero_grad(set_to_none=True)
+        if reducer is not None:
+            reducer.begin_capture()
         with torch.cuda.graph(graph, capture_error_mode=capture_mode):
             fwd_bwd()
             if reducer is None:
                 opt.step()
             # else: the gradients stay in their (static) buffers; the all-reduce and Adam follow the replay eagerly
-        graphs.append(graph)
+        # per graph: which static tensor holds each parameter's gradient after a replay (parallel.OverlappedFlatReducer)
+        graphs.append((graph, reducer.end_capture() if reducer is not None else None))
     count = [0]
 
     def step():
-        k = count[0] % len(graphs)
+        graph, token = graphs[count[0] % len(graphs)]
         count[0] += 1
-        graphs[k].replay()
-        if reducer is not None:
-            opt.step(reducer.finish(), grad_scale=1.0 / world)   # bucketed RCCL all-reduce + one Adam launch
+        graph.replay()
+        if reducer is not None:        # bucketed RCCL all-reduce + one Adam launch
+            opt.step(reducer.finish(captured=token), grad_scale=1.0 / world)
     return step
 
 

@@ -94,11 +94,27 @@ class OverlappedFlatReducer:
         opt.zero_grad(set_to_none=True); loss.backward()
         opt.step(red.finish(), grad_scale=1.0 / world)
 
-    Inside a HIP-graph capture no collective is issued from the hooks (the buckets are only marked); ``finish()`` after
-    the replay then issues them back to back -- bucketed, but not overlapped with backward."""
+    Captured steps.  Inside a HIP-graph capture no collective is issued from the hooks; they record which parameters
+    the captured backward produces a gradient for and WHERE (the static tensor autograd stored in ``.grad`` during the
+    capture -- the flat slot itself for the in-place kernels, a graph-private tensor for e.g. MIOpen's gradients):
 
-    def __init__(self, opt, world_size=None, bucket_bytes=25 << 20, group=None, always=False):
+        with torch.cuda.graph(g): fwd_bwd()
+        token = red.end_capture()                  # one token per captured graph
+        ...
+        g.replay(); opt.step(red.finish(captured=token), grad_scale=1.0 / world)
+
+    ``finish(captured=token)`` then issues the buckets back to back -- bucketed, not overlapped with backward -- reading
+    every gradient from the tensor recorded in the token.  Do NOT call ``zero_grad`` between replays: a replay writes
+    its static tensors whatever ``.grad`` says, and validity is tracked here, not through ``p.grad is None``.
+
+    Gradient accumulation (several backward passes before ``finish()``) cannot be overlapped: a bucket that already
+    left was summed over ranks and would miss the second contribution.  A hook that fires for a parameter whose bucket
+    has been launched raises; call ``finish()`` after every backward pass, or construct with ``overlap=False`` to defer
+    every launch to ``finish()``."""
+
+    def __init__(self, opt, world_size=None, bucket_bytes=25 << 20, group=None, always=False, overlap=True):
         self.opt, self.group = opt, group
+        self.overlap = overlap     # False: hooks only mark, every bucket is launched by finish() (gradient accumulation)
         self.world = world_size if world_size is not None else dist.get_world_size(group)
         self.always = always       # True: issue the collectives even with one rank (single-GPU dry run of the RCCL path)
         esz = opt.flat_grad.element_size()
@@ -115,6 +131,7 @@ class OverlappedFlatReducer:
             for i in idxs:
                 self.bucket_of[i] = b
         self.comm = torch.cuda.Stream(device=opt.flat_grad.device) if opt.flat_grad.is_cuda else None
+        self._capturing = {}
         self._reset()
         self.issued_in_backward = 0          # statistics of the last step (tests, logging)
         for i, p in enumerate(opt.params):
@@ -128,29 +145,55 @@ class OverlappedFlatReducer:
         self.seen = [False] * len(self.opt.params)
         self.works = [None] * len(self.buckets)
         self.launched = [False] * len(self.buckets)
+        self.source = {}           # parameter index -> tensor holding its gradient for THIS step (captured steps)
 
     def _make_hook(self, i):
         def hook(param):
-            if self.seen[i]:
-                return
-            self.seen[i] = True
             b = self.bucket_of[i]
+            if param.is_cuda and torch.cuda.is_current_stream_capturing():
+                # captured backward: remember the static tensor this graph writes the gradient to; nothing is issued
+                self._capturing[i] = param.grad
+                return
+            if self.seen[i]:
+                if self.launched[b]:
+                    raise RuntimeError(
+                        "OverlappedFlatReducer: a second backward pass produced a gradient for a parameter whose bucket "
+                        "was already all-reduced; call finish() after every backward pass or use overlap=False")
+                return             # accumulation before the bucket left: .grad holds the sum when the bucket is launched
+            self.seen[i] = True
             self.left[b] -= 1
-            if self.left[b] == 0 and self._active() and not (
-                    param.is_cuda and torch.cuda.is_current_stream_capturing()):
+            if self.left[b] == 0 and self._active() and self.overlap:
                 self._launch(b)
                 self.issued_in_backward += 1
         return hook
+
+    _capturing = None
+
+    def begin_capture(self):
+        """Optional: start recording a captured backward (``end_capture`` also works without it)."""
+        self._capturing = {}
+
+    def end_capture(self):
+        """Token of the graph captured since the last ``end_capture`` / ``begin_capture``: parameter index -> the
+        static tensor that graph's backward writes the gradient to.  Pass it to ``finish(captured=...)``."""
+        token, self._capturing = (self._capturing or {}), {}
+        return token
+
+    def _grad_of(self, i):
+        """The tensor holding parameter i's gradient of the current step, or None if the step produced none."""
+        if i in self.source:
+            return self.source[i]
+        return self.opt.params[i].grad if self.seen[i] else None
 
     def _launch(self, b):
         lo, hi, idxs = self.buckets[b]
         opt = self.opt
         for i in idxs:                     # gradients that did not arrive in place (or not at all) go into their slots
-            p, slot = opt.params[i], opt.params[i]._istnet_grad_slot
-            if p.grad is None:
+            slot, g = opt.params[i]._istnet_grad_slot, self._grad_of(i)
+            if g is None:
                 slot.zero_()
-            elif p.grad.data_ptr() != slot.data_ptr() or not p.grad.is_contiguous():
-                slot.copy_(p.grad.reshape(-1))
+            elif g.data_ptr() != slot.data_ptr() or not g.is_contiguous():
+                slot.copy_(g.reshape(-1))
         piece = opt.flat_grad[lo:hi]
         if self.comm is None:              # CPU tensors (gloo tests): no streams
             self.works[b] = dist.all_reduce(piece, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
@@ -164,10 +207,13 @@ class OverlappedFlatReducer:
                 self.works[b] = dist.all_reduce(piece, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
         self.launched[b] = True
 
-    def finish(self):
+    def finish(self, captured=None):
         """Issue what backward did not (unused parameters, a captured step), wait for every bucket on the current
-        stream and return the summed flat gradient (``FlatAdam.step(flat, grad_scale=1/world)`` divides)."""
+        stream and return the summed flat gradient (``FlatAdam.step(flat, grad_scale=1/world)`` divides).
+        ``captured``: the ``end_capture()`` token of the graph that was just replayed."""
         opt = self.opt
+        if captured is not None:
+            self.source = captured
         if self._active():
             for b in range(len(self.buckets)):
                 if not self.launched[b]:
@@ -177,6 +223,14 @@ class OverlappedFlatReducer:
                     w.wait()
             if self.comm is not None:
                 torch.cuda.current_stream(opt.flat_grad.device).wait_stream(self.comm)
+            out = opt.flat_grad
+        elif captured is not None:         # one rank, captured step: pack from the graph's static tensors
+            for i, p in enumerate(opt.params):
+                slot, g = p._istnet_grad_slot, self._grad_of(i)
+                if g is None:
+                    slot.zero_()
+                elif g.data_ptr() != slot.data_ptr() or not g.is_contiguous():
+                    slot.copy_(g.reshape(-1))
             out = opt.flat_grad
         else:
             out = opt.pack_grads()

@@ -179,6 +179,69 @@ def _overlap_worker(rank, world, port, out):
     dist.destroy_process_group()
 
 
+def _reducer_validity_worker(rank, world, port, out):
+    """Gradient validity is tracked by the reducer, not through ``p.grad is None``:
+    (a) a captured step's gradients are read from the tensors recorded in its token even after zero_grad / with stale
+        ``.grad`` attributes; (b) a second backward after a bucket left raises; (c) overlap=False accumulates."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.set_num_threads(1)
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import istnet_amd  # noqa: F401
+    from istnet_amd.optim import FlatAdam
+    from istnet_amd.parallel import OverlappedFlatReducer
+    from istnet_amd.pointnet2 import pointnet2_utils
+    from oracle import pn2_oracle
+    pointnet2_utils._ext = pn2_oracle     # CPU test harness only
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    want = [sum(gs) for gs in zip(*[_local_grads(_make(0), r) for r in range(world)])]
+    want_flat = torch.cat([w.reshape(-1) for w in want])
+    ok = True
+    # (a) token path: the "graph" wrote its gradients into private static tensors; .grad is None (zero_grad before the
+    # replay) for half of the parameters and points at another graph's stale tensor for the rest
+    model = _make(seed=0)
+    opt = FlatAdam(model.parameters(), lr=1e-2)
+    red = OverlappedFlatReducer(opt, world, bucket_bytes=1024)
+    static = _local_grads(model, rank)                      # fires the hooks eagerly: buckets leave ...
+    red.finish()                                            # ... and the step is closed
+    token = {i: g for i, g in enumerate(static)}
+    for i, p in enumerate(opt.params):
+        p.grad = None if i % 2 else torch.full_like(p, 123.0)
+    flat = red.finish(captured=token)
+    ok = ok and torch.allclose(flat, want_flat, rtol=1e-5, atol=1e-7)
+    # (b) accumulation with overlapped launches: the second backward must raise, not be silently dropped
+    opt.zero_grad(set_to_none=True)
+    _local_grads_keep(model, rank)
+    raised = False
+    try:
+        _local_grads_keep(model, rank)
+    except RuntimeError as exc:
+        raised = "second backward" in str(exc)
+    ok = ok and raised
+    red.finish()
+    # (c) overlap=False: every launch deferred to finish(), two backward passes accumulate
+    model2 = _make(seed=0)
+    opt2 = FlatAdam(model2.parameters(), lr=1e-2)
+    red2 = OverlappedFlatReducer(opt2, world, bucket_bytes=1024, overlap=False)
+    opt2.zero_grad(set_to_none=True)
+    _local_grads_keep(model2, rank)
+    _local_grads_keep(model2, rank)
+    flat2 = red2.finish()
+    ok = ok and torch.allclose(flat2, 2.0 * want_flat, rtol=1e-5, atol=1e-7)
+    out[rank] = bool(ok)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_overlapped_reducer_tracks_gradient_validity_world2():
+    world = 2
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_reducer_validity_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    assert dict(out) == {0: True, 1: True}
+
+
 def test_overlapped_bucket_allreduce_world2():
     world = 2
     mgr = mp.Manager()
