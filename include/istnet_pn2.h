@@ -59,6 +59,17 @@ ISTNET_PN2_API int istnet_pn2_furthest_point_sampling(int b, int n, int m, const
 ISTNET_PN2_API int istnet_pn2_fps_gather(int b, int n, int m, const float *dataset, int *idxs,
                                          float *picked, void *stream);
 
+/* Chained sampling for a stack of set-abstraction levels (model/modules.py:311-320 applies
+ * pointnet2_modules.py:49-58 level after level: level l+1 samples from level l's picks, in pick order, starting at
+ * index 0).  Same results as istnet_pn2_fps_gather, bit for bit.  tie_out (b) i32: the first round of THIS run whose
+ * maximum was attained by more than one point among rounds 1 .. min(m, track_rounds)-1, else INT_MAX (or track_rounds
+ * when track_rounds < m: later rounds were not examined).  tie_in (b) i32 or NULL: the tie_out of the run whose picks
+ * are this run's `dataset` rows; a cloud with tie_in >= m needs no scan -- its picks are provably 0 .. m-1 (the parent's
+ * pick of round j maximised the same running minimum distance over a superset, uniquely) -- and gets tie_out = tie_in;
+ * every other cloud runs the full scan.  n <= 4096. */
+ISTNET_PN2_API int istnet_pn2_fps_gather_chain(int b, int n, int m, const float *dataset, int *idxs, float *picked,
+                                               const int *tie_in, int *tie_out, int track_rounds, void *stream);
+
 /* replaces gather_points_kernel_wrapper (sampling.cpp:9-11): points (b,c,n), idx (b,npoints) -> out (b,c,npoints) */
 ISTNET_PN2_API int istnet_pn2_gather_points(int b, int c, int n, int npoints, const float *points,
                              const int *idx, float *out, void *stream);

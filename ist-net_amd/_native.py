@@ -35,6 +35,7 @@ SIGNATURES = {
     "istnet_pn2_furthest_point_sampling": [_i, _i, _i, _p, _p, _p, _p],
     "istnet_debug_marker": [_p, _p],
     "istnet_pn2_fps_gather": [_i, _i, _i, _p, _p, _p, _p],
+    "istnet_pn2_fps_gather_chain": [_i, _i, _i, _p, _p, _p, _p, _p, _i, _p],
     "istnet_pn2_gather_points": [_i, _i, _i, _i, _p, _p, _p, _p],
     "istnet_pn2_gather_points_grad": [_i, _i, _i, _i, _p, _p, _p, _p],
     "istnet_pn2_query_ball_point": [_i, _i, _i, _f, _i, _p, _p, _p, _p],

@@ -122,11 +122,28 @@ __device__ __forceinline__ int tiekey_to_k(unsigned tk, int bs_log2, int nper) {
   return (int)(slot + (row << bs_log2));
 }
 
-template <int NW, int PPT, int CONV>
+// Chained sampling (the encoder samples level l+1 from level l's picks IN PICK ORDER, pointnet2_modules.py:49-58 applied
+// level after level): round j of the child run maximises the running minimum distance over S = {p_0 .. p_{m_parent-1}},
+// the parent's picks.  The parent's pick p_j maximised the same quantity -- same picked set by induction, bit-identical
+// distances (same expression, same operands) -- over the full cloud X, a superset of S, and p_j is in S; so whenever the
+// parent's maximum of round j was UNIQUE, the child's pick of round j is p_j, i.e. index j of its input.  TRACK makes a
+// run report the first round whose maximum was attained by more than one point (`tie_out`, conservative for its
+// children: a tie inside S is a tie inside X), and a run whose parent had no tie before round m (`tie_in[cloud] >= m`)
+// writes the prefix 0 .. m-1 and returns.  Any tie (duplicate points, equal distances) falls back to the full scan.
+constexpr int kFpsNoTie = 0x7fffffff;
+
+template <bool V> struct fps_tag { static constexpr bool value = V; };
+__device__ __forceinline__ int med3_i32(int a, int b, int c) {     // v_med3_i32
+  return max(min(a, b), min(max(a, b), c));
+}
+
+template <int NW, int PPT, int CONV, bool TRACK>
 __global__ __launch_bounds__(NW * 64) void fps_regs_kernel(int n, int m, int bs_log2, int nper,
                                                            const float* __restrict__ dataset_all,
                                                            int* __restrict__ idxs_all,
-                                                           float* __restrict__ picked_all) {
+                                                           float* __restrict__ picked_all,
+                                                           const int* __restrict__ tie_in,
+                                                           int* __restrict__ tie_out, int track_rounds) {
   constexpr int THREADS = NW * 64;
   extern __shared__ __attribute__((aligned(16))) float fps_lds[];  // xyz AoS copy [3n] (+ exchange)
   const int cloud = blockIdx.x;
@@ -135,8 +152,19 @@ __global__ __launch_bounds__(NW * 64) void fps_regs_kernel(int n, int m, int bs_
   float* picked = picked_all ? picked_all + (size_t)cloud * m * 3 : nullptr;  // optional: coordinates of the picks
   const int tid = threadIdx.x;
 
+  if (TRACK && tie_in != nullptr) {
+    const int parent_tie = tie_in[cloud];        // uniform: one cloud per workgroup
+    if (parent_tie >= m && m <= n) {             // the parent's rounds 1 .. m-1 had unique maxima: picks = prefix
+      for (int j = tid; j < m; j += THREADS) idxs[j] = j;
+      if (picked != nullptr)
+        for (int e = tid; e < 3 * m; e += THREADS) picked[e] = dataset[e];
+      if (tid == 0 && tie_out != nullptr) tie_out[cloud] = parent_tie;
+      return;
+    }
+  }
+
   for (int e = tid; e < 3 * n; e += THREADS) fps_lds[e] = dataset[e];
-  unsigned* xchg = reinterpret_cast<unsigned*>(fps_lds + 3 * n);  // [2][NW][2]
+  unsigned* xchg = reinterpret_cast<unsigned*>(fps_lds + 3 * n);  // [2][NW][3]
   __syncthreads();
 
   constexpr int PP = (PPT + 1) / 2;  // point slots are held in pairs (packed f32 math)
@@ -159,9 +187,15 @@ __global__ __launch_bounds__(NW * 64) void fps_regs_kernel(int n, int m, int bs_
   }
 
   int old = 0;
+  int first_tie = kFpsNoTie;
   if (tid == 0) idxs[0] = 0;
   if (picked != nullptr && tid < 3) picked[tid] = fps_lds[tid];
-  for (int j = 1; j < m; ++j) {
+  // one round; `track` (a compile-time tag) adds the uniqueness test of the maximum: per pair of slots the running
+  // SECOND largest value of the lane (v_med3 + v_max: the second largest of {lane's values so far} is
+  // max(old second, median(old best, a, c))), and after the reduction "more than one lane holds the maximum, or the
+  // lane that holds it holds it twice"
+  auto round = [&](auto track, int j) {
+    constexpr bool TR = decltype(track)::value;
     const float x1 = fps_lds[3 * old + 0];
     const float y1 = fps_lds[3 * old + 1];
     const float z1 = fps_lds[3 * old + 2];
@@ -170,6 +204,7 @@ __global__ __launch_bounds__(NW * 64) void fps_regs_kernel(int n, int m, int bs_
     // so a lane keeps its LOWEST slot among equals): 7 instructions per pair besides the distances.
     int best = -1;
     int besti = 0;
+    int second = -1;
 #pragma unroll
     for (int i = 0; i < PP; ++i) {
       const f32x2 d = sqdist2<CONV>(px[i], py[i], pz[i], x1, y1, z1);
@@ -179,10 +214,12 @@ __global__ __launch_bounds__(NW * 64) void fps_regs_kernel(int n, int m, int bs_
         const int c = min(__float_as_int(d[1]), tmp[2 * i + 1]);
         tmp[2 * i + 1] = c;
         const int code = c > a ? 2 * i + 1 : 2 * i;
+        if (TR) second = max(second, med3_i32(best, a, c));
         const int nb = max(best, max(a, c));
         besti = nb > best ? code : besti;
         best = nb;
       } else {
+        if (TR) second = max(second, min(best, a));
         besti = a > best ? 2 * i : besti;
         best = max(best, a);
       }
@@ -190,29 +227,52 @@ __global__ __launch_bounds__(NW * 64) void fps_regs_kernel(int n, int m, int bs_
     // value key: 0 for "no valid slot", otherwise float bits + 1 (d2 >= +0 => monotone)
     const unsigned vkey = (unsigned)(best + 1);
     unsigned vmax = wave_max_u32(vkey);
-    const unsigned tk = (vkey == vmax) ? (unsigned)(besti * THREADS + tid) : 0xffffffffu;
+    const bool holds = vkey == vmax;
+    const unsigned tk = holds ? (unsigned)(besti * THREADS + tid) : 0xffffffffu;
     unsigned tkmin = wave_min_u32(tk);
+    bool tied = false;
+    if (TR) {
+      const unsigned long long hm = __ballot(holds);
+      const unsigned long long twice = __ballot(holds && second == best);
+      tied = vmax != 0u && ((hm & (hm - 1)) != 0ull || twice != 0ull);
+    }
     if (NW > 1) {
-      unsigned* slot = xchg + (j & 1) * (NW * 2);
+      unsigned* slot = xchg + (j & 1) * (NW * 3);
       if (lane_id() == 0) {
-        slot[(tid >> 6) * 2 + 0] = vmax;
-        slot[(tid >> 6) * 2 + 1] = tkmin;
+        slot[(tid >> 6) * 3 + 0] = vmax;
+        slot[(tid >> 6) * 3 + 1] = tkmin;
+        if (TR) slot[(tid >> 6) * 3 + 2] = tied ? 1u : 0u;
       }
       lds_only_barrier();
-      unsigned bv = 0u, bt = 0xffffffffu;
+      unsigned bv = 0u, bt = 0xffffffffu, bf = 0u, nbest = 0u;
 #pragma unroll
       for (int w = 0; w < NW; ++w) {
-        const unsigned v = slot[w * 2 + 0], t = slot[w * 2 + 1];
+        const unsigned v = slot[w * 3 + 0], t = slot[w * 3 + 1];
         const bool better = (v > bv) || (v == bv && t < bt);
+        if (TR) {
+          const unsigned f = slot[w * 3 + 2];
+          nbest = v > bv ? 1u : (v == bv ? nbest + 1u : nbest);   // waves holding the workgroup maximum
+          bf = v > bv ? f : (v == bv ? (bf | f) : bf);            // ... and whether any of them holds it twice
+        }
         bv = better ? v : bv;
         bt = better ? t : bt;
       }
       tkmin = bt;
+      if (TR) tied = bv != 0u && (nbest > 1u || bf != 0u);
     }
+    if (TR && tied && first_tie == kFpsNoTie) first_tie = j;
     old = tiekey_to_k(tkmin, bs_log2, nper);
     if (tid == 0) idxs[j] = old;
     if (picked != nullptr && tid < 3) picked[3 * j + tid] = fps_lds[3 * old + tid];
+  };
+  int j = 1;
+  if (TRACK) {
+    const int upto = min(m, track_rounds);      // children sample at most this many points
+    for (; j < upto; ++j) round(fps_tag<true>{}, j);
   }
+  for (; j < m; ++j) round(fps_tag<false>{}, j);
+  // "no tie before round tie_out": rounds >= track_rounds were not examined
+  if (TRACK && tid == 0 && tie_out != nullptr) tie_out[cloud] = min(first_tie, track_rounds >= m ? kFpsNoTie : track_rounds);
 }
 
 // Generic fallback for very large clouds (n > 4096): running distances live in
@@ -1004,12 +1064,19 @@ int launch_interp_grad(int b, int c, int n, int m, const float* grad_out, const 
 
 template <int NW>
 int launch_fps_regs(int b, int n, int m, int bs_log2, int nper, const float* dataset, int* idxs,
-                    float* picked, hipStream_t st) {
+                    float* picked, const int* tie_in, int* tie_out, int track_rounds, hipStream_t st) {
   const int ppt = ceil_div(nper << bs_log2, NW * 64);  // tiekey slots per thread (holes included)
-  const size_t lds = (size_t)3 * n * 4 + (NW > 1 ? 2 * NW * 2 * 4 : 0);
-#define ISTNET_FPS_CASE(P)                                                                          \
-  ISTNET_CONV_DISPATCH(hipLaunchKernelGGL((fps_regs_kernel<NW, P, CONV_>), dim3(b), dim3(NW * 64), lds, st, n, m, \
-                                          bs_log2, nper, dataset, idxs, picked))
+  const size_t lds = (size_t)3 * n * 4 + (NW > 1 ? 2 * NW * 3 * 4 : 0);
+  const bool track = tie_in != nullptr || tie_out != nullptr;
+#define ISTNET_FPS_CASE(P)                                                                                          \
+  do {                                                                                                              \
+    if (track)                                                                                                      \
+      ISTNET_CONV_DISPATCH(hipLaunchKernelGGL((fps_regs_kernel<NW, P, CONV_, true>), dim3(b), dim3(NW * 64), lds, st, n, m, \
+                                              bs_log2, nper, dataset, idxs, picked, tie_in, tie_out, track_rounds)); \
+    else                                                                                                            \
+      ISTNET_CONV_DISPATCH(hipLaunchKernelGGL((fps_regs_kernel<NW, P, CONV_, false>), dim3(b), dim3(NW * 64), lds, st, n, m, \
+                                              bs_log2, nper, dataset, idxs, picked, tie_in, tie_out, track_rounds)); \
+  } while (0)
   if (ppt <= 1) ISTNET_FPS_CASE(1);
   else if (ppt <= 2) ISTNET_FPS_CASE(2);
   else if (ppt <= 4) ISTNET_FPS_CASE(4);
@@ -1044,7 +1111,7 @@ int istnet_pn2_set_tuning(int key, int value) {
 const char* istnet_pn2_target(void) { return "gfx950"; }
 
 static int fps_impl(int b, int n, int m, const float* dataset, float* temp, int* idxs, float* picked,
-                    void* stream) {
+                    const int* tie_in, int* tie_out, int track_rounds, void* stream) {
   if (b < 0 || n <= 0 || m < 0) return ISTNET_PN2_EINVAL;
   if (b == 0 || m == 0) return 0;
   // reference block size: opt_n_threads(n) = clamp(2^floor(log2 n), 1, 512)  (cuda_utils.h:18-22)
@@ -1056,9 +1123,12 @@ static int fps_impl(int b, int n, int m, const float* dataset, float* temp, int*
   // one wave per cloud is barrier-free and measured faster than 2 / 4 / 8 waves (LDS exchange + barrier per round:
   // ~0.5 us per round whatever the points per lane, against 0.28-0.50 us for one wave) for every n <= 1024
   // (profiles/r01_index_microbench.txt; round 2 re-measured with the LDS-only barrier: 256 vs 266 / 270 / 405 us)
-  if (slots < g_fps_multiwave_min) return launch_fps_regs<1>(b, n, m, bs_log2, nper, dataset, idxs, picked, st);
-  if (slots <= 256 * 16) return launch_fps_regs<4>(b, n, m, bs_log2, nper, dataset, idxs, picked, st);
-  if (temp == nullptr || picked != nullptr) return ISTNET_PN2_EINVAL;  // large clouds: scratch buffer, no fused gather
+  if (slots < g_fps_multiwave_min)
+    return launch_fps_regs<1>(b, n, m, bs_log2, nper, dataset, idxs, picked, tie_in, tie_out, track_rounds, st);
+  if (slots <= 256 * 16)
+    return launch_fps_regs<4>(b, n, m, bs_log2, nper, dataset, idxs, picked, tie_in, tie_out, track_rounds, st);
+  if (temp == nullptr || picked != nullptr || tie_in != nullptr || tie_out != nullptr)
+    return ISTNET_PN2_EINVAL;  // large clouds: scratch buffer, no fused gather, no chained sampling
   ISTNET_CONV_DISPATCH(hipLaunchKernelGGL(fps_generic_kernel<CONV_>, dim3(b), dim3(1024), 0, st, n, m, bs_log2, nper,
                                           dataset, temp, idxs));
   return (int)hipGetLastError();
@@ -1066,12 +1136,18 @@ static int fps_impl(int b, int n, int m, const float* dataset, float* temp, int*
 
 int istnet_pn2_furthest_point_sampling(int b, int n, int m, const float* dataset, float* temp,
                                        int* idxs, void* stream) {
-  return fps_impl(b, n, m, dataset, temp, idxs, nullptr, stream);
+  return fps_impl(b, n, m, dataset, temp, idxs, nullptr, nullptr, nullptr, 0, stream);
 }
 
 int istnet_pn2_fps_gather(int b, int n, int m, const float* dataset, int* idxs, float* picked, void* stream) {
   if (picked == nullptr || n > 4096) return ISTNET_PN2_EINVAL;
-  return fps_impl(b, n, m, dataset, nullptr, idxs, picked, stream);
+  return fps_impl(b, n, m, dataset, nullptr, idxs, picked, nullptr, nullptr, 0, stream);
+}
+
+int istnet_pn2_fps_gather_chain(int b, int n, int m, const float* dataset, int* idxs, float* picked,
+                                const int* tie_in, int* tie_out, int track_rounds, void* stream) {
+  if (picked == nullptr || n > 4096 || tie_out == nullptr || track_rounds < 0) return ISTNET_PN2_EINVAL;
+  return fps_impl(b, n, m, dataset, nullptr, idxs, picked, tie_in, tie_out, track_rounds, stream);
 }
 
 int istnet_pn2_gather_points(int b, int c, int n, int npoints, const float* points, const int* idx,

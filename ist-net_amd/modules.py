@@ -20,6 +20,10 @@ from .pointnet2.pointnet2_modules import PointnetFPModule, PointnetSAModuleMSG
 # on a second HIP stream at the start of the forward and overlap the MFMA stacks of the earlier levels;
 # the main stream waits on one event per level.
 USE_GEOMETRY_STREAM = True
+# Level l+1 samples from level l's picks in pick order, so its picks are the prefix 0..m-1 of its input whenever no
+# arg-max tie occurred in the parent's first m rounds: the parent run reports its first tied round and the children
+# skip their scan (include/istnet_pn2.h, istnet_pn2_fps_gather_chain).  Bit-identical to sampling every level.
+USE_FPS_CHAIN = True
 _GEOMETRY_STREAMS = {}
 
 
@@ -97,8 +101,14 @@ class PointNet2MSG(nn.Module):
         sa_geo, fp_geo = [], [None] * len(self.FP_modules)
         with torch.cuda.stream(side), torch.no_grad():
             cur, levels = xyz, [xyz]
-            for sa in self.SA_modules:
-                new_xyz = sa._sample_centroids(cur)
+            chain = getattr(pointnet2_utils._ext, "furthest_point_sampling_chain", None) if USE_FPS_CHAIN else None
+            tie = None
+            for li, sa in enumerate(self.SA_modules):
+                if chain is not None and cur.shape[1] <= 4096:
+                    nxt = self.SA_modules[li + 1].npoint if li + 1 < len(self.SA_modules) else 0
+                    _, new_xyz, tie = chain(cur, sa.npoint, tie_in=tie, track_rounds=min(nxt or 0, sa.npoint))
+                else:
+                    new_xyz, tie = sa._sample_centroids(cur), None
                 idx = [pointnet2_utils.ball_query(g.radius, g.nsample, cur, new_xyz) for g in sa.groupers]
                 comps = None
                 ball_compact = getattr(pointnet2_utils._ext, "ball_compact", None)   # absent from a plain reference _ext

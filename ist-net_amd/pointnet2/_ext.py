@@ -107,6 +107,30 @@ def furthest_point_sampling_gather(points, nsamples):
     return out, picked
 
 
+def furthest_point_sampling_chain(points, nsamples, tie_in=None, track_rounds=None):
+    """Sampling for a stack of set-abstraction levels: (idx (B,nsamples) i32, picked (B,nsamples,3), tie (B,) i32).
+    ``tie`` = first round of this run whose maximum was not unique (INT_MAX if none, ``track_rounds`` if only the
+    rounds below it were examined).  ``tie_in`` = the ``tie`` of the run whose picks, in pick order, ARE ``points``:
+    clouds with ``tie_in >= nsamples`` get the prefix 0..nsamples-1 without a scan (include/istnet_pn2.h).  Results
+    equal furthest_point_sampling_gather bit for bit.  N <= 4096."""
+    _contig(points, "points"); _is_float(points, "points")
+    dev = _device_of(points, "points")
+    b, n = points.shape[0], points.shape[1]
+    nsamples = int(nsamples)
+    if tie_in is not None:
+        _contig(tie_in, "tie_in"); _is_int(tie_in, "tie_in")
+        _req(tie_in.is_cuda and tie_in.device == dev and tie_in.numel() == b, "tie_in must be (B,) int32 on the device of points")
+    out = torch.empty((b, nsamples), dtype=torch.int32, device=dev)
+    picked = torch.empty((b, nsamples, 3), dtype=torch.float32, device=dev)
+    tie = torch.empty((b,), dtype=torch.int32, device=dev)
+    track = nsamples if track_rounds is None else int(track_rounds)
+    with torch.cuda.device(dev):
+        _native.check(_native.lib().istnet_pn2_fps_gather_chain(
+            b, n, nsamples, _ptr(points), _ptr(out), _ptr(picked), _ptr(tie_in) if tie_in is not None else None,
+            _ptr(tie), track, _stream(dev)), "fps_gather_chain")
+    return out, picked, tie
+
+
 def three_nn(unknowns, knows):
     """(B,n,3), (B,m,3) f32 -> [dist2 (B,n,3) f32, idx (B,n,3) i32].  interpolate.cpp:19-45"""
     _contig(unknowns, "unknowns"); _contig(knows, "knows")

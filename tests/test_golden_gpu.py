@@ -65,21 +65,22 @@ def test_encoder_b2(monkeypatch):
             captured[f"{name}_{i}"] = res
             return res
         monkeypatch.setattr(_ext, name, fn)
-    # the encoder samples + gathers in one op, and takes three_nn together with the interpolation weights
-    for n in ("furthest_point_sampling_gather", "ball_query", "three_nn_weights"):
+    # the encoder samples + gathers in one op (chained over the levels: a level whose parent run had no arg-max tie
+    # takes the prefix of its input), and takes three_nn together with the interpolation weights
+    for n in ("furthest_point_sampling_chain", "ball_query", "three_nn_weights"):
         tap(n)
     torch.manual_seed(0)
     enc = PointNet2MSG([list(r) for r in CAM]).to(DEV).train()
     pts = torch.from_numpy(z["pts"]).to(DEV)
     out = enc(pts)
     for i in range(4):
-        assert np.array_equal(captured[f"furthest_point_sampling_gather_{i}"][0].cpu().numpy(),
+        assert np.array_equal(captured[f"furthest_point_sampling_chain_{i}"][0].cpu().numpy(),
                               z[f"furthest_point_sampling_{i}"].astype(np.int32)), i
         idx, wgt = captured[f"three_nn_weights_{i}"]
         assert np.array_equal(idx.cpu().numpy(), z[f"three_nn_idx_{i}"].astype(np.int32)), i
         # the weights follow from the golden distances; the squared distances themselves bit for bit from the
         # stand-alone op on the same level coordinates (call i of the encoder is propagation level 3 - i)
-        levels = [pts[:, :, :3].contiguous()] + [captured[f"furthest_point_sampling_gather_{k}"][1] for k in range(4)]
+        levels = [pts[:, :, :3].contiguous()] + [captured[f"furthest_point_sampling_chain_{k}"][1] for k in range(4)]
         d2, idx_again = _ext.three_nn(levels[3 - i].contiguous(), levels[4 - i].contiguous())
         assert np.array_equal(d2.cpu().numpy(), z[f"three_nn_dist2_{i}"]), i
         assert torch.equal(idx_again, idx)

@@ -212,6 +212,66 @@ def test_fps_gather_matches_fps_plus_gather(ext, oracle, n, m, kind):
     assert torch.equal(picked.cpu(), expect)
 
 
+def _first_tie_round(xyz, m):
+    """CPU brute force in the kernels' arithmetic (IEEE f32, ((dx*dx + dy*dy) + dz*dz), no fusion): for every cloud the
+    first round of furthest point sampling whose maximum is attained by more than one point (INT_MAX if none), taking
+    the picks from ``picks`` (the oracle's, so the tie rule plays no part here)."""
+    from oracle import pn2_oracle
+    picks = pn2_oracle.furthest_point_sampling(xyz, m).long()
+    b, n, _ = xyz.shape
+    out = torch.full((b,), 2**31 - 1, dtype=torch.int64)
+    for c in range(b):
+        p = xyz[c]
+        run = torch.full((n,), 1e10, dtype=torch.float32)
+        for j in range(1, m):
+            d = p - p[picks[c, j - 1]]
+            d2 = (d[:, 0] * d[:, 0] + d[:, 1] * d[:, 1]) + d[:, 2] * d[:, 2]
+            run = torch.minimum(run, d2)
+            if int((run == run.max()).sum()) > 1:
+                out[c] = j
+                break
+    return out
+
+
+@pytest.mark.parametrize("n,levels,kind,b", [
+    (1024, (512, 256, 128, 64), "shell", 4),      # the encoder's chain (modules.py)
+    (1024, (512, 256, 128, 64), "cube", 3), (1024, (512, 256, 128, 64), "dup", 3),
+    (1024, (512, 256, 128, 64), "grid", 2), (2048, (1024, 512, 256, 128), "shell", 2),     # four waves per cloud
+    (2048, (700, 300, 300, 17), "dup", 2), (700, (333, 120, 50, 50), "cube", 3), (300, (299, 150, 2, 1), "shell", 2),
+])
+def test_chained_fps_equals_level_by_level_sampling(ext, oracle, n, levels, kind, b):
+    """istnet_pn2_fps_gather_chain: every level bit-identical to sampling it with the full scan (the oracle), whether a
+    cloud took the prefix shortcut (parent run without an arg-max tie in the rounds the child needs) or the scan;
+    the reported first tied round equals a brute-force count of the maxima; un-tied clouds DO take the shortcut."""
+    xyz = _cloud(b, n, seed=n + len(kind), kind=kind)
+    if kind in ("shell", "cube"):          # one cloud with duplicates inside an otherwise tie-free batch
+        xyz[-1, n // 2:] = xyz[-1, :n - n // 2]
+    cur_c, cur_g, tie = xyz, xyz.to(DEV), None
+    shortcut = 0
+    for li, m in enumerate(levels):
+        nxt = levels[li + 1] if li + 1 < len(levels) else 0
+        track = min(nxt, m)
+        idx_ref = oracle.furthest_point_sampling(cur_c, m)
+        idx, picked, tie_out = ext.furthest_point_sampling_chain(cur_g, m, tie_in=tie, track_rounds=track)
+        assert torch.equal(idx.cpu(), idx_ref), f"level {li}"
+        new_c = torch.gather(cur_c, 1, idx_ref.long().unsqueeze(-1).expand(-1, -1, 3)).contiguous()
+        assert torch.equal(picked.cpu(), new_c), f"level {li}"
+        took = None if tie is None else (tie.cpu().long() >= m) & (m <= cur_c.shape[1])
+        if took is not None:
+            shortcut += int(took.sum())
+            assert torch.equal(tie_out.cpu()[took], tie.cpu()[took])            # shortcut: the parent's report passes on
+            ar = torch.arange(m, dtype=torch.int32)
+            assert all(torch.equal(idx.cpu()[c], ar) for c in range(b) if took[c])
+        scanned = torch.ones(b, dtype=torch.bool) if took is None else ~took
+        if scanned.any() and track > 1:
+            want = _first_tie_round(cur_c[scanned], track).clamp(max=2**31 - 1)
+            want = torch.where(want < track, want, torch.full_like(want, track if track < m else 2**31 - 1))
+            assert torch.equal(tie_out.cpu().long()[scanned], want), f"level {li}: first tied round"
+        cur_c, cur_g, tie = new_c, picked, tie_out
+    if kind == "shell":
+        assert shortcut >= (b - 1) * (len(levels) - 1) - 1      # tie-free clouds skip the scan on every later level
+
+
 def test_index_ops_random_shapes_bit_exact(ext, oracle):
     """Seeded fuzz over small random shapes / distributions: FPS, ball query and three_nn stay bit-exact with the
     oracle for sizes that are not multiples of any tile, m > n, heavy ties and empty balls."""
