@@ -93,6 +93,21 @@ SIGNATURES = {
     "istnet_pw_wgrad": [_i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _l, _p, _p, _p, _p, _p],
     "istnet_pw_wgrad_reduce": [_i, _i, _p, _p, _p],
     "istnet_pw_wgrad_reduce_multi": [_i, _p, _p, _p, _p, _p],
+    "istnet_pw_wgrad_reduce_multi_ld": [_i, _p, _p, _p, _p, _p, _p, _p, _p],
+    "istnet_pack_words": [_i, _p, _p, _p, _p],
+    # csrc/pw_last.hip
+    "istnet_pw_forward_pool_ok": [_i, _i, _i, _i, _i],
+    "istnet_pw_forward_pool": [_i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p],
+    "istnet_bn_finalize_pool_apply": [_i, _i, _i, _i, _d, _p, _p, _p, _p, _f, _f, _p, _p, _p, _p, _p, _l, _p],
+    "istnet_pool_apply": [_i, _i, _i, _p, _p, _p, _l, _p],
+    "istnet_pw_bwd_last_ok": [_i, _i, _i, _i],
+    "istnet_pw_bwd_last_splits": [_i, _i, _i, _i, _i],
+    "istnet_pw_last_set_tuning": [_i, _i],
+    "istnet_pw_last_prep": [_i, _i, _i, _i, _i, _p, _p, _p, _p, _l, _p, _p, _p, _p, _p, _p, _p, _p],
+    "istnet_pw_bwd_last": [_i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p],
+    "istnet_pw_dw_last_parts": [_i, _i, _i, _i, _i],
+    "istnet_pw_dw_last": [_i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p],
+    "istnet_pw_dw_last_finish": [_i, _i, _p, _p, _p, _p, _p, _p, _p],
     # compact-column form of a set-abstraction scale (csrc/sa_compact.hip)
     "istnet_sa_compact": [_i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p],
     "istnet_pw_gather_add_cols": [_i, _i, _i, _l, _i, _p, _p, _p, _p, _p, _p, _p, _p, _i, _p, _p, _p, _p],
@@ -223,7 +238,8 @@ def affine_consts_multi(items, stream):
 
 
 def reduce_multi(items, stream):
-    """items: list of (count, splits, part_ptr, dw_ptr); one launch per <= 8 layers."""
+    """items: list of (count, splits, part_ptr, dw_ptr[, cols, ld, pstride]); one launch per <= 8 items.  The long form
+    writes a column block of a wider destination from a row block of wider partials (istnet_pw_wgrad_reduce_multi_ld)."""
     handle = lib()
     for i in range(0, len(items), 8):
         chunk = items[i:i + 8]
@@ -232,4 +248,25 @@ def reduce_multi(items, stream):
         splits = (ctypes.c_int * n)(*[c[1] for c in chunk])
         parts = (ctypes.c_void_p * n)(*[c[2] for c in chunk])
         dws = (ctypes.c_void_p * n)(*[c[3] for c in chunk])
-        check(handle.istnet_pw_wgrad_reduce_multi(n, counts, splits, parts, dws, stream), "pw_wgrad_reduce_multi")
+        if any(len(c) > 4 for c in chunk):
+            full = [c if len(c) > 4 else (*c, c[0], c[0], c[0]) for c in chunk]
+            cols = (ctypes.c_int * n)(*[c[4] for c in full])
+            lds = (ctypes.c_int * n)(*[c[5] for c in full])
+            pst = (ctypes.c_longlong * n)(*[c[6] for c in full])
+            check(handle.istnet_pw_wgrad_reduce_multi_ld(n, counts, splits, parts, dws, cols, lds, pst, stream),
+                  "pw_wgrad_reduce_multi_ld")
+        else:
+            check(handle.istnet_pw_wgrad_reduce_multi(n, counts, splits, parts, dws, stream), "pw_wgrad_reduce_multi")
+
+
+def pack_words(srcs, dst, stream):
+    """Copy the tensors ``srcs`` (4-byte element types, contiguous) back to back into ``dst``; one launch per <= 64."""
+    handle = lib()
+    off = 0
+    for i in range(0, len(srcs), 64):
+        chunk = srcs[i:i + 64]
+        n = len(chunk)
+        words = [t.numel() * t.element_size() // 4 for t in chunk]
+        check(handle.istnet_pack_words(n, (ctypes.c_void_p * n)(*[t.data_ptr() for t in chunk]),
+                                       (ctypes.c_longlong * n)(*words), dst.data_ptr() + 4 * off, stream), "pack_words")
+        off += sum(words)

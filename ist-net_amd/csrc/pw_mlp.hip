@@ -437,12 +437,45 @@ __global__ __launch_bounds__(kThreads) void pw_fwd_kernel(
 // 4 TMW MFMAs -- the LDS-tiled kernel above needs 2 ds_read_b32 per MFMA at its 64 x 64 tiles.
 // Wave tile: 32 TMW rows x 128 points; WM x WN waves per workgroup; grid (tiles_per_cloud * B, ceil(cout / M_WG)).
 // ============================================================================================
-template <int TMW, int WM, int WN, int KC>
+// POOL = S > 0 (the LAST layer of a set-abstraction scale, nsample S in {16, 32}): y is NOT written.  The reference's
+// tail  max_pool2d(relu(bn(y)))  (pointnet2_modules.py:65-68) commutes with the monotone map y -> relu(scale y + shift):
+// the pooled value of a group is relu(scale y* + shift) with y* the raw maximum for scale >= 0 and the raw minimum for
+// scale < 0, and sign(scale) = sign(gamma) is known before the statistics are.  So the epilogue reduces each group of S
+// consecutive points of a row -- S / 4 adjacent lanes x the 4 accumulators -- to (y*, slot of y*) with DPP quad / row
+// permutes and stores (B, C, G) values (`gval`, `arg`); the widest activation of the stack (34-67 MB per scale) never
+// exists, the max-pool pass does not read it back, and the backward pass runs from act(y_{L-1}) (pw_bwd_last_kernel).
+template <int CTRL>
+__device__ __forceinline__ float dpp_perm_f(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
+}
+template <int CTRL>
+__device__ __forceinline__ int dpp_perm_i(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, false); }
+// all-reduce over S / 4 adjacent lanes: quad_perm [1,0,3,2], quad_perm [2,3,0,1], row_half_mirror, row_mirror
+template <int S>
+__device__ __forceinline__ float group_max_f(float m) {
+  m = fmaxf(m, dpp_perm_f<0xB1>(m));
+  m = fmaxf(m, dpp_perm_f<0x4E>(m));
+  if (S >= 32) m = fmaxf(m, dpp_perm_f<0x141>(m));
+  if (S >= 64) m = fmaxf(m, dpp_perm_f<0x140>(m));
+  return m;
+}
+template <int S>
+__device__ __forceinline__ int group_min_i(int m) {
+  m = min(m, dpp_perm_i<0xB1>(m));
+  m = min(m, dpp_perm_i<0x4E>(m));
+  if (S >= 32) m = min(m, dpp_perm_i<0x141>(m));
+  if (S >= 64) m = min(m, dpp_perm_i<0x140>(m));
+  return m;
+}
+
+template <int TMW, int WM, int WN, int KC, int POOL = 0>
 __global__ __launch_bounds__(kThreads, 2) void pw_fwd2_kernel(
     int cin, int cout, int P, int tiles_per_cloud, const float* __restrict__ x, const float* __restrict__ w,
     const float* __restrict__ in_scale, const float* __restrict__ in_shift, float* __restrict__ y,
-    float* __restrict__ part_sum, float* __restrict__ part_sq, int nt_total) {
+    float* __restrict__ part_sum, float* __restrict__ part_sq, int nt_total,
+    const float* __restrict__ gamma = nullptr, float* __restrict__ gval = nullptr, uint8_t* __restrict__ garg = nullptr) {
   static_assert(WM * WN == 4 && (KC == 16 || KC == 32), "4 waves; K chunk of 16 or 32 channels");
+  static_assert(POOL == 0 || POOL == 16 || POOL == 32 || POOL == 64, "nsample of the pooled epilogue");
   constexpr int M_WG = 32 * TMW * WM, N_WG = 128 * WN;
   constexpr int LDA = M_WG + 1;                 // odd: the transposed scalar stores of a weight chunk spread over the banks
   constexpr int NA = KC * M_WG / kThreads;      // weight elements per thread per chunk
@@ -461,6 +494,12 @@ __global__ __launch_bounds__(kThreads, 2) void pw_fwd2_kernel(
   const float* xb = x + (size_t)b * cin * P + (live ? p0 : 0) + 4 * l31;
   if (has_bn)
     for (int c = tid; c < cin; c += kThreads) { s_in[0][c] = in_scale[c]; s_in[1][c] = in_shift[c]; }
+  __shared__ unsigned s_sgn[POOL ? M_WG : 1];   // sign bit of gamma per output row: the group extremum is taken of sgn * y
+  if (POOL)
+    for (int c = tid; c < M_WG; c += kThreads) {     // bit 31: sign of gamma; bit 0: gamma == 0 (every slot ties: slot 0 wins,
+      const unsigned gb = __float_as_uint(gamma[min(m0 + c, cout - 1)]);   // as max_pool2d's first maximum does)
+      s_sgn[c] = (gb & 0x80000000u) | ((gb & 0x7fffffffu) == 0u ? 1u : 0u);
+    }
 
   float areg[NA];
   auto load_a = [&](int k0) {
@@ -534,7 +573,26 @@ __global__ __launch_bounds__(kThreads, 2) void pw_fwd2_kernel(
     for (int r = 0; r < 16; ++r) {
       const int row_l = a_col0 + 32 * tm + mfma_row(r, lane), row = m0 + row_l;
       const float4 v = make_float4(acc[tm][0][r], acc[tm][1][r], acc[tm][2][r], acc[tm][3][r]);
-      if (live && row < cout) *reinterpret_cast<float4*>(yb + (size_t)row * P) = v;
+      if (POOL) {
+        // group of POOL consecutive points = POOL / 4 adjacent lanes x (x, y, z, w); keys = sgn(gamma) * y
+        const unsigned sw = s_sgn[row_l], sb = sw & 0x80000000u;
+        const float k0 = __uint_as_float(__float_as_uint(v.x) ^ sb), k1 = __uint_as_float(__float_as_uint(v.y) ^ sb);
+        const float k2 = __uint_as_float(__float_as_uint(v.z) ^ sb), k3 = __uint_as_float(__float_as_uint(v.w) ^ sb);
+        const float m = group_max_f<POOL>(fmaxf(fmaxf(k0, k1), fmaxf(k2, k3)));
+        const int lg = l31 & (POOL / 4 - 1);                 // lane within the group
+        int cand = k0 == m ? 0 : (k1 == m ? 1 : (k2 == m ? 2 : (k3 == m ? 3 : 255)));
+        cand = cand < 4 ? 4 * lg + cand : 255;               // slot of the FIRST extremum this lane holds
+        cand = group_min_i<POOL>(cand);
+        if (live && row < cout && lg == 0) {
+          const int G = P / POOL;
+          const size_t o = ((size_t)b * cout + row) * G + (p0 + 4 * l31) / POOL;
+          const bool zero_gamma = (sw & 1u) != 0u;         // constant output: the gradient goes to slot 0 (this lane's x)
+          gval[o] = zero_gamma ? v.x : __uint_as_float(__float_as_uint(m) ^ sb);
+          garg[o] = zero_gamma ? (uint8_t)0 : (uint8_t)cand;
+        }
+      } else if (live && row < cout) {
+        *reinterpret_cast<float4*>(yb + (size_t)row * P) = v;
+      }
       if (part_sum != nullptr) {
         float s = live ? (v.x + v.y) + (v.z + v.w) : 0.f;
         float q = live ? (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w) : 0.f;
@@ -2914,11 +2972,19 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(int count, int splits
 
 // Same reduction for up to 8 layers in one launch (descriptors by value): one launch per SharedMLP instead of
 // one per layer -- the reduce is pure launch latency (~9 us for ~1 us of work).
+// An item may be a COLUMN BLOCK of a wider destination matrix (cols / ld: element i goes to row i / cols, column
+// i % cols of a matrix with leading dimension ld) and its partials may be a row block of wider partial matrices
+// (pstride: distance between consecutive splits): the pieces of a weight gradient that come from different launches
+// (xyz columns + feature columns of a set-abstraction layer 0; interpolated + skip columns of a feature-propagation
+// layer 0) land in the parameter's gradient directly, with no concatenation afterwards.
 struct ReduceBatch {
   const float* part[8];
   float* dw[8];
   int count[8];
   int splits[8];
+  int cols[8];
+  int ld[8];
+  long long pstride[8];
   int block_begin[9];  // prefix sum of ceil(count / 16)
   int n;
 };
@@ -2927,6 +2993,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_multi_kernel(ReduceBatch rb)
   int l = 0;
   while (l + 1 < rb.n && (int)blockIdx.x >= rb.block_begin[l + 1]) ++l;
   const int count = rb.count[l], splits = rb.splits[l];
+  const size_t ps = (size_t)rb.pstride[l];
   const float* __restrict__ part = rb.part[l];
   const int el = threadIdx.x & 15, sg = threadIdx.x >> 4;
   const int i = ((int)blockIdx.x - rb.block_begin[l]) * 16 + el;
@@ -2934,12 +3001,12 @@ __global__ __launch_bounds__(256) void wgrad_reduce_multi_kernel(ReduceBatch rb)
   if (i < count) {
     int k = sg;
     for (; k + 48 < splits; k += 64) {
-      s0 += part[(size_t)k * count + i];
-      s1 += part[(size_t)(k + 16) * count + i];
-      s2 += part[(size_t)(k + 32) * count + i];
-      s3 += part[(size_t)(k + 48) * count + i];
+      s0 += part[(size_t)k * ps + i];
+      s1 += part[(size_t)(k + 16) * ps + i];
+      s2 += part[(size_t)(k + 32) * ps + i];
+      s3 += part[(size_t)(k + 48) * ps + i];
     }
-    for (; k < splits; k += 16) s0 += part[(size_t)k * count + i];
+    for (; k < splits; k += 16) s0 += part[(size_t)k * ps + i];
   }
   red[sg][el] = (s0 + s1) + (s2 + s3);
   __syncthreads();
@@ -2947,7 +3014,27 @@ __global__ __launch_bounds__(256) void wgrad_reduce_multi_kernel(ReduceBatch rb)
     float s = 0.f;
 #pragma unroll
     for (int g = 0; g < 16; ++g) s += red[g][el];
-    rb.dw[l][i] = s;
+    const int cols = rb.cols[l];
+    rb.dw[l][(size_t)(i / cols) * rb.ld[l] + i % cols] = s;
+  }
+}
+
+// Row blocks of up to 8 small matrices copied into one buffer in ONE launch (the layer-0 weights of a level's scales
+// stacked for the level-wide feature-gradient product; the tensors of a geometry slot packed into its flat storage).
+struct PackBatch {
+  const unsigned* src[64];
+  long long begin[65];   // prefix sum of the sources' sizes in 4-byte words
+  int n;
+};
+__global__ __launch_bounds__(256) void pack_words_kernel(PackBatch pb, unsigned* __restrict__ dst) {
+  const long long total = pb.begin[pb.n];
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    int lo = 0, hi = pb.n - 1;          // source holding word i: last l with begin[l] <= i
+    while (lo < hi) {
+      const int mid = (lo + hi + 1) >> 1;
+      if (pb.begin[mid] <= i) lo = mid; else hi = mid - 1;
+    }
+    dst[i] = pb.src[lo][i - pb.begin[lo]];
   }
 }
 
@@ -3134,13 +3221,21 @@ int istnet_pw_forward_cfg(int b, int cin, int cout, int p) {
 
 static int launch_pw_fwd2(int cfg, int b, int cin, int cout, int p, const float* x, const float* w,
                           const float* in_scale, const float* in_shift, float* y, float* part_sum, float* part_sq,
-                          void* stream) {
+                          void* stream, int pool = 0, const float* gamma = nullptr, float* gval = nullptr,
+                          uint8_t* garg = nullptr) {
   const int tmw = cfg / 1000, wm = (cfg / 100) % 10, wn = (cfg / 10) % 10, kc32 = cfg % 10;
   const int tpc = p / (128 * wn);
   const dim3 grid(tpc * b, ceil_div(cout, 32 * tmw * wm));
+#define ISTNET_FWD2P(TMW, WM, WN, KC, POOL)                                                                        \
+  hipLaunchKernelGGL((pw_fwd2_kernel<TMW, WM, WN, KC, POOL>), grid, dim3(kThreads), 0, as_stream(stream), cin, cout, p, \
+                     tpc, x, w, in_scale, in_shift, y, part_sum, part_sq, tpc * b, gamma, gval, garg)
 #define ISTNET_FWD2(TMW, WM, WN, KC)                                                                               \
-  hipLaunchKernelGGL((pw_fwd2_kernel<TMW, WM, WN, KC>), grid, dim3(kThreads), 0, as_stream(stream), cin, cout, p,  \
-                     tpc, x, w, in_scale, in_shift, y, part_sum, part_sq, tpc * b)
+  do {                                                                                                             \
+    if (pool == 0) ISTNET_FWD2P(TMW, WM, WN, KC, 0);                                                               \
+    else if (TMW == 2 && pool == 16) ISTNET_FWD2P(TMW, WM, WN, KC, (TMW == 2 ? 16 : 0));                           \
+    else if (TMW == 2 && pool == 32) ISTNET_FWD2P(TMW, WM, WN, KC, (TMW == 2 ? 32 : 0));                           \
+    else return ISTNET_PN2_EINVAL;                                                                                 \
+  } while (0)
 #define ISTNET_FWD2_K(TMW, WM, WN)                                                                                 \
   do {                                                                                                             \
     if (kc32) ISTNET_FWD2(TMW, WM, WN, 32); else ISTNET_FWD2(TMW, WM, WN, 16);                                     \
@@ -3152,7 +3247,16 @@ static int launch_pw_fwd2(int cfg, int b, int cin, int cout, int p, const float*
   }
 #undef ISTNET_FWD2_K
 #undef ISTNET_FWD2
+#undef ISTNET_FWD2P
   return (int)hipGetLastError();
+}
+
+// ---- last layer of a set-abstraction scale with the max-pool in the epilogue (pw_fwd2_kernel<..., POOL>) ----
+static bool fwd_pool_ok(int b, int cin, int cout, int p, int nsample) {
+  if (nsample != 16 && nsample != 32) return false;
+  if (cout < 64 || p % nsample) return false;
+  const int cfg = fwd2_cfg(b, cin, cout, p);
+  return cfg != 0 && cfg / 1000 == 2;
 }
 
 static int launch_pw_forward(bool gather, int b, int cin, int cout, int p, const float* x, const GatherSrc& g,
@@ -3207,6 +3311,20 @@ int istnet_pw_forward(int b, int cin, int cout, int p, const float* x, const flo
   if (cfg2) return launch_pw_fwd2(cfg2, b, cin, cout, p, x, w, in_scale, in_shift, y, part_sum, part_sq, stream);
   return launch_pw_forward(false, b, cin, cout, p, x, GatherSrc{}, w, cin, in_scale, in_shift, y, part_sum, part_sq,
                            stream);
+}
+
+int istnet_pw_forward_pool_ok(int b, int cin, int cout, int p, int nsample) {
+  return fwd_pool_ok(b, cin, cout, p, nsample) ? 1 : 0;
+}
+
+int istnet_pw_forward_pool(int b, int cin, int cout, int p, int nsample, const float* x, const float* w,
+                           const float* in_scale, const float* in_shift, const float* gamma, float* gval,
+                           unsigned char* arg, float* part_sum, float* part_sq, void* stream) {
+  if (b <= 0 || cin <= 0 || cout <= 0 || p <= 0 || (p & 3) || gamma == nullptr || gval == nullptr || arg == nullptr)
+    return ISTNET_PN2_EINVAL;
+  if (!fwd_pool_ok(b, cin, cout, p, nsample)) return ISTNET_PN2_EINVAL;
+  return launch_pw_fwd2(fwd2_cfg(b, cin, cout, p), b, cin, cout, p, x, w, in_scale, in_shift, nullptr, part_sum, part_sq,
+                        stream, nsample, gamma, gval, arg);
 }
 
 int istnet_pw_forward_tiles(int b, int cin, int cout, int p) {
@@ -3881,8 +3999,8 @@ int istnet_pw_wgrad_gather(int b, int n, int npoint, int nsample, int cfeat, int
                          d_dense, d_pooled, pooled_bstride, arg, bn, bwdc, dw_part, stream);
 }
 
-int istnet_pw_wgrad_reduce_multi(int n, const int* counts, const int* splits, const float* const* parts,
-                                 float* const* dws, void* stream) {
+static int reduce_multi_impl(int n, const int* counts, const int* splits, const float* const* parts, float* const* dws,
+                             const int* cols, const int* lds, const long long* pstrides, void* stream) {
   if (n <= 0 || n > 8) return ISTNET_PN2_EINVAL;
   ReduceBatch rb;
   rb.n = n;
@@ -3893,9 +4011,45 @@ int istnet_pw_wgrad_reduce_multi(int n, const int* counts, const int* splits, co
     rb.dw[l] = dws[l];
     rb.count[l] = counts[l];
     rb.splits[l] = splits[l];
+    rb.cols[l] = cols != nullptr ? cols[l] : counts[l];
+    rb.ld[l] = lds != nullptr ? lds[l] : counts[l];
+    rb.pstride[l] = pstrides != nullptr ? pstrides[l] : (long long)counts[l];
+    if (rb.cols[l] <= 0 || counts[l] % rb.cols[l] || rb.ld[l] < rb.cols[l] || rb.pstride[l] < counts[l]) return ISTNET_PN2_EINVAL;
     rb.block_begin[l + 1] = rb.block_begin[l] + ceil_div(counts[l], 16);
   }
   hipLaunchKernelGGL(wgrad_reduce_multi_kernel, dim3(rb.block_begin[n]), dim3(256), 0, as_stream(stream), rb);
+  return (int)hipGetLastError();
+}
+
+int istnet_pw_wgrad_reduce_multi(int n, const int* counts, const int* splits, const float* const* parts,
+                                 float* const* dws, void* stream) {
+  return reduce_multi_impl(n, counts, splits, parts, dws, nullptr, nullptr, nullptr, stream);
+}
+
+int istnet_pw_wgrad_reduce_multi_ld(int n, const int* counts, const int* splits, const float* const* parts,
+                                    float* const* dws, const int* cols, const int* lds, const long long* pstrides,
+                                    void* stream) {
+  if (cols == nullptr || lds == nullptr || pstrides == nullptr) return ISTNET_PN2_EINVAL;
+  return reduce_multi_impl(n, counts, splits, parts, dws, cols, lds, pstrides, stream);
+}
+
+int istnet_pack_words(int n, const void* const* srcs, const long long* words, void* dst, void* stream) {
+  if (n <= 0 || n > 64 || dst == nullptr) return ISTNET_PN2_EINVAL;
+  PackBatch pb;
+  pb.n = n;
+  pb.begin[0] = 0;
+  for (int l = 0; l < n; ++l) {
+    if (words[l] < 0 || (words[l] > 0 && srcs[l] == nullptr)) return ISTNET_PN2_EINVAL;
+    pb.src[l] = static_cast<const unsigned*>(srcs[l]);
+    pb.begin[l + 1] = pb.begin[l] + words[l];
+  }
+  for (int l = n; l < 64; ++l) { pb.src[l] = nullptr; pb.begin[l + 1] = pb.begin[n]; }
+  const long long total = pb.begin[n];
+  if (total == 0) return 0;
+  long long blocks = (total + 1023) / 1024;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(pack_words_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), pb,
+                     static_cast<unsigned*>(dst));
   return (int)hipGetLastError();
 }
 

@@ -201,7 +201,11 @@ class PointNet2MSG(nn.Module):
                            for _, _, csr in fresh.fp]
                 slot.shape = tuple(xyz.shape)
             for dt, flat in slot.flat.items():
-                torch.cat([t.reshape(-1) for t in src if t.dtype == dt], out=flat)
+                group = [t for t in src if t.dtype == dt]
+                if flat.element_size() == 4 and all(t.is_contiguous() for t in group):
+                    _native.pack_words(group, flat, side.cuda_stream)     # one launch per <= 64 tensors
+                else:
+                    torch.cat([t.reshape(-1) for t in group], out=flat)
             if not torch.cuda.is_current_stream_capturing():
                 slot.event = torch.cuda.Event()
                 slot.event.record(side)

@@ -33,6 +33,7 @@ else:
         return torch.empty(shape, dtype=dtype, device=device)
 
 
+STATS = {"pool_epilogue": 0}     # how often a stack took the activation-free last layer (tests assert the path they mean)
 FALLBACKS = {}     # reason -> number of times a CUDA input took the torch composition instead of the fused kernels
 
 
@@ -265,7 +266,6 @@ def _forward_stack(lib, dev, st, b, c0, g, s, x, gather, training, layers, param
             cur, cur_c, in_bn = start[0], cout, start[1]
             continue
         w2 = w.reshape(cout, cur_c)
-        y = _empty((b, cout, p), torch.float32, dev)
         bn = fixed[li] if li in fixed else _empty((4, cout), torch.float32, dev)
         if lay.bias_only:
             gamma = None                      # params[3*li+1] is a ones vector, beta is the conv bias
@@ -281,8 +281,41 @@ def _forward_stack(lib, dev, st, b, c0, g, s, x, gather, training, layers, param
         if cfg2 == 1:
             kname = "pw_fwd_sk_kernel"
         elif cfg2:
-            kname = f"pw_fwd2_kernel<{cfg2 // 1000}, {cfg2 // 100 % 10}, {cfg2 // 10 % 10}, {32 if cfg2 % 10 else 16}>"
+            kname = f"pw_fwd2_kernel<{cfg2 // 1000}, {cfg2 // 100 % 10}, {cfg2 // 10 % 10}, {32 if cfg2 % 10 else 16}, 0>"
         flops, nbytes = 2.0 * b * p * cur_c * cout, 4.0 * b * p * (cur_c + cout)
+        if (USE_POOL_EPILOGUE and li == len(layers) - 1 and li > 0 and s > 1 and plain and not lay.bias_only
+                and lay.relu and lib.istnet_pw_forward_pool_ok(b, cur_c, cout, p, s)
+                and lib.istnet_pw_bwd_last_ok(cur_c, cout, p, s)):
+            # LAST layer of a scale: the widest activation of the stack is never written -- the GEMM's epilogue keeps the
+            # raw extremum and its slot per (channel, ball) (csrc/pw_last.hip), one launch finishes the statistics and
+            # applies BatchNorm + ReLU to the (B, C, G) values; the backward pass runs from act(y_{L-1})
+            if out_spec is None:
+                out = _empty((b, cout, g), torch.float32, dev)
+                out_ptr, out_bstride = out.data_ptr(), 0
+            else:
+                out, coff = out_spec
+                out_ptr, out_bstride = out.data_ptr() + coff * g * 4, out.shape[1] * g
+            arg = _empty((_arg_bytes(b * cout * g) + 4 * b * cout * g,), torch.uint8, dev)
+            gval = _ymax_ptr(arg, b * cout * g)
+            STATS["pool_epilogue"] += 1
+            sc, sh = _p(in_bn[0]), _p(in_bn[1])
+            cin_l, src = cur_c, cur
+            kname = kname[:-2] + f"{s}>"
+            _native.check(_native.timed(kname, flops, 4.0 * b * (p * cur_c + 2 * g * cout), lambda: lib.istnet_pw_forward_pool(
+                b, cin_l, cout, p, s, src.data_ptr(), w2.data_ptr(), sc, sh, gamma.data_ptr(), gval, arg.data_ptr(), ps, pq,
+                st)), "pw_forward_pool")
+            if li not in fixed:
+                _native.check(lib.istnet_bn_finalize_pool_apply(
+                    b, cout, g, nt, float(b * p), ps, pq, gamma.data_ptr(), beta.data_ptr(), float(lay.eps),
+                    float(lay.momentum), _p(lay.running_mean), _p(lay.running_var), bn.data_ptr(), gval, out_ptr,
+                    out_bstride, st), "bn_finalize_pool_apply")
+            else:
+                _native.check(lib.istnet_pool_apply(b, cout, g, bn.data_ptr(), gval, out_ptr, out_bstride, st),
+                              "pool_apply")
+            ys.append(_empty((0,), torch.float32, dev))       # placeholder: this layer has no stored activation
+            bns.append(bn)
+            return out, arg, ys, bns
+        y = _empty((b, cout, p), torch.float32, dev)
         if li == 0 and gather is not None and USE_SPLIT_LAYER0:
             # layer 0 by linearity: Z = W0[:, 3:] . feat over the n source points (nsample*npoint/n times fewer MACs
             # than over the grouped points), then y0 = Z[:, idx] + W0[:, :3] . (xyz[idx] - centre); an xyz-only
@@ -537,6 +570,7 @@ def _compact_ok(lib, ga, layers, params, needs_backward, needs_feature_grad):
     return True
 
 
+USE_POOL_EPILOGUE = True     # last layer of a scale: max-pool in the GEMM epilogue, no stored activation (pw_last.hip)
 USE_FUSED_SMALL_BWD = True
 USE_POOLED_FINALIZE = True   # last layer of a scale: pooled statistics + BN-backward finalize in one launch
 USE_FINALIZE_IN_SCATTER = True  # layer 0 of an SA scale: BN-backward finalize inside the inverse-list scatter kernel
@@ -592,6 +626,7 @@ def _backward_stack(lib, dev, st, b, c0, g, s, x, gather, training, ys, bns, par
     wjobs = []                       # weight-gradient launches of the stack: (launch(stream) -> (n, splits, ws, dw))
     wlayers = []                     # layer index of each job
     wextra = []                      # further closures for the wgrad stream (layer0_hook)
+    wlast = []                       # (layer, job) of a last layer without activation: launches + its own reduce / finish
     for li in range(n - 1, -1, -1):
         w, gamma = params[3 * li], params[3 * li + 1]
         cout = w.shape[0]
@@ -603,6 +638,59 @@ def _backward_stack(lib, dev, st, b, c0, g, s, x, gather, training, ys, bns, par
         pbs = pooled_bstride if (pooled and li == n - 1) else 0
         grad_elems = b * cout * (p if dd is not None else p // s)
         part, dense_fin = None, False
+        if li == n - 1 and pooled and y.numel() == 0:
+            # the layer whose activation was never stored (pool in the forward epilogue): everything from act(y_{L-1})
+            dgamma = _grad_dest(gamma, (cout,), dev)
+            dbeta = _grad_dest(params[3 * li + 2], (cout,), dev)
+            bwdc = _empty((3, cout), torch.float32, dev)
+            gval = _ymax_ptr(d_arg, b * cout * g)
+            _native.check(lib.istnet_bn_bwd_pooled_finalize(
+                b, cout, g, float(b * p), 1 if training else 0, dp, pbs, gval, gamma.data_ptr(), bn.data_ptr(),
+                dgamma.data_ptr(), dbeta.data_ptr(), bwdc.data_ptr(), st), "bn_bwd_pooled_finalize")
+            grads[3 * li + 1], grads[3 * li + 2] = dgamma, dbeta
+            e_nat = _empty((b, cout, g), torch.float32, dev)
+            e_t = _empty((b, g, cout), torch.float32, dev)
+            slot_t = _empty((b, g, cout), torch.uint8, dev)
+            mmat = _empty((cin, cin), torch.float32, dev)
+            c0v = _empty((cin,), torch.float32, dev)
+            _native.check(lib.istnet_pw_last_prep(b, cin, cout, p, s, w2.data_ptr(), bn.data_ptr(), bwdc.data_ptr(), dp, pbs,
+                                                  gval, da, e_nat.data_ptr(), e_t.data_ptr(), slot_t.data_ptr(),
+                                                  mmat.data_ptr(), c0v.data_ptr(), st), "pw_last_prep")
+            splits = lib.istnet_pw_bwd_last_splits(b, cin, cout, p, s)
+            dprev = _empty((b, cin, p), torch.float32, dev)
+            fused_part, fused_nt = _empty((2, cin, splits), torch.float32, dev), splits
+            x_prev, bn_prev = ys[li - 1], bns[li - 1]
+            _native.check(_native.timed(
+                f"pw_bwd_last_kernel<{cin // 32}, {s}>", 2.0 * b * p * cin * cin, 8.0 * b * p * cin,
+                lambda: lib.istnet_pw_bwd_last(b, cin, cout, p, s, w2.data_ptr(), x_prev.data_ptr(), bn_prev.data_ptr(),
+                                               mmat.data_ptr(), c0v.data_ptr(), e_t.data_ptr(), slot_t.data_ptr(),
+                                               dprev.data_ptr(), fused_part[0].data_ptr(), fused_part[1].data_ptr(), st)),
+                "pw_bwd_last")
+            if need_w[li]:
+                def last_job(wst, cin=cin, cout=cout, w=w, w2=w2, x_prev=x_prev, bn_prev=bn_prev, e_nat=e_nat, d_arg=d_arg,
+                             bwdc=bwdc, splits=splits):
+                    nparts = lib.istnet_pw_dw_last_parts(b, cin, cout, p, s)
+                    gram_part = _empty((splits, cin, cin), torch.float32, dev)
+                    sa_part = _empty((splits, cin), torch.float32, dev)
+                    dws_part = _empty((nparts, cout, cin), torch.float32, dev)
+                    _native.check(_native.timed(
+                        f"pw_dw_last_kernel<{cin // 32}, {s}>", 2.0 * b * p * cin * cin, 4.0 * b * p * cin,
+                        lambda: lib.istnet_pw_dw_last(b, cin, cout, p, s, x_prev.data_ptr(), bn_prev.data_ptr(),
+                                                      e_nat.data_ptr(), d_arg.data_ptr(), gram_part.data_ptr(),
+                                                      sa_part.data_ptr(), dws_part.data_ptr(), wst)), "pw_dw_last")
+                    gram = _empty((cin, cin), torch.float32, dev)
+                    sa = _empty((cin,), torch.float32, dev)
+                    dw = _grad_dest(w, (cout, cin), dev)
+                    _native.reduce_multi([(cin * cin, splits, gram_part.data_ptr(), gram.data_ptr()),
+                                          (cin, splits, sa_part.data_ptr(), sa.data_ptr()),
+                                          (cout * cin, nparts, dws_part.data_ptr(), dw.data_ptr())], wst)
+                    _native.check(lib.istnet_pw_dw_last_finish(cin, cout, w2.data_ptr(), bwdc.data_ptr(), gram.data_ptr(),
+                                                               sa.data_ptr(), dw.data_ptr(), dw.data_ptr(), wst),
+                                  "pw_dw_last_finish")
+                    return (gram_part, sa_part, dws_part, gram, sa, e_nat, d_arg, bwdc, x_prev, bn_prev), dw
+                wlast.append((li, last_job))
+            d_dense, d_pooled, d_arg = dprev, None, None
+            continue
         if fused_part is not None:
             part, nt_l = fused_part, fused_nt
         elif ns_arg and USE_POOLED_FINALIZE and not (li == 0 and layer0_hook is not None):
@@ -752,8 +840,9 @@ def _backward_stack(lib, dev, st, b, c0, g, s, x, gather, training, ys, bns, par
             d_dense, d_pooled, d_arg = dprev, None, None
             if li == 0:
                 dx = dprev
-    if wjobs or wextra:
-        wparams = [params[3 * li] for li in wlayers] + ([params[0]] if wextra else [])
+    if wjobs or wextra or wlast:
+        wparams = ([params[3 * li] for li in wlayers] + ([params[0]] if wextra else [])
+                   + [params[3 * li] for li, _ in wlast])
         if _can_defer(wparams):
             # after the chain, on the wgrad stream; joined by the end-of-backward callback
             cur = torch.cuda.current_stream(dev)
@@ -761,20 +850,24 @@ def _backward_stack(lib, dev, st, b, c0, g, s, x, gather, training, ys, bns, par
             _Deferred.mains.setdefault(key, cur)
             wstream.wait_stream(cur)
             with torch.cuda.stream(wstream):
+                last_done = [(li, job(wstream.cuda_stream)) for li, job in wlast]
                 done = [job(wstream.cuda_stream) for job in wjobs]
                 if done:
                     _native.reduce_multi([(cnt, splits, ws.data_ptr(), dw.data_ptr()) for cnt, splits, ws, dw in done],
                                          wstream.cuda_stream)
                 extra_keep = [fn(wstream.cuda_stream) for fn in wextra]
-            _Deferred.keep += [wjobs, done, wextra, extra_keep]
+            _Deferred.keep += [wjobs, done, wextra, extra_keep, wlast, last_done]
             _Deferred.arm()
         else:
+            last_done = [(li, job(st)) for li, job in wlast]
             done = [job(st) for job in wjobs]
             if done:
                 _native.reduce_multi([(cnt, splits, ws.data_ptr(), dw.data_ptr()) for cnt, splits, ws, dw in done], st)
             for fn in wextra:
                 fn(st)
         for li, (_, _, _, dw) in zip(wlayers, done):
+            grads[3 * li] = dw.view_as(params[3 * li])
+        for li, (_, dw) in last_done:
             grads[3 * li] = dw.view_as(params[3 * li])
     return grads, dx, scattered
 
@@ -1018,6 +1111,14 @@ class FusedSALevelFunction(Function):
         feat_t = (feat.transpose(1, 2).contiguous()
                   if (feat is not None and feat.shape[1] % 16 == 0 and not USE_SPLIT_LAYER0) else None)
         with torch.cuda.device(dev):
+            # the layer-0 weights of the scales stacked for the level-wide feature-gradient product of backward: packed
+            # here (one small launch, before the scales fork) so the backward chain does not start with a concatenation
+            wcat = None
+            if feat is not None and nsc > 1 and ctx.needs_input_grad[0] and xyz.shape[1] <= 4096 and xyz.shape[1] % 4 == 0:
+                w0s = [pl[0] for pl in plist]
+                if all(w.is_contiguous() for w in w0s):
+                    wcat = _empty((sum(w.shape[0] for w in w0s), 3 + feat.shape[1]), torch.float32, dev)
+                    _native.pack_words(w0s, wcat, _st(dev))
             streams = _scale_streams(dev, len(scales))
             compacts = list(compacts) if compacts is not None else [None] * nsc
             used = []
@@ -1046,8 +1147,10 @@ class FusedSALevelFunction(Function):
         ctx.compacts = used
         ctx.dims = (b, g, ctot)
         ctx.has_feat_t = feat_t is not None
+        ctx.has_wcat = wcat is not None
         ctx.save_for_backward(feat if feat is not None else torch.empty(0, device=dev), xyz, new_xyz,
-                              feat_t if feat_t is not None else torch.empty(0, device=dev), *idxs, *saved,
+                              feat_t if feat_t is not None else torch.empty(0, device=dev),
+                              wcat if wcat is not None else torch.empty(0, device=dev), *idxs, *saved,
                               *tensors[nsc:])
         return out
 
@@ -1061,12 +1164,13 @@ class FusedSALevelFunction(Function):
         sv = ctx.saved_tensors
         feat, xyz, new_xyz = sv[0], sv[1], sv[2]
         feat_t = sv[3] if ctx.has_feat_t else None
-        idxs = sv[4:4 + nsc]
+        wcat_saved = sv[4] if ctx.has_wcat else None
+        idxs = sv[5:5 + nsc]
         dev = xyz.device
         _enter_backward(dev)
         _native.mark(f"bwd SA(g={g}) start")
         dout = dout.contiguous()
-        pos = 4 + nsc
+        pos = 5 + nsc
         per_scale = []
         for (nl, s, coff, clast) in meta:
             arg = sv[pos]
@@ -1107,7 +1211,7 @@ class FusedSALevelFunction(Function):
             _join_streams(streams)
             if use_level_gemm:
                 # dfeat[b] = [W0f_0^T | W0f_1^T ...] . [G_0; G_1; ...]: the dgrad kernel with identity "BN" constants
-                wcat = torch.cat(w0f, dim=0) if nsc > 1 else w0f[0]           # (sum Cout0, 3 + C)
+                wcat = wcat_saved if wcat_saved is not None else (torch.cat(w0f, dim=0) if nsc > 1 else w0f[0])   # (sum Cout0, 3 + C)
                 ident, bwdc = _ident_consts(dev, cout0_tot)                   # mask always on, dY = g
                 dfeat = _empty((b, cfeat, n_src), torch.float32, dev)
                 _native.check(_native.timed(
@@ -1144,16 +1248,21 @@ def _finish_layer0_grads(lib, dev, b, cfeat, cout0_tot, n_src, feat, gbuf, ident
     def work(wst):
         splits = lib.istnet_pw_wgrad_splits(b, cfeat, cout0_tot, n_src)
         ws = _empty((splits, cout0_tot, cfeat), torch.float32, dev)
-        dwf = _empty((cout0_tot, cfeat), torch.float32, dev)
         _native.check(_native.timed(
             _kname("pw_wgrad_kernel", lib.istnet_pw_wgrad_tile_cfg(b, cfeat, cout0_tot, n_src), 0),
             2.0 * b * n_src * cfeat * cout0_tot, 4.0 * b * n_src * (cfeat + cout0_tot), lambda: lib.istnet_pw_wgrad(
                 b, cfeat, cout0_tot, n_src, 0, feat.data_ptr(), None, None, gbuf.data_ptr(), gbuf.data_ptr(), None, 0,
                 None, ident.data_ptr(), bwdc.data_ptr(), ws.data_ptr(), wst)), "pw_wgrad(level G)")
-        _native.reduce_multi([(cout0_tot * cfeat, splits, ws.data_ptr(), dwf.data_ptr())], wst)
+        # one reduce launch writes both column blocks of every scale's dW0 in place: columns 0..2 = sum over the clouds
+        # of the xyz partials, columns 3.. = this scale's rows of the level-wide split-K partials
+        items, ld = [], 3 + cfeat
         for (gi, row0, p), dwx, dest in zip(w0_slots, placeholders, dests):
-            torch.cat([dwx.sum(dim=0), dwf[row0:row0 + p.shape[0]]], dim=1, out=dest)
-        return ws, dwf
+            ci = p.shape[0]
+            items.append((ci * 3, b, dwx.data_ptr(), dest.data_ptr(), 3, ld, ci * 3))
+            items.append((ci * cfeat, splits, ws.data_ptr() + 4 * row0 * cfeat, dest.data_ptr() + 12, cfeat, ld,
+                          cout0_tot * cfeat))
+        _native.reduce_multi(items, wst)
+        return ws
 
     if _can_defer(params):
         cur = torch.cuda.current_stream(dev)
@@ -1316,30 +1425,24 @@ class FusedFPFunction(Function):
                 def wjob(wst):
                     sp_a = lib.istnet_pw_wgrad_splits(b, c2, cout0, m)
                     ws_a = _empty((sp_a, cout0, c2), torch.float32, dev)
-                    dwa = _empty((cout0, c2), torch.float32, dev)
                     _native.check(_native.timed(
                         _kname("pw_wgrad_kernel", lib.istnet_pw_wgrad_tile_cfg(b, c2, cout0, m), 0),
                         2.0 * b * m * c2 * cout0, 4.0 * b * m * (c2 + cout0), lambda: lib.istnet_pw_wgrad(
                             b, c2, cout0, m, 0, known.data_ptr(), None, None, gk.data_ptr(), gk.data_ptr(), None, 0,
                             None, ident.data_ptr(), ibw.data_ptr(), ws_a.data_ptr(), wst)), "pw_wgrad(fp known)")
-                    red = [(cout0 * c2, sp_a, ws_a.data_ptr(), dwa.data_ptr())]
-                    keep = [ws_a, dwa]
+                    red = [(cout0 * c2, sp_a, ws_a.data_ptr(), dest.data_ptr(), c2, cin, cout0 * c2)]
+                    keep = [ws_a]
                     if skip is not None:
                         sp_b = lib.istnet_pw_wgrad_splits(b, c1, cout0, n)
                         ws_b = _empty((sp_b, cout0, c1), torch.float32, dev)
-                        dwb = _empty((cout0, c1), torch.float32, dev)
                         _native.check(_native.timed(
                             _kname("pw_wgrad_kernel", lib.istnet_pw_wgrad_tile_cfg(b, c1, cout0, n), 0),
                             2.0 * b * n * c1 * cout0, 4.0 * b * n * (c1 + cout0), lambda: lib.istnet_pw_wgrad(
                                 b, c1, cout0, n, 0, skip.data_ptr(), None, None, dy0.data_ptr(), dy0.data_ptr(), None,
                                 0, None, ident.data_ptr(), ibw.data_ptr(), ws_b.data_ptr(), wst)), "pw_wgrad(fp skip)")
-                        red.append((cout0 * c1, sp_b, ws_b.data_ptr(), dwb.data_ptr()))
-                        keep += [ws_b, dwb]
-                    _native.reduce_multi(red, wst)
-                    if skip is not None:
-                        torch.cat([dwa, dwb], dim=1, out=dest)
-                    else:
-                        dest.copy_(dwa)
+                        red.append((cout0 * c1, sp_b, ws_b.data_ptr(), dest.data_ptr() + 4 * c2, c1, cin, cout0 * c1))
+                        keep += [ws_b]
+                    _native.reduce_multi(red, wst)     # both column blocks of dW0 in place: no concatenation
                     return keep, dy0, gk
                 wextra.append(wjob)
             _join_streams(streams)
@@ -1527,23 +1630,23 @@ class FusedMultiSourceBiasMLPFunction(Function):
                 grads[0] = dest.view_as(w0)
 
                 def wjob(wst):
-                    parts, red, keep = [], [], []
+                    red, keep, coff = [], [], 0
                     for src, c in zip(srcs, chans):
                         sp = lib.istnet_pw_wgrad_splits(b, c, cout0, npts)
                         ws = _empty((sp, cout0, c), torch.float32, dev)
-                        dwa = _empty((cout0, c), torch.float32, dev)
                         _native.check(_native.timed(
                             _kname("pw_wgrad_kernel", lib.istnet_pw_wgrad_tile_cfg(b, c, cout0, npts), 0),
                             2.0 * b * npts * c * cout0, 4.0 * b * npts * (c + 2 * cout0), lambda: lib.istnet_pw_wgrad(
                                 b, c, cout0, npts, 0, src.data_ptr(), None, None, y0.data_ptr(), d_a0.data_ptr(), None, 0,
                                 None, bn0.data_ptr(), bwdc0.data_ptr(), ws.data_ptr(), wst)), "pw_wgrad(head source)")
-                        red.append((cout0 * c, sp, ws.data_ptr(), dwa.data_ptr()))
-                        parts.append(dwa)
-                        keep += [ws, dwa]
-                    _native.reduce_multi(red, wst)
+                        red.append((cout0 * c, sp, ws.data_ptr(), dest.data_ptr() + 4 * coff, c, cin_total, cout0 * c))
+                        keep.append(ws)
+                        coff += c
+                    _native.reduce_multi(red, wst)     # every source's column block of dW0 in place
+                    parts = []
                     if with_mean:
                         parts.append(torch.matmul(s_cb, mean))               # dWb = sum_b (sum_p dY0[b]) (x) mean_b
-                    torch.cat(parts, dim=1, out=dest)
+                        dest[:, csum:].copy_(parts[0])
                     return keep, parts, y0, d_a0, s_cb
                 wextra.append(wjob)
             return None
