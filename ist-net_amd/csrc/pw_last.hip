@@ -148,7 +148,7 @@ __global__ __launch_bounds__(256) void pw_last_prep_kernel(
     float* __restrict__ eT, uint8_t* __restrict__ slotT, float* __restrict__ M, float* __restrict__ c0) {
   __shared__ float tile[64][65];
   __shared__ uint8_t stile[64][68];
-  __shared__ float wa[256][17], wb[256][17];     // role B: W[:, 16 ci] and W[:, 16 k] of up to 256 channels
+  __shared__ float wa[256][9], wb[256][9];       // role B: W[:, 8 ci] and W[:, 8 k] of up to 256 channels
   const int tid = threadIdx.x;
   if ((int)blockIdx.x < nA) {
     const int gt = (G + 63) / 64, ct = COUT / 64;
@@ -187,25 +187,37 @@ __global__ __launch_bounds__(256) void pw_last_prep_kernel(
     }
     return;
   }
-  // ---- role B: a 16 x 16 tile of M (and 16 entries of c0 when the k tile is the first) ----
-  const int nk = CIN / 16;
+  // ---- role B: an 8 x 8 tile of M (and 8 entries of c0 when the k tile is the first); the four waves of the workgroup
+  // take quarters of the output channels and meet in LDS ----
+  const int nk = CIN / 8;
   const int t = blockIdx.x - nA;
   const int ti = t / nk, tk = t % nk;
-  for (int el = tid; el < COUT * 16; el += 256) {
-    const int c = el >> 4, j = el & 15;
-    wa[c][j] = w[(size_t)c * CIN + ti * 16 + j];
-    wb[c][j] = w[(size_t)c * CIN + tk * 16 + j];
+  float (*wa8)[9] = reinterpret_cast<float (*)[9]>(&wa[0][0]);     // [COUT][8 + 1]
+  float (*wb8)[9] = reinterpret_cast<float (*)[9]>(&wb[0][0]);
+  for (int el = tid; el < COUT * 8; el += 256) {
+    const int c = el >> 3, j = el & 7;
+    wa8[c][j] = w[(size_t)c * CIN + ti * 8 + j];
+    wb8[c][j] = w[(size_t)c * CIN + tk * 8 + j];
   }
   __syncthreads();
-  const int i = tid >> 4, k = tid & 15;
-  double acc = 0.0;
-  for (int c = 0; c < COUT; ++c) acc += (double)bwdc[2 * COUT + c] * (double)wa[c][i] * (double)wb[c][k];
-  M[(size_t)(ti * 16 + i) * CIN + tk * 16 + k] = (float)acc;
-  if (tk == 0 && tid < 16) {
-    double a0 = 0.0;
-    for (int c = 0; c < COUT; ++c) a0 += (double)bwdc[COUT + c] * (double)wa[c][tid];
-    c0[ti * 16 + tid] = (float)a0;
+  const int part = tid >> 6, i = (tid >> 3) & 7, k = tid & 7;
+  const int cq = COUT / 4;
+  double acc = 0.0, a0 = 0.0;
+  for (int c = part * cq; c < (part + 1) * cq; ++c) {
+    const double wi = (double)wa8[c][i];
+    acc += (double)bwdc[2 * COUT + c] * wi * (double)wb8[c][k];
+    if (k == 0) a0 += (double)bwdc[COUT + c] * wi;
   }
+  double* dred = reinterpret_cast<double*>(&tile[0][0]);            // [4][64] M partials, [4][8] c0 partials
+  dred[part * 64 + (tid & 63)] = acc;
+  if (k == 0) dred[256 + part * 8 + i] = a0;
+  __syncthreads();
+  if (tid < 64) {
+    const double v = (dred[tid] + dred[64 + tid]) + (dred[128 + tid] + dred[192 + tid]);
+    M[(size_t)(ti * 8 + (tid >> 3)) * CIN + tk * 8 + (tid & 7)] = (float)v;
+  }
+  if (tk == 0 && tid < 8)
+    c0[ti * 8 + tid] = (float)((dred[256 + tid] + dred[264 + tid]) + (dred[272 + tid] + dred[280 + tid]));
 }
 
 // ============================================================================================
@@ -238,6 +250,12 @@ struct LastCfg {
   static_assert(NX == 4 && NG >= 1 && ITEMS % 4 == 0 && (NCS == 1 || NCS == 2), "unsupported shape");
 };
 
+// acc[slot] += e * w with the slot a wave-uniform REGISTER index (s_set_gpr_idx): the compiler's form toggles the
+// VGPR-index mode four times per entry.  MEASURED (profiles/r03_last_layer_activation_free.txt): ~150 cycles per entry,
+// which makes the loader waves 3-5x slower than the MFMA waves and the kernel slower than the stored-activation backward
+// it was meant to replace; a hand-written block that keeps the mode on and swaps the index with s_set_gpr_idx_idx (one
+// indexed v_fma_f32 per entry, accumulators pinned to v[64:95]) was slower still.  VGPR indexing is not a fast path on
+// gfx950; a per-ball list sorted by slot (plain FMAs, one LDS store per slot) is the untried alternative.
 template <int S> struct SlotAcc;
 template <> struct SlotAcc<16> { typedef f32x16 type; };
 template <> struct SlotAcc<32> { typedef f32x32 type; };
@@ -310,36 +328,47 @@ __global__ __launch_bounds__(kLastThreads) void pw_bwd_last_kernel(
         const int nch = COUT / NCS, c_lo = cs * nch;
         const size_t lo = ((size_t)b * G + g0 + gidx) * COUT + c_lo;      // wave-uniform
         const float* er = eT + lo;
-        const uint8_t* sr = slotT + lo;
+        const unsigned* sr = reinterpret_cast<const unsigned*>(slotT + lo);
         const float* wr = w + (size_t)c_lo * CIN + (act ? ci : 0);
+        // the item's (e, slot) lists as vector registers -- lane l holds e[64 q + l] and the slot word l (four slots) --
+        // read back with v_readlane: no scalar-memory wait inside the loop
+        float evq[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) evq[q] = (64 * q + lane < nch) ? er[64 * q + lane] : 0.f;
+        const unsigned sw = (4 * lane < nch) ? sr[lane] : 0u;
         acc_t acc;
 #pragma unroll
         for (int s = 0; s < S; ++s) acc[s] = 0.f;
-        float wn[8];
+        float wn[16];                                  // W rows of the NEXT 16 channels (L2 latency >> 16 entries' work)
 #pragma unroll
-        for (int j = 0; j < 8; ++j) wn[j] = wr[(size_t)j * CIN];
-        for (int c = 0; c < nch; c += 8) {
-          float wc[8];
+        for (int j = 0; j < 16; ++j) wn[j] = wr[(size_t)j * CIN];
 #pragma unroll
-          for (int j = 0; j < 8; ++j) wc[j] = wn[j];
-          if (c + 8 < nch) {
+        for (int q = 0; q < 4; ++q) {
+          if (64 * q < nch) {
+            for (int cc = 0; cc < 64; cc += 16) {
+              const int c = 64 * q + cc;
+              float wc[16];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) wn[j] = wr[(size_t)(c + 8 + j) * CIN];
-          }
-          const float4 e0 = *reinterpret_cast<const float4*>(er + c), e1 = *reinterpret_cast<const float4*>(er + c + 4);
-          const uint2 sl = *reinterpret_cast<const uint2*>(sr + c);
-          const float ev[8] = {e0.x, e0.y, e0.z, e0.w, e1.x, e1.y, e1.z, e1.w};
+              for (int j = 0; j < 16; ++j) wc[j] = wn[j];
+              if (c + 16 < nch) {
 #pragma unroll
-          for (int j = 0; j < 8; ++j) {
-            const unsigned word = j < 4 ? sl.x : sl.y;
-            const int s = __builtin_amdgcn_readfirstlane((int)((word >> (8 * (j & 3))) & 0xffu));
-            acc[s] = __builtin_fmaf(ev[j], wc[j], acc[s]);
+                for (int j = 0; j < 16; ++j) wn[j] = wr[(size_t)(c + 16 + j) * CIN];
+              }
+#pragma unroll
+              for (int j = 0; j < 16; ++j) {
+                const int ebits = __builtin_amdgcn_readlane(__float_as_int(evq[q]), cc + j);
+                const unsigned word = (unsigned)__builtin_amdgcn_readlane((int)sw, 16 * q + (cc >> 2) + (j >> 2));
+                const int sl = (int)((word >> (8 * (j & 3))) & 0xffu);
+                acc[sl] = __builtin_fmaf(__int_as_float(ebits), wc[j], acc[sl]);
+              }
+            }
           }
         }
         if (act) {
           float* Ss = buf + (2 + cs) * CIN * LD + ci * LD + gidx * S;
 #pragma unroll
-          for (int s = 0; s < S; ++s) Ss[s] = acc[s];
+          for (int s = 0; s < S; s += 4)
+            *reinterpret_cast<float4*>(Ss + s) = make_float4(acc[s], acc[s + 1], acc[s + 2], acc[s + 3]);
         }
       }
     };
@@ -622,8 +651,15 @@ __global__ __launch_bounds__(64) void pw_dw_last_finish_kernel(int COUT, int CIN
   if (ci >= CIN) return;
   const double cb = bwdc[COUT + c], cc = bwdc[2 * COUT + c];
   const float* wr = w + (size_t)c * CIN;
-  double acc = 0.0;
-  for (int k = 0; k < CIN; ++k) acc += (double)wr[k] * (double)gram[(size_t)k * CIN + ci];
+  double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;      // CIN % 32 == 0: four independent chains keep the loads in flight
+#pragma unroll 2
+  for (int k = 0; k < CIN; k += 4) {
+    a0 += (double)wr[k + 0] * (double)gram[(size_t)(k + 0) * CIN + ci];
+    a1 += (double)wr[k + 1] * (double)gram[(size_t)(k + 1) * CIN + ci];
+    a2 += (double)wr[k + 2] * (double)gram[(size_t)(k + 2) * CIN + ci];
+    a3 += (double)wr[k + 3] * (double)gram[(size_t)(k + 3) * CIN + ci];
+  }
+  const double acc = (a0 + a1) + (a2 + a3);
   dw[(size_t)c * CIN + ci] = (float)((double)dws[(size_t)c * CIN + ci] + cb * (double)sa[ci] + cc * acc);
 }
 
@@ -693,7 +729,7 @@ int istnet_pw_last_prep(int b, int cin, int cout, int p, int nsample, const floa
   if (!w || !bn || !bwdc || !d_pooled || !gval || !arg || !e_nat || !e_t || !slot_t || !m || !c0) return ISTNET_PN2_EINVAL;
   const int G = p / nsample;
   const int nA = b * ceil_div(G, 64) * (cout / 64);
-  const int nB = (cin / 16) * (cin / 16);
+  const int nB = (cin / 8) * (cin / 8);
   hipLaunchKernelGGL(pw_last_prep_kernel, dim3(nA + nB), dim3(256), 0, as_stream(stream), b, cout, cin, G, nA, w, bn, bwdc,
                      d_pooled, pooled_bstride > 0 ? pooled_bstride : (long long)cout * G, gval, arg, e_nat, e_t, slot_t, m,
                      c0);

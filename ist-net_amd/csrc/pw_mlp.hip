@@ -444,29 +444,31 @@ __global__ __launch_bounds__(kThreads) void pw_fwd_kernel(
 // consecutive points of a row -- S / 4 adjacent lanes x the 4 accumulators -- to (y*, slot of y*) with DPP quad / row
 // permutes and stores (B, C, G) values (`gval`, `arg`); the widest activation of the stack (34-67 MB per scale) never
 // exists, the max-pool pass does not read it back, and the backward pass runs from act(y_{L-1}) (pw_bwd_last_kernel).
-template <int CTRL>
-__device__ __forceinline__ float dpp_perm_f(float v) {
-  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
-}
-template <int CTRL>
-__device__ __forceinline__ int dpp_perm_i(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, false); }
+// max / min with the permuted operand as a DPP source: ONE instruction per butterfly step (the builtin form leaves a
+// v_mov_dpp, a canonicalising v_max x,x and the max itself).  s_nop 1: a DPP read of a VGPR written by the previous
+// VALU instruction needs two wait states, and the hazard recogniser does not look inside inline assembly.
+#define ISTNET_DPP_STEP(OP, TY, CTRL_STR)                                                                       \
+  asm volatile("s_nop 1\n\t" OP " %0, %1, %1 " CTRL_STR " row_mask:0xf bank_mask:0xf bound_ctrl:1" : "=v"(r) : "v"(m))
 // all-reduce over S / 4 adjacent lanes: quad_perm [1,0,3,2], quad_perm [2,3,0,1], row_half_mirror, row_mirror
 template <int S>
 __device__ __forceinline__ float group_max_f(float m) {
-  m = fmaxf(m, dpp_perm_f<0xB1>(m));
-  m = fmaxf(m, dpp_perm_f<0x4E>(m));
-  if (S >= 32) m = fmaxf(m, dpp_perm_f<0x141>(m));
-  if (S >= 64) m = fmaxf(m, dpp_perm_f<0x140>(m));
+  float r;
+  ISTNET_DPP_STEP("v_max_f32_dpp", float, "quad_perm:[1,0,3,2]"); m = r;
+  ISTNET_DPP_STEP("v_max_f32_dpp", float, "quad_perm:[2,3,0,1]"); m = r;
+  if (S >= 32) { ISTNET_DPP_STEP("v_max_f32_dpp", float, "row_half_mirror"); m = r; }
+  if (S >= 64) { ISTNET_DPP_STEP("v_max_f32_dpp", float, "row_mirror"); m = r; }
   return m;
 }
 template <int S>
 __device__ __forceinline__ int group_min_i(int m) {
-  m = min(m, dpp_perm_i<0xB1>(m));
-  m = min(m, dpp_perm_i<0x4E>(m));
-  if (S >= 32) m = min(m, dpp_perm_i<0x141>(m));
-  if (S >= 64) m = min(m, dpp_perm_i<0x140>(m));
+  int r;
+  ISTNET_DPP_STEP("v_min_i32_dpp", int, "quad_perm:[1,0,3,2]"); m = r;
+  ISTNET_DPP_STEP("v_min_i32_dpp", int, "quad_perm:[2,3,0,1]"); m = r;
+  if (S >= 32) { ISTNET_DPP_STEP("v_min_i32_dpp", int, "row_half_mirror"); m = r; }
+  if (S >= 64) { ISTNET_DPP_STEP("v_min_i32_dpp", int, "row_mirror"); m = r; }
   return m;
 }
+#undef ISTNET_DPP_STEP
 
 template <int TMW, int WM, int WN, int KC, int POOL = 0>
 __global__ __launch_bounds__(kThreads, 2) void pw_fwd2_kernel(
@@ -580,9 +582,12 @@ __global__ __launch_bounds__(kThreads, 2) void pw_fwd2_kernel(
         const float k2 = __uint_as_float(__float_as_uint(v.z) ^ sb), k3 = __uint_as_float(__float_as_uint(v.w) ^ sb);
         const float m = group_max_f<POOL>(fmaxf(fmaxf(k0, k1), fmaxf(k2, k3)));
         const int lg = l31 & (POOL / 4 - 1);                 // lane within the group
-        int cand = k0 == m ? 0 : (k1 == m ? 1 : (k2 == m ? 2 : (k3 == m ? 3 : 255)));
-        cand = cand < 4 ? 4 * lg + cand : 255;               // slot of the FIRST extremum this lane holds
-        cand = group_min_i<POOL>(cand);
+        int cand = 0x10000;                                  // slot of the FIRST extremum this lane holds (selects, no branches)
+        cand = k3 == m ? 3 : cand;
+        cand = k2 == m ? 2 : cand;
+        cand = k1 == m ? 1 : cand;
+        cand = k0 == m ? 0 : cand;
+        cand = group_min_i<POOL>(cand + 4 * lg);             // some lane of the group holds the extremum: the minimum is a slot
         if (live && row < cout && lg == 0) {
           const int G = P / POOL;
           const size_t o = ((size_t)b * cout + row) * G + (p0 + 4 * l31) / POOL;

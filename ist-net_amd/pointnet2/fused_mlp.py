@@ -570,7 +570,12 @@ def _compact_ok(lib, ga, layers, params, needs_backward, needs_feature_grad):
     return True
 
 
-USE_POOL_EPILOGUE = True     # last layer of a scale: max-pool in the GEMM epilogue, no stored activation (pw_last.hip)
+# Last layer of a scale WITHOUT its stored activation (csrc/pw_last.hip: max-pool in the GEMM epilogue, backward from
+# act(y_{L-1}) as M a + c0 + S).  Parity-green (tests/test_pw_last_gpu.py) and 1.0 GB per step lighter on HBM, but SLOWER:
+# 2.99-3.07 ms/step against 2.82 (profiles/r03_last_layer_activation_free.txt) -- the kernels it replaces run at 1.3-2.5
+# TB/s, i.e. they are instruction- / latency-bound, not HBM-bound, and the per-ball sparse term costs more issue slots than
+# the bytes were worth.  Off by default; ISTNET_POOL_EPILOGUE=1 (or assigning this attribute) turns it on.
+USE_POOL_EPILOGUE = os.environ.get("ISTNET_POOL_EPILOGUE", "0") == "1"
 USE_FUSED_SMALL_BWD = True
 USE_POOLED_FINALIZE = True   # last layer of a scale: pooled statistics + BN-backward finalize in one launch
 USE_FINALIZE_IN_SCATTER = True  # layer 0 of an SA scale: BN-backward finalize inside the inverse-list scatter kernel
