@@ -42,13 +42,35 @@ template <int CTRL, int ROW_MASK = 0xf>
 __device__ __forceinline__ float dpp_f(float v) {
   return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xf, false));
 }
+// Each step is ONE v_add_f32 with the shifted value as its DPP operand (bound_ctrl: a lane without a source adds 0).  The
+// builtin form compiles to v_mov 0 / v_mov_dpp / v_add per step -- 15 instructions per sum, two sums per accumulator row
+// in every GEMM epilogue.  Same additions in the same order: bit-identical.  s_nop: a DPP read of a VGPR the previous
+// VALU instruction wrote needs two wait states, and the hazard recogniser does not look inside inline assembly.
 __device__ __forceinline__ float half_wave_sum(float v) {
-  v += dpp_f<0x111>(v);         // row_shr:1
-  v += dpp_f<0x112>(v);         // row_shr:2
-  v += dpp_f<0x114>(v);         // row_shr:4
-  v += dpp_f<0x118>(v);         // row_shr:8
-  v += dpp_f<0x142, 0xa>(v);    // row_bcast:15 -> lanes 31 / 63 hold the 32-lane sums
+  asm volatile(
+      "s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf"   // lanes 31 / 63 hold the 32-lane sums
+      : "+v"(v));
   return v;
+}
+// two sums at once: the steps of one fill the wait states of the other
+__device__ __forceinline__ void half_wave_sum2(float& a, float& b) {
+  asm volatile(
+      "s_nop 1\n\t"
+      "v_add_f32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "v_add_f32_dpp %1, %1, %1 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\ts_nop 0\n\t"
+      "v_add_f32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "v_add_f32_dpp %1, %1, %1 row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\ts_nop 0\n\t"
+      "v_add_f32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "v_add_f32_dpp %1, %1, %1 row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\ts_nop 0\n\t"
+      "v_add_f32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "v_add_f32_dpp %1, %1, %1 row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\ts_nop 0\n\t"
+      "v_add_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+      "v_add_f32_dpp %1, %1, %1 row_bcast:15 row_mask:0xa bank_mask:0xf"
+      : "+v"(a), "+v"(b));
 }
 __device__ __forceinline__ float wave_sum(float v) {
   v = half_wave_sum(v);
@@ -400,8 +422,7 @@ __global__ __launch_bounds__(kThreads) void pw_fwd_kernel(
         }
       }
       if (part_sum != nullptr) {
-        s = half_wave_sum(s);
-        q = half_wave_sum(q);
+        half_wave_sum2(s, q);
         if ((lane & 31) == 31) {
           red[((wv % WN) * M_T + row_l) * 2 + 0] = s;
           red[((wv % WN) * M_T + row_l) * 2 + 1] = q;
@@ -601,8 +622,7 @@ __global__ __launch_bounds__(kThreads, 2) void pw_fwd2_kernel(
       if (part_sum != nullptr) {
         float s = live ? (v.x + v.y) + (v.z + v.w) : 0.f;
         float q = live ? (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w) : 0.f;
-        s = half_wave_sum(s);
-        q = half_wave_sum(q);
+        half_wave_sum2(s, q);
         if (l31 == 31) {
           red[((wv % WN) * M_WG + row_l) * 2 + 0] = s;
           red[((wv % WN) * M_WG + row_l) * 2 + 1] = q;
@@ -756,8 +776,7 @@ __global__ __launch_bounds__(kThreads, 2) void pw_fwd_sk_kernel(
     if (part_sum != nullptr) {
       float s1 = (o.x + o.y) + (o.z + o.w);
       float s2 = (o.x * o.x + o.y * o.y) + (o.z * o.z + o.w * o.w);
-      s1 = half_wave_sum(s1);
-      s2 = half_wave_sum(s2);
+      half_wave_sum2(s1, s2);
       if (l31 == 31 && ok) {
         part_sum[(size_t)row * nt_total + blockIdx.x] = s1;
         part_sq[(size_t)row * nt_total + blockIdx.x] = s2;
@@ -1815,8 +1834,7 @@ __global__ __launch_bounds__(kThreads) void pw_dgrad_kernel(
           sg += gq;
           sgy += gq * yv[r][tn];
         }
-        sg = half_wave_sum(sg);
-        sgy = half_wave_sum(sgy);
+        half_wave_sum2(sg, sgy);
         if ((lane & 31) == 31) {
           red[((wv % WN) * M_T + row_l) * 2 + 0] = sg;
           red[((wv % WN) * M_T + row_l) * 2 + 1] = sgy;
@@ -1848,8 +1866,7 @@ __global__ __launch_bounds__(kThreads) void pw_dgrad_kernel(
         }
       }
       if (stats) {
-        sg = half_wave_sum(sg);
-        sgy = half_wave_sum(sgy);
+        half_wave_sum2(sg, sgy);
         if ((lane & 31) == 31) {
           red[((wv % WN) * M_T + row_l) * 2 + 0] = sg;
           red[((wv % WN) * M_T + row_l) * 2 + 1] = sgy;
@@ -1988,8 +2005,7 @@ __global__ __launch_bounds__(kThreads, 2) void pw_dgrad_sk_kernel(
         sg = (g0 + g1) + (g2 + g3);
         sgy = (g0 * yi.x + g1 * yi.y) + (g2 * yi.z + g3 * yi.w);
       }
-      sg = half_wave_sum(sg);
-      sgy = half_wave_sum(sgy);
+      half_wave_sum2(sg, sgy);
       if (l31 == 31 && ok) {
         part_g[(size_t)row * nt_total + blockIdx.x] = sg;
         part_gy[(size_t)row * nt_total + blockIdx.x] = sgy;
