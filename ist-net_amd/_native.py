@@ -11,7 +11,8 @@ LIB_PATH = os.path.join(_HERE, "lib", "libistnet_pn2.so")
 INCLUDE_DIR = os.path.join(_HERE, "..", "include")
 HEADER_PATH = os.path.join(INCLUDE_DIR, "istnet_pn2.h")
 HEADER_PATHS = [HEADER_PATH, os.path.join(INCLUDE_DIR, "istnet_pw.h"), os.path.join(INCLUDE_DIR, "istnet_preproc.h"),
-                os.path.join(INCLUDE_DIR, "istnet_optim.h"), os.path.join(INCLUDE_DIR, "istnet_rgb.h")]
+                os.path.join(INCLUDE_DIR, "istnet_optim.h"), os.path.join(INCLUDE_DIR, "istnet_rgb.h"),
+                os.path.join(INCLUDE_DIR, "istnet_heads.h")]
 ABI_VERSION = 1
 
 _i, _f, _p, _d, _l = ctypes.c_int, ctypes.c_float, ctypes.c_void_p, ctypes.c_double, ctypes.c_longlong
@@ -95,6 +96,16 @@ SIGNATURES = {
     "istnet_pw_wgrad_reduce_multi": [_i, _p, _p, _p, _p, _p],
     "istnet_pw_wgrad_reduce_multi_ld": [_i, _p, _p, _p, _p, _p, _p, _p, _p],
     "istnet_pack_words": [_i, _p, _p, _p, _p],
+    # include/istnet_heads.h (csrc/pose_tail.hip)
+    "istnet_fc_forward": [_i, _i, _i, _p, _p, _p, _p, _p, _i, _p],
+    "istnet_fc_backward": [_i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _p],
+    "istnet_ortho6d_forward": [_i, _p, _p, _p],
+    "istnet_ortho6d_backward": [_i, _p, _p, _p, _p],
+    "istnet_pose_dis_forward": [_i, _p, _p, _p, _p, _p, _p, _p, _p, _p],
+    "istnet_pose_dis_backward": [_i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p],
+    "istnet_smooth_l1_parts": [_l],
+    "istnet_smooth_l1_forward": [_l, _f, _p, _p, _p, _p, _p],
+    "istnet_smooth_l1_backward": [_l, _f, _p, _p, _p, _p, _p],
     # csrc/pw_last.hip
     "istnet_pw_forward_pool_ok": [_i, _i, _i, _i, _i],
     "istnet_pw_forward_pool": [_i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p],

@@ -19,7 +19,8 @@ import torch.nn as nn
 from .modules import PointNet2MSG
 from .pointnet2.fused_mlp import pointwise_conv_stack as _run
 from .pointnet2.fused_mlp import pointwise_conv_stack_multi as _run_multi
-from .rotation_utils import Ortho6d2Mat
+from . import heads_native
+from .rotation_utils import Ortho6d2Mat, ortho6d_to_mat
 
 CAM_RADII = [[0.01, 0.02], [0.02, 0.04], [0.04, 0.08], [0.08, 0.16]]      # ist_net.py:16
 WORLD_RADII = [[0.05, 0.10], [0.10, 0.20], [0.20, 0.30], [0.30, 0.40]]    # ist_net.py:189
@@ -87,6 +88,10 @@ class _PoseHeads(nn.Module):
         self.size_estimator = _fc_head(3)
 
     def _pose(self, pooled):
+        fused = heads_native.fc_heads([self.rotation_estimator, self.translation_estimator, self.size_estimator], pooled)
+        if fused is not None:       # the three heads layer by layer in three launches, Ortho6d2Mat in one
+            r6, t, s = fused
+            return ortho6d_to_mat(r6).view(-1, 3, 3), t, s
         r6 = self.rotation_estimator(pooled)
         r = Ortho6d2Mat(r6[:, :3].contiguous(), r6[:, 3:].contiguous()).view(-1, 3, 3)
         return r, self.translation_estimator(pooled), self.size_estimator(pooled)

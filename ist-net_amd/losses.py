@@ -9,6 +9,9 @@ import torch.nn as nn
 
 def SmoothL1Dis(p1, p2, threshold=0.1):
     """p1, p2 (B,N,3): smooth-L1 per coordinate, summed over xyz, mean over points and batch."""
+    from . import heads_native
+    if heads_native.usable(p1, p2) and p1.shape == p2.shape and p1.shape[-1] == 3 and not p2.requires_grad:
+        return heads_native.SmoothL1Function.apply(p1, p2, threshold)      # one launch per direction
     diff = torch.abs(p1 - p2)
     dis = torch.where(diff > threshold, diff - threshold / 2.0, diff.pow(2) / (2.0 * threshold))
     return torch.mean(torch.sum(dis, dim=2 if p1.dim() == 3 else 1))
@@ -23,6 +26,10 @@ def ChamferDis(p1, p2):
 
 def PoseDis(r1, t1, s1, r2, t2, s2):
     """Mean column norm of R1-R2 (dim=1 as in the reference) + mean L2 of t and s differences."""
+    from . import heads_native
+    if (heads_native.usable(r1, t1, s1, r2, t2, s2) and r1.shape == r2.shape and r1.dim() == 3
+            and not (r2.requires_grad or t2.requires_grad or s2.requires_grad)):
+        return heads_native.PoseDisFunction.apply(r1, t1, s1, r2, t2, s2)   # one launch per direction
     return (torch.mean(torch.norm(r1 - r2, dim=1)) + torch.mean(torch.norm(t1 - t2, dim=1))
             + torch.mean(torch.norm(s1 - s2, dim=1)))
 

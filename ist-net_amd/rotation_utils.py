@@ -23,7 +23,18 @@ def cross_product(u, v):
 
 def Ortho6d2Mat(x_raw, y_raw):
     """(B,3), (B,3) -> (B,3,3)."""
+    from . import heads_native
+    if heads_native.usable(x_raw, y_raw) and x_raw.dim() == 2:     # one launch per direction (csrc/pose_tail.hip)
+        return heads_native.Ortho6dFunction.apply(torch.cat((x_raw, y_raw), dim=1))
     y = normalize_vector(y_raw)
     z = normalize_vector(cross_product(x_raw, y))
     x = cross_product(y, z)
     return torch.stack((x, y, z), dim=2)
+
+
+def ortho6d_to_mat(r6):
+    """``Ortho6d2Mat(r6[:, :3], r6[:, 3:])`` for the (B, 6) output of a rotation head, without the slices / concat."""
+    from . import heads_native
+    if heads_native.usable(r6) and r6.dim() == 2 and r6.shape[1] == 6:
+        return heads_native.Ortho6dFunction.apply(r6)
+    return Ortho6d2Mat(r6[:, :3].contiguous(), r6[:, 3:].contiguous())

@@ -40,19 +40,24 @@ print(f"{workload}: {ours} launches of the library's kernels, {sum(len(v) for v 
 cpu = [e for e in prof.events() if e.device_type.name == "CPU" and e.stack]
 for name, evs in sorted(other.items(), key=lambda kv: -len(kv[1])):
     print(f"{len(evs):4d} x {name}")
-print("---- CPU ops that launch framework kernels (aten::*), by source line ----")
-seen = {}
-for e in cpu:
-    if not e.name.startswith("aten::") or e.name in ("aten::empty", "aten::view", "aten::as_strided", "aten::empty_strided",
-                                                        "aten::reshape", "aten::slice", "aten::select", "aten::transpose",
-                                                        "aten::t", "aten::expand", "aten::unsqueeze", "aten::squeeze",
-                                                        "aten::_unsafe_view", "aten::detach", "aten::alias", "aten::permute",
-                                                        "aten::empty_like", "aten::contiguous", "aten::result_type", "aten::to",
-                                                        "aten::view_as", "aten::narrow", "aten::resize_", "aten::lift_fresh",
-                                                        "aten::unbind", "aten::item", "aten::_local_scalar_dense", "aten::is_nonzero"):
+print("---- aten ops by source line (key_averages grouped by stack) ----")
+skip = {"aten::empty", "aten::view", "aten::as_strided", "aten::empty_strided", "aten::reshape", "aten::slice", "aten::select",
+        "aten::transpose", "aten::t", "aten::expand", "aten::unsqueeze", "aten::squeeze", "aten::_unsafe_view", "aten::detach",
+        "aten::alias", "aten::permute", "aten::empty_like", "aten::result_type", "aten::view_as", "aten::narrow", "aten::resize_",
+        "aten::lift_fresh", "aten::unbind", "aten::item", "aten::_local_scalar_dense", "aten::is_nonzero", "aten::expand_as",
+        "aten::stride", "aten::size", "aten::set_", "aten::_reshape_alias", "aten::unflatten", "aten::flatten", "aten::chunk",
+        "aten::split", "aten::index_select_backward", "aten::zeros", "aten::ones", "aten::zero_", "aten::to", "aten::_to_copy"}
+rows = []
+for ev in prof.key_averages(group_by_stack_n=12):
+    if not ev.key.startswith("aten::") or ev.key in skip or ev.device_time_total <= 0:
         continue
-    frames = [f for f in e.stack if "/root/repo" in f or "bench.py" in f or "istnet" in f]
-    key = (e.name, frames[0] if frames else (e.stack[0] if e.stack else "?"))
-    seen[key] = seen.get(key, 0) + 1
-for (name, where), n in sorted(seen.items(), key=lambda kv: -kv[1])[:60]:
-    print(f"{n:4d} x {name:28s} {where}")
+    frames = [f for f in ev.stack if "/root/repo" in f or "/ist-net_amd/" in f or "bench.py" in f]
+    where = frames[0] if frames else (ev.stack[-1] if ev.stack else "?")
+    rows.append((ev.count, ev.device_time_total, ev.key, where))
+agg = {}
+for cnt, t, key, where in rows:
+    k = (key, where)
+    c0, t0 = agg.get(k, (0, 0.0))
+    agg[k] = (c0 + cnt, t0 + t)
+for (key, where), (cnt, t) in sorted(agg.items(), key=lambda kv: -kv[1][0])[:70]:
+    print(f"{cnt:4d} x {t:9.1f} us  {key:34s} {where}")
