@@ -505,7 +505,7 @@ class Modified_PSPNet(nn.Module):
 
     def _train_gather_ok(self, u):
         conv, bn, act = self.final[0], self.final[1], self.final[2]
-        return (USE_TRAIN_GATHER_FIRST and self.training and u.is_cuda and u.dtype == torch.float32
+        return (USE_TRAIN_GATHER_FIRST and self.training and bn.training and u.is_cuda and u.dtype == torch.float32
                 and u.is_contiguous(memory_format=torch.channels_last) and conv.bias is not None and bn.affine
                 and bn.momentum is not None and act.weight.numel() == 1)
 
