@@ -452,6 +452,8 @@ def main():
                     help="N > 1: run the step eagerly so that each ~25 MB bucket of the flat gradient is all-reduced "
                          "from an autograd hook while backward still runs (a replayed graph issues the buckets after "
                          "the replay); meant for --workload istnet (107 MB of gradients)")
+    ap.add_argument("--no-overlap-allreduce", action="store_true",
+                    help="istnet workload with N > 1: keep the captured step and issue the buckets after the replay")
     ap.add_argument("--no-prefetch", action="store_true",
                     help="encoder workload: one batch, geometry inside the step (no next-batch geometry prefetch)")
     ap.add_argument("--workload", default="encoder", choices=["encoder", "istnet", "infer", "sa_layer"],
@@ -496,8 +498,8 @@ def main():
         pointnet2_utils._ext = pn2_oracle      # checker ops stand in for the HIP library in the dry run only
         torch.set_num_threads(max(1, min(4, (os.cpu_count() or 2) // max(args.gpus, 1))))
         dev, batch_size = torch.device("cpu"), 2
-        if args.workload != "encoder":
-            raise SystemExit("--cpu-dry-run covers the encoder workload only")
+        if args.workload not in ("encoder", "istnet"):
+            raise SystemExit("--cpu-dry-run covers the encoder and istnet workloads")
     else:
         torch.cuda.set_device(local_rank)
         dev = torch.device("cuda", local_rank)
@@ -547,9 +549,16 @@ def main():
         if rank == 0:
             print(json.dumps(result), flush=True)
         return
+    npoints = NPOINTS
     if args.workload == "istnet":
         model = make_istnet(dev, seed=0, freeze_world_enhancer=args.freeze_world_enhancer)
-        batch = istnet_batch(BATCH, NPOINTS, seed=rank, device=dev)
+        if args.cpu_dry_run:         # toy size: the launch / exchange control flow is what the dry run exercises
+            npoints = 256
+            batch = istnet_batch(batch_size, npoints, seed=rank, device=dev, hw=64)
+            batch["rgb"] = batch["rgb"].contiguous()
+            model = model.to(memory_format=torch.contiguous_format)
+        else:
+            batch = istnet_batch(BATCH, NPOINTS, seed=rank, device=dev)
         opt = FlatAdam(model.parameters(), lr=1e-4)
         if dist_on:
             from istnet_amd.parallel import OverlappedFlatReducer
@@ -573,6 +582,10 @@ def main():
             fwd_bwd = [make_pipelined_fwd_bwd(model, batches, slots, i) for i in (0, 1)]
     eager_step = make_eager_step(fwd_bwd, opt, world, grad_sync)
     step, mode = eager_step, "eager"
+    if dist_on and args.workload == "istnet" and not args.no_overlap_allreduce:
+        # 107 MB of gradients in ~4 buckets: issued from autograd hooks while backward still runs they hide under it, and the
+        # eager step costs nothing for this GPU-bound model (56.6 vs 56.8 ms measured with a one-rank RCCL group) -- the default
+        args.overlap_allreduce = True
     if args.overlap_allreduce and dist_on:
         args.eager = True       # hooks issue the collectives during backward: not inside a capture
     if not args.eager:
@@ -623,13 +636,17 @@ def main():
                                    ("IST-Net full model (ResNet-18/PSP RGB branch on MIOpen + point branch, "
                                     "cam + world encoders, IST head, 3 pose heads) fwd+bwd+Adam, SupervisedLoss"
                                     + (", world enhancer frozen" if args.freeze_world_enhancer else "")),
-                       "batch_per_gpu": batch_size, "npoints": NPOINTS, "global_batch": batch_size * world,
+                       "batch_per_gpu": batch_size, "npoints": npoints, "global_batch": batch_size * world,
                        "parallelism": f"dp{world}" + (" (one-rank dry run of the RCCL path)" if args.force_dist and world == 1 else ""),
                        "launch": mode,
                        "gradient_exchange": (None if not dist_on else
-                                             f"{len(grad_sync.buckets)} bucket(s) of FlatAdam.flat_grad, sum all-reduce "
-                                             + ("from autograd hooks during backward" if mode == "eager"
-                                                else "issued back to back after the graph replay")),
+                                             {"bytes_per_step": int(opt.flat_grad.numel() * opt.flat_grad.element_size()),
+                                              "buckets": len(grad_sync.buckets),
+                                              "bucket_bytes": [int((hi - lo) * opt.flat_grad.element_size())
+                                                               for lo, hi, _ in grad_sync.buckets],
+                                              "collective": "sum all-reduce of FlatAdam.flat_grad slices (RCCL), 1/N folded into Adam",
+                                              "issued": ("from autograd hooks during backward (overlapped)" if mode == "eager"
+                                                         else "back to back after the graph replay")}),
                        "batches": ("1 (same batch every step)" if (args.workload != "encoder" or args.no_prefetch)
                                    else "2 alternating, next batch's FPS/ball-query/three_nn prefetched on the "
                                         "geometry stream during the current step")},

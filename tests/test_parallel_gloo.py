@@ -282,3 +282,16 @@ def test_bench_under_torch_distributed_run():
                       "127.0.0.1", "--master-port", str(_free_port()), "bench.py", "--gpus", "2", "--steps", "1",
                       "--warmup", "1", "--cpu-dry-run"])
     assert res["n_gpus"] == 2 and res["config"]["parallelism"] == "dp2"
+
+
+def test_bench_istnet_workload_two_ranks_overlapped_exchange():
+    """``--workload istnet`` with N = 2 (toy size on host cores): the full model's gradients leave in several buckets FROM
+    THE AUTOGRAD HOOKS while backward runs -- the default for this workload --, and the JSON says how many bytes and
+    buckets a step exchanges."""
+    res = _run_bench(["bench.py", "--gpus", "2", "--steps", "1", "--warmup", "1", "--cpu-dry-run", "--workload", "istnet"])
+    assert res["n_gpus"] == 2 and res["config"]["parallelism"] == "dp2" and res["config"]["launch"] == "eager"
+    ex = res["config"]["gradient_exchange"]
+    assert ex["buckets"] >= 4 and sum(ex["bucket_bytes"]) == ex["bytes_per_step"]
+    assert 100e6 < ex["bytes_per_step"] < 115e6          # 26.8 M parameters in fp32 (BASELINE.md section 3: 107.3 MB)
+    assert "during backward" in ex["issued"]
+    assert res["value"] > 0 and "NOT a measurement" in res["data"]
