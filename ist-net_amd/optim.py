@@ -129,14 +129,21 @@ class FlatAdam(torch.optim.Optimizer):
         flat moment buffers (a snapshot: torch's ``load_state_dict`` keeps the tensors it is given when dtype and device
         already match) -- plus ``param_groups``.  Weights are NOT part of an optimizer state."""
         state = {}
+        step_cpu = self.step_count.detach().to("cpu", torch.float32)    # torch.optim.Adam (non-capturable): CPU float tensor
         for i, (p, o) in enumerate(zip(self.params, self.offsets)):
             n = p.numel()
-            state[i] = {"step": self.step_count.detach().clone(),
+            state[i] = {"step": step_cpu.clone(),
                         "exp_avg": self.exp_avg[o:o + n].view_as(p).clone(),
                         "exp_avg_sq": self.exp_avg_sq[o:o + n].view_as(p).clone()}
         group = {"lr": self.lr, "betas": self.betas, "eps": self.eps, "weight_decay": self.weight_decay,
                  "amsgrad": False, "maximize": False, "foreach": None, "capturable": False, "differentiable": False,
-                 "fused": None, "decoupled_weight_decay": False, "params": list(range(len(self.params)))}
+                 "fused": None, "decoupled_weight_decay": False}
+        # keys a scheduler added to the group (CyclicLR / LambdaLR write ``initial_lr``, ``base_momentum`` ...): a resumed
+        # scheduler built with last_epoch != -1 needs them back
+        for k, v in self.param_groups[0].items():
+            if k not in group and k != "params":
+                group[k] = v
+        group["params"] = list(range(len(self.params)))
         return {"state": state, "param_groups": [group]}
 
     def load_state_dict(self, sd):
@@ -146,13 +153,24 @@ class FlatAdam(torch.optim.Optimizer):
         if len(groups) != 1:
             raise ValueError("FlatAdam.load_state_dict: exactly one parameter group expected")
         g = groups[0]
-        if len(g["params"]) != len(self.params):
-            raise ValueError(f"FlatAdam.load_state_dict: {len(g['params'])} parameters in the state, "
-                             f"{len(self.params)} in the optimizer")
+        keys = list(g["params"])
+        if len(keys) != len(self.params):
+            # A reference checkpoint of the non-frozen configuration was saved by Adam(model.parameters()) over ALL
+            # parameters (train.py:101-107), while this optimizer holds the trainable ones only.  ``all_params`` (set by the
+            # caller: ``opt.all_params = list(model.parameters())``) maps the checkpoint's indices over every parameter and
+            # the non-trainable ones are skipped.
+            every = getattr(self, "all_params", None)
+            if every is not None and len(keys) == len(every):
+                mine = {id(p) for p in self.params}
+                keys = [k for k, p in zip(keys, every) if id(p) in mine]
+            if len(keys) != len(self.params):
+                raise ValueError(f"FlatAdam.load_state_dict: {len(g['params'])} parameters in the state, "
+                                 f"{len(self.params)} in the optimizer (set opt.all_params = list(model.parameters()) to "
+                                 "load a checkpoint saved over all parameters)")
         if g.get("amsgrad", False) or g.get("maximize", False):
             raise ValueError("FlatAdam.load_state_dict: amsgrad / maximize states are not supported")
         steps = set()
-        for key, p, o in zip(g["params"], self.params, self.offsets):
+        for key, p, o in zip(keys, self.params, self.offsets):
             st = sd["state"].get(key)
             n = p.numel()
             if st is None:                       # parameter never stepped: zero moments
@@ -170,3 +188,6 @@ class FlatAdam(torch.optim.Optimizer):
         self.lr = float(g["lr"])
         self.betas, self.eps, self.weight_decay = tuple(g["betas"]), float(g["eps"]), float(g["weight_decay"])
         self.param_groups[0].update(lr=self.lr, betas=self.betas, eps=self.eps, weight_decay=self.weight_decay)
+        for k, v in g.items():                   # scheduler bookkeeping (initial_lr, ...) travels with the group
+            if k not in self.param_groups[0] and k != "params":
+                self.param_groups[0][k] = v

@@ -215,6 +215,42 @@ def test_flat_adam_state_dict_round_trips_with_torch_adam():
         FlatAdam(list(b.parameters())[:2], lr=1e-2).load_state_dict(sd_ref)
 
 
+def test_flat_adam_state_dict_details_of_reference_checkpoints():
+    """``step`` is saved as a CPU float tensor (torch.optim.Adam's non-capturable layout); keys a scheduler
+    adds to the parameter group (``initial_lr``) survive a save / load round trip, so a scheduler resumed with
+    last_epoch != -1 works; a checkpoint saved by Adam over ALL parameters of a model loads into an optimizer over the
+    trainable ones (the frozen-world-enhancer stage, train.py:102-118) through ``all_params``."""
+    a, b = _models()
+    opt = FlatAdam(b.parameters(), lr=1e-3)
+    sched = torch.optim.lr_scheduler.CyclicLR(opt, base_lr=1e-5, max_lr=1e-2, step_size_up=3, cycle_momentum=False)
+    for _ in range(2):
+        opt.zero_grad(set_to_none=True)
+        b(torch.ones(4, 5)).square().mean().backward()
+        opt.step(); sched.step()
+    sd = opt.state_dict()
+    assert all(v["step"].device.type == "cpu" and v["step"].dtype == torch.float32 for v in sd["state"].values())
+    assert "initial_lr" in sd["param_groups"][0]
+    _, b2 = _models()
+    opt2 = FlatAdam(b2.parameters(), lr=1e-3)
+    opt2.load_state_dict(sd)
+    assert opt2.param_groups[0]["initial_lr"] == sd["param_groups"][0]["initial_lr"]
+    torch.optim.lr_scheduler.CyclicLR(opt2, base_lr=1e-5, max_lr=1e-2, step_size_up=3, cycle_momentum=False, last_epoch=1)
+    # a state saved over all parameters, loaded by an optimizer over the trainable subset
+    m, _ = _models()
+    full = torch.optim.Adam(m.parameters(), lr=1e-2)
+    m(torch.ones(4, 5)).square().mean().backward()
+    full.step()
+    sd_full = full.state_dict()
+    params = list(m.parameters())
+    params[0].requires_grad_(False)
+    sub = FlatAdam(m.parameters(), lr=1e-2)
+    with pytest.raises(ValueError):
+        sub.load_state_dict(sd_full)
+    sub.all_params = params
+    sub.load_state_dict(sd_full)
+    torch.testing.assert_close(sub.exp_avg[:params[1].numel()].view_as(params[1]), sd_full["state"][1]["exp_avg"])
+
+
 @pytest.mark.gpu
 def test_shared_module_used_twice_in_one_graph_under_flat_adam():
     """A fused module applied twice in ONE autograd graph (siamese use): both backward nodes see ``param.grad is
