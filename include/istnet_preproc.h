@@ -38,6 +38,18 @@ ISTNET_PN2_API int istnet_backproject_choose(int count, int n, int h, int w, con
                                              double fx, double fy, double cx, double cy, double norm_scale,
                                              int img_size, float *pts, long long *choose_out, void *stream);
 
+/* replaces fill_in_multiscale of utils/data_utils.py:357-510 as fill_missing calls it (:516-540: fill_type 'multiscale',
+ * extrapolate False, blur_type 'bilateral'; provider/dataset.py:172-173,361-362): morphological depth completion of b
+ * float32 depth images (b, h, w) already scaled to the unit the thresholds are written in (metres).  Pass by pass the
+ * reference's own sequence -- inversion max_depth - d of the valid pixels (d > 0.01), cross-kernel dilations of the
+ * far / medium / near bins (3 / 5 / 7), 5x5 closing, masked 5x5 median, 9x9 hole fill under the top mask, six masked 5x5
+ * fills, masked 5x5 median, bilateral filter (d = 5, sigmaColor 0.5, sigmaSpace 2.0) on the pixels valid before the
+ * blurs, inversion back -- with OpenCV's documented border rules (csrc/depth_fill.hip).  scratch:
+ * istnet_depth_fill_scratch_floats(b, h, w) floats.  out (b, h, w). */
+ISTNET_PN2_API int istnet_depth_fill_scratch_floats(int b, int h, int w);
+ISTNET_PN2_API int istnet_depth_fill_multiscale(int b, int h, int w, const float *depth, float max_depth, float *scratch,
+                                                float *out, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -32,6 +32,8 @@ SIGNATURES = {
     "istnet_upconv3_fwd_nhwc": [_i, _i, _i, _i, _i, _i, _p, _p, _p, _p],
     "istnet_upconv3_bwd_nhwc": [_i, _i, _i, _i, _i, _i, _p, _p, _p],
     "istnet_backproject_choose": [_i, _i, _i, _i, _p, _i, _l, _p, _p, _d, _d, _d, _d, _d, _i, _p, _p, _p],
+    "istnet_depth_fill_scratch_floats": [_i, _i, _i],
+    "istnet_depth_fill_multiscale": [_i, _i, _i, _p, _f, _p, _p, _p],
     "istnet_pn2_set_tuning": [_i, _i],
     "istnet_pn2_furthest_point_sampling": [_i, _i, _i, _p, _p, _p, _p],
     "istnet_debug_marker": [_p, _p],

@@ -44,3 +44,37 @@ def backproject_choose(depth, bboxes, choose, intrinsics=REAL_INTRINSICS, norm_s
     if rc != 0:
         raise RuntimeError(f"istnet_backproject_choose failed with code {rc}")
     return pts, out
+
+
+def fill_missing(dpt, cam_scale, scale_2_80m, fill_type="multiscale", extrapolate=False, show_process=False,
+                 blur_type="bilateral"):
+    """Depth completion of the reference's data pipeline (utils/data_utils.py:516-540, same signature; the Dataset
+    classes call ``fill_missing(depth, norm_scale, 1)``, provider/dataset.py:172-173,361-362) on the GPU:
+    ``dpt`` (h, w) or (b, h, w) raw depth -- a CUDA tensor (uint16 / int16 / float) -- is scaled by
+    ``scale_2_80m / cam_scale``, completed by the multi-scale morphological pipeline of fill_in_multiscale
+    (istnet_depth_fill_multiscale, csrc/depth_fill.hip) and scaled back; returns float32 of the same shape.
+    Only the reference's own configuration is implemented: fill_type 'multiscale', extrapolate False, blur_type
+    'bilateral'.  CUDA tensors only (no CPU path)."""
+    if fill_type != "multiscale" or extrapolate or blur_type != "bilateral" or show_process:
+        raise NotImplementedError("fill_missing: only fill_type='multiscale', extrapolate=False, blur_type='bilateral' "
+                                  "(what the reference's Dataset classes use)")
+    if not torch.is_tensor(dpt) or not dpt.is_cuda:
+        raise RuntimeError("fill_missing: CPU not supported")
+    squeeze = dpt.dim() == 2
+    img = dpt.unsqueeze(0) if squeeze else dpt
+    if img.dim() != 3:
+        raise ValueError("fill_missing: expected a depth image (h, w) or a batch (b, h, w)")
+    if img.dtype in (torch.uint16, torch.int16):
+        img = img.view(torch.int16).to(torch.int32) & 0xffff            # raw millimetres, stored as 16-bit
+    # numpy evaluates dpt / cam_scale * scale_2_80m in float64 and fill_in_multiscale rounds to float32 once
+    depth = (img.to(torch.float64) / float(cam_scale) * float(scale_2_80m)).to(torch.float32).contiguous()
+    b, h, w = depth.shape
+    lib = _native.lib()
+    scratch = torch.empty(lib.istnet_depth_fill_scratch_floats(b, h, w), dtype=torch.float32, device=depth.device)
+    out = torch.empty_like(depth)
+    with torch.cuda.device(depth.device):
+        _native.check(lib.istnet_depth_fill_multiscale(b, h, w, depth.data_ptr(), 3.0, scratch.data_ptr(), out.data_ptr(),
+                                                       torch.cuda.current_stream(depth.device).cuda_stream),
+                      "depth_fill_multiscale")
+    out = out / float(scale_2_80m) * float(cam_scale)
+    return out[0] if squeeze else out

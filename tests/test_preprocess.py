@@ -79,3 +79,71 @@ def test_backproject_edge_cases_and_errors():
         preprocess.backproject_choose(depth.double(), torch.tensor([[0, 40, 0, 40]]), torch.zeros(1, 4, dtype=torch.int64))
     with pytest.raises(ValueError):
         preprocess.backproject_choose(depth, torch.tensor([[0, 40, 0, 40]]), torch.zeros(2, 4, dtype=torch.int64))
+
+
+# ---------------------------------------------------------------------------------------------
+# fill_missing (utils/data_utils.py:357-540): oracle known answers on CPU, HIP kernels vs oracle on the GPU
+# ---------------------------------------------------------------------------------------------
+def _depth_scene(seed, h=120, w=160):
+    """A synthetic raw depth image (uint16 millimetres): a slanted plane 0.4-2.6 m with an object, 12 % dropouts, holes of
+    several sizes, an empty band at the top (no return above the scene) and a few far outliers."""
+    rng = np.random.default_rng(seed)
+    yy, xx = np.mgrid[0:h, 0:w]
+    d = 400.0 + 1700.0 * yy / h + 480.0 * xx / w + rng.normal(0, 4, (h, w))
+    oh, ow = h // 4, w // 4
+    d[h // 3:h // 3 + oh, w // 3:w // 3 + ow] = 700.0 + rng.normal(0, 3, (oh, ow))
+    d[rng.random((h, w)) < 0.12] = 0
+    for _ in range(8):
+        r, c, s = int(rng.integers(10, max(h - 20, 11))), int(rng.integers(0, max(w - 20, 1))), int(rng.integers(3, 14))
+        d[r:r + s, c:c + s] = 0
+    d[:9, :] = 0
+    d[rng.random((h, w)) < 0.002] = 3400.0
+    return np.clip(d, 0, 65535).astype(np.uint16)
+
+
+def test_depth_fill_oracle_known_answers():
+    from oracle import depth_fill_oracle as dfo
+    # the OpenCV primitives as restated: dilation ignores the outside of the image, the cross element has no corners
+    img = np.zeros((5, 5), np.float32); img[0, 0] = 2.0; img[2, 2] = 1.0
+    np.testing.assert_array_equal(dfo.dilate(img, dfo.CROSS(3)),
+                                  np.float32([[2, 2, 0, 0, 0], [2, 0, 1, 0, 0], [0, 1, 1, 1, 0], [0, 0, 1, 0, 0], [0] * 5]))
+    np.testing.assert_array_equal(dfo.erode(np.ones((4, 4), np.float32), dfo.FULL(5)), np.ones((4, 4), np.float32))
+    ramp = np.arange(49, dtype=np.float32).reshape(7, 7)
+    assert dfo.median_blur5(ramp)[3, 3] == 24.0 and dfo.median_blur5(ramp)[0, 0] == 2.0       # replicated border: nine 0s, three 1s, three 2s ...
+    flat = np.full((6, 6), 1.25, np.float32)
+    np.testing.assert_allclose(dfo.bilateral5(flat), flat, rtol=1e-6)
+    # end to end on a constant plane with one hole: the hole is filled with the plane's depth, valid pixels are unchanged
+    d = np.full((40, 40), 1200, np.uint16); d[20:23, 20:23] = 0
+    out = dfo.fill_missing(d, 1000.0, 1)
+    assert out.dtype == np.float32 or out.dtype == np.float64
+    np.testing.assert_allclose(out, 1200.0, rtol=1e-5)
+    # nothing above the first valid row of a column is invented (top mask), empty columns stay empty
+    d = np.full((40, 40), 900, np.uint16); d[:12, :] = 0; d[:, 5] = 0
+    out = dfo.fill_missing(d, 1000.0, 1)
+    assert (out[:8, 20] == 0).all() and out[30, 20] == pytest.approx(900.0, rel=1e-5)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(120, 160), (480, 640), (37, 53)])
+def test_fill_missing_matches_oracle(shape):
+    """istnet_depth_fill_multiscale against the numpy / scipy restatement, pass for pass the same selections (dilations,
+    medians: exact) and the bilateral filter in float32: the completed depth within 1e-5 relative, zeros in the same
+    places, batch entries independent."""
+    from istnet_amd import preprocess
+    from oracle import depth_fill_oracle as dfo
+    dev = torch.device("cuda:0")
+    imgs = [_depth_scene(s, *shape) for s in (1, 2, 3)]
+    batch = torch.from_numpy(np.stack(imgs).view(np.int16)).to(dev)
+    got = preprocess.fill_missing(batch, 1000.0, 1).cpu().numpy()
+    for i, img in enumerate(imgs):
+        want = np.float32(dfo.fill_missing(img, 1000.0, 1))
+        assert ((got[i] == 0) == (want == 0)).all()
+        np.testing.assert_allclose(got[i], want, rtol=1e-5, atol=1e-3)           # millimetres
+        filled = (img == 0) & (want > 0)
+        assert filled.sum() > 0.5 * (img[10:] == 0).sum()                         # the holes below the top band are closed
+    single = preprocess.fill_missing(batch[1], 1000.0, 1).cpu().numpy()
+    np.testing.assert_array_equal(single, got[1])
+    with pytest.raises(RuntimeError):
+        preprocess.fill_missing(batch.cpu(), 1000.0, 1)
+    with pytest.raises(NotImplementedError):
+        preprocess.fill_missing(batch, 1000.0, 1, fill_type="fast")
