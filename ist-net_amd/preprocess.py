@@ -78,3 +78,32 @@ def fill_missing(dpt, cam_scale, scale_2_80m, fill_type="multiscale", extrapolat
                       "depth_fill_multiscale")
     out = out / float(scale_2_80m) * float(cam_scale)
     return out[0] if squeeze else out
+
+
+def instance_labels(pts, translation, rotation, scale, sizes, symmetric):
+    """Pose labels of a batch of instances, the arithmetic of provider/dataset.py:236-257 as batched tensor expressions
+    (device-agnostic): for classes with a rotational symmetry about the y axis (``symmetric`` (B,) bool: bottle, bowl, can in
+    NOCS) the rotation is canonicalised by the in-plane map s_map; ``size = scale * sizes``; the NOCS coordinates of the sampled
+    points ``qo = (pts - t) / (|size| + 1e-8) @ R``; ``sRT`` = [scale * R | t].  pts (B,n,3), translation (B,3), rotation
+    (B,3,3), scale (B,), sizes (B,3).  Returns rotation (B,3,3), size (B,3), qo (B,n,3) -- float64 like the numpy code, which
+    promotes through s_map / np.linalg.norm; the caller casts as the reference's ``torch.FloatTensor`` does -- and sRT (B,4,4)
+    float32."""
+    f64 = torch.float64
+    t32 = translation.to(torch.float32)
+    rot = rotation.to(torch.float32)
+    size = scale.reshape(-1, 1).to(torch.float32) * sizes.to(torch.float32)
+    theta_x = (rot[:, 0, 0] + rot[:, 2, 2]).to(f64)
+    theta_y = (rot[:, 0, 2] - rot[:, 2, 0]).to(f64)
+    r_norm = torch.sqrt(theta_x ** 2 + theta_y ** 2)
+    cx, sy = theta_x / r_norm, theta_y / r_norm
+    zero, one = torch.zeros_like(cx), torch.ones_like(cx)
+    s_map = torch.stack([torch.stack([cx, zero, -sy], 1), torch.stack([zero, one, zero], 1), torch.stack([sy, zero, cx], 1)], 1)
+    sym = symmetric.reshape(-1, 1, 1).to(torch.bool)
+    rot64 = torch.where(sym, rot.to(f64) @ s_map, rot.to(f64))
+    rot_out = torch.where(sym, rot64, rot.to(f64))
+    norm = torch.linalg.vector_norm(size, dim=1).to(f64) + 1e-8          # np.linalg.norm of a float32 vector is float32
+    qo = ((pts.to(torch.float32) - t32.unsqueeze(1)).to(f64) / norm.reshape(-1, 1, 1)) @ rot_out
+    srt = torch.eye(4, dtype=torch.float32, device=pts.device).repeat(pts.shape[0], 1, 1)
+    srt[:, :3, :3] = (scale.reshape(-1, 1, 1).to(f64) * rot_out).to(torch.float32)
+    srt[:, :3, 3] = t32
+    return rot_out, size, qo, srt

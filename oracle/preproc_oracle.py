@@ -27,3 +27,26 @@ def backproject_choose(depth, bbox, choose, intrinsics, norm_scale=1000.0, img_s
     row_idx = choose // crop_w
     choose_out = (np.floor(row_idx * ratio) * img_size + np.floor(col_idx * ratio)).astype(np.int64)   # :231
     return pts, choose_out
+
+
+def instance_labels(pts, translation, rotation, scale, sizes, symmetric):
+    """provider/dataset.py:236-257 for one instance: rotation canonicalised about the y axis for a symmetric class, size
+    label, NOCS coordinates ``qo`` of the sampled points and the 4x4 sRT.  pts (n,3) f32, translation (3,), rotation (3,3),
+    scale scalar, sizes (3,)."""
+    import math
+    translation = translation.astype(np.float32)
+    rotation = rotation.astype(np.float32)
+    size = scale * sizes.astype(np.float32)                                      # :239
+    if symmetric:                                                                # :241-248
+        theta_x = rotation[0, 0] + rotation[2, 2]
+        theta_y = rotation[0, 2] - rotation[2, 0]
+        r_norm = math.sqrt(theta_x ** 2 + theta_y ** 2)
+        s_map = np.array([[theta_x / r_norm, 0.0, -theta_y / r_norm],
+                          [0.0, 1.0, 0.0],
+                          [theta_y / r_norm, 0.0, theta_x / r_norm]])
+        rotation = rotation @ s_map
+    qo = (pts - translation[np.newaxis, :]) / (np.linalg.norm(size) + 1e-8) @ rotation      # :249
+    sRT = np.identity(4, dtype=np.float32)                                       # :251-253
+    sRT[:3, :3] = scale * rotation
+    sRT[:3, 3] = translation
+    return rotation, size, qo, sRT

@@ -147,3 +147,27 @@ def test_fill_missing_matches_oracle(shape):
         preprocess.fill_missing(batch.cpu(), 1000.0, 1)
     with pytest.raises(NotImplementedError):
         preprocess.fill_missing(batch, 1000.0, 1, fill_type="fast")
+
+
+def test_instance_labels_match_numpy_restatement():
+    """preprocess.instance_labels (batched tensor form of provider/dataset.py:236-257) against the per-instance numpy
+    restatement: symmetric and asymmetric classes, rotation / size / NOCS coordinates / sRT."""
+    from istnet_amd import preprocess
+    rng = np.random.default_rng(5)
+    b, n = 6, 64
+    pts = rng.normal(0, 0.1, (b, n, 3)).astype(np.float32) + np.float32([0, 0, 0.8])
+    trans = rng.normal(0, 0.05, (b, 3)) + [0, 0, 0.8]
+    rots = np.stack([np.linalg.qr(rng.normal(size=(3, 3)))[0] for _ in range(b)])
+    scale = rng.uniform(0.1, 0.4, b)
+    sizes = rng.uniform(0.3, 1.0, (b, 3))
+    sym = np.array([True, False, True, False, False, True])
+    got = preprocess.instance_labels(torch.from_numpy(pts), torch.from_numpy(trans), torch.from_numpy(rots),
+                                     torch.from_numpy(scale), torch.from_numpy(sizes), torch.from_numpy(sym))
+    for i in range(b):
+        r, s, qo, srt = preproc_oracle.instance_labels(pts[i], trans[i], rots[i], scale[i], sizes[i], bool(sym[i]))
+        np.testing.assert_allclose(got[0][i].numpy(), r, rtol=1e-6, atol=1e-7)
+        np.testing.assert_allclose(got[1][i].numpy(), s, rtol=1e-6)
+        np.testing.assert_allclose(got[2][i].numpy(), qo, rtol=1e-5, atol=1e-7)
+        np.testing.assert_allclose(got[3][i].numpy(), srt, rtol=1e-6, atol=1e-7)
+    # a symmetric class: the canonical rotation has no in-plane component left (R[0,2] == R[2,0])
+    assert abs(float(got[0][0][0, 2] - got[0][0][2, 0])) < 1e-6
