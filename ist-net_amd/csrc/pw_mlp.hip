@@ -3006,35 +3006,36 @@ struct ReduceBatch {
   int cols[8];
   int ld[8];
   long long pstride[8];
-  int block_begin[9];  // prefix sum of ceil(count / 16)
+  int block_begin[9];  // prefix sum of ceil(count / 64)
   int n;
 };
+// Workgroup = 64 consecutive elements x 4 split groups: a wave reads 256 contiguous bytes per split (the earlier layout --
+// 16 elements x 16 split groups -- read 64-byte segments), four independent chains per thread keep loads in flight, the
+// four group sums meet in LDS in a fixed order.
 __global__ __launch_bounds__(256) void wgrad_reduce_multi_kernel(ReduceBatch rb) {
-  __shared__ float red[16][17];
+  __shared__ float red[4][64];
   int l = 0;
   while (l + 1 < rb.n && (int)blockIdx.x >= rb.block_begin[l + 1]) ++l;
   const int count = rb.count[l], splits = rb.splits[l];
   const size_t ps = (size_t)rb.pstride[l];
   const float* __restrict__ part = rb.part[l];
-  const int el = threadIdx.x & 15, sg = threadIdx.x >> 4;
-  const int i = ((int)blockIdx.x - rb.block_begin[l]) * 16 + el;
+  const int el = threadIdx.x & 63, sg = threadIdx.x >> 6;
+  const int i = ((int)blockIdx.x - rb.block_begin[l]) * 64 + el;
   float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
   if (i < count) {
     int k = sg;
-    for (; k + 48 < splits; k += 64) {
+    for (; k + 12 < splits; k += 16) {
       s0 += part[(size_t)k * ps + i];
-      s1 += part[(size_t)(k + 16) * ps + i];
-      s2 += part[(size_t)(k + 32) * ps + i];
-      s3 += part[(size_t)(k + 48) * ps + i];
+      s1 += part[(size_t)(k + 4) * ps + i];
+      s2 += part[(size_t)(k + 8) * ps + i];
+      s3 += part[(size_t)(k + 12) * ps + i];
     }
-    for (; k < splits; k += 16) s0 += part[(size_t)k * ps + i];
+    for (; k < splits; k += 4) s0 += part[(size_t)k * ps + i];
   }
   red[sg][el] = (s0 + s1) + (s2 + s3);
   __syncthreads();
-  if (threadIdx.x < 16 && i < count) {
-    float s = 0.f;
-#pragma unroll
-    for (int g = 0; g < 16; ++g) s += red[g][el];
+  if (threadIdx.x < 64 && i < count) {
+    const float s = (red[0][el] + red[1][el]) + (red[2][el] + red[3][el]);
     const int cols = rb.cols[l];
     rb.dw[l][(size_t)(i / cols) * rb.ld[l] + i % cols] = s;
   }
@@ -3117,12 +3118,18 @@ int g_fwd_sk_max_tiles = 1024; // key 16: launches with more 32 x 128 tiles than
 int g_fwd2_enable = 1;         // key 13: 0 = pw_fwd_kernel for every forward launch
 int g_fwd2_min_waves = 1024;   // key 14 (step time at 2048 / 1024 / 768 / 512 / 256: 2.912 / 2.870 / 2.879 / 2.933 / 2.997 ms)
 int g_wgrad2_enable = 1;       // key 11: 0 = pw_wgrad_kernel for every dense layer
-int g_wgrad2_target = 256;     // key 12: workgroups of a pw_wgrad2_kernel launch (one per CU)
+int g_wgrad2_target = 512;     // key 12: workgroups of a pw_wgrad2_kernel launch (two per CU with the 64 x 64 tiles, see key 20)
 inline bool wgrad2_ok(int cin, int cout) {
   return g_wgrad2_enable && cin >= 64 && cout >= 64 && cin % 32 == 0 && cout % 32 == 0;
 }
-inline int wgrad2_mt(int cout) { return cout >= 128 ? 128 : 64; }
-inline int wgrad2_nt(int cin) { return cin >= 128 ? 128 : 64; }
+int g_wgrad2_tile_max = 64;    // key 20.  Round 3: 64 x 64 output tiles for every role-split wgrad.  A launch's split-K partials
+                               // are (workgroups x tile bytes): 256 x 64 KB = 16 MB at 128 x 128, 512 x 16 KB = 8 MB now -- half the
+                               // partial traffic of the 13 launches per step -- and inside the step the smaller tiles with 512
+                               // workgroups measure 2.74-2.75 ms against 2.77-2.78 (A/B on one box; 384 / 768 / 1024 workgroups:
+                               // 2.79).  Alone the 128 x 128 tiles are 25-45 % faster (round 2), but these launches run beside the
+                               // dgrad chain and their partials compete with it for HBM.
+inline int wgrad2_mt(int cout) { return (cout >= 128 && g_wgrad2_tile_max >= 128) ? 128 : 64; }
+inline int wgrad2_nt(int cin) { return (cin >= 128 && g_wgrad2_tile_max >= 128) ? 128 : 64; }
 inline int wgrad_split_len(int b, int cin, int cout, int P) {
   if (wgrad2_ok(cin, cout)) {
     // one workgroup of eight waves per CU: as many splits as keep tiles * splits at or under the target
@@ -3201,7 +3208,8 @@ int istnet_pw_set_tuning(int key, int value) {
     case 18: g_dgrad_sk_min_k = value > 0 ? value : 256; return 0;
     case 16: g_fwd_sk_max_tiles = value > 0 ? value : 1024; return 0;
     case 14: g_fwd2_min_waves = value > 0 ? value : 1024; return 0;
-    case 12: g_wgrad2_target = value > 0 ? value : 256; return 0;
+    case 12: g_wgrad2_target = value > 0 ? value : 512; return 0;
+    case 20: g_wgrad2_tile_max = value >= 128 ? 128 : 64; return 0;
     default: return ISTNET_PN2_EINVAL;
   }
 }
@@ -4036,7 +4044,7 @@ static int reduce_multi_impl(int n, const int* counts, const int* splits, const 
     rb.ld[l] = lds != nullptr ? lds[l] : counts[l];
     rb.pstride[l] = pstrides != nullptr ? pstrides[l] : (long long)counts[l];
     if (rb.cols[l] <= 0 || counts[l] % rb.cols[l] || rb.ld[l] < rb.cols[l] || rb.pstride[l] < counts[l]) return ISTNET_PN2_EINVAL;
-    rb.block_begin[l + 1] = rb.block_begin[l] + ceil_div(counts[l], 16);
+    rb.block_begin[l + 1] = rb.block_begin[l] + ceil_div(counts[l], 64);
   }
   hipLaunchKernelGGL(wgrad_reduce_multi_kernel, dim3(rb.block_begin[n]), dim3(256), 0, as_stream(stream), rb);
   return (int)hipGetLastError();
