@@ -258,6 +258,12 @@ ISTNET_PN2_API int istnet_pw_wgrad_reduce(int count, int splits, const float *dw
 ISTNET_PN2_API int istnet_pw_wgrad_reduce_multi(int n, const int *counts, const int *splits,
                                                 const float *const *parts, float *const *dws, void *stream);
 
+/* out (b, c) = mean over the p points of relu(scale_c * y[b][c][:] + shift_c)  (bn = [scale | shift | ...] as everywhere):
+ * the AdaptiveAvgPool1d(1) that ends pose_mlp2 of both estimators (model/ist_net.py:246,314) from the raw output of the
+ * stack's last layer; istnet_expand_rows is its adjoint, out[row][:] = g[row] / p for rows = b * c.  p % 4 == 0. */
+ISTNET_PN2_API int istnet_bn_relu_mean(int b, int c, int p, const float *y, const float *bn, float *out, void *stream);
+ISTNET_PN2_API int istnet_expand_rows(int rows, int p, const float *g, float *out, void *stream);
+
 /* ---- the LAST layer of a set-abstraction scale without its activation (csrc/pw_last.hip; reference
  * pointnet2_modules.py:61-71: conv1x1 -> BatchNorm2d -> ReLU -> max_pool2d over nsample) ----
  * forward: istnet_pw_forward_pool = istnet_pw_forward whose epilogue keeps, per (channel, ball of nsample consecutive

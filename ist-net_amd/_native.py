@@ -98,6 +98,8 @@ SIGNATURES = {
     "istnet_pw_wgrad_reduce_multi": [_i, _p, _p, _p, _p, _p],
     "istnet_pw_wgrad_reduce_multi_ld": [_i, _p, _p, _p, _p, _p, _p, _p, _p],
     "istnet_pack_words": [_i, _p, _p, _p, _p],
+    "istnet_bn_relu_mean": [_i, _i, _i, _p, _p, _p, _p],
+    "istnet_expand_rows": [_i, _i, _p, _p, _p],
     # include/istnet_heads.h (csrc/pose_tail.hip)
     "istnet_fc_forward": [_i, _i, _i, _p, _p, _p, _p, _p, _i, _p],
     "istnet_fc_backward": [_i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _p],

@@ -957,6 +957,35 @@ __global__ __launch_bounds__(256) void bn_relu_apply_kernel(int C, int P4, const
 
 // bn[4][C] of a layer whose normalisation is a fixed affine map: eval-mode BatchNorm (running statistics) or a
 // plain conv bias (gamma / mean / var absent).  One launch instead of the 4-9 tiny tensor ops it replaces.
+// mean over the points of relu(scale y + shift): the AdaptiveAvgPool1d(1) that ends pose_mlp2 of both estimators
+// (model/ist_net.py:246,314) taken straight from the raw output of the stack's last layer -- the (B, C, N) activation is
+// neither written nor read back.  One wave per (cloud, channel) row; rows (B*C), P % 4 == 0.
+__global__ __launch_bounds__(256) void bn_relu_mean_kernel(int C, int P, int rows, const float* __restrict__ y,
+                                                           const float* __restrict__ scale, const float* __restrict__ shift,
+                                                           float* __restrict__ out) {
+  const int row = blockIdx.x * 4 + wave_id(), lane = lane_id();
+  if (row >= rows) return;
+  const float s = scale[row % C], h = shift[row % C];
+  const float4* src = reinterpret_cast<const float4*>(y + (size_t)row * P);
+  float acc = 0.f;
+  for (int i = lane; i < P / 4; i += 64) {
+    const float4 v = src[i];
+    acc += (fmaxf(v.x * s + h, 0.f) + fmaxf(v.y * s + h, 0.f)) + (fmaxf(v.z * s + h, 0.f) + fmaxf(v.w * s + h, 0.f));
+  }
+  acc = wave_sum(acc);
+  if (lane == 0) out[row] = acc / (float)P;
+}
+// its adjoint as a dense gradient for the stack's backward: out[row][p] = g[row] * inv_p
+__global__ __launch_bounds__(256) void expand_rows_kernel(int P4, int rows, float inv_p, const float* __restrict__ g,
+                                                          float* __restrict__ out) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= P4) return;
+  for (int row = blockIdx.y; row < rows; row += gridDim.y) {
+    const float v = g[row] * inv_p;
+    reinterpret_cast<float4*>(out + (size_t)row * P4 * 4)[i] = make_float4(v, v, v, v);
+  }
+}
+
 __global__ __launch_bounds__(256) void affine_consts_kernel(int C, const float* __restrict__ gamma,
                                                             const float* __restrict__ beta,
                                                             const float* __restrict__ mean,
@@ -3479,6 +3508,20 @@ int istnet_bn_relu_pool(int b, int c, int g, int s, const float* y, const float*
     default: return ISTNET_PN2_EINVAL;
   }
 #undef ISTNET_POOL
+  return (int)hipGetLastError();
+}
+
+int istnet_bn_relu_mean(int b, int c, int p, const float* y, const float* bn, float* out, void* stream) {
+  if (b <= 0 || c <= 0 || p <= 0 || (p & 3) || !y || !bn || !out) return ISTNET_PN2_EINVAL;
+  const int rows = b * c;
+  hipLaunchKernelGGL(bn_relu_mean_kernel, dim3(ceil_div(rows, 4)), dim3(256), 0, as_stream(stream), c, p, rows, y, bn,
+                     bn + c, out);
+  return (int)hipGetLastError();
+}
+int istnet_expand_rows(int rows, int p, const float* g, float* out, void* stream) {
+  if (rows <= 0 || p <= 0 || (p & 3) || !g || !out) return ISTNET_PN2_EINVAL;
+  hipLaunchKernelGGL(expand_rows_kernel, dim3(ceil_div(p / 4, 256), grid_rows(rows)), dim3(256), 0, as_stream(stream),
+                     p / 4, rows, 1.f / (float)p, g, out);
   return (int)hipGetLastError();
 }
 

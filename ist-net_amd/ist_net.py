@@ -44,7 +44,7 @@ def _fc_head(out_dim):
 def _pooled(seq, feat):
     """``seq`` = [conv, relu, conv, relu, AdaptiveAvgPool1d(1)] (pose_mlp2) on [feat, global mean of feat] (:256-257,
     :324-325): fused convs with the mean as a per-cloud bias, then the mean over N."""
-    return _run_multi(seq[:-1], [feat], with_mean=True).mean(dim=2)
+    return _run_multi(seq[:-1], [feat], with_mean=True, pool_mean=True)
 
 
 class FeatureDeformer(nn.Module):

@@ -231,8 +231,9 @@ class _Gather:
         self.cfeat = 0 if feat is None else feat.shape[1]
 
 
-def _forward_stack(lib, dev, st, b, c0, g, s, x, gather, training, layers, params, out_spec=None, start=None):
-    """Runs all layers + the BN/ReLU/max tail.  Returns (out, arg, ys, bns).
+def _forward_stack(lib, dev, st, b, c0, g, s, x, gather, training, layers, params, out_spec=None, start=None, tail=True):
+    """Runs all layers + the BN/ReLU/max tail.  Returns (out, arg, ys, bns).  ``tail=False``: the caller applies its own
+    tail to the last raw output (ys[-1], bns[-1]); out is None.
 
     ``out_spec`` = (tensor (B, Ctot, G), channel offset): write the pooled result into that channel slice
     (the MSG concat happens in place) instead of a fresh tensor."""
@@ -355,6 +356,8 @@ def _forward_stack(lib, dev, st, b, c0, g, s, x, gather, training, layers, param
         ys.append(y)
         bns.append(bn)
         cur, cur_c, in_bn = y, cout, bn
+    if not tail:
+        return None, None, ys, bns
     if out_spec is None:
         out = _empty((b, cur_c, g), torch.float32, dev)
         out_ptr, out_bstride = out.data_ptr(), 0
@@ -1556,7 +1559,10 @@ class FusedMultiSourceBiasMLPFunction(Function):
     layer-1 dgrad already produced.  tensors = [src_0 .. src_{k-1}, w0, b0, w1, b1, ...]."""
 
     @staticmethod
-    def forward(ctx, nsrc, with_mean, relu_last, *tensors):
+    def forward(ctx, nsrc, with_mean, relu_last, pool_mean, *tensors):
+        # pool_mean: return the mean over the points of the stack's (ReLU) output, (B, C_L) -- the AdaptiveAvgPool1d(1) that
+        # ends pose_mlp2 (model/ist_net.py:246,314) -- from the last RAW output in one pass (istnet_bn_relu_mean): the
+        # (B, C_L, N) activation is neither written nor read back
         import ctypes
         lib = _native.lib()
         srcs = [t.contiguous() for t in tensors[:nsrc]]
@@ -1588,8 +1594,14 @@ class FusedMultiSourceBiasMLPFunction(Function):
             _native.check(lib.istnet_affine_consts(cout0, None, b0.data_ptr(), None, None, 0.0, bn0.data_ptr(), st),
                           "affine_consts")
             out, _, ys, bns = _forward_stack(lib, dev, st, b, cin_total, npts, 1, None, None, False, layers, flat,
-                                             start=(y0, bn0))
+                                             start=(y0, bn0), tail=not pool_mean)
+            if pool_mean:
+                c_last = flat[-3].shape[0]
+                out = _empty((b, c_last), torch.float32, dev)
+                _native.check(lib.istnet_bn_relu_mean(b, c_last, npts, ys[-1].data_ptr(), bns[-1].data_ptr(), out.data_ptr(),
+                                                      st), "bn_relu_mean")
         ctx.meta = (nsrc, with_mean, b, npts, chans, n)
+        ctx.pool_mean = pool_mean
         ctx.save_for_backward(*srcs, mean if mean is not None else torch.empty(0, device=dev), *ys, *bns, *flat)
         return out
 
@@ -1606,8 +1618,8 @@ class FusedMultiSourceBiasMLPFunction(Function):
         cout0, cin_total = w0.shape[0], w0.shape[1]
         w2 = w0.reshape(cout0, cin_total)
         csum = sum(chans)
-        need_src = [ctx.needs_input_grad[3 + i] for i in range(nsrc)]
-        need_w = [ctx.needs_input_grad[3 + nsrc + 2 * li] for li in range(n)]
+        need_src = [ctx.needs_input_grad[4 + i] for i in range(nsrc)]
+        need_w = [ctx.needs_input_grad[4 + nsrc + 2 * li] for li in range(n)]
         dsrc = [None] * nsrc
 
         def layer0(y0, d_a0, bn0, bwdc0, grads, wextra, part, nt_l):
@@ -1658,16 +1670,23 @@ class FusedMultiSourceBiasMLPFunction(Function):
         layer0.takes_partials = True
 
         with torch.cuda.device(dev):
+            dout = dout.contiguous()
+            if ctx.pool_mean:          # adjoint of the mean over the points: a dense gradient g[b, c] / N for the stack
+                c_last = flat[-3].shape[0]
+                dense = _empty((b, c_last, npts), torch.float32, dev)
+                _native.check(lib.istnet_expand_rows(b * c_last, npts, dout.data_ptr(), dense.data_ptr(), _st(dev)),
+                              "expand_rows")
+                dout = dense
             grads, _, _ = _backward_stack(lib, dev, _st(dev), b, cin_total, npts, 1, None, None, False, ys, bns, flat,
-                                          None, dout.contiguous(), need_w, True, layer0_hook=layer0)
+                                          None, dout, need_w, True, layer0_hook=layer0)
         out = []
         for li in range(n):
             dw = grads[3 * li]
             out += [dw.view_as(flat[3 * li]) if dw is not None else None, grads[3 * li + 2]]
-        return (None, None, None, *dsrc, *out)
+        return (None, None, None, None, *dsrc, *out)
 
 
-def pointwise_conv_stack_multi(seq, sources, with_mean=False):
+def pointwise_conv_stack_multi(seq, sources, with_mean=False, pool_mean=False):
     """``seq(cat(sources [+ mean of the single source expanded], dim=1))`` for an ``nn.Sequential`` of
     [Conv1d(k=1) (+ ReLU)]* without building the concatenation on CUDA (FusedMultiSourceBiasMLPFunction); anything the
     fused form does not cover builds the input and runs ``pointwise_conv_stack``."""
@@ -1694,7 +1713,8 @@ def pointwise_conv_stack_multi(seq, sources, with_mean=False):
         i += 2 if has_relu else 1
     csum = sum(t.shape[1] for t in sources) * (2 if with_mean else 1)
     if not ok or len(convs) < 2 or not all(relu_after[:-1]) or convs[0].in_channels != csum:
-        return pointwise_conv_stack(seq, build())
+        out = pointwise_conv_stack(seq, build())
+        return out.mean(dim=2) if pool_mean else out
     if with_mean:
         # the mean term's backward reads the per-cloud sums of dY0 out of the statistics partials of the layer-1 dgrad,
         # which are laid out [cloud][tile] only on the plain / split-K dgrad paths; the fused small / mid-size backward
@@ -1705,11 +1725,14 @@ def pointwise_conv_stack_multi(seq, sources, with_mean=False):
         if ((USE_FUSED_SMALL_BWD and lib.istnet_pw_bwd_small_ok(c0, c1, npts))
                 or (USE_FUSED_MID_BWD and lib.istnet_pw_bwd_mid_ok(c0, c1, npts))
                 or lib.istnet_pw_dgrad_rs(b, c0, c1, npts, 1)):
-            return pointwise_conv_stack(seq, build())
+            out = pointwise_conv_stack(seq, build())
+            return out.mean(dim=2) if pool_mean else out
     params = []
     for m in convs:
         params += [m.weight, m.bias]
-    return FusedMultiSourceBiasMLPFunction.apply(len(sources), with_mean, relu_after[-1], *sources, *params)
+    if pool_mean and not relu_after[-1]:
+        return FusedMultiSourceBiasMLPFunction.apply(len(sources), with_mean, False, False, *sources, *params).mean(dim=2)
+    return FusedMultiSourceBiasMLPFunction.apply(len(sources), with_mean, relu_after[-1], pool_mean, *sources, *params)
 
 
 USE_CONCAT_FREE_HEADS = True

@@ -140,3 +140,29 @@ def test_estimator_heads_gradients_vs_float64():
     for name, a, c in zip(names, grads, grads64):
         err = float((a.double() - c).norm() / (c.norm() + 1e-30))
         assert err < 1e-4, (name, err)
+
+
+def test_stack_with_fused_mean_pool_equals_stack_then_mean():
+    """pose_mlp2 = [conv, relu, conv, relu, AdaptiveAvgPool1d(1)] on [feat, global mean of feat]: the pooled form (mean of the
+    ReLU output taken from the last raw activation, dense gradient re-expanded in backward) against the stack followed by
+    torch's mean -- value and every gradient."""
+    from istnet_amd.pointnet2 import fused_mlp
+    torch.manual_seed(4)
+    b, n = 4, 512
+    seq = torch.nn.Sequential(torch.nn.Conv1d(512, 512, 1), torch.nn.ReLU(), torch.nn.Conv1d(512, 512, 1), torch.nn.ReLU()).to(DEV)
+    feat0 = torch.relu(torch.randn(b, 256, n, device=DEV))
+    wgt = torch.randn(b, 512, device=DEV)
+    res = []
+    for pooled in (True, False):
+        seq.zero_grad(set_to_none=True)
+        feat = feat0.clone().requires_grad_(True)
+        out = fused_mlp.pointwise_conv_stack_multi(seq, [feat], with_mean=True, pool_mean=pooled)
+        if not pooled:
+            out = out.mean(dim=2)
+        (out * wgt).sum().backward()
+        res.append((out.detach(), feat.grad.clone(), [p.grad.clone() for p in seq.parameters()]))
+    assert res[0][0].shape == (b, 512)
+    assert _rel(res[0][0], res[1][0]) < 1e-6
+    assert _rel(res[0][1], res[1][1]) < 1e-5
+    for a, c in zip(res[0][2], res[1][2]):
+        assert _rel(a, c) < 1e-5
