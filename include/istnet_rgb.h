@@ -45,6 +45,27 @@ ISTNET_PN2_API int istnet_upconv3_fwd_nhwc(int b, int c, int hin, int win, int h
 ISTNET_PN2_API int istnet_upconv3_bwd_nhwc(int b, int c, int hin, int win, int hout, int wout, const float *dy,
                                            float *dq, void *stream);
 
+/* BatchNorm2d with batch statistics + PReLU (one slope) + optional Dropout2d mask of a channels-last map y (b, hw, c), the
+ * tail of every decoder stage (model/modules.py:25-34,63-65), as two streaming passes per direction:
+ *   forward   istnet_nhwc_channel_stats: part_sum / part_sq [c][istnet_nhwc_stat_parts(b * hw)] (finalised by
+ *             istnet_bn_finalize_fwd of istnet_pw.h, which also updates the running statistics and writes
+ *             bn = [scale | shift | mean | invstd]);  istnet_nhwc_bn_prelu_apply: z = prelu(scale y + shift) * mask[b][c]
+ *   backward  istnet_nhwc_bn_prelu_bwd_stats: with g = dz * mask * prelu'(scale y + shift): part_g = sum g,
+ *             part_gy = sum g y per channel (finalised by istnet_bn_finalize_bwd -> dgamma, dbeta, bwdc = [ca | cb | cc]),
+ *             part_slope[parts] = partial sums of the slope gradient;  istnet_nhwc_bn_prelu_bwd_apply: dy = ca g + cb + cc y.
+ * c % 4 == 0, c <= 1024; mask (b, c) or NULL. */
+ISTNET_PN2_API int istnet_nhwc_stat_parts(long long rows);
+ISTNET_PN2_API int istnet_nhwc_channel_stats(long long rows, int c, const float *y, float *part_sum, float *part_sq,
+                                             void *stream);
+ISTNET_PN2_API int istnet_nhwc_bn_prelu_apply(int b, long long hw, int c, const float *y, const float *bn,
+                                              const float *slope, const float *mask, float *z, void *stream);
+ISTNET_PN2_API int istnet_nhwc_bn_prelu_bwd_stats(int b, long long hw, int c, const float *y, const float *dz,
+                                                  const float *bn, const float *slope, const float *mask, float *part_g,
+                                                  float *part_gy, float *part_slope, void *stream);
+ISTNET_PN2_API int istnet_nhwc_bn_prelu_bwd_apply(int b, long long hw, int c, const float *y, const float *dz,
+                                                  const float *bn, const float *bwdc, const float *slope, const float *mask,
+                                                  float *dy, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

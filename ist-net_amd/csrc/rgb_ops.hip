@@ -225,6 +225,152 @@ __global__ __launch_bounds__(kThreads) void upconv3_bwd_kernel(int c4, int hin, 
   for (int k = 0; k < 9; ++k) out[(size_t)k * c4] = acc[k];
 }
 
+// ============================================================================================
+// BatchNorm2d (training statistics) + PReLU (+ Dropout2d mask) of a channels-last map as two streaming passes per
+// direction (model/modules.py:25-34: every decoder stage ends conv -> BatchNorm2d -> PReLU, and Dropout2d follows two of
+// them, :63-65).  The framework runs MIOpen's two-kernel BatchNorm, a PReLU kernel and a dropout multiply: 4 reads + 3
+// writes of the map forward, ~7 reads + 3 writes backward; here 2 + 1 and 4 + 1.
+// Layout: rows = B * H * W pixels of C channels (C % 4 == 0, C <= 1024); a workgroup walks a range of pixels with
+// thread = (pixel lane, channel quad), so a wave reads whole contiguous pixels.
+// ============================================================================================
+constexpr int kStatPixels = 512;       // pixels per workgroup in the statistics passes
+
+// pass 1 forward: per-channel sum and sum of squares of the pixels [blockIdx.x * kStatPixels, +kStatPixels)
+__global__ __launch_bounds__(kThreads) void nhwc_stats_kernel(long long rows, int c4, const float4* __restrict__ y,
+                                                              float* __restrict__ part_sum, float* __restrict__ part_sq,
+                                                              int nparts) {
+  extern __shared__ float4 red4[];                  // [2][lanes_p][c4]
+  const int lanes_p = kThreads / c4;                // pixel lanes (host: c4 divides 256 or the tail threads idle)
+  const int q = threadIdx.x % c4, pl = threadIdx.x / c4;
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f), sq = s;
+  if (pl < lanes_p) {
+    const long long p0 = (long long)blockIdx.x * kStatPixels, p1 = min(p0 + kStatPixels, rows);
+    for (long long p = p0 + pl; p < p1; p += lanes_p) {
+      const float4 v = y[p * c4 + q];
+      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+      sq.x += v.x * v.x; sq.y += v.y * v.y; sq.z += v.z * v.z; sq.w += v.w * v.w;
+    }
+    red4[pl * c4 + q] = s;
+    red4[(lanes_p + pl) * c4 + q] = sq;
+  }
+  __syncthreads();
+  if (threadIdx.x < c4) {
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
+    for (int k = 0; k < lanes_p; ++k) {
+      const float4 u = red4[k * c4 + q], w = red4[(lanes_p + k) * c4 + q];
+      a.x += u.x; a.y += u.y; a.z += u.z; a.w += u.w;
+      b.x += w.x; b.y += w.y; b.z += w.z; b.w += w.w;
+    }
+    const int c = 4 * q;
+    part_sum[(size_t)(c + 0) * nparts + blockIdx.x] = a.x; part_sum[(size_t)(c + 1) * nparts + blockIdx.x] = a.y;
+    part_sum[(size_t)(c + 2) * nparts + blockIdx.x] = a.z; part_sum[(size_t)(c + 3) * nparts + blockIdx.x] = a.w;
+    part_sq[(size_t)(c + 0) * nparts + blockIdx.x] = b.x; part_sq[(size_t)(c + 1) * nparts + blockIdx.x] = b.y;
+    part_sq[(size_t)(c + 2) * nparts + blockIdx.x] = b.z; part_sq[(size_t)(c + 3) * nparts + blockIdx.x] = b.w;
+  }
+}
+
+__device__ __forceinline__ float prelu1(float u, float a) { return u > 0.f ? u : a * u; }
+
+// pass 2 forward: z = prelu(scale_c y + shift_c) * mask[b][c]
+__global__ __launch_bounds__(kThreads) void nhwc_bn_prelu_apply_kernel(long long n4, int c4, long long hw_c4,
+                                                                       const float4* __restrict__ y,
+                                                                       const float4* __restrict__ scale,
+                                                                       const float4* __restrict__ shift,
+                                                                       const float* __restrict__ slope,
+                                                                       const float4* __restrict__ mask,
+                                                                       float4* __restrict__ z) {
+  const float a = *slope;
+  for (long long i = (long long)blockIdx.x * kThreads + threadIdx.x; i < n4; i += (long long)gridDim.x * kThreads) {
+    const int q = (int)(i % c4);
+    const float4 v = y[i], sc = scale[q], sh = shift[q];
+    float4 o;
+    o.x = prelu1(v.x * sc.x + sh.x, a); o.y = prelu1(v.y * sc.y + sh.y, a);
+    o.z = prelu1(v.z * sc.z + sh.z, a); o.w = prelu1(v.w * sc.w + sh.w, a);
+    if (mask != nullptr) {
+      const float4 m = mask[(i / hw_c4) * c4 + q];
+      o.x *= m.x; o.y *= m.y; o.z *= m.z; o.w *= m.w;
+    }
+    z[i] = o;
+  }
+}
+
+// pass 1 backward: g = dz * mask * prelu'(u), u = scale y + shift: per-channel sum g, sum g y; the slope gradient
+// sum dz * mask * min(u, 0) over everything (one partial per workgroup)
+__global__ __launch_bounds__(kThreads) void nhwc_bn_prelu_bwd_stats_kernel(
+    long long rows, int c4, long long hw, const float4* __restrict__ y, const float4* __restrict__ dz,
+    const float4* __restrict__ scale, const float4* __restrict__ shift, const float* __restrict__ slope,
+    const float4* __restrict__ mask, float* __restrict__ part_g, float* __restrict__ part_gy,
+    float* __restrict__ part_slope, int nparts) {
+  extern __shared__ float4 red4[];
+  __shared__ float sred[kThreads / 64];
+  const int lanes_p = kThreads / c4;
+  const int q = threadIdx.x % c4, pl = threadIdx.x / c4;
+  const float a = *slope;
+  float4 sg = make_float4(0.f, 0.f, 0.f, 0.f), sgy = sg;
+  float ds = 0.f;
+  if (pl < lanes_p) {
+    const float4 sc = scale[q], sh = shift[q];
+    const long long p0 = (long long)blockIdx.x * kStatPixels, p1 = min(p0 + kStatPixels, rows);
+    for (long long p = p0 + pl; p < p1; p += lanes_p) {
+      const float4 v = y[p * c4 + q];
+      float4 d = dz[p * c4 + q];
+      if (mask != nullptr) {
+        const float4 m = mask[(p / hw) * c4 + q];
+        d.x *= m.x; d.y *= m.y; d.z *= m.z; d.w *= m.w;
+      }
+      const float ux = v.x * sc.x + sh.x, uy = v.y * sc.y + sh.y, uz = v.z * sc.z + sh.z, uw = v.w * sc.w + sh.w;
+      ds += (d.x * fminf(ux, 0.f) + d.y * fminf(uy, 0.f)) + (d.z * fminf(uz, 0.f) + d.w * fminf(uw, 0.f));
+      const float gx = ux > 0.f ? d.x : a * d.x, gy = uy > 0.f ? d.y : a * d.y;
+      const float gz = uz > 0.f ? d.z : a * d.z, gw = uw > 0.f ? d.w : a * d.w;
+      sg.x += gx; sg.y += gy; sg.z += gz; sg.w += gw;
+      sgy.x += gx * v.x; sgy.y += gy * v.y; sgy.z += gz * v.z; sgy.w += gw * v.w;
+    }
+    red4[pl * c4 + q] = sg;
+    red4[(lanes_p + pl) * c4 + q] = sgy;
+  }
+  ds = wave_sum64(ds);
+  if ((threadIdx.x & 63) == 0) sred[threadIdx.x >> 6] = ds;
+  __syncthreads();
+  if (threadIdx.x == 0) part_slope[blockIdx.x] = (sred[0] + sred[1]) + (sred[2] + sred[3]);
+  if (threadIdx.x < c4) {
+    float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0;
+    for (int k = 0; k < lanes_p; ++k) {
+      const float4 u = red4[k * c4 + q], w = red4[(lanes_p + k) * c4 + q];
+      s0.x += u.x; s0.y += u.y; s0.z += u.z; s0.w += u.w;
+      s1.x += w.x; s1.y += w.y; s1.z += w.z; s1.w += w.w;
+    }
+    const int c = 4 * q;
+    part_g[(size_t)(c + 0) * nparts + blockIdx.x] = s0.x; part_g[(size_t)(c + 1) * nparts + blockIdx.x] = s0.y;
+    part_g[(size_t)(c + 2) * nparts + blockIdx.x] = s0.z; part_g[(size_t)(c + 3) * nparts + blockIdx.x] = s0.w;
+    part_gy[(size_t)(c + 0) * nparts + blockIdx.x] = s1.x; part_gy[(size_t)(c + 1) * nparts + blockIdx.x] = s1.y;
+    part_gy[(size_t)(c + 2) * nparts + blockIdx.x] = s1.z; part_gy[(size_t)(c + 3) * nparts + blockIdx.x] = s1.w;
+  }
+}
+
+// pass 2 backward: dy = ca_c g + cb_c + cc_c y   (ca, cb, cc from the finalize of the statistics)
+__global__ __launch_bounds__(kThreads) void nhwc_bn_prelu_bwd_apply_kernel(
+    long long n4, int c4, long long hw_c4, const float4* __restrict__ y, const float4* __restrict__ dz,
+    const float4* __restrict__ scale, const float4* __restrict__ shift, const float* __restrict__ slope,
+    const float4* __restrict__ mask, const float4* __restrict__ ca, const float4* __restrict__ cb,
+    const float4* __restrict__ cc, float4* __restrict__ dy) {
+  const float a = *slope;
+  for (long long i = (long long)blockIdx.x * kThreads + threadIdx.x; i < n4; i += (long long)gridDim.x * kThreads) {
+    const int q = (int)(i % c4);
+    const float4 v = y[i], sc = scale[q], sh = shift[q], fa = ca[q], fb = cb[q], fc = cc[q];
+    float4 d = dz[i];
+    if (mask != nullptr) {
+      const float4 m = mask[(i / hw_c4) * c4 + q];
+      d.x *= m.x; d.y *= m.y; d.z *= m.z; d.w *= m.w;
+    }
+    float4 o;
+    o.x = fa.x * ((v.x * sc.x + sh.x > 0.f) ? d.x : a * d.x) + fb.x + fc.x * v.x;
+    o.y = fa.y * ((v.y * sc.y + sh.y > 0.f) ? d.y : a * d.y) + fb.y + fc.y * v.y;
+    o.z = fa.z * ((v.z * sc.z + sh.z > 0.f) ? d.z : a * d.z) + fb.z + fc.z * v.z;
+    o.w = fa.w * ((v.w * sc.w + sh.w > 0.f) ? d.w : a * d.w) + fb.w + fc.w * v.w;
+    dy[i] = o;
+  }
+}
+
 }  // namespace
 
 extern "C" {
@@ -283,6 +429,61 @@ int istnet_upconv3_bwd_nhwc(int b, int c, int hin, int win, int hout, int wout, 
   const long long total = (long long)b * hin * win * (c / 4);
   hipLaunchKernelGGL(upconv3_bwd_kernel, dim3((unsigned)((total + kThreads - 1) / kThreads)), dim3(kThreads), 0,
                      (hipStream_t)stream, c / 4, hin, win, hout, wout, rh, rw, 1.f / rh, 1.f / rw, dy, dq, total);
+  return (int)hipGetLastError();
+}
+
+int istnet_nhwc_stat_parts(long long rows) { return rows <= 0 ? 0 : (int)((rows + kStatPixels - 1) / kStatPixels); }
+
+static bool nhwc_ok(long long rows, int c) { return rows > 0 && c >= 4 && c <= 1024 && c % 4 == 0; }
+
+int istnet_nhwc_channel_stats(long long rows, int c, const float* y, float* part_sum, float* part_sq, void* stream) {
+  if (!nhwc_ok(rows, c) || c / 4 > kThreads || !y || !part_sum || !part_sq) return ISTNET_PN2_EINVAL;
+  const int c4 = c / 4, nparts = istnet_nhwc_stat_parts(rows), lanes_p = kThreads / c4;
+  hipLaunchKernelGGL(nhwc_stats_kernel, dim3(nparts), dim3(kThreads), (size_t)2 * lanes_p * c4 * sizeof(float4),
+                     (hipStream_t)stream, rows, c4, reinterpret_cast<const float4*>(y), part_sum, part_sq, nparts);
+  return (int)hipGetLastError();
+}
+
+int istnet_nhwc_bn_prelu_apply(int b, long long hw, int c, const float* y, const float* bn, const float* slope,
+                               const float* mask, float* z, void* stream) {
+  if (b <= 0 || !nhwc_ok(hw, c) || !y || !bn || !slope || !z) return ISTNET_PN2_EINVAL;
+  const long long n4 = (long long)b * hw * (c / 4);
+  long long blocks = (n4 + kThreads * 4 - 1) / (kThreads * 4);
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(nhwc_bn_prelu_apply_kernel, dim3((unsigned)blocks), dim3(kThreads), 0, (hipStream_t)stream, n4, c / 4,
+                     hw * (c / 4), reinterpret_cast<const float4*>(y), reinterpret_cast<const float4*>(bn),
+                     reinterpret_cast<const float4*>(bn + c), slope, reinterpret_cast<const float4*>(mask),
+                     reinterpret_cast<float4*>(z));
+  return (int)hipGetLastError();
+}
+
+int istnet_nhwc_bn_prelu_bwd_stats(int b, long long hw, int c, const float* y, const float* dz, const float* bn,
+                                   const float* slope, const float* mask, float* part_g, float* part_gy, float* part_slope,
+                                   void* stream) {
+  const long long rows = (long long)b * hw;
+  if (b <= 0 || !nhwc_ok(hw, c) || c / 4 > kThreads || !y || !dz || !bn || !slope || !part_g || !part_gy || !part_slope)
+    return ISTNET_PN2_EINVAL;
+  const int c4 = c / 4, nparts = istnet_nhwc_stat_parts(rows), lanes_p = kThreads / c4;
+  hipLaunchKernelGGL(nhwc_bn_prelu_bwd_stats_kernel, dim3(nparts), dim3(kThreads), (size_t)2 * lanes_p * c4 * sizeof(float4),
+                     (hipStream_t)stream, rows, c4, hw, reinterpret_cast<const float4*>(y),
+                     reinterpret_cast<const float4*>(dz), reinterpret_cast<const float4*>(bn),
+                     reinterpret_cast<const float4*>(bn + c), slope, reinterpret_cast<const float4*>(mask), part_g, part_gy,
+                     part_slope, nparts);
+  return (int)hipGetLastError();
+}
+
+int istnet_nhwc_bn_prelu_bwd_apply(int b, long long hw, int c, const float* y, const float* dz, const float* bn,
+                                   const float* bwdc, const float* slope, const float* mask, float* dy, void* stream) {
+  if (b <= 0 || !nhwc_ok(hw, c) || !y || !dz || !bn || !bwdc || !slope || !dy) return ISTNET_PN2_EINVAL;
+  const long long n4 = (long long)b * hw * (c / 4);
+  long long blocks = (n4 + kThreads * 4 - 1) / (kThreads * 4);
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(nhwc_bn_prelu_bwd_apply_kernel, dim3((unsigned)blocks), dim3(kThreads), 0, (hipStream_t)stream, n4,
+                     c / 4, hw * (c / 4), reinterpret_cast<const float4*>(y), reinterpret_cast<const float4*>(dz),
+                     reinterpret_cast<const float4*>(bn), reinterpret_cast<const float4*>(bn + c), slope,
+                     reinterpret_cast<const float4*>(mask), reinterpret_cast<const float4*>(bwdc),
+                     reinterpret_cast<const float4*>(bwdc + c), reinterpret_cast<const float4*>(bwdc + 2 * c),
+                     reinterpret_cast<float4*>(dy));
   return (int)hipGetLastError();
 }
 

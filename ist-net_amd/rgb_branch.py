@@ -310,7 +310,10 @@ class _UpConvTailFn(torch.autograd.Function):
             _native.check(_native.lib().istnet_upconv3_bwd_nhwc(
                 b, cout, h, w, 2 * h, 2 * w, dy.data_ptr(), dq.data_ptr(),
                 torch.cuda.current_stream(dy.device).cuda_stream), "upconv3_bwd_nhwc")
-        dbias = dy.sum(dim=(0, 2, 3)) if (ctx.has_bias and ctx.needs_input_grad[1]) else None
+        dbias = None
+        if ctx.has_bias and ctx.needs_input_grad[1]:
+            colsum = getattr(dy, "_istnet_colsum", None)     # left by _BnPReLUDropFn.backward: no pass over the map
+            dbias = colsum if colsum is not None else dy.sum(dim=(0, 2, 3))
         return dq, dbias, None
 
 
@@ -342,6 +345,78 @@ class _PointMixFn(torch.autograd.Function):
         return dx, dw
 
 
+USE_FUSED_DECODER_NORM = True   # decoder stages: BatchNorm (batch statistics) + PReLU + Dropout2d as two passes per direction
+
+
+class _BnPReLUDropFn(torch.autograd.Function):
+    """BatchNorm2d (training statistics) -> PReLU (one slope) [-> Dropout2d mask] of a channels-last map in two streaming
+    passes per direction (include/istnet_rgb.h, istnet_nhwc_*; finalizes of include/istnet_pw.h): the tail of a decoder
+    stage (reference model/modules.py:25-34,63-65).  The framework's sequence -- MIOpen's two-kernel BatchNorm, a PReLU
+    kernel, a dropout multiply -- moves the 75-302 MB map 7 times forward and ~10 times backward; this node 3 and 5 times.
+    Statistics as in the point branch: fp32 partial sums per 512 pixels, combined in float64; running statistics updated
+    with torch's semantics (momentum, unbiased variance).  mask: (B, C) Dropout2d factors (0 or 1 / (1 - p)) or None."""
+
+    @staticmethod
+    def forward(ctx, y, gamma, beta, slope, mask, running_mean, running_var, momentum, eps):
+        from . import _native
+        lib = _native.lib()
+        b, c, h, w = y.shape
+        dev = y.device
+        rows = b * h * w
+        nparts = lib.istnet_nhwc_stat_parts(rows)
+        part = torch.empty((2, c, nparts), dtype=torch.float32, device=dev)
+        bn = torch.empty((4, c), dtype=torch.float32, device=dev)
+        z = torch.empty_like(y, memory_format=torch.channels_last)
+        with torch.cuda.device(dev):
+            st = torch.cuda.current_stream(dev).cuda_stream
+            _native.check(lib.istnet_nhwc_channel_stats(rows, c, y.data_ptr(), part[0].data_ptr(), part[1].data_ptr(), st),
+                          "nhwc_channel_stats")
+            _native.check(lib.istnet_bn_finalize_fwd(
+                c, nparts, float(rows), part[0].data_ptr(), part[1].data_ptr(), gamma.data_ptr(), beta.data_ptr(), float(eps),
+                float(momentum), running_mean.data_ptr() if running_mean is not None else None,
+                running_var.data_ptr() if running_var is not None else None, bn.data_ptr(), st), "bn_finalize_fwd")
+            _native.check(lib.istnet_nhwc_bn_prelu_apply(b, h * w, c, y.data_ptr(), bn.data_ptr(), slope.data_ptr(),
+                                                         mask.data_ptr() if mask is not None else None, z.data_ptr(), st),
+                          "nhwc_bn_prelu_apply")
+        ctx.save_for_backward(y, gamma, slope, bn, mask if mask is not None else torch.empty(0, device=dev))
+        ctx.has_mask = mask is not None
+        return z
+
+    @staticmethod
+    def backward(ctx, dz):
+        from . import _native
+        lib = _native.lib()
+        y, gamma, slope, bn, mask = ctx.saved_tensors
+        mask = mask if ctx.has_mask else None
+        b, c, h, w = y.shape
+        dev = y.device
+        rows = b * h * w
+        dz = dz.contiguous(memory_format=torch.channels_last)
+        nparts = lib.istnet_nhwc_stat_parts(rows)
+        part = torch.empty((2, c, nparts), dtype=torch.float32, device=dev)
+        pslope = torch.empty((nparts,), dtype=torch.float32, device=dev)
+        dgamma = torch.empty((c,), dtype=torch.float32, device=dev)
+        dbeta = torch.empty((c,), dtype=torch.float32, device=dev)
+        bwdc = torch.empty((3, c), dtype=torch.float32, device=dev)
+        dy = torch.empty_like(y, memory_format=torch.channels_last)
+        mptr = mask.data_ptr() if mask is not None else None
+        with torch.cuda.device(dev):
+            st = torch.cuda.current_stream(dev).cuda_stream
+            _native.check(lib.istnet_nhwc_bn_prelu_bwd_stats(b, h * w, c, y.data_ptr(), dz.data_ptr(), bn.data_ptr(),
+                                                             slope.data_ptr(), mptr, part[0].data_ptr(), part[1].data_ptr(),
+                                                             pslope.data_ptr(), st), "nhwc_bn_prelu_bwd_stats")
+            _native.check(lib.istnet_bn_finalize_bwd(c, nparts, float(rows), 1, part[0].data_ptr(), part[1].data_ptr(),
+                                                     gamma.data_ptr(), bn.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(),
+                                                     bwdc.data_ptr(), st), "bn_finalize_bwd")
+            _native.check(lib.istnet_nhwc_bn_prelu_bwd_apply(b, h * w, c, y.data_ptr(), dz.data_ptr(), bn.data_ptr(),
+                                                             bwdc.data_ptr(), slope.data_ptr(), mptr, dy.data_ptr(), st),
+                          "nhwc_bn_prelu_bwd_apply")
+        # the column sums of dy, which the convolution's bias gradient is, follow from the statistics without another pass
+        # over the map: sum_p dy = ca sum g + rows cb + cc rows mean  (analytically zero: BatchNorm removes the bias)
+        dy._istnet_colsum = bwdc[0] * dbeta + float(rows) * (bwdc[1] + bwdc[2] * bn[2])
+        return dy, dgamma, dbeta, pslope.sum().reshape(slope.shape), None, None, None, None, None
+
+
 class PSPUpsample(nn.Module):
     """Upsample(2x, bilinear, align_corners) -> Conv2d(3x3, padding 1) -> BatchNorm2d -> PReLU  [ref modules.py:36-49].
 
@@ -363,16 +438,32 @@ class PSPUpsample(nn.Module):
                 and x.is_contiguous(memory_format=torch.channels_last) and x.shape[2] > 1 and x.shape[3] > 1
                 and conv.in_channels >= UPCONV_MIN_CIN and conv.out_channels % 4 == 0)
 
-    def forward(self, x):
+    def forward(self, x, drop=None):
+        """``drop``: the nn.Dropout2d the caller applies to this stage's output (reference modules.py:63-65), fused into
+        the stage's tail when it can be; otherwise applied here."""
         if not self._split_ok(x):
-            return self.conv(x)
+            out = self.conv(x)
+            return drop(out) if drop is not None else out
         conv = self.conv[1]
         b, cin, h, w = x.shape
         cout = conv.out_channels
         wr = conv.weight.permute(1, 2, 3, 0).reshape(cin, 9 * cout)          # Wr[ci][(ky*3+kx)*Cout + co]
         q = _PointMixFn.apply(x.permute(0, 2, 3, 1).reshape(b * h * w, cin), wr).view(b, h, w, 9 * cout)
         y = _UpConvTailFn.apply(q, conv.bias, cout)
-        return self.conv[3](self.conv[2](y))
+        bn, act = self.conv[2], self.conv[3]
+        if (USE_FUSED_DECODER_NORM and bn.training and bn.affine and bn.momentum is not None and act.weight.numel() == 1
+                and cout % 4 == 0 and cout <= 1024 and torch.is_grad_enabled()):
+            mask = None
+            if drop is not None and drop.training and drop.p > 0:
+                keep = 1.0 - drop.p
+                mask = torch.empty((b, cout), dtype=torch.float32, device=x.device).bernoulli_(keep).div_(keep)
+            if bn.track_running_stats and bn.num_batches_tracked is not None:
+                bn.num_batches_tracked.add_(1)
+            return _BnPReLUDropFn.apply(y, bn.weight, bn.bias, act.weight, mask,
+                                        bn.running_mean if bn.track_running_stats else None,
+                                        bn.running_var if bn.track_running_stats else None, bn.momentum, bn.eps)
+        out = act(bn(y))
+        return drop(out) if drop is not None else out
 
 
 USE_TRAIN_GATHER_FIRST = True    # training: `final` at the chosen pixels only, batch statistics from the moments of its input
@@ -481,8 +572,8 @@ class Modified_PSPNet(nn.Module):
         from the moments of the last stage's input)."""
         f, _ = self.feats(x)
         p = self.drop_1(self.psp(f))
-        p = self.drop_2(self.up_1(p))
-        p = self.drop_2(self.up_2(p))
+        p = self.up_1(p, drop=self.drop_2)
+        p = self.up_2(p, drop=self.drop_2)
         if choose is not None and not self.training:
             return self._tail_at(p, choose)
         u = self.up_3(p)

@@ -266,3 +266,46 @@ def test_extractor_training_forward_with_choose_equals_dense_then_gather():
                  "model.feats.conv1.weight"):
         err = float((g1[name] - g0[name]).norm() / (g0[name].norm() + 1e-12))
         assert err < 2e-2, (name, err)          # MIOpen's own run-to-run differences on the trunk are of this order
+
+
+@pytest.mark.parametrize("b,c,h,w,with_mask", [(4, 64, 24, 24, True), (2, 256, 12, 20, False), (3, 48, 10, 14, True),
+                                               (2, 64, 96, 96, True)])
+def test_fused_batchnorm_prelu_dropout_of_a_channels_last_map(b, c, h, w, with_mask):
+    """_BnPReLUDropFn (two streaming passes per direction) against BatchNorm2d(train) -> PReLU -> mask multiply evaluated in
+    float64: output, running statistics, input gradient, dgamma / dbeta / dslope, and the column sums of the input gradient
+    it leaves for the convolution's bias gradient."""
+    from istnet_amd import rgb_branch
+    g = torch.Generator().manual_seed(c + h)
+    y = (torch.randn(b, c, h, w, generator=g) * 1.3 + 0.4).to(DEV).contiguous(memory_format=torch.channels_last)
+    bn = torch.nn.BatchNorm2d(c).to(DEV).train()
+    act = torch.nn.PReLU().to(DEV)
+    with torch.no_grad():
+        bn.weight.copy_((torch.rand(c, generator=g) + 0.5).to(DEV)); bn.bias.copy_((torch.randn(c, generator=g) * 0.2).to(DEV))
+        act.weight.fill_(0.2)
+    mask = (torch.empty(b, c).bernoulli_(0.8, generator=g) / 0.8).to(DEV) if with_mask else None
+    wgt = torch.randn(b, c, h, w, generator=g).to(DEV)
+    yy = y.clone().requires_grad_(True)
+    rm, rv = bn.running_mean.clone(), bn.running_var.clone()
+    z = rgb_branch._BnPReLUDropFn.apply(yy, bn.weight, bn.bias, act.weight, mask, rm, rv, bn.momentum, bn.eps)
+    (z * wgt).sum().backward()
+    got = (z.detach(), yy.grad.clone(), bn.weight.grad.clone(), bn.bias.grad.clone(), act.weight.grad.clone())
+    colsum = yy.grad.sum(dim=(0, 2, 3))
+    bn.zero_grad(); act.zero_grad()
+    bn64, act64 = torch.nn.BatchNorm2d(c).to(DEV).double().train(), torch.nn.PReLU().to(DEV).double()
+    bn64.load_state_dict({k: (v.double() if v.is_floating_point() else v) for k, v in bn.state_dict().items()})
+    bn64.running_mean.zero_(); bn64.running_var.fill_(1.0)
+    act64.weight.data.fill_(0.2)
+    y64 = y.double().clone().requires_grad_(True)
+    z64 = act64(bn64(y64))
+    if mask is not None:
+        z64 = z64 * mask.double()[:, :, None, None]
+    (z64 * wgt.double()).sum().backward()
+    rel = lambda a, c_: float((a.double() - c_).abs().max() / (c_.abs().max() + 1e-30))
+    assert rel(got[0], z64.detach()) < 1e-5
+    assert rel(got[1], y64.grad) < 1e-4
+    assert rel(got[2], bn64.weight.grad) < 1e-4 and rel(got[3], bn64.bias.grad) < 1e-4
+    assert rel(got[4], act64.weight.grad) < 1e-4
+    assert rel(rm, bn64.running_mean) < 1e-5 and rel(rv, bn64.running_var) < 1e-5
+    # the input gradient of a batch-statistics BatchNorm sums to zero per channel: what the shortcut reports must be at the
+    # round-off level of the honest column sum
+    assert float(colsum.abs().max()) < 1e-2 * float(yy.grad.abs().sum(dim=(0, 2, 3)).max())
