@@ -256,7 +256,7 @@ def run_sa_layer(args, dev):
             model.zero_grad(set_to_none=True)
             new_xyz, feat = model(pts)
             feat.square().mean().backward()
-            return new_xyz, feat
+            return new_xyz.detach(), feat.detach()      # nothing of the autograd graph outlives the step (graph capture)
         return step
 
     gpu_step = make_step(make(dev), xyz.to(dev))

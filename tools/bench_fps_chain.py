@@ -41,10 +41,11 @@ def timeit(fn, reps=20):
 for n, b in ((1024, 32), (2048, 64)):
     xyz = shell_cloud(b, n, seed=0, device=dev)
     a = run_plain(xyz)
-    c, tie = run_chain(xyz)
+    c, _ = run_chain(xyz)
     assert torch.equal(a, c)
+    _, _, tie = _ext.furthest_point_sampling_chain(xyz, LEVELS[0], None, LEVELS[1])     # level 1's own report
     print(f"n={n} b={b}: every level scanned {timeit(lambda: run_plain(xyz)):.1f} us, chained {timeit(lambda: run_chain(xyz)):.1f} us, "
           f"level 1 alone plain {timeit(lambda: _ext.furthest_point_sampling_gather(xyz, n // 2)):.1f} us / tracking "
           f"{n // 4} rounds {timeit(lambda: _ext.furthest_point_sampling_chain(xyz, n // 2, None, n // 4)):.1f} us / tracking all "
-          f"{timeit(lambda: _ext.furthest_point_sampling_chain(xyz, n // 2, None, n // 2)):.1f} us; clouds with a tie before round {n // 4}: "
-          f"{int((tie.cpu() < n // 4).sum())} of {b}")
+          f"{timeit(lambda: _ext.furthest_point_sampling_chain(xyz, n // 2, None, n // 2)):.1f} us; level-1 clouds with an arg-max tie before round {LEVELS[1]}: "
+          f"{int((tie.cpu() < LEVELS[1]).sum())} of {b}")
