@@ -6,7 +6,7 @@ instance, as rocprofv3 names it) with the largest total time, and reports its ac
 rate against the chip peak of /opt/skills/guides/MI355X_MICROARCH.md (157.3 TFLOP/s for
 v_mfma_f32_32x32x2_f32; there is no TF32 on gfx950).
 
-Algorithmic work per launch (DESIGN.md section 6): 2 * B*P * Cin * Cout flop for one layer GEMM
+Algorithmic work per launch (DESIGN.md section 7): 2 * B*P * Cin * Cout flop for one layer GEMM
 (forward, dgrad and wgrad alike), with B*P = points x samples processed by the launch.
 """
 import torch

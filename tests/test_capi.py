@@ -97,7 +97,7 @@ def test_missing_library_fails_loudly(monkeypatch, tmp_path):
 
 
 def test_no_kernel_has_a_scratch_segment(tmp_path):
-    """A kernel with a scratch (private) segment does not share the chip with kernels of other streams (DESIGN.md 5.4:
+    """A kernel with a scratch (private) segment does not share the chip with kernels of other streams (docs/DESIGN_rounds_1_2.md 5.4:
     a 128-workgroup finalize kernel waited 55 us for the GEMM beside it), and register spills cost bandwidth on their own:
     every kernel of the built library must report private_segment_fixed_size 0 and no spills."""
     import os

@@ -512,7 +512,7 @@ def test_concat_free_head_stack_equals_concatenated_input(chans, with_mean, widt
 
 @pytest.mark.parametrize("ratio", [10.0, 30.0])
 def test_batchnorm_statistics_on_badly_centred_activations(ratio):
-    """BatchNorm batch variance is E[y^2] - mean^2 from fp32 tile sums combined in float64 (DESIGN.md 5.2): its relative
+    """BatchNorm batch variance is E[y^2] - mean^2 from fp32 tile sums combined in float64 (DESIGN.md section 4): its relative
     error grows as ~6e-8 (mean / std)^2.  A layer whose output sits |mean| = ratio x std away from zero (identity first
     layer on shifted inputs) must still give the pooled output, the running variance and the gradients within 1e-4 of a
     float64 evaluation."""

@@ -145,7 +145,7 @@ def test_training_steps_are_bit_reproducible():
 
 
 @pytest.mark.parametrize("switch", ["USE_DEFERRED_WGRAD", "USE_SCALE_STREAMS", "USE_FUSED_SMALL_BWD", "USE_FUSED_MID_BWD", "USE_POOLED_FINALIZE", "USE_DENSE_FINALIZE", "USE_INTERP_IN_EPILOGUE", "USE_FINALIZE_IN_SCATTER", "USE_SPLIT_LAYER0", "USE_FP_SKIP_STREAM",
-                                    "USE_CSR_SCATTER", "USE_FUSED_FP", "USE_GEOMETRY_STREAM", "USE_FUSED_NN_WEIGHTS", "COMPACT_LEVELS=", "COMPACT_LEVELS=0,1,2"])
+                                    "USE_CSR_SCATTER", "USE_FUSED_FP", "USE_GEOMETRY_STREAM", "USE_FPS_CHAIN", "USE_FUSED_NN_WEIGHTS", "COMPACT_LEVELS=", "COMPACT_LEVELS=0,1,2"])
 def test_fallback_paths_agree_with_default(switch):
     """Every module-level switch of the fused path selects code that a caller can reach (fallbacks and measured
     alternatives): one encoder training step with the switch flipped gives the output and the parameter gradients of
@@ -168,7 +168,7 @@ def test_fallback_paths_agree_with_default(switch):
     base_out, base_grads = run()
     name, _, val = switch.partition("=")
     from istnet_amd.pointnet2 import pointnet2_modules
-    owner = {"USE_GEOMETRY_STREAM": enc_mod, "USE_FUSED_NN_WEIGHTS": pointnet2_modules}.get(name, fused_mlp)
+    owner = {"USE_GEOMETRY_STREAM": enc_mod, "USE_FPS_CHAIN": enc_mod, "USE_FUSED_NN_WEIGHTS": pointnet2_modules}.get(name, fused_mlp)
     saved = getattr(owner, name)
     try:
         setattr(owner, name, frozenset(int(v) for v in val.split(",") if v) if name == "COMPACT_LEVELS" else False)
