@@ -66,6 +66,20 @@ ISTNET_PN2_API int istnet_nhwc_bn_prelu_bwd_apply(int b, long long hw, int c, co
                                                   const float *bn, const float *bwdc, const float *slope, const float *mask,
                                                   float *dy, void *stream);
 
+/* The same two passes for the tail of a ResNet basic block (reference model/resnet.py:36-67: out = relu(bn2(conv2(.)) +
+ * identity), torch's BatchNorm2d + add + ReLU kernels), slope = 0 for ReLU (any slope >= 0 works; the slope gradient is
+ * not formed):
+ *   forward   istnet_nhwc_bn_act_res_apply: z = act(scale y + shift + res)
+ *   backward  istnet_nhwc_bn_act_res_bwd_stats: g = dz * act'(.) with the sign taken from the saved output z; writes g (the
+ *             identity branch's gradient) and the per-channel partials of sum g, sum g y; after istnet_bn_finalize_bwd the
+ *             input gradient is istnet_nhwc_bn_prelu_bwd_apply(y, g, ..., slope = 1, mask = NULL).
+ * A plain BatchNorm2d + ReLU (bn1 of a block, the stem) is istnet_nhwc_bn_prelu_* with slope = 0. */
+ISTNET_PN2_API int istnet_nhwc_bn_act_res_apply(int b, long long hw, int c, const float *y, const float *bn,
+                                                const float *slope, const float *res, float *z, void *stream);
+ISTNET_PN2_API int istnet_nhwc_bn_act_res_bwd_stats(int b, long long hw, int c, const float *y, const float *dz,
+                                                    const float *z, const float *bn, const float *slope, float *g,
+                                                    float *part_g, float *part_gy, float *part_slope, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

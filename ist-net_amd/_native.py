@@ -30,6 +30,8 @@ SIGNATURES = {
     "istnet_nhwc_bn_prelu_apply": [_i, _l, _i, _p, _p, _p, _p, _p, _p],
     "istnet_nhwc_bn_prelu_bwd_stats": [_i, _l, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p],
     "istnet_nhwc_bn_prelu_bwd_apply": [_i, _l, _i, _p, _p, _p, _p, _p, _p, _p, _p],
+    "istnet_nhwc_bn_act_res_apply": [_i, _l, _i, _p, _p, _p, _p, _p, _p],
+    "istnet_nhwc_bn_act_res_bwd_stats": [_i, _l, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p],
     "istnet_prelu_bwd_parts": [_l],
     "istnet_prelu_bwd": [_l, _p, _p, _p, _p, _p, _p],
     "istnet_upsample_bilinear_ac_bwd_nhwc": [_i, _i, _i, _i, _i, _i, _p, _p, _p],

@@ -146,6 +146,10 @@ __global__ __launch_bounds__(NW * 64) void fps_regs_kernel(int n, int m, int bs_
                                                            int* __restrict__ tie_out, int track_rounds) {
   constexpr int THREADS = NW * 64;
   extern __shared__ __attribute__((aligned(16))) float fps_lds[];  // xyz AoS copy [3n] (+ exchange)
+  // a dependent chain of one wave per cloud: when GEMM / convolution waves of other streams share the SIMD the chain is
+  // served in turn with them (the level-1 pass measured 290 us alone, 890 us beside the RGB trunk); highest issue priority
+  // costs the others nothing measurable (32 waves on 1 024 SIMDs)
+  __builtin_amdgcn_s_setprio(3);
   const int cloud = blockIdx.x;
   const float* dataset = dataset_all + (size_t)cloud * n * 3;
   int* idxs = idxs_all + (size_t)cloud * m;

@@ -84,8 +84,7 @@ __global__ __launch_bounds__(256) void fc_fwd_kernel(FcBatch fb, int B, int K, i
 }
 
 // ---- backward, input gradient: dX[b][k] (+)= sum_h sum_j dZ_h[b][j] W_h[j][k],  dZ = dY . [Y > 0] (relu) or dY.
-// Workgroup = 64 input columns (lane = column, coalesced weight rows); the four waves take quarters of the batch rows (8
-// or 16 accumulators per lane); dZ is staged TRANSPOSED per 64-neuron chunk in LDS and read as broadcasts.
+// Lane = input column (coalesced weight rows); dZ is staged transposed in LDS and read as broadcasts.
 struct FcBwdBatch {
   const float* dy[kMaxHeads];   // (B, N_h)
   const float* y[kMaxHeads];    // (B, N_h) post-activation output of the layer (relu mask), or null
@@ -100,50 +99,68 @@ struct FcBwdBatch {
   int shared_x;                 // 1: all heads read the same X and their input gradients are summed into dx[0]
 };
 
-template <int BPAD>
-__global__ __launch_bounds__(256) void fc_bwd_dx_kernel(FcBwdBatch fb, int B, int K, int relu) {
-  constexpr int RB = BPAD / 4;                       // batch rows per wave
-  constexpr int JC = 64;
-  __shared__ float dzt[JC][BPAD];                    // [neuron][batch row]
+// Launch shape: the product is 1.5-3 MB of weights against a 32-row operand, i.e. pure latency -- a lane's weight loads are
+// a dependent-looking chain the compiler does not pipeline.  So the chain is cut three ways: a workgroup owns 64 columns and
+// RB = 8 batch rows (grid = column tiles x row groups [x heads]); its SIXTEEN waves each take 1/16 of every 512-neuron chunk
+// with all 8 rows in registers, eight independent weight loads in flight per lane; the 16 partial sums meet in LDS and are
+// added in wave order (deterministic).  512 -> 512 x 3 heads: 96 loads per lane instead of 1 536.
+constexpr int kFcDxRows = 8, kFcDxWaves = 16, kFcDxChunk = 512;
+__global__ __launch_bounds__(64 * kFcDxWaves) void fc_bwd_dx_kernel(FcBwdBatch fb, int B, int K, int relu) {
+  constexpr int RB = kFcDxRows, NW = kFcDxWaves, JC = kFcDxChunk, JW = JC / NW;
+  __shared__ __attribute__((aligned(16))) float dzt[JC][RB];        // [neuron][row]: a wave reads two broadcast float4
+  __shared__ float red[NW][RB][64];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  const int ktiles = ceil_div(K, 64);
-  const int hsel = fb.shared_x ? -1 : (int)blockIdx.x / ktiles;      // -1: loop over all heads
-  const int k = ((int)blockIdx.x % ktiles) * 64 + lane;
+  const int ktiles = ceil_div(K, 64), rgroups = ceil_div(B, RB);
+  const int kt = (int)blockIdx.x % ktiles, rg = ((int)blockIdx.x / ktiles) % rgroups;
+  const int hsel = fb.shared_x ? -1 : (int)blockIdx.x / (ktiles * rgroups);      // -1: loop over all heads
+  const int k = kt * 64 + lane, kc = min(k, K - 1), b0 = rg * RB;
   float acc[RB];
 #pragma unroll
   for (int r = 0; r < RB; ++r) acc[r] = 0.f;
   const int h_lo = hsel < 0 ? 0 : hsel, h_hi = hsel < 0 ? fb.nheads : hsel + 1;
   for (int h = h_lo; h < h_hi; ++h) {
     const int N = fb.n[h];
-    const float* __restrict__ w = fb.w[h];
+    const float* __restrict__ w = fb.w[h] + kc;
     for (int j0 = 0; j0 < N; j0 += JC) {
       __syncthreads();
-      for (int e = tid; e < JC * BPAD; e += 256) {
-        const int jj = e % JC, bb = e / JC;          // consecutive threads: consecutive neurons (coalesced dY rows)
+      for (int e = tid; e < JC * RB; e += 64 * NW) {
+        const int jj = e % JC, r = e / JC;           // consecutive threads: consecutive neurons (coalesced dY rows)
         float v = 0.f;
-        if (bb < B && j0 + jj < N) {
-          v = fb.dy[h][(size_t)bb * N + j0 + jj];
-          if (relu && !(fb.y[h][(size_t)bb * N + j0 + jj] > 0.f)) v = 0.f;
+        if (b0 + r < B && j0 + jj < N) {
+          v = fb.dy[h][(size_t)(b0 + r) * N + j0 + jj];
+          if (relu && !(fb.y[h][(size_t)(b0 + r) * N + j0 + jj] > 0.f)) v = 0.f;
         }
-        dzt[jj][bb] = v;
+        dzt[jj][r] = v;
       }
       __syncthreads();
-      const int jn = min(JC, N - j0);
-      for (int jj = 0; jj < jn; ++jj) {
-        const float wv_ = k < K ? w[(size_t)(j0 + jj) * K + k] : 0.f;
-        const float* dz = &dzt[jj][wv * RB];
+      const int ja = wv * JW, jn = min(JW, N - j0 - ja);            // this wave's neurons of the chunk
+      for (int jj = 0; jj < jn; jj += 8) {
+        float wr[8];
 #pragma unroll
-        for (int r = 0; r < RB; ++r) acc[r] = __builtin_fmaf(dz[r], wv_, acc[r]);
+        for (int u = 0; u < 8; ++u) wr[u] = w[(size_t)(j0 + ja + min(jj + u, jn - 1)) * K];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const float wu = jj + u < jn ? wr[u] : 0.f;
+          const float4 d0 = *reinterpret_cast<const float4*>(&dzt[ja + min(jj + u, jn - 1)][0]);
+          const float4 d1 = *reinterpret_cast<const float4*>(&dzt[ja + min(jj + u, jn - 1)][4]);
+          acc[0] = __builtin_fmaf(d0.x, wu, acc[0]); acc[1] = __builtin_fmaf(d0.y, wu, acc[1]);
+          acc[2] = __builtin_fmaf(d0.z, wu, acc[2]); acc[3] = __builtin_fmaf(d0.w, wu, acc[3]);
+          acc[4] = __builtin_fmaf(d1.x, wu, acc[4]); acc[5] = __builtin_fmaf(d1.y, wu, acc[5]);
+          acc[6] = __builtin_fmaf(d1.z, wu, acc[6]); acc[7] = __builtin_fmaf(d1.w, wu, acc[7]);
+        }
       }
     }
   }
-  if (k < K) {
-    float* out = fb.dx[hsel < 0 ? 0 : hsel];
 #pragma unroll
-    for (int r = 0; r < RB; ++r) {
-      const int bb = wv * RB + r;
-      if (bb < B) out[(size_t)bb * K + k] = acc[r];
-    }
+  for (int r = 0; r < RB; ++r) red[wv][r][lane] = acc[r];
+  __syncthreads();
+  if (tid < RB * 64) {
+    const int r = tid / 64, c = tid % 64;
+    float sum = 0.f;
+#pragma unroll
+    for (int q = 0; q < NW; ++q) sum += red[q][r][c];
+    const int kk = kt * 64 + c;
+    if (kk < K && b0 + r < B) fb.dx[hsel < 0 ? 0 : hsel][(size_t)(b0 + r) * K + kk] = sum;
   }
 }
 
@@ -405,9 +422,8 @@ int istnet_fc_backward(int nheads, int b, int k, const int* n, const float* cons
   if (want_dx) {
     for (int h = 0; h < (shared_x ? 1 : nheads); ++h)
       if (fb.dx[h] == nullptr) return ISTNET_PN2_EINVAL;
-    const int grid = (shared_x ? 1 : nheads) * ceil_div(k, 64);
-    if (b <= 32) hipLaunchKernelGGL(fc_bwd_dx_kernel<32>, dim3(grid), dim3(256), 0, as_stream(stream), fb, b, k, relu);
-    else hipLaunchKernelGGL(fc_bwd_dx_kernel<64>, dim3(grid), dim3(256), 0, as_stream(stream), fb, b, k, relu);
+    const int grid = (shared_x ? 1 : nheads) * ceil_div(k, 64) * ceil_div(b, kFcDxRows);
+    hipLaunchKernelGGL(fc_bwd_dx_kernel, dim3(grid), dim3(64 * kFcDxWaves), 0, as_stream(stream), fb, b, k, relu);
   }
   if (want_dw) {
     for (int h = 0; h < nheads; ++h)

@@ -233,9 +233,15 @@ __global__ __launch_bounds__(kThreads) void upconv3_bwd_kernel(int c4, int hin, 
 // Layout: rows = B * H * W pixels of C channels (C % 4 == 0, C <= 1024); a workgroup walks a range of pixels with
 // thread = (pixel lane, channel quad), so a wave reads whole contiguous pixels.
 // ============================================================================================
-constexpr int kStatPixels = 512;       // pixels per workgroup in the statistics passes
+// pixels per workgroup in the statistics passes: 512 for the decoder's maps (>= 1 M pixels per batch), fewer for the trunk's
+// (18 432 pixels at 24 x 24 x 32 would be 36 workgroups): a power of two aiming at ~2 048 workgroups, at least 32
+__host__ __device__ inline int stat_pixels(long long rows) {
+  int pix = 32;
+  while (pix < 512 && (long long)pix * 2048 < rows) pix *= 2;
+  return pix;
+}
 
-// pass 1 forward: per-channel sum and sum of squares of the pixels [blockIdx.x * kStatPixels, +kStatPixels)
+// pass 1 forward: per-channel sum and sum of squares of the pixels [blockIdx.x * pix, +pix), pix = stat_pixels(rows)
 __global__ __launch_bounds__(kThreads) void nhwc_stats_kernel(long long rows, int c4, const float4* __restrict__ y,
                                                               float* __restrict__ part_sum, float* __restrict__ part_sq,
                                                               int nparts) {
@@ -244,7 +250,8 @@ __global__ __launch_bounds__(kThreads) void nhwc_stats_kernel(long long rows, in
   const int q = threadIdx.x % c4, pl = threadIdx.x / c4;
   float4 s = make_float4(0.f, 0.f, 0.f, 0.f), sq = s;
   if (pl < lanes_p) {
-    const long long p0 = (long long)blockIdx.x * kStatPixels, p1 = min(p0 + kStatPixels, rows);
+    const int pix = stat_pixels(rows);
+    const long long p0 = (long long)blockIdx.x * pix, p1 = min(p0 + pix, rows);
     for (long long p = p0 + pl; p < p1; p += lanes_p) {
       const float4 v = y[p * c4 + q];
       s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
@@ -271,21 +278,26 @@ __global__ __launch_bounds__(kThreads) void nhwc_stats_kernel(long long rows, in
 
 __device__ __forceinline__ float prelu1(float u, float a) { return u > 0.f ? u : a * u; }
 
-// pass 2 forward: z = prelu(scale_c y + shift_c) * mask[b][c]
+// pass 2 forward: z = prelu(scale_c y + shift_c [+ res]) * mask[b][c]   (res: the identity branch of a residual block)
 __global__ __launch_bounds__(kThreads) void nhwc_bn_prelu_apply_kernel(long long n4, int c4, long long hw_c4,
                                                                        const float4* __restrict__ y,
                                                                        const float4* __restrict__ scale,
                                                                        const float4* __restrict__ shift,
                                                                        const float* __restrict__ slope,
                                                                        const float4* __restrict__ mask,
+                                                                       const float4* __restrict__ res,
                                                                        float4* __restrict__ z) {
   const float a = *slope;
   for (long long i = (long long)blockIdx.x * kThreads + threadIdx.x; i < n4; i += (long long)gridDim.x * kThreads) {
     const int q = (int)(i % c4);
     const float4 v = y[i], sc = scale[q], sh = shift[q];
+    float4 u = make_float4(v.x * sc.x + sh.x, v.y * sc.y + sh.y, v.z * sc.z + sh.z, v.w * sc.w + sh.w);
+    if (res != nullptr) {
+      const float4 r = res[i];
+      u.x += r.x; u.y += r.y; u.z += r.z; u.w += r.w;
+    }
     float4 o;
-    o.x = prelu1(v.x * sc.x + sh.x, a); o.y = prelu1(v.y * sc.y + sh.y, a);
-    o.z = prelu1(v.z * sc.z + sh.z, a); o.w = prelu1(v.w * sc.w + sh.w, a);
+    o.x = prelu1(u.x, a); o.y = prelu1(u.y, a); o.z = prelu1(u.z, a); o.w = prelu1(u.w, a);
     if (mask != nullptr) {
       const float4 m = mask[(i / hw_c4) * c4 + q];
       o.x *= m.x; o.y *= m.y; o.z *= m.z; o.w *= m.w;
@@ -299,8 +311,8 @@ __global__ __launch_bounds__(kThreads) void nhwc_bn_prelu_apply_kernel(long long
 __global__ __launch_bounds__(kThreads) void nhwc_bn_prelu_bwd_stats_kernel(
     long long rows, int c4, long long hw, const float4* __restrict__ y, const float4* __restrict__ dz,
     const float4* __restrict__ scale, const float4* __restrict__ shift, const float* __restrict__ slope,
-    const float4* __restrict__ mask, float* __restrict__ part_g, float* __restrict__ part_gy,
-    float* __restrict__ part_slope, int nparts) {
+    const float4* __restrict__ mask, const float4* __restrict__ zs, float4* __restrict__ gout,
+    float* __restrict__ part_g, float* __restrict__ part_gy, float* __restrict__ part_slope, int nparts) {
   extern __shared__ float4 red4[];
   __shared__ float sred[kThreads / 64];
   const int lanes_p = kThreads / c4;
@@ -310,7 +322,8 @@ __global__ __launch_bounds__(kThreads) void nhwc_bn_prelu_bwd_stats_kernel(
   float ds = 0.f;
   if (pl < lanes_p) {
     const float4 sc = scale[q], sh = shift[q];
-    const long long p0 = (long long)blockIdx.x * kStatPixels, p1 = min(p0 + kStatPixels, rows);
+    const int pix = stat_pixels(rows);
+    const long long p0 = (long long)blockIdx.x * pix, p1 = min(p0 + pix, rows);
     for (long long p = p0 + pl; p < p1; p += lanes_p) {
       const float4 v = y[p * c4 + q];
       float4 d = dz[p * c4 + q];
@@ -318,10 +331,16 @@ __global__ __launch_bounds__(kThreads) void nhwc_bn_prelu_bwd_stats_kernel(
         const float4 m = mask[(p / hw) * c4 + q];
         d.x *= m.x; d.y *= m.y; d.z *= m.z; d.w *= m.w;
       }
-      const float ux = v.x * sc.x + sh.x, uy = v.y * sc.y + sh.y, uz = v.z * sc.z + sh.z, uw = v.w * sc.w + sh.w;
-      ds += (d.x * fminf(ux, 0.f) + d.y * fminf(uy, 0.f)) + (d.z * fminf(uz, 0.f) + d.w * fminf(uw, 0.f));
+      float ux = v.x * sc.x + sh.x, uy = v.y * sc.y + sh.y, uz = v.z * sc.z + sh.z, uw = v.w * sc.w + sh.w;
+      if (zs != nullptr) {        // residual block: the activation's argument is u + res; its sign is the saved output's
+        const float4 zv = zs[p * c4 + q];      // (slope >= 0; the slope gradient is not formed on this route)
+        ux = zv.x; uy = zv.y; uz = zv.z; uw = zv.w;
+      } else {
+        ds += (d.x * fminf(ux, 0.f) + d.y * fminf(uy, 0.f)) + (d.z * fminf(uz, 0.f) + d.w * fminf(uw, 0.f));
+      }
       const float gx = ux > 0.f ? d.x : a * d.x, gy = uy > 0.f ? d.y : a * d.y;
       const float gz = uz > 0.f ? d.z : a * d.z, gw = uw > 0.f ? d.w : a * d.w;
+      if (gout != nullptr) gout[p * c4 + q] = make_float4(gx, gy, gz, gw);
       sg.x += gx; sg.y += gy; sg.z += gz; sg.w += gw;
       sgy.x += gx * v.x; sgy.y += gy * v.y; sgy.z += gz * v.z; sgy.w += gw * v.w;
     }
@@ -432,7 +451,11 @@ int istnet_upconv3_bwd_nhwc(int b, int c, int hin, int win, int hout, int wout, 
   return (int)hipGetLastError();
 }
 
-int istnet_nhwc_stat_parts(long long rows) { return rows <= 0 ? 0 : (int)((rows + kStatPixels - 1) / kStatPixels); }
+int istnet_nhwc_stat_parts(long long rows) {
+  if (rows <= 0) return 0;
+  const int pix = stat_pixels(rows);
+  return (int)((rows + pix - 1) / pix);
+}
 
 static bool nhwc_ok(long long rows, int c) { return rows > 0 && c >= 4 && c <= 1024 && c % 4 == 0; }
 
@@ -453,7 +476,36 @@ int istnet_nhwc_bn_prelu_apply(int b, long long hw, int c, const float* y, const
   hipLaunchKernelGGL(nhwc_bn_prelu_apply_kernel, dim3((unsigned)blocks), dim3(kThreads), 0, (hipStream_t)stream, n4, c / 4,
                      hw * (c / 4), reinterpret_cast<const float4*>(y), reinterpret_cast<const float4*>(bn),
                      reinterpret_cast<const float4*>(bn + c), slope, reinterpret_cast<const float4*>(mask),
-                     reinterpret_cast<float4*>(z));
+                     (const float4*)nullptr, reinterpret_cast<float4*>(z));
+  return (int)hipGetLastError();
+}
+
+int istnet_nhwc_bn_act_res_apply(int b, long long hw, int c, const float* y, const float* bn, const float* slope,
+                                 const float* res, float* z, void* stream) {
+  if (b <= 0 || !nhwc_ok(hw, c) || !y || !bn || !slope || !res || !z) return ISTNET_PN2_EINVAL;
+  const long long n4 = (long long)b * hw * (c / 4);
+  long long blocks = (n4 + kThreads * 4 - 1) / (kThreads * 4);
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(nhwc_bn_prelu_apply_kernel, dim3((unsigned)blocks), dim3(kThreads), 0, (hipStream_t)stream, n4, c / 4,
+                     hw * (c / 4), reinterpret_cast<const float4*>(y), reinterpret_cast<const float4*>(bn),
+                     reinterpret_cast<const float4*>(bn + c), slope, (const float4*)nullptr,
+                     reinterpret_cast<const float4*>(res), reinterpret_cast<float4*>(z));
+  return (int)hipGetLastError();
+}
+
+int istnet_nhwc_bn_act_res_bwd_stats(int b, long long hw, int c, const float* y, const float* dz, const float* z,
+                                     const float* bn, const float* slope, float* g, float* part_g, float* part_gy,
+                                     float* part_slope, void* stream) {
+  const long long rows = (long long)b * hw;
+  if (b <= 0 || !nhwc_ok(hw, c) || c / 4 > kThreads || !y || !dz || !z || !bn || !slope || !g || !part_g || !part_gy ||
+      !part_slope)
+    return ISTNET_PN2_EINVAL;
+  const int c4 = c / 4, nparts = istnet_nhwc_stat_parts(rows), lanes_p = kThreads / c4;
+  hipLaunchKernelGGL(nhwc_bn_prelu_bwd_stats_kernel, dim3(nparts), dim3(kThreads), (size_t)2 * lanes_p * c4 * sizeof(float4),
+                     (hipStream_t)stream, rows, c4, hw, reinterpret_cast<const float4*>(y),
+                     reinterpret_cast<const float4*>(dz), reinterpret_cast<const float4*>(bn),
+                     reinterpret_cast<const float4*>(bn + c), slope, (const float4*)nullptr,
+                     reinterpret_cast<const float4*>(z), reinterpret_cast<float4*>(g), part_g, part_gy, part_slope, nparts);
   return (int)hipGetLastError();
 }
 
@@ -467,8 +519,8 @@ int istnet_nhwc_bn_prelu_bwd_stats(int b, long long hw, int c, const float* y, c
   hipLaunchKernelGGL(nhwc_bn_prelu_bwd_stats_kernel, dim3(nparts), dim3(kThreads), (size_t)2 * lanes_p * c4 * sizeof(float4),
                      (hipStream_t)stream, rows, c4, hw, reinterpret_cast<const float4*>(y),
                      reinterpret_cast<const float4*>(dz), reinterpret_cast<const float4*>(bn),
-                     reinterpret_cast<const float4*>(bn + c), slope, reinterpret_cast<const float4*>(mask), part_g, part_gy,
-                     part_slope, nparts);
+                     reinterpret_cast<const float4*>(bn + c), slope, reinterpret_cast<const float4*>(mask),
+                     (const float4*)nullptr, (float4*)nullptr, part_g, part_gy, part_slope, nparts);
   return (int)hipGetLastError();
 }
 

@@ -16,6 +16,7 @@ the pyramid priors are upsampled with align_corners=False, the decoder with alig
 No weights are downloaded (the reference fetches resnet18-5c106cde.pth, resnet.py:205-214).
 """
 import math
+import os
 
 import torch
 import torch.nn as nn
@@ -122,6 +123,110 @@ def _conv3x3(cin, cout, stride=1, dilation=1):
     return nn.Conv2d(cin, cout, kernel_size=3, stride=stride, padding=dilation, dilation=dilation, bias=False)
 
 
+USE_FUSED_TRUNK_NORM = os.environ.get("ISTNET_FUSED_TRUNK_NORM", "1") != "0"   # trunk: BatchNorm2d (batch statistics) [+ identity] + ReLU as two passes per direction
+
+
+class _BnReluFn(torch.autograd.Function):
+    """BatchNorm2d (training statistics) [+ residual] -> ReLU of a channels-last map: the two normalisation sites of a
+    ResNet basic block and the stem (reference model/resnet.py:48-65,166-168).  The framework's sequence is MIOpen's
+    three-kernel BatchNorm, an add and a clamp forward (8 passes over the map with the residual, 5 without) and threshold
+    + three-kernel BatchNorm backward (8); here: statistics + apply forward (4 / 3), statistics + apply backward (7 / 5),
+    the same kernels as the decoder stages (include/istnet_rgb.h: slope 0 is ReLU; with a residual the sign of the
+    activation's argument is read from the saved output and the masked gradient g, which IS the identity branch's
+    gradient, is written by the statistics pass).  ``zero`` / ``one``: one-element constants on the device."""
+
+    @staticmethod
+    def forward(ctx, y, gamma, beta, res, zero, one, running_mean, running_var, momentum, eps):
+        from . import _native
+        lib = _native.lib()
+        b, c, h, w = y.shape
+        dev = y.device
+        rows = b * h * w
+        nparts = lib.istnet_nhwc_stat_parts(rows)
+        part = torch.empty((2, c, nparts), dtype=torch.float32, device=dev)
+        bn = torch.empty((4, c), dtype=torch.float32, device=dev)
+        z = torch.empty_like(y, memory_format=torch.channels_last)
+        with torch.cuda.device(dev):
+            st = torch.cuda.current_stream(dev).cuda_stream
+            _native.check(lib.istnet_nhwc_channel_stats(rows, c, y.data_ptr(), part[0].data_ptr(), part[1].data_ptr(), st),
+                          "nhwc_channel_stats")
+            _native.check(lib.istnet_bn_finalize_fwd(
+                c, nparts, float(rows), part[0].data_ptr(), part[1].data_ptr(), gamma.data_ptr(), beta.data_ptr(), float(eps),
+                float(momentum), running_mean.data_ptr() if running_mean is not None else None,
+                running_var.data_ptr() if running_var is not None else None, bn.data_ptr(), st), "bn_finalize_fwd")
+            if res is None:
+                _native.check(lib.istnet_nhwc_bn_prelu_apply(b, h * w, c, y.data_ptr(), bn.data_ptr(), zero.data_ptr(), None,
+                                                             z.data_ptr(), st), "nhwc_bn_prelu_apply")
+            else:
+                _native.check(lib.istnet_nhwc_bn_act_res_apply(b, h * w, c, y.data_ptr(), bn.data_ptr(), zero.data_ptr(),
+                                                               res.data_ptr(), z.data_ptr(), st), "nhwc_bn_act_res_apply")
+        ctx.has_res = res is not None
+        ctx.save_for_backward(y, gamma, bn, zero, one, z if res is not None else torch.empty(0, device=dev))
+        return z
+
+    @staticmethod
+    def backward(ctx, dz):
+        from . import _native
+        lib = _native.lib()
+        y, gamma, bn, zero, one, z = ctx.saved_tensors
+        b, c, h, w = y.shape
+        dev = y.device
+        rows = b * h * w
+        dz = dz.contiguous(memory_format=torch.channels_last)
+        nparts = lib.istnet_nhwc_stat_parts(rows)
+        part = torch.empty((2, c, nparts), dtype=torch.float32, device=dev)
+        pslope = torch.empty((nparts,), dtype=torch.float32, device=dev)
+        dgamma = torch.empty((c,), dtype=torch.float32, device=dev)
+        dbeta = torch.empty((c,), dtype=torch.float32, device=dev)
+        bwdc = torch.empty((3, c), dtype=torch.float32, device=dev)
+        dy = torch.empty_like(y, memory_format=torch.channels_last)
+        g = torch.empty_like(y, memory_format=torch.channels_last) if ctx.has_res else None
+        with torch.cuda.device(dev):
+            st = torch.cuda.current_stream(dev).cuda_stream
+            if g is None:
+                _native.check(lib.istnet_nhwc_bn_prelu_bwd_stats(b, h * w, c, y.data_ptr(), dz.data_ptr(), bn.data_ptr(),
+                                                                 zero.data_ptr(), None, part[0].data_ptr(), part[1].data_ptr(),
+                                                                 pslope.data_ptr(), st), "nhwc_bn_prelu_bwd_stats")
+            else:
+                _native.check(lib.istnet_nhwc_bn_act_res_bwd_stats(b, h * w, c, y.data_ptr(), dz.data_ptr(), z.data_ptr(),
+                                                                   bn.data_ptr(), zero.data_ptr(), g.data_ptr(),
+                                                                   part[0].data_ptr(), part[1].data_ptr(), pslope.data_ptr(),
+                                                                   st), "nhwc_bn_act_res_bwd_stats")
+            _native.check(lib.istnet_bn_finalize_bwd(c, nparts, float(rows), 1, part[0].data_ptr(), part[1].data_ptr(),
+                                                     gamma.data_ptr(), bn.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(),
+                                                     bwdc.data_ptr(), st), "bn_finalize_bwd")
+            if g is None:
+                _native.check(lib.istnet_nhwc_bn_prelu_bwd_apply(b, h * w, c, y.data_ptr(), dz.data_ptr(), bn.data_ptr(),
+                                                                 bwdc.data_ptr(), zero.data_ptr(), None, dy.data_ptr(), st),
+                              "nhwc_bn_prelu_bwd_apply")
+            else:                   # g already carries the activation's mask: slope 1 makes the apply pass take it as it is
+                _native.check(lib.istnet_nhwc_bn_prelu_bwd_apply(b, h * w, c, y.data_ptr(), g.data_ptr(), bn.data_ptr(),
+                                                                 bwdc.data_ptr(), one.data_ptr(), None, dy.data_ptr(), st),
+                              "nhwc_bn_prelu_bwd_apply")
+        return dy, dgamma, dbeta, g, None, None, None, None, None, None
+
+
+def _bn_relu(bn, y, res, owner):
+    """relu(bn(y) [+ res]) -- by _BnReluFn when the map is a channels-last float32 CUDA tensor and ``bn`` normalises with
+    batch statistics, by the framework's modules otherwise (eval mode, CPU, other layouts)."""
+    c = y.shape[1] if y.dim() == 4 else 0
+    if (USE_FUSED_TRUNK_NORM and y.is_cuda and y.dtype == torch.float32 and y.dim() == 4 and bn.training and bn.affine
+            and bn.momentum is not None and c % 4 == 0 and 4 <= c <= 1024 and torch.is_grad_enabled()
+            and y.is_contiguous(memory_format=torch.channels_last)
+            and (res is None or (res.shape == y.shape and res.dtype == torch.float32))):
+        if res is not None:
+            res = res.contiguous(memory_format=torch.channels_last)
+        if bn.track_running_stats and bn.num_batches_tracked is not None:
+            bn.num_batches_tracked.add_(1)
+        return _BnReluFn.apply(y, bn.weight, bn.bias, res, owner._zero, owner._one,
+                               bn.running_mean if bn.track_running_stats else None,
+                               bn.running_var if bn.track_running_stats else None, bn.momentum, bn.eps)
+    out = bn(y)
+    if res is not None:
+        out = out + res
+    return torch.relu(out)
+
+
 class BasicBlock(nn.Module):
     expansion = 1
 
@@ -134,12 +239,12 @@ class BasicBlock(nn.Module):
         self.bn2 = nn.BatchNorm2d(planes)
         self.downsample = downsample
         self.stride = stride
+        self.register_buffer("_zero", torch.zeros(1), persistent=False)    # ReLU as a PReLU slope / identity slope
+        self.register_buffer("_one", torch.ones(1), persistent=False)
 
     def forward(self, x):
-        out = self.relu(self.bn1(self.conv1(x)))
-        out = self.bn2(self.conv2(out))
-        out = out + (x if self.downsample is None else self.downsample(x))
-        return self.relu(out)
+        out = _bn_relu(self.bn1, self.conv1(x), None, self)
+        return _bn_relu(self.bn2, self.conv2(out), x if self.downsample is None else self.downsample(x), self)
 
 
 class ResNet(nn.Module):
@@ -158,6 +263,8 @@ class ResNet(nn.Module):
         self.layer4 = self._stage(512, layers[3])   # reference passes dilation=4: ignored there
         self.avgpool = nn.AvgPool2d(7)
         self.fc = nn.Linear(512, num_classes)
+        self.register_buffer("_zero", torch.zeros(1), persistent=False)
+        self.register_buffer("_one", torch.ones(1), persistent=False)
         for m in self.modules():
             if isinstance(m, nn.Conv2d):
                 fan = m.kernel_size[0] * m.kernel_size[1] * m.out_channels
@@ -182,7 +289,7 @@ class ResNet(nn.Module):
         return nn.Sequential(*seq)
 
     def forward(self, x):
-        x = self.maxpool(self.relu(self.bn1(self.conv1(x))))
+        x = self.maxpool(_bn_relu(self.bn1, self.conv1(x), None, self))
         x = self.layer2(self.layer1(x))
         x3 = self.layer3(x)
         return self.layer4(x3), x3
@@ -353,7 +460,7 @@ class _BnPReLUDropFn(torch.autograd.Function):
     passes per direction (include/istnet_rgb.h, istnet_nhwc_*; finalizes of include/istnet_pw.h): the tail of a decoder
     stage (reference model/modules.py:25-34,63-65).  The framework's sequence -- MIOpen's two-kernel BatchNorm, a PReLU
     kernel, a dropout multiply -- moves the 75-302 MB map 7 times forward and ~10 times backward; this node 3 and 5 times.
-    Statistics as in the point branch: fp32 partial sums per 512 pixels, combined in float64; running statistics updated
+    Statistics as in the point branch: fp32 partial sums per 32-512 pixels, combined in float64; running statistics updated
     with torch's semantics (momentum, unbiased variance).  mask: (B, C) Dropout2d factors (0 or 1 / (1 - p)) or None."""
 
     @staticmethod

@@ -309,3 +309,50 @@ def test_fused_batchnorm_prelu_dropout_of_a_channels_last_map(b, c, h, w, with_m
     # the input gradient of a batch-statistics BatchNorm sums to zero per channel: what the shortcut reports must be at the
     # round-off level of the honest column sum
     assert float(colsum.abs().max()) < 1e-2 * float(yy.grad.abs().sum(dim=(0, 2, 3)).max())
+
+
+@pytest.mark.parametrize("inplanes,planes,stride,h", [(64, 64, 1, 24), (64, 128, 2, 24), (16, 16, 1, 9)])
+def test_fused_trunk_batchnorm_relu_of_a_basic_block(inplanes, planes, stride, h):
+    """A ResNet basic block in training mode through _BnReluFn (BatchNorm + ReLU and BatchNorm + identity + ReLU as two
+    passes per direction, include/istnet_rgb.h) against the same block evaluated in float64 by the framework's modules:
+    output, input gradient, every parameter gradient, running statistics and the batch counters."""
+    import copy
+    torch.manual_seed(inplanes + planes)
+    ds = None
+    if stride != 1 or inplanes != planes:
+        ds = torch.nn.Sequential(torch.nn.Conv2d(inplanes, planes, 1, stride=stride, bias=False), torch.nn.BatchNorm2d(planes))
+    blk = rgb_branch.BasicBlock(inplanes, planes, stride, ds).to(DEV).train().to(memory_format=torch.channels_last)
+    with torch.no_grad():
+        for m in blk.modules():
+            if isinstance(m, torch.nn.BatchNorm2d):
+                m.weight.uniform_(0.5, 1.5); m.bias.normal_(0, 0.2)
+    ref = copy.deepcopy(blk).double()
+    x = torch.randn(3, inplanes, h, h, device=DEV).contiguous(memory_format=torch.channels_last)
+    wgt = torch.randn(3, planes, (h - 1) // stride + 1, (h - 1) // stride + 1, device=DEV)
+    xx = x.clone().requires_grad_(True)
+    assert rgb_branch.USE_FUSED_TRUNK_NORM
+    out = blk(xx)
+    assert type(out.grad_fn).__name__ == "_BnReluFnBackward"
+    (out * wgt).sum().backward()
+    saved = rgb_branch.USE_FUSED_TRUNK_NORM
+    rgb_branch.USE_FUSED_TRUNK_NORM = False
+    try:
+        x64 = x.double().clone().requires_grad_(True)
+        out64 = ref(x64)
+        (out64 * wgt.double()).sum().backward()
+    finally:
+        rgb_branch.USE_FUSED_TRUNK_NORM = saved
+    rel = lambda a, c_: float((a.double() - c_).abs().max() / (c_.abs().max() + 1e-30))
+    assert rel(out.detach(), out64.detach()) < 1e-5
+    assert rel(xx.grad, x64.grad) < 1e-4
+    for (n, p), q in zip(blk.named_parameters(), ref.parameters()):
+        assert rel(p.grad, q.grad) < 2e-4, n
+    for (n, u), v in zip(blk.state_dict().items(), ref.state_dict().values()):
+        if "running" in n:
+            assert rel(u, v) < 1e-5, n
+        if "num_batches" in n:
+            assert int(u) == int(v) == 1, n
+    # eval mode takes the framework's modules and agrees with them
+    blk.eval(); ref.eval()
+    with torch.no_grad():
+        assert rel(blk(x), ref(x.double())) < 1e-5
