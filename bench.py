@@ -468,6 +468,11 @@ def main():
                          "one rank: exercises RCCL + HIP-graph capture on a 1-GPU box")
     ap.add_argument("--same-device", action="store_true",
                     help="dry run of the N>1 control flow on a 1-GPU box: every rank uses cuda:0 (gloo only)")
+    ap.add_argument("--tune-gemms", action="store_true",
+                    help="istnet / infer: search the library-GEMM solutions of the RGB decoder with TunableOp and record "
+                         "them in gpurun_out/tunableop_gfx950.csv (minutes; copy the table to ist-net_amd/tuning/)")
+    ap.add_argument("--no-tuned-gemms", action="store_true",
+                    help="istnet / infer: the library's heuristic GEMM solutions instead of the recorded table")
     ap.add_argument("--cpu-dry-run", action="store_true",
                     help="NOT a measurement: run the launch / rendezvous / barrier / all-reduce / rank-0-JSON control "
                          "flow of --gpus N on host cores (gloo, B=2, the cpu_baseline port over the oracle ops) so the "
@@ -536,6 +541,18 @@ def main():
             os.dup2(saved_fd, 1)
             os.close(saved_fd)
 
+    tuned_table = None
+    if args.workload in ("istnet", "infer") and not args.cpu_dry_run and not args.no_tuned_gemms:
+        from istnet_amd import tuned_gemm
+        if args.tune_gemms:
+            os.makedirs("gpurun_out", exist_ok=True)
+            out = os.path.join("gpurun_out", "tunableop_gfx950.csv")
+            if os.path.isfile(tuned_gemm.DEFAULT_TABLE) and not os.path.isfile(out):
+                import shutil
+                shutil.copyfile(tuned_gemm.DEFAULT_TABLE, out)      # new shapes are added to the recorded ones
+            tuned_table = tuned_gemm.enable(out, tune=True)
+        else:
+            tuned_table = tuned_gemm.enable()
     if args.workload == "sa_layer":
         if dist_on:
             raise SystemExit("--workload sa_layer is a single-GPU parity / timing case (BASELINE configs[0])")
@@ -639,6 +656,9 @@ def main():
                        "batch_per_gpu": batch_size, "npoints": npoints, "global_batch": batch_size * world,
                        "parallelism": f"dp{world}" + (" (one-rank dry run of the RCCL path)" if args.force_dist and world == 1 else ""),
                        "launch": mode,
+                       "library_gemms": (None if args.workload == "encoder" else
+                                         ("TunableOp look-up, " + os.path.basename(tuned_table)) if tuned_table
+                                         else "library heuristic"),
                        "gradient_exchange": (None if not dist_on else
                                              {"bytes_per_step": int(opt.flat_grad.numel() * opt.flat_grad.element_size()),
                                               "buckets": len(grad_sync.buckets),

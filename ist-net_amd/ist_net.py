@@ -141,8 +141,11 @@ class WorldSpaceEnhancer(nn.Module):
         if not freeze:
             self.pose_estimator = HeavyEstimator()
 
-    def forward(self, pts, pts_w_gt, rgb_local, pts_local):
-        pts_w_local_gt = self.extractor(pts_w_gt)
+    def forward(self, pts, pts_w_gt, rgb_local, pts_local, pts_w_local_gt=None):
+        """``pts_w_local_gt``: the extractor's output when the caller has already run it (IST_Net.forward does, beside the
+        RGB branch: it depends on the ground-truth coordinates only)."""
+        if pts_w_local_gt is None:
+            pts_w_local_gt = self.extractor(pts_w_gt)
         if self.freeze:
             return None, None, None, pts_w_local_gt
         r, t, s = self.pose_estimator(pts, pts_w_gt, rgb_local.detach(), pts_local.detach(), pts_w_local_gt)
@@ -150,6 +153,7 @@ class WorldSpaceEnhancer(nn.Module):
 
 
 USE_RGB_STREAM = True
+USE_EARLY_WORLD_EXTRACTOR = os.environ.get("ISTNET_EARLY_WORLD", "1") != "0"   # training: the auxiliary world-space encoder beside the RGB branch (it reads inputs only)
 USE_GATHER_FIRST = True
 _RGB_STREAMS = {}
 
@@ -214,6 +218,12 @@ class IST_Net(nn.Module):
             rgb_local = self._rgb_local(inputs, b)
 
         pts_local = self.pts_cam_extractor(pts)
+        pts_w_local_gt = None
+        if self.training and USE_EARLY_WORLD_EXTRACTOR:
+            # the world-space encoder of the auxiliary branch reads the ground-truth coordinates only (reference ist_net.py:50-51 calls
+            # it last): issued here, its sampling chain and its many short kernels run beside the RGB branch instead of
+            # heading the serial part of the step; backward follows the same order in reverse
+            pts_w_local_gt = self.world_enhancer.extractor(inputs["qo"])
         if side is not None:
             main.wait_stream(side)
             rgb_local.record_stream(main)
@@ -226,7 +236,7 @@ class IST_Net(nn.Module):
         end_points["pred_translation"] = t + c.squeeze(1)
         end_points["pred_size"] = s
         if self.training:
-            r_w, t_w, s_w, pts_w_local_gt = self.world_enhancer(pts, inputs["qo"], rgb_local, pts_local)
+            r_w, t_w, s_w, pts_w_local_gt = self.world_enhancer(pts, inputs["qo"], rgb_local, pts_local, pts_w_local_gt)
             end_points["pts_w_local"] = pts_w_local
             end_points["pts_w_local_gt"] = pts_w_local_gt
             end_points["pred_rotation_aux_cam"] = r_cam
