@@ -77,7 +77,7 @@ def test_pose_dis_and_smooth_l1():
     assert _rel(a.grad, a64.grad) < 1e-5
 
 
-@pytest.mark.parametrize("b", [2, 32, 64])
+@pytest.mark.parametrize("b", [2, 5, 32, 33, 64])
 def test_fc_heads_forward_backward_vs_float64(b):
     """The three heads of an estimator: outputs, the gradient of the pooled feature and of all 18 parameters within 1e-4
     relative of a float64 evaluation of the nn.Sequential modules."""

@@ -28,7 +28,7 @@ def run(tag):
         t2 = bench(lambda: dq @ wr.t())
         t3 = bench(lambda: p.t() @ dq)
         gf = 2.0 * m * k * n / 1e9
-        print(f"{tag:10s} {name}: fwd {t1:7.1f} us ({gf / t1 * 1e-3:6.1f} TF)  dgrad {t2:7.1f} us ({gf / t2 * 1e-3:6.1f} TF)  wgrad {t3:7.1f} us ({gf / t3 * 1e-3:6.1f} TF)")
+        print(f"{tag:10s} {name}: fwd {t1:7.1f} us ({gf / t1 * 1e3:6.1f} TF)  dgrad {t2:7.1f} us ({gf / t2 * 1e3:6.1f} TF)  wgrad {t3:7.1f} us ({gf / t3 * 1e3:6.1f} TF)")
         tot += t1 + t2 + t3
     print(f"{tag:10s} total {tot / 1e3:.2f} ms")
 
@@ -41,6 +41,6 @@ elif mode == "hipblaslt":
 elif mode == "tunable":
     torch.cuda.tunable.enable(True)
     torch.cuda.tunable.set_max_tuning_duration(300)
-    torch.cuda.tunable.set_filename("gpurun_out/tunableop_decoder.csv")
+    torch.cuda.tunable.set_filename("/tmp/tunableop_decoder.csv")
 print("preferred:", torch.backends.cuda.preferred_blas_library())
 run(mode)

@@ -19,6 +19,12 @@ python bench.py --no-prefetch --no-roofline --no-cpu-baseline --steps 50 --warmu
 python tools/aten_in_step.py encoder 2>&1 | grep -v "amdgpu.ids\|Warning\|warn" > $O/framework_kernels_encoder.txt
 python tools/aten_in_step.py istnet 2>&1 | grep -v "amdgpu.ids\|Warning\|warn" > $O/framework_kernels_istnet.txt
 python tools/bench_fps_chain.py 2>&1 | grep -v amdgpu.ids > $O/fps_chain.txt
-for f in bench_final bench_sa_layer bench_istnet_full_model bench_infer_full_model bench_istnet_force_dist bench_noprefetch; do python -c "
+python tools/gemm_launch_table.py 2>&1 | grep -v amdgpu.ids > $O/encoder_gemm_launch_table.txt
+python tools/step_timeline.py 2>&1 | grep -v amdgpu.ids > $O/step_timeline.txt
+python tools/istnet_kernel_times.py --timeline 2>/dev/null > $O/istnet_kernel_times.txt
+python tools/istnet_kernel_times.py --infer --timeline 2>/dev/null > $O/infer_kernel_times.txt
+python bench.py --workload istnet --no-tuned-gemms --no-roofline --steps 30 --warmup 5 2>/dev/null | tail -1 > $O/bench_istnet_untuned_gemms.json
+for m in default tunable; do python tools/exp/decoder_gemm_libs.py $m 2>&1 | grep -v "Warning\|amdgpu.ids"; done > $O/decoder_gemm_libraries.txt
+for f in bench_final bench_sa_layer bench_istnet_full_model bench_istnet_untuned_gemms bench_infer_full_model bench_istnet_force_dist bench_noprefetch; do python -c "
 import json; d=json.load(open('$O/$f.json')); print('$f', round(d['ms_per_step'],4), round(d['value'],1), (d.get('roofline') or {}).get('frac'), (d.get('unpipelined') or {}).get('ms_per_step'))"; done
 head -8 $O/encoder_kernel_stats.txt | cut -c1-150

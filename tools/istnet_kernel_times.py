@@ -9,9 +9,20 @@ from istnet_amd.optim import FlatAdam
 
 dev = torch.device("cuda:0")
 model = bench.make_istnet(dev)
-fwd = [bench.make_istnet_fwd_bwd(model, bench.istnet_batch(32, 1024, 0, dev))]
-opt = FlatAdam(model.parameters(), lr=1e-4)
-step = bench.make_eager_step(fwd, opt, 1)
+if "--infer" in sys.argv:          # config 5: eval mode, B=64 N=2048, post-processing and the copy to the host included
+    from istnet_amd import postprocess
+    model.eval()
+    batch = bench.istnet_batch(64, 2048, seed=0, device=dev)
+
+    def step():
+        with torch.no_grad():
+            ep = model(batch)
+            rts, scales = postprocess.assemble_pred_RTs(ep["pred_rotation"], ep["pred_translation"], ep["pred_size"])
+            return rts.cpu(), scales.cpu()
+else:
+    fwd = [bench.make_istnet_fwd_bwd(model, bench.istnet_batch(32, 1024, 0, dev))]
+    opt = FlatAdam(model.parameters(), lr=1e-4)
+    step = bench.make_eager_step(fwd, opt, 1)
 for _ in range(5):
     step()
 torch.cuda.synchronize()
@@ -46,7 +57,7 @@ def cat(n):
 
 
 total = sum(s for _, s in agg.values())
-print(f"# full model eager step: {wall:.2f} ms wall; sum of device time {total / 1e3:.2f} ms in {sum(c for c, _ in agg.values())} activities")
+print(f"# full model eager {'inference batch' if '--infer' in sys.argv else 'training step'}: {wall:.2f} ms wall; sum of device time {total / 1e3:.2f} ms in {sum(c for c, _ in agg.values())} activities")
 cats = {}
 for n, (c, s) in agg.items():
     k = cat(n)
