@@ -38,6 +38,25 @@ ISTNET_PN2_API int istnet_backproject_choose(int count, int n, int h, int w, con
                                              double fx, double fy, double cx, double cy, double norm_scale,
                                              int img_size, float *pts, long long *choose_out, void *stream);
 
+/* replaces provider/dataset.py:213-219 (TrainingDataset, without the random colour jitter of :218) and :397-399
+ * (TestDataset): crop [rmin:rmax, cmin:cmax] of the (h, w, 3) uint8 image, cv2.resize(..., (img_size, img_size),
+ * INTER_LINEAR), ToTensor and Normalize(mean, std) -- one thread per output pixel.
+ *   image            device memory, (h, w, 3) uint8; instance i reads image + i * image_stride BYTES (0: one image for all
+ *                    instances, as the detections of one test image)
+ *   reverse_channels 1: channel c of the output is channel 2 - c of the image (cv2.imread returns BGR, dataset.py:214)
+ *   bbox             (count, 4) int32 rmin, rmax, cmin, cmax (get_bbox); clamped into the image
+ *   mean, std        HOST pointers, 3 floats each (dataset.py:103-105: ImageNet statistics)
+ *   out_u8           (count, img_size, img_size, 3) uint8 or NULL: the resized crop (what the colour jitter would take)
+ *   out              (count, 3, img_size, img_size) float32 or NULL: ((u8 / 255) - mean) / std in float32, IEEE division
+ * The resize is OpenCV's generic 8-bit path: taps and weights from fx = (float)((dx + 0.5) * scale - 0.5) in 11-bit
+ * fixed point (round half to even), horizontal pass in int32, vertical pass
+ * (((b0 * (S0 >> 4)) >> 16) + ((b1 * (S1 >> 4)) >> 16) + 2) >> 2.  Bit-exact with the numpy restatement
+ * oracle/preproc_oracle.py (parity unpinned: cv2 is not importable in this image). */
+ISTNET_PN2_API int istnet_crop_resize_normalize(int count, int h, int w, const unsigned char *image,
+                                                long long image_stride, int reverse_channels, const int *bbox,
+                                                int img_size, const float *mean, const float *std,
+                                                unsigned char *out_u8, float *out, void *stream);
+
 /* replaces fill_in_multiscale of utils/data_utils.py:357-510 as fill_missing calls it (:516-540: fill_type 'multiscale',
  * extrapolate False, blur_type 'bilateral'; provider/dataset.py:172-173,361-362): morphological depth completion of b
  * float32 depth images (b, h, w) already scaled to the unit the thresholds are written in (metres).  Pass by pass the

@@ -39,6 +39,7 @@ SIGNATURES = {
     "istnet_upconv3_fwd_nhwc": [_i, _i, _i, _i, _i, _i, _p, _p, _p, _p],
     "istnet_upconv3_bwd_nhwc": [_i, _i, _i, _i, _i, _i, _p, _p, _p],
     "istnet_backproject_choose": [_i, _i, _i, _i, _p, _i, _l, _p, _p, _d, _d, _d, _d, _d, _i, _p, _p, _p],
+    "istnet_crop_resize_normalize": [_i, _i, _i, _p, _l, _i, _p, _i, _p, _p, _p, _p, _p],
     "istnet_depth_fill_scratch_floats": [_i, _i, _i],
     "istnet_depth_fill_multiscale": [_i, _i, _i, _p, _f, _p, _p, _p],
     "istnet_pn2_set_tuning": [_i, _i],

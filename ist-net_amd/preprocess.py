@@ -4,8 +4,10 @@
 instance crop and the sampled pixel list into the network inputs ``pts`` and ``choose``
 (provider/dataset.py:203-210,226-231 for training, :348-355,392,401-405 for testing).  The host code there builds
 the whole (480,640,3) float64 point map for every image; the kernel (csrc/preproc.hip through
-include/istnet_preproc.h) back-projects only the sampled pixels, bit-exactly.  Mask logic, random sampling
-(`np.random.choice`), image decoding and the RGB resize stay with the caller.
+include/istnet_preproc.h) back-projects only the sampled pixels, bit-exactly.  ``get_bbox`` (the square crop window),
+``crop_resize_normalize`` (RGB crop -> cv2-style bilinear resize -> ToTensor / Normalize), ``fill_missing`` (depth
+completion) and ``instance_labels`` cover the rest of the tensor arithmetic of ``__getitem__``; image decoding, the mask
+test, the random pixel sampling (`np.random.choice`) and the random colour jitter stay with the caller.
 """
 import torch
 
@@ -44,6 +46,60 @@ def backproject_choose(depth, bboxes, choose, intrinsics=REAL_INTRINSICS, norm_s
     if rc != 0:
         raise RuntimeError(f"istnet_backproject_choose failed with code {rc}")
     return pts, out
+
+
+IMAGENET_MEAN = (0.485, 0.456, 0.406)       # [ref dataset.py:103-105]
+IMAGENET_STD = (0.229, 0.224, 0.225)
+
+
+def get_bbox(bboxes, img_height=480, img_length=640):
+    """utils/data_utils.py:43-71 for a batch: detection boxes (count, 4) = y1, x1, y2, x2 -> square crop windows (count, 4) =
+    rmin, rmax, cmin, cmax (side a multiple of 40 pixels, at most 440, centred on the box, pushed back inside the image).
+    Integer tensor arithmetic, any device."""
+    bb = torch.as_tensor(bboxes).to(torch.int64).reshape(-1, 4)
+    y1, x1, y2, x2 = bb.unbind(1)
+    window = torch.clamp((torch.maximum(y2 - y1, x2 - x1).div(40, rounding_mode="floor") + 1) * 40, max=440)
+    half = window.div(2, rounding_mode="trunc")                   # int(window_size / 2)
+    cy, cx = (y1 + y2).div(2, rounding_mode="floor"), (x1 + x2).div(2, rounding_mode="floor")
+    rmin, rmax, cmin, cmax = cy - half, cy + half, cx - half, cx + half
+    d = torch.clamp(-rmin, min=0); rmin, rmax = rmin + d, rmax + d          # the four `if` blocks, in the reference's order
+    d = torch.clamp(-cmin, min=0); cmin, cmax = cmin + d, cmax + d
+    d = torch.clamp(rmax - img_height, min=0); rmin, rmax = rmin - d, rmax - d
+    d = torch.clamp(cmax - img_length, min=0); cmin, cmax = cmin - d, cmax - d
+    return torch.stack([rmin, rmax, cmin, cmax], dim=1).to(torch.int32)
+
+
+def crop_resize_normalize(image, bboxes, img_size=192, reverse_channels=True, mean=IMAGENET_MEAN, std=IMAGENET_STD,
+                          return_uint8=False):
+    """provider/dataset.py:213-219 / :397-399 on the GPU: ``image`` (h, w, 3) uint8 shared by all instances or
+    (count, h, w, 3), as cv2.imread returns it (BGR: ``reverse_channels``); bboxes (count, 4) rmin, rmax, cmin, cmax.
+    Returns the network input (count, 3, img_size, img_size) float32 -- crop, cv2.INTER_LINEAR resize (OpenCV's 8-bit
+    fixed-point arithmetic), / 255, Normalize -- and with ``return_uint8`` also the resized crops (count, S, S, 3) uint8
+    (what a colour jitter would be applied to).  CUDA tensors only."""
+    if not image.is_cuda:
+        raise RuntimeError("crop_resize_normalize: CPU not supported")
+    if image.dtype != torch.uint8 or image.dim() not in (3, 4) or image.shape[-1] != 3:
+        raise TypeError("crop_resize_normalize: image must be uint8 (h, w, 3) or (count, h, w, 3)")
+    bboxes = torch.as_tensor(bboxes).to(device=image.device, dtype=torch.int32).reshape(-1, 4).contiguous()
+    count = bboxes.size(0)
+    if image.dim() == 4 and image.size(0) != count:
+        raise ValueError("crop_resize_normalize: one image per instance, or one shared image")
+    image = image.contiguous()
+    h, w = image.shape[-3], image.shape[-2]
+    out = torch.empty(count, 3, img_size, img_size, dtype=torch.float32, device=image.device)
+    small = torch.empty(count, img_size, img_size, 3, dtype=torch.uint8, device=image.device) if return_uint8 else None
+    import ctypes
+    m = (ctypes.c_float * 3)(*[float(v) for v in mean])
+    sd = (ctypes.c_float * 3)(*[float(v) for v in std])
+    with torch.cuda.device(image.device):
+        rc = _native.lib().istnet_crop_resize_normalize(
+            count, h, w, image.data_ptr(), h * w * 3 if image.dim() == 4 else 0, 1 if reverse_channels else 0,
+            bboxes.data_ptr(), int(img_size), ctypes.cast(m, ctypes.c_void_p), ctypes.cast(sd, ctypes.c_void_p),
+            small.data_ptr() if small is not None else None, out.data_ptr(),
+            torch.cuda.current_stream(image.device).cuda_stream)
+    if rc != 0:
+        raise RuntimeError(f"istnet_crop_resize_normalize failed with code {rc}")
+    return (out, small) if return_uint8 else out
 
 
 def fill_missing(dpt, cam_scale, scale_2_80m, fill_type="multiscale", extrapolate=False, show_process=False,

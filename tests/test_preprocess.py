@@ -171,3 +171,68 @@ def test_instance_labels_match_numpy_restatement():
         np.testing.assert_allclose(got[3][i].numpy(), srt, rtol=1e-6, atol=1e-7)
     # a symmetric class: the canonical rotation has no in-plane component left (R[0,2] == R[2,0])
     assert abs(float(got[0][0][0, 2] - got[0][0][2, 0])) < 1e-6
+
+
+def test_get_bbox_matches_the_scalar_restatement():
+    """preprocess.get_bbox (batched integer tensor arithmetic) against the statement-by-statement restatement of
+    utils/data_utils.py:43-71, including windows pushed back from every image border and the 440-pixel cap."""
+    from istnet_amd import preprocess
+    rng = np.random.default_rng(3)
+    boxes = []
+    for _ in range(4000):
+        y1, x1 = int(rng.integers(0, 479)), int(rng.integers(0, 639))
+        boxes.append((y1, x1, int(rng.integers(y1 + 1, 480)), int(rng.integers(x1 + 1, 640))))
+    boxes += [(0, 0, 479, 639), (0, 0, 10, 10), (470, 630, 479, 639), (0, 600, 30, 639), (200, 0, 479, 50)]
+    got = preprocess.get_bbox(torch.tensor(boxes)).tolist()
+    for b, g in zip(boxes, got):
+        assert tuple(g) == preproc_oracle.get_bbox(b), b
+    assert preproc_oracle.get_bbox((100, 200, 180, 330)) == (60, 220, 185, 345)       # hand-computed: window 160
+    assert preproc_oracle.get_bbox((0, 0, 50, 60)) == (0, 80, 0, 80)                  # pushed back from the corner
+
+
+def test_resize_oracle_known_answers():
+    """The cv2.INTER_LINEAR restatement: a constant image stays constant, an integer 2x down-sampling averages 2 x 2 blocks
+    (taps at .5 / .5: (a + b + c + d + 2) >> 2 in this fixed-point form), an identity resize returns the image, and the result
+    is within one grey level of a float bilinear interpolation with half-pixel centres."""
+    rng = np.random.default_rng(0)
+    flat = np.full((40, 40, 3), 77, np.uint8)
+    assert (preproc_oracle.resize_linear_u8(flat, 192) == 77).all()
+    img = rng.integers(0, 256, (80, 80, 3), dtype=np.uint8)
+    np.testing.assert_array_equal(preproc_oracle.resize_linear_u8(img, 80), img)
+    half = preproc_oracle.resize_linear_u8(img, 40)
+    blocks = img.astype(np.int64).reshape(40, 2, 40, 2, 3)
+    want = ((((1024 * ((blocks[:, 0, :, 0] * 1024 + blocks[:, 0, :, 1] * 1024) >> 4)) >> 16)
+             + ((1024 * ((blocks[:, 1, :, 0] * 1024 + blocks[:, 1, :, 1] * 1024) >> 4)) >> 16) + 2) >> 2)
+    np.testing.assert_array_equal(half, want.astype(np.uint8))
+    assert np.abs(half.astype(np.int64) - np.round(blocks.mean(axis=(1, 3)))).max() <= 1
+    big = preproc_oracle.resize_linear_u8(img, 192).astype(np.float64)
+    ref = torch.nn.functional.interpolate(torch.from_numpy(img).permute(2, 0, 1)[None].double(), size=(192, 192),
+                                          mode="bilinear", align_corners=False)[0].permute(1, 2, 0).numpy()
+    assert np.abs(big - ref).max() < 1.0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shared", [True, False])
+def test_crop_resize_normalize_matches_oracle_bit_exact(shared):
+    """istnet_crop_resize_normalize against the numpy restatement: resized uint8 crops equal, normalised float32 tensors equal
+    to the bit, for windows of every size get_bbox produces (40 ... 440) and both channel orders."""
+    from istnet_amd import preprocess
+    rng = np.random.default_rng(11)
+    count = 7
+    imgs = rng.integers(0, 256, (1 if shared else count, 480, 640, 3), dtype=np.uint8)
+    boxes, _ = _instances(rng, count, 4)
+    dev = torch.device("cuda:0")
+    image = torch.from_numpy(imgs[0] if shared else imgs).to(dev)
+    for rev in (True, False):
+        out, small = preprocess.crop_resize_normalize(image, torch.from_numpy(boxes), 192, reverse_channels=rev,
+                                                      return_uint8=True)
+        for i in range(count):
+            want_small, want = preproc_oracle.crop_resize_normalize(imgs[0 if shared else i], tuple(boxes[i]), 192, rev)
+            np.testing.assert_array_equal(small[i].cpu().numpy(), want_small)
+            np.testing.assert_array_equal(out[i].cpu().numpy().view(np.uint32), want.view(np.uint32))
+    only = preprocess.crop_resize_normalize(image, torch.from_numpy(boxes), 64)
+    assert only.shape == (count, 3, 64, 64)
+    with pytest.raises(RuntimeError):
+        preprocess.crop_resize_normalize(image.cpu(), torch.from_numpy(boxes))
+    with pytest.raises(TypeError):
+        preprocess.crop_resize_normalize(image.float(), torch.from_numpy(boxes))
