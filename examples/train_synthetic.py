@@ -24,6 +24,7 @@ from istnet_amd.optim import FlatAdam  # noqa: E402
 from istnet_amd.parallel import OverlappedFlatReducer, broadcast_parameters  # noqa: E402
 from istnet_amd.pointnet2.pytorch_utils import BNMomentumScheduler  # noqa: E402
 from istnet_amd.rgb_branch import ModifiedResnet  # noqa: E402
+from istnet_amd import tuned_gemm  # noqa: E402
 
 
 def main(argv=None):
@@ -43,6 +44,7 @@ def main(argv=None):
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", device_id=dev)
 
+    tuned_gemm.enable()          # recorded solutions for the RGB decoder's library GEMMs (look-up only; no-op without a table)
     torch.manual_seed(0)
     model = IST_Net(rgb_extractor=ModifiedResnet(), freeze_world_enhancer=args.freeze_world_enhancer).to(dev).train()
     model.rgb_cam_extractor.to(memory_format=torch.channels_last)
