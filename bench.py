@@ -46,6 +46,13 @@ def shell_cloud(b, n, seed, device="cpu"):
     return pts.contiguous().to(device)
 
 
+def mse_value_and_grad(out):
+    """The encoder workloads' scalar loss, mean(out^2), and its gradient -- the mean-squared-error op of the reference's
+    SupervisedLoss (model/ist_net.py:99) against a zero target, value and gradient from one launch."""
+    from istnet_amd.losses import mse_value_and_grad as f
+    return f(out)
+
+
 def make_model(device, seed=0):
     from istnet_amd.modules import PointNet2MSG
     torch.manual_seed(seed)
@@ -98,8 +105,8 @@ def make_istnet_fwd_bwd(model, batch):
 def make_encoder_fwd_bwd(model, pts):
     def fwd_bwd():
         out = model(pts)
-        loss = out.square().mean()
-        loss.backward()
+        loss, grad = mse_value_and_grad(out)
+        out.backward(grad)
         return loss
     return fwd_bwd
 
@@ -111,8 +118,8 @@ def make_pipelined_fwd_bwd(model, batches, slots, i):
     def fwd_bwd():
         model.prefetch_geometry(batches[1 - i], slots[1 - i])
         out = model(batches[i], geometry=slots[i])
-        loss = out.square().mean()
-        loss.backward()
+        loss, grad = mse_value_and_grad(out)      # mean of squares and its gradient 2 out / n from one launch
+        out.backward(grad)
         model.join_geometry()
         return loss
     return fwd_bwd

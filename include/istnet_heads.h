@@ -52,6 +52,15 @@ ISTNET_PN2_API int istnet_smooth_l1_forward(long long rows, float threshold, con
 ISTNET_PN2_API int istnet_smooth_l1_backward(long long rows, float threshold, const float *gout, const float *p1,
                                              const float *p2, float *dp1, void *stream);
 
+/* Mean squared error of two dense float32 tensors of n elements -- the feature-alignment term nn.MSELoss of the
+ * reference's SupervisedLoss (model/ist_net.py:99) -- together with its gradient, one pass over the operands:
+ * loss = mean (a - b)^2 (per-workgroup partial sums in part[istnet_mse_parts(n)], added in a fixed order in float64) and
+ * da = 2 (a - b) / n  (the gradient with respect to b is -da).  b may be NULL (b = 0: the mean of squares).  a, b, da
+ * 16-byte aligned. */
+ISTNET_PN2_API int istnet_mse_parts(long long n);
+ISTNET_PN2_API int istnet_mse_value_grad(long long n, const float *a, const float *b, float *da, float *part, float *loss,
+                                         void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -118,6 +118,8 @@ SIGNATURES = {
     "istnet_smooth_l1_parts": [_l],
     "istnet_smooth_l1_forward": [_l, _f, _p, _p, _p, _p, _p],
     "istnet_smooth_l1_backward": [_l, _f, _p, _p, _p, _p, _p],
+    "istnet_mse_parts": [_l],
+    "istnet_mse_value_grad": [_l, _p, _p, _p, _p, _p, _p],
     # csrc/pw_last.hip
     "istnet_pw_forward_pool_ok": [_i, _i, _i, _i, _i],
     "istnet_pw_forward_pool": [_i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p],

@@ -362,6 +362,37 @@ __global__ __launch_bounds__(256) void smooth_l1_finish_kernel(int nparts, doubl
   }
   if (threadIdx.x == 0) *loss = (float)(red[0] / rows);
 }
+// mean squared error of two dense tensors (the feature-alignment term of SupervisedLoss, model/ist_net.py:99) with its
+// gradient in the same pass: part[block] = sum (a - b)^2, da = (2 / n) (a - b) [* gscale]; b == nullptr: b = 0
+__global__ __launch_bounds__(256) void mse_value_grad_kernel(long long n4, long long n, float two_over_n,
+                                                             const float* __restrict__ a, const float* __restrict__ b,
+                                                             float* __restrict__ da, float* __restrict__ part) {
+  __shared__ float red[256];
+  float acc = 0.f;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+    const float4 x = reinterpret_cast<const float4*>(a)[i];
+    float4 d = x;
+    if (b != nullptr) {
+      const float4 y = reinterpret_cast<const float4*>(b)[i];
+      d.x -= y.x; d.y -= y.y; d.z -= y.z; d.w -= y.w;
+    }
+    acc += (d.x * d.x + d.y * d.y) + (d.z * d.z + d.w * d.w);
+    reinterpret_cast<float4*>(da)[i] = make_float4(d.x * two_over_n, d.y * two_over_n, d.z * two_over_n, d.w * two_over_n);
+  }
+  if (blockIdx.x == 0)
+    for (long long i = 4 * n4 + threadIdx.x; i < n; i += 256) {           // tail of a length that is not a multiple of 4
+      const float d = a[i] - (b != nullptr ? b[i] : 0.f);
+      acc += d * d;
+      da[i] = d * two_over_n;
+    }
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  for (int off = 128; off >= 1; off >>= 1) {
+    if (threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) part[blockIdx.x] = red[0];
+}
 __global__ __launch_bounds__(256) void smooth_l1_bwd_kernel(long long n3, float thr, float inv_rows,
                                                             const float* __restrict__ gout, const float* __restrict__ p1,
                                                             const float* __restrict__ p2, float* __restrict__ dp1) {
@@ -478,6 +509,20 @@ int istnet_smooth_l1_backward(long long rows, float threshold, const float* gout
   if (rows <= 0 || threshold <= 0.f || !gout || !p1 || !p2 || !dp1) return ISTNET_PN2_EINVAL;
   hipLaunchKernelGGL(smooth_l1_bwd_kernel, dim3(istnet_smooth_l1_parts(rows)), dim3(256), 0, as_stream(stream), rows * 3,
                      threshold, (float)(1.0 / (double)rows), gout, p1, p2, dp1);
+  return (int)hipGetLastError();
+}
+
+int istnet_mse_parts(long long n) {
+  const long long blocks = (n / 4 + 256 * 4 - 1) / (256 * 4);           // >= 4 float4 per thread
+  return (int)(blocks < 1 ? 1 : (blocks > 1024 ? 1024 : blocks));
+}
+int istnet_mse_value_grad(long long n, const float* a, const float* b, float* da, float* part, float* loss, void* stream) {
+  if (n <= 0 || !a || !da || !part || !loss) return ISTNET_PN2_EINVAL;
+  if (((uintptr_t)a | (uintptr_t)da | (uintptr_t)b) & 15) return ISTNET_PN2_EINVAL;
+  const int parts = istnet_mse_parts(n);
+  hipLaunchKernelGGL(mse_value_grad_kernel, dim3(parts), dim3(256), 0, as_stream(stream), n / 4, n, (float)(2.0 / (double)n), a,
+                     b, da, part);
+  hipLaunchKernelGGL(smooth_l1_finish_kernel, dim3(1), dim3(256), 0, as_stream(stream), parts, (double)n, part, loss);
   return (int)hipGetLastError();
 }
 

@@ -51,3 +51,28 @@ class SupervisedLoss(nn.Module):
             loss = loss + PoseDis(ep["pred_rotation_aux_world"], ep["pred_translation_aux_world"],
                                   ep["pred_size_aux_world"], *labels)
         return loss
+
+
+def mse_value_and_grad(a, b=None):
+    """``nn.functional.mse_loss(a, b)`` (``b=None``: against zero, i.e. the mean of squares) together with its gradient with
+    respect to ``a`` -- (loss, 2 (a - b) / n) -- from ONE pass over the operands (include/istnet_heads.h,
+    istnet_mse_value_grad) for CUDA float32 tensors; the framework's mse_loss + autograd are five launches over the same
+    bytes.  For loops that start backward from an explicit gradient: ``loss, g = mse_value_and_grad(out); out.backward(g)``
+    (what bench.py does for its encoder workload); the gradient with respect to ``b`` is ``-g``.  No graph is recorded."""
+    x = a.detach()
+    y = b.detach() if b is not None else None
+    if (not x.is_cuda or x.dtype != torch.float32 or not x.is_contiguous()
+            or (y is not None and (y.shape != x.shape or y.dtype != x.dtype or not y.is_contiguous()))):
+        d = x if y is None else x - y
+        return d.square().mean(), d * (2.0 / d.numel())
+    from . import _native
+    lib = _native.lib()
+    n = x.numel()
+    g = torch.empty_like(x)
+    part = torch.empty(lib.istnet_mse_parts(n), dtype=torch.float32, device=x.device)
+    loss = torch.empty((), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        _native.check(lib.istnet_mse_value_grad(n, x.data_ptr(), y.data_ptr() if y is not None else None, g.data_ptr(),
+                                                part.data_ptr(), loss.data_ptr(),
+                                                torch.cuda.current_stream(x.device).cuda_stream), "mse_value_grad")
+    return loss, g

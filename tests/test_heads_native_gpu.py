@@ -166,3 +166,24 @@ def test_stack_with_fused_mean_pool_equals_stack_then_mean():
     assert _rel(res[0][1], res[1][1]) < 1e-5
     for a, c in zip(res[0][2], res[1][2]):
         assert _rel(a, c) < 1e-5
+
+
+@pytest.mark.parametrize("n,with_target", [(32 * 128 * 1024, False), (4099, True), (7, False), (32 * 128 * 1024, True)])
+def test_mse_value_and_gradient_from_one_pass(n, with_target):
+    """losses.mse_value_and_grad (istnet_mse_value_grad) against nn.functional.mse_loss and its autograd gradient in float64."""
+    from istnet_amd import losses
+    g = torch.Generator().manual_seed(n)
+    a = torch.randn(n, generator=g).to(DEV)
+    b = torch.randn(n, generator=g).to(DEV) if with_target else None
+    loss, grad = losses.mse_value_and_grad(a, b)
+    a64 = a.double().requires_grad_(True)
+    want = torch.nn.functional.mse_loss(a64, b.double() if b is not None else torch.zeros_like(a64))
+    want.backward()
+    assert abs(float(loss) - float(want)) <= 1e-6 * abs(float(want))
+    torch.testing.assert_close(grad.double(), a64.grad, rtol=1e-6, atol=1e-12)
+    # deterministic: the partial sums are added in a fixed order
+    loss2, grad2 = losses.mse_value_and_grad(a, b)
+    assert torch.equal(loss, loss2) and torch.equal(grad, grad2)
+    # CPU tensors take the torch expression
+    lc, gc = losses.mse_value_and_grad(a.cpu(), b.cpu() if b is not None else None)
+    assert abs(float(lc) - float(want)) <= 1e-5 * abs(float(want))
