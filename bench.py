@@ -518,7 +518,7 @@ def main():
     sync = (lambda: None) if args.cpu_dry_run else torch.cuda.synchronize
 
     import torch.distributed as dist
-    from istnet_amd.optim import FlatAdam
+    from istnet_amd.optim import FlatAdam, layout_hints
     grad_sync = None
     dist_on = world > 1 or args.force_dist
     if dist_on:
@@ -583,7 +583,7 @@ def main():
             model = model.to(memory_format=torch.contiguous_format)
         else:
             batch = istnet_batch(BATCH, NPOINTS, seed=rank, device=dev)
-        opt = FlatAdam(model.parameters(), lr=1e-4)
+        opt = FlatAdam(model.parameters(), lr=1e-4, adjacent=layout_hints(model))
         if dist_on:
             from istnet_amd.parallel import OverlappedFlatReducer
             grad_sync = OverlappedFlatReducer(opt, world, always=args.force_dist)
@@ -592,7 +592,7 @@ def main():
     else:
         model = make_model(dev, seed=0)  # identical weights on every rank (same seed)
         pts = shell_cloud(batch_size, NPOINTS, seed=rank, device=dev)
-        opt = FlatAdam(model.parameters(), lr=1e-4)
+        opt = FlatAdam(model.parameters(), lr=1e-4, adjacent=layout_hints(model))
         if dist_on:
             from istnet_amd.parallel import OverlappedFlatReducer
             grad_sync = OverlappedFlatReducer(opt, world, always=args.force_dist)

@@ -20,7 +20,7 @@ import bench  # noqa: E402  (synthetic batch generator of SURVEY.md 8d config 3)
 import istnet_amd  # noqa: E402,F401
 from istnet_amd.ist_net import IST_Net  # noqa: E402
 from istnet_amd.losses import SupervisedLoss  # noqa: E402
-from istnet_amd.optim import FlatAdam  # noqa: E402
+from istnet_amd.optim import FlatAdam, layout_hints  # noqa: E402
 from istnet_amd.parallel import OverlappedFlatReducer, broadcast_parameters  # noqa: E402
 from istnet_amd.pointnet2.pytorch_utils import BNMomentumScheduler  # noqa: E402
 from istnet_amd.rgb_branch import ModifiedResnet  # noqa: E402
@@ -54,7 +54,7 @@ def main(argv=None):
     if world > 1:
         broadcast_parameters(model, src=0)
     # solver.py:40-49 -- Adam (betas of config/ist_net_default.yaml), CyclicLR every iteration, BN momentum decay
-    opt = FlatAdam(model.parameters(), lr=1e-5, betas=(0.5, 0.999))
+    opt = FlatAdam(model.parameters(), lr=1e-5, betas=(0.5, 0.999), adjacent=layout_hints(model))
     sched = torch.optim.lr_scheduler.CyclicLR(opt, base_lr=1e-5, max_lr=1e-3, step_size_up=max(args.iters // 6, 1),
                                               mode="triangular", cycle_momentum=False)
     bnm = BNMomentumScheduler(model, bn_lambda=lambda it: max(0.5 * 0.5 ** int(it / 200000), 0.01), last_epoch=0)

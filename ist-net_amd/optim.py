@@ -13,12 +13,28 @@ State lives on the device, so a step can be captured in a HIP graph.
 import torch
 
 
+def layout_hints(model):
+    """Parameter groups a model wants adjacent in a flat buffer (``FlatAdam(..., adjacent=layout_hints(model))``): every
+    module may offer ``flat_layout_hints()`` returning lists of parameters."""
+    hints = []
+    for m in model.modules():
+        f = getattr(m, "flat_layout_hints", None)
+        if f is not None:
+            hints += [list(g) for g in f()]
+    return hints
+
+
 class FlatAdam(torch.optim.Optimizer):
     """A ``torch.optim.Optimizer`` (so ``torch.optim.lr_scheduler`` classes accept it -- the reference drives Adam
     with ``CyclicLR``, utils/solver.py:41-47) with ONE parameter group: ``param_groups[0]['lr']`` is what schedulers
     write and what ``step()`` reads."""
 
-    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, adjacent=None):
+        """``adjacent``: lists of parameters to lay out back to back in the flat buffer, in the order given (each list at
+        the place of its first member); ``layout_hints(model)`` collects them.  Kernels that want several weight matrices
+        as one (the layer-0 weights of the scales of a set-abstraction level: the level-wide feature-gradient product)
+        then take a view of the buffer instead of packing a copy every step.  The optimizer state (``state_dict``) stays
+        in parameter order whatever the layout."""
         params = list(params)
         if params and isinstance(params[0], dict):
             raise ValueError("FlatAdam: one parameter group only (pass the parameters, not a list of groups)")
@@ -28,12 +44,26 @@ class FlatAdam(torch.optim.Optimizer):
         dev, dt = self.params[0].device, self.params[0].dtype
         if any(p.device != dev or p.dtype != dt for p in self.params):
             raise ValueError("FlatAdam: all parameters must share one device and dtype")
-        self.flat = torch.cat([p.detach().reshape(-1) for p in self.params])
-        self.offsets, off = [], 0
-        for p in self.params:                       # parameters become views of the flat buffer
+        index = {id(p): i for i, p in enumerate(self.params)}
+        group_of = {}
+        for grp in (adjacent or []):
+            members = [index[id(p)] for p in grp if id(p) in index]
+            if len(members) > 1 and not any(i in group_of for i in members):
+                for i in members:
+                    group_of[i] = members
+        self.layout, placed = [], set()             # parameter indices in memory order
+        for i in range(len(self.params)):
+            for j in group_of.get(i, [i]):
+                if j not in placed:
+                    placed.add(j)
+                    self.layout.append(j)
+        self.flat = torch.cat([self.params[i].detach().reshape(-1) for i in self.layout])
+        self.offsets, off = [0] * len(self.params), 0
+        for i in self.layout:                       # parameters become views of the flat buffer
+            p = self.params[i]
             n = p.numel()
             p.data = self.flat[off:off + n].view_as(p)
-            self.offsets.append(off)
+            self.offsets[i] = off
             off += n
         # Gradients are produced in place: the fused backward kernels write dW / dgamma / dbeta of a parameter
         # straight into its slot of this buffer (fused_mlp._grad_dest), so step() and the data-parallel
@@ -81,11 +111,12 @@ class FlatAdam(torch.optim.Optimizer):
                    and p.grad.is_contiguous() for p in self.params)
 
     def pack_grads(self):
-        """One flat gradient tensor in parameter order (a parameter without gradient contributes zeros):
+        """One flat gradient tensor in the buffer's layout (a parameter without gradient contributes zeros):
         ``flat_grad`` itself when the gradients were produced in place, else one ``torch.cat``."""
         if self.grads_in_place():
             return self.flat_grad
-        return torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in self.params])
+        return torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1)
+                          for p in (self.params[i] for i in self.layout)])
 
     def grad_views(self, flat_grad):
         return [flat_grad[o:o + p.numel()].view_as(p) for o, p in zip(self.offsets, self.params)]

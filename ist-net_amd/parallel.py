@@ -120,10 +120,12 @@ class OverlappedFlatReducer:
         esz = opt.flat_grad.element_size()
         self.buckets = []          # [lo, hi, parameter indices], from the end of the buffer
         cur, hi = [], opt.flat_grad.numel()
-        for i in range(len(opt.params) - 1, -1, -1):
+        order = list(getattr(opt, "layout", range(len(opt.params))))      # parameter indices in memory order
+        for k in range(len(order) - 1, -1, -1):
+            i = order[k]
             cur.append(i)
             lo = opt.offsets[i]
-            if (hi - lo) * esz >= bucket_bytes or i == 0:
+            if (hi - lo) * esz >= bucket_bytes or k == 0:
                 self.buckets.append((lo, hi, cur))
                 cur, hi = [], lo
         self.bucket_of = {}

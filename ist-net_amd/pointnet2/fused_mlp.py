@@ -1125,8 +1125,16 @@ class FusedSALevelFunction(Function):
             if feat is not None and nsc > 1 and ctx.needs_input_grad[0] and xyz.shape[1] <= 4096 and xyz.shape[1] % 4 == 0:
                 w0s = [pl[0] for pl in plist]
                 if all(w.is_contiguous() for w in w0s):
-                    wcat = _empty((sum(w.shape[0] for w in w0s), 3 + feat.shape[1]), torch.float32, dev)
-                    _native.pack_words(w0s, wcat, _st(dev))
+                    rows, cols = sum(w.shape[0] for w in w0s), 3 + feat.shape[1]
+                    if all(a.data_ptr() + 4 * a.numel() == b_.data_ptr() and a.untyped_storage().data_ptr() ==
+                           b_.untyped_storage().data_ptr() for a, b_ in zip(w0s[:-1], w0s[1:])):
+                        # back to back in one flat parameter buffer (optim.FlatAdam with the module's layout hint): the
+                        # stacked matrix is a view, nothing to pack
+                        wcat = w0s[0].detach().as_strided((rows, cols), (cols, 1))
+                        STATS["wcat_views"] = STATS.get("wcat_views", 0) + 1
+                    else:
+                        wcat = _empty((rows, cols), torch.float32, dev)
+                        _native.pack_words(w0s, wcat, _st(dev))
             streams = _scale_streams(dev, len(scales))
             compacts = list(compacts) if compacts is not None else [None] * nsc
             used = []

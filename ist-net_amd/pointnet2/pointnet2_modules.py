@@ -80,6 +80,12 @@ class PointnetSAModuleMSG(_PointnetSAModuleBase):
                 spec[0] += 3
             self.mlps.append(pytorch_utils.SharedMLP(spec, bn=bn))
 
+    def flat_layout_hints(self):
+        """The layer-0 weights of the scales, in scale order: adjacent in a flat parameter buffer (optim.FlatAdam) they ARE
+        the stacked matrix the level-wide feature-gradient product of backward reads, so no copy is packed per step."""
+        w0 = [m[0].conv.weight for m in self.mlps if len(m) > 0 and hasattr(m[0], "conv")]
+        return [w0] if len(w0) > 1 and len({tuple(w.shape[1:]) for w in w0}) == 1 else []
+
 
 class PointnetSAModule(PointnetSAModuleMSG):
     """Single-scale SA layer.  [ref :117-145]"""

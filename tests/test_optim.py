@@ -49,6 +49,45 @@ def test_flat_adam_parameters_are_views_and_packed_grads():
     assert not torch.equal(before, opt.flat)
 
 
+def test_flat_adam_adjacent_layout_keeps_the_parameter_order_of_the_state():
+    """``adjacent`` lays the named parameters out back to back (a view of the buffer is then their stacked matrix) while
+    updates, packed gradients and the torch-Adam state_dict stay those of the parameter order."""
+    from istnet_amd.optim import layout_hints
+    from istnet_amd.pointnet2.pointnet2_modules import PointnetSAModuleMSG
+    torch.manual_seed(5)
+    a = torch.nn.Sequential(torch.nn.Linear(5, 7), torch.nn.Tanh(), torch.nn.Linear(7, 3), torch.nn.Linear(3, 7))
+    b = torch.nn.Sequential(torch.nn.Linear(5, 7), torch.nn.Tanh(), torch.nn.Linear(7, 3), torch.nn.Linear(3, 7))
+    b.load_state_dict(a.state_dict())
+    ref = torch.optim.Adam(a.parameters(), lr=1e-2)
+    opt = FlatAdam(b.parameters(), lr=1e-2, adjacent=[[b[0].bias, b[3].bias]])
+    i0, i3 = 1, 5                                                   # indices of the two biases in parameter order
+    assert opt.offsets[i3] == opt.offsets[i0] + 7 and opt.layout[:3] == [0, 1, 5]
+    stacked = b[0].bias.detach().as_strided((2, 7), (7, 1))
+    assert torch.equal(stacked[1], b[3].bias.detach())
+    g = torch.Generator().manual_seed(0)
+    for _ in range(4):
+        x = torch.randn(4, 5, generator=g)
+        for m, o in ((a, ref), (b, opt)):
+            o.zero_grad(set_to_none=True)
+            (m[2](torch.tanh(m[0](x))).square().mean() + m[3](m[2](torch.tanh(m[0](x)))).mean()).backward()
+            o.step()
+    for p, q in zip(a.parameters(), b.parameters()):
+        torch.testing.assert_close(q, p, rtol=1e-5, atol=1e-7)
+    sd, sd_ref = opt.state_dict(), ref.state_dict()
+    for k in sd_ref["state"]:
+        torch.testing.assert_close(sd["state"][k]["exp_avg"], sd_ref["state"][k]["exp_avg"], rtol=1e-5, atol=1e-8)
+    flat = opt.pack_grads()
+    for v, p in zip(opt.grad_views(flat), opt.params):
+        assert torch.equal(v, p.grad)
+    # the set-abstraction module offers its scales' layer-0 weights
+    sa = PointnetSAModuleMSG(npoint=8, radii=[0.1, 0.2], nsamples=[4, 8], mlps=[[6, 8, 8], [6, 8, 16]])
+    hints = layout_hints(sa)
+    assert len(hints) == 1 and [tuple(w.shape) for w in hints[0]] == [(8, 9, 1, 1), (8, 9, 1, 1)]
+    o2 = FlatAdam(sa.parameters(), adjacent=hints)
+    w0a, w0b = hints[0]
+    assert w0b.data_ptr() == w0a.data_ptr() + 4 * w0a.numel()
+
+
 @pytest.mark.gpu
 def test_flat_adam_matches_torch_adam_gpu():
     _run("cuda:0")

@@ -5,7 +5,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from torch.profiler import profile, ProfilerActivity
 import bench
-from istnet_amd.optim import FlatAdam
+from istnet_amd.optim import FlatAdam, layout_hints
 from istnet_amd.modules import GeometrySlot
 
 dev = torch.device("cuda:0")
@@ -18,7 +18,7 @@ if workload == "encoder":
 else:
     model = bench.make_istnet(dev)
     fwd = [bench.make_istnet_fwd_bwd(model, bench.istnet_batch(32, 1024, 0, dev))]
-opt = FlatAdam(model.parameters(), lr=1e-4)
+opt = FlatAdam(model.parameters(), lr=1e-4, adjacent=layout_hints(model))
 step = bench.make_eager_step(fwd, opt, 1)
 for _ in range(4):
     step()

@@ -5,7 +5,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import bench
 from istnet_amd import _native
-from istnet_amd.optim import FlatAdam
+from istnet_amd.optim import FlatAdam, layout_hints
 from istnet_amd.modules import GeometrySlot
 
 dev = torch.device("cuda:0")
@@ -13,7 +13,7 @@ model = bench.make_model(dev)
 batches = [bench.shell_cloud(32, 1024, s, dev) for s in (0, 1000)]
 slots = [model.prefetch_geometry(bt, GeometrySlot()) for bt in batches]
 fwd = [bench.make_pipelined_fwd_bwd(model, batches, slots, i) for i in (0, 1)]
-opt = FlatAdam(model.parameters(), lr=1e-4)
+opt = FlatAdam(model.parameters(), lr=1e-4, adjacent=layout_hints(model))
 step = bench.make_eager_step(fwd, opt, 1)
 for _ in range(4):
     step()

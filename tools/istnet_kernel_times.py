@@ -5,7 +5,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from torch.profiler import profile, ProfilerActivity
 import bench
-from istnet_amd.optim import FlatAdam
+from istnet_amd.optim import FlatAdam, layout_hints
 
 dev = torch.device("cuda:0")
 model = bench.make_istnet(dev)
@@ -21,7 +21,7 @@ if "--infer" in sys.argv:          # config 5: eval mode, B=64 N=2048, post-proc
             return rts.cpu(), scales.cpu()
 else:
     fwd = [bench.make_istnet_fwd_bwd(model, bench.istnet_batch(32, 1024, 0, dev))]
-    opt = FlatAdam(model.parameters(), lr=1e-4)
+    opt = FlatAdam(model.parameters(), lr=1e-4, adjacent=layout_hints(model))
     step = bench.make_eager_step(fwd, opt, 1)
 for _ in range(5):
     step()

@@ -5,7 +5,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import bench
 from istnet_amd import _native
-from istnet_amd.optim import FlatAdam
+from istnet_amd.optim import FlatAdam, layout_hints
 
 dev = torch.device("cuda:0")
 model = bench.make_model(dev)
@@ -13,7 +13,7 @@ from istnet_amd.modules import GeometrySlot
 batches = [bench.shell_cloud(32, 1024, 0, dev), bench.shell_cloud(32, 1024, 1000, dev)]
 slots = [model.prefetch_geometry(bt, GeometrySlot()) for bt in batches]
 pts = batches[0]
-opt = FlatAdam(model.parameters(), lr=1e-4)
+opt = FlatAdam(model.parameters(), lr=1e-4, adjacent=layout_hints(model))
 buf = torch.zeros(256, dtype=torch.int64, device=dev)
 
 
