@@ -147,3 +147,29 @@ def test_pmc_traffic_summary_is_tied_to_the_kernel_sources(tmp_path):
     assert val is None and why.startswith("stale")
     f.write_text(json.dumps(rec))                      # summaries from before the stamp existed
     assert roofline.pmc_traffic("some_kernel", str(f))[0] is None
+
+
+def test_entry_points_reject_invalid_arguments_before_touching_the_device():
+    """Argument validation is host code ahead of any HIP call: an invalid size or a missing pointer returns
+    ISTNET_PN2_EINVAL (100001) on a box without a GPU too -- never a crash, never a launch."""
+    from istnet_amd import _native
+    lib = _native.lib()
+    EINVAL = 100001
+    one = 16                       # a non-null, 16-byte aligned "pointer" that is never dereferenced on these paths
+    assert lib.istnet_mse_value_grad(0, one, None, one, one, one, None) == EINVAL
+    assert lib.istnet_mse_value_grad(8, None, None, one, one, one, None) == EINVAL
+    assert lib.istnet_mse_value_grad(8, one + 4, None, one, one, one, None) == EINVAL            # misaligned operand
+    assert lib.istnet_crop_resize_normalize(1, 0, 640, one, 0, 1, one, 192, one, one, None, one, None) == EINVAL
+    assert lib.istnet_crop_resize_normalize(1, 480, 640, one, 0, 1, one, 192, one, one, None, None, None) == EINVAL
+    assert lib.istnet_crop_resize_normalize(-1, 480, 640, one, 0, 1, one, 192, one, one, None, one, None) == EINVAL
+    assert lib.istnet_nhwc_bn_act_res_apply(0, 64, 64, one, one, one, one, one, None) == EINVAL
+    assert lib.istnet_nhwc_bn_act_res_apply(2, 64, 6, one, one, one, one, one, None) == EINVAL   # channels % 4
+    assert lib.istnet_nhwc_bn_act_res_bwd_stats(2, 64, 64, one, one, None, one, one, one, one, one, one, None) == EINVAL
+    assert lib.istnet_fc_forward(0, 32, 512, None, None, None, None, None, 1, None) == EINVAL
+    assert lib.istnet_ortho6d_forward(0, one, one, None) == EINVAL
+    assert lib.istnet_smooth_l1_forward(0, 0.1, one, one, one, one, None) == EINVAL
+    assert lib.istnet_backproject_choose(1, 4, 0, 640, one, 0, 0, one, one, 1.0, 1.0, 0.0, 0.0, 1000.0, 192, one, one,
+                                         None) == EINVAL
+    assert lib.istnet_pw_set_tuning(999, 1) == EINVAL
+    assert lib.istnet_mse_parts(1) == 1 and lib.istnet_mse_parts(1 << 30) == 1024
+    assert lib.istnet_nhwc_stat_parts(0) == 0 and lib.istnet_nhwc_stat_parts(18432) == 576
