@@ -28,6 +28,31 @@
 
 namespace {
 
+// Build-time experiment (-DISTNET_PHASE_TIMING, tools/fwd_sk_phases.py): cycles per phase of pw_fwd_sk_kernel (thread 0 of
+// every workgroup, clock64; accumulated in registers, one set of atomics at the end), read back with
+// istnet_debug_phase_read.  Not in the default build.
+#ifdef ISTNET_PHASE_TIMING
+__device__ unsigned long long g_phase_sum[16];     // [kind][phase]
+__device__ unsigned long long g_phase_wgs[2];
+#define PHASE_INIT(kind) long long ph_last = clock64(); const int ph_kind = (kind); long long ph_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define PHASE_T(i)                                                         \
+  if (threadIdx.x == 0) {                                                  \
+    const long long ph_now = clock64();                                    \
+    ph_acc[i] = ph_now - ph_last;                                          \
+    ph_last = ph_now;                                                      \
+  }
+#define PHASE_END                                                                                     \
+  if (threadIdx.x == 0) {                                                                             \
+    for (int ph_i = 0; ph_i < 8; ++ph_i)                                                              \
+      atomicAdd(&g_phase_sum[8 * ph_kind + ph_i], (unsigned long long)ph_acc[ph_i]);                  \
+    atomicAdd(&g_phase_wgs[ph_kind], 1ull);                                                           \
+  }
+#else
+#define PHASE_INIT(kind)
+#define PHASE_T(i)
+#define PHASE_END
+#endif
+
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int kThreads = 256;
@@ -674,10 +699,12 @@ __global__ __launch_bounds__(kThreads, 2) void pw_fwd_sk_kernel(
   const int m0 = blockIdx.y * 32;
   const bool has_bn = in_scale != nullptr;
   const bool w_vec = (ldw & 3) == 0 && ((uintptr_t)w & 15) == 0;
+  PHASE_INIT(zk != nullptr ? 1 : 0)
   if (has_bn) {
     for (int c = tid; c < cin; c += kThreads) { s_sc[c] = in_scale[c]; s_sh[c] = in_shift[c]; }
     __syncthreads();
   }
+  PHASE_T(0)                    // BatchNorm constants staged
   const float* xb = x + (size_t)b * cin * P + p0 + 4 * l31;
   const float* wrow = w + (size_t)min(m0 + l31, cout - 1) * ldw + 4 * half;
 
@@ -716,6 +743,10 @@ __global__ __launch_bounds__(kThreads, 2) void pw_fwd_sk_kernel(
   // this wave's groups: wv, wv + 4, ...; two register sets, the next group's loads in flight during the MFMAs
   int j = wv;
   if (j < ngroups) load_group(a4[0], b4[0], j);
+#ifdef ISTNET_PHASE_TIMING
+  __builtin_amdgcn_s_waitcnt(0);
+  PHASE_T(1)                    // first operand group arrived
+#endif
   for (; j < ngroups; j += 8) {
     if (j + 4 < ngroups) load_group(a4[1], b4[1], j + 4);
     mma_group(a4[0], b4[0], j);
@@ -724,13 +755,19 @@ __global__ __launch_bounds__(kThreads, 2) void pw_fwd_sk_kernel(
       mma_group(a4[1], b4[1], j + 4);
     }
   }
+#ifdef ISTNET_PHASE_TIMING
+  asm volatile("s_nop 0" ::"v"(acc[0][0]), "v"(acc[1][0]), "v"(acc[2][0]), "v"(acc[3][0]));   // MFMA results landed
+  PHASE_T(2)                    // K loop of wave 0
+#endif
   // ---- the four partial sums meet in LDS; wave w finishes registers 4w .. 4w + 3, i.e. rows 8w .. 8w + 7 ----
   __syncthreads();              // every wave is done with the BN constants
+  PHASE_T(3)                    // waiting for the other three waves
 #pragma unroll
   for (int q = 0; q < 4; ++q)
 #pragma unroll
     for (int r = 0; r < 16; ++r) lds[((wv * 4 + q) * 16 + r) * 64 + lane] = acc[q][r];
   __syncthreads();
+  PHASE_T(4)                    // partial sums exchanged through LDS
   float* yb = y + (size_t)b * cout * P + p0 + 4 * l31;
   const float* cb = c_init != nullptr ? c_init + (size_t)b * cout * P + p0 + 4 * l31 : nullptr;
   // feature propagation, layer 0: the accumulators start from three_interpolate(zk) (reference
@@ -783,6 +820,12 @@ __global__ __launch_bounds__(kThreads, 2) void pw_fwd_sk_kernel(
       }
     }
   }
+#ifdef ISTNET_PHASE_TIMING
+  PHASE_T(5)                    // epilogue: rows formed and stored (s_memtime drains this wave's older stores first)
+  __builtin_amdgcn_s_waitcnt(0);
+  PHASE_T(6)                    // the stores acknowledged -- s_endpgm waits for this in the plain build as well
+  PHASE_END
+#endif
 }
 
 // ============================================================================================
@@ -3217,6 +3260,18 @@ int istnet_pw_wgrad_tile_cfg(int b, int cin, int cout, int p) {
   return wgrad_small(cin, cout) ? 32032 : wgrad_mt(cout, pts) * 1000 + wgrad_nt(cin, pts);
 }
 
+#ifdef ISTNET_PHASE_TIMING
+__attribute__((visibility("default"))) int istnet_debug_phase_read(unsigned long long* out18, int reset) {
+  unsigned long long zero[18] = {0};
+  if (hipMemcpyFromSymbol(out18, HIP_SYMBOL(g_phase_sum), 16 * sizeof(unsigned long long)) != hipSuccess) return 1;
+  if (hipMemcpyFromSymbol(out18 + 16, HIP_SYMBOL(g_phase_wgs), 2 * sizeof(unsigned long long)) != hipSuccess) return 1;
+  if (reset) {
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_phase_sum), zero, 16 * sizeof(unsigned long long));
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_phase_wgs), zero, 2 * sizeof(unsigned long long));
+  }
+  return 0;
+}
+#endif
 int istnet_pw_set_tuning(int key, int value) {
   switch (key) {
     case 0: g_wg_small_pts = value; return 0;
