@@ -57,14 +57,17 @@ class FlatAdam(torch.optim.Optimizer):
                 if j not in placed:
                     placed.add(j)
                     self.layout.append(j)
-        self.flat = torch.cat([self.params[i].detach().reshape(-1) for i in self.layout])
+        # A parameter keeps its physical layout inside the buffer: a channels-last convolution weight (the RGB branch runs
+        # channels-last on MIOpen) stays channels-last -- re-pointed as a plain contiguous view it would be converted back by
+        # a copy kernel in every convolution call, forward and backward (52 launches per full-model step).
+        self._strides = [self._physical_strides(p) for p in self.params]
+        self.flat = torch.cat([self._physical_flat(self.params[i].detach(), self._strides[i]) for i in self.layout])
         self.offsets, off = [0] * len(self.params), 0
         for i in self.layout:                       # parameters become views of the flat buffer
             p = self.params[i]
-            n = p.numel()
-            p.data = self.flat[off:off + n].view_as(p)
             self.offsets[i] = off
-            off += n
+            p.data = self._view(self.flat, i)
+            off += p.numel()
         # Gradients are produced in place: the fused backward kernels write dW / dgamma / dbeta of a parameter
         # straight into its slot of this buffer (fused_mlp._grad_dest), so step() and the data-parallel
         # all-reduce use it as is -- no pack.  Parameters whose gradient arrives some other way are packed.
@@ -81,6 +84,26 @@ class FlatAdam(torch.optim.Optimizer):
         self.betas, self.eps, self.weight_decay = tuple(betas), float(eps), float(weight_decay)
         super().__init__(self.params, dict(lr=float(lr), betas=tuple(betas), eps=float(eps),
                                            weight_decay=float(weight_decay)))
+
+    @staticmethod
+    def _physical_strides(p):
+        if p.dim() == 4 and not p.is_contiguous() and p.is_contiguous(memory_format=torch.channels_last):
+            return tuple(p.stride())
+        return None                                  # row-major contiguous in the buffer
+
+    @staticmethod
+    def _physical_flat(t, strides):
+        """The elements of ``t`` in the order its slot of the flat buffer stores them."""
+        if strides is None:
+            return t.reshape(-1)
+        return t.permute(0, 2, 3, 1).reshape(-1)     # channels-last: NHWC order is the memory order (a view, no copy)
+
+    def _view(self, buf, i):
+        """Parameter ``i``'s slot of a flat buffer, shaped and strided like the parameter."""
+        p, o = self.params[i], self.offsets[i]
+        if self._strides[i] is None:
+            return buf[o:o + p.numel()].view(p.shape)
+        return buf.as_strided(p.shape, self._strides[i], o)
 
     @property
     def lr(self):
@@ -116,13 +139,13 @@ class FlatAdam(torch.optim.Optimizer):
         one multi-tensor copy, and the slot of a parameter without a gradient is zeroed.  (Until round 3 this concatenated
         every gradient of the model whenever one of them was not in place: 2 x 107 MB at the end of a full-model step.)"""
         src, dst, zero = [], [], []
-        for p in self.params:
+        for i, p in enumerate(self.params):
             slot = p._istnet_grad_slot
             if p.grad is None:
                 zero.append(slot)
             elif p.grad.data_ptr() != slot.data_ptr() or not p.grad.is_contiguous():
                 src.append(p.grad)
-                dst.append(slot.view_as(p))
+                dst.append(self._view(self.flat_grad, i))
         if dst:
             torch._foreach_copy_(dst, src)
         if zero:
@@ -130,7 +153,7 @@ class FlatAdam(torch.optim.Optimizer):
         return self.flat_grad
 
     def grad_views(self, flat_grad):
-        return [flat_grad[o:o + p.numel()].view_as(p) for o, p in zip(self.offsets, self.params)]
+        return [self._view(flat_grad, i) for i in range(len(self.params))]
 
     @torch.no_grad()
     def step(self, flat_grad=None, grad_scale=1.0):
@@ -175,8 +198,8 @@ class FlatAdam(torch.optim.Optimizer):
         for i, (p, o) in enumerate(zip(self.params, self.offsets)):
             n = p.numel()
             state[i] = {"step": step_cpu.clone(),
-                        "exp_avg": self.exp_avg[o:o + n].view_as(p).clone(),
-                        "exp_avg_sq": self.exp_avg_sq[o:o + n].view_as(p).clone()}
+                        "exp_avg": self._view(self.exp_avg, i).clone(),
+                        "exp_avg_sq": self._view(self.exp_avg_sq, i).clone()}
         group = {"lr": self.lr, "betas": self.betas, "eps": self.eps, "weight_decay": self.weight_decay,
                  "amsgrad": False, "maximize": False, "foreach": None, "capturable": False, "differentiable": False,
                  "fused": None, "decoupled_weight_decay": False}
@@ -212,7 +235,7 @@ class FlatAdam(torch.optim.Optimizer):
         if g.get("amsgrad", False) or g.get("maximize", False):
             raise ValueError("FlatAdam.load_state_dict: amsgrad / maximize states are not supported")
         steps = set()
-        for key, p, o in zip(keys, self.params, self.offsets):
+        for i, (key, p, o) in enumerate(zip(keys, self.params, self.offsets)):
             st = sd["state"].get(key)
             n = p.numel()
             if st is None:                       # parameter never stepped: zero moments
@@ -221,8 +244,8 @@ class FlatAdam(torch.optim.Optimizer):
             if tuple(st["exp_avg"].shape) != tuple(p.shape):
                 raise ValueError(f"FlatAdam.load_state_dict: shape mismatch for parameter {key}: "
                                  f"{tuple(st['exp_avg'].shape)} vs {tuple(p.shape)}")
-            self.exp_avg[o:o + n].copy_(st["exp_avg"].reshape(-1))
-            self.exp_avg_sq[o:o + n].copy_(st["exp_avg_sq"].reshape(-1))
+            self._view(self.exp_avg, i).copy_(st["exp_avg"])
+            self._view(self.exp_avg_sq, i).copy_(st["exp_avg_sq"])
             steps.add(float(st["step"]))
         if len(steps) > 1:
             raise ValueError("FlatAdam.load_state_dict: parameters with different step counts cannot share one flat step")

@@ -195,7 +195,7 @@ class OverlappedFlatReducer:
             if g is None:
                 slot.zero_()
             elif g.data_ptr() != slot.data_ptr() or not g.is_contiguous():
-                slot.copy_(g.reshape(-1))
+                opt._view(opt.flat_grad, i).copy_(g)      # the slot in the parameter's own (possibly channels-last) layout
         piece = opt.flat_grad[lo:hi]
         if self.comm is None:              # CPU tensors (gloo tests): no streams
             self.works[b] = dist.all_reduce(piece, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
@@ -232,7 +232,7 @@ class OverlappedFlatReducer:
                 if g is None:
                     slot.zero_()
                 elif g.data_ptr() != slot.data_ptr() or not g.is_contiguous():
-                    slot.copy_(g.reshape(-1))
+                    opt._view(opt.flat_grad, i).copy_(g)
             out = opt.flat_grad
         else:
             out = opt.pack_grads()

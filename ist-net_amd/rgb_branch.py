@@ -123,6 +123,21 @@ def _conv3x3(cin, cout, stride=1, dilation=1):
     return nn.Conv2d(cin, cout, kernel_size=3, stride=stride, padding=dilation, dilation=dilation, bias=False)
 
 
+_COUNTER_SCOPE = None     # inside ModifiedResnet.forward: the BatchNorm batch counters of the fused sites, bumped by ONE launch
+
+
+def _bump_batch_counter(bn):
+    """``num_batches_tracked += 1`` of a BatchNorm whose statistics a fused kernel just updated (torch does this in
+    BatchNorm.forward).  Twenty-three four-microsecond launches on the RGB branch's stream when done one by one; inside
+    the extractor's forward they are collected and added by one multi-tensor launch at its end."""
+    if not (bn.track_running_stats and bn.num_batches_tracked is not None):
+        return
+    if _COUNTER_SCOPE is not None:
+        _COUNTER_SCOPE.append(bn.num_batches_tracked)
+    else:
+        bn.num_batches_tracked.add_(1)
+
+
 USE_FUSED_TRUNK_NORM = os.environ.get("ISTNET_FUSED_TRUNK_NORM", "1") != "0"   # trunk: BatchNorm2d (batch statistics) [+ identity] + ReLU as two passes per direction
 
 
@@ -216,8 +231,7 @@ def _bn_relu(bn, y, res, owner):
             and (res is None or (res.shape == y.shape and res.dtype == torch.float32))):
         if res is not None:
             res = res.contiguous(memory_format=torch.channels_last)
-        if bn.track_running_stats and bn.num_batches_tracked is not None:
-            bn.num_batches_tracked.add_(1)
+        _bump_batch_counter(bn)
         return _BnReluFn.apply(y, bn.weight, bn.bias, res, owner._zero, owner._one,
                                bn.running_mean if bn.track_running_stats else None,
                                bn.running_var if bn.track_running_stats else None, bn.momentum, bn.eps)
@@ -564,8 +578,7 @@ class PSPUpsample(nn.Module):
             if drop is not None and drop.training and drop.p > 0:
                 keep = 1.0 - drop.p
                 mask = torch.empty((b, cout), dtype=torch.float32, device=x.device).bernoulli_(keep).div_(keep)
-            if bn.track_running_stats and bn.num_batches_tracked is not None:
-                bn.num_batches_tracked.add_(1)
+            _bump_batch_counter(bn)
             return _BnPReLUDropFn.apply(y, bn.weight, bn.bias, act.weight, mask,
                                         bn.running_mean if bn.track_running_stats else None,
                                         bn.running_var if bn.track_running_stats else None, bn.momentum, bn.eps)
@@ -686,8 +699,7 @@ class Modified_PSPNet(nn.Module):
         u = self.up_3(p)
         if choose is not None and self._train_gather_ok(u):
             conv, bn, act = self.final[0], self.final[1], self.final[2]
-            if bn.track_running_stats and bn.num_batches_tracked is not None:
-                bn.num_batches_tracked.add_(1)
+            _bump_batch_counter(bn)
             return _FinalAtChosenFn.apply(u, choose, conv.weight, conv.bias, bn.weight, bn.bias, act.weight,
                                           bn.running_mean if bn.track_running_stats else None,
                                           bn.running_var if bn.track_running_stats else None,
@@ -749,4 +761,11 @@ class ModifiedResnet(nn.Module):
         self.model = Modified_PSPNet(sizes=(1, 2, 3, 6), psp_size=512)
 
     def forward(self, x, choose=None):
-        return self.model(x, choose)
+        global _COUNTER_SCOPE
+        outer, _COUNTER_SCOPE = _COUNTER_SCOPE, []
+        try:
+            return self.model(x, choose)
+        finally:
+            pending, _COUNTER_SCOPE = _COUNTER_SCOPE, outer
+            if pending:
+                torch._foreach_add_(pending, 1)

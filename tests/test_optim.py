@@ -352,3 +352,37 @@ def test_shared_module_used_twice_in_one_graph_under_flat_adam():
     torch.cuda.synchronize()
     for (name, p), w in zip(enc.named_parameters(), want):
         torch.testing.assert_close(p.grad, w, rtol=2e-4, atol=1e-6, msg=lambda s: f"{name}: {s}")
+
+
+def test_flat_adam_keeps_channels_last_parameters_channels_last():
+    """A channels-last convolution weight stays channels-last as a view of the flat buffer (no per-call layout conversion
+    on the GPU), and updates, packed gradients and the state_dict are those of the logical tensor."""
+    torch.manual_seed(2)
+    a = torch.nn.Sequential(torch.nn.Conv2d(4, 6, 3, padding=1), torch.nn.ReLU(), torch.nn.Conv2d(6, 2, 1))
+    b = torch.nn.Sequential(torch.nn.Conv2d(4, 6, 3, padding=1), torch.nn.ReLU(), torch.nn.Conv2d(6, 2, 1))
+    b.load_state_dict(a.state_dict())
+    a, b = a.to(memory_format=torch.channels_last), b.to(memory_format=torch.channels_last)
+    ref = torch.optim.Adam(a.parameters(), lr=1e-2)
+    opt = FlatAdam(b.parameters(), lr=1e-2)
+    w = b[0].weight
+    assert w.is_contiguous(memory_format=torch.channels_last) and not w.is_contiguous()
+    assert w.untyped_storage().data_ptr() == opt.flat.untyped_storage().data_ptr()
+    torch.testing.assert_close(w, a[0].weight)
+    g = torch.Generator().manual_seed(0)
+    for _ in range(3):
+        x = torch.randn(2, 4, 5, 5, generator=g).contiguous(memory_format=torch.channels_last)
+        for m, o in ((a, ref), (b, opt)):
+            o.zero_grad(set_to_none=True)
+            m(x).square().mean().backward()
+            o.step()
+    for p, q in zip(a.parameters(), b.parameters()):
+        torch.testing.assert_close(q, p, rtol=1e-5, atol=1e-7)
+    sd, sd_ref = opt.state_dict(), ref.state_dict()
+    for k in sd_ref["state"]:
+        torch.testing.assert_close(sd["state"][k]["exp_avg"], sd_ref["state"][k]["exp_avg"], rtol=1e-5, atol=1e-8)
+        torch.testing.assert_close(sd["state"][k]["exp_avg_sq"], sd_ref["state"][k]["exp_avg_sq"], rtol=1e-5, atol=1e-10)
+    opt2 = FlatAdam(b.parameters(), lr=1e-2)
+    opt2.load_state_dict(sd)
+    torch.testing.assert_close(opt2.exp_avg, opt.exp_avg)
+    for v, p in zip(opt.grad_views(opt.pack_grads()), opt.params):
+        torch.testing.assert_close(v, p.grad)

@@ -28,8 +28,8 @@ agg = collections.defaultdict(lambda: [0, 0.0])
 for ev in prof.key_averages(group_by_stack_n=30):
     if ev.key not in want or ev.device_time_total <= 0:
         continue
-    frames = [f for f in ev.stack if ("/ist-net_amd/" in f or "/istnet_amd/" in f or "bench.py" in f or "/torch/autograd" in f)]
-    ours = [f for f in frames if "/torch/" not in f]
+    frames = [f for f in ev.stack if ("ist-net_amd/" in f or "istnet_amd/" in f or "bench.py" in f or "torch/autograd" in f)]
+    ours = [f for f in frames if "torch/" not in f]
     inner = [f for f in ours if "bench.py" not in f]
     where = inner[0] if inner else (ours[0] if ours else (frames[0] if frames else (ev.stack[0] if ev.stack else "?")))
     if len(inner) > 1:
@@ -40,11 +40,3 @@ for ev in prof.key_averages(group_by_stack_n=30):
 print("  n     us   op                where")
 for (key, where), (cnt, t) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:60]:
     print(f"{cnt:4d} {t:7.1f}  {key:18s} {where}")
-print("---- raw stacks of the first few aten::copy_ / aten::contiguous / aten::sum groups ----")
-shown = 0
-for ev in prof.key_averages(group_by_stack_n=30):
-    if ev.key in ("aten::copy_", "aten::sum", "aten::add_") and ev.device_time_total > 0 and shown < 12:
-        shown += 1
-        print(ev.key, ev.count, f"{ev.device_time_total:.1f}us")
-        for f in ev.stack[:14]:
-            print("     ", f.strip()[-150:])
