@@ -208,13 +208,15 @@ class IST_Net(nn.Module):
         # RGB branch on its own stream so the encoder's many short kernels fill in around the convolutions
         # (autograd replays each op's backward on the stream its forward ran on, so backward overlaps too).
         side = None
+        rgb_last = os.environ.get("ISTNET_RGB_LAST", "0") == "1"       # experiment: issue the RGB branch after the encoders
         if "rgb_local" not in inputs and pts.is_cuda and USE_RGB_STREAM:
             main = torch.cuda.current_stream(pts.device)
             side = _rgb_stream(pts.device)
             side.wait_stream(main)
-            with torch.cuda.stream(side):
-                rgb_local = self._rgb_local(inputs, b)
-        else:
+            if not rgb_last:
+                with torch.cuda.stream(side):
+                    rgb_local = self._rgb_local(inputs, b)
+        elif not rgb_last:
             rgb_local = self._rgb_local(inputs, b)
 
         pts_local = self.pts_cam_extractor(pts)
@@ -224,6 +226,12 @@ class IST_Net(nn.Module):
             # it last): issued here, its sampling chain and its many short kernels run beside the RGB branch instead of
             # heading the serial part of the step; backward follows the same order in reverse
             pts_w_local_gt = self.world_enhancer.extractor(inputs["qo"])
+        if rgb_last:
+            if side is not None:
+                with torch.cuda.stream(side):
+                    rgb_local = self._rgb_local(inputs, b)
+            else:
+                rgb_local = self._rgb_local(inputs, b)
         if side is not None:
             main.wait_stream(side)
             rgb_local.record_stream(main)

@@ -19,7 +19,7 @@ from .pointnet2.pointnet2_modules import PointnetFPModule, PointnetSAModuleMSG
 # They are tiny-grid, latency-bound kernels (FPS is 956 dependent rounds per cloud), so they are issued
 # on a second HIP stream at the start of the forward and overlap the MFMA stacks of the earlier levels;
 # the main stream waits on one event per level.
-USE_GEOMETRY_STREAM = True
+USE_GEOMETRY_STREAM = os.environ.get("ISTNET_GEOMETRY_STREAM", "1") != "0"
 # Level l+1 samples from level l's picks in pick order, so its picks are the prefix 0..m-1 of its input whenever no
 # arg-max tie occurred in the parent's first m rounds: the parent run reports its first tied round and the children
 # skip their scan (include/istnet_pn2.h, istnet_pn2_fps_gather_chain).  Bit-identical to sampling every level.

@@ -120,7 +120,7 @@ def _ident_consts(dev, c):
 # .grad would be read on the main stream before the join), no kernel timing in progress.  Everything the
 # deferred launches read is kept alive until the join.  (A per-layer fork onto a side stream was measured
 # slower: 32 extra cross-stream edges per step.)
-USE_DEFERRED_WGRAD = True    # module attributes, not environment switches: tests flip each fallback once
+USE_DEFERRED_WGRAD = os.environ.get("ISTNET_DEFERRED_WGRAD", "1") != "0"    # module attributes, not environment switches: tests flip each fallback once
                              # (tests/test_pipeline_gpu.py::test_fallback_paths_agree_with_default)
 
 
@@ -442,7 +442,7 @@ def _forward_stack_compact(lib, dev, st, b, g, s, ga, training, layers, params, 
 # Run scale i >= 1 on its own stream: one chain's launch gaps and tiny kernels are filled by the other's GEMMs.
 # Fork/join discipline: the side stream waits on the main stream before it starts and the main stream joins it
 # before the level's result is used, so tensors may cross (allocated in one stream's pool, read by the other).
-USE_SCALE_STREAMS = True
+USE_SCALE_STREAMS = os.environ.get("ISTNET_SCALE_STREAMS", "1") != "0"
 _SCALE_STREAMS = {}
 
 
@@ -1492,7 +1492,7 @@ def fp_level(mlp, known_feats, skip, idx, weight, csr=None):
 
 
 USE_FUSED_FP = True
-USE_FP_SKIP_STREAM = True     # feature-propagation backward: skip-branch dgrad on a side stream (off the chain)
+USE_FP_SKIP_STREAM = os.environ.get("ISTNET_FP_SKIP_STREAM", "1") != "0"     # feature-propagation backward: skip-branch dgrad on a side stream (off the chain)
 _ONES = {}
 
 

@@ -25,7 +25,7 @@ if "--infer" in sys.argv:          # config 5: eval mode, B=64 N=2048, post-proc
 else:
     fwd = [bench.make_istnet_fwd_bwd(model, bench.istnet_batch(32, 1024, 0, dev))]
     opt = FlatAdam(model.parameters(), lr=1e-4, adjacent=layout_hints(model))
-    step = bench.make_eager_step(fwd, opt, 1)
+    step = bench.make_graphed_step(fwd, opt, 1) if "--graph" in sys.argv else bench.make_eager_step(fwd, opt, 1)
 for _ in range(5):
     step()
 torch.cuda.synchronize()
