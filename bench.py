@@ -575,6 +575,9 @@ def main():
         return
     npoints = NPOINTS
     if args.workload == "istnet":
+        if not args.cpu_dry_run:
+            from istnet_amd.ist_net import point_branch_side_streams
+            point_branch_side_streams(False)      # beside the RGB branch the point branch is better off on one stream
         model = make_istnet(dev, seed=0, freeze_world_enhancer=args.freeze_world_enhancer)
         if args.cpu_dry_run:         # toy size: the launch / exchange control flow is what the dry run exercises
             npoints = 256

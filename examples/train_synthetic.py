@@ -18,7 +18,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import bench  # noqa: E402  (synthetic batch generator of SURVEY.md 8d config 3)
 import istnet_amd  # noqa: E402,F401
-from istnet_amd.ist_net import IST_Net  # noqa: E402
+from istnet_amd.ist_net import IST_Net, point_branch_side_streams  # noqa: E402
 from istnet_amd.losses import SupervisedLoss  # noqa: E402
 from istnet_amd.optim import FlatAdam, layout_hints  # noqa: E402
 from istnet_amd.parallel import OverlappedFlatReducer, broadcast_parameters  # noqa: E402
@@ -44,6 +44,7 @@ def main(argv=None):
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", device_id=dev)
 
+    point_branch_side_streams(False)      # the RGB branch fills the chip: the point branch's side streams only get in its way
     tuned_gemm.enable()          # recorded solutions for the RGB decoder's library GEMMs (look-up only; no-op without a table)
     torch.manual_seed(0)
     model = IST_Net(rgb_extractor=ModifiedResnet(), freeze_world_enhancer=args.freeze_world_enhancer).to(dev).train()

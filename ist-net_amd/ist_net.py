@@ -165,6 +165,18 @@ def _rgb_stream(dev):
     return _RGB_STREAMS[key]
 
 
+def point_branch_side_streams(enabled):
+    """The point branch's own side streams -- the concurrent MSG scales and the deferred weight-gradient stream of
+    pointnet2.fused_mlp -- on or off for the whole process.  They are worth 15 % for the encoder alone, where nothing else
+    shares the chip; inside the full model the RGB branch's convolutions fill it, and the extra streams only let the
+    encoders' backward be queued behind the RGB backward instead of beside it (HIP-graph replay of the config-3 step:
+    33.8 ms with them, 32.3 without; tools/istnet_step_timeline.py shows the stall).  Call with False before training
+    the full model (bench.py --workload istnet and examples/train_synthetic.py do)."""
+    from .pointnet2 import fused_mlp
+    fused_mlp.USE_SCALE_STREAMS = bool(enabled)
+    fused_mlp.USE_DEFERRED_WGRAD = bool(enabled)
+
+
 class IST_Net(nn.Module):
     """IST-Net wiring.  [ref :10-76]  ``rgb_extractor`` maps (B,3,H,W) -> (B,128,H,W)."""
 

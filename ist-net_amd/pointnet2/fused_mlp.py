@@ -443,6 +443,7 @@ def _forward_stack_compact(lib, dev, st, b, g, s, ga, training, layers, params, 
 # Fork/join discipline: the side stream waits on the main stream before it starts and the main stream joins it
 # before the level's result is used, so tensors may cross (allocated in one stream's pool, read by the other).
 USE_SCALE_STREAMS = os.environ.get("ISTNET_SCALE_STREAMS", "1") != "0"
+USE_SCALE_STREAMS_BWD = os.environ.get("ISTNET_SCALE_STREAMS_BWD", "1") != "0"    # the same fork in the level's backward
 _SCALE_STREAMS = {}
 
 
@@ -1204,7 +1205,8 @@ class FusedSALevelFunction(Function):
         base = 7 + nsc   # index of the first parameter among forward()'s arguments
         with torch.cuda.device(dev):
             st = _st(dev)
-            streams = _scale_streams(dev, nsc) if (use_level_gemm or not need_x) else [torch.cuda.current_stream(dev)] * nsc
+            streams = _scale_streams(dev, nsc) if ((use_level_gemm or not need_x) and USE_SCALE_STREAMS_BWD) \
+                else [torch.cuda.current_stream(dev)] * nsc
             for (nl, s, coff, clast), (arg, ys, bns), idx, csr, stream, cm in zip(meta, per_scale, idxs, ctx.csrs, streams,
                                                                                       ctx.compacts):
                 params = params_all[ppos:ppos + 3 * nl]
