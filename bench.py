@@ -460,7 +460,7 @@ def main():
                          "from an autograd hook while backward still runs (a replayed graph issues the buckets after "
                          "the replay); meant for --workload istnet (107 MB of gradients)")
     ap.add_argument("--no-overlap-allreduce", action="store_true",
-                    help="istnet workload with N > 1: keep the captured step and issue the buckets after the replay")
+                    help="(the default since round 3; kept for old command lines) captured step, buckets after the replay")
     ap.add_argument("--no-prefetch", action="store_true",
                     help="encoder workload: one batch, geometry inside the step (no next-batch geometry prefetch)")
     ap.add_argument("--workload", default="encoder", choices=["encoder", "istnet", "infer", "sa_layer"],
@@ -609,10 +609,11 @@ def main():
             fwd_bwd = [make_pipelined_fwd_bwd(model, batches, slots, i) for i in (0, 1)]
     eager_step = make_eager_step(fwd_bwd, opt, world, grad_sync)
     step, mode = eager_step, "eager"
-    if dist_on and args.workload == "istnet" and not args.no_overlap_allreduce:
-        # 107 MB of gradients in ~4 buckets: issued from autograd hooks while backward still runs they hide under it, and the
-        # eager step costs nothing for this GPU-bound model (56.6 vs 56.8 ms measured with a one-rank RCCL group) -- the default
-        args.overlap_allreduce = True
+    # istnet with N > 1: 107 MB of gradients in ~4 buckets.  Issued from autograd hooks during an EAGER backward they hide
+    # under it, but since round 3 the eager full-model step is host-bound (37.9 ms with the hooks against 33.2 ms for the
+    # graph replay followed by the buckets back to back, one-rank RCCL group on a 1-GPU box: profiles/r03_bench_istnet_*),
+    # and the exposed exchange is ~1 ms at N = 8 (107 MB ring all-reduce over xGMI).  So the replay + back-to-back buckets is
+    # the default again; --overlap-allreduce selects the hook-overlapped eager step.
     if args.overlap_allreduce and dist_on:
         args.eager = True       # hooks issue the collectives during backward: not inside a capture
     if not args.eager:

@@ -286,9 +286,10 @@ def test_bench_under_torch_distributed_run():
 
 def test_bench_istnet_workload_two_ranks_overlapped_exchange():
     """``--workload istnet`` with N = 2 (toy size on host cores): the full model's gradients leave in several buckets FROM
-    THE AUTOGRAD HOOKS while backward runs -- the default for this workload --, and the JSON says how many bytes and
-    buckets a step exchanges."""
-    res = _run_bench(["bench.py", "--gpus", "2", "--steps", "1", "--warmup", "1", "--cpu-dry-run", "--workload", "istnet"])
+    THE AUTOGRAD HOOKS while backward runs (``--overlap-allreduce``: the eager step; the default on GPUs is the captured
+    step with the buckets after the replay), and the JSON says how many bytes and buckets a step exchanges."""
+    res = _run_bench(["bench.py", "--gpus", "2", "--steps", "1", "--warmup", "1", "--cpu-dry-run", "--workload", "istnet",
+                      "--overlap-allreduce"])
     assert res["n_gpus"] == 2 and res["config"]["parallelism"] == "dp2" and res["config"]["launch"] == "eager"
     ex = res["config"]["gradient_exchange"]
     assert ex["buckets"] >= 4 and sum(ex["bucket_bytes"]) == ex["bytes_per_step"]
