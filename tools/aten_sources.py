@@ -9,6 +9,8 @@ from istnet_amd import tuned_gemm
 from istnet_amd.optim import FlatAdam, layout_hints
 
 tuned_gemm.enable()
+from istnet_amd.ist_net import point_branch_side_streams
+point_branch_side_streams(False)
 dev = torch.device("cuda:0")
 model = bench.make_istnet(dev)
 fwd = [bench.make_istnet_fwd_bwd(model, bench.istnet_batch(32, 1024, 0, dev))]

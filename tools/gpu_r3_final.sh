@@ -23,6 +23,9 @@ python tools/gemm_launch_table.py 2>&1 | grep -v amdgpu.ids > $O/encoder_gemm_la
 python tools/step_timeline.py 2>&1 | grep -v amdgpu.ids > $O/step_timeline.txt
 python tools/istnet_kernel_times.py --timeline 2>/dev/null > $O/istnet_kernel_times.txt
 python tools/istnet_kernel_times.py --infer --timeline 2>/dev/null > $O/infer_kernel_times.txt
+ISTNET_SCALE_STREAMS=1 python tools/istnet_step_timeline.py 2>/dev/null > $O/istnet_step_timeline_graph_with_side_streams.txt
+ISTNET_SCALE_STREAMS=0 ISTNET_DEFERRED_WGRAD=0 python tools/istnet_step_timeline.py 2>/dev/null > $O/istnet_step_timeline_graph.txt
+python tools/aten_sources.py 2>/dev/null > $O/framework_kernels_istnet_by_source_line.txt
 python bench.py --workload istnet --no-tuned-gemms --no-roofline --steps 30 --warmup 5 2>/dev/null | tail -1 > $O/bench_istnet_untuned_gemms.json
 for m in default tunable; do python tools/exp/decoder_gemm_libs.py $m 2>&1 | grep -v "Warning\|amdgpu.ids"; done > $O/decoder_gemm_libraries.txt
 for f in bench_final bench_sa_layer bench_istnet_full_model bench_istnet_untuned_gemms bench_infer_full_model bench_istnet_force_dist bench_noprefetch; do python -c "

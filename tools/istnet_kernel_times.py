@@ -10,6 +10,9 @@ from istnet_amd.optim import FlatAdam, layout_hints
 from istnet_amd import tuned_gemm
 
 tuned_gemm.enable()          # as bench.py --workload istnet / infer does
+if "--infer" not in sys.argv:
+    from istnet_amd.ist_net import point_branch_side_streams
+    point_branch_side_streams(False)
 dev = torch.device("cuda:0")
 model = bench.make_istnet(dev)
 if "--infer" in sys.argv:          # config 5: eval mode, B=64 N=2048, post-processing and the copy to the host included
