@@ -183,12 +183,29 @@ def _enter_backward(dev):
         _Deferred.mains[key] = torch.cuda.current_stream(dev)
 
 
+# The per-point MLP stacks of the IST / pose heads (FusedBiasMLPFunction, FusedMultiSourceBiasMLPFunction) may keep deferring
+# their weight gradients when the encoders' nodes do not (ist_net.point_branch_side_streams): their wgrad GEMMs (3 ms of the
+# full-model step) then run beside the RGB backward instead of delaying the gradient it waits for.
+USE_DEFERRED_WGRAD_HEADS = os.environ.get("ISTNET_DEFERRED_WGRAD_HEADS", "0") == "1"
+_IN_HEAD_STACK = False
+
+
+class _head_stack:
+    def __enter__(self):
+        global _IN_HEAD_STACK
+        self.prev, _IN_HEAD_STACK = _IN_HEAD_STACK, USE_DEFERRED_WGRAD_HEADS
+    def __exit__(self, *exc):
+        global _IN_HEAD_STACK
+        _IN_HEAD_STACK = self.prev
+
+
 def _can_defer(params):
     """Deferral is legal only while AccumulateGrad will just STORE the produced tensors.  A parameter with an
     existing .grad, or one that another node of this pass already produced a gradient for (shared module: the
     engine adds the two tensors on the main stream), forces the launches onto the current stream -- after the
     current stream has waited for whatever the wgrad stream still holds of the earlier producer."""
-    if not (USE_DEFERRED_WGRAD and (_native.TIMING is None or _native.TIMING_IN_GRAPH) and torch.is_grad_enabled() is False
+    if not ((USE_DEFERRED_WGRAD or _IN_HEAD_STACK) and (_native.TIMING is None or _native.TIMING_IN_GRAPH)
+            and torch.is_grad_enabled() is False
             and all(getattr(p, "grad", None) is None for p in params)):
         return False
     if any(_Claims.taken_by_other_node(p) for p in params):
@@ -1543,7 +1560,7 @@ class FusedBiasMLPFunction(Function):
         dev = x.device
         _enter_backward(dev)
         need_w = [ctx.needs_input_grad[2 + 2 * li] for li in range(n)]
-        with torch.cuda.device(dev):
+        with torch.cuda.device(dev), _head_stack():
             grads, dx, _ = _backward_stack(lib, dev, _st(dev), b, c0, npts, 1, x, None, False, ys, bns, flat,
                                            None, dout.contiguous(), need_w, ctx.needs_input_grad[0])
         out = []
@@ -1687,8 +1704,9 @@ class FusedMultiSourceBiasMLPFunction(Function):
                 _native.check(lib.istnet_expand_rows(b * c_last, npts, dout.data_ptr(), dense.data_ptr(), _st(dev)),
                               "expand_rows")
                 dout = dense
-            grads, _, _ = _backward_stack(lib, dev, _st(dev), b, cin_total, npts, 1, None, None, False, ys, bns, flat,
-                                          None, dout, need_w, True, layer0_hook=layer0)
+            with _head_stack():
+                grads, _, _ = _backward_stack(lib, dev, _st(dev), b, cin_total, npts, 1, None, None, False, ys, bns, flat,
+                                              None, dout, need_w, True, layer0_hook=layer0)
         out = []
         for li in range(n):
             dw = grads[3 * li]
