@@ -156,6 +156,16 @@ USE_RGB_STREAM = True
 USE_EARLY_WORLD_EXTRACTOR = os.environ.get("ISTNET_EARLY_WORLD", "1") != "0"   # training: the auxiliary world-space encoder beside the RGB branch (it reads inputs only)
 USE_GATHER_FIRST = True
 _RGB_STREAMS = {}
+_WORLD_STREAMS = {}
+USE_WORLD_EXTRACTOR_STREAM = os.environ.get("ISTNET_WORLD_EXTRACTOR_STREAM", "0") == "1"   # experiment
+
+
+def _world_stream(dev):
+    key = dev.index if dev.index is not None else torch.cuda.current_device()
+    if key not in _WORLD_STREAMS:
+        _WORLD_STREAMS[key] = torch.cuda.Stream(device=dev)
+    return _WORLD_STREAMS[key]
+
 
 
 def _rgb_stream(dev):
@@ -240,7 +250,18 @@ class IST_Net(nn.Module):
             # the world-space encoder of the auxiliary branch reads the ground-truth coordinates only (reference ist_net.py:50-51 calls
             # it last): issued here, its sampling chain and its many short kernels run beside the RGB branch instead of
             # heading the serial part of the step; backward follows the same order in reverse
-            pts_w_local_gt = self.world_enhancer.extractor(inputs["qo"])
+            if USE_WORLD_EXTRACTOR_STREAM and pts.is_cuda:
+                # on a stream of its own: autograd replays its backward there, so in a graph replay it starts as soon as
+                # its output's gradient exists (the auxiliary estimator and the feature loss are the first things backward
+                # does) instead of after all the heads' backward on the main stream
+                cur = torch.cuda.current_stream(pts.device)
+                ws = _world_stream(pts.device)
+                ws.wait_stream(cur)
+                with torch.cuda.stream(ws):
+                    pts_w_local_gt = self.world_enhancer.extractor(inputs["qo"])
+                self._world_join = (cur, ws)
+            else:
+                pts_w_local_gt = self.world_enhancer.extractor(inputs["qo"])
         if rgb_last:
             if side is not None:
                 with torch.cuda.stream(side):
@@ -250,6 +271,11 @@ class IST_Net(nn.Module):
         if side is not None:
             main.wait_stream(side)
             rgb_local.record_stream(main)
+        if getattr(self, "_world_join", None) is not None:
+            cur, ws = self._world_join
+            cur.wait_stream(ws)
+            pts_w_local_gt.record_stream(cur)
+            self._world_join = None
         if self.training:
             r_cam, t_cam, s_cam = self.cam_enhancer(pts, rgb_local, pts_local)
         pts_w, pts_w_local = self.implicit_transform(rgb_local, pts_local, pts, c, index)
