@@ -113,10 +113,13 @@ ISTNET_PN2_API int istnet_pw_forward_gather(int b, int n, int npoint, int nsampl
                                             const float *feat_t, const int *idx, const float *w, float *y,
                                             float *part_sum, float *part_sq, void *stream);
 
-/* partials -> bn[4][c]; updates running_mean / running_var (unbiased) with `momentum` unless NULL */
+/* partials -> bn[4][c]; updates running_mean / running_var (unbiased) unless they are NULL.  `momentum` is a DEVICE
+ * pointer to one float, read when the kernel runs: a step captured in a HIP graph then follows the per-iteration
+ * BNMomentumScheduler.step of the reference (utils/solver.py:91-92, pytorch_utils.py:303-330) instead of replaying the
+ * value it was captured with. */
 ISTNET_PN2_API int istnet_bn_finalize_fwd(int c, int nt, double count, const float *part_sum,
                                           const float *part_sq, const float *gamma, const float *beta,
-                                          float eps, float momentum, float *running_mean,
+                                          float eps, const float *momentum, float *running_mean,
                                           float *running_var, float *bn, void *stream);
 
 /* out[b][c][g] = max_s relu(y[b][c][g][s]*scale+shift), arg = index of the first maximum (s > 1); cloud b of
@@ -264,55 +267,30 @@ ISTNET_PN2_API int istnet_pw_wgrad_reduce_multi(int n, const int *counts, const 
 ISTNET_PN2_API int istnet_bn_relu_mean(int b, int c, int p, const float *y, const float *bn, float *out, void *stream);
 ISTNET_PN2_API int istnet_expand_rows(int rows, int p, const float *g, float *out, void *stream);
 
-/* ---- the LAST layer of a set-abstraction scale without its activation (csrc/pw_last.hip; reference
+/* ---- the LAST layer of a set-abstraction scale with the max-pool in the GEMM's epilogue (reference
  * pointnet2_modules.py:61-71: conv1x1 -> BatchNorm2d -> ReLU -> max_pool2d over nsample) ----
- * forward: istnet_pw_forward_pool = istnet_pw_forward whose epilogue keeps, per (channel, ball of nsample consecutive
- * points), the raw extremum of sign(gamma) * y (`gval`, (b, cout, p / nsample)) and its slot (`arg`, uint8) instead of
- * writing y; part_sum / part_sq as in istnet_pw_forward ([cout][istnet_pw_forward_tiles(...)]).  Shapes for which
+ * istnet_pw_forward_pool = istnet_pw_forward whose epilogue ALSO keeps, per (channel, ball of nsample consecutive
+ * points), the raw extremum of sign(gamma) * y (`gval`, (b, cout, p / nsample)) and its slot (`arg`, uint8): the pool
+ * commutes with the monotone map y -> relu(scale y + shift).  y may be NULL (the activation is then not stored);
+ * part_sum / part_sq as in istnet_pw_forward ([cout][istnet_pw_forward_tiles(...)]).  Shapes for which
  * istnet_pw_forward_pool_ok(...) is 0 return ISTNET_PN2_EINVAL (nsample in {16, 32}, cout >= 64, the direct-operand
  * forward kernel's launch sizes). */
 ISTNET_PN2_API int istnet_pw_forward_pool_ok(int b, int cin, int cout, int p, int nsample);
 ISTNET_PN2_API int istnet_pw_forward_pool(int b, int cin, int cout, int p, int nsample, const float *x, const float *w,
-                                          const float *in_scale, const float *in_shift, const float *gamma,
+                                          const float *in_scale, const float *in_shift, const float *gamma, float *y,
                                           float *gval, unsigned char *arg, float *part_sum, float *part_sq,
                                           void *stream);
-/* training-mode tail: istnet_bn_finalize_fwd on the partials (writes bn[4][c], updates the running statistics), then
- * out[b][c][g] = relu(scale_c * gval[b][c][g] + shift_c); out rows may be a channel slice of a wider tensor
- * (out_bstride elements between clouds, 0 = c * g). */
+/* training-mode tail: istnet_bn_finalize_fwd on the partials (writes bn[4][c], updates the running statistics; momentum
+ * is a device pointer as there), then out[b][c][g] = relu(scale_c * gval[b][c][g] + shift_c); out rows may be a channel
+ * slice of a wider tensor (out_bstride elements between clouds, 0 = c * g). */
 ISTNET_PN2_API int istnet_bn_finalize_pool_apply(int b, int c, int g, int nt, double count, const float *part_sum,
                                                  const float *part_sq, const float *gamma, const float *beta, float eps,
-                                                 float momentum, float *running_mean, float *running_var, float *bn,
-                                                 const float *gval, float *out, long long out_bstride, void *stream);
+                                                 const float *momentum, float *running_mean, float *running_var,
+                                                 float *bn, const float *gval, float *out, long long out_bstride,
+                                                 void *stream);
 /* the apply alone, constants given (eval-mode BatchNorm) */
 ISTNET_PN2_API int istnet_pool_apply(int b, int c, int g, const float *bn, const float *gval, float *out,
                                      long long out_bstride, void *stream);
-/* backward of that layer from a = act(y_{L-1}) only.  With g' the max-pool gradient (one non-zero per channel and ball)
- * and dY = ca g' + cb + cc y (bwdc of istnet_bn_bwd_pooled_finalize), y = W a:
- *     dA = (W^T diag(cc) W) a + W^T cb + W^T (ca g')        dW = diag(cc) W (a a^T) + cb (sum a)^T + (ca g') a^T
- * 1. istnet_pw_last_prep: e_nat (b, cout, g) = ca g' per ball, e_t / slot_t (b, g, cout) the same and the slots with the
- *    channel index contiguous, m (cin, cin) = W^T diag(cc) W, c0 (cin) = W^T cb;
- * 2. istnet_pw_bwd_last: dx (b, cin, p) and the statistics partials of layer L-1 [cin][istnet_pw_bwd_last_splits(...)];
- * 3. istnet_pw_dw_last (off the critical chain): per-workgroup partials gram_part [splits][cin][cin], sa_part
- *    [splits][cin], dws_part [istnet_pw_dw_last_parts(...)][cout][cin]; after summing them (istnet_pw_wgrad_reduce_multi)
- * 4. istnet_pw_dw_last_finish: dw = dws + cb sa^T + diag(cc) W gram   (dws and dw may be the same buffer).
- * cin in {32, 64, 128}, cout in {64, 128, 256}, nsample in {16, 32}, p % 128 == 0 (istnet_pw_bwd_last_ok). */
-ISTNET_PN2_API int istnet_pw_bwd_last_ok(int cin, int cout, int p, int nsample);
-ISTNET_PN2_API int istnet_pw_bwd_last_splits(int b, int cin, int cout, int p, int nsample);
-ISTNET_PN2_API int istnet_pw_last_set_tuning(int key, int value);   /* 0: workgroup target, 1: enable */
-ISTNET_PN2_API int istnet_pw_last_prep(int b, int cin, int cout, int p, int nsample, const float *w, const float *bn,
-                                       const float *bwdc, const float *d_pooled, long long pooled_bstride,
-                                       const float *gval, const unsigned char *arg, float *e_nat, float *e_t,
-                                       unsigned char *slot_t, float *m, float *c0, void *stream);
-ISTNET_PN2_API int istnet_pw_bwd_last(int b, int cin, int cout, int p, int nsample, const float *w, const float *x,
-                                      const float *bn_in, const float *m, const float *c0, const float *e_t,
-                                      const unsigned char *slot_t, float *dx, float *part_g, float *part_gy,
-                                      void *stream);
-ISTNET_PN2_API int istnet_pw_dw_last_parts(int b, int cin, int cout, int p, int nsample);
-ISTNET_PN2_API int istnet_pw_dw_last(int b, int cin, int cout, int p, int nsample, const float *x, const float *bn_in,
-                                     const float *e_nat, const unsigned char *arg, float *gram_part, float *sa_part,
-                                     float *dws_part, void *stream);
-ISTNET_PN2_API int istnet_pw_dw_last_finish(int cin, int cout, const float *w, const float *bwdc, const float *gram,
-                                            const float *sa, const float *dws, float *dw, void *stream);
 
 /* ... where item l may be a column block of a wider destination and a row block of wider partials: element i of the
  * item (i < counts[l], counts[l] % cols[l] == 0) is the sum over k < splits[l] of parts[l][k * pstrides[l] + i] and goes

@@ -82,7 +82,7 @@ SIGNATURES = {
     "istnet_pw_gather_add": [_i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _i, _p, _p, _p, _p],
     "istnet_pw_forward_gather": [_i, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p],
     "istnet_pw_wgrad_gather": [_i, _i, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _l, _p, _p, _p, _p, _p],
-    "istnet_bn_finalize_fwd": [_i, _i, _d, _p, _p, _p, _p, _f, _f, _p, _p, _p, _p],
+    "istnet_bn_finalize_fwd": [_i, _i, _d, _p, _p, _p, _p, _f, _p, _p, _p, _p, _p],
     "istnet_bn_relu_pool": [_i, _i, _i, _i, _p, _p, _p, _l, _p, _p, _p],
     "istnet_pw_bwd_stats_pooled": [_i, _i, _i, _p, _l, _p, _p, _p, _p, _p],
     "istnet_bn_bwd_dense_finalize": [_i, _i, _i, _d, _i, _p, _p, _p, _p, _p, _p, _p, _p],
@@ -120,19 +120,11 @@ SIGNATURES = {
     "istnet_smooth_l1_backward": [_l, _f, _p, _p, _p, _p, _p],
     "istnet_mse_parts": [_l],
     "istnet_mse_value_grad": [_l, _p, _p, _p, _p, _p, _p],
-    # csrc/pw_last.hip
+    # last layer of a set-abstraction scale with the max-pool in the GEMM epilogue (csrc/pw_mlp.hip)
     "istnet_pw_forward_pool_ok": [_i, _i, _i, _i, _i],
-    "istnet_pw_forward_pool": [_i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p],
-    "istnet_bn_finalize_pool_apply": [_i, _i, _i, _i, _d, _p, _p, _p, _p, _f, _f, _p, _p, _p, _p, _p, _l, _p],
+    "istnet_pw_forward_pool": [_i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p],
+    "istnet_bn_finalize_pool_apply": [_i, _i, _i, _i, _d, _p, _p, _p, _p, _f, _p, _p, _p, _p, _p, _p, _l, _p],
     "istnet_pool_apply": [_i, _i, _i, _p, _p, _p, _l, _p],
-    "istnet_pw_bwd_last_ok": [_i, _i, _i, _i],
-    "istnet_pw_bwd_last_splits": [_i, _i, _i, _i, _i],
-    "istnet_pw_last_set_tuning": [_i, _i],
-    "istnet_pw_last_prep": [_i, _i, _i, _i, _i, _p, _p, _p, _p, _l, _p, _p, _p, _p, _p, _p, _p, _p],
-    "istnet_pw_bwd_last": [_i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p],
-    "istnet_pw_dw_last_parts": [_i, _i, _i, _i, _i],
-    "istnet_pw_dw_last": [_i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p],
-    "istnet_pw_dw_last_finish": [_i, _i, _p, _p, _p, _p, _p, _p, _p],
     # compact-column form of a set-abstraction scale (csrc/sa_compact.hip)
     "istnet_sa_compact": [_i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p],
     "istnet_pw_gather_add_cols": [_i, _i, _i, _l, _i, _p, _p, _p, _p, _p, _p, _p, _p, _i, _p, _p, _p, _p],

@@ -483,13 +483,15 @@ __global__ __launch_bounds__(kThreads) void pw_fwd_kernel(
 // 4 TMW MFMAs -- the LDS-tiled kernel above needs 2 ds_read_b32 per MFMA at its 64 x 64 tiles.
 // Wave tile: 32 TMW rows x 128 points; WM x WN waves per workgroup; grid (tiles_per_cloud * B, ceil(cout / M_WG)).
 // ============================================================================================
-// POOL = S > 0 (the LAST layer of a set-abstraction scale, nsample S in {16, 32}): y is NOT written.  The reference's
+// POOL = S > 0 (the LAST layer of a set-abstraction scale, nsample S in {16, 32}): the max-pool happens HERE.  The reference's
 // tail  max_pool2d(relu(bn(y)))  (pointnet2_modules.py:65-68) commutes with the monotone map y -> relu(scale y + shift):
 // the pooled value of a group is relu(scale y* + shift) with y* the raw maximum for scale >= 0 and the raw minimum for
 // scale < 0, and sign(scale) = sign(gamma) is known before the statistics are.  So the epilogue reduces each group of S
 // consecutive points of a row -- S / 4 adjacent lanes x the 4 accumulators -- to (y*, slot of y*) with DPP quad / row
-// permutes and stores (B, C, G) values (`gval`, `arg`); the widest activation of the stack (34-67 MB per scale) never
-// exists, the max-pool pass does not read it back, and the backward pass runs from act(y_{L-1}) (pw_bwd_last_kernel).
+// permutes and stores (B, C, G) values (`gval`, `arg`): the separate max-pool pass, which read the widest activation of the
+// stack (34-67 MB per scale) back and sat on the forward chain, does not exist; bn_finalize_pool_apply_kernel finishes
+// the statistics and applies BatchNorm + ReLU to the (B, C, G) extrema.  y is still written when the caller passes it
+// (the backward pass reads it; round 3's activation-free backward, tools/exp/pw_last/, was measured slower and removed).
 // max / min with the permuted operand as a DPP source: ONE instruction per butterfly step (the builtin form leaves a
 // v_mov_dpp, a canonicalising v_max x,x and the max itself).  s_nop 1: a DPP read of a VGPR written by the previous
 // VALU instruction needs two wait states, and the hazard recogniser does not look inside inline assembly.
@@ -641,9 +643,8 @@ __global__ __launch_bounds__(kThreads, 2) void pw_fwd2_kernel(
           gval[o] = zero_gamma ? v.x : __uint_as_float(__float_as_uint(m) ^ sb);
           garg[o] = zero_gamma ? (uint8_t)0 : (uint8_t)cand;
         }
-      } else if (live && row < cout) {
-        *reinterpret_cast<float4*>(yb + (size_t)row * P) = v;
       }
+      if ((!POOL || y != nullptr) && live && row < cout) *reinterpret_cast<float4*>(yb + (size_t)row * P) = v;
       if (part_sum != nullptr) {
         float s = live ? (v.x + v.y) + (v.z + v.w) : 0.f;
         float q = live ? (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w) : 0.f;
@@ -926,7 +927,7 @@ __device__ __forceinline__ void reduce_partials2(const float* __restrict__ pa, c
 // out: bn[0]=scale, bn[1]=shift, bn[2]=mean, bn[3]=invstd   (each [C])
 __global__ __launch_bounds__(kFinThreads) void bn_finalize_fwd_kernel(
     int C, int nt, double count, const float* __restrict__ part_sum, const float* __restrict__ part_sq,
-    const float* __restrict__ gamma, const float* __restrict__ beta, float eps, float momentum,
+    const float* __restrict__ gamma, const float* __restrict__ beta, float eps, const float* __restrict__ momentum_p,
     float* __restrict__ running_mean, float* __restrict__ running_var, float* __restrict__ bn) {
   const int c = blockIdx.x;
   double s, q;
@@ -942,10 +943,68 @@ __global__ __launch_bounds__(kFinThreads) void bn_finalize_fwd_kernel(
     bn[2 * C + c] = (float)mean;
     bn[3 * C + c] = istd;
     if (running_mean != nullptr) {
+      // momentum lives in device memory: a captured step replays with whatever BNMomentumScheduler.step wrote last
+      // (reference utils/solver.py:91-92 steps it every iteration)
+      const float momentum = *momentum_p;
       const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
       running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
       running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
     }
+  }
+}
+
+// ============================================================================================
+// forward tail of a pooled last layer (pw_fwd2_kernel<..., POOL>): BatchNorm statistics from the GEMM's partials, then
+// out = relu(scale y* + shift) on the (B, C, G) extrema the pooled epilogue left -- the finalize and the (former)
+// max-pool launch in one.  One workgroup per channel.
+// ============================================================================================
+__global__ __launch_bounds__(kFinThreads) void bn_finalize_pool_apply_kernel(
+    int C, int B, int G, int nt, double count, const float* __restrict__ part_sum, const float* __restrict__ part_sq,
+    const float* __restrict__ gamma, const float* __restrict__ beta, float eps, const float* __restrict__ momentum_p,
+    float* __restrict__ running_mean, float* __restrict__ running_var, float* __restrict__ bn,
+    const float* __restrict__ gval, float* __restrict__ out, long long out_bstride) {
+  const int c = blockIdx.x;
+  double s, q;
+  reduce_partials2(part_sum + (size_t)c * nt, part_sq + (size_t)c * nt, nt, s, q);
+  __shared__ float s_aff[2];
+  if (threadIdx.x == 0) {
+    const double mean = s / count;
+    double var = q / count - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const float istd = (float)(1.0 / sqrt(var + (double)eps));
+    const float sc = gamma[c] * istd;
+    const float shf = beta[c] - (float)mean * sc;
+    bn[0 * C + c] = sc;
+    bn[1 * C + c] = shf;
+    bn[2 * C + c] = (float)mean;
+    bn[3 * C + c] = istd;
+    if (running_mean != nullptr) {
+      const float momentum = *momentum_p;
+      const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
+      running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
+      running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
+    }
+    s_aff[0] = sc;
+    s_aff[1] = shf;
+  }
+  __syncthreads();
+  const float sc = s_aff[0], shf = s_aff[1];
+  for (int e = threadIdx.x; e < B * G; e += kFinThreads) {
+    const int b = e / G, g = e - b * G;
+    const float v = gval[((size_t)b * C + c) * G + g];
+    out[(size_t)b * out_bstride + (size_t)c * G + g] = fmaxf(v * sc + shf, 0.f);
+  }
+}
+
+// eval-mode / fixed-affine variant of the tail: constants given, only the apply
+__global__ __launch_bounds__(256) void pool_apply_kernel(int C, int G, int rows, const float* __restrict__ bn,
+                                                         const float* __restrict__ gval, float* __restrict__ out,
+                                                         long long out_bstride) {
+  const int g = blockIdx.x * 256 + threadIdx.x;
+  if (g >= G) return;
+  for (int bc = blockIdx.y; bc < rows; bc += gridDim.y) {
+    const int b = bc / C, c = bc - b * C;
+    out[(size_t)b * out_bstride + (size_t)c * G + g] = fmaxf(gval[(size_t)bc * G + g] * bn[c] + bn[C + c], 0.f);
   }
 }
 
@@ -3431,13 +3490,35 @@ int istnet_pw_forward_pool_ok(int b, int cin, int cout, int p, int nsample) {
 }
 
 int istnet_pw_forward_pool(int b, int cin, int cout, int p, int nsample, const float* x, const float* w,
-                           const float* in_scale, const float* in_shift, const float* gamma, float* gval,
+                           const float* in_scale, const float* in_shift, const float* gamma, float* y, float* gval,
                            unsigned char* arg, float* part_sum, float* part_sq, void* stream) {
   if (b <= 0 || cin <= 0 || cout <= 0 || p <= 0 || (p & 3) || gamma == nullptr || gval == nullptr || arg == nullptr)
     return ISTNET_PN2_EINVAL;
   if (!fwd_pool_ok(b, cin, cout, p, nsample)) return ISTNET_PN2_EINVAL;
-  return launch_pw_fwd2(fwd2_cfg(b, cin, cout, p), b, cin, cout, p, x, w, in_scale, in_shift, nullptr, part_sum, part_sq,
+  return launch_pw_fwd2(fwd2_cfg(b, cin, cout, p), b, cin, cout, p, x, w, in_scale, in_shift, y, part_sum, part_sq,
                         stream, nsample, gamma, gval, arg);
+}
+
+int istnet_bn_finalize_pool_apply(int b, int c, int g, int nt, double count, const float* part_sum, const float* part_sq,
+                                  const float* gamma, const float* beta, float eps, const float* momentum,
+                                  float* running_mean, float* running_var, float* bn, const float* gval, float* out,
+                                  long long out_bstride, void* stream) {
+  if (b <= 0 || c <= 0 || g <= 0 || nt <= 0 || count <= 0.0 || !part_sum || !part_sq || !gamma || !beta || !bn || !gval ||
+      !out || (running_mean != nullptr && momentum == nullptr))
+    return ISTNET_PN2_EINVAL;
+  hipLaunchKernelGGL(bn_finalize_pool_apply_kernel, dim3(c), dim3(kFinThreads), 0, as_stream(stream), c, b, g, nt, count,
+                     part_sum, part_sq, gamma, beta, eps, momentum, running_mean, running_var, bn, gval, out,
+                     out_bstride > 0 ? out_bstride : (long long)c * g);
+  return (int)hipGetLastError();
+}
+
+int istnet_pool_apply(int b, int c, int g, const float* bn, const float* gval, float* out, long long out_bstride,
+                      void* stream) {
+  if (b <= 0 || c <= 0 || g <= 0 || !bn || !gval || !out) return ISTNET_PN2_EINVAL;
+  const long long rows = (long long)b * c;
+  hipLaunchKernelGGL(pool_apply_kernel, dim3(ceil_div(g, 256), (unsigned)(rows < 65535 ? rows : 65535)), dim3(256), 0,
+                     as_stream(stream), c, g, (int)rows, bn, gval, out, out_bstride > 0 ? out_bstride : (long long)c * g);
+  return (int)hipGetLastError();
 }
 
 int istnet_pw_forward_tiles(int b, int cin, int cout, int p) {
@@ -3529,9 +3610,9 @@ int istnet_pw_forward_gather(int b, int n, int npoint, int nsample, int cfeat, i
 }
 
 int istnet_bn_finalize_fwd(int c, int nt, double count, const float* part_sum, const float* part_sq,
-                           const float* gamma, const float* beta, float eps, float momentum,
+                           const float* gamma, const float* beta, float eps, const float* momentum,
                            float* running_mean, float* running_var, float* bn, void* stream) {
-  if (c <= 0 || nt <= 0) return ISTNET_PN2_EINVAL;
+  if (c <= 0 || nt <= 0 || (running_mean != nullptr && momentum == nullptr)) return ISTNET_PN2_EINVAL;
   hipLaunchKernelGGL(bn_finalize_fwd_kernel, dim3(c), dim3(kFinThreads), 0, as_stream(stream), c, nt, count,
                      part_sum, part_sq, gamma, beta, eps, momentum, running_mean, running_var, bn);
   return (int)hipGetLastError();

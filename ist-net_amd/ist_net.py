@@ -175,19 +175,38 @@ def _rgb_stream(dev):
     return _RGB_STREAMS[key]
 
 
-def point_branch_side_streams(enabled):
+class point_branch_side_streams:
     """The point branch's own side streams -- the concurrent MSG scales and the deferred weight-gradient stream of
-    pointnet2.fused_mlp -- on or off for the whole process.  They are worth 15 % for the encoder alone, where nothing else
-    shares the chip; inside the full model the RGB branch's convolutions fill it, and the extra streams only let the
-    encoders' backward be queued behind the RGB backward instead of beside it (HIP-graph replay of the config-3 step:
-    33.8 ms with them, 32.3 without; tools/istnet_step_timeline.py shows the stall).  Call with False before training
-    the full model (bench.py --workload istnet and examples/train_synthetic.py do)."""
-    from .pointnet2 import fused_mlp
-    fused_mlp.USE_SCALE_STREAMS = bool(enabled)
-    fused_mlp.USE_DEFERRED_WGRAD = bool(enabled)
-    # the IST / pose heads' per-point stacks keep deferring their weight-gradient GEMMs either way: on the chain they delay
-    # the gradient the RGB backward waits for (32.4 -> 32.1 ms)
-    fused_mlp.USE_DEFERRED_WGRAD_HEADS = True
+    pointnet2.fused_mlp -- on or off.  They are worth 15 % for the encoder alone, where nothing else shares the chip;
+    inside the full model the RGB branch's convolutions fill it, and the extra streams only let the encoders' backward be
+    queued behind the RGB backward instead of beside it (HIP-graph replay of the config-3 step: 33.8 ms with them, 32.3
+    without; tools/istnet_step_timeline.py shows the stall).
+
+    ``point_branch_side_streams(False)`` takes effect at once (bench.py --workload istnet and
+    examples/train_synthetic.py call it before training the full model); the returned object restores the previous
+    process-wide values with ``.restore()`` or as a context manager (``with point_branch_side_streams(False): ...``), so
+    a test that flips the switches does not leak into the next one."""
+
+    def __init__(self, enabled):
+        from .pointnet2 import fused_mlp
+        self._saved = (fused_mlp.USE_SCALE_STREAMS, fused_mlp.USE_DEFERRED_WGRAD, fused_mlp.USE_DEFERRED_WGRAD_HEADS)
+        fused_mlp.USE_SCALE_STREAMS = bool(enabled)
+        fused_mlp.USE_DEFERRED_WGRAD = bool(enabled)
+        if not enabled:
+            # the IST / pose heads' per-point stacks keep deferring their weight-gradient GEMMs when the encoders' nodes
+            # do not: on the chain they delay the gradient the RGB backward waits for (32.4 -> 32.1 ms)
+            fused_mlp.USE_DEFERRED_WGRAD_HEADS = True
+
+    def restore(self):
+        from .pointnet2 import fused_mlp
+        fused_mlp.USE_SCALE_STREAMS, fused_mlp.USE_DEFERRED_WGRAD, fused_mlp.USE_DEFERRED_WGRAD_HEADS = self._saved
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.restore()
+        return False
 
 
 class IST_Net(nn.Module):
@@ -257,6 +276,7 @@ class IST_Net(nn.Module):
                 cur = torch.cuda.current_stream(pts.device)
                 ws = _world_stream(pts.device)
                 ws.wait_stream(cur)
+                inputs["qo"].record_stream(ws)
                 with torch.cuda.stream(ws):
                     pts_w_local_gt = self.world_enhancer.extractor(inputs["qo"])
                 self._world_join = (cur, ws)

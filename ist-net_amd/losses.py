@@ -61,8 +61,9 @@ def mse_value_and_grad(a, b=None):
     (what bench.py does for its encoder workload); the gradient with respect to ``b`` is ``-g``.  No graph is recorded."""
     x = a.detach()
     y = b.detach() if b is not None else None
-    if (not x.is_cuda or x.dtype != torch.float32 or not x.is_contiguous()
-            or (y is not None and (y.shape != x.shape or y.dtype != x.dtype or not y.is_contiguous()))):
+    if (not x.is_cuda or x.dtype != torch.float32 or not x.is_contiguous() or x.data_ptr() % 16
+            or (y is not None and (y.shape != x.shape or y.dtype != x.dtype or not y.is_contiguous() or y.data_ptr() % 16))):
+        # (the native pass reads float4: a contiguous view at an odd storage offset takes the framework's ops too)
         d = x if y is None else x - y
         return d.square().mean(), d * (2.0 / d.numel())
     from . import _native

@@ -175,6 +175,15 @@ class FlatAdam(torch.optim.Optimizer):
                     self.betas[0], self.betas[1],
                     self.eps, self.weight_decay, float(grad_scale),
                     torch.cuda.current_stream(self.flat.device).cuda_stream), "adam_step")
+            # The native update writes the flat buffer through raw pointers, which autograd cannot see: tell it.  A
+            # forward whose backward runs AFTER this step (two forwards then backward / step / backward, a prefetched
+            # next forward) then raises "modified by an inplace operation" instead of silently differentiating with the
+            # updated weights -- the fused nodes save views of live parameter memory (fused_mlp.FusedSALevelFunction).
+            try:
+                torch._C._autograd._unsafe_set_version_counter(
+                    tuple(self.params), tuple(p._version + 1 for p in self.params))
+            except (AttributeError, TypeError):      # private API: best effort
+                pass
             return
         if grad_scale != 1.0:
             g = g * grad_scale

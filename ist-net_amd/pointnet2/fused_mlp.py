@@ -20,6 +20,7 @@ import torch
 from torch.autograd import Function
 
 from .. import _native
+from .pytorch_utils import bn_momentum_ptr
 
 
 if os.environ.get("ISTNET_POISON_ALLOC"):  # debugging aid: expose reads of never-written workspace
@@ -33,7 +34,7 @@ else:
         return torch.empty(shape, dtype=dtype, device=device)
 
 
-STATS = {"pool_epilogue": 0}     # how often a stack took the activation-free last layer (tests assert the path they mean)
+STATS = {"pool_epilogue": 0}     # how often a stack took the pooled-epilogue last layer (tests assert the path they mean)
 FALLBACKS = {}     # reason -> number of times a CUDA input took the torch composition instead of the fused kernels
 
 
@@ -120,8 +121,9 @@ def _ident_consts(dev, c):
 # .grad would be read on the main stream before the join), no kernel timing in progress.  Everything the
 # deferred launches read is kept alive until the join.  (A per-layer fork onto a side stream was measured
 # slower: 32 extra cross-stream edges per step.)
-USE_DEFERRED_WGRAD = os.environ.get("ISTNET_DEFERRED_WGRAD", "1") != "0"    # module attributes, not environment switches: tests flip each fallback once
-                             # (tests/test_pipeline_gpu.py::test_fallback_paths_agree_with_default)
+USE_DEFERRED_WGRAD = os.environ.get("ISTNET_DEFERRED_WGRAD", "1") != "0"    # module attribute; the environment variable only sets its import-time
+                             # default (A/B runs).  tests/test_pipeline_gpu.py::test_fallback_paths_agree_with_default flips each
+                             # switch once; ist_net.point_branch_side_streams sets and restores this one and USE_SCALE_STREAMS
 
 
 # Stream priorities were tried too (capture stream and scale streams at priority -1, the wgrad stream at 0): the step
@@ -222,7 +224,7 @@ def _p(t):
 
 class _Layer:
     """Per-layer constants handed to the autograd function (not differentiable)."""
-    __slots__ = ("running_mean", "running_var", "momentum", "eps", "bias_only", "relu")
+    __slots__ = ("running_mean", "running_var", "momentum_ptr", "eps", "bias_only", "relu")
 
     def __init__(self, bn=None, relu=True):
         self.bias_only = bn is None      # conv + bias (+ ReLU) instead of conv + BatchNorm + ReLU
@@ -230,7 +232,10 @@ class _Layer:
         if bn is not None:
             self.running_mean = bn.running_mean
             self.running_var = bn.running_var
-            self.momentum = bn.momentum
+            # device address of the module's momentum slot (pytorch_utils._MomentumSlots): the finalize kernels read the
+            # momentum from memory, so a captured step follows BNMomentumScheduler.step [ref utils/solver.py:91-92]
+            self.momentum_ptr = (bn_momentum_ptr(bn, bn.weight.device)
+                                 if (bn.weight.is_cuda and bn.momentum is not None) else None)
             self.eps = bn.eps
 
 
@@ -301,12 +306,12 @@ def _forward_stack(lib, dev, st, b, c0, g, s, x, gather, training, layers, param
         elif cfg2:
             kname = f"pw_fwd2_kernel<{cfg2 // 1000}, {cfg2 // 100 % 10}, {cfg2 // 10 % 10}, {32 if cfg2 % 10 else 16}, 0>"
         flops, nbytes = 2.0 * b * p * cur_c * cout, 4.0 * b * p * (cur_c + cout)
-        if (USE_POOL_EPILOGUE and li == len(layers) - 1 and li > 0 and s > 1 and plain and not lay.bias_only
-                and lay.relu and lib.istnet_pw_forward_pool_ok(b, cur_c, cout, p, s)
-                and lib.istnet_pw_bwd_last_ok(cur_c, cout, p, s)):
-            # LAST layer of a scale: the widest activation of the stack is never written -- the GEMM's epilogue keeps the
-            # raw extremum and its slot per (channel, ball) (csrc/pw_last.hip), one launch finishes the statistics and
-            # applies BatchNorm + ReLU to the (B, C, G) values; the backward pass runs from act(y_{L-1})
+        if (USE_POOL_EPILOGUE and tail and li == len(layers) - 1 and li > 0 and s > 1 and plain and not lay.bias_only
+                and lay.relu and lib.istnet_pw_forward_pool_ok(b, cur_c, cout, p, s)):
+            # LAST layer of a scale: the max-pool happens in the GEMM's epilogue (raw extremum + slot per (channel, ball)),
+            # and ONE launch finishes the statistics and applies BatchNorm + ReLU to the (B, C, G) extrema -- the separate
+            # pool pass, which read the stack's widest activation back and sat on the forward chain, is gone.  y is still
+            # written: the backward pass reads it.  [ref pointnet2_modules.py:65-68]
             if out_spec is None:
                 out = _empty((b, cout, g), torch.float32, dev)
                 out_ptr, out_bstride = out.data_ptr(), 0
@@ -315,22 +320,23 @@ def _forward_stack(lib, dev, st, b, c0, g, s, x, gather, training, layers, param
                 out_ptr, out_bstride = out.data_ptr() + coff * g * 4, out.shape[1] * g
             arg = _empty((_arg_bytes(b * cout * g) + 4 * b * cout * g,), torch.uint8, dev)
             gval = _ymax_ptr(arg, b * cout * g)
+            y = _empty((b, cout, p), torch.float32, dev)
             STATS["pool_epilogue"] += 1
             sc, sh = _p(in_bn[0]), _p(in_bn[1])
             cin_l, src = cur_c, cur
             kname = kname[:-2] + f"{s}>"
-            _native.check(_native.timed(kname, flops, 4.0 * b * (p * cur_c + 2 * g * cout), lambda: lib.istnet_pw_forward_pool(
-                b, cin_l, cout, p, s, src.data_ptr(), w2.data_ptr(), sc, sh, gamma.data_ptr(), gval, arg.data_ptr(), ps, pq,
-                st)), "pw_forward_pool")
+            _native.check(_native.timed(kname, flops, nbytes, lambda: lib.istnet_pw_forward_pool(
+                b, cin_l, cout, p, s, src.data_ptr(), w2.data_ptr(), sc, sh, gamma.data_ptr(), y.data_ptr(), gval,
+                arg.data_ptr(), ps, pq, st)), "pw_forward_pool")
             if li not in fixed:
                 _native.check(lib.istnet_bn_finalize_pool_apply(
                     b, cout, g, nt, float(b * p), ps, pq, gamma.data_ptr(), beta.data_ptr(), float(lay.eps),
-                    float(lay.momentum), _p(lay.running_mean), _p(lay.running_var), bn.data_ptr(), gval, out_ptr,
+                    lay.momentum_ptr, _p(lay.running_mean), _p(lay.running_var), bn.data_ptr(), gval, out_ptr,
                     out_bstride, st), "bn_finalize_pool_apply")
             else:
                 _native.check(lib.istnet_pool_apply(b, cout, g, bn.data_ptr(), gval, out_ptr, out_bstride, st),
                               "pool_apply")
-            ys.append(_empty((0,), torch.float32, dev))       # placeholder: this layer has no stored activation
+            ys.append(y)
             bns.append(bn)
             return out, arg, ys, bns
         y = _empty((b, cout, p), torch.float32, dev)
@@ -368,7 +374,7 @@ def _forward_stack(lib, dev, st, b, c0, g, s, x, gather, training, layers, param
         if li not in fixed:                  # training-mode BatchNorm: batch statistics of this layer's output
             _native.check(lib.istnet_bn_finalize_fwd(
                 cout, nt, float(b * p), ps, pq, gamma.data_ptr(), beta.data_ptr(), float(lay.eps),
-                float(lay.momentum), _p(lay.running_mean), _p(lay.running_var), bn.data_ptr(), st),
+                lay.momentum_ptr, _p(lay.running_mean), _p(lay.running_var), bn.data_ptr(), st),
                 "bn_finalize_fwd")
         ys.append(y)
         bns.append(bn)
@@ -434,7 +440,7 @@ def _forward_stack_compact(lib, dev, st, b, g, s, ga, training, layers, params, 
         if training:
             _native.check(lib.istnet_bn_finalize_fwd(
                 cout, nt, float(b * g * s), ps, pq, gamma.data_ptr(), beta.data_ptr(), float(lay.eps),
-                float(lay.momentum), _p(lay.running_mean), _p(lay.running_var), bn.data_ptr(), st), "bn_finalize_fwd")
+                lay.momentum_ptr, _p(lay.running_mean), _p(lay.running_var), bn.data_ptr(), st), "bn_finalize_fwd")
         else:
             _native.check(lib.istnet_affine_consts(cout, gamma.data_ptr(), beta.data_ptr(), lay.running_mean.data_ptr(),
                                                    lay.running_var.data_ptr(), float(lay.eps), bn.data_ptr(), st),
@@ -591,12 +597,12 @@ def _compact_ok(lib, ga, layers, params, needs_backward, needs_feature_grad):
     return True
 
 
-# Last layer of a scale WITHOUT its stored activation (csrc/pw_last.hip: max-pool in the GEMM epilogue, backward from
-# act(y_{L-1}) as M a + c0 + S).  Parity-green (tests/test_pw_last_gpu.py) and 1.0 GB per step lighter on HBM, but SLOWER:
-# 2.99-3.07 ms/step against 2.82 (profiles/r03_last_layer_activation_free.txt) -- the kernels it replaces run at 1.3-2.5
-# TB/s, i.e. they are instruction- / latency-bound, not HBM-bound, and the per-ball sparse term costs more issue slots than
-# the bytes were worth.  Off by default; ISTNET_POOL_EPILOGUE=1 (or assigning this attribute) turns it on.
-USE_POOL_EPILOGUE = os.environ.get("ISTNET_POOL_EPILOGUE", "0") == "1"
+# Last layer of a scale with the max-pool in the GEMM's epilogue (pw_fwd2_kernel<..., POOL>) and the finalize + apply in one
+# launch: one launch less on every scale's forward chain and no read-back of the widest activation.  (Round 3's
+# activation-FREE variant, whose backward ran from act(y_{L-1}) without y_L, moved 0.9 GB less per step but was slower --
+# profiles/r03_last_layer_activation_free.txt -- and lives in tools/exp/pw_last/ now.)  ISTNET_POOL_EPILOGUE=0 restores
+# the separate pool pass.
+USE_POOL_EPILOGUE = os.environ.get("ISTNET_POOL_EPILOGUE", "1") != "0"
 USE_FUSED_SMALL_BWD = True
 USE_POOLED_FINALIZE = True   # last layer of a scale: pooled statistics + BN-backward finalize in one launch
 USE_FINALIZE_IN_SCATTER = True  # layer 0 of an SA scale: BN-backward finalize inside the inverse-list scatter kernel
@@ -652,7 +658,6 @@ def _backward_stack(lib, dev, st, b, c0, g, s, x, gather, training, ys, bns, par
     wjobs = []                       # weight-gradient launches of the stack: (launch(stream) -> (n, splits, ws, dw))
     wlayers = []                     # layer index of each job
     wextra = []                      # further closures for the wgrad stream (layer0_hook)
-    wlast = []                       # (layer, job) of a last layer without activation: launches + its own reduce / finish
     for li in range(n - 1, -1, -1):
         w, gamma = params[3 * li], params[3 * li + 1]
         cout = w.shape[0]
@@ -664,59 +669,6 @@ def _backward_stack(lib, dev, st, b, c0, g, s, x, gather, training, ys, bns, par
         pbs = pooled_bstride if (pooled and li == n - 1) else 0
         grad_elems = b * cout * (p if dd is not None else p // s)
         part, dense_fin = None, False
-        if li == n - 1 and pooled and y.numel() == 0:
-            # the layer whose activation was never stored (pool in the forward epilogue): everything from act(y_{L-1})
-            dgamma = _grad_dest(gamma, (cout,), dev)
-            dbeta = _grad_dest(params[3 * li + 2], (cout,), dev)
-            bwdc = _empty((3, cout), torch.float32, dev)
-            gval = _ymax_ptr(d_arg, b * cout * g)
-            _native.check(lib.istnet_bn_bwd_pooled_finalize(
-                b, cout, g, float(b * p), 1 if training else 0, dp, pbs, gval, gamma.data_ptr(), bn.data_ptr(),
-                dgamma.data_ptr(), dbeta.data_ptr(), bwdc.data_ptr(), st), "bn_bwd_pooled_finalize")
-            grads[3 * li + 1], grads[3 * li + 2] = dgamma, dbeta
-            e_nat = _empty((b, cout, g), torch.float32, dev)
-            e_t = _empty((b, g, cout), torch.float32, dev)
-            slot_t = _empty((b, g, cout), torch.uint8, dev)
-            mmat = _empty((cin, cin), torch.float32, dev)
-            c0v = _empty((cin,), torch.float32, dev)
-            _native.check(lib.istnet_pw_last_prep(b, cin, cout, p, s, w2.data_ptr(), bn.data_ptr(), bwdc.data_ptr(), dp, pbs,
-                                                  gval, da, e_nat.data_ptr(), e_t.data_ptr(), slot_t.data_ptr(),
-                                                  mmat.data_ptr(), c0v.data_ptr(), st), "pw_last_prep")
-            splits = lib.istnet_pw_bwd_last_splits(b, cin, cout, p, s)
-            dprev = _empty((b, cin, p), torch.float32, dev)
-            fused_part, fused_nt = _empty((2, cin, splits), torch.float32, dev), splits
-            x_prev, bn_prev = ys[li - 1], bns[li - 1]
-            _native.check(_native.timed(
-                f"pw_bwd_last_kernel<{cin // 32}, {s}>", 2.0 * b * p * cin * cin, 8.0 * b * p * cin,
-                lambda: lib.istnet_pw_bwd_last(b, cin, cout, p, s, w2.data_ptr(), x_prev.data_ptr(), bn_prev.data_ptr(),
-                                               mmat.data_ptr(), c0v.data_ptr(), e_t.data_ptr(), slot_t.data_ptr(),
-                                               dprev.data_ptr(), fused_part[0].data_ptr(), fused_part[1].data_ptr(), st)),
-                "pw_bwd_last")
-            if need_w[li]:
-                def last_job(wst, cin=cin, cout=cout, w=w, w2=w2, x_prev=x_prev, bn_prev=bn_prev, e_nat=e_nat, d_arg=d_arg,
-                             bwdc=bwdc, splits=splits):
-                    nparts = lib.istnet_pw_dw_last_parts(b, cin, cout, p, s)
-                    gram_part = _empty((splits, cin, cin), torch.float32, dev)
-                    sa_part = _empty((splits, cin), torch.float32, dev)
-                    dws_part = _empty((nparts, cout, cin), torch.float32, dev)
-                    _native.check(_native.timed(
-                        f"pw_dw_last_kernel<{cin // 32}, {s}>", 2.0 * b * p * cin * cin, 4.0 * b * p * cin,
-                        lambda: lib.istnet_pw_dw_last(b, cin, cout, p, s, x_prev.data_ptr(), bn_prev.data_ptr(),
-                                                      e_nat.data_ptr(), d_arg.data_ptr(), gram_part.data_ptr(),
-                                                      sa_part.data_ptr(), dws_part.data_ptr(), wst)), "pw_dw_last")
-                    gram = _empty((cin, cin), torch.float32, dev)
-                    sa = _empty((cin,), torch.float32, dev)
-                    dw = _grad_dest(w, (cout, cin), dev)
-                    _native.reduce_multi([(cin * cin, splits, gram_part.data_ptr(), gram.data_ptr()),
-                                          (cin, splits, sa_part.data_ptr(), sa.data_ptr()),
-                                          (cout * cin, nparts, dws_part.data_ptr(), dw.data_ptr())], wst)
-                    _native.check(lib.istnet_pw_dw_last_finish(cin, cout, w2.data_ptr(), bwdc.data_ptr(), gram.data_ptr(),
-                                                               sa.data_ptr(), dw.data_ptr(), dw.data_ptr(), wst),
-                                  "pw_dw_last_finish")
-                    return (gram_part, sa_part, dws_part, gram, sa, e_nat, d_arg, bwdc, x_prev, bn_prev), dw
-                wlast.append((li, last_job))
-            d_dense, d_pooled, d_arg = dprev, None, None
-            continue
         if fused_part is not None:
             part, nt_l = fused_part, fused_nt
         elif ns_arg and USE_POOLED_FINALIZE and not (li == 0 and layer0_hook is not None):
@@ -866,9 +818,8 @@ def _backward_stack(lib, dev, st, b, c0, g, s, x, gather, training, ys, bns, par
             d_dense, d_pooled, d_arg = dprev, None, None
             if li == 0:
                 dx = dprev
-    if wjobs or wextra or wlast:
-        wparams = ([params[3 * li] for li in wlayers] + ([params[0]] if wextra else [])
-                   + [params[3 * li] for li, _ in wlast])
+    if wjobs or wextra:
+        wparams = [params[3 * li] for li in wlayers] + ([params[0]] if wextra else [])
         if _can_defer(wparams):
             # after the chain, on the wgrad stream; joined by the end-of-backward callback
             cur = torch.cuda.current_stream(dev)
@@ -876,24 +827,20 @@ def _backward_stack(lib, dev, st, b, c0, g, s, x, gather, training, ys, bns, par
             _Deferred.mains.setdefault(key, cur)
             wstream.wait_stream(cur)
             with torch.cuda.stream(wstream):
-                last_done = [(li, job(wstream.cuda_stream)) for li, job in wlast]
                 done = [job(wstream.cuda_stream) for job in wjobs]
                 if done:
                     _native.reduce_multi([(cnt, splits, ws.data_ptr(), dw.data_ptr()) for cnt, splits, ws, dw in done],
                                          wstream.cuda_stream)
                 extra_keep = [fn(wstream.cuda_stream) for fn in wextra]
-            _Deferred.keep += [wjobs, done, wextra, extra_keep, wlast, last_done]
+            _Deferred.keep += [wjobs, done, wextra, extra_keep]
             _Deferred.arm()
         else:
-            last_done = [(li, job(st)) for li, job in wlast]
             done = [job(st) for job in wjobs]
             if done:
                 _native.reduce_multi([(cnt, splits, ws.data_ptr(), dw.data_ptr()) for cnt, splits, ws, dw in done], st)
             for fn in wextra:
                 fn(st)
         for li, (_, _, _, dw) in zip(wlayers, done):
-            grads[3 * li] = dw.view_as(params[3 * li])
-        for li, (_, dw) in last_done:
             grads[3 * li] = dw.view_as(params[3 * li])
     return grads, dx, scattered
 
@@ -1384,7 +1331,7 @@ class FusedFPFunction(Function):
             if training:
                 _native.check(lib.istnet_bn_finalize_fwd(
                     cout0, nt, float(b * n), part[0].data_ptr(), part[1].data_ptr(), gamma0.data_ptr(), beta0.data_ptr(),
-                    float(lay0.eps), float(lay0.momentum), _p(lay0.running_mean), _p(lay0.running_var),
+                    float(lay0.eps), lay0.momentum_ptr, _p(lay0.running_mean), _p(lay0.running_var),
                     bn0.data_ptr(), st), "bn_finalize_fwd")
             else:
                 _native.check(lib.istnet_affine_consts(cout0, gamma0.data_ptr(), beta0.data_ptr(),

@@ -7,6 +7,7 @@ Mirror of the parts of model/pointnet2/pytorch_utils.py that the hot path uses
 (weight 1, bias 0) -> ``activation`` (ReLU, in place)], so a reference checkpoint key such as
 ``SA_modules.0.mlps.0.layer0.normlayer.bn.running_mean`` loads unchanged.
 """
+import torch
 import torch.nn as nn
 
 
@@ -125,6 +126,105 @@ def group_model_params(model, **kwargs):
     return [dict(params=decayed, **kwargs), dict(params=plain, **{**kwargs, "weight_decay": 0.0})]
 
 
+class _MomentumSlots:
+    """BatchNorm momenta in device memory, one f32 slot per module that runs on the fused kernels.
+
+    The finalize kernels (istnet_bn_finalize_fwd / istnet_bn_finalize_pool_apply) read the momentum through a pointer
+    instead of taking it by value, so a step captured in a HIP graph keeps following ``bn.momentum``: the reference
+    re-sets every BatchNorm's momentum each iteration (utils/solver.py:91-92 -> pytorch_utils.py:303-330).  The host
+    value of a module (``bn.momentum``) stays authoritative; ``ptr`` mirrors it into the module's slot whenever the two
+    differ -- with a one-element fill outside a capture, never inside one (a fill recorded in the graph would put the
+    old value back on every replay): there the caller must have synced before (``sync_bn_momentum`` /
+    ``BNMomentumScheduler.step``, both of which update all slots of a model with one host-to-device copy)."""
+    CAP = 4096
+    _bufs = {}          # device index -> [device tensor (CAP,), pinned host staging (CAP,), slots in use, host values]
+
+    @classmethod
+    def _buf(cls, dev):
+        key = dev.index if dev.index is not None else torch.cuda.current_device()
+        if key not in cls._bufs:
+            if torch.cuda.is_current_stream_capturing():
+                raise RuntimeError("BatchNorm momentum slots cannot be created while a HIP graph is being captured: "
+                                   "run one eager step or call pytorch_utils.sync_bn_momentum(model) before the capture")
+            host = torch.zeros(cls.CAP, dtype=torch.float32).pin_memory()
+            cls._bufs[key] = [torch.zeros(cls.CAP, dtype=torch.float32, device=dev), host, 0, []]
+        return key, cls._bufs[key]
+
+    @classmethod
+    def _slot(cls, bn, dev):
+        """(device key, index) of the module's slot on ``dev``; allocated on first use.  The record carries the owner's id:
+        a deep-copied module must not share its source's slot."""
+        rec = bn.__dict__.get("_istnet_mslot")
+        key = dev.index if dev.index is not None else torch.cuda.current_device()
+        if rec is not None and rec[0] == key and rec[2] == id(bn):
+            return rec
+        key, entry = cls._buf(dev)
+        if entry[2] >= cls.CAP:
+            raise RuntimeError(f"more than {cls.CAP} BatchNorm modules on one device")
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("a BatchNorm module met the fused kernels for the first time inside a HIP-graph capture: "
+                               "run one eager step or call pytorch_utils.sync_bn_momentum(model) before the capture")
+        rec = (key, entry[2], id(bn))
+        entry[2] += 1
+        entry[3].append(None)                # host value of the slot (python float, compared exactly); None forces a sync
+        bn.__dict__["_istnet_mslot"] = rec
+        return rec
+
+    @classmethod
+    def ptr(cls, bn, dev):
+        """Device address of the module's momentum slot, holding ``bn.momentum``."""
+        key, i, _ = cls._slot(bn, dev)
+        buf, host, _, values = cls._bufs[key]
+        want = float(bn.momentum)
+        if values[i] != want:
+            if torch.cuda.is_current_stream_capturing():
+                raise RuntimeError("bn.momentum changed since the last sync and a HIP graph is being captured: call "
+                                   "pytorch_utils.sync_bn_momentum(model) (BNMomentumScheduler.step does) before capturing")
+            values[i] = want
+            host[i] = want
+            buf[i:i + 1].fill_(want)
+        return buf.data_ptr() + 4 * i
+
+    @classmethod
+    def sync(cls, model):
+        """Mirror ``m.momentum`` of every BatchNorm of ``model`` that has (or, for CUDA modules, now gets) a slot; one
+        host-to-device copy per device, and only when something changed."""
+        dirty = set()
+        for m in model.modules():
+            if not isinstance(m, (nn.BatchNorm1d, nn.BatchNorm2d, nn.BatchNorm3d)) or m.momentum is None:
+                continue
+            dev = m.weight.device if m.weight is not None else (m.running_mean.device if m.running_mean is not None else None)
+            if dev is None or dev.type != "cuda":
+                continue
+            key, i, _ = cls._slot(m, dev)
+            _, host, _, values = cls._bufs[key]
+            want = float(m.momentum)
+            if values[i] != want:
+                values[i] = want
+                host[i] = want
+                dirty.add(key)
+        for key in dirty:
+            buf, host, used, _ = cls._bufs[key]
+            buf[:used].copy_(host[:used], non_blocking=True)
+
+
+def bn_momentum_ptr(bn, dev):
+    return _MomentumSlots.ptr(bn, dev)
+
+
+def bn_momentum_tensor(bn, dev):
+    """The module's device slot as a one-element tensor (for running-statistics updates written with torch ops)."""
+    _MomentumSlots.ptr(bn, dev)
+    key, i, _ = bn.__dict__["_istnet_mslot"]
+    return _MomentumSlots._bufs[key][0][i:i + 1]
+
+
+def sync_bn_momentum(model):
+    """Push every BatchNorm momentum of ``model`` to its device slot (call after changing ``bn.momentum`` by hand when
+    the training step is a captured HIP graph; ``BNMomentumScheduler.step`` calls it)."""
+    _MomentumSlots.sync(model)
+
+
 def set_bn_momentum_default(bn_momentum):
     def fn(m):
         if isinstance(m, (nn.BatchNorm1d, nn.BatchNorm2d, nn.BatchNorm3d)):
@@ -133,7 +233,9 @@ def set_bn_momentum_default(bn_momentum):
 
 
 class BNMomentumScheduler(object):
-    """Walks the model and sets every BatchNorm's momentum to ``bn_lambda(epoch)``.  [ref :303-330]"""
+    """Walks the model and sets every BatchNorm's momentum to ``bn_lambda(epoch)``.  [ref :303-330]
+    The device-side slots the fused kernels read are refreshed in the same call, so a step replayed from a HIP graph
+    sees the new value (the reference steps this scheduler every iteration, utils/solver.py:91-92)."""
 
     def __init__(self, model, bn_lambda, last_epoch=-1, setter=set_bn_momentum_default):
         if not isinstance(model, nn.Module):
@@ -149,3 +251,4 @@ class BNMomentumScheduler(object):
             epoch = self.last_epoch + 1
         self.last_epoch = epoch
         self.model.apply(self.setter(self.lmbd(epoch)))
+        sync_bn_momentum(self.model)

@@ -22,6 +22,8 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from .pointnet2.pytorch_utils import bn_momentum_ptr, bn_momentum_tensor
+
 
 USE_NATIVE_DECODER_BACKWARD = True   # False: the framework's own backward of PReLU / bilinear upsample
 
@@ -167,7 +169,7 @@ class _BnReluFn(torch.autograd.Function):
                           "nhwc_channel_stats")
             _native.check(lib.istnet_bn_finalize_fwd(
                 c, nparts, float(rows), part[0].data_ptr(), part[1].data_ptr(), gamma.data_ptr(), beta.data_ptr(), float(eps),
-                float(momentum), running_mean.data_ptr() if running_mean is not None else None,
+                momentum, running_mean.data_ptr() if running_mean is not None else None,
                 running_var.data_ptr() if running_var is not None else None, bn.data_ptr(), st), "bn_finalize_fwd")
             if res is None:
                 _native.check(lib.istnet_nhwc_bn_prelu_apply(b, h * w, c, y.data_ptr(), bn.data_ptr(), zero.data_ptr(), None,
@@ -234,7 +236,7 @@ def _bn_relu(bn, y, res, owner):
         _bump_batch_counter(bn)
         return _BnReluFn.apply(y, bn.weight, bn.bias, res, owner._zero, owner._one,
                                bn.running_mean if bn.track_running_stats else None,
-                               bn.running_var if bn.track_running_stats else None, bn.momentum, bn.eps)
+                               bn.running_var if bn.track_running_stats else None, bn_momentum_ptr(bn, y.device), bn.eps)
     out = bn(y)
     if res is not None:
         out = out + res
@@ -494,7 +496,7 @@ class _BnPReLUDropFn(torch.autograd.Function):
                           "nhwc_channel_stats")
             _native.check(lib.istnet_bn_finalize_fwd(
                 c, nparts, float(rows), part[0].data_ptr(), part[1].data_ptr(), gamma.data_ptr(), beta.data_ptr(), float(eps),
-                float(momentum), running_mean.data_ptr() if running_mean is not None else None,
+                momentum, running_mean.data_ptr() if running_mean is not None else None,
                 running_var.data_ptr() if running_var is not None else None, bn.data_ptr(), st), "bn_finalize_fwd")
             _native.check(lib.istnet_nhwc_bn_prelu_apply(b, h * w, c, y.data_ptr(), bn.data_ptr(), slope.data_ptr(),
                                                          mask.data_ptr() if mask is not None else None, z.data_ptr(), st),
@@ -581,7 +583,7 @@ class PSPUpsample(nn.Module):
             _bump_batch_counter(bn)
             return _BnPReLUDropFn.apply(y, bn.weight, bn.bias, act.weight, mask,
                                         bn.running_mean if bn.track_running_stats else None,
-                                        bn.running_var if bn.track_running_stats else None, bn.momentum, bn.eps)
+                                        bn.running_var if bn.track_running_stats else None, bn_momentum_ptr(bn, y.device), bn.eps)
         out = act(bn(y))
         return drop(out) if drop is not None else out
 
@@ -634,8 +636,10 @@ class _FinalAtChosenFn(torch.autograd.Function):
         y = torch.where(v > 0, v, v * slope)
         if running_mean is not None:
             with torch.no_grad():
-                running_mean.mul_(1.0 - momentum).add_(mu.to(running_mean.dtype), alpha=momentum)
-                running_var.mul_(1.0 - momentum).add_((var * (npix / max(npix - 1, 1))).to(running_var.dtype), alpha=momentum)
+                # momentum: the module's one-element device slot (pytorch_utils.bn_momentum_tensor), so a captured step
+                # follows BNMomentumScheduler.step; lerp(start, end, w) = (1 - w) start + w end
+                running_mean.lerp_(mu.to(running_mean.dtype), momentum)
+                running_var.lerp_((var * (npix / max(npix - 1, 1))).to(running_var.dtype), momentum)
         ctx.save_for_backward(u, choose, weight, bias, gamma, slope, u_sel, zhat, v, s1, s2, mu, istd)
         return y.view(b, n, -1).transpose(1, 2).contiguous()                                        # (B, Cout, N)
 
@@ -703,7 +707,7 @@ class Modified_PSPNet(nn.Module):
             return _FinalAtChosenFn.apply(u, choose, conv.weight, conv.bias, bn.weight, bn.bias, act.weight,
                                           bn.running_mean if bn.track_running_stats else None,
                                           bn.running_var if bn.track_running_stats else None,
-                                          bn.momentum, bn.eps)
+                                          bn_momentum_tensor(bn, u.device), bn.eps)
         out = self.final(u)
         if choose is None:
             return out

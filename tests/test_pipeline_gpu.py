@@ -144,7 +144,7 @@ def test_training_steps_are_bit_reproducible():
     assert torch.equal(a, b), float((a - b).abs().max())
 
 
-@pytest.mark.parametrize("switch", ["USE_DEFERRED_WGRAD", "USE_SCALE_STREAMS", "USE_FUSED_SMALL_BWD", "USE_FUSED_MID_BWD", "USE_POOLED_FINALIZE", "USE_DENSE_FINALIZE", "USE_INTERP_IN_EPILOGUE", "USE_FINALIZE_IN_SCATTER", "USE_SPLIT_LAYER0", "USE_FP_SKIP_STREAM",
+@pytest.mark.parametrize("switch", ["USE_DEFERRED_WGRAD", "USE_SCALE_STREAMS", "USE_FUSED_SMALL_BWD", "USE_FUSED_MID_BWD", "USE_POOLED_FINALIZE", "USE_DENSE_FINALIZE", "USE_INTERP_IN_EPILOGUE", "USE_FINALIZE_IN_SCATTER", "USE_POOL_EPILOGUE", "USE_SPLIT_LAYER0", "USE_FP_SKIP_STREAM",
                                     "USE_CSR_SCATTER", "USE_FUSED_FP", "USE_GEOMETRY_STREAM", "USE_FPS_CHAIN", "USE_FUSED_NN_WEIGHTS", "COMPACT_LEVELS=", "COMPACT_LEVELS=0,1,2"])
 def test_fallback_paths_agree_with_default(switch):
     """Every module-level switch of the fused path selects code that a caller can reach (fallbacks and measured
@@ -318,3 +318,83 @@ def test_adjacent_layer0_weights_make_the_stacked_matrix_a_view():
     assert torch.equal(out_a, out_b)
     for a, b in zip(par_a, par_b):
         assert torch.equal(a, b)
+
+
+def test_captured_step_follows_bn_momentum_schedule(monkeypatch):
+    """The reference re-sets every BatchNorm's momentum each iteration (utils/solver.py:91-92 ->
+    pytorch_utils.py:303-330).  A step captured in a HIP graph must keep following it: the finalize kernels read the
+    momentum from a device slot that ``BNMomentumScheduler.step`` writes.  Captures a training step, changes the momentum
+    through the scheduler between replays, and compares every running_mean / running_var with torch's eager BatchNorm
+    (the same modules run as the plain torch composition) under the same schedule."""
+    import copy
+    import bench
+    from istnet_amd.optim import FlatAdam
+    from istnet_amd.pointnet2 import fused_mlp
+    from istnet_amd.pointnet2.pytorch_utils import BNMomentumScheduler
+    dev = torch.device(DEV)
+    model = bench.make_model(dev, seed=3)
+    ref, frozen = copy.deepcopy(model), copy.deepcopy(model)
+    pts = bench.shell_cloud(4, 512, seed=5, device=dev)
+    sched = [0.5, 0.2, 0.05, 0.9]                                  # momentum of the warm-up steps, then of replay 1, 2, 3
+    opt = FlatAdam(model.parameters(), lr=0.0)                     # parameters stay put: only the statistics move
+    bnm = BNMomentumScheduler(model, bn_lambda=lambda it: sched[it], last_epoch=-1)        # momentum sched[0], slots synced
+    step = bench.make_graphed_step(bench.make_encoder_fwd_bwd(model, pts), opt, 1)         # 4 eager warm-ups, then capture
+    for it in (1, 2, 3):
+        bnm.step(it)                                               # host attribute AND device slot
+        step()                                                     # graph replay
+    torch.cuda.synchronize()
+
+    monkeypatch.setattr(fused_mlp, "_fusable", lambda *a, **k: False)          # torch's Conv2d / BatchNorm2d / ReLU
+    monkeypatch.setattr(fused_mlp, "_fusable_shape", lambda *a, **k: False)
+    monkeypatch.setattr(fused_mlp, "USE_FUSED_FP", False)
+
+    def run_torch(net, momenta):
+        for m in momenta:
+            for mod in net.modules():
+                if isinstance(mod, torch.nn.BatchNorm2d):
+                    mod.momentum = m
+            with torch.no_grad():
+                net(pts)
+        return {k: v for k, v in net.state_dict().items() if k.endswith(("running_mean", "running_var"))}
+
+    want = run_torch(ref, [sched[0]] * 4 + sched[1:])
+    stale = run_torch(frozen, [sched[0]] * 7)                      # what a momentum baked in at capture time would give
+    got = {k: v for k, v in model.state_dict().items() if k in want}
+    assert len(want) >= 32
+    worst_stale = 0.0
+    for k in want:
+        torch.testing.assert_close(got[k], want[k], rtol=2e-4, atol=1e-6, msg=lambda m, k=k: f"{k}: {m}")
+        worst_stale = max(worst_stale, ((stale[k] - want[k]).abs().max() / want[k].abs().max().clamp_min(1e-12)).item())
+    assert worst_stale > 1e-2          # the schedule matters on this input: a baked-in momentum would have been caught
+    counters = [v for k, v in model.state_dict().items() if k.endswith("num_batches_tracked")]
+    assert all(int(c) == 7 for c in counters)
+
+
+def test_momentum_change_inside_capture_is_refused():
+    """A momentum that differs from the device slot cannot be fixed up inside a capture (the fill would be recorded and
+    replayed): the stack raises and names the remedy instead of silently baking the old value in."""
+    from istnet_amd.pointnet2.pointnet2_modules import PointnetSAModuleMSG
+    from istnet_amd.pointnet2.pytorch_utils import sync_bn_momentum
+    sa = PointnetSAModuleMSG(npoint=64, radii=[0.15, 0.3], nsamples=[8, 16], mlps=[[8, 16, 32], [8, 16, 32]]).to(DEV).train()
+    xyz = torch.rand(2, 256, 3, device=DEV)
+    feats = torch.randn(2, 8, 256, device=DEV)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side), torch.no_grad():
+        sa(xyz, feats)
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    for m in sa.modules():
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.momentum = 0.3                   # by hand, no sync
+    graph = torch.cuda.CUDAGraph()
+    with pytest.raises(RuntimeError, match="sync_bn_momentum"):
+        with torch.cuda.graph(graph), torch.no_grad():
+            sa(xyz, feats)
+    torch.cuda.synchronize()
+    sync_bn_momentum(sa)                       # the remedy: now the capture goes through
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph), torch.no_grad():
+        sa(xyz, feats)
+    graph.replay()
+    torch.cuda.synchronize()

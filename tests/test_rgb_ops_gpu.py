@@ -286,7 +286,8 @@ def test_fused_batchnorm_prelu_dropout_of_a_channels_last_map(b, c, h, w, with_m
     wgt = torch.randn(b, c, h, w, generator=g).to(DEV)
     yy = y.clone().requires_grad_(True)
     rm, rv = bn.running_mean.clone(), bn.running_var.clone()
-    z = rgb_branch._BnPReLUDropFn.apply(yy, bn.weight, bn.bias, act.weight, mask, rm, rv, bn.momentum, bn.eps)
+    z = rgb_branch._BnPReLUDropFn.apply(yy, bn.weight, bn.bias, act.weight, mask, rm, rv,
+                                        rgb_branch.bn_momentum_ptr(bn, yy.device), bn.eps)
     (z * wgt).sum().backward()
     got = (z.detach(), yy.grad.clone(), bn.weight.grad.clone(), bn.bias.grad.clone(), act.weight.grad.clone())
     colsum = yy.grad.sum(dim=(0, 2, 3))

@@ -1,7 +1,13 @@
 #!/bin/bash
-# build tmp_ab/base.so from the csrc of a git revision (default HEAD) -- NB host-side python is NOT switched
+# build ab_base/base.so from the csrc + include of a git revision (default HEAD), with build.py's flags.
+# NB the host-side python is NOT switched: only use for kernel-only A/Bs where the C ABI did not change.
 REV=${1:-HEAD}
-mkdir -p tmp_ab/src/ist-net_amd/csrc tmp_ab/src/include
-for f in pw_mlp.hip pn2_index_ops.hip; do git show $REV:ist-net_amd/csrc/$f > tmp_ab/src/ist-net_amd/csrc/$f; done
-for f in istnet_pn2.h istnet_pw.h; do git show $REV:include/$f > tmp_ab/src/include/$f; done
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -shared -fvisibility=hidden -I tmp_ab/src/include tmp_ab/src/ist-net_amd/csrc/*.hip -o tmp_ab/base.so && rm -rf tmp_ab/src && ls -la tmp_ab
+rm -rf ab_base/src; mkdir -p ab_base/src/csrc ab_base/src/include ab_base/src/obj
+for f in $(git ls-tree --name-only $REV ist-net_amd/csrc/); do git show $REV:$f > ab_base/src/csrc/$(basename $f); done
+for f in $(git ls-tree --name-only $REV include/); do git show $REV:$f > ab_base/src/include/$(basename $f); done
+# build.py resolves "../../include" relative to csrc: mirror that layout
+mkdir -p ab_base/src/pkg; mv ab_base/src/csrc ab_base/src/pkg/csrc
+for s in ab_base/src/pkg/csrc/*.hip; do
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fvisibility=hidden -ffp-contract=off -c $s -o ab_base/src/obj/$(basename $s .hip).o &
+done; wait
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -fPIC -shared -fvisibility=hidden ab_base/src/obj/*.o -o ab_base/base.so && rm -rf ab_base/src && ls -la ab_base

@@ -1,6 +1,6 @@
 """Where a launch of pw_fwd_sk_kernel spends its time: cycles per phase (thread 0 of every workgroup, clock64) summed over the
 launches of a few encoder training steps.  Needs a library built with -DISTNET_PHASE_TIMING (tools/gpu_phase.sh builds
-nothing on the GPU box: the instrumented library is built beforehand as tmp_ab/phase.so and copied over the product's)."""
+nothing on the GPU box: the instrumented library is built beforehand as ab_base/phase.so and copied over the product's)."""
 import ctypes, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
