@@ -34,6 +34,7 @@ def main(argv=None):
     ap.add_argument("--npoints", type=int, default=1024)
     ap.add_argument("--img", type=int, default=192)
     ap.add_argument("--freeze-world-enhancer", action="store_true")
+    ap.add_argument("--eager", action="store_true", help="single GPU: do not capture the step in a HIP graph")
     args = ap.parse_args(argv)
     world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -44,8 +45,22 @@ def main(argv=None):
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", device_id=dev)
 
-    point_branch_side_streams(False)      # the RGB branch fills the chip: the point branch's side streams only get in its way
-    tuned_gemm.enable()          # recorded solutions for the RGB decoder's library GEMMs (look-up only; no-op without a table)
+    # the RGB branch fills the chip: the point branch's side streams only get in its way (restored on the way out)
+    switches = point_branch_side_streams(False)
+    tuned = tuned_gemm.enable()  # recorded solutions for the RGB decoder's library GEMMs (look-up only; no-op without a table)
+    try:
+        return _train(args, dev, world, rank)
+    finally:
+        switches.restore()
+        if tuned:
+            tuned_gemm.disable()
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+            dist.destroy_process_group()
+
+
+def _train(args, dev, world, rank):
     torch.manual_seed(0)
     model = IST_Net(rgb_extractor=ModifiedResnet(), freeze_world_enhancer=args.freeze_world_enhancer).to(dev).train()
     model.rgb_cam_extractor.to(memory_format=torch.channels_last)
@@ -62,27 +77,47 @@ def main(argv=None):
     # buckets of the flat gradient buffer leave from autograd hooks while backward still runs
     reducer = OverlappedFlatReducer(opt, world) if world > 1 else None
     criterion = SupervisedLoss(1.0, 10.0, freeze_world_enhancer=args.freeze_world_enhancer)
+    label_keys = ("rotation_label", "translation_label", "size_label", "qo")
 
+    # One process, one GPU: forward + backward + Adam are captured ONCE in a HIP graph and replayed; what changes per
+    # iteration reaches the replay through device memory -- the batch (copied into static tensors), the learning rate
+    # (FlatAdam's device slot, ``sync_lr``) and the BatchNorm momentum (``BNMomentumScheduler.step`` writes the slots the
+    # finalize kernels read).  [solver.py:88-99: lr_scheduler.step, bnm_scheduler.step, forward, backward, optimizer.step]
+    graphed = world == 1 and not args.eager
+    static = bench.istnet_batch(args.batch, args.npoints, seed=1000 * rank, device=dev, hw=args.img)
+    holder = {}
+
+    def fwd_bwd():
+        end_points = model(static)
+        end_points.update({k: static[k] for k in label_keys})
+        loss = criterion(end_points)
+        loss.backward()
+        holder["loss"] = loss.detach()
+        return loss
+
+    replay = None
     history = []
     for it in range(args.iters):
         batch = bench.istnet_batch(args.batch, args.npoints, seed=1000 * rank + it, device=dev, hw=args.img)
+        for k, v in batch.items():
+            static[k].copy_(v)
         bnm.step(it)
-        opt.zero_grad(set_to_none=True)
-        end_points = model(batch)
-        end_points.update({k: batch[k] for k in ("rotation_label", "translation_label", "size_label", "qo")})
-        loss = criterion(end_points)
-        loss.backward()
-        if reducer is not None:
-            opt.step(reducer.finish(), grad_scale=1.0 / world)
+        if graphed:
+            if replay is None:      # (make_graphed_step runs four eager warm-up steps on the first batch before capturing)
+                replay = bench.make_graphed_step(fwd_bwd, opt, 1)
+            opt.sync_lr()           # this iteration's learning rate -> the device slot the captured Adam launch reads
+            replay()
         else:
-            opt.step()
+            opt.zero_grad(set_to_none=True)
+            fwd_bwd()
+            if reducer is not None:
+                opt.step(reducer.finish(), grad_scale=1.0 / world)
+            else:
+                opt.step()
         sched.step()
-        history.append(float(loss.detach()))
+        history.append(float(holder["loss"]))
         if rank == 0 and (it % 5 == 0 or it == args.iters - 1):
             print(f"iter {it:4d}  lr {opt.param_groups[0]['lr']:.2e}  loss {history[-1]:.4f}", flush=True)
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
     return history
 
 

@@ -267,30 +267,6 @@ ISTNET_PN2_API int istnet_pw_wgrad_reduce_multi(int n, const int *counts, const 
 ISTNET_PN2_API int istnet_bn_relu_mean(int b, int c, int p, const float *y, const float *bn, float *out, void *stream);
 ISTNET_PN2_API int istnet_expand_rows(int rows, int p, const float *g, float *out, void *stream);
 
-/* ---- the LAST layer of a set-abstraction scale with the max-pool in the GEMM's epilogue (reference
- * pointnet2_modules.py:61-71: conv1x1 -> BatchNorm2d -> ReLU -> max_pool2d over nsample) ----
- * istnet_pw_forward_pool = istnet_pw_forward whose epilogue ALSO keeps, per (channel, ball of nsample consecutive
- * points), the raw extremum of sign(gamma) * y (`gval`, (b, cout, p / nsample)) and its slot (`arg`, uint8): the pool
- * commutes with the monotone map y -> relu(scale y + shift).  y may be NULL (the activation is then not stored);
- * part_sum / part_sq as in istnet_pw_forward ([cout][istnet_pw_forward_tiles(...)]).  Shapes for which
- * istnet_pw_forward_pool_ok(...) is 0 return ISTNET_PN2_EINVAL (nsample in {16, 32}, cout >= 64, the direct-operand
- * forward kernel's launch sizes). */
-ISTNET_PN2_API int istnet_pw_forward_pool_ok(int b, int cin, int cout, int p, int nsample);
-ISTNET_PN2_API int istnet_pw_forward_pool(int b, int cin, int cout, int p, int nsample, const float *x, const float *w,
-                                          const float *in_scale, const float *in_shift, const float *gamma, float *y,
-                                          float *gval, unsigned char *arg, float *part_sum, float *part_sq,
-                                          void *stream);
-/* training-mode tail: istnet_bn_finalize_fwd on the partials (writes bn[4][c], updates the running statistics; momentum
- * is a device pointer as there), then out[b][c][g] = relu(scale_c * gval[b][c][g] + shift_c); out rows may be a channel
- * slice of a wider tensor (out_bstride elements between clouds, 0 = c * g). */
-ISTNET_PN2_API int istnet_bn_finalize_pool_apply(int b, int c, int g, int nt, double count, const float *part_sum,
-                                                 const float *part_sq, const float *gamma, const float *beta, float eps,
-                                                 const float *momentum, float *running_mean, float *running_var,
-                                                 float *bn, const float *gval, float *out, long long out_bstride,
-                                                 void *stream);
-/* the apply alone, constants given (eval-mode BatchNorm) */
-ISTNET_PN2_API int istnet_pool_apply(int b, int c, int g, const float *bn, const float *gval, float *out,
-                                     long long out_bstride, void *stream);
 
 /* ... where item l may be a column block of a wider destination and a row block of wider partials: element i of the
  * item (i < counts[l], counts[l] % cols[l] == 0) is the sum over k < splits[l] of parts[l][k * pstrides[l] + i] and goes

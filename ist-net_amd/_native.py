@@ -120,11 +120,6 @@ SIGNATURES = {
     "istnet_smooth_l1_backward": [_l, _f, _p, _p, _p, _p, _p],
     "istnet_mse_parts": [_l],
     "istnet_mse_value_grad": [_l, _p, _p, _p, _p, _p, _p],
-    # last layer of a set-abstraction scale with the max-pool in the GEMM epilogue (csrc/pw_mlp.hip)
-    "istnet_pw_forward_pool_ok": [_i, _i, _i, _i, _i],
-    "istnet_pw_forward_pool": [_i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p],
-    "istnet_bn_finalize_pool_apply": [_i, _i, _i, _i, _d, _p, _p, _p, _p, _f, _p, _p, _p, _p, _p, _p, _l, _p],
-    "istnet_pool_apply": [_i, _i, _i, _p, _p, _p, _l, _p],
     # compact-column form of a set-abstraction scale (csrc/sa_compact.hip)
     "istnet_sa_compact": [_i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p],
     "istnet_pw_gather_add_cols": [_i, _i, _i, _l, _i, _p, _p, _p, _p, _p, _p, _p, _p, _i, _p, _p, _p, _p],

@@ -483,49 +483,12 @@ __global__ __launch_bounds__(kThreads) void pw_fwd_kernel(
 // 4 TMW MFMAs -- the LDS-tiled kernel above needs 2 ds_read_b32 per MFMA at its 64 x 64 tiles.
 // Wave tile: 32 TMW rows x 128 points; WM x WN waves per workgroup; grid (tiles_per_cloud * B, ceil(cout / M_WG)).
 // ============================================================================================
-// POOL = S > 0 (the LAST layer of a set-abstraction scale, nsample S in {16, 32}): the max-pool happens HERE.  The reference's
-// tail  max_pool2d(relu(bn(y)))  (pointnet2_modules.py:65-68) commutes with the monotone map y -> relu(scale y + shift):
-// the pooled value of a group is relu(scale y* + shift) with y* the raw maximum for scale >= 0 and the raw minimum for
-// scale < 0, and sign(scale) = sign(gamma) is known before the statistics are.  So the epilogue reduces each group of S
-// consecutive points of a row -- S / 4 adjacent lanes x the 4 accumulators -- to (y*, slot of y*) with DPP quad / row
-// permutes and stores (B, C, G) values (`gval`, `arg`): the separate max-pool pass, which read the widest activation of the
-// stack (34-67 MB per scale) back and sat on the forward chain, does not exist; bn_finalize_pool_apply_kernel finishes
-// the statistics and applies BatchNorm + ReLU to the (B, C, G) extrema.  y is still written when the caller passes it
-// (the backward pass reads it; round 3's activation-free backward, tools/exp/pw_last/, was measured slower and removed).
-// max / min with the permuted operand as a DPP source: ONE instruction per butterfly step (the builtin form leaves a
-// v_mov_dpp, a canonicalising v_max x,x and the max itself).  s_nop 1: a DPP read of a VGPR written by the previous
-// VALU instruction needs two wait states, and the hazard recogniser does not look inside inline assembly.
-#define ISTNET_DPP_STEP(OP, TY, CTRL_STR)                                                                       \
-  asm volatile("s_nop 1\n\t" OP " %0, %1, %1 " CTRL_STR " row_mask:0xf bank_mask:0xf bound_ctrl:1" : "=v"(r) : "v"(m))
-// all-reduce over S / 4 adjacent lanes: quad_perm [1,0,3,2], quad_perm [2,3,0,1], row_half_mirror, row_mirror
-template <int S>
-__device__ __forceinline__ float group_max_f(float m) {
-  float r;
-  ISTNET_DPP_STEP("v_max_f32_dpp", float, "quad_perm:[1,0,3,2]"); m = r;
-  ISTNET_DPP_STEP("v_max_f32_dpp", float, "quad_perm:[2,3,0,1]"); m = r;
-  if (S >= 32) { ISTNET_DPP_STEP("v_max_f32_dpp", float, "row_half_mirror"); m = r; }
-  if (S >= 64) { ISTNET_DPP_STEP("v_max_f32_dpp", float, "row_mirror"); m = r; }
-  return m;
-}
-template <int S>
-__device__ __forceinline__ int group_min_i(int m) {
-  int r;
-  ISTNET_DPP_STEP("v_min_i32_dpp", int, "quad_perm:[1,0,3,2]"); m = r;
-  ISTNET_DPP_STEP("v_min_i32_dpp", int, "quad_perm:[2,3,0,1]"); m = r;
-  if (S >= 32) { ISTNET_DPP_STEP("v_min_i32_dpp", int, "row_half_mirror"); m = r; }
-  if (S >= 64) { ISTNET_DPP_STEP("v_min_i32_dpp", int, "row_mirror"); m = r; }
-  return m;
-}
-#undef ISTNET_DPP_STEP
-
-template <int TMW, int WM, int WN, int KC, int POOL = 0>
+template <int TMW, int WM, int WN, int KC>
 __global__ __launch_bounds__(kThreads, 2) void pw_fwd2_kernel(
     int cin, int cout, int P, int tiles_per_cloud, const float* __restrict__ x, const float* __restrict__ w,
     const float* __restrict__ in_scale, const float* __restrict__ in_shift, float* __restrict__ y,
-    float* __restrict__ part_sum, float* __restrict__ part_sq, int nt_total,
-    const float* __restrict__ gamma = nullptr, float* __restrict__ gval = nullptr, uint8_t* __restrict__ garg = nullptr) {
+    float* __restrict__ part_sum, float* __restrict__ part_sq, int nt_total) {
   static_assert(WM * WN == 4 && (KC == 16 || KC == 32), "4 waves; K chunk of 16 or 32 channels");
-  static_assert(POOL == 0 || POOL == 16 || POOL == 32 || POOL == 64, "nsample of the pooled epilogue");
   constexpr int M_WG = 32 * TMW * WM, N_WG = 128 * WN;
   constexpr int LDA = M_WG + 1;                 // odd: the transposed scalar stores of a weight chunk spread over the banks
   constexpr int NA = KC * M_WG / kThreads;      // weight elements per thread per chunk
@@ -544,12 +507,6 @@ __global__ __launch_bounds__(kThreads, 2) void pw_fwd2_kernel(
   const float* xb = x + (size_t)b * cin * P + (live ? p0 : 0) + 4 * l31;
   if (has_bn)
     for (int c = tid; c < cin; c += kThreads) { s_in[0][c] = in_scale[c]; s_in[1][c] = in_shift[c]; }
-  __shared__ unsigned s_sgn[POOL ? M_WG : 1];   // sign bit of gamma per output row: the group extremum is taken of sgn * y
-  if (POOL)
-    for (int c = tid; c < M_WG; c += kThreads) {     // bit 31: sign of gamma; bit 0: gamma == 0 (every slot ties: slot 0 wins,
-      const unsigned gb = __float_as_uint(gamma[min(m0 + c, cout - 1)]);   // as max_pool2d's first maximum does)
-      s_sgn[c] = (gb & 0x80000000u) | ((gb & 0x7fffffffu) == 0u ? 1u : 0u);
-    }
 
   float areg[NA];
   auto load_a = [&](int k0) {
@@ -623,28 +580,7 @@ __global__ __launch_bounds__(kThreads, 2) void pw_fwd2_kernel(
     for (int r = 0; r < 16; ++r) {
       const int row_l = a_col0 + 32 * tm + mfma_row(r, lane), row = m0 + row_l;
       const float4 v = make_float4(acc[tm][0][r], acc[tm][1][r], acc[tm][2][r], acc[tm][3][r]);
-      if (POOL) {
-        // group of POOL consecutive points = POOL / 4 adjacent lanes x (x, y, z, w); keys = sgn(gamma) * y
-        const unsigned sw = s_sgn[row_l], sb = sw & 0x80000000u;
-        const float k0 = __uint_as_float(__float_as_uint(v.x) ^ sb), k1 = __uint_as_float(__float_as_uint(v.y) ^ sb);
-        const float k2 = __uint_as_float(__float_as_uint(v.z) ^ sb), k3 = __uint_as_float(__float_as_uint(v.w) ^ sb);
-        const float m = group_max_f<POOL>(fmaxf(fmaxf(k0, k1), fmaxf(k2, k3)));
-        const int lg = l31 & (POOL / 4 - 1);                 // lane within the group
-        int cand = 0x10000;                                  // slot of the FIRST extremum this lane holds (selects, no branches)
-        cand = k3 == m ? 3 : cand;
-        cand = k2 == m ? 2 : cand;
-        cand = k1 == m ? 1 : cand;
-        cand = k0 == m ? 0 : cand;
-        cand = group_min_i<POOL>(cand + 4 * lg);             // some lane of the group holds the extremum: the minimum is a slot
-        if (live && row < cout && lg == 0) {
-          const int G = P / POOL;
-          const size_t o = ((size_t)b * cout + row) * G + (p0 + 4 * l31) / POOL;
-          const bool zero_gamma = (sw & 1u) != 0u;         // constant output: the gradient goes to slot 0 (this lane's x)
-          gval[o] = zero_gamma ? v.x : __uint_as_float(__float_as_uint(m) ^ sb);
-          garg[o] = zero_gamma ? (uint8_t)0 : (uint8_t)cand;
-        }
-      }
-      if ((!POOL || y != nullptr) && live && row < cout) *reinterpret_cast<float4*>(yb + (size_t)row * P) = v;
+      if (live && row < cout) *reinterpret_cast<float4*>(yb + (size_t)row * P) = v;
       if (part_sum != nullptr) {
         float s = live ? (v.x + v.y) + (v.z + v.w) : 0.f;
         float q = live ? (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w) : 0.f;
@@ -950,61 +886,6 @@ __global__ __launch_bounds__(kFinThreads) void bn_finalize_fwd_kernel(
       running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
       running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
     }
-  }
-}
-
-// ============================================================================================
-// forward tail of a pooled last layer (pw_fwd2_kernel<..., POOL>): BatchNorm statistics from the GEMM's partials, then
-// out = relu(scale y* + shift) on the (B, C, G) extrema the pooled epilogue left -- the finalize and the (former)
-// max-pool launch in one.  One workgroup per channel.
-// ============================================================================================
-__global__ __launch_bounds__(kFinThreads) void bn_finalize_pool_apply_kernel(
-    int C, int B, int G, int nt, double count, const float* __restrict__ part_sum, const float* __restrict__ part_sq,
-    const float* __restrict__ gamma, const float* __restrict__ beta, float eps, const float* __restrict__ momentum_p,
-    float* __restrict__ running_mean, float* __restrict__ running_var, float* __restrict__ bn,
-    const float* __restrict__ gval, float* __restrict__ out, long long out_bstride) {
-  const int c = blockIdx.x;
-  double s, q;
-  reduce_partials2(part_sum + (size_t)c * nt, part_sq + (size_t)c * nt, nt, s, q);
-  __shared__ float s_aff[2];
-  if (threadIdx.x == 0) {
-    const double mean = s / count;
-    double var = q / count - mean * mean;
-    if (var < 0.0) var = 0.0;
-    const float istd = (float)(1.0 / sqrt(var + (double)eps));
-    const float sc = gamma[c] * istd;
-    const float shf = beta[c] - (float)mean * sc;
-    bn[0 * C + c] = sc;
-    bn[1 * C + c] = shf;
-    bn[2 * C + c] = (float)mean;
-    bn[3 * C + c] = istd;
-    if (running_mean != nullptr) {
-      const float momentum = *momentum_p;
-      const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
-      running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
-      running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
-    }
-    s_aff[0] = sc;
-    s_aff[1] = shf;
-  }
-  __syncthreads();
-  const float sc = s_aff[0], shf = s_aff[1];
-  for (int e = threadIdx.x; e < B * G; e += kFinThreads) {
-    const int b = e / G, g = e - b * G;
-    const float v = gval[((size_t)b * C + c) * G + g];
-    out[(size_t)b * out_bstride + (size_t)c * G + g] = fmaxf(v * sc + shf, 0.f);
-  }
-}
-
-// eval-mode / fixed-affine variant of the tail: constants given, only the apply
-__global__ __launch_bounds__(256) void pool_apply_kernel(int C, int G, int rows, const float* __restrict__ bn,
-                                                         const float* __restrict__ gval, float* __restrict__ out,
-                                                         long long out_bstride) {
-  const int g = blockIdx.x * 256 + threadIdx.x;
-  if (g >= G) return;
-  for (int bc = blockIdx.y; bc < rows; bc += gridDim.y) {
-    const int b = bc / C, c = bc - b * C;
-    out[(size_t)b * out_bstride + (size_t)c * G + g] = fmaxf(gval[(size_t)bc * G + g] * bn[c] + bn[C + c], 0.f);
   }
 }
 
@@ -3393,21 +3274,13 @@ int istnet_pw_forward_cfg(int b, int cin, int cout, int p) {
 
 static int launch_pw_fwd2(int cfg, int b, int cin, int cout, int p, const float* x, const float* w,
                           const float* in_scale, const float* in_shift, float* y, float* part_sum, float* part_sq,
-                          void* stream, int pool = 0, const float* gamma = nullptr, float* gval = nullptr,
-                          uint8_t* garg = nullptr) {
+                          void* stream) {
   const int tmw = cfg / 1000, wm = (cfg / 100) % 10, wn = (cfg / 10) % 10, kc32 = cfg % 10;
   const int tpc = p / (128 * wn);
   const dim3 grid(tpc * b, ceil_div(cout, 32 * tmw * wm));
-#define ISTNET_FWD2P(TMW, WM, WN, KC, POOL)                                                                        \
-  hipLaunchKernelGGL((pw_fwd2_kernel<TMW, WM, WN, KC, POOL>), grid, dim3(kThreads), 0, as_stream(stream), cin, cout, p, \
-                     tpc, x, w, in_scale, in_shift, y, part_sum, part_sq, tpc * b, gamma, gval, garg)
 #define ISTNET_FWD2(TMW, WM, WN, KC)                                                                               \
-  do {                                                                                                             \
-    if (pool == 0) ISTNET_FWD2P(TMW, WM, WN, KC, 0);                                                               \
-    else if (TMW == 2 && pool == 16) ISTNET_FWD2P(TMW, WM, WN, KC, (TMW == 2 ? 16 : 0));                           \
-    else if (TMW == 2 && pool == 32) ISTNET_FWD2P(TMW, WM, WN, KC, (TMW == 2 ? 32 : 0));                           \
-    else return ISTNET_PN2_EINVAL;                                                                                 \
-  } while (0)
+  hipLaunchKernelGGL((pw_fwd2_kernel<TMW, WM, WN, KC>), grid, dim3(kThreads), 0, as_stream(stream), cin, cout, p, tpc, x, \
+                     w, in_scale, in_shift, y, part_sum, part_sq, tpc * b)
 #define ISTNET_FWD2_K(TMW, WM, WN)                                                                                 \
   do {                                                                                                             \
     if (kc32) ISTNET_FWD2(TMW, WM, WN, 32); else ISTNET_FWD2(TMW, WM, WN, 16);                                     \
@@ -3419,16 +3292,7 @@ static int launch_pw_fwd2(int cfg, int b, int cin, int cout, int p, const float*
   }
 #undef ISTNET_FWD2_K
 #undef ISTNET_FWD2
-#undef ISTNET_FWD2P
   return (int)hipGetLastError();
-}
-
-// ---- last layer of a set-abstraction scale with the max-pool in the epilogue (pw_fwd2_kernel<..., POOL>) ----
-static bool fwd_pool_ok(int b, int cin, int cout, int p, int nsample) {
-  if (nsample != 16 && nsample != 32) return false;
-  if (cout < 64 || p % nsample) return false;
-  const int cfg = fwd2_cfg(b, cin, cout, p);
-  return cfg != 0 && cfg / 1000 == 2;
 }
 
 static int launch_pw_forward(bool gather, int b, int cin, int cout, int p, const float* x, const GatherSrc& g,
@@ -3483,42 +3347,6 @@ int istnet_pw_forward(int b, int cin, int cout, int p, const float* x, const flo
   if (cfg2) return launch_pw_fwd2(cfg2, b, cin, cout, p, x, w, in_scale, in_shift, y, part_sum, part_sq, stream);
   return launch_pw_forward(false, b, cin, cout, p, x, GatherSrc{}, w, cin, in_scale, in_shift, y, part_sum, part_sq,
                            stream);
-}
-
-int istnet_pw_forward_pool_ok(int b, int cin, int cout, int p, int nsample) {
-  return fwd_pool_ok(b, cin, cout, p, nsample) ? 1 : 0;
-}
-
-int istnet_pw_forward_pool(int b, int cin, int cout, int p, int nsample, const float* x, const float* w,
-                           const float* in_scale, const float* in_shift, const float* gamma, float* y, float* gval,
-                           unsigned char* arg, float* part_sum, float* part_sq, void* stream) {
-  if (b <= 0 || cin <= 0 || cout <= 0 || p <= 0 || (p & 3) || gamma == nullptr || gval == nullptr || arg == nullptr)
-    return ISTNET_PN2_EINVAL;
-  if (!fwd_pool_ok(b, cin, cout, p, nsample)) return ISTNET_PN2_EINVAL;
-  return launch_pw_fwd2(fwd2_cfg(b, cin, cout, p), b, cin, cout, p, x, w, in_scale, in_shift, y, part_sum, part_sq,
-                        stream, nsample, gamma, gval, arg);
-}
-
-int istnet_bn_finalize_pool_apply(int b, int c, int g, int nt, double count, const float* part_sum, const float* part_sq,
-                                  const float* gamma, const float* beta, float eps, const float* momentum,
-                                  float* running_mean, float* running_var, float* bn, const float* gval, float* out,
-                                  long long out_bstride, void* stream) {
-  if (b <= 0 || c <= 0 || g <= 0 || nt <= 0 || count <= 0.0 || !part_sum || !part_sq || !gamma || !beta || !bn || !gval ||
-      !out || (running_mean != nullptr && momentum == nullptr))
-    return ISTNET_PN2_EINVAL;
-  hipLaunchKernelGGL(bn_finalize_pool_apply_kernel, dim3(c), dim3(kFinThreads), 0, as_stream(stream), c, b, g, nt, count,
-                     part_sum, part_sq, gamma, beta, eps, momentum, running_mean, running_var, bn, gval, out,
-                     out_bstride > 0 ? out_bstride : (long long)c * g);
-  return (int)hipGetLastError();
-}
-
-int istnet_pool_apply(int b, int c, int g, const float* bn, const float* gval, float* out, long long out_bstride,
-                      void* stream) {
-  if (b <= 0 || c <= 0 || g <= 0 || !bn || !gval || !out) return ISTNET_PN2_EINVAL;
-  const long long rows = (long long)b * c;
-  hipLaunchKernelGGL(pool_apply_kernel, dim3(ceil_div(g, 256), (unsigned)(rows < 65535 ? rows : 65535)), dim3(256), 0,
-                     as_stream(stream), c, g, (int)rows, bn, gval, out, out_bstride > 0 ? out_bstride : (long long)c * g);
-  return (int)hipGetLastError();
 }
 
 int istnet_pw_forward_tiles(int b, int cin, int cout, int p) {

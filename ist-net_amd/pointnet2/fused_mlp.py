@@ -34,7 +34,7 @@ else:
         return torch.empty(shape, dtype=dtype, device=device)
 
 
-STATS = {"pool_epilogue": 0}     # how often a stack took the pooled-epilogue last layer (tests assert the path they mean)
+STATS = {}         # path counters (tests assert the path they mean)
 FALLBACKS = {}     # reason -> number of times a CUDA input took the torch composition instead of the fused kernels
 
 
@@ -306,39 +306,6 @@ def _forward_stack(lib, dev, st, b, c0, g, s, x, gather, training, layers, param
         elif cfg2:
             kname = f"pw_fwd2_kernel<{cfg2 // 1000}, {cfg2 // 100 % 10}, {cfg2 // 10 % 10}, {32 if cfg2 % 10 else 16}, 0>"
         flops, nbytes = 2.0 * b * p * cur_c * cout, 4.0 * b * p * (cur_c + cout)
-        if (USE_POOL_EPILOGUE and tail and li == len(layers) - 1 and li > 0 and s > 1 and plain and not lay.bias_only
-                and lay.relu and lib.istnet_pw_forward_pool_ok(b, cur_c, cout, p, s)):
-            # LAST layer of a scale: the max-pool happens in the GEMM's epilogue (raw extremum + slot per (channel, ball)),
-            # and ONE launch finishes the statistics and applies BatchNorm + ReLU to the (B, C, G) extrema -- the separate
-            # pool pass, which read the stack's widest activation back and sat on the forward chain, is gone.  y is still
-            # written: the backward pass reads it.  [ref pointnet2_modules.py:65-68]
-            if out_spec is None:
-                out = _empty((b, cout, g), torch.float32, dev)
-                out_ptr, out_bstride = out.data_ptr(), 0
-            else:
-                out, coff = out_spec
-                out_ptr, out_bstride = out.data_ptr() + coff * g * 4, out.shape[1] * g
-            arg = _empty((_arg_bytes(b * cout * g) + 4 * b * cout * g,), torch.uint8, dev)
-            gval = _ymax_ptr(arg, b * cout * g)
-            y = _empty((b, cout, p), torch.float32, dev)
-            STATS["pool_epilogue"] += 1
-            sc, sh = _p(in_bn[0]), _p(in_bn[1])
-            cin_l, src = cur_c, cur
-            kname = kname[:-2] + f"{s}>"
-            _native.check(_native.timed(kname, flops, nbytes, lambda: lib.istnet_pw_forward_pool(
-                b, cin_l, cout, p, s, src.data_ptr(), w2.data_ptr(), sc, sh, gamma.data_ptr(), y.data_ptr(), gval,
-                arg.data_ptr(), ps, pq, st)), "pw_forward_pool")
-            if li not in fixed:
-                _native.check(lib.istnet_bn_finalize_pool_apply(
-                    b, cout, g, nt, float(b * p), ps, pq, gamma.data_ptr(), beta.data_ptr(), float(lay.eps),
-                    lay.momentum_ptr, _p(lay.running_mean), _p(lay.running_var), bn.data_ptr(), gval, out_ptr,
-                    out_bstride, st), "bn_finalize_pool_apply")
-            else:
-                _native.check(lib.istnet_pool_apply(b, cout, g, bn.data_ptr(), gval, out_ptr, out_bstride, st),
-                              "pool_apply")
-            ys.append(y)
-            bns.append(bn)
-            return out, arg, ys, bns
         y = _empty((b, cout, p), torch.float32, dev)
         if li == 0 and gather is not None and USE_SPLIT_LAYER0:
             # layer 0 by linearity: Z = W0[:, 3:] . feat over the n source points (nsample*npoint/n times fewer MACs
@@ -597,12 +564,6 @@ def _compact_ok(lib, ga, layers, params, needs_backward, needs_feature_grad):
     return True
 
 
-# Last layer of a scale with the max-pool in the GEMM's epilogue (pw_fwd2_kernel<..., POOL>) and the finalize + apply in one
-# launch: one launch less on every scale's forward chain and no read-back of the widest activation.  (Round 3's
-# activation-FREE variant, whose backward ran from act(y_{L-1}) without y_L, moved 0.9 GB less per step but was slower --
-# profiles/r03_last_layer_activation_free.txt -- and lives in tools/exp/pw_last/ now.)  ISTNET_POOL_EPILOGUE=0 restores
-# the separate pool pass.
-USE_POOL_EPILOGUE = os.environ.get("ISTNET_POOL_EPILOGUE", "1") != "0"
 USE_FUSED_SMALL_BWD = True
 USE_POOLED_FINALIZE = True   # last layer of a scale: pooled statistics + BN-backward finalize in one launch
 USE_FINALIZE_IN_SCATTER = True  # layer 0 of an SA scale: BN-backward finalize inside the inverse-list scatter kernel

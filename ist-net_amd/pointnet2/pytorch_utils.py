@@ -7,6 +7,8 @@ Mirror of the parts of model/pointnet2/pytorch_utils.py that the hot path uses
 (weight 1, bias 0) -> ``activation`` (ReLU, in place)], so a reference checkpoint key such as
 ``SA_modules.0.mlps.0.layer0.normlayer.bn.running_mean`` loads unchanged.
 """
+import weakref
+
 import torch
 import torch.nn as nn
 
@@ -137,7 +139,8 @@ class _MomentumSlots:
     old value back on every replay): there the caller must have synced before (``sync_bn_momentum`` /
     ``BNMomentumScheduler.step``, both of which update all slots of a model with one host-to-device copy)."""
     CAP = 4096
-    _bufs = {}          # device index -> [device tensor (CAP,), pinned host staging (CAP,), slots in use, host values]
+    _bufs = {}          # device index -> [device tensor (CAP,), slots in use, host values]
+    _free = {}          # device index -> indices of slots whose module was garbage-collected
 
     @classmethod
     def _buf(cls, dev):
@@ -146,8 +149,7 @@ class _MomentumSlots:
             if torch.cuda.is_current_stream_capturing():
                 raise RuntimeError("BatchNorm momentum slots cannot be created while a HIP graph is being captured: "
                                    "run one eager step or call pytorch_utils.sync_bn_momentum(model) before the capture")
-            host = torch.zeros(cls.CAP, dtype=torch.float32).pin_memory()
-            cls._bufs[key] = [torch.zeros(cls.CAP, dtype=torch.float32, device=dev), host, 0, []]
+            cls._bufs[key] = [torch.zeros(cls.CAP, dtype=torch.float32, device=dev), 0, []]
         return key, cls._bufs[key]
 
     @classmethod
@@ -159,29 +161,35 @@ class _MomentumSlots:
         if rec is not None and rec[0] == key and rec[2] == id(bn):
             return rec
         key, entry = cls._buf(dev)
-        if entry[2] >= cls.CAP:
-            raise RuntimeError(f"more than {cls.CAP} BatchNorm modules on one device")
         if torch.cuda.is_current_stream_capturing():
             raise RuntimeError("a BatchNorm module met the fused kernels for the first time inside a HIP-graph capture: "
                                "run one eager step or call pytorch_utils.sync_bn_momentum(model) before the capture")
-        rec = (key, entry[2], id(bn))
-        entry[2] += 1
-        entry[3].append(None)                # host value of the slot (python float, compared exactly); None forces a sync
+        free = cls._free.setdefault(key, [])
+        if free:
+            i = free.pop()
+            entry[2][i] = None               # host value of the slot (python float, compared exactly); None forces a sync
+        else:
+            if entry[1] >= cls.CAP:
+                raise RuntimeError(f"more than {cls.CAP} live BatchNorm modules on one device")
+            i = entry[1]
+            entry[1] += 1
+            entry[2].append(None)
+        rec = (key, i, id(bn))
         bn.__dict__["_istnet_mslot"] = rec
+        weakref.finalize(bn, free.append, i)     # the slot returns to the pool with its module
         return rec
 
     @classmethod
     def ptr(cls, bn, dev):
         """Device address of the module's momentum slot, holding ``bn.momentum``."""
         key, i, _ = cls._slot(bn, dev)
-        buf, host, _, values = cls._bufs[key]
+        buf, _, values = cls._bufs[key]
         want = float(bn.momentum)
         if values[i] != want:
             if torch.cuda.is_current_stream_capturing():
                 raise RuntimeError("bn.momentum changed since the last sync and a HIP graph is being captured: call "
                                    "pytorch_utils.sync_bn_momentum(model) (BNMomentumScheduler.step does) before capturing")
             values[i] = want
-            host[i] = want
             buf[i:i + 1].fill_(want)
         return buf.data_ptr() + 4 * i
 
@@ -197,15 +205,19 @@ class _MomentumSlots:
             if dev is None or dev.type != "cuda":
                 continue
             key, i, _ = cls._slot(m, dev)
-            _, host, _, values = cls._bufs[key]
+            values = cls._bufs[key][2]
             want = float(m.momentum)
             if values[i] != want:
                 values[i] = want
-                host[i] = want
                 dirty.add(key)
         for key in dirty:
-            buf, host, used, _ = cls._bufs[key]
-            buf[:used].copy_(host[:used], non_blocking=True)
+            buf, used, values = cls._bufs[key]
+            # a FRESH pinned staging tensor per copy: the copy is asynchronous (it queues behind the step in flight), and
+            # a staging buffer reused by the next scheduler step would be overwritten before this copy has read it -- the
+            # replay in between would then run with the NEXT iteration's momentum (the caching host allocator keeps the
+            # block alive until the copy is done).  Slots never synced yet (None) get their value at first use.
+            stage = torch.tensor([0.0 if v is None else v for v in values[:used]], dtype=torch.float32).pin_memory()
+            buf[:used].copy_(stage, non_blocking=True)
 
 
 def bn_momentum_ptr(bn, dev):

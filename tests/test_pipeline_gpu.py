@@ -144,7 +144,7 @@ def test_training_steps_are_bit_reproducible():
     assert torch.equal(a, b), float((a - b).abs().max())
 
 
-@pytest.mark.parametrize("switch", ["USE_DEFERRED_WGRAD", "USE_SCALE_STREAMS", "USE_FUSED_SMALL_BWD", "USE_FUSED_MID_BWD", "USE_POOLED_FINALIZE", "USE_DENSE_FINALIZE", "USE_INTERP_IN_EPILOGUE", "USE_FINALIZE_IN_SCATTER", "USE_POOL_EPILOGUE", "USE_SPLIT_LAYER0", "USE_FP_SKIP_STREAM",
+@pytest.mark.parametrize("switch", ["USE_DEFERRED_WGRAD", "USE_SCALE_STREAMS", "USE_FUSED_SMALL_BWD", "USE_FUSED_MID_BWD", "USE_POOLED_FINALIZE", "USE_DENSE_FINALIZE", "USE_INTERP_IN_EPILOGUE", "USE_FINALIZE_IN_SCATTER", "USE_SPLIT_LAYER0", "USE_FP_SKIP_STREAM",
                                     "USE_CSR_SCATTER", "USE_FUSED_FP", "USE_GEOMETRY_STREAM", "USE_FPS_CHAIN", "USE_FUSED_NN_WEIGHTS", "COMPACT_LEVELS=", "COMPACT_LEVELS=0,1,2"])
 def test_fallback_paths_agree_with_default(switch):
     """Every module-level switch of the fused path selects code that a caller can reach (fallbacks and measured
