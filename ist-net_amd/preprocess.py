@@ -163,3 +163,153 @@ def instance_labels(pts, translation, rotation, scale, sizes, symmetric):
     srt[:, :3, :3] = (scale.reshape(-1, 1, 1).to(f64) * rot_out).to(torch.float32)
     srt[:, :3, 3] = t32
     return rot_out, size, qo, srt
+
+
+AUG_PROBS_DEFAULT = (0.3, 0.3, 0.0, 0.0, 0.0)     # aug_bb_pro, aug_rt_pro, aug_bc_pro, aug_pc_pro, aug_nl_pro [ref config/ist_net_default.yaml:37-42]
+
+
+def generate_aug_parameters(count, device="cpu", generator=None, s_x=(0.8, 1.2), s_y=(0.8, 1.2), s_z=(0.8, 1.2), ax=50,
+                            ay=50, az=50, a=15):
+    """provider/dataset.py:123-133 for a batch: box stretch factors (count, 3) in [0.8, 1.2), a translation (count, 3) of up
+    to +-50 mm per axis (in metres) and a rotation (count, 3, 3) of up to +-15 degrees about each axis, R_z R_y R_x as
+    data_augmentation.get_rotation (:8-25) composes it.  Drawn from ``generator`` (torch), not from numpy's global state."""
+    import math
+    u = torch.rand(count, 9, generator=generator, dtype=torch.float64).to(device)
+    lo = torch.tensor([s_x[0], s_y[0], s_z[0]], dtype=torch.float64, device=device)
+    hi = torch.tensor([s_x[1], s_y[1], s_z[1]], dtype=torch.float64, device=device)
+    bb = (u[:, 0:3] * (hi - lo) + lo).to(torch.float32)
+    ang = (u[:, 3:6] * 2 * a - a) / 180.0 * math.pi
+    lim = torch.tensor([ax, ay, az], dtype=torch.float64, device=device)
+    trans = ((u[:, 6:9] * 2 * lim - lim).to(torch.float32) / 1000.0)
+    cx, cy, cz = torch.cos(ang).unbind(1)
+    sx, sy, sz = torch.sin(ang).unbind(1)
+    one, zero = torch.ones_like(cx), torch.zeros_like(cx)
+    rx = torch.stack([one, zero, zero, zero, cx, -sx, zero, sx, cx], 1).view(-1, 3, 3)
+    ry = torch.stack([cy, zero, sy, zero, one, zero, -sy, zero, cy], 1).view(-1, 3, 3)
+    rz = torch.stack([cz, -sz, zero, sz, cz, zero, zero, zero, one], 1).view(-1, 3, 3)
+    return bb, trans, (rz @ ry @ rx).to(torch.float32)
+
+
+def data_augment(probs, pts, rotation, translation, size, sym, aug_bb, aug_rt_t, aug_rt_r, model, nocs, obj_id, pc_r=0.002,
+                 draws=None, generator=None):
+    """The point-cloud augmentation of the reference's training set for a whole batch at once
+    (provider/data_augmentation.py:217-285 ``data_augment``, called per sample from provider/dataset.py:277-283), as
+    batched tensor expressions on whatever device the inputs live on -- the reference walks the samples one by one on
+    the host inside ``__getitem__``.
+
+    ``probs``: (aug_bb_pro, aug_rt_pro, aug_bc_pro, aug_pc_pro, aug_nl_pro) -- object with those attributes (the
+    reference's config) or a 5-sequence.  pts (B, N, 3), rotation (B, 3, 3), translation (B, 3), size (B, 3), sym
+    (B, 4) integer symmetry codes (only column 0 is read, :49), aug_bb / aug_rt_t (B, 3), aug_rt_r (B, 3, 3)
+    (``generate_aug_parameters``), model (B, M, 3), nocs (B, N, 3), obj_id (B,) 0-based class ids.
+    Returns (pts, rotation, translation, size, model, nocs) like the reference; inputs are not modified.
+
+    In order, each branch taken where its uniform draw is below its probability:
+      bb  box deformation (:45-91): stretch along the object's axes (one in-plane factor for y-symmetric classes);
+      rt  rigid perturbation (:95-130);
+      bc  box-cage resize, mug and bowl only (:132-164);
+      pc  Gaussian point noise of sigma ``pc_r`` (:166-169);
+      nl  non-linear stretch along one axis, classes 0, 1, 2, 3, 5 (:173-215; axis 0 for the camera class 2, else 1).
+
+    ``draws``: the random numbers, as a dict -- "prop" (B, 5) uniforms deciding the branches (bb, rt, bc, pc, nl), "bc"
+    (B, 2) and "nl" (B, 2) the raw uniforms of those two branches, "noise" (B, N, 3) standard normals.  None: drawn
+    here from ``generator``.  With the reference's own draws the outputs equal the reference's to float32 round-off
+    (tests/test_preprocess.py against tests/golden/data_augment.npz)."""
+    if not isinstance(probs, (tuple, list)):
+        probs = (probs.aug_bb_pro, probs.aug_rt_pro, probs.aug_bc_pro, probs.aug_pc_pro, probs.aug_nl_pro)
+    f32 = torch.float32
+    dev = pts.device
+    pts, model, nocs = pts.to(f32), model.to(f32), nocs.to(f32)
+    rot, trans, size = rotation.to(f32), translation.to(f32).reshape(-1, 3), size.to(f32).reshape(-1, 3)
+    b, n, _ = pts.shape
+    obj = torch.as_tensor(obj_id, device=dev).reshape(-1).to(torch.int64)
+    if draws is None:
+        draws = {"prop": torch.rand(b, 5, generator=generator).to(dev), "bc": torch.rand(b, 2, generator=generator).to(dev),
+                 "nl": torch.rand(b, 2, generator=generator).to(dev),
+                 "noise": torch.randn(b, n, 3, generator=generator).to(dev)}
+    prop = draws["prop"].to(device=dev, dtype=f32)
+    take = prop < torch.tensor([float(p) for p in probs], dtype=f32, device=dev)
+    isin = lambda ids: (obj.unsqueeze(1) == torch.tensor(ids, device=dev)).any(1)
+    do_bb, do_rt, do_pc = take[:, 0], take[:, 1], take[:, 3]
+    do_bc = take[:, 2] & isin([5, 1])
+    do_nl = take[:, 4] & isin([0, 1, 2, 3, 5])
+    sel3 = lambda m, a, c: torch.where(m.view(-1, 1), a, c)              # (B, 3) tensors
+    sel = lambda m, a, c: torch.where(m.view(-1, 1, 1), a, c)            # (B, *, 3) tensors
+    norm = lambda v: torch.linalg.vector_norm(v, dim=1)
+
+    def extents(mp):
+        """(lx, ly, lz) of the deformed model points (:147-149, :195-197): symmetric extent in x, plain extents in y, z."""
+        mx, mn = mp.max(dim=1).values, mp.min(dim=1).values
+        return torch.stack([2 * torch.maximum(mx[:, 0], -mn[:, 0]), mx[:, 1] - mn[:, 1], mx[:, 2] - mn[:, 2]], 1)
+
+    # ---- bb (:45-91) ----
+    e = aug_bb.to(device=dev, dtype=f32).reshape(-1, 3)
+    exz = (e[:, 0] + e[:, 2]) / 2
+    e = sel3(torch.as_tensor(sym, device=dev).reshape(b, -1)[:, 0] == 1, torch.stack([exz, e[:, 1], exz], 1), e)
+    reproj = (pts - trans.unsqueeze(1)) @ rot                            # rows: R^T (p - t)
+    s_bb = size * e
+    k = (norm(s_bb) / norm(size)).view(-1, 1, 1)
+    pts = sel(do_bb, (reproj * e.unsqueeze(1)) @ rot.transpose(1, 2) + trans.unsqueeze(1), pts)
+    nocs = sel(do_bb, nocs * e.unsqueeze(1) / k, nocs)
+    model = sel(do_bb, model * e.unsqueeze(1) / k, model)
+    size = sel3(do_bb, s_bb, size)
+
+    # ---- rt (:95-130) ----
+    d = aug_rt_t.to(device=dev, dtype=f32).reshape(-1, 3)
+    rm = aug_rt_r.to(device=dev, dtype=f32).reshape(-1, 3, 3)
+    pts = sel(do_rt, (pts + d.unsqueeze(1)) @ rm.transpose(1, 2), pts)
+    trans_rt = (rm @ (trans + d).unsqueeze(2)).squeeze(2)
+    rot = sel(do_rt, rm @ rot, rot)
+    trans = sel3(do_rt, trans_rt, trans)
+
+    # ---- bc (:132-164): resize x, z linearly along y ----
+    ub = draws["bc"].to(device=dev, dtype=f32)
+    up, down = ub[:, 0:1] * (1.2 - 0.8) + 0.8, ub[:, 1:2] * (1.2 - 0.8) + 0.8
+    reproj = (pts - trans.unsqueeze(1)) @ rot
+    sy = size[:, 1:2]
+    xz = torch.tensor([True, False, True], device=dev)
+    scale_by = lambda p, r: torch.where(xz, p * r.unsqueeze(2), p)
+    pts_bc = scale_by(reproj, (reproj[:, :, 1] + sy / 2) / sy * (up - down) + down) @ rot.transpose(1, 2) + trans.unsqueeze(1)
+    ns = size / norm(size).view(-1, 1)
+    nsy = ns[:, 1:2]
+    model_bc = scale_by(model, (model[:, :, 1] + nsy / 2) / nsy * (up - down) + down)
+    ext = extents(model_bc)
+    aug = norm(ext).view(-1, 1, 1)
+    nocs_bc = scale_by(nocs, (nocs[:, :, 1] + nsy / 2) / nsy * (up - down) + down) / aug
+    pts, model, nocs = sel(do_bc, pts_bc, pts), sel(do_bc, model_bc / aug, model), sel(do_bc, nocs_bc, nocs)
+    size = sel3(do_bc, ext * norm(size).view(-1, 1), size)
+
+    # ---- pc (:166-169) ----
+    pts = sel(do_pc, pts + draws["noise"].to(device=dev, dtype=f32) * float(pc_r), pts)
+
+    # ---- nl (:173-215): stretch one axis by a factor growing with the square of the coordinate ----
+    un = draws["nl"].to(device=dev, dtype=f32)
+    r_max, r_min = un[:, 0:1] * 0.2 + 1.1, -un[:, 1:2] * 0.2 + 0.9
+    axis = torch.where(obj == 2, 0, 1)                                   # (:268-271)
+    amask = torch.nn.functional.one_hot(axis, 3).to(torch.bool).unsqueeze(1)           # (B, 1, 3)
+    pick = lambda p: torch.gather(p, 2, axis.view(-1, 1, 1).expand(-1, p.shape[1], 1)).squeeze(2)
+    stretch = lambda p, r: torch.where(amask, p * r.unsqueeze(2), p)
+    reproj = (pts - trans.unsqueeze(1)) @ rot
+    sa = torch.gather(size, 1, axis.view(-1, 1))
+    xa = pick(reproj)
+    pts_nl = stretch(reproj, r_min + 4 * (xa * xa) / (sa ** 2) * (r_max - r_min)) @ rot.transpose(1, 2) + trans.unsqueeze(1)
+    ns = size / norm(size).view(-1, 1)
+    nsa = torch.gather(ns, 1, axis.view(-1, 1))
+    ma = pick(model)
+    model_nl = stretch(model, r_min + 4 * (ma * ma) / (nsa ** 2) * (r_max - r_min))
+    ext = extents(model_nl)
+    aug = norm(ext).view(-1, 1, 1)
+    na = pick(nocs)
+    nocs_nl = stretch(nocs, r_min + 4 * (na * na) / (nsa ** 2) * (r_max - r_min)) / aug
+    pts, model, nocs = sel(do_nl, pts_nl, pts), sel(do_nl, model_nl / aug, model), sel(do_nl, nocs_nl, nocs)
+    size = sel3(do_nl, ext * norm(size).view(-1, 1), size)
+    return pts, rot, trans, size, model, nocs
+
+
+def jitter_points(pts, noise=None, generator=None):
+    """provider/dataset.py:211 for a batch: ``pts + clip(0.001 * N(0, 1), -0.005, 0.005)`` -- one millimetre of Gaussian
+    sensor noise per coordinate, clipped at five.  The reference adds float64 noise to the float32 points and rounds to
+    float32 once (``torch.FloatTensor(pts)``, :225); so does this.  ``noise``: the standard normals, same shape as ``pts``
+    (None: drawn from ``generator``)."""
+    if noise is None:
+        noise = torch.randn(pts.shape, generator=generator, dtype=torch.float64).to(pts.device)
+    return (pts.to(torch.float64) + (0.001 * noise.to(device=pts.device, dtype=torch.float64)).clamp(-0.005, 0.005)).to(torch.float32)

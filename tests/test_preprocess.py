@@ -236,3 +236,87 @@ def test_crop_resize_normalize_matches_oracle_bit_exact(shared):
         preprocess.crop_resize_normalize(image.cpu(), torch.from_numpy(boxes))
     with pytest.raises(TypeError):
         preprocess.crop_resize_normalize(image.float(), torch.from_numpy(boxes))
+
+
+# ---- pinned to the reference's own outputs (tests/golden/make_golden_augment.py imports its modules) ----
+def _golden(name):
+    import os
+    return np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", name))
+
+
+def test_get_bbox_matches_reference_golden():
+    """preprocess.get_bbox AND the oracle's restatement against utils/data_utils.py:43-71 itself on 4 000 boxes, boxes
+    touching and crossing the image border included (tests/golden/get_bbox.npz)."""
+    from istnet_amd import preprocess
+    g = _golden("get_bbox.npz")
+    got = preprocess.get_bbox(torch.from_numpy(g["boxes"]))
+    assert torch.equal(got.to(torch.int64), torch.from_numpy(g["windows"]))
+    for b, w in zip(g["boxes"][:500], g["windows"][:500]):
+        assert preproc_oracle.get_bbox(tuple(b)) == tuple(w)
+
+
+def _augment_against_golden(device):
+    from istnet_amd import preprocess
+    g = _golden("data_augment.npz")
+    T = lambda k: torch.from_numpy(g[k]).to(device)
+    probs = g["probs"]
+    taken = np.zeros(5, dtype=np.int64)
+    for uniq in np.unique(probs, axis=0):             # one batched call per probability setting of the fixture
+        idx = torch.from_numpy(np.where((probs == uniq).all(1))[0]).to(device)
+        draws = {k: T(k)[idx] for k in ("prop", "bc", "nl", "noise")}
+        inputs = [T(k)[idx] for k in ("pts", "R", "t", "s", "sym", "aug_bb", "aug_rt_t", "aug_rt_r", "model", "qo", "obj_id")]
+        before = [t.clone() for t in inputs]
+        out = preprocess.data_augment(tuple(float(v) for v in uniq), *inputs, pc_r=float(g["pc_r"][0]), draws=draws)
+        for a, b in zip(inputs, before):
+            assert torch.equal(a, b)                  # (the reference's functions write into their arguments; this one does not)
+        for name, o in zip(("out_pts", "out_R", "out_t", "out_s", "out_model", "out_qo"), out):
+            assert o.device.type == torch.device(device).type
+            torch.testing.assert_close(o.cpu(), torch.from_numpy(g[name])[idx.cpu()], rtol=1e-6, atol=1e-6,
+                                       msg=lambda m, name=name, uniq=uniq: f"{name} at probs {uniq}: {m}")
+        taken += (g["prop"][idx.cpu().numpy()] < uniq).sum(0)
+    assert (taken >= 20).all(), taken                 # every branch of data_augment is exercised by the fixture
+
+
+def test_data_augment_matches_reference_golden():
+    """preprocess.data_augment (batched) against provider/data_augmentation.py:217-285 run sample by sample with the
+    same random draws: every branch alone, all together, the shipped probabilities and 0.5 each; all six classes
+    (symmetric / asymmetric box deformation, the mug / bowl cage, both non-linear axes).  1e-6."""
+    _augment_against_golden("cpu")
+
+
+@pytest.mark.gpu
+def test_data_augment_matches_reference_golden_on_device():
+    _augment_against_golden("cuda:0")
+
+
+def test_data_augment_draws_its_own_numbers():
+    """Without ``draws`` the batch is augmented from a torch generator: reproducible, a no-op at probability zero, and
+    rigid where only the rigid branch is on (pairwise distances preserved)."""
+    from istnet_amd import preprocess
+    g = _golden("data_augment.npz")
+    T = lambda k: torch.from_numpy(g[k][:12])
+    args = [T(k) for k in ("pts", "R", "t", "s", "sym")]
+    bb, tr, rm = preprocess.generate_aug_parameters(12, generator=torch.Generator().manual_seed(5))
+    assert bb.shape == (12, 3) and float(bb.min()) >= 0.8 and float(bb.max()) < 1.2 and float(tr.abs().max()) <= 0.05
+    torch.testing.assert_close(rm @ rm.transpose(1, 2), torch.eye(3).expand(12, 3, 3), rtol=0, atol=1e-6)
+    rest = [T("model"), T("qo"), T("obj_id")]
+    same = preprocess.data_augment((0.0,) * 5, *args, bb, tr, rm, *rest, generator=torch.Generator().manual_seed(1))
+    for got, key in zip(same, ("pts", "R", "t", "s", "model", "qo")):
+        assert torch.equal(got, T(key))
+    a = preprocess.data_augment((0.0, 1.0, 0.0, 0.0, 0.0), *args, bb, tr, rm, *rest, generator=torch.Generator().manual_seed(1))
+    b = preprocess.data_augment((0.0, 1.0, 0.0, 0.0, 0.0), *args, bb, tr, rm, *rest, generator=torch.Generator().manual_seed(1))
+    assert all(torch.equal(x, y) for x, y in zip(a, b))
+    pair = lambda p: (p[:, :, None] - p[:, None]).norm(dim=-1)
+    torch.testing.assert_close(pair(a[0]), pair(T("pts")), rtol=1e-4, atol=1e-6)
+
+
+def test_jitter_points_is_the_dataset_line():
+    """provider/dataset.py:211 restated in numpy (float64 noise on float32 points, one rounding) against the batched form."""
+    from istnet_amd import preprocess
+    rng = np.random.default_rng(2)
+    pts = rng.uniform(-0.3, 0.9, (3, 64, 3)).astype(np.float32)
+    z = rng.standard_normal((3, 64, 3)) * np.array([1.0, 4.0, 8.0]).reshape(3, 1, 1)      # some draws beyond the clip
+    want = (pts + np.clip(0.001 * z, -0.005, 0.005)).astype(np.float32)
+    got = preprocess.jitter_points(torch.from_numpy(pts), noise=torch.from_numpy(z))
+    assert got.dtype == torch.float32 and np.array_equal(got.numpy(), want)
+    assert float((got - torch.from_numpy(pts)).abs().max()) <= 0.005 + 1e-7
