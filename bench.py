@@ -173,6 +173,7 @@ def make_graphed_step(fwd_bwds, opt, world, reducer=None):
     # aborts the process (measured on this stack: tools/exp/rccl_capture_modes.py).  "thread_local" restricts the
     # check to the capturing thread.
     capture_mode = "global" if reducer is None else "thread_local"
+    in_graph = reducer is not None and getattr(reducer, "capture_collectives", False)
     for fwd_bwd in fwd_bwds:                           # one graph per closure (two when the batches alternate)
         graph = torch.cuda.CUDAGraph()
         opt.zero_grad(set_to_none=True)
@@ -182,6 +183,10 @@ def make_graphed_step(fwd_bwds, opt, world, reducer=None):
             fwd_bwd()
             if reducer is None:
                 opt.step()
+            elif in_graph:
+                # the buckets left from the backward hooks as graph nodes (forked onto the communication stream as soon as
+                # their slice was final); join them and capture the Adam launch too: one host call per step
+                opt.step(reducer.finish_captured(), grad_scale=1.0 / world)
             # else: the gradients stay in their (static) buffers; the all-reduce and Adam follow the replay eagerly
         # per graph: which static tensor holds each parameter's gradient after a replay (parallel.OverlappedFlatReducer)
         graphs.append((graph, reducer.end_capture() if reducer is not None else None))
@@ -191,7 +196,7 @@ def make_graphed_step(fwd_bwds, opt, world, reducer=None):
         graph, token = graphs[count[0] % len(graphs)]
         count[0] += 1
         graph.replay()
-        if reducer is not None:        # bucketed RCCL all-reduce + one Adam launch
+        if reducer is not None and not in_graph:        # bucketed RCCL all-reduce + one Adam launch
             opt.step(reducer.finish(captured=token), grad_scale=1.0 / world)
     return step
 
@@ -459,6 +464,10 @@ def main():
                     help="N > 1: run the step eagerly so that each ~25 MB bucket of the flat gradient is all-reduced "
                          "from an autograd hook while backward still runs (a replayed graph issues the buckets after "
                          "the replay); meant for --workload istnet (107 MB of gradients)")
+    ap.add_argument("--capture-allreduce", action="store_true",
+                    help="N > 1 (or --force-dist): capture the bucketed all-reduce and the Adam launch INSIDE the HIP graph, "
+                         "each bucket forked onto the communication stream when its slice is final (overlaps the tail of "
+                         "backward without host launches); falls back to replay + eager buckets if the capture fails")
     ap.add_argument("--no-overlap-allreduce", action="store_true",
                     help="(the default since round 3; kept for old command lines) captured step, buckets after the replay")
     ap.add_argument("--no-prefetch", action="store_true",
@@ -589,7 +598,8 @@ def main():
         opt = FlatAdam(model.parameters(), lr=1e-4, adjacent=layout_hints(model))
         if dist_on:
             from istnet_amd.parallel import OverlappedFlatReducer
-            grad_sync = OverlappedFlatReducer(opt, world, always=args.force_dist)
+            grad_sync = OverlappedFlatReducer(opt, world, always=args.force_dist,
+                                              capture_collectives=args.capture_allreduce)
         fwd_bwd = make_istnet_fwd_bwd(model, batch)
         args.no_cpu_baseline = True
     else:
@@ -598,7 +608,8 @@ def main():
         opt = FlatAdam(model.parameters(), lr=1e-4, adjacent=layout_hints(model))
         if dist_on:
             from istnet_amd.parallel import OverlappedFlatReducer
-            grad_sync = OverlappedFlatReducer(opt, world, always=args.force_dist)
+            grad_sync = OverlappedFlatReducer(opt, world, always=args.force_dist,
+                                              capture_collectives=args.capture_allreduce)
         if args.no_prefetch:
             fwd_bwd = make_encoder_fwd_bwd(model, pts)
         else:
@@ -616,7 +627,16 @@ def main():
     # the default again; --overlap-allreduce selects the hook-overlapped eager step.
     if args.overlap_allreduce and dist_on:
         args.eager = True       # hooks issue the collectives during backward: not inside a capture
-    if not args.eager:
+    if not args.eager and args.capture_allreduce and grad_sync is not None:
+        try:
+            step, mode = make_graphed_step(fwd_bwd, opt, world, grad_sync), "hipgraph"
+        except Exception as exc:  # the collectives could not be captured: replay + eager buckets instead
+            print(f"[bench] capturing the all-reduce failed ({type(exc).__name__}: {exc}); buckets after the replay",
+                  file=sys.stderr)
+            torch.cuda.synchronize()
+            grad_sync.capture_collectives = False
+            args.capture_allreduce = False
+    if not args.eager and mode != "hipgraph":
         try:
             step, mode = make_graphed_step(fwd_bwd, opt, world, grad_sync), "hipgraph"
         except Exception as exc:  # capture unsupported in this configuration: run the same step eagerly
@@ -677,6 +697,8 @@ def main():
                                                                for lo, hi, _ in grad_sync.buckets],
                                               "collective": "sum all-reduce of FlatAdam.flat_grad slices (RCCL), 1/N folded into Adam",
                                               "issued": ("from autograd hooks during backward (overlapped)" if mode == "eager"
+                                                         else "inside the HIP graph, each bucket forked when its slice is final; "
+                                                              "Adam captured too" if args.capture_allreduce
                                                          else "back to back after the graph replay")}),
                        "batches": ("1 (same batch every step)" if (args.workload != "encoder" or args.no_prefetch)
                                    else "2 alternating, next batch's FPS/ball-query/three_nn prefetched on the "

@@ -261,6 +261,26 @@ ISTNET_PN2_API int istnet_pw_wgrad_reduce(int count, int splits, const float *dw
 ISTNET_PN2_API int istnet_pw_wgrad_reduce_multi(int n, const int *counts, const int *splits,
                                                 const float *const *parts, float *const *dws, void *stream);
 
+/* istnet_bn_finalize_fwd of a stack's LAST layer folded into its tail (istnet_bn_relu_pool): one launch that finishes the
+ * batch statistics from the partials (writes bn[4][c], updates the running statistics; `momentum` is a device pointer),
+ * then applies out = max_s relu(scale y + shift) (+ arg / ymax) exactly as istnet_bn_relu_pool does -- bit-identical to
+ * the two launches.  s == 1: out = relu(scale y + shift) (arg / ymax unused).  [ref pytorch_utils.py:25-50 +
+ * pointnet2_modules.py:65-68] */
+ISTNET_PN2_API int istnet_bn_fin_relu_pool(int b, int c, int g, int s, int nt, double count, const float *part_sum,
+                                           const float *part_sq, const float *gamma, const float *beta, float eps,
+                                           const float *momentum, float *running_mean, float *running_var, float *bn,
+                                           const float *y, float *out, long long out_bstride, unsigned char *arg,
+                                           float *ymax, void *stream);
+
+/* three_interpolate_grad over the inverse lists of the taps (istnet_pn2_three_interpolate_grad_csr; reference
+ * interpolate_gpu.cu:115-148) of dY = ca * relu'(bn(y)) * d_dense + cb + cc * y, formed on the fly from the raw pair
+ * (y, d_dense) (b, c, n) and the constant blocks bn[4][c] / bwdc[3][c]: grad_points (b, c, m).  Bit-identical to
+ * istnet_pw_dy followed by istnet_pn2_three_interpolate_grad_csr. */
+ISTNET_PN2_API int istnet_interp_grad_csr_dy(int b, int c, int n, int m, const float *y, const float *d_dense,
+                                             const float *bn, const float *bwdc, const float *weight,
+                                             const int *offsets, const int *entries, float *grad_points,
+                                             void *stream);
+
 /* out (b, c) = mean over the p points of relu(scale_c * y[b][c][:] + shift_c)  (bn = [scale | shift | ...] as everywhere):
  * the AdaptiveAvgPool1d(1) that ends pose_mlp2 of both estimators (model/ist_net.py:246,314) from the raw output of the
  * stack's last layer; istnet_expand_rows is its adjoint, out[row][:] = g[row] / p for rows = b * c.  p % 4 == 0. */

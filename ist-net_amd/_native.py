@@ -107,6 +107,8 @@ SIGNATURES = {
     "istnet_pw_wgrad_reduce_multi_ld": [_i, _p, _p, _p, _p, _p, _p, _p, _p],
     "istnet_pack_words": [_i, _p, _p, _p, _p],
     "istnet_bn_relu_mean": [_i, _i, _i, _p, _p, _p, _p],
+    "istnet_bn_fin_relu_pool": [_i, _i, _i, _i, _i, _d, _p, _p, _p, _p, _f, _p, _p, _p, _p, _p, _p, _l, _p, _p, _p],
+    "istnet_interp_grad_csr_dy": [_i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p],
     "istnet_expand_rows": [_i, _i, _p, _p, _p],
     # include/istnet_heads.h (csrc/pose_tail.hip)
     "istnet_fc_forward": [_i, _i, _i, _p, _p, _p, _p, _p, _i, _p],

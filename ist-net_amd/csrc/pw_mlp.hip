@@ -938,6 +938,107 @@ __global__ __launch_bounds__(256) void bn_relu_apply_kernel(int C, int P4, const
   }
 }
 
+// ============================================================================================
+// The LAST BatchNorm finalize of a stack folded into its consumer.  The tail kernels above are per-channel consumers: a
+// workgroup of the fused forms below serves ONE channel, so it can reduce that channel's statistics partials itself
+// (2 nt floats, the same fixed-order float64 reduction as bn_finalize_fwd_kernel -> bit-identical constants in every
+// workgroup of the channel) and go straight on to its rows.  One launch and one kernel boundary less on the forward
+// chain of every set-abstraction scale and of the encoder's last feature-propagation level.  The chunk-0 workgroup of a
+// channel writes bn[4][C] and the running statistics.  grid (C, chunks): chunk j serves clouds [B j / chunks, B (j+1) / chunks).
+// ============================================================================================
+__device__ __forceinline__ void finalize_channel(int C, int c, int nt, double count, const float* __restrict__ part_sum,
+                                                 const float* __restrict__ part_sq, const float* __restrict__ gamma,
+                                                 const float* __restrict__ beta, float eps,
+                                                 const float* __restrict__ momentum_p, float* __restrict__ running_mean,
+                                                 float* __restrict__ running_var, float* __restrict__ bn, bool writer,
+                                                 float& sc_out, float& sh_out) {
+  double s, q;
+  reduce_partials2(part_sum + (size_t)c * nt, part_sq + (size_t)c * nt, nt, s, q);
+  __shared__ float s_aff[2];
+  if (threadIdx.x == 0) {
+    const double mean = s / count;
+    double var = q / count - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const float istd = (float)(1.0 / sqrt(var + (double)eps));
+    const float sc = gamma[c] * istd;
+    const float shf = beta[c] - (float)mean * sc;
+    if (writer) {
+      bn[0 * C + c] = sc;
+      bn[1 * C + c] = shf;
+      bn[2 * C + c] = (float)mean;
+      bn[3 * C + c] = istd;
+      if (running_mean != nullptr) {
+        const float momentum = *momentum_p;
+        const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
+        running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
+        running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
+      }
+    }
+    s_aff[0] = sc;
+    s_aff[1] = shf;
+  }
+  __syncthreads();
+  sc_out = s_aff[0];
+  sh_out = s_aff[1];
+}
+
+template <int S4>  // finalize + bn_relu_pool_kernel<S4>
+__global__ __launch_bounds__(kFinThreads) void bn_fin_relu_pool_kernel(
+    int C, int B, int G, int nt, double count, const float* __restrict__ part_sum, const float* __restrict__ part_sq,
+    const float* __restrict__ gamma, const float* __restrict__ beta, float eps, const float* __restrict__ momentum_p,
+    float* __restrict__ running_mean, float* __restrict__ running_var, float* __restrict__ bn,
+    const float* __restrict__ y, float* __restrict__ out, long long out_bstride, uint8_t* __restrict__ arg,
+    float* __restrict__ ymax) {
+  const int c = blockIdx.x;
+  float s, h;
+  finalize_channel(C, c, nt, count, part_sum, part_sq, gamma, beta, eps, momentum_p, running_mean, running_var, bn,
+                   blockIdx.y == 0, s, h);
+  const int b0 = (int)((long long)B * blockIdx.y / gridDim.y), b1 = (int)((long long)B * (blockIdx.y + 1) / gridDim.y);
+  const int total = (b1 - b0) * G;
+  for (int e = threadIdx.x; e < total; e += kFinThreads) {
+    const int bl = e / G, g = e - bl * G;
+    const size_t bc = (size_t)(b0 + bl) * C + c;
+    const float4* src = reinterpret_cast<const float4*>(y + (bc * G + g) * (S4 * 4));
+    float best = -1.f, raw = 0.f;
+    int besti = 0;
+#pragma unroll
+    for (int i = 0; i < S4; ++i) {
+      const float4 v = src[i];
+      const float a0 = fmaxf(v.x * s + h, 0.f), a1 = fmaxf(v.y * s + h, 0.f);
+      const float a2 = fmaxf(v.z * s + h, 0.f), a3 = fmaxf(v.w * s + h, 0.f);
+      if (a0 > best) { best = a0; besti = 4 * i + 0; raw = v.x; }
+      if (a1 > best) { best = a1; besti = 4 * i + 1; raw = v.y; }
+      if (a2 > best) { best = a2; besti = 4 * i + 2; raw = v.z; }
+      if (a3 > best) { best = a3; besti = 4 * i + 3; raw = v.w; }
+    }
+    out[(size_t)(b0 + bl) * out_bstride + (size_t)c * G + g] = best;
+    arg[bc * G + g] = (uint8_t)besti;
+    if (ymax != nullptr) ymax[bc * G + g] = raw;
+  }
+}
+
+// finalize + bn_relu_apply_kernel (nsample == 1: the tail of a feature-propagation stack)
+__global__ __launch_bounds__(kFinThreads) void bn_fin_relu_apply_kernel(
+    int C, int B, int P4, int nt, double count, const float* __restrict__ part_sum, const float* __restrict__ part_sq,
+    const float* __restrict__ gamma, const float* __restrict__ beta, float eps, const float* __restrict__ momentum_p,
+    float* __restrict__ running_mean, float* __restrict__ running_var, float* __restrict__ bn,
+    const float* __restrict__ y, float* __restrict__ out) {
+  const int c = blockIdx.x;
+  float s, h;
+  finalize_channel(C, c, nt, count, part_sum, part_sq, gamma, beta, eps, momentum_p, running_mean, running_var, bn,
+                   blockIdx.y == 0, s, h);
+  const int b0 = (int)((long long)B * blockIdx.y / gridDim.y), b1 = (int)((long long)B * (blockIdx.y + 1) / gridDim.y);
+  for (int b = b0; b < b1; ++b) {
+    const size_t row = ((size_t)b * C + c) * P4;
+    for (int i = threadIdx.x; i < P4; i += kFinThreads) {
+      float4 v = reinterpret_cast<const float4*>(y)[row + i];
+      v.x = fmaxf(v.x * s + h, 0.f); v.y = fmaxf(v.y * s + h, 0.f);
+      v.z = fmaxf(v.z * s + h, 0.f); v.w = fmaxf(v.w * s + h, 0.f);
+      reinterpret_cast<float4*>(out)[row + i] = v;
+    }
+  }
+}
+
 // bn[4][C] of a layer whose normalisation is a fixed affine map: eval-mode BatchNorm (running statistics) or a
 // plain conv bias (gamma / mean / var absent).  One launch instead of the 4-9 tiny tensor ops it replaces.
 // mean over the points of relu(scale y + shift): the AdaptiveAvgPool1d(1) that ends pose_mlp2 of both estimators
@@ -1107,6 +1208,68 @@ __global__ __launch_bounds__(256) void pw_dy_kernel(int C, int P4, const float* 
     o.w = ca * ((v.w * rs + rh > 0.f) ? g.w : 0.f) + cb + cc * v.w;
     reinterpret_cast<float4*>(out + (size_t)bc * P4 * 4)[i] = o;
   }
+}
+
+// Gradient of three_interpolate (reference interpolate_gpu.cu:115-148) taken over the inverse lists of the taps, with the
+// layer's dY formed on the fly from (y, dA, BatchNorm constants) -- pw_dy_kernel's expression, evaluated per gathered
+// element instead of materialising dY for one consumer (the feature-propagation backward chain loses a launch; the other
+// consumers of dY, the skip dgrad and the weight gradients, form it in their loaders anyway).  Same terms in the same
+// order as interp_grad_csr_kernel (csrc/pn2_index_ops.hip) on the materialised tensor: bit-identical.
+// grid (ceil(m / 256), ceil(C / 8), B).
+constexpr int kInterpDyCH = 8;
+__global__ __launch_bounds__(256) void interp_grad_csr_dy_kernel(int C, int n, int m, const float* __restrict__ y,
+                                                                 const float* __restrict__ d, const float* __restrict__ bn,
+                                                                 const float* __restrict__ bwdc,
+                                                                 const float* __restrict__ w_all,
+                                                                 const int* __restrict__ off_all,
+                                                                 const int* __restrict__ ent_all,
+                                                                 float* __restrict__ grad_points) {
+  const int b = blockIdx.z, c0 = blockIdx.y * kInterpDyCH;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= m) return;
+  const int* off = off_all + (size_t)b * (m + 1);
+  const int* ent = ent_all + (size_t)b * n * 3;
+  const float* w = w_all + (size_t)b * n * 3;
+  const int a = off[i], z = off[i + 1];
+  const int nch = min(kInterpDyCH, C - c0);
+  float rs[kInterpDyCH], rh[kInterpDyCH], ca[kInterpDyCH], cb[kInterpDyCH], cc[kInterpDyCH], sum[kInterpDyCH];
+#pragma unroll
+  for (int ch = 0; ch < kInterpDyCH; ++ch) {
+    const int c = c0 + min(ch, nch - 1);
+    rs[ch] = bn[c]; rh[ch] = bn[C + c];
+    ca[ch] = bwdc[c]; cb[ch] = bwdc[C + c]; cc[ch] = bwdc[2 * C + c];
+    sum[ch] = 0.f;
+  }
+  for (int u = a; u < z; u += 4) {
+    int e[4];
+    float we[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) e[q] = ent[min(u + q, z - 1)];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) we[q] = (u + q < z) ? w[e[q]] : 0.f;
+    float vq[4][kInterpDyCH], gq[4][kInterpDyCH];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int j = e[q] / 3;
+#pragma unroll
+      for (int ch = 0; ch < kInterpDyCH; ++ch) {
+        const size_t o = ((size_t)b * C + c0 + min(ch, nch - 1)) * n + j;
+        vq[q][ch] = y[o];
+        gq[q][ch] = d[o];
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int ch = 0; ch < kInterpDyCH; ++ch) {
+        const float v = vq[q][ch];
+        const float dy = ca[ch] * ((v * rs[ch] + rh[ch] > 0.f) ? gq[q][ch] : 0.f) + cb[ch] + cc[ch] * v;
+        sum[ch] += dy * we[q];
+      }
+  }
+#pragma unroll
+  for (int ch = 0; ch < kInterpDyCH; ++ch)
+    if (ch < nch) grad_points[((size_t)b * C + c0 + ch) * m + i] = sum[ch];
 }
 
 // per-channel partial sums of g and g * y  (-> dbeta, dgamma after finalize)
@@ -3472,6 +3635,59 @@ int istnet_bn_relu_pool(int b, int c, int g, int s, const float* y, const float*
     default: return ISTNET_PN2_EINVAL;
   }
 #undef ISTNET_POOL
+  return (int)hipGetLastError();
+}
+
+// chunks of clouds per channel: about 32 KB of y per workgroup, so that the redundant reduction of the channel's partials
+// (8 nt bytes) stays small beside the rows it serves
+static int fin_chunks(int b, long long row_bytes) {
+  long long ch = (long long)b * row_bytes / 32768;
+  if (ch < 1) ch = 1;
+  if (ch > b) ch = b;
+  return (int)ch;
+}
+
+int istnet_bn_fin_relu_pool(int b, int c, int g, int s, int nt, double count, const float* part_sum, const float* part_sq,
+                            const float* gamma, const float* beta, float eps, const float* momentum, float* running_mean,
+                            float* running_var, float* bn, const float* y, float* out, long long out_bstride,
+                            unsigned char* arg, float* ymax, void* stream) {
+  if (out_bstride <= 0) out_bstride = (long long)c * g;
+  if (b <= 0 || c <= 0 || g <= 0 || nt <= 0 || count <= 0.0 || !part_sum || !part_sq || !gamma || !beta || !bn || !y ||
+      !out || (running_mean != nullptr && momentum == nullptr))
+    return ISTNET_PN2_EINVAL;
+  if (s == 1) {
+    if ((g & 3) || out_bstride != (long long)c * g) return ISTNET_PN2_EINVAL;
+    hipLaunchKernelGGL(bn_fin_relu_apply_kernel, dim3(c, fin_chunks(b, 4LL * g)), dim3(kFinThreads), 0, as_stream(stream),
+                       c, b, g / 4, nt, count, part_sum, part_sq, gamma, beta, eps, momentum, running_mean, running_var, bn,
+                       y, out);
+    return (int)hipGetLastError();
+  }
+  if (arg == nullptr) return ISTNET_PN2_EINVAL;
+  const dim3 grid(c, fin_chunks(b, 4LL * g * s));
+#define ISTNET_FPOOL(S4)                                                                                             \
+  hipLaunchKernelGGL((bn_fin_relu_pool_kernel<S4>), grid, dim3(kFinThreads), 0, as_stream(stream), c, b, g, nt, count, \
+                     part_sum, part_sq, gamma, beta, eps, momentum, running_mean, running_var, bn, y, out, out_bstride, \
+                     arg, ymax)
+  switch (s) {
+    case 4: ISTNET_FPOOL(1); break;
+    case 8: ISTNET_FPOOL(2); break;
+    case 16: ISTNET_FPOOL(4); break;
+    case 32: ISTNET_FPOOL(8); break;
+    case 64: ISTNET_FPOOL(16); break;
+    default: return ISTNET_PN2_EINVAL;
+  }
+#undef ISTNET_FPOOL
+  return (int)hipGetLastError();
+}
+
+int istnet_interp_grad_csr_dy(int b, int c, int n, int m, const float* y, const float* d_dense, const float* bn,
+                              const float* bwdc, const float* weight, const int* offsets, const int* entries,
+                              float* grad_points, void* stream) {
+  if (b <= 0 || c <= 0 || m <= 0 || n <= 0 || !y || !d_dense || !bn || !bwdc || !weight || !offsets || !entries ||
+      !grad_points)
+    return ISTNET_PN2_EINVAL;
+  hipLaunchKernelGGL(interp_grad_csr_dy_kernel, dim3(ceil_div(m, 256), ceil_div(c, kInterpDyCH), b), dim3(256), 0,
+                     as_stream(stream), c, n, m, y, d_dense, bn, bwdc, weight, offsets, entries, grad_points);
   return (int)hipGetLastError();
 }
 

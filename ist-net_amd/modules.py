@@ -264,8 +264,11 @@ class PointNet2MSG(nn.Module):
                 if ev is not None:
                     main.wait_event(ev)
                 interp = (idx, weight, csr)
+            # levels 3..1 hand their RAW last output + BatchNorm constants to the next level (fused_mlp.LazyAct): its
+            # loaders apply the activation, the tensor of activated features is never written  [ref :322-325]
+            lazy = fused_mlp.USE_LAZY_FP and lvl > 0 and type(self.FP_modules[lvl - 1]) is PointnetFPModule
             l_features[lvl] = self.FP_modules[lvl](l_xyz[lvl], l_xyz[lvl + 1], l_features[lvl],
-                                                   l_features[lvl + 1], interp=interp)
+                                                   l_features[lvl + 1], interp=interp, lazy_out=lazy)
             _native.mark(f"fwd FP{lvl + 1} done")
         if csr_ev is not None:
             main.wait_event(csr_ev)       # the backward pass reads the inverse lists built at the end of the pre-pass

@@ -112,9 +112,16 @@ class OverlappedFlatReducer:
     has been launched raises; call ``finish()`` after every backward pass, or construct with ``overlap=False`` to defer
     every launch to ``finish()``."""
 
-    def __init__(self, opt, world_size=None, bucket_bytes=25 << 20, group=None, always=False, overlap=True):
+    def __init__(self, opt, world_size=None, bucket_bytes=25 << 20, group=None, always=False, overlap=True,
+                 capture_collectives=False):
         self.opt, self.group = opt, group
         self.overlap = overlap     # False: hooks only mark, every bucket is launched by finish() (gradient accumulation)
+        # True: a backward pass that is being CAPTURED issues its buckets from the hooks like an eager one -- the
+        # collectives become nodes of the HIP graph, forked onto the communication stream as soon as their slice is
+        # final, and ``finish_captured()`` joins them before the (captured) optimizer launch.  A replay then runs
+        # backward, the overlapped exchange and Adam with one host call (RCCL collectives are capturable; the capture
+        # must use capture_error_mode="thread_local": ProcessGroupNCCL's watchdog polls events from another thread).
+        self.capture_collectives = capture_collectives
         self.world = world_size if world_size is not None else dist.get_world_size(group)
         self.always = always       # True: issue the collectives even with one rank (single-GPU dry run of the RCCL path)
         esz = opt.flat_grad.element_size()
@@ -134,6 +141,9 @@ class OverlappedFlatReducer:
                 self.bucket_of[i] = b
         self.comm = torch.cuda.Stream(device=opt.flat_grad.device) if opt.flat_grad.is_cuda else None
         self._capturing = {}
+        self._cap_left = [len(idxs) for _, _, idxs in self.buckets]
+        self._cap_seen = [False] * len(opt.params)
+        self._cap_launched = [False] * len(self.buckets)
         self._reset()
         self.issued_in_backward = 0          # statistics of the last step (tests, logging)
         for i, p in enumerate(opt.params):
@@ -153,8 +163,14 @@ class OverlappedFlatReducer:
         def hook(param):
             b = self.bucket_of[i]
             if param.is_cuda and torch.cuda.is_current_stream_capturing():
-                # captured backward: remember the static tensor this graph writes the gradient to; nothing is issued
+                # captured backward: remember the static tensor this graph writes the gradient to
                 self._capturing[i] = param.grad
+                if self.capture_collectives and self._active() and not self._cap_seen[i]:
+                    self._cap_seen[i] = True
+                    self._cap_left[b] -= 1
+                    if self._cap_left[b] == 0:          # the slice is final: its all-reduce becomes a graph node here
+                        self._launch(b, source=self._capturing)
+                        self._cap_launched[b] = True
                 return
             if self.seen[i]:
                 if self.launched[b]:
@@ -172,8 +188,37 @@ class OverlappedFlatReducer:
     _capturing = None
 
     def begin_capture(self):
-        """Optional: start recording a captured backward (``end_capture`` also works without it)."""
+        """Start recording a captured backward (optional without ``capture_collectives``; ``end_capture`` also works
+        without it)."""
         self._capturing = {}
+        self._cap_left = [len(idxs) for _, _, idxs in self.buckets]
+        self._cap_seen = [False] * len(self.opt.params)
+        self._cap_launched = [False] * len(self.buckets)
+
+    def finish_captured(self):
+        """``capture_collectives``: call INSIDE the capture, after the captured backward and before the captured
+        optimizer launch.  Issues the buckets backward did not complete (parameters without a gradient in this graph: their
+        slots are zeroed), joins the communication stream into the capturing stream and returns the flat gradient buffer,
+        which holds the sum over ranks when the graph is replayed.  Nothing is left to do after a replay."""
+        if not self.capture_collectives:
+            raise RuntimeError("finish_captured() needs OverlappedFlatReducer(..., capture_collectives=True)")
+        opt = self.opt
+        if self._active():
+            for b in range(len(self.buckets)):
+                if not self._cap_launched[b]:
+                    self._launch(b, source=self._capturing)
+                    self._cap_launched[b] = True
+            if self.comm is not None:
+                torch.cuda.current_stream(opt.flat_grad.device).wait_stream(self.comm)
+        else:                                   # one rank, no collective: pack from the graph's static tensors
+            for i, p in enumerate(opt.params):
+                slot, g = p._istnet_grad_slot, self._capturing.get(i)
+                if g is None:
+                    slot.zero_()
+                elif g.data_ptr() != slot.data_ptr() or not g.is_contiguous():
+                    opt._view(opt.flat_grad, i).copy_(g)
+        self.works = [None] * len(self.buckets)      # Work handles of captured collectives are not waited on: the join above is the edge
+        return opt.flat_grad
 
     def end_capture(self):
         """Token of the graph captured since the last ``end_capture`` / ``begin_capture``: parameter index -> the
@@ -187,11 +232,11 @@ class OverlappedFlatReducer:
             return self.source[i]
         return self.opt.params[i].grad if self.seen[i] else None
 
-    def _launch(self, b):
+    def _launch(self, b, source=None):
         lo, hi, idxs = self.buckets[b]
         opt = self.opt
         for i in idxs:                     # gradients that did not arrive in place (or not at all) go into their slots
-            slot, g = opt.params[i]._istnet_grad_slot, self._grad_of(i)
+            slot, g = opt.params[i]._istnet_grad_slot, (source.get(i) if source is not None else self._grad_of(i))
             if g is None:
                 slot.zero_()
             elif g.data_ptr() != slot.data_ptr() or not g.is_contiguous():

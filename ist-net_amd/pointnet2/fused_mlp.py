@@ -264,6 +264,7 @@ def _forward_stack(lib, dev, st, b, c0, g, s, x, gather, training, layers, param
         return _forward_stack_compact(lib, dev, st, b, g, s, gather, training, layers, params, out_spec)
     ys, bns = [], []
     cur, cur_c, in_bn = x, c0, None
+    pending = None                   # the last layer's finalize, when the tail takes it over
     # layers whose normalisation is a fixed affine map (conv bias; eval-mode BatchNorm): their constant blocks depend
     # on parameters only -- ONE launch for the whole stack, before its first GEMM, instead of one per layer in the chain
     fixed, fixed_items = {}, []
@@ -339,10 +340,14 @@ def _forward_stack(lib, dev, st, b, c0, g, s, x, gather, training, layers, param
             _native.check(_native.timed(kname, flops, nbytes, lambda: lib.istnet_pw_forward(
                 b, cin_l, cout, p, src.data_ptr(), w2.data_ptr(), sc, sh, y.data_ptr(), ps, pq, st)), "pw_forward")
         if li not in fixed:                  # training-mode BatchNorm: batch statistics of this layer's output
-            _native.check(lib.istnet_bn_finalize_fwd(
-                cout, nt, float(b * p), ps, pq, gamma.data_ptr(), beta.data_ptr(), float(lay.eps),
-                lay.momentum_ptr, _p(lay.running_mean), _p(lay.running_var), bn.data_ptr(), st),
-                "bn_finalize_fwd")
+            if USE_FINALIZE_IN_TAIL and tail and li == len(layers) - 1 and lay.relu:
+                # the stack's tail is a per-channel consumer: it finishes this layer's statistics itself (below)
+                pending = (nt, ps, pq, part, gamma, beta, lay)
+            else:
+                _native.check(lib.istnet_bn_finalize_fwd(
+                    cout, nt, float(b * p), ps, pq, gamma.data_ptr(), beta.data_ptr(), float(lay.eps),
+                    lay.momentum_ptr, _p(lay.running_mean), _p(lay.running_var), bn.data_ptr(), st),
+                    "bn_finalize_fwd")
         ys.append(y)
         bns.append(bn)
         cur, cur_c, in_bn = y, cout, bn
@@ -356,7 +361,13 @@ def _forward_stack(lib, dev, st, b, c0, g, s, x, gather, training, layers, param
         out_ptr, out_bstride = out.data_ptr() + coff * g * 4, out.shape[1] * g
     # arg-max slots (uint8) followed by the raw maxima (f32) in one buffer: see _ymax_ptr
     arg = _empty((_arg_bytes(b * cur_c * g) + 4 * b * cur_c * g,), torch.uint8, dev) if s > 1 else None
-    if s == 1 and not layers[-1].relu:
+    if pending is not None:
+        nt_l, ps_l, pq_l, _, gamma_l, beta_l, lay_l = pending
+        _native.check(lib.istnet_bn_fin_relu_pool(
+            b, cur_c, g, s, nt_l, float(b * p), ps_l, pq_l, gamma_l.data_ptr(), beta_l.data_ptr(), float(lay_l.eps),
+            lay_l.momentum_ptr, _p(lay_l.running_mean), _p(lay_l.running_var), in_bn.data_ptr(), cur.data_ptr(), out_ptr,
+            out_bstride, _p(arg), _ymax_ptr(arg, b * cur_c * g), st), "bn_fin_relu_pool")
+    elif s == 1 and not layers[-1].relu:
         _native.check(lib.istnet_affine_apply(b, cur_c, g, 0, cur.data_ptr(), in_bn.data_ptr(), out.data_ptr(), st),
                       "affine_apply")
         # backward of a ReLU-free last layer: gradient mask "always active" (scale 0, shift 1)
@@ -568,6 +579,7 @@ USE_FUSED_SMALL_BWD = True
 USE_POOLED_FINALIZE = True   # last layer of a scale: pooled statistics + BN-backward finalize in one launch
 USE_FINALIZE_IN_SCATTER = True  # layer 0 of an SA scale: BN-backward finalize inside the inverse-list scatter kernel
 USE_INTERP_IN_EPILOGUE = True   # FP layer 0 (small launches): three_interpolate inside the skip product's epilogue
+USE_FINALIZE_IN_TAIL = os.environ.get("ISTNET_FINALIZE_IN_TAIL", "1") != "0"   # forward: a stack's last finalize inside its pool / apply launch
 USE_DENSE_FINALIZE = True    # last layer of an FP / head stack (dense gradient, <= 65 536 points): the same
 USE_FUSED_MID_BWD = True     # 64 / 128-channel layers: dgrad + wgrad + statistics in one pass (pw_bwd_mid_kernel)
 USE_SPLIT_LAYER0 = True
@@ -1234,11 +1246,15 @@ class FusedFPFunction(Function):
     known_feats (B, C2, m), skip (B, C1, n) or None, idx / weight (B, n, 3), csr = _ext.interp_csr(idx, m) or None."""
 
     @staticmethod
-    def forward(ctx, known_feats, skip, idx, weight, csr, training, layers, *params):
+    def forward(ctx, known_feats, skip, idx, weight, csr, training, layers, known_bn, lazy_out, *params):
+        # known_bn: None, or the BatchNorm constant block (4, C2) of the stack that produced ``known_feats`` as its RAW last
+        #   output (a LazyAct): the loaders of the products over the known points apply relu(scale y + shift) themselves;
+        # lazy_out: return (raw last output, its constant block) instead of the activated tensor (see LazyAct)
         from . import _ext
         lib = _native.lib()
         dev = known_feats.device
         known = known_feats.contiguous()
+        ksc, ksh = (known_bn[0].data_ptr(), known_bn[1].data_ptr()) if known_bn is not None else (None, None)
         skip_c = skip.contiguous() if skip is not None else None
         b, c2, m = known.shape
         n = idx.shape[1]
@@ -1253,7 +1269,7 @@ class FusedFPFunction(Function):
             _native.check(_native.timed(
                 _fwd_ld_kname(lib, b, c2, cout0, m), 2.0 * b * m * c2 * cout0,
                 4.0 * b * m * (c2 + cout0), lambda: lib.istnet_pw_forward_ld(
-                    b, c2, cout0, m, known.data_ptr(), w2.data_ptr(), cin, None, None, zk.data_ptr(), None, None,
+                    b, c2, cout0, m, known.data_ptr(), w2.data_ptr(), cin, ksc, ksh, zk.data_ptr(), None, None,
                     st)), "pw_forward_ld(fp)")
             fuse_interp = (skip_c is not None and USE_INTERP_IN_EPILOGUE and lib.istnet_pw_forward_cfg(b, c1, cout0, n) == 1
                            and idx.dtype == torch.int32 and idx.is_contiguous() and weight.is_contiguous())
@@ -1299,22 +1315,27 @@ class FusedFPFunction(Function):
                                                        lay0.running_mean.data_ptr(), lay0.running_var.data_ptr(),
                                                        float(lay0.eps), bn0.data_ptr(), st), "affine_consts")
             out, _, ys, bns = _forward_stack(lib, dev, st, b, cin, n, 1, None, None, training, layers, params,
-                                             start=(y0, bn0))
+                                             start=(y0, bn0), tail=not lazy_out)
         ctx.training, ctx.dims, ctx.n_layers, ctx.has_skip, ctx.csr = training, (b, c2, c1, m, n), len(layers), \
             skip_c is not None, csr
+        ctx.has_known_bn = known_bn is not None
         ctx.save_for_backward(known, skip_c if skip_c is not None else torch.empty(0, device=dev), idx, weight,
-                              *ys, *bns, *params)
+                              known_bn if known_bn is not None else torch.empty(0, device=dev), *ys, *bns, *params)
+        if lazy_out:
+            ctx.mark_non_differentiable(bns[-1])
+            return ys[-1], bns[-1]
         return out
 
     @staticmethod
-    def backward(ctx, dout):
+    def backward(ctx, dout, *_unused):
         from . import _ext
         lib = _native.lib()
         b, c2, c1, m, n = ctx.dims
         nl = ctx.n_layers
         sv = ctx.saved_tensors
         known, skip, idx, weight = sv[0], (sv[1] if ctx.has_skip else None), sv[2], sv[3]
-        ys, bns, params = sv[4:4 + nl], sv[4 + nl:4 + 2 * nl], sv[4 + 2 * nl:]
+        known_bn = sv[4] if ctx.has_known_bn else None
+        ys, bns, params = sv[5:5 + nl], sv[5 + nl:5 + 2 * nl], sv[5 + 2 * nl:]
         dev = known.device
         _enter_backward(dev)
         cin = c2 + c1
@@ -1323,15 +1344,23 @@ class FusedFPFunction(Function):
         w2 = w0.reshape(cout0, cin)
         _native.mark(f"bwd FP(n={n}) start")
         need_known, need_skip = ctx.needs_input_grad[0], ctx.has_skip and ctx.needs_input_grad[1]
-        need_w = [ctx.needs_input_grad[7 + 3 * li] for li in range(nl)]
+        need_w = [ctx.needs_input_grad[9 + 3 * li] for li in range(nl)]
         result = {}
 
         def layer0(y0, d_a0, bn0, bwdc0, grads, wextra):
             st = _st(dev)
             ident, ibw = _ident_consts(dev, cout0)          # mask always on, dY = g: products of a given dY
-            dy0 = _empty((b, cout0, n), torch.float32, dev)
-            _native.check(lib.istnet_pw_dy(b, cout0, n, y0.data_ptr(), d_a0.data_ptr(), bn0.data_ptr(),
-                                           bwdc0.data_ptr(), dy0.data_ptr(), st), "pw_dy")
+            # dY0 = BatchNorm / ReLU backward of dA0.  With the inverse lists of the taps at hand nobody needs it as a
+            # tensor: the interpolation gradient forms it per gathered element (istnet_interp_grad_csr_dy) and the GEMM
+            # loaders form it from (y0, dA0, constants) as they do in every other layer -- one launch less on the chain.
+            raw_pair = USE_FP_RAW_DY and ctx.csr is not None
+            if raw_pair:
+                dy_y, dy_d, dy_bn, dy_bw = y0, d_a0, bn0, bwdc0
+            else:
+                dy0 = _empty((b, cout0, n), torch.float32, dev)
+                _native.check(lib.istnet_pw_dy(b, cout0, n, y0.data_ptr(), d_a0.data_ptr(), bn0.data_ptr(),
+                                               bwdc0.data_ptr(), dy0.data_ptr(), st), "pw_dy")
+                dy_y, dy_d, dy_bn, dy_bw = dy0, dy0, ident, ibw
             # The skip gradient feeds the set-abstraction backward much later; the interpolation gradient feeds the next
             # (coarser) propagation level at once.  So the skip dgrad leaves the chain: it runs on a side stream beside
             # the interpolation scatter and the known-feature dgrad, joined before this node returns.
@@ -1344,14 +1373,20 @@ class FusedFPFunction(Function):
                     _native.check(_native.timed(
                         _dgrad_kname(lib, b, c1, cout0, n, dense=True), 2.0 * b * n * c1 * cout0,
                         4.0 * b * n * (c1 + cout0), lambda: lib.istnet_pw_dgrad(
-                            b, cin, c2, c1, cout0, n, 0, w2.data_ptr(), dy0.data_ptr(), dy0.data_ptr(), None, 0, None,
-                            ident.data_ptr(), ibw.data_ptr(), ds.data_ptr(), None, None, None, None, sst)),
+                            b, cin, c2, c1, cout0, n, 0, w2.data_ptr(), dy_y.data_ptr(), dy_d.data_ptr(), None, 0, None,
+                            dy_bn.data_ptr(), dy_bw.data_ptr(), ds.data_ptr(), None, None, None, None, sst)),
                         "pw_dgrad(fp skip)")
                 result["dskip"] = ds
             gk = None
             if need_known or need_w[0]:
-                gk = (_ext.three_interpolate_grad(dy0, idx, weight, m, ctx.csr) if ctx.csr is not None
-                      else _ext.three_interpolate_grad(dy0, idx, weight, m))                       # (B, cout0, m)
+                if raw_pair:
+                    gk = _empty((b, cout0, m), torch.float32, dev)                                  # (B, cout0, m)
+                    _native.check(lib.istnet_interp_grad_csr_dy(
+                        b, cout0, n, m, y0.data_ptr(), d_a0.data_ptr(), bn0.data_ptr(), bwdc0.data_ptr(), weight.data_ptr(),
+                        ctx.csr[0].data_ptr(), ctx.csr[1].data_ptr(), gk.data_ptr(), st), "interp_grad_csr_dy")
+                else:
+                    gk = (_ext.three_interpolate_grad(dy0, idx, weight, m, ctx.csr) if ctx.csr is not None
+                          else _ext.three_interpolate_grad(dy0, idx, weight, m))
             if need_known:
                 dk = _empty((b, c2, m), torch.float32, dev)
                 _native.check(_native.timed(
@@ -1364,6 +1399,7 @@ class FusedFPFunction(Function):
             if need_w[0]:
                 dest = _grad_dest(w0, (cout0, cin), dev)
                 grads[0] = dest.view_as(w0)
+                ksc, ksh = (known_bn[0].data_ptr(), known_bn[1].data_ptr()) if known_bn is not None else (None, None)
 
                 def wjob(wst):
                     sp_a = lib.istnet_pw_wgrad_splits(b, c2, cout0, m)
@@ -1371,7 +1407,7 @@ class FusedFPFunction(Function):
                     _native.check(_native.timed(
                         _kname("pw_wgrad_kernel", lib.istnet_pw_wgrad_tile_cfg(b, c2, cout0, m), 0),
                         2.0 * b * m * c2 * cout0, 4.0 * b * m * (c2 + cout0), lambda: lib.istnet_pw_wgrad(
-                            b, c2, cout0, m, 0, known.data_ptr(), None, None, gk.data_ptr(), gk.data_ptr(), None, 0,
+                            b, c2, cout0, m, 0, known.data_ptr(), ksc, ksh, gk.data_ptr(), gk.data_ptr(), None, 0,
                             None, ident.data_ptr(), ibw.data_ptr(), ws_a.data_ptr(), wst)), "pw_wgrad(fp known)")
                     red = [(cout0 * c2, sp_a, ws_a.data_ptr(), dest.data_ptr(), c2, cin, cout0 * c2)]
                     keep = [ws_a]
@@ -1381,12 +1417,12 @@ class FusedFPFunction(Function):
                         _native.check(_native.timed(
                             _kname("pw_wgrad_kernel", lib.istnet_pw_wgrad_tile_cfg(b, c1, cout0, n), 0),
                             2.0 * b * n * c1 * cout0, 4.0 * b * n * (c1 + cout0), lambda: lib.istnet_pw_wgrad(
-                                b, c1, cout0, n, 0, skip.data_ptr(), None, None, dy0.data_ptr(), dy0.data_ptr(), None,
-                                0, None, ident.data_ptr(), ibw.data_ptr(), ws_b.data_ptr(), wst)), "pw_wgrad(fp skip)")
+                                b, c1, cout0, n, 0, skip.data_ptr(), None, None, dy_y.data_ptr(), dy_d.data_ptr(), None,
+                                0, None, dy_bn.data_ptr(), dy_bw.data_ptr(), ws_b.data_ptr(), wst)), "pw_wgrad(fp skip)")
                         red.append((cout0 * c1, sp_b, ws_b.data_ptr(), dest.data_ptr() + 4 * c2, c1, cin, cout0 * c1))
                         keep += [ws_b]
                     _native.reduce_multi(red, wst)     # both column blocks of dW0 in place: no concatenation
-                    return keep, dy0, gk
+                    return keep, dy_y, dy_d, dy_bn, dy_bw, gk, known_bn
                 wextra.append(wjob)
             _join_streams(streams)
             return None
@@ -1395,12 +1431,47 @@ class FusedFPFunction(Function):
             grads, _, _ = _backward_stack(lib, dev, _st(dev), b, cin, n, 1, None, None, ctx.training, ys, bns, params,
                                           None, dout.contiguous(), need_w, True, layer0_hook=layer0)
             _native.mark(f"bwd FP(n={n}) chain done")
-        return (result.get("dknown"), result.get("dskip"), None, None, None, None, None, *grads)
+        return (result.get("dknown"), result.get("dskip"), None, None, None, None, None, None, None, *grads)
 
 
-def fp_level(mlp, known_feats, skip, idx, weight, csr=None):
+class LazyAct:
+    """The output of a fused stack BEFORE its last BatchNorm + ReLU: ``raw`` (B, C, n) and the constant block ``bn``
+    (4, C: scale, shift, mean, invstd).  Consumers that stage their operands through a loader (the products over the known
+    points of the next feature-propagation level) apply relu(scale y + shift) there, so the activated tensor is never
+    written or read back and its launch leaves the forward chain.  In the autograd graph ``raw`` STANDS FOR the activated
+    values: the gradient that reaches it is the gradient with respect to relu(bn(raw)) -- exactly what the producing
+    node's backward expects.  ``materialize()`` gives the activated tensor to a consumer that needs one."""
+    __slots__ = ("raw", "bn")
+
+    def __init__(self, raw, bn):
+        self.raw, self.bn = raw, bn
+
+    def materialize(self):
+        return _MaterializeFn.apply(self.raw, self.bn)
+
+
+class _MaterializeFn(Function):
+    @staticmethod
+    def forward(ctx, raw, bn):
+        lib = _native.lib()
+        b, c, n = raw.shape
+        out = _empty((b, c, n), torch.float32, raw.device)
+        with torch.cuda.device(raw.device):
+            _native.check(lib.istnet_bn_relu_pool(b, c, n, 1, raw.data_ptr(), bn.data_ptr(), out.data_ptr(), 0, None, None,
+                                                  _st(raw.device)), "bn_relu_pool")
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        return dout, None          # raw stands for the activated values (see LazyAct)
+
+
+def fp_level(mlp, known_feats, skip, idx, weight, csr=None, lazy_out=False):
     """``mlp(cat([three_interpolate(known_feats, idx, weight), skip], 1).unsqueeze(-1)).squeeze(-1)`` through the
     fused node when shapes allow; None otherwise (the caller then runs the reference composition)."""
+    known_bn = None
+    if isinstance(known_feats, LazyAct):
+        known_feats, known_bn = known_feats.raw, known_feats.bn
     if not (USE_FUSED_FP and known_feats.is_cuda and known_feats.dtype == torch.float32):
         return None
     n, m = idx.shape[1], known_feats.shape[2]
@@ -1412,13 +1483,15 @@ def fp_level(mlp, known_feats, skip, idx, weight, csr=None):
                        "channels % 4 == 0 and a plain conv1x1/BatchNorm/ReLU stack")
         return None
     layers, params = _layer_args(mlp)
-    out = FusedFPFunction.apply(known_feats, skip, idx, weight, csr, mlp.training, layers, *params)
+    out = FusedFPFunction.apply(known_feats, skip, idx, weight, csr, mlp.training, layers, known_bn, bool(lazy_out), *params)
     if mlp.training:
         _bump_counters(list(mlp))
-    return out
+    return LazyAct(*out) if lazy_out else out
 
 
 USE_FUSED_FP = True
+USE_FP_RAW_DY = os.environ.get("ISTNET_FP_RAW_DY", "1") != "0"       # feature-propagation backward: no materialised dY0 (one launch less per level)
+USE_LAZY_FP = os.environ.get("ISTNET_LAZY_FP", "1") != "0"           # encoder: FP levels 4..2 hand their RAW output + constants to the next level
 USE_FP_SKIP_STREAM = os.environ.get("ISTNET_FP_SKIP_STREAM", "1") != "0"     # feature-propagation backward: skip-branch dgrad on a side stream (off the chain)
 _ONES = {}
 

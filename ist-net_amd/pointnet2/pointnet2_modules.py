@@ -13,7 +13,7 @@ import torch
 import torch.nn as nn
 
 from . import pointnet2_utils, pytorch_utils
-from .fused_mlp import fp_level, sa_level, shared_mlp_maxpool
+from .fused_mlp import LazyAct, fp_level, sa_level, shared_mlp_maxpool
 
 
 class _PointnetSAModuleBase(nn.Module):
@@ -121,17 +121,24 @@ class PointnetFPModule(nn.Module):
             return idx, weight, (interp_csr(idx, known.size(1)) if interp_csr is not None and idx.is_cuda else None)
         return idx, weight
 
-    def forward(self, unknown, known, unknow_feats, known_feats, interp=None):
+    def forward(self, unknown, known, unknow_feats, known_feats, interp=None, lazy_out=False):
         """unknown (B,n,3), known (B,m,3), unknow_feats (B,C1,n) or None, known_feats (B,C2,m)
-        -> (B, mlp[-1], n).  ``interp`` = precomputed (idx, weight) of interpolation_weights()."""
+        -> (B, mlp[-1], n).  ``interp`` = precomputed (idx, weight) of interpolation_weights().
+        Extensions used by PointNet2MSG between its own levels: ``known_feats`` may be a fused_mlp.LazyAct (the previous
+        level's raw output + BatchNorm constants), and ``lazy_out`` asks for one back when the fused node runs."""
+        lazy_in = isinstance(known_feats, LazyAct)
         if known is None:
+            if lazy_in:
+                known_feats = known_feats.materialize()
             interpolated = known_feats.expand(*known_feats.size()[0:2], unknown.size(1))
         else:
             idx, weight, *csr = interp if interp is not None else self.interpolation_weights(unknown, known)
             fused = fp_level(self.mlp, known_feats, unknow_feats, idx.detach(), weight.detach(),
-                             csr[0] if csr else None)
+                             csr[0] if csr else None, lazy_out=lazy_out)
             if fused is not None:        # interpolation + concat + SharedMLP as one node (layer 0 split by linearity)
                 return fused
+            if lazy_in:
+                known_feats = known_feats.materialize()
             if csr and csr[0] is not None:
                 interpolated = pointnet2_utils.three_interpolate(known_feats, idx.detach(), weight.detach(), csr[0])
             else:

@@ -144,7 +144,7 @@ def test_training_steps_are_bit_reproducible():
     assert torch.equal(a, b), float((a - b).abs().max())
 
 
-@pytest.mark.parametrize("switch", ["USE_DEFERRED_WGRAD", "USE_SCALE_STREAMS", "USE_FUSED_SMALL_BWD", "USE_FUSED_MID_BWD", "USE_POOLED_FINALIZE", "USE_DENSE_FINALIZE", "USE_INTERP_IN_EPILOGUE", "USE_FINALIZE_IN_SCATTER", "USE_SPLIT_LAYER0", "USE_FP_SKIP_STREAM",
+@pytest.mark.parametrize("switch", ["USE_DEFERRED_WGRAD", "USE_SCALE_STREAMS", "USE_FUSED_SMALL_BWD", "USE_FUSED_MID_BWD", "USE_POOLED_FINALIZE", "USE_DENSE_FINALIZE", "USE_INTERP_IN_EPILOGUE", "USE_FINALIZE_IN_SCATTER", "USE_FINALIZE_IN_TAIL", "USE_FP_RAW_DY", "USE_LAZY_FP", "USE_SPLIT_LAYER0", "USE_FP_SKIP_STREAM",
                                     "USE_CSR_SCATTER", "USE_FUSED_FP", "USE_GEOMETRY_STREAM", "USE_FPS_CHAIN", "USE_FUSED_NN_WEIGHTS", "COMPACT_LEVELS=", "COMPACT_LEVELS=0,1,2"])
 def test_fallback_paths_agree_with_default(switch):
     """Every module-level switch of the fused path selects code that a caller can reach (fallbacks and measured
@@ -398,3 +398,36 @@ def test_momentum_change_inside_capture_is_refused():
         sa(xyz, feats)
     graph.replay()
     torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("switch", ["USE_FINALIZE_IN_TAIL", "USE_FP_RAW_DY", "USE_LAZY_FP"])
+def test_chain_shortening_fusions_are_bit_identical(switch):
+    """Round 4 took three launches per level off the dependent chain without touching the arithmetic: the last BatchNorm
+    finalize of a stack runs inside its pool / apply launch, the feature-propagation backward gathers dY0 from the raw
+    pair instead of a materialised tensor, and levels 3..1 of the feature propagation hand their RAW output + constants
+    to the next level's loaders.  Each must reproduce the unfused step bit for bit: output, every parameter gradient and
+    every BatchNorm buffer after one training step."""
+    from istnet_amd.pointnet2 import fused_mlp
+    g = torch.Generator().manual_seed(17)
+    d = torch.randn(3, 1024, 3, generator=g)
+    pts = (d / d.norm(dim=2, keepdim=True) * 0.1 + torch.randn(3, 1024, 3, generator=g) * 0.002).to(DEV)
+
+    def run():
+        torch.manual_seed(8)
+        enc = PointNet2MSG(CAM).to(DEV).train()
+        out = enc(pts)
+        (out * torch.linspace(-1, 1, out.shape[2], device=DEV)).sum().backward()
+        torch.cuda.synchronize()
+        return out.detach().clone(), [p.grad.clone() for p in enc.parameters()], [b.clone() for b in enc.buffers()]
+
+    base = run()
+    saved = getattr(fused_mlp, switch)
+    try:
+        setattr(fused_mlp, switch, False)
+        other = run()
+    finally:
+        setattr(fused_mlp, switch, saved)
+    assert saved is True
+    assert torch.equal(base[0], other[0])
+    for a, b in zip(base[1] + base[2], other[1] + other[2]):
+        assert torch.equal(a, b)

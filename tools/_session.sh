@@ -1,3 +1,2 @@
-mkdir -p gpurun_out/r4c
-python -m pytest tests -m gpu -x -q 2>&1 | grep -v "Warn\|warn" | tail -30 > gpurun_out/r4c/test.txt; grep -n "Error\|^E \|passed\|failed" gpurun_out/r4c/test.txt | head -20
-python bench.py --no-roofline --no-cpu-baseline --steps 50 --warmup 10 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('bench', d['ms_per_step'], (d.get('unpipelined') or {}).get('ms_per_step'))"
+mkdir -p gpurun_out/r4e
+python -m pytest tests -m gpu -q 2>&1 | grep -v "Warning:\|warnings.warn\|amdgpu.ids\|shared_mlp_maxpool\|^$\|^tests/" | tail -40 > gpurun_out/r4e/test.txt; grep -n "Error\|^E \|passed\|failed\|FAILED" gpurun_out/r4e/test.txt | head -30

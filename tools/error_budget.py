@@ -52,6 +52,8 @@ def run_levels(enc, pts, capture_inputs=False):
 
             def hook(mod, args, kwargs, out, name=name):
                 feat = out[1] if isinstance(out, tuple) else out
+                if isinstance(feat, fused_mlp.LazyAct):      # levels 3..1 of the feature propagation hand on raw output + constants
+                    feat = feat.materialize()
                 outs.append((name, feat.detach()))
                 if capture_inputs:
                     ins.append((name, args, kwargs))
