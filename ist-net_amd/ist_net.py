@@ -16,6 +16,7 @@ import os
 import torch
 import torch.nn as nn
 
+from . import modules as enc_modules
 from .modules import PointNet2MSG
 from .pointnet2.fused_mlp import pointwise_conv_stack as _run
 from .pointnet2.fused_mlp import pointwise_conv_stack_multi as _run_multi
@@ -277,8 +278,17 @@ class IST_Net(nn.Module):
                 ws = _world_stream(pts.device)
                 ws.wait_stream(cur)
                 inputs["qo"].record_stream(ws)
-                with torch.cuda.stream(ws):
-                    pts_w_local_gt = self.world_enhancer.extractor(inputs["qo"])
+                # No geometry side stream inside this forked stream: a stream forked from a FORKED stream and joined back
+                # into it (a diamond on a non-origin stream) makes hipStreamEndCapture segfault on this stack
+                # (tools/exp/capture_nested_fork.py: nested_join_parent dies, the same diamond on the origin stream or a
+                # join into the origin only is fine).  The pre-pass then runs in line on `ws`, which is itself beside
+                # the main stream's work.
+                saved_geo, enc_modules.USE_GEOMETRY_STREAM = enc_modules.USE_GEOMETRY_STREAM, False
+                try:
+                    with torch.cuda.stream(ws):
+                        pts_w_local_gt = self.world_enhancer.extractor(inputs["qo"])
+                finally:
+                    enc_modules.USE_GEOMETRY_STREAM = saved_geo
                 self._world_join = (cur, ws)
             else:
                 pts_w_local_gt = self.world_enhancer.extractor(inputs["qo"])

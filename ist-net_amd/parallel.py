@@ -162,7 +162,7 @@ class OverlappedFlatReducer:
     def _make_hook(self, i):
         def hook(param):
             b = self.bucket_of[i]
-            if param.is_cuda and torch.cuda.is_current_stream_capturing():
+            if self._in_capture(param):
                 # captured backward: remember the static tensor this graph writes the gradient to
                 self._capturing[i] = param.grad
                 if self.capture_collectives and self._active() and not self._cap_seen[i]:
@@ -187,6 +187,11 @@ class OverlappedFlatReducer:
 
     _capturing = None
 
+    @staticmethod
+    def _in_capture(param):
+        """Is this hook running inside a HIP-graph capture?  (A method so that the CPU tests can stand in for one.)"""
+        return param.is_cuda and torch.cuda.is_current_stream_capturing()
+
     def begin_capture(self):
         """Start recording a captured backward (optional without ``capture_collectives``; ``end_capture`` also works
         without it)."""
@@ -210,6 +215,10 @@ class OverlappedFlatReducer:
                     self._cap_launched[b] = True
             if self.comm is not None:
                 torch.cuda.current_stream(opt.flat_grad.device).wait_stream(self.comm)
+            else:                               # CPU tensors (gloo tests): no streams, wait on the handles
+                for w in self.works:
+                    if w is not None:
+                        w.wait()
         else:                                   # one rank, no collective: pack from the graph's static tensors
             for i, p in enumerate(opt.params):
                 slot, g = p._istnet_grad_slot, self._capturing.get(i)

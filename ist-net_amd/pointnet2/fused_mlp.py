@@ -160,11 +160,16 @@ class _Deferred:
 
     @classmethod
     def flush(cls):
+        """End-of-backward callback.  The engine runs it on the AMBIENT stream of the backward() call, after it has
+        joined every leaf stream into that stream -- so that is the stream to join the wgrad stream into.  (Joining into
+        the stream of the first fused node that ran, as rounds 1-3 did, is the same thing while every node runs on the
+        ambient stream; when that node ran on a forked stream the join landed on a stream the engine had already joined,
+        and a capture ended with unjoined work: tools/exp/capture_fork_autograd.py, variant cb_first.)"""
         for (key, _), wstream in cls.streams.items():
             if key in cls.mains:
                 with torch.cuda.stream(wstream):
                     _native.mark("wgrad stream drained")
-                cls.mains[key].wait_stream(wstream)
+                torch.cuda.current_stream(wstream.device).wait_stream(wstream)
         cls.mains.clear()
         cls.keep.clear()
         cls.armed = False

@@ -229,6 +229,29 @@ def _reducer_validity_worker(rank, world, port, out):
     _local_grads_keep(model2, rank)
     flat2 = red2.finish()
     ok = ok and torch.allclose(flat2, 2.0 * want_flat, rtol=1e-5, atol=1e-7)
+    # (d) capture_collectives: a backward pass that is being captured issues its buckets from the hooks (they become graph
+    # nodes on the GPU); finish_captured() issues the rest (the unused parameter's bucket), joins, returns the summed buffer.
+    # No HIP graph on CPU: the hook's capture test is stood in for, the collectives run as they are issued.
+    model3 = _make(seed=0)
+    extra3 = torch.nn.Parameter(torch.ones(5))                # never used: no hook fires, its slot must come back zero
+    opt3 = FlatAdam(list(model3.parameters()) + [extra3], lr=1e-2)
+    red3 = OverlappedFlatReducer(opt3, world, bucket_bytes=1024, capture_collectives=True)
+    red3._in_capture = lambda param: True
+    red3.begin_capture()
+    opt3.zero_grad(set_to_none=True)
+    _local_grads_keep(model3, rank)
+    launched_in_backward = sum(red3._cap_launched)
+    flat3 = red3.finish_captured().clone()
+    token3 = red3.end_capture()
+    ok = ok and launched_in_backward == len(red3.buckets) - 1 and len(token3) == len(opt3.params) - 1
+    ok = ok and torch.allclose(flat3[:want_flat.numel()], want_flat, rtol=1e-5, atol=1e-7)
+    ok = ok and bool((flat3[want_flat.numel():] == 0).all())
+    raised = False
+    try:
+        OverlappedFlatReducer(FlatAdam(_make(0).parameters(), lr=1e-2), world).finish_captured()
+    except RuntimeError as exc:
+        raised = "capture_collectives" in str(exc)
+    ok = ok and raised
     out[rank] = bool(ok)
     dist.barrier()
     dist.destroy_process_group()
@@ -268,7 +291,8 @@ def test_bench_self_launches_n_ranks():
     """``python bench.py --gpus 2 ...`` (the driver's N=1 command form with N=2, no launcher, WORLD_SIZE unset)
     spawns its own two ranks and rank 0 prints the one JSON line.  --cpu-dry-run keeps the control flow of the GPU
     run (rendezvous, flat-gradient all-reduce, barriers, max-over-ranks timing) on host cores."""
-    res = _run_bench(["bench.py", "--gpus", "2", "--steps", "2", "--warmup", "1", "--cpu-dry-run"])
+    res = _run_bench(["bench.py", "--gpus", "2", "--steps", "2", "--warmup", "1", "--cpu-dry-run", "--capture-allreduce"])
+    # (--capture-allreduce: the flag of the in-graph exchange; a CPU dry run has no graph, the eager form must still run)
     assert res["n_gpus"] == 2 and res["steps"] == 2 and res["warmup"] == 1
     assert res["config"]["parallelism"] == "dp2" and res["scaling"] == "weak"
     assert res["config"]["global_batch"] == 2 * res["config"]["batch_per_gpu"]
