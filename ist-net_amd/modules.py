@@ -24,6 +24,10 @@ USE_GEOMETRY_STREAM = os.environ.get("ISTNET_GEOMETRY_STREAM", "1") != "0"
 # arg-max tie occurred in the parent's first m rounds: the parent run reports its first tied round and the children
 # skip their scan (include/istnet_pn2.h, istnet_pn2_fps_gather_chain).  Bit-identical to sampling every level.
 USE_FPS_CHAIN = True
+# Largest cloud whose sampling run keeps the tie bookkeeping its child needs.  Measured (profiles/r04_fps_chain.txt): with the
+# encoder's own sizes the full chain wins at n = 2048 too (B = 64: 466 us every level scanned, 421 us chained from level 2
+# on, 367 us chained throughout; config 5 end to end 18.46 -> 18.40 ms), so the default keeps every level tracked.
+FPS_CHAIN_MAX_TRACKED_N = int(os.environ.get("ISTNET_FPS_TRACK_MAX_N", "4096"))
 _GEOMETRY_STREAMS = {}
 
 
@@ -106,7 +110,9 @@ class PointNet2MSG(nn.Module):
             for li, sa in enumerate(self.SA_modules):
                 if chain is not None and cur.shape[1] <= 4096:
                     nxt = self.SA_modules[li + 1].npoint if li + 1 < len(self.SA_modules) else 0
-                    _, new_xyz, tie = chain(cur, sa.npoint, tie_in=tie, track_rounds=min(nxt or 0, sa.npoint))
+                    # above FPS_CHAIN_MAX_TRACKED_N points a level scans without the tie bookkeeping (and its child scans too)
+                    rounds = min(nxt or 0, sa.npoint) if cur.shape[1] <= FPS_CHAIN_MAX_TRACKED_N else 0
+                    _, new_xyz, tie = chain(cur, sa.npoint, tie_in=tie, track_rounds=rounds)
                 else:
                     new_xyz, tie = sa._sample_centroids(cur), None
                 idx = [pointnet2_utils.ball_query(g.radius, g.nsample, cur, new_xyz) for g in sa.groupers]

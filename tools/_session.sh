@@ -1,1 +1,5 @@
-for v in 0 1 0 1; do echo -n "WORLD_EXTRACTOR_STREAM=$v: "; ISTNET_WORLD_EXTRACTOR_STREAM=$v timeout 300 python bench.py --workload istnet --no-roofline --steps 20 --warmup 5 2>gpurun_out/world.err | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['ms_per_step'], d['config']['launch'])" || tail -3 gpurun_out/world.err; done
+mkdir -p gpurun_out/r4h
+python tools/bench_fps_chain.py 2>&1 | grep -v amdgpu.ids | tee gpurun_out/r4h/fps_chain.txt
+for v in 1024 4096; do echo -n "infer ISTNET_FPS_TRACK_MAX_N=$v: "; ISTNET_FPS_TRACK_MAX_N=$v python bench.py --workload infer --no-roofline --steps 30 --warmup 5 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(round(d['ms_per_step'],3))"; done
+for v in 1024 4096; do echo -n "infer ISTNET_FPS_TRACK_MAX_N=$v: "; ISTNET_FPS_TRACK_MAX_N=$v python bench.py --workload infer --no-roofline --steps 30 --warmup 5 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(round(d['ms_per_step'],3))"; done
+python -m pytest tests/test_ops_gpu.py tests/test_golden_gpu.py -m gpu -q -k "fps or chain or config5 or infer" 2>&1 | tail -2

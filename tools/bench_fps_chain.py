@@ -17,11 +17,15 @@ def run_plain(xyz):
     return cur
 
 
-def run_chain(xyz, track=True):
+def run_chain(xyz, track=True, track_from=0):
+    """track_from: first level (0-based) whose run reports ties -- earlier levels scan without the bookkeeping and their
+    children scan too (modules.FPS_CHAIN_MAX_TRACKED_N: above 1 024 points the 4-wave kernel pays more for the tracking
+    than the level below saves)."""
     cur, tie = xyz, None
     for li, m in enumerate(LEVELS):
         nxt = LEVELS[li + 1] if li + 1 < len(LEVELS) else 0
-        _, cur, tie = _ext.furthest_point_sampling_chain(cur, m, tie_in=tie, track_rounds=min(nxt, m) if track else 0)
+        rounds = min(nxt, m) if (track and li >= track_from) else 0
+        _, cur, tie = _ext.furthest_point_sampling_chain(cur, m, tie_in=tie, track_rounds=rounds)
     return cur, tie
 
 
@@ -44,8 +48,12 @@ for n, b in ((1024, 32), (2048, 64)):
     c, _ = run_chain(xyz)
     assert torch.equal(a, c)
     _, _, tie = _ext.furthest_point_sampling_chain(xyz, LEVELS[0], None, LEVELS[1])     # level 1's own report
+    c1, _ = run_chain(xyz, track_from=1)
+    assert torch.equal(a, c1)
     print(f"n={n} b={b}: every level scanned {timeit(lambda: run_plain(xyz)):.1f} us, chained {timeit(lambda: run_chain(xyz)):.1f} us, "
-          f"level 1 alone plain {timeit(lambda: _ext.furthest_point_sampling_gather(xyz, n // 2)):.1f} us / tracking "
-          f"{n // 4} rounds {timeit(lambda: _ext.furthest_point_sampling_chain(xyz, n // 2, None, n // 4)):.1f} us / tracking all "
-          f"{timeit(lambda: _ext.furthest_point_sampling_chain(xyz, n // 2, None, n // 2)):.1f} us; level-1 clouds with an arg-max tie before round {LEVELS[1]}: "
+          f"chained from level 2 on (level 1 untracked) {timeit(lambda: run_chain(xyz, track_from=1)):.1f} us, "
+          f"level 1 alone (the encoder's {LEVELS[0]} of {n}) plain {timeit(lambda: _ext.furthest_point_sampling_gather(xyz, LEVELS[0])):.1f} us / tracking "
+          f"{LEVELS[1]} rounds {timeit(lambda: _ext.furthest_point_sampling_chain(xyz, LEVELS[0], None, LEVELS[1])):.1f} us; "
+          f"(a run of {n // 2} of {n}: plain {timeit(lambda: _ext.furthest_point_sampling_gather(xyz, n // 2)):.1f} us / tracking {n // 4} rounds "
+          f"{timeit(lambda: _ext.furthest_point_sampling_chain(xyz, n // 2, None, n // 4)):.1f} us); level-1 clouds with an arg-max tie before round {LEVELS[1]}: "
           f"{int((tie.cpu() < LEVELS[1]).sum())} of {b}")
