@@ -97,15 +97,18 @@ def test_native_decoder_backward_equals_framework_backward():
             grads.append((out.detach().clone(), {k: p.grad.clone() for k, p in net.named_parameters() if p.grad is not None}))   # (avgpool / fc of the trunk are unused)
         finally:
             rgb_branch.USE_NATIVE_DECODER_BACKWARD = True
-    torch.testing.assert_close(grads[0][0], grads[1][0], rtol=1e-3, atol=1e-3)   # (MIOpen may pick another algorithm on the second pass)
+    # budget (profiles/r04_rgb_gradient_budget.txt, tools/rgb_gradient_budget.py): output native vs framework 4.9e-6 relative,
+    # the framework against its own rerun 4.0e-6
+    assert float((grads[0][0] - grads[1][0]).norm() / grads[1][0].norm()) < 1e-4
     assert len(grads[0][1]) == len(grads[1][1]) > 60
     worst = max(((float((grads[0][1][k] - grads[1][1][k]).norm() / (grads[1][1][k].norm() + 1e-12)), k) for k in grads[0][1]))
     # conv biases in front of a train-mode BatchNorm have a mathematically zero gradient (round-off only): not compared
     rel = {k: float((grads[0][1][k] - grads[1][1][k]).norm() / (grads[1][1][k].norm() + 1e-12)) for k in grads[0][1]
            if not (k.endswith(".bias") and float(grads[1][1][k].norm()) < 1e-4)}
-    # wiring-level bound: MIOpen may pick other (non-deterministic) algorithms on the second pass and the B=2 train-mode
-    # BatchNorms amplify round-off; the op-level tests above hold the kernels themselves to 1e-5
-    assert max(rel.values()) < 2e-2, (worst, sorted(rel.items(), key=lambda kv: -kv[1])[:5])
+    # budget table (same file): over all 100+ parameter gradients the native path sits 1.5e-4 .. 4.3e-4 from the framework's,
+    # which is where the framework sits from ITS OWN rerun (1.6e-4 .. 4.2e-4: MIOpen picks algorithms per call and the B=2
+    # train-mode BatchNorms amplify round-off).  Bound = 5x the measured worst; the op-level tests hold the kernels to 1e-5.
+    assert max(rel.values()) < 2e-3, (worst, sorted(rel.items(), key=lambda kv: -kv[1])[:5])
 
 
 @pytest.mark.parametrize("b,c,cout,h", [(2, 32, 48, 24), (3, 16, 8, 12), (1, 8, 8, 7)])
@@ -265,7 +268,10 @@ def test_extractor_training_forward_with_choose_equals_dense_then_gather():
                  "model.up_1.conv.1.weight", "model.psp.bottleneck.weight", "model.feats.layer4.1.conv2.weight",
                  "model.feats.conv1.weight"):
         err = float((g1[name] - g0[name]).norm() / (g0[name].norm() + 1e-12))
-        assert err < 2e-2, (name, err)          # MIOpen's own run-to-run differences on the trunk are of this order
+        # measured over four processes (profiles/r04_rgb_gradient_budget.txt): 6e-7 .. 2.6e-5 for every tensor, except the stem's
+        # 7x7 weight gradient, whose MIOpen backward-weights kernel is not run-to-run reproducible (1.8e-6 / 2.6e-5 / 8.7e-3)
+        bound = 2e-2 if name == "model.feats.conv1.weight" else 2e-4
+        assert err < bound, (name, err)
 
 
 @pytest.mark.parametrize("b,c,h,w,with_mask", [(4, 64, 24, 24, True), (2, 256, 12, 20, False), (3, 48, 10, 14, True),
