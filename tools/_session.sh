@@ -1,1 +1,6 @@
-for i in 1 2 3 4; do python -m pytest tests/test_rgb_ops_gpu.py -m gpu -q -s -k "choose_equals_dense" 2>&1 | grep GATHERFIRST | awk '{printf "%s=%s ", $2, $3} END {print ""}'; done
+run() { echo -n "$1: "; env $1 python bench.py --no-roofline --no-cpu-baseline --steps 50 --warmup 10 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(round(d['ms_per_step'],4), round(d['unpipelined']['ms_per_step'],4))"; }
+run "A=1"
+run "ISTNET_EXP_SKIP_DEFERRED_WGRAD=1"
+run "ISTNET_DEFERRED_WGRAD=0"
+run "A=1"
+run "ISTNET_EXP_SKIP_DEFERRED_WGRAD=1"
