@@ -47,10 +47,23 @@ __device__ unsigned long long g_phase_wgs[2];
       atomicAdd(&g_phase_sum[8 * ph_kind + ph_i], (unsigned long long)ph_acc[ph_i]);                  \
     atomicAdd(&g_phase_wgs[ph_kind], 1ull);                                                           \
   }
+// the same for pw_bwd_mid_kernel (tools/bwd_mid_phases.py): [template instance][role: 0 MFMA wave 0, 1 loader wave 4][phase]
+__device__ unsigned long long g_mid_phase[6][2][8];
+__device__ unsigned long long g_mid_wgs[6];
+#define MID_T0() long long mt_last = clock64(); long long mt_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define MID_T(i) { const long long mt_now = clock64(); mt_acc[i] += mt_now - mt_last; mt_last = mt_now; }
+#define MID_END(kind, role)                                                                                   \
+  if ((threadIdx.x & 255) == 0) {                                                                             \
+    for (int mt_i = 0; mt_i < 8; ++mt_i) atomicAdd(&g_mid_phase[kind][role][mt_i], (unsigned long long)mt_acc[mt_i]); \
+    if (role == 0) atomicAdd(&g_mid_wgs[kind], 1ull);                                                         \
+  }
 #else
 #define PHASE_INIT(kind)
 #define PHASE_T(i)
 #define PHASE_END
+#define MID_T0()
+#define MID_T(i)
+#define MID_END(kind, role)
 #endif
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -541,9 +554,14 @@ __global__ __launch_bounds__(kThreads, 2) void pw_fwd2_kernel(
   load_a(0);
   store_a(0);
   __syncthreads();
+  // Every prefetch below is issued UNCONDITIONALLY, clamped to the last valid chunk / k-step (the tail re-reads it: a few
+  // redundant L2 hits per workgroup).  With the prefetches under `if (t + 1 < nchunks)` / `if (g + DEPTH < ksteps)` the
+  // compiler's wait counts at the end of every chunk merged over both branch outcomes and ended in `s_waitcnt vmcnt(0)`:
+  // the whole ring of B loads was drained once per chunk (ISA of round 3), now the waits in front of the weight staging
+  // stores leave the DEPTH newest loads in flight.
   for (int t = 0; t < nchunks; ++t) {
     const int buf = t & 1;
-    if (t + 1 < nchunks) load_a((t + 1) * KC);
+    load_a(min(t + 1, nchunks - 1) * KC);
     const float* ap = &As[buf][half][a_col0 + l31];
     float a[2][TMW];
 #pragma unroll
@@ -552,7 +570,7 @@ __global__ __launch_bounds__(kThreads, 2) void pw_fwd2_kernel(
     for (int kk = 0; kk < KC / 2; ++kk) {
       const int g = t * (KC / 2) + kk, cur = kk & 1, nxt = cur ^ 1;
       float4 bv = ring[kk % DEPTH];
-      if (g + DEPTH < ksteps) ring[kk % DEPTH] = *reinterpret_cast<const float4*>(xb + (size_t)(2 * (g + DEPTH) + half) * P);
+      ring[kk % DEPTH] = *reinterpret_cast<const float4*>(xb + (size_t)(2 * min(g + DEPTH, ksteps - 1) + half) * P);
       if (has_bn) bv = bn_relu4(bv, s_in[0][2 * g + half], s_in[1][2 * g + half]);
       if (kk + 1 < KC / 2) {
 #pragma unroll
@@ -568,7 +586,7 @@ __global__ __launch_bounds__(kThreads, 2) void pw_fwd2_kernel(
       }
       __builtin_amdgcn_sched_barrier(0);
     }
-    if (t + 1 < nchunks) store_a(buf ^ 1);
+    store_a(buf ^ 1);
     lds_barrier();
   }
   // ---- epilogue: register r of accumulator (tm, q) is output row 32 tm + mfma_row(r, lane), point 4 l31 + q ----
@@ -684,13 +702,19 @@ __global__ __launch_bounds__(kThreads, 2) void pw_fwd_sk_kernel(
   __builtin_amdgcn_s_waitcnt(0);
   PHASE_T(1)                    // first operand group arrived
 #endif
-  for (; j < ngroups; j += 8) {
+  // main loop without a branch (both groups of the pair and the next pair's first exist), the last one or two groups
+  // peeled: with the prefetches under `if (j + 4 < ngroups)` the compiler's wait counts merged over the branch outcomes
+  // and drained the prefetch (`s_waitcnt vmcnt(0)` inside the loop, ISA of round 3); same accumulation order
+  for (; j + 8 < ngroups; j += 8) {
+    load_group(a4[1], b4[1], j + 4);
+    mma_group(a4[0], b4[0], j);
+    load_group(a4[0], b4[0], j + 8);
+    mma_group(a4[1], b4[1], j + 4);
+  }
+  if (j < ngroups) {
     if (j + 4 < ngroups) load_group(a4[1], b4[1], j + 4);
     mma_group(a4[0], b4[0], j);
-    if (j + 4 < ngroups) {
-      if (j + 8 < ngroups) load_group(a4[0], b4[0], j + 8);
-      mma_group(a4[1], b4[1], j + 4);
-    }
+    if (j + 4 < ngroups) mma_group(a4[1], b4[1], j + 4);
   }
 #ifdef ISTNET_PHASE_TIMING
   asm volatile("s_nop 0" ::"v"(acc[0][0]), "v"(acc[1][0]), "v"(acc[2][0]), "v"(acc[3][0]));   // MFMA results landed
@@ -802,10 +826,18 @@ __global__ __launch_bounds__(256) void pw_gather_add_kernel(int n, int P, int S,
   __syncthreads();
   const int wv = tid >> 6;
   const bool stats = part_sum != nullptr;
+  // the gathers of the NEXT four channels are issued before this group's arithmetic and stores (unconditionally, clamped to
+  // the last channel): eight gathers in flight instead of four, and the wait in front of a group's first use leaves the
+  // stores behind it outstanding (`vmcnt(4)`) instead of draining them with the loads (`vmcnt(0)`, round 3)
+  float zn[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) zn[j] = z != nullptr ? zb[(size_t)min(j, nco - 1) * n] : 0.f;
   for (int co = 0; co < nco; co += 4) {
     float zv[4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) zv[j] = z != nullptr ? zb[(size_t)min(co + j, nco - 1) * n] : 0.f;   // four gathers in flight
+    for (int j = 0; j < 4; ++j) zv[j] = zn[j];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) zn[j] = z != nullptr ? zb[(size_t)min(co + 4 + j, nco - 1) * n] : 0.f;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       if (co + j < nco) {
@@ -2140,13 +2172,17 @@ __global__ __launch_bounds__(kThreads, 2) void pw_dgrad_sk_kernel(
   };
   int j = wv;
   if (j < ngroups) load_group(a4[0], y4[0], g4[0], j);
-  for (; j < ngroups; j += 8) {
+  // (branch-free main loop, tail peeled: see pw_fwd_sk_kernel)
+  for (; j + 8 < ngroups; j += 8) {
+    load_group(a4[1], y4[1], g4[1], j + 4);
+    mma_group(a4[0], y4[0], g4[0], j);
+    load_group(a4[0], y4[0], g4[0], j + 8);
+    mma_group(a4[1], y4[1], g4[1], j + 4);
+  }
+  if (j < ngroups) {
     if (j + 4 < ngroups) load_group(a4[1], y4[1], g4[1], j + 4);
     mma_group(a4[0], y4[0], g4[0], j);
-    if (j + 4 < ngroups) {
-      if (j + 8 < ngroups) load_group(a4[0], y4[0], g4[0], j + 8);
-      mma_group(a4[1], y4[1], g4[1], j + 4);
-    }
+    if (j + 4 < ngroups) mma_group(a4[1], y4[1], g4[1], j + 4);
   }
   __syncthreads();              // every wave is done with the constants
 #pragma unroll
@@ -2353,8 +2389,8 @@ __global__ __launch_bounds__(kThreads) void pw_wgrad_kernel(
 // ============================================================================================
 // wgrad, dense input, cout and cin >= 64 (the FP levels, SA4, the layers pw_bwd_mid_kernel does not take): the same
 // product as pw_wgrad_kernel with the machinery of pw_bwd_mid_kernel -- eight waves in two roles, one workgroup per
-// CU.  Waves 4..7 load (two chunks of 32 points ahead, two register sets), finish dY and write both operand tiles
-// into the other half of a double-buffered LDS IN THE TENSORS' OWN LAYOUT ([channel][point], float4 stores; the
+// CU.  Waves 4..7 load (one chunk of 32 points ahead, every slot re-issued as soon as it has been consumed), finish dY
+// and write both operand tiles into the other half of a double-buffered LDS IN THE TENSORS' OWN LAYOUT ([channel][point], float4 stores; the
 // k-major tiles of pw_wgrad_kernel need four scalar ds_write_b32 per float4).  Waves 0..3 own a 2 x 2 grid of
 // (M_T/2) x (N_T/2) sub-tiles and read both operands as float4 ALONG THE POINTS: K is a dummy index, so a lane's four
 // values serve four consecutive k-steps as long as A and B agree on the point a (lane half, step) pair means -- a
@@ -2390,86 +2426,97 @@ __global__ __launch_bounds__(kMidThreads) void pw_wgrad2_kernel(
   }
   __syncthreads();
   if (loader) {
-    float4 ry[2][NA], rx[2][NB];
-    float4 rd[2][POOLED ? 1 : NA];
-    float rpv[2][POOLED ? NA : 1];
-    int rarg[2][POOLED ? NA : 1];
-    auto load_chunk = [&](int set, long long qk) {
-      int b, pk;
-      split_point(qk, P, b, pk);
+    // One register set, re-issued slot by slot (see pw_bwd_mid_kernel): consumption always wants the oldest outstanding
+    // loads -> exact `s_waitcnt vmcnt(n - k)`.  Round 3's two whole-chunk sets read the input layer's BatchNorm scale /
+    // shift from GLOBAL memory inside store_chunk (four dword loads per chunk, each followed by a wait that drained the
+    // other set's prefetch: `vmcnt(3) .. vmcnt(0)` once per chunk in the ISA); a thread's rows are the same in every
+    // chunk, so they are registers now.
+    static_assert(NB == 2 || NB == 4, "64- or 128-wide x tile: two or four float4 per loader thread");
+    float4 ry[NA];
+    float4 rd[POOLED ? 1 : NA];
+    float rpv[POOLED ? NA : 1];
+    int rarg[POOLED ? NA : 1];
+    float4 rx0, rx1, rx2, rx3;      // named, not an array (an array of them ends up in scratch memory)
+    float xsc[NB], xsh[NB];
 #pragma unroll
-      for (int i = 0; i < NA; ++i) {
-        const int e = tid + 256 * i, row = min(m0 + e / F4, cout - 1), p = pk + (e % F4) * 4;
-        const size_t rowo = (size_t)b * cout + row;
-        ry[set][i] = *reinterpret_cast<const float4*>(y + rowo * (size_t)P + p);
-        if (POOLED) {
-          const int G = P / gs.S, g = p / gs.S;
-          rpv[set][i] = pooled_at(gs, b, row, G, g);
-          rarg[set][i] = gs.arg[rowo * (size_t)G + g];
-        } else {
-          rd[set][i] = *reinterpret_cast<const float4*>(gs.dense + rowo * (size_t)P + p);
-        }
-      }
-#pragma unroll
-      for (int i = 0; i < NB; ++i) {
-        const int e = tid + 256 * i, row = min(n0 + e / F4, cin - 1), p = pk + (e % F4) * 4;
-        rx[set][i] = *reinterpret_cast<const float4*>(x + ((size_t)b * cin + row) * P + p);
-      }
-    };
-    auto store_chunk = [&](int set, float* buf, long long qk) {
-      float* As = buf;
-      float* Bs = buf + M_T * LD;
-      int pk = 0;
+    for (int i = 0; i < NB; ++i) {
+      const int ch = min(n0 + (tid + 256 * i) / F4, cin - 1);
+      xsc[i] = has_bn ? in_scale[ch] : 1.f;
+      xsh[i] = has_bn ? in_shift[ch] : 0.f;
+    }
+    auto issue_y = [&](int i, int b, int pk) {
+      const int e = tid + 256 * i, row = min(m0 + e / F4, cout - 1), p = pk + (e % F4) * 4;
+      const size_t rowo = (size_t)b * cout + row;
+      ry[i] = *reinterpret_cast<const float4*>(y + rowo * (size_t)P + p);
       if (POOLED) {
-        int b_unused;
-        split_point(qk, P, b_unused, pk);
-      }
-#pragma unroll
-      for (int i = 0; i < NA; ++i) {
-        const int e = tid + 256 * i, row = e / F4, k = (e % F4) * 4;
-        const float rs = s_c[row], rh = s_c[M_T + row], rca = s_c[2 * M_T + row], rcb = s_c[3 * M_T + row],
-                    rcc = s_c[4 * M_T + row];
-        float4 d;
-        if (POOLED) {
-          const int ks = (pk + k) % gs.S, a = rarg[set][i];
-          const float pv = rpv[set][i];
-          d = make_float4(a == ks ? pv : 0.f, a == ks + 1 ? pv : 0.f, a == ks + 2 ? pv : 0.f, a == ks + 3 ? pv : 0.f);
-        } else {
-          d = rd[set][i];
-        }
-        const float4 yv = ry[set][i];
-        float4 v;
-        v.x = rca * ((yv.x * rs + rh > 0.f) ? d.x : 0.f) + rcb + rcc * yv.x;
-        v.y = rca * ((yv.y * rs + rh > 0.f) ? d.y : 0.f) + rcb + rcc * yv.y;
-        v.z = rca * ((yv.z * rs + rh > 0.f) ? d.z : 0.f) + rcb + rcc * yv.z;
-        v.w = rca * ((yv.w * rs + rh > 0.f) ? d.w : 0.f) + rcb + rcc * yv.w;
-        if (m0 + row >= cout) v = zero4();
-        *reinterpret_cast<float4*>(&As[row * LD + k]) = v;
-      }
-#pragma unroll
-      for (int i = 0; i < NB; ++i) {
-        const int e = tid + 256 * i, row = e / F4, k = (e % F4) * 4;
-        float4 v = rx[set][i];
-        if (has_bn) {
-          const int ch = min(n0 + row, cin - 1);
-          v = bn_relu4(v, in_scale[ch], in_shift[ch]);
-        }
-        if (n0 + row >= cin) v = zero4();
-        *reinterpret_cast<float4*>(&Bs[row * LD + k]) = v;
+        const int G = P / gs.S, g = p / gs.S;
+        rpv[i] = pooled_at(gs, b, row, G, g);
+        rarg[i] = gs.arg[rowo * (size_t)G + g];
+      } else {
+        rd[i] = *reinterpret_cast<const float4*>(gs.dense + rowo * (size_t)P + p);
       }
     };
-    if (nchunks > 0) load_chunk(0, qbeg);
-    if (nchunks > 1) load_chunk(1, qbeg + PT);
-    for (int t = 0; t < nchunks; t += 2) {
-#pragma unroll
-      for (int u = 0; u < 2; ++u) {
-        if (t + u < nchunks) {
-          const long long qk = qbeg + (long long)(t + u) * PT;
-          store_chunk(u, wg2_lds + u * TILE, qk);
-          if (t + u + 2 < nchunks) load_chunk(u, qk + 2 * PT);
-          lds_barrier();
-        }
+    auto load_x = [&](int i, int b, int pk) {
+      const int e = tid + 256 * i, row = min(n0 + e / F4, cin - 1), p = pk + (e % F4) * 4;
+      return *reinterpret_cast<const float4*>(x + ((size_t)b * cin + row) * P + p);
+    };
+    auto finish_y = [&](int i, float* As, int pk) {
+      const int e = tid + 256 * i, row = e / F4, k = (e % F4) * 4;
+      const float rs = s_c[row], rh = s_c[M_T + row], rca = s_c[2 * M_T + row], rcb = s_c[3 * M_T + row],
+                  rcc = s_c[4 * M_T + row];
+      float4 d;
+      if (POOLED) {
+        const int ks = (pk + k) % gs.S, a = rarg[i];
+        const float pv = rpv[i];
+        d = make_float4(a == ks ? pv : 0.f, a == ks + 1 ? pv : 0.f, a == ks + 2 ? pv : 0.f, a == ks + 3 ? pv : 0.f);
+      } else {
+        d = rd[i];
       }
+      const float4 yv = ry[i];
+      float4 v;
+      v.x = rca * ((yv.x * rs + rh > 0.f) ? d.x : 0.f) + rcb + rcc * yv.x;
+      v.y = rca * ((yv.y * rs + rh > 0.f) ? d.y : 0.f) + rcb + rcc * yv.y;
+      v.z = rca * ((yv.z * rs + rh > 0.f) ? d.z : 0.f) + rcb + rcc * yv.z;
+      v.w = rca * ((yv.w * rs + rh > 0.f) ? d.w : 0.f) + rcb + rcc * yv.w;
+      if (m0 + row >= cout) v = zero4();
+      *reinterpret_cast<float4*>(&As[row * LD + k]) = v;
+    };
+    auto put_x = [&](int i, float* Bs, float4 v) {
+      const int e = tid + 256 * i, row = e / F4, k = (e % F4) * 4;
+      if (has_bn) v = bn_relu4(v, xsc[i], xsh[i]);
+      if (n0 + row >= cin) v = zero4();
+      *reinterpret_cast<float4*>(&Bs[row * LD + k]) = v;
+    };
+    if (nchunks > 0) {
+      int b, pk;
+      split_point(qbeg, P, b, pk);
+#pragma unroll
+      for (int i = 0; i < NA; ++i) issue_y(i, b, pk);
+      rx0 = load_x(0, b, pk); rx1 = load_x(1, b, pk);
+      if (NB > 2) { rx2 = load_x(2, b, pk); rx3 = load_x(3, b, pk); }
+    }
+    for (int t = 0; t < nchunks; ++t) {
+      float* As = wg2_lds + (t & 1) * TILE;
+      float* Bs = As + M_T * LD;
+      int b_cur, pk_cur, b_nxt, pk_nxt;
+      split_point(qbeg + (long long)t * PT, P, b_cur, pk_cur);
+      // the next chunk unconditionally (the last iteration re-reads its own chunk): a branch around the issue makes the
+      // compiler's wait counts merge to vmcnt(0); scheduling fences keep "finish slot i, re-issue slot i" in order
+      split_point(qbeg + (long long)min(t + 1, nchunks - 1) * PT, P, b_nxt, pk_nxt);
+#pragma unroll
+      for (int i = 0; i < NA; ++i) {
+        finish_y(i, As, pk_cur);
+        __builtin_amdgcn_sched_barrier(0);
+        issue_y(i, b_nxt, pk_nxt);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      put_x(0, Bs, rx0); __builtin_amdgcn_sched_barrier(0); rx0 = load_x(0, b_nxt, pk_nxt); __builtin_amdgcn_sched_barrier(0);
+      put_x(1, Bs, rx1); __builtin_amdgcn_sched_barrier(0); rx1 = load_x(1, b_nxt, pk_nxt); __builtin_amdgcn_sched_barrier(0);
+      if (NB > 2) {
+        put_x(2, Bs, rx2); __builtin_amdgcn_sched_barrier(0); rx2 = load_x(2, b_nxt, pk_nxt); __builtin_amdgcn_sched_barrier(0);
+        put_x(3, Bs, rx3); __builtin_amdgcn_sched_barrier(0); rx3 = load_x(3, b_nxt, pk_nxt); __builtin_amdgcn_sched_barrier(0);
+      }
+      lds_barrier();
     }
     return;
   }
@@ -2644,6 +2691,9 @@ __global__ __launch_bounds__(kThreads, ISTNET_BWD_SMALL_WAVES) void pw_bwd_small
   constexpr int LD = 33;
   __shared__ float lds[4][2][kKTW][LD];  // [wave][dY | raw x][k = point][row = channel]
   __shared__ float s_in[2][32];          // BN constants of the input layer
+  __shared__ float s_k[5][32];           // this layer's BN scale / shift and the three BN-backward constants per output channel:
+                                         // read from LDS in store_chunk -- as global loads inside the chunk loop (round 3) every
+                                         // one of them was followed by a wait that drained the next chunk's prefetch
   __shared__ float s_w[4][kKTW];         // column multiplicities of a wave's chunk (compact-column mode)
   const int lane = lane_id(), wv = wave_id();
   if (ncols != nullptr) {                // compact columns: the valid range and an even split of it come from the device
@@ -2660,6 +2710,9 @@ __global__ __launch_bounds__(kThreads, ISTNET_BWD_SMALL_WAVES) void pw_bwd_small
     const int c = min((int)threadIdx.x, cin - 1);
     s_in[0][threadIdx.x] = in_scale[c];
     s_in[1][threadIdx.x] = in_shift[c];
+    const int co = min((int)threadIdx.x, cout - 1);
+    s_k[0][threadIdx.x] = bn[co]; s_k[1][threadIdx.x] = bn[cout + co];
+    s_k[2][threadIdx.x] = bwdc[co]; s_k[3][threadIdx.x] = bwdc[cout + co]; s_k[4][threadIdx.x] = bwdc[2 * cout + co];
   }
   // B operand of the dgrad MFMAs: B[k = co][j = ci] = w[co][ci], co = 2*kk + (lane >> 5), ci = lane & 31
   float wfrag[16];
@@ -2709,9 +2762,8 @@ __global__ __launch_bounds__(kThreads, ISTNET_BWD_SMALL_WAVES) void pw_bwd_small
       const int e = lane + 64 * i;
       const int row = e >> 3, k = (e & 7) * 4;
       const bool okq = qk + k < qend;
-      const int ch = min(row, cout - 1);
-      const float rs = bn[ch], rh = bn[cout + ch];
-      const float rca = bwdc[ch], rcb = bwdc[cout + ch], rcc = bwdc[2 * cout + ch];
+      const float rs = s_k[0][row], rh = s_k[1][row];
+      const float rca = s_k[2][row], rcb = s_k[3][row], rcc = s_k[4][row];
       float4 d;
       if (POOLED) {
         const int ks = (pk + k) % gs.S, a = aarg[i];
@@ -2884,99 +2936,117 @@ __global__ __launch_bounds__(kMidThreads) void pw_bwd_mid_kernel(
     s_c[2 * COUT + c] = bwdc[c]; s_c[3 * COUT + c] = bwdc[COUT + c]; s_c[4 * COUT + c] = bwdc[2 * COUT + c];
   }
 
-  // ---------------- loader state ----------------
-  // two register sets of raw loads, passed to the lambdas BY NAME: as one array indexed by the set number they ended
-  // up in scratch memory, and a kernel with a scratch segment does not share the chip with kernels of other streams
-  // (measured, tools/exp/corun.py: a 128-workgroup finalize kernel took 60 us instead of 8 beside this one)
-  struct Raw {
-    float4 y[NY], x[NX];
-    float4 d[POOLED ? 1 : NY];
-    float pv[POOLED ? NY : 1];
-    int arg[POOLED ? NY : 1];
-  };
-  Raw raw0, raw1;
-  auto load_chunk = [&](Raw& rw, long long qk) {
-    int b, pk;
-    split_point(qk, P, b, pk);
-#pragma unroll
-    for (int i = 0; i < NY; ++i) {
+  __syncthreads();                                 // s_c
+  // ---------------- loader role ----------------
+  // ONE register set, re-issued SLOT BY SLOT: as soon as a float4 (pair) of chunk t has been finished into the LDS tile,
+  // the load of the same slot of chunk t + 1 goes out into the same registers.  Every load is then in flight for a whole
+  // chunk period (the rest of this iteration, the barrier, the start of the next) -- several times the HBM latency --
+  // and consumption always wants the OLDEST outstanding loads, so the compiler's waits are exact `s_waitcnt vmcnt(11)` /
+  // `(10)` and nothing is ever drained.  Rounds 2-3 kept two whole-chunk register sets (a chunk's loads issued after
+  // the previous chunk's stores as one block); in the 252-register kernel the allocator re-used pieces of an in-flight
+  // set for temporaries and copied them away right after the load, which put a `vmcnt(7)` behind every second chunk's
+  // issue and a full drain in front of every second chunk's stores (ISA of round 3): the MFMA waves stood 17-34 % of
+  // their time at the chunk barrier (tools/bwd_mid_phases.py, profiles/r04_bwd_mid_phases.txt: now 12-31 %; what is left
+  // is the loaders' own throughput -- 6.5 B / cycle / CU on the cout-256 layer, near what a CU streams -- and a second
+  // set in flight, tried with the same exact waits (vmcnt(23)), changes nothing).  Named x registers, not `float4 x[NX]`:
+  // as an array the four rows went to scratch memory, and a kernel with a scratch segment does not share the chip with
+  // the kernels of other streams (tools/exp/corun.py).
+  if (loader) {
+    static_assert(NX == 4, "CIN * PT == 4096: four float4 of the x tile per loader thread");
+    struct Set {
+      float4 y[NY];
+      float4 d[POOLED ? 1 : NY];
+      float pv[POOLED ? NY : 1];
+      int arg[POOLED ? NY : 1];
+      float4 x0, x1, x2, x3;
+    };
+    Set s0;
+    auto issue_y = [&](Set& st, int i, int b, int pk) {
       const int e = tid + 256 * i, row = e / F4, p = pk + (e % F4) * 4;
       const size_t rowo = (size_t)b * COUT + row;
-      rw.y[i] = *reinterpret_cast<const float4*>(y + rowo * (size_t)P + p);
+      st.y[i] = *reinterpret_cast<const float4*>(y + rowo * (size_t)P + p);
       if (POOLED) {
         const int G = P / gs.S, g = p / gs.S;
-        rw.pv[i] = pooled_at(gs, b, row, G, g);
-        rw.arg[i] = gs.arg[rowo * (size_t)G + g];
+        st.pv[i] = pooled_at(gs, b, row, G, g);
+        st.arg[i] = gs.arg[rowo * (size_t)G + g];
       } else {
-        rw.d[i] = *reinterpret_cast<const float4*>(gs.dense + rowo * (size_t)P + p);
+        st.d[i] = *reinterpret_cast<const float4*>(gs.dense + rowo * (size_t)P + p);
       }
-    }
-#pragma unroll
-    for (int i = 0; i < NX; ++i) {
+    };
+    auto load_x = [&](int i, int b, int pk) {
       const int e = tid + 256 * i, row = e / F4, p = pk + (e % F4) * 4;
-      rw.x[i] = *reinterpret_cast<const float4*>(x + ((size_t)b * CIN + row) * P + p);
-    }
-  };
-  auto store_chunk = [&](const Raw& rw, float* buf, long long qk) {
-    float* dYs = buf;
-    float* Xs = buf + COUT * LD;
-    int pk = 0;
-    if (POOLED) {
-      int b_unused;
-      split_point(qk, P, b_unused, pk);
-    }
-#pragma unroll
-    for (int i = 0; i < NY; ++i) {
+      return *reinterpret_cast<const float4*>(x + ((size_t)b * CIN + row) * P + p);
+    };
+    auto put_x = [&](int i, float* Xs, const float4& v) {      // RAW y_{l-1}: the statistics need it, act() is applied on read
+      const int e = tid + 256 * i, row = e / F4, k = (e % F4) * 4;
+      *reinterpret_cast<float4*>(&Xs[row * LD + k]) = v;
+    };
+    auto finish_y = [&](const Set& st, int i, float* dYs, int pk) {
       const int e = tid + 256 * i, row = e / F4, k = (e % F4) * 4;
       const float rs = s_c[row], rh = s_c[COUT + row], rca = s_c[2 * COUT + row], rcb = s_c[3 * COUT + row],
                   rcc = s_c[4 * COUT + row];
       float4 d;
       if (POOLED) {
-        const int ks = (pk + k) % gs.S, a = rw.arg[i];
-        const float pv = rw.pv[i];
+        const int ks = (pk + k) % gs.S, a = st.arg[i];
+        const float pv = st.pv[i];
         d = make_float4(a == ks ? pv : 0.f, a == ks + 1 ? pv : 0.f, a == ks + 2 ? pv : 0.f, a == ks + 3 ? pv : 0.f);
       } else {
-        d = rw.d[i];
+        d = st.d[i];
       }
-      const float4 yv = rw.y[i];
+      const float4 yv = st.y[i];
       float4 v;
       v.x = rca * ((yv.x * rs + rh > 0.f) ? d.x : 0.f) + rcb + rcc * yv.x;
       v.y = rca * ((yv.y * rs + rh > 0.f) ? d.y : 0.f) + rcb + rcc * yv.y;
       v.z = rca * ((yv.z * rs + rh > 0.f) ? d.z : 0.f) + rcb + rcc * yv.z;
       v.w = rca * ((yv.w * rs + rh > 0.f) ? d.w : 0.f) + rcb + rcc * yv.w;
       *reinterpret_cast<float4*>(&dYs[row * LD + k]) = v;
-    }
+    };
+    auto issue_all = [&](Set& st, long long qk) {
+      int b, pk;
+      split_point(qk, P, b, pk);
 #pragma unroll
-    for (int i = 0; i < NX; ++i) {
-      const int e = tid + 256 * i, row = e / F4, k = (e % F4) * 4;
-      *reinterpret_cast<float4*>(&Xs[row * LD + k]) = rw.x[i];   // RAW y_{l-1}: the statistics need it, act() is applied on read
-    }
-  };
-
-  // Each role runs its OWN loop (same number of barriers on both sides), so the register allocation of a role does
-  // not carry the other role's state.
-  __syncthreads();                                 // s_c
-  if (loader) {
-    // Chunk t: the loaders fill buffer t & 1 BEFORE barrier t, the compute waves read it AFTER barrier t.  A loader is
-    // at most one chunk ahead: it reaches barrier t + 1 (buffer (t + 1) & 1 written) only after the compute waves
-    // passed barrier t, i.e. finished chunk t - 1, the last reader of that buffer.
+      for (int i = 0; i < NY; ++i) issue_y(st, i, b, pk);
+      st.x0 = load_x(0, b, pk); st.x1 = load_x(1, b, pk); st.x2 = load_x(2, b, pk); st.x3 = load_x(3, b, pk);
+    };
+    // chunk t out of the set into LDS buffer `buf`; every slot is re-issued for chunk t + 1 (clamped to the last chunk:
+    // the tail re-reads it -- one chunk of redundant L2 hits per workgroup -- because a branch around the issue makes
+    // the compiler's wait counts merge to vmcnt(0)).  Scheduling fences keep "finish slot i, re-issue slot i" in this
+    // order: left alone, the scheduler hoists the re-issues and double-buffers the old values.
+    auto step_set = [&](Set& st, float* buf, int t) {
+      float* Xs = buf + COUT * LD;
+      int b_cur, pk_cur, b_nxt, pk_nxt;
+      split_point(qbeg + (long long)t * PT, P, b_cur, pk_cur);
+      split_point(qbeg + (long long)min(t + 1, nchunks - 1) * PT, P, b_nxt, pk_nxt);
+#pragma unroll
+      for (int i = 0; i < NY; ++i) {
+        finish_y(st, i, buf, pk_cur);
+        __builtin_amdgcn_sched_barrier(0);
+        issue_y(st, i, b_nxt, pk_nxt);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      put_x(0, Xs, st.x0); __builtin_amdgcn_sched_barrier(0); st.x0 = load_x(0, b_nxt, pk_nxt); __builtin_amdgcn_sched_barrier(0);
+      put_x(1, Xs, st.x1); __builtin_amdgcn_sched_barrier(0); st.x1 = load_x(1, b_nxt, pk_nxt); __builtin_amdgcn_sched_barrier(0);
+      put_x(2, Xs, st.x2); __builtin_amdgcn_sched_barrier(0); st.x2 = load_x(2, b_nxt, pk_nxt); __builtin_amdgcn_sched_barrier(0);
+      put_x(3, Xs, st.x3); __builtin_amdgcn_sched_barrier(0); st.x3 = load_x(3, b_nxt, pk_nxt); __builtin_amdgcn_sched_barrier(0);
+    };
     // The loader's VALU work shares the SIMD's issue port with the MFMA wave and loses to it (measured: the store phase
     // takes 1.7x longer beside the MFMAs).  Where the loaders are the longer side (cin <= 64) they get priority; on
     // the 128 -> 128 layers the MFMA wave is the critical path and priority costs 8 %.
     if (CIT <= 2) __builtin_amdgcn_s_setprio(3);
-    if (nchunks > 0) load_chunk(raw0, qbeg);
-    if (nchunks > 1) load_chunk(raw1, qbeg + PT);
-    for (int t = 0; t < nchunks; t += 2) {
-      const long long qk = qbeg + (long long)t * PT;
-      store_chunk(raw0, mid_lds, qk);
-      if (t + 2 < nchunks) load_chunk(raw0, qk + 2 * PT);          // two chunks ahead, into the set just consumed
+    [[maybe_unused]] constexpr int kMidKind = COT == 8 ? 0 : (COT == 4 && CIT == 4 ? 1 : (COT == 4 && CIT == 2 ? 2 : (COT == 2 && CIT == 2 ? 3 : (COT == 2 && CIT == 1 ? 4 : 5))));
+    MID_T0()
+    if (nchunks > 0) issue_all(s0, qbeg);
+    MID_T(0)                                                       // the first chunk's loads issued
+    // Chunk t: the loaders fill buffer t & 1 BEFORE barrier t, the compute waves read it AFTER barrier t.  A loader is
+    // at most one chunk ahead: it reaches barrier t + 1 (buffer (t + 1) & 1 written) only after the compute waves
+    // passed barrier t, i.e. finished chunk t - 1, the last reader of that buffer.
+    for (int t = 0; t < nchunks; ++t) {
+      step_set(s0, mid_lds + (t & 1) * C::TILE, t);
+      MID_T(1)                                                     // wait for loads + dY arithmetic + LDS writes + re-issue
       lds_barrier();
-      if (t + 1 < nchunks) {
-        store_chunk(raw1, mid_lds + C::TILE, qk + PT);
-        if (t + 3 < nchunks) load_chunk(raw1, qk + 3 * PT);
-        lds_barrier();
-      }
+      MID_T(3)                                                     // barrier: waiting for the compute waves
     }
+    MID_END(kMidKind, 1)
     __syncthreads();                               // the four barriers of the compute waves' epilogue
     if (WGRAD && C::WGK == 2) { __syncthreads(); __syncthreads(); }
     __syncthreads();
@@ -3090,10 +3160,18 @@ __global__ __launch_bounds__(kMidThreads) void pw_bwd_mid_kernel(
     }
   };
 
+  [[maybe_unused]] constexpr int kMidKindC = COT == 8 ? 0 : (COT == 4 && CIT == 4 ? 1 : (COT == 4 && CIT == 2 ? 2 : (COT == 2 && CIT == 2 ? 3 : (COT == 2 && CIT == 1 ? 4 : 5))));
+  MID_T0()
   for (int t = 0; t < nchunks; ++t) {
     lds_barrier();
+    MID_T(0)                                                       // barrier: waiting for the loaders
     compute_chunk(mid_lds + (t & 1) * C::TILE, qbeg + (long long)t * PT);
+#ifdef ISTNET_PHASE_TIMING
+    asm volatile("s_nop 0" ::"v"(accw[0][0][0]), "v"(sg));
+#endif
+    MID_T(1)                                                       // the chunk's MFMAs, epilogue stores and statistics
   }
+  if (cw == 0) { MID_END(kMidKindC, 0) }
   // ---- per-workgroup results ----
   __syncthreads();      // the compute waves are done with the tiles
   float* red = mid_lds;
@@ -3364,6 +3442,16 @@ int istnet_pw_wgrad_tile_cfg(int b, int cin, int cout, int p) {
 }
 
 #ifdef ISTNET_PHASE_TIMING
+__attribute__((visibility("default"))) int istnet_debug_mid_phase_read(unsigned long long* out102, int reset) {
+  unsigned long long zero[102] = {0};
+  if (hipMemcpyFromSymbol(out102, HIP_SYMBOL(g_mid_phase), 96 * sizeof(unsigned long long)) != hipSuccess) return 1;
+  if (hipMemcpyFromSymbol(out102 + 96, HIP_SYMBOL(g_mid_wgs), 6 * sizeof(unsigned long long)) != hipSuccess) return 1;
+  if (reset) {
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_mid_phase), zero, 96 * sizeof(unsigned long long));
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_mid_wgs), zero, 6 * sizeof(unsigned long long));
+  }
+  return 0;
+}
 __attribute__((visibility("default"))) int istnet_debug_phase_read(unsigned long long* out18, int reset) {
   unsigned long long zero[18] = {0};
   if (hipMemcpyFromSymbol(out18, HIP_SYMBOL(g_phase_sum), 16 * sizeof(unsigned long long)) != hipSuccess) return 1;

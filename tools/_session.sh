@@ -1,6 +1,4 @@
-run() { echo -n "$1: "; env $1 python bench.py --no-roofline --no-cpu-baseline --steps 50 --warmup 10 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(round(d['ms_per_step'],4), round(d['unpipelined']['ms_per_step'],4))"; }
-run "A=1"
-run "ISTNET_EXP_SKIP_DEFERRED_WGRAD=1"
-run "ISTNET_DEFERRED_WGRAD=0"
-run "A=1"
-run "ISTNET_EXP_SKIP_DEFERRED_WGRAD=1"
+mkdir -p gpurun_out/r4j
+python -m pytest tests/test_pw_kernels_gpu.py tests/test_fused_mlp_gpu.py -m gpu -q 2>&1 | tail -2
+bash tools/ab.sh 3 2>&1 | tee gpurun_out/r4j/ab2.txt
+bash tools/ab.sh 2 --workload istnet --steps 20 2>&1 | tee gpurun_out/r4j/ab_istnet.txt
