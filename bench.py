@@ -729,7 +729,7 @@ def main():
                     timed_step = make_graphed_step(fwd_bwd, opt, world, grad_sync)
                     return lambda: [timed_step() for _ in range(n_graphs)]
             result["roofline"] = roofline.measure(
-                eager_step, traffic_file=os.path.join(ROOT, "profiles", "r03_pmc_traffic.json"), capture=capture,
+                eager_step, traffic_file=os.path.join(ROOT, "profiles", "r04_pmc_traffic.json"), capture=capture,
                 steps_per_replay=(len(fwd_bwd) if isinstance(fwd_bwd, (list, tuple)) else 1))
         if not dist_on and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline()

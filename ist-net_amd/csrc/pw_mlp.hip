@@ -2172,12 +2172,18 @@ __global__ __launch_bounds__(kThreads, 2) void pw_dgrad_sk_kernel(
   };
   int j = wv;
   if (j < ngroups) load_group(a4[0], y4[0], g4[0], j);
-  // (branch-free main loop, tail peeled: see pw_fwd_sk_kernel)
+  // (branch-free main loop, tail peeled: see pw_fwd_sk_kernel.  The scheduling fences pin "all twelve loads of the next
+  // group, THEN this group's arithmetic and MFMAs": left alone the scheduler sank the loads between the MFMAs, each a few
+  // instructions in front of its first use -- four `s_waitcnt vmcnt(0)` per group in the ISA of round 3, i.e. no prefetch)
   for (; j + 8 < ngroups; j += 8) {
     load_group(a4[1], y4[1], g4[1], j + 4);
+    __builtin_amdgcn_sched_barrier(0);
     mma_group(a4[0], y4[0], g4[0], j);
+    __builtin_amdgcn_sched_barrier(0);
     load_group(a4[0], y4[0], g4[0], j + 8);
+    __builtin_amdgcn_sched_barrier(0);
     mma_group(a4[1], y4[1], g4[1], j + 4);
+    __builtin_amdgcn_sched_barrier(0);
   }
   if (j < ngroups) {
     if (j + 4 < ngroups) load_group(a4[1], y4[1], g4[1], j + 4);
