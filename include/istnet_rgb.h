@@ -80,6 +80,20 @@ ISTNET_PN2_API int istnet_nhwc_bn_act_res_bwd_stats(int b, long long hw, int c, 
                                                     const float *z, const float *bn, const float *slope, float *g,
                                                     float *part_g, float *part_gy, float *part_slope, void *stream);
 
+/* The decoder's `final` stage (Conv2d 1x1 -> BatchNorm2d -> PReLU, modules.py:63-67) at the chosen pixels only
+ * (ist_net.py:41-45), training mode: its batch statistics follow from the moments of the stage's input u, a
+ * channels-last map of `rows` = b*h*w pixels x 64 channels.
+ *   istnet_nhwc_gram64: s1[64] = sum_p u_p, s2[64][64] = sum_p u_p u_p^T as FLOAT64 (per-workgroup fp32 MFMA partials
+ *     part_s2 [istnet_nhwc_gram64_parts(rows)][64][64], part_s1 [parts][64], summed in a fixed order in float64) -- one
+ *     pass over u;
+ *   istnet_nhwc_rowmix64: out[p][j] = c0[j] + sum_i u[p][i] * a[j][i], the dense part of the stage's input gradient
+ *     (the statistics couple every pixel: dL/du_p = A u_p + c0, A = W^T diag(k) W). */
+ISTNET_PN2_API int istnet_nhwc_gram64_parts(long long rows);
+ISTNET_PN2_API int istnet_nhwc_gram64(long long rows, const float *u, float *part_s2, float *part_s1, double *s2,
+                                      double *s1, void *stream);
+ISTNET_PN2_API int istnet_nhwc_rowmix64(long long rows, const float *u, const float *a, const float *c0, float *out,
+                                        void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -25,6 +25,9 @@ SIGNATURES = {
     "istnet_pw_scatter_dy_csr": [_i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _l, _p, _p, _i, _p, _p],
     "istnet_pw_scatter_dy_csr_fin": [_i, _i, _i, _i, _p, _p, _p, _i, _d, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _l, _p, _p, _i, _p, _p],
     "istnet_adam_step": [_l, _p, _p, _p, _p, _p, _p, _d, _d, _d, _d, _d, _d, _p],
+    "istnet_nhwc_gram64_parts": [_l],
+    "istnet_nhwc_gram64": [_l, _p, _p, _p, _p, _p, _p],
+    "istnet_nhwc_rowmix64": [_l, _p, _p, _p, _p, _p],
     "istnet_nhwc_stat_parts": [_l],
     "istnet_nhwc_channel_stats": [_l, _i, _p, _p, _p, _p],
     "istnet_nhwc_bn_prelu_apply": [_i, _l, _i, _p, _p, _p, _p, _p, _p],

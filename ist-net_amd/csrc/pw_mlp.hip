@@ -3268,11 +3268,13 @@ struct ReduceBatch {
   int block_begin[9];  // prefix sum of ceil(count / 64)
   int n;
 };
-// Workgroup = 64 consecutive elements x 4 split groups: a wave reads 256 contiguous bytes per split (the earlier layout --
-// 16 elements x 16 split groups -- read 64-byte segments), four independent chains per thread keep loads in flight, the
-// four group sums meet in LDS in a fixed order.
-__global__ __launch_bounds__(256) void wgrad_reduce_multi_kernel(ReduceBatch rb) {
-  __shared__ float red[4][64];
+// Workgroup = 64 consecutive elements x 16 split groups (1024 threads): a wave reads 256 contiguous bytes per split, four
+// independent chains per thread keep loads in flight, the sixteen group sums meet in LDS in a fixed order.  (Round 3 used
+// four groups: with 128 - 512 splits a thread walked 32 - 128 dependent-latency steps, 10 us per launch on average;
+// sixteen groups cut the walk fourfold.  Deterministic, but a different summation order than round 3's.)
+constexpr int kRedGroups = 16;
+__global__ __launch_bounds__(64 * kRedGroups) void wgrad_reduce_multi_kernel(ReduceBatch rb) {
+  __shared__ float red[kRedGroups][64];
   int l = 0;
   while (l + 1 < rb.n && (int)blockIdx.x >= rb.block_begin[l + 1]) ++l;
   const int count = rb.count[l], splits = rb.splits[l];
@@ -3283,18 +3285,20 @@ __global__ __launch_bounds__(256) void wgrad_reduce_multi_kernel(ReduceBatch rb)
   float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
   if (i < count) {
     int k = sg;
-    for (; k + 12 < splits; k += 16) {
+    for (; k + 3 * kRedGroups < splits; k += 4 * kRedGroups) {
       s0 += part[(size_t)k * ps + i];
-      s1 += part[(size_t)(k + 4) * ps + i];
-      s2 += part[(size_t)(k + 8) * ps + i];
-      s3 += part[(size_t)(k + 12) * ps + i];
+      s1 += part[(size_t)(k + kRedGroups) * ps + i];
+      s2 += part[(size_t)(k + 2 * kRedGroups) * ps + i];
+      s3 += part[(size_t)(k + 3 * kRedGroups) * ps + i];
     }
-    for (; k < splits; k += 4) s0 += part[(size_t)k * ps + i];
+    for (; k < splits; k += kRedGroups) s0 += part[(size_t)k * ps + i];
   }
   red[sg][el] = (s0 + s1) + (s2 + s3);
   __syncthreads();
   if (threadIdx.x < 64 && i < count) {
-    const float s = (red[0][el] + red[1][el]) + (red[2][el] + red[3][el]);
+    float s = 0.f;
+#pragma unroll
+    for (int g = 0; g < kRedGroups; g += 4) s += (red[g][el] + red[g + 1][el]) + (red[g + 2][el] + red[g + 3][el]);
     const int cols = rb.cols[l];
     rb.dw[l][(size_t)(i / cols) * rb.ld[l] + i % cols] = s;
   }
@@ -4363,7 +4367,7 @@ static int reduce_multi_impl(int n, const int* counts, const int* splits, const 
     if (rb.cols[l] <= 0 || counts[l] % rb.cols[l] || rb.ld[l] < rb.cols[l] || rb.pstride[l] < counts[l]) return ISTNET_PN2_EINVAL;
     rb.block_begin[l + 1] = rb.block_begin[l] + ceil_div(counts[l], 64);
   }
-  hipLaunchKernelGGL(wgrad_reduce_multi_kernel, dim3(rb.block_begin[n]), dim3(256), 0, as_stream(stream), rb);
+  hipLaunchKernelGGL(wgrad_reduce_multi_kernel, dim3(rb.block_begin[n]), dim3(64 * kRedGroups), 0, as_stream(stream), rb);
   return (int)hipGetLastError();
 }
 

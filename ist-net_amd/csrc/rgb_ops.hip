@@ -392,6 +392,182 @@ __global__ __launch_bounds__(kThreads) void nhwc_bn_prelu_bwd_apply_kernel(
 
 }  // namespace
 
+// ============================================================================================
+// The decoder's `final` stage evaluated at the chosen pixels only (rgb_branch._FinalAtChosenFn; reference
+// model/modules.py:63-67 + model/ist_net.py:41-45): training-mode BatchNorm statistics of z = W u + b over ALL pixels
+// follow from the first and second moments of the stage's input u (rows, 64) -- ONE pass over u here (fp32 MFMA,
+// v_mfma_f32_32x32x2_f32: the 64 x 64 Gram matrix as 2 x 2 tiles, one per wave, K = pixels) instead of a framework
+// column sum (0.9 TB/s) plus a batched library product over a second pass -- and its backward reaches every pixel
+// through those statistics as the affine map  du_p = A u_p + c0  (nhwc_rowmix64_kernel: M = pixels, K = N = 64).
+// Both kernels are HBM-bound streaming passes over the 302 MB map of the training batch.
+// ============================================================================================
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+__device__ __forceinline__ int mfma_row(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
+
+constexpr int kGramC = 64;
+// grid: nparts workgroups, each a contiguous range of `rows_per` rows (a multiple of 32); partials
+// part_s2[nparts][64][64], part_s1[nparts][64] (rows past `rows` count as zero)
+__global__ __launch_bounds__(kThreads) void nhwc_gram64_kernel(long long rows, long long rows_per,
+                                                               const float* __restrict__ u, float* __restrict__ part_s2,
+                                                               float* __restrict__ part_s1) {
+  __shared__ __attribute__((aligned(16))) float tile[2][32][kGramC];      // [buffer][k = pixel][m = channel]: k-major for both operands
+  __shared__ float colred[16][kGramC];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int l31 = lane & 31, half = lane >> 5;
+  const int tm = wv >> 1, tn = wv & 1;
+  const long long r0 = (long long)blockIdx.x * rows_per;
+  const long long r1 = r0 + rows_per < rows ? r0 + rows_per : rows;
+  const int nchunks = r1 > r0 ? (int)((r1 - r0 + 31) / 32) : 0;
+  // a thread stages two float4 per chunk: element e = tid + 256 i -> pixel e / 16, channels 4 (e % 16) .. +3 (the same
+  // channels in every chunk: its running column sums are four registers per i)
+  float4 stage[2], colsum[2];
+  colsum[0] = colsum[1] = make_float4(0.f, 0.f, 0.f, 0.f);
+  auto load = [&](int t) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int e = tid + kThreads * i;
+      const long long row = r0 + (long long)t * 32 + e / 16;
+      stage[i] = row < r1 ? *reinterpret_cast<const float4*>(u + row * kGramC + (e % 16) * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  };
+  auto put = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int e = tid + kThreads * i;
+      *reinterpret_cast<float4*>(&tile[buf][e / 16][(e % 16) * 4]) = stage[i];
+      colsum[i].x += stage[i].x; colsum[i].y += stage[i].y; colsum[i].z += stage[i].z; colsum[i].w += stage[i].w;
+    }
+  };
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  if (nchunks > 0) { load(0); put(0); }
+  __syncthreads();
+  for (int t = 0; t < nchunks; ++t) {
+    const int buf = t & 1;
+    load(t + 1 < nchunks ? t + 1 : t);             // unconditional issue (the tail re-reads its chunk): exact wait counts
+    const float* ap = &tile[buf][half][32 * tm + l31];
+    const float* bp = &tile[buf][half][32 * tn + l31];
+#pragma unroll
+    for (int s2 = 0; s2 < 16; ++s2)
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[2 * s2 * kGramC], bp[2 * s2 * kGramC], acc, 0, 0, 0);
+    if (t + 1 < nchunks) put(buf ^ 1);
+    __syncthreads();
+  }
+  float* o2 = part_s2 + (size_t)blockIdx.x * kGramC * kGramC;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) o2[(32 * tm + mfma_row(r, lane)) * kGramC + 32 * tn + l31] = acc[r];
+  // column sums: 16 threads share a channel quad (tid % 16; the same quad for both of a thread's elements), fixed-order
+  // sum through LDS
+  const float4 cs = make_float4(colsum[0].x + colsum[1].x, colsum[0].y + colsum[1].y, colsum[0].z + colsum[1].z,
+                                colsum[0].w + colsum[1].w);
+  *reinterpret_cast<float4*>(&colred[tid / 16][(tid % 16) * 4]) = cs;
+  __syncthreads();
+  if (tid < kGramC) {
+    float a = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) a += colred[k][tid];
+    part_s1[(size_t)blockIdx.x * kGramC + tid] = a;
+  }
+}
+
+// fixed-order float64 sum of the partials: s2 (64 x 64) and s1 (64) as float64.  One workgroup = 64 consecutive output
+// elements x 16 slices of the partial index (1024 threads): a thread sums every 16th partial with eight loads in flight,
+// the 16 slice sums meet in LDS in slice order.  (A thread per element walking all partials alone was 250 us of dependent
+// loads -- three times the streaming pass it finishes.)
+__global__ __launch_bounds__(1024) void nhwc_gram64_reduce_kernel(int nparts, const float* __restrict__ part_s2,
+                                                                   const float* __restrict__ part_s1,
+                                                                   double* __restrict__ s2, double* __restrict__ s1) {
+  __shared__ double red[16][64];
+  const int el = threadIdx.x & 63, sl = threadIdx.x >> 6;
+  const int e = blockIdx.x * 64 + el;                      // 0 .. 4095: s2; 4096 .. 4159: s1
+  const bool is2 = e < kGramC * kGramC;
+  const float* src = is2 ? part_s2 + e : part_s1 + (e - kGramC * kGramC);
+  const size_t pitch = is2 ? (size_t)kGramC * kGramC : (size_t)kGramC;
+  double a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  int k = sl;
+  for (; k + 7 * 16 < nparts; k += 8 * 16) {
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = src[(size_t)(k + 16 * j) * pitch];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) a[j] += (double)v[j];
+  }
+  for (; k < nparts; k += 16) a[0] += (double)src[(size_t)k * pitch];
+  red[sl][el] = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
+  __syncthreads();
+  if (sl == 0) {
+    double t = 0.0;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) t += red[j][el];
+    if (is2) s2[e] = t; else s1[e - kGramC * kGramC] = t;
+  }
+}
+
+// out[p][j] = c0[j] + sum_i u[p][i] * a[j][i]   (rows x 64) x (64 x 64)^T: one wave = 32 pixels x 64 output channels per
+// chunk, the A^T fragments (64 registers) loaded once; u staged through LDS ([pixel][channel], odd pitch), the output
+// leaves as 128-byte runs (a half-wave writes 32 consecutive channels of one pixel)
+__global__ __launch_bounds__(kThreads) void nhwc_rowmix64_kernel(long long rows, const float* __restrict__ u,
+                                                                 const float* __restrict__ a, const float* __restrict__ c0,
+                                                                 float* __restrict__ out) {
+  constexpr int LD = kGramC + 1;
+  __shared__ float tile[2][128][LD];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int l31 = lane & 31, half = lane >> 5;
+  float bfrag[2][32];                       // B[k = i][n = j] = a[j][i]: j = 32 t + l31, i = 2 s + half
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int s2 = 0; s2 < 32; ++s2) bfrag[t][s2] = a[(size_t)(32 * t + l31) * kGramC + 2 * s2 + half];
+  const float cj0 = c0[l31], cj1 = c0[32 + l31];
+  const long long nblk = (rows + 127) / 128;
+  float4 stage[8];                          // 128 x 64 floats = 2048 float4 = 8 per thread
+  auto load = [&](long long blk) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int e = tid + kThreads * i;
+      const long long row = blk * 128 + e / 16;
+      stage[i] = row < rows ? *reinterpret_cast<const float4*>(u + row * kGramC + (e % 16) * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  };
+  auto put = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int e = tid + kThreads * i;
+      float* d = &tile[buf][e / 16][(e % 16) * 4];
+      d[0] = stage[i].x; d[1] = stage[i].y; d[2] = stage[i].z; d[3] = stage[i].w;
+    }
+  };
+  long long blk = blockIdx.x;
+  if (blk < nblk) { load(blk); put(0); }
+  __syncthreads();
+  int buf = 0;
+  for (; blk < nblk; blk += gridDim.x, buf ^= 1) {
+    const long long nxt = blk + gridDim.x < nblk ? blk + gridDim.x : blk;
+    load(nxt);
+    f32x16 acc0, acc1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+    const float* ap = &tile[buf][32 * wv + l31][half];      // A[m = pixel][k = i]
+#pragma unroll
+    for (int s2 = 0; s2 < 32; ++s2) {
+      const float av = ap[2 * s2];
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bfrag[0][s2], acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bfrag[1][s2], acc1, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const long long row = blk * 128 + 32 * wv + mfma_row(r, lane);
+      if (row < rows) {
+        out[row * kGramC + l31] = acc0[r] + cj0;
+        out[row * kGramC + 32 + l31] = acc1[r] + cj1;
+      }
+    }
+    if (blk + gridDim.x < nblk) put(buf ^ 1);
+    __syncthreads();
+  }
+}
+
 extern "C" {
 
 int istnet_prelu_bwd_parts(long long n) {
@@ -536,6 +712,30 @@ int istnet_nhwc_bn_prelu_bwd_apply(int b, long long hw, int c, const float* y, c
                      reinterpret_cast<const float4*>(mask), reinterpret_cast<const float4*>(bwdc),
                      reinterpret_cast<const float4*>(bwdc + c), reinterpret_cast<const float4*>(bwdc + 2 * c),
                      reinterpret_cast<float4*>(dy));
+  return (int)hipGetLastError();
+}
+
+int istnet_nhwc_gram64_parts(long long rows) {
+  long long parts = (rows + 32 * 36 - 1) / (32 * 36);            // >= 36 chunks of 32 pixels per workgroup
+  return (int)(parts < 1 ? 1 : (parts > 512 ? 512 : parts));
+}
+
+int istnet_nhwc_gram64(long long rows, const float* u, float* part_s2, float* part_s1, double* s2, double* s1, void* stream) {
+  if (rows <= 0 || !u || !part_s2 || !part_s1 || !s2 || !s1 || ((uintptr_t)u & 15)) return ISTNET_PN2_EINVAL;
+  const int nparts = istnet_nhwc_gram64_parts(rows);
+  const long long rows_per = ((rows + nparts - 1) / nparts + 31) / 32 * 32;
+  hipLaunchKernelGGL(nhwc_gram64_kernel, dim3(nparts), dim3(kThreads), 0, (hipStream_t)stream, rows, rows_per, u, part_s2,
+                     part_s1);
+  hipLaunchKernelGGL(nhwc_gram64_reduce_kernel, dim3((kGramC * kGramC + kGramC) / 64), dim3(1024), 0, (hipStream_t)stream,
+                     nparts, part_s2, part_s1, s2, s1);
+  return (int)hipGetLastError();
+}
+
+int istnet_nhwc_rowmix64(long long rows, const float* u, const float* a, const float* c0, float* out, void* stream) {
+  if (rows <= 0 || !u || !a || !c0 || !out || (((uintptr_t)u | (uintptr_t)out) & 15)) return ISTNET_PN2_EINVAL;
+  long long blocks = (rows + 127) / 128;
+  if (blocks > 1024) blocks = 1024;
+  hipLaunchKernelGGL(nhwc_rowmix64_kernel, dim3((unsigned)blocks), dim3(kThreads), 0, (hipStream_t)stream, rows, u, a, c0, out);
   return (int)hipGetLastError();
 }
 

@@ -591,10 +591,29 @@ class PSPUpsample(nn.Module):
 USE_TRAIN_GATHER_FIRST = True    # training: `final` at the chosen pixels only, batch statistics from the moments of its input
 
 
+USE_NATIVE_MOMENTS = True     # _FinalAtChosenFn: moments and the dense affine backward by include/istnet_rgb.h's MFMA kernels (C = 64)
+
+
 def _moments(rows):
-    """sum_p u_p (C) and sum_p u_p u_p^T (C, C) of rows (P, C): the reduction over P as a batch of slice products (the
-    library under-fills the chip on a (C, P) x (P, C) product, see _PointMixFn), summed in a fixed order."""
+    """sum_p u_p (C) and sum_p u_p u_p^T (C, C) of rows (P, C).  CUDA, C = 64 (the decoder's last stage), contiguous rows:
+    one streaming pass (istnet_nhwc_gram64: fp32-MFMA Gram partials per workgroup, summed in float64 in a fixed order;
+    returns float64).  Otherwise the reduction over P as a batch of slice products (the library under-fills the chip on a
+    (C, P) x (P, C) product, see _PointMixFn), summed in a fixed order."""
     p, c = rows.shape
+    if (USE_NATIVE_MOMENTS and rows.is_cuda and rows.dtype == torch.float32 and c == 64 and rows.is_contiguous()
+            and rows.data_ptr() % 16 == 0):
+        from . import _native
+        lib = _native.lib()
+        nparts = lib.istnet_nhwc_gram64_parts(p)
+        part2 = torch.empty((nparts, 64, 64), dtype=torch.float32, device=rows.device)
+        part1 = torch.empty((nparts, 64), dtype=torch.float32, device=rows.device)
+        s2 = torch.empty((64, 64), dtype=torch.float64, device=rows.device)
+        s1 = torch.empty((64,), dtype=torch.float64, device=rows.device)
+        with torch.cuda.device(rows.device):
+            _native.check(lib.istnet_nhwc_gram64(p, rows.data_ptr(), part2.data_ptr(), part1.data_ptr(), s2.data_ptr(),
+                                                 s1.data_ptr(), torch.cuda.current_stream(rows.device).cuda_stream),
+                          "nhwc_gram64")
+        return s1, s2
     s = 32 if p >= 200000 else 16
     if p % s == 0 and p // s >= 256:
         v = rows.view(s, p // s, c)
@@ -665,7 +684,17 @@ class _FinalAtChosenFn(torch.autograd.Function):
         amat = (wd.t() * k) @ wd                                           # W^T diag(k) W  (C, C)
         c0 = wd.t() @ off
         rows = u.permute(0, 2, 3, 1).reshape(npix, c)
-        du = torch.addmm(c0.to(rows.dtype), rows, amat.to(rows.dtype).t())               # dense: A u_p + c0, (P, C)
+        if (USE_NATIVE_MOMENTS and rows.is_cuda and rows.dtype == torch.float32 and c == 64 and rows.is_contiguous()
+                and rows.data_ptr() % 16 == 0):
+            from . import _native
+            du = torch.empty_like(rows)
+            a32, c32 = amat.to(torch.float32).contiguous(), c0.to(torch.float32).contiguous()
+            with torch.cuda.device(rows.device):
+                _native.check(_native.lib().istnet_nhwc_rowmix64(
+                    npix, rows.data_ptr(), a32.data_ptr(), c32.data_ptr(), du.data_ptr(),
+                    torch.cuda.current_stream(rows.device).cuda_stream), "nhwc_rowmix64")
+        else:
+            du = torch.addmm(c0.to(rows.dtype), rows, amat.to(rows.dtype).t())           # dense: A u_p + c0, (P, C)
         du = du.view(b, h * w, c)
         du.scatter_add_(1, choose.unsqueeze(-1).expand(-1, -1, c), torch.matmul(dz, w2).view(b, n, c))
         du = du.view(b, h, w, c).permute(0, 3, 1, 2)                       # (B, C, H, W), channels-last

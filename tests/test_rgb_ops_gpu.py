@@ -363,3 +363,36 @@ def test_fused_trunk_batchnorm_relu_of_a_basic_block(inplanes, planes, stride, h
     blk.eval(); ref.eval()
     with torch.no_grad():
         assert rel(blk(x), ref(x.double())) < 1e-5
+
+
+@pytest.mark.parametrize("rows", [32, 1000, 4096 + 17, 36864])
+def test_gram64_and_rowmix64_against_float64(rows):
+    """include/istnet_rgb.h's two MFMA passes of the training-mode `final`-at-the-chosen-pixels stage (reference
+    model/modules.py:63-67 over every pixel): first and second moments of a (rows, 64) channels-last map -- float64 out,
+    compared with a float64 evaluation -- and the dense affine backward out = u A^T + c0; ragged row counts included
+    (the last chunk / block is partly empty)."""
+    import ctypes
+    from istnet_amd import _native
+    lib = _native.lib()
+    g = torch.Generator().manual_seed(rows)
+    u = (torch.randn(rows, 64, generator=g) * 0.7 + 0.3).to(DEV)
+    s1, s2 = rgb_branch._moments(u)
+    assert s1.dtype == torch.float64 and s2.dtype == torch.float64
+    ud = u.double()
+    torch.testing.assert_close(s1, ud.sum(0), rtol=1e-6, atol=1e-6 * rows ** 0.5)
+    torch.testing.assert_close(s2, ud.t() @ ud, rtol=2e-6, atol=2e-6 * rows ** 0.5)
+    a = (torch.randn(64, 64, generator=g) * 0.1).to(DEV)
+    c0 = torch.randn(64, generator=g).to(DEV)
+    out = torch.empty_like(u)
+    _native.check(lib.istnet_nhwc_rowmix64(rows, u.data_ptr(), a.data_ptr(), c0.data_ptr(), out.data_ptr(),
+                                           torch.cuda.current_stream().cuda_stream), "nhwc_rowmix64")
+    want = (ud @ a.double().t() + c0.double())
+    torch.testing.assert_close(out.double(), want, rtol=1e-5, atol=1e-5)
+    # the slice-product fallback agrees with the native pass
+    rgb_branch.USE_NATIVE_MOMENTS = False
+    try:
+        f1, f2 = rgb_branch._moments(u)
+    finally:
+        rgb_branch.USE_NATIVE_MOMENTS = True
+    torch.testing.assert_close(f1.double(), s1, rtol=1e-5, atol=1e-4 * rows ** 0.5)
+    torch.testing.assert_close(f2.double(), s2, rtol=1e-5, atol=1e-4 * rows ** 0.5)

@@ -1,7 +1,3 @@
-mkdir -p gpurun_out/r04
-O=gpurun_out/r04
-bash tools/pmc_traffic.sh r04 > $O/pmc_traffic.txt 2>&1
-cp gpurun_out/pmc_r04_traffic.json $O/pmc_traffic.json
-rm -rf gpurun_out/pmc_r04_FETCH_SIZE gpurun_out/pmc_r04_WRITE_SIZE
-tail -5 $O/pmc_traffic.txt | cut -c1-160
-python -m pytest tests -m gpu -q 2>&1 | grep -v "Warning:\|warnings.warn\|amdgpu.ids\|shared_mlp_maxpool\|^$\|^tests/" | tail -6 > $O/gpu_tests.txt; tail -2 $O/gpu_tests.txt
+run() { echo -n "$1: "; env $1 python bench.py --workload istnet --no-roofline --steps 20 --warmup 5 2>/tmp/err.txt | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(round(d['ms_per_step'],3))" || tail -5 /tmp/err.txt; }
+run "ISTNET_RGB_LAST=1"; run "ISTNET_RGB_LAST=0"; run "ISTNET_RGB_LAST=1"
+ISTNET_SCALE_STREAMS=0 ISTNET_DEFERRED_WGRAD=0 python tools/istnet_step_timeline.py 2>/dev/null | head -60
