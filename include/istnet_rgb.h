@@ -94,6 +94,26 @@ ISTNET_PN2_API int istnet_nhwc_gram64(long long rows, const float *u, float *par
 ISTNET_PN2_API int istnet_nhwc_rowmix64(long long rows, const float *u, const float *a, const float *c0, float *out,
                                         void *stream);
 
+/* The whole stage in two calls (round 4; rgb_branch._FinalAtChosenFn, reference model/modules.py:63-67 evaluated at the pixels
+ * of model/ist_net.py:41-45).  u: (b, hw, 64) channels-last input of the stage, choose: (b, n) int64 flat pixel indices,
+ * w: (cout, 64) the 1x1 convolution, cout <= 512, one PReLU slope.  forward: moments (as above) -> batch statistics
+ * stat[3][cout] float64 (mean, 1/sqrt(var + eps), var; running statistics updated with *momentum_p when given) -> y and
+ * zhat (b, cout, n).  backward: dy (b, cout, n) -> du (b, hw, 64) (every pixel: A u_p + c0; the chosen ones also dz W, added
+ * atomically because a pixel may be chosen twice), dw, db, dgamma, dbeta, dslope.  Work buffers: part [3][cout][b] float,
+ * bwdc [4][cout] double, amat [64][64], c0 [64], dwp [istnet_final_chosen_workgroups(b*n)][cout][64] float. */
+ISTNET_PN2_API int istnet_final_chosen_workgroups(long long rows);
+ISTNET_PN2_API int istnet_final_chosen_forward(int b, long long hw, int n, int cout, const float *u, const long long *choose,
+                                               const float *w, const float *bias, const float *gamma, const float *beta,
+                                               const float *slope, float *running_mean, float *running_var,
+                                               const float *momentum_p, double eps, float *part_s2, float *part_s1, double *s2,
+                                               double *s1, double *stat, float *y, float *zhat, void *stream);
+ISTNET_PN2_API int istnet_final_chosen_backward(int b, long long hw, int n, int cout, const float *u, const long long *choose,
+                                                const float *w, const float *bias, const float *gamma, const float *beta,
+                                                const float *slope, const double *s2, const double *s1, const double *stat,
+                                                const float *dy, const float *zhat, float *part, double *bwdc, float *amat,
+                                                float *c0, float *dwp, float *du, float *dw, float *db, float *dgamma,
+                                                float *dbeta, float *dslope, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -28,6 +28,9 @@ SIGNATURES = {
     "istnet_nhwc_gram64_parts": [_l],
     "istnet_nhwc_gram64": [_l, _p, _p, _p, _p, _p, _p],
     "istnet_nhwc_rowmix64": [_l, _p, _p, _p, _p, _p],
+    "istnet_final_chosen_workgroups": [_l],
+    "istnet_final_chosen_forward": [_i, _l, _i, _i] + [_p] * 10 + [_d] + [_p] * 8,
+    "istnet_final_chosen_backward": [_i, _l, _i, _i] + [_p] * 24,
     "istnet_nhwc_stat_parts": [_l],
     "istnet_nhwc_channel_stats": [_l, _i, _p, _p, _p, _p],
     "istnet_nhwc_bn_prelu_apply": [_i, _l, _i, _p, _p, _p, _p, _p, _p],

@@ -568,6 +568,306 @@ __global__ __launch_bounds__(kThreads) void nhwc_rowmix64_kernel(long long rows,
   }
 }
 
+// ---- the rest of the final-at-chosen stage (rgb_branch._FinalAtChosenFn): everything between the moments and the
+// stage's outputs / gradients, which was ~85 framework launches of small float64 algebra per step ----
+constexpr int kFinC = 64;          // input channels of the stage (the decoder's last PSPUpsample)
+constexpr int kFinMaxOut = 512;    // output channels handled (the model has 128)
+
+__device__ __forceinline__ double wave_sum64d(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  return v;
+}
+
+// batch statistics of z = W u + b over all `npix` pixels from the moments of u; grid = cout workgroups of 64 threads.
+// stat[0][c] = mean, stat[1][c] = 1 / sqrt(var + eps), stat[2][c] = biased var (float64); running statistics updated as
+// BatchNorm2d does (momentum read from device memory, unbiased variance).
+__global__ __launch_bounds__(64) void final_stats_kernel(int cout, double npix, double eps, const double* __restrict__ s1,
+                                                         const double* __restrict__ s2, const float* __restrict__ w,
+                                                         const float* __restrict__ bias, const float* __restrict__ momentum_p,
+                                                         float* __restrict__ running_mean, float* __restrict__ running_var,
+                                                         double* __restrict__ stat) {
+  __shared__ double wc[kFinC], mu_u[kFinC];
+  const int c = blockIdx.x, j = threadIdx.x;
+  wc[j] = (double)w[(size_t)c * kFinC + j];
+  mu_u[j] = s1[j] / npix;
+  __syncthreads();
+  double t = 0.0;                    // (Cov w_c)[j]
+  for (int i = 0; i < kFinC; ++i) t += (s2[(size_t)i * kFinC + j] / npix - mu_u[j] * mu_u[i]) * wc[i];    // S2 is symmetric
+  double var = wave_sum64d(wc[j] * t);
+  double mean = wave_sum64d(wc[j] * mu_u[j]);
+  if (j == 0) {
+    mean += (double)bias[c];
+    var = var > 0.0 ? var : 0.0;
+    stat[c] = mean;
+    stat[cout + c] = 1.0 / sqrt(var + eps);
+    stat[2 * cout + c] = var;
+    if (running_mean) {
+      const float m = *momentum_p;
+      const float unb = (float)(var * (npix / (npix > 1.0 ? npix - 1.0 : 1.0)));
+      running_mean[c] = running_mean[c] + m * ((float)mean - running_mean[c]);      // lerp(start, end, w), as the framework
+      running_var[c] = running_var[c] + m * (unb - running_var[c]);
+    }
+  }
+}
+
+// z = W u_sel + b at the chosen pixels -> zhat = (z - mean) istd, y = prelu(zhat gamma + beta); y and zhat leave as
+// (B, Cout, N).  One workgroup = 64 rows (b, n); a thread = one row x 32 output channels per pass of 128 channels.
+__global__ __launch_bounds__(kThreads) void final_chosen_fwd_kernel(
+    int n, long long hw, int cout, long long rows, const float* __restrict__ u, const long long* __restrict__ choose,
+    const float* __restrict__ w, const float* __restrict__ bias, const double* __restrict__ stat,
+    const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ slope_p,
+    float* __restrict__ y, float* __restrict__ zhat) {
+  __shared__ float ut[64][kFinC + 1];
+  __shared__ __attribute__((aligned(16))) float wt[kFinC][128];          // W^T of the current 128-channel block
+  const int tid = threadIdx.x, r = tid & 63, cg = tid >> 6;
+  const long long row0 = (long long)blockIdx.x * 64;
+  for (int e = tid; e < 64 * 16; e += kThreads) {                        // gather 64 rows x 64 channels (float4 pieces)
+    const long long row = row0 + e / 16;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (row < rows) {
+      const long long b = row / n, pix = choose[row];
+      v = *reinterpret_cast<const float4*>(u + ((size_t)b * hw + pix) * kFinC + (e % 16) * 4);
+    }
+    float* d = &ut[e / 16][(e % 16) * 4];
+    d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+  }
+  const float slope = *slope_p;
+  const long long row = row0 + r;
+  const long long b = row / n, nn = row % n;
+  for (int cb = 0; cb < cout; cb += 128) {
+    __syncthreads();
+    for (int e = tid; e < 128 * kFinC; e += kThreads) {                  // wt[k][c] = w[cb + c][k] (32 KB, L2-resident)
+      const int k = e / 128, c = e % 128;
+      wt[k][c] = cb + c < cout ? w[(size_t)(cb + c) * kFinC + k] : 0.f;
+    }
+    __syncthreads();
+    float acc[32];
+#pragma unroll
+    for (int q = 0; q < 32; ++q) acc[q] = 0.f;
+#pragma unroll 4
+    for (int k = 0; k < kFinC; ++k) {
+      const float uv = ut[r][k];
+      const float4* wr = reinterpret_cast<const float4*>(&wt[k][cg * 32]);
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const float4 wv = wr[q];
+        acc[4 * q + 0] = fmaf(uv, wv.x, acc[4 * q + 0]);
+        acc[4 * q + 1] = fmaf(uv, wv.y, acc[4 * q + 1]);
+        acc[4 * q + 2] = fmaf(uv, wv.z, acc[4 * q + 2]);
+        acc[4 * q + 3] = fmaf(uv, wv.w, acc[4 * q + 3]);
+      }
+    }
+    if (row < rows) {
+#pragma unroll
+      for (int q = 0; q < 32; ++q) {
+        const int c = cb + cg * 32 + q;
+        if (c < cout) {
+          const float z = acc[q] + bias[c];
+          const float zh = (z - (float)stat[c]) * (float)stat[cout + c];
+          const float v = zh * gamma[c] + beta[c];
+          const size_t o = ((size_t)b * cout + c) * n + nn;
+          zhat[o] = zh;
+          y[o] = v > 0.f ? v : v * slope;
+        }
+      }
+    }
+  }
+}
+
+// per (channel, batch entry): sums over the N chosen pixels of gv, gv zhat and g v [v <= 0]  (g = dL/dy, v = zhat gamma +
+// beta, gv = g (v > 0 ? 1 : slope)); part[3][cout][b]
+__global__ __launch_bounds__(kThreads) void final_chosen_bwd_sums_kernel(int n, int cout, int nb, const float* __restrict__ dy,
+                                                                         const float* __restrict__ zhat,
+                                                                         const float* __restrict__ gamma,
+                                                                         const float* __restrict__ beta,
+                                                                         const float* __restrict__ slope_p,
+                                                                         float* __restrict__ part) {
+  __shared__ float red[3][kThreads / 64];
+  const int c = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+  const float ga = gamma[c], be = beta[c], slope = *slope_p;
+  const size_t base = ((size_t)b * cout + c) * n;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+  for (int i = tid; i < n; i += kThreads) {
+    const float g = dy[base + i], zh = zhat[base + i];
+    const float v = zh * ga + be;
+    const bool neg = v <= 0.f;
+    const float gv = neg ? g * slope : g;
+    s0 += gv; s1 += gv * zh; s2 += neg ? g * v : 0.f;
+  }
+  s0 = wave_sum64(s0); s1 = wave_sum64(s1); s2 = wave_sum64(s2);
+  if ((tid & 63) == 0) { red[0][tid >> 6] = s0; red[1][tid >> 6] = s1; red[2][tid >> 6] = s2; }
+  __syncthreads();
+  if (tid < 3) {
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < kThreads / 64; ++k) t += red[tid][k];
+    part[((size_t)tid * cout + c) * nb + b] = t;
+  }
+}
+
+// the constants of the backward pass; grid = 64 workgroups (row i of A) of 64 threads (column j).  Every workgroup reduces
+// the per-batch partial sums itself (fixed order, float64).  bwdc (float64) [4][cout] = a, k, bias - mean, dz scale
+// (gamma istd); A = W^T diag(k) W and c0 = W^T (a + k (bias - mean)) as float32 for the dense pass; workgroup 0 writes
+// dgamma, dbeta, dslope.
+__global__ __launch_bounds__(64) void final_bwd_consts_kernel(int cout, int nb, double npix, const float* __restrict__ part,
+                                                              const float* __restrict__ w, const float* __restrict__ bias,
+                                                              const float* __restrict__ gamma, const double* __restrict__ stat,
+                                                              double* __restrict__ bwdc, float* __restrict__ amat,
+                                                              float* __restrict__ c0, float* __restrict__ dgamma,
+                                                              float* __restrict__ dbeta, float* __restrict__ dslope) {
+  __shared__ double kk[kFinMaxOut], off[kFinMaxOut];
+  const int i = blockIdx.x, j = threadIdx.x;
+  double dsl = 0.0;
+  for (int c = j; c < cout; c += 64) {
+    double p0 = 0.0, p1 = 0.0, p2 = 0.0;
+    for (int b = 0; b < nb; ++b) {
+      p0 += (double)part[((size_t)0 * cout + c) * nb + b];
+      p1 += (double)part[((size_t)1 * cout + c) * nb + b];
+      p2 += (double)part[((size_t)2 * cout + c) * nb + b];
+    }
+    dsl += p2;
+    const double istd = stat[cout + c], ga = (double)gamma[c];
+    const double a = -(istd * (ga * p0)) / npix;                  // dL/dmean / P
+    const double k = -(istd * istd) * (ga * p1) / npix;           // 2 dL/dvar / P
+    const double d = (double)bias[c] - stat[c];
+    kk[c] = k;
+    off[c] = a + k * d;
+    if (i == 0) {
+      bwdc[c] = a; bwdc[cout + c] = k; bwdc[2 * cout + c] = d; bwdc[3 * cout + c] = ga * istd;
+      dbeta[c] = (float)p0; dgamma[c] = (float)p1;
+    }
+  }
+  dsl = wave_sum64d(dsl);
+  if (i == 0 && j == 0) *dslope = (float)dsl;
+  __syncthreads();
+  double t = 0.0, t0 = 0.0;
+  for (int c = 0; c < cout; ++c) {
+    const double wi = (double)w[(size_t)c * kFinC + i], wj = (double)w[(size_t)c * kFinC + j];
+    t += wi * kk[c] * wj;
+    t0 += wj * off[c];
+  }
+  amat[(size_t)i * kFinC + j] = (float)t;
+  if (i == 0) c0[j] = (float)t0;
+}
+
+// the direct path: dz = gv gamma istd at the chosen pixels; du[pixel] += dz W (atomic: a pixel may be chosen twice) and
+// the partial weight gradient dwp[workgroup][c][i] = sum_rows dz[row][c] u_sel[row][i].  A workgroup walks tiles of 64
+// rows; cout <= 128 per pass of the channel loop.
+__global__ __launch_bounds__(kThreads) void final_chosen_bwd_rows_kernel(
+    int n, long long hw, int cout, long long rows, const float* __restrict__ u, const long long* __restrict__ choose,
+    const float* __restrict__ w, const float* __restrict__ dy, const float* __restrict__ zhat,
+    const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ slope_p,
+    const double* __restrict__ bwdc, float* __restrict__ du, float* __restrict__ dwp) {
+  __shared__ float ut[64][kFinC + 1];
+  __shared__ float dzt[128][65];                                          // [c][row]
+  __shared__ __attribute__((aligned(16))) float wl[128][kFinC];           // W rows of the current channel block
+  const int tid = threadIdx.x, lo = tid & 63, hi = tid >> 6;
+  const float slope = *slope_p;
+  const long long ntiles = (rows + 63) / 64;
+  for (int cb = 0; cb < cout; cb += 128) {
+    __syncthreads();
+    for (int e = tid; e < 128 * kFinC; e += kThreads) wl[e / kFinC][e % kFinC] = cb + e / kFinC < cout ? w[(size_t)cb * kFinC + e] : 0.f;
+    float dwa[32];                                                        // thread: i = lo, channels hi*32 .. +31
+#pragma unroll
+    for (int q = 0; q < 32; ++q) dwa[q] = 0.f;
+    for (long long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+      const long long row0 = tile * 64;
+      __syncthreads();
+      for (int e = tid; e < 64 * 16; e += kThreads) {
+        const long long row = row0 + e / 16;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (row < rows) v = *reinterpret_cast<const float4*>(u + ((size_t)(row / n) * hw + choose[row]) * kFinC + (e % 16) * 4);
+        float* d = &ut[e / 16][(e % 16) * 4];
+        d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+      }
+      {                                                                   // dz tile: lanes = rows (contiguous n), 32 channels per wave
+        const long long row = row0 + lo;
+        const long long b = row / n, nn = row % n;
+#pragma unroll 4
+        for (int q = 0; q < 32; ++q) {
+          const int cl = hi * 32 + q, c = cb + cl;
+          float dz = 0.f;
+          if (row < rows && c < cout) {
+            const size_t o = ((size_t)b * cout + c) * n + nn;
+            const float g = dy[o], zh = zhat[o];
+            const float v = zh * gamma[c] + beta[c];
+            dz = (v <= 0.f ? g * slope : g) * (float)bwdc[3 * cout + c];
+          }
+          dzt[cl][lo] = dz;
+        }
+      }
+      __syncthreads();
+      {                                                                   // du_sel[row][i]: row = lo, i = hi*16 .. +15
+        float acc[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc[q] = 0.f;
+#pragma unroll 4
+        for (int c = 0; c < 128; ++c) {
+          const float dv = dzt[c][lo];
+          const float4* wr = reinterpret_cast<const float4*>(&wl[c][hi * 16]);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const float4 wv = wr[q];
+            acc[4 * q + 0] = fmaf(dv, wv.x, acc[4 * q + 0]);
+            acc[4 * q + 1] = fmaf(dv, wv.y, acc[4 * q + 1]);
+            acc[4 * q + 2] = fmaf(dv, wv.z, acc[4 * q + 2]);
+            acc[4 * q + 3] = fmaf(dv, wv.w, acc[4 * q + 3]);
+          }
+        }
+        const long long row = row0 + lo;
+        if (row < rows) {
+          float* d = du + ((size_t)(row / n) * hw + choose[row]) * kFinC + hi * 16;
+#pragma unroll
+          for (int q = 0; q < 16; ++q) atomicAdd(d + q, acc[q]);
+        }
+      }
+#pragma unroll 2
+      for (int rr = 0; rr < 64; ++rr) {                                   // dw partial: i = lo, channels hi*32 .. +31
+        const float uv = ut[rr][lo];
+#pragma unroll
+        for (int q = 0; q < 32; ++q) dwa[q] = fmaf(dzt[hi * 32 + q][rr], uv, dwa[q]);
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < 32; ++q) {
+      const int c = cb + hi * 32 + q;
+      if (c < cout) dwp[((size_t)blockIdx.x * cout + c) * kFinC + lo] = dwa[q];
+    }
+  }
+}
+
+// dW = sum of the partials + a s1^T + k (W S2 + (bias - mean) s1^T),  db = sum dz + P a + k (W s1 + P (bias - mean));
+// grid = cout workgroups of 64 threads (column i)
+__global__ __launch_bounds__(64) void final_bwd_params_kernel(int cout, int nwg, int nb, double npix, const float* __restrict__ dwp,
+                                                              const float* __restrict__ part, const double* __restrict__ bwdc,
+                                                              const float* __restrict__ w, const double* __restrict__ s1,
+                                                              const double* __restrict__ s2, float* __restrict__ dw,
+                                                              float* __restrict__ db) {
+  const int c = blockIdx.x, i = threadIdx.x;
+  double acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  int g = 0;
+  for (; g + 8 <= nwg; g += 8) {
+    float v[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) v[q] = dwp[((size_t)(g + q) * cout + c) * kFinC + i];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) acc[q] += (double)v[q];
+  }
+  for (; g < nwg; ++g) acc[0] += (double)dwp[((size_t)g * cout + c) * kFinC + i];
+  double direct = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
+  const double a = bwdc[c], k = bwdc[cout + c], d = bwdc[2 * cout + c];
+  double ws2 = 0.0;
+  for (int j = 0; j < kFinC; ++j) ws2 += (double)w[(size_t)c * kFinC + j] * s2[(size_t)j * kFinC + i];
+  dw[(size_t)c * kFinC + i] = (float)(direct + a * s1[i] + k * (ws2 + d * s1[i]));
+  const double ws1 = wave_sum64d((double)w[(size_t)c * kFinC + i] * s1[i]);
+  if (i == 0) {
+    double p0 = 0.0;
+    for (int b = 0; b < nb; ++b) p0 += (double)part[(size_t)c * nb + b];
+    db[c] = (float)(bwdc[3 * cout + c] * p0 + npix * a + k * (ws1 + npix * d));
+  }
+}
+
 extern "C" {
 
 int istnet_prelu_bwd_parts(long long n) {
@@ -736,6 +1036,53 @@ int istnet_nhwc_rowmix64(long long rows, const float* u, const float* a, const f
   long long blocks = (rows + 127) / 128;
   if (blocks > 1024) blocks = 1024;
   hipLaunchKernelGGL(nhwc_rowmix64_kernel, dim3((unsigned)blocks), dim3(kThreads), 0, (hipStream_t)stream, rows, u, a, c0, out);
+  return (int)hipGetLastError();
+}
+
+int istnet_final_chosen_workgroups(long long rows) {
+  long long tiles = (rows + 63) / 64;
+  return (int)(tiles < 1 ? 1 : (tiles > 256 ? 256 : tiles));
+}
+
+int istnet_final_chosen_forward(int b, long long hw, int n, int cout, const float* u, const long long* choose, const float* w,
+                                const float* bias, const float* gamma, const float* beta, const float* slope,
+                                float* running_mean, float* running_var, const float* momentum_p, double eps, float* part_s2,
+                                float* part_s1, double* s2, double* s1, double* stat, float* y, float* zhat, void* stream) {
+  if (b <= 0 || hw <= 0 || n <= 0 || cout <= 0 || cout > kFinMaxOut || !u || !choose || !w || !bias || !gamma || !beta ||
+      !slope || !part_s2 || !part_s1 || !s2 || !s1 || !stat || !y || !zhat || ((uintptr_t)u & 15) ||
+      ((running_mean || running_var) && (!running_mean || !running_var || !momentum_p)))
+    return ISTNET_PN2_EINVAL;
+  const long long npix = (long long)b * hw, rows = (long long)b * n;
+  const int rc = istnet_nhwc_gram64(npix, u, part_s2, part_s1, s2, s1, stream);
+  if (rc) return rc;
+  hipLaunchKernelGGL(final_stats_kernel, dim3(cout), dim3(64), 0, (hipStream_t)stream, cout, (double)npix, eps, s1, s2, w, bias,
+                     momentum_p, running_mean, running_var, stat);
+  hipLaunchKernelGGL(final_chosen_fwd_kernel, dim3((unsigned)((rows + 63) / 64)), dim3(kThreads), 0, (hipStream_t)stream, n, hw,
+                     cout, rows, u, choose, w, bias, stat, gamma, beta, slope, y, zhat);
+  return (int)hipGetLastError();
+}
+
+int istnet_final_chosen_backward(int b, long long hw, int n, int cout, const float* u, const long long* choose, const float* w,
+                                 const float* bias, const float* gamma, const float* beta, const float* slope, const double* s2,
+                                 const double* s1, const double* stat, const float* dy, const float* zhat, float* part,
+                                 double* bwdc, float* amat, float* c0, float* dwp, float* du, float* dw, float* db,
+                                 float* dgamma, float* dbeta, float* dslope, void* stream) {
+  if (b <= 0 || hw <= 0 || n <= 0 || cout <= 0 || cout > kFinMaxOut || !u || !choose || !w || !bias || !gamma || !beta ||
+      !slope || !s2 || !s1 || !stat || !dy || !zhat || !part || !bwdc || !amat || !c0 || !dwp || !du || !dw || !db ||
+      !dgamma || !dbeta || !dslope || (((uintptr_t)u | (uintptr_t)du) & 15))
+    return ISTNET_PN2_EINVAL;
+  const long long npix = (long long)b * hw, rows = (long long)b * n;
+  const int nwg = istnet_final_chosen_workgroups(rows);
+  hipLaunchKernelGGL(final_chosen_bwd_sums_kernel, dim3(cout, b), dim3(kThreads), 0, (hipStream_t)stream, n, cout, b, dy, zhat,
+                     gamma, beta, slope, part);
+  hipLaunchKernelGGL(final_bwd_consts_kernel, dim3(kFinC), dim3(64), 0, (hipStream_t)stream, cout, b, (double)npix, part, w, bias,
+                     gamma, stat, bwdc, amat, c0, dgamma, dbeta, dslope);
+  const int rc = istnet_nhwc_rowmix64(npix, u, amat, c0, du, stream);
+  if (rc) return rc;
+  hipLaunchKernelGGL(final_chosen_bwd_rows_kernel, dim3(nwg), dim3(kThreads), 0, (hipStream_t)stream, n, hw, cout, rows, u, choose,
+                     w, dy, zhat, gamma, beta, slope, bwdc, du, dwp);
+  hipLaunchKernelGGL(final_bwd_params_kernel, dim3(cout), dim3(64), 0, (hipStream_t)stream, cout, nwg, b, (double)npix, dwp, part,
+                     bwdc, w, s1, s2, dw, db);
   return (int)hipGetLastError();
 }
 

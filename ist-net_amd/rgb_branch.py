@@ -621,6 +621,74 @@ def _moments(rows):
     return rows.sum(0), torch.matmul(rows.t(), rows)
 
 
+USE_NATIVE_FINAL_AT_CHOSEN = True   # the whole stage through include/istnet_rgb.h (istnet_final_chosen_*): 9 launches per step
+                                    # instead of ~85 framework launches of small float64 algebra
+
+
+def _final_native_ok(u, choose, weight, slope):
+    return (USE_NATIVE_FINAL_AT_CHOSEN and USE_NATIVE_MOMENTS and u.is_cuda and u.dtype == torch.float32 and u.shape[1] == 64
+            and u.is_contiguous(memory_format=torch.channels_last) and u.data_ptr() % 16 == 0 and weight.shape[0] <= 512
+            and slope.numel() == 1 and choose.dtype == torch.int64)
+
+
+class _FinalAtChosenNativeFn(torch.autograd.Function):
+    """_FinalAtChosenFn (below: the derivation and the framework form) as two calls into include/istnet_rgb.h:
+    istnet_final_chosen_forward (moments -> batch statistics -> y, zhat at the chosen pixels) and
+    istnet_final_chosen_backward (sums -> constants -> dense affine pass -> direct path -> parameter gradients)."""
+
+    @staticmethod
+    def forward(ctx, u, choose, weight, bias, gamma, beta, slope, running_mean, running_var, momentum_ptr, eps):
+        from . import _native
+        lib = _native.lib()
+        b, c, h, w = u.shape
+        n, cout, dev = choose.shape[1], weight.shape[0], u.device
+        choose = choose.contiguous()
+        w2 = weight.reshape(cout, c).contiguous()
+        nparts = lib.istnet_nhwc_gram64_parts(b * h * w)
+        part2 = torch.empty((nparts, 64, 64), dtype=torch.float32, device=dev)
+        part1 = torch.empty((nparts, 64), dtype=torch.float32, device=dev)
+        s2 = torch.empty((64, 64), dtype=torch.float64, device=dev)
+        s1 = torch.empty((64,), dtype=torch.float64, device=dev)
+        stat = torch.empty((3, cout), dtype=torch.float64, device=dev)
+        y = torch.empty((b, cout, n), dtype=torch.float32, device=dev)
+        zhat = torch.empty((b, cout, n), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            _native.check(lib.istnet_final_chosen_forward(
+                b, h * w, n, cout, u.data_ptr(), choose.data_ptr(), w2.data_ptr(), bias.data_ptr(), gamma.data_ptr(),
+                beta.data_ptr(), slope.data_ptr(), running_mean.data_ptr() if running_mean is not None else 0,
+                running_var.data_ptr() if running_mean is not None else 0, momentum_ptr if running_mean is not None else 0,
+                float(eps), part2.data_ptr(), part1.data_ptr(), s2.data_ptr(), s1.data_ptr(), stat.data_ptr(), y.data_ptr(),
+                zhat.data_ptr(), torch.cuda.current_stream(dev).cuda_stream), "final_chosen_forward")
+        ctx.save_for_backward(u, choose, w2, bias, gamma, beta, slope, s1, s2, stat, zhat)
+        ctx.wshape = weight.shape
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        from . import _native
+        lib = _native.lib()
+        u, choose, w2, bias, gamma, beta, slope, s1, s2, stat, zhat = ctx.saved_tensors
+        b, c, h, w = u.shape
+        n, cout, dev = choose.shape[1], w2.shape[0], u.device
+        dy = dy.contiguous()
+        f32 = dict(dtype=torch.float32, device=dev)
+        part = torch.empty((3, cout, b), **f32)
+        bwdc = torch.empty((4, cout), dtype=torch.float64, device=dev)
+        amat, c0 = torch.empty((64, 64), **f32), torch.empty((64,), **f32)
+        dwp = torch.empty((lib.istnet_final_chosen_workgroups(b * n), cout, 64), **f32)
+        du = torch.empty((b, h, w, c), **f32)
+        dw, db = torch.empty((cout, c), **f32), torch.empty((cout,), **f32)
+        dgamma, dbeta, dslope = torch.empty((cout,), **f32), torch.empty((cout,), **f32), torch.empty(slope.shape, **f32)
+        with torch.cuda.device(dev):
+            _native.check(lib.istnet_final_chosen_backward(
+                b, h * w, n, cout, u.data_ptr(), choose.data_ptr(), w2.data_ptr(), bias.data_ptr(), gamma.data_ptr(),
+                beta.data_ptr(), slope.data_ptr(), s2.data_ptr(), s1.data_ptr(), stat.data_ptr(), dy.data_ptr(), zhat.data_ptr(),
+                part.data_ptr(), bwdc.data_ptr(), amat.data_ptr(), c0.data_ptr(), dwp.data_ptr(), du.data_ptr(), dw.data_ptr(),
+                db.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), dslope.data_ptr(),
+                torch.cuda.current_stream(dev).cuda_stream), "final_chosen_backward")
+        return (du.permute(0, 3, 1, 2), None, dw.view(ctx.wshape), db, dgamma, dbeta, dslope, None, None, None, None)
+
+
 class _FinalAtChosenFn(torch.autograd.Function):
     """`final` = Conv2d(1x1) -> BatchNorm2d (train mode) -> PReLU of the decoder, evaluated at the chosen pixels only.
 
@@ -733,9 +801,12 @@ class Modified_PSPNet(nn.Module):
         if choose is not None and self._train_gather_ok(u):
             conv, bn, act = self.final[0], self.final[1], self.final[2]
             _bump_batch_counter(bn)
-            return _FinalAtChosenFn.apply(u, choose, conv.weight, conv.bias, bn.weight, bn.bias, act.weight,
-                                          bn.running_mean if bn.track_running_stats else None,
-                                          bn.running_var if bn.track_running_stats else None,
+            rm = bn.running_mean if bn.track_running_stats else None
+            rv = bn.running_var if bn.track_running_stats else None
+            if _final_native_ok(u, choose, conv.weight, act.weight):
+                return _FinalAtChosenNativeFn.apply(u, choose, conv.weight, conv.bias, bn.weight, bn.bias, act.weight, rm, rv,
+                                                    bn_momentum_ptr(bn, u.device), bn.eps)
+            return _FinalAtChosenFn.apply(u, choose, conv.weight, conv.bias, bn.weight, bn.bias, act.weight, rm, rv,
                                           bn_momentum_tensor(bn, u.device), bn.eps)
         out = self.final(u)
         if choose is None:

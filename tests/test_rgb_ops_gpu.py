@@ -239,6 +239,59 @@ def test_training_mode_final_stage_at_the_chosen_pixels(b, c, cout, h, w, n):
         torch.testing.assert_close(a, r, rtol=1e-3, atol=atol, msg=name)
 
 
+@pytest.mark.parametrize("b,cout,h,w,n", [(2, 128, 48, 48, 256), (3, 96, 10, 14, 40), (32, 128, 32, 32, 64), (2, 132, 9, 9, 70)])
+def test_native_final_stage_at_the_chosen_pixels(b, cout, h, w, n):
+    """istnet_final_chosen_forward / _backward (the whole training-mode `final` stage at the chosen pixels in nine launches,
+    rgb_branch._FinalAtChosenNativeFn) against the dense map followed by the gather (reference order, model/ist_net.py:41-45
+    over model/modules.py:63-67) evaluated in FLOAT64, and against the framework form of the same algebra; ragged sizes
+    (rows not a multiple of the 64-row tile, cout not a multiple of 128 / 32), a pixel chosen three times."""
+    from istnet_amd.pointnet2.pytorch_utils import bn_momentum_ptr
+    c = 64
+    torch.manual_seed(b + cout + n)
+    final = torch.nn.Sequential(torch.nn.Conv2d(c, cout, 1), torch.nn.BatchNorm2d(cout), rgb_branch.PReLU()).to(DEV)
+    final = final.to(memory_format=torch.channels_last).train()
+    with torch.no_grad():
+        final[1].weight.uniform_(0.5, 1.5)
+        final[1].bias.normal_()
+    x = (torch.randn(b, c, h, w, device=DEV) * 0.7 + 0.3).contiguous(memory_format=torch.channels_last)
+    choose = torch.randint(0, h * w, (b, n), device=DEV)
+    choose[0, :3] = 5
+    dy = torch.randn(b, cout, n, device=DEV)
+    ref_mod = torch.nn.Sequential(torch.nn.Conv2d(c, cout, 1), torch.nn.BatchNorm2d(cout), rgb_branch.PReLU()).to(DEV).double().train()
+    ref_mod.load_state_dict({k: v.double() if v.is_floating_point() else v for k, v in final.state_dict().items()})
+    xr = x.double().contiguous().requires_grad_(True)
+    out = ref_mod(xr)
+    ref = torch.gather(out.permute(0, 2, 3, 1).reshape(b, h * w, cout), 1, choose.unsqueeze(-1).expand(-1, -1, cout)).transpose(1, 2)
+    ref.backward(dy.double())
+    want = [xr.grad] + [p.grad for p in ref_mod.parameters()]
+
+    def run(fn, mom):
+        final.zero_grad(set_to_none=True)
+        final[1].running_mean.zero_(); final[1].running_var.fill_(1.0)
+        xa = x.clone(memory_format=torch.preserve_format).requires_grad_(True)
+        got = fn.apply(xa, choose, final[0].weight, final[0].bias, final[1].weight, final[1].bias, final[2].weight,
+                       final[1].running_mean, final[1].running_var, mom, 1e-5)
+        got.backward(dy)
+        return (got.detach(), [xa.grad] + [p.grad.clone() for p in final.parameters()],
+                final[1].running_mean.clone(), final[1].running_var.clone())
+
+    assert rgb_branch._final_native_ok(x, choose, final[0].weight, final[2].weight)
+    y_n, g_n, rm_n, rv_n = run(rgb_branch._FinalAtChosenNativeFn, bn_momentum_ptr(final[1], DEV))
+    y_f, g_f, rm_f, rv_f = run(rgb_branch._FinalAtChosenFn, 0.1)
+    torch.testing.assert_close(y_n.double(), ref, rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(y_n, y_f, rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(rm_n.double(), ref_mod[1].running_mean, rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(rv_n.double(), ref_mod[1].running_var, rtol=1e-5, atol=1e-6)
+    for name, a, f, r in zip(["input", "conv.weight", "conv.bias", "bn.weight", "bn.bias", "prelu.weight"], g_n, g_f, want):
+        scale = float(r.abs().max())
+        # the convolution bias in front of a train-mode BatchNorm has a zero gradient: every value is round-off
+        atol = 1e-3 if name == "conv.bias" else 1e-4 * scale + 1e-6
+        torch.testing.assert_close(a.double(), r, rtol=1e-4, atol=atol, msg=name + " vs float64")
+        if name != "conv.bias":
+            err_n, err_f = float((a.double() - r).abs().max()), float((f.double() - r).abs().max())
+            assert err_n <= 3 * err_f + 1e-5 * scale + 1e-7, (name, err_n, err_f)      # no less accurate than the framework form
+
+
 def test_extractor_training_forward_with_choose_equals_dense_then_gather():
     """ModifiedResnet in training mode, channels-last: forward(x, choose) (last stage at the chosen pixels) against
     forward(x) followed by the gather, same dropout masks (same seed), output and a spread of parameter gradients."""
