@@ -62,6 +62,13 @@ ISTNET_PN2_API int istnet_nhwc_bn_prelu_apply(int b, long long hw, int c, const 
 ISTNET_PN2_API int istnet_nhwc_bn_prelu_bwd_stats(int b, long long hw, int c, const float *y, const float *dz,
                                                   const float *bn, const float *slope, const float *mask, float *part_g,
                                                   float *part_gy, float *part_slope, void *stream);
+/* finalize of the backward statistics of a decoder stage: istnet_bn_finalize_bwd's algebra (training mode) plus colsum[c] =
+ * sum_p dy (the preceding convolution's bias gradient, from the statistics: no pass over the map; NULL: not formed) and
+ * *dslope = sum of part_slope (NULL: not formed). */
+ISTNET_PN2_API int istnet_nhwc_bn_prelu_bwd_finalize(int c, int nparts, double count, const float *part_g,
+                                                     const float *part_gy, const float *part_slope, const float *gamma,
+                                                     const float *bn, float *dgamma, float *dbeta, float *bwdc,
+                                                     float *colsum, float *dslope, void *stream);
 ISTNET_PN2_API int istnet_nhwc_bn_prelu_bwd_apply(int b, long long hw, int c, const float *y, const float *dz,
                                                   const float *bn, const float *bwdc, const float *slope, const float *mask,
                                                   float *dy, void *stream);

@@ -35,6 +35,7 @@ SIGNATURES = {
     "istnet_nhwc_channel_stats": [_l, _i, _p, _p, _p, _p],
     "istnet_nhwc_bn_prelu_apply": [_i, _l, _i, _p, _p, _p, _p, _p, _p],
     "istnet_nhwc_bn_prelu_bwd_stats": [_i, _l, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p],
+    "istnet_nhwc_bn_prelu_bwd_finalize": [_i, _i, _d] + [_p] * 11,
     "istnet_nhwc_bn_prelu_bwd_apply": [_i, _l, _i, _p, _p, _p, _p, _p, _p, _p, _p],
     "istnet_nhwc_bn_act_res_apply": [_i, _l, _i, _p, _p, _p, _p, _p, _p],
     "istnet_nhwc_bn_act_res_bwd_stats": [_i, _l, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p],

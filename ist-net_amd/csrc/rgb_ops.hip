@@ -579,6 +579,55 @@ __device__ __forceinline__ double wave_sum64d(double v) {
   return v;
 }
 
+// finalize of the backward statistics pass of a decoder stage (the float64 algebra of istnet_bn_finalize_bwd) that also
+// leaves (i) the column sums of dy = ca g + cb + cc y, which the preceding convolution's bias gradient is:
+// sum_p dy = ca sum g + rows (cb + cc mean) -- analytically zero, BatchNorm removes the bias; the reference computes the same
+// round-off -- and (ii) the PReLU slope gradient (sum of the per-workgroup partials).  grid = C workgroups.
+__global__ __launch_bounds__(kThreads) void nhwc_bn_prelu_bwd_finalize_kernel(int C, int nt, double count,
+                                                                              const float* __restrict__ part_g,
+                                                                              const float* __restrict__ part_gy,
+                                                                              const float* __restrict__ part_slope,
+                                                                              const float* __restrict__ gamma,
+                                                                              const float* __restrict__ bn,
+                                                                              float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                                              float* __restrict__ bwdc, float* __restrict__ colsum,
+                                                                              float* __restrict__ dslope) {
+  __shared__ double sh[3][kThreads / 64];
+  const int c = blockIdx.x, tid = threadIdx.x;
+  const float* pa = part_g + (size_t)c * nt;
+  const float* pb = part_gy + (size_t)c * nt;
+  const bool slope_wg = dslope != nullptr && c == 0;
+  double a[4] = {0, 0, 0, 0}, b[4] = {0, 0, 0, 0}, e = 0.0;
+  int i = tid;
+  for (; i + 3 * kThreads < nt; i += 4 * kThreads) {
+    float x[4], y[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { x[k] = pa[i + k * kThreads]; y[k] = pb[i + k * kThreads]; }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { a[k] += (double)x[k]; b[k] += (double)y[k]; }
+  }
+  for (; i < nt; i += kThreads) { a[0] += (double)pa[i]; b[0] += (double)pb[i]; }
+  if (slope_wg)
+    for (int k = tid; k < nt; k += kThreads) e += (double)part_slope[k];
+  double sa = (a[0] + a[1]) + (a[2] + a[3]), sb = (b[0] + b[1]) + (b[2] + b[3]);
+  sa = wave_sum64d(sa); sb = wave_sum64d(sb); e = wave_sum64d(e);
+  if ((tid & 63) == 0) { sh[0][tid >> 6] = sa; sh[1][tid >> 6] = sb; sh[2][tid >> 6] = e; }
+  __syncthreads();
+  if (tid == 0) {
+    const double sg = (sh[0][0] + sh[0][1]) + (sh[0][2] + sh[0][3]), sgy = (sh[1][0] + sh[1][1]) + (sh[1][2] + sh[1][3]);
+    const double mean = bn[2 * C + c], istd = bn[3 * C + c];
+    const double dg = (sgy - mean * sg) * istd;
+    dgamma[c] = (float)dg;
+    dbeta[c] = (float)sg;
+    const double gsc = (double)gamma[c] * istd;
+    const double c1 = sg / count, c2 = dg / count;
+    const float ca = (float)gsc, cb = (float)(-gsc * c1 + gsc * mean * istd * c2), cc = (float)(-gsc * istd * c2);
+    bwdc[0 * C + c] = ca; bwdc[1 * C + c] = cb; bwdc[2 * C + c] = cc;
+    if (colsum) colsum[c] = (float)((double)ca * sg + count * ((double)cb + (double)cc * mean));
+    if (slope_wg) *dslope = (float)((sh[2][0] + sh[2][1]) + (sh[2][2] + sh[2][3]));
+  }
+}
+
 // batch statistics of z = W u + b over all `npix` pixels from the moments of u; grid = cout workgroups of 64 threads.
 // stat[0][c] = mean, stat[1][c] = 1 / sqrt(var + eps), stat[2][c] = biased var (float64); running statistics updated as
 // BatchNorm2d does (momentum read from device memory, unbiased variance).
@@ -1012,6 +1061,17 @@ int istnet_nhwc_bn_prelu_bwd_apply(int b, long long hw, int c, const float* y, c
                      reinterpret_cast<const float4*>(mask), reinterpret_cast<const float4*>(bwdc),
                      reinterpret_cast<const float4*>(bwdc + c), reinterpret_cast<const float4*>(bwdc + 2 * c),
                      reinterpret_cast<float4*>(dy));
+  return (int)hipGetLastError();
+}
+
+int istnet_nhwc_bn_prelu_bwd_finalize(int c, int nparts, double count, const float* part_g, const float* part_gy,
+                                      const float* part_slope, const float* gamma, const float* bn, float* dgamma,
+                                      float* dbeta, float* bwdc, float* colsum, float* dslope, void* stream) {
+  if (c <= 0 || nparts <= 0 || count <= 0 || !part_g || !part_gy || !gamma || !bn || !dgamma || !dbeta || !bwdc ||
+      (dslope && !part_slope))
+    return ISTNET_PN2_EINVAL;
+  hipLaunchKernelGGL(nhwc_bn_prelu_bwd_finalize_kernel, dim3(c), dim3(kThreads), 0, (hipStream_t)stream, c, nparts, count, part_g,
+                     part_gy, part_slope, gamma, bn, dgamma, dbeta, bwdc, colsum, dslope);
   return (int)hipGetLastError();
 }
 

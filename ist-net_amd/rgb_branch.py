@@ -223,9 +223,10 @@ class _BnReluFn(torch.autograd.Function):
         return dy, dgamma, dbeta, g, None, None, None, None, None, None
 
 
-def _bn_relu(bn, y, res, owner):
+def _bn_relu(bn, y, res, owner, identity=False):
     """relu(bn(y) [+ res]) -- by _BnReluFn when the map is a channels-last float32 CUDA tensor and ``bn`` normalises with
-    batch statistics, by the framework's modules otherwise (eval mode, CPU, other layouts)."""
+    batch statistics, by the framework's modules otherwise (eval mode, CPU, other layouts).  ``identity``: bn(y) alone (the
+    BatchNorm of a block's downsample branch, reference model/resnet.py:139-143): the same two passes with slope 1."""
     c = y.shape[1] if y.dim() == 4 else 0
     if (USE_FUSED_TRUNK_NORM and y.is_cuda and y.dtype == torch.float32 and y.dim() == 4 and bn.training and bn.affine
             and bn.momentum is not None and c % 4 == 0 and 4 <= c <= 1024 and torch.is_grad_enabled()
@@ -234,10 +235,12 @@ def _bn_relu(bn, y, res, owner):
         if res is not None:
             res = res.contiguous(memory_format=torch.channels_last)
         _bump_batch_counter(bn)
-        return _BnReluFn.apply(y, bn.weight, bn.bias, res, owner._zero, owner._one,
+        return _BnReluFn.apply(y, bn.weight, bn.bias, res, owner._one if identity else owner._zero, owner._one,
                                bn.running_mean if bn.track_running_stats else None,
                                bn.running_var if bn.track_running_stats else None, bn_momentum_ptr(bn, y.device), bn.eps)
     out = bn(y)
+    if identity:
+        return out
     if res is not None:
         out = out + res
     return torch.relu(out)
@@ -260,7 +263,13 @@ class BasicBlock(nn.Module):
 
     def forward(self, x):
         out = _bn_relu(self.bn1, self.conv1(x), None, self)
-        return _bn_relu(self.bn2, self.conv2(out), x if self.downsample is None else self.downsample(x), self)
+        return _bn_relu(self.bn2, self.conv2(out), x if self.downsample is None else self._shortcut(x), self)
+
+    def _shortcut(self, x):
+        ds = self.downsample
+        if isinstance(ds, nn.Sequential) and len(ds) == 2 and isinstance(ds[1], nn.BatchNorm2d):
+            return _bn_relu(ds[1], ds[0](x), None, self, identity=True)
+        return ds(x)
 
 
 class ResNet(nn.Module):
@@ -355,6 +364,57 @@ def _psp_matrices(sizes, h, w, device):
     return out
 
 
+class _PSPLinearFn(torch.autograd.Function):
+    """relu( x Wb_n^T + bias + U [ (P_k x) Ws_k^T Wb_k^T ]_k ) for x (B, HW, C) -- PSPModule's linear form (its docstring) as
+    one autograd node with the backward written out.  Left to autograd, the column slices of the bottleneck weight and the row
+    slices of the pooled map each came back as a zero-filled full-size gradient plus a copy plus an add (~60 framework
+    launches per step for 10 % of the module's arithmetic); here every product writes its slice of the result in place
+    (``out=`` on a view) and the bin-size blocks are contiguous because pooled maps are kept as (R, B, C).
+    Plain tensor products (library GEMMs), any device / dtype: the float64 host test checks the algebra exactly."""
+
+    @staticmethod
+    def forward(ctx, x, pmat, umat, rows, bias, wb, *ws):
+        b, hw, c = x.shape
+        cout, n, r = wb.shape[0], len(ws), pmat.shape[0]
+        x2 = x.reshape(b * hw, c)
+        pooled = torch.matmul(pmat, x).transpose(0, 1).contiguous()        # (R, B, C): a bin size = a contiguous row block
+        mid = torch.empty_like(pooled)                                     # pooled_k Ws_k^T
+        t = x.new_empty((r, b, cout))
+        for k, (r0, r1) in enumerate(rows):
+            torch.mm(pooled[r0:r1].view(-1, c), ws[k].t(), out=mid[r0:r1].view(-1, c))
+            torch.mm(mid[r0:r1].view(-1, c), wb[:, k * c:(k + 1) * c].t(), out=t[r0:r1].view(-1, cout))
+        acc = torch.addmm(bias, x2, wb[:, n * c:].t()).view(b, hw, cout)
+        y = torch.baddbmm(acc, umat.unsqueeze(0).expand(b, -1, -1), t.transpose(0, 1))
+        torch.relu_(y)
+        ctx.save_for_backward(x, pmat, umat, wb, pooled, mid, y, *ws)
+        ctx.rows = rows
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, pmat, umat, wb, pooled, mid, y, *ws = ctx.saved_tensors
+        rows = ctx.rows
+        b, hw, c = x.shape
+        cout, n = wb.shape[0], len(ws)
+        g = torch.ops.aten.threshold_backward(dy.contiguous(), y, 0)       # dy where y > 0
+        g2, x2 = g.view(b * hw, cout), x.reshape(b * hw, c)
+        dwb = torch.empty_like(wb)
+        dx = torch.mm(g2, wb[:, n * c:]).view(b, hw, c)
+        torch.mm(g2.t(), x2, out=dwb[:, n * c:])
+        dbias = g2.sum(0)
+        dt = torch.matmul(umat.t(), g).transpose(0, 1).contiguous()        # (R, B, Cout)
+        dpooled = torch.empty_like(pooled)
+        dws = []
+        for k, (r0, r1) in enumerate(rows):
+            dtk, wbk = dt[r0:r1].view(-1, cout), wb[:, k * c:(k + 1) * c]
+            torch.mm(dtk.t(), mid[r0:r1].view(-1, c), out=dwb[:, k * c:(k + 1) * c])
+            dmk = torch.mm(dtk, wbk)
+            dws.append(torch.mm(dmk.t(), pooled[r0:r1].view(-1, c)))
+            torch.mm(dmk, ws[k], out=dpooled[r0:r1].view(-1, c))
+        dx.baddbmm_(pmat.t().unsqueeze(0).expand(b, -1, -1), dpooled.transpose(0, 1))
+        return (dx, None, None, None, dbias, dwb, *dws)
+
+
 class PSPModule(nn.Module):
     """Pyramid pooling at bin sizes (1,2,3,6) + 1x1 bottleneck.  [ref modules.py:10-34]
 
@@ -379,18 +439,14 @@ class PSPModule(nn.Module):
 
     def _forward_linear(self, feats):
         b, c, h, w = feats.shape
-        n, cout = len(self.stages), self.bottleneck.out_channels
+        cout = self.bottleneck.out_channels
         x = feats.permute(0, 2, 3, 1).reshape(b, h * w, c)                 # a view of the channels-last map
         pmat, umat, rows = _psp_matrices(self.sizes, h, w, feats.device)
         pmat, umat = pmat.to(x.dtype), umat.to(x.dtype)                   # no-ops for float32
-        wb = self.bottleneck.weight.view(cout, (n + 1) * c)
-        pooled = torch.matmul(pmat, x)                                     # (B, R, C): all bin sizes at once
-        small = [torch.matmul(torch.matmul(pooled[:, r0:r1], st[1].weight.view(c, c).t()), wb[:, k * c:(k + 1) * c].t())
-                 for k, (st, (r0, r1)) in enumerate(zip(self.stages, rows))]
-        t = torch.cat(small, dim=1)                                        # (B, R, Cout)
-        acc = torch.addmm(self.bottleneck.bias, x.reshape(b * h * w, c), wb[:, n * c:].t()).view(b, h * w, cout)
-        y = torch.baddbmm(acc, umat.unsqueeze(0).expand(b, -1, -1), t)
-        return torch.relu_(y).view(b, h, w, cout).permute(0, 3, 1, 2)      # (B, Cout, h, w), channels-last
+        y = _PSPLinearFn.apply(x, pmat, umat, tuple(rows), self.bottleneck.bias,
+                               self.bottleneck.weight.view(cout, (len(self.stages) + 1) * c),
+                               *[st[1].weight.view(c, c) for st in self.stages])
+        return y.view(b, h, w, cout).permute(0, 3, 1, 2)                   # (B, Cout, h, w), channels-last
 
     def forward(self, feats):
         if (USE_PSP_LINEAR_FUSION and feats.is_cuda and feats.dtype == torch.float32 and feats.dim() == 4
@@ -406,37 +462,44 @@ USE_UPCONV_SPLIT = True      # PSPUpsample: channel mixing on the small map + in
 UPCONV_MIN_CIN = 64          # all three decoder stages; below this moving q (9 x Cout channels) costs more than it saves
 
 
+def _upconv_tail_forward(q, bias, cout):
+    from . import _native
+    b, h, w, _ = q.shape
+    y = torch.empty((b, cout, 2 * h, 2 * w), dtype=q.dtype, device=q.device, memory_format=torch.channels_last)
+    with torch.cuda.device(q.device):
+        _native.check(_native.lib().istnet_upconv3_fwd_nhwc(
+            b, cout, h, w, 2 * h, 2 * w, q.data_ptr(), bias.data_ptr() if bias is not None else None, y.data_ptr(),
+            torch.cuda.current_stream(q.device).cuda_stream), "upconv3_fwd_nhwc")
+    return y
+
+
+def _upconv_tail_backward(dy, dims):
+    from . import _native
+    b, h, w, cout = dims
+    dy = dy.contiguous(memory_format=torch.channels_last)
+    dq = torch.empty((b, h, w, 9 * cout), dtype=dy.dtype, device=dy.device)
+    with torch.cuda.device(dy.device):
+        _native.check(_native.lib().istnet_upconv3_bwd_nhwc(
+            b, cout, h, w, 2 * h, 2 * w, dy.data_ptr(), dq.data_ptr(),
+            torch.cuda.current_stream(dy.device).cuda_stream), "upconv3_bwd_nhwc")
+    return dq
+
+
 class _UpConvTailFn(torch.autograd.Function):
     """q (B, h, w, 9*Cout) -> y (B, Cout, 2h, 2w) channels-last: the full-size part of upsample -> conv3x3
     (include/istnet_rgb.h, istnet_upconv3_*).  Linear in q; the bias gradient is the plain sum of dy."""
 
     @staticmethod
     def forward(ctx, q, bias, cout):
-        from . import _native
         b, h, w, _ = q.shape
         ctx.dims = (b, h, w, cout)
         ctx.has_bias = bias is not None
-        y = torch.empty((b, cout, 2 * h, 2 * w), dtype=q.dtype, device=q.device, memory_format=torch.channels_last)
-        with torch.cuda.device(q.device):
-            _native.check(_native.lib().istnet_upconv3_fwd_nhwc(
-                b, cout, h, w, 2 * h, 2 * w, q.data_ptr(), bias.data_ptr() if bias is not None else None, y.data_ptr(),
-                torch.cuda.current_stream(q.device).cuda_stream), "upconv3_fwd_nhwc")
-        return y
+        return _upconv_tail_forward(q, bias, cout)
 
     @staticmethod
     def backward(ctx, dy):
-        from . import _native
-        b, h, w, cout = ctx.dims
-        dy = dy.contiguous(memory_format=torch.channels_last)
-        dq = torch.empty((b, h, w, 9 * cout), dtype=dy.dtype, device=dy.device)
-        with torch.cuda.device(dy.device):
-            _native.check(_native.lib().istnet_upconv3_bwd_nhwc(
-                b, cout, h, w, 2 * h, 2 * w, dy.data_ptr(), dq.data_ptr(),
-                torch.cuda.current_stream(dy.device).cuda_stream), "upconv3_bwd_nhwc")
-        dbias = None
-        if ctx.has_bias and ctx.needs_input_grad[1]:
-            colsum = getattr(dy, "_istnet_colsum", None)     # left by _BnPReLUDropFn.backward: no pass over the map
-            dbias = colsum if colsum is not None else dy.sum(dim=(0, 2, 3))
+        dq = _upconv_tail_backward(dy, ctx.dims)
+        dbias = dy.sum(dim=(0, 2, 3)) if ctx.has_bias and ctx.needs_input_grad[1] else None
         return dq, dbias, None
 
 
@@ -471,6 +534,63 @@ class _PointMixFn(torch.autograd.Function):
 USE_FUSED_DECODER_NORM = True   # decoder stages: BatchNorm (batch statistics) + PReLU + Dropout2d as two passes per direction
 
 
+def _bn_prelu_forward(y, gamma, beta, slope, mask, running_mean, running_var, momentum, eps):
+    """-> (z, bn): statistics pass, finalize (running statistics updated, momentum from its device slot), apply pass."""
+    from . import _native
+    lib = _native.lib()
+    b, c, h, w = y.shape
+    dev = y.device
+    rows = b * h * w
+    nparts = lib.istnet_nhwc_stat_parts(rows)
+    part = torch.empty((2, c, nparts), dtype=torch.float32, device=dev)
+    bn = torch.empty((4, c), dtype=torch.float32, device=dev)
+    z = torch.empty_like(y, memory_format=torch.channels_last)
+    with torch.cuda.device(dev):
+        st = torch.cuda.current_stream(dev).cuda_stream
+        _native.check(lib.istnet_nhwc_channel_stats(rows, c, y.data_ptr(), part[0].data_ptr(), part[1].data_ptr(), st),
+                      "nhwc_channel_stats")
+        _native.check(lib.istnet_bn_finalize_fwd(
+            c, nparts, float(rows), part[0].data_ptr(), part[1].data_ptr(), gamma.data_ptr(), beta.data_ptr(), float(eps),
+            momentum, running_mean.data_ptr() if running_mean is not None else None,
+            running_var.data_ptr() if running_var is not None else None, bn.data_ptr(), st), "bn_finalize_fwd")
+        _native.check(lib.istnet_nhwc_bn_prelu_apply(b, h * w, c, y.data_ptr(), bn.data_ptr(), slope.data_ptr(),
+                                                     mask.data_ptr() if mask is not None else None, z.data_ptr(), st),
+                      "nhwc_bn_prelu_apply")
+    return z, bn
+
+
+def _bn_prelu_backward(y, dz, gamma, slope, bn, mask, want_colsum):
+    """-> (dy, dgamma, dbeta, dslope, colsum): statistics pass, finalize (which also leaves the slope gradient and, when
+    asked for, the column sums of dy = the preceding convolution's bias gradient), apply pass."""
+    from . import _native
+    lib = _native.lib()
+    b, c, h, w = y.shape
+    dev = y.device
+    rows = b * h * w
+    dz = dz.contiguous(memory_format=torch.channels_last)
+    nparts = lib.istnet_nhwc_stat_parts(rows)
+    f32 = dict(dtype=torch.float32, device=dev)
+    part, pslope = torch.empty((2, c, nparts), **f32), torch.empty((nparts,), **f32)
+    dgamma, dbeta, bwdc = torch.empty((c,), **f32), torch.empty((c,), **f32), torch.empty((3, c), **f32)
+    dslope = torch.empty(slope.shape, **f32)
+    colsum = torch.empty((c,), **f32) if want_colsum else None
+    dy = torch.empty_like(y, memory_format=torch.channels_last)
+    mptr = mask.data_ptr() if mask is not None else None
+    with torch.cuda.device(dev):
+        st = torch.cuda.current_stream(dev).cuda_stream
+        _native.check(lib.istnet_nhwc_bn_prelu_bwd_stats(b, h * w, c, y.data_ptr(), dz.data_ptr(), bn.data_ptr(),
+                                                         slope.data_ptr(), mptr, part[0].data_ptr(), part[1].data_ptr(),
+                                                         pslope.data_ptr(), st), "nhwc_bn_prelu_bwd_stats")
+        _native.check(lib.istnet_nhwc_bn_prelu_bwd_finalize(
+            c, nparts, float(rows), part[0].data_ptr(), part[1].data_ptr(), pslope.data_ptr(), gamma.data_ptr(), bn.data_ptr(),
+            dgamma.data_ptr(), dbeta.data_ptr(), bwdc.data_ptr(), colsum.data_ptr() if colsum is not None else None,
+            dslope.data_ptr(), st), "nhwc_bn_prelu_bwd_finalize")
+        _native.check(lib.istnet_nhwc_bn_prelu_bwd_apply(b, h * w, c, y.data_ptr(), dz.data_ptr(), bn.data_ptr(),
+                                                         bwdc.data_ptr(), slope.data_ptr(), mptr, dy.data_ptr(), st),
+                      "nhwc_bn_prelu_bwd_apply")
+    return dy, dgamma, dbeta, dslope, colsum
+
+
 class _BnPReLUDropFn(torch.autograd.Function):
     """BatchNorm2d (training statistics) -> PReLU (one slope) [-> Dropout2d mask] of a channels-last map in two streaming
     passes per direction (include/istnet_rgb.h, istnet_nhwc_*; finalizes of include/istnet_pw.h): the tail of a decoder
@@ -481,63 +601,39 @@ class _BnPReLUDropFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, y, gamma, beta, slope, mask, running_mean, running_var, momentum, eps):
-        from . import _native
-        lib = _native.lib()
-        b, c, h, w = y.shape
-        dev = y.device
-        rows = b * h * w
-        nparts = lib.istnet_nhwc_stat_parts(rows)
-        part = torch.empty((2, c, nparts), dtype=torch.float32, device=dev)
-        bn = torch.empty((4, c), dtype=torch.float32, device=dev)
-        z = torch.empty_like(y, memory_format=torch.channels_last)
-        with torch.cuda.device(dev):
-            st = torch.cuda.current_stream(dev).cuda_stream
-            _native.check(lib.istnet_nhwc_channel_stats(rows, c, y.data_ptr(), part[0].data_ptr(), part[1].data_ptr(), st),
-                          "nhwc_channel_stats")
-            _native.check(lib.istnet_bn_finalize_fwd(
-                c, nparts, float(rows), part[0].data_ptr(), part[1].data_ptr(), gamma.data_ptr(), beta.data_ptr(), float(eps),
-                momentum, running_mean.data_ptr() if running_mean is not None else None,
-                running_var.data_ptr() if running_var is not None else None, bn.data_ptr(), st), "bn_finalize_fwd")
-            _native.check(lib.istnet_nhwc_bn_prelu_apply(b, h * w, c, y.data_ptr(), bn.data_ptr(), slope.data_ptr(),
-                                                         mask.data_ptr() if mask is not None else None, z.data_ptr(), st),
-                          "nhwc_bn_prelu_apply")
-        ctx.save_for_backward(y, gamma, slope, bn, mask if mask is not None else torch.empty(0, device=dev))
+        z, bn = _bn_prelu_forward(y, gamma, beta, slope, mask, running_mean, running_var, momentum, eps)
+        ctx.save_for_backward(y, gamma, slope, bn, mask if mask is not None else torch.empty(0, device=y.device))
         ctx.has_mask = mask is not None
         return z
 
     @staticmethod
     def backward(ctx, dz):
-        from . import _native
-        lib = _native.lib()
         y, gamma, slope, bn, mask = ctx.saved_tensors
-        mask = mask if ctx.has_mask else None
-        b, c, h, w = y.shape
-        dev = y.device
-        rows = b * h * w
-        dz = dz.contiguous(memory_format=torch.channels_last)
-        nparts = lib.istnet_nhwc_stat_parts(rows)
-        part = torch.empty((2, c, nparts), dtype=torch.float32, device=dev)
-        pslope = torch.empty((nparts,), dtype=torch.float32, device=dev)
-        dgamma = torch.empty((c,), dtype=torch.float32, device=dev)
-        dbeta = torch.empty((c,), dtype=torch.float32, device=dev)
-        bwdc = torch.empty((3, c), dtype=torch.float32, device=dev)
-        dy = torch.empty_like(y, memory_format=torch.channels_last)
-        mptr = mask.data_ptr() if mask is not None else None
-        with torch.cuda.device(dev):
-            st = torch.cuda.current_stream(dev).cuda_stream
-            _native.check(lib.istnet_nhwc_bn_prelu_bwd_stats(b, h * w, c, y.data_ptr(), dz.data_ptr(), bn.data_ptr(),
-                                                             slope.data_ptr(), mptr, part[0].data_ptr(), part[1].data_ptr(),
-                                                             pslope.data_ptr(), st), "nhwc_bn_prelu_bwd_stats")
-            _native.check(lib.istnet_bn_finalize_bwd(c, nparts, float(rows), 1, part[0].data_ptr(), part[1].data_ptr(),
-                                                     gamma.data_ptr(), bn.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(),
-                                                     bwdc.data_ptr(), st), "bn_finalize_bwd")
-            _native.check(lib.istnet_nhwc_bn_prelu_bwd_apply(b, h * w, c, y.data_ptr(), dz.data_ptr(), bn.data_ptr(),
-                                                             bwdc.data_ptr(), slope.data_ptr(), mptr, dy.data_ptr(), st),
-                          "nhwc_bn_prelu_bwd_apply")
-        # the column sums of dy, which the convolution's bias gradient is, follow from the statistics without another pass
-        # over the map: sum_p dy = ca sum g + rows cb + cc rows mean  (analytically zero: BatchNorm removes the bias)
-        dy._istnet_colsum = bwdc[0] * dbeta + float(rows) * (bwdc[1] + bwdc[2] * bn[2])
-        return dy, dgamma, dbeta, pslope.sum().reshape(slope.shape), None, None, None, None, None
+        dy, dgamma, dbeta, dslope, _ = _bn_prelu_backward(y, dz, gamma, slope, bn, mask if ctx.has_mask else None, False)
+        return dy, dgamma, dbeta, dslope, None, None, None, None, None
+
+
+class _UpConvNormFn(torch.autograd.Function):
+    """_UpConvTailFn followed by _BnPReLUDropFn as ONE node: the tail of a decoder stage from the channel-mixed small map q
+    to the stage's output.  Being one node, the convolution's bias gradient (the column sums of the gradient that leaves the
+    normalisation) is taken from the backward statistics instead of a pass over the full-size map."""
+
+    @staticmethod
+    def forward(ctx, q, bias, cout, gamma, beta, slope, mask, running_mean, running_var, momentum, eps):
+        b, h, w, _ = q.shape
+        ctx.dims = (b, h, w, cout)
+        ctx.has_mask, ctx.has_bias = mask is not None, bias is not None
+        y = _upconv_tail_forward(q, bias, cout)
+        z, bn = _bn_prelu_forward(y, gamma, beta, slope, mask, running_mean, running_var, momentum, eps)
+        ctx.save_for_backward(y, gamma, slope, bn, mask if mask is not None else torch.empty(0, device=q.device))
+        return z
+
+    @staticmethod
+    def backward(ctx, dz):
+        y, gamma, slope, bn, mask = ctx.saved_tensors
+        want = ctx.has_bias and ctx.needs_input_grad[1]
+        dy, dgamma, dbeta, dslope, colsum = _bn_prelu_backward(y, dz, gamma, slope, bn, mask if ctx.has_mask else None, want)
+        return (_upconv_tail_backward(dy, ctx.dims), colsum, None, dgamma, dbeta, dslope, None, None, None, None, None)
 
 
 class PSPUpsample(nn.Module):
@@ -572,7 +668,6 @@ class PSPUpsample(nn.Module):
         cout = conv.out_channels
         wr = conv.weight.permute(1, 2, 3, 0).reshape(cin, 9 * cout)          # Wr[ci][(ky*3+kx)*Cout + co]
         q = _PointMixFn.apply(x.permute(0, 2, 3, 1).reshape(b * h * w, cin), wr).view(b, h, w, 9 * cout)
-        y = _UpConvTailFn.apply(q, conv.bias, cout)
         bn, act = self.conv[2], self.conv[3]
         if (USE_FUSED_DECODER_NORM and bn.training and bn.affine and bn.momentum is not None and act.weight.numel() == 1
                 and cout % 4 == 0 and cout <= 1024 and torch.is_grad_enabled()):
@@ -581,9 +676,10 @@ class PSPUpsample(nn.Module):
                 keep = 1.0 - drop.p
                 mask = torch.empty((b, cout), dtype=torch.float32, device=x.device).bernoulli_(keep).div_(keep)
             _bump_batch_counter(bn)
-            return _BnPReLUDropFn.apply(y, bn.weight, bn.bias, act.weight, mask,
-                                        bn.running_mean if bn.track_running_stats else None,
-                                        bn.running_var if bn.track_running_stats else None, bn_momentum_ptr(bn, y.device), bn.eps)
+            return _UpConvNormFn.apply(q, conv.bias, cout, bn.weight, bn.bias, act.weight, mask,
+                                       bn.running_mean if bn.track_running_stats else None,
+                                       bn.running_var if bn.track_running_stats else None, bn_momentum_ptr(bn, x.device), bn.eps)
+        y = _UpConvTailFn.apply(q, conv.bias, cout)
         out = act(bn(y))
         return drop(out) if drop is not None else out
 

@@ -327,6 +327,79 @@ def test_extractor_training_forward_with_choose_equals_dense_then_gather():
         assert err < bound, (name, err)
 
 
+@pytest.mark.parametrize("b,cout,h,w,with_mask", [(2, 64, 12, 12, True), (3, 16, 5, 7, False)])
+def test_decoder_stage_tail_as_one_node(b, cout, h, w, with_mask):
+    """_UpConvNormFn (upsample -> conv3x3 tail, BatchNorm, PReLU, dropout mask as ONE autograd node) against the two-node
+    composition _UpConvTailFn -> _BnPReLUDropFn: same output and gradients bit for bit (the same kernels in the same order);
+    the convolution's bias gradient, which the single node takes from the backward statistics and the composition from a sum
+    over the full-size map, is round-off on both sides (BatchNorm removes the bias)."""
+    from istnet_amd import rgb_branch
+    g = torch.Generator().manual_seed(cout + h)
+    q0 = torch.randn(b, h, w, 9 * cout, generator=g).to(DEV)
+    bias0 = torch.randn(cout, generator=g).to(DEV)
+    bn = torch.nn.BatchNorm2d(cout).to(DEV).train()
+    act = torch.nn.PReLU().to(DEV)
+    with torch.no_grad():
+        bn.weight.copy_((torch.rand(cout, generator=g) + 0.5).to(DEV)); bn.bias.copy_((torch.randn(cout, generator=g) * 0.2).to(DEV))
+    mask = (torch.empty(b, cout).bernoulli_(0.8, generator=g) / 0.8).to(DEV) if with_mask else None
+    wgt = torch.randn(b, cout, 2 * h, 2 * w, generator=g).to(DEV)
+    mom = rgb_branch.bn_momentum_ptr(bn, DEV)
+
+    def run(one_node):
+        q, bias = q0.clone().requires_grad_(True), bias0.clone().requires_grad_(True)
+        bn.zero_grad(); act.zero_grad()
+        rm, rv = torch.zeros(cout, device=DEV), torch.ones(cout, device=DEV)
+        if one_node:
+            z = rgb_branch._UpConvNormFn.apply(q, bias, cout, bn.weight, bn.bias, act.weight, mask, rm, rv, mom, bn.eps)
+        else:
+            y = rgb_branch._UpConvTailFn.apply(q, bias, cout)
+            z = rgb_branch._BnPReLUDropFn.apply(y, bn.weight, bn.bias, act.weight, mask, rm, rv, mom, bn.eps)
+        (z * wgt).sum().backward()
+        return z.detach(), q.grad, bn.weight.grad.clone(), bn.bias.grad.clone(), act.weight.grad.clone(), rm, rv, bias.grad
+
+    one, two = run(True), run(False)
+    for name, a, c_ in zip(["z", "dq", "dgamma", "dbeta", "dslope", "running_mean", "running_var"], one, two):
+        assert torch.equal(a, c_), name
+    scale = float(one[1].abs().max()) * b * 4 * h * w
+    assert float(one[7].abs().max()) < 1e-5 * scale and float(two[7].abs().max()) < 1e-5 * scale
+
+
+def test_downsample_batchnorm_of_a_basic_block_takes_the_fused_passes():
+    """BasicBlock with a downsample branch (conv1x1 stride 2 -> BatchNorm2d, reference model/resnet.py:139-143): the branch's
+    BatchNorm runs through the two NHWC passes with slope 1 (identity activation); output, running statistics and
+    gradients against the framework's modules (rgb_branch.USE_FUSED_TRUNK_NORM off)."""
+    from istnet_amd import rgb_branch
+    torch.manual_seed(3)
+    ds = torch.nn.Sequential(torch.nn.Conv2d(64, 128, 1, stride=2, bias=False), torch.nn.BatchNorm2d(128))
+    blk = rgb_branch.BasicBlock(64, 128, stride=2, downsample=ds).to(DEV).to(memory_format=torch.channels_last).train()
+    x = torch.randn(4, 64, 24, 24, device=DEV).contiguous(memory_format=torch.channels_last)
+    wgt = torch.randn(4, 128, 12, 12, device=DEV)
+
+    def run(flag):
+        old = rgb_branch.USE_FUSED_TRUNK_NORM
+        rgb_branch.USE_FUSED_TRUNK_NORM = flag
+        try:
+            blk.zero_grad(set_to_none=True)
+            for m in blk.modules():
+                if isinstance(m, torch.nn.BatchNorm2d):
+                    m.reset_running_stats()
+            xx = x.clone(memory_format=torch.preserve_format).requires_grad_(True)
+            with torch.backends.cudnn.flags(enabled=flag):
+                out = blk(xx)
+                (out * wgt).sum().backward()
+            return (out.detach(), xx.grad, {n: p.grad.clone() for n, p in blk.named_parameters()},
+                    ds[1].running_mean.clone(), ds[1].running_var.clone())
+        finally:
+            rgb_branch.USE_FUSED_TRUNK_NORM = old
+
+    f, r = run(True), run(False)
+    rel = lambda a, c_: float((a - c_).abs().max() / (c_.abs().max() + 1e-30))
+    assert rel(f[0], r[0]) < 1e-4 and rel(f[1], r[1]) < 1e-3
+    for name in f[2]:
+        assert rel(f[2][name], r[2][name]) < 1e-3, name
+    assert rel(f[3], r[3]) < 1e-5 and rel(f[4], r[4]) < 1e-5
+
+
 @pytest.mark.parametrize("b,c,h,w,with_mask", [(4, 64, 24, 24, True), (2, 256, 12, 20, False), (3, 48, 10, 14, True),
                                                (2, 64, 96, 96, True)])
 def test_fused_batchnorm_prelu_dropout_of_a_channels_last_map(b, c, h, w, with_mask):
