@@ -244,11 +244,7 @@ class IST_Net(nn.Module):
     def forward(self, inputs):
         end_points = {}
         pts = inputs["pts"]
-        cls = inputs["category_label"].reshape(-1)
-        c = torch.mean(pts, 1, keepdim=True)
-        pts = pts - c
         b = pts.size(0)
-        index = cls + torch.arange(b, dtype=torch.long, device=pts.device) * self.nclass
         # The RGB branch (dense 2-D convolutions) and the point encoder are independent until the heads: run the
         # RGB branch on its own stream so the encoder's many short kernels fill in around the convolutions
         # (autograd replays each op's backward on the stream its forward ran on, so backward overlaps too).
@@ -264,6 +260,12 @@ class IST_Net(nn.Module):
         elif not rgb_last:
             rgb_local = self._rgb_local(inputs, b)
 
+        # (after the fork: the five small launches below would otherwise delay the start of the RGB branch, which is the longest
+        # chain of the step)
+        cls = inputs["category_label"].reshape(-1)
+        c = torch.mean(pts, 1, keepdim=True)
+        pts = pts - c
+        index = cls + torch.arange(b, dtype=torch.long, device=pts.device) * self.nclass
         pts_local = self.pts_cam_extractor(pts)
         pts_w_local_gt = None
         if self.training and USE_EARLY_WORLD_EXTRACTOR:

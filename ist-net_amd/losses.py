@@ -34,23 +34,72 @@ def PoseDis(r1, t1, s1, r2, t2, s2):
             + torch.mean(torch.norm(s1 - s2, dim=1)))
 
 
+class _WeightedSumFn(torch.autograd.Function):
+    """sum_i w_i s_i of scalar terms as one node: stack + dot forward, one scaled copy of the weights backward -- the
+    reference's chain ``loss = a + b + g1 * c + g2 * d + e`` (model/ist_net.py:95-110) is four adds and two multiplies
+    forward and two multiplies backward, each a launch at the turn from forward to backward."""
+
+    @staticmethod
+    def forward(ctx, weights, *terms):
+        ctx.save_for_backward(weights)
+        return torch.dot(torch.stack([t.reshape(()) for t in terms]), weights)
+
+    @staticmethod
+    def backward(ctx, g):
+        (weights,) = ctx.saved_tensors
+        return (None, *(g * weights).unbind(0))
+
+
+class _MseFn(torch.autograd.Function):
+    """nn.functional.mse_loss(a, b) with value and gradient from ONE pass over the operands (mse_value_and_grad)."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        loss, g = mse_value_and_grad(a, b)
+        ctx.save_for_backward(g)
+        return loss
+
+    @staticmethod
+    def backward(ctx, gl):
+        (g,) = ctx.saved_tensors
+        ga = g * gl
+        return (ga if ctx.needs_input_grad[0] else None, -ga if ctx.needs_input_grad[1] else None)
+
+
+def _mse(a, b):
+    if (a.is_cuda and a.dtype == torch.float32 and b.dtype == torch.float32 and a.shape == b.shape and a.is_contiguous()
+            and b.is_contiguous() and a.data_ptr() % 16 == 0 and b.data_ptr() % 16 == 0):
+        return _MseFn.apply(a, b)
+    return nn.functional.mse_loss(a, b)
+
+
 class SupervisedLoss(nn.Module):
     def __init__(self, gamma1=1.0, gamma2=10.0, freeze_world_enhancer=False):
         super().__init__()
         self.gamma1, self.gamma2, self.freeze_world_enhancer = gamma1, gamma2, freeze_world_enhancer
+        self._weights = {}
 
     def forward(self, end_points):
         ep = end_points
         labels = (ep["rotation_label"], ep["translation_label"], ep["size_label"])
-        loss = PoseDis(ep["pred_rotation"], ep["pred_translation"], ep["pred_size"], *labels)
-        loss = loss + PoseDis(ep["pred_rotation_aux_cam"], ep["pred_translation_aux_cam"], ep["pred_size_aux_cam"],
-                              *labels)
-        loss = loss + self.gamma1 * SmoothL1Dis(ep["pred_qo"], ep["qo"])
-        loss = loss + self.gamma2 * nn.functional.mse_loss(ep["pts_w_local"], ep["pts_w_local_gt"])
+        terms = [PoseDis(ep["pred_rotation"], ep["pred_translation"], ep["pred_size"], *labels),
+                 PoseDis(ep["pred_rotation_aux_cam"], ep["pred_translation_aux_cam"], ep["pred_size_aux_cam"], *labels),
+                 SmoothL1Dis(ep["pred_qo"], ep["qo"]),
+                 _mse(ep["pts_w_local"], ep["pts_w_local_gt"])]
+        weights = [1.0, 1.0, self.gamma1, self.gamma2]
         if not self.freeze_world_enhancer:
-            loss = loss + PoseDis(ep["pred_rotation_aux_world"], ep["pred_translation_aux_world"],
-                                  ep["pred_size_aux_world"], *labels)
-        return loss
+            terms.append(PoseDis(ep["pred_rotation_aux_world"], ep["pred_translation_aux_world"],
+                                 ep["pred_size_aux_world"], *labels))
+            weights.append(1.0)
+        if not terms[0].is_cuda:
+            loss = terms[0]                          # host: the reference's chain as it is written
+            for w, t in zip(weights[1:], terms[1:]):
+                loss = loss + (t if w == 1.0 else w * t)
+            return loss
+        key = (terms[0].device, terms[0].dtype, tuple(weights))
+        if key not in self._weights:
+            self._weights[key] = torch.tensor(weights, dtype=terms[0].dtype, device=terms[0].device)
+        return _WeightedSumFn.apply(self._weights[key], *terms)
 
 
 def mse_value_and_grad(a, b=None):

@@ -1328,6 +1328,7 @@ class FusedFPFunction(Function):
                               known_bn if known_bn is not None else torch.empty(0, device=dev), *ys, *bns, *params)
         if lazy_out:
             ctx.mark_non_differentiable(bns[-1])
+            ctx.set_materialize_grads(False)      # no zero-filled "gradient" of the constant block (a fill launch per level)
             return ys[-1], bns[-1]
         return out
 
@@ -1338,6 +1339,8 @@ class FusedFPFunction(Function):
         b, c2, c1, m, n = ctx.dims
         nl = ctx.n_layers
         sv = ctx.saved_tensors
+        if dout is None:                          # (only without materialised gradients: the output was not used)
+            dout = torch.zeros_like(sv[5 + nl - 1])
         known, skip, idx, weight = sv[0], (sv[1] if ctx.has_skip else None), sv[2], sv[3]
         known_bn = sv[4] if ctx.has_known_bn else None
         ys, bns, params = sv[5:5 + nl], sv[5 + nl:5 + 2 * nl], sv[5 + 2 * nl:]

@@ -364,6 +364,22 @@ def _psp_matrices(sizes, h, w, device):
     return out
 
 
+_UNIT_CONSTS = {}
+
+
+def _unit_consts(dev, c):
+    """Constant blocks that turn the decoder's BatchNorm + PReLU passes into ReLU (+ mask): bn = (scale 1, shift 0, mean 0,
+    invstd 1), bwdc = (1, 0, 0), slope 0."""
+    key = (str(dev), c)
+    if key not in _UNIT_CONSTS:
+        bn = torch.zeros((4, c), dtype=torch.float32, device=dev)
+        bn[0].fill_(1.0); bn[3].fill_(1.0)
+        bwdc = torch.zeros((3, c), dtype=torch.float32, device=dev)
+        bwdc[0].fill_(1.0)
+        _UNIT_CONSTS[key] = (bn, bwdc, torch.zeros(1, dtype=torch.float32, device=dev))
+    return _UNIT_CONSTS[key]
+
+
 class _PSPLinearFn(torch.autograd.Function):
     """relu( x Wb_n^T + bias + U [ (P_k x) Ws_k^T Wb_k^T ]_k ) for x (B, HW, C) -- PSPModule's linear form (its docstring) as
     one autograd node with the backward written out.  Left to autograd, the column slices of the bottleneck weight and the row
@@ -373,7 +389,8 @@ class _PSPLinearFn(torch.autograd.Function):
     Plain tensor products (library GEMMs), any device / dtype: the float64 host test checks the algebra exactly."""
 
     @staticmethod
-    def forward(ctx, x, pmat, umat, rows, bias, wb, *ws):
+    def forward(ctx, x, pmat, umat, rows, mask, bias, wb, *ws):
+        # mask: (B, Cout) Dropout2d factors applied after the ReLU (the drop_1 of Modified_PSPNet, model/modules.py:60) or None
         b, hw, c = x.shape
         cout, n, r = wb.shape[0], len(ws), pmat.shape[0]
         x2 = x.reshape(b * hw, c)
@@ -385,18 +402,41 @@ class _PSPLinearFn(torch.autograd.Function):
             torch.mm(mid[r0:r1].view(-1, c), wb[:, k * c:(k + 1) * c].t(), out=t[r0:r1].view(-1, cout))
         acc = torch.addmm(bias, x2, wb[:, n * c:].t()).view(b, hw, cout)
         y = torch.baddbmm(acc, umat.unsqueeze(0).expand(b, -1, -1), t.transpose(0, 1))
-        torch.relu_(y)
-        ctx.save_for_backward(x, pmat, umat, wb, pooled, mid, y, *ws)
-        ctx.rows = rows
+        native = mask is not None and y.is_cuda and y.dtype == torch.float32 and cout % 4 == 0 and cout <= 1024
+        if native:            # relu(y) * mask in one pass (istnet_nhwc_bn_prelu_apply with scale 1, shift 0, slope 0), in place
+            from . import _native
+            bn, _, zero = _unit_consts(y.device, cout)
+            with torch.cuda.device(y.device):
+                _native.check(_native.lib().istnet_nhwc_bn_prelu_apply(
+                    b, hw, cout, y.data_ptr(), bn.data_ptr(), zero.data_ptr(), mask.data_ptr(), y.data_ptr(),
+                    torch.cuda.current_stream(y.device).cuda_stream), "nhwc_bn_prelu_apply")
+        else:
+            torch.relu_(y)
+            if mask is not None:
+                y.mul_(mask.unsqueeze(1))
+        ctx.save_for_backward(x, pmat, umat, wb, pooled, mid, y, mask if mask is not None else x.new_empty(0), *ws)
+        ctx.rows, ctx.has_mask, ctx.native = rows, mask is not None, native
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, pmat, umat, wb, pooled, mid, y, *ws = ctx.saved_tensors
+        x, pmat, umat, wb, pooled, mid, y, mask, *ws = ctx.saved_tensors
         rows = ctx.rows
         b, hw, c = x.shape
         cout, n = wb.shape[0], len(ws)
-        g = torch.ops.aten.threshold_backward(dy.contiguous(), y, 0)       # dy where y > 0
+        dy = dy.contiguous()
+        if ctx.native:        # dy * mask where the (masked) output is positive: a dropped channel has no gradient either way
+            from . import _native
+            bn, bwdc, zero = _unit_consts(y.device, cout)
+            g = torch.empty_like(y)
+            with torch.cuda.device(y.device):
+                _native.check(_native.lib().istnet_nhwc_bn_prelu_bwd_apply(
+                    b, hw, cout, y.data_ptr(), dy.data_ptr(), bn.data_ptr(), bwdc.data_ptr(), zero.data_ptr(), mask.data_ptr(),
+                    g.data_ptr(), torch.cuda.current_stream(y.device).cuda_stream), "nhwc_bn_prelu_bwd_apply")
+        else:
+            g = torch.ops.aten.threshold_backward(dy, y, 0)                # dy where y > 0
+            if ctx.has_mask:
+                g = g * mask.unsqueeze(1)
         g2, x2 = g.view(b * hw, cout), x.reshape(b * hw, c)
         dwb = torch.empty_like(wb)
         dx = torch.mm(g2, wb[:, n * c:]).view(b, hw, c)
@@ -412,7 +452,7 @@ class _PSPLinearFn(torch.autograd.Function):
             dws.append(torch.mm(dmk.t(), pooled[r0:r1].view(-1, c)))
             torch.mm(dmk, ws[k], out=dpooled[r0:r1].view(-1, c))
         dx.baddbmm_(pmat.t().unsqueeze(0).expand(b, -1, -1), dpooled.transpose(0, 1))
-        return (dx, None, None, None, dbias, dwb, *dws)
+        return (dx, None, None, None, None, dbias, dwb, *dws)
 
 
 class PSPModule(nn.Module):
@@ -437,25 +477,33 @@ class PSPModule(nn.Module):
         self.relu = nn.ReLU()
         self.sizes = tuple(sizes)
 
-    def _forward_linear(self, feats):
+    def _forward_linear(self, feats, mask=None):
         b, c, h, w = feats.shape
         cout = self.bottleneck.out_channels
         x = feats.permute(0, 2, 3, 1).reshape(b, h * w, c)                 # a view of the channels-last map
         pmat, umat, rows = _psp_matrices(self.sizes, h, w, feats.device)
         pmat, umat = pmat.to(x.dtype), umat.to(x.dtype)                   # no-ops for float32
-        y = _PSPLinearFn.apply(x, pmat, umat, tuple(rows), self.bottleneck.bias,
+        y = _PSPLinearFn.apply(x, pmat, umat, tuple(rows), mask, self.bottleneck.bias,
                                self.bottleneck.weight.view(cout, (len(self.stages) + 1) * c),
                                *[st[1].weight.view(c, c) for st in self.stages])
         return y.view(b, h, w, cout).permute(0, 3, 1, 2)                   # (B, Cout, h, w), channels-last
 
-    def forward(self, feats):
+    def forward(self, feats, drop=None):
+        """``drop``: the nn.Dropout2d the caller applies to the module's output (reference model/modules.py:60), folded into
+        the ReLU pass of the linear form; otherwise applied here."""
         if (USE_PSP_LINEAR_FUSION and feats.is_cuda and feats.dtype == torch.float32 and feats.dim() == 4
                 and feats.is_contiguous(memory_format=torch.channels_last) and self.bottleneck.bias is not None):
-            return self._forward_linear(feats)
+            mask = None
+            if drop is not None and drop.training and drop.p > 0:
+                keep = 1.0 - drop.p
+                mask = torch.empty((feats.shape[0], self.bottleneck.out_channels), dtype=torch.float32,
+                                   device=feats.device).bernoulli_(keep).div_(keep)
+            return self._forward_linear(feats, mask)
         h, w = feats.size(2), feats.size(3)
         priors = [F.interpolate(stage(feats), size=(h, w), mode="bilinear", align_corners=False)
                   for stage in self.stages] + [feats]
-        return self.relu(self.bottleneck(torch.cat(priors, 1)))
+        out = self.relu(self.bottleneck(torch.cat(priors, 1)))
+        return drop(out) if drop is not None else out
 
 
 USE_UPCONV_SPLIT = True      # PSPUpsample: channel mixing on the small map + interpolate / shift / add kernel
@@ -888,7 +936,7 @@ class Modified_PSPNet(nn.Module):
         pixels only: eval mode through ``_tail_at``, training mode through ``_FinalAtChosenFn`` (exact batch statistics
         from the moments of the last stage's input)."""
         f, _ = self.feats(x)
-        p = self.drop_1(self.psp(f))
+        p = self.psp(f, drop=self.drop_1)
         p = self.up_1(p, drop=self.drop_2)
         p = self.up_2(p, drop=self.drop_2)
         if choose is not None and not self.training:

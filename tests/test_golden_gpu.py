@@ -684,6 +684,41 @@ def test_supervised_loss_golden_on_gpu():
     assert not bad, bad
 
 
+def test_supervised_loss_gradients_match_the_written_chain_in_float64():
+    """SupervisedLoss on the GPU (native PoseDis / SmoothL1Dis, one-pass MSE, the weighted sum as one node) against the
+    reference's chain of adds and multiplies (model/ist_net.py:95-110, model/losses.py:3-49) evaluated in float64 on the
+    host: value and the gradient of every prediction, the feature target included (both sides of the MSE carry a gradient)."""
+    from istnet_amd import losses
+    g = torch.Generator().manual_seed(11)
+    b, n = 6, 128
+
+    def rot():
+        q, _ = torch.linalg.qr(torch.randn(b, 3, 3, generator=g))
+        return q
+
+    names = {"pred_rotation": rot(), "pred_translation": torch.randn(b, 3, generator=g), "pred_size": torch.rand(b, 3, generator=g),
+             "pred_rotation_aux_cam": rot(), "pred_translation_aux_cam": torch.randn(b, 3, generator=g),
+             "pred_size_aux_cam": torch.rand(b, 3, generator=g), "pred_rotation_aux_world": rot(),
+             "pred_translation_aux_world": torch.randn(b, 3, generator=g), "pred_size_aux_world": torch.rand(b, 3, generator=g),
+             "pred_qo": torch.randn(b, n, 3, generator=g) * 0.2, "pts_w_local": torch.randn(b, 64, n, generator=g),
+             "pts_w_local_gt": torch.randn(b, 64, n, generator=g)}
+    fixed = {"rotation_label": rot(), "translation_label": torch.randn(b, 3, generator=g), "size_label": torch.rand(b, 3, generator=g),
+             "qo": torch.randn(b, n, 3, generator=g) * 0.2}
+
+    def run(dev, dtype):
+        ep = {k: v.to(device=dev, dtype=dtype).requires_grad_(True) for k, v in names.items()}
+        ep.update({k: v.to(device=dev, dtype=dtype) for k, v in fixed.items()})
+        loss = losses.SupervisedLoss(1.0, 10.0, False)(ep)
+        loss.backward()
+        return float(loss.detach()), {k: ep[k].grad.detach().cpu().double() for k in names}
+
+    lg, gg = run(DEV, torch.float32)
+    lr, gr = run("cpu", torch.float64)
+    assert abs(lg - lr) < 1e-5 * abs(lr)
+    for k in names:
+        torch.testing.assert_close(gg[k], gr[k], rtol=1e-4, atol=1e-6 * float(gr[k].abs().max()) + 1e-9, msg=k)
+
+
 def test_full_size_config3_one_training_step(oracle):
     """BASELINE configs[2] at full size under pytest: B = 32, 192 x 192 RGB + N = 1024 points, one training step on the GPU
     (end points finite, every trainable parameter receives a finite gradient), and the same model at a B = 4 sub-batch against

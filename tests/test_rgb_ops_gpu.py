@@ -111,13 +111,16 @@ def test_native_decoder_backward_equals_framework_backward():
     assert max(rel.values()) < 2e-3, (worst, sorted(rel.items(), key=lambda kv: -kv[1])[:5])
 
 
-@pytest.mark.parametrize("b,c,cout,h", [(2, 32, 48, 24), (3, 16, 8, 12), (1, 8, 8, 7)])
-def test_pyramid_module_linear_form_matches_the_reference_composition(b, c, cout, h):
-    """PSPModule on the GPU (bottleneck slices applied before the upsample, pooling / upsampling as matrix products)
-    against pool -> conv -> upsample -> cat -> bottleneck of the reference (model/modules.py:10-34): output and every
-    gradient."""
+@pytest.mark.parametrize("b,c,cout,h,dropout", [(2, 32, 48, 24, False), (3, 16, 8, 12, False), (1, 8, 8, 7, False),
+                                                (4, 32, 48, 24, True), (3, 16, 6, 12, True)])
+def test_pyramid_module_linear_form_matches_the_reference_composition(b, c, cout, h, dropout):
+    """PSPModule on the GPU (bottleneck slices applied before the upsample, pooling / upsampling as matrix products, one
+    autograd node with its backward written out) against pool -> conv -> upsample -> cat -> bottleneck of the reference
+    (model/modules.py:10-34): output and every gradient; with ``dropout`` the Dropout2d that follows the module
+    (model/modules.py:60) is folded into the node's ReLU pass and must draw the mask the framework's module draws."""
     torch.manual_seed(b + c + h)
     mod = rgb_branch.PSPModule(c, cout).to(DEV)
+    drop = torch.nn.Dropout2d(0.3).train() if dropout else None
     x = torch.randn(b, c, h, h, device=DEV).contiguous(memory_format=torch.channels_last)
     dy = torch.randn(b, cout, h, h, device=DEV).contiguous(memory_format=torch.channels_last)
 
@@ -127,7 +130,8 @@ def test_pyramid_module_linear_form_matches_the_reference_composition(b, c, cout
         try:
             mod.zero_grad(set_to_none=True)
             xi = x.clone(memory_format=torch.preserve_format).requires_grad_(True)
-            y = mod(xi)
+            torch.manual_seed(99)                                           # the dropout mask
+            y = mod(xi, drop=drop)
             y.backward(dy)
             return y.detach(), xi.grad, [p.grad.clone() for p in mod.parameters()]
         finally:
@@ -136,6 +140,8 @@ def test_pyramid_module_linear_form_matches_the_reference_composition(b, c, cout
     y1, g1, p1 = run(True)
     y0, g0, p0 = run(False)
     assert y1.shape == y0.shape and y1.is_contiguous(memory_format=torch.channels_last)
+    if dropout:
+        assert bool((y0.abs().amax(dim=(2, 3)) == 0).any()) and bool((y0.abs().amax(dim=(2, 3)) > 0).any())   # some dropped
     torch.testing.assert_close(y1, y0, rtol=1e-5, atol=1e-5)
     torch.testing.assert_close(g1, g0, rtol=1e-4, atol=1e-5)
     for a, r in zip(p1, p0):
