@@ -798,6 +798,9 @@ __global__ __launch_bounds__(kThreads, 2) void pw_fwd_sk_kernel(
 // point, loop over the output channels, per-channel sum / sum-of-squares partials for the BatchNorm.
 // grid (ceil(P / 256), B); partials [cout][B * tiles].
 // ============================================================================================
+// (Round 4: staging the Z rows of 8 channels + the cloud's xyz in LDS, as interp_grad_csr_dy_lds_kernel does for its rows, was
+// 10-35 % SLOWER here -- 14.1 / 23.6 / 13.4 / 21.8 / 13.1 / 21.9 us against 12.4 / 17.2 / 12.2 / 16.8 / 11.7 / 20.0 on the six
+// SA2-SA4 scales: Z is 16-64 KB per cloud, L2-resident, and each gathered word is used once.)
 constexpr int kGatherAddCO = 32;   // output channels per workgroup (grid.z): keeps enough waves in flight for the
                                    // deep levels, where a cloud has only a few 256-point tiles
 __global__ __launch_bounds__(256) void pw_gather_add_kernel(int n, int P, int S, int cout, int ldw,
@@ -1304,6 +1307,83 @@ __global__ __launch_bounds__(256) void interp_grad_csr_dy_kernel(int C, int n, i
     if (ch < nch) grad_points[((size_t)b * C + c0 + ch) * m + i] = sum[ch];
 }
 
+// The same sums with the dY rows staged in LDS: a workgroup owns kInterpDyCH channels of one cloud, streams their (y, d)
+// rows coalesced, forms dY once per element and keeps it point-major ([n][CH], 32 KB at n = 1024); the list walk then
+// gathers from LDS instead of moving a 64-byte sector per 4 useful bytes (31.8 -> see profiles/r04_fp_dgrad_microbench.txt).
+// Same terms in the same order per output: bit-identical with the kernel above.  grid (ceil(C / 8), B).
+template <int NT>
+__global__ __launch_bounds__(NT) void interp_grad_csr_dy_lds_kernel(int C, int n, int m, const float* __restrict__ y,
+                                                                    const float* __restrict__ d,
+                                                                    const float* __restrict__ bn,
+                                                                    const float* __restrict__ bwdc,
+                                                                    const float* __restrict__ w_all,
+                                                                    const int* __restrict__ off_all,
+                                                                    const int* __restrict__ ent_all,
+                                                                    float* __restrict__ grad_points) {
+  constexpr int CH = kInterpDyCH;
+  extern __shared__ __attribute__((aligned(16))) float dyl[];     // [n][CH]
+  const int b = blockIdx.y, c0 = blockIdx.x * CH;
+  const int nch = min(CH, C - c0);
+  float rs[CH], rh[CH], ca[CH], cb[CH], cc[CH];
+#pragma unroll
+  for (int ch = 0; ch < CH; ++ch) {
+    const int c = c0 + min(ch, nch - 1);
+    rs[ch] = bn[c]; rh[ch] = bn[C + c];
+    ca[ch] = bwdc[c]; cb[ch] = bwdc[C + c]; cc[ch] = bwdc[2 * C + c];
+  }
+  for (int p = threadIdx.x * 4; p < n; p += NT * 4) {             // n % 4 == 0 (host-checked)
+    float4 v[CH];
+#pragma unroll
+    for (int ch = 0; ch < CH; ++ch) {
+      const size_t row = ((size_t)b * C + c0 + min(ch, nch - 1)) * n + p;
+      const float4 yv = *reinterpret_cast<const float4*>(y + row);
+      const float4 dv = *reinterpret_cast<const float4*>(d + row);
+      v[ch].x = ca[ch] * ((yv.x * rs[ch] + rh[ch] > 0.f) ? dv.x : 0.f) + cb[ch] + cc[ch] * yv.x;
+      v[ch].y = ca[ch] * ((yv.y * rs[ch] + rh[ch] > 0.f) ? dv.y : 0.f) + cb[ch] + cc[ch] * yv.y;
+      v[ch].z = ca[ch] * ((yv.z * rs[ch] + rh[ch] > 0.f) ? dv.z : 0.f) + cb[ch] + cc[ch] * yv.z;
+      v[ch].w = ca[ch] * ((yv.w * rs[ch] + rh[ch] > 0.f) ? dv.w : 0.f) + cb[ch] + cc[ch] * yv.w;
+    }
+#pragma unroll
+    for (int h = 0; h < CH / 4; ++h) {
+      *reinterpret_cast<float4*>(&dyl[(size_t)(p + 0) * CH + 4 * h]) = make_float4(v[4 * h].x, v[4 * h + 1].x, v[4 * h + 2].x, v[4 * h + 3].x);
+      *reinterpret_cast<float4*>(&dyl[(size_t)(p + 1) * CH + 4 * h]) = make_float4(v[4 * h].y, v[4 * h + 1].y, v[4 * h + 2].y, v[4 * h + 3].y);
+      *reinterpret_cast<float4*>(&dyl[(size_t)(p + 2) * CH + 4 * h]) = make_float4(v[4 * h].z, v[4 * h + 1].z, v[4 * h + 2].z, v[4 * h + 3].z);
+      *reinterpret_cast<float4*>(&dyl[(size_t)(p + 3) * CH + 4 * h]) = make_float4(v[4 * h].w, v[4 * h + 1].w, v[4 * h + 2].w, v[4 * h + 3].w);
+    }
+  }
+  __syncthreads();
+  const int* off = off_all + (size_t)b * (m + 1);
+  const int* ent = ent_all + (size_t)b * n * 3;
+  const float* w = w_all + (size_t)b * n * 3;
+  for (int i = threadIdx.x; i < m; i += NT) {
+    const int a = off[i], z = off[i + 1];
+    float sum[CH];
+#pragma unroll
+    for (int ch = 0; ch < CH; ++ch) sum[ch] = 0.f;
+    for (int u = a; u < z; u += 4) {
+      int e[4];
+      float we[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) e[q] = ent[min(u + q, z - 1)];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) we[q] = (u + q < z) ? w[e[q]] : 0.f;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float4* src = reinterpret_cast<const float4*>(&dyl[(size_t)(e[q] / 3) * CH]);
+#pragma unroll
+        for (int h = 0; h < CH / 4; ++h) {
+          const float4 t = src[h];
+          sum[4 * h + 0] += t.x * we[q]; sum[4 * h + 1] += t.y * we[q];
+          sum[4 * h + 2] += t.z * we[q]; sum[4 * h + 3] += t.w * we[q];
+        }
+      }
+    }
+#pragma unroll
+    for (int ch = 0; ch < CH; ++ch)
+      if (ch < nch) grad_points[((size_t)b * C + c0 + ch) * m + i] = sum[ch];
+  }
+}
+
 // per-channel partial sums of g and g * y  (-> dbeta, dgamma after finalize)
 // grid: (chunks_per_row, C, B); partials [C][B*chunks]
 constexpr int kStatChunk = 4096;
@@ -1685,8 +1765,8 @@ struct BwdFinArgs {
   int nt;
   int training;
 };
-template <int CH>
-__global__ __launch_bounds__(256) void pw_scatter_csr_kernel(int cout, int n, int P, const float* __restrict__ y,
+template <int CH, int NT>
+__global__ __launch_bounds__(NT) void pw_scatter_csr_kernel(int cout, int n, int P, const float* __restrict__ y,
                                                              const float* __restrict__ d,
                                                              const float* __restrict__ bn,
                                                              const float* __restrict__ bwdc,
@@ -1704,7 +1784,7 @@ __global__ __launch_bounds__(256) void pw_scatter_csr_kernel(int cout, int n, in
     // wave w reduces the partials of channels w, w + 4, ... of this workgroup (double, fixed order), then the constants
     // go through LDS to every thread
     float* cst = dy;                     // [CH][3] (dy is written after the barrier below)
-    for (int ch = wave_id(); ch < CH; ch += 4) {
+    for (int ch = wave_id(); ch < CH; ch += NT / 64) {
       const int co = min(c0 + ch, cout - 1);
       const float* pg = fin.part_g + (size_t)co * fin.nt;
       const float* pgy = fin.part_gy + (size_t)co * fin.nt;
@@ -1747,7 +1827,7 @@ __global__ __launch_bounds__(256) void pw_scatter_csr_kernel(int cout, int n, in
     }
   }
   // ---- phase 1: dY0 of CH channel rows -> LDS (P % 4 == 0) ----
-  for (int p = threadIdx.x * 4; p < P; p += 1024) {
+  for (int p = threadIdx.x * 4; p < P; p += NT * 4) {
     float4 v[CH];
 #pragma unroll
     for (int ch = 0; ch < CH; ++ch) {
@@ -1776,7 +1856,7 @@ __global__ __launch_bounds__(256) void pw_scatter_csr_kernel(int cout, int n, in
   for (int ch = 0; ch < CH; ++ch) wx[ch][0] = wx[ch][1] = wx[ch][2] = 0.f;
   const int part = threadIdx.x & 3;
   const int n_round = (n + 63) / 64 * 64;            // whole quads stay converged for the DPP combine
-  for (int i = threadIdx.x >> 2; i < n_round; i += 64) {
+  for (int i = threadIdx.x >> 2; i < n_round; i += NT / 4) {
     const bool valid = i < n;
     const int a0 = valid ? off[i] : 0, z0 = valid ? off[i + 1] : 0;
     const int len = z0 - a0, q = (len + 3) >> 2;
@@ -1822,7 +1902,7 @@ __global__ __launch_bounds__(256) void pw_scatter_csr_kernel(int cout, int n, in
   }
   if (dwx != nullptr) {   // fixed-order workgroup sum -> dwx[b][co][0:3]
     __syncthreads();
-    float* wred = dy;     // [4 waves][CH*3]
+    float* wred = dy;     // [NT / 64 waves][CH*3]
 #pragma unroll
     for (int ch = 0; ch < CH; ++ch)
 #pragma unroll
@@ -1831,9 +1911,14 @@ __global__ __launch_bounds__(256) void pw_scatter_csr_kernel(int cout, int n, in
         if (lane_id() == 0) wred[wave_id() * CH * 3 + ch * 3 + k] = t;
       }
     __syncthreads();
-    if (threadIdx.x < nch * 3)
-      dwx[((size_t)b * cout + c0) * 3 + threadIdx.x] = (wred[threadIdx.x] + wred[CH * 3 + threadIdx.x]) +
-                                                       (wred[2 * CH * 3 + threadIdx.x] + wred[3 * CH * 3 + threadIdx.x]);
+    if (threadIdx.x < nch * 3) {
+      float t = 0.f;                      // waves in groups of four, ((w0 + w1) + (w2 + w3)) + ...: the 256-thread order first
+#pragma unroll
+      for (int w = 0; w < NT / 64; w += 4)
+        t += (wred[w * CH * 3 + threadIdx.x] + wred[(w + 1) * CH * 3 + threadIdx.x]) +
+             (wred[(w + 2) * CH * 3 + threadIdx.x] + wred[(w + 3) * CH * 3 + threadIdx.x]);
+      dwx[((size_t)b * cout + c0) * 3 + threadIdx.x] = t;
+    }
   }
 }
 
@@ -3385,6 +3470,10 @@ int g_wgrad2_target = 512;     // key 12: workgroups of a pw_wgrad2_kernel launc
 inline bool wgrad2_ok(int cin, int cout) {
   return g_wgrad2_enable && cin >= 64 && cout >= 64 && cin % 32 == 0 && cout % 32 == 0;
 }
+int g_interp_dy_lds = 1;           // key 22: 0 = interp_grad_csr_dy gathers dY from global memory (no LDS staging)
+int g_scatter_csr_threads = 0;    // key 21: threads per workgroup of pw_scatter_csr_kernel (256 / 512 / 1024); 0 = 512 when the cloud has
+                                  // >= 256 source points, else 256 (alone on SA2 / SA3 / SA4 layer 0: 512 threads 25.8 + 40.8 / 17.4 + 23.3 /
+                                  // 18.6 + 28.4 us, 256 threads 35.5 + 50.9 / 22.0 + 28.4 / 15.6 + 23.1, 1024 never best)
 int g_wgrad2_tile_max = 64;    // key 20.  Round 3: 64 x 64 output tiles for every role-split wgrad.  A launch's split-K partials
                                // are (workgroups x tile bytes): 256 x 64 KB = 16 MB at 128 x 128, 512 x 16 KB = 8 MB now -- half the
                                // partial traffic of the 13 launches per step -- and inside the step the smaller tiles with 512
@@ -3495,6 +3584,8 @@ int istnet_pw_set_tuning(int key, int value) {
     case 14: g_fwd2_min_waves = value > 0 ? value : 1024; return 0;
     case 12: g_wgrad2_target = value > 0 ? value : 512; return 0;
     case 20: g_wgrad2_tile_max = value >= 128 ? 128 : 64; return 0;
+    case 21: g_scatter_csr_threads = value; return 0;
+    case 22: g_interp_dy_lds = value != 0; return 0;
     default: return ISTNET_PN2_EINVAL;
   }
 }
@@ -3784,6 +3875,16 @@ int istnet_interp_grad_csr_dy(int b, int c, int n, int m, const float* y, const 
   if (b <= 0 || c <= 0 || m <= 0 || n <= 0 || !y || !d_dense || !bn || !bwdc || !weight || !offsets || !entries ||
       !grad_points)
     return ISTNET_PN2_EINVAL;
+  const size_t lds = (size_t)kInterpDyCH * n * 4;
+  if (g_interp_dy_lds && (n & 3) == 0 && lds <= 64 * 1024) {
+    if (m >= 512)
+      hipLaunchKernelGGL(interp_grad_csr_dy_lds_kernel<512>, dim3(ceil_div(c, kInterpDyCH), b), dim3(512), lds,
+                         as_stream(stream), c, n, m, y, d_dense, bn, bwdc, weight, offsets, entries, grad_points);
+    else
+      hipLaunchKernelGGL(interp_grad_csr_dy_lds_kernel<256>, dim3(ceil_div(c, kInterpDyCH), b), dim3(256), lds,
+                         as_stream(stream), c, n, m, y, d_dense, bn, bwdc, weight, offsets, entries, grad_points);
+    return (int)hipGetLastError();
+  }
   hipLaunchKernelGGL(interp_grad_csr_dy_kernel, dim3(ceil_div(m, 256), ceil_div(c, kInterpDyCH), b), dim3(256), 0,
                      as_stream(stream), c, n, m, y, d_dense, bn, bwdc, weight, offsets, entries, grad_points);
   return (int)hipGetLastError();
@@ -4072,13 +4173,20 @@ static int scatter_dy_csr_impl(int b, int cout, int n, int p, const float* y, co
     return ISTNET_PN2_EINVAL;
   const int ch = scatter_csr_ch(b, cout, p);
   if ((size_t)ch * p * 4 > 64 * 1024) return ISTNET_PN2_EINVAL;    // a single row does not fit: caller uses the atomic kernel
-  const size_t lds = (size_t)ch * p * 4 < 4 * 16 * 3 * 4 ? 4 * 16 * 3 * 4 : (size_t)ch * p * 4;
+  const size_t lds = (size_t)ch * p * 4 < 16 * 16 * 3 * 4 ? 16 * 16 * 3 * 4 : (size_t)ch * p * 4;
   const dim3 grid(ceil_div(cout, ch), b);
   const long long obs = out_bstride > 0 ? out_bstride : (long long)cout * n;
   const int gsz = group_nsample > 0 ? group_nsample : 1;
+#define ISTNET_SCSR_NT(CH, NT)                                                                                       \
+  hipLaunchKernelGGL((pw_scatter_csr_kernel<CH, NT>), grid, dim3(NT), lds, as_stream(stream), cout, n, p, y, d_dense, \
+                     bn, bwdc, offsets, entries, out, obs, xyz, new_xyz, gsz, dwx, fin)
 #define ISTNET_SCSR(CH)                                                                                            \
-  hipLaunchKernelGGL(pw_scatter_csr_kernel<CH>, grid, dim3(256), lds, as_stream(stream), cout, n, p, y, d_dense, bn, \
-                     bwdc, offsets, entries, out, obs, xyz, new_xyz, gsz, dwx, fin)
+  do {                                                                                                             \
+    const int nt_ = g_scatter_csr_threads > 0 ? g_scatter_csr_threads : (n >= 256 ? 512 : 256);                    \
+    if (nt_ >= 1024) ISTNET_SCSR_NT(CH, 1024);                                                                     \
+    else if (nt_ >= 512) ISTNET_SCSR_NT(CH, 512);                                                                  \
+    else ISTNET_SCSR_NT(CH, 256);                                                                                  \
+  } while (0)
   switch (ch) {
     case 16: ISTNET_SCSR(16); break;
     case 8: ISTNET_SCSR(8); break;
@@ -4087,6 +4195,7 @@ static int scatter_dy_csr_impl(int b, int cout, int n, int p, const float* y, co
     default: ISTNET_SCSR(1); break;
   }
 #undef ISTNET_SCSR
+#undef ISTNET_SCSR_NT
   return (int)hipGetLastError();
 }
 

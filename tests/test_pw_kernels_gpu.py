@@ -517,17 +517,61 @@ def test_scatter_csr_matches_dense_scatter_and_is_deterministic(n, npoint, s, co
     want_g = torch.zeros(b, cout, n, device=DEV).scatter_add_(2, flat.unsqueeze(1).expand(-1, cout, -1), dy)
     want_dwx = torch.einsum("bcp,bpk->ck", dy, xrel)
     chunks = lib.istnet_pw_scatter_csr_chunks(n)
+    first = None
+    try:
+        for threads in (0, 256, 512, 1024):              # key 21: workgroup size (0 = by the cloud's size)
+            assert lib.istnet_pw_set_tuning(21, threads) == 0
+            outs = []
+            for _ in range(2):
+                out = torch.empty(b, cout, n, device=DEV)
+                dwx = torch.empty(b * chunks, cout, 3, device=DEV)
+                assert lib.istnet_pw_scatter_dy_csr(b, cout, n, p, y.data_ptr(), d.data_ptr(), bn.data_ptr(), bwdc.data_ptr(),
+                                                    off.data_ptr(), ent.data_ptr(), out.data_ptr(), 0, xyz.data_ptr(),
+                                                    new_xyz.data_ptr(), s, dwx.data_ptr(), _st()) == 0
+                outs.append((out, dwx))
+            torch.testing.assert_close(outs[0][0], want_g, rtol=1e-4, atol=1e-4)
+            torch.testing.assert_close(outs[0][1].sum(0), want_dwx, rtol=1e-4, atol=2e-4)
+            assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+            if first is None:
+                first = outs[0][0]
+            assert torch.equal(outs[0][0], first)        # a point's list is summed in the same order whatever the workgroup size
+    finally:
+        lib.istnet_pw_set_tuning(21, 0)
+
+
+@pytest.mark.parametrize("b,c,n,m", [(2, 128, 1024, 512), (3, 20, 256, 100), (2, 8, 64, 16), (1, 260, 128, 64)])
+def test_interp_grad_with_dy_formed_per_element(b, c, n, m):
+    """istnet_interp_grad_csr_dy: the gradient of three_interpolate's input with dY = ca g [y scale + shift > 0] + cb + cc y
+    formed per gathered element -- from global memory (key 22 = 0) and from LDS-staged rows (default) -- against
+    three_interpolate's scatter of the materialised dY; the two variants bit-identical; ragged sizes."""
+    from istnet_amd.pointnet2 import _ext
+    lib = _native.lib()
+    g = torch.Generator().manual_seed(c + n)
+    unknown, known = torch.rand(b, n, 3, generator=g).to(DEV), torch.rand(b, m, 3, generator=g).to(DEV)
+    idx, weight = _ext.three_nn_weights(unknown, known)
+    off, ent = _ext.interp_csr(idx, m)
+    y = torch.randn(b, c, n, generator=g).to(DEV)
+    d = torch.randn(b, c, n, generator=g).to(DEV)
+    bn = _bn_block(c, g)
+    bwdc = torch.stack([torch.rand(c, generator=g) + 0.5, torch.randn(c, generator=g) * 0.1,
+                        torch.randn(c, generator=g) * 0.1]).contiguous().to(DEV)
+    mask = (y * bn[0].view(1, -1, 1) + bn[1].view(1, -1, 1)) > 0
+    dy = (bwdc[0].view(1, -1, 1) * (d * mask) + bwdc[1].view(1, -1, 1) + bwdc[2].view(1, -1, 1) * y).double()
+    want = torch.zeros(b, c, m, dtype=torch.float64, device=DEV)
+    for k in range(3):
+        want.scatter_add_(2, idx[:, :, k].long().unsqueeze(1).expand(-1, c, -1), dy * weight[:, :, k].double().unsqueeze(1))
     outs = []
-    for _ in range(2):
-        out = torch.empty(b, cout, n, device=DEV)
-        dwx = torch.empty(b * chunks, cout, 3, device=DEV)
-        assert lib.istnet_pw_scatter_dy_csr(b, cout, n, p, y.data_ptr(), d.data_ptr(), bn.data_ptr(), bwdc.data_ptr(),
-                                            off.data_ptr(), ent.data_ptr(), out.data_ptr(), 0, xyz.data_ptr(),
-                                            new_xyz.data_ptr(), s, dwx.data_ptr(), _st()) == 0
-        outs.append((out, dwx))
-    torch.testing.assert_close(outs[0][0], want_g, rtol=1e-4, atol=1e-4)
-    torch.testing.assert_close(outs[0][1].sum(0), want_dwx, rtol=1e-4, atol=2e-4)
-    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    try:
+        for flag in (0, 1):
+            assert lib.istnet_pw_set_tuning(22, flag) == 0
+            out = torch.empty(b, c, m, device=DEV)
+            assert lib.istnet_interp_grad_csr_dy(b, c, n, m, y.data_ptr(), d.data_ptr(), bn.data_ptr(), bwdc.data_ptr(),
+                                                 weight.data_ptr(), off.data_ptr(), ent.data_ptr(), out.data_ptr(), _st()) == 0
+            outs.append(out)
+    finally:
+        lib.istnet_pw_set_tuning(22, 1)
+    torch.testing.assert_close(outs[1].double(), want, rtol=1e-5, atol=1e-5)
+    assert torch.equal(outs[0], outs[1])
 
 
 def test_inverse_lists_on_degenerate_indices():

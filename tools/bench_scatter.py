@@ -35,8 +35,12 @@ for name, n, npoint, s, cout in [("SA2-s16", 512, 256, 16, 32), ("SA2-s32", 512,
     dwx2 = torch.empty(B * ch, cout, 3, device=dev)
     f2 = lambda: lib.istnet_pw_scatter_dy_csr(B, cout, n, p, y.data_ptr(), d.data_ptr(), bn.data_ptr(), bw.data_ptr(), off.data_ptr(),
                                               ent.data_ptr(), out.data_ptr(), 0, xyz.data_ptr(), new_xyz.data_ptr(), s, dwx2.data_ptr(), st)
-    t2 = timeit(f2)
+    per_nt = []
+    for nt in (512, 1024, 256, 0):           # istnet_pw_set_tuning key 21; the default (0 = by size) last, so it is what stays set
+        lib.istnet_pw_set_tuning(21, nt)
+        per_nt.append((nt, timeit(f2)))
+    t2 = per_nt[-1][1]
     tb = timeit(lambda: _ext.ball_csr(idx, n))
     t = timeit(f)
     nbytes = 4.0 * B * (2 * cout * p + p + cout * n)
-    print(f"{name}: cout {cout:4d} P {p:6d}  {t:7.1f} us  {nbytes / t / 1e3:7.0f} GB/s  ({B * ((cout + 3) // 4)} workgroups)   csr: {t2:6.1f} us {nbytes / t2 / 1e3:6.0f} GB/s  (+ list build {tb:5.1f} us, geometry stream)")
+    print(f"{name}: cout {cout:4d} P {p:6d}  {t:7.1f} us  {nbytes / t / 1e3:7.0f} GB/s  ({B * ((cout + 3) // 4)} workgroups)   csr: {t2:6.1f} us {nbytes / t2 / 1e3:6.0f} GB/s  (+ list build {tb:5.1f} us, geometry stream)   threads: " + "  ".join(f"{nt}: {t_:.1f} us" for nt, t_ in per_nt))
