@@ -937,6 +937,33 @@ __global__ __launch_bounds__(256) void scatter_add_global_kernel(
 // ============================================================================
 constexpr int kNnTile = 2048;  // known points staged per LDS tile (24 KB)
 
+// FOUR lanes per unknown point (round 4): lane q of a quad scans the known points q, q + 4, ... in ascending order with
+// the reference's strict-less insertion, then the quad merges its four sorted triples (two quad_perm exchanges) under the
+// order (distance, index) -- which is exactly what the reference's sequential scan produces: a candidate displaces an entry
+// only when strictly closer, so among equal distances the smaller index stays ahead.  One thread per point gave 128
+// workgroups of 512-step loops on the encoder's largest level (32 us); this form gives 512 workgroups of 128-step loops.
+struct Nn3 { float d1, d2, d3; int i1, i2, i3; };
+__device__ __forceinline__ bool nn_before(float da, int ia, float db, int ib) { return da < db || (da == db && ia < ib); }
+__device__ __forceinline__ void nn_insert(Nn3& t, float d, int k) {          // (d, k) into the sorted triple, (distance, index) order
+  if (nn_before(d, k, t.d1, t.i1)) { t.d3 = t.d2; t.i3 = t.i2; t.d2 = t.d1; t.i2 = t.i1; t.d1 = d; t.i1 = k; }
+  else if (nn_before(d, k, t.d2, t.i2)) { t.d3 = t.d2; t.i3 = t.i2; t.d2 = d; t.i2 = k; }
+  else if (nn_before(d, k, t.d3, t.i3)) { t.d3 = d; t.i3 = k; }
+}
+template <int CTRL>
+__device__ __forceinline__ void nn_merge_quad(Nn3& t) {
+  const float e1 = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(t.d1), CTRL, 0xf, 0xf, false));
+  const float e2 = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(t.d2), CTRL, 0xf, 0xf, false));
+  const float e3 = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(t.d3), CTRL, 0xf, 0xf, false));
+  const int j1 = __builtin_amdgcn_mov_dpp(t.i1, CTRL, 0xf, 0xf, false);
+  const int j2 = __builtin_amdgcn_mov_dpp(t.i2, CTRL, 0xf, 0xf, false);
+  const int j3 = __builtin_amdgcn_mov_dpp(t.i3, CTRL, 0xf, 0xf, false);
+  // an unfilled slot is (+inf, index 0, as the reference initialises it): it must never displace a real candidate, and two
+  // unfilled slots are interchangeable -- insert the partner's entries only while they are real
+  if (e1 < __builtin_inff()) nn_insert(t, e1, j1);
+  if (e2 < __builtin_inff()) nn_insert(t, e2, j2);
+  if (e3 < __builtin_inff()) nn_insert(t, e3, j3);
+}
+
 template <int CONV>
 __global__ __launch_bounds__(256) void three_nn_kernel(int n, int m,
                                                        const float* __restrict__ unknown_all,
@@ -948,47 +975,40 @@ __global__ __launch_bounds__(256) void three_nn_kernel(int n, int m,
   const int cloud = blockIdx.y;
   const float* unknown = unknown_all + (size_t)cloud * n * 3;
   const float* known = known_all + (size_t)cloud * m * 3;
-  const int j = blockIdx.x * 256 + threadIdx.x;
+  const int j = blockIdx.x * 64 + (threadIdx.x >> 2), sub = threadIdx.x & 3;
   const bool active = j < n;
   float ux = 0.f, uy = 0.f, uz = 0.f;
   if (active) { ux = unknown[3 * j + 0]; uy = unknown[3 * j + 1]; uz = unknown[3 * j + 2]; }
   // The reference keeps doubles initialised to 1e40 and stores them back as f32
   // (=> +inf when unfilled); f32 +inf gives the same comparisons and result.
-  float best1 = __builtin_inff(), best2 = __builtin_inff(), best3 = __builtin_inff();
-  int besti1 = 0, besti2 = 0, besti3 = 0;
+  Nn3 t{__builtin_inff(), __builtin_inff(), __builtin_inff(), 0, 0, 0};
   for (int base = 0; base < m; base += kNnTile) {
     const int cntk = min(kNnTile, m - base);
     __syncthreads();
     for (int e = threadIdx.x; e < 3 * cntk; e += 256) kn[e] = known[(size_t)3 * base + e];
     __syncthreads();
-    if (active) {
-      for (int kk = 0; kk < cntk; ++kk) {
-        const float d = sqdist<CONV>(ux, uy, uz, kn[3 * kk + 0], kn[3 * kk + 1], kn[3 * kk + 2]);
-        const int k = base + kk;
-        if (d < best1) {
-          best3 = best2; besti3 = besti2;
-          best2 = best1; besti2 = besti1;
-          best1 = d; besti1 = k;
-        } else if (d < best2) {
-          best3 = best2; besti3 = besti2;
-          best2 = d; besti2 = k;
-        } else if (d < best3) {
-          best3 = d; besti3 = k;
-        }
-      }
+    for (int kk = sub; kk < cntk; kk += 4) {
+      const float d = sqdist<CONV>(ux, uy, uz, kn[3 * kk + 0], kn[3 * kk + 1], kn[3 * kk + 2]);
+      const int k = base + kk;
+      // ascending k inside a lane: the reference's strict-less chain (a NaN distance is never taken, as there)
+      if (d < t.d1) { t.d3 = t.d2; t.i3 = t.i2; t.d2 = t.d1; t.i2 = t.i1; t.d1 = d; t.i1 = k; }
+      else if (d < t.d2) { t.d3 = t.d2; t.i3 = t.i2; t.d2 = d; t.i2 = k; }
+      else if (d < t.d3) { t.d3 = d; t.i3 = k; }
     }
   }
-  if (active) {
+  nn_merge_quad<0xB1>(t);          // quad_perm [1,0,3,2]: lanes 0<->1, 2<->3
+  nn_merge_quad<0x4E>(t);          // quad_perm [2,3,0,1]: pairs 0,1 <-> 2,3
+  if (active && sub == 0) {
     int* ix = idx_all + ((size_t)cloud * n + j) * 3;
-    ix[0] = besti1; ix[1] = besti2; ix[2] = besti3;
+    ix[0] = t.i1; ix[1] = t.i2; ix[2] = t.i3;
     if (dist2_all != nullptr) {
       float* d2 = dist2_all + ((size_t)cloud * n + j) * 3;
-      d2[0] = best1; d2[1] = best2; d2[2] = best3;
+      d2[0] = t.d1; d2[1] = t.d2; d2[2] = t.d3;
     }
     if (weight_all != nullptr) {
       // inverse-distance weights of PointnetFPModule (pointnet2_modules.py:185-188 with ThreeNN's sqrt,
       // pointnet2_utils.py:140-149): r = 1 / (sqrt(d2) + 1e-8), w = r / (r0 + r1 + r2); IEEE sqrt and division
-      const float r1 = 1.0f / (sqrtf(best1) + 1e-8f), r2 = 1.0f / (sqrtf(best2) + 1e-8f), r3 = 1.0f / (sqrtf(best3) + 1e-8f);
+      const float r1 = 1.0f / (sqrtf(t.d1) + 1e-8f), r2 = 1.0f / (sqrtf(t.d2) + 1e-8f), r3 = 1.0f / (sqrtf(t.d3) + 1e-8f);
       const float norm = (r1 + r2) + r3;
       float* w = weight_all + ((size_t)cloud * n + j) * 3;
       w[0] = r1 / norm; w[1] = r2 / norm; w[2] = r3 / norm;
@@ -1247,7 +1267,7 @@ int istnet_pn2_three_nn(int b, int n, int m, const float* unknown, const float* 
                         int* idx, void* stream) {
   if (b < 0 || n < 0 || m < 0) return ISTNET_PN2_EINVAL;
   if (b == 0 || n == 0) return 0;
-  ISTNET_CONV_DISPATCH(hipLaunchKernelGGL(three_nn_kernel<CONV_>, dim3(ceil_div(n, 256), b), dim3(256), 0,
+  ISTNET_CONV_DISPATCH(hipLaunchKernelGGL(three_nn_kernel<CONV_>, dim3(ceil_div(n, 64), b), dim3(256), 0,
                                           as_stream(stream), n, m, unknown, known, dist2, idx, (float*)nullptr));
   return (int)hipGetLastError();
 }
@@ -1256,7 +1276,7 @@ int istnet_pn2_three_nn_weights(int b, int n, int m, const float* unknown, const
                                 void* stream) {
   if (b < 0 || n < 0 || m < 0 || !idx || !weight) return ISTNET_PN2_EINVAL;
   if (b == 0 || n == 0) return 0;
-  ISTNET_CONV_DISPATCH(hipLaunchKernelGGL(three_nn_kernel<CONV_>, dim3(ceil_div(n, 256), b), dim3(256), 0,
+  ISTNET_CONV_DISPATCH(hipLaunchKernelGGL(three_nn_kernel<CONV_>, dim3(ceil_div(n, 64), b), dim3(256), 0,
                                           as_stream(stream), n, m, unknown, known, (float*)nullptr, idx, weight));
   return (int)hipGetLastError();
 }

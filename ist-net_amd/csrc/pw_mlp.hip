@@ -3356,7 +3356,8 @@ struct ReduceBatch {
 // Workgroup = 64 consecutive elements x 16 split groups (1024 threads): a wave reads 256 contiguous bytes per split, four
 // independent chains per thread keep loads in flight, the sixteen group sums meet in LDS in a fixed order.  (Round 3 used
 // four groups: with 128 - 512 splits a thread walked 32 - 128 dependent-latency steps, 10 us per launch on average;
-// sixteen groups cut the walk fourfold.  Deterministic, but a different summation order than round 3's.)
+// sixteen groups cut the walk fourfold.  Deterministic, but a different summation order than round 3's.  Round 4 also tried
+// 64 groups of 16 lanes x float4 -- four splits per wave instruction, a quarter of the steps: +1 % on the step, in-box A/B.)
 constexpr int kRedGroups = 16;
 __global__ __launch_bounds__(64 * kRedGroups) void wgrad_reduce_multi_kernel(ReduceBatch rb) {
   __shared__ float red[kRedGroups][64];

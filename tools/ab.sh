@@ -6,6 +6,6 @@ B="python bench.py --no-roofline --no-cpu-baseline --steps 50 --warmup 10 $*"
 L=ist-net_amd/lib/libistnet_pn2.so
 cp $L ab_base/new.so
 for i in $(seq $R); do
-  cp ab_base/base.so $L; echo -n "base: "; $B 2>&1 | tail -1 | python -c "import sys,json; print(json.loads(sys.stdin.read())['ms_per_step'])"
-  cp ab_base/new.so $L;  echo -n "new:  "; $B 2>&1 | tail -1 | python -c "import sys,json; print(json.loads(sys.stdin.read())['ms_per_step'])"
+  cp ab_base/base.so $L; echo -n "base: "; $B 2>&1 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['ms_per_step'], (d.get('unpipelined') or {}).get('ms_per_step', ''))"
+  cp ab_base/new.so $L;  echo -n "new:  "; $B 2>&1 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['ms_per_step'], (d.get('unpipelined') or {}).get('ms_per_step', ''))"
 done
