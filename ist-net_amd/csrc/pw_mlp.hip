@@ -1309,7 +1309,7 @@ __global__ __launch_bounds__(256) void interp_grad_csr_dy_kernel(int C, int n, i
 
 // The same sums with the dY rows staged in LDS: a workgroup owns kInterpDyCH channels of one cloud, streams their (y, d)
 // rows coalesced, forms dY once per element and keeps it point-major ([n][CH], 32 KB at n = 1024); the list walk then
-// gathers from LDS instead of moving a 64-byte sector per 4 useful bytes (31.8 -> see profiles/r04_fp_dgrad_microbench.txt).
+// gathers from LDS instead of moving a 64-byte sector per 4 useful bytes (31.8 -> see profiles/r04_interp_grad_microbench.txt).
 // Same terms in the same order per output: bit-identical with the kernel above.  grid (ceil(C / 8), B).
 template <int NT>
 __global__ __launch_bounds__(NT) void interp_grad_csr_dy_lds_kernel(int C, int n, int m, const float* __restrict__ y,
@@ -1343,12 +1343,14 @@ __global__ __launch_bounds__(NT) void interp_grad_csr_dy_lds_kernel(int C, int n
       v[ch].z = ca[ch] * ((yv.z * rs[ch] + rh[ch] > 0.f) ? dv.z : 0.f) + cb[ch] + cc[ch] * yv.z;
       v[ch].w = ca[ch] * ((yv.w * rs[ch] + rh[ch] > 0.f) ? dv.w : 0.f) + cb[ch] + cc[ch] * yv.w;
     }
+    // LDS row of point j: (j & 3) * n / 4 + (j >> 2) -- consecutive lanes write consecutive rows (see pw_scatter_csr_kernel)
+    const size_t r0 = (size_t)(p >> 2), q4 = (size_t)(n >> 2);
 #pragma unroll
     for (int h = 0; h < CH / 4; ++h) {
-      *reinterpret_cast<float4*>(&dyl[(size_t)(p + 0) * CH + 4 * h]) = make_float4(v[4 * h].x, v[4 * h + 1].x, v[4 * h + 2].x, v[4 * h + 3].x);
-      *reinterpret_cast<float4*>(&dyl[(size_t)(p + 1) * CH + 4 * h]) = make_float4(v[4 * h].y, v[4 * h + 1].y, v[4 * h + 2].y, v[4 * h + 3].y);
-      *reinterpret_cast<float4*>(&dyl[(size_t)(p + 2) * CH + 4 * h]) = make_float4(v[4 * h].z, v[4 * h + 1].z, v[4 * h + 2].z, v[4 * h + 3].z);
-      *reinterpret_cast<float4*>(&dyl[(size_t)(p + 3) * CH + 4 * h]) = make_float4(v[4 * h].w, v[4 * h + 1].w, v[4 * h + 2].w, v[4 * h + 3].w);
+      *reinterpret_cast<float4*>(&dyl[(r0) * CH + 4 * h]) = make_float4(v[4 * h].x, v[4 * h + 1].x, v[4 * h + 2].x, v[4 * h + 3].x);
+      *reinterpret_cast<float4*>(&dyl[(q4 + r0) * CH + 4 * h]) = make_float4(v[4 * h].y, v[4 * h + 1].y, v[4 * h + 2].y, v[4 * h + 3].y);
+      *reinterpret_cast<float4*>(&dyl[(2 * q4 + r0) * CH + 4 * h]) = make_float4(v[4 * h].z, v[4 * h + 1].z, v[4 * h + 2].z, v[4 * h + 3].z);
+      *reinterpret_cast<float4*>(&dyl[(3 * q4 + r0) * CH + 4 * h]) = make_float4(v[4 * h].w, v[4 * h + 1].w, v[4 * h + 2].w, v[4 * h + 3].w);
     }
   }
   __syncthreads();
@@ -1369,7 +1371,8 @@ __global__ __launch_bounds__(NT) void interp_grad_csr_dy_lds_kernel(int C, int n
       for (int q = 0; q < 4; ++q) we[q] = (u + q < z) ? w[e[q]] : 0.f;
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        const float4* src = reinterpret_cast<const float4*>(&dyl[(size_t)(e[q] / 3) * CH]);
+        const int j = e[q] / 3;
+        const float4* src = reinterpret_cast<const float4*>(&dyl[((size_t)(j & 3) * (n >> 2) + (j >> 2)) * CH]);
 #pragma unroll
         for (int h = 0; h < CH / 4; ++h) {
           const float4 t = src[h];
@@ -1754,6 +1757,7 @@ __global__ __launch_bounds__(256) void pw_scatter_dy_kernel(int cout, int n, int
 // dwx[b][co][0:3] = sum_i xyz[i] * G[co][i] - sum_slots dY0[co][e] * centre[e / S].
 // Optional: bn_finalize_bwd of this layer done here (the statistics partials of layer 0 come from the fused backward
 // kernel of layer 1; each workgroup needs the constants of its CH channels only): one launch less on the chain.
+__device__ __forceinline__ float f4_get(const float4& v, int k) { return k == 0 ? v.x : (k == 1 ? v.y : (k == 2 ? v.z : v.w)); }
 struct BwdFinArgs {
   const float* part_g;     // [cout][nt]; null: constants come from bwdc
   const float* part_gy;
@@ -1839,10 +1843,27 @@ __global__ __launch_bounds__(NT) void pw_scatter_csr_kernel(int cout, int n, int
       v[ch].z = ca[ch] * ((yv.z * rs[ch] + rh[ch] > 0.f) ? dv.z : 0.f) + cb[ch] + cc[ch] * yv.z;
       v[ch].w = ca[ch] * ((yv.w * rs[ch] + rh[ch] > 0.f) ? dv.w : 0.f) + cb[ch] + cc[ch] * yv.w;
     }
+    // LDS row of slot e: (e & 3) * P / 4 + (e >> 2).  A thread holds slots p .. p + 3 of CH channels; with slot-major rows
+    // ([e][CH]) consecutive lanes would write 4 * CH words apart -- the same bank for every lane at CH = 8 (64-way conflict on
+    // 32 scalar writes per thread and round).  With the rows of one (e & 3) class contiguous, lanes write consecutive rows:
+    // whole rows as 16-byte pieces, at most 2-way conflicts (4-way at CH = 16).
+    {
+      const int r0 = p >> 2;
 #pragma unroll
-    for (int ch = 0; ch < CH; ++ch) {
-      dy[(size_t)(p + 0) * CH + ch] = v[ch].x; dy[(size_t)(p + 1) * CH + ch] = v[ch].y;
-      dy[(size_t)(p + 2) * CH + ch] = v[ch].z; dy[(size_t)(p + 3) * CH + ch] = v[ch].w;
+      for (int k = 0; k < 4; ++k) {
+        float* row = dy + ((size_t)k * (P >> 2) + r0) * CH;
+        if constexpr (CH % 4 == 0) {
+#pragma unroll
+          for (int h = 0; h < CH / 4; ++h)
+            *reinterpret_cast<float4*>(row + 4 * h) =
+                make_float4(f4_get(v[4 * h], k), f4_get(v[4 * h + 1], k), f4_get(v[4 * h + 2], k), f4_get(v[4 * h + 3], k));
+        } else if constexpr (CH == 2) {
+          *reinterpret_cast<float2*>(row) = make_float2(f4_get(v[0], k), f4_get(v[1], k));
+        } else {
+#pragma unroll
+          for (int ch = 0; ch < CH; ++ch) row[ch] = f4_get(v[ch], k);
+        }
+      }
     }
   }
   __syncthreads();
@@ -1868,9 +1889,21 @@ __global__ __launch_bounds__(NT) void pw_scatter_csr_kernel(int cout, int n, int
       const int e = ent[u];
       float c3[3] = {0.f, 0.f, 0.f};
       if (dwx != nullptr) { const float* cp = ctr + (size_t)(e / group_s) * 3; c3[0] = cp[0]; c3[1] = cp[1]; c3[2] = cp[2]; }
+      const float* row = dy + ((size_t)(e & 3) * (P >> 2) + (e >> 2)) * CH;
+      float rv[CH];
+      if constexpr (CH % 4 == 0) {
+#pragma unroll
+        for (int h = 0; h < CH / 4; ++h) {
+          const float4 t = *reinterpret_cast<const float4*>(row + 4 * h);
+          rv[4 * h] = t.x; rv[4 * h + 1] = t.y; rv[4 * h + 2] = t.z; rv[4 * h + 3] = t.w;
+        }
+      } else {
+#pragma unroll
+        for (int ch = 0; ch < CH; ++ch) rv[ch] = row[ch];
+      }
 #pragma unroll
       for (int ch = 0; ch < CH; ++ch) {
-        const float v = dy[(size_t)e * CH + ch];
+        const float v = rv[ch];
         sum[ch] += v;
         wc[ch][0] += v * c3[0]; wc[ch][1] += v * c3[1]; wc[ch][2] += v * c3[2];
       }
@@ -3350,41 +3383,49 @@ struct ReduceBatch {
   int cols[8];
   int ld[8];
   long long pstride[8];
-  int block_begin[9];  // prefix sum of ceil(count / 64)
+  int groups[8];       // split groups of the item's workgroups (a power of two <= kRedGroups); 1024 / groups elements each
+  int block_begin[9];  // prefix sum of ceil(count / (1024 / groups))
   int n;
 };
-// Workgroup = 64 consecutive elements x 16 split groups (1024 threads): a wave reads 256 contiguous bytes per split, four
-// independent chains per thread keep loads in flight, the sixteen group sums meet in LDS in a fixed order.  (Round 3 used
-// four groups: with 128 - 512 splits a thread walked 32 - 128 dependent-latency steps, 10 us per launch on average;
-// sixteen groups cut the walk fourfold.  Deterministic, but a different summation order than round 3's.  Round 4 also tried
-// 64 groups of 16 lanes x float4 -- four splits per wave instruction, a quarter of the steps: +1 % on the step, in-box A/B.)
+// Workgroup = 1024 threads = (1024 / G consecutive elements) x (G split groups): a wave reads 256 contiguous bytes per
+// split, four independent chains per thread keep loads in flight, the G group sums meet in LDS in a fixed order.  G follows
+// the item's split count (reduce_groups(): about four or more splits per thread, at most 16 groups): round 3 used four
+// groups for everything (32 - 128 dependent-latency steps per thread at 128 - 512 splits, 10 us per launch); the first form of
+// round 4 used sixteen for everything, which at 8 - 32 splits -- the 256- and 512-channel layers -- left most of a
+// workgroup's threads without a load and launched 4 096 workgroups where 512 do.  Deterministic; the summation order is a
+// function of the split count only.  (Also tried: 64 groups of 16 lanes x float4, +1 % on the step in an in-box A/B.)
 constexpr int kRedGroups = 16;
-__global__ __launch_bounds__(64 * kRedGroups) void wgrad_reduce_multi_kernel(ReduceBatch rb) {
-  __shared__ float red[kRedGroups][64];
+static int reduce_groups(int splits) {
+  int g = 1;
+  while (g < kRedGroups && g * 4 < splits) g <<= 1;
+  return g;
+}
+__global__ __launch_bounds__(1024) void wgrad_reduce_multi_kernel(ReduceBatch rb) {
+  __shared__ float red[1024];
   int l = 0;
   while (l + 1 < rb.n && (int)blockIdx.x >= rb.block_begin[l + 1]) ++l;
-  const int count = rb.count[l], splits = rb.splits[l];
+  const int count = rb.count[l], splits = rb.splits[l], groups = rb.groups[l];
+  const int epw = 1024 / groups;                       // elements per workgroup
   const size_t ps = (size_t)rb.pstride[l];
   const float* __restrict__ part = rb.part[l];
-  const int el = threadIdx.x & 63, sg = threadIdx.x >> 6;
-  const int i = ((int)blockIdx.x - rb.block_begin[l]) * 64 + el;
+  const int el = threadIdx.x & (epw - 1), sg = threadIdx.x / epw;
+  const int i = ((int)blockIdx.x - rb.block_begin[l]) * epw + el;
   float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
   if (i < count) {
     int k = sg;
-    for (; k + 3 * kRedGroups < splits; k += 4 * kRedGroups) {
+    for (; k + 3 * groups < splits; k += 4 * groups) {
       s0 += part[(size_t)k * ps + i];
-      s1 += part[(size_t)(k + kRedGroups) * ps + i];
-      s2 += part[(size_t)(k + 2 * kRedGroups) * ps + i];
-      s3 += part[(size_t)(k + 3 * kRedGroups) * ps + i];
+      s1 += part[(size_t)(k + groups) * ps + i];
+      s2 += part[(size_t)(k + 2 * groups) * ps + i];
+      s3 += part[(size_t)(k + 3 * groups) * ps + i];
     }
-    for (; k < splits; k += kRedGroups) s0 += part[(size_t)k * ps + i];
+    for (; k < splits; k += groups) s0 += part[(size_t)k * ps + i];
   }
-  red[sg][el] = (s0 + s1) + (s2 + s3);
+  red[threadIdx.x] = (s0 + s1) + (s2 + s3);
   __syncthreads();
-  if (threadIdx.x < 64 && i < count) {
-    float s = 0.f;
-#pragma unroll
-    for (int g = 0; g < kRedGroups; g += 4) s += (red[g][el] + red[g + 1][el]) + (red[g + 2][el] + red[g + 3][el]);
+  if (sg == 0 && i < count) {
+    float s = red[el];
+    for (int g = 1; g < groups; ++g) s += red[g * epw + el];
     const int cols = rb.cols[l];
     rb.dw[l][(size_t)(i / cols) * rb.ld[l] + i % cols] = s;
   }
@@ -3472,9 +3513,10 @@ inline bool wgrad2_ok(int cin, int cout) {
   return g_wgrad2_enable && cin >= 64 && cout >= 64 && cin % 32 == 0 && cout % 32 == 0;
 }
 int g_interp_dy_lds = 1;           // key 22: 0 = interp_grad_csr_dy gathers dY from global memory (no LDS staging)
-int g_scatter_csr_threads = 0;    // key 21: threads per workgroup of pw_scatter_csr_kernel (256 / 512 / 1024); 0 = 512 when the cloud has
-                                  // >= 256 source points, else 256 (alone on SA2 / SA3 / SA4 layer 0: 512 threads 25.8 + 40.8 / 17.4 + 23.3 /
-                                  // 18.6 + 28.4 us, 256 threads 35.5 + 50.9 / 22.0 + 28.4 / 15.6 + 23.1, 1024 never best)
+int g_scatter_csr_threads = 0;    // key 21: threads per workgroup of pw_scatter_csr_kernel (256 / 512 / 1024); 0 = by the cloud's source
+                                  // points: 1024 from 512 points, 512 from 256, else 256.  Alone on layer 0 of SA2 / SA3 / SA4 (two
+                                  // scales each, profiles/r04_scatter_microbench.txt): 256 threads 36.4 + 51.5 / 22.6 + 28.6 / 15.0 +
+                                  // 22.6 us, 512: 26.1 + 40.9 / 17.5 + 23.8 / 17.8 + 27.7, 1024: 20.9 + 35.8 / 21.2 + 25.2 / 18.9 + 28.7
 int g_wgrad2_tile_max = 64;    // key 20.  Round 3: 64 x 64 output tiles for every role-split wgrad.  A launch's split-K partials
                                // are (workgroups x tile bytes): 256 x 64 KB = 16 MB at 128 x 128, 512 x 16 KB = 8 MB now -- half the
                                // partial traffic of the 13 launches per step -- and inside the step the smaller tiles with 512
@@ -4183,7 +4225,7 @@ static int scatter_dy_csr_impl(int b, int cout, int n, int p, const float* y, co
                      bn, bwdc, offsets, entries, out, obs, xyz, new_xyz, gsz, dwx, fin)
 #define ISTNET_SCSR(CH)                                                                                            \
   do {                                                                                                             \
-    const int nt_ = g_scatter_csr_threads > 0 ? g_scatter_csr_threads : (n >= 256 ? 512 : 256);                    \
+    const int nt_ = g_scatter_csr_threads > 0 ? g_scatter_csr_threads : (n >= 512 ? 1024 : (n >= 256 ? 512 : 256)); \
     if (nt_ >= 1024) ISTNET_SCSR_NT(CH, 1024);                                                                     \
     else if (nt_ >= 512) ISTNET_SCSR_NT(CH, 512);                                                                  \
     else ISTNET_SCSR_NT(CH, 256);                                                                                  \
@@ -4475,9 +4517,10 @@ static int reduce_multi_impl(int n, const int* counts, const int* splits, const 
     rb.ld[l] = lds != nullptr ? lds[l] : counts[l];
     rb.pstride[l] = pstrides != nullptr ? pstrides[l] : (long long)counts[l];
     if (rb.cols[l] <= 0 || counts[l] % rb.cols[l] || rb.ld[l] < rb.cols[l] || rb.pstride[l] < counts[l]) return ISTNET_PN2_EINVAL;
-    rb.block_begin[l + 1] = rb.block_begin[l] + ceil_div(counts[l], 64);
+    rb.groups[l] = reduce_groups(splits[l]);
+    rb.block_begin[l + 1] = rb.block_begin[l] + ceil_div(counts[l], 1024 / rb.groups[l]);
   }
-  hipLaunchKernelGGL(wgrad_reduce_multi_kernel, dim3(rb.block_begin[n]), dim3(64 * kRedGroups), 0, as_stream(stream), rb);
+  hipLaunchKernelGGL(wgrad_reduce_multi_kernel, dim3(rb.block_begin[n]), dim3(1024), 0, as_stream(stream), rb);
   return (int)hipGetLastError();
 }
 
