@@ -4226,9 +4226,10 @@ static int scatter_dy_csr_impl(int b, int cout, int n, int p, const float* y, co
 #define ISTNET_SCSR(CH)                                                                                            \
   do {                                                                                                             \
     const int nt_ = g_scatter_csr_threads > 0 ? g_scatter_csr_threads : (n >= 512 ? 1024 : (n >= 256 ? 512 : 256)); \
-    if (nt_ >= 1024) ISTNET_SCSR_NT(CH, 1024);                                                                     \
-    else if (nt_ >= 512) ISTNET_SCSR_NT(CH, 512);                                                                  \
-    else ISTNET_SCSR_NT(CH, 256);                                                                                  \
+    /* register budget: 1024 threads leave 128 VGPRs (CH <= 4 fits), 512 threads 256 (CH <= 8) */                   \
+    if constexpr (CH <= 4) { if (nt_ >= 1024) { ISTNET_SCSR_NT(CH, 1024); break; } }                               \
+    if constexpr (CH <= 8) { if (nt_ >= 512) { ISTNET_SCSR_NT(CH, 512); break; } }                                 \
+    ISTNET_SCSR_NT(CH, 256);                                                                                       \
   } while (0)
   switch (ch) {
     case 16: ISTNET_SCSR(16); break;

@@ -28,9 +28,13 @@ grep '^{"metric' $O/prof_ist.log | tail -1 > $O/bench_istnet_traced.json
 MS2=$(python -c "import json; print(json.load(open('$O/bench_istnet_traced.json'))['ms_per_step'])")
 python tools/rocprof_libsplit.py $O/prof_ist/ist_results.db 20 $MS2 1.0 > $O/istnet_kernel_times.txt 2>&1
 rm -rf $O/prof_ist $O/prof_ist.log
+cp ist-net_amd/lib/libistnet_pn2.so /tmp/prod.so; cp ab_base/phase.so ist-net_amd/lib/libistnet_pn2.so
+python tools/bwd_mid_phases.py 2>&1 | grep -v amdgpu.ids > $O/bwd_mid_phases.txt
+cp /tmp/prod.so ist-net_amd/lib/libistnet_pn2.so
+python tools/bench_interp_grad.py 2>&1 | grep -v amdgpu.ids > $O/interp_grad_microbench.txt
+python tools/bench_scatter.py 2>&1 | grep -v amdgpu.ids > $O/scatter_microbench.txt
 python tools/exp/capture_nested_fork.py 2>&1 | grep -v amdgpu.ids > $O/capture_nested_fork.txt
 python tools/exp/capture_fork_autograd.py 2>&1 | grep -v amdgpu.ids > $O/capture_fork_autograd.txt
-python tools/exp/world_stream_bisect.py 2>&1 | grep -v amdgpu.ids > $O/world_stream_bisect.txt
 for f in bench_final bench_sa_layer bench_istnet_full_model bench_infer_full_model bench_istnet_force_dist bench_istnet_force_dist_captured bench_encoder_force_dist bench_encoder_force_dist_captured bench_noprefetch; do python -c "
 import json; d=json.load(open('$O/$f.json')); print('$f', round(d['ms_per_step'],4), round(d['value'],1), (d.get('roofline') or {}).get('frac'), (d.get('unpipelined') or {}).get('ms_per_step'))"; done
 head -8 $O/encoder_kernel_stats.txt | cut -c1-150
