@@ -12,7 +12,7 @@ INCLUDE_DIR = os.path.join(_HERE, "..", "include")
 HEADER_PATH = os.path.join(INCLUDE_DIR, "istnet_pn2.h")
 HEADER_PATHS = [HEADER_PATH, os.path.join(INCLUDE_DIR, "istnet_pw.h"), os.path.join(INCLUDE_DIR, "istnet_preproc.h"),
                 os.path.join(INCLUDE_DIR, "istnet_optim.h"), os.path.join(INCLUDE_DIR, "istnet_rgb.h"),
-                os.path.join(INCLUDE_DIR, "istnet_heads.h")]
+                os.path.join(INCLUDE_DIR, "istnet_heads.h"), os.path.join(INCLUDE_DIR, "istnet_conv.h")]
 ABI_VERSION = 1
 
 _i, _f, _p, _d, _l = ctypes.c_int, ctypes.c_float, ctypes.c_void_p, ctypes.c_double, ctypes.c_longlong
@@ -25,6 +25,12 @@ SIGNATURES = {
     "istnet_pw_scatter_dy_csr": [_i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _l, _p, _p, _i, _p, _p],
     "istnet_pw_scatter_dy_csr_fin": [_i, _i, _i, _i, _p, _p, _p, _i, _d, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _l, _p, _p, _i, _p, _p],
     "istnet_adam_step": [_l, _p, _p, _p, _p, _p, _p, _d, _d, _d, _d, _d, _d, _p],
+    "istnet_conv_supported": [_i] * 6,
+    "istnet_conv_workspace_floats": [_i] * 10,
+    "istnet_conv_forward": [_i] * 9 + [_p] * 5,
+    "istnet_conv_backward_data": [_i] * 9 + [_p] * 5,
+    "istnet_conv_wrw_splits": [_i] * 9,
+    "istnet_conv_backward_weights": [_i] * 9 + [_p] * 5,
     "istnet_nhwc_gram64_parts": [_l],
     "istnet_nhwc_gram64": [_l, _p, _p, _p, _p, _p, _p],
     "istnet_nhwc_rowmix64": [_l, _p, _p, _p, _p, _p],

@@ -125,6 +125,97 @@ def _conv3x3(cin, cout, stride=1, dilation=1):
     return nn.Conv2d(cin, cout, kernel_size=3, stride=stride, padding=dilation, dilation=dilation, bias=False)
 
 
+USE_NATIVE_TRUNK_CONV = os.environ.get("ISTNET_NATIVE_TRUNK_CONV", "1") != "0"   # the trunk's 3x3 / 1x1 convolutions through include/istnet_conv.h
+# which layers take the native backward-weights product ("all", "1x1", "none"); the others keep the framework's (MIOpen).
+# Alone on the trunk's shapes at B = 32 (profiles/r04_conv_microbench.txt) the native forward and backward-data win or tie on
+# every stride-1 layer, the native backward-weights wins on the 1x1 layers and loses 15 % on the large 3x3 ones.
+NATIVE_TRUNK_WRW = os.environ.get("ISTNET_NATIVE_TRUNK_WRW", "1x1")
+
+
+def _native_conv_ok(conv, x):
+    if not (USE_NATIVE_TRUNK_CONV and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4
+            and x.is_contiguous(memory_format=torch.channels_last) and conv.bias is None and conv.groups == 1
+            and conv.dilation == (1, 1) and conv.kernel_size[0] == conv.kernel_size[1] and conv.stride[0] == conv.stride[1]
+            and conv.padding[0] == conv.padding[1] and isinstance(conv.padding, tuple) and conv.padding_mode == "zeros"
+            and conv.weight.dtype == torch.float32 and conv.weight.is_contiguous(memory_format=torch.channels_last)):
+        return False
+    from . import _native
+    return bool(_native.lib().istnet_conv_supported(conv.in_channels, conv.out_channels, conv.kernel_size[0], conv.kernel_size[1],
+                                                    conv.stride[0], conv.padding[0])) and x.shape[0] * x.shape[2] * x.shape[3] < 2 ** 24
+
+
+def _conv_workspace(lib, backward_data, args, dev):
+    n = lib.istnet_conv_workspace_floats(backward_data, *args)
+    return torch.empty((n,), dtype=torch.float32, device=dev) if n > 0 else None
+
+
+class _ConvFn(torch.autograd.Function):
+    """Conv2d (channels-last float32, no bias / groups / dilation) of the ResNet trunk through include/istnet_conv.h: the
+    forward and the input gradient as implicit GEMMs on the fp32 matrix cores (reference model/resnet.py:18-25 on cuDNN;
+    PyTorch-ROCm on MIOpen), the weight gradient natively or by the framework per NATIVE_TRUNK_WRW.  Exact fp32 products,
+    fp32 accumulation; deterministic (split-K partial sums are added in a fixed order, no atomics)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, stride, pad):
+        from . import _native
+        lib = _native.lib()
+        b, cin, h, w = x.shape
+        cout, _, kh, kw = weight.shape
+        args = (b, h, w, cin, cout, kh, kw, stride, pad)
+        oh, ow = (h + 2 * pad - kh) // stride + 1, (w + 2 * pad - kw) // stride + 1
+        out = torch.empty((b, cout, oh, ow), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
+        ws = _conv_workspace(lib, 0, args, x.device)
+        with torch.cuda.device(x.device):
+            _native.check(lib.istnet_conv_forward(*args, x.data_ptr(), weight.data_ptr(), out.data_ptr(),
+                                                  ws.data_ptr() if ws is not None else None,
+                                                  torch.cuda.current_stream(x.device).cuda_stream), "conv_forward")
+        ctx.save_for_backward(x, weight)
+        ctx.geom = (stride, pad)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        from . import _native
+        lib = _native.lib()
+        x, weight = ctx.saved_tensors
+        stride, pad = ctx.geom
+        b, cin, h, w = x.shape
+        cout, _, kh, kw = weight.shape
+        args = (b, h, w, cin, cout, kh, kw, stride, pad)
+        dout = dout.contiguous(memory_format=torch.channels_last)
+        dx = dw = None
+        st = torch.cuda.current_stream(x.device).cuda_stream
+        with torch.cuda.device(x.device):
+            if ctx.needs_input_grad[0]:
+                if stride == 1:
+                    dx = torch.empty_like(x, memory_format=torch.channels_last)
+                    ws = _conv_workspace(lib, 1, args, x.device)
+                    _native.check(lib.istnet_conv_backward_data(*args, dout.data_ptr(), weight.data_ptr(), dx.data_ptr(),
+                                                                ws.data_ptr() if ws is not None else None, st), "conv_backward_data")
+                else:       # a stride-2 input gradient touches a quarter of the taps per pixel: the gather form wastes the rest
+                    dx = torch.ops.aten.convolution_backward(dout, x, weight, None, [stride, stride], [pad, pad], [1, 1], False,
+                                                             [0, 0], 1, [True, False, False])[0]
+            if ctx.needs_input_grad[1]:
+                splits = lib.istnet_conv_wrw_splits(*args)
+                native = splits > 0 and (NATIVE_TRUNK_WRW == "all" or (NATIVE_TRUNK_WRW == "1x1" and kh == 1))
+                if native:
+                    part = torch.empty((splits, weight.numel()), dtype=torch.float32, device=x.device)
+                    dw = torch.empty_like(weight, memory_format=torch.channels_last)
+                    _native.check(lib.istnet_conv_backward_weights(*args, x.data_ptr(), dout.data_ptr(), part.data_ptr(),
+                                                                   dw.data_ptr(), st), "conv_backward_weights")
+                else:
+                    dw = torch.ops.aten.convolution_backward(dout, x, weight, None, [stride, stride], [pad, pad], [1, 1], False,
+                                                             [0, 0], 1, [False, True, False])[1]
+        return dx, dw, None, None
+
+
+def _conv(conv, x):
+    """conv(x) for a trunk convolution: include/istnet_conv.h when the layer and the tensor qualify, the module otherwise."""
+    if _native_conv_ok(conv, x):
+        return _ConvFn.apply(x, conv.weight, conv.stride[0], conv.padding[0])
+    return conv(x)
+
+
 _COUNTER_SCOPE = None     # inside ModifiedResnet.forward: the BatchNorm batch counters of the fused sites, bumped by ONE launch
 
 
@@ -262,13 +353,13 @@ class BasicBlock(nn.Module):
         self.register_buffer("_one", torch.ones(1), persistent=False)
 
     def forward(self, x):
-        out = _bn_relu(self.bn1, self.conv1(x), None, self)
-        return _bn_relu(self.bn2, self.conv2(out), x if self.downsample is None else self._shortcut(x), self)
+        out = _bn_relu(self.bn1, _conv(self.conv1, x), None, self)
+        return _bn_relu(self.bn2, _conv(self.conv2, out), x if self.downsample is None else self._shortcut(x), self)
 
     def _shortcut(self, x):
         ds = self.downsample
         if isinstance(ds, nn.Sequential) and len(ds) == 2 and isinstance(ds[1], nn.BatchNorm2d):
-            return _bn_relu(ds[1], ds[0](x), None, self, identity=True)
+            return _bn_relu(ds[1], _conv(ds[0], x), None, self, identity=True)
         return ds(x)
 
 
