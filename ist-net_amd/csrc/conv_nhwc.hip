@@ -22,7 +22,11 @@ namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int kThreads = 256;
-constexpr int KC = 32;       // K chunk
+#ifndef ISTNET_CONV_KC
+#define ISTNET_CONV_KC 32
+#endif
+constexpr int KC = ISTNET_CONV_KC;       // K chunk (32, or 16 for half the LDS)
+constexpr int LPR = KC / 4;  // lanes per K-contiguous tile row (one float4 each)
 constexpr int LDK = KC + 4;  // pitch of a K-contiguous LDS row: 144 bytes keeps the 16-byte reads of 32 rows off each other's banks
 
 __device__ __forceinline__ int mfma_row(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
@@ -61,9 +65,9 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 2) void conv_igemm_kernel
                                                                 int tile_m_first, int tile_m_count) {
   constexpr int TM = MT / (32 * WM), TN = NT / (32 * WN);
   constexpr int NTHR = 64 * WM * WN;   // 4 or 8 waves per workgroup
-  constexpr int RPP = NTHR / 8;        // tile rows covered by one pass of the workgroup (8 lanes x float4 = one 128-byte row)
-  constexpr int AR = MT / RPP;         // float4 of the A tile per thread: rows tid / 8 + RPP i, columns 4 (tid % 8) .. + 3
-  constexpr int BR = NT / RPP;         // float4 of the B tile per thread
+  constexpr int RPP = NTHR / LPR;      // tile rows covered by one pass of the workgroup (LPR lanes x float4 = one row of the chunk)
+  constexpr int AR = MT / RPP;         // float4 of the A tile per thread: rows tid / LPR + RPP i, columns 4 (tid % LPR) .. + 3
+  constexpr int BR = NT / RPP;         // float4 of the B tile per thread (the same count in both modes)
   constexpr int LDB1 = NT + 4;         // MODE 1: B tile [KC][NT + 4]
   constexpr int A_STAGE = MT * LDK;
   constexpr int B_STAGE = MODE == 0 ? NT * LDK : KC * LDB1;
@@ -95,13 +99,13 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 2) void conv_igemm_kernel
   if (tile_local >= tile_m_count) return;                                // (the grid is padded to a multiple of 8 row tiles)
   const long long m0 = (long long)(tile_m_first + tile_local) * MT;
   const int n0 = (jt % tiles_n) * NT;
-  const int acol = (tid & 7) * 4;
+  const int acol = (tid % LPR) * 4;
   // this thread's A rows: image base row (b * SH), y, x of the output pixel; rv: the row exists (pm < M)
   int rb[AR], ry[AR], rx[AR];
   unsigned rvalid = 0;
 #pragma unroll
   for (int i = 0; i < AR; ++i) {
-    const long long pm = m0 + (tid >> 3) + RPP * i;
+    const long long pm = m0 + (tid / LPR) + RPP * i;
     const long long pc = pm < M ? pm : M - 1;
     const int b = (int)(pc / (MH * MW));
     const int rem = (int)(pc - (long long)b * MH * MW);
@@ -148,7 +152,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 2) void conv_igemm_kernel
     static_for<BR>([&](auto ic) {
       constexpr int i = decltype(ic)::value;
       if (MODE == 0) {
-        const int n = n0 + (tid >> 3) + RPP * i;
+        const int n = n0 + (tid / LPR) + RPP * i;
         st_b<i>(s) = *reinterpret_cast<const float4*>(wgt + ((size_t)n * taps + tap) * g.Cin + (size_t)cb * KC + acol);
       } else {
         const int e = tid + NTHR * i;
@@ -162,12 +166,12 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 2) void conv_igemm_kernel
     float* bs = Bs + buf * B_STAGE;
     static_for<AR>([&](auto ic) {
       constexpr int i = decltype(ic)::value;
-      *reinterpret_cast<float4*>(as + ((tid >> 3) + RPP * i) * LDK + acol) = keep_if((s.ok >> i) & 1u, st_a<i>(s));
+      *reinterpret_cast<float4*>(as + ((tid / LPR) + RPP * i) * LDK + acol) = keep_if((s.ok >> i) & 1u, st_a<i>(s));
     });
     static_for<BR>([&](auto ic) {
       constexpr int i = decltype(ic)::value;
       if (MODE == 0) {
-        *reinterpret_cast<float4*>(bs + ((tid >> 3) + RPP * i) * LDK + acol) = st_b<i>(s);
+        *reinterpret_cast<float4*>(bs + ((tid / LPR) + RPP * i) * LDK + acol) = st_b<i>(s);
       } else {
         const int e = tid + NTHR * i;
         *reinterpret_cast<float4*>(bs + (e / (NT / 4)) * LDB1 + 4 * (e % (NT / 4))) = st_b<i>(s);

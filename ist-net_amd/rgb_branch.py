@@ -125,7 +125,13 @@ def _conv3x3(cin, cout, stride=1, dilation=1):
     return nn.Conv2d(cin, cout, kernel_size=3, stride=stride, padding=dilation, dilation=dilation, bias=False)
 
 
-USE_NATIVE_TRUNK_CONV = os.environ.get("ISTNET_NATIVE_TRUNK_CONV", "1") != "0"   # the trunk's 3x3 / 1x1 convolutions through include/istnet_conv.h
+# The trunk's 3x3 / 1x1 convolutions through include/istnet_conv.h.  Measured (profiles/r04_conv_microbench.txt, r04_conv_end_to_end.txt):
+# alone, the native forward and backward-data beat MIOpen on the large layers (121 / 120 vs 111 / 115 TFLOP/s at 512 -> 512) and the
+# 1x1 ones; inside the training step, beside the two point encoders, the step is the same with either (31.4-31.7 ms); inside
+# the inference batch (forward only, the encoder hidden beside the trunk) MIOpen's smaller workgroups leave it more room and
+# the batch is 0.3 ms faster with them.  So: on when gradients are recorded; without gradients only if forced ("2").
+USE_NATIVE_TRUNK_CONV = os.environ.get("ISTNET_NATIVE_TRUNK_CONV", "1") != "0"
+NATIVE_TRUNK_CONV_NO_GRAD = os.environ.get("ISTNET_NATIVE_TRUNK_CONV", "1") == "2"
 # which layers take the native backward-weights product ("all", "1x1", "none"); the others keep the framework's (MIOpen).
 # Alone on the trunk's shapes at B = 32 (profiles/r04_conv_microbench.txt) the native forward and backward-data win or tie on
 # every stride-1 layer, the native backward-weights wins on the 1x1 layers and loses 15 % on the large 3x3 ones.
@@ -133,7 +139,8 @@ NATIVE_TRUNK_WRW = os.environ.get("ISTNET_NATIVE_TRUNK_WRW", "1x1")
 
 
 def _native_conv_ok(conv, x):
-    if not (USE_NATIVE_TRUNK_CONV and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4
+    if not (USE_NATIVE_TRUNK_CONV and (torch.is_grad_enabled() or NATIVE_TRUNK_CONV_NO_GRAD) and x.is_cuda
+            and x.dtype == torch.float32 and x.dim() == 4
             and x.is_contiguous(memory_format=torch.channels_last) and conv.bias is None and conv.groups == 1
             and conv.dilation == (1, 1) and conv.kernel_size[0] == conv.kernel_size[1] and conv.stride[0] == conv.stride[1]
             and conv.padding[0] == conv.padding[1] and isinstance(conv.padding, tuple) and conv.padding_mode == "zeros"
