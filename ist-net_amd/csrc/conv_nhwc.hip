@@ -322,12 +322,22 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 2) void conv_wrw_kernel(C
   const unsigned magic = 65536u / (unsigned)g.OW;          // floor: the quotient is never too large, at most one too small
   const int chunks_per_image = ohw / KC;
 
+  // issue() is called for consecutive chunks (c_begin, c_begin + 1, ...): the image index and the first pixel of the chunk
+  // inside its image advance by one chunk per call (uniform values: scalar registers, no division in the loop)
+  int ib = (int)(c_begin / chunks_per_image);
+  int iq0 = (int)(c_begin - (long long)ib * chunks_per_image) * KC;
+  long long ic_next = c_begin;
   auto issue = [&](Stage& s, long long c) {
-    const long long cc = c < nchunks_all ? c : nchunks_all - 1;          // past the end: the last chunk again (never used)
-    const int b = (int)(cc / chunks_per_image);
-    const int q0 = (int)(cc - (long long)b * chunks_per_image) * KC;
+    (void)c;
+    const bool live = ic_next < nchunks_all;                // past the end: the last chunk again (committed as zeros, never used)
+    const int b = ib, q0 = iq0;
+    if (live && ic_next + 1 < nchunks_all) {
+      iq0 += KC;
+      if (iq0 == ohw) { iq0 = 0; ++ib; }
+    }
+    ++ic_next;
     const size_t orow = ((size_t)b * ohw + q0) * g.Cout;
-    s.ok = c < nchunks_all ? 0xffffffffu : 0u;
+    s.ok = live ? 0xffffffffu : 0u;
     static_for<AR>([&](auto ic) {
       constexpr int i = decltype(ic)::value;
       const int e = tid + NTHR * i;
