@@ -302,13 +302,16 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 2) void conv_wrw_kernel(C
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int l31 = lane & 31, half = lane >> 5;
   const int wm = wv / WN, wn = wv % WN;
-  // workgroup id -> (split, output tile, tap), the split slowest: workgroups resident together share pixel ranges
+  // workgroup id -> (XCD x = id % 8, j = id / 8).  The taps of one (split, output tile) read the same dout rows and the same
+  // input rows (shifted): they are consecutive workgroups of ONE XCD, so those rows come into that L2 once for the nine of
+  // them (in launch order the hardware deals the nine to eight different L2s).  Groups (split, tile) are dealt to the XCDs
+  // round-robin: 7 splits x 16 tiles = 112 groups = 14 per XCD.
   const int taps = g.KH * g.KW;
   const int ntn = g.Cin / NT, ntiles = (g.Cout / MT) * ntn;
-  const int inner = ntiles * taps;
-  const int split = blockIdx.x / inner;
-  if (split >= nsplits) return;
-  const int tile = (blockIdx.x % inner) / taps, tap = (blockIdx.x % inner) % taps;
+  const int xcd = blockIdx.x & 7, jj = blockIdx.x >> 3;
+  const int group = (jj / taps) * 8 + xcd, tap = jj % taps;
+  if (group >= nsplits * ntiles) return;
+  const int split = group / ntiles, tile = group % ntiles;
   const int ky = tap / g.KW, kx = tap - ky * g.KW;
   const int co0 = (tile / ntn) * MT, ci0 = (tile % ntn) * NT;
   const long long P = (long long)g.B * g.OH * g.OW;
@@ -316,27 +319,38 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 2) void conv_wrw_kernel(C
   const long long c_begin = (long long)split * chunks_per_split;
   long long c_end = c_begin + chunks_per_split;
   if (c_end > nchunks_all) c_end = nchunks_all;
-  // A chunk of 32 output pixels lies inside one image (the host requires OH * OW % 32 == 0), so the image index is uniform per
-  // chunk and a pixel's row / column follow from its index inside the image (< 2^16) by one multiply-shift and a correction.
+  // Source-pixel table of this workgroup's pixel range for its tap: tab[j] = input pixel index (b * H + sy) * W + sx of output
+  // pixel c_begin * 32 + j, or -1 outside the image.  Built once (a pixel's row / column from its index inside the image --
+  // the host requires OH * OW % 32 == 0 and < 2^16 -- by one multiply-shift and a correction); the loop then spends one LDS
+  // read per row instead of ~28 VALU instructions, which at four rows per thread and chunk were a fifth of the MFMA time.
   const int ohw = g.OH * g.OW;
-  const unsigned magic = 65536u / (unsigned)g.OW;          // floor: the quotient is never too large, at most one too small
-  const int chunks_per_image = ohw / KC;
+  int* tab = reinterpret_cast<int*>(smem + 2 * A_STAGE + 2 * B_STAGE);
+  {
+    const unsigned magic = 65536u / (unsigned)g.OW;        // floor: the quotient is never too large, at most one too small
+    const long long p_first = c_begin * KC;
+    const int npix = (int)((c_end > c_begin ? c_end - c_begin : 0) * KC);
+    for (int j = tid; j < npix; j += NTHR) {
+      const long long p = p_first + j;
+      const int b = (int)(p / ohw);
+      const int q = (int)(p - (long long)b * ohw);
+      int oy = (int)(((unsigned)q * magic) >> 16);
+      int ox = q - oy * g.OW;
+      if (ox >= g.OW) { ox -= g.OW; ++oy; }
+      const int sy = oy * STRIDE + ky - g.pad, sx = ox * STRIDE + kx - g.pad;
+      tab[j] = (sy >= 0 && sy < g.H && sx >= 0 && sx < g.W) ? (b * g.H + sy) * g.W + sx : -1;
+    }
+  }
+  __syncthreads();
 
-  // issue() is called for consecutive chunks (c_begin, c_begin + 1, ...): the image index and the first pixel of the chunk
-  // inside its image advance by one chunk per call (uniform values: scalar registers, no division in the loop)
-  int ib = (int)(c_begin / chunks_per_image);
-  int iq0 = (int)(c_begin - (long long)ib * chunks_per_image) * KC;
+  // issue() is called for consecutive chunks (c_begin, c_begin + 1, ...)
   long long ic_next = c_begin;
   auto issue = [&](Stage& s, long long c) {
     (void)c;
-    const bool live = ic_next < nchunks_all;                // past the end: the last chunk again (committed as zeros, never used)
-    const int b = ib, q0 = iq0;
-    if (live && ic_next + 1 < nchunks_all) {
-      iq0 += KC;
-      if (iq0 == ohw) { iq0 = 0; ++ib; }
-    }
+    const bool live = ic_next < c_end;                      // past the end: the last chunk again (committed as zeros, never used)
+    const long long cc = live ? ic_next : c_end - 1;
     ++ic_next;
-    const size_t orow = ((size_t)b * ohw + q0) * g.Cout;
+    const int j0 = (int)(cc - c_begin) * KC;
+    const size_t orow = (size_t)cc * KC * g.Cout;
     s.ok = live ? 0xffffffffu : 0u;
     static_for<AR>([&](auto ic) {
       constexpr int i = decltype(ic)::value;
@@ -348,15 +362,9 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 2) void conv_wrw_kernel(C
       constexpr int i = decltype(ic)::value;
       const int e = tid + NTHR * i;
       const int k = e / (NT / 4), c4 = e % (NT / 4);
-      const int q = q0 + k;
-      int oy = (int)(((unsigned)q * magic) >> 16);
-      int ox = q - oy * g.OW;
-      if (ox >= g.OW) { ox -= g.OW; ++oy; }
-      const int sy = oy * STRIDE + ky - g.pad, sx = ox * STRIDE + kx - g.pad;
-      const bool ok = sy >= 0 && sy < g.H && sx >= 0 && sx < g.W;
-      const size_t off = ((size_t)(b * g.H + clampi(sy, 0, g.H - 1)) * g.W + clampi(sx, 0, g.W - 1)) * g.Cin + ci0 + 4 * c4;
-      st_b<i>(s) = *reinterpret_cast<const float4*>(in + off);
-      if (!ok) s.ok &= ~(1u << (8 + i));
+      const int t = tab[j0 + k];
+      st_b<i>(s) = *reinterpret_cast<const float4*>(in + (size_t)(t < 0 ? 0 : t) * g.Cin + ci0 + 4 * c4);
+      if (t < 0) s.ok &= ~(1u << (8 + i));
     });
   };
   auto commit = [&](Stage& s, int buf) {
@@ -365,7 +373,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 2) void conv_wrw_kernel(C
     static_for<AR>([&](auto ic) {
       constexpr int i = decltype(ic)::value;
       const int e = tid + NTHR * i;
-      *reinterpret_cast<float4*>(as + (e / (MT / 4)) * LDA + 4 * (e % (MT / 4))) = keep_if((s.ok >> i) & 1u, st_a<i>(s));
+      *reinterpret_cast<float4*>(as + (e / (MT / 4)) * LDA + 4 * (e % (MT / 4))) = keep_if((s.ok >> i) & 1u, st_a<i>(s));   // (storing the loaded value unmasked measured 15 % SLOWER: 892 vs 772 us at 512 -> 512)
     });
     static_for<BR>([&](auto ic) {
       constexpr int i = decltype(ic)::value;
@@ -491,6 +499,7 @@ template <int MT, int NT, int MODE>
 constexpr size_t igemm_lds() {
   return (size_t)(2 * MT * LDK + 2 * (MODE == 0 ? NT * LDK : KC * (NT + 4))) * sizeof(float);
 }
+constexpr int kWrwMaxChunks = 96;      // chunks per split at most: the source-pixel table of a split is 4 * 32 * 96 = 12 KB of LDS
 template <int MT, int NT>
 constexpr size_t wrw_lds() { return (size_t)(2 * KC * (MT + 4) + 2 * KC * (NT + 4)) * sizeof(float); }
 
@@ -631,7 +640,7 @@ static int wrw_plan(const ConvGeom& g, int& mt, int& nt, int& per) {
   const double t_full = 2.0 * (double)g.B * g.OH * g.OW * g.Cout * g.Cin * g.KH * g.KW / 130e12;
   long long best = 1;
   double best_t = 1e30;
-  for (long long sp = 1; sp <= 1024 && chunks / sp >= 6; ++sp) {
+  for (long long sp = (chunks + kWrwMaxChunks - 1) / kWrwMaxChunks; sp <= 1024 && (chunks / sp >= 6 || sp == (chunks + kWrwMaxChunks - 1) / kWrwMaxChunks); ++sp) {
     const long long units = tiles * sp, rounds = (units + 511) / 512;
     const double t = t_full * (double)(rounds * 512) / (double)units + (sp + 1) * wbytes / 3.0e12 + 2e-6 * rounds / sp;
     if (t < best_t) { best_t = t; best = sp; }
@@ -657,16 +666,17 @@ int istnet_conv_backward_weights(int b, int h, int w, int cin, int cout, int kh,
   if (!wrw_ok(g)) return ISTNET_PN2_EINVAL;
   int mt, nt, per;
   const int splits = wrw_plan(g, mt, nt, per);
-  const dim3 grid((unsigned)(splits * (cout / mt) * (cin / nt) * kh * kw));
+  const size_t tab_bytes = (size_t)per * KC * 4;
+  const dim3 grid((unsigned)((splits * (cout / mt) * (cin / nt) + 7) / 8 * 8 * kh * kw));
 #define ISTNET_WRW(MT, NT, WM, WN)                                                                                       \
   do {                                                                                                                   \
     if (stride == 1) {                                                                                                   \
-      ISTNET_ALLOW_LDS((conv_wrw_kernel<MT, NT, WM, WN, 1>), (wrw_lds<MT, NT>()));                                       \
-      hipLaunchKernelGGL((conv_wrw_kernel<MT, NT, WM, WN, 1>), grid, dim3(64 * WM * WN), (wrw_lds<MT, NT>()),             \
+      ISTNET_ALLOW_LDS((conv_wrw_kernel<MT, NT, WM, WN, 1>), (wrw_lds<MT, NT>() + (size_t)kWrwMaxChunks * KC * 4));        \
+      hipLaunchKernelGGL((conv_wrw_kernel<MT, NT, WM, WN, 1>), grid, dim3(64 * WM * WN), (wrw_lds<MT, NT>() + tab_bytes), \
                          (hipStream_t)stream, g, in, dout, part, per, splits);                                          \
     } else {                                                                                                             \
-      ISTNET_ALLOW_LDS((conv_wrw_kernel<MT, NT, WM, WN, 2>), (wrw_lds<MT, NT>()));                                       \
-      hipLaunchKernelGGL((conv_wrw_kernel<MT, NT, WM, WN, 2>), grid, dim3(64 * WM * WN), (wrw_lds<MT, NT>()),             \
+      ISTNET_ALLOW_LDS((conv_wrw_kernel<MT, NT, WM, WN, 2>), (wrw_lds<MT, NT>() + (size_t)kWrwMaxChunks * KC * 4));        \
+      hipLaunchKernelGGL((conv_wrw_kernel<MT, NT, WM, WN, 2>), grid, dim3(64 * WM * WN), (wrw_lds<MT, NT>() + tab_bytes), \
                          (hipStream_t)stream, g, in, dout, part, per, splits);                                          \
     }                                                                                                                    \
   } while (0)
