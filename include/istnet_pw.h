@@ -36,6 +36,8 @@ ISTNET_PN2_API int istnet_pw_wgrad_tile_cfg(int b, int cin, int cout, int p);
  * workgroups of the role-split wgrad kernel (dense input, cin and cout >= 64; istnet_pw_wgrad_tile_cfg then reports
  * 1000000 + M_T * 1000 + N_T).  Returns ISTNET_PN2_EINVAL for an unknown key. */
 ISTNET_PN2_API int istnet_pw_set_tuning(int key, int value);
+/* current value of a tuning key (the keys that are plain numbers: 5, 7, 8, 12, 14, 16, 18, 20, 21), or -1 */
+ISTNET_PN2_API int istnet_pw_get_tuning(int key);
 
 /* number of per-channel partial-statistics slots istnet_pw_forward writes for this shape */
 ISTNET_PN2_API int istnet_pw_stat_tiles(int b, int cout, int p);

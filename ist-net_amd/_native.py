@@ -77,6 +77,7 @@ SIGNATURES = {
     "istnet_pw_wgrad_tile_cfg": [_i, _i, _i, _i],
     "istnet_pw_dgrad_tile_cfg": [_i, _i, _i],
     "istnet_pw_set_tuning": [_i, _i],
+    "istnet_pw_get_tuning": [_i],
     "istnet_pw_stat_tiles": [_i, _i, _i],
     "istnet_pw_forward_tiles": [_i, _i, _i, _i],
     "istnet_pw_forward_cfg": [_i, _i, _i, _i],

@@ -3633,6 +3633,21 @@ int istnet_pw_set_tuning(int key, int value) {
   }
 }
 
+int istnet_pw_get_tuning(int key) {
+  switch (key) {
+    case 5: return g_bwd_small_target;
+    case 7: return g_dgrad_min_wgs;
+    case 8: return g_bwd_mid_target;
+    case 12: return g_wgrad2_target;
+    case 14: return g_fwd2_min_waves;
+    case 16: return g_fwd_sk_max_tiles;
+    case 18: return g_dgrad_sk_min_k;
+    case 20: return g_wgrad2_tile_max;
+    case 21: return g_scatter_csr_threads;
+    default: return -1;
+  }
+}
+
 int istnet_pw_stat_tiles(int b, int cout, int p) {
   return b * ceil_div(p, cfg_nt(pick_cfg(b, cout, p, g_force_fwd_cfg)));
 }

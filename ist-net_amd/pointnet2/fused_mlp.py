@@ -121,6 +121,7 @@ def _ident_consts(dev, c):
 # .grad would be read on the main stream before the join), no kernel timing in progress.  Everything the
 # deferred launches read is kept alive until the join.  (A per-layer fork onto a side stream was measured
 # slower: 32 extra cross-stream edges per step.)
+FP_BWD_MID_WORKGROUPS = int(os.environ.get("ISTNET_FP_BWD_MID_WGS", "256"))   # 0: the library's default (128) in the FP levels too
 USE_DEFERRED_WGRAD = os.environ.get("ISTNET_DEFERRED_WGRAD", "1") != "0"    # module attribute; the environment variable only sets its import-time
                              # default (A/B runs).  tests/test_pipeline_gpu.py::test_fallback_paths_agree_with_default flips each
                              # switch once; ist_net.point_branch_side_streams sets and restores this one and USE_SCALE_STREAMS
@@ -1436,8 +1437,17 @@ class FusedFPFunction(Function):
             return None
 
         with torch.cuda.device(dev):
-            grads, _, _ = _backward_stack(lib, dev, _st(dev), b, cin, n, 1, None, None, ctx.training, ys, bns, params,
-                                          None, dout.contiguous(), need_w, True, layer0_hook=layer0)
+            # the fused mid-size backward kernel takes 128 workgroups by default -- half the chip, because in the
+            # set-abstraction phases two or three scale chains run side by side; a feature-propagation level is ONE chain
+            # (with the deferred weight gradients beside it): 256 workgroups there, 2.562 -> 2.543 ms on the step
+            saved = lib.istnet_pw_get_tuning(8)
+            if FP_BWD_MID_WORKGROUPS:
+                lib.istnet_pw_set_tuning(8, FP_BWD_MID_WORKGROUPS)
+            try:
+                grads, _, _ = _backward_stack(lib, dev, _st(dev), b, cin, n, 1, None, None, ctx.training, ys, bns, params,
+                                              None, dout.contiguous(), need_w, True, layer0_hook=layer0)
+            finally:
+                lib.istnet_pw_set_tuning(8, saved)
             _native.mark(f"bwd FP(n={n}) chain done")
         return (result.get("dknown"), result.get("dskip"), None, None, None, None, None, None, None, *grads)
 
