@@ -4,7 +4,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, istnet_amd
 from istnet_amd import _native
 lib = _native.lib(); dev = torch.device("cuda:0"); st = torch.cuda.current_stream().cuda_stream
-B, P = 64, 2048
+B, P = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (64, 2048)
 for kv in os.environ.get("PW_TUNE", "").split(","):
     if kv:
         k, v = kv.split(":"); assert lib.istnet_pw_set_tuning(int(k), int(v)) == 0
