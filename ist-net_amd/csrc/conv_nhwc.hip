@@ -11,6 +11,15 @@
 // MFMAs per wave.  NHWC rows are K-contiguous, so the pixel operand is staged [row][32 + 4] and read as one ds_read_b128 per
 // four k; operands whose contiguous direction is the OUTPUT index (the weights in backward-data, both operands in
 // backward-weights) are staged [k][cols + 4] and read as scalars with consecutive lanes on consecutive words.
+//
+// Measured on the way (512 -> 512 at 24 x 24, B = 32, forward; profiles/r04_conv_microbench.txt holds the final table):
+//   first version (prefetch arrays captured by lambdas -> scratch, conditional loads)            62 TFLOP/s
+//   named prefetch registers, unconditional clamped loads, stride as a template parameter        87
+//   two chunks of loads in flight / eight waves per workgroup / tiles dealt to the XCDs by row   87 / 85 / 84  (not the bound)
+//   K split 8 ways for every tile (576 tiles on 512 slots are 1.125 rounds)                     103
+//   per-tap row addresses formed once per tap                                                   108
+//   whole rounds unsplit, only the remaining 64 tiles split 8 ways                              121  (MIOpen: 111-117)
+//   K chunks of 16 instead of 32 (half the LDS: -DISTNET_CONV_KC=16)                            104, and +1 ms on the step
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
