@@ -644,10 +644,8 @@ __global__ __launch_bounds__(kThreads, 2) void pw_fwd_sk_kernel(
     const float* __restrict__ in_scale, const float* __restrict__ in_shift, const float* __restrict__ c_init,
     float* __restrict__ y, float* __restrict__ part_sum, float* __restrict__ part_sq, int nt_total,
     const float* __restrict__ zk, int m_known, const int* __restrict__ iidx, const float* __restrict__ iw) {
-  __shared__ __attribute__((aligned(16))) float lds[4 * 4 * 16 * 64];   // 64 KB: BN constants during the loop, then the partials
-  float* s_sc = lds;            // [cin]
-  float* s_sh = lds + 2048;     // [cin]
-  const int tid = threadIdx.x, lane = lane_id(), wv = wave_id();
+  __shared__ __attribute__((aligned(16))) float lds[4 * 4 * 16 * 64];   // 64 KB: the four waves' partial sums
+  const int lane = lane_id(), wv = wave_id();
   const int l31 = lane & 31, half = lane >> 5;
   const int b = blockIdx.x / tiles_per_cloud;
   const int p0 = (blockIdx.x - b * tiles_per_cloud) * 128;
@@ -655,10 +653,9 @@ __global__ __launch_bounds__(kThreads, 2) void pw_fwd_sk_kernel(
   const bool has_bn = in_scale != nullptr;
   const bool w_vec = (ldw & 3) == 0 && ((uintptr_t)w & 15) == 0;
   PHASE_INIT(zk != nullptr ? 1 : 0)
-  if (has_bn) {
-    for (int c = tid; c < cin; c += kThreads) { s_sc[c] = in_scale[c]; s_sh[c] = in_shift[c]; }
-    __syncthreads();
-  }
+  // (round 4) the BatchNorm constants of a group's channels travel with the group's operands: two 16-byte loads per group and
+  // lane half (the same address for 32 lanes) into registers, instead of a staging pass through LDS and a barrier in front
+  // of the first operand load
   PHASE_T(0)                    // BatchNorm constants staged
   const float* xb = x + (size_t)b * cin * P + p0 + 4 * l31;
   const float* wrow = w + (size_t)min(m0 + l31, cout - 1) * ldw + 4 * half;
@@ -670,17 +667,22 @@ __global__ __launch_bounds__(kThreads, 2) void pw_fwd_sk_kernel(
     for (int r = 0; r < 16; ++r) acc[q][r] = 0.f;
 
   const int ngroups = cin / 8;
-  float4 a4[2], b4[2][4];
-  auto load_group = [&](float4& a, float4 (&bq)[4], int j) {
+  float4 a4[2], b4[2][4], c4[2][2];
+  auto load_group = [&](float4& a, float4 (&bq)[4], float4 (&cq)[2], int j) {
     const float* wp = wrow + 8 * j;
     a = w_vec ? *reinterpret_cast<const float4*>(wp) : make_float4(wp[0], wp[1], wp[2], wp[3]);
 #pragma unroll
     for (int t = 0; t < 4; ++t) bq[t] = *reinterpret_cast<const float4*>(xb + (size_t)(8 * j + 4 * half + t) * P);
-  };
-  auto mma_group = [&](const float4& a, float4 (&bq)[4], int j) {
     if (has_bn) {
-      const float4 sc = *reinterpret_cast<const float4*>(&s_sc[8 * j + 4 * half]);
-      const float4 sh = *reinterpret_cast<const float4*>(&s_sh[8 * j + 4 * half]);
+      cq[0] = *reinterpret_cast<const float4*>(in_scale + 8 * j + 4 * half);
+      cq[1] = *reinterpret_cast<const float4*>(in_shift + 8 * j + 4 * half);
+    }
+  };
+  auto mma_group = [&](const float4& a, float4 (&bq)[4], const float4 (&cq)[2], int j) {
+    (void)j;
+    if (has_bn) {
+      const float4 sc = cq[0];
+      const float4 sh = cq[1];
       bq[0] = bn_relu4(bq[0], sc.x, sh.x);
       bq[1] = bn_relu4(bq[1], sc.y, sh.y);
       bq[2] = bn_relu4(bq[2], sc.z, sh.z);
@@ -697,7 +699,7 @@ __global__ __launch_bounds__(kThreads, 2) void pw_fwd_sk_kernel(
   };
   // this wave's groups: wv, wv + 4, ...; two register sets, the next group's loads in flight during the MFMAs
   int j = wv;
-  if (j < ngroups) load_group(a4[0], b4[0], j);
+  if (j < ngroups) load_group(a4[0], b4[0], c4[0], j);
 #ifdef ISTNET_PHASE_TIMING
   __builtin_amdgcn_s_waitcnt(0);
   PHASE_T(1)                    // first operand group arrived
@@ -706,23 +708,22 @@ __global__ __launch_bounds__(kThreads, 2) void pw_fwd_sk_kernel(
   // peeled: with the prefetches under `if (j + 4 < ngroups)` the compiler's wait counts merged over the branch outcomes
   // and drained the prefetch (`s_waitcnt vmcnt(0)` inside the loop, ISA of round 3); same accumulation order
   for (; j + 8 < ngroups; j += 8) {
-    load_group(a4[1], b4[1], j + 4);
-    mma_group(a4[0], b4[0], j);
-    load_group(a4[0], b4[0], j + 8);
-    mma_group(a4[1], b4[1], j + 4);
+    load_group(a4[1], b4[1], c4[1], j + 4);
+    mma_group(a4[0], b4[0], c4[0], j);
+    load_group(a4[0], b4[0], c4[0], j + 8);
+    mma_group(a4[1], b4[1], c4[1], j + 4);
   }
   if (j < ngroups) {
-    if (j + 4 < ngroups) load_group(a4[1], b4[1], j + 4);
-    mma_group(a4[0], b4[0], j);
-    if (j + 4 < ngroups) mma_group(a4[1], b4[1], j + 4);
+    if (j + 4 < ngroups) load_group(a4[1], b4[1], c4[1], j + 4);
+    mma_group(a4[0], b4[0], c4[0], j);
+    if (j + 4 < ngroups) mma_group(a4[1], b4[1], c4[1], j + 4);
   }
 #ifdef ISTNET_PHASE_TIMING
   asm volatile("s_nop 0" ::"v"(acc[0][0]), "v"(acc[1][0]), "v"(acc[2][0]), "v"(acc[3][0]));   // MFMA results landed
   PHASE_T(2)                    // K loop of wave 0
 #endif
   // ---- the four partial sums meet in LDS; wave w finishes registers 4w .. 4w + 3, i.e. rows 8w .. 8w + 7 ----
-  __syncthreads();              // every wave is done with the BN constants
-  PHASE_T(3)                    // waiting for the other three waves
+  PHASE_T(3)                    // (nothing to wait for: LDS is untouched until the partial sums are written)
 #pragma unroll
   for (int q = 0; q < 4; ++q)
 #pragma unroll
