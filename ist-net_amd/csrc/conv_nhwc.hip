@@ -21,6 +21,7 @@
 //   whole rounds unsplit, only the remaining 64 tiles split 8 ways                              121  (MIOpen: 111-117)
 //   K chunks of 16 instead of 32 (half the LDS: -DISTNET_CONV_KC=16)                            104, and +1 ms on the step
 #include <hip/hip_runtime.h>
+#include <atomic>
 #include <stdint.h>
 
 #include <type_traits>
@@ -513,14 +514,20 @@ template <int MT, int NT>
 constexpr size_t wrw_lds() { return (size_t)(2 * KC * (MT + 4) + 2 * KC * (NT + 4)) * sizeof(float); }
 
 // more than 64 KB of dynamic LDS has to be granted once per kernel (the static flag is per expansion site)
+// (the attribute is per DEVICE: a process that drives several GPUs needs it on each, so the flag is a per-device bit)
 #define ISTNET_ALLOW_LDS(KERNEL, BYTES)                                                                              \
   do {                                                                                                               \
-    static bool done_ = false;                                                                                       \
-    if (!done_ && (BYTES) > 64 * 1024) {                                                                             \
-      auto k_ = KERNEL;                                                                                              \
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_), hipFuncAttributeMaxDynamicSharedMemorySize,      \
-                                (int)(BYTES));                                                                       \
-      done_ = true;                                                                                                  \
+    static std::atomic<unsigned long long> done_{0};                                                                 \
+    if ((BYTES) > 64 * 1024) {                                                                                       \
+      int dev_ = 0;                                                                                                  \
+      (void)hipGetDevice(&dev_);                                                                                     \
+      const unsigned long long bit_ = 1ull << (dev_ & 63);                                                           \
+      if (!(done_.load(std::memory_order_relaxed) & bit_)) {                                                         \
+        auto k_ = KERNEL;                                                                                            \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_), hipFuncAttributeMaxDynamicSharedMemorySize,    \
+                                  (int)(BYTES));                                                                     \
+        done_.fetch_or(bit_, std::memory_order_relaxed);                                                             \
+      }                                                                                                              \
     }                                                                                                                \
   } while (0)
 
@@ -655,10 +662,16 @@ static int wrw_plan(const ConvGeom& g, int& mt, int& nt, int& per) {
     if (t < best_t) { best_t = t; best = sp; }
   }
   per = (int)((chunks + best - 1) / best);
+  if (per > kWrwMaxChunks) return 0;      // unreachable behind wrw_ok(); the launch's LDS table is sized by `per`
   return (int)((chunks + per - 1) / per);
 }
 
-static bool wrw_ok(const ConvGeom& g) { return (g.OH * g.OW) % KC == 0 && g.OH * g.OW < 65536 && g.OW >= 2; }
+// the split search stops at 1024 splits; beyond 96 * 1024 chunks (3.1 M output pixels) no plan keeps a split's
+// source-pixel table within kWrwMaxChunks, so such a layer is not taken (the caller keeps the framework's product)
+static bool wrw_ok(const ConvGeom& g) {
+  return (g.OH * g.OW) % KC == 0 && g.OH * g.OW < 65536 && g.OW >= 2 &&
+         ((long long)g.B * g.OH * g.OW + KC - 1) / KC <= (long long)kWrwMaxChunks * 1024;
+}
 
 int istnet_conv_wrw_splits(int b, int h, int w, int cin, int cout, int kh, int kw, int stride, int pad) {
   if (!geom_ok(b, h, w, cin, cout, kh, kw, stride, pad) || !wrw_ok(make_geom(b, h, w, cin, cout, kh, kw, stride, pad))) return 0;
@@ -675,6 +688,7 @@ int istnet_conv_backward_weights(int b, int h, int w, int cin, int cout, int kh,
   if (!wrw_ok(g)) return ISTNET_PN2_EINVAL;
   int mt, nt, per;
   const int splits = wrw_plan(g, mt, nt, per);
+  if (splits <= 0) return ISTNET_PN2_EINVAL;
   const size_t tab_bytes = (size_t)per * KC * 4;
   const dim3 grid((unsigned)((splits * (cout / mt) * (cin / nt) + 7) / 8 * 8 * kh * kw));
 #define ISTNET_WRW(MT, NT, WM, WN)                                                                                       \

@@ -22,9 +22,23 @@
 // 256 threads = 4 waves per workgroup, LDS double-buffered, global loads for chunk t+1 in flight
 // during the MFMAs of chunk t (register staging, one barrier per chunk).
 #include <hip/hip_runtime.h>
+#include <atomic>
 #include <stdint.h>
 
 #include "../../include/istnet_pw.h"
+
+// hipFuncAttributeMaxDynamicSharedMemorySize is a per-DEVICE attribute: one bit per device ordinal, so that a process
+// driving several GPUs (nn.DataParallel-style callers) opts in on each of them.
+struct PerDeviceOnce {
+  std::atomic<unsigned long long> bits{0};
+  bool pending(unsigned long long& bit) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    bit = 1ull << (dev & 63);
+    return !(bits.load(std::memory_order_relaxed) & bit);
+  }
+  void done(unsigned long long bit) { bits.fetch_or(bit, std::memory_order_relaxed); }
+};
 
 namespace {
 
@@ -4110,14 +4124,14 @@ static int launch_pw_dgrad(int b, int cin_total, int ci_off, int m_rows, int cou
     const int len = bwd_mid_len(b, m_rows, p);
     const int splits = (int)(((long long)b * p + len - 1) / len);
     constexpr size_t lds = MidCfg<8, 4>::LDS_BYTES;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static PerDeviceOnce attr_once; unsigned long long attr_bit;
+    if (attr_once.pending(attr_bit)) {
       if (hipFuncSetAttribute(reinterpret_cast<const void*>(&pw_bwd_mid_kernel<8, 4, false, false>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
           hipFuncSetAttribute(reinterpret_cast<const void*>(&pw_bwd_mid_kernel<8, 4, true, false>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
         return ISTNET_PN2_EINVAL;
-      attr_set = true;
+      attr_once.done(attr_bit);
     }
     if (d_dense != nullptr)
       hipLaunchKernelGGL((pw_bwd_mid_kernel<8, 4, false, false>), dim3(splits), dim3(kMidThreads), lds, as_stream(stream), p,
@@ -4315,14 +4329,14 @@ static int launch_pw_wgrad(bool gather, int b, int cin, int cout, int p, int nsa
 #define ISTNET_WGRAD2(MT, NT)                                                                                      \
   do {                                                                                                             \
     constexpr size_t lds = (2 * (MT + NT) * 36 + 5 * MT) * sizeof(float);                                          \
-    static bool attr_set = false;   /* > 64 KB of LDS per workgroup: opt in once per kernel */                     \
-    if (!attr_set) {                                                                                               \
+    static PerDeviceOnce attr_once; unsigned long long attr_bit;   /* > 64 KB of LDS per workgroup: opt in once per kernel */                     \
+    if (attr_once.pending(attr_bit)) {                                                                                               \
       if (hipFuncSetAttribute(reinterpret_cast<const void*>(&pw_wgrad2_kernel<MT, NT, false>),                     \
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||              \
           hipFuncSetAttribute(reinterpret_cast<const void*>(&pw_wgrad2_kernel<MT, NT, true>),                      \
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)                \
         return ISTNET_PN2_EINVAL;                                                                                  \
-      attr_set = true;                                                                                             \
+      attr_once.done(attr_bit);                                                                                             \
     }                                                                                                              \
     if (d_dense != nullptr)                                                                                        \
       hipLaunchKernelGGL((pw_wgrad2_kernel<MT, NT, false>), grid2, dim3(kMidThreads), lds, as_stream(stream), cin, \
@@ -4438,14 +4452,14 @@ int istnet_pw_bwd_mid(int b, int cin, int cout, int p, int nsample, const float*
 #define ISTNET_BWD_MID(COT, CIT)                                                                                   \
   do {                                                                                                             \
     constexpr size_t lds = MidCfg<COT, CIT>::LDS_BYTES;                                                            \
-    static bool attr_set = false;   /* more than 64 KB of LDS per workgroup needs the opt-in, once per kernel */   \
-    if (!attr_set) {                                                                                               \
+    static PerDeviceOnce attr_once; unsigned long long attr_bit;   /* more than 64 KB of LDS per workgroup needs the opt-in, once per kernel */   \
+    if (attr_once.pending(attr_bit)) {                                                                                               \
       if (hipFuncSetAttribute(reinterpret_cast<const void*>(&pw_bwd_mid_kernel<COT, CIT, false>),                  \
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||              \
           hipFuncSetAttribute(reinterpret_cast<const void*>(&pw_bwd_mid_kernel<COT, CIT, true>),                   \
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)                \
         return ISTNET_PN2_EINVAL;                                                                                  \
-      attr_set = true;                                                                                             \
+      attr_once.done(attr_bit);                                                                                             \
     }                                                                                                              \
     if (d_dense != nullptr)                                                                                        \
       hipLaunchKernelGGL((pw_bwd_mid_kernel<COT, CIT, false>), dim3(splits), dim3(kMidThreads), lds,               \

@@ -1,0 +1,223 @@
+"""Transparent HIP-graph segments for an eager caller.
+
+The reference's training loop (utils/solver.py:88-99) is eager: ``zero_grad`` -> ``model(batch)`` -> ``loss.backward()`` ->
+``optimizer.step()``.  The point encoder is ~230 kernel launches of 2-30 us each per step, so an eager caller is bound by
+the host issuing them (5.8-7.6 ms per B=32 step against 2.9 ms of device time, profiles/r05_eager_baseline.txt).  On this
+hardware the launch sequence of a fixed-shape step belongs in a HIP graph: ``AutoGraph`` gives an ``nn.Module`` that, for
+the caller's unchanged eager loop, replays one captured graph for its forward and one for its backward.
+
+How it works (the recipe of ``torch.cuda.make_graphed_callables``, applied lazily and per input shape so that the caller
+does not have to ask for it):
+
+* the first ``WARMUP_CALLS`` calls with a new key run the module's plain path (allocator / stream pools / library handles
+  warm up, and a caller that only ever makes a few calls never pays for a capture);
+* the next call captures the forward into a HIP graph on a static copy of the input, then the backward
+  (``torch.autograd.grad`` of the static output w.r.t. the trainable parameters) into a second graph sharing its memory pool;
+* from then on ``forward`` = copy the input into the static buffer + one graph launch, ``backward`` = copy the incoming
+  gradient + one graph launch; parameter gradients come back to autograd as the static buffers the backward kernels wrote
+  (with ``optim.FlatAdam`` attached those are the optimizer's flat gradient slots, so nothing is copied at all).
+
+The kernels, their order and their arithmetic are the plain path's: results are bit-identical (tests/test_autograph_gpu.py).
+
+The plain path is taken -- silently, it is always correct -- whenever replaying would not be: inside somebody else's stream
+capture, with autograd disabled, for inputs that require grad, while the previous graphed forward's output is still alive
+and has not been back-propagated (two forwards before one backward: siamese use, gradient accumulation over micro-batches
+held at once), when a trainable parameter already holds a ``.grad`` (accumulation: the captured kernels overwrite their
+destination), and when a module in the tree carries forward / backward hooks.  The key of a captured entry holds
+everything the capture baked in: input shape / dtype / device, every module's ``training`` flag, the addresses of all
+parameters and buffers, which parameters require grad, the presence of optimizer gradient slots, and the library's switch state.
+
+Unlike ``make_graphed_callables`` the returned tensor is the caller's own (a copy of the static output buffer), so holding
+outputs across steps is safe.  The one cost a caller can see is memory: an entry keeps its activations' pool (1.3 GB for the
+B=32 encoder) until ``graphed.reset(module)`` or the module dies.
+
+``ISTNET_AUTO_GRAPH=0`` (or ``graphed.ENABLED = False``) turns the whole mechanism off.
+"""
+import os
+import warnings
+import weakref
+
+import torch
+
+ENABLED = os.environ.get("ISTNET_AUTO_GRAPH", "1") != "0"
+WARMUP_CALLS = 2
+MAX_ENTRIES = 4          # captured shapes kept per module (least recently used goes first)
+STATS = {"captures": 0, "replays": 0, "plain": 0, "failed": 0}
+
+
+class _Entry:
+    __slots__ = ("calls", "failed", "fwd", "bwd", "static_in", "static_out", "static_gout", "static_grads", "params",
+                 "out_ref", "pending", "pool", "stamp")
+
+    def __init__(self):
+        self.calls, self.failed, self.fwd, self.bwd = 0, False, None, None
+        self.out_ref, self.pending, self.stamp = None, False, 0
+
+
+class _Replay(torch.autograd.Function):
+    """forward = input copy + forward-graph launch; backward = gradient copy + backward-graph launch."""
+
+    @staticmethod
+    def forward(ctx, entry, x, *params):
+        ctx.entry = entry
+        if x.data_ptr() != entry.static_in.data_ptr():
+            entry.static_in.copy_(x)
+        entry.fwd.replay()
+        entry.pending = True
+        # a copy (16 MB at B=32, ~10 us): the caller owns its output like on the plain path, whatever it keeps across steps
+        return entry.static_out.clone()
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, gout):
+        entry = ctx.entry
+        if gout.data_ptr() != entry.static_gout.data_ptr():
+            entry.static_gout.copy_(gout)
+        entry.bwd.replay()
+        entry.pending = False
+        # fresh tensor objects over the static buffers: AccumulateGrad then stores them instead of cloning
+        return (None, None) + tuple(None if g is None else g.detach() for g in entry.static_grads)
+
+
+class AutoGraph:
+    """Per-module cache of captured (forward, backward) graph pairs; see the module docstring.
+
+    ``plain`` is the module's ordinary forward as a callable of ONE tensor returning ONE tensor."""
+
+    def __init__(self, plain, switch_state=None):
+        self._plain = plain                  # plain(module, x) -> tensor
+        self.switch_state = switch_state or (lambda: ())
+        self.entries = {}
+        self._stamp = 0
+        self.module = None                   # weak reference, set by for_module()
+
+    def plain(self, x):
+        return self._plain(self.module(), x)
+
+    # -- what a capture bakes in -------------------------------------------------------------------------------------
+    def _key(self, module, x):
+        flags, addrs, req = [], [], []
+        for m in module.modules():
+            flags.append(m.training)
+            if m._forward_hooks or m._forward_pre_hooks or m._backward_hooks or m._backward_pre_hooks:
+                return None
+        for p in module.parameters():
+            addrs.append(p.data_ptr())
+            req.append(p.requires_grad)
+            if p.requires_grad and p.grad is not None:
+                return None              # accumulation into an existing .grad: the captured kernels overwrite
+            addrs.append(0 if getattr(p, "_istnet_grad_slot", None) is None else p._istnet_grad_slot.data_ptr())
+        for b in module.buffers():
+            addrs.append(b.data_ptr())
+        return (tuple(x.shape), x.dtype, x.device, tuple(flags), tuple(addrs), tuple(req), self.switch_state())
+
+    def __call__(self, x):
+        module = self.module()
+        if not (ENABLED and x.is_cuda and torch.is_grad_enabled() and not x.requires_grad and x.is_contiguous()
+                and not torch.cuda.is_current_stream_capturing()):
+            return self.plain(x)
+        key = self._key(module, x)
+        if key is None or not any(key[5]):
+            STATS["plain"] += 1
+            return self.plain(x)
+        entry = self.entries.get(key)
+        if entry is None:
+            if len(self.entries) >= MAX_ENTRIES:          # shapes come and go (last partial batch): keep the recent ones
+                oldest = min(self.entries, key=lambda k: self.entries[k].stamp)
+                del self.entries[oldest]
+            entry = self.entries[key] = _Entry()
+        self._stamp += 1
+        entry.stamp = self._stamp
+        entry.calls += 1
+        if entry.failed or entry.calls <= WARMUP_CALLS:
+            STATS["plain"] += 1
+            return self.plain(x)
+        if entry.fwd is None:
+            try:
+                self._capture(entry, module, x)
+            except Exception as exc:            # capture refused (unsupported op, allocator state ...): plain path for good
+                entry.failed = True
+                entry.fwd = entry.bwd = None
+                STATS["failed"] += 1
+                torch.cuda.synchronize(x.device)
+                warnings.warn(f"istnet_amd.graphed: HIP-graph capture of {type(module).__name__} failed "
+                              f"({type(exc).__name__}: {exc}); this shape keeps running launch by launch", RuntimeWarning)
+                return self.plain(x)
+        if entry.pending and entry.out_ref is not None and entry.out_ref() is not None:
+            # the previous graphed forward has not been back-propagated and its output is still referenced: a replay
+            # would overwrite the activations that backward needs
+            STATS["plain"] += 1
+            return self.plain(x)
+        params = entry.params
+        out = _Replay.apply(entry, x, *params)
+        entry.out_ref = weakref.ref(out)
+        STATS["replays"] += 1
+        return out
+
+    def _capture(self, entry, module, x):
+        dev = x.device
+        params = [p for p in module.parameters() if p.requires_grad]
+        # The capture differentiates w.r.t. fresh leaf ALIASES of the parameters (same storage), swapped into the modules
+        # for the duration of the forward capture.  The engine synchronises a gradient with the stream its leaf's
+        # AccumulateGrad node was created on; a parameter whose node is kept alive by an autograd graph the caller still
+        # holds (last step's loss / output) has the caller's stream there -- usually the default stream -- and that sync
+        # pulls the default stream into the capture, which then cannot end (hipStreamEndCapture dies on this stack).  An
+        # alias gets its node inside the capture, on the capture stream.
+        alias, swaps = {}, []
+        for m in module.modules():
+            for name, p in list(m._parameters.items()):
+                if p is None or not p.requires_grad:
+                    continue
+                a = alias.get(id(p))
+                if a is None:
+                    a = alias[id(p)] = p.detach().requires_grad_(True)
+                    slot = getattr(p, "_istnet_grad_slot", None)
+                    if slot is not None:
+                        a._istnet_grad_slot = slot          # optim.FlatAdam: the backward kernels write the flat gradient
+                swaps.append((m, name, p))
+                m._parameters[name] = a
+        try:
+            with torch.cuda.device(dev):
+                torch.cuda.synchronize(dev)
+                pool = torch.cuda.graph_pool_handle()
+                static_in = x.detach().clone()
+                fwd = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(fwd, pool=pool):
+                    static_out = self.plain(static_in)
+                if not (isinstance(static_out, torch.Tensor) and static_out.requires_grad):
+                    raise RuntimeError("the module's output is not a differentiable tensor")
+                static_gout = torch.empty_like(static_out)
+                bwd = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(bwd, pool=pool):
+                    grads = torch.autograd.grad((static_out,), [alias[id(p)] for p in params], (static_gout,),
+                                                allow_unused=True)
+                torch.cuda.synchronize(dev)
+        finally:
+            for m, name, p in swaps:
+                m._parameters[name] = p
+        entry.fwd, entry.bwd, entry.pool = fwd, bwd, pool
+        entry.static_in, entry.static_out, entry.static_gout = static_in, static_out.detach(), static_gout
+        entry.static_grads, entry.params = list(grads), params
+        STATS["captures"] += 1
+
+    def reset(self):
+        self.entries.clear()
+
+
+_REGISTRY = weakref.WeakKeyDictionary()      # module -> AutoGraph (kept outside the module: deepcopy / pickle stay plain)
+
+
+def for_module(module, plain, switch_state=None):
+    """The AutoGraph of ``module`` (created on first use).  ``plain(module, x)`` is the module's ordinary forward."""
+    ag = _REGISTRY.get(module)
+    if ag is None:
+        ag = _REGISTRY[module] = AutoGraph(plain, switch_state)
+        ag.module = weakref.ref(module)
+    return ag
+
+
+def reset(module=None):
+    """Drop captured graphs (of one module, or of all): frees their memory pools."""
+    for m, ag in list(_REGISTRY.items()):
+        if module is None or m is module:
+            ag.reset()

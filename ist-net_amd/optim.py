@@ -179,11 +179,8 @@ class FlatAdam(torch.optim.Optimizer):
             # forward whose backward runs AFTER this step (two forwards then backward / step / backward, a prefetched
             # next forward) then raises "modified by an inplace operation" instead of silently differentiating with the
             # updated weights -- the fused nodes save views of live parameter memory (fused_mlp.FusedSALevelFunction).
-            try:
-                torch._C._autograd._unsafe_set_version_counter(
-                    tuple(self.params), tuple(p._version + 1 for p in self.params))
-            except (AttributeError, TypeError):      # private API: best effort
-                pass
+            # (tests/test_optim.py::test_backward_after_native_step_raises pins the guard)
+            torch.autograd.graph.increment_version(self.params)      # public API (torch >= 2.1); an absent one raises here
             return
         if grad_scale != 1.0:
             g = g * grad_scale

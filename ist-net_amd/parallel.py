@@ -226,7 +226,10 @@ class OverlappedFlatReducer:
                     slot.zero_()
                 elif g.data_ptr() != slot.data_ptr() or not g.is_contiguous():
                     opt._view(opt.flat_grad, i).copy_(g)
-        self.works = [None] * len(self.buckets)      # Work handles of captured collectives are not waited on: the join above is the edge
+        # Work handles of captured collectives are not waited on (the join above is the edge), and the eager bookkeeping
+        # _launch() touched during the capture (launched / works) must not leak into the next eager backward: a bucket
+        # left marked "launched" would be skipped by finish() when not all of its hooks fire (unused parameters)
+        self._reset()
         return opt.flat_grad
 
     def end_capture(self):

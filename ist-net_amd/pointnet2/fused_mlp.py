@@ -592,6 +592,12 @@ USE_SPLIT_LAYER0 = True
 USE_CSR_SCATTER = True     # False: LDS-atomic scatter (steps are then not bit-reproducible)
 
 
+def switch_state():
+    """The module-level switches as a hashable value (a captured HIP graph bakes the paths they select in)."""
+    g = globals()
+    return tuple((k, g[k]) for k in sorted(g) if k.startswith("USE_")) + (COMPACT_LEVELS, FP_BWD_MID_WORKGROUPS)
+
+
 def _dwx_only_job(lib, dev, b, cout, p, ns_arg, ga, y, d_dense, d_pooled, pbs, d_arg, bn, bwdc, wparam):
     """Weight gradient of an xyz-only layer 0: per-(cloud, point chunk) partials of sum_p dY0 * xrel from the
     scatter kernel in its dwx-only mode; the batched reduce sums them into dW0 (cout, 3)."""

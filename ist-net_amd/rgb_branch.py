@@ -146,9 +146,24 @@ def _native_conv_ok(conv, x):
             and conv.padding[0] == conv.padding[1] and isinstance(conv.padding, tuple) and conv.padding_mode == "zeros"
             and conv.weight.dtype == torch.float32 and conv.weight.is_contiguous(memory_format=torch.channels_last)):
         return False
-    from . import _native
-    return bool(_native.lib().istnet_conv_supported(conv.in_channels, conv.out_channels, conv.kernel_size[0], conv.kernel_size[1],
-                                                    conv.stride[0], conv.padding[0])) and x.shape[0] * x.shape[2] * x.shape[3] < 2 ** 24
+    if x.shape[0] * x.shape[2] * x.shape[3] >= 2 ** 24:
+        return False
+    key = (x.shape[0], x.shape[2], x.shape[3], conv.in_channels, conv.out_channels, conv.kernel_size[0], conv.kernel_size[1],
+           conv.stride[0], conv.padding[0])
+    ok = _CONV_GEOM_OK.get(key)
+    if ok is None:
+        from . import _native
+        lib = _native.lib()
+        ok = bool(lib.istnet_conv_supported(*key[3:]))
+        # a split plan whose work space the library cannot size (>= 2^31 floats, or a geometry it rejects) would make the
+        # launch fail inside forward / backward: such a layer keeps the framework's convolution
+        ok = ok and lib.istnet_conv_workspace_floats(0, *key) >= 0
+        ok = ok and (conv.stride[0] != 1 or lib.istnet_conv_workspace_floats(1, *key) >= 0)
+        _CONV_GEOM_OK[key] = ok
+    return ok
+
+
+_CONV_GEOM_OK = {}
 
 
 def _conv_workspace(lib, backward_data, args, dev):

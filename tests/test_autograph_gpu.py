@@ -1,0 +1,130 @@
+"""graphed.AutoGraph: the eager caller's loop (utils/solver.py:88-99) replays captured HIP graphs -- same kernels, same
+order, so every output and gradient must be BIT-identical with the launch-by-launch path, and every situation in which a
+replay would be wrong must take the plain path."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+CAM_RADII = [[0.01, 0.02], [0.02, 0.04], [0.04, 0.08], [0.08, 0.16]]
+
+
+def _cloud(b, n, seed):
+    g = torch.Generator().manual_seed(seed)
+    d = torch.randn(b, n, 3, generator=g)
+    return (d / d.norm(dim=2, keepdim=True) * 0.1 + torch.randn(b, n, 3, generator=g) * 0.002).cuda().contiguous()
+
+
+def _model(seed=0):
+    from istnet_amd.modules import PointNet2MSG
+    torch.manual_seed(seed)
+    return PointNet2MSG([list(r) for r in CAM_RADII]).cuda().train()
+
+
+def _train(auto, opt_kind, steps=7, b=4, n=512):
+    """Reference-style loop; returns per-step (loss, output) and the final parameters / running statistics."""
+    from istnet_amd import graphed
+    from istnet_amd.optim import FlatAdam, layout_hints
+    graphed.ENABLED = auto
+    try:
+        model = _model()
+        opt = (torch.optim.Adam(model.parameters(), lr=1e-3) if opt_kind == "torch"
+               else FlatAdam(model.parameters(), lr=1e-3, adjacent=layout_hints(model)))
+        outs = []
+        for it in range(steps):
+            pts = _cloud(b, n, 100 + it)
+            opt.zero_grad()
+            out = model(pts)
+            loss = out.square().mean()
+            loss.backward()
+            opt.step()
+            outs.append((loss.detach().clone(), out.detach()))      # outputs are held across steps on purpose
+        state = {k: v.detach().clone() for k, v in model.state_dict().items()}
+        return outs, state
+    finally:
+        graphed.ENABLED = True
+
+
+@pytest.mark.parametrize("opt_kind", ["torch", "flat"])
+def test_graphed_training_loop_is_bit_identical_with_the_plain_path(opt_kind):
+    from istnet_amd import graphed
+    before = dict(graphed.STATS)
+    outs_g, state_g = _train(True, opt_kind)
+    assert graphed.STATS["captures"] == before["captures"] + 1
+    assert graphed.STATS["replays"] >= before["replays"] + 5          # steps 3..7 replayed
+    assert graphed.STATS["failed"] == before["failed"]
+    outs_p, state_p = _train(False, opt_kind)
+    for (lg, og), (lp, op) in zip(outs_g, outs_p):
+        assert torch.equal(lg, lp)
+        assert torch.equal(og, op)
+    assert state_g.keys() == state_p.keys()
+    for k in state_g:
+        assert torch.equal(state_g[k], state_p[k]), k
+
+
+def test_two_forwards_before_backward_take_the_plain_path():
+    from istnet_amd import graphed
+    model = _model()
+    a, b = _cloud(2, 256, 1), _cloud(2, 256, 2)
+    for _ in range(3):                       # warm-up + capture + one replay
+        model.zero_grad()
+        model(a).square().mean().backward()
+    replays = graphed.STATS["replays"]
+    model.zero_grad()
+    oa = model(a)                            # graphed
+    ob = model(b)                            # previous output alive and not back-propagated: plain path
+    assert graphed.STATS["replays"] == replays + 1
+    (oa.square().mean() + ob.square().mean()).backward()
+    got = [p.grad.clone() for p in model.parameters()]
+    graphed.ENABLED = False
+    try:
+        # BatchNorm running statistics differ by now, gradients do not depend on them in train mode
+        model.zero_grad()
+        (model(a).square().mean() + model(b).square().mean()).backward()
+    finally:
+        graphed.ENABLED = True
+    for g, p in zip(got, model.parameters()):
+        assert torch.equal(g, p.grad)
+
+
+def test_gradient_accumulation_and_no_grad_take_the_plain_path():
+    from istnet_amd import graphed
+    model = _model()
+    a = _cloud(2, 256, 3)
+    for _ in range(3):
+        model.zero_grad()
+        model(a).square().mean().backward()
+    replays = graphed.STATS["replays"]
+    model(a).square().mean().backward()      # .grad exists: accumulate, launch by launch
+    assert graphed.STATS["replays"] == replays
+    with torch.no_grad():
+        model(a)
+    assert graphed.STATS["replays"] == replays
+    g1 = [p.grad.clone() for p in model.parameters()]
+    model.zero_grad()
+    model(a).square().mean().backward()      # graphed again
+    assert graphed.STATS["replays"] == replays + 1
+    for acc, p in zip(g1, model.parameters()):
+        torch.testing.assert_close(acc, 2 * p.grad, rtol=1e-6, atol=1e-9)
+
+
+def test_new_shape_gets_its_own_graph_and_eval_mode_its_own_key():
+    from istnet_amd import graphed
+    model = _model()
+    caps = graphed.STATS["captures"]
+    for shape_seed, (b, n) in enumerate([(2, 256), (3, 512), (2, 256)]):
+        x = _cloud(b, n, shape_seed)
+        for _ in range(3):
+            model.zero_grad()
+            model(x).square().mean().backward()
+    assert graphed.STATS["captures"] == caps + 2
+    model.eval()
+    x = _cloud(2, 256, 9)
+    ref = None
+    for it in range(4):                      # eval-mode BatchNorm with autograd on (fine-tuning): its own entry
+        model.zero_grad()
+        out = model(x)
+        out.square().mean().backward()
+        ref = out.detach().clone() if ref is None else ref
+        assert torch.equal(out, ref)
+    assert graphed.STATS["captures"] == caps + 3

@@ -131,6 +131,27 @@ def test_fused_backward_writes_gradients_in_place():
 
 
 @pytest.mark.gpu
+def test_backward_after_native_step_raises():
+    """forward -> step -> backward: the native update writes the flat buffer through raw pointers; FlatAdam.step bumps the
+    parameters' version counters so that autograd refuses to differentiate against the already-updated weights (the fused
+    nodes save views of live parameter memory) instead of doing it silently (pin the guard)."""
+    from istnet_amd.pointnet2.pointnet2_modules import PointnetSAModuleMSG
+    torch.manual_seed(0)
+    sa = PointnetSAModuleMSG(npoint=64, radii=[0.2, 0.4], nsamples=[16, 32], mlps=[[16, 32, 32], [16, 32, 64]]).cuda().train()
+    g = torch.Generator().manual_seed(3)
+    xyz = torch.rand(2, 256, 3, generator=g).cuda()
+    feat = torch.randn(2, 16, 256, generator=g).cuda()
+    opt = FlatAdam(sa.parameters(), lr=1e-3)
+    sa(xyz, feat)[1].square().mean().backward()
+    versions = [p._version for p in sa.parameters()]
+    stale = sa(xyz, feat)[1].square().mean()        # forward BEFORE the update ...
+    opt.step()
+    assert all(p._version == v + 1 for p, v in zip(sa.parameters(), versions))
+    with pytest.raises(RuntimeError, match="modified by an inplace operation"):
+        stale.backward()                            # ... backward after it
+
+
+@pytest.mark.gpu
 def test_flat_adam_kernel_odd_sizes_and_grad_scale():
     """istnet_adam_step on lengths that are not multiples of 4 / 1024, with weight decay and a folded 1/world scale,
     against the plain-ops update in float64."""

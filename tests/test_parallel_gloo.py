@@ -246,6 +246,16 @@ def _reducer_validity_worker(rank, world, port, out):
     ok = ok and launched_in_backward == len(red3.buckets) - 1 and len(token3) == len(opt3.params) - 1
     ok = ok and torch.allclose(flat3[:want_flat.numel()], want_flat, rtol=1e-5, atol=1e-7)
     ok = ok and bool((flat3[want_flat.numel():] == 0).all())
+    # (e) ADVICE round 4: an EAGER backward on the same reducer after a capture.  The capture's _launch() calls marked every
+    # bucket "launched"; left that way, finish() would skip the bucket whose hooks do not all fire (the unused parameter's):
+    # its slice neither zeroed nor all-reduced.  Poison the slot to see it.
+    red3._in_capture = lambda param: False
+    opt3.zero_grad(set_to_none=True)
+    opt3.flat_grad.fill_(777.0)
+    _local_grads_keep(model3, rank)
+    flat3e = red3.finish()
+    ok = ok and torch.allclose(flat3e[:want_flat.numel()], want_flat, rtol=1e-5, atol=1e-7)
+    ok = ok and bool((flat3e[want_flat.numel():] == 0).all())
     raised = False
     try:
         OverlappedFlatReducer(FlatAdam(_make(0).parameters(), lr=1e-2), world).finish_captured()
