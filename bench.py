@@ -35,6 +35,8 @@ if ROOT not in sys.path:
 
 CAM_RADII = [[0.01, 0.02], [0.02, 0.04], [0.04, 0.08], [0.08, 0.16]]  # ist_net.py:16
 BATCH, NPOINTS = 32, 1024
+ENCODER_FWD_BWD_MFLOP_PER_CLOUD = 4394.7      # 3 x 1 464.9 MFLOP dense forward work per cloud
+PMC_TRAFFIC_FILE = "r05_pmc_traffic.json"     # rocprofv3 --pmc summary the roofline object's `traffic` is read from
 
 
 def shell_cloud(b, n, seed, device="cpu"):
@@ -158,6 +160,15 @@ def make_graphed_step(fwd_bwds, opt, world, reducer=None):
     host call.  With N > 1 the gradient all-reduce and the optimizer run eagerly after the replay."""
 
     fwd_bwds = list(fwd_bwds) if isinstance(fwd_bwds, (list, tuple)) else [fwd_bwds]
+    from istnet_amd import graphed
+    auto_graph, graphed.ENABLED = graphed.ENABLED, False   # the whole step goes into ONE graph here: no per-module segments
+    try:
+        return _make_graphed_step(fwd_bwds, opt, world, reducer)
+    finally:
+        graphed.ENABLED = auto_graph
+
+
+def _make_graphed_step(fwd_bwds, opt, world, reducer):
     side = torch.cuda.Stream()
     side.wait_stream(torch.cuda.current_stream())
     with torch.cuda.stream(side):                      # warm-up off the default stream (allocator, autograd)
@@ -199,6 +210,58 @@ def make_graphed_step(fwd_bwds, opt, world, reducer=None):
         if reducer is not None and not in_graph:        # bucketed RCCL all-reduce + one Adam launch
             opt.step(reducer.finish(captured=token), grad_scale=1.0 / world)
     return step
+
+
+def measure_eager(dev, workload="encoder", steps=30, warmup=8):
+    """What a reference-style caller gets (utils/solver.py:88-99): ``zero_grad`` -> ``model(batch)`` -> ``loss.backward()``
+    -> ``optimizer.step()`` issued from Python every step, no whole-step graph, no geometry prefetch, the loss built from
+    framework ops.  Four variants: torch.optim.Adam (the reference's optimizer) and FlatAdam, each with the module-level
+    HIP-graph segments of istnet_amd.graphed (the default: forward and backward of the encoder are one graph launch each
+    after two warm-up calls) and launch by launch (``ISTNET_AUTO_GRAPH=0``).  ``host_ms`` is the time the Python loop
+    needs to ISSUE a step (the loop's wall clock before the final synchronize): host-bound when it equals ``ms_per_step``."""
+    from istnet_amd import graphed
+    from istnet_amd.optim import FlatAdam, layout_hints
+    out = {}
+    saved = graphed.ENABLED
+    try:
+        for auto in (True, False):
+            graphed.ENABLED = auto
+            for opt_name in ("torch.optim.Adam", "FlatAdam"):
+                if workload == "encoder":
+                    model = make_model(dev, seed=0)
+                    pts = shell_cloud(BATCH, NPOINTS, seed=0, device=dev)
+
+                    def fwd_bwd(model=model, pts=pts):
+                        loss = model(pts).square().mean()
+                        loss.backward()
+                else:
+                    model = make_istnet(dev, seed=0)
+                    fwd_bwd = make_istnet_fwd_bwd(model, istnet_batch(BATCH, NPOINTS, seed=0, device=dev))
+                opt = (torch.optim.Adam(model.parameters(), lr=1e-4) if opt_name == "torch.optim.Adam"
+                       else FlatAdam(model.parameters(), lr=1e-4, adjacent=layout_hints(model)))
+
+                def step():
+                    opt.zero_grad()
+                    fwd_bwd()
+                    opt.step()
+                for _ in range(warmup):
+                    step()
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(steps):
+                    step()
+                t1 = time.perf_counter()
+                torch.cuda.synchronize()
+                t2 = time.perf_counter()
+                ms, host = (t2 - t0) / steps * 1e3, (t1 - t0) / steps * 1e3
+                key = ("graph_segments" if auto else "launch_by_launch") + "/" + opt_name
+                out[key] = {"ms_per_step": ms, "clouds_per_s": BATCH / ms * 1e3, "host_ms": host}
+                del model, opt, fwd_bwd, step
+                graphed.reset()
+                torch.cuda.empty_cache()
+    finally:
+        graphed.ENABLED = saved
+    return out
 
 
 def run_inference(args, dev, world, rank, dist):
@@ -373,7 +436,7 @@ def host_cpu():
     return model, (len(cores) or logical), logical
 
 
-def cpu_baseline(budget_s=60.0):
+def cpu_baseline(budget_s=60.0, thread_counts=(8, 16, 32)):
     """The same step on the host cores with the CPU oracle ops (kind 'port'), to BASELINE.md section 2's protocol:
     thread-count sweep (8 / 16 / 32 threads, 1 warm-up + 2 timed steps each) keeping the fastest, then
     3 warm-up + 10 timed steps at that count, median -- cut short only if the time budget runs out (the sample string
@@ -402,8 +465,16 @@ def cpu_baseline(budget_s=60.0):
 
         sweep = {}
         # 8 / 16 / 32 threads: every box measured so far is fastest at 16 and 4-5x SLOWER with all 128 physical cores
-        # (a 5 s step that burnt a third of the driver's bench run for a number that is then discarded)
-        for nt in sorted({t for t in (8, 16, 32) if 1 <= t <= avail} or {avail}):
+        # (profiles/r05_cpu_baseline_all_cores.json: `--cpu-threads 128`), a multi-second step that burnt a third of
+        # the driver's bench run for a number that is then discarded.
+        # The process is warmed BEFORE the sweep (allocator, oneDNN primitive caches, OpenMP pools: the first two steps of
+        # a process are 20-30 % slower, which the round-4 sweep charged to whichever thread count came first), and every
+        # count gets its own untimed step after the pool is resized.
+        counts = sorted({t for t in thread_counts if 1 <= t <= avail} or {avail})
+        torch.set_num_threads(counts[0])
+        pn2_oracle.set_threads(counts[0])
+        step(); step()
+        for nt in counts:
             torch.set_num_threads(nt)
             pn2_oracle.set_threads(nt)
             step()
@@ -456,7 +527,11 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--windows", type=int, default=0,
+                    help="timed windows of --steps steps each, the median is reported (default: 5 when steps <= 20, else 1)")
+    ap.add_argument("--no-eager-leg", action="store_true", help="skip the reference-style eager measurement (the `eager` object)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-threads", default="", help="cpu_baseline: comma-separated thread counts to sweep (default 8,16,32)")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--eager", action="store_true", help="do not capture the step in a HIP graph")
     ap.add_argument("--no-unpipelined", action="store_true", help="skip the extra unpipelined measurement")
@@ -653,20 +728,28 @@ def main():
 
     for _ in range(args.warmup):
         step()
-    if dist_on:
-        dist.barrier()
-    sync()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    sync()
-    if dist_on:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    if dist_on:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    # A window = exactly ``steps`` steps between barrier + synchronize on both sides, max over ranks.  A short window
+    # (20 steps = 50 ms for the encoder) moves by +-1 % with the box's clocks, so short runs take several windows back
+    # to back and report the MEDIAN window; every window is in the JSON line.
+    n_windows = args.windows if args.windows > 0 else (5 if args.steps <= 20 and not args.cpu_dry_run else 1)
+    windows = []
+    for _ in range(n_windows):
+        if dist_on:
+            dist.barrier()
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        sync()
+        if dist_on:
+            dist.barrier()
+        elapsed = time.perf_counter() - t0
+        if dist_on:
+            t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        windows.append(elapsed)
+    elapsed = sorted(windows)[len(windows) // 2]
 
     result = None
     if rank == 0:
@@ -678,6 +761,8 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32",
+            "windows_ms_per_step": [round(w / args.steps * 1e3, 4) for w in windows],
+            "window_statistic": "median of %d windows of %d steps" % (len(windows), args.steps),
             "data": "synthetic" if not args.cpu_dry_run else "synthetic (CPU dry run of the launch path: NOT a measurement)",
             "config": {"workload": ("PointNet2MSG encoder (4 SA-MSG + 4 FP, cam radii) fwd+bwd+Adam, "
                                     "train-mode BN, shell clouds") if args.workload == "encoder" else
@@ -711,14 +796,28 @@ def main():
             plain = make_graphed_step(make_encoder_fwd_bwd(model, pts), opt, world, grad_sync)
             for _ in range(min(args.warmup, 5)):
                 plain()
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            for _ in range(args.steps):
-                plain()
-            torch.cuda.synchronize()
-            dt = (time.perf_counter() - t1) / args.steps
+            dts = []
+            for _ in range(n_windows):
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for _ in range(args.steps):
+                    plain()
+                torch.cuda.synchronize()
+                dts.append((time.perf_counter() - t1) / args.steps)
+            dt = sorted(dts)[len(dts) // 2]
             result["unpipelined"] = {"value": BATCH / dt, "unit": "clouds/s", "ms_per_step": dt * 1e3,
+                                     "windows_ms_per_step": [round(d * 1e3, 4) for d in dts],
                                      "note": "one batch, FPS / ball query / three_nn inside the step (--no-prefetch)"}
+        if not dist_on and not args.no_eager_leg and not args.cpu_dry_run and mode == "hipgraph":
+            # the step an unchanged reference-style loop gets (no whole-step graph, no prefetch, torch.optim.Adam)
+            result["eager"] = measure_eager(dev, args.workload)
+            ref = result.get("unpipelined", result)["ms_per_step"]
+            result["eager"]["note"] = (
+                "reference-style loop (utils/solver.py:88-99: zero_grad, model(batch), loss.backward(), optimizer.step()) "
+                "issued from Python each step; graph_segments = istnet_amd.graphed (default: the encoder's forward and "
+                "backward replay lazily captured HIP graphs), launch_by_launch = ISTNET_AUTO_GRAPH=0; ratio_to_graph_replay "
+                "is against the whole-step graph of the same un-prefetched step")
+            result["eager"]["ratio_to_graph_replay"] = result["eager"]["graph_segments/torch.optim.Adam"]["ms_per_step"] / ref
         if not dist_on and not args.no_roofline:
             from istnet_amd import roofline
             capture = None
@@ -729,10 +828,17 @@ def main():
                     timed_step = make_graphed_step(fwd_bwd, opt, world, grad_sync)
                     return lambda: [timed_step() for _ in range(n_graphs)]
             result["roofline"] = roofline.measure(
-                eager_step, traffic_file=os.path.join(ROOT, "profiles", "r04_pmc_traffic.json"), capture=capture,
+                eager_step, traffic_file=os.path.join(ROOT, "profiles", PMC_TRAFFIC_FILE), capture=capture,
                 steps_per_replay=(len(fwd_bwd) if isinstance(fwd_bwd, (list, tuple)) else 1))
+            if result["roofline"] is not None and args.workload == "encoder":
+                # whole-step rate: the encoder's dense work (4 394.7 MFLOP per cloud, forward + backward) over
+                # the step time, against the fp32 MFMA peak -- includes every non-GEMM kernel and every gap
+                flop = ENCODER_FWD_BWD_MFLOP_PER_CLOUD * 1e6 * batch_size
+                result["roofline"]["step_flops_tflops"] = flop / (ms * 1e-3) / 1e12
+                result["roofline"]["step_flops_frac"] = flop / (ms * 1e-3) / 1e12 / roofline.PEAK_MFMA_F32_TFLOPS
         if not dist_on and not args.no_cpu_baseline:
-            result["cpu_baseline"] = cpu_baseline()
+            result["cpu_baseline"] = (cpu_baseline() if not args.cpu_threads else
+                                      cpu_baseline(180.0, tuple(int(t) for t in args.cpu_threads.split(","))))
     if dist_on:
         dist.barrier()
         dist.destroy_process_group()

@@ -90,25 +90,36 @@ class AutoGraph:
         self.entries = {}
         self._stamp = 0
         self.module = None                   # weak reference, set by for_module()
+        self._mods = None                    # the module tree, flattened once
 
     def plain(self, x):
         return self._plain(self.module(), x)
 
     # -- what a capture bakes in -------------------------------------------------------------------------------------
     def _key(self, module, x):
+        # the module TREE is walked once (nn.Module's generators cost ~0.7 ms per call for the encoder's 168 modules); what
+        # the modules hold -- parameters, buffers, flags, hooks -- is read afresh every call.  A submodule added or replaced
+        # after the first call needs graphed.reset(module).
+        mods = self._mods
+        if mods is None:
+            mods = self._mods = list(module.modules())
         flags, addrs, req = [], [], []
-        for m in module.modules():
+        for m in mods:
             flags.append(m.training)
             if m._forward_hooks or m._forward_pre_hooks or m._backward_hooks or m._backward_pre_hooks:
                 return None
-        for p in module.parameters():
-            addrs.append(p.data_ptr())
-            req.append(p.requires_grad)
-            if p.requires_grad and p.grad is not None:
-                return None              # accumulation into an existing .grad: the captured kernels overwrite
-            addrs.append(0 if getattr(p, "_istnet_grad_slot", None) is None else p._istnet_grad_slot.data_ptr())
-        for b in module.buffers():
-            addrs.append(b.data_ptr())
+            for p in m._parameters.values():
+                if p is None:
+                    continue
+                addrs.append(p.data_ptr())
+                req.append(p.requires_grad)
+                if p.requires_grad and p.grad is not None:
+                    return None              # accumulation into an existing .grad: the captured kernels overwrite
+                slot = p.__dict__.get("_istnet_grad_slot")
+                addrs.append(0 if slot is None else slot.data_ptr())
+            for b in m._buffers.values():
+                if b is not None:
+                    addrs.append(b.data_ptr())
         return (tuple(x.shape), x.dtype, x.device, tuple(flags), tuple(addrs), tuple(req), self.switch_state())
 
     def __call__(self, x):
@@ -202,6 +213,7 @@ class AutoGraph:
 
     def reset(self):
         self.entries.clear()
+        self._mods = None
 
 
 _REGISTRY = weakref.WeakKeyDictionary()      # module -> AutoGraph (kept outside the module: deepcopy / pickle stay plain)

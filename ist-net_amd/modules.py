@@ -71,7 +71,7 @@ class GeometrySlot:
 def _switch_state():
     """Everything process-global that a captured forward / backward bakes in (graphed.AutoGraph keys on it)."""
     return (fused_mlp.switch_state(), USE_GEOMETRY_STREAM, USE_FPS_CHAIN, FPS_CHAIN_MAX_TRACKED_N,
-            pointnet2_utils._ext.__name__)
+            id(pointnet2_utils._ext))
 
 
 class PointNet2MSG(nn.Module):
@@ -240,7 +240,7 @@ class PointNet2MSG(nn.Module):
         """(B, N, 3[+C]) -> (B, 128, N).  ``geometry``: a GeometrySlot filled by ``prefetch_geometry`` for THIS
         point cloud (extension of the reference signature)."""
         if (geometry is None and graphed.ENABLED and pointcloud.is_cuda and pointcloud.dim() == 3
-                and pointcloud.size(-1) == 3 and _native.TIMING is None and _native.MARKERS is None):
+                and pointcloud.size(-1) == 3 and pointcloud.dtype == torch.float32 and _native.TIMING is None and _native.MARKERS is None):
             # an eager caller (the reference's loop, utils/solver.py:88-99): forward and backward of a shape seen before are
             # one HIP-graph launch each (graphed.AutoGraph: same kernels, same order, bit-identical results)
             return graphed.for_module(self, PointNet2MSG._plain_forward, _switch_state)(pointcloud)
