@@ -16,6 +16,26 @@ import torch
 from .. import _native
 
 
+def set_distance_convention(convention):
+    """Arithmetic of the index-deciding squared distances in furthest_point_sampling / ball_query / three_nn:
+    0 = the reference's source expression ``((dx*dx + dy*dy) + dz*dz)`` with every operation rounded (default);
+    1 = ``fma(dz,dz, fma(dx,dx, dy*dy))`` -- what a contracting compiler makes of that expression, i.e. what the reference
+        built with its own setup.py (nvcc -O3, default -fmad=true) most likely computes: SELECT THIS to reproduce a CUDA
+        build's indices bit for bit (profiles/r05_fma_contraction_llvm.txt);
+    2 = ``fma(dz,dz, fma(dy,dy, dx*dx))``, the other possible fusion.
+    Process-wide; returns the previous value.  The environment variable ISTNET_DISTANCE_CONVENTION sets it at load time.
+    Measured exposure: 0 of 8.6 M index entries on scan-like clouds, 0.008 % on uniform cubes (profiles/r02_fma_convention_flips.txt)."""
+    global _CONVENTION
+    convention = int(convention)
+    if _native.lib().istnet_pn2_set_tuning(1, convention) != 0:
+        raise ValueError(f"distance convention must be 0, 1 or 2, got {convention}")
+    prev, _CONVENTION = _CONVENTION, convention
+    return prev
+
+
+_CONVENTION = 0
+
+
 def _req(cond, msg):
     if not cond:
         raise RuntimeError(msg)
@@ -404,3 +424,8 @@ def group_points_grad(grad_out, idx, n, csr=None):
                 b, c, int(n), npoints, nsample, _ptr(grad_out), _ptr(idx), _ptr(out), _stream(dev)),
                 "group_points_grad")
     return out
+
+
+import os as _os
+if _os.environ.get("ISTNET_DISTANCE_CONVENTION", "0") != "0" and _os.path.exists(_native.LIB_PATH):
+    set_distance_convention(int(_os.environ["ISTNET_DISTANCE_CONVENTION"]))

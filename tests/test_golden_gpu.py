@@ -46,6 +46,8 @@ def test_sa_fp_layer():
     np.testing.assert_allclose(out.detach().cpu().numpy(), z["fp_out"], **TOL)
     np.testing.assert_allclose(feat.grad.cpu().numpy(), z["grad_feat"], **TOL)
     for name, p in list(sa.named_parameters()) + list(fp.named_parameters()):
+        d_ = np.abs(p.grad.cpu().numpy() - z["gradp_" + name])
+        print("SLACK sa_fp", name, float(d_.max()), float((d_ / (np.abs(z["gradp_" + name]) + 1e-4)).max()))
         np.testing.assert_allclose(p.grad.cpu().numpy(), z["gradp_" + name], rtol=1e-3, atol=1e-4, err_msg=name)
     # the bar above compares two float32 evaluations (the golden is the reference's fp32 run).  Against a float64 evaluation
     # of the same modules with the same index decisions every parameter gradient holds 1e-4 of its own norm, except where a
@@ -69,6 +71,7 @@ def test_sa_fp_layer():
     assert rel(feat.grad, feat64.grad) < 1e-4
     errs = {n_: rel(p.grad, q.grad) for (n_, p), q in zip(list(sa.named_parameters()) + list(fp.named_parameters()),
                                                           list(sa64.parameters()) + list(fp64.parameters()))}
+    print("SLACK sa_fp f64", sorted(errs.values())[-3:])
     assert sorted(errs.values())[-2] < 1e-4 and max(errs.values()) < 2e-3, errs
 
 
@@ -126,11 +129,13 @@ def test_encoder_b2(monkeypatch):
     # layer by layer, see test_fused_mlp_gpu.py::test_fused_vs_float64), so the golden gradient norms
     # are a wiring check with a loose tolerance; the 1e-4 bar applies to the forward features above.
     norms = np.array([float(p.grad.double().norm()) for _, p in enc.named_parameters()])
+    print("SLACK encoder_b2 grad norms max rel", float(np.max(np.abs(norms - z["grad_norms"]) / np.maximum(z["grad_norms"], 1e-30))))
     np.testing.assert_allclose(norms, z["grad_norms"], rtol=3e-2, atol=1e-7)
     g = dict(enc.named_parameters())
     for key, name in (("SA_modules.0.mlps.0.layer0.conv.weight", "grad_first_conv"),
                       ("FP_modules.0.mlp.layer1.conv.weight", "grad_last_fp_conv")):
         got, want = g[key].grad.cpu().numpy(), z[name]
+        print("SLACK encoder_b2", key, float(np.linalg.norm(got - want) / np.linalg.norm(want)))
         assert np.linalg.norm(got - want) / np.linalg.norm(want) < 3e-2, key
     sd = enc.state_dict()
     np.testing.assert_allclose(sd["SA_modules.3.mlps.1.layer2.normlayer.bn.running_mean"].cpu().numpy(),
@@ -141,6 +146,66 @@ def test_encoder_b2(monkeypatch):
     with torch.no_grad():
         out_eval = enc(pts)
     np.testing.assert_allclose(out_eval.cpu().numpy()[:, :, ::8], z["out_eval"], **TOL)
+
+
+@pytest.mark.parametrize("conv", [0, 1, 2])
+def test_index_goldens_under_each_fma_convention(conv, monkeypatch):
+    """DESIGN.md section 4 / INTEGRATION.md A: the index-deciding squared distances under the source-order convention (0,
+    the default) and under the two FMA contractions an nvcc -O3 build of the reference may use (1 = LLVM's contraction of this
+    expression tree, the likely one; 2).  tests/golden/index_conventions.npz holds, per convention, what the REFERENCE's
+    Python produced over the CPU oracle in that convention (make_golden_conventions.py): config 1's FPS / ball-query
+    indices and every index tensor of the encoder on four cube clouds, one of which flips 138 entries between conventions.
+    The HIP kernels, switched with istnet_pn2_set_tuning(1, conv), must reproduce each set bit for bit."""
+    from istnet_amd import _native
+    from istnet_amd.modules import PointNet2MSG
+    from istnet_amd.pointnet2 import _ext
+    z = np.load(os.path.join(GOLD, "index_conventions.npz"))
+    lib = _native.lib()
+    assert lib.istnet_pn2_set_tuning(1, conv) == 0
+    try:
+        xyz1 = torch.from_numpy(z["xyz_config1"]).to(DEV)
+        fps = _ext.furthest_point_sampling(xyz1, 512)
+        assert np.array_equal(fps.cpu().numpy(), z[f"c{conv}_config1_fps"].astype(np.int32))
+        new_xyz = torch.gather(xyz1, 1, fps.long().unsqueeze(-1).expand(-1, -1, 3)).contiguous()
+        assert np.array_equal(_ext.ball_query(new_xyz, xyz1, 0.2, 32).cpu().numpy(), z[f"c{conv}_config1_ball"].astype(np.int32))
+        captured, counters = {}, {}
+
+        def tap(name):
+            orig = getattr(_ext, name)
+
+            def fn(*a, **k):
+                res = orig(*a, **k)
+                i = counters.get(name, 0)
+                counters[name] = i + 1
+                captured[f"{name}_{i}"] = res
+                return res
+            monkeypatch.setattr(_ext, name, fn)
+        for n in ("furthest_point_sampling_chain", "ball_query", "three_nn_weights"):
+            tap(n)
+        torch.manual_seed(0)
+        enc = PointNet2MSG([list(r) for r in CAM]).to(DEV).train()
+        pts = torch.from_numpy(z["pts_cube"]).to(DEV)
+        with torch.no_grad():
+            out = enc(pts)
+        flips = 0
+        for i in range(4):
+            want = z[f"c{conv}_furthest_point_sampling_{i}"].astype(np.int32)
+            assert np.array_equal(captured[f"furthest_point_sampling_chain_{i}"][0].cpu().numpy(), want), i
+            flips += int((want != z[f"c0_furthest_point_sampling_{i}"]).sum())
+        for i in range(8):
+            want = z[f"c{conv}_ball_query_{i}"].astype(np.int32)
+            assert np.array_equal(captured[f"ball_query_{i}"].cpu().numpy(), want), i
+            flips += int((want != z[f"c0_ball_query_{i}"]).sum())
+        levels = [pts.contiguous()] + [captured[f"furthest_point_sampling_chain_{k}"][1] for k in range(4)]
+        for i in range(4):
+            idx = captured[f"three_nn_weights_{i}"][0]
+            assert np.array_equal(idx.cpu().numpy(), z[f"c{conv}_three_nn_idx_{i}"].astype(np.int32)), i
+            d2, _ = _ext.three_nn(levels[3 - i].contiguous(), levels[4 - i].contiguous())
+            assert np.array_equal(d2.cpu().numpy(), z[f"c{conv}_three_nn_dist2_{i}"]), i
+        assert (flips > 0) == (conv != 0)            # the stored clouds do depend on the convention
+        np.testing.assert_allclose(out.cpu().numpy()[:, :, ::8], z[f"c{conv}_out_train"], rtol=2e-4, atol=2e-4)
+    finally:
+        assert lib.istnet_pn2_set_tuning(1, 0) == 0
 
 
 def test_istnet_point_branch_poses():
@@ -176,6 +241,37 @@ def test_istnet_point_branch_poses():
 # ---------------------------------------------------------------------------------------------
 # full-size (B=32, N=1024) size-independent properties
 # ---------------------------------------------------------------------------------------------
+def test_heads_match_reference_golden_on_gpu():
+    """SURVEY 8c item 4 on the GPU: FeatureDeformer, LightEstimator, HeavyEstimator and Ortho6d2Mat against the fixture the
+    reference's own modules produced (tests/golden/make_golden.py imports model/ist_net.py:114-332 and
+    utils/rotation_utils.py:4-28 unmodified).  Same seed -> same initial weights (state checksum), outputs within the 1e-4
+    bar; train mode, so the heads' BatchNorm batch statistics run through the native kernels."""
+    from istnet_amd import ist_net, rotation_utils
+    z = np.load(os.path.join(GOLD, "ist_heads_b2.npz"))
+    t = lambda k: torch.from_numpy(z[k]).to(DEV)
+    index = (t("cls").long() + torch.arange(2, device=DEV) * 6)
+    cases = {"deformer": (ist_net.FeatureDeformer, (t("pts"), t("rgb_local"), t("pts_local"), index)),
+             "light": (ist_net.LightEstimator, (t("pts"), t("rgb_local"), t("pts_local"))),
+             "heavy": (ist_net.HeavyEstimator, (t("pts"), t("pts_w"), t("rgb_local"), t("pts_local"), t("pts_w_local")))}
+    from istnet_amd.pointnet2 import fused_mlp
+    fused_mlp.FALLBACKS.clear()
+    for name, (ctor, args) in cases.items():
+        torch.manual_seed(40)
+        m = ctor()
+        sd = {k: v for k, v in m.state_dict().items() if "running_" not in k and "num_batches" not in k}
+        chk = np.array([[float(v.double().sum()), float(v.double().abs().sum())] for v in sd.values()])
+        np.testing.assert_allclose(chk, z[f"{name}_state_checksum"], rtol=0, atol=0)
+        m = m.to(DEV)
+        for i, o in enumerate(m(*args)):
+            want = z[f"{name}_out{i}"]
+            o = o.detach().cpu()
+            got = o.numpy() if o.numel() < 4096 else o.numpy().reshape(o.shape[0], -1)[:, ::16]
+            np.testing.assert_allclose(got, want, rtol=1e-4, atol=1e-5, err_msg=f"{name}[{i}]")
+    assert not fused_mlp.FALLBACKS, fused_mlp.FALLBACKS          # the native kernels ran, not the torch composition
+    rot = rotation_utils.Ortho6d2Mat(t("x6"), t("y6")).cpu()
+    np.testing.assert_allclose(rot.numpy(), z["rot"], rtol=1e-5, atol=1e-6)
+
+
 def _shell(b, n, seed):
     g = torch.Generator().manual_seed(seed)
     d = torch.randn(b, n, 3, generator=g)

@@ -138,3 +138,33 @@ def test_oracle_reproduces_golden_encoder_indices(oracle):
         d2, idx = oracle.three_nn(levels[lvl], levels[lvl + 1])
         assert np.array_equal(idx.numpy(), z[f"three_nn_idx_{i}"].astype(np.int32))
         assert np.array_equal(d2.numpy(), z[f"three_nn_dist2_{i}"])
+
+
+@pytest.mark.parametrize("conv", [0, 1, 2])
+def test_oracle_reproduces_the_convention_goldens(conv):
+    """tests/golden/index_conventions.npz (reference Python over the oracle, per arithmetic convention of the squared
+    distances; make_golden_conventions.py): the oracle's stand-alone ops give the stored config-1 indices and the level-1
+    tensors of the cube clouds again, and the three conventions really differ on the stored clouds."""
+    import os
+    import numpy as np
+    import torch
+    from oracle import pn2_oracle
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "index_conventions.npz"))
+    prev = pn2_oracle.set_convention(conv)
+    try:
+        xyz1 = torch.from_numpy(z["xyz_config1"])
+        fps = pn2_oracle.furthest_point_sampling(xyz1, 512)
+        assert np.array_equal(fps.numpy(), z[f"c{conv}_config1_fps"].astype(np.int32))
+        new_xyz = torch.gather(xyz1, 1, fps.long().unsqueeze(-1).expand(-1, -1, 3)).contiguous()
+        assert np.array_equal(pn2_oracle.ball_query(new_xyz, xyz1, 0.2, 32).numpy(), z[f"c{conv}_config1_ball"].astype(np.int32))
+        pts = torch.from_numpy(z["pts_cube"])
+        fps = pn2_oracle.furthest_point_sampling(pts, 512)
+        assert np.array_equal(fps.numpy(), z[f"c{conv}_furthest_point_sampling_0"].astype(np.int32))
+        new_xyz = torch.gather(pts, 1, fps.long().unsqueeze(-1).expand(-1, -1, 3)).contiguous()
+        for i, (r, s) in enumerate(((0.01, 16), (0.02, 32))):
+            assert np.array_equal(pn2_oracle.ball_query(new_xyz, pts, r, s).numpy(), z[f"c{conv}_ball_query_{i}"].astype(np.int32))
+    finally:
+        pn2_oracle.set_convention(prev)
+    if conv:
+        keys = [k for k in z.files if k.startswith("c0_") and z[k].dtype == np.int16]
+        assert sum(int((z[k] != z[f"c{conv}_" + k[3:]]).sum()) for k in keys) == 138
