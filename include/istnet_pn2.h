@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define ISTNET_PN2_ABI_VERSION 1
+#define ISTNET_PN2_ABI_VERSION 2
 #define ISTNET_PN2_API __attribute__((visibility("default")))
 #define ISTNET_PN2_EINVAL 100001
 

@@ -103,17 +103,9 @@ ISTNET_PN2_API int istnet_pw_gather_add(int b, int n, int npoint, int nsample, i
                                         const float *new_xyz, const int *idx, const float *z, const float *w0,
                                         int ldw, float *y, float *part_sum, float *part_sq, void *stream);
 
-/* Same GEMM with the layer-0 input of a set-abstraction scale gathered on the fly (the grouped tensor of
- * QueryAndGroup, pointnet2_utils.py:348-358, is never materialised): input channel k < 3 is
- * xyz[b][idx[b][p]][k] - new_xyz[b][p / nsample][k], channel k >= 3 is feat[b][k-3][idx[b][p]];
- * cin = 3 + cfeat, p = npoint * nsample, nsample % 4 == 0, feat may be NULL when cfeat == 0.
- * feat_t (optional, may be NULL): point-major copy of feat, (b, n, cfeat).  When given and cfeat % 16 == 0 a
- * neighbour's channels are gathered as contiguous float4 runs (the K loop then runs features first, xyz last --
- * the sum is the same up to fp32 association). */
-ISTNET_PN2_API int istnet_pw_forward_gather(int b, int n, int npoint, int nsample, int cfeat, int cout,
-                                            const float *xyz, const float *new_xyz, const float *feat,
-                                            const float *feat_t, const int *idx, const float *w, float *y,
-                                            float *part_sum, float *part_sq, void *stream);
+/* (Round 5: the un-split gathered layer-0 forward, istnet_pw_forward_gather, is gone.  Layer 0 of a set-abstraction scale
+ * always runs in the split form -- istnet_pw_forward_ld over the n source points + istnet_pw_gather_add -- which does
+ * nsample * npoint / n times fewer MACs; the gathered operand loader survives in the weight-gradient kernel below.) */
 
 /* partials -> bn[4][c]; updates running_mean / running_var (unbiased) unless they are NULL.  `momentum` is a DEVICE
  * pointer to one float, read when the kernel runs: a step captured in a HIP graph then follows the per-iteration
@@ -249,11 +241,13 @@ ISTNET_PN2_API int istnet_pw_bwd_small(int b, int cin, int cout, int p, int nsam
                                        const float *bn, const float *bwdc, float *dx, float *part_g,
                                        float *part_gy, float *dw_part, void *stream);
 
-/* wgrad with the gathered layer-0 input (see istnet_pw_forward_gather); grad_nsample = nsample of the pooled
- * gradient source (0 when d_dense is given) */
+/* wgrad with the layer-0 input of a set-abstraction scale gathered on the fly (the grouped tensor of QueryAndGroup,
+ * pointnet2_utils.py:348-358, is never materialised): input channel k < 3 is xyz[b][idx[b][p]][k] - new_xyz[b][p / nsample][k],
+ * channel k >= 3 is feat[b][k-3][idx[b][p]]; cin = 3 + cfeat, p = npoint * nsample, nsample % 4 == 0, feat may be NULL when
+ * cfeat == 0.  grad_nsample = nsample of the pooled gradient source (0 when d_dense is given) */
 ISTNET_PN2_API int istnet_pw_wgrad_gather(int b, int n, int npoint, int nsample, int cfeat, int cout,
                                           int grad_nsample, const float *xyz, const float *new_xyz,
-                                          const float *feat, const float *feat_t, const int *idx, const float *y,
+                                          const float *feat, const int *idx, const float *y,
                                           const float *d_dense, const float *d_pooled, long long pooled_bstride,
                                           const unsigned char *arg, const float *bn, const float *bwdc,
                                           float *dw_part, void *stream);

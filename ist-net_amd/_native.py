@@ -13,7 +13,7 @@ HEADER_PATH = os.path.join(INCLUDE_DIR, "istnet_pn2.h")
 HEADER_PATHS = [HEADER_PATH, os.path.join(INCLUDE_DIR, "istnet_pw.h"), os.path.join(INCLUDE_DIR, "istnet_preproc.h"),
                 os.path.join(INCLUDE_DIR, "istnet_optim.h"), os.path.join(INCLUDE_DIR, "istnet_rgb.h"),
                 os.path.join(INCLUDE_DIR, "istnet_heads.h"), os.path.join(INCLUDE_DIR, "istnet_conv.h")]
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 _i, _f, _p, _d, _l = ctypes.c_int, ctypes.c_float, ctypes.c_void_p, ctypes.c_double, ctypes.c_longlong
 # name -> argtypes (restype is always int); mirrors include/istnet_pn2.h
@@ -94,8 +94,7 @@ SIGNATURES = {
     "istnet_pw_dy": [_i, _i, _i, _p, _p, _p, _p, _p, _p],
     "istnet_pw_gather_add_tiles": [_i, _i],
     "istnet_pw_gather_add": [_i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _i, _p, _p, _p, _p],
-    "istnet_pw_forward_gather": [_i, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p],
-    "istnet_pw_wgrad_gather": [_i, _i, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _l, _p, _p, _p, _p, _p],
+    "istnet_pw_wgrad_gather": [_i, _i, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _l, _p, _p, _p, _p, _p],
     "istnet_bn_finalize_fwd": [_i, _i, _d, _p, _p, _p, _p, _f, _p, _p, _p, _p, _p],
     "istnet_bn_relu_pool": [_i, _i, _i, _i, _p, _p, _p, _l, _p, _p, _p],
     "istnet_pw_bwd_stats_pooled": [_i, _i, _i, _p, _l, _p, _p, _p, _p, _p],

@@ -163,14 +163,7 @@ struct GatherSrc {
   const float* feat;     // (B, cfeat, n) or null
   const int* idx;        // (B, P) int32
   int n, S, cfeat;
-  const float* featT;    // (B, n, cfeat) point-major copy of feat, or null.  With it (GATHER == 2) a neighbour's
-                         // channels are one contiguous run: float4 gathers instead of one scattered load per
-                         // channel.  The GEMM then walks K in the order [features..., x, y, z].
 };
-// point-major gather of 4 consecutive channels c..c+3 of neighbour `src` (cfeat % 4 == 0)
-__device__ __forceinline__ float4 gather_featT4(const GatherSrc& gs, int b, int src, int c) {
-  return *reinterpret_cast<const float4*>(gs.featT + ((size_t)b * gs.n + src) * gs.cfeat + c);
-}
 __device__ __forceinline__ int4 gather_idx4(const GatherSrc& gs, int b, int P, int p) {
   return *reinterpret_cast<const int4*>(gs.idx + (size_t)b * P + p);
 }
@@ -262,9 +255,9 @@ __device__ __forceinline__ float4 zero4() { return make_float4(0.f, 0.f, 0.f, 0.
 // ============================================================================================
 // forward:  y[b][co][p] = sum_ci wt[ci][co] * act(x[b][ci][p]),  optional BN-statistics partials
 // ============================================================================================
-template <int M_T, int N_T, int WM, int WN, int GATHER>  // 0: x is a tensor, 1: channel-major gather, 2: point-major gather
+template <int M_T, int N_T, int WM, int WN>
 __global__ __launch_bounds__(kThreads) void pw_fwd_kernel(
-    int cin, int cout, int P, int tiles_per_cloud, const float* __restrict__ x, GatherSrc gsrc,
+    int cin, int cout, int P, int tiles_per_cloud, const float* __restrict__ x,
     const float* __restrict__ w, const float* __restrict__ in_scale, const float* __restrict__ in_shift,
     float* __restrict__ y, float* __restrict__ part_sum, float* __restrict__ part_sq, int nt_total, int ldw,
     const float* __restrict__ c_init, const int* __restrict__ ncols, const float* __restrict__ colw, MultiSrc msrc,
@@ -295,9 +288,8 @@ __global__ __launch_bounds__(kThreads) void pw_fwd_kernel(
   const int b = blockIdx.x / tiles_per_cloud;
   const int p0 = (blockIdx.x - b * tiles_per_cloud) * N_T;
   const int m0 = blockIdx.y * M_T;
-  const float* xb = GATHER ? nullptr : x + (size_t)b * cin * P;
+  const float* xb = x + (size_t)b * cin * P;
   const bool has_bn = in_scale != nullptr;
-  const int cfeat = gsrc.cfeat;  // GATHER == 2: K order is [cfeat feature channels (multiple of 16), x, y, z]
 
   // Staging is split in two so the global loads of chunk t+1 stay in flight during the MFMAs of
   // chunk t: load_chunk only issues loads (clamped addresses, no branches, no use of the data),
@@ -305,45 +297,18 @@ __global__ __launch_bounds__(kThreads) void pw_fwd_kernel(
   float areg[NA];
   float4 braw[NB];
   float bsc[NB], bsh[NB];
-  int4 gidx[NB];
-  int pidx[NB];
-  if (GATHER == 1) {
-#pragma unroll
-    for (int i = 0; i < NB; ++i) {  // neighbour indices depend on the point only: load once per tile
-      const int e = tid + kThreads * i;
-      const int p = min(p0 + (e % (N_T / 4)) * 4, P - 4);
-      gidx[i] = gather_idx4(gsrc, b, P, p);
-    }
-  }
-  if (GATHER == 2) {
-#pragma unroll
-    for (int i = 0; i < NB; ++i) {  // item = (point e / 4, channel quad e % 4)
-      const int e = tid + kThreads * i;
-      pidx[i] = gsrc.idx[(size_t)b * P + min(p0 + e / 4, P - 1)];
-    }
-  }
   auto load_chunk = [&](int k0) {
-    const bool feat_chunk = GATHER == 2 && k0 < cfeat;
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
       const int e = tid + kThreads * i;
-      int k = k0 + e % kKT;
-      if (GATHER == 2) k = feat_chunk ? k + 3 : k - cfeat;   // position in K -> column of w
-      k = min(k, cin - 1);
+      const int k = min(k0 + e % kKT, cin - 1);
       const int m = min(m0 + e / kKT, cout - 1);
       areg[i] = w[(size_t)m * ldw + k];   // ldw > cin: w is a column slice of a wider matrix
     }
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
       const int e = tid + kThreads * i;
-      if (feat_chunk) {
-        braw[i] = gather_featT4(gsrc, b, pidx[i], k0 + (e % 4) * 4);
-      } else if (GATHER) {
-        const int row = e / (N_T / 4);
-        const int p = min(p0 + (e % (N_T / 4)) * 4, P - 4);
-        const int k = GATHER == 2 ? min(row, 2) : min(k0 + row, cin - 1);
-        braw[i] = gather4(gsrc, b, k, P, p, GATHER == 2 ? gather_idx4(gsrc, b, P, p) : gidx[i]);
-      } else {
+      {
         const int k = min(k0 + e / (N_T / 4), cin - 1), p = min(p0 + (e % (N_T / 4)) * 4, P - 4);
         if (msrc.n > 0) {          // the chunk's source tensor (uniform: chunks do not straddle sources)
           int sidx = 0;
@@ -359,26 +324,20 @@ __global__ __launch_bounds__(kThreads) void pw_fwd_kernel(
     }
   };
   auto store_chunk = [&](int buf, int k0) {
-    const bool feat_chunk = GATHER == 2 && k0 < cfeat;
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
       const int e = tid + kThreads * i;
       const int kk = k0 + e % kKT;
-      const bool kok = GATHER == 2 ? (feat_chunk || kk - cfeat < 3) : (kk < cin);
-      As[buf][e % kKT][e / kKT] = (kok && m0 + e / kKT < cout) ? areg[i] : 0.f;
+      As[buf][e % kKT][e / kKT] = (kk < cin && m0 + e / kKT < cout) ? areg[i] : 0.f;
     }
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
       const int e = tid + kThreads * i;
       float4 v = braw[i];
-      if (feat_chunk) {                         // (point, 4 channels) -> k-major tile: four scalar writes
-        const int pl = e / 4, q = (e % 4) * 4;
-        if (p0 + pl >= P) v = zero4();
-        Bs[buf][q + 0][pl] = v.x; Bs[buf][q + 1][pl] = v.y; Bs[buf][q + 2][pl] = v.z; Bs[buf][q + 3][pl] = v.w;
-      } else {
+      {
         const int row = e / (N_T / 4);
-        const bool kok = GATHER == 2 ? row < 3 : (k0 + row < cin);
-        if (!GATHER && has_bn) v = bn_relu4(v, bsc[i], bsh[i]);
+        const bool kok = k0 + row < cin;
+        if (has_bn) v = bn_relu4(v, bsc[i], bsh[i]);
         if (!(kok && p0 + (e % (N_T / 4)) * 4 < P)) v = zero4();
         *reinterpret_cast<float4*>(&Bs[buf][row][(e % (N_T / 4)) * 4]) = v;
       }
@@ -2370,7 +2329,7 @@ __global__ __launch_bounds__(kThreads, 2) void pw_dgrad_sk_kernel(
 // grid: (splits, ceil(cout / M_T), ceil(cin / N_T)); K = the points of one split.  A split is a range of
 // the flattened (cloud, point) index, so few-point layers (FP levels) are not forced to one split per
 // cloud; a 32-point K chunk never straddles two clouds because P % 32 == 0 is required by the launcher.
-template <int M_T, int N_T, int WM, int WN, int GATHER>  // 0 tensor input, 1 channel-major gather, 2 point-major gather
+template <int M_T, int N_T, int WM, int WN, bool GATHER>  // false: tensor input, true: gathered layer-0 input (channel-major)
 __global__ __launch_bounds__(kThreads) void pw_wgrad_kernel(
     int cin, int cout, int P, long long total, int split_len, const float* __restrict__ x, GatherSrc gsrc,
     const float* __restrict__ in_scale, const float* __restrict__ in_shift, const float* __restrict__ y,
@@ -2384,7 +2343,7 @@ __global__ __launch_bounds__(kThreads) void pw_wgrad_kernel(
     split_len = (int)((per + kKTW - 1) / kKTW * kKTW);
   }
   constexpr int LDA = M_T + 1;                          // odd leading dim: transposed scalar writes spread over banks
-  constexpr int LDB = GATHER == 2 ? N_T + 4 : N_T + 1;  // point-major gather writes whole float4 rows (16-B aligned)
+  constexpr int LDB = N_T + 1;
   constexpr int NA = M_T * kKTW / 4 / kThreads;  // float4 (along p) per thread per chunk
   constexpr int NB = N_T * kKTW / 4 / kThreads;
   static_assert(NA >= 1 && NB >= 1, "tile too small");
@@ -2401,8 +2360,6 @@ __global__ __launch_bounds__(kThreads) void pw_wgrad_kernel(
   float4 braw[NB];
   float bsc[NB], bsh[NB];
   int4 gidx[NB];  // GATHER: neighbour indices, loaded one chunk ahead of their use
-  int sidx[NB];   // GATHER == 2: item = (point e / (N_T/4), channel quad e % (N_T/4)), one index per item
-  const int cfeat = gsrc.cfeat;
   // chunk start qk (multiple of 32, inside one cloud) -> cloud b and in-cloud point of this thread's float4
   auto load_gidx = [&](long long qk) {
     const long long qc = min(qk, total - kKTW);
@@ -2411,8 +2368,7 @@ __global__ __launch_bounds__(kThreads) void pw_wgrad_kernel(
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
       const int e = tid + kThreads * i;
-      if (GATHER == 2) sidx[i] = gsrc.idx[(size_t)b * P + pk + e / (N_T / 4)];
-      else gidx[i] = gather_idx4(gsrc, b, P, pk + (e % (kKTW / 4)) * 4);
+      gidx[i] = gather_idx4(gsrc, b, P, pk + (e % (kKTW / 4)) * 4);
     }
   };
   auto load_chunk = [&](long long qk) {
@@ -2429,20 +2385,7 @@ __global__ __launch_bounds__(kThreads) void pw_wgrad_kernel(
     for (int i = 0; i < NB; ++i) {
       const int e = tid + kThreads * i;
       const int n = min(n0 + e / (kKTW / 4), cin - 1), p = pk + (e % (kKTW / 4)) * 4;
-      if (GATHER == 2) {
-        // columns in K order [features..., x, y, z]: a float4 of 4 consecutive feature channels of one neighbour,
-        // or the (x, y, z, 0) offset to the centroid
-        const int c = n0 + (e % (N_T / 4)) * 4, pp = pk + e / (N_T / 4);
-        if (c < cfeat) {
-          braw[i] = gather_featT4(gsrc, b, sidx[i], c);
-        } else if (c == cfeat) {
-          const float* xs = gsrc.xyz + ((size_t)b * gsrc.n + sidx[i]) * 3;
-          const float* xc = gsrc.new_xyz + ((size_t)b * (P / gsrc.S) + pp / gsrc.S) * 3;
-          braw[i] = make_float4(xs[0] - xc[0], xs[1] - xc[1], xs[2] - xc[2], 0.f);
-        } else {
-          braw[i] = zero4();
-        }
-      } else if (GATHER) {
+      if (GATHER) {
         braw[i] = gather4(gsrc, b, n, P, p, gidx[i]);
       } else {
         braw[i] = *reinterpret_cast<const float4*>(x + ((size_t)b * cin + n) * P + p);
@@ -2471,12 +2414,6 @@ __global__ __launch_bounds__(kThreads) void pw_wgrad_kernel(
     for (int i = 0; i < NB; ++i) {
       const int e = tid + kThreads * i;
       float4 v = braw[i];
-      if (GATHER == 2) {
-        const int pl = e / (N_T / 4), c4 = (e % (N_T / 4)) * 4;
-        if (qk + pl >= qend) v = zero4();
-        *reinterpret_cast<float4*>(&Bs[buf][pl][c4]) = v;
-        continue;
-      }
       const int n = e / (kKTW / 4), k = (e % (kKTW / 4)) * 4;
       const bool ok = (n0 + n < cin) && (qk + k < qend);
       if (!GATHER && has_bn) v = bn_relu4(v, bsc[i], bsh[i]);
@@ -2518,8 +2455,7 @@ __global__ __launch_bounds__(kThreads) void pw_wgrad_kernel(
       const int row = m0 + a_col0 + tm * 32 + mfma_row(r, lane);
 #pragma unroll
       for (int tn = 0; tn < TN; ++tn) {
-        int col = n0 + b_col0 + tn * 32 + (lane & 31);
-        if (GATHER == 2) col = col < cfeat ? col + 3 : col - cfeat + (col < cfeat + 3 ? 0 : cin);  // K order -> column of w
+        const int col = n0 + b_col0 + tn * 32 + (lane & 31);
         if (row < cout && col < cin) out[(size_t)row * cin + col] = acc[tm][tn][r];
       }
     }
@@ -3720,7 +3656,7 @@ static int launch_pw_fwd2(int cfg, int b, int cin, int cout, int p, const float*
   return (int)hipGetLastError();
 }
 
-static int launch_pw_forward(bool gather, int b, int cin, int cout, int p, const float* x, const GatherSrc& g,
+static int launch_pw_forward(int b, int cin, int cout, int p, const float* x,
                              const float* w, int ldw, const float* in_scale, const float* in_shift, float* y,
                              float* part_sum, float* part_sq, void* stream, const float* c_init = nullptr,
                              const int* ncols = nullptr, const float* colw = nullptr, const MultiSrc* msrc_p = nullptr,
@@ -3729,7 +3665,7 @@ static int launch_pw_forward(bool gather, int b, int cin, int cout, int p, const
   msrc.n = 0;
   if (msrc_p != nullptr) msrc = *msrc_p;
   if (b <= 0 || cin <= 0 || cout <= 0 || p <= 0 || (p & 3)) return ISTNET_PN2_EINVAL;
-  if (!gather && msrc_p == nullptr && ncols == nullptr && row_init == nullptr && fwd_sk_ok(b, cin, cout, p)) {
+  if (msrc_p == nullptr && ncols == nullptr && row_init == nullptr && fwd_sk_ok(b, cin, cout, p)) {
     const int tpc = p / 128;
     hipLaunchKernelGGL(pw_fwd_sk_kernel, dim3(tpc * b, ceil_div(cout, 32)), dim3(kThreads), 0, as_stream(stream), cin, cout,
                        p, tpc, x, w, ldw, in_scale, in_shift, c_init, y, part_sum, part_sq, tpc * b, nullptr, 0, nullptr,
@@ -3740,19 +3676,9 @@ static int launch_pw_forward(bool gather, int b, int cin, int cout, int p, const
   const int tpc = ceil_div(p, cfg_nt(cfg));
   const dim3 grid(tpc * b, ceil_div(cout, cfg_mt(cfg)));
   const int nt = tpc * b;
-  const int mode = !gather ? 0 : ((g.featT != nullptr && g.cfeat > 0 && g.cfeat % kKT == 0) ? 2 : 1);
 #define ISTNET_FWD(MT, NT, WM, WN)                                                                          \
-  do {                                                                                                      \
-    if (mode == 2)                                                                                          \
-      hipLaunchKernelGGL((pw_fwd_kernel<MT, NT, WM, WN, 2>), grid, dim3(kThreads), 0, as_stream(stream),    \
-                         cin, cout, p, tpc, x, g, w, in_scale, in_shift, y, part_sum, part_sq, nt, ldw, c_init, ncols, colw, msrc, row_init); \
-    else if (mode == 1)                                                                                     \
-      hipLaunchKernelGGL((pw_fwd_kernel<MT, NT, WM, WN, 1>), grid, dim3(kThreads), 0, as_stream(stream),    \
-                         cin, cout, p, tpc, x, g, w, in_scale, in_shift, y, part_sum, part_sq, nt, ldw, c_init, ncols, colw, msrc, row_init); \
-    else                                                                                                    \
-      hipLaunchKernelGGL((pw_fwd_kernel<MT, NT, WM, WN, 0>), grid, dim3(kThreads), 0, as_stream(stream),    \
-                         cin, cout, p, tpc, x, g, w, in_scale, in_shift, y, part_sum, part_sq, nt, ldw, c_init, ncols, colw, msrc, row_init); \
-  } while (0)
+  hipLaunchKernelGGL((pw_fwd_kernel<MT, NT, WM, WN>), grid, dim3(kThreads), 0, as_stream(stream), cin, cout, p, tpc, x, w, \
+                     in_scale, in_shift, y, part_sum, part_sq, nt, ldw, c_init, ncols, colw, msrc, row_init)
   switch (cfg) {
     case kCfg128x128: ISTNET_FWD(128, 128, 2, 2); break;
     case kCfg64x128: ISTNET_FWD(64, 128, 2, 2); break;
@@ -3770,7 +3696,7 @@ int istnet_pw_forward(int b, int cin, int cout, int p, const float* x, const flo
   if (b <= 0 || cin <= 0 || cout <= 0 || p <= 0 || (p & 3)) return ISTNET_PN2_EINVAL;
   const int cfg2 = fwd2_cfg(b, cin, cout, p);
   if (cfg2) return launch_pw_fwd2(cfg2, b, cin, cout, p, x, w, in_scale, in_shift, y, part_sum, part_sq, stream);
-  return launch_pw_forward(false, b, cin, cout, p, x, GatherSrc{}, w, cin, in_scale, in_shift, y, part_sum, part_sq,
+  return launch_pw_forward(b, cin, cout, p, x, w, cin, in_scale, in_shift, y, part_sum, part_sq,
                            stream);
 }
 
@@ -3789,14 +3715,14 @@ int istnet_pw_forward_ld(int b, int cin, int cout, int p, const float* x, const 
                          const float* in_scale, const float* in_shift, float* y, float* part_sum,
                          float* part_sq, void* stream) {
   if (ldw < cin) return ISTNET_PN2_EINVAL;
-  return launch_pw_forward(false, b, cin, cout, p, x, GatherSrc{}, w, ldw, in_scale, in_shift, y, part_sum, part_sq,
+  return launch_pw_forward(b, cin, cout, p, x, w, ldw, in_scale, in_shift, y, part_sum, part_sq,
                            stream);
 }
 
 int istnet_pw_forward_acc(int b, int cin, int cout, int p, const float* x, const float* w, int ldw,
                           const float* c_init, float* y, float* part_sum, float* part_sq, void* stream) {
   if (ldw < cin || c_init == nullptr) return ISTNET_PN2_EINVAL;
-  return launch_pw_forward(false, b, cin, cout, p, x, GatherSrc{}, w, ldw, nullptr, nullptr, y, part_sum, part_sq,
+  return launch_pw_forward(b, cin, cout, p, x, w, ldw, nullptr, nullptr, y, part_sum, part_sq,
                            stream, c_init);
 }
 
@@ -3828,7 +3754,7 @@ int istnet_pw_forward_multi(int b, int nsrc, const float* const* srcs, const int
   for (int s = nsrc; s < kMaxSrc; ++s) { ms.ptr[s] = nullptr; ms.cbeg[s + 1] = ms.cbeg[nsrc]; }
   const int cin = ms.cbeg[nsrc];
   if (ldw < cin) return ISTNET_PN2_EINVAL;
-  return launch_pw_forward(false, b, cin, cout, p, nullptr, GatherSrc{}, w, ldw, nullptr, nullptr, y, nullptr, nullptr,
+  return launch_pw_forward(b, cin, cout, p, nullptr, w, ldw, nullptr, nullptr, y, nullptr, nullptr,
                            stream, nullptr, nullptr, nullptr, &ms, row_init);
 }
 
@@ -3836,7 +3762,7 @@ int istnet_pw_forward_cols(int cin, int cout, long long cap, const float* x, con
                            const float* in_shift, float* y, float* part_sum, float* part_sq, const int* ncols,
                            const float* colw, void* stream) {
   if (cap <= 0 || (cap & 255) || cap >= (1LL << 31) || ncols == nullptr || colw == nullptr) return ISTNET_PN2_EINVAL;
-  return launch_pw_forward(false, 1, cin, cout, (int)cap, x, GatherSrc{}, w, cin, in_scale, in_shift, y, part_sum,
+  return launch_pw_forward(1, cin, cout, (int)cap, x, w, cin, in_scale, in_shift, y, part_sum,
                            part_sq, stream, nullptr, ncols, colw);
 }
 
@@ -3851,15 +3777,6 @@ int istnet_pw_gather_add(int b, int n, int npoint, int nsample, int cout, const 
   hipLaunchKernelGGL(pw_gather_add_kernel, grid, dim3(256), 0, as_stream(stream), n, p, nsample, cout, ldw, xyz,
                      new_xyz, idx, z, w0, y, part_sum, part_sq, (int)(grid.x * b));
   return (int)hipGetLastError();
-}
-
-int istnet_pw_forward_gather(int b, int n, int npoint, int nsample, int cfeat, int cout, const float* xyz,
-                             const float* new_xyz, const float* feat, const float* feat_t, const int* idx,
-                             const float* w, float* y, float* part_sum, float* part_sq, void* stream) {
-  if (n <= 0 || npoint <= 0 || nsample <= 0 || (nsample & 3) || cfeat < 0) return ISTNET_PN2_EINVAL;
-  const GatherSrc g{xyz, new_xyz, feat, idx, n, nsample, cfeat, feat_t};
-  return launch_pw_forward(true, b, 3 + cfeat, cout, npoint * nsample, nullptr, g, w, 3 + cfeat, nullptr, nullptr, y,
-                           part_sum, part_sq, stream);
 }
 
 int istnet_bn_finalize_fwd(int c, int nt, double count, const float* part_sum, const float* part_sq,
@@ -4354,17 +4271,13 @@ static int launch_pw_wgrad(bool gather, int b, int cin, int cout, int p, int nsa
   }
   const int mt = wgrad_mt(cout, total), nt = wgrad_nt(cin, total);
   const dim3 grid(fixed_splits > 0 ? fixed_splits : wgrad_splits(b, cin, cout, p), ceil_div(cout, mt), ceil_div(cin, nt));
-  const int mode = !gather ? 0 : ((g.featT != nullptr && g.cfeat > 0 && g.cfeat % 4 == 0) ? 2 : 1);
 #define ISTNET_WGRAD(MT, NT)                                                                                  \
   do {                                                                                                        \
-    if (mode == 2)                                                                                            \
-      hipLaunchKernelGGL((pw_wgrad_kernel<MT, NT, 2, 2, 2>), grid, dim3(kThreads), 0, as_stream(stream),      \
-                         cin, cout, p, total, len, x, g, in_scale, in_shift, y, gs, bn, bwdc, dw_part, ncols, colw); \
-    else if (mode == 1)                                                                                       \
-      hipLaunchKernelGGL((pw_wgrad_kernel<MT, NT, 2, 2, 1>), grid, dim3(kThreads), 0, as_stream(stream),      \
+    if (gather)                                                                                               \
+      hipLaunchKernelGGL((pw_wgrad_kernel<MT, NT, 2, 2, true>), grid, dim3(kThreads), 0, as_stream(stream),   \
                          cin, cout, p, total, len, x, g, in_scale, in_shift, y, gs, bn, bwdc, dw_part, ncols, colw); \
     else                                                                                                      \
-      hipLaunchKernelGGL((pw_wgrad_kernel<MT, NT, 2, 2, 0>), grid, dim3(kThreads), 0, as_stream(stream),      \
+      hipLaunchKernelGGL((pw_wgrad_kernel<MT, NT, 2, 2, false>), grid, dim3(kThreads), 0, as_stream(stream),  \
                          cin, cout, p, total, len, x, g, in_scale, in_shift, y, gs, bn, bwdc, dw_part, ncols, colw); \
   } while (0)
   if (mt == 128 && nt == 128) ISTNET_WGRAD(128, 128);
@@ -4522,12 +4435,12 @@ int istnet_pw_wgrad_cols(int cin, int cout, long long cap, const float* x, const
 }
 
 int istnet_pw_wgrad_gather(int b, int n, int npoint, int nsample, int cfeat, int cout, int grad_nsample,
-                           const float* xyz, const float* new_xyz, const float* feat, const float* feat_t,
+                           const float* xyz, const float* new_xyz, const float* feat,
                            const int* idx, const float* y, const float* d_dense, const float* d_pooled,
                            long long pooled_bstride, const unsigned char* arg, const float* bn,
                            const float* bwdc, float* dw_part, void* stream) {
   if (n <= 0 || npoint <= 0 || nsample <= 0 || (nsample & 3) || cfeat < 0) return ISTNET_PN2_EINVAL;
-  const GatherSrc g{xyz, new_xyz, feat, idx, n, nsample, cfeat, feat_t};
+  const GatherSrc g{xyz, new_xyz, feat, idx, n, nsample, cfeat};
   return launch_pw_wgrad(true, b, 3 + cfeat, cout, npoint * nsample, grad_nsample, nullptr, g, nullptr, nullptr, y,
                          d_dense, d_pooled, pooled_bstride, arg, bn, bwdc, dw_part, stream);
 }

@@ -154,19 +154,8 @@ class WorldSpaceEnhancer(nn.Module):
 
 
 USE_RGB_STREAM = True
-USE_EARLY_WORLD_EXTRACTOR = os.environ.get("ISTNET_EARLY_WORLD", "1") != "0"   # training: the auxiliary world-space encoder beside the RGB branch (it reads inputs only)
 USE_GATHER_FIRST = True
 _RGB_STREAMS = {}
-_WORLD_STREAMS = {}
-USE_WORLD_EXTRACTOR_STREAM = os.environ.get("ISTNET_WORLD_EXTRACTOR_STREAM", "0") == "1"   # experiment
-
-
-def _world_stream(dev):
-    key = dev.index if dev.index is not None else torch.cuda.current_device()
-    if key not in _WORLD_STREAMS:
-        _WORLD_STREAMS[key] = torch.cuda.Stream(device=dev)
-    return _WORLD_STREAMS[key]
-
 
 
 def _rgb_stream(dev):
@@ -249,15 +238,13 @@ class IST_Net(nn.Module):
         # RGB branch on its own stream so the encoder's many short kernels fill in around the convolutions
         # (autograd replays each op's backward on the stream its forward ran on, so backward overlaps too).
         side = None
-        rgb_last = os.environ.get("ISTNET_RGB_LAST", "0") == "1"       # experiment: issue the RGB branch after the encoders
         if "rgb_local" not in inputs and pts.is_cuda and USE_RGB_STREAM:
             main = torch.cuda.current_stream(pts.device)
             side = _rgb_stream(pts.device)
             side.wait_stream(main)
-            if not rgb_last:
-                with torch.cuda.stream(side):
-                    rgb_local = self._rgb_local(inputs, b)
-        elif not rgb_last:
+            with torch.cuda.stream(side):
+                rgb_local = self._rgb_local(inputs, b)
+        else:
             rgb_local = self._rgb_local(inputs, b)
 
         # (after the fork: the five small launches below would otherwise delay the start of the RGB branch, which is the longest
@@ -268,46 +255,15 @@ class IST_Net(nn.Module):
         index = cls + torch.arange(b, dtype=torch.long, device=pts.device) * self.nclass
         pts_local = self.pts_cam_extractor(pts)
         pts_w_local_gt = None
-        if self.training and USE_EARLY_WORLD_EXTRACTOR:
-            # the world-space encoder of the auxiliary branch reads the ground-truth coordinates only (reference ist_net.py:50-51 calls
-            # it last): issued here, its sampling chain and its many short kernels run beside the RGB branch instead of
-            # heading the serial part of the step; backward follows the same order in reverse
-            if USE_WORLD_EXTRACTOR_STREAM and pts.is_cuda:
-                # on a stream of its own: autograd replays its backward there, so in a graph replay it starts as soon as
-                # its output's gradient exists (the auxiliary estimator and the feature loss are the first things backward
-                # does) instead of after all the heads' backward on the main stream
-                cur = torch.cuda.current_stream(pts.device)
-                ws = _world_stream(pts.device)
-                ws.wait_stream(cur)
-                inputs["qo"].record_stream(ws)
-                # No geometry side stream inside this forked stream: a stream forked from a FORKED stream and joined back
-                # into it (a diamond on a non-origin stream) makes hipStreamEndCapture segfault on this stack
-                # (tools/exp/capture_nested_fork.py: nested_join_parent dies, the same diamond on the origin stream or a
-                # join into the origin only is fine).  The pre-pass then runs in line on `ws`, which is itself beside
-                # the main stream's work.
-                saved_geo, enc_modules.USE_GEOMETRY_STREAM = enc_modules.USE_GEOMETRY_STREAM, False
-                try:
-                    with torch.cuda.stream(ws):
-                        pts_w_local_gt = self.world_enhancer.extractor(inputs["qo"])
-                finally:
-                    enc_modules.USE_GEOMETRY_STREAM = saved_geo
-                self._world_join = (cur, ws)
-            else:
-                pts_w_local_gt = self.world_enhancer.extractor(inputs["qo"])
-        if rgb_last:
-            if side is not None:
-                with torch.cuda.stream(side):
-                    rgb_local = self._rgb_local(inputs, b)
-            else:
-                rgb_local = self._rgb_local(inputs, b)
+        if self.training:
+            # the world-space encoder of the auxiliary branch reads the ground-truth coordinates only (reference ist_net.py:50-51
+            # calls it last): issued here, its sampling chain and its many short kernels run beside the RGB branch instead of
+            # heading the serial part of the step; backward follows the same order in reverse.  (On a stream of its own it
+            # measured 34.3 vs 32.2 ms and needs care under capture -- tools/exp/world_stream_bisect.py)
+            pts_w_local_gt = self.world_enhancer.extractor(inputs["qo"])
         if side is not None:
             main.wait_stream(side)
             rgb_local.record_stream(main)
-        if getattr(self, "_world_join", None) is not None:
-            cur, ws = self._world_join
-            cur.wait_stream(ws)
-            pts_w_local_gt.record_stream(cur)
-            self._world_join = None
         if self.training:
             r_cam, t_cam, s_cam = self.cam_enhancer(pts, rgb_local, pts_local)
         pts_w, pts_w_local = self.implicit_transform(rgb_local, pts_local, pts, c, index)

@@ -23,11 +23,10 @@ USE_GEOMETRY_STREAM = os.environ.get("ISTNET_GEOMETRY_STREAM", "1") != "0"
 # Level l+1 samples from level l's picks in pick order, so its picks are the prefix 0..m-1 of its input whenever no
 # arg-max tie occurred in the parent's first m rounds: the parent run reports its first tied round and the children
 # skip their scan (include/istnet_pn2.h, istnet_pn2_fps_gather_chain).  Bit-identical to sampling every level.
-USE_FPS_CHAIN = True
 # Largest cloud whose sampling run keeps the tie bookkeeping its child needs.  Measured (profiles/r04_fps_chain.txt): with the
 # encoder's own sizes the full chain wins at n = 2048 too (B = 64: 466 us every level scanned, 421 us chained from level 2
 # on, 367 us chained throughout; config 5 end to end 18.46 -> 18.40 ms), so the default keeps every level tracked.
-FPS_CHAIN_MAX_TRACKED_N = int(os.environ.get("ISTNET_FPS_TRACK_MAX_N", "4096"))
+FPS_CHAIN_MAX_TRACKED_N = 4096
 _GEOMETRY_STREAMS = {}
 
 
@@ -70,7 +69,7 @@ class GeometrySlot:
 
 def _switch_state():
     """Everything process-global that a captured forward / backward bakes in (graphed.AutoGraph keys on it)."""
-    return (fused_mlp.switch_state(), USE_GEOMETRY_STREAM, USE_FPS_CHAIN, FPS_CHAIN_MAX_TRACKED_N,
+    return (fused_mlp.switch_state(), USE_GEOMETRY_STREAM, FPS_CHAIN_MAX_TRACKED_N,
             id(pointnet2_utils._ext))
 
 
@@ -111,7 +110,7 @@ class PointNet2MSG(nn.Module):
         sa_geo, fp_geo = [], [None] * len(self.FP_modules)
         with torch.cuda.stream(side), torch.no_grad():
             cur, levels = xyz, [xyz]
-            chain = getattr(pointnet2_utils._ext, "furthest_point_sampling_chain", None) if USE_FPS_CHAIN else None
+            chain = getattr(pointnet2_utils._ext, "furthest_point_sampling_chain", None)     # absent from a plain reference _ext
             tie = None
             for li, sa in enumerate(self.SA_modules):
                 if chain is not None and cur.shape[1] <= 4096:
@@ -286,7 +285,7 @@ class PointNet2MSG(nn.Module):
                 interp = (idx, weight, csr)
             # levels 3..1 hand their RAW last output + BatchNorm constants to the next level (fused_mlp.LazyAct): its
             # loaders apply the activation, the tensor of activated features is never written  [ref :322-325]
-            lazy = fused_mlp.USE_LAZY_FP and lvl > 0 and type(self.FP_modules[lvl - 1]) is PointnetFPModule
+            lazy = lvl > 0 and type(self.FP_modules[lvl - 1]) is PointnetFPModule
             l_features[lvl] = self.FP_modules[lvl](l_xyz[lvl], l_xyz[lvl + 1], l_features[lvl],
                                                    l_features[lvl + 1], interp=interp, lazy_out=lazy)
             _native.mark(f"fwd FP{lvl + 1} done")

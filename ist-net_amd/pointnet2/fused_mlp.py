@@ -49,9 +49,8 @@ def _note_fallback(reason):
 
 
 def _kname(base, cfg, gather=None, pooled=False):
-    """Kernel symbol as rocprofv3 prints it, e.g. pw_dgrad_kernel<64, 64, 2, 2> or pw_fwd_kernel<128, 128, 2, 2, 0>.
-    ``gather``: None for kernels without the template parameter, else the operand-loader mode (0 tensor input,
-    1 channel-major gather, 2 point-major gather; a bool counts as 0 / 1)."""
+    """Kernel symbol as rocprofv3 prints it, e.g. pw_dgrad_kernel<64, 64, 2, 2> or pw_wgrad_kernel<64, 64, 2, 2, false>.
+    ``gather``: None for kernels without the template parameter, else whether the operand loader gathers (wgrad only)."""
     if cfg >= 1000000:       # istnet_pw_wgrad_tile_cfg: the role-split kernel takes dense-input layers of this shape
         cfg -= 1000000
         if base == "pw_wgrad_kernel" and not gather:
@@ -61,7 +60,7 @@ def _kname(base, cfg, gather=None, pooled=False):
     if base == "pw_wgrad_kernel" and mt == 32:
         return "pw_wgrad_small_kernel<%s>" % ("true" if gather else "false")
     wm, wn = (1, 4) if mt == 32 else ((4, 1) if mt == 256 else (2, 2))
-    tail = "" if gather is None else f", {int(gather)}"
+    tail = "" if gather is None else (", true" if gather else ", false")
     return f"{base}<{mt}, {nt}, {wm}, {wn}{tail}>"
 
 
@@ -69,7 +68,7 @@ def _fwd_ld_kname(lib, b, cin, cout, p):
     """Kernel an istnet_pw_forward_ld / istnet_pw_forward_acc launch runs: the split-K kernel for small launches."""
     if lib.istnet_pw_forward_cfg(b, cin, cout, p) == 1:
         return "pw_fwd_sk_kernel"
-    return _kname("pw_fwd_kernel", lib.istnet_pw_tile_cfg(b, cout, p), 0)
+    return _kname("pw_fwd_kernel", lib.istnet_pw_tile_cfg(b, cout, p))
 
 
 def _dgrad_kname(lib, b, rows, cout, p, dense=False, stats=False):
@@ -83,13 +82,6 @@ def _dgrad_kname(lib, b, rows, cout, p, dense=False, stats=False):
     mt, nt = cfg // 1000, cfg % 1000
     fast = rows % mt == 0 and p % nt == 0 and cout % 16 == 0
     return _kname("pw_dgrad_kernel", cfg)[:-1] + (", true>" if fast else ", false>")
-
-
-def _gather_mode(ga, multiple):
-    """Loader mode the C launcher picks for a gathered layer 0 (see launch_pw_forward / launch_pw_wgrad)."""
-    if ga is None:
-        return 0
-    return 2 if (ga.feat_t is not None and ga.cfeat > 0 and ga.cfeat % multiple == 0) else 1
 
 
 def _st(dev):
@@ -121,7 +113,7 @@ def _ident_consts(dev, c):
 # .grad would be read on the main stream before the join), no kernel timing in progress.  Everything the
 # deferred launches read is kept alive until the join.  (A per-layer fork onto a side stream was measured
 # slower: 32 extra cross-stream edges per step.)
-FP_BWD_MID_WORKGROUPS = int(os.environ.get("ISTNET_FP_BWD_MID_WGS", "256"))   # 0: the library's default (128) in the FP levels too
+FP_BWD_MID_WORKGROUPS = 256   # workgroups of the fused mid-size backward kernel in the FP levels (one chain: the whole chip; the SA phases keep the library's 128)
 USE_DEFERRED_WGRAD = os.environ.get("ISTNET_DEFERRED_WGRAD", "1") != "0"    # module attribute; the environment variable only sets its import-time
                              # default (A/B runs).  tests/test_pipeline_gpu.py::test_fallback_paths_agree_with_default flips each
                              # switch once; ist_net.point_branch_side_streams sets and restores this one and USE_SCALE_STREAMS
@@ -247,13 +239,12 @@ class _Layer:
 
 class _Gather:
     """Layer-0 input of a set-abstraction scale described by its sources instead of a grouped tensor."""
-    __slots__ = ("xyz", "new_xyz", "feat", "idx", "n", "npoint", "nsample", "cfeat", "feat_t", "csr", "compact")
+    __slots__ = ("xyz", "new_xyz", "feat", "idx", "n", "npoint", "nsample", "cfeat", "csr", "compact")
 
-    def __init__(self, xyz, new_xyz, feat, idx, feat_t=None, csr=None, compact=None):
+    def __init__(self, xyz, new_xyz, feat, idx, csr=None, compact=None):
         self.xyz, self.new_xyz, self.feat, self.idx = xyz, new_xyz, feat, idx
         self.csr = csr           # (offsets, entries): inverse lists of idx over the n source points, or None
         self.compact = compact   # _ext.BallCompact: evaluate the scale on compact columns (padded repeats once), or None
-        self.feat_t = feat_t     # (B, n, C) point-major copy: contiguous float4 gathers in the layer-0 loaders
         self.n = xyz.shape[1]
         self.npoint, self.nsample = idx.shape[1], idx.shape[2]
         self.cfeat = 0 if feat is None else feat.shape[1]
@@ -306,7 +297,7 @@ def _forward_stack(lib, dev, st, b, c0, g, s, x, gather, training, layers, param
             ps, pq = part[0].data_ptr(), part[1].data_ptr()
         else:
             nt, ps, pq = 0, None, None
-        kname = _kname("pw_fwd_kernel", lib.istnet_pw_tile_cfg(b, cout, p), _gather_mode(gather if li == 0 else None, 16))
+        kname = _kname("pw_fwd_kernel", lib.istnet_pw_tile_cfg(b, cout, p))
         cfg2 = lib.istnet_pw_forward_cfg(b, cur_c, cout, p) if plain else 0
         if cfg2 == 1:
             kname = "pw_fwd_sk_kernel"
@@ -314,7 +305,7 @@ def _forward_stack(lib, dev, st, b, c0, g, s, x, gather, training, layers, param
             kname = f"pw_fwd2_kernel<{cfg2 // 1000}, {cfg2 // 100 % 10}, {cfg2 // 10 % 10}, {32 if cfg2 % 10 else 16}, 0>"
         flops, nbytes = 2.0 * b * p * cur_c * cout, 4.0 * b * p * (cur_c + cout)
         y = _empty((b, cout, p), torch.float32, dev)
-        if li == 0 and gather is not None and USE_SPLIT_LAYER0:
+        if li == 0 and gather is not None:
             # layer 0 by linearity: Z = W0[:, 3:] . feat over the n source points (nsample*npoint/n times fewer MACs
             # than over the grouped points), then y0 = Z[:, idx] + W0[:, :3] . (xyz[idx] - centre); an xyz-only
             # layer (level 1) is just the second term
@@ -334,19 +325,13 @@ def _forward_stack(lib, dev, st, b, c0, g, s, x, gather, training, layers, param
             _native.check(lib.istnet_pw_gather_add(b, ga.n, ga.npoint, ga.nsample, cout, ga.xyz.data_ptr(),
                                                    ga.new_xyz.data_ptr(), ga.idx.data_ptr(), _p(z),
                                                    w2.data_ptr(), cur_c, y.data_ptr(), ps, pq, st), "pw_gather_add")
-        elif li == 0 and gather is not None:
-            ga = gather
-            _native.check(_native.timed(kname, flops, 4.0 * b * p * (1 + cout), lambda: lib.istnet_pw_forward_gather(
-                b, ga.n, ga.npoint, ga.nsample, ga.cfeat, cout, ga.xyz.data_ptr(), ga.new_xyz.data_ptr(),
-                _p(ga.feat), _p(ga.feat_t), ga.idx.data_ptr(), w2.data_ptr(), y.data_ptr(), ps, pq, st)),
-                "pw_forward_gather")
         else:
             sc, sh = (_p(in_bn[0]), _p(in_bn[1])) if in_bn is not None else (None, None)
             cin_l, src = cur_c, cur
             _native.check(_native.timed(kname, flops, nbytes, lambda: lib.istnet_pw_forward(
                 b, cin_l, cout, p, src.data_ptr(), w2.data_ptr(), sc, sh, y.data_ptr(), ps, pq, st)), "pw_forward")
         if li not in fixed:                  # training-mode BatchNorm: batch statistics of this layer's output
-            if USE_FINALIZE_IN_TAIL and tail and li == len(layers) - 1 and lay.relu:
+            if tail and li == len(layers) - 1 and lay.relu:
                 # the stack's tail is a per-channel consumer: it finishes this layer's statistics itself (below)
                 pending = (nt, ps, pq, part, gamma, beta, lay)
             else:
@@ -449,8 +434,7 @@ def _forward_stack_compact(lib, dev, st, b, g, s, ga, training, layers, params, 
 # Run scale i >= 1 on its own stream: one chain's launch gaps and tiny kernels are filled by the other's GEMMs.
 # Fork/join discipline: the side stream waits on the main stream before it starts and the main stream joins it
 # before the level's result is used, so tensors may cross (allocated in one stream's pool, read by the other).
-USE_SCALE_STREAMS = os.environ.get("ISTNET_SCALE_STREAMS", "1") != "0"
-USE_SCALE_STREAMS_BWD = os.environ.get("ISTNET_SCALE_STREAMS_BWD", "1") != "0"    # the same fork in the level's backward
+USE_SCALE_STREAMS = os.environ.get("ISTNET_SCALE_STREAMS", "1") != "0"     # forward and backward of a level, and the FP backward's skip branch
 _SCALE_STREAMS = {}
 
 
@@ -534,15 +518,14 @@ def _wgrad_job(lib, dev, b, cin, cout, p, ns_arg, use_gather, ga, src, in_bn, y,
         ws = _empty((splits, cout, cin), torch.float32, dev)
         dw = _grad_dest(wparam, (cout, cin), dev)
         kname = _kname("pw_wgrad_kernel", lib.istnet_pw_wgrad_tile_cfg(b, cin, cout, p),
-                       (_gather_mode(ga, 4) if lib.istnet_pw_wgrad_tile_cfg(b, cin, cout, p) // 1000 != 32 else use_gather)
-                       if use_gather else 0, pooled=d_dense is None)
+                       bool(use_gather), pooled=d_dense is None)
         flops = 2.0 * b * p * cin * cout
         dd, dp, da = _p(d_dense), _p(d_pooled), _p(d_arg)
         if use_gather:
             _native.check(_native.timed(
                 kname, flops, 4.0 * (b * p * (1 + cout) + grad_elems), lambda: lib.istnet_pw_wgrad_gather(
                     b, ga.n, ga.npoint, ga.nsample, ga.cfeat, cout, ns_arg, ga.xyz.data_ptr(),
-                    ga.new_xyz.data_ptr(), _p(ga.feat), _p(ga.feat_t), ga.idx.data_ptr(), y.data_ptr(), dd, dp, pbs, da,
+                    ga.new_xyz.data_ptr(), _p(ga.feat), ga.idx.data_ptr(), y.data_ptr(), dd, dp, pbs, da,
                     bn.data_ptr(), bwdc.data_ptr(), ws.data_ptr(), wst)), "pw_wgrad_gather")
         else:
             sc, sh = (_p(in_bn[0]), _p(in_bn[1])) if in_bn is not None else (None, None)
@@ -569,11 +552,8 @@ def _compact_ok(lib, ga, layers, params, needs_backward, needs_feature_grad):
     """Can this scale run on compact columns?  Layer 0 must be the split form (source-point GEMM + gather-add); the
     backward of a scale with input features scatters the layer-0 gradient through the inverse lists of its columns into
     the level-wide feature-gradient GEMM (n <= 4096, n % 4 == 0), which exists only when that gradient is wanted."""
-    if ga.compact is None or not USE_SPLIT_LAYER0 or len(layers) < 2:
+    if ga.compact is None or len(layers) < 2:
         return False
-    widths = [params[3 * li].shape[0] for li in range(len(layers))]
-    if not USE_FUSED_SMALL_BWD and any(lib.istnet_pw_bwd_small_ok(widths[li - 1], widths[li], 256) for li in range(1, len(widths))):
-        return False       # <= 32-channel layers have no weighted dgrad / wgrad pair, only the fused kernel
     if ga.cfeat > 0 and (ga.cfeat % 4 or ga.n % 4):
         return False
     if ga.cfeat > 0 and needs_backward:
@@ -581,14 +561,10 @@ def _compact_ok(lib, ga, layers, params, needs_backward, needs_feature_grad):
     return True
 
 
-USE_FUSED_SMALL_BWD = True
-USE_POOLED_FINALIZE = True   # last layer of a scale: pooled statistics + BN-backward finalize in one launch
-USE_FINALIZE_IN_SCATTER = True  # layer 0 of an SA scale: BN-backward finalize inside the inverse-list scatter kernel
-USE_INTERP_IN_EPILOGUE = True   # FP layer 0 (small launches): three_interpolate inside the skip product's epilogue
-USE_FINALIZE_IN_TAIL = os.environ.get("ISTNET_FINALIZE_IN_TAIL", "1") != "0"   # forward: a stack's last finalize inside its pool / apply launch
-USE_DENSE_FINALIZE = True    # last layer of an FP / head stack (dense gradient, <= 65 536 points): the same
-USE_FUSED_MID_BWD = True     # 64 / 128-channel layers: dgrad + wgrad + statistics in one pass (pw_bwd_mid_kernel)
-USE_SPLIT_LAYER0 = True
+# Round 5 pruned the switches whose off-state was a superseded variant (each was a second code path kept alive by a test):
+# the fused small / mid backward kernels, the pooled / dense / in-scatter / in-tail finalizes, the interpolation in the
+# skip product's epilogue, the split layer 0, the raw-pair FP gradient and the lazy FP hand-over are simply what runs when
+# their shape conditions hold; where a condition fails the older form still runs as the FALLBACK it always was.
 USE_CSR_SCATTER = True     # False: LDS-atomic scatter (steps are then not bit-reproducible)
 
 
@@ -656,14 +632,14 @@ def _backward_stack(lib, dev, st, b, c0, g, s, x, gather, training, ys, bns, par
         part, dense_fin = None, False
         if fused_part is not None:
             part, nt_l = fused_part, fused_nt
-        elif ns_arg and USE_POOLED_FINALIZE and not (li == 0 and layer0_hook is not None):
+        elif ns_arg and not (li == 0 and layer0_hook is not None):
             pass       # statistics and finalize in one launch, below
         elif ns_arg:   # gradient through the max-pool: statistics from the (B, C, G) tensors only
             part, nt_l = _empty((2, cout, b), torch.float32, dev), b
             _native.check(lib.istnet_pw_bwd_stats_pooled(b, cout, g, dp, pbs, _ymax_ptr(d_arg, b * cout * g),
                                                          bn.data_ptr(), part[0].data_ptr(), part[1].data_ptr(), st),
                           "pw_bwd_stats_pooled")
-        elif (dd is not None and not ns_arg and USE_DENSE_FINALIZE and b * p <= 65536
+        elif (dd is not None and not ns_arg and b * p <= 65536
               and not (li == 0 and layer0_hook is not None)):
             dense_fin = True       # dense statistics and finalize in one launch, below (small launches: the FP levels)
         else:
@@ -677,7 +653,7 @@ def _backward_stack(lib, dev, st, b, c0, g, s, x, gather, training, ys, bns, par
         # layer 0 of a scale whose gradient leaves through the inverse-list scatter: that kernel derives the constants
         # of its channels from the partials itself (one launch less on the chain)
         scatter_fin = (li == 0 and part is not None and gather is not None and need_x and gather.n <= 4096
-                       and layer0_hook is None and USE_FINALIZE_IN_SCATTER and USE_CSR_SCATTER and gather.csr is not None
+                       and layer0_hook is None and USE_CSR_SCATTER and gather.csr is not None
                        and d_dense is not None and p % 4 == 0 and 4 * p <= 65536)
         if scatter_fin:
             pass
@@ -706,9 +682,8 @@ def _backward_stack(lib, dev, st, b, c0, g, s, x, gather, training, ys, bns, par
         use_gather = li == 0 and gather is not None
         # layer 0 of a scale inside a fused level: dW0 comes from the scattered dY0 (see FusedSALevelFunction)
         split_w0 = (use_gather and need_w[0] and need_x and scatter_out is not None and gather.n <= 4096
-                    and gather.cfeat > 0 and USE_SPLIT_LAYER0)
-        if (li > 0 and need_w[li] and USE_FUSED_SMALL_BWD
-                and lib.istnet_pw_bwd_small_ok(cin, cout, p)):
+                    and gather.cfeat > 0)
+        if li > 0 and need_w[li] and lib.istnet_pw_bwd_small_ok(cin, cout, p):
             # small layer: dA_{l-1}, its statistics partials and the dW partials from ONE pass over (y, g, y_{l-1})
             splits = lib.istnet_pw_bwd_small_splits(b, p)
             ws = _empty((splits, cout, cin), torch.float32, dev)
@@ -724,7 +699,7 @@ def _backward_stack(lib, dev, st, b, c0, g, s, x, gather, training, ys, bns, par
             wlayers.append(li)
             d_dense, d_pooled, d_arg = dprev, None, None
             continue
-        if li > 0 and need_w[li] and USE_FUSED_MID_BWD and lib.istnet_pw_bwd_mid_ok(cin, cout, p):
+        if li > 0 and need_w[li] and lib.istnet_pw_bwd_mid_ok(cin, cout, p):
             # mid-size layer (64 / 128 channels): the same one-pass contract, the whole weight matrix in one workgroup
             splits = lib.istnet_pw_bwd_mid_splits(b, cin, cout, p)
             ws = _empty((splits, cout, cin), torch.float32, dev)
@@ -741,7 +716,7 @@ def _backward_stack(lib, dev, st, b, c0, g, s, x, gather, training, ys, bns, par
             wlayers.append(li)
             d_dense, d_pooled, d_arg = dprev, None, None
             continue
-        if (use_gather and need_w[0] and gather.cfeat == 0 and USE_SPLIT_LAYER0):
+        if use_gather and need_w[0] and gather.cfeat == 0:
             # xyz-only layer 0 (level 1): dW0 = sum_p dY0[:, p] * xrel[p], a reduction over (y0, dA0) -- no GEMM
             wjobs.append(_dwx_only_job(lib, dev, b, cout, p, ns_arg, gather, y, d_dense, d_pooled, pbs, d_arg, bn,
                                        bwdc, w))
@@ -868,7 +843,7 @@ def _backward_stack_compact(lib, dev, st, b, g, s, ga, training, ys, bns, params
             cout, nt_l, count, 1 if training else 0, part[0].data_ptr(), part[1].data_ptr(), gamma.data_ptr(),
             bn.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), bwdc.data_ptr(), st), "bn_finalize_bwd")
         grads[3 * li + 1], grads[3 * li + 2] = dgamma, dbeta
-        if li > 0 and USE_FUSED_SMALL_BWD and lib.istnet_pw_bwd_small_ok(cin, cout, 256):
+        if li > 0 and lib.istnet_pw_bwd_small_ok(cin, cout, 256):
             splits = lib.istnet_pw_bwd_small_cols_splits()
             ws = _empty((splits, cout, cin), torch.float32, dev)
             dprev = _empty((1, cin, cap), torch.float32, dev)
@@ -1065,9 +1040,6 @@ class FusedSALevelFunction(Function):
         ctot = sum(pl[-3].shape[0] for pl in plist)
         out = _empty((b, ctot, g), torch.float32, dev)
         saved, meta, coff = [], [], 0
-        # point-major copy of the features (one small transpose per level) for contiguous neighbour gathers
-        feat_t = (feat.transpose(1, 2).contiguous()
-                  if (feat is not None and feat.shape[1] % 16 == 0 and not USE_SPLIT_LAYER0) else None)
         with torch.cuda.device(dev):
             # the layer-0 weights of the scales stacked for the level-wide feature-gradient product of backward: packed
             # here (one small launch, before the scales fork) so the backward chain does not start with a concatenation
@@ -1089,7 +1061,7 @@ class FusedSALevelFunction(Function):
             compacts = list(compacts) if compacts is not None else [None] * nsc
             used = []
             for layers, params, idx, stream, cm in zip(scales, plist, idxs, streams, compacts):
-                ga = _Gather(xyz, new_xyz, feat, idx, feat_t, compact=cm)
+                ga = _Gather(xyz, new_xyz, feat, idx, compact=cm)
                 if not _compact_ok(lib, ga, layers, params, any(ctx.needs_input_grad), ctx.needs_input_grad[0]):
                     ga.compact = None
                 used.append(ga.compact)
@@ -1112,10 +1084,8 @@ class FusedSALevelFunction(Function):
         ctx.csrs = csrs
         ctx.compacts = used
         ctx.dims = (b, g, ctot)
-        ctx.has_feat_t = feat_t is not None
         ctx.has_wcat = wcat is not None
         ctx.save_for_backward(feat if feat is not None else torch.empty(0, device=dev), xyz, new_xyz,
-                              feat_t if feat_t is not None else torch.empty(0, device=dev),
                               wcat if wcat is not None else torch.empty(0, device=dev), *idxs, *saved,
                               *tensors[nsc:])
         return out
@@ -1129,14 +1099,13 @@ class FusedSALevelFunction(Function):
         nsc = len(meta)
         sv = ctx.saved_tensors
         feat, xyz, new_xyz = sv[0], sv[1], sv[2]
-        feat_t = sv[3] if ctx.has_feat_t else None
-        wcat_saved = sv[4] if ctx.has_wcat else None
-        idxs = sv[5:5 + nsc]
+        wcat_saved = sv[3] if ctx.has_wcat else None
+        idxs = sv[4:4 + nsc]
         dev = xyz.device
         _enter_backward(dev)
         _native.mark(f"bwd SA(g={g}) start")
         dout = dout.contiguous()
-        pos = 5 + nsc
+        pos = 4 + nsc
         per_scale = []
         for (nl, s, coff, clast) in meta:
             arg = sv[pos]
@@ -1154,14 +1123,14 @@ class FusedSALevelFunction(Function):
         base = 7 + nsc   # index of the first parameter among forward()'s arguments
         with torch.cuda.device(dev):
             st = _st(dev)
-            streams = _scale_streams(dev, nsc) if ((use_level_gemm or not need_x) and USE_SCALE_STREAMS_BWD) \
+            streams = _scale_streams(dev, nsc) if (use_level_gemm or not need_x) \
                 else [torch.cuda.current_stream(dev)] * nsc
             for (nl, s, coff, clast), (arg, ys, bns), idx, csr, stream, cm in zip(meta, per_scale, idxs, ctx.csrs, streams,
                                                                                       ctx.compacts):
                 params = params_all[ppos:ppos + 3 * nl]
                 need_w = [ctx.needs_input_grad[base + ppos + 3 * li] for li in range(nl)]
                 ppos += 3 * nl
-                ga = _Gather(xyz, new_xyz, feat if ctx.has_feat else None, idx, feat_t, csr=csr, compact=cm)
+                ga = _Gather(xyz, new_xyz, feat if ctx.has_feat else None, idx, csr=csr, compact=cm)
                 cout0 = params[0].shape[0]
                 with torch.cuda.stream(stream):
                     grads, dxf, scattered = _backward_stack(
@@ -1283,7 +1252,7 @@ class FusedFPFunction(Function):
                 4.0 * b * m * (c2 + cout0), lambda: lib.istnet_pw_forward_ld(
                     b, c2, cout0, m, known.data_ptr(), w2.data_ptr(), cin, ksc, ksh, zk.data_ptr(), None, None,
                     st)), "pw_forward_ld(fp)")
-            fuse_interp = (skip_c is not None and USE_INTERP_IN_EPILOGUE and lib.istnet_pw_forward_cfg(b, c1, cout0, n) == 1
+            fuse_interp = (skip_c is not None and lib.istnet_pw_forward_cfg(b, c1, cout0, n) == 1
                            and idx.dtype == torch.int32 and idx.is_contiguous() and weight.is_contiguous())
             t = None if fuse_interp else _ext.three_interpolate(zk, idx, weight)               # (B, cout0, n)
             bn0 = _empty((4, cout0), torch.float32, dev)
@@ -1368,7 +1337,7 @@ class FusedFPFunction(Function):
             # dY0 = BatchNorm / ReLU backward of dA0.  With the inverse lists of the taps at hand nobody needs it as a
             # tensor: the interpolation gradient forms it per gathered element (istnet_interp_grad_csr_dy) and the GEMM
             # loaders form it from (y0, dA0, constants) as they do in every other layer -- one launch less on the chain.
-            raw_pair = USE_FP_RAW_DY and ctx.csr is not None
+            raw_pair = ctx.csr is not None
             if raw_pair:
                 dy_y, dy_d, dy_bn, dy_bw = y0, d_a0, bn0, bwdc0
             else:
@@ -1379,7 +1348,7 @@ class FusedFPFunction(Function):
             # The skip gradient feeds the set-abstraction backward much later; the interpolation gradient feeds the next
             # (coarser) propagation level at once.  So the skip dgrad leaves the chain: it runs on a side stream beside
             # the interpolation scatter and the known-feature dgrad, joined before this node returns.
-            streams = _scale_streams(dev, 2) if (USE_FP_SKIP_STREAM and need_skip and (need_known or need_w[0])) \
+            streams = _scale_streams(dev, 2) if (need_skip and (need_known or need_w[0])) \
                 else [torch.cuda.current_stream(dev)] * 2
             if need_skip:
                 ds = _empty((b, c1, n), torch.float32, dev)
@@ -1496,7 +1465,7 @@ def fp_level(mlp, known_feats, skip, idx, weight, csr=None, lazy_out=False):
     known_bn = None
     if isinstance(known_feats, LazyAct):
         known_feats, known_bn = known_feats.raw, known_feats.bn
-    if not (USE_FUSED_FP and known_feats.is_cuda and known_feats.dtype == torch.float32):
+    if not (known_feats.is_cuda and known_feats.dtype == torch.float32):
         return None
     n, m = idx.shape[1], known_feats.shape[2]
     if skip is not None and not (skip.is_cuda and skip.dtype == torch.float32 and skip.shape[2] == n):
@@ -1513,10 +1482,6 @@ def fp_level(mlp, known_feats, skip, idx, weight, csr=None, lazy_out=False):
     return LazyAct(*out) if lazy_out else out
 
 
-USE_FUSED_FP = True
-USE_FP_RAW_DY = os.environ.get("ISTNET_FP_RAW_DY", "1") != "0"       # feature-propagation backward: no materialised dY0 (one launch less per level)
-USE_LAZY_FP = os.environ.get("ISTNET_LAZY_FP", "1") != "0"           # encoder: FP levels 4..2 hand their RAW output + constants to the next level
-USE_FP_SKIP_STREAM = os.environ.get("ISTNET_FP_SKIP_STREAM", "1") != "0"     # feature-propagation backward: skip-branch dgrad on a side stream (off the chain)
 _ONES = {}
 
 
@@ -1730,7 +1695,7 @@ def pointwise_conv_stack_multi(seq, sources, with_mean=False, pool_mean=False):
         return x
     mods = list(seq)
     convs, relu_after, i = [], [], 0
-    ok = (USE_CONCAT_FREE_HEADS and all(t.is_cuda and t.dtype == torch.float32 and t.dim() == 3 for t in sources)
+    ok = (all(t.is_cuda and t.dtype == torch.float32 and t.dim() == 3 for t in sources)
           and len(sources) <= 6 and all(t.shape[1] % 16 == 0 for t in sources) and sources[0].shape[2] % 32 == 0
           and all(t.shape[0] == sources[0].shape[0] and t.shape[2] == sources[0].shape[2] for t in sources)
           and (not with_mean or len(sources) == 1))
@@ -1755,8 +1720,8 @@ def pointwise_conv_stack_multi(seq, sources, with_mean=False, pool_mean=False):
         lib = _native.lib()
         b, npts = sources[0].shape[0], sources[0].shape[2]
         c0, c1 = convs[0].out_channels, convs[1].out_channels
-        if ((USE_FUSED_SMALL_BWD and lib.istnet_pw_bwd_small_ok(c0, c1, npts))
-                or (USE_FUSED_MID_BWD and lib.istnet_pw_bwd_mid_ok(c0, c1, npts))
+        if (lib.istnet_pw_bwd_small_ok(c0, c1, npts)
+                or lib.istnet_pw_bwd_mid_ok(c0, c1, npts)
                 or lib.istnet_pw_dgrad_rs(b, c0, c1, npts, 1)):
             out = pointwise_conv_stack(seq, build())
             return out.mean(dim=2) if pool_mean else out
@@ -1766,9 +1731,6 @@ def pointwise_conv_stack_multi(seq, sources, with_mean=False, pool_mean=False):
     if pool_mean and not relu_after[-1]:
         return FusedMultiSourceBiasMLPFunction.apply(len(sources), with_mean, False, False, *sources, *params).mean(dim=2)
     return FusedMultiSourceBiasMLPFunction.apply(len(sources), with_mean, relu_after[-1], pool_mean, *sources, *params)
-
-
-USE_CONCAT_FREE_HEADS = True
 
 
 def pointwise_conv_stack(seq, x):

@@ -95,8 +95,6 @@ class PointnetSAModule(PointnetSAModuleMSG):
                          use_xyz=use_xyz)
 
 
-USE_FUSED_NN_WEIGHTS = True   # three_nn + inverse-distance weights in one kernel (False: the reference's five tensor ops)
-
 class PointnetFPModule(nn.Module):
     """Feature propagation from a coarse set (known) to a dense one (unknown).  [ref :148-209]"""
 
@@ -109,7 +107,7 @@ class PointnetFPModule(nn.Module):
         """three_nn + inverse-distance weights (idx (B,n,3) i32, weight (B,n,3)).  [ref :185-188]
         with_csr: also return the inverse lists of idx used by the backward of three_interpolate."""
         fused = getattr(pointnet2_utils._ext, "three_nn_weights", None)     # absent from a plain reference _ext
-        if (USE_FUSED_NN_WEIGHTS and fused is not None and unknown.is_cuda and unknown.dtype == torch.float32
+        if (fused is not None and unknown.is_cuda and unknown.dtype == torch.float32
                 and not unknown.requires_grad and not known.requires_grad and known.size(1) >= 3):
             idx, weight = fused(unknown.contiguous(), known.contiguous())   # one launch instead of six
         else:

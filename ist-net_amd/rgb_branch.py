@@ -25,7 +25,12 @@ import torch.nn.functional as F
 from .pointnet2.pytorch_utils import bn_momentum_ptr, bn_momentum_tensor
 
 
-USE_NATIVE_DECODER_BACKWARD = True   # False: the framework's own backward of PReLU / bilinear upsample
+# ONE switch for everything this file fuses (round 5; there were eight): the decoder's native PReLU / upsample backward, the
+# two-pass BatchNorm + activation kernels of the trunk and the decoder, the pyramid module's linear form, the up-convolution
+# split, `final` at the chosen pixels with its MFMA moment passes.  False = the reference's module composition on the
+# framework's kernels (model/modules.py:10-81, model/resnet.py:109-202), which is also what CPU tensors and unsupported shapes
+# run; tests compare the two.  The trunk's convolutions have their own switch below.
+USE_FUSED = os.environ.get("ISTNET_RGB_FUSED", "1") != "0"
 
 
 class _PReLUFn(torch.autograd.Function):
@@ -62,7 +67,7 @@ class PReLU(nn.PReLU):
     """nn.PReLU (same parameter, same state-dict key) with the native backward on the GPU."""
 
     def forward(self, x):
-        if (USE_NATIVE_DECODER_BACKWARD and x.is_cuda and x.dtype == torch.float32 and self.weight.numel() == 1
+        if (USE_FUSED and x.is_cuda and x.dtype == torch.float32 and self.weight.numel() == 1
                 and torch.is_grad_enabled() and (x.requires_grad or self.weight.requires_grad)):
             return _PReLUFn.apply(x, self.weight)
         return super().forward(x)
@@ -111,7 +116,7 @@ class Upsample2x(nn.Upsample):
         super().__init__(scale_factor=2, mode="bilinear", align_corners=True)
 
     def forward(self, x):
-        if (USE_NATIVE_DECODER_BACKWARD and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4
+        if (USE_FUSED and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4
                 and x.shape[1] % 4 == 0 and x.shape[2] > 1 and x.shape[3] > 1
                 and x.is_contiguous(memory_format=torch.channels_last)):
             size = (2 * x.shape[2], 2 * x.shape[3])
@@ -131,15 +136,15 @@ def _conv3x3(cin, cout, stride=1, dilation=1):
 # the inference batch (forward only, the encoder hidden beside the trunk) MIOpen's smaller workgroups leave it more room and
 # the batch is 0.3 ms faster with them.  So: on when gradients are recorded; without gradients only if forced ("2").
 USE_NATIVE_TRUNK_CONV = os.environ.get("ISTNET_NATIVE_TRUNK_CONV", "1") != "0"
-NATIVE_TRUNK_CONV_NO_GRAD = os.environ.get("ISTNET_NATIVE_TRUNK_CONV", "1") == "2"
-# which layers take the native backward-weights product ("all", "1x1", "none"); the others keep the framework's (MIOpen).
-# Alone on the trunk's shapes at B = 32 (profiles/r04_conv_microbench.txt) the native forward and backward-data win or tie on
-# every stride-1 layer, the native backward-weights wins on the 1x1 layers and loses 15 % on the large 3x3 ones.
-NATIVE_TRUNK_WRW = os.environ.get("ISTNET_NATIVE_TRUNK_WRW", "1x1")
+# The native backward-weights product is taken on the 1x1 layers only: alone on the trunk's shapes at B = 32
+# (profiles/r04_conv_microbench.txt) the native forward and backward-data win or tie on every stride-1 layer, the native
+# backward-weights wins on the 1x1 layers and loses 15 % on the large 3x3 ones, which keep the framework's (MIOpen).  (Rounds 4's
+# "all" / "none" modes measured +0.7 ms / +-0 on the step and are gone; istnet_conv_backward_weights itself is tested on
+# every trunk shape through the C ABI, tests/test_conv_gpu.py.)
 
 
 def _native_conv_ok(conv, x):
-    if not (USE_NATIVE_TRUNK_CONV and (torch.is_grad_enabled() or NATIVE_TRUNK_CONV_NO_GRAD) and x.is_cuda
+    if not (USE_NATIVE_TRUNK_CONV and torch.is_grad_enabled() and x.is_cuda
             and x.dtype == torch.float32 and x.dim() == 4
             and x.is_contiguous(memory_format=torch.channels_last) and conv.bias is None and conv.groups == 1
             and conv.dilation == (1, 1) and conv.kernel_size[0] == conv.kernel_size[1] and conv.stride[0] == conv.stride[1]
@@ -174,7 +179,7 @@ def _conv_workspace(lib, backward_data, args, dev):
 class _ConvFn(torch.autograd.Function):
     """Conv2d (channels-last float32, no bias / groups / dilation) of the ResNet trunk through include/istnet_conv.h: the
     forward and the input gradient as implicit GEMMs on the fp32 matrix cores (reference model/resnet.py:18-25 on cuDNN;
-    PyTorch-ROCm on MIOpen), the weight gradient natively or by the framework per NATIVE_TRUNK_WRW.  Exact fp32 products,
+    PyTorch-ROCm on MIOpen), the weight gradient natively on the 1x1 layers, by the framework on the 3x3 ones.  Exact fp32 products,
     fp32 accumulation; deterministic (split-K partial sums are added in a fixed order, no atomics)."""
 
     @staticmethod
@@ -219,7 +224,7 @@ class _ConvFn(torch.autograd.Function):
                                                              [0, 0], 1, [True, False, False])[0]
             if ctx.needs_input_grad[1]:
                 splits = lib.istnet_conv_wrw_splits(*args)
-                native = splits > 0 and (NATIVE_TRUNK_WRW == "all" or (NATIVE_TRUNK_WRW == "1x1" and kh == 1))
+                native = splits > 0 and kh == 1
                 if native:
                     part = torch.empty((splits, weight.numel()), dtype=torch.float32, device=x.device)
                     dw = torch.empty_like(weight, memory_format=torch.channels_last)
@@ -253,7 +258,6 @@ def _bump_batch_counter(bn):
         bn.num_batches_tracked.add_(1)
 
 
-USE_FUSED_TRUNK_NORM = os.environ.get("ISTNET_FUSED_TRUNK_NORM", "1") != "0"   # trunk: BatchNorm2d (batch statistics) [+ identity] + ReLU as two passes per direction
 
 
 class _BnReluFn(torch.autograd.Function):
@@ -341,7 +345,7 @@ def _bn_relu(bn, y, res, owner, identity=False):
     batch statistics, by the framework's modules otherwise (eval mode, CPU, other layouts).  ``identity``: bn(y) alone (the
     BatchNorm of a block's downsample branch, reference model/resnet.py:139-143): the same two passes with slope 1."""
     c = y.shape[1] if y.dim() == 4 else 0
-    if (USE_FUSED_TRUNK_NORM and y.is_cuda and y.dtype == torch.float32 and y.dim() == 4 and bn.training and bn.affine
+    if (USE_FUSED and y.is_cuda and y.dtype == torch.float32 and y.dim() == 4 and bn.training and bn.affine
             and bn.momentum is not None and c % 4 == 0 and 4 <= c <= 1024 and torch.is_grad_enabled()
             and y.is_contiguous(memory_format=torch.channels_last)
             and (res is None or (res.shape == y.shape and res.dtype == torch.float32))):
@@ -433,7 +437,6 @@ class ResNet(nn.Module):
         return self.layer4(x3), x3
 
 
-USE_PSP_LINEAR_FUSION = True   # False: the reference composition (pool -> conv -> upsample -> cat -> 2560-channel bottleneck)
 _PSP_MATRICES = {}
 
 
@@ -604,7 +607,7 @@ class PSPModule(nn.Module):
     def forward(self, feats, drop=None):
         """``drop``: the nn.Dropout2d the caller applies to the module's output (reference model/modules.py:60), folded into
         the ReLU pass of the linear form; otherwise applied here."""
-        if (USE_PSP_LINEAR_FUSION and feats.is_cuda and feats.dtype == torch.float32 and feats.dim() == 4
+        if (USE_FUSED and feats.is_cuda and feats.dtype == torch.float32 and feats.dim() == 4
                 and feats.is_contiguous(memory_format=torch.channels_last) and self.bottleneck.bias is not None):
             mask = None
             if drop is not None and drop.training and drop.p > 0:
@@ -619,7 +622,6 @@ class PSPModule(nn.Module):
         return drop(out) if drop is not None else out
 
 
-USE_UPCONV_SPLIT = True      # PSPUpsample: channel mixing on the small map + interpolate / shift / add kernel
 UPCONV_MIN_CIN = 64          # all three decoder stages; below this moving q (9 x Cout channels) costs more than it saves
 
 
@@ -692,7 +694,6 @@ class _PointMixFn(torch.autograd.Function):
         return dx, dw
 
 
-USE_FUSED_DECODER_NORM = True   # decoder stages: BatchNorm (batch statistics) + PReLU + Dropout2d as two passes per direction
 
 
 def _bn_prelu_forward(y, gamma, beta, slope, mask, running_mean, running_var, momentum, eps):
@@ -814,7 +815,7 @@ class PSPUpsample(nn.Module):
 
     def _split_ok(self, x):
         conv = self.conv[1]
-        return (USE_UPCONV_SPLIT and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4
+        return (USE_FUSED and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4
                 and x.is_contiguous(memory_format=torch.channels_last) and x.shape[2] > 1 and x.shape[3] > 1
                 and conv.in_channels >= UPCONV_MIN_CIN and conv.out_channels % 4 == 0)
 
@@ -830,7 +831,7 @@ class PSPUpsample(nn.Module):
         wr = conv.weight.permute(1, 2, 3, 0).reshape(cin, 9 * cout)          # Wr[ci][(ky*3+kx)*Cout + co]
         q = _PointMixFn.apply(x.permute(0, 2, 3, 1).reshape(b * h * w, cin), wr).view(b, h, w, 9 * cout)
         bn, act = self.conv[2], self.conv[3]
-        if (USE_FUSED_DECODER_NORM and bn.training and bn.affine and bn.momentum is not None and act.weight.numel() == 1
+        if (USE_FUSED and bn.training and bn.affine and bn.momentum is not None and act.weight.numel() == 1
                 and cout % 4 == 0 and cout <= 1024 and torch.is_grad_enabled()):
             mask = None
             if drop is not None and drop.training and drop.p > 0:
@@ -845,10 +846,8 @@ class PSPUpsample(nn.Module):
         return drop(out) if drop is not None else out
 
 
-USE_TRAIN_GATHER_FIRST = True    # training: `final` at the chosen pixels only, batch statistics from the moments of its input
 
 
-USE_NATIVE_MOMENTS = True     # _FinalAtChosenFn: moments and the dense affine backward by include/istnet_rgb.h's MFMA kernels (C = 64)
 
 
 def _moments(rows):
@@ -857,7 +856,7 @@ def _moments(rows):
     returns float64).  Otherwise the reduction over P as a batch of slice products (the library under-fills the chip on a
     (C, P) x (P, C) product, see _PointMixFn), summed in a fixed order."""
     p, c = rows.shape
-    if (USE_NATIVE_MOMENTS and rows.is_cuda and rows.dtype == torch.float32 and c == 64 and rows.is_contiguous()
+    if (USE_FUSED and rows.is_cuda and rows.dtype == torch.float32 and c == 64 and rows.is_contiguous()
             and rows.data_ptr() % 16 == 0):
         from . import _native
         lib = _native.lib()
@@ -878,12 +877,11 @@ def _moments(rows):
     return rows.sum(0), torch.matmul(rows.t(), rows)
 
 
-USE_NATIVE_FINAL_AT_CHOSEN = True   # the whole stage through include/istnet_rgb.h (istnet_final_chosen_*): 9 launches per step
                                     # instead of ~85 framework launches of small float64 algebra
 
 
 def _final_native_ok(u, choose, weight, slope):
-    return (USE_NATIVE_FINAL_AT_CHOSEN and USE_NATIVE_MOMENTS and u.is_cuda and u.dtype == torch.float32 and u.shape[1] == 64
+    return (USE_FUSED and u.is_cuda and u.dtype == torch.float32 and u.shape[1] == 64
             and u.is_contiguous(memory_format=torch.channels_last) and u.data_ptr() % 16 == 0 and weight.shape[0] <= 512
             and slope.numel() == 1 and choose.dtype == torch.int64)
 
@@ -1009,7 +1007,7 @@ class _FinalAtChosenFn(torch.autograd.Function):
         amat = (wd.t() * k) @ wd                                           # W^T diag(k) W  (C, C)
         c0 = wd.t() @ off
         rows = u.permute(0, 2, 3, 1).reshape(npix, c)
-        if (USE_NATIVE_MOMENTS and rows.is_cuda and rows.dtype == torch.float32 and c == 64 and rows.is_contiguous()
+        if (USE_FUSED and rows.is_cuda and rows.dtype == torch.float32 and c == 64 and rows.is_contiguous()
                 and rows.data_ptr() % 16 == 0):
             from . import _native
             du = torch.empty_like(rows)
@@ -1076,7 +1074,7 @@ class Modified_PSPNet(nn.Module):
 
     def _train_gather_ok(self, u):
         conv, bn, act = self.final[0], self.final[1], self.final[2]
-        return (USE_TRAIN_GATHER_FIRST and self.training and bn.training and u.is_cuda and u.dtype == torch.float32
+        return (USE_FUSED and self.training and bn.training and u.is_cuda and u.dtype == torch.float32
                 and u.is_contiguous(memory_format=torch.channels_last) and conv.bias is not None and bn.affine
                 and bn.momentum is not None and act.weight.numel() == 1)
 

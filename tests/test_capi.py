@@ -35,7 +35,7 @@ def test_binding_table_matches_header():
 def test_abi_version_and_target():
     from istnet_amd import _native
     lib = _native.lib()
-    assert lib.istnet_pn2_abi_version() == _native.ABI_VERSION == 1
+    assert lib.istnet_pn2_abi_version() == _native.ABI_VERSION == 2
     assert lib.istnet_pn2_target() == b"gfx950"
 
 

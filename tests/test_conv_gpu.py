@@ -96,10 +96,9 @@ def test_conv_rejects_what_it_does_not_cover():
     assert lib.istnet_conv_forward(1, 8, 8, 3, 64, 7, 7, 2, 3, x.data_ptr(), x.data_ptr(), x.data_ptr(), None, _st()) != 0
 
 
-@pytest.mark.parametrize("wrw", ["all", "1x1", "none"])
-def test_basic_block_with_native_convolutions(wrw):
+def test_basic_block_with_native_convolutions():
     """BasicBlock (reference model/resnet.py:36-67) with its convolutions on include/istnet_conv.h against the same block on
-    the framework's convolutions: output and every gradient; the three settings of the weight-gradient switch."""
+    the framework's convolutions: output and every gradient (the 1x1 downsample layer takes the native weight gradient)."""
     from istnet_amd import rgb_branch
     torch.manual_seed(4)
     ds = torch.nn.Sequential(torch.nn.Conv2d(64, 128, 1, stride=2, bias=False), torch.nn.BatchNorm2d(128))
@@ -109,8 +108,8 @@ def test_basic_block_with_native_convolutions(wrw):
     wgt = torch.randn(4, 128, 8, 8, device=DEV)
 
     def run(native):
-        old = rgb_branch.USE_NATIVE_TRUNK_CONV, rgb_branch.NATIVE_TRUNK_WRW
-        rgb_branch.USE_NATIVE_TRUNK_CONV, rgb_branch.NATIVE_TRUNK_WRW = native, wrw
+        old = rgb_branch.USE_NATIVE_TRUNK_CONV
+        rgb_branch.USE_NATIVE_TRUNK_CONV = native
         try:
             for m in (blk, blk2):
                 m.zero_grad(set_to_none=True)
@@ -120,7 +119,7 @@ def test_basic_block_with_native_convolutions(wrw):
             grads = {n: p.grad.clone() for m in (blk, blk2) for n, p in m.named_parameters()}
             return out.detach(), xx.grad, grads
         finally:
-            rgb_branch.USE_NATIVE_TRUNK_CONV, rgb_branch.NATIVE_TRUNK_WRW = old
+            rgb_branch.USE_NATIVE_TRUNK_CONV = old
 
     a, r = run(True), run(False)
     rel = lambda u, v: float((u - v).abs().max() / (v.abs().max() + 1e-30))

@@ -494,12 +494,13 @@ def test_concat_free_head_stack_equals_concatenated_input(chans, with_mean, widt
     for fused in (True, False):
         seq.zero_grad(set_to_none=True)
         srcs = [t.clone().requires_grad_(True) for t in srcs0]
-        saved = fused_mlp.USE_CONCAT_FREE_HEADS
-        try:
-            fused_mlp.USE_CONCAT_FREE_HEADS = fused
+        if fused:
             out = fused_mlp.pointwise_conv_stack_multi(seq, srcs, with_mean=with_mean)
-        finally:
-            fused_mlp.USE_CONCAT_FREE_HEADS = saved
+        else:           # the reference form (ist_net.py:148-175): build the concatenation, run the stack on it
+            x = torch.cat(srcs, dim=1) if len(srcs) > 1 else srcs[0]
+            if with_mean:
+                x = torch.cat([x, x.mean(dim=2, keepdim=True).expand_as(x)], dim=1)
+            out = fused_mlp.pointwise_conv_stack(seq, x)
         (out * wgt).sum().backward()
         torch.cuda.synchronize()
         res.append((out.detach(), [t.grad.clone() for t in srcs], [p.grad.clone() for p in seq.parameters()]))

@@ -46,9 +46,9 @@ def test_sa_fp_layer():
     np.testing.assert_allclose(out.detach().cpu().numpy(), z["fp_out"], **TOL)
     np.testing.assert_allclose(feat.grad.cpu().numpy(), z["grad_feat"], **TOL)
     for name, p in list(sa.named_parameters()) + list(fp.named_parameters()):
-        d_ = np.abs(p.grad.cpu().numpy() - z["gradp_" + name])
-        print("SLACK sa_fp", name, float(d_.max()), float((d_ / (np.abs(z["gradp_" + name]) + 1e-4)).max()))
-        np.testing.assert_allclose(p.grad.cpu().numpy(), z["gradp_" + name], rtol=1e-3, atol=1e-4, err_msg=name)
+        # measured (round 5): max |difference| 1.1e-8 on gradients of magnitude 1e-4 .. 1e-3 -- two fp32 evaluations; the
+        # float64 comparison below is the bar that counts
+        np.testing.assert_allclose(p.grad.cpu().numpy(), z["gradp_" + name], rtol=2e-4, atol=1e-7, err_msg=name)
     # the bar above compares two float32 evaluations (the golden is the reference's fp32 run).  Against a float64 evaluation
     # of the same modules with the same index decisions every parameter gradient holds 1e-4 of its own norm, except where a
     # max-pool candidate within round-off of the maximum re-routes a gradient (at most one layer may carry such a flip here)
@@ -71,8 +71,9 @@ def test_sa_fp_layer():
     assert rel(feat.grad, feat64.grad) < 1e-4
     errs = {n_: rel(p.grad, q.grad) for (n_, p), q in zip(list(sa.named_parameters()) + list(fp.named_parameters()),
                                                           list(sa64.parameters()) + list(fp64.parameters()))}
-    print("SLACK sa_fp f64", sorted(errs.values())[-3:])
-    assert sorted(errs.values())[-2] < 1e-4 and max(errs.values()) < 2e-3, errs
+    # measured (round 5): the three largest are 1.4e-6, 1.6e-6, 1.7e-5 -- no max-pool flip on this input, so the plain
+    # 1e-4 bar holds for every parameter (rounds 2-4 allowed one layer 2e-3 for a flip that this fixture does not have)
+    assert max(errs.values()) < 1e-4, errs
 
 
 def test_encoder_b2(monkeypatch):
@@ -124,19 +125,20 @@ def test_encoder_b2(monkeypatch):
     np.testing.assert_allclose(got, z["out_train_f64"], **TOL)
     np.testing.assert_allclose(got, z["out_train"], rtol=2e-4, atol=2e-4)
     out.square().mean().backward()
-    # Gradients of this loss are ill-conditioned end to end (torch-CPU vs torch-GPU composition already
-    # differ by ~0.3-1% on several parameters; the fused kernels are within ~1e-6 of an f64 reference
-    # layer by layer, see test_fused_mlp_gpu.py::test_fused_vs_float64), so the golden gradient norms
-    # are a wiring check with a loose tolerance; the 1e-4 bar applies to the forward features above.
+    # WIRING CHECK ONLY (every parameter receives a gradient of the right size): the golden is the reference's own fp32
+    # backward, and gradients of this loss through 16 train-mode BatchNorm layers are ill-conditioned end to end -- two valid
+    # fp32 evaluations (torch-CPU vs torch-GPU composition) already differ by 0.3-1 % on several parameters.  The accuracy
+    # bar for gradients is test_encoder_parameter_gradients_vs_float64_autograd below (every parameter gradient of the HIP
+    # path against float64 autograd with the same index decisions), not this comparison.
     norms = np.array([float(p.grad.double().norm()) for _, p in enc.named_parameters()])
-    print("SLACK encoder_b2 grad norms max rel", float(np.max(np.abs(norms - z["grad_norms"]) / np.maximum(z["grad_norms"], 1e-30))))
     np.testing.assert_allclose(norms, z["grad_norms"], rtol=3e-2, atol=1e-7)
     g = dict(enc.named_parameters())
-    for key, name in (("SA_modules.0.mlps.0.layer0.conv.weight", "grad_first_conv"),
-                      ("FP_modules.0.mlp.layer1.conv.weight", "grad_last_fp_conv")):
+    # measured (round 5) against the reference's fp32 gradients: 1.3e-5 for the last layer (one GEMM away from the loss),
+    # 3.4e-3 for the first convolution (the whole network away: the ill-conditioning described above)
+    for key, name, bound in (("SA_modules.0.mlps.0.layer0.conv.weight", "grad_first_conv", 1e-2),
+                             ("FP_modules.0.mlp.layer1.conv.weight", "grad_last_fp_conv", 1e-4)):
         got, want = g[key].grad.cpu().numpy(), z[name]
-        print("SLACK encoder_b2", key, float(np.linalg.norm(got - want) / np.linalg.norm(want)))
-        assert np.linalg.norm(got - want) / np.linalg.norm(want) < 3e-2, key
+        assert np.linalg.norm(got - want) / np.linalg.norm(want) < bound, key
     sd = enc.state_dict()
     np.testing.assert_allclose(sd["SA_modules.3.mlps.1.layer2.normlayer.bn.running_mean"].cpu().numpy(),
                                z["running_mean_sa3"], rtol=1e-4, atol=1e-6)

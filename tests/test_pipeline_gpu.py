@@ -101,7 +101,6 @@ def test_training_trajectory_matches_torch_composition(monkeypatch):
         if composed:     # every fusable-shape test answers "no": the modules run the reference composition with torch ops
             monkeypatch.setattr(fused_mlp, "_fusable", lambda *a, **k: False)
             monkeypatch.setattr(fused_mlp, "_fusable_shape", lambda *a, **k: False)
-            monkeypatch.setattr(fused_mlp, "USE_FUSED_FP", False)
         opt = torch.optim.Adam(model.parameters(), lr=1e-3)
         curve = []
         for _ in range(30):
@@ -144,12 +143,13 @@ def test_training_steps_are_bit_reproducible():
     assert torch.equal(a, b), float((a - b).abs().max())
 
 
-@pytest.mark.parametrize("switch", ["USE_DEFERRED_WGRAD", "USE_SCALE_STREAMS", "USE_FUSED_SMALL_BWD", "USE_FUSED_MID_BWD", "USE_POOLED_FINALIZE", "USE_DENSE_FINALIZE", "USE_INTERP_IN_EPILOGUE", "USE_FINALIZE_IN_SCATTER", "USE_FINALIZE_IN_TAIL", "USE_FP_RAW_DY", "USE_LAZY_FP", "USE_SPLIT_LAYER0", "USE_FP_SKIP_STREAM",
-                                    "USE_CSR_SCATTER", "USE_FUSED_FP", "USE_GEOMETRY_STREAM", "USE_FPS_CHAIN", "USE_FUSED_NN_WEIGHTS", "COMPACT_LEVELS=", "COMPACT_LEVELS=0,1,2"])
+@pytest.mark.parametrize("switch", ["USE_DEFERRED_WGRAD", "USE_SCALE_STREAMS", "USE_CSR_SCATTER", "USE_GEOMETRY_STREAM",
+                                    "COMPACT_LEVELS=", "COMPACT_LEVELS=0,1,2"])
 def test_fallback_paths_agree_with_default(switch):
-    """Every module-level switch of the fused path selects code that a caller can reach (fallbacks and measured
-    alternatives): one encoder training step with the switch flipped gives the output and the parameter gradients of
-    the default configuration (fp32 round-off apart)."""
+    """The switches that are left (round 5 pruned the ones whose off-state was a superseded variant) each select a
+    SUPPORTED alternative -- side streams off beside the RGB branch, atomic instead of list-driven scatter, no geometry stream,
+    other compact-column levels: one encoder training step with the switch flipped gives the output and the parameter
+    gradients of the default configuration (fp32 round-off apart)."""
     import istnet_amd.modules as enc_mod
     from istnet_amd.modules import PointNet2MSG
     from istnet_amd.pointnet2 import fused_mlp
@@ -167,8 +167,7 @@ def test_fallback_paths_agree_with_default(switch):
 
     base_out, base_grads = run()
     name, _, val = switch.partition("=")
-    from istnet_amd.pointnet2 import pointnet2_modules
-    owner = {"USE_GEOMETRY_STREAM": enc_mod, "USE_FPS_CHAIN": enc_mod, "USE_FUSED_NN_WEIGHTS": pointnet2_modules}.get(name, fused_mlp)
+    owner = {"USE_GEOMETRY_STREAM": enc_mod}.get(name, fused_mlp)
     saved = getattr(owner, name)
     try:
         setattr(owner, name, frozenset(int(v) for v in val.split(",") if v) if name == "COMPACT_LEVELS" else False)
@@ -346,7 +345,6 @@ def test_captured_step_follows_bn_momentum_schedule(monkeypatch):
 
     monkeypatch.setattr(fused_mlp, "_fusable", lambda *a, **k: False)          # torch's Conv2d / BatchNorm2d / ReLU
     monkeypatch.setattr(fused_mlp, "_fusable_shape", lambda *a, **k: False)
-    monkeypatch.setattr(fused_mlp, "USE_FUSED_FP", False)
 
     def run_torch(net, momenta):
         for m in momenta:
@@ -400,34 +398,3 @@ def test_momentum_change_inside_capture_is_refused():
     torch.cuda.synchronize()
 
 
-@pytest.mark.parametrize("switch", ["USE_FINALIZE_IN_TAIL", "USE_FP_RAW_DY", "USE_LAZY_FP"])
-def test_chain_shortening_fusions_are_bit_identical(switch):
-    """Round 4 took three launches per level off the dependent chain without touching the arithmetic: the last BatchNorm
-    finalize of a stack runs inside its pool / apply launch, the feature-propagation backward gathers dY0 from the raw
-    pair instead of a materialised tensor, and levels 3..1 of the feature propagation hand their RAW output + constants
-    to the next level's loaders.  Each must reproduce the unfused step bit for bit: output, every parameter gradient and
-    every BatchNorm buffer after one training step."""
-    from istnet_amd.pointnet2 import fused_mlp
-    g = torch.Generator().manual_seed(17)
-    d = torch.randn(3, 1024, 3, generator=g)
-    pts = (d / d.norm(dim=2, keepdim=True) * 0.1 + torch.randn(3, 1024, 3, generator=g) * 0.002).to(DEV)
-
-    def run():
-        torch.manual_seed(8)
-        enc = PointNet2MSG(CAM).to(DEV).train()
-        out = enc(pts)
-        (out * torch.linspace(-1, 1, out.shape[2], device=DEV)).sum().backward()
-        torch.cuda.synchronize()
-        return out.detach().clone(), [p.grad.clone() for p in enc.parameters()], [b.clone() for b in enc.buffers()]
-
-    base = run()
-    saved = getattr(fused_mlp, switch)
-    try:
-        setattr(fused_mlp, switch, False)
-        other = run()
-    finally:
-        setattr(fused_mlp, switch, saved)
-    assert saved is True
-    assert torch.equal(base[0], other[0])
-    for a, b in zip(base[1] + base[2], other[1] + other[2]):
-        assert torch.equal(a, b)

@@ -89,14 +89,14 @@ def test_native_decoder_backward_equals_framework_backward():
     x = torch.randn(2, 3, 64, 64, device=DEV).contiguous(memory_format=torch.channels_last)
     grads = []
     for native in (True, False):
-        rgb_branch.USE_NATIVE_DECODER_BACKWARD = native
+        rgb_branch.USE_FUSED = native
         try:
             net.zero_grad(set_to_none=True)
             out = net(x)
             out.square().mean().backward()
             grads.append((out.detach().clone(), {k: p.grad.clone() for k, p in net.named_parameters() if p.grad is not None}))   # (avgpool / fc of the trunk are unused)
         finally:
-            rgb_branch.USE_NATIVE_DECODER_BACKWARD = True
+            rgb_branch.USE_FUSED = True
     # budget (profiles/r04_rgb_gradient_budget.txt, tools/rgb_gradient_budget.py): output native vs framework 4.9e-6 relative,
     # the framework against its own rerun 4.0e-6
     assert float((grads[0][0] - grads[1][0]).norm() / grads[1][0].norm()) < 1e-4
@@ -125,8 +125,8 @@ def test_pyramid_module_linear_form_matches_the_reference_composition(b, c, cout
     dy = torch.randn(b, cout, h, h, device=DEV).contiguous(memory_format=torch.channels_last)
 
     def run(flag):
-        old = rgb_branch.USE_PSP_LINEAR_FUSION
-        rgb_branch.USE_PSP_LINEAR_FUSION = flag
+        old = rgb_branch.USE_FUSED
+        rgb_branch.USE_FUSED = flag
         try:
             mod.zero_grad(set_to_none=True)
             xi = x.clone(memory_format=torch.preserve_format).requires_grad_(True)
@@ -135,7 +135,7 @@ def test_pyramid_module_linear_form_matches_the_reference_composition(b, c, cout
             y.backward(dy)
             return y.detach(), xi.grad, [p.grad.clone() for p in mod.parameters()]
         finally:
-            rgb_branch.USE_PSP_LINEAR_FUSION = old
+            rgb_branch.USE_FUSED = old
 
     y1, g1, p1 = run(True)
     y0, g0, p0 = run(False)
@@ -158,8 +158,8 @@ def test_upsample_conv_split_matches_the_full_size_convolution(b, cin, cout, h, 
     dy = torch.randn(b, cout, 2 * h, 2 * w, device=DEV).contiguous(memory_format=torch.channels_last)
 
     def run(flag):
-        old = rgb_branch.USE_UPCONV_SPLIT
-        rgb_branch.USE_UPCONV_SPLIT = flag
+        old = rgb_branch.USE_FUSED
+        rgb_branch.USE_FUSED = flag
         try:
             mod.zero_grad(set_to_none=True)
             xi = x.clone(memory_format=torch.preserve_format).requires_grad_(True)
@@ -167,7 +167,7 @@ def test_upsample_conv_split_matches_the_full_size_convolution(b, cin, cout, h, 
             y.backward(dy)
             return y.detach(), xi.grad, {n: p.grad.clone() for n, p in mod.named_parameters()}
         finally:
-            rgb_branch.USE_UPCONV_SPLIT = old
+            rgb_branch.USE_FUSED = old
 
     y1, g1, p1 = run(True)
     y0, g0, p0 = run(False)
@@ -308,8 +308,8 @@ def test_extractor_training_forward_with_choose_equals_dense_then_gather():
     dy = torch.randn(2, 128, 200, device=DEV)
 
     def run(flag):
-        old = rgb_branch.USE_TRAIN_GATHER_FIRST
-        rgb_branch.USE_TRAIN_GATHER_FIRST = flag
+        old = rgb_branch.USE_FUSED
+        rgb_branch.USE_FUSED = flag
         try:
             net.zero_grad(set_to_none=True)
             torch.manual_seed(7)                                            # the Dropout2d masks
@@ -318,7 +318,7 @@ def test_extractor_training_forward_with_choose_equals_dense_then_gather():
             grads = {n: p.grad.clone() for n, p in net.named_parameters() if p.grad is not None}
             return y.detach(), grads
         finally:
-            rgb_branch.USE_TRAIN_GATHER_FIRST = old
+            rgb_branch.USE_FUSED = old
 
     y1, g1 = run(True)
     y0, g0 = run(False)
@@ -373,7 +373,7 @@ def test_decoder_stage_tail_as_one_node(b, cout, h, w, with_mask):
 def test_downsample_batchnorm_of_a_basic_block_takes_the_fused_passes():
     """BasicBlock with a downsample branch (conv1x1 stride 2 -> BatchNorm2d, reference model/resnet.py:139-143): the branch's
     BatchNorm runs through the two NHWC passes with slope 1 (identity activation); output, running statistics and
-    gradients against the framework's modules (rgb_branch.USE_FUSED_TRUNK_NORM off)."""
+    gradients against the framework's modules (rgb_branch.USE_FUSED off)."""
     from istnet_amd import rgb_branch
     torch.manual_seed(3)
     ds = torch.nn.Sequential(torch.nn.Conv2d(64, 128, 1, stride=2, bias=False), torch.nn.BatchNorm2d(128))
@@ -382,8 +382,8 @@ def test_downsample_batchnorm_of_a_basic_block_takes_the_fused_passes():
     wgt = torch.randn(4, 128, 12, 12, device=DEV)
 
     def run(flag):
-        old = rgb_branch.USE_FUSED_TRUNK_NORM
-        rgb_branch.USE_FUSED_TRUNK_NORM = flag
+        old = rgb_branch.USE_FUSED
+        rgb_branch.USE_FUSED = flag
         try:
             blk.zero_grad(set_to_none=True)
             for m in blk.modules():
@@ -396,7 +396,7 @@ def test_downsample_batchnorm_of_a_basic_block_takes_the_fused_passes():
             return (out.detach(), xx.grad, {n: p.grad.clone() for n, p in blk.named_parameters()},
                     ds[1].running_mean.clone(), ds[1].running_var.clone())
         finally:
-            rgb_branch.USE_FUSED_TRUNK_NORM = old
+            rgb_branch.USE_FUSED = old
 
     f, r = run(True), run(False)
     rel = lambda a, c_: float((a - c_).abs().max() / (c_.abs().max() + 1e-30))
@@ -469,18 +469,18 @@ def test_fused_trunk_batchnorm_relu_of_a_basic_block(inplanes, planes, stride, h
     x = torch.randn(3, inplanes, h, h, device=DEV).contiguous(memory_format=torch.channels_last)
     wgt = torch.randn(3, planes, (h - 1) // stride + 1, (h - 1) // stride + 1, device=DEV)
     xx = x.clone().requires_grad_(True)
-    assert rgb_branch.USE_FUSED_TRUNK_NORM
+    assert rgb_branch.USE_FUSED
     out = blk(xx)
     assert type(out.grad_fn).__name__ == "_BnReluFnBackward"
     (out * wgt).sum().backward()
-    saved = rgb_branch.USE_FUSED_TRUNK_NORM
-    rgb_branch.USE_FUSED_TRUNK_NORM = False
+    saved = rgb_branch.USE_FUSED
+    rgb_branch.USE_FUSED = False
     try:
         x64 = x.double().clone().requires_grad_(True)
         out64 = ref(x64)
         (out64 * wgt.double()).sum().backward()
     finally:
-        rgb_branch.USE_FUSED_TRUNK_NORM = saved
+        rgb_branch.USE_FUSED = saved
     rel = lambda a, c_: float((a.double() - c_).abs().max() / (c_.abs().max() + 1e-30))
     assert rel(out.detach(), out64.detach()) < 1e-5
     assert rel(xx.grad, x64.grad) < 1e-4
@@ -521,10 +521,10 @@ def test_gram64_and_rowmix64_against_float64(rows):
     want = (ud @ a.double().t() + c0.double())
     torch.testing.assert_close(out.double(), want, rtol=1e-5, atol=1e-5)
     # the slice-product fallback agrees with the native pass
-    rgb_branch.USE_NATIVE_MOMENTS = False
+    rgb_branch.USE_FUSED = False
     try:
         f1, f2 = rgb_branch._moments(u)
     finally:
-        rgb_branch.USE_NATIVE_MOMENTS = True
+        rgb_branch.USE_FUSED = True
     torch.testing.assert_close(f1.double(), s1, rtol=1e-5, atol=1e-4 * rows ** 0.5)
     torch.testing.assert_close(f2.double(), s2, rtol=1e-5, atol=1e-4 * rows ** 0.5)

@@ -37,7 +37,7 @@ def ref_style_step(model, opt):
 from istnet_amd import graphed
 for auto, streams in ((True, True), (False, True), (False, False)):
     graphed.ENABLED = auto
-    fused_mlp.USE_SCALE_STREAMS = fused_mlp.USE_SCALE_STREAMS_BWD = fused_mlp.USE_DEFERRED_WGRAD = streams
+    fused_mlp.USE_SCALE_STREAMS = fused_mlp.USE_DEFERRED_WGRAD = streams
     for name, mk in (("torch.optim.Adam", lambda m: torch.optim.Adam(m.parameters(), lr=1e-4)),
                      ("torch.optim.Adam(fused)", lambda m: torch.optim.Adam(m.parameters(), lr=1e-4, fused=True)),
                      ("FlatAdam", lambda m: FlatAdam(m.parameters(), lr=1e-4, adjacent=layout_hints(m)))):
@@ -48,7 +48,7 @@ for auto, streams in ((True, True), (False, True), (False, False)):
 
 graphed.ENABLED = False
 if "--profile" in sys.argv:
-    fused_mlp.USE_SCALE_STREAMS = fused_mlp.USE_SCALE_STREAMS_BWD = fused_mlp.USE_DEFERRED_WGRAD = True
+    fused_mlp.USE_SCALE_STREAMS = fused_mlp.USE_DEFERRED_WGRAD = True
     model = bench.make_model(dev)
     opt = FlatAdam(model.parameters(), lr=1e-4, adjacent=layout_hints(model))
     step = ref_style_step(model, opt)

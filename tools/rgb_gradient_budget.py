@@ -3,7 +3,7 @@ differences between the native decoder backward and the framework's come from?
 
 For every parameter gradient, relative L2 distance to a FLOAT64 evaluation of the same module (the arithmetic truth) of
     native   this package's path (fused decoder kernels, native backward)
-    torch    the framework's composition of the same modules (USE_NATIVE_DECODER_BACKWARD = USE_FUSED_*_NORM = False)
+    torch    the framework's composition of the same modules (rgb_branch.USE_FUSED = False)
     rerun    the SAME framework path run twice: its own run-to-run spread (MIOpen picks algorithms per call; atomics)
 and the direct distance native <-> torch that tests/test_rgb_ops_gpu.py bounds.
 
@@ -18,7 +18,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from istnet_amd import rgb_branch  # noqa: E402
 
 DEV = "cuda:0"
-SWITCHES = ("USE_NATIVE_DECODER_BACKWARD", "USE_FUSED_DECODER_NORM", "USE_FUSED_TRUNK_NORM")
+SWITCHES = ("USE_FUSED",)
 
 
 def build(double=False):
