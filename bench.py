@@ -264,6 +264,186 @@ def measure_eager(dev, workload="encoder", steps=30, warmup=8):
     return out
 
 
+def synthetic_frames(b, n, seed, device):
+    """What the reference's Dataset reads from disk for ``b`` instances (provider/dataset.py:162-200, 333-390), synthetic and
+    resident in HBM: raw 480 x 640 depth in millimetres (a slanted plane, 10 % dropouts, holes, an empty band on top), the
+    BGR colour image, one detection box per instance and the ``choose`` list -- the flat crop indices of n mask pixels,
+    which the reference draws on the host with np.random.choice (the mask test and the draw stay with the caller)."""
+    from istnet_amd import preprocess
+    g = torch.Generator().manual_seed(7000 + seed)
+    yy, xx = torch.meshgrid(torch.arange(480.0), torch.arange(640.0), indexing="ij")
+    depth = 500.0 + 1500.0 * yy / 480 + 400.0 * xx / 640 + torch.randn(b, 480, 640, generator=g) * 4
+    depth[torch.rand(b, 480, 640, generator=g) < 0.10] = 0
+    for i in range(b):
+        for _ in range(6):
+            r, c, sz = (int(torch.randint(20, 440, (1,), generator=g)), int(torch.randint(0, 600, (1,), generator=g)),
+                        int(torch.randint(4, 20, (1,), generator=g)))
+            depth[i, r:r + sz, c:c + sz] = 0
+    depth[:, :9] = 0
+    depth = depth.clamp(0, 65535).to(torch.int32).to(torch.int16)
+    image = torch.randint(0, 256, (b, 480, 640, 3), generator=g, dtype=torch.uint8)
+    side = torch.randint(40, 300, (b,), generator=g)
+    y1 = (torch.rand(b, generator=g) * (480 - side)).long()
+    x1 = (torch.rand(b, generator=g) * (640 - side)).long()
+    boxes = torch.stack([y1, x1, y1 + side, x1 + side], 1)
+    win = preprocess.get_bbox(boxes)
+    crop = (win[:, 1] - win[:, 0]).long()
+    choose = (torch.rand(b, n, generator=g) * (crop * crop).unsqueeze(1)).long()
+    return {k: v.to(device) for k, v in dict(depth=depth, image=image, boxes=boxes, choose=choose).items()}
+
+
+def preprocess_batch(frames, labels, train, generator):
+    """The tensor arithmetic of ``__getitem__`` for a whole batch on the device (provider/dataset.py:162-296
+    for training, :333-433 for testing): depth completion, crop window, RGB crop + resize + normalise, back-projection of the
+    chosen pixels + ``choose`` remap, sensor jitter, pose labels, shape augmentation.  Returns the network's input dict."""
+    from istnet_amd import preprocess
+    depth = preprocess.fill_missing(frames["depth"], 1000.0, 1)
+    win = preprocess.get_bbox(frames["boxes"])
+    rgb = preprocess.crop_resize_normalize(frames["image"], win, 192)
+    pts, choose = preprocess.backproject_choose(depth, win, frames["choose"])
+    out = {"rgb": rgb.contiguous(memory_format=torch.channels_last), "pts": pts, "choose": choose,
+           "category_label": labels["category_label"]}
+    if train:
+        b = pts.shape[0]
+        pts = preprocess.jitter_points(pts, generator=generator)
+        sym = labels["category_label"].reshape(-1) < 3            # bottle / bowl / can stand-ins: y-symmetric classes
+        rot, size, qo, _ = preprocess.instance_labels(pts, labels["translation"], labels["rotation"], labels["scale"],
+                                                      labels["sizes"], sym)
+        bb, rt_t, rt_r = preprocess.generate_aug_parameters(b, device=pts.device, generator=generator)
+        sym_info = torch.stack([sym.long()] + [torch.zeros_like(sym, dtype=torch.long)] * 3, 1)
+        pts, rot, trans, size, _, qo = preprocess.data_augment(
+            preprocess.AUG_PROBS_DEFAULT, pts, rot.float(), labels["translation"], size, sym_info, bb, rt_t, rt_r,
+            labels["model"], qo.float(), labels["category_label"].reshape(-1), generator=generator)
+        out.update(pts=pts, qo=qo, rotation_label=rot, translation_label=trans, size_label=size)
+    return out
+
+
+def run_pipeline(args, dev):
+    """``--workload pipeline`` / ``pipeline_infer``: the config-3 training step (or the config-5 inference batch) WITH the
+    device-side input preparation in front of it, every step on fresh raw frames that are resident in HBM.  Reports the
+    whole step, the preparation alone and its share."""
+    train = args.workload == "pipeline"
+    b, n = (BATCH, NPOINTS) if train else (64, 2048)
+    from istnet_amd import postprocess
+    from istnet_amd.ist_net import point_branch_side_streams
+    from istnet_amd.optim import FlatAdam, layout_hints
+    point_branch_side_streams(False)
+    net = make_istnet(dev, seed=0)
+    gen = torch.Generator().manual_seed(11)
+    frames = [synthetic_frames(b, n, s, dev) for s in (0, 1)]
+    g = torch.Generator().manual_seed(12)
+    rot = torch.linalg.qr(torch.randn(b, 3, 3, generator=g))[0]
+    labels = {k: v.to(dev) for k, v in dict(
+        category_label=torch.randint(0, 6, (b, 1), generator=g), rotation=rot,
+        translation=torch.tensor([0.0, 0.0, 1.2]) + torch.randn(b, 3, generator=g) * 0.05, scale=torch.rand(b, generator=g) * 0.3 + 0.1,
+        sizes=torch.rand(b, 3, generator=g) * 0.5 + 0.5, model=torch.rand(b, 1024, 3, generator=g) - 0.5).items()}
+    static = preprocess_batch(frames[0], labels, train, gen)          # the tensors the captured step reads
+    static = {k: v.clone(memory_format=torch.preserve_format) for k, v in static.items()}
+    if train:
+        opt = FlatAdam(net.parameters(), lr=1e-4, adjacent=layout_hints(net))
+        model_step = make_graphed_step(make_istnet_fwd_bwd(net, static), opt, 1)
+    else:
+        net.eval()
+
+        def model_step():
+            with torch.no_grad():
+                ep = net(static)
+                rts, scales = postprocess.assemble_pred_RTs(ep["pred_rotation"], ep["pred_translation"], ep["pred_size"])
+                return rts.cpu(), scales.cpu()
+    # The preparation is a fixed-shape sequence of ~200 small launches (most of them the batched tensor expressions of
+    # data_augment): issued from Python it is host-bound (4.1 ms at B = 32, profiles/r05_preproc_stages.txt), so it is captured
+    # into HIP graphs once per frame set, like the model step.  Random draws come from the device's default generator, which
+    # torch advances correctly across replays.
+    staged = [None, None]
+    prep_graphs = []
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for i in (0, 1):
+            for _ in range(2):
+                preprocess_batch(frames[i], labels, train, None)
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    for i in (0, 1):
+        gr = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(gr):
+            staged[i] = preprocess_batch(frames[i], labels, train, None)
+        prep_graphs.append(gr)
+    count = [0]
+    prep_stream = torch.cuda.Stream()
+
+    def load(i):
+        for k, v in staged[i].items():
+            static[k].copy_(v)
+
+    def prep():                       # preparation alone (replay + hand-over to the model's static inputs)
+        i = count[0] % 2
+        count[0] += 1
+        prep_graphs[i].replay()
+        load(i)
+
+    def step():                       # serial: prepare this step's batch, then train on it
+        prep()
+        return model_step()
+
+    def step_overlapped():            # loader-style: batch t+1 is prepared on a side stream while step t trains
+        i = count[0] % 2
+        count[0] += 1
+        main = torch.cuda.current_stream()
+        main.wait_stream(prep_stream)             # batch t is ready (prepared during step t-1)
+        load(i)
+        prep_stream.wait_stream(main)             # its staging buffers may be overwritten from here on
+        with torch.cuda.stream(prep_stream):
+            prep_graphs[1 - i].replay()
+        return model_step()
+
+    def timed(fn, steps):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / steps
+    for _ in range(args.warmup):
+        step()
+    n_windows = args.windows if args.windows > 0 else (5 if args.steps <= 20 else 1)
+    serial = sorted(timed(step, args.steps) for _ in range(n_windows))
+    dt_serial = serial[len(serial) // 2]
+    dt_prep = sorted(timed(prep, args.steps) for _ in range(3))[1]
+    dt_model = sorted(timed(model_step, args.steps) for _ in range(3))[1]
+    with torch.cuda.stream(prep_stream):
+        prep_graphs[count[0] % 2].replay()            # pipeline prologue
+    for _ in range(3):
+        step_overlapped()
+    windows = sorted(timed(step_overlapped, args.steps) for _ in range(n_windows))
+    dt_overlapped = windows[len(windows) // 2]
+    # the reported step is the faster arrangement: beside the training step's convolutions the side-stream preparation
+    # costs MORE than in line (its stencil kernels and the trunk compete for the same CUs); beside the inference forward less
+    mode = "overlapped" if dt_overlapped < dt_serial else "serial"
+    dt, windows = (dt_overlapped, windows) if mode == "overlapped" else (dt_serial, serial)
+    return {"metric": ("point-clouds/sec fwd+bwd incl. input preparation, B=32 N=1024" if train else
+                       "instances/sec inference incl. input preparation, B=64 N=2048"),
+            "value": b / dt, "unit": "clouds/s" if train else "instances/s", "n_gpus": 1, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": dt * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "windows_ms_per_step": [round(w * 1e3, 4) for w in windows],
+            "config": {"workload": ("raw 480x640 depth + BGR frames resident in HBM -> fill_missing -> get_bbox -> crop / resize / "
+                                    "normalise -> back-projection + choose remap"
+                                    + (" -> jitter -> pose labels -> data_augment -> IST-Net training step (config 3, HIP graph)"
+                                       if train else " -> IST-Net eval forward + pose post-processing + copy to the host (config 5)")),
+                       "batch_per_gpu": b, "npoints": n, "global_batch": b, "parallelism": "dp1",
+                       "launch": ("preparation: HIP graph replay, " + ("on a side stream one batch ahead (loader-style)" if mode == "overlapped"
+                                                                           else "in line before the model step")
+                                  + "; model step: " + ("HIP graph replay" if train else "eager forward"))},
+            "preparation": {"ms_per_step_alone": dt_prep * 1e3, "model_step_alone_ms": dt_model * 1e3,
+                            "serial_ms_per_step": dt_serial * 1e3, "share_of_serial_step": dt_prep / dt_serial,
+                            "overlapped_ms_per_step": dt_overlapped * 1e3,
+                            "overlapped_cost_share": (dt_overlapped - dt_model) / dt_overlapped, "reported": mode,
+                            "note": "every step runs on fresh frames.  serial_*: prepare, then the model step, same stream; "
+                                    "overlapped_*: batch t+1 prepared on a side stream during step t; *_alone: each part by "
+                                    "itself; value / ms_per_step = the faster of the two arrangements (`reported`)"}}
+
+
 def run_inference(args, dev, world, rank, dist):
     """``--workload infer`` (BASELINE configs[4] / SURVEY 8d config 5): eval-mode IST-Net, B=64 instances of
     N=2048 points + 192x192 crops per step; one step = the forward pass, the post-processing of test_func
@@ -547,7 +727,7 @@ def main():
                     help="(the default since round 3; kept for old command lines) captured step, buckets after the replay")
     ap.add_argument("--no-prefetch", action="store_true",
                     help="encoder workload: one batch, geometry inside the step (no next-batch geometry prefetch)")
-    ap.add_argument("--workload", default="encoder", choices=["encoder", "istnet", "infer", "sa_layer"],
+    ap.add_argument("--workload", default="encoder", choices=["encoder", "istnet", "infer", "sa_layer", "pipeline", "pipeline_infer"],
                     help="encoder = BASELINE configs[1] (the headline metric); istnet = full model, configs[2]/[3]; "
                          "infer = eval-mode full model + post-processing, B=64 N=2048 (config 5); sa_layer = configs[0]: "
                          "one set-abstraction layer (ball_query r=0.2, nsample=32) on B=4 N=1024, GPU beside the CPU path")
@@ -633,7 +813,7 @@ def main():
             os.close(saved_fd)
 
     tuned_table = None
-    if args.workload in ("istnet", "infer") and not args.cpu_dry_run and not args.no_tuned_gemms:
+    if args.workload in ("istnet", "infer", "pipeline", "pipeline_infer") and not args.cpu_dry_run and not args.no_tuned_gemms:
         from istnet_amd import tuned_gemm
         if args.tune_gemms:
             os.makedirs("gpurun_out", exist_ok=True)
@@ -648,6 +828,11 @@ def main():
         if dist_on:
             raise SystemExit("--workload sa_layer is a single-GPU parity / timing case (BASELINE configs[0])")
         print(json.dumps(run_sa_layer(args, dev)), flush=True)
+        return
+    if args.workload in ("pipeline", "pipeline_infer"):
+        if dist_on:
+            raise SystemExit("--workload pipeline is a single-GPU measurement of the input preparation's share")
+        print(json.dumps(run_pipeline(args, dev)), flush=True)
         return
     if args.workload == "infer":
         result = run_inference(args, dev, world, rank, dist if dist_on else None)

@@ -121,18 +121,19 @@ def fill_missing(dpt, cam_scale, scale_2_80m, fill_type="multiscale", extrapolat
     if img.dim() != 3:
         raise ValueError("fill_missing: expected a depth image (h, w) or a batch (b, h, w)")
     if img.dtype in (torch.uint16, torch.int16):
-        img = img.view(torch.int16).to(torch.int32) & 0xffff            # raw millimetres, stored as 16-bit
-    # numpy evaluates dpt / cam_scale * scale_2_80m in float64 and fill_in_multiscale rounds to float32 once
-    depth = (img.to(torch.float64) / float(cam_scale) * float(scale_2_80m)).to(torch.float32).contiguous()
-    b, h, w = depth.shape
+        raw, is_float = img.contiguous(), 0                             # raw millimetres, 16-bit storage read as unsigned
+    else:
+        raw, is_float = img.to(torch.float32).contiguous(), 1
+    b, h, w = raw.shape
     lib = _native.lib()
-    scratch = torch.empty(lib.istnet_depth_fill_scratch_floats(b, h, w), dtype=torch.float32, device=depth.device)
-    out = torch.empty_like(depth)
-    with torch.cuda.device(depth.device):
-        _native.check(lib.istnet_depth_fill_multiscale(b, h, w, depth.data_ptr(), 3.0, scratch.data_ptr(), out.data_ptr(),
-                                                       torch.cuda.current_stream(depth.device).cuda_stream),
-                      "depth_fill_multiscale")
-    out = out / float(scale_2_80m) * float(cam_scale)
+    scratch = torch.empty(lib.istnet_depth_fill_scratch_floats(b, h, w), dtype=torch.float32, device=raw.device)
+    out = torch.empty((b, h, w), dtype=torch.float32, device=raw.device)
+    with torch.cuda.device(raw.device):
+        # numpy evaluates dpt / cam_scale * scale_2_80m in float64 and fill_in_multiscale rounds to float32 once; the result is
+        # scaled back in float32: both inside the kernels (include/istnet_preproc.h)
+        _native.check(lib.istnet_depth_fill_missing(b, h, w, raw.data_ptr(), is_float, float(cam_scale), float(scale_2_80m), 3.0,
+                                                    scratch.data_ptr(), out.data_ptr(),
+                                                    torch.cuda.current_stream(raw.device).cuda_stream), "depth_fill_missing")
     return out[0] if squeeze else out
 
 
@@ -165,6 +166,27 @@ def instance_labels(pts, translation, rotation, scale, sizes, symmetric):
     return rot_out, size, qo, srt
 
 
+_CONSTS = {}
+
+
+def _const(values, dtype, device):
+    """A small constant tensor on ``device``, uploaded once per (values, dtype, device): a host-to-device copy of pageable
+    memory per call is what keeps a sequence of tensor expressions from being captured in a HIP graph."""
+    key = (tuple(values), dtype, str(device))
+    t = _CONSTS.get(key)
+    if t is None:
+        t = _CONSTS[key] = torch.tensor(list(values), dtype=dtype, device=device)
+    return t
+
+
+def _draw(fn, shape, dtype, device, generator):
+    """Random numbers for ``device``: drawn THERE when no generator is given (the device's default generator: no host
+    work, no copy, capturable in a HIP graph) or when the generator lives there; a CPU generator (replayable draws, the
+    tests) draws on the host and copies."""
+    where = device if generator is None else generator.device
+    return fn(tuple(shape), generator=generator, dtype=dtype, device=where).to(device)
+
+
 AUG_PROBS_DEFAULT = (0.3, 0.3, 0.0, 0.0, 0.0)     # aug_bb_pro, aug_rt_pro, aug_bc_pro, aug_pc_pro, aug_nl_pro [ref config/ist_net_default.yaml:37-42]
 
 
@@ -174,12 +196,12 @@ def generate_aug_parameters(count, device="cpu", generator=None, s_x=(0.8, 1.2),
     to +-50 mm per axis (in metres) and a rotation (count, 3, 3) of up to +-15 degrees about each axis, R_z R_y R_x as
     data_augmentation.get_rotation (:8-25) composes it.  Drawn from ``generator`` (torch), not from numpy's global state."""
     import math
-    u = torch.rand(count, 9, generator=generator, dtype=torch.float64).to(device)
-    lo = torch.tensor([s_x[0], s_y[0], s_z[0]], dtype=torch.float64, device=device)
-    hi = torch.tensor([s_x[1], s_y[1], s_z[1]], dtype=torch.float64, device=device)
+    u = _draw(torch.rand, (count, 9), torch.float64, torch.device(device), generator)
+    lo = _const([s_x[0], s_y[0], s_z[0]], torch.float64, device)
+    hi = _const([s_x[1], s_y[1], s_z[1]], torch.float64, device)
     bb = (u[:, 0:3] * (hi - lo) + lo).to(torch.float32)
     ang = (u[:, 3:6] * 2 * a - a) / 180.0 * math.pi
-    lim = torch.tensor([ax, ay, az], dtype=torch.float64, device=device)
+    lim = _const([ax, ay, az], torch.float64, device)
     trans = ((u[:, 6:9] * 2 * lim - lim).to(torch.float32) / 1000.0)
     cx, cy, cz = torch.cos(ang).unbind(1)
     sx, sy, sz = torch.sin(ang).unbind(1)
@@ -223,12 +245,11 @@ def data_augment(probs, pts, rotation, translation, size, sym, aug_bb, aug_rt_t,
     b, n, _ = pts.shape
     obj = torch.as_tensor(obj_id, device=dev).reshape(-1).to(torch.int64)
     if draws is None:
-        draws = {"prop": torch.rand(b, 5, generator=generator).to(dev), "bc": torch.rand(b, 2, generator=generator).to(dev),
-                 "nl": torch.rand(b, 2, generator=generator).to(dev),
-                 "noise": torch.randn(b, n, 3, generator=generator).to(dev)}
+        draws = {"prop": _draw(torch.rand, (b, 5), f32, dev, generator), "bc": _draw(torch.rand, (b, 2), f32, dev, generator),
+                 "nl": _draw(torch.rand, (b, 2), f32, dev, generator), "noise": _draw(torch.randn, (b, n, 3), f32, dev, generator)}
     prop = draws["prop"].to(device=dev, dtype=f32)
-    take = prop < torch.tensor([float(p) for p in probs], dtype=f32, device=dev)
-    isin = lambda ids: (obj.unsqueeze(1) == torch.tensor(ids, device=dev)).any(1)
+    take = prop < _const([float(p) for p in probs], f32, dev)
+    isin = lambda ids: (obj.unsqueeze(1) == _const(ids, torch.int64, dev)).any(1)
     do_bb, do_rt, do_pc = take[:, 0], take[:, 1], take[:, 3]
     do_bc = take[:, 2] & isin([5, 1])
     do_nl = take[:, 4] & isin([0, 1, 2, 3, 5])
@@ -266,7 +287,7 @@ def data_augment(probs, pts, rotation, translation, size, sym, aug_bb, aug_rt_t,
     up, down = ub[:, 0:1] * (1.2 - 0.8) + 0.8, ub[:, 1:2] * (1.2 - 0.8) + 0.8
     reproj = (pts - trans.unsqueeze(1)) @ rot
     sy = size[:, 1:2]
-    xz = torch.tensor([True, False, True], device=dev)
+    xz = _const([True, False, True], torch.bool, dev)
     scale_by = lambda p, r: torch.where(xz, p * r.unsqueeze(2), p)
     pts_bc = scale_by(reproj, (reproj[:, :, 1] + sy / 2) / sy * (up - down) + down) @ rot.transpose(1, 2) + trans.unsqueeze(1)
     ns = size / norm(size).view(-1, 1)
@@ -311,5 +332,5 @@ def jitter_points(pts, noise=None, generator=None):
     float32 once (``torch.FloatTensor(pts)``, :225); so does this.  ``noise``: the standard normals, same shape as ``pts``
     (None: drawn from ``generator``)."""
     if noise is None:
-        noise = torch.randn(pts.shape, generator=generator, dtype=torch.float64).to(pts.device)
+        noise = _draw(torch.randn, pts.shape, torch.float64, pts.device, generator)
     return (pts.to(torch.float64) + (0.001 * noise.to(device=pts.device, dtype=torch.float64)).clamp(-0.005, 0.005)).to(torch.float32)

@@ -1,11 +1,11 @@
-mkdir -p gpurun_out/r5e
-python -m pytest tests -m gpu -q --timeout 900 > gpurun_out/r5e/gputests.txt 2>&1
-tail -12 gpurun_out/r5e/gputests.txt
-python bench.py --steps 20 --warmup 10 --no-cpu-baseline 2>gpurun_out/r5e/bench.err | tail -1 > gpurun_out/r5e/bench.json
-python bench.py --workload istnet --steps 10 --warmup 5 --no-eager-leg 2>/dev/null | tail -1 > gpurun_out/r5e/istnet.json
+mkdir -p gpurun_out/r5f
+python bench.py --workload pipeline --steps 10 --warmup 5 2>gpurun_out/r5f/pipe.err | tail -1 > gpurun_out/r5f/pipeline.json
+python bench.py --workload pipeline_infer --steps 10 --warmup 5 2>gpurun_out/r5f/pipei.err | tail -1 > gpurun_out/r5f/pipeline_infer.json
+tail -3 gpurun_out/r5f/pipe.err gpurun_out/r5f/pipei.err | grep -v amdgpu
 python - <<'PY'
 import json
-d=json.load(open('gpurun_out/r5e/bench.json'))
-print(d['ms_per_step'], d['windows_ms_per_step'], d['unpipelined']['ms_per_step'], {k:v['ms_per_step'] for k,v in d['eager'].items() if isinstance(v,dict)})
-d=json.load(open('gpurun_out/r5e/istnet.json')); print('istnet', d['ms_per_step'], d.get('windows_ms_per_step'))
+for f in ('pipeline','pipeline_infer'):
+    try:
+        d=json.load(open('gpurun_out/r5f/%s.json'%f)); print(f, d['ms_per_step'], d['value'], d['preparation'])
+    except Exception as e: print(f, 'FAILED', e)
 PY
