@@ -38,6 +38,13 @@ ISTNET_PN2_API int istnet_conv_wrw_splits(int b, int h, int w, int cin, int cout
 ISTNET_PN2_API int istnet_conv_backward_weights(int b, int h, int w, int cin, int cout, int kh, int kw, int stride, int pad,
                                                 const float *in, const float *dout, float *part, float *dwgt, void *stream);
 
+/* process-wide launch options.  key 1: arithmetic of istnet_conv_forward -- 0 (default) exact fp32 matrix cores
+ * (v_mfma_f32_32x32x2_f32); 1 split precision, an OPT-IN experiment: every fp32 operand is split exactly into three bf16
+ * terms and the product evaluated as six v_mfma_f32_32x32x16_bf16 products with fp32 accumulation (the dropped terms are
+ * <= 2^-24 relative: fp32-class accuracy at ~2.6x the fp32 matrix rate).  Returns 0, or ISTNET_PN2_EINVAL. */
+ISTNET_PN2_API int istnet_conv_set_tuning(int key, int value);
+ISTNET_PN2_API int istnet_conv_get_tuning(int key);
+
 #ifdef __cplusplus
 }
 #endif

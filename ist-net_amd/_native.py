@@ -55,6 +55,8 @@ SIGNATURES = {
     "istnet_crop_resize_normalize": [_i, _i, _i, _p, _l, _i, _p, _i, _p, _p, _p, _p, _p],
     "istnet_depth_fill_scratch_floats": [_i, _i, _i],
     "istnet_depth_fill_multiscale": [_i, _i, _i, _p, _f, _p, _p, _p],
+    "istnet_conv_set_tuning": [_i, _i],
+    "istnet_conv_get_tuning": [_i],
     "istnet_depth_fill_missing": [_i, _i, _i, _p, _i, _d, _d, _f, _p, _p, _p],
     "istnet_pn2_set_tuning": [_i, _i],
     "istnet_pn2_furthest_point_sampling": [_i, _i, _i, _p, _p, _p, _p],

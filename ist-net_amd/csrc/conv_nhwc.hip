@@ -294,6 +294,223 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 2) void conv_igemm_kernel
     }
 }
 
+// ============================================================================================
+// Split-precision forward (opt-in experiment, istnet_conv_set_tuning(1, 1); DESIGN.md "split precision").
+// Every fp32 operand is split EXACTLY into three bf16 terms x = hi + mid + lo (each takes the top 8 significand bits of what
+// is left: truncation, so the remainders are exact fp32 subtractions), and a.b is evaluated as the six products
+//   a_lo b_hi + a_hi b_lo + a_mid b_mid + a_mid b_hi + a_hi b_mid + a_hi b_hi
+// on v_mfma_f32_32x32x16_bf16 with fp32 accumulation.  Every bf16 x bf16 product is exact in fp32; the three dropped terms
+// (mid lo, lo mid, lo lo) are <= 2^-24 |a b| each -- the size of ONE fp32 rounding of the product.  The bf16 matrix pipe runs
+// 16x the fp32 one, so six products cost 6/16 of v_mfma_f32_32x32x2_f32: the roof moves from 157 to ~417 TFLOP/s.
+// Operands are split once, when a chunk goes from registers to LDS (three bf16 planes per operand tile, rows K-contiguous,
+// 80-byte pitch); a lane's MFMA fragment is one ds_read_b128 per plane.  128 x NT tiles, one workgroup per CU (120 KB of LDS).
+// ============================================================================================
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+constexpr int LDKH = KC + 8;          // bf16 elements per LDS row (80 bytes: 16-byte aligned, rows spread over the banks)
+
+struct Split3 { uint2 hi, mid, lo; };      // 4 consecutive k as packed bf16 pairs
+__device__ __forceinline__ Split3 split3(const float4& v) {
+  const unsigned x0 = __float_as_uint(v.x), x1 = __float_as_uint(v.y), x2 = __float_as_uint(v.z), x3 = __float_as_uint(v.w);
+  // remainders after the top 8 significand bits: exact (hi shares sign and exponent with x)
+  const float r0 = v.x - __uint_as_float(x0 & 0xffff0000u), r1 = v.y - __uint_as_float(x1 & 0xffff0000u);
+  const float r2 = v.z - __uint_as_float(x2 & 0xffff0000u), r3 = v.w - __uint_as_float(x3 & 0xffff0000u);
+  const unsigned m0 = __float_as_uint(r0), m1 = __float_as_uint(r1), m2 = __float_as_uint(r2), m3 = __float_as_uint(r3);
+  const float q0 = r0 - __uint_as_float(m0 & 0xffff0000u), q1 = r1 - __uint_as_float(m1 & 0xffff0000u);
+  const float q2 = r2 - __uint_as_float(m2 & 0xffff0000u), q3 = r3 - __uint_as_float(m3 & 0xffff0000u);
+  Split3 s;
+  // v_perm_b32: the upper halves of two dwords side by side (element k in the low half: little-endian bf16 order)
+  s.hi = make_uint2(__builtin_amdgcn_perm(x1, x0, 0x07060302u), __builtin_amdgcn_perm(x3, x2, 0x07060302u));
+  s.mid = make_uint2(__builtin_amdgcn_perm(m1, m0, 0x07060302u), __builtin_amdgcn_perm(m3, m2, 0x07060302u));
+  s.lo = make_uint2(__builtin_amdgcn_perm(__float_as_uint(q1), __float_as_uint(q0), 0x07060302u),
+                    __builtin_amdgcn_perm(__float_as_uint(q3), __float_as_uint(q2), 0x07060302u));
+  return s;
+}
+
+template <int NT, int STRIDE, int WM, bool INTERLEAVE>      // WM = 4: eight waves of 32 x NT/2;  WM = 2: four waves of 64 x NT/2
+__global__ __launch_bounds__(128 * WM, 1) void conv_igemm_split_kernel(ConvGeom g, const float* __restrict__ a_src,
+                                                                       const float* __restrict__ wgt, float* __restrict__ c_dst,
+                                                                       float* __restrict__ ws, int chunks_per_split, int nsplits,
+                                                                       int tile_m_first, int tile_m_count) {
+  constexpr int MT = 128, WN = 2, NTHR = 64 * WM * WN;
+  constexpr int TM = MT / (32 * WM), TN = NT / (32 * WN);
+  constexpr int RPP = NTHR / LPR;                       // tile rows per pass of the workgroup
+  constexpr int AR = MT / RPP, BR = NT / RPP;           // float4 per thread and operand
+  constexpr int A_PLANE = MT * LDKH, B_PLANE = NT * LDKH;               // bf16 elements
+  constexpr int STAGE = 3 * (A_PLANE + B_PLANE);
+  static_assert(AR >= 1 && AR <= 4 && BR >= 1 && BR <= 4 && TM >= 1 && TN >= 1, "128 x 128 or 128 x 64 tiles, 4 or 8 waves");
+  extern __shared__ __attribute__((aligned(16))) unsigned short smem_h[];       // [2][STAGE]
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int l31 = lane & 31, half = lane >> 5;
+  const int wm = wv / WN, wn = wv % WN;
+  const int taps = g.KH * g.KW;
+  const int Ka = g.Cin, Ncols = g.Cout;
+  const int MH = g.OH, MW = g.OW, SH = g.H, SW = g.W;
+  const long long M = (long long)g.B * MH * MW;
+  const int tiles_n = Ncols / NT;
+  const int xcd = blockIdx.x & 7, jj = blockIdx.x >> 3;                  // XCD-aware tile order: see conv_igemm_kernel
+  const int split = jj % nsplits, jt = jj / nsplits;
+  const int tile_local = (jt / tiles_n) * 8 + xcd;
+  if (tile_local >= tile_m_count) return;
+  const long long m0 = (long long)(tile_m_first + tile_local) * MT;
+  const int n0 = (jt % tiles_n) * NT;
+  const int acol = (tid % LPR) * 4;
+  int rb[AR], ry[AR], rx[AR];
+  unsigned rvalid = 0;
+#pragma unroll
+  for (int i = 0; i < AR; ++i) {
+    const long long pm = m0 + (tid / LPR) + RPP * i;
+    const long long pc = pm < M ? pm : M - 1;
+    const int b = (int)(pc / (MH * MW));
+    const int rem = (int)(pc - (long long)b * MH * MW);
+    ry[i] = rem / MW;
+    rx[i] = rem - ry[i] * MW;
+    rb[i] = b * SH;
+    rvalid |= (pm < M ? 1u : 0u) << i;
+  }
+  const int nb = Ka / KC;
+  const int c_first = split * chunks_per_split;
+  const int nchunks = min(chunks_per_split, taps * nb - c_first);
+  size_t aoff[AR];
+  unsigned tap_ok = 0;
+  auto set_tap = [&](int ky, int kx) {
+    tap_ok = 0;
+#pragma unroll
+    for (int i = 0; i < AR; ++i) {
+      const int sy = ry[i] * STRIDE + ky - g.pad, sx = rx[i] * STRIDE + kx - g.pad;
+      const bool ok = ((rvalid >> i) & 1u) && sy >= 0 && sy < SH && sx >= 0 && sx < SW;
+      aoff[i] = ((size_t)(rb[i] + clampi(sy, 0, SH - 1)) * SW + clampi(sx, 0, SW - 1)) * Ka + acol;
+      tap_ok |= (ok ? 1u : 0u) << i;
+    }
+  };
+  auto issue = [&](Stage& st, int ky, int kx, int cb) {
+    const int tap = ky * g.KW + kx;
+    st.ok = tap_ok;
+    static_for<AR>([&](auto ic) {
+      constexpr int i = decltype(ic)::value;
+      st_a<i>(st) = *reinterpret_cast<const float4*>(a_src + aoff[i] + (size_t)cb * KC);
+    });
+    static_for<BR>([&](auto ic) {
+      constexpr int i = decltype(ic)::value;
+      const int n = n0 + (tid / LPR) + RPP * i;
+      st_b<i>(st) = *reinterpret_cast<const float4*>(wgt + ((size_t)n * taps + tap) * g.Cin + (size_t)cb * KC + acol);
+    });
+  };
+  auto put = [&](unsigned short* plane0, int plane_elems, int row, const float4& v) {
+    const Split3 s = split3(v);
+    unsigned short* p = plane0 + row * LDKH + acol;
+    *reinterpret_cast<uint2*>(p) = s.hi;
+    *reinterpret_cast<uint2*>(p + plane_elems) = s.mid;
+    *reinterpret_cast<uint2*>(p + 2 * plane_elems) = s.lo;
+  };
+  auto commit = [&](Stage& st, int buf) {
+    unsigned short* as = smem_h + buf * STAGE;
+    unsigned short* bs = as + 3 * A_PLANE;
+    static_for<AR>([&](auto ic) {
+      constexpr int i = decltype(ic)::value;
+      put(as, A_PLANE, (tid / LPR) + RPP * i, keep_if((st.ok >> i) & 1u, st_a<i>(st)));
+    });
+    static_for<BR>([&](auto ic) {
+      constexpr int i = decltype(ic)::value;
+      put(bs, B_PLANE, (tid / LPR) + RPP * i, st_b<i>(st));
+    });
+  };
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < TN; ++ni)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+  auto mma = [&](int buf) {
+    const unsigned short* as = smem_h + buf * STAGE + ((wm * TM) * 32 + l31) * LDKH + 8 * half;
+    const unsigned short* bs = smem_h + buf * STAGE + 3 * A_PLANE + ((wn * TN) * 32 + l31) * LDKH + 8 * half;
+#pragma unroll
+    for (int g16 = 0; g16 < KC / 16; ++g16) {
+      bf16x8 ah[TM], am[TM], al[TM];
+#pragma unroll
+      for (int mi = 0; mi < TM; ++mi) {
+        const unsigned short* ap = as + mi * 32 * LDKH + 16 * g16;
+        ah[mi] = *reinterpret_cast<const bf16x8*>(ap);
+        am[mi] = *reinterpret_cast<const bf16x8*>(ap + A_PLANE);
+        al[mi] = *reinterpret_cast<const bf16x8*>(ap + 2 * A_PLANE);
+      }
+#pragma unroll
+      for (int ni = 0; ni < TN; ++ni) {
+        const unsigned short* bp = bs + ni * 32 * LDKH + 16 * g16;
+        const bf16x8 bh = *reinterpret_cast<const bf16x8*>(bp);
+        const bf16x8 bm = *reinterpret_cast<const bf16x8*>(bp + B_PLANE);
+        const bf16x8 bl = *reinterpret_cast<const bf16x8*>(bp + 2 * B_PLANE);
+#pragma unroll
+        for (int mi = 0; mi < TM; ++mi) {
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[mi], bh, acc[mi][ni], 0, 0, 0);
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mi], bl, acc[mi][ni], 0, 0, 0);
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am[mi], bm, acc[mi][ni], 0, 0, 0);
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am[mi], bh, acc[mi][ni], 0, 0, 0);
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mi], bm, acc[mi][ni], 0, 0, 0);
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mi], bh, acc[mi][ni], 0, 0, 0);
+        }
+      }
+    }
+  };
+  int ky = (c_first / nb) / g.KW, kx = (c_first / nb) % g.KW, cb = c_first % nb;
+  auto advance = [&]() {
+    if (++cb == nb) {
+      cb = 0;
+      if (++kx == g.KW) { kx = 0; ++ky; }
+      if (ky == g.KH) { ky = g.KH - 1; kx = g.KW - 1; cb = nb - 1; }
+      else set_tap(ky, kx);
+    }
+  };
+  set_tap(ky, kx);
+  // Two stages of registers in flight (a chunk's loads are issued two MFMA phases before they are split and written to LDS;
+  // four stages measured no gain: not bound by load latency), LDS double buffered, one barrier per chunk.  Past the end the
+  // prefetch repeats the last chunk (loaded, never read).
+  // mma(buf) and commit(next chunk -> buf ^ 1) are INDEPENDENT (the other buffer was last read before the previous barrier),
+  // and the waves of a workgroup are all in the same phase: as two blocks, the matrix pipe idles while every wave splits and
+  // the VALU idles while every wave multiplies.  INTERLEAVE puts them in one scheduling region and asks (group barriers) for
+  // one MFMA, then a few VALU / LDS instructions, and so on.
+  Stage sa, sb;
+  issue(sa, ky, kx, cb); advance();
+  commit(sa, 0);
+  issue(sa, ky, kx, cb); advance();       // chunk 1
+  __syncthreads();
+  auto body = [&](Stage& snew, Stage& scommit, int buf) {
+    issue(snew, ky, kx, cb); advance();
+    __builtin_amdgcn_sched_barrier(0);
+    mma(buf);
+    if (!INTERLEAVE) __builtin_amdgcn_sched_barrier(0);
+    commit(scommit, buf ^ 1);
+    if (INTERLEAVE) {
+#pragma unroll
+      for (int q = 0; q < 12 * TM * TN; ++q) {
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // DS read
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // MFMA
+        __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);   // VALU
+        __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);   // DS write
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    __syncthreads();
+  };
+  for (int c = 0; c < nchunks; c += 2) {
+    body(sb, sa, 0);                      // chunk c from buffer 0; chunk c + 1 -> buffer 1; loads of chunk c + 2
+    if (c + 1 >= nchunks) break;
+    body(sa, sb, 1);
+  }
+  const long long m_first = (long long)tile_m_first * MT;
+  float* dst = nsplits == 1 ? c_dst : ws + ((size_t)split * (M - m_first) - m_first) * Ncols;
+#pragma unroll
+  for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const long long row = m0 + (wm * TM + mi) * 32 + mfma_row(r, lane);
+      if (row < M) {
+#pragma unroll
+        for (int ni = 0; ni < TN; ++ni) dst[(size_t)row * Ncols + n0 + (wn * TN + ni) * 32 + l31] = acc[mi][ni][r];
+      }
+    }
+}
+
 // backward-weights: part[split][co][tap][ci] = sum over this split's output pixels of dout[p][co] * in[src(p, tap)][ci]
 // grid (splits, co tiles x ci tiles, taps)
 template <int MT, int NT, int WM, int WN, int STRIDE>
@@ -505,6 +722,7 @@ inline ConvGeom make_geom(int b, int h, int w, int cin, int cout, int kh, int kw
   g.OW = (w + 2 * pad - kw) / stride + 1;
   return g;
 }
+int g_conv_split = 0;      // istnet_conv_set_tuning(1, v): forward kernel arithmetic, 0 fp32 MFMA, 1..3 split-precision variants
 template <int MT, int NT, int MODE>
 constexpr size_t igemm_lds() {
   return (size_t)(2 * MT * LDK + 2 * (MODE == 0 ? NT * LDK : KC * (NT + 4))) * sizeof(float);
@@ -534,6 +752,14 @@ constexpr size_t wrw_lds() { return (size_t)(2 * KC * (MT + 4) + 2 * KC * (NT + 
 }  // namespace
 
 extern "C" {
+
+int istnet_conv_set_tuning(int key, int value) {
+  // key 1: forward kernel arithmetic -- 0 exact fp32 matrix cores (default); 1 split precision (three bf16 terms per operand,
+  // six bf16 MFMA products, fp32 accumulation: fp32-class accuracy, opt-in experiment); 2, 3: its A/B variants
+  if (key == 1) { if (value < 0 || value > 3) return ISTNET_PN2_EINVAL; g_conv_split = value; return 0; }
+  return ISTNET_PN2_EINVAL;
+}
+int istnet_conv_get_tuning(int key) { return key == 1 ? g_conv_split : -1; }
 
 int istnet_conv_supported(int cin, int cout, int kh, int kw, int stride, int pad) {
   return cin > 0 && cout > 0 && cin % 64 == 0 && cout % 64 == 0 && kh >= 1 && kh <= 7 && kh == kw &&
@@ -578,6 +804,22 @@ static IgemmPlan igemm_plan(const ConvGeom& g, int mode) {
   return p;
 }
 
+constexpr size_t kSplitLds128 = (size_t)2 * 3 * (128 + 128) * LDKH * sizeof(unsigned short);
+constexpr size_t kSplitLds64 = (size_t)2 * 3 * (128 + 64) * LDKH * sizeof(unsigned short);
+#define ISTNET_IGEMM_SPLIT_ONE(NT, STRIDE, LDS, WMV, IL)                                                               \
+  do {                                                                                                                 \
+    ISTNET_ALLOW_LDS((conv_igemm_split_kernel<NT, STRIDE, WMV, IL>), (LDS));                                           \
+    hipLaunchKernelGGL((conv_igemm_split_kernel<NT, STRIDE, WMV, IL>), dim3(grid), dim3(128 * WMV), (LDS),             \
+                       (hipStream_t)stream, g, a, wgt, c, ws, per, splits, first, count);                              \
+  } while (0)
+// variants (A/B): 1 = eight waves, MFMA and split interleaved; 2 = eight waves, two blocks; 3 = four waves, interleaved
+#define ISTNET_IGEMM_SPLIT(NT, STRIDE, LDS)                                                                            \
+  do {                                                                                                                 \
+    if (g_conv_split == 1) ISTNET_IGEMM_SPLIT_ONE(NT, STRIDE, LDS, 4, true);                                           \
+    else if (g_conv_split == 2) ISTNET_IGEMM_SPLIT_ONE(NT, STRIDE, LDS, 4, false);                                     \
+    else ISTNET_IGEMM_SPLIT_ONE(NT, STRIDE, LDS, 2, true);                                                             \
+  } while (0)
+
 #define ISTNET_IGEMM(MT, NT, WM, WN, MODE, STRIDE)                                                                     \
   do {                                                                                                                 \
     ISTNET_ALLOW_LDS((conv_igemm_kernel<MT, NT, WM, WN, MODE, STRIDE>), (igemm_lds<MT, NT, MODE>()));                 \
@@ -589,7 +831,10 @@ static void igemm_part(const ConvGeom& g, int mode, int nt, int first, int count
                        const float* wgt, float* c, float* ws, void* stream) {
   const int ncols = mode == 0 ? g.Cout : g.Cin;
   const unsigned grid = (unsigned)((count + 7) / 8 * 8 * (ncols / nt) * splits);
-  if (mode == 0) {
+  if (mode == 0 && g_conv_split) {
+    if (nt == 128) { if (g.stride == 1) ISTNET_IGEMM_SPLIT(128, 1, kSplitLds128); else ISTNET_IGEMM_SPLIT(128, 2, kSplitLds128); }
+    else { if (g.stride == 1) ISTNET_IGEMM_SPLIT(64, 1, kSplitLds64); else ISTNET_IGEMM_SPLIT(64, 2, kSplitLds64); }
+  } else if (mode == 0) {
     if (nt == 128) { if (g.stride == 1) ISTNET_IGEMM(128, 128, 2, 2, 0, 1); else ISTNET_IGEMM(128, 128, 2, 2, 0, 2); }
     else { if (g.stride == 1) ISTNET_IGEMM(128, 64, 4, 1, 0, 1); else ISTNET_IGEMM(128, 64, 4, 1, 0, 2); }
   } else {
@@ -598,6 +843,8 @@ static void igemm_part(const ConvGeom& g, int mode, int nt, int first, int count
   }
 }
 #undef ISTNET_IGEMM
+#undef ISTNET_IGEMM_SPLIT
+#undef ISTNET_IGEMM_SPLIT_ONE
 
 static int igemm_launch(const ConvGeom& g, int mode, const float* a, const float* wgt, float* c, float* ws, void* stream) {
   const IgemmPlan plan = igemm_plan(g, mode);
