@@ -511,6 +511,188 @@ __global__ __launch_bounds__(128 * WM, 1) void conv_igemm_split_kernel(ConvGeom 
     }
 }
 
+// ---- split precision, weights pre-split in global memory ("W" variant) ----
+// The first split kernel is bound by LDS traffic: three planes for BOTH operands are 208 KB of LDS reads + writes per 32-k
+// chunk against 1 536 matrix-pipe cycles.  The weights are the same for every pixel tile, so they are split ONCE per call by
+// split_weights_kernel into three bf16 planes in global memory (layout of wgt: [cout][tap][cin], rows K-contiguous), and
+// every wave loads its B fragments straight from there into registers in MFMA layout (one 16-byte load per plane, column and
+// 16-k group; the tile's weights are L2 / L1 resident and shared by the four row-waves of the workgroup), one chunk ahead.
+// Only the A operand (gathered pixels) goes through registers -> split -> LDS: a third of the LDS traffic, half of the VALU.
+__global__ __launch_bounds__(kThreads) void split_weights_kernel(long long n4, const float4* __restrict__ w,
+                                                                 uint2* __restrict__ hi, uint2* __restrict__ mid,
+                                                                 uint2* __restrict__ lo) {
+  const long long i = (long long)blockIdx.x * kThreads + threadIdx.x;
+  if (i >= n4) return;
+  const Split3 s = split3(w[i]);
+  hi[i] = s.hi; mid[i] = s.mid; lo[i] = s.lo;
+}
+
+struct BFrag { bf16x8 h, m, l; };
+
+template <int NT, int STRIDE>
+__global__ __launch_bounds__(512, 1) void conv_igemm_splitw_kernel(ConvGeom g, const float* __restrict__ a_src,
+                                                                   const unsigned short* __restrict__ wsplit, long long wplane,
+                                                                   float* __restrict__ c_dst, float* __restrict__ ws,
+                                                                   int chunks_per_split, int nsplits, int tile_m_first,
+                                                                   int tile_m_count) {
+  constexpr int MT = 128, WM = 4, WN = 2, NTHR = 512;
+  constexpr int TN = NT / (32 * WN);
+  constexpr int RPP = NTHR / LPR, AR = MT / RPP;        // 64 rows per pass, 2 float4 of A per thread
+  constexpr int A_PLANE = MT * LDKH, STAGE = 3 * A_PLANE;
+  constexpr int G16 = KC / 16;
+  static_assert(AR == 2 && TN >= 1 && TN <= 2, "128 x 128 or 128 x 64 tiles");
+  extern __shared__ __attribute__((aligned(16))) unsigned short smem_h[];       // [2][STAGE]
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int l31 = lane & 31, half = lane >> 5;
+  const int wm = wv / WN, wn = wv % WN;
+  (void)WM;
+  const int taps = g.KH * g.KW;
+  const int Ka = g.Cin, Ncols = g.Cout;
+  const int MH = g.OH, MW = g.OW, SH = g.H, SW = g.W;
+  const long long M = (long long)g.B * MH * MW;
+  const int tiles_n = Ncols / NT;
+  const int xcd = blockIdx.x & 7, jj = blockIdx.x >> 3;
+  const int split = jj % nsplits, jt = jj / nsplits;
+  const int tile_local = (jt / tiles_n) * 8 + xcd;
+  if (tile_local >= tile_m_count) return;
+  const long long m0 = (long long)(tile_m_first + tile_local) * MT;
+  const int n0 = (jt % tiles_n) * NT;
+  const int acol = (tid % LPR) * 4;
+  int rb[AR], ry[AR], rx[AR];
+  unsigned rvalid = 0;
+#pragma unroll
+  for (int i = 0; i < AR; ++i) {
+    const long long pm = m0 + (tid / LPR) + RPP * i;
+    const long long pc = pm < M ? pm : M - 1;
+    const int b = (int)(pc / (MH * MW));
+    const int rem = (int)(pc - (long long)b * MH * MW);
+    ry[i] = rem / MW;
+    rx[i] = rem - ry[i] * MW;
+    rb[i] = b * SH;
+    rvalid |= (pm < M ? 1u : 0u) << i;
+  }
+  const int nb = Ka / KC;
+  const int c_first = split * chunks_per_split;
+  const int nchunks = min(chunks_per_split, taps * nb - c_first);
+  size_t aoff[AR];
+  unsigned tap_ok = 0;
+  auto set_tap = [&](int ky, int kx) {
+    tap_ok = 0;
+#pragma unroll
+    for (int i = 0; i < AR; ++i) {
+      const int sy = ry[i] * STRIDE + ky - g.pad, sx = rx[i] * STRIDE + kx - g.pad;
+      const bool ok = ((rvalid >> i) & 1u) && sy >= 0 && sy < SH && sx >= 0 && sx < SW;
+      aoff[i] = ((size_t)(rb[i] + clampi(sy, 0, SH - 1)) * SW + clampi(sx, 0, SW - 1)) * Ka + acol;
+      tap_ok |= (ok ? 1u : 0u) << i;
+    }
+  };
+  // this lane's weight rows (output columns) in the pre-split planes: element offset of (column, tap 0, k = 8 half)
+  size_t wrow[TN];
+#pragma unroll
+  for (int ni = 0; ni < TN; ++ni) wrow[ni] = (size_t)(n0 + (wn * TN + ni) * 32 + l31) * taps * g.Cin + 8 * half;
+  struct AStage { float4 a0, a1; unsigned ok; };
+  auto issue_a = [&](AStage& st, int cb) {
+    st.ok = tap_ok;
+    st.a0 = *reinterpret_cast<const float4*>(a_src + aoff[0] + (size_t)cb * KC);
+    st.a1 = *reinterpret_cast<const float4*>(a_src + aoff[1] + (size_t)cb * KC);
+  };
+  auto issue_b = [&](BFrag (&bf)[TN][G16], int tap, int cb) {
+#pragma unroll
+    for (int ni = 0; ni < TN; ++ni)
+#pragma unroll
+      for (int q = 0; q < G16; ++q) {
+        const unsigned short* p = wsplit + wrow[ni] + (size_t)tap * g.Cin + (size_t)cb * KC + 16 * q;
+        bf[ni][q].h = *reinterpret_cast<const bf16x8*>(p);
+        bf[ni][q].m = *reinterpret_cast<const bf16x8*>(p + wplane);
+        bf[ni][q].l = *reinterpret_cast<const bf16x8*>(p + 2 * wplane);
+      }
+  };
+  auto put = [&](unsigned short* plane0, int row, const float4& v) {
+    const Split3 s = split3(v);
+    unsigned short* p = plane0 + row * LDKH + acol;
+    *reinterpret_cast<uint2*>(p) = s.hi;
+    *reinterpret_cast<uint2*>(p + A_PLANE) = s.mid;
+    *reinterpret_cast<uint2*>(p + 2 * A_PLANE) = s.lo;
+  };
+  auto commit = [&](AStage& st, int buf) {
+    unsigned short* as = smem_h + buf * STAGE;
+    put(as, (tid / LPR), keep_if(st.ok & 1u, st.a0));
+    put(as, (tid / LPR) + RPP, keep_if((st.ok >> 1) & 1u, st.a1));
+  };
+  f32x16 acc[TN];
+#pragma unroll
+  for (int ni = 0; ni < TN; ++ni)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[ni][r] = 0.f;
+  auto mma = [&](int buf, BFrag (&bf)[TN][G16]) {
+    const unsigned short* as = smem_h + buf * STAGE + (wm * 32 + l31) * LDKH + 8 * half;
+#pragma unroll
+    for (int q = 0; q < G16; ++q) {
+      const bf16x8 ah = *reinterpret_cast<const bf16x8*>(as + 16 * q);
+      const bf16x8 am = *reinterpret_cast<const bf16x8*>(as + A_PLANE + 16 * q);
+      const bf16x8 al = *reinterpret_cast<const bf16x8*>(as + 2 * A_PLANE + 16 * q);
+#pragma unroll
+      for (int ni = 0; ni < TN; ++ni) {
+        acc[ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bf[ni][q].h, acc[ni], 0, 0, 0);
+        acc[ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bf[ni][q].l, acc[ni], 0, 0, 0);
+        acc[ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bf[ni][q].m, acc[ni], 0, 0, 0);
+        acc[ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bf[ni][q].h, acc[ni], 0, 0, 0);
+        acc[ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bf[ni][q].m, acc[ni], 0, 0, 0);
+        acc[ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bf[ni][q].h, acc[ni], 0, 0, 0);
+      }
+    }
+  };
+  int ky = (c_first / nb) / g.KW, kx = (c_first / nb) % g.KW, cb = c_first % nb;
+  auto advance = [&]() {
+    if (++cb == nb) {
+      cb = 0;
+      if (++kx == g.KW) { kx = 0; ++ky; }
+      if (ky == g.KH) { ky = g.KH - 1; kx = g.KW - 1; cb = nb - 1; }
+      else set_tap(ky, kx);
+    }
+  };
+  set_tap(ky, kx);
+  // A: two register stages (loads issued two MFMA phases before the split), LDS double buffered.  B: the fragments of the
+  // chunk being multiplied and of the next one (loaded during this chunk's MFMAs).
+  AStage sa, sb;
+  BFrag b0[TN][G16], b1[TN][G16];
+  issue_a(sa, cb); issue_b(b0, ky * g.KW + kx, cb); advance();
+  commit(sa, 0);
+  issue_a(sa, cb); issue_b(b1, ky * g.KW + kx, cb); advance();       // chunk 1
+  __syncthreads();
+  for (int c = 0; c < nchunks; c += 2) {
+    issue_a(sb, cb);                      // A of chunk c + 2
+    const int tap2 = ky * g.KW + kx, cb2 = cb;
+    advance();
+    __builtin_amdgcn_sched_barrier(0);
+    mma(0, b0);                           // chunk c
+    __builtin_amdgcn_sched_barrier(0);
+    issue_b(b0, tap2, cb2);               // B of chunk c + 2 (b0 is free now)
+    commit(sa, 1);                        // chunk c + 1
+    __syncthreads();
+    if (c + 1 >= nchunks) break;
+    issue_a(sa, cb);                      // A of chunk c + 3
+    const int tap3 = ky * g.KW + kx, cb3 = cb;
+    advance();
+    __builtin_amdgcn_sched_barrier(0);
+    mma(1, b1);                           // chunk c + 1
+    __builtin_amdgcn_sched_barrier(0);
+    issue_b(b1, tap3, cb3);
+    commit(sb, 0);                        // chunk c + 2
+    __syncthreads();
+  }
+  const long long m_first = (long long)tile_m_first * MT;
+  float* dst = nsplits == 1 ? c_dst : ws + ((size_t)split * (M - m_first) - m_first) * Ncols;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const long long row = m0 + wm * 32 + mfma_row(r, lane);
+    if (row < M) {
+#pragma unroll
+      for (int ni = 0; ni < TN; ++ni) dst[(size_t)row * Ncols + n0 + (wn * TN + ni) * 32 + l31] = acc[ni][r];
+    }
+  }
+}
+
 // backward-weights: part[split][co][tap][ci] = sum over this split's output pixels of dout[p][co] * in[src(p, tap)][ci]
 // grid (splits, co tiles x ci tiles, taps)
 template <int MT, int NT, int WM, int WN, int STRIDE>
@@ -812,11 +994,15 @@ constexpr size_t kSplitLds64 = (size_t)2 * 3 * (128 + 64) * LDKH * sizeof(unsign
     hipLaunchKernelGGL((conv_igemm_split_kernel<NT, STRIDE, WMV, IL>), dim3(grid), dim3(128 * WMV), (LDS),             \
                        (hipStream_t)stream, g, a, wgt, c, ws, per, splits, first, count);                              \
   } while (0)
-// variants (A/B): 1 = eight waves, MFMA and split interleaved; 2 = eight waves, two blocks; 3 = four waves, interleaved
+constexpr size_t kSplitWLds = (size_t)2 * 3 * 128 * LDKH * sizeof(unsigned short);
+// variants (A/B): 1 = weights pre-split in global memory (the fast one); 2 = both operands through LDS, eight waves;
+// 3 = both operands through LDS, four waves
 #define ISTNET_IGEMM_SPLIT(NT, STRIDE, LDS)                                                                            \
   do {                                                                                                                 \
-    if (g_conv_split == 1) ISTNET_IGEMM_SPLIT_ONE(NT, STRIDE, LDS, 4, true);                                           \
-    else if (g_conv_split == 2) ISTNET_IGEMM_SPLIT_ONE(NT, STRIDE, LDS, 4, false);                                     \
+    if (g_conv_split == 1) {                                                                                           \
+      hipLaunchKernelGGL((conv_igemm_splitw_kernel<NT, STRIDE>), dim3(grid), dim3(512), kSplitWLds, (hipStream_t)stream, g, a, \
+                         wsplit, wplane, c, ws, per, splits, first, count);                                            \
+    } else if (g_conv_split == 2) ISTNET_IGEMM_SPLIT_ONE(NT, STRIDE, LDS, 4, true);                                    \
     else ISTNET_IGEMM_SPLIT_ONE(NT, STRIDE, LDS, 2, true);                                                             \
   } while (0)
 
@@ -828,7 +1014,8 @@ constexpr size_t kSplitLds64 = (size_t)2 * 3 * (128 + 64) * LDKH * sizeof(unsign
   } while (0)
 
 static void igemm_part(const ConvGeom& g, int mode, int nt, int first, int count, int splits, int per, const float* a,
-                       const float* wgt, float* c, float* ws, void* stream) {
+                       const float* wgt, float* c, float* ws, void* stream, const unsigned short* wsplit = nullptr,
+                       long long wplane = 0) {
   const int ncols = mode == 0 ? g.Cout : g.Cin;
   const unsigned grid = (unsigned)((count + 7) / 8 * 8 * (ncols / nt) * splits);
   if (mode == 0 && g_conv_split) {
@@ -846,15 +1033,47 @@ static void igemm_part(const ConvGeom& g, int mode, int nt, int first, int count
 #undef ISTNET_IGEMM_SPLIT
 #undef ISTNET_IGEMM_SPLIT_ONE
 
+// floats of the K-split slabs of a plan (0: none)
+static long long plan_slab_floats(const ConvGeom& g, int mode, const IgemmPlan& plan) {
+  if (plan.splits == 1) return 0;
+  const long long m = mode == 0 ? (long long)g.B * g.OH * g.OW : (long long)g.B * g.H * g.W;
+  return (long long)plan.splits * (m - (long long)plan.rows_a * 128) * (mode == 0 ? g.Cout : g.Cin);
+}
+static long long split_weight_floats(const ConvGeom& g) {      // three bf16 planes of the weights, in floats (16-byte multiple)
+  const long long n = (long long)g.Cout * g.KH * g.KW * g.Cin;
+  return (3 * n / 2 + 3) / 4 * 4;
+}
+
 static int igemm_launch(const ConvGeom& g, int mode, const float* a, const float* wgt, float* c, float* ws, void* stream) {
   const IgemmPlan plan = igemm_plan(g, mode);
   if (plan.splits > 1 && ws == nullptr) return ISTNET_PN2_EINVAL;
+  const unsigned short* wsplit = nullptr;
+  const long long wplane = (long long)g.Cout * g.KH * g.KW * g.Cin;
+  if (mode == 0 && g_conv_split == 1) {       // the weights' three bf16 planes live behind the K-split slabs of the work space
+    if (ws == nullptr) return ISTNET_PN2_EINVAL;
+    unsigned short* dst = reinterpret_cast<unsigned short*>(ws + plan_slab_floats(g, mode, plan));
+    const long long n4 = wplane / 4;
+    hipLaunchKernelGGL(split_weights_kernel, dim3((unsigned)((n4 + kThreads - 1) / kThreads)), dim3(kThreads), 0,
+                       (hipStream_t)stream, n4, reinterpret_cast<const float4*>(wgt), reinterpret_cast<uint2*>(dst),
+                       reinterpret_cast<uint2*>(dst + wplane), reinterpret_cast<uint2*>(dst + 2 * wplane));
+    wsplit = dst;
+    static std::atomic<unsigned long long> lds_done{0};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (!(lds_done.load(std::memory_order_relaxed) & (1ull << (dev & 63)))) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_splitw_kernel<128, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kSplitWLds);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_splitw_kernel<128, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kSplitWLds);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_splitw_kernel<64, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kSplitWLds);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_splitw_kernel<64, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kSplitWLds);
+      lds_done.fetch_or(1ull << (dev & 63), std::memory_order_relaxed);
+    }
+  }
   const int ncols = mode == 0 ? g.Cout : g.Cin, kch = mode == 0 ? g.Cin : g.Cout;
   const long long m = mode == 0 ? (long long)g.B * g.OH * g.OW : (long long)g.B * g.H * g.W;
   const int nchunks = g.KH * g.KW * (kch / KC);
-  if (plan.rows_a > 0) igemm_part(g, mode, plan.nt, 0, plan.rows_a, 1, nchunks, a, wgt, c, ws, stream);
+  if (plan.rows_a > 0) igemm_part(g, mode, plan.nt, 0, plan.rows_a, 1, nchunks, a, wgt, c, ws, stream, wsplit, wplane);
   if (plan.rows_b > 0) {
-    igemm_part(g, mode, plan.nt, plan.rows_a, plan.rows_b, plan.splits, plan.per, a, wgt, c, ws, stream);
+    igemm_part(g, mode, plan.nt, plan.rows_a, plan.rows_b, plan.splits, plan.per, a, wgt, c, ws, stream, wsplit, wplane);
     if (plan.splits > 1) {
       const long long m_first = (long long)plan.rows_a * 128;
       const long long n4 = (m - m_first) * ncols / 4;
@@ -871,9 +1090,8 @@ int istnet_conv_workspace_floats(int backward_data, int b, int h, int w, int cin
   if (!geom_ok(b, h, w, cin, cout, kh, kw, stride, pad)) return -1;
   const ConvGeom g = make_geom(b, h, w, cin, cout, kh, kw, stride, pad);
   const IgemmPlan plan = igemm_plan(g, backward_data ? 1 : 0);
-  if (plan.splits == 1) return 0;
-  const long long m = backward_data ? (long long)b * h * w : (long long)b * g.OH * g.OW;
-  const long long n = (long long)plan.splits * (m - (long long)plan.rows_a * 128) * (backward_data ? cin : cout);
+  long long n = plan_slab_floats(g, backward_data ? 1 : 0, plan);
+  if (!backward_data && g_conv_split == 1) n += split_weight_floats(g);      // the pre-split weights (split-precision forward)
   return n < (1ll << 31) ? (int)n : -1;
 }
 
