@@ -710,6 +710,9 @@ def main():
     ap.add_argument("--windows", type=int, default=0,
                     help="timed windows of --steps steps each, the median is reported (default: 5 when steps <= 20, else 1)")
     ap.add_argument("--no-eager-leg", action="store_true", help="skip the reference-style eager measurement (the `eager` object)")
+    ap.add_argument("--split-precision", action="store_true",
+                    help="istnet: ALSO measure the opt-in split-precision trunk (bf16 x 3 on the bf16 matrix pipe) and report it "
+                         "under the extra key `split_precision`; the headline value stays on the exact-fp32 path")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", default="", help="cpu_baseline: comma-separated thread counts to sweep (default 8,16,32)")
     ap.add_argument("--no-roofline", action="store_true")
@@ -1021,6 +1024,41 @@ def main():
                 flop = ENCODER_FWD_BWD_MFLOP_PER_CLOUD * 1e6 * batch_size
                 result["roofline"]["step_flops_tflops"] = flop / (ms * 1e-3) / 1e12
                 result["roofline"]["step_flops_frac"] = flop / (ms * 1e-3) / 1e12 / roofline.PEAK_MFMA_F32_TFLOPS
+        if args.split_precision and not dist_on and args.workload == "istnet" and mode == "hipgraph":
+            # OPT-IN experiment, never the headline: the same step with the trunk's forward / backward-data products on the
+            # bf16 matrix pipe (three exact bf16 terms per fp32 operand, six products, fp32 accumulation; rgb_branch.set_split_precision)
+            from istnet_amd import rgb_branch
+
+            def rgb_features():
+                torch.manual_seed(123)                                   # the decoder's Dropout2d masks
+                with torch.enable_grad():
+                    return model.rgb_cam_extractor(batch["rgb"], batch["choose"]).detach().double()
+            ref = rgb_features()
+            rgb_branch.set_split_precision(True)
+            try:
+                got = rgb_features()
+                split_step = make_graphed_step(fwd_bwd, opt, world, grad_sync)
+                for _ in range(args.warmup):
+                    split_step()
+                dts = []
+                for _ in range(n_windows):
+                    torch.cuda.synchronize()
+                    t1 = time.perf_counter()
+                    for _ in range(args.steps):
+                        split_step()
+                    torch.cuda.synchronize()
+                    dts.append((time.perf_counter() - t1) / args.steps)
+            finally:
+                rgb_branch.set_split_precision(False)
+            again = rgb_features()
+            dt = sorted(dts)[len(dts) // 2]
+            result["split_precision"] = {
+                "ms_per_step": dt * 1e3, "value": batch_size / dt, "unit": "clouds/s", "speedup_vs_fp32_mfma": ms / (dt * 1e3),
+                "rgb_features_max_rel_diff_vs_fp32_mfma": float((got - ref).abs().max() / ref.abs().max()),
+                "rgb_features_run_to_run_fp32_mfma": float((again - ref).abs().max() / ref.abs().max()),
+                "scope": "ResNet trunk 3x3 / 1x1 convolutions: forward and backward-data (stride 1); everything else unchanged",
+                "kernel_level_errors_vs_float64": "profiles/r05_split_precision_conv.txt (0.8-1.0x the fp32 MFMA kernel's)",
+                "note": "opt-in (rgb_branch.set_split_precision / ISTNET_SPLIT_PRECISION=1); the headline value above is the exact-fp32 MFMA path"}
         if not dist_on and not args.no_cpu_baseline:
             result["cpu_baseline"] = (cpu_baseline() if not args.cpu_threads else
                                       cpu_baseline(180.0, tuple(int(t) for t in args.cpu_threads.split(","))))

@@ -326,16 +326,18 @@ __device__ __forceinline__ Split3 split3(const float4& v) {
   return s;
 }
 
-template <int NT, int STRIDE, int WM, bool INTERLEAVE>      // WM = 4: eight waves of 32 x NT/2;  WM = 2: four waves of 64 x NT/2
-__global__ __launch_bounds__(128 * WM, 1) void conv_igemm_split_kernel(ConvGeom g, const float* __restrict__ a_src,
+template <int NT, int STRIDE, int WM, bool INTERLEAVE, int DIAG = 0, int KCS = KC, int MINW = 1>      // WM = 4: eight waves of 32 x NT/2;  WM = 2: four waves of 64 x NT/2
+// DIAG (timing experiments, wrong results): 1 no MFMAs, 2 no split / LDS writes, 3 no LDS reads, 4 no global loads
+__global__ __launch_bounds__(128 * WM, MINW) void conv_igemm_split_kernel(ConvGeom g, const float* __restrict__ a_src,
                                                                        const float* __restrict__ wgt, float* __restrict__ c_dst,
                                                                        float* __restrict__ ws, int chunks_per_split, int nsplits,
                                                                        int tile_m_first, int tile_m_count) {
   constexpr int MT = 128, WN = 2, NTHR = 64 * WM * WN;
+  constexpr int KC_ = KCS, LPR_ = KCS / 4, LDKH_ = KCS + 8;      // K chunk of THIS kernel (32, or 16: half the LDS, two workgroups per CU)
   constexpr int TM = MT / (32 * WM), TN = NT / (32 * WN);
-  constexpr int RPP = NTHR / LPR;                       // tile rows per pass of the workgroup
+  constexpr int RPP = NTHR / LPR_;                       // tile rows per pass of the workgroup
   constexpr int AR = MT / RPP, BR = NT / RPP;           // float4 per thread and operand
-  constexpr int A_PLANE = MT * LDKH, B_PLANE = NT * LDKH;               // bf16 elements
+  constexpr int A_PLANE = MT * LDKH_, B_PLANE = NT * LDKH_;               // bf16 elements
   constexpr int STAGE = 3 * (A_PLANE + B_PLANE);
   static_assert(AR >= 1 && AR <= 4 && BR >= 1 && BR <= 4 && TM >= 1 && TN >= 1, "128 x 128 or 128 x 64 tiles, 4 or 8 waves");
   extern __shared__ __attribute__((aligned(16))) unsigned short smem_h[];       // [2][STAGE]
@@ -353,12 +355,12 @@ __global__ __launch_bounds__(128 * WM, 1) void conv_igemm_split_kernel(ConvGeom 
   if (tile_local >= tile_m_count) return;
   const long long m0 = (long long)(tile_m_first + tile_local) * MT;
   const int n0 = (jt % tiles_n) * NT;
-  const int acol = (tid % LPR) * 4;
+  const int acol = (tid % LPR_) * 4;
   int rb[AR], ry[AR], rx[AR];
   unsigned rvalid = 0;
 #pragma unroll
   for (int i = 0; i < AR; ++i) {
-    const long long pm = m0 + (tid / LPR) + RPP * i;
+    const long long pm = m0 + (tid / LPR_) + RPP * i;
     const long long pc = pm < M ? pm : M - 1;
     const int b = (int)(pc / (MH * MW));
     const int rem = (int)(pc - (long long)b * MH * MW);
@@ -367,7 +369,7 @@ __global__ __launch_bounds__(128 * WM, 1) void conv_igemm_split_kernel(ConvGeom 
     rb[i] = b * SH;
     rvalid |= (pm < M ? 1u : 0u) << i;
   }
-  const int nb = Ka / KC;
+  const int nb = Ka / KC_;
   const int c_first = split * chunks_per_split;
   const int nchunks = min(chunks_per_split, taps * nb - c_first);
   size_t aoff[AR];
@@ -385,19 +387,24 @@ __global__ __launch_bounds__(128 * WM, 1) void conv_igemm_split_kernel(ConvGeom 
   auto issue = [&](Stage& st, int ky, int kx, int cb) {
     const int tap = ky * g.KW + kx;
     st.ok = tap_ok;
+    if (DIAG == 4) {
+      const float f = (float)(tap + cb);
+      st.a0 = st.a1 = st.a2 = st.a3 = st.b0 = st.b1 = st.b2 = st.b3 = make_float4(f, f + 1.f, f + 2.f, f + 3.f);
+      return;
+    }
     static_for<AR>([&](auto ic) {
       constexpr int i = decltype(ic)::value;
-      st_a<i>(st) = *reinterpret_cast<const float4*>(a_src + aoff[i] + (size_t)cb * KC);
+      st_a<i>(st) = *reinterpret_cast<const float4*>(a_src + aoff[i] + (size_t)cb * KC_);
     });
     static_for<BR>([&](auto ic) {
       constexpr int i = decltype(ic)::value;
-      const int n = n0 + (tid / LPR) + RPP * i;
-      st_b<i>(st) = *reinterpret_cast<const float4*>(wgt + ((size_t)n * taps + tap) * g.Cin + (size_t)cb * KC + acol);
+      const int n = n0 + (tid / LPR_) + RPP * i;
+      st_b<i>(st) = *reinterpret_cast<const float4*>(wgt + ((size_t)n * taps + tap) * g.Cin + (size_t)cb * KC_ + acol);
     });
   };
   auto put = [&](unsigned short* plane0, int plane_elems, int row, const float4& v) {
     const Split3 s = split3(v);
-    unsigned short* p = plane0 + row * LDKH + acol;
+    unsigned short* p = plane0 + row * LDKH_ + acol;
     *reinterpret_cast<uint2*>(p) = s.hi;
     *reinterpret_cast<uint2*>(p + plane_elems) = s.mid;
     *reinterpret_cast<uint2*>(p + 2 * plane_elems) = s.lo;
@@ -405,13 +412,17 @@ __global__ __launch_bounds__(128 * WM, 1) void conv_igemm_split_kernel(ConvGeom 
   auto commit = [&](Stage& st, int buf) {
     unsigned short* as = smem_h + buf * STAGE;
     unsigned short* bs = as + 3 * A_PLANE;
+    if (DIAG == 2) {        // keep the loads alive without the split and the LDS writes
+      if (st.a0.x == 123.456f && st.b0.x == 654.321f) as[tid] = 1;
+      return;
+    }
     static_for<AR>([&](auto ic) {
       constexpr int i = decltype(ic)::value;
-      put(as, A_PLANE, (tid / LPR) + RPP * i, keep_if((st.ok >> i) & 1u, st_a<i>(st)));
+      put(as, A_PLANE, (tid / LPR_) + RPP * i, keep_if((st.ok >> i) & 1u, st_a<i>(st)));
     });
     static_for<BR>([&](auto ic) {
       constexpr int i = decltype(ic)::value;
-      put(bs, B_PLANE, (tid / LPR) + RPP * i, st_b<i>(st));
+      put(bs, B_PLANE, (tid / LPR_) + RPP * i, st_b<i>(st));
     });
   };
   f32x16 acc[TM][TN];
@@ -422,34 +433,37 @@ __global__ __launch_bounds__(128 * WM, 1) void conv_igemm_split_kernel(ConvGeom 
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
   auto mma = [&](int buf) {
-    const unsigned short* as = smem_h + buf * STAGE + ((wm * TM) * 32 + l31) * LDKH + 8 * half;
-    const unsigned short* bs = smem_h + buf * STAGE + 3 * A_PLANE + ((wn * TN) * 32 + l31) * LDKH + 8 * half;
+    const unsigned short* as = smem_h + buf * STAGE + ((wm * TM) * 32 + l31) * LDKH_ + 8 * half;
+    const unsigned short* bs = smem_h + buf * STAGE + 3 * A_PLANE + ((wn * TN) * 32 + l31) * LDKH_ + 8 * half;
 #pragma unroll
-    for (int g16 = 0; g16 < KC / 16; ++g16) {
+    for (int g16 = 0; g16 < KC_ / 16; ++g16) {
       bf16x8 ah[TM], am[TM], al[TM];
 #pragma unroll
       for (int mi = 0; mi < TM; ++mi) {
-        const unsigned short* ap = as + mi * 32 * LDKH + 16 * g16;
+        const unsigned short* ap = as + mi * 32 * LDKH_ + 16 * g16;
+        if (DIAG == 3) { ah[mi] = am[mi] = al[mi] = bf16x8{}; ah[mi][0] = (__bf16)(float)lane; continue; }
         ah[mi] = *reinterpret_cast<const bf16x8*>(ap);
         am[mi] = *reinterpret_cast<const bf16x8*>(ap + A_PLANE);
         al[mi] = *reinterpret_cast<const bf16x8*>(ap + 2 * A_PLANE);
       }
+      bf16x8 bh[TN], bm[TN], bl[TN];
 #pragma unroll
       for (int ni = 0; ni < TN; ++ni) {
-        const unsigned short* bp = bs + ni * 32 * LDKH + 16 * g16;
-        const bf16x8 bh = *reinterpret_cast<const bf16x8*>(bp);
-        const bf16x8 bm = *reinterpret_cast<const bf16x8*>(bp + B_PLANE);
-        const bf16x8 bl = *reinterpret_cast<const bf16x8*>(bp + 2 * B_PLANE);
-#pragma unroll
-        for (int mi = 0; mi < TM; ++mi) {
-          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[mi], bh, acc[mi][ni], 0, 0, 0);
-          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mi], bl, acc[mi][ni], 0, 0, 0);
-          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am[mi], bm, acc[mi][ni], 0, 0, 0);
-          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am[mi], bh, acc[mi][ni], 0, 0, 0);
-          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mi], bm, acc[mi][ni], 0, 0, 0);
-          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mi], bh, acc[mi][ni], 0, 0, 0);
-        }
+        const unsigned short* bp = bs + ni * 32 * LDKH_ + 16 * g16;
+        if (DIAG == 3) { bh[ni] = bm[ni] = bl[ni] = bf16x8{}; bh[ni][0] = (__bf16)(float)lane; continue; }
+        bh[ni] = *reinterpret_cast<const bf16x8*>(bp);
+        bm[ni] = *reinterpret_cast<const bf16x8*>(bp + B_PLANE);
+        bl[ni] = *reinterpret_cast<const bf16x8*>(bp + 2 * B_PLANE);
       }
+      // products outer, accumulators inner: consecutive MFMAs never share an accumulator (a dependent bf16 MFMA waits for
+      // its predecessor's result; with TM * TN >= 2 tiles per wave the chain of one tile hides behind the other's)
+#define ISTNET_P(A, B)                                                                         \
+  _Pragma("unroll") for (int mi = 0; mi < TM; ++mi)                                             \
+    _Pragma("unroll") for (int ni = 0; ni < TN; ++ni)                                           \
+      if (DIAG != 1) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[mi], B[ni], acc[mi][ni], 0, 0, 0); \
+      else acc[mi][ni][0] += (float)A[mi][0] + (float)B[ni][0];
+      ISTNET_P(al, bh) ISTNET_P(ah, bl) ISTNET_P(am, bm) ISTNET_P(am, bh) ISTNET_P(ah, bm) ISTNET_P(ah, bh)
+#undef ISTNET_P
     }
   };
   int ky = (c_first / nb) / g.KW, kx = (c_first / nb) % g.KW, cb = c_first % nb;
@@ -518,20 +532,48 @@ __global__ __launch_bounds__(128 * WM, 1) void conv_igemm_split_kernel(ConvGeom 
 // every wave loads its B fragments straight from there into registers in MFMA layout (one 16-byte load per plane, column and
 // 16-k group; the tile's weights are L2 / L1 resident and shared by the four row-waves of the workgroup), one chunk ahead.
 // Only the A operand (gathered pixels) goes through registers -> split -> LDS: a third of the LDS traffic, half of the VALU.
-__global__ __launch_bounds__(kThreads) void split_weights_kernel(long long n4, const float4* __restrict__ w,
-                                                                 uint2* __restrict__ hi, uint2* __restrict__ mid,
-                                                                 uint2* __restrict__ lo) {
+// Output layout = MFMA fragment order, so that a wave's fragment load is ONE contiguous kilobyte (in the weights' own
+// [cout][tap][cin] order a lane's 16 bytes sit 2 * taps * cin bytes from its neighbour's: every load touched 32 cache lines
+// for 32 useful bytes each and the kernel ran at half the speed of the LDS variant):
+//   [column tile of 32][tap][16-k group][plane hi / mid / lo][lane = 32 (k % 16 / 8) + column % 32][8 bf16]
+__global__ __launch_bounds__(kThreads) void split_weights_kernel(long long n4, int taps, int cin, const float4* __restrict__ w,
+                                                                 unsigned short* __restrict__ dst) {
   const long long i = (long long)blockIdx.x * kThreads + threadIdx.x;
   if (i >= n4) return;
   const Split3 s = split3(w[i]);
-  hi[i] = s.hi; mid[i] = s.mid; lo[i] = s.lo;
+  const long long e = 4 * i;                                  // element index in [cout][tap][cin]
+  const int k = (int)(e % cin);
+  const long long nt_ = e / cin;
+  const int tap = (int)(nt_ % taps), n = (int)(nt_ / taps);
+  const size_t frag = ((size_t)(n >> 5) * taps + tap) * (cin >> 4) + (k >> 4);
+  unsigned short* p = dst + frag * (3 * 512) + (size_t)(((k & 15) >> 3) * 32 + (n & 31)) * 8 + (k & 7);
+  *reinterpret_cast<uint2*>(p) = s.hi;
+  *reinterpret_cast<uint2*>(p + 512) = s.mid;
+  *reinterpret_cast<uint2*>(p + 1024) = s.lo;
+}
+
+// Backward-data at stride 1 IS a forward convolution of dout with the weights transposed and rotated by 180 degrees:
+//   din[b, y, x, ci] = sum_{ky', kx', co} dout[b, y - (KH - 1 - pad) + ky', x - (KW - 1 - pad) + kx', co] w'[ci][ky'][kx'][co],
+//   w'[ci][ky'][kx'][co] = w[co][KH - 1 - ky'][KW - 1 - kx'][ci]
+// so the split-precision forward kernel serves it once the weights are laid out that way (one small pass per call).
+__global__ __launch_bounds__(kThreads) void rotate_weights_kernel(int cout, int cin, int kh, int kw, const float* __restrict__ w,
+                                                                  float* __restrict__ wt) {
+  const long long i = (long long)blockIdx.x * kThreads + threadIdx.x;      // index into wt [cin][kh][kw][cout]
+  const long long n = (long long)cout * cin * kh * kw;
+  if (i >= n) return;
+  const int co = (int)(i % cout);
+  long long r = i / cout;
+  const int kx = (int)(r % kw); r /= kw;
+  const int ky = (int)(r % kh);
+  const int ci = (int)(r / kh);
+  wt[i] = w[(((size_t)co * kh + (kh - 1 - ky)) * kw + (kw - 1 - kx)) * cin + ci];
 }
 
 struct BFrag { bf16x8 h, m, l; };
 
 template <int NT, int STRIDE>
 __global__ __launch_bounds__(512, 1) void conv_igemm_splitw_kernel(ConvGeom g, const float* __restrict__ a_src,
-                                                                   const unsigned short* __restrict__ wsplit, long long wplane,
+                                                                   const unsigned short* __restrict__ wsplit, long long,
                                                                    float* __restrict__ c_dst, float* __restrict__ ws,
                                                                    int chunks_per_split, int nsplits, int tile_m_first,
                                                                    int tile_m_count) {
@@ -586,10 +628,11 @@ __global__ __launch_bounds__(512, 1) void conv_igemm_splitw_kernel(ConvGeom g, c
       tap_ok |= (ok ? 1u : 0u) << i;
     }
   };
-  // this lane's weight rows (output columns) in the pre-split planes: element offset of (column, tap 0, k = 8 half)
+  // this wave's column tiles in the fragment-ordered planes (split_weights_kernel): fragment index of (tile, tap 0, k 0)
   size_t wrow[TN];
+  const int kg_all = g.Cin >> 4;
 #pragma unroll
-  for (int ni = 0; ni < TN; ++ni) wrow[ni] = (size_t)(n0 + (wn * TN + ni) * 32 + l31) * taps * g.Cin + 8 * half;
+  for (int ni = 0; ni < TN; ++ni) wrow[ni] = (size_t)((n0 >> 5) + wn * TN + ni) * taps * kg_all;
   struct AStage { float4 a0, a1; unsigned ok; };
   auto issue_a = [&](AStage& st, int cb) {
     st.ok = tap_ok;
@@ -601,10 +644,10 @@ __global__ __launch_bounds__(512, 1) void conv_igemm_splitw_kernel(ConvGeom g, c
     for (int ni = 0; ni < TN; ++ni)
 #pragma unroll
       for (int q = 0; q < G16; ++q) {
-        const unsigned short* p = wsplit + wrow[ni] + (size_t)tap * g.Cin + (size_t)cb * KC + 16 * q;
+        const unsigned short* p = wsplit + (wrow[ni] + (size_t)tap * kg_all + (size_t)cb * G16 + q) * (3 * 512) + lane * 8;
         bf[ni][q].h = *reinterpret_cast<const bf16x8*>(p);
-        bf[ni][q].m = *reinterpret_cast<const bf16x8*>(p + wplane);
-        bf[ni][q].l = *reinterpret_cast<const bf16x8*>(p + 2 * wplane);
+        bf[ni][q].m = *reinterpret_cast<const bf16x8*>(p + 512);
+        bf[ni][q].l = *reinterpret_cast<const bf16x8*>(p + 1024);
       }
   };
   auto put = [&](unsigned short* plane0, int row, const float4& v) {
@@ -938,7 +981,7 @@ extern "C" {
 int istnet_conv_set_tuning(int key, int value) {
   // key 1: forward kernel arithmetic -- 0 exact fp32 matrix cores (default); 1 split precision (three bf16 terms per operand,
   // six bf16 MFMA products, fp32 accumulation: fp32-class accuracy, opt-in experiment); 2, 3: its A/B variants
-  if (key == 1) { if (value < 0 || value > 3) return ISTNET_PN2_EINVAL; g_conv_split = value; return 0; }
+  if (key == 1) { if (value < 0 || value > 7) return ISTNET_PN2_EINVAL; g_conv_split = value; return 0; }
   return ISTNET_PN2_EINVAL;
 }
 int istnet_conv_get_tuning(int key) { return key == 1 ? g_conv_split : -1; }
@@ -995,15 +1038,32 @@ constexpr size_t kSplitLds64 = (size_t)2 * 3 * (128 + 64) * LDKH * sizeof(unsign
                        (hipStream_t)stream, g, a, wgt, c, ws, per, splits, first, count);                              \
   } while (0)
 constexpr size_t kSplitWLds = (size_t)2 * 3 * 128 * LDKH * sizeof(unsigned short);
-// variants (A/B): 1 = weights pre-split in global memory (the fast one); 2 = both operands through LDS, eight waves;
-// 3 = both operands through LDS, four waves
+#define ISTNET_IGEMM_SPLIT_DIAG(NT, STRIDE, LDS, D)                                                                    \
+  do {                                                                                                                 \
+    ISTNET_ALLOW_LDS((conv_igemm_split_kernel<NT, STRIDE, 4, true, D>), (LDS));                                        \
+    hipLaunchKernelGGL((conv_igemm_split_kernel<NT, STRIDE, 4, true, D>), dim3(grid), dim3(512), (LDS),                \
+                       (hipStream_t)stream, g, a, wgt, c, ws, per, splits, first, count);                              \
+  } while (0)
+// variants: 1 = both operands through LDS, eight waves, K chunks of 16 (73 KB of LDS, 128 VGPRs: two workgroups per CU, whose
+// phases interleave) -- the fastest, the one "split precision" means; 2 = the same with K chunks of 32, one workgroup per CU;
+// 3 = weights pre-split in global memory in fragment order (a third of the LDS traffic -- and slower: profiles/r05_split_precision.txt);
+// 4..7 = timing experiments (DIAG)
 #define ISTNET_IGEMM_SPLIT(NT, STRIDE, LDS)                                                                            \
   do {                                                                                                                 \
-    if (g_conv_split == 1) {                                                                                           \
+    if (g_conv_split == 3) {                                                                                           \
       hipLaunchKernelGGL((conv_igemm_splitw_kernel<NT, STRIDE>), dim3(grid), dim3(512), kSplitWLds, (hipStream_t)stream, g, a, \
                          wsplit, wplane, c, ws, per, splits, first, count);                                            \
     } else if (g_conv_split == 2) ISTNET_IGEMM_SPLIT_ONE(NT, STRIDE, LDS, 4, true);                                    \
-    else ISTNET_IGEMM_SPLIT_ONE(NT, STRIDE, LDS, 2, true);                                                             \
+    else if (g_conv_split == 1 && NT == 128) {                                                                         \
+      constexpr size_t lds16 = (size_t)2 * 3 * (128 + 128) * (16 + 8) * sizeof(unsigned short);                        \
+      ISTNET_ALLOW_LDS((conv_igemm_split_kernel<128, STRIDE, 4, true, 0, 16, 4>), lds16);                              \
+      hipLaunchKernelGGL((conv_igemm_split_kernel<128, STRIDE, 4, true, 0, 16, 4>), dim3(grid), dim3(512), lds16,      \
+                         (hipStream_t)stream, g, a, wgt, c, ws, 2 * per, splits, first, count);                        \
+    } else if (g_conv_split == 1) ISTNET_IGEMM_SPLIT_ONE(NT, STRIDE, LDS, 4, true);                                    \
+    else if (g_conv_split == 4) ISTNET_IGEMM_SPLIT_DIAG(NT, STRIDE, LDS, 1);                                           \
+    else if (g_conv_split == 5) ISTNET_IGEMM_SPLIT_DIAG(NT, STRIDE, LDS, 2);                                           \
+    else if (g_conv_split == 6) ISTNET_IGEMM_SPLIT_DIAG(NT, STRIDE, LDS, 3);                                           \
+    else ISTNET_IGEMM_SPLIT_DIAG(NT, STRIDE, LDS, 4);                                                                  \
   } while (0)
 
 #define ISTNET_IGEMM(MT, NT, WM, WN, MODE, STRIDE)                                                                     \
@@ -1049,13 +1109,12 @@ static int igemm_launch(const ConvGeom& g, int mode, const float* a, const float
   if (plan.splits > 1 && ws == nullptr) return ISTNET_PN2_EINVAL;
   const unsigned short* wsplit = nullptr;
   const long long wplane = (long long)g.Cout * g.KH * g.KW * g.Cin;
-  if (mode == 0 && g_conv_split == 1) {       // the weights' three bf16 planes live behind the K-split slabs of the work space
+  if (mode == 0 && g_conv_split == 3) {       // the weights' three bf16 planes live behind the K-split slabs of the work space
     if (ws == nullptr) return ISTNET_PN2_EINVAL;
     unsigned short* dst = reinterpret_cast<unsigned short*>(ws + plan_slab_floats(g, mode, plan));
     const long long n4 = wplane / 4;
     hipLaunchKernelGGL(split_weights_kernel, dim3((unsigned)((n4 + kThreads - 1) / kThreads)), dim3(kThreads), 0,
-                       (hipStream_t)stream, n4, reinterpret_cast<const float4*>(wgt), reinterpret_cast<uint2*>(dst),
-                       reinterpret_cast<uint2*>(dst + wplane), reinterpret_cast<uint2*>(dst + 2 * wplane));
+                       (hipStream_t)stream, n4, g.KH * g.KW, g.Cin, reinterpret_cast<const float4*>(wgt), dst);
     wsplit = dst;
     static std::atomic<unsigned long long> lds_done{0};
     int dev = 0;
@@ -1091,7 +1150,13 @@ int istnet_conv_workspace_floats(int backward_data, int b, int h, int w, int cin
   const ConvGeom g = make_geom(b, h, w, cin, cout, kh, kw, stride, pad);
   const IgemmPlan plan = igemm_plan(g, backward_data ? 1 : 0);
   long long n = plan_slab_floats(g, backward_data ? 1 : 0, plan);
-  if (!backward_data && g_conv_split == 1) n += split_weight_floats(g);      // the pre-split weights (split-precision forward)
+  if (!backward_data && g_conv_split == 3) n += split_weight_floats(g);      // the pre-split weights (split-precision forward)
+  if (backward_data && g_conv_split && stride == 1) {
+    // split precision: backward-data runs as a forward product of dout with the rotated weights (rotated copy + that plan's slabs)
+    const ConvGeom gt = make_geom(b, g.OH, g.OW, cout, cin, kh, kw, 1, kh - 1 - pad);
+    n = plan_slab_floats(gt, 0, igemm_plan(gt, 0)) + (long long)cout * cin * kh * kw;
+    if (g_conv_split == 3) n += split_weight_floats(gt);
+  }
   return n < (1ll << 31) ? (int)n : -1;
 }
 
@@ -1108,7 +1173,20 @@ int istnet_conv_backward_data(int b, int h, int w, int cin, int cout, int kh, in
   if (!geom_ok(b, h, w, cin, cout, kh, kw, stride, pad) || !dout || !wgt || !din ||
       (((uintptr_t)dout | (uintptr_t)wgt | (uintptr_t)din | (uintptr_t)ws) & 15))
     return ISTNET_PN2_EINVAL;
-  return igemm_launch(make_geom(b, h, w, cin, cout, kh, kw, stride, pad), 1, dout, wgt, din, ws, stream);
+  const ConvGeom g = make_geom(b, h, w, cin, cout, kh, kw, stride, pad);
+  if (g_conv_split && stride == 1 && kh - 1 - pad >= 0) {
+    if (ws == nullptr) return ISTNET_PN2_EINVAL;
+    const ConvGeom gt = make_geom(b, g.OH, g.OW, cout, cin, kh, kw, 1, kh - 1 - pad);     // its output is (b, h, w, cin)
+    if (gt.OH != h || gt.OW != w) return ISTNET_PN2_EINVAL;
+    const long long nw = (long long)cout * cin * kh * kw;
+    long long slabs = plan_slab_floats(gt, 0, igemm_plan(gt, 0));
+    if (g_conv_split == 3) slabs += split_weight_floats(gt);
+    float* wt = ws + slabs;                                                              // behind the forward launch's own work space
+    hipLaunchKernelGGL(rotate_weights_kernel, dim3((unsigned)((nw + kThreads - 1) / kThreads)), dim3(kThreads), 0,
+                       (hipStream_t)stream, cout, cin, kh, kw, wgt, wt);
+    return igemm_launch(gt, 0, dout, wt, din, ws, stream);
+  }
+  return igemm_launch(g, 1, dout, wgt, din, ws, stream);
 }
 
 static int wrw_plan(const ConvGeom& g, int& mt, int& nt, int& per) {

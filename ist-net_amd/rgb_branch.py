@@ -143,6 +143,20 @@ USE_NATIVE_TRUNK_CONV = os.environ.get("ISTNET_NATIVE_TRUNK_CONV", "1") != "0"
 # every trunk shape through the C ABI, tests/test_conv_gpu.py.)
 
 
+def set_split_precision(enabled):
+    """OPT-IN experiment (DESIGN.md "split precision"; off by default, the headline numbers never use it): the trunk's native
+    forward and backward-data (stride 1) products on the bf16 matrix pipe -- every fp32 operand split exactly into three bf16
+    terms, six bf16 MFMA products per fp32 product, fp32 accumulation.  fp32-class accuracy (the error against float64 is
+    0.8-1.0x the exact-fp32 kernel's, tests/test_conv_gpu.py), 1.2-1.6x faster on the trunk's layers.  Process-wide; returns the
+    previous setting.  Environment: ISTNET_SPLIT_PRECISION=1."""
+    from . import _native
+    lib = _native.lib()
+    prev = lib.istnet_conv_get_tuning(1)
+    _native.check(lib.istnet_conv_set_tuning(1, 1 if enabled else 0), "conv_set_tuning")
+    _CONV_GEOM_OK.clear()              # the work-space sizes the guard cached depend on the mode
+    return bool(prev)
+
+
 def _native_conv_ok(conv, x):
     if not (USE_NATIVE_TRUNK_CONV and torch.is_grad_enabled() and x.is_cuda
             and x.dtype == torch.float32 and x.dim() == 4
@@ -169,6 +183,11 @@ def _native_conv_ok(conv, x):
 
 
 _CONV_GEOM_OK = {}
+if os.environ.get("ISTNET_SPLIT_PRECISION", "0") == "1":
+    try:
+        set_split_precision(True)
+    except RuntimeError:          # library not built yet (import during the build)
+        pass
 
 
 def _conv_workspace(lib, backward_data, args, dev):

@@ -126,3 +126,44 @@ def test_basic_block_with_native_convolutions():
     assert rel(a[0], r[0]) < 1e-4 and rel(a[1], r[1]) < 1e-3
     for name in a[2]:
         assert rel(a[2][name], r[2][name]) < 1e-3, name
+
+
+@pytest.mark.parametrize("cin,cout,k,s,h,w", LAYERS)
+@pytest.mark.parametrize("variant", [1, 2, 3])
+def test_split_precision_kernels_hold_the_fp32_error(cin, cout, k, s, h, w, variant):
+    """Opt-in split precision (istnet_conv_set_tuning(1, v), include/istnet_conv.h): every fp32 operand as three exact bf16
+    terms, six v_mfma_f32_32x32x16_bf16 products, fp32 accumulation.  The acceptance gate of the experiment, per shape and for
+    forward AND backward-data (stride 1; stride 2 keeps the fp32 path): the error against a float64 convolution is at most 2x
+    the exact-fp32 MFMA kernel's own error, in the maximum and in the rms (measured: 0.8-1.0x, profiles/r05_split_precision_conv.txt)."""
+    from istnet_amd import _native
+    lib = _native.lib()
+    pad = k // 2
+    b = 3
+    g = torch.Generator().manual_seed(7 * cin + cout + k + h + variant)
+    x = (torch.randn(b, cin, h, w, generator=g).abs() * torch.rand(b, cin, 1, 1, generator=g) * 3).to(DEV).contiguous(memory_format=torch.channels_last)
+    wgt = (torch.randn(cout, cin, k, k, generator=g) * (2.0 / (cin * k * k)) ** 0.5).to(DEV).contiguous(memory_format=torch.channels_last)
+    oh, ow = (h + 2 * pad - k) // s + 1, (w + 2 * pad - k) // s + 1
+    dy = torch.randn(b, cout, oh, ow, generator=g).to(DEV).contiguous(memory_format=torch.channels_last)
+    y64 = torch.nn.functional.conv2d(x.double(), wgt.double(), None, s, pad)
+    dx64 = torch.nn.grad.conv2d_input(x.shape, wgt.double(), dy.double(), s, pad)
+    args = (b, h, w, cin, cout, k, k, s, pad)
+    errs = {}
+    try:
+        for mode in (0, variant):
+            assert lib.istnet_conv_set_tuning(1, mode) == 0 and lib.istnet_conv_get_tuning(1) == mode
+            y = torch.empty((b, cout, oh, ow), device=DEV).contiguous(memory_format=torch.channels_last)
+            assert lib.istnet_conv_forward(*args, x.data_ptr(), wgt.data_ptr(), y.data_ptr(), _ws(lib, 0, args).data_ptr(), _st()) == 0
+            dx = torch.empty_like(x)
+            if s == 1:
+                assert lib.istnet_conv_backward_data(*args, dy.data_ptr(), wgt.data_ptr(), dx.data_ptr(), _ws(lib, 1, args).data_ptr(), _st()) == 0
+            torch.cuda.synchronize()
+            e = [(y.double() - y64).abs().max() / y64.abs().max(), (y.double() - y64).pow(2).mean().sqrt()]
+            if s == 1:
+                e += [(dx.double() - dx64).abs().max() / dx64.abs().max(), (dx.double() - dx64).pow(2).mean().sqrt()]
+            errs[mode] = [float(v) for v in e]
+    finally:
+        assert lib.istnet_conv_set_tuning(1, 0) == 0
+    assert lib.istnet_conv_set_tuning(1, 99) != 0
+    for e_split, e_fp32 in zip(errs[variant], errs[0]):
+        assert e_split <= 2.0 * e_fp32 + 1e-12, (errs[variant], errs[0])
+    assert errs[variant][0] < 1e-5

@@ -1,7 +1,7 @@
-"""Split-precision forward convolution (istnet_conv_set_tuning(1, 1): three bf16 terms per operand, six bf16 MFMA products, fp32
-accumulation) against the exact-fp32 MFMA kernel on the trunk's layers at B = 32: time, TFLOP/s, and the error of BOTH against
-a float64 convolution (max |diff| / max |ref| and rms).  Acceptance: split error <= 2 x the fp32
-kernel's error on every layer, gain >= 10 %."""
+"""Split-precision convolution (istnet_conv_set_tuning(1, 1): three bf16 terms per operand, six bf16 MFMA products, fp32
+accumulation) against the exact-fp32 MFMA kernels on the trunk's layers at B = 32: forward and backward-data, time, TFLOP/s,
+and the error of BOTH against a float64 convolution (max |diff| / max |ref|, rms ratio in brackets).
+Acceptance: split error <= 2 x the fp32 kernel's error on every layer, gain >= 10 %."""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))))
 import torch, istnet_amd
@@ -26,32 +26,45 @@ LAYERS = [("layer1 3x3", 64, 64, 3, 1, 48), ("layer2.0 3x3 s2", 64, 128, 3, 2, 4
           ("layer3 down 1x1", 128, 256, 1, 1, 24), ("layer4.0 3x3", 256, 512, 3, 1, 24), ("layer4 3x3", 512, 512, 3, 1, 24),
           ("layer4 down 1x1", 256, 512, 1, 1, 24)]
 g = torch.Generator().manual_seed(0)
-print(f"# B={B}; err = max|y - y64| / max|y64| (rms in brackets); gate: split err <= 2 x fp32-MFMA err, gain >= 10 %")
-ok_all = True
+print(f"# B={B}; err = max|y - y64| / max|y64| (ratio of the rms errors in brackets); gate: split err <= 2 x fp32-MFMA err, gain >= 10 %")
+print("# variants of the split kernel: 1 = K chunks of 16, two workgroups per CU (the default); 2 = K chunks of 32; 3 = weights pre-split in global memory")
+ok_all, tot = True, {"fwd": [0.0, 0.0], "bwd": [0.0, 0.0]}
 for name, cin, cout, k, s, h in LAYERS:
     pad = k // 2
     # activations with a non-zero mean and a spread of magnitudes (post-ReLU-like), weights kaiming-like
     x = (torch.randn(B, cin, h, h, generator=g).abs() * torch.rand(B, cin, 1, 1, generator=g) * 3).to(dev).contiguous(memory_format=torch.channels_last)
     w = (torch.randn(cout, cin, k, k, generator=g) * (2.0 / (cin * k * k)) ** 0.5).to(dev).contiguous(memory_format=torch.channels_last)
     oh = (h + 2 * pad - k) // s + 1
+    dy = torch.randn(B, cout, oh, oh, generator=g).to(dev).contiguous(memory_format=torch.channels_last)
     flop = 2.0 * B * oh * oh * cout * cin * k * k
     y64 = torch.nn.functional.conv2d(x.double(), w.double(), None, s, pad)
+    dx64 = torch.nn.grad.conv2d_input(x.shape, w.double(), dy.double(), s, pad)
     args = (B, h, h, cin, cout, k, k, s, pad)
-    res = {}
-    for mode in (0, 1, 2, 3):
-        assert lib.istnet_conv_set_tuning(1, mode) == 0
-        y = torch.empty((B, cout, oh, oh), device=dev).contiguous(memory_format=torch.channels_last)
-        ws = torch.empty(max(1, lib.istnet_conv_workspace_floats(0, *args)), device=dev)
-        f = lambda: lib.istnet_conv_forward(*args, x.data_ptr(), w.data_ptr(), y.data_ptr(), ws.data_ptr(), st())
-        assert f() == 0
-        t = timeit(f)
-        d = (y.double() - y64)
-        res[mode] = (t, float(d.abs().max() / y64.abs().max()), float(d.pow(2).mean().sqrt() / y64.pow(2).mean().sqrt()))
-    lib.istnet_conv_set_tuning(1, 0)
-    (t0, e0, r0), (t1, e1, r1) = res[0], res[1]
-    t2, t3 = res[2][0], res[3][0]
-    ok = e1 <= 2 * e0 and r1 <= 2 * r0
-    ok_all &= ok
-    print(f"{name:20s} {flop / 1e9:6.1f} GFLOP | fp32 MFMA {t0:7.1f} us {flop / t0 / 1e6:6.1f} TF err {e0:.1e} ({r0:.1e}) | "
-          f"bf16x3 {t1:7.1f} us {flop / t1 / 1e6:6.1f} TF err {e1:.1e} ({r1:.1e}) | speed-up {t0 / t1:4.2f}x (variants: 8 waves two blocks {t2:6.1f}, 4 waves interleaved {t3:6.1f} us) err ratio {e1 / e0:4.2f} ({r1 / r0:4.2f}) {'ok' if ok else 'GATE FAILED'}")
+    for kind in ("fwd", "bwd"):
+        if kind == "bwd" and s != 1:
+            continue                      # the native backward-data covers stride 1 (stride 2 stays with the framework)
+        ref = y64 if kind == "fwd" else dx64
+        res = {}
+        for mode in (0, 1, 2, 3):
+            assert lib.istnet_conv_set_tuning(1, mode) == 0
+            out = torch.empty_like(ref, dtype=torch.float32).contiguous(memory_format=torch.channels_last)
+            ws = torch.empty(max(4, lib.istnet_conv_workspace_floats(0 if kind == "fwd" else 1, *args)), device=dev)
+            if kind == "fwd":
+                f = lambda: lib.istnet_conv_forward(*args, x.data_ptr(), w.data_ptr(), out.data_ptr(), ws.data_ptr(), st())
+            else:
+                f = lambda: lib.istnet_conv_backward_data(*args, dy.data_ptr(), w.data_ptr(), out.data_ptr(), ws.data_ptr(), st())
+            assert f() == 0
+            t = timeit(f)
+            d = (out.double() - ref)
+            res[mode] = (t, float(d.abs().max() / ref.abs().max()), float(d.pow(2).mean().sqrt()))
+        lib.istnet_conv_set_tuning(1, 0)
+        (t0, e0, r0), (t1, e1, r1) = res[0], res[1]
+        ok = e1 <= 2 * e0 and r1 <= 2 * r0
+        ok_all &= ok
+        tot[kind][0] += t0; tot[kind][1] += t1
+        print(f"{name:20s} {kind} {flop / 1e9:6.1f} GFLOP | fp32 MFMA {t0:7.1f} us {flop / t0 / 1e6:6.1f} TF err {e0:.1e} | bf16x3 {t1:7.1f} us "
+              f"{flop / t1 / 1e6:6.1f} TF err {e1:.1e} | speed-up {t0 / t1:4.2f}x  err ratio {e1 / e0:4.2f} ({r1 / r0:4.2f}) {'ok' if ok else 'GATE FAILED'}"
+              f" | variants 2: {res[2][0]:6.1f} 3: {res[3][0]:6.1f} us")
+for kind in ("fwd", "bwd"):
+    print(f"# sum over the layers, {kind}: fp32 MFMA {tot[kind][0]:7.1f} us, split {tot[kind][1]:7.1f} us ({tot[kind][0] / tot[kind][1]:4.2f}x)")
 print("# accuracy gate", "PASSED" if ok_all else "FAILED")
