@@ -303,10 +303,10 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 2) void conv_igemm_kernel
 // (mid lo, lo mid, lo lo) are <= 2^-24 |a b| each -- the size of ONE fp32 rounding of the product.  The bf16 matrix pipe runs
 // 16x the fp32 one, so six products cost 6/16 of v_mfma_f32_32x32x2_f32: the roof moves from 157 to ~417 TFLOP/s.
 // Operands are split once, when a chunk goes from registers to LDS (three bf16 planes per operand tile, rows K-contiguous,
-// 80-byte pitch); a lane's MFMA fragment is one ds_read_b128 per plane.  128 x NT tiles, one workgroup per CU (120 KB of LDS).
+// pitch KCS + 8 elements: 16-byte aligned, conflict-free 16-byte reads); a lane's MFMA fragment is one ds_read_b128 per plane.
+// 128 x NT tiles, eight waves.
 // ============================================================================================
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-constexpr int LDKH = KC + 8;          // bf16 elements per LDS row (80 bytes: 16-byte aligned, rows spread over the banks)
 
 struct Split3 { uint2 hi, mid, lo; };      // 4 consecutive k as packed bf16 pairs
 __device__ __forceinline__ Split3 split3(const float4& v) {
@@ -326,8 +326,7 @@ __device__ __forceinline__ Split3 split3(const float4& v) {
   return s;
 }
 
-template <int NT, int STRIDE, int WM, bool INTERLEAVE, int DIAG = 0, int KCS = KC, int MINW = 1>      // WM = 4: eight waves of 32 x NT/2;  WM = 2: four waves of 64 x NT/2
-// DIAG (timing experiments, wrong results): 1 no MFMAs, 2 no split / LDS writes, 3 no LDS reads, 4 no global loads
+template <int NT, int STRIDE, int WM, int KCS, int MINW>      // WM = 4: eight waves of 32 x NT/2 (WM = 2: four of 64 x NT/2, measured slower)
 __global__ __launch_bounds__(128 * WM, MINW) void conv_igemm_split_kernel(ConvGeom g, const float* __restrict__ a_src,
                                                                        const float* __restrict__ wgt, float* __restrict__ c_dst,
                                                                        float* __restrict__ ws, int chunks_per_split, int nsplits,
@@ -387,11 +386,6 @@ __global__ __launch_bounds__(128 * WM, MINW) void conv_igemm_split_kernel(ConvGe
   auto issue = [&](Stage& st, int ky, int kx, int cb) {
     const int tap = ky * g.KW + kx;
     st.ok = tap_ok;
-    if (DIAG == 4) {
-      const float f = (float)(tap + cb);
-      st.a0 = st.a1 = st.a2 = st.a3 = st.b0 = st.b1 = st.b2 = st.b3 = make_float4(f, f + 1.f, f + 2.f, f + 3.f);
-      return;
-    }
     static_for<AR>([&](auto ic) {
       constexpr int i = decltype(ic)::value;
       st_a<i>(st) = *reinterpret_cast<const float4*>(a_src + aoff[i] + (size_t)cb * KC_);
@@ -412,10 +406,6 @@ __global__ __launch_bounds__(128 * WM, MINW) void conv_igemm_split_kernel(ConvGe
   auto commit = [&](Stage& st, int buf) {
     unsigned short* as = smem_h + buf * STAGE;
     unsigned short* bs = as + 3 * A_PLANE;
-    if (DIAG == 2) {        // keep the loads alive without the split and the LDS writes
-      if (st.a0.x == 123.456f && st.b0.x == 654.321f) as[tid] = 1;
-      return;
-    }
     static_for<AR>([&](auto ic) {
       constexpr int i = decltype(ic)::value;
       put(as, A_PLANE, (tid / LPR_) + RPP * i, keep_if((st.ok >> i) & 1u, st_a<i>(st)));
@@ -441,7 +431,6 @@ __global__ __launch_bounds__(128 * WM, MINW) void conv_igemm_split_kernel(ConvGe
 #pragma unroll
       for (int mi = 0; mi < TM; ++mi) {
         const unsigned short* ap = as + mi * 32 * LDKH_ + 16 * g16;
-        if (DIAG == 3) { ah[mi] = am[mi] = al[mi] = bf16x8{}; ah[mi][0] = (__bf16)(float)lane; continue; }
         ah[mi] = *reinterpret_cast<const bf16x8*>(ap);
         am[mi] = *reinterpret_cast<const bf16x8*>(ap + A_PLANE);
         al[mi] = *reinterpret_cast<const bf16x8*>(ap + 2 * A_PLANE);
@@ -450,7 +439,6 @@ __global__ __launch_bounds__(128 * WM, MINW) void conv_igemm_split_kernel(ConvGe
 #pragma unroll
       for (int ni = 0; ni < TN; ++ni) {
         const unsigned short* bp = bs + ni * 32 * LDKH_ + 16 * g16;
-        if (DIAG == 3) { bh[ni] = bm[ni] = bl[ni] = bf16x8{}; bh[ni][0] = (__bf16)(float)lane; continue; }
         bh[ni] = *reinterpret_cast<const bf16x8*>(bp);
         bm[ni] = *reinterpret_cast<const bf16x8*>(bp + B_PLANE);
         bl[ni] = *reinterpret_cast<const bf16x8*>(bp + 2 * B_PLANE);
@@ -460,8 +448,7 @@ __global__ __launch_bounds__(128 * WM, MINW) void conv_igemm_split_kernel(ConvGe
 #define ISTNET_P(A, B)                                                                         \
   _Pragma("unroll") for (int mi = 0; mi < TM; ++mi)                                             \
     _Pragma("unroll") for (int ni = 0; ni < TN; ++ni)                                           \
-      if (DIAG != 1) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[mi], B[ni], acc[mi][ni], 0, 0, 0); \
-      else acc[mi][ni][0] += (float)A[mi][0] + (float)B[ni][0];
+      acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[mi], B[ni], acc[mi][ni], 0, 0, 0);
       ISTNET_P(al, bh) ISTNET_P(ah, bl) ISTNET_P(am, bm) ISTNET_P(am, bh) ISTNET_P(ah, bm) ISTNET_P(ah, bh)
 #undef ISTNET_P
     }
@@ -479,10 +466,11 @@ __global__ __launch_bounds__(128 * WM, MINW) void conv_igemm_split_kernel(ConvGe
   // Two stages of registers in flight (a chunk's loads are issued two MFMA phases before they are split and written to LDS;
   // four stages measured no gain: not bound by load latency), LDS double buffered, one barrier per chunk.  Past the end the
   // prefetch repeats the last chunk (loaded, never read).
-  // mma(buf) and commit(next chunk -> buf ^ 1) are INDEPENDENT (the other buffer was last read before the previous barrier),
-  // and the waves of a workgroup are all in the same phase: as two blocks, the matrix pipe idles while every wave splits and
-  // the VALU idles while every wave multiplies.  INTERLEAVE puts them in one scheduling region and asks (group barriers) for
-  // one MFMA, then a few VALU / LDS instructions, and so on.
+  // (Interleaving mma(buf) with the independent commit(next chunk -> buf ^ 1) through sched_group_barrier hints, four
+  // register stages, and four waves per workgroup all measured no gain or a loss: tools/exp/split_precision/.  The kernel is
+  // bound by the SUM of its non-MFMA work -- LDS reads 178, split + LDS writes 133, global loads 117 of 532 us on layer4 3x3,
+  // against 209 us of matrix-pipe time -- which the waves of ONE workgroup, all in the same phase, cannot overlap; with K chunks
+  // of 16 two workgroups fit a CU and their phases interleave: 532 -> 476 us.)
   Stage sa, sb;
   issue(sa, ky, kx, cb); advance();
   commit(sa, 0);
@@ -492,18 +480,8 @@ __global__ __launch_bounds__(128 * WM, MINW) void conv_igemm_split_kernel(ConvGe
     issue(snew, ky, kx, cb); advance();
     __builtin_amdgcn_sched_barrier(0);
     mma(buf);
-    if (!INTERLEAVE) __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_sched_barrier(0);
     commit(scommit, buf ^ 1);
-    if (INTERLEAVE) {
-#pragma unroll
-      for (int q = 0; q < 12 * TM * TN; ++q) {
-        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // DS read
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // MFMA
-        __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);   // VALU
-        __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);   // DS write
-      }
-      __builtin_amdgcn_sched_barrier(0);
-    }
     __syncthreads();
   };
   for (int c = 0; c < nchunks; c += 2) {
@@ -525,33 +503,6 @@ __global__ __launch_bounds__(128 * WM, MINW) void conv_igemm_split_kernel(ConvGe
     }
 }
 
-// ---- split precision, weights pre-split in global memory ("W" variant) ----
-// The first split kernel is bound by LDS traffic: three planes for BOTH operands are 208 KB of LDS reads + writes per 32-k
-// chunk against 1 536 matrix-pipe cycles.  The weights are the same for every pixel tile, so they are split ONCE per call by
-// split_weights_kernel into three bf16 planes in global memory (layout of wgt: [cout][tap][cin], rows K-contiguous), and
-// every wave loads its B fragments straight from there into registers in MFMA layout (one 16-byte load per plane, column and
-// 16-k group; the tile's weights are L2 / L1 resident and shared by the four row-waves of the workgroup), one chunk ahead.
-// Only the A operand (gathered pixels) goes through registers -> split -> LDS: a third of the LDS traffic, half of the VALU.
-// Output layout = MFMA fragment order, so that a wave's fragment load is ONE contiguous kilobyte (in the weights' own
-// [cout][tap][cin] order a lane's 16 bytes sit 2 * taps * cin bytes from its neighbour's: every load touched 32 cache lines
-// for 32 useful bytes each and the kernel ran at half the speed of the LDS variant):
-//   [column tile of 32][tap][16-k group][plane hi / mid / lo][lane = 32 (k % 16 / 8) + column % 32][8 bf16]
-__global__ __launch_bounds__(kThreads) void split_weights_kernel(long long n4, int taps, int cin, const float4* __restrict__ w,
-                                                                 unsigned short* __restrict__ dst) {
-  const long long i = (long long)blockIdx.x * kThreads + threadIdx.x;
-  if (i >= n4) return;
-  const Split3 s = split3(w[i]);
-  const long long e = 4 * i;                                  // element index in [cout][tap][cin]
-  const int k = (int)(e % cin);
-  const long long nt_ = e / cin;
-  const int tap = (int)(nt_ % taps), n = (int)(nt_ / taps);
-  const size_t frag = ((size_t)(n >> 5) * taps + tap) * (cin >> 4) + (k >> 4);
-  unsigned short* p = dst + frag * (3 * 512) + (size_t)(((k & 15) >> 3) * 32 + (n & 31)) * 8 + (k & 7);
-  *reinterpret_cast<uint2*>(p) = s.hi;
-  *reinterpret_cast<uint2*>(p + 512) = s.mid;
-  *reinterpret_cast<uint2*>(p + 1024) = s.lo;
-}
-
 // Backward-data at stride 1 IS a forward convolution of dout with the weights transposed and rotated by 180 degrees:
 //   din[b, y, x, ci] = sum_{ky', kx', co} dout[b, y - (KH - 1 - pad) + ky', x - (KW - 1 - pad) + kx', co] w'[ci][ky'][kx'][co],
 //   w'[ci][ky'][kx'][co] = w[co][KH - 1 - ky'][KW - 1 - kx'][ci]
@@ -567,173 +518,6 @@ __global__ __launch_bounds__(kThreads) void rotate_weights_kernel(int cout, int 
   const int ky = (int)(r % kh);
   const int ci = (int)(r / kh);
   wt[i] = w[(((size_t)co * kh + (kh - 1 - ky)) * kw + (kw - 1 - kx)) * cin + ci];
-}
-
-struct BFrag { bf16x8 h, m, l; };
-
-template <int NT, int STRIDE>
-__global__ __launch_bounds__(512, 1) void conv_igemm_splitw_kernel(ConvGeom g, const float* __restrict__ a_src,
-                                                                   const unsigned short* __restrict__ wsplit, long long,
-                                                                   float* __restrict__ c_dst, float* __restrict__ ws,
-                                                                   int chunks_per_split, int nsplits, int tile_m_first,
-                                                                   int tile_m_count) {
-  constexpr int MT = 128, WM = 4, WN = 2, NTHR = 512;
-  constexpr int TN = NT / (32 * WN);
-  constexpr int RPP = NTHR / LPR, AR = MT / RPP;        // 64 rows per pass, 2 float4 of A per thread
-  constexpr int A_PLANE = MT * LDKH, STAGE = 3 * A_PLANE;
-  constexpr int G16 = KC / 16;
-  static_assert(AR == 2 && TN >= 1 && TN <= 2, "128 x 128 or 128 x 64 tiles");
-  extern __shared__ __attribute__((aligned(16))) unsigned short smem_h[];       // [2][STAGE]
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  const int l31 = lane & 31, half = lane >> 5;
-  const int wm = wv / WN, wn = wv % WN;
-  (void)WM;
-  const int taps = g.KH * g.KW;
-  const int Ka = g.Cin, Ncols = g.Cout;
-  const int MH = g.OH, MW = g.OW, SH = g.H, SW = g.W;
-  const long long M = (long long)g.B * MH * MW;
-  const int tiles_n = Ncols / NT;
-  const int xcd = blockIdx.x & 7, jj = blockIdx.x >> 3;
-  const int split = jj % nsplits, jt = jj / nsplits;
-  const int tile_local = (jt / tiles_n) * 8 + xcd;
-  if (tile_local >= tile_m_count) return;
-  const long long m0 = (long long)(tile_m_first + tile_local) * MT;
-  const int n0 = (jt % tiles_n) * NT;
-  const int acol = (tid % LPR) * 4;
-  int rb[AR], ry[AR], rx[AR];
-  unsigned rvalid = 0;
-#pragma unroll
-  for (int i = 0; i < AR; ++i) {
-    const long long pm = m0 + (tid / LPR) + RPP * i;
-    const long long pc = pm < M ? pm : M - 1;
-    const int b = (int)(pc / (MH * MW));
-    const int rem = (int)(pc - (long long)b * MH * MW);
-    ry[i] = rem / MW;
-    rx[i] = rem - ry[i] * MW;
-    rb[i] = b * SH;
-    rvalid |= (pm < M ? 1u : 0u) << i;
-  }
-  const int nb = Ka / KC;
-  const int c_first = split * chunks_per_split;
-  const int nchunks = min(chunks_per_split, taps * nb - c_first);
-  size_t aoff[AR];
-  unsigned tap_ok = 0;
-  auto set_tap = [&](int ky, int kx) {
-    tap_ok = 0;
-#pragma unroll
-    for (int i = 0; i < AR; ++i) {
-      const int sy = ry[i] * STRIDE + ky - g.pad, sx = rx[i] * STRIDE + kx - g.pad;
-      const bool ok = ((rvalid >> i) & 1u) && sy >= 0 && sy < SH && sx >= 0 && sx < SW;
-      aoff[i] = ((size_t)(rb[i] + clampi(sy, 0, SH - 1)) * SW + clampi(sx, 0, SW - 1)) * Ka + acol;
-      tap_ok |= (ok ? 1u : 0u) << i;
-    }
-  };
-  // this wave's column tiles in the fragment-ordered planes (split_weights_kernel): fragment index of (tile, tap 0, k 0)
-  size_t wrow[TN];
-  const int kg_all = g.Cin >> 4;
-#pragma unroll
-  for (int ni = 0; ni < TN; ++ni) wrow[ni] = (size_t)((n0 >> 5) + wn * TN + ni) * taps * kg_all;
-  struct AStage { float4 a0, a1; unsigned ok; };
-  auto issue_a = [&](AStage& st, int cb) {
-    st.ok = tap_ok;
-    st.a0 = *reinterpret_cast<const float4*>(a_src + aoff[0] + (size_t)cb * KC);
-    st.a1 = *reinterpret_cast<const float4*>(a_src + aoff[1] + (size_t)cb * KC);
-  };
-  auto issue_b = [&](BFrag (&bf)[TN][G16], int tap, int cb) {
-#pragma unroll
-    for (int ni = 0; ni < TN; ++ni)
-#pragma unroll
-      for (int q = 0; q < G16; ++q) {
-        const unsigned short* p = wsplit + (wrow[ni] + (size_t)tap * kg_all + (size_t)cb * G16 + q) * (3 * 512) + lane * 8;
-        bf[ni][q].h = *reinterpret_cast<const bf16x8*>(p);
-        bf[ni][q].m = *reinterpret_cast<const bf16x8*>(p + 512);
-        bf[ni][q].l = *reinterpret_cast<const bf16x8*>(p + 1024);
-      }
-  };
-  auto put = [&](unsigned short* plane0, int row, const float4& v) {
-    const Split3 s = split3(v);
-    unsigned short* p = plane0 + row * LDKH + acol;
-    *reinterpret_cast<uint2*>(p) = s.hi;
-    *reinterpret_cast<uint2*>(p + A_PLANE) = s.mid;
-    *reinterpret_cast<uint2*>(p + 2 * A_PLANE) = s.lo;
-  };
-  auto commit = [&](AStage& st, int buf) {
-    unsigned short* as = smem_h + buf * STAGE;
-    put(as, (tid / LPR), keep_if(st.ok & 1u, st.a0));
-    put(as, (tid / LPR) + RPP, keep_if((st.ok >> 1) & 1u, st.a1));
-  };
-  f32x16 acc[TN];
-#pragma unroll
-  for (int ni = 0; ni < TN; ++ni)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[ni][r] = 0.f;
-  auto mma = [&](int buf, BFrag (&bf)[TN][G16]) {
-    const unsigned short* as = smem_h + buf * STAGE + (wm * 32 + l31) * LDKH + 8 * half;
-#pragma unroll
-    for (int q = 0; q < G16; ++q) {
-      const bf16x8 ah = *reinterpret_cast<const bf16x8*>(as + 16 * q);
-      const bf16x8 am = *reinterpret_cast<const bf16x8*>(as + A_PLANE + 16 * q);
-      const bf16x8 al = *reinterpret_cast<const bf16x8*>(as + 2 * A_PLANE + 16 * q);
-#pragma unroll
-      for (int ni = 0; ni < TN; ++ni) {
-        acc[ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bf[ni][q].h, acc[ni], 0, 0, 0);
-        acc[ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bf[ni][q].l, acc[ni], 0, 0, 0);
-        acc[ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bf[ni][q].m, acc[ni], 0, 0, 0);
-        acc[ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bf[ni][q].h, acc[ni], 0, 0, 0);
-        acc[ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bf[ni][q].m, acc[ni], 0, 0, 0);
-        acc[ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bf[ni][q].h, acc[ni], 0, 0, 0);
-      }
-    }
-  };
-  int ky = (c_first / nb) / g.KW, kx = (c_first / nb) % g.KW, cb = c_first % nb;
-  auto advance = [&]() {
-    if (++cb == nb) {
-      cb = 0;
-      if (++kx == g.KW) { kx = 0; ++ky; }
-      if (ky == g.KH) { ky = g.KH - 1; kx = g.KW - 1; cb = nb - 1; }
-      else set_tap(ky, kx);
-    }
-  };
-  set_tap(ky, kx);
-  // A: two register stages (loads issued two MFMA phases before the split), LDS double buffered.  B: the fragments of the
-  // chunk being multiplied and of the next one (loaded during this chunk's MFMAs).
-  AStage sa, sb;
-  BFrag b0[TN][G16], b1[TN][G16];
-  issue_a(sa, cb); issue_b(b0, ky * g.KW + kx, cb); advance();
-  commit(sa, 0);
-  issue_a(sa, cb); issue_b(b1, ky * g.KW + kx, cb); advance();       // chunk 1
-  __syncthreads();
-  for (int c = 0; c < nchunks; c += 2) {
-    issue_a(sb, cb);                      // A of chunk c + 2
-    const int tap2 = ky * g.KW + kx, cb2 = cb;
-    advance();
-    __builtin_amdgcn_sched_barrier(0);
-    mma(0, b0);                           // chunk c
-    __builtin_amdgcn_sched_barrier(0);
-    issue_b(b0, tap2, cb2);               // B of chunk c + 2 (b0 is free now)
-    commit(sa, 1);                        // chunk c + 1
-    __syncthreads();
-    if (c + 1 >= nchunks) break;
-    issue_a(sa, cb);                      // A of chunk c + 3
-    const int tap3 = ky * g.KW + kx, cb3 = cb;
-    advance();
-    __builtin_amdgcn_sched_barrier(0);
-    mma(1, b1);                           // chunk c + 1
-    __builtin_amdgcn_sched_barrier(0);
-    issue_b(b1, tap3, cb3);
-    commit(sb, 0);                        // chunk c + 2
-    __syncthreads();
-  }
-  const long long m_first = (long long)tile_m_first * MT;
-  float* dst = nsplits == 1 ? c_dst : ws + ((size_t)split * (M - m_first) - m_first) * Ncols;
-#pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const long long row = m0 + wm * 32 + mfma_row(r, lane);
-    if (row < M) {
-#pragma unroll
-      for (int ni = 0; ni < TN; ++ni) dst[(size_t)row * Ncols + n0 + (wn * TN + ni) * 32 + l31] = acc[ni][r];
-    }
-  }
 }
 
 // backward-weights: part[split][co][tap][ci] = sum over this split's output pixels of dout[p][co] * in[src(p, tap)][ci]
@@ -1029,41 +813,19 @@ static IgemmPlan igemm_plan(const ConvGeom& g, int mode) {
   return p;
 }
 
-constexpr size_t kSplitLds128 = (size_t)2 * 3 * (128 + 128) * LDKH * sizeof(unsigned short);
-constexpr size_t kSplitLds64 = (size_t)2 * 3 * (128 + 64) * LDKH * sizeof(unsigned short);
-#define ISTNET_IGEMM_SPLIT_ONE(NT, STRIDE, LDS, WMV, IL)                                                               \
+// variants: 1 = K chunks of 16 (73 KB of LDS, 128 VGPRs: two workgroups per CU, whose phases interleave) -- the default of
+// "split precision"; 2 = K chunks of 32, one workgroup per CU (A/B).  128 x 64 tiles always take the K-32 form.
+#define ISTNET_IGEMM_SPLIT_ONE(NT, STRIDE, KCS, MINW, PERMUL)                                                          \
   do {                                                                                                                 \
-    ISTNET_ALLOW_LDS((conv_igemm_split_kernel<NT, STRIDE, WMV, IL>), (LDS));                                           \
-    hipLaunchKernelGGL((conv_igemm_split_kernel<NT, STRIDE, WMV, IL>), dim3(grid), dim3(128 * WMV), (LDS),             \
-                       (hipStream_t)stream, g, a, wgt, c, ws, per, splits, first, count);                              \
+    constexpr size_t lds_ = (size_t)2 * 3 * (128 + NT) * (KCS + 8) * sizeof(unsigned short);                           \
+    ISTNET_ALLOW_LDS((conv_igemm_split_kernel<NT, STRIDE, 4, KCS, MINW>), lds_);                                       \
+    hipLaunchKernelGGL((conv_igemm_split_kernel<NT, STRIDE, 4, KCS, MINW>), dim3(grid), dim3(512), lds_,               \
+                       (hipStream_t)stream, g, a, wgt, c, ws, (PERMUL) * per, splits, first, count);                   \
   } while (0)
-constexpr size_t kSplitWLds = (size_t)2 * 3 * 128 * LDKH * sizeof(unsigned short);
-#define ISTNET_IGEMM_SPLIT_DIAG(NT, STRIDE, LDS, D)                                                                    \
+#define ISTNET_IGEMM_SPLIT(NT, STRIDE)                                                                                 \
   do {                                                                                                                 \
-    ISTNET_ALLOW_LDS((conv_igemm_split_kernel<NT, STRIDE, 4, true, D>), (LDS));                                        \
-    hipLaunchKernelGGL((conv_igemm_split_kernel<NT, STRIDE, 4, true, D>), dim3(grid), dim3(512), (LDS),                \
-                       (hipStream_t)stream, g, a, wgt, c, ws, per, splits, first, count);                              \
-  } while (0)
-// variants: 1 = both operands through LDS, eight waves, K chunks of 16 (73 KB of LDS, 128 VGPRs: two workgroups per CU, whose
-// phases interleave) -- the fastest, the one "split precision" means; 2 = the same with K chunks of 32, one workgroup per CU;
-// 3 = weights pre-split in global memory in fragment order (a third of the LDS traffic -- and slower: profiles/r05_split_precision.txt);
-// 4..7 = timing experiments (DIAG)
-#define ISTNET_IGEMM_SPLIT(NT, STRIDE, LDS)                                                                            \
-  do {                                                                                                                 \
-    if (g_conv_split == 3) {                                                                                           \
-      hipLaunchKernelGGL((conv_igemm_splitw_kernel<NT, STRIDE>), dim3(grid), dim3(512), kSplitWLds, (hipStream_t)stream, g, a, \
-                         wsplit, wplane, c, ws, per, splits, first, count);                                            \
-    } else if (g_conv_split == 2) ISTNET_IGEMM_SPLIT_ONE(NT, STRIDE, LDS, 4, true);                                    \
-    else if (g_conv_split == 1 && NT == 128) {                                                                         \
-      constexpr size_t lds16 = (size_t)2 * 3 * (128 + 128) * (16 + 8) * sizeof(unsigned short);                        \
-      ISTNET_ALLOW_LDS((conv_igemm_split_kernel<128, STRIDE, 4, true, 0, 16, 4>), lds16);                              \
-      hipLaunchKernelGGL((conv_igemm_split_kernel<128, STRIDE, 4, true, 0, 16, 4>), dim3(grid), dim3(512), lds16,      \
-                         (hipStream_t)stream, g, a, wgt, c, ws, 2 * per, splits, first, count);                        \
-    } else if (g_conv_split == 1) ISTNET_IGEMM_SPLIT_ONE(NT, STRIDE, LDS, 4, true);                                    \
-    else if (g_conv_split == 4) ISTNET_IGEMM_SPLIT_DIAG(NT, STRIDE, LDS, 1);                                           \
-    else if (g_conv_split == 5) ISTNET_IGEMM_SPLIT_DIAG(NT, STRIDE, LDS, 2);                                           \
-    else if (g_conv_split == 6) ISTNET_IGEMM_SPLIT_DIAG(NT, STRIDE, LDS, 3);                                           \
-    else ISTNET_IGEMM_SPLIT_DIAG(NT, STRIDE, LDS, 4);                                                                  \
+    if (g_conv_split == 1 && NT == 128) ISTNET_IGEMM_SPLIT_ONE(128, STRIDE, 16, 4, 2);                                 \
+    else ISTNET_IGEMM_SPLIT_ONE(NT, STRIDE, KC, 1, 1);                                                                 \
   } while (0)
 
 #define ISTNET_IGEMM(MT, NT, WM, WN, MODE, STRIDE)                                                                     \
@@ -1074,13 +836,12 @@ constexpr size_t kSplitWLds = (size_t)2 * 3 * 128 * LDKH * sizeof(unsigned short
   } while (0)
 
 static void igemm_part(const ConvGeom& g, int mode, int nt, int first, int count, int splits, int per, const float* a,
-                       const float* wgt, float* c, float* ws, void* stream, const unsigned short* wsplit = nullptr,
-                       long long wplane = 0) {
+                       const float* wgt, float* c, float* ws, void* stream) {
   const int ncols = mode == 0 ? g.Cout : g.Cin;
   const unsigned grid = (unsigned)((count + 7) / 8 * 8 * (ncols / nt) * splits);
   if (mode == 0 && g_conv_split) {
-    if (nt == 128) { if (g.stride == 1) ISTNET_IGEMM_SPLIT(128, 1, kSplitLds128); else ISTNET_IGEMM_SPLIT(128, 2, kSplitLds128); }
-    else { if (g.stride == 1) ISTNET_IGEMM_SPLIT(64, 1, kSplitLds64); else ISTNET_IGEMM_SPLIT(64, 2, kSplitLds64); }
+    if (nt == 128) { if (g.stride == 1) ISTNET_IGEMM_SPLIT(128, 1); else ISTNET_IGEMM_SPLIT(128, 2); }
+    else { if (g.stride == 1) ISTNET_IGEMM_SPLIT(64, 1); else ISTNET_IGEMM_SPLIT(64, 2); }
   } else if (mode == 0) {
     if (nt == 128) { if (g.stride == 1) ISTNET_IGEMM(128, 128, 2, 2, 0, 1); else ISTNET_IGEMM(128, 128, 2, 2, 0, 2); }
     else { if (g.stride == 1) ISTNET_IGEMM(128, 64, 4, 1, 0, 1); else ISTNET_IGEMM(128, 64, 4, 1, 0, 2); }
@@ -1099,40 +860,15 @@ static long long plan_slab_floats(const ConvGeom& g, int mode, const IgemmPlan& 
   const long long m = mode == 0 ? (long long)g.B * g.OH * g.OW : (long long)g.B * g.H * g.W;
   return (long long)plan.splits * (m - (long long)plan.rows_a * 128) * (mode == 0 ? g.Cout : g.Cin);
 }
-static long long split_weight_floats(const ConvGeom& g) {      // three bf16 planes of the weights, in floats (16-byte multiple)
-  const long long n = (long long)g.Cout * g.KH * g.KW * g.Cin;
-  return (3 * n / 2 + 3) / 4 * 4;
-}
-
 static int igemm_launch(const ConvGeom& g, int mode, const float* a, const float* wgt, float* c, float* ws, void* stream) {
   const IgemmPlan plan = igemm_plan(g, mode);
   if (plan.splits > 1 && ws == nullptr) return ISTNET_PN2_EINVAL;
-  const unsigned short* wsplit = nullptr;
-  const long long wplane = (long long)g.Cout * g.KH * g.KW * g.Cin;
-  if (mode == 0 && g_conv_split == 3) {       // the weights' three bf16 planes live behind the K-split slabs of the work space
-    if (ws == nullptr) return ISTNET_PN2_EINVAL;
-    unsigned short* dst = reinterpret_cast<unsigned short*>(ws + plan_slab_floats(g, mode, plan));
-    const long long n4 = wplane / 4;
-    hipLaunchKernelGGL(split_weights_kernel, dim3((unsigned)((n4 + kThreads - 1) / kThreads)), dim3(kThreads), 0,
-                       (hipStream_t)stream, n4, g.KH * g.KW, g.Cin, reinterpret_cast<const float4*>(wgt), dst);
-    wsplit = dst;
-    static std::atomic<unsigned long long> lds_done{0};
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    if (!(lds_done.load(std::memory_order_relaxed) & (1ull << (dev & 63)))) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_splitw_kernel<128, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kSplitWLds);
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_splitw_kernel<128, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kSplitWLds);
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_splitw_kernel<64, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kSplitWLds);
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_splitw_kernel<64, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kSplitWLds);
-      lds_done.fetch_or(1ull << (dev & 63), std::memory_order_relaxed);
-    }
-  }
   const int ncols = mode == 0 ? g.Cout : g.Cin, kch = mode == 0 ? g.Cin : g.Cout;
   const long long m = mode == 0 ? (long long)g.B * g.OH * g.OW : (long long)g.B * g.H * g.W;
   const int nchunks = g.KH * g.KW * (kch / KC);
-  if (plan.rows_a > 0) igemm_part(g, mode, plan.nt, 0, plan.rows_a, 1, nchunks, a, wgt, c, ws, stream, wsplit, wplane);
+  if (plan.rows_a > 0) igemm_part(g, mode, plan.nt, 0, plan.rows_a, 1, nchunks, a, wgt, c, ws, stream);
   if (plan.rows_b > 0) {
-    igemm_part(g, mode, plan.nt, plan.rows_a, plan.rows_b, plan.splits, plan.per, a, wgt, c, ws, stream, wsplit, wplane);
+    igemm_part(g, mode, plan.nt, plan.rows_a, plan.rows_b, plan.splits, plan.per, a, wgt, c, ws, stream);
     if (plan.splits > 1) {
       const long long m_first = (long long)plan.rows_a * 128;
       const long long n4 = (m - m_first) * ncols / 4;
@@ -1150,12 +886,10 @@ int istnet_conv_workspace_floats(int backward_data, int b, int h, int w, int cin
   const ConvGeom g = make_geom(b, h, w, cin, cout, kh, kw, stride, pad);
   const IgemmPlan plan = igemm_plan(g, backward_data ? 1 : 0);
   long long n = plan_slab_floats(g, backward_data ? 1 : 0, plan);
-  if (!backward_data && g_conv_split == 3) n += split_weight_floats(g);      // the pre-split weights (split-precision forward)
   if (backward_data && g_conv_split && stride == 1) {
     // split precision: backward-data runs as a forward product of dout with the rotated weights (rotated copy + that plan's slabs)
     const ConvGeom gt = make_geom(b, g.OH, g.OW, cout, cin, kh, kw, 1, kh - 1 - pad);
     n = plan_slab_floats(gt, 0, igemm_plan(gt, 0)) + (long long)cout * cin * kh * kw;
-    if (g_conv_split == 3) n += split_weight_floats(gt);
   }
   return n < (1ll << 31) ? (int)n : -1;
 }
@@ -1179,8 +913,7 @@ int istnet_conv_backward_data(int b, int h, int w, int cin, int cout, int kh, in
     const ConvGeom gt = make_geom(b, g.OH, g.OW, cout, cin, kh, kw, 1, kh - 1 - pad);     // its output is (b, h, w, cin)
     if (gt.OH != h || gt.OW != w) return ISTNET_PN2_EINVAL;
     const long long nw = (long long)cout * cin * kh * kw;
-    long long slabs = plan_slab_floats(gt, 0, igemm_plan(gt, 0));
-    if (g_conv_split == 3) slabs += split_weight_floats(gt);
+    const long long slabs = plan_slab_floats(gt, 0, igemm_plan(gt, 0));
     float* wt = ws + slabs;                                                              // behind the forward launch's own work space
     hipLaunchKernelGGL(rotate_weights_kernel, dim3((unsigned)((nw + kThreads - 1) / kThreads)), dim3(kThreads), 0,
                        (hipStream_t)stream, cout, cin, kh, kw, wgt, wt);

@@ -1213,555 +1213,6 @@ def _finish_layer0_grads(lib, dev, b, cfeat, cout0_tot, n_src, feat, gbuf, ident
         work(torch.cuda.current_stream(dev).cuda_stream)
 
 
-class FusedFPFunction(Function):
-    """Feature propagation: ``mlp(cat([three_interpolate(known_feats, idx, weight), skip]))`` as one node
-    (reference pointnet2_modules.py:185-209), with layer 0 split by linearity.  With W0 = [Wa | Wb]:
-
-        y0 = Wa . interp(K) + Wb . S = interp(Wa . K) + Wb . S
-
-    so the product with the interpolated part runs over the m KNOWN points (m = n/2 in the encoder) and the
-    interpolation acts on the layer's output width; the concatenated input never exists.  Backward, with
-    G' = interp_grad(dY0):  dK = Wa^T . G',  dWa = G' . K^T (both over m points),  dS = Wb^T . dY0,
-    dWb = dY0 . S^T (over n points, skip columns only).
-
-    known_feats (B, C2, m), skip (B, C1, n) or None, idx / weight (B, n, 3), csr = _ext.interp_csr(idx, m) or None."""
-
-    @staticmethod
-    def forward(ctx, known_feats, skip, idx, weight, csr, training, layers, known_bn, lazy_out, *params):
-        # known_bn: None, or the BatchNorm constant block (4, C2) of the stack that produced ``known_feats`` as its RAW last
-        #   output (a LazyAct): the loaders of the products over the known points apply relu(scale y + shift) themselves;
-        # lazy_out: return (raw last output, its constant block) instead of the activated tensor (see LazyAct)
-        from . import _ext
-        lib = _native.lib()
-        dev = known_feats.device
-        known = known_feats.contiguous()
-        ksc, ksh = (known_bn[0].data_ptr(), known_bn[1].data_ptr()) if known_bn is not None else (None, None)
-        skip_c = skip.contiguous() if skip is not None else None
-        b, c2, m = known.shape
-        n = idx.shape[1]
-        c1 = skip_c.shape[1] if skip_c is not None else 0
-        w0, gamma0, beta0 = params[0], params[1], params[2]
-        cout0, cin = w0.shape[0], c2 + c1
-        w2 = w0.reshape(cout0, cin)
-        lay0 = layers[0]
-        with torch.cuda.device(dev):
-            st = _st(dev)
-            zk = _empty((b, cout0, m), torch.float32, dev)
-            _native.check(_native.timed(
-                _fwd_ld_kname(lib, b, c2, cout0, m), 2.0 * b * m * c2 * cout0,
-                4.0 * b * m * (c2 + cout0), lambda: lib.istnet_pw_forward_ld(
-                    b, c2, cout0, m, known.data_ptr(), w2.data_ptr(), cin, ksc, ksh, zk.data_ptr(), None, None,
-                    st)), "pw_forward_ld(fp)")
-            fuse_interp = (skip_c is not None and lib.istnet_pw_forward_cfg(b, c1, cout0, n) == 1
-                           and idx.dtype == torch.int32 and idx.is_contiguous() and weight.is_contiguous())
-            t = None if fuse_interp else _ext.three_interpolate(zk, idx, weight)               # (B, cout0, n)
-            bn0 = _empty((4, cout0), torch.float32, dev)
-            part = None
-            if fuse_interp:
-                # small launch: the interpolation of zk is evaluated in the epilogue of the skip-connection product
-                y0 = _empty((b, cout0, n), torch.float32, dev)
-                if training:
-                    nt = lib.istnet_pw_forward_ld_tiles(b, c1, cout0, n)
-                    part = _empty((2, cout0, nt), torch.float32, dev)
-                _native.check(_native.timed(
-                    "pw_fwd_sk_kernel", 2.0 * b * n * c1 * cout0, 4.0 * b * n * (c1 + cout0),
-                    lambda: lib.istnet_pw_forward_acc_interp(
-                        b, c1, cout0, n, skip_c.data_ptr(), w2.data_ptr() + 4 * c2, cin, zk.data_ptr(), m, idx.data_ptr(),
-                        weight.data_ptr(), y0.data_ptr(), _p(part[0]) if training else None,
-                        _p(part[1]) if training else None, st)), "pw_forward_acc_interp")
-            elif skip_c is not None:
-                y0 = _empty((b, cout0, n), torch.float32, dev)
-                if training:
-                    nt = lib.istnet_pw_forward_ld_tiles(b, c1, cout0, n)
-                    part = _empty((2, cout0, nt), torch.float32, dev)
-                _native.check(_native.timed(
-                    _fwd_ld_kname(lib, b, c1, cout0, n), 2.0 * b * n * c1 * cout0,
-                    4.0 * b * n * (c1 + 2 * cout0), lambda: lib.istnet_pw_forward_acc(
-                        b, c1, cout0, n, skip_c.data_ptr(), w2.data_ptr() + 4 * c2, cin, t.data_ptr(), y0.data_ptr(),
-                        _p(part[0]) if training else None, _p(part[1]) if training else None, st)), "pw_forward_acc")
-            else:
-                y0 = t
-                if training:
-                    nt = lib.istnet_pw_bwd_stat_tiles(b, n)
-                    part = _empty((2, cout0, nt), torch.float32, dev)
-                    _native.check(lib.istnet_pw_channel_stats(b, cout0, n, y0.data_ptr(), part[0].data_ptr(),
-                                                              part[1].data_ptr(), st), "pw_channel_stats")
-            if training:
-                _native.check(lib.istnet_bn_finalize_fwd(
-                    cout0, nt, float(b * n), part[0].data_ptr(), part[1].data_ptr(), gamma0.data_ptr(), beta0.data_ptr(),
-                    float(lay0.eps), lay0.momentum_ptr, _p(lay0.running_mean), _p(lay0.running_var),
-                    bn0.data_ptr(), st), "bn_finalize_fwd")
-            else:
-                _native.check(lib.istnet_affine_consts(cout0, gamma0.data_ptr(), beta0.data_ptr(),
-                                                       lay0.running_mean.data_ptr(), lay0.running_var.data_ptr(),
-                                                       float(lay0.eps), bn0.data_ptr(), st), "affine_consts")
-            out, _, ys, bns = _forward_stack(lib, dev, st, b, cin, n, 1, None, None, training, layers, params,
-                                             start=(y0, bn0), tail=not lazy_out)
-        ctx.training, ctx.dims, ctx.n_layers, ctx.has_skip, ctx.csr = training, (b, c2, c1, m, n), len(layers), \
-            skip_c is not None, csr
-        ctx.has_known_bn = known_bn is not None
-        ctx.save_for_backward(known, skip_c if skip_c is not None else torch.empty(0, device=dev), idx, weight,
-                              known_bn if known_bn is not None else torch.empty(0, device=dev), *ys, *bns, *params)
-        if lazy_out:
-            ctx.mark_non_differentiable(bns[-1])
-            ctx.set_materialize_grads(False)      # no zero-filled "gradient" of the constant block (a fill launch per level)
-            return ys[-1], bns[-1]
-        return out
-
-    @staticmethod
-    def backward(ctx, dout, *_unused):
-        from . import _ext
-        lib = _native.lib()
-        b, c2, c1, m, n = ctx.dims
-        nl = ctx.n_layers
-        sv = ctx.saved_tensors
-        if dout is None:                          # (only without materialised gradients: the output was not used)
-            dout = torch.zeros_like(sv[5 + nl - 1])
-        known, skip, idx, weight = sv[0], (sv[1] if ctx.has_skip else None), sv[2], sv[3]
-        known_bn = sv[4] if ctx.has_known_bn else None
-        ys, bns, params = sv[5:5 + nl], sv[5 + nl:5 + 2 * nl], sv[5 + 2 * nl:]
-        dev = known.device
-        _enter_backward(dev)
-        cin = c2 + c1
-        w0 = params[0]
-        cout0 = w0.shape[0]
-        w2 = w0.reshape(cout0, cin)
-        _native.mark(f"bwd FP(n={n}) start")
-        need_known, need_skip = ctx.needs_input_grad[0], ctx.has_skip and ctx.needs_input_grad[1]
-        need_w = [ctx.needs_input_grad[9 + 3 * li] for li in range(nl)]
-        result = {}
-
-        def layer0(y0, d_a0, bn0, bwdc0, grads, wextra):
-            st = _st(dev)
-            ident, ibw = _ident_consts(dev, cout0)          # mask always on, dY = g: products of a given dY
-            # dY0 = BatchNorm / ReLU backward of dA0.  With the inverse lists of the taps at hand nobody needs it as a
-            # tensor: the interpolation gradient forms it per gathered element (istnet_interp_grad_csr_dy) and the GEMM
-            # loaders form it from (y0, dA0, constants) as they do in every other layer -- one launch less on the chain.
-            raw_pair = ctx.csr is not None
-            if raw_pair:
-                dy_y, dy_d, dy_bn, dy_bw = y0, d_a0, bn0, bwdc0
-            else:
-                dy0 = _empty((b, cout0, n), torch.float32, dev)
-                _native.check(lib.istnet_pw_dy(b, cout0, n, y0.data_ptr(), d_a0.data_ptr(), bn0.data_ptr(),
-                                               bwdc0.data_ptr(), dy0.data_ptr(), st), "pw_dy")
-                dy_y, dy_d, dy_bn, dy_bw = dy0, dy0, ident, ibw
-            # The skip gradient feeds the set-abstraction backward much later; the interpolation gradient feeds the next
-            # (coarser) propagation level at once.  So the skip dgrad leaves the chain: it runs on a side stream beside
-            # the interpolation scatter and the known-feature dgrad, joined before this node returns.
-            streams = _scale_streams(dev, 2) if (need_skip and (need_known or need_w[0])) \
-                else [torch.cuda.current_stream(dev)] * 2
-            if need_skip:
-                ds = _empty((b, c1, n), torch.float32, dev)
-                with torch.cuda.stream(streams[1]):
-                    sst = _st(dev)
-                    _native.check(_native.timed(
-                        _dgrad_kname(lib, b, c1, cout0, n, dense=True), 2.0 * b * n * c1 * cout0,
-                        4.0 * b * n * (c1 + cout0), lambda: lib.istnet_pw_dgrad(
-                            b, cin, c2, c1, cout0, n, 0, w2.data_ptr(), dy_y.data_ptr(), dy_d.data_ptr(), None, 0, None,
-                            dy_bn.data_ptr(), dy_bw.data_ptr(), ds.data_ptr(), None, None, None, None, sst)),
-                        "pw_dgrad(fp skip)")
-                result["dskip"] = ds
-            gk = None
-            if need_known or need_w[0]:
-                if raw_pair:
-                    gk = _empty((b, cout0, m), torch.float32, dev)                                  # (B, cout0, m)
-                    _native.check(lib.istnet_interp_grad_csr_dy(
-                        b, cout0, n, m, y0.data_ptr(), d_a0.data_ptr(), bn0.data_ptr(), bwdc0.data_ptr(), weight.data_ptr(),
-                        ctx.csr[0].data_ptr(), ctx.csr[1].data_ptr(), gk.data_ptr(), st), "interp_grad_csr_dy")
-                else:
-                    gk = (_ext.three_interpolate_grad(dy0, idx, weight, m, ctx.csr) if ctx.csr is not None
-                          else _ext.three_interpolate_grad(dy0, idx, weight, m))
-            if need_known:
-                dk = _empty((b, c2, m), torch.float32, dev)
-                _native.check(_native.timed(
-                    _dgrad_kname(lib, b, c2, cout0, m, dense=True), 2.0 * b * m * c2 * cout0,
-                    4.0 * b * m * (c2 + cout0), lambda: lib.istnet_pw_dgrad(
-                        b, cin, 0, c2, cout0, m, 0, w2.data_ptr(), gk.data_ptr(), gk.data_ptr(), None, 0, None,
-                        ident.data_ptr(), ibw.data_ptr(), dk.data_ptr(), None, None, None, None, st)),
-                    "pw_dgrad(fp known)")
-                result["dknown"] = dk
-            if need_w[0]:
-                dest = _grad_dest(w0, (cout0, cin), dev)
-                grads[0] = dest.view_as(w0)
-                ksc, ksh = (known_bn[0].data_ptr(), known_bn[1].data_ptr()) if known_bn is not None else (None, None)
-
-                def wjob(wst):
-                    sp_a = lib.istnet_pw_wgrad_splits(b, c2, cout0, m)
-                    ws_a = _empty((sp_a, cout0, c2), torch.float32, dev)
-                    _native.check(_native.timed(
-                        _kname("pw_wgrad_kernel", lib.istnet_pw_wgrad_tile_cfg(b, c2, cout0, m), 0),
-                        2.0 * b * m * c2 * cout0, 4.0 * b * m * (c2 + cout0), lambda: lib.istnet_pw_wgrad(
-                            b, c2, cout0, m, 0, known.data_ptr(), ksc, ksh, gk.data_ptr(), gk.data_ptr(), None, 0,
-                            None, ident.data_ptr(), ibw.data_ptr(), ws_a.data_ptr(), wst)), "pw_wgrad(fp known)")
-                    red = [(cout0 * c2, sp_a, ws_a.data_ptr(), dest.data_ptr(), c2, cin, cout0 * c2)]
-                    keep = [ws_a]
-                    if skip is not None:
-                        sp_b = lib.istnet_pw_wgrad_splits(b, c1, cout0, n)
-                        ws_b = _empty((sp_b, cout0, c1), torch.float32, dev)
-                        _native.check(_native.timed(
-                            _kname("pw_wgrad_kernel", lib.istnet_pw_wgrad_tile_cfg(b, c1, cout0, n), 0),
-                            2.0 * b * n * c1 * cout0, 4.0 * b * n * (c1 + cout0), lambda: lib.istnet_pw_wgrad(
-                                b, c1, cout0, n, 0, skip.data_ptr(), None, None, dy_y.data_ptr(), dy_d.data_ptr(), None,
-                                0, None, dy_bn.data_ptr(), dy_bw.data_ptr(), ws_b.data_ptr(), wst)), "pw_wgrad(fp skip)")
-                        red.append((cout0 * c1, sp_b, ws_b.data_ptr(), dest.data_ptr() + 4 * c2, c1, cin, cout0 * c1))
-                        keep += [ws_b]
-                    _native.reduce_multi(red, wst)     # both column blocks of dW0 in place: no concatenation
-                    return keep, dy_y, dy_d, dy_bn, dy_bw, gk, known_bn
-                wextra.append(wjob)
-            _join_streams(streams)
-            return None
-
-        with torch.cuda.device(dev):
-            # the fused mid-size backward kernel takes 128 workgroups by default -- half the chip, because in the
-            # set-abstraction phases two or three scale chains run side by side; a feature-propagation level is ONE chain
-            # (with the deferred weight gradients beside it): 256 workgroups there, 2.562 -> 2.543 ms on the step
-            saved = lib.istnet_pw_get_tuning(8)
-            if FP_BWD_MID_WORKGROUPS:
-                lib.istnet_pw_set_tuning(8, FP_BWD_MID_WORKGROUPS)
-            try:
-                grads, _, _ = _backward_stack(lib, dev, _st(dev), b, cin, n, 1, None, None, ctx.training, ys, bns, params,
-                                              None, dout.contiguous(), need_w, True, layer0_hook=layer0)
-            finally:
-                lib.istnet_pw_set_tuning(8, saved)
-            _native.mark(f"bwd FP(n={n}) chain done")
-        return (result.get("dknown"), result.get("dskip"), None, None, None, None, None, None, None, *grads)
-
-
-class LazyAct:
-    """The output of a fused stack BEFORE its last BatchNorm + ReLU: ``raw`` (B, C, n) and the constant block ``bn``
-    (4, C: scale, shift, mean, invstd).  Consumers that stage their operands through a loader (the products over the known
-    points of the next feature-propagation level) apply relu(scale y + shift) there, so the activated tensor is never
-    written or read back and its launch leaves the forward chain.  In the autograd graph ``raw`` STANDS FOR the activated
-    values: the gradient that reaches it is the gradient with respect to relu(bn(raw)) -- exactly what the producing
-    node's backward expects.  ``materialize()`` gives the activated tensor to a consumer that needs one."""
-    __slots__ = ("raw", "bn")
-
-    def __init__(self, raw, bn):
-        self.raw, self.bn = raw, bn
-
-    def materialize(self):
-        return _MaterializeFn.apply(self.raw, self.bn)
-
-
-class _MaterializeFn(Function):
-    @staticmethod
-    def forward(ctx, raw, bn):
-        lib = _native.lib()
-        b, c, n = raw.shape
-        out = _empty((b, c, n), torch.float32, raw.device)
-        with torch.cuda.device(raw.device):
-            _native.check(lib.istnet_bn_relu_pool(b, c, n, 1, raw.data_ptr(), bn.data_ptr(), out.data_ptr(), 0, None, None,
-                                                  _st(raw.device)), "bn_relu_pool")
-        return out
-
-    @staticmethod
-    def backward(ctx, dout):
-        return dout, None          # raw stands for the activated values (see LazyAct)
-
-
-def fp_level(mlp, known_feats, skip, idx, weight, csr=None, lazy_out=False):
-    """``mlp(cat([three_interpolate(known_feats, idx, weight), skip], 1).unsqueeze(-1)).squeeze(-1)`` through the
-    fused node when shapes allow; None otherwise (the caller then runs the reference composition)."""
-    known_bn = None
-    if isinstance(known_feats, LazyAct):
-        known_feats, known_bn = known_feats.raw, known_feats.bn
-    if not (known_feats.is_cuda and known_feats.dtype == torch.float32):
-        return None
-    n, m = idx.shape[1], known_feats.shape[2]
-    if skip is not None and not (skip.is_cuda and skip.dtype == torch.float32 and skip.shape[2] == n):
-        return None
-    c1 = skip.shape[1] if skip is not None else 0
-    if m % 32 or n % 32 or known_feats.shape[1] % 4 or c1 % 4 or not _fusable_shape(mlp, n, 1):
-        _note_fallback(f"feature propagation with n={n}, m={m}, channels {known_feats.shape[1]}+{c1}: needs n, m % 32 == 0, "
-                       "channels % 4 == 0 and a plain conv1x1/BatchNorm/ReLU stack")
-        return None
-    layers, params = _layer_args(mlp)
-    out = FusedFPFunction.apply(known_feats, skip, idx, weight, csr, mlp.training, layers, known_bn, bool(lazy_out), *params)
-    if mlp.training:
-        _bump_counters(list(mlp))
-    return LazyAct(*out) if lazy_out else out
-
-
-_ONES = {}
-
-
-def _ones(dev, c):
-    key = (dev.index, c)
-    if key not in _ONES:
-        _ONES[key] = torch.ones(c, dtype=torch.float32, device=dev)
-    return _ONES[key]
-
-
-class FusedBiasMLPFunction(Function):
-    """x (B, C0, N) -> (B, C_L, N): stack of Conv1d(k=1) + bias (+ ReLU) layers -- the per-point MLPs of the
-    IST head and the pose heads (reference model/ist_net.py:130-160, 206-248, 271-316).
-
-    Same kernels as the BatchNorm stack with constant "BN" blocks (scale 1, shift = bias): each layer is
-    one MFMA GEMM whose operand loader applies the previous layer's bias + ReLU; backward uses
-    dY = g, dbias = sum g.  ``relu_last`` tells whether the last conv is followed by a ReLU."""
-
-    @staticmethod
-    def forward(ctx, x, relu_last, *params):          # params = [w0, b0, w1, b1, ...]
-        lib = _native.lib()
-        dev = x.device
-        b, c0, npts = x.shape
-        x = x.contiguous()
-        n = len(params) // 2
-        layers = [_Layer(None, relu=(relu_last or li < n - 1)) for li in range(n)]
-        ones = [_ones(dev, params[2 * li].shape[0]) for li in range(n)]   # stand-in "gamma" of a bias layer
-        flat = []
-        for li in range(n):
-            flat += [params[2 * li], ones[li], params[2 * li + 1]]
-        with torch.cuda.device(dev):
-            out, _, ys, bns = _forward_stack(lib, dev, _st(dev), b, c0, npts, 1, x, None, False, layers, flat)
-        ctx.shape = (b, c0, npts)
-        ctx.n_layers = n
-        ctx.save_for_backward(x, *ys, *bns, *flat)
-        return out
-
-    @staticmethod
-    def backward(ctx, dout):
-        lib = _native.lib()
-        b, c0, npts = ctx.shape
-        n = ctx.n_layers
-        saved = ctx.saved_tensors
-        x = saved[0]
-        ys, bns, flat = saved[1:1 + n], saved[1 + n:1 + 2 * n], saved[1 + 2 * n:]
-        dev = x.device
-        _enter_backward(dev)
-        need_w = [ctx.needs_input_grad[2 + 2 * li] for li in range(n)]
-        with torch.cuda.device(dev), _head_stack():
-            grads, dx, _ = _backward_stack(lib, dev, _st(dev), b, c0, npts, 1, x, None, False, ys, bns, flat,
-                                           None, dout.contiguous(), need_w, ctx.needs_input_grad[0])
-        out = []
-        for li in range(n):
-            dw = grads[3 * li]
-            out += [dw.view_as(flat[3 * li]) if dw is not None else None, grads[3 * li + 2]]   # dW, dbias
-        return (dx, None, *out)
-
-
-class FusedMultiSourceBiasMLPFunction(Function):
-    """Per-point Conv1d(k=1) + bias (+ ReLU) stack whose input is the channel concatenation of several tensors
-    (B, C_i, N) -- optionally followed by the per-cloud mean of the (single) source expanded over the points -- WITHOUT
-    building that input.  The IST head and the pose heads concatenate 3-5 feature tensors, or a feature map with its
-    global mean, in front of every stack (reference model/ist_net.py:167-175,253-257,322-325: up to 512 channels x
-    32 768 points = 67 MB per concat, written and read back).  Here layer 0 walks the sources in its K loop
-    (istnet_pw_forward_multi), and with W0 = [Wa | Wb] the mean part is the rank-1 per-cloud bias Wb . mean(feat):
-
-        y0 = sum_i W0[:, slice_i] . src_i  (+ (Wb . mean_b)[:, None])  + bias
-
-    Backward: d src_i = W0[:, slice_i]^T . dY0 and dW0[:, slice_i] = dY0 . src_i^T per source (existing dgrad / wgrad
-    kernels on the slices); the mean term adds Wb^T . (sum_p dY0) / N to every point of the cloud and
-    dWb = sum_b (sum_p dY0[b]) (x) mean_b, with the per-cloud sums of dY0 taken from the statistics partials the
-    layer-1 dgrad already produced.  tensors = [src_0 .. src_{k-1}, w0, b0, w1, b1, ...]."""
-
-    @staticmethod
-    def forward(ctx, nsrc, with_mean, relu_last, pool_mean, *tensors):
-        # pool_mean: return the mean over the points of the stack's (ReLU) output, (B, C_L) -- the AdaptiveAvgPool1d(1) that
-        # ends pose_mlp2 (model/ist_net.py:246,314) -- from the last RAW output in one pass (istnet_bn_relu_mean): the
-        # (B, C_L, N) activation is neither written nor read back
-        import ctypes
-        lib = _native.lib()
-        srcs = [t.contiguous() for t in tensors[:nsrc]]
-        params = tensors[nsrc:]
-        dev = srcs[0].device
-        b, _, npts = srcs[0].shape
-        chans = [t.shape[1] for t in srcs]
-        csum = sum(chans)
-        n = len(params) // 2
-        w0, b0 = params[0], params[1]
-        cout0, cin_total = w0.shape[0], w0.shape[1]
-        w2 = w0.reshape(cout0, cin_total)
-        layers = [_Layer(None, relu=(relu_last or li < n - 1)) for li in range(n)]
-        ones = [_ones(dev, params[2 * li].shape[0]) for li in range(n)]
-        flat = []
-        for li in range(n):
-            flat += [params[2 * li], ones[li], params[2 * li + 1]]
-        with torch.cuda.device(dev):
-            st = _st(dev)
-            mean = row_init = None
-            if with_mean:
-                mean = srcs[0].mean(dim=2)                               # (B, C)
-                row_init = torch.matmul(mean, w2[:, csum:].t()).contiguous()   # (B, cout0) = (Wb . mean_b)^T
-            y0 = _empty((b, cout0, npts), torch.float32, dev)
-            _native.check(lib.istnet_pw_forward_multi(
-                b, nsrc, (ctypes.c_void_p * nsrc)(*[t.data_ptr() for t in srcs]), (ctypes.c_int * nsrc)(*chans), cout0,
-                npts, w2.data_ptr(), cin_total, _p(row_init), y0.data_ptr(), st), "pw_forward_multi")
-            bn0 = _empty((4, cout0), torch.float32, dev)
-            _native.check(lib.istnet_affine_consts(cout0, None, b0.data_ptr(), None, None, 0.0, bn0.data_ptr(), st),
-                          "affine_consts")
-            out, _, ys, bns = _forward_stack(lib, dev, st, b, cin_total, npts, 1, None, None, False, layers, flat,
-                                             start=(y0, bn0), tail=not pool_mean)
-            if pool_mean:
-                c_last = flat[-3].shape[0]
-                out = _empty((b, c_last), torch.float32, dev)
-                _native.check(lib.istnet_bn_relu_mean(b, c_last, npts, ys[-1].data_ptr(), bns[-1].data_ptr(), out.data_ptr(),
-                                                      st), "bn_relu_mean")
-        ctx.meta = (nsrc, with_mean, b, npts, chans, n)
-        ctx.pool_mean = pool_mean
-        ctx.save_for_backward(*srcs, mean if mean is not None else torch.empty(0, device=dev), *ys, *bns, *flat)
-        return out
-
-    @staticmethod
-    def backward(ctx, dout):
-        lib = _native.lib()
-        nsrc, with_mean, b, npts, chans, n = ctx.meta
-        sv = ctx.saved_tensors
-        srcs, mean = sv[:nsrc], sv[nsrc]
-        ys, bns, flat = sv[nsrc + 1:nsrc + 1 + n], sv[nsrc + 1 + n:nsrc + 1 + 2 * n], sv[nsrc + 1 + 2 * n:]
-        dev = srcs[0].device
-        _enter_backward(dev)
-        w0 = flat[0]
-        cout0, cin_total = w0.shape[0], w0.shape[1]
-        w2 = w0.reshape(cout0, cin_total)
-        csum = sum(chans)
-        need_src = [ctx.needs_input_grad[4 + i] for i in range(nsrc)]
-        need_w = [ctx.needs_input_grad[4 + nsrc + 2 * li] for li in range(n)]
-        dsrc = [None] * nsrc
-
-        def layer0(y0, d_a0, bn0, bwdc0, grads, wextra, part, nt_l):
-            st = _st(dev)
-            off = 0
-            for i, (src, c) in enumerate(zip(srcs, chans)):
-                if need_src[i]:
-                    dx = _empty((b, c, npts), torch.float32, dev)
-                    _native.check(_native.timed(
-                        _dgrad_kname(lib, b, c, cout0, npts), 2.0 * b * npts * c * cout0, 4.0 * b * npts * (c + 2 * cout0),
-                        lambda: lib.istnet_pw_dgrad(b, cin_total, off, c, cout0, npts, 0, w2.data_ptr(), y0.data_ptr(),
-                                                    d_a0.data_ptr(), None, 0, None, bn0.data_ptr(), bwdc0.data_ptr(),
-                                                    dx.data_ptr(), None, None, None, None, st)), "pw_dgrad(head source)")
-                    dsrc[i] = dx
-                off += c
-            s_cb = None
-            if with_mean:
-                # per-cloud sums of dY0 from the statistics partials ([cout0][b * tiles], a cloud's tiles contiguous)
-                s_cb = part[0].view(cout0, b, nt_l // b).sum(dim=2)          # (cout0, b)
-                if need_src[0]:
-                    dmean = torch.matmul(w2[:, csum:].t(), s_cb)              # (C, b) = Wb^T . sum_p dY0
-                    dsrc[0].add_(dmean.t().unsqueeze(2), alpha=1.0 / npts)
-            if need_w[0]:
-                dest = _grad_dest(w0, (cout0, cin_total), dev)
-                grads[0] = dest.view_as(w0)
-
-                def wjob(wst):
-                    red, keep, coff = [], [], 0
-                    for src, c in zip(srcs, chans):
-                        sp = lib.istnet_pw_wgrad_splits(b, c, cout0, npts)
-                        ws = _empty((sp, cout0, c), torch.float32, dev)
-                        _native.check(_native.timed(
-                            _kname("pw_wgrad_kernel", lib.istnet_pw_wgrad_tile_cfg(b, c, cout0, npts), 0),
-                            2.0 * b * npts * c * cout0, 4.0 * b * npts * (c + 2 * cout0), lambda: lib.istnet_pw_wgrad(
-                                b, c, cout0, npts, 0, src.data_ptr(), None, None, y0.data_ptr(), d_a0.data_ptr(), None, 0,
-                                None, bn0.data_ptr(), bwdc0.data_ptr(), ws.data_ptr(), wst)), "pw_wgrad(head source)")
-                        red.append((cout0 * c, sp, ws.data_ptr(), dest.data_ptr() + 4 * coff, c, cin_total, cout0 * c))
-                        keep.append(ws)
-                        coff += c
-                    _native.reduce_multi(red, wst)     # every source's column block of dW0 in place
-                    parts = []
-                    if with_mean:
-                        parts.append(torch.matmul(s_cb, mean))               # dWb = sum_b (sum_p dY0[b]) (x) mean_b
-                        dest[:, csum:].copy_(parts[0])
-                    return keep, parts, y0, d_a0, s_cb
-                wextra.append(wjob)
-            return None
-        layer0.takes_partials = True
-
-        with torch.cuda.device(dev):
-            dout = dout.contiguous()
-            if ctx.pool_mean:          # adjoint of the mean over the points: a dense gradient g[b, c] / N for the stack
-                c_last = flat[-3].shape[0]
-                dense = _empty((b, c_last, npts), torch.float32, dev)
-                _native.check(lib.istnet_expand_rows(b * c_last, npts, dout.data_ptr(), dense.data_ptr(), _st(dev)),
-                              "expand_rows")
-                dout = dense
-            with _head_stack():
-                grads, _, _ = _backward_stack(lib, dev, _st(dev), b, cin_total, npts, 1, None, None, False, ys, bns, flat,
-                                              None, dout, need_w, True, layer0_hook=layer0)
-        out = []
-        for li in range(n):
-            dw = grads[3 * li]
-            out += [dw.view_as(flat[3 * li]) if dw is not None else None, grads[3 * li + 2]]
-        return (None, None, None, None, *dsrc, *out)
-
-
-def pointwise_conv_stack_multi(seq, sources, with_mean=False, pool_mean=False):
-    """``seq(cat(sources [+ mean of the single source expanded], dim=1))`` for an ``nn.Sequential`` of
-    [Conv1d(k=1) (+ ReLU)]* without building the concatenation on CUDA (FusedMultiSourceBiasMLPFunction); anything the
-    fused form does not cover builds the input and runs ``pointwise_conv_stack``."""
-    def build():
-        x = torch.cat(list(sources), dim=1) if len(sources) > 1 else sources[0]
-        if with_mean:
-            x = torch.cat([x, x.mean(dim=2, keepdim=True).expand_as(x)], dim=1)
-        return x
-    mods = list(seq)
-    convs, relu_after, i = [], [], 0
-    ok = (all(t.is_cuda and t.dtype == torch.float32 and t.dim() == 3 for t in sources)
-          and len(sources) <= 6 and all(t.shape[1] % 16 == 0 for t in sources) and sources[0].shape[2] % 32 == 0
-          and all(t.shape[0] == sources[0].shape[0] and t.shape[2] == sources[0].shape[2] for t in sources)
-          and (not with_mean or len(sources) == 1))
-    while ok and i < len(mods):
-        m = mods[i]
-        if not (isinstance(m, torch.nn.Conv1d) and m.kernel_size == (1,) and m.stride == (1,) and m.padding == (0,)
-                and m.groups == 1 and m.bias is not None):
-            ok = False
-            break
-        has_relu = i + 1 < len(mods) and isinstance(mods[i + 1], torch.nn.ReLU)
-        convs.append(m)
-        relu_after.append(has_relu)
-        i += 2 if has_relu else 1
-    csum = sum(t.shape[1] for t in sources) * (2 if with_mean else 1)
-    if not ok or len(convs) < 2 or not all(relu_after[:-1]) or convs[0].in_channels != csum:
-        out = pointwise_conv_stack(seq, build())
-        return out.mean(dim=2) if pool_mean else out
-    if with_mean:
-        # the mean term's backward reads the per-cloud sums of dY0 out of the statistics partials of the layer-1 dgrad,
-        # which are laid out [cloud][tile] only on the plain / split-K dgrad paths; the fused small / mid-size backward
-        # and the role-split dgrad cut the flattened (cloud, point) axis into chunks that straddle clouds
-        lib = _native.lib()
-        b, npts = sources[0].shape[0], sources[0].shape[2]
-        c0, c1 = convs[0].out_channels, convs[1].out_channels
-        if (lib.istnet_pw_bwd_small_ok(c0, c1, npts)
-                or lib.istnet_pw_bwd_mid_ok(c0, c1, npts)
-                or lib.istnet_pw_dgrad_rs(b, c0, c1, npts, 1)):
-            out = pointwise_conv_stack(seq, build())
-            return out.mean(dim=2) if pool_mean else out
-    params = []
-    for m in convs:
-        params += [m.weight, m.bias]
-    if pool_mean and not relu_after[-1]:
-        return FusedMultiSourceBiasMLPFunction.apply(len(sources), with_mean, False, False, *sources, *params).mean(dim=2)
-    return FusedMultiSourceBiasMLPFunction.apply(len(sources), with_mean, relu_after[-1], pool_mean, *sources, *params)
-
-
-def pointwise_conv_stack(seq, x):
-    """Run an ``nn.Sequential`` of [Conv1d(k=1) (+ ReLU)]* on x (B, C, N).
-
-    CUDA f32 inputs with N % 32 == 0 take the fused MFMA path; anything else runs ``seq(x)``."""
-    mods = list(seq)
-    convs, relu_after = [], []
-    i = 0
-    ok = x.is_cuda and x.dtype == torch.float32 and x.dim() == 3 and x.shape[2] % 32 == 0
-    while ok and i < len(mods):
-        m = mods[i]
-        if not (isinstance(m, torch.nn.Conv1d) and m.kernel_size == (1,) and m.stride == (1,)
-                and m.padding == (0,) and m.groups == 1 and m.bias is not None):
-            ok = False
-            break
-        has_relu = i + 1 < len(mods) and isinstance(mods[i + 1], torch.nn.ReLU)
-        convs.append(m)
-        relu_after.append(has_relu)
-        i += 2 if has_relu else 1
-    if not ok or not convs or not all(relu_after[:-1]):
-        if x.is_cuda:
-            _note_fallback(f"per-point conv stack on input {tuple(x.shape)} {x.dtype}: needs float32 (B, C, N) with N % 32 == 0 "
-                           "and Conv1d(k=1, bias) [+ ReLU] layers")
-        return seq(x)
-    params = []
-    for m in convs:
-        params += [m.weight, m.bias]
-    return FusedBiasMLPFunction.apply(x, relu_after[-1], *params)
-
-
 def _fusable(mlp, x):
     """True when `mlp` is a plain [conv1x1(no bias) -> BatchNorm2d -> ReLU] x k stack on a CUDA f32 tensor."""
     if not (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4):
@@ -1904,3 +1355,10 @@ def sa_level(groupers, mlps, xyz, new_xyz, features, ball_idx=None, ball_csr=Non
     if training:
         _bump_counters([unit for mlp in mlps for unit in mlp])
     return out
+
+
+# ---- the feature-propagation node and the heads' per-point stacks live in their own modules (round 5); the names stay
+# importable from here.  (At the bottom: those modules import the stack / stream helpers defined above.)
+from .fused_fp import FusedFPFunction, LazyAct, _MaterializeFn, fp_level  # noqa: E402,F401
+from .fused_heads import (FusedBiasMLPFunction, FusedMultiSourceBiasMLPFunction, pointwise_conv_stack,  # noqa: E402,F401
+                          pointwise_conv_stack_multi)

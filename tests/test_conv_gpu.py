@@ -129,7 +129,7 @@ def test_basic_block_with_native_convolutions():
 
 
 @pytest.mark.parametrize("cin,cout,k,s,h,w", LAYERS)
-@pytest.mark.parametrize("variant", [1, 2, 3])
+@pytest.mark.parametrize("variant", [1, 2])
 def test_split_precision_kernels_hold_the_fp32_error(cin, cout, k, s, h, w, variant):
     """Opt-in split precision (istnet_conv_set_tuning(1, v), include/istnet_conv.h): every fp32 operand as three exact bf16
     terms, six v_mfma_f32_32x32x16_bf16 products, fp32 accumulation.  The acceptance gate of the experiment, per shape and for
