@@ -9,7 +9,7 @@ from torch.autograd import Function
 from .. import _native
 from . import fused_mlp as _fm
 from .fused_mlp import (_backward_stack, _bump_counters, _dgrad_kname, _empty, _enter_backward, _forward_stack,
-                        _fwd_ld_kname, _grad_dest, _ident_consts, _join_streams, _kname, _layer_args, _note_fallback, _p,
+                        _fwd_ld_kname, _grad_dest, _ident_consts, _join_streams, _kname, _wgrad_kname, _layer_args, _note_fallback, _p,
                         _scale_streams, _st)
 
 
@@ -189,7 +189,7 @@ class FusedFPFunction(Function):
                     sp_a = lib.istnet_pw_wgrad_splits(b, c2, cout0, m)
                     ws_a = _empty((sp_a, cout0, c2), torch.float32, dev)
                     _native.check(_native.timed(
-                        _kname("pw_wgrad_kernel", lib.istnet_pw_wgrad_tile_cfg(b, c2, cout0, m), 0),
+                        _wgrad_kname(lib, b, c2, cout0, m),
                         2.0 * b * m * c2 * cout0, 4.0 * b * m * (c2 + cout0), lambda: lib.istnet_pw_wgrad(
                             b, c2, cout0, m, 0, known.data_ptr(), ksc, ksh, gk.data_ptr(), gk.data_ptr(), None, 0,
                             None, ident.data_ptr(), ibw.data_ptr(), ws_a.data_ptr(), wst)), "pw_wgrad(fp known)")
@@ -199,7 +199,7 @@ class FusedFPFunction(Function):
                         sp_b = lib.istnet_pw_wgrad_splits(b, c1, cout0, n)
                         ws_b = _empty((sp_b, cout0, c1), torch.float32, dev)
                         _native.check(_native.timed(
-                            _kname("pw_wgrad_kernel", lib.istnet_pw_wgrad_tile_cfg(b, c1, cout0, n), 0),
+                            _wgrad_kname(lib, b, c1, cout0, n),
                             2.0 * b * n * c1 * cout0, 4.0 * b * n * (c1 + cout0), lambda: lib.istnet_pw_wgrad(
                                 b, c1, cout0, n, 0, skip.data_ptr(), None, None, dy_y.data_ptr(), dy_d.data_ptr(), None,
                                 0, None, dy_bn.data_ptr(), dy_bw.data_ptr(), ws_b.data_ptr(), wst)), "pw_wgrad(fp skip)")

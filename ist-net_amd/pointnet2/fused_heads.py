@@ -8,7 +8,7 @@ from torch.autograd import Function
 
 from .. import _native
 from .fused_mlp import (_Layer, _backward_stack, _dgrad_kname, _empty, _enter_backward, _forward_stack, _grad_dest, _head_stack,
-                        _kname, _note_fallback, _p, _st)
+                        _kname, _wgrad_kname, _note_fallback, _p, _st)
 
 
 _ONES = {}
@@ -178,7 +178,7 @@ class FusedMultiSourceBiasMLPFunction(Function):
                         sp = lib.istnet_pw_wgrad_splits(b, c, cout0, npts)
                         ws = _empty((sp, cout0, c), torch.float32, dev)
                         _native.check(_native.timed(
-                            _kname("pw_wgrad_kernel", lib.istnet_pw_wgrad_tile_cfg(b, c, cout0, npts), 0),
+                            _wgrad_kname(lib, b, c, cout0, npts),
                             2.0 * b * npts * c * cout0, 4.0 * b * npts * (c + 2 * cout0), lambda: lib.istnet_pw_wgrad(
                                 b, c, cout0, npts, 0, src.data_ptr(), None, None, y0.data_ptr(), d_a0.data_ptr(), None, 0,
                                 None, bn0.data_ptr(), bwdc0.data_ptr(), ws.data_ptr(), wst)), "pw_wgrad(head source)")

@@ -64,8 +64,30 @@ def _kname(base, cfg, gather=None, pooled=False):
     return f"{base}<{mt}, {nt}, {wm}, {wn}{tail}>"
 
 
+# The kernel names below label launches for the per-launch timing of roofline.py only: without it (_native.TIMING is None) they
+# return "" before asking the library anything -- two to three ctypes calls per layer that an eager step does not need.
+def _fwd_kname(lib, b, cin, cout, p, plain=True):
+    """Kernel an istnet_pw_forward launch runs (split-K / role-split / LDS-tiled, as launch_pw_forward picks)."""
+    if _native.TIMING is None:
+        return ""
+    cfg2 = lib.istnet_pw_forward_cfg(b, cin, cout, p) if plain else 0
+    if cfg2 == 1:
+        return "pw_fwd_sk_kernel"
+    if cfg2:
+        return f"pw_fwd2_kernel<{cfg2 // 1000}, {cfg2 // 100 % 10}, {cfg2 // 10 % 10}, {32 if cfg2 % 10 else 16}, 0>"
+    return _kname("pw_fwd_kernel", lib.istnet_pw_tile_cfg(b, cout, p))
+
+
+def _wgrad_kname(lib, b, cin, cout, p, gather=False, pooled=False):
+    if _native.TIMING is None:
+        return ""
+    return _kname("pw_wgrad_kernel", lib.istnet_pw_wgrad_tile_cfg(b, cin, cout, p), bool(gather), pooled=pooled)
+
+
 def _fwd_ld_kname(lib, b, cin, cout, p):
     """Kernel an istnet_pw_forward_ld / istnet_pw_forward_acc launch runs: the split-K kernel for small launches."""
+    if _native.TIMING is None:
+        return ""
     if lib.istnet_pw_forward_cfg(b, cin, cout, p) == 1:
         return "pw_fwd_sk_kernel"
     return _kname("pw_fwd_kernel", lib.istnet_pw_tile_cfg(b, cout, p))
@@ -74,6 +96,8 @@ def _fwd_ld_kname(lib, b, cin, cout, p):
 def _dgrad_kname(lib, b, rows, cout, p, dense=False, stats=False):
     """pw_dgrad_kernel<M_T, N_T, WM, WN, FAST> as launch_pw_dgrad picks it: FAST = every tile interior and the
     reduction length a multiple of the k-tile (kKT = 16)."""
+    if _native.TIMING is None:
+        return ""
     if dense and lib.istnet_pw_dgrad_sk(b, rows, cout, p):
         return "pw_dgrad_sk_kernel"          # small launch, dense gradient source: K split over the waves, no LDS operands
     if stats and lib.istnet_pw_dgrad_rs(b, rows, cout, p, 1 if dense else 0):
@@ -297,12 +321,7 @@ def _forward_stack(lib, dev, st, b, c0, g, s, x, gather, training, layers, param
             ps, pq = part[0].data_ptr(), part[1].data_ptr()
         else:
             nt, ps, pq = 0, None, None
-        kname = _kname("pw_fwd_kernel", lib.istnet_pw_tile_cfg(b, cout, p))
-        cfg2 = lib.istnet_pw_forward_cfg(b, cur_c, cout, p) if plain else 0
-        if cfg2 == 1:
-            kname = "pw_fwd_sk_kernel"
-        elif cfg2:
-            kname = f"pw_fwd2_kernel<{cfg2 // 1000}, {cfg2 // 100 % 10}, {cfg2 // 10 % 10}, {32 if cfg2 % 10 else 16}, 0>"
+        kname = _fwd_kname(lib, b, cur_c, cout, p, plain)
         flops, nbytes = 2.0 * b * p * cur_c * cout, 4.0 * b * p * (cur_c + cout)
         y = _empty((b, cout, p), torch.float32, dev)
         if li == 0 and gather is not None:
@@ -517,8 +536,7 @@ def _wgrad_job(lib, dev, b, cin, cout, p, ns_arg, use_gather, ga, src, in_bn, y,
         splits = lib.istnet_pw_wgrad_splits(b, cin, cout, p)
         ws = _empty((splits, cout, cin), torch.float32, dev)
         dw = _grad_dest(wparam, (cout, cin), dev)
-        kname = _kname("pw_wgrad_kernel", lib.istnet_pw_wgrad_tile_cfg(b, cin, cout, p),
-                       bool(use_gather), pooled=d_dense is None)
+        kname = _wgrad_kname(lib, b, cin, cout, p, use_gather, d_dense is None)
         flops = 2.0 * b * p * cin * cout
         dd, dp, da = _p(d_dense), _p(d_pooled), _p(d_arg)
         if use_gather:
@@ -1185,7 +1203,7 @@ def _finish_layer0_grads(lib, dev, b, cfeat, cout0_tot, n_src, feat, gbuf, ident
         splits = lib.istnet_pw_wgrad_splits(b, cfeat, cout0_tot, n_src)
         ws = _empty((splits, cout0_tot, cfeat), torch.float32, dev)
         _native.check(_native.timed(
-            _kname("pw_wgrad_kernel", lib.istnet_pw_wgrad_tile_cfg(b, cfeat, cout0_tot, n_src), 0),
+            _wgrad_kname(lib, b, cfeat, cout0_tot, n_src),
             2.0 * b * n_src * cfeat * cout0_tot, 4.0 * b * n_src * (cfeat + cout0_tot), lambda: lib.istnet_pw_wgrad(
                 b, cfeat, cout0_tot, n_src, 0, feat.data_ptr(), None, None, gbuf.data_ptr(), gbuf.data_ptr(), None, 0,
                 None, ident.data_ptr(), bwdc.data_ptr(), ws.data_ptr(), wst)), "pw_wgrad(level G)")
