@@ -17,6 +17,12 @@ batch is used every step and its geometry is computed inside the step.
     python bench.py [--gpus N] [--steps K] [--warmup W]
     python bench.py --workload istnet      # full IST-Net training step (configs[2]/[3]): RGB branch + point branch
     python bench.py --workload infer       # eval-mode full model + post-processing, B=64 N=2048 (config 5)
+    python bench.py --workload pipeline    # config 3 WITH the device-side input preparation in front (pipeline_infer: config 5)
+    python bench.py --workload istnet --split-precision   # + the opt-in split-precision trunk under the key `split_precision`
+
+A short run (steps <= 20) times five windows and reports the median.  Besides `roofline` and `cpu_baseline` the encoder line
+carries `unpipelined` (the same step without the geometry prefetch) and `eager`: what an unchanged reference-style loop gets
+(zero_grad / model(batch) / loss.backward() / torch.optim.Adam.step(), no whole-step graph, no prefetch).
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 Prints ONE JSON line on rank 0.
@@ -998,7 +1004,12 @@ def main():
                                      "note": "one batch, FPS / ball query / three_nn inside the step (--no-prefetch)"}
         if not dist_on and not args.no_eager_leg and not args.cpu_dry_run and mode == "hipgraph":
             # the step an unchanged reference-style loop gets (no whole-step graph, no prefetch, torch.optim.Adam)
-            result["eager"] = measure_eager(dev, args.workload)
+            try:
+                result["eager"] = measure_eager(dev, args.workload)
+            except Exception as exc:      # an extra leg must never cost the headline line
+                result["eager"] = {"error": f"{type(exc).__name__}: {exc}"}
+                torch.cuda.synchronize()
+        if isinstance(result.get("eager"), dict) and "error" not in result["eager"]:
             ref = result.get("unpipelined", result)["ms_per_step"]
             result["eager"]["note"] = (
                 "reference-style loop (utils/solver.py:88-99: zero_grad, model(batch), loss.backward(), optimizer.step()) "
