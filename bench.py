@@ -471,23 +471,44 @@ def run_inference(args, dev, world, rank, dist):
             rts, scales = postprocess.assemble_pred_RTs(ep["pred_rotation"], ep["pred_translation"], ep["pred_size"])
             return rts.cpu(), scales.cpu()
 
-    for _ in range(args.warmup):
-        step()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
+    def timed():
+        for _ in range(args.warmup):
+            step()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        return time.perf_counter() - t0
+
+    elapsed = timed()
     if dist is not None:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    return {"metric": "instances/sec inference, B=64 N=2048", "value": b * world * args.steps / elapsed,
+    extra = {}
+    if args.split_precision and dist is None:
+        # OPT-IN experiment, never the headline: the trunk's forward convolutions on the bf16 matrix pipe (three exact bf16
+        # terms per fp32 operand, six products, fp32 accumulation; rgb_branch.set_split_precision)
+        from istnet_amd import rgb_branch
+        ref = [t.double() for t in step()]
+        rgb_branch.set_split_precision(True)
+        try:
+            got = [t.double() for t in step()]
+            dt = timed() / args.steps
+        finally:
+            rgb_branch.set_split_precision(False)
+        extra["split_precision"] = {
+            "ms_per_step": dt * 1e3, "value": b / dt, "unit": "instances/s",
+            "speedup_vs_fp32": elapsed / args.steps / dt,
+            "pose_max_abs_diff_vs_fp32": max(float((g_ - r_).abs().max()) for g_, r_ in zip(got, ref)),
+            "scope": "ResNet trunk 3x3 / 1x1 convolutions (forward); everything else unchanged",
+            "note": "opt-in (rgb_branch.set_split_precision / ISTNET_SPLIT_PRECISION=1); the value above is the exact-fp32 path"}
+    return {**extra, "metric": "instances/sec inference, B=64 N=2048", "value": b * world * args.steps / elapsed,
             "unit": "instances/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
@@ -717,7 +738,7 @@ def main():
                     help="timed windows of --steps steps each, the median is reported (default: 5 when steps <= 20, else 1)")
     ap.add_argument("--no-eager-leg", action="store_true", help="skip the reference-style eager measurement (the `eager` object)")
     ap.add_argument("--split-precision", action="store_true",
-                    help="istnet: ALSO measure the opt-in split-precision trunk (bf16 x 3 on the bf16 matrix pipe) and report it "
+                    help="istnet / infer: ALSO measure the opt-in split-precision trunk (bf16 x 3 on the bf16 matrix pipe) and report it "
                          "under the extra key `split_precision`; the headline value stays on the exact-fp32 path")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", default="", help="cpu_baseline: comma-separated thread counts to sweep (default 8,16,32)")

@@ -167,3 +167,26 @@ def test_split_precision_kernels_hold_the_fp32_error(cin, cout, k, s, h, w, vari
     for e_split, e_fp32 in zip(errs[variant], errs[0]):
         assert e_split <= 2.0 * e_fp32 + 1e-12, (errs[variant], errs[0])
     assert errs[variant][0] < 1e-5
+
+
+def test_split_precision_serves_inference_through_the_native_forward():
+    """With split precision on, the native forward is also taken without gradients (eval / torch.no_grad: the exact-fp32 native
+    forward stays off there, rgb_branch._native_conv_ok); the eval-mode block agrees with the framework's convolutions to
+    fp32 rounding, and turning the mode off restores the framework path."""
+    from istnet_amd import rgb_branch
+    torch.manual_seed(5)
+    blk = rgb_branch.BasicBlock(128, 128).to(DEV).to(memory_format=torch.channels_last).eval()
+    x = torch.randn(4, 128, 24, 24, device=DEV).contiguous(memory_format=torch.channels_last)
+    with torch.no_grad():
+        assert not rgb_branch._native_conv_ok(blk.conv1, x)
+        ref = blk(x)
+        prev = rgb_branch.set_split_precision(True)
+        try:
+            assert rgb_branch._native_conv_ok(blk.conv1, x)
+            got = blk(x)
+        finally:
+            rgb_branch.set_split_precision(prev)
+        assert not rgb_branch._native_conv_ok(blk.conv1, x)
+    y64 = blk.double()(x.double())
+    e_ref, e_got = float((ref.double() - y64).abs().max()), float((got.double() - y64).abs().max())
+    assert e_got <= 2.0 * e_ref + 1e-12 and e_got < 1e-4 * float(y64.abs().max()), (e_got, e_ref)
