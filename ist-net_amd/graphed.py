@@ -60,20 +60,22 @@ class _Replay(torch.autograd.Function):
     @staticmethod
     def forward(ctx, entry, x, *params):
         ctx.entry = entry
-        if x.data_ptr() != entry.static_in.data_ptr():
-            entry.static_in.copy_(x)
-        entry.fwd.replay()
-        entry.pending = True
-        # a copy (16 MB at B=32, ~10 us): the caller owns its output like on the plain path, whatever it keeps across steps
-        return entry.static_out.clone()
+        with torch.cuda.device(x.device):       # a graph launches on the CURRENT device's current stream
+            if x.data_ptr() != entry.static_in.data_ptr():
+                entry.static_in.copy_(x)
+            entry.fwd.replay()
+            entry.pending = True
+            # a copy (16 MB at B=32, ~10 us): the caller owns its output like on the plain path, whatever it keeps across steps
+            return entry.static_out.clone()
 
     @staticmethod
     @torch.autograd.function.once_differentiable
     def backward(ctx, gout):
         entry = ctx.entry
-        if gout.data_ptr() != entry.static_gout.data_ptr():
-            entry.static_gout.copy_(gout)
-        entry.bwd.replay()
+        with torch.cuda.device(entry.static_gout.device):
+            if gout.data_ptr() != entry.static_gout.data_ptr():
+                entry.static_gout.copy_(gout)
+            entry.bwd.replay()
         entry.pending = False
         # fresh tensor objects over the static buffers: AccumulateGrad then stores them instead of cloning
         return (None, None) + tuple(None if g is None else g.detach() for g in entry.static_grads)
