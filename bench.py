@@ -515,7 +515,9 @@ def run_inference(args, dev, world, rank, dist):
             "config": {"workload": "IST-Net inference (eval mode; RGB branch on MIOpen with the last layer on the chosen "
                                    "pixels only, point branch on the HIP kernels, pose post-processing, result copied "
                                    "to the host)", "batch_per_gpu": b, "npoints": n, "global_batch": b * world,
-                       "parallelism": f"replicas x{world}", "launch": "eager"}}
+                       "parallelism": f"replicas x{world}",
+                       "launch": "model(inputs) under no_grad, as the reference's test loop calls it; IST_Net.forward replays its "
+                                 "own per-shape HIP graph (graphed.InferenceGraph; GPU-bound at this batch either way)"}}
 
 
 def run_sa_layer(args, dev):

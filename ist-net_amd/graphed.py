@@ -31,6 +31,8 @@ Unlike ``make_graphed_callables`` the returned tensor is the caller's own (a cop
 outputs across steps is safe.  The one cost a caller can see is memory: an entry keeps its activations' pool (1.3 GB for the
 B=32 encoder) until ``graphed.reset(module)`` or the module dies.
 
+``InferenceGraph`` (below) is the forward-only counterpart for eval-mode, ``torch.no_grad()`` callers of the full model.
+
 ``ISTNET_AUTO_GRAPH=0`` (or ``graphed.ENABLED = False``) turns the whole mechanism off.
 """
 import os
@@ -42,7 +44,11 @@ import torch
 ENABLED = os.environ.get("ISTNET_AUTO_GRAPH", "1") != "0"
 WARMUP_CALLS = 2
 MAX_ENTRIES = 4          # captured shapes kept per module (least recently used goes first)
-STATS = {"captures": 0, "replays": 0, "plain": 0, "failed": 0}
+STATS = {"captures": 0, "replays": 0, "plain": 0, "failed": 0,                       # AutoGraph (training)
+         "infer_captures": 0, "infer_replays": 0, "infer_plain": 0, "infer_failed": 0}    # InferenceGraph
+# other threads of the caller (a DataLoader's pin-memory thread, a logger) keep making HIP calls while this thread captures:
+# only this thread's calls are checked against the capture
+_CAPTURE_MODE = "thread_local"
 
 
 class _Entry:
@@ -195,13 +201,13 @@ class AutoGraph:
                 pool = torch.cuda.graph_pool_handle()
                 static_in = x.detach().clone()
                 fwd = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(fwd, pool=pool):
+                with torch.cuda.graph(fwd, pool=pool, capture_error_mode=_CAPTURE_MODE):
                     static_out = self.plain(static_in)
                 if not (isinstance(static_out, torch.Tensor) and static_out.requires_grad):
                     raise RuntimeError("the module's output is not a differentiable tensor")
                 static_gout = torch.empty_like(static_out)
                 bwd = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(bwd, pool=pool):
+                with torch.cuda.graph(bwd, pool=pool, capture_error_mode=_CAPTURE_MODE):
                     grads = torch.autograd.grad((static_out,), [alias[id(p)] for p in params], (static_gout,),
                                                 allow_unused=True)
                 torch.cuda.synchronize(dev)
@@ -218,7 +224,109 @@ class AutoGraph:
         self._mods = None
 
 
+class InferenceGraph:
+    """Forward-only graphs for an eval-mode, ``torch.no_grad()`` caller whose module maps a dict of tensors to a dict of tensors.
+
+    The reference's test loop (test.py / utils/solver.py:199-262) feeds ONE IMAGE per step: the batch is that image's
+    instances, usually 1-8.  At that size the forward pass of the full model is ~600 launches of a few microseconds each and
+    the step is the host issuing them: 5.0 ms per image whatever the batch, against 1.7-2.4 ms of device time
+    (profiles/r05_infer_small_batch.txt).  Same recipe as ``AutoGraph``: per input signature (every tensor's key, shape, dtype
+    and contiguity) two plain warm-up calls, then the whole forward pass captured once on static copies of the inputs and
+    replayed -- copy the inputs in, one graph launch, hand back copies of the outputs.  A test set's images have a handful of
+    different instance counts; ``INFER_MAX_ENTRIES`` signatures are kept (least recently used goes first).
+
+    The key also holds what the capture baked in: the addresses of every parameter and buffer (``load_state_dict`` copies in
+    place and is picked up by the next replay; ``.to()`` / ``.half()`` move the storage and start a new entry), every module's
+    ``training`` flag and the library's switch state.  The parameter / buffer / module LISTS are flattened once: a caller that
+    replaces Parameter objects or submodules after the first call (pruning, weight tying) calls ``graphed.reset(module)``.
+    Modules carrying hooks, inputs that require grad, a surrounding stream capture and ``ISTNET_AUTO_GRAPH=0`` keep the
+    plain path; a capture that fails (an extractor with host-side control flow) warns once and keeps it for that signature."""
+
+    def __init__(self, plain, switch_state=None):
+        self._plain = plain                  # plain(module, inputs) -> dict of tensors
+        self.switch_state = switch_state or (lambda: ())
+        self.entries = {}
+        self._stamp = 0
+        self.module = None
+        self._mods = self._tensors = None
+        self._hooked = False
+
+    def plain(self, inputs):
+        return self._plain(self.module(), inputs)
+
+    def _fingerprint(self, module):
+        if self._tensors is None:
+            self._mods = list(module.modules())
+            self._hooked = any(m._forward_hooks or m._forward_pre_hooks for m in self._mods)
+            self._tensors = list(module.parameters()) + list(module.buffers())
+        return (tuple(t.data_ptr() for t in self._tensors), tuple(m.training for m in self._mods))
+
+    def __call__(self, inputs, keys):
+        first = inputs[keys[0]]
+        if not (ENABLED and isinstance(first, torch.Tensor) and first.is_cuda and not torch.is_grad_enabled()
+                and not torch.cuda.is_current_stream_capturing()):
+            return self.plain(inputs)
+        sig = []
+        for k in keys:
+            t = inputs[k]
+            if not isinstance(t, torch.Tensor) or t.device != first.device or t.requires_grad:
+                return self.plain(inputs)
+            sig.append((k, tuple(t.shape), t.dtype, t.is_contiguous()))
+        module = self.module()
+        fp = self._fingerprint(module)
+        if self._hooked or module._forward_hooks or module._forward_pre_hooks:
+            STATS["infer_plain"] += 1
+            return self.plain(inputs)
+        key = (tuple(sig), fp, self.switch_state())
+        entry = self.entries.get(key)
+        if entry is None:
+            if len(self.entries) >= INFER_MAX_ENTRIES:
+                del self.entries[min(self.entries, key=lambda k: self.entries[k].stamp)]
+            entry = self.entries[key] = _Entry()
+        self._stamp += 1
+        entry.stamp = self._stamp
+        entry.calls += 1
+        if entry.failed or entry.calls <= WARMUP_CALLS:
+            STATS["infer_plain"] += 1
+            return self.plain(inputs)
+        dev = first.device
+        if entry.fwd is None:
+            try:
+                with torch.cuda.device(dev):
+                    torch.cuda.synchronize(dev)
+                    static_in = {k: inputs[k].detach().clone() for k in keys}
+                    graph = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(graph, capture_error_mode=_CAPTURE_MODE):
+                        static_out = self.plain(static_in)     # ONLY the declared keys: nothing else can be baked in
+                    if not (isinstance(static_out, dict) and all(isinstance(v, torch.Tensor) for v in static_out.values())):
+                        raise RuntimeError("the module's output is not a dict of tensors")
+                    torch.cuda.synchronize(dev)
+                entry.fwd, entry.static_in, entry.static_out = graph, static_in, static_out
+                STATS["infer_captures"] += 1
+            except Exception as exc:
+                entry.failed, entry.fwd = True, None
+                STATS["infer_failed"] += 1
+                torch.cuda.synchronize(dev)
+                warnings.warn(f"istnet_amd.graphed: HIP-graph capture of {type(module).__name__}'s inference pass failed "
+                              f"({type(exc).__name__}: {exc}); this input signature keeps running launch by launch", RuntimeWarning)
+                return self.plain(inputs)
+        with torch.cuda.device(dev):
+            for k in keys:
+                if inputs[k].data_ptr() != entry.static_in[k].data_ptr():
+                    entry.static_in[k].copy_(inputs[k])
+            entry.fwd.replay()
+            STATS["infer_replays"] += 1
+            return {k: v.clone() for k, v in entry.static_out.items()}     # the caller owns its outputs
+
+    def reset(self):
+        self.entries.clear()
+        self._mods = self._tensors = None
+
+
+INFER_MAX_ENTRIES = 12      # input signatures (batch sizes) kept per module
+
 _REGISTRY = weakref.WeakKeyDictionary()      # module -> AutoGraph (kept outside the module: deepcopy / pickle stay plain)
+_INFER_REGISTRY = weakref.WeakKeyDictionary()      # module -> InferenceGraph
 
 
 def for_module(module, plain, switch_state=None):
@@ -230,8 +338,19 @@ def for_module(module, plain, switch_state=None):
     return ag
 
 
+def for_inference(module, plain, switch_state=None):
+    """The InferenceGraph of ``module`` (created on first use).  ``plain(module, inputs)`` is the module's ordinary forward."""
+    ig = _INFER_REGISTRY.get(module)
+    if ig is None:
+        ig = _INFER_REGISTRY[module] = InferenceGraph(plain, switch_state)
+        ig.module = weakref.ref(module)
+    return ig
+
+
 def reset(module=None):
-    """Drop captured graphs (of one module, or of all): frees their memory pools."""
-    for m, ag in list(_REGISTRY.items()):
-        if module is None or m is module:
-            ag.reset()
+    """Drop captured graphs (of one module and of the modules inside it, or of all): frees their memory pools."""
+    inside = None if module is None else {id(m) for m in module.modules()}
+    for registry in (_REGISTRY, _INFER_REGISTRY):
+        for m, ag in list(registry.items()):
+            if inside is None or id(m) in inside:
+                ag.reset()

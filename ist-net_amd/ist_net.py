@@ -20,7 +20,7 @@ from . import modules as enc_modules
 from .modules import PointNet2MSG
 from .pointnet2.fused_mlp import pointwise_conv_stack as _run
 from .pointnet2.fused_mlp import pointwise_conv_stack_multi as _run_multi
-from . import heads_native
+from . import _native, graphed, heads_native
 from .rotation_utils import Ortho6d2Mat, ortho6d_to_mat
 
 CAM_RADII = [[0.01, 0.02], [0.02, 0.04], [0.04, 0.08], [0.08, 0.16]]      # ist_net.py:16
@@ -199,6 +199,13 @@ class point_branch_side_streams:
         return False
 
 
+def _infer_switch_state():
+    """Everything process-global that a captured inference pass bakes in (graphed.InferenceGraph keys on it)."""
+    from . import rgb_branch
+    return (enc_modules._switch_state(), USE_RGB_STREAM, USE_GATHER_FIRST, heads_native.USE_NATIVE_TAIL, rgb_branch.USE_FUSED,
+            rgb_branch.USE_NATIVE_TRUNK_CONV, rgb_branch._SPLIT_ON, torch.cuda.tunable.is_enabled())
+
+
 class IST_Net(nn.Module):
     """IST-Net wiring.  [ref :10-76]  ``rgb_extractor`` maps (B,3,H,W) -> (B,128,H,W)."""
 
@@ -231,6 +238,17 @@ class IST_Net(nn.Module):
         return torch.gather(feat.reshape(b, d, -1), 2, choose).contiguous()   # :41-45
 
     def forward(self, inputs):
+        # An eval-mode, no_grad caller (the reference's test loop: one image per step, its 1-8 instances the batch) is bound
+        # by the host issuing ~600 launches; graphed.InferenceGraph replays the whole pass from one HIP graph per batch shape
+        pts = inputs["pts"]
+        if (not self.training and not torch.is_grad_enabled() and graphed.ENABLED and isinstance(pts, torch.Tensor)
+                and pts.is_cuda and _native.TIMING is None and _native.MARKERS is None):
+            keys = ("pts", "category_label", "rgb_local") if "rgb_local" in inputs else ("pts", "category_label", "rgb", "choose")
+            if all(k in inputs for k in keys):
+                return graphed.for_inference(self, IST_Net._plain_forward, _infer_switch_state)(inputs, keys)
+        return self._plain_forward(inputs)
+
+    def _plain_forward(self, inputs):
         end_points = {}
         pts = inputs["pts"]
         b = pts.size(0)

@@ -128,3 +128,93 @@ def test_new_shape_gets_its_own_graph_and_eval_mode_its_own_key():
         ref = out.detach().clone() if ref is None else ref
         assert torch.equal(out, ref)
     assert graphed.STATS["captures"] == caps + 3
+
+
+# ---- graphed.InferenceGraph: the reference's test loop (one image per step, its instances the batch; utils/solver.py:199-262) ----
+
+def _infer_net():
+    import bench
+    dev = torch.device("cuda:0")
+    net = bench.make_istnet(dev, seed=0)
+    g = torch.Generator().manual_seed(5)
+    for m in net.modules():          # non-trivial running statistics, as after training
+        if isinstance(m, torch.nn.modules.batchnorm._BatchNorm):
+            m.running_mean.copy_(torch.randn(m.num_features, generator=g) * 0.1)
+            m.running_var.copy_(torch.rand(m.num_features, generator=g) + 0.5)
+    return net.eval(), dev
+
+
+def _plain(net, batch):
+    from istnet_amd import graphed
+    graphed.ENABLED = False
+    try:
+        with torch.no_grad():
+            return {k: v.clone() for k, v in net(batch).items()}
+    finally:
+        graphed.ENABLED = True
+
+
+def _close(got, ref, tol=2e-5):
+    assert got.keys() == ref.keys()
+    for k in ref:
+        assert float((got[k] - ref[k]).abs().max()) <= tol * (1.0 + float(ref[k].abs().max())), k
+
+
+def test_inference_graphs_follow_the_batch_size_and_match_the_plain_path():
+    import bench
+    from istnet_amd import graphed
+    net, dev = _infer_net()
+    before = dict(graphed.STATS)
+    sizes = [1, 3, 1, 3, 5, 1]
+    held = []
+    for rnd in range(4):                              # two warm-up calls per size, then capture, then replays
+        for i, b in enumerate(sizes):
+            batch = bench.istnet_batch(b, 1024, seed=10 * rnd + i, device=dev)      # new data every call
+            with torch.no_grad():
+                got = net(batch)
+            _close(got, _plain(net, batch))
+            held.append(got["pred_rotation"])
+    assert graphed.STATS["infer_captures"] == before["infer_captures"] + 3           # one per distinct batch size
+    assert graphed.STATS["infer_failed"] == before["infer_failed"]
+    assert graphed.STATS["infer_replays"] >= before["infer_replays"] + 9
+    # the caller owns what it was handed: no two results share storage (a replay overwrites only the graph's own buffers)
+    assert len({t.data_ptr() for t in held}) == len(held)
+    # weights loaded IN PLACE (load_state_dict, checkpoint averaging) are what the next replay reads
+    batch = bench.istnet_batch(3, 1024, seed=99, device=dev)
+    with torch.no_grad():
+        old = net(batch)
+        for p in net.main_estimator.parameters():
+            p.mul_(1.05)
+        new = net(batch)
+    assert graphed.STATS["infer_captures"] == before["infer_captures"] + 3
+    _close(new, _plain(net, batch))
+    assert float((new["pred_size"] - old["pred_size"]).abs().max()) > 1e-6
+    graphed.reset(net)
+
+
+def test_inference_graph_leaves_training_and_grad_mode_alone():
+    import bench
+    from istnet_amd import graphed
+    net, dev = _infer_net()
+    batch = bench.istnet_batch(2, 1024, seed=3, device=dev)
+    before = dict(graphed.STATS)
+    for _ in range(4):                 # eval mode WITH autograd (e.g. test-time refinement of an input): plain path
+        out = net(batch)
+    assert out["pred_rotation"].requires_grad
+    out["pred_rotation"].sum().backward()
+    assert graphed.STATS["infer_captures"] == before["infer_captures"]
+    # the switch state is part of the key: flipping a library switch starts a new entry instead of replaying the old kernels
+    from istnet_amd import ist_net
+    with torch.no_grad():
+        for _ in range(4):
+            a = net(batch)
+        assert graphed.STATS["infer_captures"] == before["infer_captures"] + 1
+        ist_net.USE_GATHER_FIRST = False
+        try:
+            for _ in range(4):
+                b_ = net(batch)
+        finally:
+            ist_net.USE_GATHER_FIRST = True
+        assert graphed.STATS["infer_captures"] == before["infer_captures"] + 2
+    _close(b_, a, tol=1e-4)
+    graphed.reset(net)
