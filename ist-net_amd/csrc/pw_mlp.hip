@@ -3475,7 +3475,8 @@ int g_wgrad2_tile_max = 64;    // key 20.  Round 3: 64 x 64 output tiles for eve
                                // 2.79).  Alone the 128 x 128 tiles are 25-45 % faster (round 2), but these launches run beside the
                                // dgrad chain and their partials compete with it for HBM.
 inline int wgrad2_mt(int cout) { return (cout >= 128 && g_wgrad2_tile_max >= 128) ? 128 : 64; }
-inline int wgrad2_nt(int cin) { return (cin >= 128 && g_wgrad2_tile_max >= 128) ? 128 : 64; }
+int g_wgrad2_nt_max = 0;       // key 23: 0 = follow key 20; 128 = 64 x 128 tiles (x is the single-tensor operand: (2 M + N) loads per M N products)
+inline int wgrad2_nt(int cin) { return (cin >= 128 && (g_wgrad2_nt_max ? g_wgrad2_nt_max : g_wgrad2_tile_max) >= 128) ? 128 : 64; }
 inline int wgrad_split_len(int b, int cin, int cout, int P) {
   if (wgrad2_ok(cin, cout)) {
     // one workgroup of eight waves per CU: as many splits as keep tiles * splits at or under the target
@@ -3580,6 +3581,7 @@ int istnet_pw_set_tuning(int key, int value) {
     case 20: g_wgrad2_tile_max = value >= 128 ? 128 : 64; return 0;
     case 21: g_scatter_csr_threads = value; return 0;
     case 22: g_interp_dy_lds = value != 0; return 0;
+    case 23: g_wgrad2_nt_max = value >= 128 ? 128 : (value > 0 ? 64 : 0); return 0;
     default: return ISTNET_PN2_EINVAL;
   }
 }

@@ -926,7 +926,12 @@ def _backward_stack_compact(lib, dev, st, b, g, s, ga, training, ys, bns, params
             raise RuntimeError("compact set-abstraction scale with input features needs the level-wide feature gradient")
     if wjobs:
         wparams = [params[3 * li] for li in wlayers]
-        if _can_defer(wparams):
+        # An xyz-only scale (level 1) ends the backward pass: nothing follows its chain, so there is nothing for a deferred
+        # weight gradient to overlap -- and on the one deferred stream the two scales' xyz reductions and split-K sums ran
+        # one after the other behind the last GEMM of the step.  They stay on the scale's own stream (the scales run side by
+        # side): 2.565 -> 2.559 ms pipelined, 2.898 -> 2.885 un-pipelined (A/B on one box, profiles/r05_tail_and_tiles_ab.txt).
+        chain_ends_here = ga.cfeat == 0
+        if not chain_ends_here and _can_defer(wparams):
             cur = torch.cuda.current_stream(dev)
             key, wstream = _Deferred.stream(dev, cur)
             _Deferred.mains.setdefault(key, cur)

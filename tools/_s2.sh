@@ -1,11 +1,5 @@
-mkdir -p gpurun_out/r5f
-python bench.py --workload pipeline --steps 10 --warmup 5 2>gpurun_out/r5f/pipe.err | tail -1 > gpurun_out/r5f/pipeline.json
-python bench.py --workload pipeline_infer --steps 10 --warmup 5 2>gpurun_out/r5f/pipei.err | tail -1 > gpurun_out/r5f/pipeline_infer.json
-tail -3 gpurun_out/r5f/pipe.err gpurun_out/r5f/pipei.err | grep -v amdgpu
-python - <<'PY'
-import json
-for f in ('pipeline','pipeline_infer'):
-    try:
-        d=json.load(open('gpurun_out/r5f/%s.json'%f)); print(f, d['ms_per_step'], d['value'], d['preparation'])
-    except Exception as e: print(f, 'FAILED', e)
-PY
+mkdir -p gpurun_out/s2
+python -m pytest tests/test_pipeline_gpu.py -m gpu -q -k "bn_momentum_schedule" 2>&1 | grep -v Warning | tail -40 > gpurun_out/s2/fail.txt
+python -m pytest tests -m gpu -q --deselect tests/test_pipeline_gpu.py::test_captured_step_follows_bn_momentum_schedule 2>&1 | tail -8 > gpurun_out/s2/test_rest.txt
+tools/exp/ab_vals.sh ISTNET_PW_TUNE "20:64 23:128 20:128" > gpurun_out/s2/ab_wgrad_tiles.txt 2>&1
+cat gpurun_out/s2/fail.txt gpurun_out/s2/test_rest.txt gpurun_out/s2/ab_wgrad_tiles.txt

@@ -1,7 +1,5 @@
-mkdir -p gpurun_out/r5g
-python -m pytest tests/test_preprocess.py tests/test_capi.py -q 2>&1 | tail -4
-(cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats -d /root/repo/gpurun_out/r5g/prof -o fill -- python /root/repo/tools/prof_fill.py > /root/repo/gpurun_out/r5g/prof.log 2>&1)
-python tools/rocprof_summary.py gpurun_out/r5g/prof/fill_results.db 12 > gpurun_out/r5g/fill_kernel_stats_new.txt
-rm -rf gpurun_out/r5g/prof
-head -16 gpurun_out/r5g/fill_kernel_stats_new.txt | cut -c1-150
-bash tools/_s2.sh
+mkdir -p gpurun_out/s3
+python -m pytest tests -m gpu -x -q --tb=short -p no:warnings 2>&1 | tail -60 > gpurun_out/s3/test_full.txt
+python tools/exp/find_copies2.py > gpurun_out/s3/find_copies2.txt 2>&1
+tools/exp/ab_vals.sh ISTNET_EXP_TAIL "0 1" > gpurun_out/s3/ab_tail.txt 2>&1
+cat gpurun_out/s3/test_full.txt; tail -40 gpurun_out/s3/find_copies2.txt; cat gpurun_out/s3/ab_tail.txt
