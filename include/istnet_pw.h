@@ -89,6 +89,13 @@ ISTNET_PN2_API int istnet_pw_forward_acc(int b, int cin, int cout, int p, const 
 /* BatchNorm statistics partials of an arbitrary (b, c, p) tensor: part_sum / part_sq [c][istnet_pw_bwd_stat_tiles(b, p)] */
 ISTNET_PN2_API int istnet_pw_channel_stats(int b, int c, int p, const float *y, float *part_sum, float *part_sq,
                                            void *stream);
+/* three_interpolate (reference interpolate_gpu.cu:77-106, pointnet2_utils.py:249-273) of points (b, c, m) to n points
+ * together with the BatchNorm statistics partials of the result, one launch: out (b, c, n), bit-identical to
+ * istnet_pn2_three_interpolate; part_sum / part_sq [c][istnet_pw_interp_stats_tiles(b, n)].  Layer 0 of a feature-
+ * propagation level without skip features (reference pointnet2_modules.py:196-209 with unknow_feats = None). */
+ISTNET_PN2_API int istnet_pw_interp_stats_tiles(int b, int n);
+ISTNET_PN2_API int istnet_pw_interp_stats(int b, int c, int m, int n, const float *points, const int *idx,
+                                          const float *weight, float *out, float *part_sum, float *part_sq, void *stream);
 
 /* out = dY = bwdc[0]*(d_dense*[relu(bn(y)) > 0]) + bwdc[1] + bwdc[2]*y, materialised (b, c, p) */
 ISTNET_PN2_API int istnet_pw_dy(int b, int c, int p, const float *y, const float *d_dense, const float *bn,

@@ -94,6 +94,8 @@ SIGNATURES = {
     "istnet_pw_forward_acc": [_i, _i, _i, _i, _p, _p, _i, _p, _p, _p, _p, _p],
     "istnet_pw_forward_multi": [_i, _i, _p, _p, _i, _i, _p, _i, _p, _p, _p],
     "istnet_pw_channel_stats": [_i, _i, _i, _p, _p, _p, _p],
+    "istnet_pw_interp_stats": [_i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p],
+    "istnet_pw_interp_stats_tiles": [_i, _i],
     "istnet_pw_dy": [_i, _i, _i, _p, _p, _p, _p, _p, _p],
     "istnet_pw_gather_add_tiles": [_i, _i],
     "istnet_pw_gather_add": [_i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _i, _p, _p, _p, _p],

@@ -1197,6 +1197,45 @@ __global__ __launch_bounds__(256) void pw_channel_stats_kernel(int C, int P, con
   }
 }
 
+// three_interpolate (interpolate_gpu.cu:77-106) of a (B, C, m) tensor to n points TOGETHER with the BatchNorm statistics
+// partials of the result: layer 0 of a feature-propagation level without skip features (the finest level: its raw output IS
+// the interpolated product over the known points), where three_interpolate_kernel + pw_channel_stats_kernel were two
+// launches on the forward chain.  A thread owns one point and 8 channels (the same expression and operand order as the
+// stand-alone kernel: bit-identical values); the workgroup's 256 points are summed per channel in wave order.
+// grid: (ceil(n / 256), ceil(C / 8), B); partials [C][B * gridDim.x]
+__global__ __launch_bounds__(256) void interp_stats_kernel(int c, int m, int n, const float* __restrict__ points,
+                                                           const int* __restrict__ idx, const float* __restrict__ weight,
+                                                           float* __restrict__ out, float* __restrict__ part_sum,
+                                                           float* __restrict__ part_sq, int nt_total) {
+  const int b = blockIdx.z;
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  const bool live = j < n;
+  const int jj = live ? j : n - 1;
+  const int* ix = idx + ((size_t)b * n + jj) * 3;
+  const float* w = weight + ((size_t)b * n + jj) * 3;
+  const int i1 = ix[0], i2 = ix[1], i3 = ix[2];
+  const float w1 = w[0], w2 = w[1], w3 = w[2];
+  const int c0 = blockIdx.y * 8;
+  __shared__ float red[4][8][2];
+#pragma unroll
+  for (int u = 0; u < 8; ++u) {
+    const int l = min(c0 + u, c - 1);
+    const float* row = points + ((size_t)b * c + l) * m;
+    const float v = (row[i1] * w1 + row[i2] * w2) + row[i3] * w3;
+    if (live && c0 + u < c) out[((size_t)b * c + l) * n + j] = v;
+    const float vv = live ? v : 0.f;
+    const float s = wave_sum(vv), q = wave_sum(vv * vv);
+    if (lane_id() == 0) { red[wave_id()][u][0] = s; red[wave_id()][u][1] = q; }
+  }
+  __syncthreads();
+  if (threadIdx.x < 8 && c0 + threadIdx.x < c) {
+    const int u = threadIdx.x;
+    const size_t t = (size_t)(c0 + u) * nt_total + (size_t)b * gridDim.x + blockIdx.x;
+    part_sum[t] = (red[0][u][0] + red[1][u][0]) + (red[2][u][0] + red[3][u][0]);
+    part_sq[t] = (red[0][u][1] + red[1][u][1]) + (red[2][u][1] + red[3][u][1]);
+  }
+}
+
 // dY = ca * (dA * [relu(bn(y)) > 0]) + cb + cc * y, written out (dense gradient source).  Used where the same dY
 // feeds several small products (feature-propagation layer 0).  grid (ceil(P/4 / 256), B*C)
 __global__ __launch_bounds__(256) void pw_dy_kernel(int C, int P4, const float* __restrict__ y,
@@ -3937,6 +3976,17 @@ int istnet_pw_channel_stats(int b, int c, int p, const float* y, float* part_sum
   const dim3 grid(ceil_div(p, 4096), c, b);   // partials [c][istnet_pw_bwd_stat_tiles(b, p)]
   hipLaunchKernelGGL(pw_channel_stats_kernel, grid, dim3(256), 0, as_stream(stream), c, p, y, part_sum, part_sq,
                      (int)(grid.x * b));
+  return (int)hipGetLastError();
+}
+
+int istnet_pw_interp_stats_tiles(int b, int n) { return b * ceil_div(n, 256); }
+
+int istnet_pw_interp_stats(int b, int c, int m, int n, const float* points, const int* idx, const float* weight, float* out,
+                           float* part_sum, float* part_sq, void* stream) {
+  if (b <= 0 || c <= 0 || m <= 0 || n <= 0 || !points || !idx || !weight || !out || !part_sum || !part_sq) return ISTNET_PN2_EINVAL;
+  const dim3 grid(ceil_div(n, 256), ceil_div(c, 8), b);   // partials [c][istnet_pw_interp_stats_tiles(b, n)]
+  hipLaunchKernelGGL(interp_stats_kernel, grid, dim3(256), 0, as_stream(stream), c, m, n, points, idx, weight, out, part_sum,
+                     part_sq, (int)(grid.x * b));
   return (int)hipGetLastError();
 }
 

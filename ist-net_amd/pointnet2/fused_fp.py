@@ -54,7 +54,10 @@ class FusedFPFunction(Function):
                     st)), "pw_forward_ld(fp)")
             fuse_interp = (skip_c is not None and lib.istnet_pw_forward_cfg(b, c1, cout0, n) == 1
                            and idx.dtype == torch.int32 and idx.is_contiguous() and weight.is_contiguous())
-            t = None if fuse_interp else _ext.three_interpolate(zk, idx, weight)               # (B, cout0, n)
+            # no skip features (the finest level): the interpolated product IS y0; its statistics come from the same launch
+            interp_stats = (skip_c is None and training and idx.dtype == torch.int32 and idx.is_contiguous()
+                            and weight.is_contiguous() and weight.dtype == torch.float32)
+            t = None if (fuse_interp or interp_stats) else _ext.three_interpolate(zk, idx, weight)   # (B, cout0, n)
             bn0 = _empty((4, cout0), torch.float32, dev)
             part = None
             if fuse_interp:
@@ -79,6 +82,13 @@ class FusedFPFunction(Function):
                     4.0 * b * n * (c1 + 2 * cout0), lambda: lib.istnet_pw_forward_acc(
                         b, c1, cout0, n, skip_c.data_ptr(), w2.data_ptr() + 4 * c2, cin, t.data_ptr(), y0.data_ptr(),
                         _p(part[0]) if training else None, _p(part[1]) if training else None, st)), "pw_forward_acc")
+            elif interp_stats:
+                y0 = _empty((b, cout0, n), torch.float32, dev)
+                nt = lib.istnet_pw_interp_stats_tiles(b, n)
+                part = _empty((2, cout0, nt), torch.float32, dev)
+                _native.check(lib.istnet_pw_interp_stats(b, cout0, m, n, zk.data_ptr(), idx.data_ptr(), weight.data_ptr(),
+                                                         y0.data_ptr(), part[0].data_ptr(), part[1].data_ptr(), st),
+                              "pw_interp_stats")
             else:
                 y0 = t
                 if training:
@@ -173,6 +183,9 @@ class FusedFPFunction(Function):
                           else _ext.three_interpolate_grad(dy0, idx, weight, m))
             if need_known:
                 dk = _empty((b, c2, m), torch.float32, dev)
+                # (round 5, measured neutral and removed: with the known features a LazyAct, this product's epilogue can leave the
+                # BatchNorm-backward sums of dk for the coarser level -- bn_bwd_dense_finalize becomes bn_finalize_bwd there, 3
+                # launches of ~13 us -> ~6 us -- but the product itself gets 2-3 us slower: profiles/r05_tail_and_tiles_ab.txt (d))
                 _native.check(_native.timed(
                     _dgrad_kname(lib, b, c2, cout0, m, dense=True), 2.0 * b * m * c2 * cout0,
                     4.0 * b * m * (c2 + cout0), lambda: lib.istnet_pw_dgrad(

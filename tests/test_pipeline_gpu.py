@@ -361,7 +361,10 @@ def test_captured_step_follows_bn_momentum_schedule(monkeypatch):
     assert len(want) >= 32
     worst_stale = 0.0
     for k in want:
-        torch.testing.assert_close(got[k], want[k], rtol=2e-4, atol=1e-6, msg=lambda m, k=k: f"{k}: {m}")
+        # atol: a channel whose batch mean is ~0 has nothing for rtol to scale; torch's own BatchNorm (MIOpen, reduction order
+        # not fixed) moves such a mean by a few 1e-7 of the activations' scale from run to run -- one failure in eight full
+        # runs at atol=1e-6 (round 5), none since; a stale momentum is off by > 1e-2 (asserted below)
+        torch.testing.assert_close(got[k], want[k], rtol=2e-4, atol=1e-5, msg=lambda m, k=k: f"{k}: {m}")
         worst_stale = max(worst_stale, ((stale[k] - want[k]).abs().max() / want[k].abs().max().clamp_min(1e-12)).item())
     assert worst_stale > 1e-2          # the schedule matters on this input: a baked-in momentum would have been caught
     counters = [v for k, v in model.state_dict().items() if k.endswith("num_batches_tracked")]

@@ -672,3 +672,28 @@ def test_row_kernels_beyond_the_grid_y_limit():
     assert lib.istnet_pw_dy(b, c, g * s, y.data_ptr(), d.data_ptr(), bn.data_ptr(), bwdc.data_ptr(), dy.data_ptr(), _st()) == 0
     want = bwdc[0].view(1, -1, 1) * (d * (act.view(b, c, -1) > 0)) + bwdc[1].view(1, -1, 1) + bwdc[2].view(1, -1, 1) * y
     torch.testing.assert_close(dy, want, rtol=1e-6, atol=1e-6)
+
+
+@pytest.mark.parametrize("b,c,m,n", [(2, 20, 64, 128), (3, 128, 96, 300), (1, 7, 32, 256)])
+def test_interp_stats_is_three_interpolate_plus_channel_sums(b, c, m, n):
+    """istnet_pw_interp_stats: the interpolated tensor is bit-identical to the stand-alone three_interpolate (reference
+    interpolate_gpu.cu:77-106) and the partials sum to the per-channel sums of that tensor (ragged n and c included)."""
+    from istnet_amd.pointnet2 import _ext
+    lib = _native.lib()
+    g = torch.Generator().manual_seed(17 * b + n)
+    pts = torch.randn(b, c, m, generator=g).to(DEV)
+    idx = torch.randint(0, m, (b, n, 3), generator=g, dtype=torch.int32).to(DEV)
+    wt = torch.rand(b, n, 3, generator=g)
+    wt = (wt / wt.sum(-1, keepdim=True)).to(DEV)
+    out = torch.empty(b, c, n, device=DEV)
+    nt = lib.istnet_pw_interp_stats_tiles(b, n)
+    part = torch.full((2, c, nt), float("nan"), device=DEV)
+    assert lib.istnet_pw_interp_stats(b, c, m, n, pts.data_ptr(), idx.data_ptr(), wt.data_ptr(), out.data_ptr(),
+                                      part[0].data_ptr(), part[1].data_ptr(), _st()) == 0
+    want = _ext.three_interpolate(pts, idx, wt)
+    assert torch.equal(out, want)
+    w64 = want.double()
+    torch.testing.assert_close(part[0].double().sum(-1), w64.sum(dim=(0, 2)), rtol=1e-5, atol=1e-4)
+    torch.testing.assert_close(part[1].double().sum(-1), w64.square().sum(dim=(0, 2)), rtol=1e-5, atol=1e-4)
+    assert lib.istnet_pw_interp_stats(b, c, m, n, None, idx.data_ptr(), wt.data_ptr(), out.data_ptr(),
+                                      part[0].data_ptr(), part[1].data_ptr(), _st()) != 0

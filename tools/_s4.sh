@@ -1,7 +1,6 @@
-mkdir -p gpurun_out/r5i
-python -m pytest tests -m gpu -q --timeout 900 > gpurun_out/r5i/gputests.txt 2>&1
-tail -4 gpurun_out/r5i/gputests.txt
-python tools/exp/split_precision/bench_split_conv.py 2>&1 | grep -v amdgpu > gpurun_out/r5i/split_conv.txt; tail -4 gpurun_out/r5i/split_conv.txt | cut -c1-200
-python bench.py --workload istnet --steps 10 --warmup 5 --no-eager-leg --split-precision 2>/dev/null | tail -1 > gpurun_out/r5i/istnet_split.json
-python -c "
-import json; d=json.load(open('gpurun_out/r5i/istnet_split.json')); print(d['ms_per_step'], d['split_precision']['ms_per_step'], d['split_precision']['rgb_features_max_rel_diff_vs_fp32_mfma'])"
+mkdir -p gpurun_out/s4
+for i in 1 2 3 4 5 6; do
+  python -m pytest tests/test_autograph_gpu.py tests/test_golden_gpu.py tests/test_pipeline_gpu.py -m gpu -x -q --tb=short -p no:warnings 2>&1 | tail -30 > gpurun_out/s4/run_$i.txt
+  tail -1 gpurun_out/s4/run_$i.txt
+done
+grep -l "failed" gpurun_out/s4/run_*.txt | head -3 | xargs -r -n1 cat
