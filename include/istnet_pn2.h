@@ -83,6 +83,14 @@ ISTNET_PN2_API int istnet_pn2_gather_points_grad(int b, int c, int n, int npoint
 ISTNET_PN2_API int istnet_pn2_query_ball_point(int b, int n, int m, float radius, int nsample,
                                 const float *new_xyz, const float *xyz, int *idx, void *stream);
 
+/* query_ball_point_kernel_wrapper (ball_query.cpp:9-11) for the TWO radii an MSG level asks for on the same centroids
+ * (reference model/modules.py:249-297, pointnet2_modules.py:48-58: one QueryAndGroup per radius): one pass over the cloud,
+ * idx_a (b,m,nsample_a) / idx_b (b,m,nsample_b) bit-identical to two istnet_pn2_query_ball_point calls.  glen_a / glen_b
+ * (b*m each, or NULL): compact-column count of every row for istnet_sa_compact_pair (include/istnet_pw.h). */
+ISTNET_PN2_API int istnet_pn2_query_ball_point_pair(int b, int n, int m, float radius_a, int nsample_a, float radius_b,
+                                                    int nsample_b, const float *new_xyz, const float *xyz, int *idx_a,
+                                                    int *idx_b, int *glen_a, int *glen_b, void *stream);
+
 /* replaces group_points_kernel_wrapper (group_points.cpp:9-11): points (b,c,n), idx (b,npoints,nsample) -> out (b,c,npoints,nsample) */
 ISTNET_PN2_API int istnet_pn2_group_points(int b, int c, int n, int npoints, int nsample, const float *points,
                             const int *idx, float *out, void *stream);

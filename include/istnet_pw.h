@@ -328,6 +328,12 @@ ISTNET_PN2_API int istnet_pw_forward_multi(int b, int nsrc, const float *const *
  *   colw (cap) multiplicity (1, or nsample - cnt for the representative; 0 on the null columns T .. roundup(T, 256)). */
 ISTNET_PN2_API int istnet_sa_compact(int b, int g, int s, int n, const int *idx, int *glen, int *gstart, int *cidx,
                                      int *meta, float *colw, void *stream);
+/* the same for the two scales of one level in 2 launches (3 without counts) instead of 6; have_glen: glen_a / glen_b were
+ * written by istnet_pn2_query_ball_point_pair */
+ISTNET_PN2_API int istnet_sa_compact_pair(int b, int g, int n, int s_a, const int *idx_a, int *glen_a, int *gstart_a,
+                                          int *cidx_a, int *meta_a, float *colw_a, int s_b, const int *idx_b, int *glen_b,
+                                          int *gstart_b, int *cidx_b, int *meta_b, float *colw_b, int have_glen,
+                                          void *stream);
 /* layer 0 on compact columns: y (cout, cap) = z[cloud][:, point] + W0[:, 0:3] . (xyz[source] - new_xyz[group]), weighted
  * partials [cout][cap / 256]; z (b, cout, n) or NULL (xyz-only level) */
 ISTNET_PN2_API int istnet_pw_gather_add_cols(int b, int n, int g, long long cap, int cout, const float *xyz,

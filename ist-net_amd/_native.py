@@ -66,6 +66,7 @@ SIGNATURES = {
     "istnet_pn2_gather_points": [_i, _i, _i, _i, _p, _p, _p, _p],
     "istnet_pn2_gather_points_grad": [_i, _i, _i, _i, _p, _p, _p, _p],
     "istnet_pn2_query_ball_point": [_i, _i, _i, _f, _i, _p, _p, _p, _p],
+    "istnet_pn2_query_ball_point_pair": [_i, _i, _i, _f, _i, _f, _i, _p, _p, _p, _p, _p, _p, _p],
     "istnet_pn2_group_points": [_i, _i, _i, _i, _i, _p, _p, _p, _p],
     "istnet_pn2_group_points_grad": [_i, _i, _i, _i, _i, _p, _p, _p, _p],
     "istnet_pn2_three_nn": [_i, _i, _i, _p, _p, _p, _p, _p],
@@ -142,6 +143,7 @@ SIGNATURES = {
     "istnet_mse_value_grad": [_l, _p, _p, _p, _p, _p, _p],
     # compact-column form of a set-abstraction scale (csrc/sa_compact.hip)
     "istnet_sa_compact": [_i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p],
+    "istnet_sa_compact_pair": [_i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _i, _p, _p, _p, _p, _p, _p, _i, _p],
     "istnet_pw_gather_add_cols": [_i, _i, _i, _l, _i, _p, _p, _p, _p, _p, _p, _p, _p, _i, _p, _p, _p, _p],
     "istnet_pw_forward_cols": [_i, _i, _l, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p],
     "istnet_bn_relu_pool_cols": [_i, _i, _i, _l, _p, _p, _p, _p, _l, _p, _p, _p],

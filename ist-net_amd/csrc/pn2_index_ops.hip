@@ -396,6 +396,82 @@ __global__ __launch_bounds__(kBqWaves * 64) void ball_query_kernel(
   }
 }
 
+// Both radii of an MSG level in ONE pass over the cloud (model/modules.py:249-297: every level queries the same centroids
+// with two radii): the squared distance of a (centroid, point) pair is evaluated once and tested against both radii; each
+// list is emitted exactly as ball_query_kernel emits it (ordered ballot emit, first-hit padding), so both index tensors are
+// bit-identical to two single launches.  Optional: glen[cloud * m + j] = compact-column count of the row (csrc/sa_compact.hip:
+// hits capped at nsample, plus one representative of the padded repeats), which the stand-alone count launch re-derives.
+struct BqList {
+  float radius2;
+  int nsample;
+  int* idx;
+  int* glen;   // or null
+};
+template <bool LDS_XYZ, int CONV>
+__global__ __launch_bounds__(kBqWaves * 64) void ball_query_pair_kernel(
+    int n, int m, BqList la, BqList lb, const float* __restrict__ new_xyz_all, const float* __restrict__ xyz_all) {
+  extern __shared__ __attribute__((aligned(16))) float bq_lds[];  // SoA: x[n] y[n] z[n]
+  const int cloud = blockIdx.y;
+  const float* xyz = xyz_all + (size_t)cloud * n * 3;
+  const float* new_xyz = new_xyz_all + (size_t)cloud * m * 3;
+  const int lane = lane_id(), wave = threadIdx.x >> 6;
+  if (LDS_XYZ) {
+    for (int e = threadIdx.x; e < 3 * n; e += kBqWaves * 64) {
+      const int k = e / 3, comp = e - 3 * k;
+      bq_lds[comp * n + k] = xyz[e];
+    }
+    __syncthreads();
+  }
+  const int j0 = (blockIdx.x * kBqWaves + wave) * kBqCentroidsPerWave;
+  for (int jj = 0; jj < kBqCentroidsPerWave; ++jj) {
+    const int j = j0 + jj;
+    if (j >= m) break;  // wave-uniform
+    const float cx = new_xyz[3 * j + 0], cy = new_xyz[3 * j + 1], cz = new_xyz[3 * j + 2];
+    int* rowa = la.idx + ((size_t)cloud * m + j) * la.nsample;
+    int* rowb = lb.idx + ((size_t)cloud * m + j) * lb.nsample;
+    int cnta = 0, firsta = 0, cntb = 0, firstb = 0;
+    for (int base = 0; base < n && (cnta < la.nsample || cntb < lb.nsample); base += 64) {
+      const int k = base + lane;
+      bool hita = false, hitb = false;
+      if (k < n) {
+        float x, y, z;
+        if (LDS_XYZ) { x = bq_lds[k]; y = bq_lds[n + k]; z = bq_lds[2 * n + k]; }
+        else { x = xyz[3 * k + 0]; y = xyz[3 * k + 1]; z = xyz[3 * k + 2]; }
+        const float d2 = sqdist<CONV>(cx, cy, cz, x, y, z);
+        hita = d2 < la.radius2;
+        hitb = d2 < lb.radius2;
+      }
+      if (cnta < la.nsample) {
+        const unsigned long long mask = __ballot(hita);
+        if (mask) {
+          if (cnta == 0) firsta = base + __ffsll((long long)mask) - 1;
+          const int pos = cnta + __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+          if (hita && pos < la.nsample) rowa[pos] = k;
+          cnta += __popcll(mask);
+        }
+      }
+      if (cntb < lb.nsample) {
+        const unsigned long long mask = __ballot(hitb);
+        if (mask) {
+          if (cntb == 0) firstb = base + __ffsll((long long)mask) - 1;
+          const int pos = cntb + __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+          if (hitb && pos < lb.nsample) rowb[pos] = k;
+          cntb += __popcll(mask);
+        }
+      }
+    }
+    cnta = cnta < la.nsample ? cnta : la.nsample;
+    cntb = cntb < lb.nsample ? cntb : lb.nsample;
+    for (int pos = cnta + lane; pos < la.nsample; pos += 64) rowa[pos] = firsta;  // pad / zeros
+    for (int pos = cntb + lane; pos < lb.nsample; pos += 64) rowb[pos] = firstb;
+    if (lane == 0) {
+      // a row without a hit is all zeros: one distinct entry (index 0), like a row with one hit
+      if (la.glen != nullptr) { const int c = cnta > 0 ? cnta : 1; la.glen[(size_t)cloud * m + j] = c + (c < la.nsample ? 1 : 0); }
+      if (lb.glen != nullptr) { const int c = cntb > 0 ? cntb : 1; lb.glen[(size_t)cloud * m + j] = c + (c < lb.nsample ? 1 : 0); }
+    }
+  }
+}
+
 // ============================================================================
 // group_points   (group_points_gpu.cu:13-33)
 // ============================================================================
@@ -1203,6 +1279,25 @@ int istnet_pn2_query_ball_point(int b, int n, int m, float radius, int nsample,
   } else {
     ISTNET_CONV_DISPATCH(hipLaunchKernelGGL((ball_query_kernel<false, CONV_>), grid, dim3(kBqWaves * 64), 0,
                                             as_stream(stream), n, m, radius2, nsample, new_xyz, xyz, idx));
+  }
+  return (int)hipGetLastError();
+}
+
+int istnet_pn2_query_ball_point_pair(int b, int n, int m, float radius_a, int nsample_a, float radius_b, int nsample_b,
+                                     const float* new_xyz, const float* xyz, int* idx_a, int* idx_b, int* glen_a,
+                                     int* glen_b, void* stream) {
+  if (b < 0 || n <= 0 || m < 0 || nsample_a <= 0 || nsample_b <= 0 || !idx_a || !idx_b) return ISTNET_PN2_EINVAL;
+  if (b == 0 || m == 0) return 0;
+  const BqList la{radius_a * radius_a, nsample_a, idx_a, glen_a};   // ball_query_gpu.cu:27, f32 products
+  const BqList lb{radius_b * radius_b, nsample_b, idx_b, glen_b};
+  const dim3 grid(ceil_div(m, kBqWaves * kBqCentroidsPerWave), b);
+  const size_t lds = (size_t)3 * n * 4;
+  if (lds <= 64 * 1024) {
+    ISTNET_CONV_DISPATCH(hipLaunchKernelGGL((ball_query_pair_kernel<true, CONV_>), grid, dim3(kBqWaves * 64), lds,
+                                            as_stream(stream), n, m, la, lb, new_xyz, xyz));
+  } else {
+    ISTNET_CONV_DISPATCH(hipLaunchKernelGGL((ball_query_pair_kernel<false, CONV_>), grid, dim3(kBqWaves * 64), 0,
+                                            as_stream(stream), n, m, la, lb, new_xyz, xyz));
   }
   return (int)hipGetLastError();
 }

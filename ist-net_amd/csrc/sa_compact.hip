@@ -119,6 +119,113 @@ __global__ __launch_bounds__(256) void compact_fill_kernel(int NG, int G, int S,
   }
 }
 
+// ---- the two scales of an MSG level in one launch each (blockIdx.y = scale) -------------------------------------------
+struct CompactOne {
+  int S;
+  const int* idx;
+  int* glen;
+  int* gstart;
+  int* cidx;
+  int* meta;
+  float* colw;
+};
+struct CompactPair { CompactOne s[2]; };
+
+__global__ __launch_bounds__(256) void compact_count_pair_kernel(int NG, CompactPair cp) {
+  const CompactOne c = cp.s[blockIdx.y];
+  const int g = blockIdx.x * 256 + threadIdx.x;
+  if (g >= NG) return;
+  const int* row = c.idx + (size_t)g * c.S;
+  const int first = row[0];
+  int cnt = 1;
+  for (int s = 1; s < c.S; ++s) cnt += row[s] != first ? 1 : 0;
+  c.glen[g] = cnt + (cnt < c.S ? 1 : 0);
+}
+
+// compact_scan_kernel for two tables; a thread's slice (<= 64 entries, int4 loads) stays in registers between the sum and
+// the write-back (the stand-alone kernel re-reads glen entry by entry in a dependent loop: 18 us for 16 384 groups)
+__global__ __launch_bounds__(1024) void compact_scan_pair_kernel(int NG, CompactPair cp) {
+  const CompactOne c = cp.s[blockIdx.x];
+  __shared__ int wave_tot[16];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int per = ((NG + 1023) / 1024 + 3) & ~3;          // multiple of 4, <= 64 (NG <= 1024 * 64)
+  const int lo = min(tid * per, NG), hi = min(lo + per, NG);
+  int4 v[16];
+  int s = 0;
+#pragma unroll
+  for (int q = 0; q < 16; ++q) {
+    const int i = lo + 4 * q;
+    v[q] = make_int4(0, 0, 0, 0);
+    if (4 * q < per) {
+      if (i + 3 < hi) v[q] = *reinterpret_cast<const int4*>(c.glen + i);
+      else {
+        if (i < hi) v[q].x = c.glen[i];
+        if (i + 1 < hi) v[q].y = c.glen[i + 1];
+        if (i + 2 < hi) v[q].z = c.glen[i + 2];
+      }
+      s += (v[q].x + v[q].y) + (v[q].z + v[q].w);
+    }
+  }
+  int incl = s;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const int up = __shfl_up(incl, d);
+    if (lane >= d) incl += up;
+  }
+  if (lane == 63) wave_tot[wv] = incl;
+  __syncthreads();
+  int base = 0;
+#pragma unroll
+  for (int w = 0; w < 16; ++w) base += w < wv ? wave_tot[w] : 0;
+  int run = base + incl - s;
+#pragma unroll
+  for (int q = 0; q < 16; ++q) {
+    const int i = lo + 4 * q;
+    if (4 * q < per && i < hi) {
+      int4 o;
+      o.x = run; run += v[q].x;
+      o.y = run; run += v[q].y;
+      o.z = run; run += v[q].z;
+      o.w = run; run += v[q].w;
+      if (i + 3 < hi) *reinterpret_cast<int4*>(c.gstart + i) = o;
+      else {
+        c.gstart[i] = o.x;
+        if (i + 1 < hi) c.gstart[i + 1] = o.y;
+        if (i + 2 < hi) c.gstart[i + 2] = o.z;
+      }
+    }
+  }
+  if (tid == 1023) c.gstart[NG] = base + incl;
+}
+
+__global__ __launch_bounds__(256) void compact_fill_pair_kernel(int NG, int G, int n, CompactPair cp) {
+  const CompactOne c = cp.s[blockIdx.y];
+  const int S = c.S;
+  const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+  const long long total = (long long)NG * S;
+  if (e < 256) {                                  // tail (also covers T == 0)
+    const int T = c.gstart[NG];
+    const long long p = T + e;
+    if (p < ((long long)T + 255) / 256 * 256 && p < total) { c.cidx[p] = 0; c.meta[p] = 0; c.colw[p] = 0.f; }
+  }
+  if (e >= total) return;
+  const int g = (int)(e / S), s = (int)(e - (long long)g * S);
+  const int* row = c.idx + (size_t)g * S;
+  const int first = row[0], len = c.gstart[g + 1] - c.gstart[g];
+  const int cnt = len < S ? len - 1 : (row[S - 1] != first || S == 1 ? S : S - 1);
+  const int b = g / G;
+  const int base = c.gstart[g];
+  if (s < cnt) {
+    c.cidx[base + s] = b * n + row[s];
+    c.meta[base + s] = g * 64 + s;
+    c.colw[base + s] = 1.f;
+  } else if (s == cnt) {                          // the representative of the S - cnt repeats of slot 0
+    c.cidx[base + s] = b * n + first;
+    c.meta[base + s] = g * 64 + s;
+    c.colw[base + s] = (float)(S - cnt);
+  }
+}
+
 // ---- layer 0: y0[c][p] = z[cloud][c][point] + W0x[c] . (xyz[source] - centre[group]), weighted statistics ------------
 constexpr int kGatherAddCO = 32;
 __global__ __launch_bounds__(256) void gather_add_cols_kernel(int n, int G, long long cap, int cout, int ldw,
@@ -412,6 +519,28 @@ int istnet_sa_compact(int b, int g, int s, int n, const int* idx, int* glen, int
   hipLaunchKernelGGL(compact_scan_kernel, dim3(1), dim3(1024), 0, as_stream(stream), (int)ng, glen, gstart);
   hipLaunchKernelGGL(compact_fill_kernel, dim3((unsigned)((ng * s + 255) / 256)), dim3(256), 0, as_stream(stream),
                      (int)ng, g, s, n, idx, gstart, cidx, meta, colw);
+  return (int)hipGetLastError();
+}
+
+// istnet_sa_compact for the two scales of one level (same b, g, n): 2 launches (3 when the counts are not supplied)
+// instead of 6.  have_glen != 0: glen_a / glen_b already hold the column counts (istnet_pn2_query_ball_point_pair).
+int istnet_sa_compact_pair(int b, int g, int n, int s_a, const int* idx_a, int* glen_a, int* gstart_a, int* cidx_a,
+                           int* meta_a, float* colw_a, int s_b, const int* idx_b, int* glen_b, int* gstart_b,
+                           int* cidx_b, int* meta_b, float* colw_b, int have_glen, void* stream) {
+  if (b <= 0 || g <= 0 || n <= 0 || s_a <= 0 || s_a > 64 || s_b <= 0 || s_b > 64 || !idx_a || !glen_a || !gstart_a ||
+      !cidx_a || !meta_a || !colw_a || !idx_b || !glen_b || !gstart_b || !cidx_b || !meta_b || !colw_b)
+    return ISTNET_PN2_EINVAL;
+  const long long ng = (long long)b * g;
+  const int smax = s_a > s_b ? s_a : s_b;
+  if (ng > 1024 * 64 || ng * smax >= (1LL << 31) || ng >= (1 << 25)) return ISTNET_PN2_EINVAL;
+  CompactPair cp;
+  cp.s[0] = CompactOne{s_a, idx_a, glen_a, gstart_a, cidx_a, meta_a, colw_a};
+  cp.s[1] = CompactOne{s_b, idx_b, glen_b, gstart_b, cidx_b, meta_b, colw_b};
+  if (!have_glen)
+    hipLaunchKernelGGL(compact_count_pair_kernel, dim3(ceil_div((int)ng, 256), 2), dim3(256), 0, as_stream(stream), (int)ng, cp);
+  hipLaunchKernelGGL(compact_scan_pair_kernel, dim3(2), dim3(1024), 0, as_stream(stream), (int)ng, cp);
+  hipLaunchKernelGGL(compact_fill_pair_kernel, dim3((unsigned)((ng * smax + 255) / 256), 2), dim3(256), 0, as_stream(stream),
+                     (int)ng, g, n, cp);
   return (int)hipGetLastError();
 }
 

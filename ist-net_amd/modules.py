@@ -53,6 +53,8 @@ class GeometrySlot:
         self.event = None    # recorded on the geometry stream after the last write (eager mode)
         self.shape = None
         self.flat = None     # dtype -> flat storage the tensors above are views of
+        self.plan = None     # _ext.OutputPlan: which output allocation of a prefetch pass is which view (prefetch_geometry)
+        self.grad_mode = None
 
     def tensors(self):
         out = []
@@ -120,12 +122,24 @@ class PointNet2MSG(nn.Module):
                     _, new_xyz, tie = chain(cur, sa.npoint, tie_in=tie, track_rounds=rounds)
                 else:
                     new_xyz, tie = sa._sample_centroids(cur), None
-                idx = [pointnet2_utils.ball_query(g.radius, g.nsample, cur, new_xyz) for g in sa.groupers]
+                ext = pointnet2_utils._ext
+                ball_compact = getattr(ext, "ball_compact", None)                    # absent from a plain reference _ext
+                compact = ball_compact is not None and len(sa_geo) in fused_mlp.COMPACT_LEVELS
+                pair = getattr(ext, "ball_query_pair", None) if len(sa.groupers) == 2 else None
                 comps = None
-                ball_compact = getattr(pointnet2_utils._ext, "ball_compact", None)   # absent from a plain reference _ext
-                if ball_compact is not None and len(sa_geo) in fused_mlp.COMPACT_LEVELS:
-                    comps = [ball_compact(i, cur.shape[1]) for i in idx]
-                    comps = comps if all(c is not None for c in comps) else None
+                if pair is not None:
+                    # both radii from one pass over the cloud, the compact-column counts from the same launch; the column
+                    # tables of both scales in 2 launches: 8 -> 3 launches on level 1, 2 -> 1 on the others (bit-identical)
+                    ga, gb = sa.groupers
+                    ia, ib, glens = pair(new_xyz, cur, (ga.radius, gb.radius), (ga.nsample, gb.nsample), want_glen=compact)
+                    idx = [ia, ib]
+                    if compact:
+                        comps = ext.ball_compact_pair(ia, ib, cur.shape[1], glens)
+                else:
+                    idx = [pointnet2_utils.ball_query(g.radius, g.nsample, cur, new_xyz) for g in sa.groupers]
+                    if compact:
+                        comps = [ball_compact(i, cur.shape[1]) for i in idx]
+                        comps = comps if all(c is not None for c in comps) else None
                 ev = torch.cuda.Event()
                 ev.record(side)
                 sa_geo.append([new_xyz, idx, ev, None, comps])
@@ -186,16 +200,31 @@ class PointNet2MSG(nn.Module):
         xyz, _ = self._break_up_pc(pointcloud)
         if not self._can_prepass(xyz):
             raise RuntimeError("prefetch_geometry needs a CUDA point cloud and plain MSG set-abstraction levels")
-        sa_geo, fp_geo, _ = self._geometry_prepass(xyz, with_ball_csr=torch.is_grad_enabled())
+        # The ops write straight into the slot's persistent buffers: an _ext.OutputPlan recorded on one pass (plain
+        # allocations, copied into the slot as before) hands the k-th output allocation of every later pass its slot view
+        # (round 5: the two pack launches per step -- 43 us on the geometry stream -- are gone).  A plain reference _ext has no
+        # plan: its results are copied.
+        ext = pointnet2_utils._ext
+        plan_cls, placing = getattr(ext, "OutputPlan", None), getattr(ext, "placing", None)
+        grad_mode = torch.is_grad_enabled()
+        stale = slot.sa is None or slot.shape != tuple(xyz.shape) or slot.grad_mode != grad_mode
+        plan = None if stale else slot.plan
+        recording = plan_cls is not None and plan is None and not torch.cuda.is_current_stream_capturing()
+        if recording:
+            plan = plan_cls()
+        if plan is not None:
+            with placing(plan):
+                sa_geo, fp_geo, _ = self._geometry_prepass(xyz, with_ball_csr=grad_mode)
+        else:
+            sa_geo, fp_geo, _ = self._geometry_prepass(xyz, with_ball_csr=grad_mode)
         side = _geometry_stream(xyz.device)
         with torch.cuda.stream(side), torch.no_grad():
             fresh = GeometrySlot()
             fresh.sa = [(new_xyz, list(idx), csrs, comps) for new_xyz, idx, _, csrs, comps in sa_geo]
             fresh.fp = [(idx, weight, csr) for idx, weight, csr, _ in fp_geo]
             src = fresh.tensors()
-            if slot.sa is None or slot.shape != tuple(xyz.shape) or len(src) != len(slot.tensors()):
-                # persistent storage: one flat buffer per dtype, the slot's tensors are views into them, so a refill
-                # is two pack kernels instead of one copy per tensor
+            if stale or len(src) != len(slot.tensors()):
+                # persistent storage: one flat buffer per dtype, the slot's tensors are views into them
                 slot.flat = {dt: torch.empty(sum(t.numel() for t in src if t.dtype == dt), dtype=dt, device=xyz.device)
                              for dt in {t.dtype for t in src}}
                 off = {dt: 0 for dt in slot.flat}
@@ -210,13 +239,27 @@ class PointNet2MSG(nn.Module):
                            for _, idxs, csrs, comps in fresh.sa]
                 slot.fp = [(next(it), next(it), (next(it), next(it)) if csr is not None else None)
                            for _, _, csr in fresh.fp]
-                slot.shape = tuple(xyz.shape)
-            for dt, flat in slot.flat.items():
-                group = [t for t in src if t.dtype == dt]
-                if flat.element_size() == 4 and all(t.is_contiguous() for t in group):
-                    _native.pack_words(group, flat, side.cuda_stream)     # one launch per <= 64 tensors
-                else:
-                    torch.cat([t.reshape(-1) for t in group], out=flat)
+                slot.shape, slot.grad_mode = tuple(xyz.shape), grad_mode
+                slot.plan = None
+                if not recording:
+                    plan = None          # a plan of another layout placed nothing we can trust: copy, record next time
+            views = slot.tensors()
+            todo = [(t, v) for t, v in zip(src, views) if t.data_ptr() != v.data_ptr()]
+            if todo:
+                by_dt = {}
+                for t, v in todo:
+                    by_dt.setdefault(t.dtype, []).append((t, v))
+                for dt, pairs in by_dt.items():
+                    whole = len(pairs) == sum(1 for t in src if t.dtype == dt)
+                    if whole and slot.flat[dt].element_size() == 4 and all(t.is_contiguous() for t, _ in pairs):
+                        _native.pack_words([t for t, _ in pairs], slot.flat[dt], side.cuda_stream)   # one launch per <= 64 tensors
+                    else:
+                        for t, v in pairs:
+                            v.copy_(t)
+            if recording:
+                # from the next pass on, the request that produced src[j] is handed views[j]
+                plan.bind({t.data_ptr(): v for t, v in zip(src, views)})
+                slot.plan = plan
             if not torch.cuda.is_current_stream_capturing():
                 slot.event = torch.cuda.Event()
                 slot.event.record(side)

@@ -16,6 +16,66 @@ import torch
 from .. import _native
 
 
+class OutputPlan:
+    """Where the outputs of a fixed SEQUENCE of op calls should live.  ``PointNet2MSG.prefetch_geometry`` refills a
+    GeometrySlot (persistent buffers two captured steps exchange) every step; the ops used to write fresh tensors that one or
+    two pack launches then copied into the slot.  With a plan active (``placing(plan)``) the k-th output allocation of the
+    sequence is handed the slot view recorded for it, so the kernels write the slot directly.  First pass: ``record`` mode,
+    plain allocations are remembered in call order; the caller then maps them to its views (``bind``).  A request whose shape or
+    dtype differs from the recorded one falls back to a plain allocation (the caller copies whatever is not in place)."""
+
+    def __init__(self):
+        self.recorded = []      # record mode: tensors handed out, in call order
+        self.views = None       # replay mode: view (or None) per request
+        self.k = 0
+
+    def bind(self, placed):
+        """``placed``: {data_ptr of a recorded tensor: persistent view it should be written to from now on}."""
+        self.views = [placed.get(t.data_ptr()) for t in self.recorded]
+        self.views = [v if (v is not None and v.shape == t.shape and v.dtype == t.dtype) else None
+                      for v, t in zip(self.views, self.recorded)]
+        self.recorded = None
+
+    def take(self, shape, dtype, device):
+        if self.views is None:
+            t = torch.empty(shape, dtype=dtype, device=device)
+            self.recorded.append(t)
+            return t
+        v = self.views[self.k] if self.k < len(self.views) else None
+        self.k += 1
+        shape = (shape,) if isinstance(shape, int) else tuple(shape)
+        if v is not None and tuple(v.shape) == shape and v.dtype == dtype and v.device == torch.device(device):
+            return v
+        return torch.empty(shape, dtype=dtype, device=device)
+
+
+_PLAN = None
+
+
+class placing:
+    def __init__(self, plan):
+        self.plan = plan
+
+    def __enter__(self):
+        global _PLAN
+        self.prev, _PLAN = _PLAN, self.plan
+        if self.plan is not None:
+            self.plan.k = 0
+        return self.plan
+
+    def __exit__(self, *exc):
+        global _PLAN
+        _PLAN = self.prev
+        return False
+
+
+def _new(shape, dtype=None, device=None):
+    if _PLAN is None:
+        return torch.empty(shape, dtype=dtype, device=device)
+    return _PLAN.take(shape, dtype, device)
+
+
+
 def set_distance_convention(convention):
     """Arithmetic of the index-deciding squared distances in furthest_point_sampling / ball_query / three_nn:
     0 = the reference's source expression ``((dx*dx + dy*dy) + dz*dz)`` with every operation rounded (default);
@@ -77,7 +137,7 @@ def gather_points(points, idx):
     dev = _device_of(points, "points", (idx, "idx"))
     b, c, n = points.shape
     m = idx.shape[1]
-    out = torch.empty((b, c, m), dtype=torch.float32, device=dev)
+    out = _new((b, c, m), dtype=torch.float32, device=dev)
     with torch.cuda.device(dev):
         _native.check(_native.lib().istnet_pn2_gather_points(
             b, c, n, m, _ptr(points), _ptr(idx), _ptr(out), _stream(dev)), "gather_points")
@@ -89,7 +149,7 @@ def gather_points_grad(grad_out, idx, n):
     _contig(grad_out, "grad_out"); _contig(idx, "idx"); _is_float(grad_out, "grad_out"); _is_int(idx, "idx")
     dev = _device_of(grad_out, "grad_out", (idx, "idx"))
     b, c, m = grad_out.shape
-    out = torch.empty((b, c, int(n)), dtype=torch.float32, device=dev)
+    out = _new((b, c, int(n)), dtype=torch.float32, device=dev)
     with torch.cuda.device(dev):
         _native.check(_native.lib().istnet_pn2_gather_points_grad(
             b, c, int(n), m, _ptr(grad_out), _ptr(idx), _ptr(out), _stream(dev)), "gather_points_grad")
@@ -102,9 +162,9 @@ def furthest_point_sampling(points, nsamples):
     dev = _device_of(points, "points")
     b, n = points.shape[0], points.shape[1]
     nsamples = int(nsamples)
-    out = torch.empty((b, nsamples), dtype=torch.int32, device=dev)
+    out = _new((b, nsamples), dtype=torch.int32, device=dev)
     # scratch is only needed by the large-cloud kernel (n > 4096); see include/istnet_pn2.h
-    tmp = torch.empty((b, n), dtype=torch.float32, device=dev) if n > 4096 else None
+    tmp = _new((b, n), dtype=torch.float32, device=dev) if n > 4096 else None
     with torch.cuda.device(dev):
         _native.check(_native.lib().istnet_pn2_furthest_point_sampling(
             b, n, nsamples, _ptr(points), _ptr(tmp) if tmp is not None else None, _ptr(out),
@@ -119,8 +179,8 @@ def furthest_point_sampling_gather(points, nsamples):
     dev = _device_of(points, "points")
     b, n = points.shape[0], points.shape[1]
     nsamples = int(nsamples)
-    out = torch.empty((b, nsamples), dtype=torch.int32, device=dev)
-    picked = torch.empty((b, nsamples, 3), dtype=torch.float32, device=dev)
+    out = _new((b, nsamples), dtype=torch.int32, device=dev)
+    picked = _new((b, nsamples, 3), dtype=torch.float32, device=dev)
     with torch.cuda.device(dev):
         _native.check(_native.lib().istnet_pn2_fps_gather(b, n, nsamples, _ptr(points), _ptr(out), _ptr(picked),
                                                           _stream(dev)), "fps_gather")
@@ -140,9 +200,9 @@ def furthest_point_sampling_chain(points, nsamples, tie_in=None, track_rounds=No
     if tie_in is not None:
         _contig(tie_in, "tie_in"); _is_int(tie_in, "tie_in")
         _req(tie_in.is_cuda and tie_in.device == dev and tie_in.numel() == b, "tie_in must be (B,) int32 on the device of points")
-    out = torch.empty((b, nsamples), dtype=torch.int32, device=dev)
-    picked = torch.empty((b, nsamples, 3), dtype=torch.float32, device=dev)
-    tie = torch.empty((b,), dtype=torch.int32, device=dev)
+    out = _new((b, nsamples), dtype=torch.int32, device=dev)
+    picked = _new((b, nsamples, 3), dtype=torch.float32, device=dev)
+    tie = _new((b,), dtype=torch.int32, device=dev)
     track = nsamples if track_rounds is None else int(track_rounds)
     with torch.cuda.device(dev):
         _native.check(_native.lib().istnet_pn2_fps_gather_chain(
@@ -158,8 +218,8 @@ def three_nn(unknowns, knows):
     dev = _device_of(unknowns, "unknowns", (knows, "knows"))
     b, n = unknowns.shape[0], unknowns.shape[1]
     m = knows.shape[1]
-    idx = torch.empty((b, n, 3), dtype=torch.int32, device=dev)
-    dist2 = torch.empty((b, n, 3), dtype=torch.float32, device=dev)
+    idx = _new((b, n, 3), dtype=torch.int32, device=dev)
+    dist2 = _new((b, n, 3), dtype=torch.float32, device=dev)
     with torch.cuda.device(dev):
         _native.check(_native.lib().istnet_pn2_three_nn(
             b, n, m, _ptr(unknowns), _ptr(knows), _ptr(dist2), _ptr(idx), _stream(dev)), "three_nn")
@@ -174,8 +234,8 @@ def three_nn_weights(unknowns, knows):
     dev = _device_of(unknowns, "unknowns", (knows, "knows"))
     b, n = unknowns.shape[0], unknowns.shape[1]
     m = knows.shape[1]
-    idx = torch.empty((b, n, 3), dtype=torch.int32, device=dev)
-    weight = torch.empty((b, n, 3), dtype=torch.float32, device=dev)
+    idx = _new((b, n, 3), dtype=torch.int32, device=dev)
+    weight = _new((b, n, 3), dtype=torch.float32, device=dev)
     with torch.cuda.device(dev):
         _native.check(_native.lib().istnet_pn2_three_nn_weights(
             b, n, m, _ptr(unknowns), _ptr(knows), _ptr(idx), _ptr(weight), _stream(dev)), "three_nn_weights")
@@ -189,7 +249,7 @@ def three_interpolate(points, idx, weight):
     dev = _device_of(points, "points", (idx, "idx"), (weight, "weight"))
     b, c, m = points.shape
     n = idx.shape[1]
-    out = torch.empty((b, c, n), dtype=torch.float32, device=dev)
+    out = _new((b, c, n), dtype=torch.float32, device=dev)
     with torch.cuda.device(dev):
         _native.check(_native.lib().istnet_pn2_three_interpolate(
             b, c, m, n, _ptr(points), _ptr(idx), _ptr(weight), _ptr(out), _stream(dev)),
@@ -222,8 +282,8 @@ def csr_multi(problems):
         fits_range, fits_legacy = _csr_fits(e, m)
         if not (fits_range or fits_legacy):
             continue
-        offsets = torch.empty((b, m + 1), dtype=torch.int32, device=dev)
-        entries = torch.empty((b, e), dtype=torch.int32, device=dev)
+        offsets = _new((b, m + 1), dtype=torch.int32, device=dev)
+        entries = _new((b, e), dtype=torch.int32, device=dev)
         out[i] = (offsets, entries)
         if fits_range:
             batch.append((b, e, m, idx, offsets, entries))
@@ -308,9 +368,10 @@ def ball_compact_lists(compacts):
     dev = compacts[0].gstart.device
     work = []
     for c in compacts:
-        cstart = c.gstart[::c.g].contiguous()                                    # (B + 1): first column of every cloud
-        off = torch.empty((b, c.n + 1), dtype=torch.int32, device=dev)
-        ent = torch.empty((c.cap,), dtype=torch.int32, device=dev)
+        cstart = _new((b + 1,), dtype=torch.int32, device=dev)                  # first column of every cloud
+        cstart.copy_(c.gstart[::c.g])
+        off = _new((b, c.n + 1), dtype=torch.int32, device=dev)
+        ent = _new((c.cap,), dtype=torch.int32, device=dev)
         work.append((c, cstart, off, ent))
     n = len(work)
     arr = lambda ts: (ctypes.c_void_p * n)(*[_ptr(t) for t in ts])
@@ -335,11 +396,11 @@ def ball_compact(idx, n):
     cap = b * g * s
     if cap % 256 or s > 64 or b * g > 1024 * 64 or cap >= 2 ** 31:
         return None
-    glen = torch.empty(b * g, dtype=torch.int32, device=dev)
-    gstart = torch.empty(b * g + 1, dtype=torch.int32, device=dev)
-    cidx = torch.empty(cap, dtype=torch.int32, device=dev)
-    meta = torch.empty(cap, dtype=torch.int32, device=dev)
-    colw = torch.empty(cap, dtype=torch.float32, device=dev)
+    glen = _new(b * g, dtype=torch.int32, device=dev)
+    gstart = _new(b * g + 1, dtype=torch.int32, device=dev)
+    cidx = _new(cap, dtype=torch.int32, device=dev)
+    meta = _new(cap, dtype=torch.int32, device=dev)
+    colw = _new(cap, dtype=torch.float32, device=dev)
     with torch.cuda.device(dev):
         _native.check(_native.lib().istnet_sa_compact(b, g, s, int(n), _ptr(idx), _ptr(glen), _ptr(gstart), _ptr(cidx),
                                                       _ptr(meta), _ptr(colw), _stream(dev)), "sa_compact")
@@ -354,7 +415,7 @@ def three_interpolate_grad(grad_out, idx, weight, m, csr=None):
     dev = _device_of(grad_out, "grad_out", (idx, "idx"), (weight, "weight"))
     b, c, n = grad_out.shape
     m = int(m)
-    out = torch.empty((b, c, m), dtype=torch.float32, device=dev)
+    out = _new((b, c, m), dtype=torch.float32, device=dev)
     lib = _native.lib()
     if csr is None:
         csr = interp_csr(idx, m)   # deterministic gather over per-cloud inverse lists, reused by all channels
@@ -378,12 +439,62 @@ def ball_query(new_xyz, xyz, radius, nsample):
     b, m = new_xyz.shape[0], new_xyz.shape[1]
     n = xyz.shape[1]
     nsample = int(nsample)
-    idx = torch.empty((b, m, nsample), dtype=torch.int32, device=dev)
+    idx = _new((b, m, nsample), dtype=torch.int32, device=dev)
     with torch.cuda.device(dev):
         _native.check(_native.lib().istnet_pn2_query_ball_point(
             b, n, m, float(radius), nsample, _ptr(new_xyz), _ptr(xyz), _ptr(idx), _stream(dev)),
             "ball_query")
     return idx
+
+
+def ball_query_pair(new_xyz, xyz, radii, nsamples, want_glen=False):
+    """The two ball queries of an MSG level (same centroids, two radii) in one pass over the cloud: (idx_a, idx_b, glens) with
+    idx_* bit-identical to ``ball_query(new_xyz, xyz, radius, nsample)`` per radius.  ``glens`` = (glen_a, glen_b), the
+    compact-column counts ``ball_compact_pair`` starts from, or None.  Extension of the reference's op set
+    (ball_query.cpp:13-37 once per radius)."""
+    _contig(new_xyz, "new_xyz"); _contig(xyz, "xyz"); _is_float(new_xyz, "new_xyz"); _is_float(xyz, "xyz")
+    dev = _device_of(new_xyz, "new_xyz", (xyz, "xyz"))
+    b, m = new_xyz.shape[0], new_xyz.shape[1]
+    n = xyz.shape[1]
+    (ra, rb), (sa, sb) = radii, (int(nsamples[0]), int(nsamples[1]))
+    _req(sa > 0 and sb > 0, "nsample must be positive")
+    idx_a = _new((b, m, sa), dtype=torch.int32, device=dev)
+    idx_b = _new((b, m, sb), dtype=torch.int32, device=dev)
+    glens = None
+    if want_glen:
+        glens = (_new(b * m, dtype=torch.int32, device=dev), _new(b * m, dtype=torch.int32, device=dev))
+    with torch.cuda.device(dev):
+        _native.check(_native.lib().istnet_pn2_query_ball_point_pair(
+            b, n, m, float(ra), sa, float(rb), sb, _ptr(new_xyz), _ptr(xyz), _ptr(idx_a), _ptr(idx_b),
+            _ptr(glens[0]) if glens else None, _ptr(glens[1]) if glens else None, _stream(dev)), "ball_query_pair")
+    return idx_a, idx_b, glens
+
+
+def ball_compact_pair(idx_a, idx_b, n, glens=None):
+    """``ball_compact`` for the two scales of one level in 2 launches instead of 6 (3 when ``glens`` -- the counts
+    ``ball_query_pair`` wrote -- is None); a list of two BallCompact, or None when a shape is outside what the kernels take."""
+    for t, name in ((idx_a, "idx_a"), (idx_b, "idx_b")):
+        _contig(t, name); _is_int(t, name)
+    dev = _device_of(idx_a, "idx_a", (idx_b, "idx_b"))
+    b, g, sa = idx_a.shape
+    sb = idx_b.shape[2]
+    _req(idx_b.shape[0] == b and idx_b.shape[1] == g, "the two index tensors must share (B, npoint)")
+    if any((b * g * s) % 256 or s > 64 or b * g * s >= 2 ** 31 for s in (sa, sb)) or b * g > 1024 * 64:
+        return None
+    out = []
+    for s, gl in ((sa, glens[0] if glens else None), (sb, glens[1] if glens else None)):
+        cap = b * g * s
+        out.append(BallCompact(gl if gl is not None else _new(b * g, dtype=torch.int32, device=dev),
+                               _new(b * g + 1, dtype=torch.int32, device=dev),
+                               _new(cap, dtype=torch.int32, device=dev), _new(cap, dtype=torch.int32, device=dev),
+                               _new(cap, dtype=torch.float32, device=dev), b, g, s, int(n)))
+    ca, cb = out
+    with torch.cuda.device(dev):
+        _native.check(_native.lib().istnet_sa_compact_pair(
+            b, g, int(n), sa, _ptr(idx_a), _ptr(ca.glen), _ptr(ca.gstart), _ptr(ca.cidx), _ptr(ca.meta), _ptr(ca.colw),
+            sb, _ptr(idx_b), _ptr(cb.glen), _ptr(cb.gstart), _ptr(cb.cidx), _ptr(cb.meta), _ptr(cb.colw),
+            1 if glens else 0, _stream(dev)), "sa_compact_pair")
+    return out
 
 
 def group_points(points, idx):
@@ -392,7 +503,7 @@ def group_points(points, idx):
     dev = _device_of(points, "points", (idx, "idx"))
     b, c, n = points.shape
     npoints, nsample = idx.shape[1], idx.shape[2]
-    out = torch.empty((b, c, npoints, nsample), dtype=torch.float32, device=dev)
+    out = _new((b, c, npoints, nsample), dtype=torch.float32, device=dev)
     with torch.cuda.device(dev):
         _native.check(_native.lib().istnet_pn2_group_points(
             b, c, n, npoints, nsample, _ptr(points), _ptr(idx), _ptr(out), _stream(dev)),
@@ -406,7 +517,7 @@ def group_points_grad(grad_out, idx, n, csr=None):
     _contig(grad_out, "grad_out"); _contig(idx, "idx"); _is_float(grad_out, "grad_out"); _is_int(idx, "idx")
     dev = _device_of(grad_out, "grad_out", (idx, "idx"))
     b, c, npoints, nsample = grad_out.shape
-    out = torch.empty((b, c, int(n)), dtype=torch.float32, device=dev)
+    out = _new((b, c, int(n)), dtype=torch.float32, device=dev)
     lib = _native.lib()
     # default up to 4096 slots per cloud: deterministic gather over per-cloud inverse lists (one extra launch builds
     # them, all channels reuse them): 2.2-2.6x faster than the LDS-atomic kernel there (list build included); at 8192

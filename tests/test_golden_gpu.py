@@ -94,12 +94,15 @@ def test_encoder_b2(monkeypatch):
         monkeypatch.setattr(_ext, name, fn)
     # the encoder samples + gathers in one op (chained over the levels: a level whose parent run had no arg-max tie
     # takes the prefix of its input), and takes three_nn together with the interpolation weights
-    for n in ("furthest_point_sampling_chain", "ball_query", "three_nn_weights"):
+    # ... and asks for the two radii of a level in one launch (ball_query_pair: index tensors 2l and 2l + 1 of the golden)
+    for n in ("furthest_point_sampling_chain", "ball_query_pair", "three_nn_weights"):
         tap(n)
     torch.manual_seed(0)
     enc = PointNet2MSG([list(r) for r in CAM]).to(DEV).train()
     pts = torch.from_numpy(z["pts"]).to(DEV)
     out = enc(pts)
+    for lvl in range(4):
+        captured[f"ball_query_{2 * lvl}"], captured[f"ball_query_{2 * lvl + 1}"] = captured[f"ball_query_pair_{lvl}"][:2]
     for i in range(4):
         assert np.array_equal(captured[f"furthest_point_sampling_chain_{i}"][0].cpu().numpy(),
                               z[f"furthest_point_sampling_{i}"].astype(np.int32)), i
@@ -182,13 +185,15 @@ def test_index_goldens_under_each_fma_convention(conv, monkeypatch):
                 captured[f"{name}_{i}"] = res
                 return res
             monkeypatch.setattr(_ext, name, fn)
-        for n in ("furthest_point_sampling_chain", "ball_query", "three_nn_weights"):
+        for n in ("furthest_point_sampling_chain", "ball_query_pair", "three_nn_weights"):
             tap(n)
         torch.manual_seed(0)
         enc = PointNet2MSG([list(r) for r in CAM]).to(DEV).train()
         pts = torch.from_numpy(z["pts_cube"]).to(DEV)
         with torch.no_grad():
             out = enc(pts)
+        for lvl in range(4):
+            captured[f"ball_query_{2 * lvl}"], captured[f"ball_query_{2 * lvl + 1}"] = captured[f"ball_query_pair_{lvl}"][:2]
         flips = 0
         for i in range(4):
             want = z[f"c{conv}_furthest_point_sampling_{i}"].astype(np.int32)

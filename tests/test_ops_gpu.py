@@ -81,6 +81,47 @@ def test_ball_query_edges(ext, oracle):
     assert got[0, 1].tolist() == [1, 1, 1]
 
 
+@pytest.mark.parametrize("b,n,m,ra,sa,rb,sb,kind", [
+    (2, 1024, 512, 0.01, 16, 0.02, 32, "shell"), (2, 512, 256, 0.02, 16, 0.04, 32, "shell"), (3, 300, 77, 0.3, 8, 0.1, 64, "cube"),
+    (2, 256, 64, 0.26, 16, 0.5, 32, "grid"), (1, 100, 40, 0.2, 4, 0.2, 4, "dup"), (2, 128, 64, 0.0005, 16, 0.4, 32, "cube"),
+])
+def test_ball_query_pair_equals_two_queries(ext, oracle, b, n, m, ra, sa, rb, sb, kind):
+    """One pass over the cloud for the two radii of an MSG level: both index tensors bit-identical to the oracle
+    (ball_query_gpu.cu:14-49) and to the single-radius launches, either radius larger, lists that fill at different rounds,
+    empty balls; the column counts it leaves equal those of the stand-alone compaction."""
+    xyz = _cloud(b, n, seed=7 * n + m, kind=kind)
+    fps = oracle.furthest_point_sampling(xyz, m).long()
+    new_xyz = torch.gather(xyz, 1, fps.unsqueeze(-1).expand(b, m, 3)).contiguous()
+    if kind == "grid":
+        new_xyz[:, ::3] += 5.0          # empty balls: rows of zeros
+    ia, ib, glens = ext.ball_query_pair(new_xyz.to(DEV), xyz.to(DEV), (ra, rb), (sa, sb), want_glen=True)
+    for got, r, ns, gl in ((ia, ra, sa, glens[0]), (ib, rb, sb, glens[1])):
+        assert torch.equal(got.cpu(), oracle.ball_query(new_xyz, xyz, r, ns))
+        assert torch.equal(got, ext.ball_query(new_xyz.to(DEV), xyz.to(DEV), r, ns))
+        row = got.cpu()
+        cnt = 1 + (row[:, :, 1:] != row[:, :, :1]).sum(-1)
+        assert torch.equal(gl.cpu().view(b, m), (cnt + (cnt < ns)).int())
+    ja, jb, none = ext.ball_query_pair(new_xyz.to(DEV), xyz.to(DEV), (ra, rb), (sa, sb))
+    assert none is None and torch.equal(ja, ia) and torch.equal(jb, ib)
+
+
+@pytest.mark.parametrize("with_glen", [True, False])
+def test_ball_compact_pair_equals_two_compactions(ext, with_glen):
+    b, n, m = 4, 1024, 512
+    xyz = _cloud(b, n, seed=11, kind="shell").to(DEV)
+    new_xyz = xyz[:, :m].contiguous()
+    ia, ib, glens = ext.ball_query_pair(new_xyz, xyz, (0.01, 0.02), (16, 32), want_glen=with_glen)
+    pair = ext.ball_compact_pair(ia, ib, n, glens)
+    for cm, idx in zip(pair, (ia, ib)):
+        ref = ext.ball_compact(idx, n)
+        t = int(ref.gstart[-1])
+        assert int(cm.gstart[-1]) == t and 0 < t < cm.cap
+        assert torch.equal(cm.glen, ref.glen) and torch.equal(cm.gstart, ref.gstart)
+        up = (t + 255) // 256 * 256
+        for a, r in ((cm.cidx, ref.cidx), (cm.meta, ref.meta), (cm.colw, ref.colw)):
+            assert torch.equal(a[:up], r[:up])
+
+
 @pytest.mark.parametrize("b,n,m,kind", [
     (2, 128, 64, "cube"), (2, 256, 128, "shell"), (2, 512, 256, "cube"), (4, 1024, 512, "shell"),
     (2, 1024, 512, "grid"), (2, 333, 77, "dup"), (1, 50, 2, "cube"), (1, 50, 1, "cube"),

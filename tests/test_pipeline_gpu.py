@@ -35,6 +35,52 @@ def test_prefetched_geometry_equals_in_step_geometry():
         enc(_shell(2, 512, 3), geometry=slots[0])
 
 
+def test_prefetch_refills_write_the_slot_in_place(monkeypatch):
+    """After the recording pass the ops of a prefetch write the slot's persistent buffers directly (_ext.OutputPlan): no
+    pack / copy launch, the same buffers, and a step through the refilled slot equals a step through a fresh one bit for bit
+    (tables are compared through their consumers: entries past the valid column count are unspecified); a grad-mode change
+    (the inverse lists disappear) falls back to one copying pass and records again."""
+    from istnet_amd import _native
+    torch.manual_seed(0)
+    enc = PointNet2MSG([list(r) for r in CAM]).to(DEV).train()
+    a, b = _shell(2, 1024, 11), _shell(2, 1024, 12)
+    packs = []
+    real = _native.pack_words
+    monkeypatch.setattr(_native, "pack_words", lambda srcs, dst, st: (packs.append(len(srcs)), real(srcs, dst, st))[1])
+
+    def step(pts, slot):
+        enc.zero_grad(set_to_none=True)
+        out = enc(pts, geometry=slot)
+        out.square().mean().backward()
+        return out.detach().clone(), [p.grad.clone() for p in enc.parameters()]
+
+    slot = enc.prefetch_geometry(a, GeometrySlot())
+    assert packs and slot.plan is not None           # recording pass: plain allocations, packed once
+    ptrs = [t.data_ptr() for t in slot.tensors()]
+    del packs[:]
+    enc.prefetch_geometry(b, slot)
+    enc.join_geometry()
+    assert not packs and [t.data_ptr() for t in slot.tensors()] == ptrs
+    for m in enc.modules():                          # the two steps below must see the same running statistics / counters
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.momentum = 0.0
+    got = step(b, slot)
+    fresh = enc.prefetch_geometry(b, GeometrySlot())
+    enc.join_geometry()
+    want = step(b, fresh)
+    assert torch.equal(got[0], want[0]) and all(torch.equal(g, w) for g, w in zip(got[1], want[1]))
+    for key_got, key_want in zip(slot.sa, fresh.sa):                       # the index tensors themselves are fully specified
+        assert torch.equal(key_got[0], key_want[0]) and all(torch.equal(x, y) for x, y in zip(key_got[1], key_want[1]))
+    with torch.no_grad():                            # no inverse lists without gradients: another layout
+        enc.prefetch_geometry(a, slot)
+        assert slot.plan is not None and len(slot.tensors()) < len(ptrs)
+        del packs[:]
+        enc.prefetch_geometry(b, slot)
+        enc.join_geometry()
+        assert not packs
+        assert torch.equal(enc(b, geometry=slot), enc(b))
+
+
 def test_pipelined_training_steps_match_plain_steps_under_graph_capture():
     """Two alternating batches, two captured graphs (bench.py's default mode) vs plain eager steps: the gradient
     of every step agrees (learning rate 0, so the weights stay put and step k of both runs sees the same problem;

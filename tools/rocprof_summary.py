@@ -15,6 +15,14 @@ def main():
     tot = sum(r[2] for r in rows)
     n = sum(r[1] for r in rows)
     print(f"# source: {sys.argv[1]}")
+    # steps delimited by the optimizer launches: everything between the first and the last adam_step_kernel is whole steps
+    # (set-up copies / fills and the capture's warm-up outside that window do not count as per-step dispatches)
+    adam = [r[0] for r in db.execute("select start from kernels where name like '%adam_step_kernel%' order by start")]
+    if len(adam) > 2:
+        inside = list(db.execute("select count(*), sum(end-start) from kernels where start > ? and start <= ?", (adam[0], adam[-1])))[0]
+        k = len(adam) - 1
+        print(f"# between the first and the last of {len(adam)} optimizer launches: {inside[0] / k:.1f} dispatches and "
+              f"{inside[1] / 1e3 / k:.1f} us of kernel time per step")
     print(f"# total kernel time {tot / 1e6:.3f} ms over {n} dispatches"
           + (f" ({steps} steps incl. warm-up: {tot / 1e6 / steps:.3f} ms, {n / steps:.0f} dispatches per step)" if steps else ""))
     print(f"{'pct':>6} {'calls':>7} {'total_us':>11} {'avg_us':>9} {'min_us':>9} {'max_us':>9}  name")
