@@ -151,6 +151,11 @@ ISTNET_PN2_API int istnet_pn2_three_interpolate_grad_csr(int b, int c, int n, in
  * elementwise / reduce launches per propagation level. */
 ISTNET_PN2_API int istnet_pn2_three_nn_weights(int b, int n, int m, const float *unknown, const float *known,
                                                int *idx, float *weight, void *stream);
+/* the same for up to 8 (n, m) problems over the same b clouds in ONE launch -- the four propagation levels of an encoder pass
+ * (reference model/modules.py:322-325); arrays of nprob entries, every problem bit-identical to its stand-alone launch */
+ISTNET_PN2_API int istnet_pn2_three_nn_weights_multi(int nprob, int b, const int *n, const int *m,
+                                                     const float *const *unknown, const float *const *known,
+                                                     int *const *idx, float *const *weight, void *stream);
 
 /* Deterministic, atomic-free form of group_points_grad over the inverse lists of idx (istnet_pn2_csr_build with
  * e = npoints*nsample, m = n): grad_points[b][c][i] = sum over the slots that picked point i.  The reference uses one

@@ -71,6 +71,7 @@ SIGNATURES = {
     "istnet_pn2_group_points_grad": [_i, _i, _i, _i, _i, _p, _p, _p, _p],
     "istnet_pn2_three_nn": [_i, _i, _i, _p, _p, _p, _p, _p],
     "istnet_pn2_three_nn_weights": [_i, _i, _i, _p, _p, _p, _p, _p],
+    "istnet_pn2_three_nn_weights_multi": [_i, _i, _p, _p, _p, _p, _p, _p, _p],
     "istnet_pn2_three_interpolate": [_i, _i, _i, _i, _p, _p, _p, _p, _p],
     "istnet_pn2_three_interpolate_grad": [_i, _i, _i, _i, _p, _p, _p, _p, _p],
     "istnet_pn2_interp_csr_build": [_i, _i, _i, _p, _p, _p, _p],

@@ -1040,18 +1040,17 @@ __device__ __forceinline__ void nn_merge_quad(Nn3& t) {
   if (e3 < __builtin_inff()) nn_insert(t, e3, j3);
 }
 
+// one workgroup: 64 unknown points (tile) of one cloud, four lanes per point
 template <int CONV>
-__global__ __launch_bounds__(256) void three_nn_kernel(int n, int m,
-                                                       const float* __restrict__ unknown_all,
-                                                       const float* __restrict__ known_all,
-                                                       float* __restrict__ dist2_all,
-                                                       int* __restrict__ idx_all,
-                                                       float* __restrict__ weight_all) {
-  __shared__ __attribute__((aligned(16))) float kn[kNnTile * 3];
-  const int cloud = blockIdx.y;
+__device__ __forceinline__ void three_nn_tile(float* kn, int n, int m, int tile, int cloud,
+                                              const float* __restrict__ unknown_all,
+                                              const float* __restrict__ known_all,
+                                              float* __restrict__ dist2_all,
+                                              int* __restrict__ idx_all,
+                                              float* __restrict__ weight_all) {
   const float* unknown = unknown_all + (size_t)cloud * n * 3;
   const float* known = known_all + (size_t)cloud * m * 3;
-  const int j = blockIdx.x * 64 + (threadIdx.x >> 2), sub = threadIdx.x & 3;
+  const int j = tile * 64 + (threadIdx.x >> 2), sub = threadIdx.x & 3;
   const bool active = j < n;
   float ux = 0.f, uy = 0.f, uz = 0.f;
   if (active) { ux = unknown[3 * j + 0]; uy = unknown[3 * j + 1]; uz = unknown[3 * j + 2]; }
@@ -1090,6 +1089,39 @@ __global__ __launch_bounds__(256) void three_nn_kernel(int n, int m,
       w[0] = r1 / norm; w[1] = r2 / norm; w[2] = r3 / norm;
     }
   }
+}
+
+template <int CONV>
+__global__ __launch_bounds__(256) void three_nn_kernel(int n, int m,
+                                                       const float* __restrict__ unknown_all,
+                                                       const float* __restrict__ known_all,
+                                                       float* __restrict__ dist2_all,
+                                                       int* __restrict__ idx_all,
+                                                       float* __restrict__ weight_all) {
+  __shared__ __attribute__((aligned(16))) float kn[kNnTile * 3];
+  three_nn_tile<CONV>(kn, n, m, blockIdx.x, blockIdx.y, unknown_all, known_all, dist2_all, idx_all, weight_all);
+}
+
+// The neighbour searches of all feature-propagation levels of an encoder pass (model/modules.py:322-325: four levels, each
+// its own (n, m)) in ONE launch: blockIdx.x walks the tiles of problem 0, then problem 1, ...; every problem is evaluated by
+// the same code as its stand-alone launch.
+constexpr int kNnMaxProblems = 8;
+struct NnBatch {
+  int count;
+  int n[kNnMaxProblems], m[kNnMaxProblems];
+  int first[kNnMaxProblems + 1];          // first tile of every problem
+  const float* unknown[kNnMaxProblems];
+  const float* known[kNnMaxProblems];
+  int* idx[kNnMaxProblems];
+  float* weight[kNnMaxProblems];
+};
+template <int CONV>
+__global__ __launch_bounds__(256) void three_nn_multi_kernel(NnBatch nb) {
+  __shared__ __attribute__((aligned(16))) float kn[kNnTile * 3];
+  int p = 0;
+  while (p + 1 < nb.count && (int)blockIdx.x >= nb.first[p + 1]) ++p;      // uniform
+  three_nn_tile<CONV>(kn, nb.n[p], nb.m[p], (int)blockIdx.x - nb.first[p], blockIdx.y, nb.unknown[p], nb.known[p],
+                      (float*)nullptr, nb.idx[p], nb.weight[p]);
 }
 
 // ============================================================================
@@ -1373,6 +1405,27 @@ int istnet_pn2_three_nn_weights(int b, int n, int m, const float* unknown, const
   if (b == 0 || n == 0) return 0;
   ISTNET_CONV_DISPATCH(hipLaunchKernelGGL(three_nn_kernel<CONV_>, dim3(ceil_div(n, 64), b), dim3(256), 0,
                                           as_stream(stream), n, m, unknown, known, (float*)nullptr, idx, weight));
+  return (int)hipGetLastError();
+}
+
+int istnet_pn2_three_nn_weights_multi(int nprob, int b, const int* n, const int* m, const float* const* unknown,
+                                      const float* const* known, int* const* idx, float* const* weight, void* stream) {
+  if (nprob <= 0 || nprob > kNnMaxProblems || b < 0 || !n || !m || !unknown || !known || !idx || !weight) return ISTNET_PN2_EINVAL;
+  if (b == 0) return 0;
+  NnBatch nb;
+  nb.count = 0;
+  int tiles = 0;
+  for (int p = 0; p < nprob; ++p) {
+    if (n[p] < 0 || m[p] < 0 || !idx[p] || !weight[p]) return ISTNET_PN2_EINVAL;
+    if (n[p] == 0) continue;
+    const int q = nb.count++;
+    nb.n[q] = n[p]; nb.m[q] = m[p]; nb.first[q] = tiles;
+    nb.unknown[q] = unknown[p]; nb.known[q] = known[p]; nb.idx[q] = idx[p]; nb.weight[q] = weight[p];
+    tiles += ceil_div(n[p], 64);
+  }
+  if (nb.count == 0) return 0;
+  nb.first[nb.count] = tiles;
+  ISTNET_CONV_DISPATCH(hipLaunchKernelGGL(three_nn_multi_kernel<CONV_>, dim3(tiles, b), dim3(256), 0, as_stream(stream), nb));
   return (int)hipGetLastError();
 }
 

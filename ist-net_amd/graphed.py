@@ -44,6 +44,8 @@ import torch
 ENABLED = os.environ.get("ISTNET_AUTO_GRAPH", "1") != "0"
 WARMUP_CALLS = 2
 MAX_ENTRIES = 4          # captured shapes kept per module (least recently used goes first)
+import collections
+WHY = collections.Counter()      # AutoGraph: why a call took the plain path (diagnostics; tests print it when a capture is missing)
 STATS = {"captures": 0, "replays": 0, "plain": 0, "failed": 0,                       # AutoGraph (training)
          "infer_captures": 0, "infer_replays": 0, "infer_plain": 0, "infer_failed": 0}    # InferenceGraph
 # other threads of the caller (a DataLoader's pin-memory thread, a logger) keep making HIP calls while this thread captures:
@@ -115,6 +117,7 @@ class AutoGraph:
         for m in mods:
             flags.append(m.training)
             if m._forward_hooks or m._forward_pre_hooks or m._backward_hooks or m._backward_pre_hooks:
+                WHY[f"module hook on {type(m).__name__}"] += 1
                 return None
             for p in m._parameters.values():
                 if p is None:
@@ -122,6 +125,7 @@ class AutoGraph:
                 addrs.append(p.data_ptr())
                 req.append(p.requires_grad)
                 if p.requires_grad and p.grad is not None:
+                    WHY["a parameter already holds a .grad (accumulation)"] += 1
                     return None              # accumulation into an existing .grad: the captured kernels overwrite
                 slot = p.__dict__.get("_istnet_grad_slot")
                 addrs.append(0 if slot is None else slot.data_ptr())
@@ -134,10 +138,12 @@ class AutoGraph:
         module = self.module()
         if not (ENABLED and x.is_cuda and torch.is_grad_enabled() and not x.requires_grad and x.is_contiguous()
                 and not torch.cuda.is_current_stream_capturing()):
+            WHY["not eligible (disabled / no grad mode / input requires grad / capturing)"] += 1
             return self.plain(x)
         key = self._key(module, x)
         if key is None or not any(key[5]):
             STATS["plain"] += 1
+            WHY["hooks, an existing .grad, or nothing to differentiate"] += 1
             return self.plain(x)
         entry = self.entries.get(key)
         if entry is None:
@@ -150,6 +156,7 @@ class AutoGraph:
         entry.calls += 1
         if entry.failed or entry.calls <= WARMUP_CALLS:
             STATS["plain"] += 1
+            WHY["capture failed earlier" if entry.failed else "warm-up call"] += 1
             return self.plain(x)
         if entry.fwd is None:
             try:
@@ -166,6 +173,7 @@ class AutoGraph:
             # the previous graphed forward has not been back-propagated and its output is still referenced: a replay
             # would overwrite the activations that backward needs
             STATS["plain"] += 1
+            WHY["previous graphed output still alive and not back-propagated"] += 1
             return self.plain(x)
         params = entry.params
         out = _Replay.apply(entry, x, *params)

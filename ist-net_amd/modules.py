@@ -145,11 +145,21 @@ class PointNet2MSG(nn.Module):
                 sa_geo.append([new_xyz, idx, ev, None, comps])
                 levels.append(new_xyz)
                 cur = new_xyz
-            for lvl in range(len(self.FP_modules) - 1, -1, -1):
-                idx, weight = PointnetFPModule.interpolation_weights(levels[lvl], levels[lvl + 1])
+            order = list(range(len(self.FP_modules) - 1, -1, -1))
+            multi = getattr(pointnet2_utils._ext, "three_nn_weights_multi", None)     # absent from a plain reference _ext
+            if multi is not None and len(order) <= 8 and all(levels[l + 1].shape[1] >= 3 for l in order):
+                # the neighbour searches of all propagation levels in one launch (coarse level first, as the forward asks)
+                res = multi([(levels[l], levels[l + 1]) for l in order])
                 ev = torch.cuda.Event()
                 ev.record(side)
-                fp_geo[lvl] = [idx, weight, None, ev]
+                for l, (idx, weight) in zip(order, res):
+                    fp_geo[l] = [idx, weight, None, ev]
+            else:
+                for lvl in order:
+                    idx, weight = PointnetFPModule.interpolation_weights(levels[lvl], levels[lvl + 1])
+                    ev = torch.cuda.Event()
+                    ev.record(side)
+                    fp_geo[lvl] = [idx, weight, None, ev]
             csr_ev = None
             csr_multi = getattr(pointnet2_utils._ext, "csr_multi", None)     # absent from a plain reference _ext
             if with_ball_csr and csr_multi is not None:

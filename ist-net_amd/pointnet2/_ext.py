@@ -242,6 +242,32 @@ def three_nn_weights(unknowns, knows):
     return idx, weight
 
 
+def three_nn_weights_multi(pairs):
+    """``three_nn_weights`` for several (unknowns, knows) pairs over the same B clouds in one launch (the propagation levels
+    of an encoder pass); a list of (idx, weight), each bit-identical to the stand-alone call.  At most 8 pairs."""
+    import ctypes
+    _req(0 < len(pairs) <= 8, "1 to 8 problems")
+    dev = None
+    for u, k in pairs:
+        _contig(u, "unknowns"); _contig(k, "knows"); _is_float(u, "unknowns"); _is_float(k, "knows")
+        d = _device_of(u, "unknowns", (k, "knows"))
+        _req(dev is None or d == dev, "all problems on one device")
+        _req(u.shape[0] == pairs[0][0].shape[0] == k.shape[0], "all problems over the same clouds")
+        dev = d
+    b = pairs[0][0].shape[0]
+    outs = [(_new((b, u.shape[1], 3), dtype=torch.int32, device=dev), _new((b, u.shape[1], 3), dtype=torch.float32, device=dev))
+            for u, _ in pairs]
+    k = len(pairs)
+    ints = lambda vals: (ctypes.c_int * k)(*vals)
+    ptrs = lambda ts: (ctypes.c_void_p * k)(*[_ptr(t) for t in ts])
+    with torch.cuda.device(dev):
+        _native.check(_native.lib().istnet_pn2_three_nn_weights_multi(
+            k, b, ints([u.shape[1] for u, _ in pairs]), ints([kn.shape[1] for _, kn in pairs]), ptrs([u for u, _ in pairs]),
+            ptrs([kn for _, kn in pairs]), ptrs([o[0] for o in outs]), ptrs([o[1] for o in outs]), _stream(dev)),
+            "three_nn_weights_multi")
+    return outs
+
+
 def three_interpolate(points, idx, weight):
     """(B,C,m) f32, (B,n,3) i32, (B,n,3) f32 -> (B,C,n).  interpolate.cpp:47-74"""
     _contig(points, "points"); _contig(idx, "idx"); _contig(weight, "weight")

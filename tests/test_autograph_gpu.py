@@ -49,8 +49,9 @@ def _train(auto, opt_kind, steps=7, b=4, n=512):
 def test_graphed_training_loop_is_bit_identical_with_the_plain_path(opt_kind):
     from istnet_amd import graphed
     before = dict(graphed.STATS)
+    graphed.WHY.clear()
     outs_g, state_g = _train(True, opt_kind)
-    assert graphed.STATS["captures"] == before["captures"] + 1
+    assert graphed.STATS["captures"] == before["captures"] + 1, dict(graphed.WHY)
     assert graphed.STATS["replays"] >= before["replays"] + 5          # steps 3..7 replayed
     assert graphed.STATS["failed"] == before["failed"]
     outs_p, state_p = _train(False, opt_kind)

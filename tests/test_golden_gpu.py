@@ -95,7 +95,8 @@ def test_encoder_b2(monkeypatch):
     # the encoder samples + gathers in one op (chained over the levels: a level whose parent run had no arg-max tie
     # takes the prefix of its input), and takes three_nn together with the interpolation weights
     # ... and asks for the two radii of a level in one launch (ball_query_pair: index tensors 2l and 2l + 1 of the golden)
-    for n in ("furthest_point_sampling_chain", "ball_query_pair", "three_nn_weights"):
+    # ... and the neighbour searches of the four propagation levels in one launch (three_nn_weights_multi, coarse level first)
+    for n in ("furthest_point_sampling_chain", "ball_query_pair", "three_nn_weights_multi"):
         tap(n)
     torch.manual_seed(0)
     enc = PointNet2MSG([list(r) for r in CAM]).to(DEV).train()
@@ -103,6 +104,7 @@ def test_encoder_b2(monkeypatch):
     out = enc(pts)
     for lvl in range(4):
         captured[f"ball_query_{2 * lvl}"], captured[f"ball_query_{2 * lvl + 1}"] = captured[f"ball_query_pair_{lvl}"][:2]
+        captured[f"three_nn_weights_{lvl}"] = captured["three_nn_weights_multi_0"][lvl]
     for i in range(4):
         assert np.array_equal(captured[f"furthest_point_sampling_chain_{i}"][0].cpu().numpy(),
                               z[f"furthest_point_sampling_{i}"].astype(np.int32)), i
@@ -185,7 +187,7 @@ def test_index_goldens_under_each_fma_convention(conv, monkeypatch):
                 captured[f"{name}_{i}"] = res
                 return res
             monkeypatch.setattr(_ext, name, fn)
-        for n in ("furthest_point_sampling_chain", "ball_query_pair", "three_nn_weights"):
+        for n in ("furthest_point_sampling_chain", "ball_query_pair", "three_nn_weights_multi"):
             tap(n)
         torch.manual_seed(0)
         enc = PointNet2MSG([list(r) for r in CAM]).to(DEV).train()
@@ -194,6 +196,7 @@ def test_index_goldens_under_each_fma_convention(conv, monkeypatch):
             out = enc(pts)
         for lvl in range(4):
             captured[f"ball_query_{2 * lvl}"], captured[f"ball_query_{2 * lvl + 1}"] = captured[f"ball_query_pair_{lvl}"][:2]
+            captured[f"three_nn_weights_{lvl}"] = captured["three_nn_weights_multi_0"][lvl]
         flips = 0
         for i in range(4):
             want = z[f"c{conv}_furthest_point_sampling_{i}"].astype(np.int32)
@@ -488,12 +491,19 @@ def test_benchmark_path_runs_only_native_kernels_for_the_dense_stack():
     from istnet_amd.modules import PointNet2MSG
     torch.manual_seed(0)
     enc = PointNet2MSG([list(r) for r in CAM]).to(DEV).train()
-    fired = []
+    fired, handles = [], []
     for name, m in enc.named_modules():
         if isinstance(m, (torch.nn.Conv2d, torch.nn.BatchNorm2d, torch.nn.ReLU)):
-            m.register_forward_hook(lambda mod, i, o, name=name: fired.append(name))
-    out = enc(_shell(4, 1024, 1).to(DEV))
-    out.square().mean().backward()
+            handles.append(m.register_forward_hook(lambda mod, i, o, name=name: fired.append(name)))
+    try:
+        out = enc(_shell(4, 1024, 1).to(DEV))
+        out.square().mean().backward()
+    finally:
+        # the activation module is ONE instance shared by every stack of the process (a default argument, as in the
+        # reference's pytorch_utils.py:25-50): a hook left on it follows every model built afterwards -- and switches their
+        # graph segments off (graphed.WHY says so)
+        for h in handles:
+            h.remove()
     assert fired == [], f"torch fallback used for {fired[:4]}"
     assert _native._lib is not None and os.path.exists(_native.LIB_PATH)
     assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in enc.parameters())

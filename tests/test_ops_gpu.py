@@ -136,6 +136,22 @@ def test_three_nn_bit_exact(ext, oracle, b, n, m, kind):
     assert torch.equal(d_got.cpu(), d_want)  # same f32 arithmetic, inf where m < 3
 
 
+def test_three_nn_weights_multi_equals_single_launches(ext, oracle):
+    """All propagation levels in one launch: every problem bit-identical to its own three_nn_weights launch (and its indices to
+    the oracle, interpolate_gpu.cu:14-61), ragged sizes and a problem whose unknown count is not a multiple of the tile."""
+    b = 3
+    sizes = [(64, 32), (128, 64), (300, 128), (1024, 512), (70, 3)]
+    pairs = [(_cloud(b, n, seed=n, kind="shell").to(DEV), _cloud(b, m, seed=n + m, kind="shell").to(DEV)) for n, m in sizes]
+    res = ext.three_nn_weights_multi(pairs)
+    assert len(res) == len(pairs)
+    for (u, k), (idx, w) in zip(pairs, res):
+        i1, w1 = ext.three_nn_weights(u, k)
+        assert torch.equal(idx, i1) and torch.equal(w, w1)
+        assert torch.equal(idx.cpu(), oracle.three_nn(u.cpu(), k.cpu())[1])
+    with pytest.raises(Exception):
+        ext.three_nn_weights_multi([])
+
+
 @pytest.mark.parametrize("b,c,n,m", [(2, 3, 1024, 512), (2, 64, 512, 256), (1, 7, 100, 33), (1, 1, 5, 9)])
 def test_gather_points_and_grad(ext, oracle, b, c, n, m):
     g = torch.Generator().manual_seed(c * n)
