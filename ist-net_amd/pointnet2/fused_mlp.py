@@ -237,6 +237,12 @@ def _can_defer(params):
             if key in _Deferred.mains:
                 torch.cuda.current_stream().wait_stream(wstream)
         return False
+    # This node becomes the producer of these gradients for the pass -- with or without an optimizer's slot behind them
+    # (round 5: _grad_dest claimed only parameters that HAVE a flat-gradient slot, so without FlatAdam a second node of the
+    # same pass deferred too and the engine summed two tensors the wgrad stream was still writing: loss = f(m(a)) + f(m(b))
+    # gave run-to-run different gradients on small shapes, tools/exp/determinism_small.py)
+    for p in params:
+        _Claims.claim(p)
     return True
 
 

@@ -219,3 +219,26 @@ def test_inference_graph_leaves_training_and_grad_mode_alone():
         assert graphed.STATS["infer_captures"] == before["infer_captures"] + 2
     _close(b_, a, tol=1e-4)
     graphed.reset(net)
+
+
+def test_two_uses_in_one_backward_are_reproducible_without_an_optimizer_slot():
+    """loss = f(m(a)) + f(m(b)) with plain parameters (no FlatAdam slot): the second producer of a weight gradient must not
+    defer its launches behind the engine's sum of the two tensors (round 5: it did, and on this small shape one FP weight
+    gradient changed bits from run to run).  Same step 30 times, allocator moved around in between: identical bits."""
+    from istnet_amd import graphed
+    graphed.ENABLED = False
+    try:
+        model = _model()
+        a, b = _cloud(2, 256, 1), _cloud(2, 256, 2)
+        ref = None
+        for it in range(30):
+            model.zero_grad()
+            junk = torch.empty(1 << (10 + it % 12), device="cuda").normal_()
+            (model(a).square().mean() + model(b).square().mean()).backward()
+            got = [p.grad.clone() for p in model.parameters()]
+            ref = ref or got
+            for (name, _), g, r in zip(model.named_parameters(), got, ref):
+                assert torch.equal(g, r), (it, name)
+            del junk
+    finally:
+        graphed.ENABLED = True
