@@ -198,7 +198,9 @@ class FusedFPFunction(Function):
                 grads[0] = dest.view_as(w0)
                 ksc, ksh = (known_bn[0].data_ptr(), known_bn[1].data_ptr()) if known_bn is not None else (None, None)
 
-                def wjob(wst):
+                def wjob(wst, reduce_items=None):
+                    # reduce_items: the stack's list of split-K sums -- this job adds its two column blocks to it and the
+                    # stack sums everything in ONE launch (round 5: a level issued two)
                     sp_a = lib.istnet_pw_wgrad_splits(b, c2, cout0, m)
                     ws_a = _empty((sp_a, cout0, c2), torch.float32, dev)
                     _native.check(_native.timed(
@@ -218,8 +220,12 @@ class FusedFPFunction(Function):
                                 0, None, dy_bn.data_ptr(), dy_bw.data_ptr(), ws_b.data_ptr(), wst)), "pw_wgrad(fp skip)")
                         red.append((cout0 * c1, sp_b, ws_b.data_ptr(), dest.data_ptr() + 4 * c2, c1, cin, cout0 * c1))
                         keep += [ws_b]
-                    _native.reduce_multi(red, wst)     # both column blocks of dW0 in place: no concatenation
+                    if reduce_items is not None:
+                        reduce_items.extend(red)
+                    else:
+                        _native.reduce_multi(red, wst)     # both column blocks of dW0 in place: no concatenation
                     return keep, dy_y, dy_d, dy_bn, dy_bw, gk, known_bn
+                wjob.joins_reduce = True
                 wextra.append(wjob)
             _join_streams(streams)
             return None

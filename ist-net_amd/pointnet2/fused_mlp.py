@@ -620,6 +620,18 @@ def _reduce_only_job(dev, wparam, cout, cin, splits, ws):
     return launch
 
 
+def _run_wgrad_jobs(wjobs, wextra, stream):
+    """The weight-gradient launches of a stack on ``stream``: its jobs, the extra closures that bring their own split-K sums
+    (``joins_reduce``: feature-propagation layer 0), ONE reduce launch for all of them, then the remaining closures."""
+    done = [job(stream) for job in wjobs]
+    items = [(cnt, splits, ws.data_ptr(), dw.data_ptr()) for cnt, splits, ws, dw in done]
+    keep = [fn(stream, items) for fn in wextra if getattr(fn, "joins_reduce", False)]
+    if items:
+        _native.reduce_multi(items, stream)
+    keep += [fn(stream) for fn in wextra if not getattr(fn, "joins_reduce", False)]
+    return done, keep
+
+
 def _backward_stack(lib, dev, st, b, c0, g, s, x, gather, training, ys, bns, params, arg, dout, need_w, need_x,
                     pooled_bstride=0, scatter_out=None, layer0_hook=None):
     """Returns (grads for [w, gamma, beta] * L, gradient w.r.t. the layer-0 input or None).
@@ -811,19 +823,11 @@ def _backward_stack(lib, dev, st, b, c0, g, s, x, gather, training, ys, bns, par
             _Deferred.mains.setdefault(key, cur)
             wstream.wait_stream(cur)
             with torch.cuda.stream(wstream):
-                done = [job(wstream.cuda_stream) for job in wjobs]
-                if done:
-                    _native.reduce_multi([(cnt, splits, ws.data_ptr(), dw.data_ptr()) for cnt, splits, ws, dw in done],
-                                         wstream.cuda_stream)
-                extra_keep = [fn(wstream.cuda_stream) for fn in wextra]
+                done, extra_keep = _run_wgrad_jobs(wjobs, wextra, wstream.cuda_stream)
             _Deferred.keep += [wjobs, done, wextra, extra_keep]
             _Deferred.arm()
         else:
-            done = [job(st) for job in wjobs]
-            if done:
-                _native.reduce_multi([(cnt, splits, ws.data_ptr(), dw.data_ptr()) for cnt, splits, ws, dw in done], st)
-            for fn in wextra:
-                fn(st)
+            done, _ = _run_wgrad_jobs(wjobs, wextra, st)
         for li, (_, _, _, dw) in zip(wlayers, done):
             grads[3 * li] = dw.view_as(params[3 * li])
     return grads, dx, scattered
