@@ -790,6 +790,11 @@ def main():
         for kv in os.environ["ISTNET_PW_TUNE"].split(","):
             k, v = kv.split(":")
             assert _native.lib().istnet_pw_set_tuning(int(k), int(v)) == 0
+    if os.environ.get("ISTNET_PN2_TUNE"):   # experiments: "key:value,..." for istnet_pn2_set_tuning
+        from istnet_amd import _native
+        for kv in os.environ["ISTNET_PN2_TUNE"].split(","):
+            k, v = kv.split(":")
+            assert _native.lib().istnet_pn2_set_tuning(int(k), int(v)) == 0
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         return self_launch(args.gpus)
     world = int(os.environ.get("WORLD_SIZE", "1"))
