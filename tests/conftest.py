@@ -3,6 +3,15 @@ import sys
 
 import pytest
 
+# Test-only: keep MIOpen's Find from benchmarking one assembly solver.  The torch reference compositions of these tests run
+# nn.Conv2d backward through MIOpen; for a new problem torch calls miopenFindConvolutionBackwardDataAlgorithm, which times
+# every applicable solver, and on this stack (ROCm 7.2.0, torch 2.10.0+rocm7.0, gfx950) the solver
+# ConvAsmImplicitGemmGTCDynamicBwdXdlopsNHWC (igemm_bwd_gtcx35_nhwc_fp32 ... bt256x64x4) reads out of bounds for some 1 x 1
+# problems: a GPU memory fault -- SIGABRT without a message -- whenever the allocator happens to have put the tensor at the
+# end of a mapping, i.e. depending on which tests ran before (round 5: rocgdb backtrace of the abort that only a particular
+# order of three test files produced; the product's kernels were not involved).  Must be set before MIOpen initialises.
+os.environ.setdefault("MIOPEN_DEBUG_CONV_IMPLICIT_GEMM_ASM_BWD_GTC_XDLOPS_NHWC", "0")
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
