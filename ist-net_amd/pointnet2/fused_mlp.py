@@ -853,11 +853,7 @@ def _backward_stack_compact(lib, dev, st, b, g, s, ga, training, ys, bns, params
         cin = 3 + ga.cfeat if li == 0 else params[3 * (li - 1)].shape[0]
         w2 = w.reshape(cout, cin)
         y, bn = ys[li], bns[li]
-        if li == n - 1:      # through the max-pool: statistics from the (B, C, G) tensors, then the dense compact gradient
-            part, nt_l = _empty((2, cout, b), torch.float32, dev), b
-            _native.check(lib.istnet_pw_bwd_stats_pooled(b, cout, g, dout.data_ptr(), pooled_bstride,
-                                                         _ymax_ptr(arg, b * cout * g), bn.data_ptr(),
-                                                         part[0].data_ptr(), part[1].data_ptr(), st), "pw_bwd_stats_pooled")
+        if li == n - 1:      # through the max-pool: the dense compact gradient (statistics + constants below, one launch)
             d_dense = _empty((1, cout, cap), torch.float32, dev)
             _native.check(lib.istnet_pw_pooled_grad_cols(b, cout, g, cap, dout.data_ptr(), pooled_bstride, arg.data_ptr(),
                                                          cm.meta.data_ptr(), ncols, d_dense.data_ptr(), st),
@@ -867,9 +863,18 @@ def _backward_stack_compact(lib, dev, st, b, g, s, ga, training, ys, bns, params
         dgamma = _grad_dest(gamma, (cout,), dev)
         dbeta = _grad_dest(params[3 * li + 2], (cout,), dev)
         bwdc = _empty((3, cout), torch.float32, dev)
-        _native.check(lib.istnet_bn_finalize_bwd(
-            cout, nt_l, count, 1 if training else 0, part[0].data_ptr(), part[1].data_ptr(), gamma.data_ptr(),
-            bn.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), bwdc.data_ptr(), st), "bn_finalize_bwd")
+        if li == n - 1:
+            # the sums through the max-pool live on the (B, C, G) tensors whatever the column layout (only arg-max columns
+            # carry a gradient): the padded path's statistics + finalize launch serves the compact path too (round 5: it ran
+            # pw_bwd_stats_pooled and bn_finalize_bwd, two launches on the last chain of the backward pass)
+            _native.check(lib.istnet_bn_bwd_pooled_finalize(
+                b, cout, g, count, 1 if training else 0, dout.data_ptr(), pooled_bstride, _ymax_ptr(arg, b * cout * g),
+                gamma.data_ptr(), bn.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), bwdc.data_ptr(), st),
+                "bn_bwd_pooled_finalize")
+        else:
+            _native.check(lib.istnet_bn_finalize_bwd(
+                cout, nt_l, count, 1 if training else 0, part[0].data_ptr(), part[1].data_ptr(), gamma.data_ptr(),
+                bn.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), bwdc.data_ptr(), st), "bn_finalize_bwd")
         grads[3 * li + 1], grads[3 * li + 2] = dgamma, dbeta
         if li > 0 and lib.istnet_pw_bwd_small_ok(cin, cout, 256):
             splits = lib.istnet_pw_bwd_small_cols_splits()
