@@ -25,6 +25,15 @@ ISTNET_PN2_API int istnet_adam_step(long long n, float *param, const float *grad
                                     const float *step, const float *lr_dev, double lr, double beta1, double beta2,
                                     double eps, double weight_decay, double grad_scale, void *stream);
 
+/* The same update with the step count advanced BY the launch: t = *step + 1 is what the update uses, and the last workgroup
+ * to finish stores it back (ticket: a device u32 that is 0 between launches and 0 again afterwards).  Saves the framework's
+ * `step += 1` kernel in front of every update (reference utils/solver.py:98, torch.optim.Adam.step keeps its count the
+ * same way: state['step'] += 1, then the update with the new value).  n == 0 only counts. */
+ISTNET_PN2_API int istnet_adam_step_counting(long long n, float *param, const float *grad, float *exp_avg,
+                                             float *exp_avg_sq, float *step, unsigned *ticket, const float *lr_dev,
+                                             double lr, double beta1, double beta2, double eps, double weight_decay,
+                                             double grad_scale, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

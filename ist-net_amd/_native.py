@@ -25,6 +25,7 @@ SIGNATURES = {
     "istnet_pw_scatter_dy_csr": [_i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _l, _p, _p, _i, _p, _p],
     "istnet_pw_scatter_dy_csr_fin": [_i, _i, _i, _i, _p, _p, _p, _i, _d, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _l, _p, _p, _i, _p, _p],
     "istnet_adam_step": [_l, _p, _p, _p, _p, _p, _p, _d, _d, _d, _d, _d, _d, _p],
+    "istnet_adam_step_counting": [_l, _p, _p, _p, _p, _p, _p, _p, _d, _d, _d, _d, _d, _d, _p],
     "istnet_conv_supported": [_i] * 6,
     "istnet_conv_workspace_floats": [_i] * 10,
     "istnet_conv_forward": [_i] * 9 + [_p] * 5,

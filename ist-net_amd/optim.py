@@ -77,6 +77,7 @@ class FlatAdam(torch.optim.Optimizer):
         self.exp_avg = torch.zeros_like(self.flat)
         self.exp_avg_sq = torch.zeros_like(self.flat)
         self.step_count = torch.zeros((), dtype=torch.float32, device=dev)
+        self._ticket = torch.zeros((), dtype=torch.int32, device=dev)       # istnet_adam_step_counting: 0 between launches
         # the learning rate lives on the device: a per-iteration schedule writes this scalar (``opt.lr = value``) and
         # a step captured in a HIP graph picks the new value up without re-capture
         self._lr_dev = torch.full((), float(lr), dtype=torch.float32, device=dev)
@@ -163,18 +164,18 @@ class FlatAdam(torch.optim.Optimizer):
         g = self.pack_grads() if flat_grad is None else flat_grad
         if not (self.flat.is_cuda and torch.cuda.is_current_stream_capturing()):
             self.sync_lr()          # (inside a capture the fill would be recorded and replayed: sync before capturing)
-        self.step_count += 1
         if self.flat.is_cuda:
             from . import _native
             if not g.is_contiguous() or g.dtype != torch.float32 or g.numel() != self.flat.numel():
                 raise ValueError("FlatAdam.step: flat_grad must be a contiguous float32 tensor of the parameters' size")
             with torch.cuda.device(self.flat.device):
-                _native.check(_native.lib().istnet_adam_step(
+                # the launch advances step_count itself (last workgroup to finish): no `step_count += 1` kernel in front
+                _native.check(_native.lib().istnet_adam_step_counting(
                     self.flat.numel(), self.flat.data_ptr(), g.data_ptr(), self.exp_avg.data_ptr(),
-                    self.exp_avg_sq.data_ptr(), self.step_count.data_ptr(), self._lr_dev.data_ptr(), self._lr,
-                    self.betas[0], self.betas[1],
+                    self.exp_avg_sq.data_ptr(), self.step_count.data_ptr(), self._ticket.data_ptr(),
+                    self._lr_dev.data_ptr(), self._lr, self.betas[0], self.betas[1],
                     self.eps, self.weight_decay, float(grad_scale),
-                    torch.cuda.current_stream(self.flat.device).cuda_stream), "adam_step")
+                    torch.cuda.current_stream(self.flat.device).cuda_stream), "adam_step_counting")
             # The native update writes the flat buffer through raw pointers, which autograd cannot see: tell it.  A
             # forward whose backward runs AFTER this step (two forwards then backward / step / backward, a prefetched
             # next forward) then raises "modified by an inplace operation" instead of silently differentiating with the
@@ -182,6 +183,7 @@ class FlatAdam(torch.optim.Optimizer):
             # (tests/test_optim.py::test_backward_after_native_step_raises pins the guard)
             torch.autograd.graph.increment_version(self.params)      # public API (torch >= 2.1); an absent one raises here
             return
+        self.step_count += 1
         if grad_scale != 1.0:
             g = g * grad_scale
         # CPU (host-logic tests): the same update with plain ops

@@ -407,3 +407,52 @@ def test_flat_adam_keeps_channels_last_parameters_channels_last():
     torch.testing.assert_close(opt2.exp_avg, opt.exp_avg)
     for v, p in zip(opt.grad_views(opt.pack_grads()), opt.params):
         torch.testing.assert_close(v, p.grad)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [4, 1031, 1 << 20, (1 << 21) + 5])
+def test_counting_adam_launch_equals_increment_then_update(n):
+    """istnet_adam_step_counting: the launch that advances the step count itself gives bit for bit what `step += 1` followed by
+    istnet_adam_step gives, the count goes up by one per launch (also on replays of a captured launch), and the ticket is back
+    at zero afterwards -- sizes below one workgroup, odd tails, and more quads than the capped grid covers in one sweep."""
+    from istnet_amd import _native
+    lib = _native.lib()
+    dev = "cuda:0"
+    g = torch.Generator().manual_seed(n)
+    p0 = torch.randn(n, generator=g).to(dev)
+    grads = [torch.randn(n, generator=g).to(dev) for _ in range(3)]
+    st = torch.cuda.current_stream().cuda_stream
+
+    def state():
+        return p0.clone(), torch.zeros(n, device=dev), torch.zeros(n, device=dev), torch.zeros((), device=dev)
+
+    pa, ma, va, sa = state()
+    pb, mb, vb, sb = state()
+    ticket = torch.zeros((), dtype=torch.int32, device=dev)
+    args = (None, 1e-3, 0.9, 0.999, 1e-8, 0.01, 0.5, st)
+    for gr in grads:
+        sa += 1
+        assert lib.istnet_adam_step(n, pa.data_ptr(), gr.data_ptr(), ma.data_ptr(), va.data_ptr(), sa.data_ptr(), *args) == 0
+        assert lib.istnet_adam_step_counting(n, pb.data_ptr(), gr.data_ptr(), mb.data_ptr(), vb.data_ptr(), sb.data_ptr(),
+                                             ticket.data_ptr(), *args) == 0
+    torch.cuda.synchronize()
+    assert float(sb) == 3.0 and int(ticket) == 0
+    assert torch.equal(pa, pb) and torch.equal(ma, mb) and torch.equal(va, vb)
+    graph = torch.cuda.CUDAGraph()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        with torch.cuda.graph(graph):
+            assert lib.istnet_adam_step_counting(n, pb.data_ptr(), grads[0].data_ptr(), mb.data_ptr(), vb.data_ptr(),
+                                                 sb.data_ptr(), ticket.data_ptr(), None, 1e-3, 0.9, 0.999, 1e-8, 0.01, 0.5,
+                                                 torch.cuda.current_stream().cuda_stream) == 0
+    torch.cuda.current_stream().wait_stream(side)
+    for _ in range(4):
+        graph.replay()
+    torch.cuda.synchronize()
+    assert float(sb) == 7.0 and int(ticket) == 0
+    for _ in range(4):
+        sa += 1
+        assert lib.istnet_adam_step(n, pa.data_ptr(), grads[0].data_ptr(), ma.data_ptr(), va.data_ptr(), sa.data_ptr(), *args) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(pa, pb)
