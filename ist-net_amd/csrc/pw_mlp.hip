@@ -620,8 +620,14 @@ __global__ __launch_bounds__(kThreads, 2) void pw_fwd_sk_kernel(
   __shared__ __attribute__((aligned(16))) float lds[4 * 4 * 16 * 64];   // 64 KB: the four waves' partial sums
   const int lane = lane_id(), wv = wave_id();
   const int l31 = lane & 31, half = lane >> 5;
-  const int b = blockIdx.x / tiles_per_cloud;
-  const int p0 = (blockIdx.x - b * tiles_per_cloud) * 128;
+  // A tile is 128 consecutive points of the FLATTENED (cloud, point) axis; a lane owns four of them.  With P % 128 == 0 the
+  // tile lies in one cloud; with fewer points per cloud (the coarsest propagation level: P = 64) it spans several and the
+  // cloud is a per-lane quantity (P % 4 == 0: a lane's four points never straddle two clouds).  (round 5: such launches took
+  // the LDS-tiled 64 x 64 kernel, 31-35 us for 1.07 GFLOP.)
+  (void)tiles_per_cloud;
+  const long long qpt = (long long)blockIdx.x * 128 + 4 * l31;
+  const int b = (int)(qpt / P);
+  const int pl = (int)(qpt - (long long)b * P);              // this lane's first point inside its cloud
   const int m0 = blockIdx.y * 32;
   const bool has_bn = in_scale != nullptr;
   const bool w_vec = (ldw & 3) == 0 && ((uintptr_t)w & 15) == 0;
@@ -630,7 +636,7 @@ __global__ __launch_bounds__(kThreads, 2) void pw_fwd_sk_kernel(
   // lane half (the same address for 32 lanes) into registers, instead of a staging pass through LDS and a barrier in front
   // of the first operand load
   PHASE_T(0)                    // BatchNorm constants staged
-  const float* xb = x + (size_t)b * cin * P + p0 + 4 * l31;
+  const float* xb = x + (size_t)b * cin * P + pl;
   const float* wrow = w + (size_t)min(m0 + l31, cout - 1) * ldw + 4 * half;
 
   f32x16 acc[4];
@@ -703,16 +709,16 @@ __global__ __launch_bounds__(kThreads, 2) void pw_fwd_sk_kernel(
     for (int r = 0; r < 16; ++r) lds[((wv * 4 + q) * 16 + r) * 64 + lane] = acc[q][r];
   __syncthreads();
   PHASE_T(4)                    // partial sums exchanged through LDS
-  float* yb = y + (size_t)b * cout * P + p0 + 4 * l31;
-  const float* cb = c_init != nullptr ? c_init + (size_t)b * cout * P + p0 + 4 * l31 : nullptr;
+  float* yb = y + (size_t)b * cout * P + pl;
+  const float* cb = c_init != nullptr ? c_init + (size_t)b * cout * P + pl : nullptr;
   // feature propagation, layer 0: the accumulators start from three_interpolate(zk) (reference
   // pointnet2_utils.py:249-273), evaluated here instead of by a launch of its own: the three neighbours and weights of
   // this lane's four points, then 3 gathers per output from the (B, cout, m) product over the known points
   int nb[12];
   float nw[12];
   if (zk != nullptr) {
-    const int4* ip = reinterpret_cast<const int4*>(iidx + ((size_t)b * P + p0 + 4 * l31) * 3);
-    const float4* wp = reinterpret_cast<const float4*>(iw + ((size_t)b * P + p0 + 4 * l31) * 3);
+    const int4* ip = reinterpret_cast<const int4*>(iidx + (size_t)qpt * 3);
+    const float4* wp = reinterpret_cast<const float4*>(iw + (size_t)qpt * 3);
 #pragma unroll
     for (int u = 0; u < 3; ++u) {
       const int4 iv = ip[u];
@@ -2246,8 +2252,10 @@ __global__ __launch_bounds__(kThreads, 2) void pw_dgrad_sk_kernel(
   __shared__ __attribute__((aligned(16))) float lds[4 * 4 * 16 * 64];   // 64 KB: constants during the loop, then the partials
   const int tid = threadIdx.x, lane = lane_id(), wv = wave_id();
   const int l31 = lane & 31, half = lane >> 5;
-  const int b = blockIdx.x / tiles_per_cloud;
-  const int p0 = (blockIdx.x - b * tiles_per_cloud) * 128;
+  (void)tiles_per_cloud;                     // tiles of the flattened (cloud, point) axis, cloud per lane: see pw_fwd_sk_kernel
+  const long long qpt = (long long)blockIdx.x * 128 + 4 * l31;
+  const int b = (int)(qpt / P);
+  const int pl = (int)(qpt - (long long)b * P);
   const int m0 = blockIdx.y * 32;
   // [5][cout]: scale, shift of this layer's BatchNorm; ca, cb, cc of dY = ca * g + cb + cc * y
   for (int c = tid; c < cout; c += kThreads) {
@@ -2255,8 +2263,8 @@ __global__ __launch_bounds__(kThreads, 2) void pw_dgrad_sk_kernel(
     lds[4096 + c] = bwdc[c]; lds[6144 + c] = bwdc[cout + c]; lds[8192 + c] = bwdc[2 * cout + c];
   }
   __syncthreads();
-  const float* yb = y + (size_t)b * cout * P + p0 + 4 * l31;
-  const float* gb = dA + (size_t)b * cout * P + p0 + 4 * l31;
+  const float* yb = y + (size_t)b * cout * P + pl;
+  const float* gb = dA + (size_t)b * cout * P + pl;
   const float* wcol = w + ci_off + min(m0 + l31, m_rows - 1);      // + k * cin_total: w[k][ci]
 
   f32x16 acc[4];
@@ -2327,9 +2335,9 @@ __global__ __launch_bounds__(kThreads, 2) void pw_dgrad_sk_kernel(
 #pragma unroll
     for (int r = 0; r < 16; ++r) lds[((wv * 4 + q) * 16 + r) * 64 + lane] = acc[q][r];
   __syncthreads();
-  float* dxb = dx + (size_t)b * m_rows * P + p0 + 4 * l31;
+  float* dxb = dx + (size_t)b * m_rows * P + pl;
   const bool stats = part_g != nullptr;
-  const float* xin = stats ? y_in + (size_t)b * m_rows * P + p0 + 4 * l31 : nullptr;
+  const float* xin = stats ? y_in + (size_t)b * m_rows * P + pl : nullptr;
 #pragma unroll
   for (int rr = 0; rr < 4; ++rr) {
     const int r = 4 * wv + rr;
@@ -3646,8 +3654,11 @@ int istnet_pw_stat_tiles(int b, int cout, int p) {
 
 // ---- pw_fwd_sk_kernel (small launches: no LDS operands, K split over the waves of a workgroup) ----
 static bool fwd_sk_ok(int b, int cin, int cout, int p) {
-  if (!g_fwd_sk_enable || cin % 8 || cin > 2048 || cin < 64 || p % 128 || cout < 32) return false;
-  const long long tiles = (long long)b * (p / 128) * ceil_div(cout, 32);
+  // 128-point tiles of the flattened (cloud, point) axis: whole clouds (p % 128 == 0) or several small ones (128 % p == 0)
+  if (!g_fwd_sk_enable || cin % 8 || cin > 2048 || cin < 64 || (p % 128 && (128 % p || p % 4)) || ((long long)b * p) % 128 ||
+      cout < 32)
+    return false;
+  const long long tiles = (long long)b * p / 128 * ceil_div(cout, 32);
   return tiles <= g_fwd_sk_max_tiles;
 }
 // ---- pw_fwd2_kernel (dense input, B operand straight from global memory) ----
@@ -3707,9 +3718,9 @@ static int launch_pw_forward(int b, int cin, int cout, int p, const float* x,
   if (msrc_p != nullptr) msrc = *msrc_p;
   if (b <= 0 || cin <= 0 || cout <= 0 || p <= 0 || (p & 3)) return ISTNET_PN2_EINVAL;
   if (msrc_p == nullptr && ncols == nullptr && row_init == nullptr && fwd_sk_ok(b, cin, cout, p)) {
-    const int tpc = p / 128;
-    hipLaunchKernelGGL(pw_fwd_sk_kernel, dim3(tpc * b, ceil_div(cout, 32)), dim3(kThreads), 0, as_stream(stream), cin, cout,
-                       p, tpc, x, w, ldw, in_scale, in_shift, c_init, y, part_sum, part_sq, tpc * b, nullptr, 0, nullptr,
+    const int tiles = (int)((long long)b * p / 128);          // of the flattened (cloud, point) axis
+    hipLaunchKernelGGL(pw_fwd_sk_kernel, dim3(tiles, ceil_div(cout, 32)), dim3(kThreads), 0, as_stream(stream), cin, cout,
+                       p, 0, x, w, ldw, in_scale, in_shift, c_init, y, part_sum, part_sq, tiles, nullptr, 0, nullptr,
                        nullptr);
     return (int)hipGetLastError();
   }
@@ -3744,12 +3755,12 @@ int istnet_pw_forward(int b, int cin, int cout, int p, const float* x, const flo
 int istnet_pw_forward_tiles(int b, int cin, int cout, int p) {
   const int cfg2 = fwd2_cfg(b, cin, cout, p);
   if (cfg2) return b * (p / (128 * ((cfg2 / 10) % 10)));
-  if (fwd_sk_ok(b, cin, cout, p)) return b * (p / 128);
+  if (fwd_sk_ok(b, cin, cout, p)) return (int)((long long)b * p / 128);
   return istnet_pw_stat_tiles(b, cout, p);
 }
 
 int istnet_pw_forward_ld_tiles(int b, int cin, int cout, int p) {
-  return fwd_sk_ok(b, cin, cout, p) ? b * (p / 128) : istnet_pw_stat_tiles(b, cout, p);
+  return fwd_sk_ok(b, cin, cout, p) ? (int)((long long)b * p / 128) : istnet_pw_stat_tiles(b, cout, p);
 }
 
 int istnet_pw_forward_ld(int b, int cin, int cout, int p, const float* x, const float* w, int ldw,
@@ -3775,9 +3786,9 @@ int istnet_pw_forward_acc_interp(int b, int cin, int cout, int p, const float* x
   if (b <= 0 || cin <= 0 || cout <= 0 || p <= 0 || m <= 0 || ldw < cin || !x || !w || !zk || !idx || !weight || !y)
     return ISTNET_PN2_EINVAL;
   if (!fwd_sk_ok(b, cin, cout, p)) return ISTNET_PN2_EINVAL;
-  const int tpc = p / 128;
-  hipLaunchKernelGGL(pw_fwd_sk_kernel, dim3(tpc * b, ceil_div(cout, 32)), dim3(kThreads), 0, as_stream(stream), cin, cout,
-                     p, tpc, x, w, ldw, nullptr, nullptr, nullptr, y, part_sum, part_sq, tpc * b, zk, m, idx, weight);
+  const int tiles = (int)((long long)b * p / 128);
+  hipLaunchKernelGGL(pw_fwd_sk_kernel, dim3(tiles, ceil_div(cout, 32)), dim3(kThreads), 0, as_stream(stream), cin, cout,
+                     p, 0, x, w, ldw, nullptr, nullptr, nullptr, y, part_sum, part_sq, tiles, zk, m, idx, weight);
   return (int)hipGetLastError();
 }
 
@@ -4054,8 +4065,10 @@ static int bwd_mid_len(int b, int cin, int p);
 static bool dgrad_sk_ok(int b, int m_rows, int cout, int p) {
   // (measured, tools/bench_pw.py: +6-17 % at K = cout >= 256, 10-50 % SLOWER at K = 64-128 -- forming dY costs ~14 VALU
   //  per element and short K leaves nothing to hide it behind)
-  if (!g_dgrad_sk_enable || cout % 8 || cout > 2048 || cout < g_dgrad_sk_min_k || p % 128 || m_rows < 32) return false;
-  return (long long)b * (p / 128) * ceil_div(m_rows, 32) <= g_fwd_sk_max_tiles;
+  if (!g_dgrad_sk_enable || cout % 8 || cout > 2048 || cout < g_dgrad_sk_min_k || (p % 128 && (128 % p || p % 4)) ||
+      ((long long)b * p) % 128 || m_rows < 32)
+    return false;
+  return (long long)b * p / 128 * ceil_div(m_rows, 32) <= g_fwd_sk_max_tiles;
 }
 /* 1 when istnet_pw_dgrad with a dense gradient source runs the split-K kernel for this shape */
 int istnet_pw_dgrad_sk(int b, int m_rows, int cout, int p) { return dgrad_sk_ok(b, m_rows, cout, p) ? 1 : 0; }
@@ -4063,7 +4076,7 @@ int istnet_pw_dgrad_rs(int b, int m_rows, int cout, int p, int dense) {
   return (dgrad_rs_ok(m_rows, cout, p) && !(dense && dgrad_sk_ok(b, m_rows, cout, p))) ? 1 : 0;
 }
 int istnet_pw_dgrad_tiles(int b, int m_rows, int cout, int p, int dense) {
-  if (dense && dgrad_sk_ok(b, m_rows, cout, p)) return b * (p / 128);
+  if (dense && dgrad_sk_ok(b, m_rows, cout, p)) return (int)((long long)b * p / 128);
   if (dgrad_rs_ok(m_rows, cout, p)) {       // (a launch with ci_off = 0, cin_total = m_rows and statistics)
     const int len = bwd_mid_len(b, m_rows, p);
     return (int)(((long long)b * p + len - 1) / len);
@@ -4113,10 +4126,10 @@ static int launch_pw_dgrad(int b, int cin_total, int ci_off, int m_rows, int cou
     return (int)hipGetLastError();
   }
   if (d_dense != nullptr && ncols == nullptr && dgrad_sk_ok(b, m_rows, cout, p)) {
-    const int tpc = p / 128;
-    hipLaunchKernelGGL(pw_dgrad_sk_kernel, dim3(tpc * b, ceil_div(m_rows, 32)), dim3(kThreads), 0, as_stream(stream),
-                       cin_total, ci_off, m_rows, cout, p, tpc, w, y, d_dense, bn, bwdc, dx, y_in, bn_in, part_g, part_gy,
-                       tpc * b);
+    const int tiles = (int)((long long)b * p / 128);
+    hipLaunchKernelGGL(pw_dgrad_sk_kernel, dim3(tiles, ceil_div(m_rows, 32)), dim3(kThreads), 0, as_stream(stream),
+                       cin_total, ci_off, m_rows, cout, p, 0, w, y, d_dense, bn, bwdc, dx, y_in, bn_in, part_g, part_gy,
+                       tiles);
     return (int)hipGetLastError();
   }
   GradSrc gs{d_dense, d_pooled, arg, nsample, pooled_bstride > 0 ? pooled_bstride : (long long)GS_C * (nsample > 0 ? p / nsample : 0), GS_C};

@@ -242,7 +242,10 @@ def test_forward_direct_operand_kernel(b, cin, cout, p, has_bn):
 
 @pytest.mark.parametrize("b,cin,cout,p,has_bn,mode", [(4, 512, 512, 128, True, "plain"), (2, 256, 96, 256, False, "plain"),
                                                       (3, 64, 40, 384, True, "plain"), (4, 256, 512, 128, False, "acc"),
-                                                      (2, 128, 256, 256, False, "ld"), (2, 72, 64, 128, False, "ld_unaligned")])
+                                                      (2, 128, 256, 256, False, "ld"), (2, 72, 64, 128, False, "ld_unaligned"),
+                                                      # tiles that span several small clouds (the coarsest propagation level)
+                                                      (32, 512, 512, 64, True, "ld"), (8, 128, 96, 32, True, "plain"),
+                                                      (6, 64, 64, 64, False, "acc")])
 def test_forward_split_k_kernel_for_small_launches(b, cin, cout, p, has_bn, mode):
     """pw_fwd_sk_kernel (no LDS operands, K split over the waves of a workgroup) through the three entry points that
     can take it -- istnet_pw_forward, istnet_pw_forward_acc (accumulators start from a tensor), istnet_pw_forward_ld
@@ -289,7 +292,8 @@ def test_forward_split_k_kernel_for_small_launches(b, cin, cout, p, has_bn, mode
 
 
 @pytest.mark.parametrize("b,cin_total,ci_off,rows,cout,p,stats", [(4, 512, 0, 512, 512, 128, True), (2, 320, 256, 64, 256, 256, False),
-                                                                  (3, 131, 3, 128, 192, 384, False), (2, 96, 0, 40, 64, 128, True)])
+                                                                  (3, 131, 3, 128, 192, 384, False), (2, 96, 0, 40, 64, 128, True),
+                                                                  (32, 768, 0, 512, 512, 64, False), (8, 96, 0, 40, 64, 32, True)])
 def test_dgrad_split_k_kernel_for_small_launches(b, cin_total, ci_off, rows, cout, p, stats):
     """pw_dgrad_sk_kernel (dense gradient source, small launches) against float64: dA for a column slice of the weight
     matrix, partial row tiles (rows = 40), the BatchNorm-backward statistics partials of the layer below; pw_dgrad_kernel
@@ -385,7 +389,7 @@ def test_dgrad_loader_mfma_roles_for_256_output_channels(b, p, pooled):
         lib.istnet_pw_set_tuning(17, 1)
 
 
-@pytest.mark.parametrize("b,c1,cout,n,m", [(4, 256, 512, 128, 64), (2, 64, 72, 256, 100), (3, 128, 256, 384, 192)])
+@pytest.mark.parametrize("b,c1,cout,n,m", [(4, 256, 512, 128, 64), (2, 64, 72, 256, 100), (3, 128, 256, 384, 192), (4, 64, 96, 64, 32)])
 def test_forward_acc_with_the_interpolation_in_the_epilogue(b, c1, cout, n, m):
     """istnet_pw_forward_acc_interp: y = three_interpolate(zk, idx, weight) + w . x in one launch, against float64, with the
     statistics partials; same result as interpolating first and calling istnet_pw_forward_acc."""
