@@ -122,6 +122,13 @@ ISTNET_PN2_API int istnet_bn_finalize_fwd(int c, int nt, double count, const flo
                                           const float *part_sq, const float *gamma, const float *beta,
                                           float eps, const float *momentum, float *running_mean,
                                           float *running_var, float *bn, void *stream);
+/* the same launch also counts the batch: *num_batches_tracked += 1 (the module buffer torch.nn.BatchNorm keeps, an int64 on the
+ * device; NULL: not counted) -- the framework's add for it then needs no launch of its own on the forward chain */
+ISTNET_PN2_API int istnet_bn_finalize_fwd_nbt(int c, int nt, double count, const float *part_sum,
+                                              const float *part_sq, const float *gamma, const float *beta,
+                                              float eps, const float *momentum, float *running_mean,
+                                              float *running_var, float *bn, long long *num_batches_tracked,
+                                              void *stream);
 
 /* out[b][c][g] = max_s relu(y[b][c][g][s]*scale+shift), arg = index of the first maximum (s > 1); cloud b of
  * `out` starts at out + b*out_bstride (0 = c*g), so a scale writes straight into its channel slice of the
@@ -274,6 +281,12 @@ ISTNET_PN2_API int istnet_bn_fin_relu_pool(int b, int c, int g, int s, int nt, d
                                            const float *momentum, float *running_mean, float *running_var, float *bn,
                                            const float *y, float *out, long long out_bstride, unsigned char *arg,
                                            float *ymax, void *stream);
+ISTNET_PN2_API int istnet_bn_fin_relu_pool_nbt(int b, int c, int g, int s, int nt, double count,
+                                               const float *part_sum, const float *part_sq, const float *gamma,
+                                               const float *beta, float eps, const float *momentum,
+                                               float *running_mean, float *running_var, float *bn, const float *y,
+                                               float *out, long long out_bstride, unsigned char *arg, float *ymax,
+                                               long long *num_batches_tracked, void *stream);   /* counts the batch too */
 
 /* three_interpolate_grad over the inverse lists of the taps (istnet_pn2_three_interpolate_grad_csr; reference
  * interpolate_gpu.cu:115-148) of dY = ca * relu'(bn(y)) * d_dense + cb + cc * y, formed on the fly from the raw pair

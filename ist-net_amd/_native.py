@@ -104,6 +104,7 @@ SIGNATURES = {
     "istnet_pw_gather_add": [_i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _i, _p, _p, _p, _p],
     "istnet_pw_wgrad_gather": [_i, _i, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _l, _p, _p, _p, _p, _p],
     "istnet_bn_finalize_fwd": [_i, _i, _d, _p, _p, _p, _p, _f, _p, _p, _p, _p, _p],
+    "istnet_bn_finalize_fwd_nbt": [_i, _i, _d, _p, _p, _p, _p, _f, _p, _p, _p, _p, _p, _p],
     "istnet_bn_relu_pool": [_i, _i, _i, _i, _p, _p, _p, _l, _p, _p, _p],
     "istnet_pw_bwd_stats_pooled": [_i, _i, _i, _p, _l, _p, _p, _p, _p, _p],
     "istnet_bn_bwd_dense_finalize": [_i, _i, _i, _d, _i, _p, _p, _p, _p, _p, _p, _p, _p],
@@ -129,6 +130,7 @@ SIGNATURES = {
     "istnet_pack_words": [_i, _p, _p, _p, _p],
     "istnet_bn_relu_mean": [_i, _i, _i, _p, _p, _p, _p],
     "istnet_bn_fin_relu_pool": [_i, _i, _i, _i, _i, _d, _p, _p, _p, _p, _f, _p, _p, _p, _p, _p, _p, _l, _p, _p, _p],
+    "istnet_bn_fin_relu_pool_nbt": [_i, _i, _i, _i, _i, _d, _p, _p, _p, _p, _f, _p, _p, _p, _p, _p, _p, _l, _p, _p, _p, _p],
     "istnet_interp_grad_csr_dy": [_i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p],
     "istnet_expand_rows": [_i, _i, _p, _p, _p],
     # include/istnet_heads.h (csrc/pose_tail.hip)

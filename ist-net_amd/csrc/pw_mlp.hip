@@ -879,10 +879,14 @@ __device__ __forceinline__ void reduce_partials2(const float* __restrict__ pa, c
 __global__ __launch_bounds__(kFinThreads) void bn_finalize_fwd_kernel(
     int C, int nt, double count, const float* __restrict__ part_sum, const float* __restrict__ part_sq,
     const float* __restrict__ gamma, const float* __restrict__ beta, float eps, const float* __restrict__ momentum_p,
-    float* __restrict__ running_mean, float* __restrict__ running_var, float* __restrict__ bn) {
+    float* __restrict__ running_mean, float* __restrict__ running_var, float* __restrict__ bn,
+    long long* __restrict__ nbt) {
   const int c = blockIdx.x;
   double s, q;
   reduce_partials2(part_sum + (size_t)c * nt, part_sq + (size_t)c * nt, nt, s, q);
+  // the module's num_batches_tracked, counted by the launch that updates its running statistics (round 5: the framework's
+  // multi-tensor add for all counters sat between the forward and the backward pass, behind a hop across hardware queues)
+  if (threadIdx.x == 0 && c == 0 && nbt != nullptr) *nbt += 1;
   if (threadIdx.x == 0) {
     const double mean = s / count;
     double var = q / count - mean * mean;
@@ -966,10 +970,11 @@ __device__ __forceinline__ void finalize_channel(int C, int c, int nt, double co
                                                  const float* __restrict__ beta, float eps,
                                                  const float* __restrict__ momentum_p, float* __restrict__ running_mean,
                                                  float* __restrict__ running_var, float* __restrict__ bn, bool writer,
-                                                 float& sc_out, float& sh_out) {
+                                                 float& sc_out, float& sh_out, long long* __restrict__ nbt = nullptr) {
   double s, q;
   reduce_partials2(part_sum + (size_t)c * nt, part_sq + (size_t)c * nt, nt, s, q);
   __shared__ float s_aff[2];
+  if (threadIdx.x == 0 && writer && c == 0 && nbt != nullptr) *nbt += 1;     // see bn_finalize_fwd_kernel
   if (threadIdx.x == 0) {
     const double mean = s / count;
     double var = q / count - mean * mean;
@@ -1003,11 +1008,11 @@ __global__ __launch_bounds__(kFinThreads) void bn_fin_relu_pool_kernel(
     const float* __restrict__ gamma, const float* __restrict__ beta, float eps, const float* __restrict__ momentum_p,
     float* __restrict__ running_mean, float* __restrict__ running_var, float* __restrict__ bn,
     const float* __restrict__ y, float* __restrict__ out, long long out_bstride, uint8_t* __restrict__ arg,
-    float* __restrict__ ymax) {
+    float* __restrict__ ymax, long long* __restrict__ nbt) {
   const int c = blockIdx.x;
   float s, h;
   finalize_channel(C, c, nt, count, part_sum, part_sq, gamma, beta, eps, momentum_p, running_mean, running_var, bn,
-                   blockIdx.y == 0, s, h);
+                   blockIdx.y == 0, s, h, nbt);
   const int b0 = (int)((long long)B * blockIdx.y / gridDim.y), b1 = (int)((long long)B * (blockIdx.y + 1) / gridDim.y);
   const int total = (b1 - b0) * G;
   for (int e = threadIdx.x; e < total; e += kFinThreads) {
@@ -1037,11 +1042,11 @@ __global__ __launch_bounds__(kFinThreads) void bn_fin_relu_apply_kernel(
     int C, int B, int P4, int nt, double count, const float* __restrict__ part_sum, const float* __restrict__ part_sq,
     const float* __restrict__ gamma, const float* __restrict__ beta, float eps, const float* __restrict__ momentum_p,
     float* __restrict__ running_mean, float* __restrict__ running_var, float* __restrict__ bn,
-    const float* __restrict__ y, float* __restrict__ out) {
+    const float* __restrict__ y, float* __restrict__ out, long long* __restrict__ nbt) {
   const int c = blockIdx.x;
   float s, h;
   finalize_channel(C, c, nt, count, part_sum, part_sq, gamma, beta, eps, momentum_p, running_mean, running_var, bn,
-                   blockIdx.y == 0, s, h);
+                   blockIdx.y == 0, s, h, nbt);
   const int b0 = (int)((long long)B * blockIdx.y / gridDim.y), b1 = (int)((long long)B * (blockIdx.y + 1) / gridDim.y);
   for (int b = b0; b < b1; ++b) {
     const size_t row = ((size_t)b * C + c) * P4;
@@ -3831,13 +3836,20 @@ int istnet_pw_gather_add(int b, int n, int npoint, int nsample, int cout, const 
   return (int)hipGetLastError();
 }
 
+int istnet_bn_finalize_fwd_nbt(int c, int nt, double count, const float* part_sum, const float* part_sq,
+                               const float* gamma, const float* beta, float eps, const float* momentum,
+                               float* running_mean, float* running_var, float* bn, long long* num_batches_tracked,
+                               void* stream) {
+  if (c <= 0 || nt <= 0 || (running_mean != nullptr && momentum == nullptr)) return ISTNET_PN2_EINVAL;
+  hipLaunchKernelGGL(bn_finalize_fwd_kernel, dim3(c), dim3(kFinThreads), 0, as_stream(stream), c, nt, count,
+                     part_sum, part_sq, gamma, beta, eps, momentum, running_mean, running_var, bn, num_batches_tracked);
+  return (int)hipGetLastError();
+}
 int istnet_bn_finalize_fwd(int c, int nt, double count, const float* part_sum, const float* part_sq,
                            const float* gamma, const float* beta, float eps, const float* momentum,
                            float* running_mean, float* running_var, float* bn, void* stream) {
-  if (c <= 0 || nt <= 0 || (running_mean != nullptr && momentum == nullptr)) return ISTNET_PN2_EINVAL;
-  hipLaunchKernelGGL(bn_finalize_fwd_kernel, dim3(c), dim3(kFinThreads), 0, as_stream(stream), c, nt, count,
-                     part_sum, part_sq, gamma, beta, eps, momentum, running_mean, running_var, bn);
-  return (int)hipGetLastError();
+  return istnet_bn_finalize_fwd_nbt(c, nt, count, part_sum, part_sq, gamma, beta, eps, momentum, running_mean, running_var, bn,
+                                    nullptr, stream);
 }
 
 int istnet_bn_relu_pool(int b, int c, int g, int s, const float* y, const float* bn, float* out,
@@ -3878,10 +3890,10 @@ static int fin_chunks(int b, long long row_bytes) {
   return (int)ch;
 }
 
-int istnet_bn_fin_relu_pool(int b, int c, int g, int s, int nt, double count, const float* part_sum, const float* part_sq,
-                            const float* gamma, const float* beta, float eps, const float* momentum, float* running_mean,
-                            float* running_var, float* bn, const float* y, float* out, long long out_bstride,
-                            unsigned char* arg, float* ymax, void* stream) {
+int istnet_bn_fin_relu_pool_nbt(int b, int c, int g, int s, int nt, double count, const float* part_sum, const float* part_sq,
+                                const float* gamma, const float* beta, float eps, const float* momentum, float* running_mean,
+                                float* running_var, float* bn, const float* y, float* out, long long out_bstride,
+                                unsigned char* arg, float* ymax, long long* num_batches_tracked, void* stream) {
   if (out_bstride <= 0) out_bstride = (long long)c * g;
   if (b <= 0 || c <= 0 || g <= 0 || nt <= 0 || count <= 0.0 || !part_sum || !part_sq || !gamma || !beta || !bn || !y ||
       !out || (running_mean != nullptr && momentum == nullptr))
@@ -3890,7 +3902,7 @@ int istnet_bn_fin_relu_pool(int b, int c, int g, int s, int nt, double count, co
     if ((g & 3) || out_bstride != (long long)c * g) return ISTNET_PN2_EINVAL;
     hipLaunchKernelGGL(bn_fin_relu_apply_kernel, dim3(c, fin_chunks(b, 4LL * g)), dim3(kFinThreads), 0, as_stream(stream),
                        c, b, g / 4, nt, count, part_sum, part_sq, gamma, beta, eps, momentum, running_mean, running_var, bn,
-                       y, out);
+                       y, out, num_batches_tracked);
     return (int)hipGetLastError();
   }
   if (arg == nullptr) return ISTNET_PN2_EINVAL;
@@ -3898,7 +3910,7 @@ int istnet_bn_fin_relu_pool(int b, int c, int g, int s, int nt, double count, co
 #define ISTNET_FPOOL(S4)                                                                                             \
   hipLaunchKernelGGL((bn_fin_relu_pool_kernel<S4>), grid, dim3(kFinThreads), 0, as_stream(stream), c, b, g, nt, count, \
                      part_sum, part_sq, gamma, beta, eps, momentum, running_mean, running_var, bn, y, out, out_bstride, \
-                     arg, ymax)
+                     arg, ymax, num_batches_tracked)
   switch (s) {
     case 4: ISTNET_FPOOL(1); break;
     case 8: ISTNET_FPOOL(2); break;
@@ -3909,6 +3921,14 @@ int istnet_bn_fin_relu_pool(int b, int c, int g, int s, int nt, double count, co
   }
 #undef ISTNET_FPOOL
   return (int)hipGetLastError();
+}
+
+int istnet_bn_fin_relu_pool(int b, int c, int g, int s, int nt, double count, const float* part_sum, const float* part_sq,
+                            const float* gamma, const float* beta, float eps, const float* momentum, float* running_mean,
+                            float* running_var, float* bn, const float* y, float* out, long long out_bstride,
+                            unsigned char* arg, float* ymax, void* stream) {
+  return istnet_bn_fin_relu_pool_nbt(b, c, g, s, nt, count, part_sum, part_sq, gamma, beta, eps, momentum, running_mean,
+                                     running_var, bn, y, out, out_bstride, arg, ymax, nullptr, stream);
 }
 
 int istnet_interp_grad_csr_dy(int b, int c, int n, int m, const float* y, const float* d_dense, const float* bn,

@@ -97,10 +97,10 @@ class FusedFPFunction(Function):
                     _native.check(lib.istnet_pw_channel_stats(b, cout0, n, y0.data_ptr(), part[0].data_ptr(),
                                                               part[1].data_ptr(), st), "pw_channel_stats")
             if training:
-                _native.check(lib.istnet_bn_finalize_fwd(
+                _native.check(lib.istnet_bn_finalize_fwd_nbt(
                     cout0, nt, float(b * n), part[0].data_ptr(), part[1].data_ptr(), gamma0.data_ptr(), beta0.data_ptr(),
                     float(lay0.eps), lay0.momentum_ptr, _p(lay0.running_mean), _p(lay0.running_var),
-                    bn0.data_ptr(), st), "bn_finalize_fwd")
+                    bn0.data_ptr(), lay0.nbt_ptr, st), "bn_finalize_fwd")
             else:
                 _native.check(lib.istnet_affine_consts(cout0, gamma0.data_ptr(), beta0.data_ptr(),
                                                        lay0.running_mean.data_ptr(), lay0.running_var.data_ptr(),

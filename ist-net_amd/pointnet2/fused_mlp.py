@@ -252,12 +252,16 @@ def _p(t):
 
 class _Layer:
     """Per-layer constants handed to the autograd function (not differentiable)."""
-    __slots__ = ("running_mean", "running_var", "momentum_ptr", "eps", "bias_only", "relu")
+    __slots__ = ("running_mean", "running_var", "momentum_ptr", "eps", "bias_only", "relu", "nbt_ptr")
 
     def __init__(self, bn=None, relu=True):
         self.bias_only = bn is None      # conv + bias (+ ReLU) instead of conv + BatchNorm + ReLU
         self.relu = relu                 # False only for the last layer of a bias stack
+        self.nbt_ptr = None
         if bn is not None:
+            # num_batches_tracked is counted by the launch that updates the running statistics (istnet_bn_finalize_fwd_nbt)
+            nbt = bn.num_batches_tracked
+            self.nbt_ptr = nbt.data_ptr() if (nbt is not None and nbt.is_cuda and nbt.dtype == torch.int64) else None
             self.running_mean = bn.running_mean
             self.running_var = bn.running_var
             # device address of the module's momentum slot (pytorch_utils._MomentumSlots): the finalize kernels read the
@@ -360,9 +364,9 @@ def _forward_stack(lib, dev, st, b, c0, g, s, x, gather, training, layers, param
                 # the stack's tail is a per-channel consumer: it finishes this layer's statistics itself (below)
                 pending = (nt, ps, pq, part, gamma, beta, lay)
             else:
-                _native.check(lib.istnet_bn_finalize_fwd(
+                _native.check(lib.istnet_bn_finalize_fwd_nbt(
                     cout, nt, float(b * p), ps, pq, gamma.data_ptr(), beta.data_ptr(), float(lay.eps),
-                    lay.momentum_ptr, _p(lay.running_mean), _p(lay.running_var), bn.data_ptr(), st),
+                    lay.momentum_ptr, _p(lay.running_mean), _p(lay.running_var), bn.data_ptr(), lay.nbt_ptr, st),
                     "bn_finalize_fwd")
         ys.append(y)
         bns.append(bn)
@@ -379,10 +383,10 @@ def _forward_stack(lib, dev, st, b, c0, g, s, x, gather, training, layers, param
     arg = _empty((_arg_bytes(b * cur_c * g) + 4 * b * cur_c * g,), torch.uint8, dev) if s > 1 else None
     if pending is not None:
         nt_l, ps_l, pq_l, _, gamma_l, beta_l, lay_l = pending
-        _native.check(lib.istnet_bn_fin_relu_pool(
+        _native.check(lib.istnet_bn_fin_relu_pool_nbt(
             b, cur_c, g, s, nt_l, float(b * p), ps_l, pq_l, gamma_l.data_ptr(), beta_l.data_ptr(), float(lay_l.eps),
             lay_l.momentum_ptr, _p(lay_l.running_mean), _p(lay_l.running_var), in_bn.data_ptr(), cur.data_ptr(), out_ptr,
-            out_bstride, _p(arg), _ymax_ptr(arg, b * cur_c * g), st), "bn_fin_relu_pool")
+            out_bstride, _p(arg), _ymax_ptr(arg, b * cur_c * g), lay_l.nbt_ptr, st), "bn_fin_relu_pool")
     elif s == 1 and not layers[-1].relu:
         _native.check(lib.istnet_affine_apply(b, cur_c, g, 0, cur.data_ptr(), in_bn.data_ptr(), out.data_ptr(), st),
                       "affine_apply")
@@ -432,9 +436,9 @@ def _forward_stack_compact(lib, dev, st, b, g, s, ga, training, layers, params, 
                 cur_c, cout, cap, cur.data_ptr(), w2.data_ptr(), in_bn[0].data_ptr(), in_bn[1].data_ptr(), y.data_ptr(),
                 ps, pq, ncols, cm.colw.data_ptr(), st), "pw_forward_cols")
         if training:
-            _native.check(lib.istnet_bn_finalize_fwd(
+            _native.check(lib.istnet_bn_finalize_fwd_nbt(
                 cout, nt, float(b * g * s), ps, pq, gamma.data_ptr(), beta.data_ptr(), float(lay.eps),
-                lay.momentum_ptr, _p(lay.running_mean), _p(lay.running_var), bn.data_ptr(), st), "bn_finalize_fwd")
+                lay.momentum_ptr, _p(lay.running_mean), _p(lay.running_var), bn.data_ptr(), lay.nbt_ptr, st), "bn_finalize_fwd")
         else:
             _native.check(lib.istnet_affine_consts(cout, gamma.data_ptr(), beta.data_ptr(), lay.running_mean.data_ptr(),
                                                    lay.running_var.data_ptr(), float(lay.eps), bn.data_ptr(), st),
@@ -1297,7 +1301,13 @@ class defer_bn_counters:
 
 
 def _bump_counters(units):
-    counters = [unit.normlayer.bn.num_batches_tracked for unit in units]
+    """num_batches_tracked of the stacks that just ran in training mode.  The finalize launches count the batch themselves
+    (istnet_bn_finalize_fwd_nbt) whenever the counter is an int64 CUDA tensor -- i.e. always on the fused path; what is left
+    here is the odd module whose counter the kernels could not take."""
+    counters = [unit.normlayer.bn.num_batches_tracked for unit in units
+                if not (unit.normlayer.bn.num_batches_tracked.is_cuda and unit.normlayer.bn.num_batches_tracked.dtype == torch.int64)]
+    if not counters:
+        return
     if defer_bn_counters._pending is not None:
         defer_bn_counters._pending += counters
     else:
