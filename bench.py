@@ -42,7 +42,8 @@ if ROOT not in sys.path:
 CAM_RADII = [[0.01, 0.02], [0.02, 0.04], [0.04, 0.08], [0.08, 0.16]]  # ist_net.py:16
 BATCH, NPOINTS = 32, 1024
 ENCODER_FWD_BWD_MFLOP_PER_CLOUD = 4394.7      # 3 x 1 464.9 MFLOP dense forward work per cloud
-PMC_TRAFFIC_FILE = "r05_pmc_traffic.json"     # rocprofv3 --pmc summary the roofline object's `traffic` is read from
+PMC_TRAFFIC_FILE = "r06_pmc_traffic.json"     # rocprofv3 --pmc summary the roofline object's `traffic` is read from
+PMC_SQ_FILE = "r06_pmc_sq_counters.json"      # rocprofv3 --pmc SQ counters: roofline.mfma_busy_frac (tools/pmc_sq.sh)
 
 
 def shell_cloud(b, n, seed, device="cpu"):
@@ -52,6 +53,28 @@ def shell_cloud(b, n, seed, device="cpu"):
     pts = d / d.norm(dim=2, keepdim=True) * 0.1 + torch.randn(b, n, 3, generator=g) * 0.002
     pts = pts - pts.mean(dim=1, keepdim=True)
     return pts.contiguous().to(device)
+
+
+def cube_cloud(b, n, seed, device="cpu"):
+    """U(-0.1, 0.1)^3, centred: the second distribution SURVEY.md 8d names for config 2 (balls of the fine levels mostly
+    under-full, like the shell's, but no surface structure)."""
+    g = torch.Generator().manual_seed(seed)
+    pts = torch.rand(b, n, 3, generator=g) * 0.2 - 0.1
+    pts = pts - pts.mean(dim=1, keepdim=True)
+    return pts.contiguous().to(device)
+
+
+def dense_cloud(b, n, seed, device="cpu"):
+    """A shell of radius 0.02 m (noise 0.0004): every ball of every level holds more points than nsample, so no row is
+    padded -- compact columns at level 1 and the first-hit padding buy nothing, every grouped column is distinct work."""
+    g = torch.Generator().manual_seed(seed)
+    d = torch.randn(b, n, 3, generator=g)
+    pts = d / d.norm(dim=2, keepdim=True) * 0.02 + torch.randn(b, n, 3, generator=g) * 0.0004
+    pts = pts - pts.mean(dim=1, keepdim=True)
+    return pts.contiguous().to(device)
+
+
+CLOUDS = {"shell": shell_cloud, "cube": cube_cloud, "dense": dense_cloud}
 
 
 def mse_value_and_grad(out):
@@ -699,17 +722,23 @@ def cpu_baseline(budget_s=60.0, thread_counts=(8, 16, 32)):
         while len(times) < 10 and (len(times) < 3 or time.perf_counter() - t_start < budget_s):
             times += timed_steps(1)
         times.sort()
-        dt = times[len(times) // 2] if len(times) % 2 else 0.5 * (times[len(times) // 2 - 1] + times[len(times) // 2])
+        median = times[len(times) // 2] if len(times) % 2 else 0.5 * (times[len(times) // 2 - 1] + times[len(times) // 2])
+        # ONE statistic for the sweep and the reported value: the fastest warmed step (the box's other tenants and the
+        # allocator move a 1.1-s CPU step by 20 %; the sweep already keeps the minimum of its two steps).  The chosen count's
+        # sweep entry is folded in, so `value` and `thread_sweep_ms_per_step[cores]` agree by construction.
+        dt = min(times[0], sweep[best])
+        sweep[best] = dt
     finally:
         pointnet2_utils._ext = saved
         torch.set_num_threads(saved_threads)
     return {"value": BATCH / dt, "unit": "clouds/s", "cores": best, "kind": "port",
             "cpu_model": model_name, "physical_cores": physical, "logical_cpus": logical, "cpus_available": avail,
             "thread_sweep_ms_per_step": {str(k): round(v * 1e3, 1) for k, v in sweep.items()},
-            "sample": f"median of {len(times)} timed steps after 3 warm-up steps at {best} threads (fastest of the sweep "
-                      f"{sorted(sweep)}), the same B={BATCH} N={NPOINTS} encoder fwd+bwd+Adam step (torch CPU dense "
-                      f"layers + oracle/pn2_oracle.c index ops, OpenMP)",
-            "ms_per_step": dt * 1e3}
+            "sample": f"fastest of {len(times)} timed steps (+ the sweep's two) after 3 warm-up steps at {best} threads "
+                      f"(fastest of the sweep {sorted(sweep)}; more threads are slower on every box measured: "
+                      f"profiles/r05_cpu_baseline_all_cores.json), the same B={BATCH} N={NPOINTS} encoder fwd+bwd+Adam step "
+                      f"(torch CPU dense layers + oracle/pn2_oracle.c index ops, OpenMP)",
+            "ms_per_step": dt * 1e3, "median_ms_per_step": median * 1e3}
 
 
 def self_launch(n):
@@ -757,6 +786,10 @@ def main():
                          "backward without host launches); falls back to replay + eager buckets if the capture fails")
     ap.add_argument("--no-overlap-allreduce", action="store_true",
                     help="(the default since round 3; kept for old command lines) captured step, buckets after the replay")
+    ap.add_argument("--cloud", default="shell", choices=sorted(CLOUDS),
+                    help="encoder workload: input distribution (shell = the headline; cube, dense: SURVEY 8d's other cases)")
+    ap.add_argument("--no-other-clouds", action="store_true",
+                    help="skip the extra cube / dense measurements of the default encoder line (`other_distributions`)")
     ap.add_argument("--no-prefetch", action="store_true",
                     help="encoder workload: one batch, geometry inside the step (no next-batch geometry prefetch)")
     ap.add_argument("--workload", default="encoder", choices=["encoder", "istnet", "infer", "sa_layer", "pipeline", "pipeline_infer"],
@@ -901,7 +934,8 @@ def main():
         args.no_cpu_baseline = True
     else:
         model = make_model(dev, seed=0)  # identical weights on every rank (same seed)
-        pts = shell_cloud(batch_size, NPOINTS, seed=rank, device=dev)
+        make_cloud = CLOUDS[args.cloud]
+        pts = make_cloud(batch_size, NPOINTS, seed=rank, device=dev)
         opt = FlatAdam(model.parameters(), lr=1e-4, adjacent=layout_hints(model))
         if dist_on:
             from istnet_amd.parallel import OverlappedFlatReducer
@@ -912,7 +946,7 @@ def main():
         else:
             # two batches alternate; while a step runs, the geometry stream prepares the other batch
             from istnet_amd.modules import GeometrySlot
-            batches = [pts, shell_cloud(BATCH, NPOINTS, seed=1000 + rank, device=dev)]
+            batches = [pts, make_cloud(BATCH, NPOINTS, seed=1000 + rank, device=dev)]
             slots = [model.prefetch_geometry(bt, GeometrySlot()) for bt in batches]   # pipeline prologue (untimed)
             fwd_bwd = [make_pipelined_fwd_bwd(model, batches, slots, i) for i in (0, 1)]
     eager_step = make_eager_step(fwd_bwd, opt, world, grad_sync)
@@ -987,7 +1021,7 @@ def main():
             "window_statistic": "median of %d windows of %d steps" % (len(windows), args.steps),
             "data": "synthetic" if not args.cpu_dry_run else "synthetic (CPU dry run of the launch path: NOT a measurement)",
             "config": {"workload": ("PointNet2MSG encoder (4 SA-MSG + 4 FP, cam radii) fwd+bwd+Adam, "
-                                    "train-mode BN, shell clouds") if args.workload == "encoder" else
+                                    "train-mode BN, %s clouds" % args.cloud) if args.workload == "encoder" else
                                    ("IST-Net full model (ResNet-18/PSP RGB branch on MIOpen + point branch, "
                                     "cam + world encoders, IST head, 3 pose heads) fwd+bwd+Adam, SupervisedLoss"
                                     + (", world enhancer frozen" if args.freeze_world_enhancer else "")),
@@ -1030,6 +1064,56 @@ def main():
             result["unpipelined"] = {"value": BATCH / dt, "unit": "clouds/s", "ms_per_step": dt * 1e3,
                                      "windows_ms_per_step": [round(d * 1e3, 4) for d in dts],
                                      "note": "one batch, FPS / ball query / three_nn inside the step (--no-prefetch)"}
+        if (not dist_on and args.workload == "encoder" and mode == "hipgraph" and not args.no_other_clouds
+                and not args.cpu_dry_run and args.cloud == "shell"):
+            # SURVEY 8d names two input distributions for config 2 and the step is data-dependent (compact columns at SA
+            # level 1, tie-free prefix FPS): the same captured step on the other inputs, same timing protocol
+            from istnet_amd.modules import GeometrySlot
+            other = {}
+            for kind in ("cube", "dense"):
+                try:
+                    bts = [CLOUDS[kind](BATCH, NPOINTS, seed=s, device=dev) for s in (rank, 1000 + rank)]
+                    if args.no_prefetch:
+                        fb = make_encoder_fwd_bwd(model, bts[0])
+                    else:
+                        sl = [model.prefetch_geometry(bt, GeometrySlot()) for bt in bts]
+                        fb = [make_pipelined_fwd_bwd(model, bts, sl, i) for i in (0, 1)]
+                    st_k = make_graphed_step(fb, opt, world, grad_sync)
+                    for _ in range(min(args.warmup, 5)):
+                        st_k()
+                    dts = []
+                    for _ in range(n_windows):
+                        torch.cuda.synchronize()
+                        t1 = time.perf_counter()
+                        for _ in range(args.steps):
+                            st_k()
+                        torch.cuda.synchronize()
+                        dts.append((time.perf_counter() - t1) / args.steps)
+                    dt = sorted(dts)[len(dts) // 2]
+                    other[kind] = {"ms_per_step": dt * 1e3, "value": BATCH / dt, "unit": "clouds/s",
+                                   "windows_ms_per_step": [round(d * 1e3, 4) for d in dts]}
+                    if not args.no_prefetch and not args.no_unpipelined:
+                        pl = make_graphed_step(make_encoder_fwd_bwd(model, bts[0]), opt, world, grad_sync)
+                        for _ in range(min(args.warmup, 5)):
+                            pl()
+                        dts = []
+                        for _ in range(n_windows):
+                            torch.cuda.synchronize()
+                            t1 = time.perf_counter()
+                            for _ in range(args.steps):
+                                pl()
+                            torch.cuda.synchronize()
+                            dts.append((time.perf_counter() - t1) / args.steps)
+                        other[kind]["unpipelined_ms_per_step"] = sorted(dts)[len(dts) // 2] * 1e3
+                        del pl
+                    del st_k, fb
+                except Exception as exc:      # an extra leg must never cost the headline line
+                    other[kind] = {"error": f"{type(exc).__name__}: {exc}"}
+                    torch.cuda.synchronize()
+            other["note"] = ("same model, same captured step, other inputs: cube = U(-0.1, 0.1)^3 (SURVEY 8d config 2's second "
+                             "distribution); dense = shell of radius 0.02 (every ball over-full: no padded rows, nothing for the "
+                             "compact columns or the first-hit padding to save)")
+            result["other_distributions"] = other
         if not dist_on and not args.no_eager_leg and not args.cpu_dry_run and mode == "hipgraph":
             # the step an unchanged reference-style loop gets (no whole-step graph, no prefetch, torch.optim.Adam)
             try:
@@ -1055,7 +1139,8 @@ def main():
                     timed_step = make_graphed_step(fwd_bwd, opt, world, grad_sync)
                     return lambda: [timed_step() for _ in range(n_graphs)]
             result["roofline"] = roofline.measure(
-                eager_step, traffic_file=os.path.join(ROOT, "profiles", PMC_TRAFFIC_FILE), capture=capture,
+                eager_step, traffic_file=os.path.join(ROOT, "profiles", PMC_TRAFFIC_FILE),
+                sq_file=os.path.join(ROOT, "profiles", PMC_SQ_FILE), capture=capture,
                 steps_per_replay=(len(fwd_bwd) if isinstance(fwd_bwd, (list, tuple)) else 1))
             if result["roofline"] is not None and args.workload == "encoder":
                 # whole-step rate: the encoder's dense work (4 394.7 MFLOP per cloud, forward + backward) over
@@ -1063,6 +1148,11 @@ def main():
                 flop = ENCODER_FWD_BWD_MFLOP_PER_CLOUD * 1e6 * batch_size
                 result["roofline"]["step_flops_tflops"] = flop / (ms * 1e-3) / 1e12
                 result["roofline"]["step_flops_frac"] = flop / (ms * 1e-3) / 1e12 / roofline.PEAK_MFMA_F32_TFLOPS
+                result["roofline"]["nominal_gflop_per_step"] = flop / 1e9
+                ex = result["roofline"].get("executed_gemm_gflop_per_step")
+                if ex:
+                    # the matrix pipe's own occupation over the step: executed (not nominal) GEMM flops / step time / peak
+                    result["roofline"]["executed_flops_frac"] = ex * 1e9 / (ms * 1e-3) / 1e12 / roofline.PEAK_MFMA_F32_TFLOPS
         if args.split_precision and not dist_on and args.workload == "istnet" and mode == "hipgraph":
             # OPT-IN experiment, never the headline: the same step with the trunk's forward / backward-data products on the
             # bf16 matrix pipe (three exact bf16 terms per fp32 operand, six products, fp32 accumulation; rgb_branch.set_split_precision)

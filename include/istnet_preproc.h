@@ -69,7 +69,7 @@ ISTNET_PN2_API int istnet_depth_fill_scratch_floats(int b, int h, int w);
 ISTNET_PN2_API int istnet_depth_fill_multiscale(int b, int h, int w, const float *depth, float max_depth, float *scratch,
                                                 float *out, void *stream);
 /* fill_missing itself (utils/data_utils.py:516-540; the Dataset classes call fill_missing(depth, norm_scale, 1)): the raw
- * depth images -- uint16 millimetres as cv2.imread returns them (raw_is_float 0) or float32 (1) -- are scaled by
+ * depth images -- uint16 millimetres as cv2.imread returns them (raw_is_float 0), float32 (1) or float64 (2) -- are scaled by
  * scale_2_80m / cam_scale in float64 and rounded to float32 once (what numpy does) inside the first kernel, completed as
  * above, and scaled back (float32 / scale_2_80m * cam_scale) by the last one: no conversion passes on the caller's side. */
 ISTNET_PN2_API int istnet_depth_fill_missing(int b, int h, int w, const void *depth_raw, int raw_is_float, double cam_scale,

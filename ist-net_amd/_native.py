@@ -216,7 +216,7 @@ def check(status, what):
 TIMING = None
 TIMING_IN_GRAPH = False
 TIMING_BUF = None      # int64 CUDA tensor of wall-clock slots, two per timed launch
-TIMING_ONLY = None     # in-graph timing: bracket only launches of this kernel (fewer markers = less perturbation)
+TIMING_ONLY = None     # in-graph timing: bracket only launches of this kernel -- a name, or a predicate of the name (fewer markers = less perturbation)
 
 
 def timed(name, flops, nbytes, launch):

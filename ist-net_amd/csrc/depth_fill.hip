@@ -43,14 +43,16 @@ __device__ __forceinline__ float dilate_at(const float* __restrict__ img, int h,
 }
 
 // fill_missing's `dpt / cam_scale * scale_2_80m` (numpy: float64, rounded to float32 once by fill_in_multiscale) and
-// s1: inversion of the valid depths.  RAW: 0 = uint16 millimetres, 1 = float32.
+// s1: inversion of the valid depths.  RAW: 0 = uint16 millimetres, 1 = float32, 2 = float64 (numpy keeps float64 / int32
+// input in float64 through the scaling and rounds to float32 once: converting it to float32 first would round twice).
 template <int RAW>
 __global__ void convert_invert_kernel(long long n, double cam_scale, double scale, float max_depth, const void* __restrict__ raw,
                                       float* __restrict__ depth, float* __restrict__ s1) {
   const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
-  const double v = RAW == 0 ? (double)reinterpret_cast<const unsigned short*>(raw)[i]
-                            : (double)reinterpret_cast<const float*>(raw)[i];
+  const double v = RAW == 0   ? (double)reinterpret_cast<const unsigned short*>(raw)[i]
+                   : RAW == 1 ? (double)reinterpret_cast<const float*>(raw)[i]
+                              : reinterpret_cast<const double*>(raw)[i];
   const float d = (float)(v / cam_scale * scale);
   depth[i] = d;
   s1[i] = d > kValid ? max_depth - d : d;
@@ -342,8 +344,10 @@ static int fill_impl(int b, int h, int w, const void* raw, int raw_kind, double 
   const dim3 g1((unsigned)((n + 255) / 256));
   if (raw_kind == 0)
     hipLaunchKernelGGL(convert_invert_kernel<0>, g1, dim3(256), 0, st, n, cam_scale, scale, max_depth, raw, depth, a);        // s1
-  else
+  else if (raw_kind == 1)
     hipLaunchKernelGGL(convert_invert_kernel<1>, g1, dim3(256), 0, st, n, cam_scale, scale, max_depth, raw, depth, a);
+  else
+    hipLaunchKernelGGL(convert_invert_kernel<2>, g1, dim3(256), 0, st, n, cam_scale, scale, max_depth, raw, depth, a);
   hipLaunchKernelGGL(binned_dilate_kernel, tiles, blk, 0, st, h, w, depth, a, bb);                                          // s2
   hipLaunchKernelGGL(close5_kernel, tiles, blk, 0, st, h, w, bb, a);                                                        // s3
   hipLaunchKernelGGL(median_masked_kernel, tiles, blk, 0, st, h, w, a, (const int*)nullptr, bb);                            // s4
@@ -371,7 +375,8 @@ int istnet_depth_fill_multiscale(int b, int h, int w, const float* depth, float 
 
 int istnet_depth_fill_missing(int b, int h, int w, const void* depth_raw, int raw_is_float, double cam_scale, double scale_2_80m,
                               float max_depth, float* scratch, float* out, void* stream) {
-  return fill_impl(b, h, w, depth_raw, raw_is_float ? 1 : 0, cam_scale, scale_2_80m, max_depth, scratch, out, stream);
+  if (raw_is_float < 0 || raw_is_float > 2) return ISTNET_PN2_EINVAL;
+  return fill_impl(b, h, w, depth_raw, raw_is_float, cam_scale, scale_2_80m, max_depth, scratch, out, stream);
 }
 
 }  // extern "C"

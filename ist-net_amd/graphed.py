@@ -31,35 +31,88 @@ Unlike ``make_graphed_callables`` the returned tensor is the caller's own (a cop
 outputs across steps is safe.  The one cost a caller can see is memory: an entry keeps its activations' pool (1.3 GB for the
 B=32 encoder) until ``graphed.reset(module)`` or the module dies.
 
+What a replay reads from HOST state each time, because the caller may change it between two steps without going through
+this package: every BatchNorm's ``momentum`` (the reference's own ``BNMomentumScheduler`` -- utils/scheduler.py, built at
+utils/solver.py:48-49 and stepped at :92 -- is a bare ``m.momentum = x``): the finalize kernels take the momentum from a
+device slot, and ``AutoGraph`` compares every module's host value with its slot's on every call and refreshes the slots (one
+pinned host-to-device copy, only when something changed) before it replays.  ``eps`` and ``track_running_stats`` are baked
+into the captured launches and therefore part of the key.
+
+Lifetime of the captured graphs: an entry is destroyed explicitly -- on the calling thread, with the device idle -- when it is
+evicted (``MAX_ENTRIES`` shapes per module, least recently used first) or reset; entries whose module died are parked in a
+graveyard by the module's finalizer (which may run on any thread, e.g. the autograd worker during a collection) and
+destroyed by the next call or ``reset()`` on the caller's thread.  A capture logs the memory it pins
+(``logging.getLogger("istnet_amd.graphed")``, INFO).
+
 ``InferenceGraph`` (below) is the forward-only counterpart for eval-mode, ``torch.no_grad()`` callers of the full model.
 
 ``ISTNET_AUTO_GRAPH=0`` (or ``graphed.ENABLED = False``) turns the whole mechanism off.
 """
+import collections
+import logging
 import os
 import warnings
 import weakref
 
 import torch
+from torch import nn
 
 ENABLED = os.environ.get("ISTNET_AUTO_GRAPH", "1") != "0"
 WARMUP_CALLS = 2
-MAX_ENTRIES = 4          # captured shapes kept per module (least recently used goes first)
-import collections
+# captured shapes kept per module (least recently used goes first).  An entry pins its activations' pool -- 1.3 GB for the
+# B=32 encoder -- and IST_Net holds three encoders, so the default is small; a loader with more than two batch shapes in
+# rotation raises it (ISTNET_AUTO_GRAPH_ENTRIES).
+MAX_ENTRIES = int(os.environ.get("ISTNET_AUTO_GRAPH_ENTRIES", "2"))
+PLAIN_STREAK_WARN = 10   # consecutive plain-path calls of a TRAINING module after which the caller is told why (once)
+_LOG = logging.getLogger("istnet_amd.graphed")
 WHY = collections.Counter()      # AutoGraph: why a call took the plain path (diagnostics; tests print it when a capture is missing)
-STATS = {"captures": 0, "replays": 0, "plain": 0, "failed": 0,                       # AutoGraph (training)
+STATS = {"captures": 0, "replays": 0, "plain": 0, "failed": 0, "momentum_syncs": 0,  # AutoGraph (training)
          "infer_captures": 0, "infer_replays": 0, "infer_plain": 0, "infer_failed": 0}    # InferenceGraph
 # other threads of the caller (a DataLoader's pin-memory thread, a logger) keep making HIP calls while this thread captures:
 # only this thread's calls are checked against the capture
 _CAPTURE_MODE = "thread_local"
 
 
+_BN_TYPES = (nn.BatchNorm1d, nn.BatchNorm2d, nn.BatchNorm3d)
+_GRAVEYARD = []          # entries of dead modules, parked by their finalizers; destroyed by _drain() on a caller's thread
+
+
 class _Entry:
     __slots__ = ("calls", "failed", "fwd", "bwd", "static_in", "static_out", "static_gout", "static_grads", "params",
-                 "out_ref", "pending", "pool", "stamp")
+                 "node_ref", "pending", "pool", "stamp", "gen", "bwd_gen", "baked", "__weakref__")
 
     def __init__(self):
         self.calls, self.failed, self.fwd, self.bwd = 0, False, None, None
-        self.out_ref, self.pending, self.stamp = None, False, 0
+        self.node_ref, self.pending, self.stamp = None, False, 0
+        self.gen, self.bwd_gen = 0, -1       # replays so far; the replay whose activations were last back-propagated
+        self.baked = None                    # momenta the capture baked in BY VALUE (a torch-composition fallback ran in it)
+        self.static_in = self.static_out = self.static_gout = self.static_grads = self.params = self.pool = None
+
+    def destroy(self):
+        """Release the graphs and their pool NOW, on this thread (the caller has synchronised the device).  An autograd
+        node that still holds this entry finds it dead and says so."""
+        self.fwd = self.bwd = None
+        self.static_in = self.static_out = self.static_gout = self.static_grads = self.params = self.pool = None
+        self.failed, self.pending = True, False
+
+
+def _bury(entries):
+    """Finalizer of a module with captured entries: runs wherever the collector happens to run, so it only parks them."""
+    _GRAVEYARD.extend(entries.values())
+    entries.clear()
+
+
+def _drain():
+    """Destroy parked entries on the calling thread with the device idle."""
+    if not _GRAVEYARD:
+        return
+    dead = list(_GRAVEYARD)
+    del _GRAVEYARD[:len(dead)]
+    live = [e for e in dead if e.fwd is not None]
+    if live and torch.cuda.is_available() and not torch.cuda.is_current_stream_capturing():
+        torch.cuda.synchronize()
+    for e in dead:
+        e.destroy()
 
 
 class _Replay(torch.autograd.Function):
@@ -68,10 +121,16 @@ class _Replay(torch.autograd.Function):
     @staticmethod
     def forward(ctx, entry, x, *params):
         ctx.entry = entry
+        # the parameters are saved although the captured kernels read them through their addresses: autograd's version
+        # counters then refuse forward -> optimizer.step() -> backward exactly as they do on the plain path
+        # (tests/test_optim.py::test_backward_after_native_step_raises; FlatAdam.step bumps the versions)
+        ctx.save_for_backward(*params)
         with torch.cuda.device(x.device):       # a graph launches on the CURRENT device's current stream
             if x.data_ptr() != entry.static_in.data_ptr():
                 entry.static_in.copy_(x)
             entry.fwd.replay()
+            entry.gen += 1
+            ctx.gen = entry.gen
             entry.pending = True
             # a copy (16 MB at B=32, ~10 us): the caller owns its output like on the plain path, whatever it keeps across steps
             return entry.static_out.clone()
@@ -80,11 +139,24 @@ class _Replay(torch.autograd.Function):
     @torch.autograd.function.once_differentiable
     def backward(ctx, gout):
         entry = ctx.entry
+        ctx.saved_tensors                        # version check of the parameters (raises like the plain path would)
+        if entry.fwd is None:
+            raise RuntimeError("istnet_amd.graphed: the captured graphs of this forward were destroyed (graphed.reset / "
+                               "eviction of its shape) before its backward ran")
+        if ctx.gen != entry.gen:
+            raise RuntimeError("istnet_amd.graphed: a later forward of the same shape replayed over the activations this "
+                               "backward needs (the autograd node outlived its output); ISTNET_AUTO_GRAPH=0 runs such a "
+                               "graph launch by launch")
+        if entry.bwd_gen == ctx.gen:
+            raise RuntimeError("istnet_amd.graphed: second backward through a graph segment (retain_graph=True): the "
+                               "captured backward recycles the memory of the saved activations; set ISTNET_AUTO_GRAPH=0 "
+                               "for double backward passes")
         with torch.cuda.device(entry.static_gout.device):
             if gout.data_ptr() != entry.static_gout.data_ptr():
                 entry.static_gout.copy_(gout)
             entry.bwd.replay()
         entry.pending = False
+        entry.bwd_gen = ctx.gen
         # fresh tensor objects over the static buffers: AccumulateGrad then stores them instead of cloning
         return (None, None) + tuple(None if g is None else g.detach() for g in entry.static_grads)
 
@@ -100,63 +172,105 @@ class AutoGraph:
         self.entries = {}
         self._stamp = 0
         self.module = None                   # weak reference, set by for_module()
-        self._mods = None                    # the module tree, flattened once
+        self._mods = None                    # the module tree, flattened once (weak references: this object is the VALUE of
+        #                                      a WeakKeyDictionary keyed by the module and must not keep it alive)
+        self._plain_streak, self._warned = 0, False
 
     def plain(self, x):
         return self._plain(self.module(), x)
+
+    def _note_plain(self, module, reason):
+        """Count a plain-path call; tell a training caller once when it never leaves the plain path."""
+        STATS["plain"] += 1
+        WHY[reason] += 1
+        self._plain_streak += 1
+        if (self._plain_streak >= PLAIN_STREAK_WARN and not self._warned and module.training
+                and reason not in ("warm-up call",)):
+            self._warned = True
+            warnings.warn(f"istnet_amd.graphed: {type(module).__name__} has run launch by launch for {self._plain_streak} "
+                          f"consecutive calls ({reason}); the HIP-graph path is ~1.7x faster for an eager training loop. "
+                          "Typical cause: optimizer.zero_grad(set_to_none=False) keeps .grad tensors alive -- use "
+                          "set_to_none=True (the torch >= 2.0 default).  graphed.WHY has the counts.", RuntimeWarning)
 
     # -- what a capture bakes in -------------------------------------------------------------------------------------
     def _key(self, module, x):
         # the module TREE is walked once (nn.Module's generators cost ~0.7 ms per call for the encoder's 168 modules); what
         # the modules hold -- parameters, buffers, flags, hooks -- is read afresh every call.  A submodule added or replaced
         # after the first call needs graphed.reset(module).
-        mods = self._mods
-        if mods is None:
-            mods = self._mods = list(module.modules())
+        refs = self._mods
+        if refs is None:
+            refs = self._mods = [weakref.ref(m) for m in module.modules()]
         flags, addrs, req = [], [], []
-        for m in mods:
+        for r in refs:
+            m = r()
+            if m is None:
+                return "submodule gone"
             flags.append(m.training)
             if m._forward_hooks or m._forward_pre_hooks or m._backward_hooks or m._backward_pre_hooks:
-                WHY[f"module hook on {type(m).__name__}"] += 1
-                return None
+                return f"module hook on {type(m).__name__}"
+            if isinstance(m, _BN_TYPES):
+                # eps and track_running_stats are arguments of the captured launches; the momentum is NOT part of the key:
+                # it is read from a device slot that __call__ refreshes from the host value before every replay
+                flags.append(m.eps)
+                flags.append(m.track_running_stats)
             for p in m._parameters.values():
                 if p is None:
                     continue
                 addrs.append(p.data_ptr())
                 req.append(p.requires_grad)
                 if p.requires_grad and p.grad is not None:
-                    WHY["a parameter already holds a .grad (accumulation)"] += 1
-                    return None              # accumulation into an existing .grad: the captured kernels overwrite
+                    return "a parameter already holds a .grad (accumulation, or zero_grad(set_to_none=False))"
                 slot = p.__dict__.get("_istnet_grad_slot")
                 addrs.append(0 if slot is None else slot.data_ptr())
             for b in m._buffers.values():
                 if b is not None:
                     addrs.append(b.data_ptr())
-        return (tuple(x.shape), x.dtype, x.device, tuple(flags), tuple(addrs), tuple(req), self.switch_state())
+        return (tuple(x.shape), x.dtype, x.device, tuple(flags), tuple(addrs), tuple(req), self.switch_state(),
+                torch.is_autocast_enabled())
+
+    def _follow_momentum(self, module):
+        """Mirror every BatchNorm's host ``momentum`` into its device slot when any differs (utils/scheduler.py's
+        BNMomentumScheduler and a bare ``model.apply(lambda m: setattr(m, "momentum", x))`` both land here)."""
+        from .pointnet2.pytorch_utils import _MomentumSlots
+        bufs = _MomentumSlots._bufs
+        for r in self._mods:
+            m = r()
+            rec = m.__dict__.get("_istnet_mslot") if isinstance(m, _BN_TYPES) else None
+            if rec is not None and m.momentum is not None and bufs[rec[0]][2][rec[1]] != float(m.momentum):
+                _MomentumSlots.sync(module)
+                STATS["momentum_syncs"] += 1
+                return
+
+    def _momenta(self):
+        return tuple(m.momentum for m in (r() for r in self._mods) if isinstance(m, _BN_TYPES))
+
+    def _evict(self, key):
+        entry = self.entries.pop(key)
+        if entry.fwd is not None:
+            torch.cuda.synchronize()
+        entry.destroy()
 
     def __call__(self, x):
         module = self.module()
+        _drain()
         if not (ENABLED and x.is_cuda and torch.is_grad_enabled() and not x.requires_grad and x.is_contiguous()
                 and not torch.cuda.is_current_stream_capturing()):
             WHY["not eligible (disabled / no grad mode / input requires grad / capturing)"] += 1
             return self.plain(x)
         key = self._key(module, x)
-        if key is None or not any(key[5]):
-            STATS["plain"] += 1
-            WHY["hooks, an existing .grad, or nothing to differentiate"] += 1
+        if isinstance(key, str) or not any(key[5]):
+            self._note_plain(module, key if isinstance(key, str) else "nothing to differentiate")
             return self.plain(x)
         entry = self.entries.get(key)
         if entry is None:
-            if len(self.entries) >= MAX_ENTRIES:          # shapes come and go (last partial batch): keep the recent ones
-                oldest = min(self.entries, key=lambda k: self.entries[k].stamp)
-                del self.entries[oldest]
+            while len(self.entries) >= max(MAX_ENTRIES, 1):   # shapes come and go (last partial batch): keep the recent ones
+                self._evict(min(self.entries, key=lambda k: self.entries[k].stamp))
             entry = self.entries[key] = _Entry()
         self._stamp += 1
         entry.stamp = self._stamp
         entry.calls += 1
         if entry.failed or entry.calls <= WARMUP_CALLS:
-            STATS["plain"] += 1
-            WHY["capture failed earlier" if entry.failed else "warm-up call"] += 1
+            self._note_plain(module, "capture failed earlier" if entry.failed else "warm-up call")
             return self.plain(x)
         if entry.fwd is None:
             try:
@@ -169,16 +283,23 @@ class AutoGraph:
                 warnings.warn(f"istnet_amd.graphed: HIP-graph capture of {type(module).__name__} failed "
                               f"({type(exc).__name__}: {exc}); this shape keeps running launch by launch", RuntimeWarning)
                 return self.plain(x)
-        if entry.pending and entry.out_ref is not None and entry.out_ref() is not None:
-            # the previous graphed forward has not been back-propagated and its output is still referenced: a replay
-            # would overwrite the activations that backward needs
-            STATS["plain"] += 1
-            WHY["previous graphed output still alive and not back-propagated"] += 1
+        if entry.pending and entry.node_ref is not None and entry.node_ref() is not None:
+            # the previous graphed forward has not been back-propagated and its autograd NODE is still reachable (the
+            # output tensor itself may be gone: mean / sum / cat / slicing do not keep their input): a replay would
+            # overwrite the activations that node's backward needs
+            self._note_plain(module, "previous graphed forward still awaits its backward")
             return self.plain(x)
-        params = entry.params
-        out = _Replay.apply(entry, x, *params)
-        entry.out_ref = weakref.ref(out)
+        if entry.baked is not None and entry.baked != self._momenta():
+            # a torch-composition fallback inside the capture took bn.momentum by value and the caller has changed it since:
+            # this entry is stale for good -- drop it (the shape warms up and captures again with today's values)
+            self._evict(key)
+            self._note_plain(module, "momentum changed under a capture that baked it in (torch fallback inside)")
+            return self.plain(x)
+        self._follow_momentum(module)
+        out = _Replay.apply(entry, x, *entry.params)
+        entry.node_ref = weakref.ref(out.grad_fn)
         STATS["replays"] += 1
+        self._plain_streak = 0
         return out
 
     def _capture(self, entry, module, x):
@@ -203,9 +324,16 @@ class AutoGraph:
                         a._istnet_grad_slot = slot          # optim.FlatAdam: the backward kernels write the flat gradient
                 swaps.append((m, name, p))
                 m._parameters[name] = a
+        # the slots must hold the host momenta BEFORE the capture (a fill recorded in the graph would put today's value
+        # back on every replay; pytorch_utils._MomentumSlots.ptr refuses to do that)
+        from .pointnet2 import fused_mlp
+        from .pointnet2.pytorch_utils import sync_bn_momentum
+        sync_bn_momentum(module)
+        fallbacks = sum(fused_mlp.FALLBACKS.values())
         try:
             with torch.cuda.device(dev):
                 torch.cuda.synchronize(dev)
+                before = torch.cuda.memory_reserved(dev)
                 pool = torch.cuda.graph_pool_handle()
                 static_in = x.detach().clone()
                 fwd = torch.cuda.CUDAGraph()
@@ -219,17 +347,30 @@ class AutoGraph:
                     grads = torch.autograd.grad((static_out,), [alias[id(p)] for p in params], (static_gout,),
                                                 allow_unused=True)
                 torch.cuda.synchronize(dev)
+                pinned = torch.cuda.memory_reserved(dev) - before
         finally:
             for m, name, p in swaps:
                 m._parameters[name] = p
         entry.fwd, entry.bwd, entry.pool = fwd, bwd, pool
         entry.static_in, entry.static_out, entry.static_gout = static_in, static_out.detach(), static_gout
         entry.static_grads, entry.params = list(grads), params
+        # a shape the fused kernels do not cover ran torch's BatchNorm inside the capture: that launch took the momentum by
+        # value, so the entry is only valid while the host momenta stay what they were
+        entry.baked = self._momenta() if sum(fused_mlp.FALLBACKS.values()) != fallbacks else None
         STATS["captures"] += 1
+        _LOG.info("captured %s for input %s: forward + backward HIP graphs, ~%.0f MB of device memory held until "
+                  "graphed.reset(module), eviction (%d shapes kept per module) or the module's death",
+                  type(module).__name__, tuple(x.shape), pinned / 2**20, MAX_ENTRIES)
 
     def reset(self):
+        """Destroy every captured entry now (calling thread, device idle)."""
+        if any(e.fwd is not None for e in self.entries.values()) and torch.cuda.is_available():
+            torch.cuda.synchronize()
+        for e in self.entries.values():
+            e.destroy()
         self.entries.clear()
         self._mods = None
+        self._plain_streak, self._warned = 0, False
 
 
 class InferenceGraph:
@@ -257,17 +398,27 @@ class InferenceGraph:
         self._stamp = 0
         self.module = None
         self._mods = self._tensors = None
-        self._hooked = False
 
     def plain(self, inputs):
         return self._plain(self.module(), inputs)
 
     def _fingerprint(self, module):
-        if self._tensors is None:
-            self._mods = list(module.modules())
-            self._hooked = any(m._forward_hooks or m._forward_pre_hooks for m in self._mods)
-            self._tensors = list(module.parameters()) + list(module.buffers())
-        return (tuple(t.data_ptr() for t in self._tensors), tuple(m.training for m in self._mods))
+        for attempt in (0, 1):
+            if self._tensors is None:
+                self._mods = [weakref.ref(m) for m in module.modules()]
+                self._tensors = [weakref.ref(t) for t in list(module.parameters()) + list(module.buffers())]
+            mods = [r() for r in self._mods]
+            tens = [r() for r in self._tensors]
+            if all(m is not None for m in mods) and all(t is not None for t in tens):
+                break
+            self._tensors = None             # a buffer object was replaced (``.to()`` / ``.half()``): flatten again, once
+            if attempt:
+                return None
+        # hooks are read afresh on every call (a profiler or feature extractor may register one at any time): a replay
+        # would silently stop firing them
+        if any(m._forward_hooks or m._forward_pre_hooks for m in mods):
+            return None
+        return (tuple(t.data_ptr() for t in tens), tuple(m.training for m in mods))
 
     def __call__(self, inputs, keys):
         first = inputs[keys[0]]
@@ -281,15 +432,19 @@ class InferenceGraph:
                 return self.plain(inputs)
             sig.append((k, tuple(t.shape), t.dtype, t.is_contiguous()))
         module = self.module()
+        _drain()
         fp = self._fingerprint(module)
-        if self._hooked or module._forward_hooks or module._forward_pre_hooks:
+        if fp is None:                       # a module carries a hook (or the tree changed): launch by launch
             STATS["infer_plain"] += 1
             return self.plain(inputs)
         key = (tuple(sig), fp, self.switch_state())
         entry = self.entries.get(key)
         if entry is None:
-            if len(self.entries) >= INFER_MAX_ENTRIES:
-                del self.entries[min(self.entries, key=lambda k: self.entries[k].stamp)]
+            while len(self.entries) >= max(INFER_MAX_ENTRIES, 1):
+                old = self.entries.pop(min(self.entries, key=lambda k: self.entries[k].stamp))
+                if old.fwd is not None:
+                    torch.cuda.synchronize()
+                old.destroy()                # on this thread, device idle -- not whenever the collector gets to it
             entry = self.entries[key] = _Entry()
         self._stamp += 1
         entry.stamp = self._stamp
@@ -327,6 +482,10 @@ class InferenceGraph:
             return {k: v.clone() for k, v in entry.static_out.items()}     # the caller owns its outputs
 
     def reset(self):
+        if any(e.fwd is not None for e in self.entries.values()) and torch.cuda.is_available():
+            torch.cuda.synchronize()
+        for e in self.entries.values():
+            e.destroy()
         self.entries.clear()
         self._mods = self._tensors = None
 
@@ -343,6 +502,7 @@ def for_module(module, plain, switch_state=None):
     if ag is None:
         ag = _REGISTRY[module] = AutoGraph(plain, switch_state)
         ag.module = weakref.ref(module)
+        weakref.finalize(module, _bury, ag.entries)     # the graphs of a dead module are parked, never freed by the collector
     return ag
 
 
@@ -352,11 +512,13 @@ def for_inference(module, plain, switch_state=None):
     if ig is None:
         ig = _INFER_REGISTRY[module] = InferenceGraph(plain, switch_state)
         ig.module = weakref.ref(module)
+        weakref.finalize(module, _bury, ig.entries)
     return ig
 
 
 def reset(module=None):
     """Drop captured graphs (of one module and of the modules inside it, or of all): frees their memory pools."""
+    _drain()
     inside = None if module is None else {id(m) for m in module.modules()}
     for registry in (_REGISTRY, _INFER_REGISTRY):
         for m, ag in list(registry.items()):

@@ -54,6 +54,7 @@ class GeometrySlot:
         self.shape = None
         self.flat = None     # dtype -> flat storage the tensors above are views of
         self.plan = None     # _ext.OutputPlan: which output allocation of a prefetch pass is which view (prefetch_geometry)
+        self.packed = True   # the views lie back to back in ``flat`` (no alignment padding between them)
         self.grad_mode = None
 
     def tensors(self):
@@ -235,13 +236,20 @@ class PointNet2MSG(nn.Module):
             src = fresh.tensors()
             if stale or len(src) != len(slot.tensors()):
                 # persistent storage: one flat buffer per dtype, the slot's tensors are views into them
-                slot.flat = {dt: torch.empty(sum(t.numel() for t in src if t.dtype == dt), dtype=dt, device=xyz.device)
+                # every view starts on a 16-byte boundary: kernels read / write some of these tensors with 16-byte accesses
+                # (compact_scan_pair_kernel: int4 on the per-row counts and starts; a (b * g + 1)-element table in front of
+                # them would otherwise push its successors off alignment -- ADVICE r5)
+                def _padded(t):
+                    q = max(16 // t.element_size(), 1)
+                    return (t.numel() + q - 1) // q * q
+                slot.flat = {dt: torch.empty(sum(_padded(t) for t in src if t.dtype == dt), dtype=dt, device=xyz.device)
                              for dt in {t.dtype for t in src}}
+                slot.packed = all(_padded(t) == t.numel() for t in src)      # back-to-back: one pack launch can fill it
                 off = {dt: 0 for dt in slot.flat}
                 views = []
                 for t in src:
                     views.append(slot.flat[t.dtype][off[t.dtype]:off[t.dtype] + t.numel()].view(t.shape))
-                    off[t.dtype] += t.numel()
+                    off[t.dtype] += _padded(t)
                 it = iter(views)
                 slot.sa = [(next(it), [next(it) for _ in idxs],
                             [(next(it), next(it)) for _ in csrs] if csrs is not None else None,
@@ -261,7 +269,8 @@ class PointNet2MSG(nn.Module):
                     by_dt.setdefault(t.dtype, []).append((t, v))
                 for dt, pairs in by_dt.items():
                     whole = len(pairs) == sum(1 for t in src if t.dtype == dt)
-                    if whole and slot.flat[dt].element_size() == 4 and all(t.is_contiguous() for t, _ in pairs):
+                    if (whole and slot.packed and slot.flat[dt].element_size() == 4
+                            and all(t.is_contiguous() for t, _ in pairs)):
                         _native.pack_words([t for t, _ in pairs], slot.flat[dt], side.cuda_stream)   # one launch per <= 64 tensors
                     else:
                         for t, v in pairs:

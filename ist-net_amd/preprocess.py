@@ -122,8 +122,12 @@ def fill_missing(dpt, cam_scale, scale_2_80m, fill_type="multiscale", extrapolat
         raise ValueError("fill_missing: expected a depth image (h, w) or a batch (b, h, w)")
     if img.dtype in (torch.uint16, torch.int16):
         raw, is_float = img.contiguous(), 0                             # raw millimetres, 16-bit storage read as unsigned
+    elif img.dtype == torch.float32:
+        raw, is_float = img.contiguous(), 1
     else:
-        raw, is_float = img.to(torch.float32).contiguous(), 1
+        # float64 / int32 / int64 ...: numpy scales these in float64 and rounds to float32 ONCE (utils/data_utils.py:523-526);
+        # a float32 conversion here would round twice and can move a value across the 0.1 / max_depth thresholds
+        raw, is_float = img.to(torch.float64).contiguous(), 2
     b, h, w = raw.shape
     lib = _native.lib()
     scratch = torch.empty(lib.istnet_depth_fill_scratch_floats(b, h, w), dtype=torch.float32, device=raw.device)

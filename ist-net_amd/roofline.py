@@ -48,6 +48,23 @@ def pmc_traffic(kernel_name, path):
     return rec["hbm_bytes_per_launch"], os.path.basename(path)
 
 
+def pmc_sq(kernel_name, path):
+    """MFMA-pipe busy fraction of `kernel_name` from a committed rocprofv3 SQ-counter summary (tools/pmc_sq.sh):
+    SQ_VALU_MFMA_BUSY_CYCLES / (4 SIMDs x SQ_BUSY_CU_CYCLES) over the launches of one profiled run.  Same staleness rule as
+    pmc_traffic: a summary collected on other kernel sources is reported as null with the reason."""
+    import json
+    import os
+    if not path or not os.path.exists(path):
+        return None, None
+    data = json.load(open(path))
+    rec = data.get("kernels", {}).get(kernel_name)
+    if not rec:
+        return None, None
+    if data.get("kernel_source_sha256") != kernel_source_hash():
+        return None, "stale: %s was collected on other kernel sources (re-run tools/pmc_sq.sh)" % os.path.basename(path)
+    return rec, os.path.basename(path)
+
+
 def measure_replayed(capture, replays=5, only=None):
     """Times every GEMM launch INSIDE replays of the captured step: ``capture()`` must capture the step into HIP graphs
     while _native.TIMING is active and return a function that replays them once.  Each launch is bracketed by two
@@ -114,7 +131,7 @@ def _eager_events(step, steps):
     return per_kernel
 
 
-def measure(step, steps=5, traffic_file=None, capture=None, steps_per_replay=1):
+def measure(step, steps=5, traffic_file=None, capture=None, steps_per_replay=1, sq_file=None):
     """`step` runs one full training step eagerly.  Returns the `roofline` object of the bench JSON line.
 
     Pass 1 (HIP events around every GEMM launch of instrumented eager steps, single stream) finds the kernel with the
@@ -127,7 +144,35 @@ def measure(step, steps=5, traffic_file=None, capture=None, steps_per_replay=1):
     name = max(eager.items(), key=lambda kv: kv[1][0])[0]
     obj = _roofline_object(eager, steps, traffic_file,
                            "HIP events on the launch stream around each launch, %d instrumented eager steps" % steps)
+    sq, sq_src = pmc_sq(name, sq_file)
+    if sq is not None:
+        obj["mfma_busy_frac"] = sq.get("mfma_busy_frac")
+        obj["mfma_busy_source"] = sq_src
+        obj["mfma_busy_note"] = ("SQ_VALU_MFMA_BUSY_CYCLES / (4 x SQ_BUSY_CU_CYCLES), rocprofv3 --pmc run of the encoder step "
+                                 "(counters in their own pass, profiles/%s)" % sq_src)
+    elif sq_src is not None:
+        obj["mfma_busy_frac"], obj["mfma_busy_source"] = None, sq_src
     replayed = measure_replayed(capture, steps, only=name) if capture is not None else None
+    # the dominant FAMILY on the same clock as the dominant kernel: its launches bracketed inside replays of the step
+    fam_base = obj["dominant_family"]["kernel"].split("<")[0]
+    fam_replayed = (measure_replayed(capture, steps, only=lambda n: n.split("<")[0] == fam_base)
+                    if capture is not None else None)
+    if fam_replayed:
+        fam_replayed.pop("__bracket_overhead_us__", None)
+        fms = sum(v[0] for v in fam_replayed.values())
+        fflops = sum(v[1] for v in fam_replayed.values())
+        fbytes = sum(v[2] for v in fam_replayed.values())
+        fl = sum(v[3] for v in fam_replayed.values())
+        if fms > 0 and fl:
+            d = obj["dominant_family"]
+            d.update({"achieved_eager_isolated": d["achieved"], "frac_eager_isolated": d["frac"],
+                      "achieved": fflops / (fms * 1e-3) / 1e12,
+                      "frac": fflops / (fms * 1e-3) / 1e12 / PEAK_MFMA_F32_TFLOPS,
+                      "algorithmic_gbs": fbytes / (fms * 1e-3) / 1e9,
+                      "us_per_step_in_replay": fms * 1e3 / (steps * steps_per_replay),
+                      "launches_per_step": fl / (steps * steps_per_replay),
+                      "timing": "device wall-clock markers around every launch of the family inside replays of the captured "
+                                "step (the clock of roofline.achieved); *_eager_isolated: HIP events, instrumented eager steps"})
     if replayed and name in replayed:
         overhead_us = replayed.pop("__bracket_overhead_us__", None)
         ms, flops, nbytes, launches = replayed[name]
@@ -169,6 +214,9 @@ def _roofline_object(per_kernel, steps, traffic_file, timing):
         "flop_per_launch_avg": flops / launches, "algorithmic_bytes_per_launch_avg": nbytes / launches,
         "algorithmic_gbs": nbytes / (ms * 1e-3) / 1e9,
         "all_gemm_kernels_ms_per_step": total_ms / steps,
+        # what the step EXECUTES per step in its GEMM launches (layer 0 of an SA scale runs over the source points, level 1 on
+        # compact columns, no coordinate gradient): less than SURVEY 8d's nominal 140.6 GFLOP, which step_flops_frac divides by
+        "executed_gemm_gflop_per_step": sum(v[1] for v in per_kernel.values()) / steps / 1e9,
         "all_gemm_kernels_tflops": all_tflops,
         "all_gemm_kernels_frac": all_tflops / PEAK_MFMA_F32_TFLOPS,        # plain FLOP/s over the fp32 MFMA peak
         "dominant_family": {"kernel": fname + "<*>" if any(k.startswith(fname + "<") for k in per_kernel) else fname,

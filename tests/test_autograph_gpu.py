@@ -242,3 +242,192 @@ def test_two_uses_in_one_backward_are_reproducible_without_an_optimizer_slot():
             del junk
     finally:
         graphed.ENABLED = True
+
+
+# ---- round 6: host state a replay must follow, and the hazards of an autograd node that outlives its output ----
+
+def _momentum_run(auto, sched, lr=1e-3, b=4, n=512):
+    """Reference-style loop (utils/solver.py:88-99) in which the momentum is set the way the reference's OWN scheduler sets it
+    (utils/scheduler.py BNMomentumScheduler: a bare ``m.momentum = x`` under ``model.apply``) -- no package scheduler, no
+    sync_bn_momentum.  Returns the running statistics after the run."""
+    from istnet_amd import graphed
+    graphed.ENABLED = auto
+    try:
+        model = _model()
+        opt = torch.optim.Adam(model.parameters(), lr=lr)
+        for it, mom in enumerate(sched):
+            model.apply(lambda m, mom=mom: setattr(m, "momentum", mom) if isinstance(m, torch.nn.modules.batchnorm._BatchNorm) else None)
+            pts = _cloud(b, n, 300 + it)
+            opt.zero_grad()
+            model(pts).square().mean().backward()
+            opt.step()
+        torch.cuda.synchronize()
+        return {k: v.detach().clone() for k, v in model.state_dict().items()
+                if k.endswith(("running_mean", "running_var", "num_batches_tracked"))}
+    finally:
+        graphed.ENABLED = True
+
+
+def test_graph_segments_follow_a_foreign_momentum_scheduler():
+    """replays read the momentum from a device slot; a caller that changes ``bn.momentum`` by hand (the
+    reference's own BNMomentumScheduler) must be followed, bit for bit, and the stale value must be visibly different."""
+    from istnet_amd import graphed
+    sched = [0.5, 0.5, 0.5, 0.2, 0.05, 0.9, 0.9, 0.3]            # steps 1-2 warm up, 3 captures, 4.. replay with new momenta
+    before = dict(graphed.STATS)
+    got = _momentum_run(True, sched)
+    assert graphed.STATS["captures"] == before["captures"] + 1, dict(graphed.WHY)
+    assert graphed.STATS["replays"] >= before["replays"] + 6
+    assert graphed.STATS["momentum_syncs"] >= before["momentum_syncs"] + 4      # 0.2, 0.05, 0.9, 0.3
+    want = _momentum_run(False, sched)
+    stale = _momentum_run(False, [0.5] * len(sched))              # what a momentum frozen at capture time would give
+    assert len(want) >= 96
+    worst = 0.0
+    for k in want:
+        assert torch.equal(got[k], want[k]), k
+        if not k.endswith("num_batches_tracked"):
+            worst = max(worst, ((stale[k] - want[k]).abs().max() / want[k].abs().max().clamp_min(1e-12)).item())
+    assert worst > 1e-2
+
+
+def test_eps_is_part_of_the_key():
+    from istnet_amd import graphed
+    model = _model()
+    a = _cloud(2, 256, 5)
+    for _ in range(4):
+        model.zero_grad()
+        model(a).square().mean().backward()
+    caps, replays = graphed.STATS["captures"], graphed.STATS["replays"]
+    for m in model.modules():
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.eps = 1e-3
+    model.zero_grad()
+    out = model(a)                              # new key: plain (warm-up), never a replay of the eps=1e-5 graph
+    assert graphed.STATS["replays"] == replays and graphed.STATS["captures"] == caps
+    graphed.ENABLED = False
+    try:
+        ref = model(a)
+    finally:
+        graphed.ENABLED = True
+    assert torch.equal(out, ref)
+
+
+def test_node_that_outlives_its_output_keeps_the_plain_path():
+    """``enc(a).mean() + enc(b).mean()`` -- mean() does not save its input, so the first output tensor
+    dies while its autograd node is still in the graph.  The second call must NOT replay over the first call's activations."""
+    from istnet_amd import graphed
+    model = _model()
+    a, b = _cloud(2, 256, 1), _cloud(2, 256, 2)
+    for _ in range(3):
+        model.zero_grad()
+        model(a).mean().backward()
+    replays = graphed.STATS["replays"]
+    model.zero_grad()
+    loss = model(a).mean() + model(b).mean()      # first output is garbage by the time the second call runs
+    assert graphed.STATS["replays"] == replays + 1, dict(graphed.WHY)
+    loss.backward()
+    got = [p.grad.clone() for p in model.parameters()]
+    graphed.ENABLED = False
+    try:
+        model.zero_grad()
+        (model(a).mean() + model(b).mean()).backward()
+    finally:
+        graphed.ENABLED = True
+    for g, p in zip(got, model.parameters()):
+        assert torch.equal(g, p.grad)
+
+
+def test_second_backward_through_a_segment_raises():
+    from istnet_amd import graphed
+    model = _model()
+    a = _cloud(2, 256, 4)
+    for _ in range(3):
+        model.zero_grad()
+        model(a).square().mean().backward()
+    model.zero_grad()
+    replays = graphed.STATS["replays"]
+    loss = model(a).square().mean()
+    assert graphed.STATS["replays"] == replays + 1
+    loss.backward(retain_graph=True)
+    with pytest.raises(RuntimeError, match="second backward"):
+        loss.backward()
+
+
+def test_backward_after_optimizer_step_raises_on_the_graph_path_too():
+    """forward -> optimizer.step() -> backward: the parameters the captured backward would read are no longer the ones
+    the forward used.  The plain path raises (saved tensors' version counters); the replay node saves the parameters so
+    that it does as well."""
+    from istnet_amd import graphed
+    model = _model()
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+    a = _cloud(2, 256, 6)
+    for _ in range(3):
+        opt.zero_grad()
+        model(a).square().mean().backward()
+        opt.step()
+    opt.zero_grad()
+    replays = graphed.STATS["replays"]
+    loss = model(a).square().mean()
+    assert graphed.STATS["replays"] == replays + 1
+    for p in model.parameters():
+        p.grad = torch.zeros_like(p)
+    opt.step()                                   # in-place update between forward and backward
+    with pytest.raises(RuntimeError, match="modified by an inplace operation"):
+        loss.backward()
+
+
+def test_eviction_destroys_entries_and_a_stale_node_says_so():
+    from istnet_amd import graphed
+    model = _model()
+    shapes = [(2, 256), (3, 256), (2, 512)]
+    assert graphed.MAX_ENTRIES == 2
+    held = None
+    for i, (b, n) in enumerate(shapes):
+        x = _cloud(b, n, 20 + i)
+        for _ in range(3):
+            model.zero_grad()
+            out = model(x)
+            if i == 0:
+                held = out.square().mean()          # node of the first shape's last replay, never back-propagated
+            else:
+                out.square().mean().backward()
+    ag = graphed._REGISTRY[model]
+    assert len(ag.entries) == 2                  # the first shape was evicted, its graphs destroyed on this thread
+    with pytest.raises(RuntimeError, match="destroyed"):
+        held.backward()
+    graphed.reset(model)
+    assert len(ag.entries) == 0
+
+
+def test_set_to_none_false_callers_are_told_once():
+    from istnet_amd import graphed
+    model = _model()
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+    a = _cloud(2, 256, 7)
+    with pytest.warns(RuntimeWarning, match="set_to_none"):
+        for _ in range(graphed.PLAIN_STREAK_WARN + 3):
+            opt.zero_grad(set_to_none=False)
+            model(a).square().mean().backward()
+            opt.step()
+
+
+def test_inference_graph_notices_a_hook_registered_later():
+    """a forward hook registered on a SUBMODULE after the first eval calls must keep firing."""
+    from istnet_amd import graphed
+    import bench
+    net, dev = _infer_net()
+    batch = bench.istnet_batch(2, 1024, seed=4, device=dev)
+    with torch.no_grad():
+        for _ in range(4):
+            net(batch)
+    replays = graphed.STATS["infer_replays"]
+    fired = []
+    sub = next(m for m in net.modules() if isinstance(m, torch.nn.Conv1d))
+    h = sub.register_forward_hook(lambda m, i, o: fired.append(1))
+    with torch.no_grad():
+        net(batch)
+    assert fired and graphed.STATS["infer_replays"] == replays
+    h.remove()
+    with torch.no_grad():
+        net(batch)
+    assert graphed.STATS["infer_replays"] == replays + 1
+    graphed.reset(net)

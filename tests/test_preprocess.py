@@ -293,6 +293,27 @@ def test_fill_missing_matches_oracle(shape):
         preprocess.fill_missing(batch, 1000.0, 1, fill_type="fast")
 
 
+@pytest.mark.gpu
+def test_fill_missing_float64_and_int32_input_round_once():
+    """numpy keeps float64 / int32 depth in float64 through ``dpt / cam_scale * scale_2_80m`` and rounds to
+    float32 once (utils/data_utils.py:523-526); the kernel's float64 raw kind does the same.  A cam_scale that is not a power
+    of two makes double rounding visible; int32 and float64 of the same values must give the uint16 result bit for bit."""
+    from istnet_amd import preprocess
+    from oracle import depth_fill_oracle as dfo
+    dev = torch.device("cuda:0")
+    img = _depth_scene(4, 96, 128)
+    u16 = torch.from_numpy(img.view(np.int16)).to(dev)
+    ref = preprocess.fill_missing(u16, 997.3, 1)
+    for conv in (torch.float64, torch.int32, torch.int64):
+        got = preprocess.fill_missing(torch.from_numpy(img.astype(np.int64)).to(dev).to(conv), 997.3, 1)
+        assert torch.equal(got, ref), conv
+    frac = img.astype(np.float64) + np.where(img > 0, 0.37, 0.0)           # a float64 image that is not exactly float32
+    got = preprocess.fill_missing(torch.from_numpy(frac).to(dev), 997.3, 1).cpu().numpy()
+    want = np.float32(dfo.fill_missing(frac, 997.3, 1))
+    assert ((got == 0) == (want == 0)).all()
+    np.testing.assert_allclose(got, want, rtol=1e-5, atol=1e-3)
+
+
 def test_instance_labels_match_numpy_restatement():
     """preprocess.instance_labels (batched tensor form of provider/dataset.py:236-257) against the per-instance numpy
     restatement: symmetric and asymmetric classes, rotation / size / NOCS coordinates / sRT."""
