@@ -43,6 +43,7 @@ CAM_RADII = [[0.01, 0.02], [0.02, 0.04], [0.04, 0.08], [0.08, 0.16]]  # ist_net.
 BATCH, NPOINTS = 32, 1024
 ENCODER_FWD_BWD_MFLOP_PER_CLOUD = 4394.7      # 3 x 1 464.9 MFLOP dense forward work per cloud
 PMC_TRAFFIC_FILE = "r06_pmc_traffic.json"     # rocprofv3 --pmc summary the roofline object's `traffic` is read from
+PREFETCH_SPLIT = ""       # make_pipelined_fwd_bwd: where the second part of the next batch's geometry is issued (see there)
 PMC_SQ_FILE = "r06_pmc_sq_counters.json"      # rocprofv3 --pmc SQ counters: roofline.mfma_busy_frac (tools/pmc_sq.sh)
 
 
@@ -146,9 +147,23 @@ def make_pipelined_fwd_bwd(model, batches, slots, i):
     """Step on batch i while the geometry stream prepares batch 1-i (FPS / ball query / three_nn depend on the
     coordinates only -- next-batch preprocessing, as a data loader would overlap it).  Every step still runs one
     full geometry pass; it just runs one step ahead of its consumer."""
+    split = os.environ.get("ISTNET_PREFETCH_SPLIT", PREFETCH_SPLIT)
+
     def fwd_bwd():
-        model.prefetch_geometry(batches[1 - i], slots[1 - i])
-        out = model(batches[i], geometry=slots[i])
+        # The next batch's level-1 FPS (a 300-us chain of 32 waves: nearly no load on the chip) starts with the step; the rest
+        # of its geometry (ball queries, compaction, three_nn, inverse lists: ~150 us of short bandwidth kernels) is issued where
+        # the chip has room for it -- PREFETCH_SPLIT: "" = everything at once (rounds 3-5), "after_sa" = between the SA and the
+        # FP levels of the forward pass (the FP phases are one dependent chain on a mostly idle chip), "after_fwd" = after it
+        if split:
+            finish = model.prefetch_geometry(batches[1 - i], slots[1 - i], split=True)
+            if split == "after_sa":
+                slots[i].after_sa = finish
+            out = model(batches[i], geometry=slots[i])
+            if split != "after_sa":
+                finish()
+        else:
+            model.prefetch_geometry(batches[1 - i], slots[1 - i])
+            out = model(batches[i], geometry=slots[i])
         loss, grad = mse_value_and_grad(out)      # mean of squares and its gradient 2 out / n from one launch
         out.backward(grad)
         model.join_geometry()

@@ -70,6 +70,11 @@ ISTNET_PN2_API int istnet_pw_forward_acc_interp(int b, int cin, int cout, int p,
  * p % 128 == 0, m_rows >= 32, at most 1024 tiles; key 17 disables): istnet_pw_dgrad_sk = 1 when that kernel runs,
  * istnet_pw_dgrad_tiles = statistics partials per input channel the launch writes (dense: 1 = dense gradient source). */
 ISTNET_PN2_API int istnet_pw_dgrad_sk(int b, int m_rows, int cout, int p);
+/* Row blocks of 32 per workgroup (1 or 2) of a split-K FORWARD launch with `rows` output rows over b * p points: 2 =
+ * 64 x 128 tiles, taken when the launch still has >= 256 workgroups (istnet_pw_set_tuning key 24; 0 = never).  Same sums in
+ * the same order as the 32 x 128 form: bit-identical results.  (The template argument of pw_fwd_sk_kernel<TM> in a trace;
+ * the dgrad kernel stays at 32 x 128: pw_dgrad_sk_kernel<1>.) */
+ISTNET_PN2_API int istnet_pw_sk_tm(int b, int rows, int p);
 ISTNET_PN2_API int istnet_pw_dgrad_tiles(int b, int m_rows, int cout, int p, int dense);
 /* 1 when istnet_pw_dgrad runs the loader / MFMA-wave kernel (pw_bwd_mid_kernel<8, 4, POOLED, false>: cout = 256, all 128
  * input channels (ci_off = 0, cin_total = m_rows), p % 128 == 0, statistics requested; key 19 disables) */

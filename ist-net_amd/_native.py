@@ -90,6 +90,7 @@ SIGNATURES = {
     "istnet_pw_forward_ld_tiles": [_i, _i, _i, _i],
     "istnet_pw_forward_acc_interp": [_i, _i, _i, _i, _p, _p, _i, _p, _i, _p, _p, _p, _p, _p, _p],
     "istnet_pw_dgrad_sk": [_i, _i, _i, _i],
+    "istnet_pw_sk_tm": [_i, _i, _i],
     "istnet_pw_dgrad_tiles": [_i, _i, _i, _i, _i],
     "istnet_pw_dgrad_rs": [_i, _i, _i, _i, _i],
     "istnet_pw_forward": [_i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p],
@@ -225,7 +226,8 @@ def timed(name, flops, nbytes, launch):
     import torch
     if TIMING_IN_GRAPH:
         i = len(TIMING)
-        if TIMING_BUF is None or 2 * i + 1 >= TIMING_BUF.numel() or (TIMING_ONLY is not None and name != TIMING_ONLY):
+        skip = TIMING_ONLY is not None and not (TIMING_ONLY(name) if callable(TIMING_ONLY) else name == TIMING_ONLY)
+        if TIMING_BUF is None or 2 * i + 1 >= TIMING_BUF.numel() or skip:
             return launch()
         st = torch.cuda.current_stream(TIMING_BUF.device).cuda_stream
         check(lib().istnet_debug_marker(TIMING_BUF.data_ptr() + 16 * i, st), "debug_marker")

@@ -612,6 +612,7 @@ __global__ __launch_bounds__(kThreads, 2) void pw_fwd2_kernel(
 // (c_init: the interpolated term of a feature-propagation layer 0); weights may be a column slice of a wider matrix (ldw).
 // grid: (B * P / 128, ceil(cout / 32)); cin % 8 == 0, cin <= 2048, P % 128 == 0.
 // ============================================================================================
+template <int TM>   // row blocks of 32 output channels per workgroup (1: 32 x 128 tile, 2: 64 x 128)
 __global__ __launch_bounds__(kThreads, 2) void pw_fwd_sk_kernel(
     int cin, int cout, int P, int tiles_per_cloud, const float* __restrict__ x, const float* __restrict__ w, int ldw,
     const float* __restrict__ in_scale, const float* __restrict__ in_shift, const float* __restrict__ c_init,
@@ -628,7 +629,7 @@ __global__ __launch_bounds__(kThreads, 2) void pw_fwd_sk_kernel(
   const long long qpt = (long long)blockIdx.x * 128 + 4 * l31;
   const int b = (int)(qpt / P);
   const int pl = (int)(qpt - (long long)b * P);              // this lane's first point inside its cloud
-  const int m0 = blockIdx.y * 32;
+  const int m0 = blockIdx.y * 32 * TM;
   const bool has_bn = in_scale != nullptr;
   const bool w_vec = (ldw & 3) == 0 && ((uintptr_t)w & 15) == 0;
   PHASE_INIT(zk != nullptr ? 1 : 0)
@@ -637,19 +638,26 @@ __global__ __launch_bounds__(kThreads, 2) void pw_fwd_sk_kernel(
   // of the first operand load
   PHASE_T(0)                    // BatchNorm constants staged
   const float* xb = x + (size_t)b * cin * P + pl;
-  const float* wrow = w + (size_t)min(m0 + l31, cout - 1) * ldw + 4 * half;
+  const float* wrow[TM];
+#pragma unroll
+  for (int tm = 0; tm < TM; ++tm) wrow[tm] = w + (size_t)min(m0 + 32 * tm + l31, cout - 1) * ldw + 4 * half;
 
-  f32x16 acc[4];
+  f32x16 acc[TM][4];
 #pragma unroll
-  for (int q = 0; q < 4; ++q)
+  for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[q][r] = 0.f;
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[tm][q][r] = 0.f;
 
   const int ngroups = cin / 8;
-  float4 a4[2], b4[2][4], c4[2][2];
-  auto load_group = [&](float4& a, float4 (&bq)[4], float4 (&cq)[2], int j) {
-    const float* wp = wrow + 8 * j;
-    a = w_vec ? *reinterpret_cast<const float4*>(wp) : make_float4(wp[0], wp[1], wp[2], wp[3]);
+  float4 a4[2][TM], b4[2][4], c4[2][2];
+  auto load_group = [&](float4 (&a)[TM], float4 (&bq)[4], float4 (&cq)[2], int j) {
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm) {
+      const float* wp = wrow[tm] + 8 * j;
+      a[tm] = w_vec ? *reinterpret_cast<const float4*>(wp) : make_float4(wp[0], wp[1], wp[2], wp[3]);
+    }
 #pragma unroll
     for (int t = 0; t < 4; ++t) bq[t] = *reinterpret_cast<const float4*>(xb + (size_t)(8 * j + 4 * half + t) * P);
     if (has_bn) {
@@ -657,7 +665,7 @@ __global__ __launch_bounds__(kThreads, 2) void pw_fwd_sk_kernel(
       cq[1] = *reinterpret_cast<const float4*>(in_shift + 8 * j + 4 * half);
     }
   };
-  auto mma_group = [&](const float4& a, float4 (&bq)[4], const float4 (&cq)[2], int j) {
+  auto mma_group = [&](const float4 (&a)[TM], float4 (&bq)[4], const float4 (&cq)[2], int j) {
     (void)j;
     if (has_bn) {
       const float4 sc = cq[0];
@@ -668,13 +676,15 @@ __global__ __launch_bounds__(kThreads, 2) void pw_fwd_sk_kernel(
       bq[3] = bn_relu4(bq[3], sc.w, sh.w);
     }
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      const float av = t == 0 ? a.x : (t == 1 ? a.y : (t == 2 ? a.z : a.w));
-      acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bq[t].x, acc[0], 0, 0, 0);
-      acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bq[t].y, acc[1], 0, 0, 0);
-      acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bq[t].z, acc[2], 0, 0, 0);
-      acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bq[t].w, acc[3], 0, 0, 0);
-    }
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int tm = 0; tm < TM; ++tm) {
+        const float av = t == 0 ? a[tm].x : (t == 1 ? a[tm].y : (t == 2 ? a[tm].z : a[tm].w));
+        acc[tm][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bq[t].x, acc[tm][0], 0, 0, 0);
+        acc[tm][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bq[t].y, acc[tm][1], 0, 0, 0);
+        acc[tm][2] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bq[t].z, acc[tm][2], 0, 0, 0);
+        acc[tm][3] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bq[t].w, acc[tm][3], 0, 0, 0);
+      }
   };
   // this wave's groups: wv, wv + 4, ...; two register sets, the next group's loads in flight during the MFMAs
   int j = wv;
@@ -698,17 +708,11 @@ __global__ __launch_bounds__(kThreads, 2) void pw_fwd_sk_kernel(
     if (j + 4 < ngroups) mma_group(a4[1], b4[1], c4[1], j + 4);
   }
 #ifdef ISTNET_PHASE_TIMING
-  asm volatile("s_nop 0" ::"v"(acc[0][0]), "v"(acc[1][0]), "v"(acc[2][0]), "v"(acc[3][0]));   // MFMA results landed
+  asm volatile("s_nop 0" ::"v"(acc[0][0][0]), "v"(acc[0][1][0]), "v"(acc[0][2][0]), "v"(acc[0][3][0]));   // MFMA results landed
   PHASE_T(2)                    // K loop of wave 0
 #endif
   // ---- the four partial sums meet in LDS; wave w finishes registers 4w .. 4w + 3, i.e. rows 8w .. 8w + 7 ----
   PHASE_T(3)                    // (nothing to wait for: LDS is untouched until the partial sums are written)
-#pragma unroll
-  for (int q = 0; q < 4; ++q)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) lds[((wv * 4 + q) * 16 + r) * 64 + lane] = acc[q][r];
-  __syncthreads();
-  PHASE_T(4)                    // partial sums exchanged through LDS
   float* yb = y + (size_t)b * cout * P + pl;
   const float* cb = c_init != nullptr ? c_init + (size_t)b * cout * P + pl : nullptr;
   // feature propagation, layer 0: the accumulators start from three_interpolate(zk) (reference
@@ -727,37 +731,48 @@ __global__ __launch_bounds__(kThreads, 2) void pw_fwd_sk_kernel(
       nw[4 * u + 0] = wv4.x; nw[4 * u + 1] = wv4.y; nw[4 * u + 2] = wv4.z; nw[4 * u + 3] = wv4.w;
     }
   }
+  // one row block at a time through the 64 KB exchange buffer (TM = 2: two rounds)
 #pragma unroll
-  for (int rr = 0; rr < 4; ++rr) {
-    const int r = 4 * wv + rr;
-    const int row = m0 + mfma_row(r, lane);
-    float v[4];
+  for (int tm = 0; tm < TM; ++tm) {
+    if (tm > 0) __syncthreads();      // every wave has read the previous block's partial sums
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const float* pr = lds + (q * 16 + r) * 64 + lane;
-      v[q] = (pr[0] + pr[4 * 16 * 64]) + (pr[2 * 4 * 16 * 64] + pr[3 * 4 * 16 * 64]);
-    }
-    float4 o = make_float4(v[0], v[1], v[2], v[3]);
-    const bool ok = row < cout;
-    if (cb != nullptr && ok) {
-      const float4 c0 = *reinterpret_cast<const float4*>(cb + (size_t)row * P);
-      o.x += c0.x; o.y += c0.y; o.z += c0.z; o.w += c0.w;
-    }
-    if (zk != nullptr && ok) {
-      const float* zr = zk + ((size_t)b * cout + row) * m_known;
-      o.x += (zr[nb[0]] * nw[0] + zr[nb[1]] * nw[1]) + zr[nb[2]] * nw[2];
-      o.y += (zr[nb[3]] * nw[3] + zr[nb[4]] * nw[4]) + zr[nb[5]] * nw[5];
-      o.z += (zr[nb[6]] * nw[6] + zr[nb[7]] * nw[7]) + zr[nb[8]] * nw[8];
-      o.w += (zr[nb[9]] * nw[9] + zr[nb[10]] * nw[10]) + zr[nb[11]] * nw[11];
-    }
-    if (ok) *reinterpret_cast<float4*>(yb + (size_t)row * P) = o;
-    if (part_sum != nullptr) {
-      float s1 = (o.x + o.y) + (o.z + o.w);
-      float s2 = (o.x * o.x + o.y * o.y) + (o.z * o.z + o.w * o.w);
-      half_wave_sum2(s1, s2);
-      if (l31 == 31 && ok) {
-        part_sum[(size_t)row * nt_total + blockIdx.x] = s1;
-        part_sq[(size_t)row * nt_total + blockIdx.x] = s2;
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) lds[((wv * 4 + q) * 16 + r) * 64 + lane] = acc[tm][q][r];
+    __syncthreads();
+    PHASE_T(4)                    // partial sums exchanged through LDS
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+      const int r = 4 * wv + rr;
+      const int row = m0 + 32 * tm + mfma_row(r, lane);
+      float v[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float* pr = lds + (q * 16 + r) * 64 + lane;
+        v[q] = (pr[0] + pr[4 * 16 * 64]) + (pr[2 * 4 * 16 * 64] + pr[3 * 4 * 16 * 64]);
+      }
+      float4 o = make_float4(v[0], v[1], v[2], v[3]);
+      const bool ok = row < cout;
+      if (cb != nullptr && ok) {
+        const float4 c0 = *reinterpret_cast<const float4*>(cb + (size_t)row * P);
+        o.x += c0.x; o.y += c0.y; o.z += c0.z; o.w += c0.w;
+      }
+      if (zk != nullptr && ok) {
+        const float* zr = zk + ((size_t)b * cout + row) * m_known;
+        o.x += (zr[nb[0]] * nw[0] + zr[nb[1]] * nw[1]) + zr[nb[2]] * nw[2];
+        o.y += (zr[nb[3]] * nw[3] + zr[nb[4]] * nw[4]) + zr[nb[5]] * nw[5];
+        o.z += (zr[nb[6]] * nw[6] + zr[nb[7]] * nw[7]) + zr[nb[8]] * nw[8];
+        o.w += (zr[nb[9]] * nw[9] + zr[nb[10]] * nw[10]) + zr[nb[11]] * nw[11];
+      }
+      if (ok) *reinterpret_cast<float4*>(yb + (size_t)row * P) = o;
+      if (part_sum != nullptr) {
+        float s1 = (o.x + o.y) + (o.z + o.w);
+        float s2 = (o.x * o.x + o.y * o.y) + (o.z * o.z + o.w * o.w);
+        half_wave_sum2(s1, s2);
+        if (l31 == 31 && ok) {
+          part_sum[(size_t)row * nt_total + blockIdx.x] = s1;
+          part_sq[(size_t)row * nt_total + blockIdx.x] = s2;
+        }
       }
     }
   }
@@ -2249,7 +2264,10 @@ __global__ __launch_bounds__(kThreads) void pw_dgrad_kernel(
 // the partial sums of g = dA [relu active] and g y_in over the tile (y_in read as float4 in the same layout).
 // grid: (B * P / 128, ceil(m_rows / 32)); cout % 8 == 0, cout <= 2048, P % 128 == 0.
 // ============================================================================================
-__global__ __launch_bounds__(kThreads, 2) void pw_dgrad_sk_kernel(
+// (TM = 2 holds 128 accumulator registers + two operand sets of 40: over the 256 a two-waves-per-SIMD bound allows -- 392 bytes of
+//  scratch per lane when forced --, so that instance is built for one wave per SIMD: its launches have one workgroup per CU)
+template <int TM>   // row blocks of 32 input channels per workgroup (1: 32 x 128 tile, 2: 64 x 128: dY is formed once for both)
+__global__ __launch_bounds__(kThreads, TM == 1 ? 2 : 1) void pw_dgrad_sk_kernel(
     int cin_total, int ci_off, int m_rows, int cout, int P, int tiles_per_cloud, const float* __restrict__ w,
     const float* __restrict__ y, const float* __restrict__ dA, const float* __restrict__ bn,
     const float* __restrict__ bwdc, float* __restrict__ dx, const float* __restrict__ y_in,
@@ -2261,7 +2279,7 @@ __global__ __launch_bounds__(kThreads, 2) void pw_dgrad_sk_kernel(
   const long long qpt = (long long)blockIdx.x * 128 + 4 * l31;
   const int b = (int)(qpt / P);
   const int pl = (int)(qpt - (long long)b * P);
-  const int m0 = blockIdx.y * 32;
+  const int m0 = blockIdx.y * 32 * TM;
   // [5][cout]: scale, shift of this layer's BatchNorm; ca, cb, cc of dY = ca * g + cb + cc * y
   for (int c = tid; c < cout; c += kThreads) {
     lds[c] = bn[c]; lds[2048 + c] = bn[cout + c];
@@ -2270,27 +2288,32 @@ __global__ __launch_bounds__(kThreads, 2) void pw_dgrad_sk_kernel(
   __syncthreads();
   const float* yb = y + (size_t)b * cout * P + pl;
   const float* gb = dA + (size_t)b * cout * P + pl;
-  const float* wcol = w + ci_off + min(m0 + l31, m_rows - 1);      // + k * cin_total: w[k][ci]
+  const float* wcol[TM];                     // + k * cin_total: w[k][ci]
+#pragma unroll
+  for (int tm = 0; tm < TM; ++tm) wcol[tm] = w + ci_off + min(m0 + 32 * tm + l31, m_rows - 1);
 
-  f32x16 acc[4];
+  f32x16 acc[TM][4];
 #pragma unroll
-  for (int q = 0; q < 4; ++q)
+  for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[q][r] = 0.f;
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[tm][q][r] = 0.f;
 
   const int ngroups = cout / 8;
-  float a4[2][4];
+  float a4[2][TM][4];
   float4 y4[2][4], g4[2][4];
-  auto load_group = [&](float (&a)[4], float4 (&yq)[4], float4 (&gq)[4], int j) {
+  auto load_group = [&](float (&a)[TM][4], float4 (&yq)[4], float4 (&gq)[4], int j) {
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
       const int k = 8 * j + 4 * half + t;
-      a[t] = wcol[(size_t)k * cin_total];
+#pragma unroll
+      for (int tm = 0; tm < TM; ++tm) a[tm][t] = wcol[tm][(size_t)k * cin_total];
       yq[t] = *reinterpret_cast<const float4*>(yb + (size_t)k * P);
       gq[t] = *reinterpret_cast<const float4*>(gb + (size_t)k * P);
     }
   };
-  auto mma_group = [&](const float (&a)[4], const float4 (&yq)[4], const float4 (&gq)[4], int j) {
+  auto mma_group = [&](const float (&a)[TM][4], const float4 (&yq)[4], const float4 (&gq)[4], int j) {
     const int k0 = 8 * j + 4 * half;
     const float4 rs = *reinterpret_cast<const float4*>(&lds[k0]), rh = *reinterpret_cast<const float4*>(&lds[2048 + k0]);
     const float4 ca = *reinterpret_cast<const float4*>(&lds[4096 + k0]), cb = *reinterpret_cast<const float4*>(&lds[6144 + k0]);
@@ -2308,10 +2331,13 @@ __global__ __launch_bounds__(kThreads, 2) void pw_dgrad_sk_kernel(
       d.y = fa * ((yv.y * s + h > 0.f) ? gv.y : 0.f) + fb + fc * yv.y;
       d.z = fa * ((yv.z * s + h > 0.f) ? gv.z : 0.f) + fb + fc * yv.z;
       d.w = fa * ((yv.w * s + h > 0.f) ? gv.w : 0.f) + fb + fc * yv.w;
-      acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t], d.x, acc[0], 0, 0, 0);
-      acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t], d.y, acc[1], 0, 0, 0);
-      acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t], d.z, acc[2], 0, 0, 0);
-      acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t], d.w, acc[3], 0, 0, 0);
+#pragma unroll
+      for (int tm = 0; tm < TM; ++tm) {
+        acc[tm][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tm][t], d.x, acc[tm][0], 0, 0, 0);
+        acc[tm][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tm][t], d.y, acc[tm][1], 0, 0, 0);
+        acc[tm][2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tm][t], d.z, acc[tm][2], 0, 0, 0);
+        acc[tm][3] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tm][t], d.w, acc[tm][3], 0, 0, 0);
+      }
     }
   };
   int j = wv;
@@ -2334,42 +2360,45 @@ __global__ __launch_bounds__(kThreads, 2) void pw_dgrad_sk_kernel(
     mma_group(a4[0], y4[0], g4[0], j);
     if (j + 4 < ngroups) mma_group(a4[1], y4[1], g4[1], j + 4);
   }
-  __syncthreads();              // every wave is done with the constants
-#pragma unroll
-  for (int q = 0; q < 4; ++q)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) lds[((wv * 4 + q) * 16 + r) * 64 + lane] = acc[q][r];
-  __syncthreads();
   float* dxb = dx + (size_t)b * m_rows * P + pl;
   const bool stats = part_g != nullptr;
   const float* xin = stats ? y_in + (size_t)b * m_rows * P + pl : nullptr;
 #pragma unroll
-  for (int rr = 0; rr < 4; ++rr) {
-    const int r = 4 * wv + rr;
-    const int row = m0 + mfma_row(r, lane);
-    const bool ok = row < m_rows;
-    float v[4];
+  for (int tm = 0; tm < TM; ++tm) {
+    __syncthreads();            // every wave is done with the constants (tm = 0) / has read the previous block's partial sums
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const float* pr = lds + (q * 16 + r) * 64 + lane;
-      v[q] = (pr[0] + pr[4 * 16 * 64]) + (pr[2 * 4 * 16 * 64] + pr[3 * 4 * 16 * 64]);
-    }
-    const float4 o = make_float4(v[0], v[1], v[2], v[3]);
-    if (ok) *reinterpret_cast<float4*>(dxb + (size_t)row * P) = o;
-    if (stats) {
-      float sg = 0.f, sgy = 0.f;
-      if (ok) {
-        const float4 yi = *reinterpret_cast<const float4*>(xin + (size_t)row * P);
-        const float is = bn_in[row], ih = bn_in[m_rows + row];
-        const float g0 = (yi.x * is + ih > 0.f) ? o.x : 0.f, g1 = (yi.y * is + ih > 0.f) ? o.y : 0.f;
-        const float g2 = (yi.z * is + ih > 0.f) ? o.z : 0.f, g3 = (yi.w * is + ih > 0.f) ? o.w : 0.f;
-        sg = (g0 + g1) + (g2 + g3);
-        sgy = (g0 * yi.x + g1 * yi.y) + (g2 * yi.z + g3 * yi.w);
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) lds[((wv * 4 + q) * 16 + r) * 64 + lane] = acc[tm][q][r];
+    __syncthreads();
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+      const int r = 4 * wv + rr;
+      const int row = m0 + 32 * tm + mfma_row(r, lane);
+      const bool ok = row < m_rows;
+      float v[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float* pr = lds + (q * 16 + r) * 64 + lane;
+        v[q] = (pr[0] + pr[4 * 16 * 64]) + (pr[2 * 4 * 16 * 64] + pr[3 * 4 * 16 * 64]);
       }
-      half_wave_sum2(sg, sgy);
-      if (l31 == 31 && ok) {
-        part_g[(size_t)row * nt_total + blockIdx.x] = sg;
-        part_gy[(size_t)row * nt_total + blockIdx.x] = sgy;
+      const float4 o = make_float4(v[0], v[1], v[2], v[3]);
+      if (ok) *reinterpret_cast<float4*>(dxb + (size_t)row * P) = o;
+      if (stats) {
+        float sg = 0.f, sgy = 0.f;
+        if (ok) {
+          const float4 yi = *reinterpret_cast<const float4*>(xin + (size_t)row * P);
+          const float is = bn_in[row], ih = bn_in[m_rows + row];
+          const float g0 = (yi.x * is + ih > 0.f) ? o.x : 0.f, g1 = (yi.y * is + ih > 0.f) ? o.y : 0.f;
+          const float g2 = (yi.z * is + ih > 0.f) ? o.z : 0.f, g3 = (yi.w * is + ih > 0.f) ? o.w : 0.f;
+          sg = (g0 + g1) + (g2 + g3);
+          sgy = (g0 * yi.x + g1 * yi.y) + (g2 * yi.z + g3 * yi.w);
+        }
+        half_wave_sum2(sg, sgy);
+        if (l31 == 31 && ok) {
+          part_g[(size_t)row * nt_total + blockIdx.x] = sg;
+          part_gy[(size_t)row * nt_total + blockIdx.x] = sgy;
+        }
       }
     }
   }
@@ -3508,6 +3537,9 @@ int g_dgrad_sk_enable = 1;     // key 17: 0 = no pw_dgrad_sk_kernel
 int g_dgrad_sk_min_k = 256;    // key 18
 int g_fwd_sk_max_tiles = 1024; // key 16: launches with more 32 x 128 tiles than this keep the LDS-tiled kernel (measured:
                                // +15-35 % at <= 1024 tiles -- the FP levels --, -8 % at 2048)
+int g_sk_tm2_min_wgs = 256;     // key 24: the split-K FORWARD kernel takes 64 x 128 tiles (TM = 2: the activation operand is loaded once
+                               // for two row blocks of weights -- 6 instead of 10 operand loads per 32 MFMAs) when the launch still
+                               // has this many workgroups; 0 = always 32 x 128
 int g_fwd2_enable = 1;         // key 13: 0 = pw_fwd_kernel for every forward launch
 int g_fwd2_min_waves = 1024;   // key 14 (step time at 2048 / 1024 / 768 / 512 / 256: 2.912 / 2.870 / 2.879 / 2.933 / 2.997 ms)
 int g_wgrad2_enable = 1;       // key 11: 0 = pw_wgrad_kernel for every dense layer
@@ -3634,6 +3666,7 @@ int istnet_pw_set_tuning(int key, int value) {
     case 21: g_scatter_csr_threads = value; return 0;
     case 22: g_interp_dy_lds = value != 0; return 0;
     case 23: g_wgrad2_nt_max = value >= 128 ? 128 : (value > 0 ? 64 : 0); return 0;
+    case 24: g_sk_tm2_min_wgs = value > 0 ? value : 0; return 0;
     default: return ISTNET_PN2_EINVAL;
   }
 }
@@ -3665,6 +3698,10 @@ static bool fwd_sk_ok(int b, int cin, int cout, int p) {
     return false;
   const long long tiles = (long long)b * p / 128 * ceil_div(cout, 32);
   return tiles <= g_fwd_sk_max_tiles;
+}
+// row blocks per workgroup of a split-K launch over `tiles` 128-point tiles and `rows` output rows
+static int sk_tm(int tiles, int rows) {
+  return (g_sk_tm2_min_wgs > 0 && rows >= 64 && (long long)tiles * ceil_div(rows, 64) >= g_sk_tm2_min_wgs) ? 2 : 1;
 }
 // ---- pw_fwd2_kernel (dense input, B operand straight from global memory) ----
 // 0: pw_fwd_kernel; else TMW * 1000 + WM * 100 + WN * 10 + (KC == 32)
@@ -3724,9 +3761,14 @@ static int launch_pw_forward(int b, int cin, int cout, int p, const float* x,
   if (b <= 0 || cin <= 0 || cout <= 0 || p <= 0 || (p & 3)) return ISTNET_PN2_EINVAL;
   if (msrc_p == nullptr && ncols == nullptr && row_init == nullptr && fwd_sk_ok(b, cin, cout, p)) {
     const int tiles = (int)((long long)b * p / 128);          // of the flattened (cloud, point) axis
-    hipLaunchKernelGGL(pw_fwd_sk_kernel, dim3(tiles, ceil_div(cout, 32)), dim3(kThreads), 0, as_stream(stream), cin, cout,
-                       p, 0, x, w, ldw, in_scale, in_shift, c_init, y, part_sum, part_sq, tiles, nullptr, 0, nullptr,
-                       nullptr);
+    if (sk_tm(tiles, cout) == 2)
+      hipLaunchKernelGGL(pw_fwd_sk_kernel<2>, dim3(tiles, ceil_div(cout, 64)), dim3(kThreads), 0, as_stream(stream), cin,
+                         cout, p, 0, x, w, ldw, in_scale, in_shift, c_init, y, part_sum, part_sq, tiles, nullptr, 0, nullptr,
+                         nullptr);
+    else
+      hipLaunchKernelGGL(pw_fwd_sk_kernel<1>, dim3(tiles, ceil_div(cout, 32)), dim3(kThreads), 0, as_stream(stream), cin,
+                         cout, p, 0, x, w, ldw, in_scale, in_shift, c_init, y, part_sum, part_sq, tiles, nullptr, 0, nullptr,
+                         nullptr);
     return (int)hipGetLastError();
   }
   const TileCfg cfg = pick_cfg(b, cout, p, g_force_fwd_cfg);
@@ -3792,8 +3834,12 @@ int istnet_pw_forward_acc_interp(int b, int cin, int cout, int p, const float* x
     return ISTNET_PN2_EINVAL;
   if (!fwd_sk_ok(b, cin, cout, p)) return ISTNET_PN2_EINVAL;
   const int tiles = (int)((long long)b * p / 128);
-  hipLaunchKernelGGL(pw_fwd_sk_kernel, dim3(tiles, ceil_div(cout, 32)), dim3(kThreads), 0, as_stream(stream), cin, cout,
-                     p, 0, x, w, ldw, nullptr, nullptr, nullptr, y, part_sum, part_sq, tiles, zk, m, idx, weight);
+  if (sk_tm(tiles, cout) == 2)
+    hipLaunchKernelGGL(pw_fwd_sk_kernel<2>, dim3(tiles, ceil_div(cout, 64)), dim3(kThreads), 0, as_stream(stream), cin, cout,
+                       p, 0, x, w, ldw, nullptr, nullptr, nullptr, y, part_sum, part_sq, tiles, zk, m, idx, weight);
+  else
+    hipLaunchKernelGGL(pw_fwd_sk_kernel<1>, dim3(tiles, ceil_div(cout, 32)), dim3(kThreads), 0, as_stream(stream), cin, cout,
+                       p, 0, x, w, ldw, nullptr, nullptr, nullptr, y, part_sum, part_sq, tiles, zk, m, idx, weight);
   return (int)hipGetLastError();
 }
 
@@ -4090,6 +4136,9 @@ static bool dgrad_sk_ok(int b, int m_rows, int cout, int p) {
     return false;
   return (long long)b * p / 128 * ceil_div(m_rows, 32) <= g_fwd_sk_max_tiles;
 }
+/* row blocks (1 or 2) per workgroup of a split-K forward launch with `rows` output rows (the template argument of
+ * pw_fwd_sk_kernel as a trace names it) */
+int istnet_pw_sk_tm(int b, int rows, int p) { return sk_tm((int)((long long)b * p / 128), rows); }
 /* 1 when istnet_pw_dgrad with a dense gradient source runs the split-K kernel for this shape */
 int istnet_pw_dgrad_sk(int b, int m_rows, int cout, int p) { return dgrad_sk_ok(b, m_rows, cout, p) ? 1 : 0; }
 int istnet_pw_dgrad_rs(int b, int m_rows, int cout, int p, int dense) {
@@ -4147,7 +4196,11 @@ static int launch_pw_dgrad(int b, int cin_total, int ci_off, int m_rows, int cou
   }
   if (d_dense != nullptr && ncols == nullptr && dgrad_sk_ok(b, m_rows, cout, p)) {
     const int tiles = (int)((long long)b * p / 128);
-    hipLaunchKernelGGL(pw_dgrad_sk_kernel, dim3(tiles, ceil_div(m_rows, 32)), dim3(kThreads), 0, as_stream(stream),
+    // (round 6, measured and not taken: the 64 x 128 form of this kernel.  Its 128 accumulators + two operand sets of 40 registers
+    //  need the one-wave-per-SIMD register budget, and with ONE wave per SIMD the ~11 VALU per element that form dY no longer
+    //  overlap a partner wave's MFMAs: 33.6 -> 71.7 us at 4096 x 512 x 512, 20.1 -> 39.6 at 8192 x 256 x 256,
+    //  profiles/r06_splitk_tiles.txt.  The forward kernel has no such VALU work and takes the larger tile.)
+    hipLaunchKernelGGL(pw_dgrad_sk_kernel<1>, dim3(tiles, ceil_div(m_rows, 32)), dim3(kThreads), 0, as_stream(stream),
                        cin_total, ci_off, m_rows, cout, p, 0, w, y, d_dense, bn, bwdc, dx, y_in, bn_in, part_g, part_gy,
                        tiles);
     return (int)hipGetLastError();

@@ -55,6 +55,8 @@ class GeometrySlot:
         self.flat = None     # dtype -> flat storage the tensors above are views of
         self.plan = None     # _ext.OutputPlan: which output allocation of a prefetch pass is which view (prefetch_geometry)
         self.packed = True   # the views lie back to back in ``flat`` (no alignment padding between them)
+        self.after_sa = None  # callable run ONCE by forward(geometry=self) between the set-abstraction and the feature-
+                              # propagation levels (bench.py: the second part of the next batch's split prefetch)
         self.grad_mode = None
 
     def tensors(self):
@@ -107,22 +109,41 @@ class PointNet2MSG(nn.Module):
         Returns (per-level [new_xyz, [ball idx], event, inverse lists or None], per-FP-level (idx, weight, csr, event),
         event after the inverse lists).  The inverse lists of the ball indices (``with_ball_csr``) are only read by the
         backward pass, so they are built last and the forward never waits for them."""
+        gen = self._geometry_prepass_steps(xyz, with_ball_csr)
+        try:
+            while True:
+                next(gen)
+        except StopIteration as done:
+            return done.value
+
+    def _geometry_prepass_steps(self, xyz, with_ball_csr=False):
+        """``_geometry_prepass`` as a generator that yields ONCE, after the level-1 furthest-point sampling has been issued:
+        that launch is a 511-round chain on 32 waves -- long, and next to no load on the chip -- while everything after it is
+        ~150 us of short bandwidth kernels.  ``prefetch_geometry(..., split=True)`` issues the two parts at different points of
+        the step.  No ``with`` block is open across the yield (the caller's current stream and grad mode are its own)."""
         dev = xyz.device
         main, side = torch.cuda.current_stream(dev), _geometry_stream(dev)
         side.wait_stream(main)            # xyz is produced on main; also orders reuse of last step's buffers
         sa_geo, fp_geo = [], [None] * len(self.FP_modules)
+        chain = getattr(pointnet2_utils._ext, "furthest_point_sampling_chain", None)     # absent from a plain reference _ext
+
+        def sample(li, sa, cur, tie):
+            if chain is not None and cur.shape[1] <= 4096:
+                nxt = self.SA_modules[li + 1].npoint if li + 1 < len(self.SA_modules) else 0
+                # above FPS_CHAIN_MAX_TRACKED_N points a level scans without the tie bookkeeping (and its child scans too)
+                rounds = min(nxt or 0, sa.npoint) if cur.shape[1] <= FPS_CHAIN_MAX_TRACKED_N else 0
+                _, new_xyz, tie = chain(cur, sa.npoint, tie_in=tie, track_rounds=rounds)
+                return new_xyz, tie
+            return sa._sample_centroids(cur), None
+
+        with torch.cuda.stream(side), torch.no_grad():
+            first = sample(0, self.SA_modules[0], xyz, None)
+        yield
         with torch.cuda.stream(side), torch.no_grad():
             cur, levels = xyz, [xyz]
-            chain = getattr(pointnet2_utils._ext, "furthest_point_sampling_chain", None)     # absent from a plain reference _ext
             tie = None
             for li, sa in enumerate(self.SA_modules):
-                if chain is not None and cur.shape[1] <= 4096:
-                    nxt = self.SA_modules[li + 1].npoint if li + 1 < len(self.SA_modules) else 0
-                    # above FPS_CHAIN_MAX_TRACKED_N points a level scans without the tie bookkeeping (and its child scans too)
-                    rounds = min(nxt or 0, sa.npoint) if cur.shape[1] <= FPS_CHAIN_MAX_TRACKED_N else 0
-                    _, new_xyz, tie = chain(cur, sa.npoint, tie_in=tie, track_rounds=rounds)
-                else:
-                    new_xyz, tie = sa._sample_centroids(cur), None
+                new_xyz, tie = first if li == 0 else sample(li, sa, cur, tie)
                 ext = pointnet2_utils._ext
                 ball_compact = getattr(ext, "ball_compact", None)                    # absent from a plain reference _ext
                 compact = ball_compact is not None and len(sa_geo) in fused_mlp.COMPACT_LEVELS
@@ -200,13 +221,35 @@ class PointNet2MSG(nn.Module):
             fp_geo = [tuple(g) for g in fp_geo]
         return sa_geo, fp_geo, csr_ev
 
-    def prefetch_geometry(self, pointcloud, slot=None):
+    def prefetch_geometry(self, pointcloud, slot=None, split=False):
         """Start the coordinate-only work of ``pointcloud`` NOW on the geometry stream -- concurrently with whatever
         the current stream does next, typically the training step of the previous batch -- and keep the results in
         ``slot`` for ``forward(pointcloud, geometry=slot)``.  This is next-batch preprocessing in the sense of a data
         loader: FPS is a 500-round latency chain per level that nothing inside a step can overlap.
         The slot's buffers are allocated on first use and overwritten afterwards (call this once outside a graph
-        capture before capturing steps that use the slot).  Returns the slot."""
+        capture before capturing steps that use the slot).  Returns the slot.
+
+        ``split=True``: only the level-1 furthest-point sampling is issued now; the call returns ``finish``, and
+        ``finish()`` -- called later in the step, from the stream whose work the rest should follow -- issues everything
+        else (the geometry stream first waits for the calling stream) and returns the slot."""
+        gen = self._prefetch_steps(pointcloud, slot)
+        if not split:
+            try:
+                while True:
+                    next(gen)
+            except StopIteration as done:
+                return done.value
+        next(gen)
+
+        def finish():
+            try:
+                next(gen)
+            except StopIteration as done:
+                return done.value
+            raise RuntimeError("prefetch_geometry: the second part did not complete")
+        return finish
+
+    def _prefetch_steps(self, pointcloud, slot):
         slot = slot if slot is not None else GeometrySlot()
         xyz, _ = self._break_up_pc(pointcloud)
         if not self._can_prepass(xyz):
@@ -223,12 +266,25 @@ class PointNet2MSG(nn.Module):
         recording = plan_cls is not None and plan is None and not torch.cuda.is_current_stream_capturing()
         if recording:
             plan = plan_cls()
+        steps = self._geometry_prepass_steps(xyz, with_ball_csr=grad_mode)
+        # (the plan is active only while this function runs: whatever the caller issues between the two parts allocates plainly)
         if plan is not None:
             with placing(plan):
-                sa_geo, fp_geo, _ = self._geometry_prepass(xyz, with_ball_csr=grad_mode)
+                next(steps)
         else:
-            sa_geo, fp_geo, _ = self._geometry_prepass(xyz, with_ball_csr=grad_mode)
+            next(steps)
+        yield
         side = _geometry_stream(xyz.device)
+        side.wait_stream(torch.cuda.current_stream(xyz.device))      # split mode: the rest follows the caller's work so far
+        try:
+            if plan is not None:
+                with placing(plan, resume=True):
+                    next(steps)
+            else:
+                next(steps)
+            raise RuntimeError("_geometry_prepass_steps yielded twice")
+        except StopIteration as done:
+            sa_geo, fp_geo, _ = done.value
         with torch.cuda.stream(side), torch.no_grad():
             fresh = GeometrySlot()
             fresh.sa = [(new_xyz, list(idx), csrs, comps) for new_xyz, idx, _, csrs, comps in sa_geo]
@@ -269,9 +325,15 @@ class PointNet2MSG(nn.Module):
                     by_dt.setdefault(t.dtype, []).append((t, v))
                 for dt, pairs in by_dt.items():
                     whole = len(pairs) == sum(1 for t in src if t.dtype == dt)
-                    if (whole and slot.packed and slot.flat[dt].element_size() == 4
-                            and all(t.is_contiguous() for t, _ in pairs)):
-                        _native.pack_words([t for t, _ in pairs], slot.flat[dt], side.cuda_stream)   # one launch per <= 64 tensors
+                    if (whole and slot.flat[dt].element_size() == 4 and all(t.is_contiguous() for t, _ in pairs)):
+                        srcs = [t for t, _ in pairs]
+                        if not slot.packed:
+                            # the views are 16-byte aligned: a few words of padding follow the odd-sized tensors -- filled
+                            # from a zero tensor so that the whole flat buffer is still one pack launch
+                            pad = torch.zeros(4, dtype=dt, device=xyz.device)
+                            srcs = [piece for t in srcs
+                                    for piece in ((t,) if t.numel() % 4 == 0 else (t, pad[:4 - t.numel() % 4]))]
+                        _native.pack_words(srcs, slot.flat[dt], side.cuda_stream)   # one launch per <= 64 tensors
                     else:
                         for t, v in pairs:
                             v.copy_(t)
@@ -338,6 +400,9 @@ class PointNet2MSG(nn.Module):
             l_xyz.append(nxt_xyz)
             l_features.append(nxt_feat)
             _native.mark(f"fwd SA{i + 1} done")
+        if geometry is not None and geometry.after_sa is not None:
+            hook, geometry.after_sa = geometry.after_sa, None
+            hook()
         for lvl in range(len(self.FP_modules) - 1, -1, -1):  # coarse -> fine  [ref :322-325]
             interp = None
             if fp_geo is not None:

@@ -53,13 +53,13 @@ _PLAN = None
 
 
 class placing:
-    def __init__(self, plan):
-        self.plan = plan
+    def __init__(self, plan, resume=False):
+        self.plan, self.resume = plan, resume      # resume: continue the sequence where an earlier block left it
 
     def __enter__(self):
         global _PLAN
         self.prev, _PLAN = _PLAN, self.plan
-        if self.plan is not None:
+        if self.plan is not None and not self.resume:
             self.plan.k = 0
         return self.plan
 

@@ -67,7 +67,7 @@ class FusedFPFunction(Function):
                     nt = lib.istnet_pw_forward_ld_tiles(b, c1, cout0, n)
                     part = _empty((2, cout0, nt), torch.float32, dev)
                 _native.check(_native.timed(
-                    "pw_fwd_sk_kernel", 2.0 * b * n * c1 * cout0, 4.0 * b * n * (c1 + cout0),
+                    _fwd_ld_kname(lib, b, c1, cout0, n), 2.0 * b * n * c1 * cout0, 4.0 * b * n * (c1 + cout0),
                     lambda: lib.istnet_pw_forward_acc_interp(
                         b, c1, cout0, n, skip_c.data_ptr(), w2.data_ptr() + 4 * c2, cin, zk.data_ptr(), m, idx.data_ptr(),
                         weight.data_ptr(), y0.data_ptr(), _p(part[0]) if training else None,

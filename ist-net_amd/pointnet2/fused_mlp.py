@@ -72,7 +72,7 @@ def _fwd_kname(lib, b, cin, cout, p, plain=True):
         return ""
     cfg2 = lib.istnet_pw_forward_cfg(b, cin, cout, p) if plain else 0
     if cfg2 == 1:
-        return "pw_fwd_sk_kernel"
+        return "pw_fwd_sk_kernel<%d>" % lib.istnet_pw_sk_tm(b, cout, p)
     if cfg2:
         return f"pw_fwd2_kernel<{cfg2 // 1000}, {cfg2 // 100 % 10}, {cfg2 // 10 % 10}, {32 if cfg2 % 10 else 16}, 0>"
     return _kname("pw_fwd_kernel", lib.istnet_pw_tile_cfg(b, cout, p))
@@ -89,7 +89,7 @@ def _fwd_ld_kname(lib, b, cin, cout, p):
     if _native.TIMING is None:
         return ""
     if lib.istnet_pw_forward_cfg(b, cin, cout, p) == 1:
-        return "pw_fwd_sk_kernel"
+        return "pw_fwd_sk_kernel<%d>" % lib.istnet_pw_sk_tm(b, cout, p)
     return _kname("pw_fwd_kernel", lib.istnet_pw_tile_cfg(b, cout, p))
 
 
@@ -99,7 +99,7 @@ def _dgrad_kname(lib, b, rows, cout, p, dense=False, stats=False):
     if _native.TIMING is None:
         return ""
     if dense and lib.istnet_pw_dgrad_sk(b, rows, cout, p):
-        return "pw_dgrad_sk_kernel"          # small launch, dense gradient source: K split over the waves, no LDS operands
+        return "pw_dgrad_sk_kernel<1>"       # small launch, dense gradient source: K split over the waves, no LDS operands
     if stats and lib.istnet_pw_dgrad_rs(b, rows, cout, p, 1 if dense else 0):
         return "pw_bwd_mid_kernel<8, 4, %s, false>" % ("false" if dense else "true")   # dgrad-only mode
     cfg = lib.istnet_pw_dgrad_tile_cfg(b, rows, p)

@@ -65,7 +65,7 @@ def pmc_sq(kernel_name, path):
     return rec, os.path.basename(path)
 
 
-def measure_replayed(capture, replays=5, only=None):
+def measure_replayed(capture, replays=5, only=None, errors=None):
     """Times every GEMM launch INSIDE replays of the captured step: ``capture()`` must capture the step into HIP graphs
     while _native.TIMING is active and return a function that replays them once.  Each launch is bracketed by two
     marker kernels on its launch stream that store the device wall clock (_native.timed), so the durations are those of
@@ -77,7 +77,10 @@ def measure_replayed(capture, replays=5, only=None):
     try:
         replay = capture()
         records = list(_native.TIMING)
-    except Exception:
+    except Exception as exc:
+        if errors is not None:
+            errors.append(f"{type(exc).__name__}: {exc}")
+        torch.cuda.synchronize()
         return None
     finally:
         _native.TIMING, _native.TIMING_IN_GRAPH, _native.TIMING_BUF, _native.TIMING_ONLY = None, False, None, None
@@ -155,8 +158,11 @@ def measure(step, steps=5, traffic_file=None, capture=None, steps_per_replay=1, 
     replayed = measure_replayed(capture, steps, only=name) if capture is not None else None
     # the dominant FAMILY on the same clock as the dominant kernel: its launches bracketed inside replays of the step
     fam_base = obj["dominant_family"]["kernel"].split("<")[0]
-    fam_replayed = (measure_replayed(capture, steps, only=lambda n: n.split("<")[0] == fam_base)
+    fam_errors = []
+    fam_replayed = (measure_replayed(capture, steps, only=lambda n: n.split("<")[0] == fam_base, errors=fam_errors)
                     if capture is not None else None)
+    if fam_errors:
+        obj["dominant_family"]["replay_timing_error"] = fam_errors[0][:300]
     if fam_replayed:
         fam_replayed.pop("__bracket_overhead_us__", None)
         fms = sum(v[0] for v in fam_replayed.values())

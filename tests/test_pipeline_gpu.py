@@ -35,6 +35,54 @@ def test_prefetched_geometry_equals_in_step_geometry():
         enc(_shell(2, 512, 3), geometry=slots[0])
 
 
+def test_split_prefetch_fills_the_same_slot():
+    """prefetch_geometry(..., split=True): level-1 FPS now, the rest when ``finish()`` is called (bench.py issues it between the
+    SA and the FP levels of the running step).  Same ops in the same order on the geometry stream: every tensor of the slot is
+    bit-equal to a one-call prefetch, on the recording pass and on in-place refills, and a step through it equals the plain one."""
+    torch.manual_seed(0)
+    enc = PointNet2MSG([list(r) for r in CAM]).to(DEV).train()
+    a, b = _shell(2, 1024, 21), _shell(2, 1024, 22)
+
+    def same(s1, s2):
+        for x, y in zip(s1.sa, s2.sa):
+            assert torch.equal(x[0], y[0]) and all(torch.equal(p, q) for p, q in zip(x[1], y[1]))
+        for x, y in zip(s1.fp, s2.fp):
+            assert torch.equal(x[0], y[0]) and torch.equal(x[1], y[1])
+
+    split = GeometrySlot()
+    for pts in (a, b, a):                                   # recording pass, then two in-place refills
+        finish = enc.prefetch_geometry(pts, split, split=True)
+        junk = torch.randn(1 << 16, device=DEV).sum()       # the caller's own work between the two parts
+        assert finish() is split
+        enc.join_geometry()
+        whole = enc.prefetch_geometry(pts, GeometrySlot())
+        enc.join_geometry()
+        torch.cuda.synchronize()
+        same(split, whole)
+        del junk
+    for m in enc.modules():
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.momentum = 0.0
+    outs = []
+    for slot in (split, whole):
+        enc.zero_grad(set_to_none=True)
+        out = enc(a, geometry=slot)
+        out.square().mean().backward()
+        outs.append((out.detach().clone(), [p.grad.clone() for p in enc.parameters()]))
+    assert torch.equal(outs[0][0], outs[1][0]) and all(torch.equal(g, w) for g, w in zip(outs[0][1], outs[1][1]))
+    # the hook form bench.py uses: the second part runs from inside forward(), between the SA and the FP levels
+    finish = enc.prefetch_geometry(b, split, split=True)
+    whole.after_sa = finish
+    enc.zero_grad(set_to_none=True)
+    enc(a, geometry=whole).square().mean().backward()
+    assert whole.after_sa is None
+    enc.join_geometry()
+    ref = enc.prefetch_geometry(b, GeometrySlot())
+    enc.join_geometry()
+    torch.cuda.synchronize()
+    same(split, ref)
+
+
 def test_prefetch_refills_write_the_slot_in_place(monkeypatch):
     """After the recording pass the ops of a prefetch write the slot's persistent buffers directly (_ext.OutputPlan): no
     pack / copy launch, the same buffers, and a step through the refilled slot equals a step through a fresh one bit for bit

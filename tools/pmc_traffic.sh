@@ -33,3 +33,4 @@ json.dump({"kernel_source_sha256": kernel_source_hash(), "source": "rocprofv3 --
            "correction": "FETCH_SIZE x2 on gfx950 for wide coalesced reads (MI355X_MICROARCH.md, HBM); WRITE_SIZE as reported",
            "kernels": out}, open("gpurun_out/pmc_${TAG}_traffic.json", "w"), indent=1)
 PY
+rm -rf gpurun_out/pmc_${TAG}_FETCH_SIZE gpurun_out/pmc_${TAG}_WRITE_SIZE      # keep gpurun_out under the 64 MiB copy-back limit
