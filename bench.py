@@ -1035,6 +1035,9 @@ def main():
             "windows_ms_per_step": [round(w / args.steps * 1e3, 4) for w in windows],
             "window_statistic": "median of %d windows of %d steps" % (len(windows), args.steps),
             "data": "synthetic" if not args.cpu_dry_run else "synthetic (CPU dry run of the launch path: NOT a measurement)",
+            **({"debug_ptrs": [hex(opt.flat_grad.data_ptr()), hex(pts.data_ptr()),
+                               hex(torch.empty(1 << 20, device=dev).data_ptr())]}
+               if os.environ.get("ISTNET_BENCH_DEBUG_PTRS") and args.workload == "encoder" else {}),
             "config": {"workload": ("PointNet2MSG encoder (4 SA-MSG + 4 FP, cam radii) fwd+bwd+Adam, "
                                     "train-mode BN, %s clouds" % args.cloud) if args.workload == "encoder" else
                                    ("IST-Net full model (ResNet-18/PSP RGB branch on MIOpen + point branch, "

@@ -158,7 +158,7 @@ class FusedFPFunction(Function):
             # The skip gradient feeds the set-abstraction backward much later; the interpolation gradient feeds the next
             # (coarser) propagation level at once.  So the skip dgrad leaves the chain: it runs on a side stream beside
             # the interpolation scatter and the known-feature dgrad, joined before this node returns.
-            streams = _scale_streams(dev, 2) if (need_skip and (need_known or need_w[0])) \
+            streams = _scale_streams(dev, 2, site="fpskip") if (need_skip and (need_known or need_w[0])) \
                 else [torch.cuda.current_stream(dev)] * 2
             if need_skip:
                 ds = _empty((b, c1, n), torch.float32, dev)

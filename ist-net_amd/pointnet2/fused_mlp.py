@@ -137,7 +137,7 @@ def _ident_consts(dev, c):
 # .grad would be read on the main stream before the join), no kernel timing in progress.  Everything the
 # deferred launches read is kept alive until the join.  (A per-layer fork onto a side stream was measured
 # slower: 32 extra cross-stream edges per step.)
-FP_BWD_MID_WORKGROUPS = 256   # workgroups of the fused mid-size backward kernel in the FP levels (one chain: the whole chip; the SA phases keep the library's 128)
+FP_BWD_MID_WORKGROUPS = int(os.environ.get("ISTNET_FP_BWD_MID_WGS", "256"))   # workgroups of the fused mid-size backward kernel in the FP levels (one chain: the whole chip; the SA phases keep the library's 128)
 USE_DEFERRED_WGRAD = os.environ.get("ISTNET_DEFERRED_WGRAD", "1") != "0"    # module attribute; the environment variable only sets its import-time
                              # default (A/B runs).  tests/test_pipeline_gpu.py::test_fallback_paths_agree_with_default flips each
                              # switch once; ist_net.point_branch_side_streams sets and restores this one and USE_SCALE_STREAMS
@@ -467,10 +467,17 @@ USE_SCALE_STREAMS = os.environ.get("ISTNET_SCALE_STREAMS", "1") != "0"     # for
 _SCALE_STREAMS = {}
 
 
-def _scale_streams(dev, n):
+# experiment switch (round 6, profiles/r06_stream_sites.txt): comma-separated sites that do NOT fork -- "fwd<npoint>" / "bwd<npoint>"
+# for the scale streams of one SA level (fwd512 ... bwd64), "fpskip" for the skip-branch dgrad of the FP backward.  A fork / join
+# pair is two cross-queue dependencies (10-16 us each in a trace against ~1.5 us inside a queue).
+NO_FORK_SITES = frozenset(v for v in os.environ.get("ISTNET_NO_FORK", "").split(",") if v)
+
+
+def _scale_streams(dev, n, site=None):
     """[current stream, side stream 1, ...] for the n scales of a level (side streams only if enabled)."""
     main = torch.cuda.current_stream(dev)
-    if not USE_SCALE_STREAMS or (_native.TIMING is not None and not _native.TIMING_IN_GRAPH) or n < 2:
+    if (not USE_SCALE_STREAMS or (_native.TIMING is not None and not _native.TIMING_IN_GRAPH) or n < 2
+            or (site is not None and site in NO_FORK_SITES)):
         return [main] * n
     key = dev.index if dev.index is not None else torch.cuda.current_device()
     pool = _SCALE_STREAMS.setdefault(key, [])
@@ -1099,7 +1106,7 @@ class FusedSALevelFunction(Function):
                     else:
                         wcat = _empty((rows, cols), torch.float32, dev)
                         _native.pack_words(w0s, wcat, _st(dev))
-            streams = _scale_streams(dev, len(scales))
+            streams = _scale_streams(dev, len(scales), site=f"fwd{g}")
             compacts = list(compacts) if compacts is not None else [None] * nsc
             used = []
             for layers, params, idx, stream, cm in zip(scales, plist, idxs, streams, compacts):
@@ -1165,7 +1172,7 @@ class FusedSALevelFunction(Function):
         base = 7 + nsc   # index of the first parameter among forward()'s arguments
         with torch.cuda.device(dev):
             st = _st(dev)
-            streams = _scale_streams(dev, nsc) if (use_level_gemm or not need_x) \
+            streams = _scale_streams(dev, nsc, site=f"bwd{new_xyz.shape[1]}") if (use_level_gemm or not need_x) \
                 else [torch.cuda.current_stream(dev)] * nsc
             for (nl, s, coff, clast), (arg, ys, bns), idx, csr, stream, cm in zip(meta, per_scale, idxs, ctx.csrs, streams,
                                                                                       ctx.compacts):

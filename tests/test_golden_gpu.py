@@ -418,6 +418,56 @@ def test_full_size_encoder_matches_cpu_oracle_composition(oracle, ext):
     torch.testing.assert_close(out_gpu, out_cpu, rtol=2e-4, atol=2e-4)
 
 
+@pytest.mark.parametrize("kind", ["cube", "dense"])
+def test_full_size_encoder_on_the_other_input_distributions(kind, oracle, ext):
+    """SURVEY 8d names two input distributions for config 2 (cube and shell); ``dense`` is the case where every ball is
+    over-full (no padded rows: nothing for the compact columns or the first-hit padding to save).  B=32 N=1024: every index
+    tensor of the geometry pass bit-exact against the oracle (FPS picks, both ball queries, three_nn of every level), and the
+    features of the HIP path and of the CPU oracle composition within 1e-4 of a float64 evaluation."""
+    import bench
+    from istnet_amd.modules import PointNet2MSG
+    from istnet_amd.pointnet2 import pointnet2_utils
+    pts = bench.CLOUDS[kind](32, 1024, seed=0)
+    # ---- indices, level by level, on the oracle's own picks (a mismatch is then local to the op that made it) ----
+    cur = pts
+    levels = [pts]
+    for (npoint, radii) in zip((512, 256, 128, 64), CAM):
+        want = oracle.furthest_point_sampling(cur, npoint)
+        got = ext.furthest_point_sampling(cur.to(DEV), npoint).cpu()
+        assert torch.equal(got, want), (kind, npoint, "fps")
+        new_xyz = torch.gather(cur, 1, want.long().unsqueeze(-1).expand(-1, -1, 3)).contiguous()
+        for radius, nsample in zip(radii, (16, 32)):
+            bw = oracle.ball_query(new_xyz, cur, radius, nsample)
+            bg = ext.ball_query(new_xyz.to(DEV), cur.to(DEV), radius, nsample).cpu()
+            assert torch.equal(bg, bw), (kind, npoint, radius)
+            if kind == "dense":
+                assert (bw[..., 1:] != bw[..., :1]).any(-1).all()        # no row is a single padded hit
+        levels.append(new_xyz)
+        cur = new_xyz
+    for unknown, known in zip(levels[:-1], levels[1:]):
+        dw, iw = oracle.three_nn(unknown, known)
+        dg, ig = ext.three_nn(unknown.to(DEV), known.to(DEV))
+        assert torch.equal(ig.cpu(), iw) and torch.equal(dg.cpu(), dw), (kind, unknown.shape[1])
+    # ---- features ----
+    torch.manual_seed(0)
+    enc = PointNet2MSG([list(r) for r in CAM]).train()
+    enc_gpu = PointNet2MSG([list(r) for r in CAM]).to(DEV).train()
+    enc_gpu.load_state_dict(enc.state_dict())
+    enc64 = PointNet2MSG([list(r) for r in CAM]).to(DEV).double().train()
+    enc64.load_state_dict(enc.state_dict())
+    out_gpu = enc_gpu(pts.to(DEV)).detach().cpu()
+    saved = pointnet2_utils._ext
+    try:
+        pointnet2_utils._ext = _F64Ext(ext)
+        out64 = enc64(pts.to(DEV).double()).detach().cpu()
+        pointnet2_utils._ext = oracle
+        out_cpu = enc(pts).detach()
+    finally:
+        pointnet2_utils._ext = saved
+    torch.testing.assert_close(out_gpu.double(), out64, **TOL)
+    torch.testing.assert_close(out_cpu.double(), out64, **TOL)
+
+
 def test_inference_config5_n2048_matches_cpu_oracle_composition(oracle):
     """BASELINE config 5 shape (eval mode, N=2048; B reduced so the CPU side stays fast): the IST-Net point
     branch on the GPU vs the same modules over the CPU oracle; poses within 1e-4."""
