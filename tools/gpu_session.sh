@@ -35,7 +35,7 @@ PY
     prof)
       args=${rest//,/ }
       (cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats -d /root/repo/$O/prof_$n -o enc -- \
-         python /root/repo/bench.py --no-roofline --no-cpu-baseline --no-unpipelined --steps 20 --warmup 5 $args \
+         python /root/repo/bench.py --no-roofline --no-cpu-baseline --no-unpipelined --no-other-clouds --no-eager-leg --steps 20 --warmup 5 $args \
          > /root/repo/$O/prof_$n.log 2>&1)
       python tools/rocprof_summary.py $O/prof_$n/enc_results.db ${PROF_STEPS:-29} > $O/kernel_stats_$n.txt
       rm -rf $O/prof_$n
