@@ -149,6 +149,33 @@ def test_pmc_traffic_summary_is_tied_to_the_kernel_sources(tmp_path):
     assert roofline.pmc_traffic("some_kernel", str(f))[0] is None
 
 
+def test_sq_counter_summary_follows_the_same_staleness_rule(tmp_path):
+    """roofline.mfma_busy_frac comes from a committed SQ-counter summary (tools/pmc_sq.sh) under the same rule."""
+    import json
+    from istnet_amd import roofline
+    rec = {"kernels": {"k<2>": {"mfma_busy_frac": 0.4}}}
+    f = tmp_path / "sq.json"
+    f.write_text(json.dumps(dict(rec, kernel_source_sha256=roofline.kernel_source_hash())))
+    got, src = roofline.pmc_sq("k<2>", str(f))
+    assert got["mfma_busy_frac"] == 0.4 and src == "sq.json"
+    assert roofline.pmc_sq("other", str(f)) == (None, None)
+    f.write_text(json.dumps(dict(rec, kernel_source_sha256="0" * 64)))
+    got, why = roofline.pmc_sq("k<2>", str(f))
+    assert got is None and why.startswith("stale")
+
+
+def test_committed_pmc_summaries_belong_to_these_kernel_sources():
+    """The summaries bench.py names (PMC_TRAFFIC_FILE / PMC_SQ_FILE) were collected on the kernel sources in this tree: a kernel
+    edit without a re-collection makes the bench line say `traffic: null` -- and fails here, where it is noticed."""
+    import json
+    import bench
+    from istnet_amd import roofline
+    for name in (bench.PMC_TRAFFIC_FILE, bench.PMC_SQ_FILE):
+        path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", name)
+        assert os.path.exists(path), name
+        assert json.load(open(path))["kernel_source_sha256"] == roofline.kernel_source_hash(), name
+
+
 def test_entry_points_reject_invalid_arguments_before_touching_the_device():
     """Argument validation is host code ahead of any HIP call: an invalid size or a missing pointer returns
     ISTNET_PN2_EINVAL (100001) on a box without a GPU too -- never a crash, never a launch."""
