@@ -1,6 +1,7 @@
 """CPU tests of the drop-in boundary: the C-ABI library loads, exports every symbol that
 include/istnet_pn2.h declares, and the Python binding table matches the header."""
 import ctypes
+import os
 import re
 
 import pytest
