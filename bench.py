@@ -1090,6 +1090,10 @@ def main():
             other = {}
             for kind in ("cube", "dense"):
                 try:
+                    # a model decides ONCE, from its first passes, whether level 1 keeps its compact columns
+                    # (PointNet2MSG._compact_probe); this leg stands for a user whose data looks like `kind` from the start
+                    model.__dict__.pop("_compact_off", None)
+                    model.__dict__.pop("_compact_fill", None)
                     bts = [CLOUDS[kind](BATCH, NPOINTS, seed=s, device=dev) for s in (rank, 1000 + rank)]
                     if args.no_prefetch:
                         fb = make_encoder_fwd_bwd(model, bts[0])
@@ -1109,7 +1113,9 @@ def main():
                         dts.append((time.perf_counter() - t1) / args.steps)
                     dt = sorted(dts)[len(dts) // 2]
                     other[kind] = {"ms_per_step": dt * 1e3, "value": BATCH / dt, "unit": "clouds/s",
-                                   "windows_ms_per_step": [round(d * 1e3, 4) for d in dts]}
+                                   "windows_ms_per_step": [round(d * 1e3, 4) for d in dts],
+                                   "compact_columns_level1": not model.__dict__.get("_compact_off", {}).get(0, False),
+                                   "compact_fill_seen": [round(f, 3) for f in model.__dict__.get("_compact_fill", {}).get(0, [])]}
                     if not args.no_prefetch and not args.no_unpipelined:
                         pl = make_graphed_step(make_encoder_fwd_bwd(model, bts[0]), opt, world, grad_sync)
                         for _ in range(min(args.warmup, 5)):
@@ -1128,9 +1134,12 @@ def main():
                 except Exception as exc:      # an extra leg must never cost the headline line
                     other[kind] = {"error": f"{type(exc).__name__}: {exc}"}
                     torch.cuda.synchronize()
+            model.__dict__.pop("_compact_off", None)        # back to the headline's data: the legs below probe again
+            model.__dict__.pop("_compact_fill", None)
             other["note"] = ("same model, same captured step, other inputs: cube = U(-0.1, 0.1)^3 (SURVEY 8d config 2's second "
                              "distribution); dense = shell of radius 0.02 (every ball over-full: no padded rows, nothing for the "
-                             "compact columns or the first-hit padding to save)")
+                             "compact columns or the first-hit padding to save: the model's first passes see that and evaluate level 1 on the padded "
+                             "columns, fused_mlp.COMPACT_POLICY = auto)")
             result["other_distributions"] = other
         if not dist_on and not args.no_eager_leg and not args.cpu_dry_run and mode == "hipgraph":
             # the step an unchanged reference-style loop gets (no whole-step graph, no prefetch, torch.optim.Adam)

@@ -7,6 +7,8 @@ the reference's so its state dicts load unchanged.
 """
 import os
 
+import weakref
+
 import torch
 import torch.nn as nn
 
@@ -104,6 +106,34 @@ class PointNet2MSG(nn.Module):
         features = pc[..., 3:].transpose(1, 2).contiguous() if pc.size(-1) > 3 else None
         return xyz, features
 
+    # ---- compact columns by what the data looks like (round 6) ----
+    # A level in fused_mlp.COMPACT_LEVELS evaluates its scales on compact columns (distinct neighbours + one weighted
+    # representative of the padded repeats).  That pays when balls are under-full -- shell clouds: 17 % / 33 % of the padded
+    # columns are distinct at level 1, cube 8 % / 13 % -- and LOSES when they are not: on a dense cloud (every ball over-full)
+    # the compact kernels process every column at a lower rate, 2.99 against 2.62 ms per step (profiles/r06_compact_by_input.txt).
+    # Policy "auto": the first COMPACT_PROBES passes of a model (the eager warm-up calls that precede any capture) read the
+    # valid-column count back -- one small device-to-host copy each, the only synchronisation this module ever does -- and the
+    # level keeps its compact columns only if they fill at most COMPACT_MAX_FILL of the padded capacity.  The decision is per
+    # model and per level, taken once (a later change of the data's character changes the speed, never the results);
+    # ISTNET_COMPACT_POLICY=on / off forces it.
+    def _compact_wanted(self, level):
+        policy = fused_mlp.COMPACT_POLICY
+        if policy != "auto":
+            return policy != "off"
+        return self.__dict__.setdefault("_compact_off", {}).get(level) is not True
+
+    def _compact_probe(self, level, comps):
+        if fused_mlp.COMPACT_POLICY != "auto" or torch.cuda.is_current_stream_capturing():
+            return
+        off = self.__dict__.setdefault("_compact_off", {})
+        if level in off:
+            return
+        fills = self.__dict__.setdefault("_compact_fill", {}).setdefault(level, [])
+        valid = sum(int(c.gstart[-1]) for c in comps)            # device-to-host: waits for the compaction launch
+        fills.append(valid / float(sum(c.cap for c in comps)))
+        if len(fills) >= fused_mlp.COMPACT_PROBES:
+            off[level] = (sum(fills) / len(fills)) > fused_mlp.COMPACT_MAX_FILL
+
     def _geometry_prepass(self, xyz, with_ball_csr=False):
         """Everything that depends on coordinates only, on the geometry stream.
         Returns (per-level [new_xyz, [ball idx], event, inverse lists or None], per-FP-level (idx, weight, csr, event),
@@ -146,7 +176,8 @@ class PointNet2MSG(nn.Module):
                 new_xyz, tie = first if li == 0 else sample(li, sa, cur, tie)
                 ext = pointnet2_utils._ext
                 ball_compact = getattr(ext, "ball_compact", None)                    # absent from a plain reference _ext
-                compact = ball_compact is not None and len(sa_geo) in fused_mlp.COMPACT_LEVELS
+                compact = (ball_compact is not None and len(sa_geo) in fused_mlp.COMPACT_LEVELS
+                           and self._compact_wanted(len(sa_geo)))
                 pair = getattr(ext, "ball_query_pair", None) if len(sa.groupers) == 2 else None
                 comps = None
                 if pair is not None:
@@ -162,6 +193,8 @@ class PointNet2MSG(nn.Module):
                     if compact:
                         comps = [ball_compact(i, cur.shape[1]) for i in idx]
                         comps = comps if all(c is not None for c in comps) else None
+                if compact and comps is not None:
+                    self._compact_probe(len(sa_geo), comps)
                 ev = torch.cuda.Event()
                 ev.record(side)
                 sa_geo.append([new_xyz, idx, ev, None, comps])
@@ -366,7 +399,14 @@ class PointNet2MSG(nn.Module):
                 and pointcloud.size(-1) == 3 and pointcloud.dtype == torch.float32 and _native.TIMING is None and _native.MARKERS is None):
             # an eager caller (the reference's loop, utils/solver.py:88-99): forward and backward of a shape seen before are
             # one HIP-graph launch each (graphed.AutoGraph: same kernels, same order, bit-identical results)
-            return graphed.for_module(self, PointNet2MSG._plain_forward, _switch_state)(pointcloud)
+            ref = weakref.ref(self)       # (the AutoGraph is the value of a WeakKeyDictionary keyed by this module)
+
+            def state():
+                me = ref()
+                off = me.__dict__.get("_compact_off", {}) if me is not None else {}
+                # + the levels whose compact columns the data switched off (_compact_probe): another kernel sequence
+                return _switch_state() + (tuple(sorted(l for l, v in off.items() if v)),)
+            return graphed.for_module(self, PointNet2MSG._plain_forward, state)(pointcloud)
         return self._plain_forward(pointcloud, geometry)
 
     def _plain_forward(self, pointcloud, geometry=None):

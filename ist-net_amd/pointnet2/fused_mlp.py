@@ -581,6 +581,11 @@ def _wgrad_job(lib, dev, b, cin, cout, p, ns_arg, use_gather, ga, src, in_bn, y,
 # loses 0.25 ms.  ISTNET_COMPACT_LEVELS=0,1 (or assigning this attribute) selects more levels -- denser padding: the
 # cube clouds keep 10 % / 39 % at level 1 -- and ISTNET_COMPACT_LEVELS= none.
 COMPACT_LEVELS = frozenset(int(v) for v in os.environ.get("ISTNET_COMPACT_LEVELS", "0").split(",") if v != "")
+# whether a level of COMPACT_LEVELS keeps its compact columns: "auto" = by the fill ratio the model's first passes see
+# (modules.PointNet2MSG._compact_probe), "on" / "off" = always / never
+COMPACT_POLICY = os.environ.get("ISTNET_COMPACT_POLICY", "auto")
+COMPACT_PROBES = 2          # passes read back before the decision (the warm-up calls that precede any graph capture)
+COMPACT_MAX_FILL = 0.6      # distinct columns / padded capacity above which the padded evaluation is the faster one
 
 
 def _compact_ok(lib, ga, layers, params, needs_backward, needs_feature_grad):
@@ -606,7 +611,7 @@ USE_CSR_SCATTER = True     # False: LDS-atomic scatter (steps are then not bit-r
 def switch_state():
     """The module-level switches as a hashable value (a captured HIP graph bakes the paths they select in)."""
     g = globals()
-    return tuple((k, g[k]) for k in sorted(g) if k.startswith("USE_")) + (COMPACT_LEVELS, FP_BWD_MID_WORKGROUPS)
+    return tuple((k, g[k]) for k in sorted(g) if k.startswith("USE_")) + (COMPACT_LEVELS, FP_BWD_MID_WORKGROUPS, COMPACT_POLICY)
 
 
 def _dwx_only_job(lib, dev, b, cout, p, ns_arg, ga, y, d_dense, d_pooled, pbs, d_arg, bn, bwdc, wparam):

@@ -470,6 +470,41 @@ def test_full_size_encoder_on_the_other_input_distributions(kind, oracle, ext):
     torch.testing.assert_close(out_cpu.double(), out64, rtol=2.5e-4, atol=2.5e-4)
 
 
+def test_compact_columns_follow_the_data(monkeypatch):
+    """fused_mlp.COMPACT_POLICY "auto" (round 6): the first two passes of a model read the compact-column fill ratio back; shell
+    and cube clouds keep the compact columns of level 1, a dense cloud (every ball over-full) drops them -- and the step computes
+    the same thing either way (compact columns are an exact re-grouping of the padded sums: fp32 round-off apart)."""
+    import bench
+    from istnet_amd.modules import PointNet2MSG
+    from istnet_amd.pointnet2 import fused_mlp
+
+    def run(kind, policy, steps=3):
+        monkeypatch.setattr(fused_mlp, "COMPACT_POLICY", policy)
+        torch.manual_seed(0)
+        enc = PointNet2MSG([list(r) for r in CAM]).to(DEV).train()
+        pts = bench.CLOUDS[kind](8, 1024, seed=3, device=DEV)
+        for _ in range(steps):
+            enc.zero_grad(set_to_none=True)
+            out = enc(pts)
+            out.square().mean().backward()
+        torch.cuda.synchronize()
+        return enc, out.detach(), [p.grad.clone() for p in enc.parameters()]
+
+    enc, out_auto, g_auto = run("dense", "auto")
+    assert enc._compact_off == {0: True} and min(enc._compact_fill[0]) > 0.95
+    _, out_on, g_on = run("dense", "on")
+    # two fp32 evaluations of the same sums in different orders (BatchNorm statistics included), each within 1e-4 of float64
+    # (test_full_size_encoder_on_the_other_input_distributions): they differ by at most the sum -- measured 1.2e-4
+    torch.testing.assert_close(out_auto, out_on, rtol=2.5e-4, atol=2.5e-4)
+    for a, b_ in zip(g_auto, g_on):
+        torch.testing.assert_close(a, b_, rtol=5e-3, atol=1e-6 + 2e-3 * float(b_.abs().max()))
+    for kind in ("shell", "cube"):
+        enc, _, _ = run(kind, "auto", steps=2)
+        assert enc._compact_off == {0: False} and max(enc._compact_fill[0]) < 0.5, (kind, enc._compact_fill)
+    enc, _, _ = run("dense", "on", steps=2)
+    assert "_compact_off" not in enc.__dict__ or enc._compact_off == {}
+
+
 def test_inference_config5_n2048_matches_cpu_oracle_composition(oracle):
     """BASELINE config 5 shape (eval mode, N=2048; B reduced so the CPU side stays fast): the IST-Net point
     branch on the GPU vs the same modules over the CPU oracle; poses within 1e-4."""
