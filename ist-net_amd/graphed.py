@@ -104,12 +104,11 @@ def _bury(entries):
 
 def _drain():
     """Destroy parked entries on the calling thread with the device idle."""
-    if not _GRAVEYARD:
-        return
+    if not _GRAVEYARD or (torch.cuda.is_available() and torch.cuda.is_current_stream_capturing()):
+        return                               # (inside somebody's capture nothing may synchronise: the next call drains)
     dead = list(_GRAVEYARD)
-    del _GRAVEYARD[:len(dead)]
-    live = [e for e in dead if e.fwd is not None]
-    if live and torch.cuda.is_available() and not torch.cuda.is_current_stream_capturing():
+    del _GRAVEYARD[:len(dead)]               # a finalizer on another thread appends behind these
+    if any(e.fwd is not None for e in dead) and torch.cuda.is_available():
         torch.cuda.synchronize()
     for e in dead:
         e.destroy()
