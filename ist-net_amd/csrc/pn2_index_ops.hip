@@ -168,7 +168,7 @@ __global__ __launch_bounds__(NW * 64) void fps_regs_kernel(int n, int m, int bs_
   }
 
   for (int e = tid; e < 3 * n; e += THREADS) fps_lds[e] = dataset[e];
-  unsigned* xchg = reinterpret_cast<unsigned*>(fps_lds + 3 * n);  // [2][NW][3]
+  unsigned* xchg = reinterpret_cast<unsigned*>(fps_lds + 3 * n);  // [2][NW][4]
   __syncthreads();
 
   constexpr int PP = (PPT + 1) / 2;  // point slots are held in pairs (packed f32 math)
@@ -241,28 +241,51 @@ __global__ __launch_bounds__(NW * 64) void fps_regs_kernel(int n, int m, int bs_
       tied = vmax != 0u && ((hm & (hm - 1)) != 0ull || twice != 0ull);
     }
     if (NW > 1) {
-      unsigned* slot = xchg + (j & 1) * (NW * 3);
+      // The NW waves' (maximum, tie key, tie flag) records meet in LDS.  Round 6: combined in VECTOR form -- every lane takes the
+      // record of wave (lane mod NW) and log2(NW) DPP exchanges inside each group of NW lanes leave the workgroup's result in
+      // all of them (the combination is commutative and associative: largest value, smallest tie key among equals, number of
+      // waves holding the maximum, OR of their flags).  The scalar loop over the records it replaces was ~100 of the round's
+      // 240 instructions (v_readfirstlane + s_cmp / s_cselect chains per record).
+      unsigned* slot = xchg + (j & 1) * (NW * 4);
       if (lane_id() == 0) {
-        slot[(tid >> 6) * 3 + 0] = vmax;
-        slot[(tid >> 6) * 3 + 1] = tkmin;
-        if (TR) slot[(tid >> 6) * 3 + 2] = tied ? 1u : 0u;
+        slot[(tid >> 6) * 4 + 0] = vmax;
+        slot[(tid >> 6) * 4 + 1] = tkmin;
+        if (TR) slot[(tid >> 6) * 4 + 2] = tied ? 1u : 0u;
       }
       lds_only_barrier();
-      unsigned bv = 0u, bt = 0xffffffffu, bf = 0u, nbest = 0u;
+      const unsigned* rec = slot + (lane_id() & (NW - 1)) * 4;
+      unsigned bv = rec[0], bt = rec[1], bf = TR ? rec[2] : 0u, nbest = 1u;
 #pragma unroll
-      for (int w = 0; w < NW; ++w) {
-        const unsigned v = slot[w * 3 + 0], t = slot[w * 3 + 1];
-        const bool better = (v > bv) || (v == bv && t < bt);
-        if (TR) {
-          const unsigned f = slot[w * 3 + 2];
-          nbest = v > bv ? 1u : (v == bv ? nbest + 1u : nbest);   // waves holding the workgroup maximum
-          bf = v > bv ? f : (v == bv ? (bf | f) : bf);            // ... and whether any of them holds it twice
+      for (int step = 1; step < NW; step <<= 1) {
+        // partner: lane ^ 1, lane ^ 2 (quad permutes), then the other quad of the lane's group of eight (half-row mirror:
+        // after two steps the four lanes of a quad agree, so any lane of the other quad will do)
+        unsigned pv, pt, pf = 0u, pn = 0u;
+        if (step == 1) {
+          pv = dpp_mov<0xB1>(0u, bv); pt = dpp_mov<0xB1>(0u, bt);
+          if (TR) { pf = dpp_mov<0xB1>(0u, bf); pn = dpp_mov<0xB1>(0u, nbest); }
+        } else if (step == 2) {
+          pv = dpp_mov<0x4E>(0u, bv); pt = dpp_mov<0x4E>(0u, bt);
+          if (TR) { pf = dpp_mov<0x4E>(0u, bf); pn = dpp_mov<0x4E>(0u, nbest); }
+        } else {
+          pv = dpp_mov<0x141>(0u, bv); pt = dpp_mov<0x141>(0u, bt);
+          if (TR) { pf = dpp_mov<0x141>(0u, bf); pn = dpp_mov<0x141>(0u, nbest); }
         }
-        bv = better ? v : bv;
-        bt = better ? t : bt;
+        const bool gt = pv > bv, eq = pv == bv;
+        const bool better = gt || (eq && pt < bt);
+        if (TR) {
+          nbest = eq ? nbest + pn : (gt ? pn : nbest);
+          bf = eq ? (bf | pf) : (gt ? pf : bf);
+        }
+        bv = better ? pv : bv;
+        bt = better ? pt : bt;
       }
-      tkmin = bt;
-      if (TR) tied = bv != 0u && (nbest > 1u || bf != 0u);
+      tkmin = (unsigned)__builtin_amdgcn_readfirstlane((int)bt);
+      if (TR) {
+        const unsigned rv = (unsigned)__builtin_amdgcn_readfirstlane((int)bv);
+        const unsigned rn = (unsigned)__builtin_amdgcn_readfirstlane((int)nbest);
+        const unsigned rf = (unsigned)__builtin_amdgcn_readfirstlane((int)bf);
+        tied = rv != 0u && (rn > 1u || rf != 0u);
+      }
     }
     if (TR && tied && first_tie == kFpsNoTie) first_tie = j;
     old = tiekey_to_k(tkmin, bs_log2, nper);
@@ -1158,7 +1181,12 @@ int g_dist_conv = 0;  // distance convention (file header); istnet_pn2_set_tunin
     else if (g_dist_conv == 2) { constexpr int CONV_ = 2; LAUNCH; }            \
     else { constexpr int CONV_ = 0; LAUNCH; }                                  \
   } while (0)
-int g_fps_multiwave_min = 1025;  // tuning knob (istnet_pn2_set_tuning); measured: 1 wave wins up to 1024 points
+int g_fps_multiwave_min = 1024;  // key 0: tiekey-slot count from which a cloud gets several waves.  Round 6: with the records of the
+                                 // waves combined by a DPP butterfly (fps_regs_kernel) four waves beat one at 1 024 points -- 512 of
+                                 // 1 024, B = 32 / 4 / 1: 247 / 244 / 243 us against 288 / 283 / 280 (279 vs 295 with the tie
+                                 // tracking of the chained form), un-pipelined step -20 us (profiles/r06_fps_waves.txt); below
+                                 // 1 024 slots one wave stays ahead
+int g_fps_waves = 4;             // key 3: waves per cloud of the multi-wave form (2, 4 or 8)
 inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 inline int ilog2_floor(int v) { int r = 0; while ((1 << (r + 1)) <= v) ++r; return r; }
 inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
@@ -1198,7 +1226,7 @@ template <int NW>
 int launch_fps_regs(int b, int n, int m, int bs_log2, int nper, const float* dataset, int* idxs,
                     float* picked, const int* tie_in, int* tie_out, int track_rounds, hipStream_t st) {
   const int ppt = ceil_div(nper << bs_log2, NW * 64);  // tiekey slots per thread (holes included)
-  const size_t lds = (size_t)3 * n * 4 + (NW > 1 ? 2 * NW * 3 * 4 : 0);
+  const size_t lds = (size_t)3 * n * 4 + (NW > 1 ? 2 * NW * 4 * 4 : 0);
   const bool track = tie_in != nullptr || tie_out != nullptr;
 #define ISTNET_FPS_CASE(P)                                                                                          \
   do {                                                                                                              \
@@ -1233,11 +1261,13 @@ int istnet_debug_marker(unsigned long long* slot, void* stream) {
 }
 int istnet_pn2_set_tuning(int key, int value) {
   // key 0: tiekey-slot count from which FPS uses four waves per cloud; one wave holds at most 16 slots per lane
-  if (key == 0) { if (value < 1 || value > 1025) return ISTNET_PN2_EINVAL; g_fps_multiwave_min = value; return 0; }
+  if (key == 0) { if (value < 1 || value > 1025) return ISTNET_PN2_EINVAL; g_fps_multiwave_min = value; return 0; }   // 1025: one wave up to 1 024 slots
   // key 1: distance convention of FPS / ball query / three_nn (0 un-contracted, 1 / 2 FMA-contracted; file header)
   if (key == 1) { if (value < 0 || value > 2) return ISTNET_PN2_EINVAL; g_dist_conv = value; return 0; }
   // key 2: 1 = build inverse lists with the one-workgroup-per-cloud kernels (the fallback for very large slot counts)
   if (key == 2) { g_csr_legacy = value ? 1 : 0; return 0; }
+  // key 3: waves per cloud of the multi-wave FPS (2, 4, 8)
+  if (key == 3) { if (value != 2 && value != 4 && value != 8) return ISTNET_PN2_EINVAL; g_fps_waves = value; return 0; }
   return ISTNET_PN2_EINVAL;
 }
 const char* istnet_pn2_target(void) { return "gfx950"; }
@@ -1252,11 +1282,15 @@ static int fps_impl(int b, int n, int m, const float* dataset, float* temp, int*
   const int nper = ceil_div(n, 1 << bs_log2);
   const int slots = nper << bs_log2;
   hipStream_t st = as_stream(stream);
-  // one wave per cloud is barrier-free and measured faster than 2 / 4 / 8 waves (LDS exchange + barrier per round:
-  // ~0.5 us per round whatever the points per lane, against 0.28-0.50 us for one wave) for every n <= 1024
-  // (profiles/r01_index_microbench.txt; round 2 re-measured with the LDS-only barrier: 256 vs 266 / 270 / 405 us)
+  // one wave per cloud is barrier-free and ahead of several waves below 1 024 slots (an LDS exchange + barrier per round cost
+  // ~0.5 us per round in rounds 1-2: profiles/r01_index_microbench.txt); from 1 024 slots on four waves win since the records are
+  // combined by a DPP butterfly (g_fps_multiwave_min above)
   if (slots < g_fps_multiwave_min)
     return launch_fps_regs<1>(b, n, m, bs_log2, nper, dataset, idxs, picked, tie_in, tie_out, track_rounds, st);
+  if (slots <= 128 * 16 && g_fps_waves == 2)
+    return launch_fps_regs<2>(b, n, m, bs_log2, nper, dataset, idxs, picked, tie_in, tie_out, track_rounds, st);
+  if (slots <= 512 * 16 && g_fps_waves == 8)
+    return launch_fps_regs<8>(b, n, m, bs_log2, nper, dataset, idxs, picked, tie_in, tie_out, track_rounds, st);
   if (slots <= 256 * 16)
     return launch_fps_regs<4>(b, n, m, bs_log2, nper, dataset, idxs, picked, tie_in, tie_out, track_rounds, st);
   if (temp == nullptr || picked != nullptr || tie_in != nullptr || tie_out != nullptr)

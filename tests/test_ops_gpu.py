@@ -46,6 +46,37 @@ def test_fps_bit_exact(ext, oracle, b, n, m, kind):
     assert (got[:, 0] == 0).all()
 
 
+@pytest.mark.parametrize("waves", [1, 2, 4, 8])
+def test_fps_multiwave_forms_bit_exact(ext, oracle, waves):
+    """The multi-wave form of the register FPS kernel (2 / 4 / 8 waves per cloud; the cross-wave combination is a DPP butterfly
+    over the waves' records since round 6) forced for clouds the one-wave kernel normally takes: picks bit-exact against the oracle
+    on plain, duplicate-heavy and lattice clouds, and the chained form (tie tracking across waves) equal to level-by-level scans."""
+    from istnet_amd import _native
+    lib = _native.lib()
+    assert lib.istnet_pn2_set_tuning(3, 3) != 0                              # validated knob
+    if waves == 1:
+        assert lib.istnet_pn2_set_tuning(0, 1025) == 0          # one wave up to 1 024 slots (the default until round 6)
+    else:
+        assert lib.istnet_pn2_set_tuning(0, 1) == 0 and lib.istnet_pn2_set_tuning(3, waves) == 0
+    try:
+        for (b, n, m, kind) in [(3, 1024, 512, "cube"), (2, 1024, 512, "shell"), (3, 1024, 512, "dup"), (2, 1024, 300, "grid"),
+                                (2, 512, 256, "dup"), (2, 1000, 333, "cube"), (1, 700, 100, "grid"), (2, 2048, 512, "dup")]:
+            xyz = _cloud(b, n, seed=n * 11 + m + waves, kind=kind)
+            want = oracle.furthest_point_sampling(xyz, m)
+            got = ext.furthest_point_sampling(xyz.to(DEV), m).cpu()
+            assert torch.equal(got, want), (waves, b, n, m, kind)
+        for kind in ("shell", "dup", "grid"):
+            xyz = _cloud(4, 1024, seed=5 + waves, kind=kind).to(DEV)
+            cur, tie, plain = xyz, None, xyz
+            for li, m in enumerate((512, 256, 128, 64)):
+                nxt = (256, 128, 64, 0)[li]
+                _, cur, tie = ext.furthest_point_sampling_chain(cur, m, tie_in=tie, track_rounds=min(nxt, m))
+                _, plain = ext.furthest_point_sampling_gather(plain, m)
+                assert torch.equal(cur, plain), (waves, kind, m)
+    finally:
+        assert lib.istnet_pn2_set_tuning(0, 1024) == 0 and lib.istnet_pn2_set_tuning(3, 4) == 0          # the defaults
+
+
 @pytest.mark.parametrize("b,n,m,radius,nsample,kind", [
     (4, 1024, 512, 0.2, 32, "cube"),      # BASELINE config 1
     (4, 1024, 512, 0.1, 16, "cube"), (2, 512, 256, 0.02, 16, "shell"), (2, 512, 256, 0.04, 32, "shell"),
