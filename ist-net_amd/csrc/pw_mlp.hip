@@ -129,6 +129,15 @@ __device__ __forceinline__ float wave_sum(float v) {
   v += dpp_f<0x143, 0xc>(v);    // row_bcast:31 -> lane 63 holds the wave sum
   return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
+// two wave sums at once (the same additions in the same order as two wave_sum calls; the DPP steps of one fill the wait states
+// of the other)
+__device__ __forceinline__ void wave_sum2(float& a, float& b) {
+  half_wave_sum2(a, b);
+  a += dpp_f<0x143, 0xc>(a);
+  b += dpp_f<0x143, 0xc>(b);
+  a = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(a), 63));
+  b = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(b), 63));
+}
 
 // (cloud, in-cloud point) of a flattened point index q = b*P + p.  The launchers reject b*P >= 2^31, so this is a
 // 32-bit division; the 64-bit one it replaces cost ~100 scalar instructions per K chunk.
@@ -1473,6 +1482,9 @@ __global__ __launch_bounds__(1024) void bn_bwd_dense_finalize_kernel(
   const int P4 = P >> 2;                       // float4 per row
   const int chunks = (P4 + 63) / 64;           // 64 float4 (256 points) per wave visit
   double ag = 0.0, agy = 0.0;
+  // (round 6, measured and not kept: the loads of a block of 2 / 4 / 8 visits issued before the first is consumed -- identical bits,
+  //  7.0-10.2 us against 7.4-10.2 alone: the kernel is one memory round trip + the reductions + the launch, not a chain of round
+  //  trips; profiles/r06_finalize_loads.txt)
   for (int t = wv; t < B * chunks; t += 16) {
     const int b = t / chunks, i = (t - b * chunks) * 64 + lane;
     float sg = 0.f, sgy = 0.f;
@@ -1586,18 +1598,46 @@ __global__ __launch_bounds__(64 * kPoolFinWaves) void bn_bwd_pooled_finalize_ker
   const int c = blockIdx.x, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const float s = bn[c], h = bn[C + c];
   double ag = 0.0, agy = 0.0;
-  for (int b = wv; b < B; b += kPoolFinWaves) {
-    const float* d = pooled + (size_t)b * pooled_bstride + (size_t)c * G;
-    const float* v = ymax + ((size_t)b * C + c) * G;
-    float sg = 0.f, sgy = 0.f;
-    for (int g = lane; g < G; g += 64) {
-      const float y = v[g];
-      const float gr = (y * s + h > 0.f) ? d[g] : 0.f;
-      sg += gr;
-      sgy += gr * y;
+  // Round 6: two clouds per trip and up to eight 64-group chunks of each loaded before anything is consumed (32 loads in flight per
+  // lane instead of 2): at G = 512 a wave walked 16 dependent memory round trips, 13-24 us at the head of every set-abstraction
+  // backward chain.  Same sums in the same order: per cloud the lane's groups ascending, the wave sum, clouds ascending.
+  constexpr int U = 8;
+  for (int b0 = wv; b0 < B; b0 += 2 * kPoolFinWaves) {
+    const int b1 = b0 + kPoolFinWaves;
+    const bool has1 = b1 < B;                                   // wave-uniform
+    const float* d0 = pooled + (size_t)b0 * pooled_bstride + (size_t)c * G;
+    const float* v0 = ymax + ((size_t)b0 * C + c) * G;
+    const float* d1 = pooled + (size_t)(has1 ? b1 : b0) * pooled_bstride + (size_t)c * G;
+    const float* v1 = ymax + ((size_t)(has1 ? b1 : b0) * C + c) * G;
+    float sg0 = 0.f, sgy0 = 0.f, sg1 = 0.f, sgy1 = 0.f;
+    for (int gb = 0; gb < G; gb += 64 * U) {
+      float y0[U], e0[U], y1[U], e1[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int g = min(gb + 64 * u + lane, G - 1);           // clamped: issued unconditionally
+        y0[u] = v0[g]; e0[u] = d0[g];
+        y1[u] = v1[g]; e1[u] = d1[g];
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        if (gb + 64 * u + lane < G) {
+          const float gr0 = (y0[u] * s + h > 0.f) ? e0[u] : 0.f;
+          sg0 += gr0;
+          sgy0 += gr0 * y0[u];
+          const float gr1 = (y1[u] * s + h > 0.f) ? e1[u] : 0.f;
+          sg1 += gr1;
+          sgy1 += gr1 * y1[u];
+        }
+      }
     }
-    ag += (double)wave_sum(sg);
-    agy += (double)wave_sum(sgy);
+    wave_sum2(sg0, sgy0);
+    ag += (double)sg0;
+    agy += (double)sgy0;
+    if (has1) {
+      wave_sum2(sg1, sgy1);
+      ag += (double)sg1;
+      agy += (double)sgy1;
+    }
   }
   __shared__ double sh[2][kPoolFinWaves];
   if (lane == 0) { sh[0][wv] = ag; sh[1][wv] = agy; }
