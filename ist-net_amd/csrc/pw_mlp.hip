@@ -1034,20 +1034,32 @@ __global__ __launch_bounds__(kFinThreads) void bn_fin_relu_pool_kernel(
     const float* __restrict__ y, float* __restrict__ out, long long out_bstride, uint8_t* __restrict__ arg,
     float* __restrict__ ymax, long long* __restrict__ nbt) {
   const int c = blockIdx.x;
+  const int b0 = (int)((long long)B * blockIdx.y / gridDim.y), b1 = (int)((long long)B * (blockIdx.y + 1) / gridDim.y);
+  const int total = (b1 - b0) * G;
+  // Round 6: a group's samples do not depend on the constants, so the thread's FIRST group is loaded before the partials are
+  // reduced (two dependent memory round trips + a barrier that the tail of every SA2-SA4 forward chain waited for before it
+  // issued its own first loads).  (Also tried: the next group's loads in flight while a group is compared -- most threads own one
+  // group, the clamped extra loads doubled the traffic: 17.9 -> 29.5 us; profiles/r06_finalize_loads.txt.)
+  auto load_group = [&](int e, float4 (&v)[S4]) {
+    const int bl = e / G, g = e - bl * G;
+    const float4* src = reinterpret_cast<const float4*>(y + (((size_t)(b0 + bl) * C + c) * G + g) * (S4 * 4));
+#pragma unroll
+    for (int i = 0; i < S4; ++i) v[i] = src[i];
+  };
+  float4 cur[S4];
+  if ((int)threadIdx.x < total) load_group(threadIdx.x, cur);
   float s, h;
   finalize_channel(C, c, nt, count, part_sum, part_sq, gamma, beta, eps, momentum_p, running_mean, running_var, bn,
                    blockIdx.y == 0, s, h, nbt);
-  const int b0 = (int)((long long)B * blockIdx.y / gridDim.y), b1 = (int)((long long)B * (blockIdx.y + 1) / gridDim.y);
-  const int total = (b1 - b0) * G;
   for (int e = threadIdx.x; e < total; e += kFinThreads) {
     const int bl = e / G, g = e - bl * G;
     const size_t bc = (size_t)(b0 + bl) * C + c;
-    const float4* src = reinterpret_cast<const float4*>(y + (bc * G + g) * (S4 * 4));
+    if (e != (int)threadIdx.x) load_group(e, cur);
     float best = -1.f, raw = 0.f;
     int besti = 0;
 #pragma unroll
     for (int i = 0; i < S4; ++i) {
-      const float4 v = src[i];
+      const float4 v = cur[i];
       const float a0 = fmaxf(v.x * s + h, 0.f), a1 = fmaxf(v.y * s + h, 0.f);
       const float a2 = fmaxf(v.z * s + h, 0.f), a3 = fmaxf(v.w * s + h, 0.f);
       if (a0 > best) { best = a0; besti = 4 * i + 0; raw = v.x; }
@@ -1068,10 +1080,10 @@ __global__ __launch_bounds__(kFinThreads) void bn_fin_relu_apply_kernel(
     float* __restrict__ running_mean, float* __restrict__ running_var, float* __restrict__ bn,
     const float* __restrict__ y, float* __restrict__ out, long long* __restrict__ nbt) {
   const int c = blockIdx.x;
+  const int b0 = (int)((long long)B * blockIdx.y / gridDim.y), b1 = (int)((long long)B * (blockIdx.y + 1) / gridDim.y);
   float s, h;
   finalize_channel(C, c, nt, count, part_sum, part_sq, gamma, beta, eps, momentum_p, running_mean, running_var, bn,
                    blockIdx.y == 0, s, h, nbt);
-  const int b0 = (int)((long long)B * blockIdx.y / gridDim.y), b1 = (int)((long long)B * (blockIdx.y + 1) / gridDim.y);
   for (int b = b0; b < b1; ++b) {
     const size_t row = ((size_t)b * C + c) * P4;
     for (int i = threadIdx.x; i < P4; i += kFinThreads) {

@@ -306,10 +306,20 @@ __global__ __launch_bounds__(256) void bn_relu_pool_cols_kernel(int C, int G, in
   const float* row = y + (size_t)c * cap;
   float best = -1.f, raw = 0.f;
   int besti = 0;
-  for (int p = a; p < z; ++p) {
-    const float v = row[p];
-    const float act = fmaxf(v * s + h, 0.f);
-    if (act > best) { best = act; besti = p - a; raw = v; }
+  // Round 6: eight columns loaded before the first is compared (clamped, issued unconditionally).  With one load per trip of a
+  // loop whose length is data (up to nsample + 1 columns) every column waited for its own memory round trip: 27 us for the
+  // nsample-32 scale of level 1, at the end of its forward chain.  Same comparisons in the same order.
+  for (int p0 = a; p0 < z; p0 += 8) {
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = row[min(p0 + u, z - 1)];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      if (p0 + u < z) {
+        const float act = fmaxf(v[u] * s + h, 0.f);
+        if (act > best) { best = act; besti = p0 + u - a; raw = v[u]; }
+      }
+    }
   }
   const int cloud = g / G, j = g - cloud * G;
   out[(size_t)cloud * out_bstride + (size_t)c * G + j] = best;
