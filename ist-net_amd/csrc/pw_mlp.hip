@@ -129,6 +129,42 @@ __device__ __forceinline__ float wave_sum(float v) {
   v += dpp_f<0x143, 0xc>(v);    // row_bcast:31 -> lane 63 holds the wave sum
   return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
+// four wave sums at once: with four independent chains no DPP step reads a register the previous instruction wrote, so the
+// wait states disappear altogether (the same additions in the same order as four wave_sum calls: bit-identical)
+__device__ __forceinline__ void wave_sum4(float& a, float& b, float& c, float& d) {
+  asm volatile(
+      "s_nop 1\n\t"
+      "v_add_f32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "v_add_f32_dpp %1, %1, %1 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "v_add_f32_dpp %2, %2, %2 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "v_add_f32_dpp %3, %3, %3 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "v_add_f32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "v_add_f32_dpp %1, %1, %1 row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "v_add_f32_dpp %2, %2, %2 row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "v_add_f32_dpp %3, %3, %3 row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "v_add_f32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "v_add_f32_dpp %1, %1, %1 row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "v_add_f32_dpp %2, %2, %2 row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "v_add_f32_dpp %3, %3, %3 row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "v_add_f32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "v_add_f32_dpp %1, %1, %1 row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "v_add_f32_dpp %2, %2, %2 row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "v_add_f32_dpp %3, %3, %3 row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "v_add_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+      "v_add_f32_dpp %1, %1, %1 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+      "v_add_f32_dpp %2, %2, %2 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+      "v_add_f32_dpp %3, %3, %3 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+      "v_add_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+      "v_add_f32_dpp %1, %1, %1 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+      "v_add_f32_dpp %2, %2, %2 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+      "v_add_f32_dpp %3, %3, %3 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+      "s_nop 1"
+      : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+  a = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(a), 63));
+  b = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(b), 63));
+  c = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(c), 63));
+  d = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(d), 63));
+}
 // two wave sums at once (the same additions in the same order as two wave_sum calls; the DPP steps of one fill the wait states
 // of the other)
 __device__ __forceinline__ void wave_sum2(float& a, float& b) {
@@ -845,16 +881,26 @@ __global__ __launch_bounds__(256) void pw_gather_add_kernel(int n, int P, int S,
     for (int j = 0; j < 4; ++j) zv[j] = zn[j];
 #pragma unroll
     for (int j = 0; j < 4; ++j) zn[j] = z != nullptr ? zb[(size_t)min(co + 4 + j, nco - 1) * n] : 0.f;
+    float vv[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      if (co + j < nco) {
-        const int c = co + j;
-        float v = zv[j] + ((wx[3 * c] * dx + wx[3 * c + 1] * dy) + wx[3 * c + 2] * dz);
-        if (valid) yb[(size_t)c * P] = v; else v = 0.f;
-        if (stats) {
-          const float s = wave_sum(v), q = wave_sum(v * v);
-          if ((tid & 63) == 0) { red[wv][c][0] = s; red[wv][c][1] = q; }
-        }
+      const int c = min(co + j, nco - 1);
+      float v = zv[j] + ((wx[3 * c] * dx + wx[3 * c + 1] * dy) + wx[3 * c + 2] * dz);
+      if (valid && co + j < nco) yb[(size_t)c * P] = v;
+      vv[j] = valid ? v : 0.f;
+    }
+    if (stats) {
+      // (round 6) the eight wave sums of four channels as two interleaved groups of four: the same additions in the same order
+      // (bit-identical partials) without the wait states a single DPP chain needs -- the sums were ~80 % of this kernel's issue slots
+      float s0 = vv[0], q0 = vv[0] * vv[0], s1 = vv[1], q1 = vv[1] * vv[1];
+      float s2 = vv[2], q2 = vv[2] * vv[2], s3 = vv[3], q3 = vv[3] * vv[3];
+      wave_sum4(s0, q0, s1, q1);
+      wave_sum4(s2, q2, s3, q3);
+      if ((tid & 63) == 0) {
+        red[wv][co][0] = s0; red[wv][co][1] = q0;
+        if (co + 1 < nco) { red[wv][co + 1][0] = s1; red[wv][co + 1][1] = q1; }
+        if (co + 2 < nco) { red[wv][co + 2][0] = s2; red[wv][co + 2][1] = q2; }
+        if (co + 3 < nco) { red[wv][co + 3][0] = s3; red[wv][co + 3][1] = q3; }
       }
     }
   }
