@@ -149,10 +149,14 @@ def measure(step, steps=5, traffic_file=None, capture=None, steps_per_replay=1, 
                            "HIP events on the launch stream around each launch, %d instrumented eager steps" % steps)
     sq, sq_src = pmc_sq(name, sq_file)
     if sq is not None:
-        obj["mfma_busy_frac"] = sq.get("mfma_busy_frac")
+        # the share of the SIMD-cycles of the CUs the kernel occupies with the matrix pipe busy (the definition the round-5 review
+        # asked for), and the same over ALL SIMD-cycles of the dispatch (comparable with `frac`, which is flop / time / peak)
+        obj["mfma_busy_frac"] = sq.get("mfma_busy_frac_of_busy_cus")
+        obj["mfma_busy_frac_chip"] = sq.get("mfma_busy_frac")
         obj["mfma_busy_source"] = sq_src
-        obj["mfma_busy_note"] = ("SQ_VALU_MFMA_BUSY_CYCLES / (4 x SQ_BUSY_CU_CYCLES), rocprofv3 --pmc run of the encoder step "
-                                 "(counters in their own pass, profiles/%s)" % sq_src)
+        obj["mfma_busy_note"] = ("mfma_busy_frac = SQ_VALU_MFMA_BUSY_CYCLES / (4 x SQ_BUSY_CU_CYCLES): matrix pipe busy over the "
+                                 "SIMD-cycles of the occupied CUs; mfma_busy_frac_chip = the same over 1024 SIMDs x the traced "
+                                 "duration; rocprofv3 --pmc run of the encoder step, counters in their own pass (profiles/%s)" % sq_src)
     elif sq_src is not None:
         obj["mfma_busy_frac"], obj["mfma_busy_source"] = None, sq_src
     replayed = measure_replayed(capture, steps, only=name) if capture is not None else None
